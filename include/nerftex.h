@@ -1,0 +1,139 @@
+/*
+ * nerftex.h -- C ABI of libnerftex_hip.so: the MI355X (gfx950) implementation of NeRF-Tex's
+ * volumetric render path.
+ *
+ * This is the drop-in boundary of the project.  The reference
+ * (hbaatz/nerf-tex) has no FFI of its own on this path -- it is eager TensorFlow called through
+ * Python objects -- so the entry points below are what a binding for each reference function would
+ * bind.  Each one cites the reference interface it replaces (file:line in /root/reference).
+ *
+ * Conventions
+ *   - plain C, `extern "C"`, no torch / TF / C++ types in any signature;
+ *   - every `float*` marked DEVICE is a caller-owned device pointer (row-major float32, last
+ *     dimension fastest, exactly the layouts of the reference tensors); HOST pointers are read
+ *     synchronously during the call;
+ *   - the library owns only what `ntx_create` allocates (the packed weight image); no entry point
+ *     allocates or frees device memory per call;
+ *   - every entry point is asynchronous on `stream` (a `hipStream_t` passed as `void*`; NULL = the
+ *     null stream) and returns an `ntx_status` (0 = ok, negative = error).  The message of the
+ *     last error on the calling thread is returned by `ntx_last_error()`;
+ *   - a context belongs to one device; calls on one context are not re-entrant.  Multi-GPU =
+ *     one context (and one process) per device.
+ */
+#ifndef NERFTEX_H
+#define NERFTEX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTX_ABI_VERSION 1
+
+typedef struct ntx_ctx ntx_ctx;
+typedef void *ntx_stream; /* hipStream_t */
+
+typedef enum ntx_status {
+    NTX_OK = 0,
+    NTX_E_INVALID = -1,     /* bad argument (NULL pointer, negative size, n_samples < 2 ...) */
+    NTX_E_UNSUPPORTED = -2, /* model architecture outside what the HIP kernels are built for */
+    NTX_E_HIP = -3,         /* a HIP runtime call failed; ntx_last_error() carries hipGetErrorString */
+    NTX_E_NODEVICE = -4     /* no usable gfx950 device */
+} ntx_status;
+
+/* Model architecture = the kwargs of network.model.ParamNerf (model.py:58) / Nerf (model.py:9). */
+typedef enum ntx_model_kind { NTX_MODEL_PARAMNERF = 0, NTX_MODEL_NERF = 1 } ntx_model_kind;
+
+typedef struct ntx_model_desc {
+    int32_t kind;        /* ntx_model_kind */
+    int32_t n_geo;       /* n_parameters[0]: parameters concatenated to the position embedding (model.py:88-93) */
+    int32_t n_app;       /* n_parameters[1]: parameters concatenated to the direction embedding (model.py:96-101) */
+    int32_t n_pos;       /* 3 */
+    int32_t pos_freq;    /* pos_embedding.n_freq_bands   (layer.py:11) */
+    int32_t dir_freq;    /* dir_embedding.n_freq_bands */
+    int32_t param_freq;  /* param_embedding.n_freq_bands */
+    int32_t depth;       /* 8 */
+    int32_t width;       /* 256 */
+    int32_t skip;        /* index of the single skip layer, 4 (model.py:107-108) */
+    int32_t color_depth; /* ParamNerf: 1 (model.py:118); ignored for Nerf */
+} ntx_model_desc;
+
+/* flags of ntx_composite / ntx_render_rays */
+#define NTX_FLAG_MAP_EXR 1u         /* renderer.py:182-184: colour = elu(raw)+1 instead of sigmoid  */
+#define NTX_FLAG_COMPOSITE_BKGD 2u  /* renderer.py:210-211 and 85-86: add (1-A)*bkgd; culled rays = bkgd */
+#define NTX_FLAG_CHECK_NUMERICS 4u  /* renderer.py:140-141: set *status_flag |= 1 on NaN/Inf outputs */
+
+int ntx_abi_version(void);
+const char *ntx_last_error(void);
+
+/* Number of float32 in the reference-layout weight blob of `desc`:
+ * concat over Dense layers in Keras creation order (model.py:104-123) of kernel[in,out] (row-major)
+ * then bias[out]  ==  np.concatenate([w.ravel() for w in keras_model.get_weights()]).
+ * Returns 0 if `desc` is not supported. */
+size_t ntx_weight_count(const ntx_model_desc *desc);
+
+/* Replaces: building the tf.keras.Model (model.py:125) + tf.train.Checkpoint restore (logger.py:33-39).
+ * Packs the HOST blob into the MFMA operand layout and uploads it to `device`. */
+int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_floats, int device,
+               ntx_ctx **out);
+/* Re-pack and re-upload new weights into an existing context (synchronous). */
+int ntx_set_weights(ntx_ctx *ctx, const float *weights_host, size_t n_floats);
+int ntx_destroy(ntx_ctx *ctx);
+
+/* Replaces pixel_sampler.Full (pixel_sampler.py:14-15) + ray_sampler.rays_from_camera
+ * (ray_sampler.py:39-48) + ray_sampler.Proxy (32-37) with proxy.AABB (proxy.py:13-35) [mode 0]
+ * or ray_sampler.Frustum (15-21) [mode 1], for pixels [pixel0, pixel0+n_pixels) of the row-major
+ * H x W grid.  c2w: HOST float[16] row-major 4x4.  b0/b1: HOST float[3] (mode 0).
+ * Outputs (DEVICE): rays_o[n,3], rays_d[n,3], t[n,2], cone_scale[n,1]. */
+int ntx_generate_rays(const float *c2w, int height, int width, float focal, int64_t pixel0,
+                      int64_t n_pixels, int mode, const float *b0, const float *b1, float near_t,
+                      float far_t, float *rays_o, float *rays_d, float *t, float *cone_scale,
+                      ntx_stream stream);
+
+/* Replaces layer.FourierFeatures.call (layer.py:22-23): x[M,D] -> out[M, D*(1+2*n_freq)] (DEVICE). */
+int ntx_fourier_features(const float *x, int64_t m, int d, int n_freq, float *out, ntx_stream stream);
+
+/* Replaces model((pos, dirs, params), training) (renderer.py:161; model.py:58-125):
+ * pos[M,3], dirs[M,3], params[M,P] -> color[M,3] (raw), sigma[M] (raw alpha head).  All DEVICE. */
+int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const float *params, int64_t m,
+                    float *color_out, float *sigma_out, ntx_stream stream);
+
+/* Replaces Renderer.map_model_output (renderer.py:170-213): color[N,S,3], sigma[N,S], z[N,S],
+ * rays_d[N,3] -> color_out[N,3], alpha_out[N], optional weights_out[N,S] (NULL to skip).
+ * bkgd: HOST float[3]. */
+int ntx_composite(const float *color, const float *sigma, const float *z_vals, const float *rays_d,
+                  int64_t n_rays, int n_samples, uint32_t flags, const float *bkgd, float *color_out,
+                  float *alpha_out, float *weights_out, ntx_stream stream);
+
+/* Replaces Renderer.__call__ + render_rays + evaluate_model + map_model_output
+ * (renderer.py:47-213) with perturb=False / raw_noise_std=0 / n_importance=0, fused in one launch:
+ * culling of t==inf rays, sample placement, positional encoding, the MLP and the composite.
+ *   rays_o[N,3], rays_d[N,3], t[N,2], cone_scale[N] (DEVICE)
+ *   params[n_param_rows, P] (DEVICE): ray r uses row r / rays_per_param_row (the reference's
+ *       tf.repeat(parameters, HW), renderer.py:54); rays_per_param_row = 1 gives per-ray parameters
+ *   blur_idx: -1 = off, else params[blur_idx] *= cone_scale * z per sample (renderer.py:155-158)
+ *   z_vals: NULL, or DEVICE [N,S] sample depths replacing renderer.py:101-103 (the caller's own
+ *       stratified jitter, renderer.py:106-111)
+ *   status_flag: NULL, or DEVICE int32 OR-ed with 1 when NTX_FLAG_CHECK_NUMERICS finds NaN/Inf
+ * Outputs (DEVICE): color_out[N,3] (premultiplied), alpha_out[N]; culled rays get 0 (or bkgd). */
+int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, const float *t,
+                    const float *params, int64_t rays_per_param_row, const float *cone_scale,
+                    int64_t n_rays, int n_samples, int blur_idx, uint32_t flags, const float *bkgd,
+                    const float *z_vals, float *color_out, float *alpha_out, int32_t *status_flag,
+                    ntx_stream stream);
+
+/* Introspection for benches/tests: name and launch geometry of the fused kernel in `ctx`. */
+int ntx_kernel_info(ntx_ctx *ctx, int *n_workgroups, int *threads_per_workgroup, int *n_cus);
+
+/* Host-only helpers (no device needed) exposing the weight packing, so it can be checked on CPU:
+ * number of floats of the packed image, and the packing itself. */
+size_t ntx_packed_count(const ntx_model_desc *desc);
+int ntx_pack_weights(const ntx_model_desc *desc, const float *weights_host, size_t n_floats,
+                     float *packed_out, size_t n_packed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFTEX_H */

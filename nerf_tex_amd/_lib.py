@@ -1,0 +1,78 @@
+"""ctypes binding of libnerftex_hip.so (C ABI: include/nerftex.h).
+
+The product path has NO fallback: if the shared library is missing or fails to load, importing
+this module raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C nerf_tex_amd/csrc`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnerftex_hip.so")
+
+NTX_OK, NTX_E_INVALID, NTX_E_UNSUPPORTED, NTX_E_HIP, NTX_E_NODEVICE = 0, -1, -2, -3, -4
+FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS = 1, 2, 4
+
+
+class ModelDesc(C.Structure):
+    """struct ntx_model_desc"""
+    _fields_ = [(n, C.c_int32) for n in ("kind", "n_geo", "n_app", "n_pos", "pos_freq", "dir_freq",
+                                          "param_freq", "depth", "width", "skip", "color_depth")]
+
+
+class NtxError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"nerftex error {code}: {message}")
+        self.code = code
+
+
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+# every symbol include/nerftex.h declares: (restype, argtypes)
+SYMBOLS = {
+    "ntx_abi_version": (C.c_int, []),
+    "ntx_last_error": (C.c_char_p, []),
+    "ntx_weight_count": (C.c_size_t, [C.POINTER(ModelDesc)]),
+    "ntx_create": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, C.c_int, C.POINTER(_vp)]),
+    "ntx_set_weights": (C.c_int, [_vp, _fp, C.c_size_t]),
+    "ntx_destroy": (C.c_int, [_vp]),
+    "ntx_generate_rays": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, C.c_int64, C.c_int64, C.c_int, _fp, _fp,
+                                    C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "ntx_fourier_features": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, _vp, _vp]),
+    "ntx_mlp_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "ntx_composite": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_uint32, _fp, _vp, _vp, _vp, _vp]),
+    "ntx_render_rays": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, C.c_int, C.c_uint32,
+                                  _fp, _vp, _vp, _vp, _vp, _vp]),
+    "ntx_kernel_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ntx_packed_count": (C.c_size_t, [C.POINTER(ModelDesc)]),
+    "ntx_pack_weights": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, _fp, C.c_size_t]),
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: the HIP library is not built "
+                          f"(run `make -C {os.path.join(_HERE, 'csrc')}`); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch, also fatal
+        fn.restype, fn.argtypes = res, args
+    if lib.ntx_abi_version() != 1:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.ntx_abi_version()} != 1")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != NTX_OK:
+        raise NtxError(rc, lib.ntx_last_error().decode("utf-8", "replace"))
+
+
+def f3(values) -> "C.Array":
+    return (C.c_float * 3)(*[float(v) for v in values])

@@ -1,0 +1,420 @@
+// nerftex.hip -- host side of libnerftex_hip.so: weight packing, kernel dispatch and the C ABI
+// declared in include/nerftex.h.  gfx950 only.
+#include "nerftex.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ntx_device.h"
+
+using namespace ntx;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(NTX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// supported architectures = the kernels instantiated below
+// ---------------------------------------------------------------------------------------------
+struct Variant {
+    int n_geo, n_app, cd;
+};
+static const Variant kVariants[] = {
+    {1, 6, 1},   // carpet          (configs/config_carpet_render.py:59-72)
+    {1, 4, 1},   // grass, fur, plush
+    {2, 3, 1},   // grass_filtered
+    {0, 0, 0},   // plain Nerf      (model.py:9-45)
+};
+
+static int find_variant(const ntx_model_desc *d) {
+    if (!d) return -1;
+    if (d->n_pos != 3 || d->pos_freq != POS_FREQ || d->dir_freq != DIR_FREQ || d->depth != DEPTH ||
+        d->width != WIDTH || d->skip != SKIP)
+        return -1;
+    const bool nerf = d->kind == NTX_MODEL_NERF;
+    const int g = nerf ? 0 : d->n_geo, a = nerf ? 0 : d->n_app, cd = nerf ? 0 : d->color_depth;
+    if (!nerf && (g + a > 0) && d->param_freq != PAR_FREQ) return -1;
+    for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]); ++i)
+        if (kVariants[i].n_geo == g && kVariants[i].n_app == a && kVariants[i].cd == cd) return (int)i;
+    return -1;
+}
+
+static int unsupported(const ntx_model_desc *d) {
+    if (!d) return fail(NTX_E_INVALID, "model descriptor is NULL");
+    return fail(NTX_E_UNSUPPORTED,
+                "unsupported model: kind=%d n_parameters=[%d,%d] n_pos=%d freqs=%d/%d/%d depth=%d width=%d "
+                "skip=%d color_depth=%d (built: ParamNerf [1,6] [1,4] [2,3] and Nerf, 10/4/4 bands, 8x256, skip 4)",
+                d->kind, d->n_geo, d->n_app, d->n_pos, d->pos_freq, d->dir_freq, d->param_freq, d->depth,
+                d->width, d->skip, d->color_depth);
+}
+
+// ---------------------------------------------------------------------------------------------
+// reference-layout blob -> layer views (model.py:104-123)
+// ---------------------------------------------------------------------------------------------
+struct Layer {
+    const float *w, *b;
+    int in, out;
+};
+
+struct Net {
+    Layer trunk[DEPTH], alpha, feature, c1, c2, rgb;
+    bool has_c1;
+    size_t count;
+};
+
+static Net view_blob(const Variant &v, const float *blob) {
+    Net n{};
+    const int pm = pos_map_dim(v.n_geo), dm = dir_map_dim(v.n_app);
+    size_t p = 0;
+    auto take = [&](int in, int out) {
+        Layer l{blob ? blob + p : nullptr, blob ? blob + p + (size_t)in * out : nullptr, in, out};
+        p += (size_t)in * out + out;
+        return l;
+    };
+    int k = pm;
+    for (int i = 0; i < DEPTH; ++i) {
+        n.trunk[i] = take(k, WIDTH);
+        k = WIDTH + (i == SKIP ? pm : 0);
+    }
+    n.alpha = take(WIDTH, 1);
+    n.feature = take(WIDTH, WIDTH);
+    n.has_c1 = v.cd > 0;
+    if (n.has_c1) {
+        n.c1 = take(WIDTH + dm, WIDTH);
+        n.c2 = take(WIDTH, WIDTH / 2);
+    } else {
+        n.c2 = take(WIDTH + dm, WIDTH / 2);
+    }
+    n.rgb = take(WIDTH / 2, 3);
+    n.count = p;
+    return n;
+}
+
+// one segment of the stream: for every k-step, NMT/4 records of [lane][4 consecutive M-tiles]
+template <class RowFn>
+static void emit_segment(float *&dst, const Layer &l, int nsteps, int nmt, int row_offset, RowFn rowfn) {
+    for (int s = 0; s < nsteps; ++s)
+        for (int q = 0; q < nmt / 4; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int row = rowfn(s, lane >> 5);
+                    const int col = 32 * (4 * q + e) + (lane & 31);
+                    float val = 0.0f;
+                    if (row >= 0 && col < l.out) val = l.w[(size_t)(row_offset + row) * l.out + col];
+                    *dst++ = val;
+                }
+}
+
+static void pack(const Variant &v, const float *blob, float *out) {
+    const Geometry g = make_geometry(v.n_geo, v.n_app, v.cd);
+    const Net n = view_blob(v, blob);
+    const int pm = pos_map_dim(v.n_geo), dm = dir_map_dim(v.n_app);
+    float *dst = out;
+    auto posrow = [&](int s, int h) { return pos_row(v.n_geo, s, h); };
+    auto dirrow = [&](int s, int h) { return dir_row(v.n_app, s, h); };
+    auto hidrow = [&](int s, int h) { return hidden_row(s, h); };
+
+    emit_segment(dst, n.trunk[0], g.pos_steps, 8, 0, posrow);
+    for (int i = 1; i < DEPTH; ++i) {
+        if (i == SKIP + 1) {
+            emit_segment(dst, n.trunk[i], g.pos_steps, 8, 0, posrow);
+            emit_segment(dst, n.trunk[i], HSTEPS, 8, pm, hidrow);
+        } else {
+            emit_segment(dst, n.trunk[i], HSTEPS, 8, 0, hidrow);
+        }
+    }
+    emit_segment(dst, n.feature, HSTEPS, 8, 0, hidrow);
+    if (n.has_c1) {
+        emit_segment(dst, n.c1, g.dir_steps, 8, 0, dirrow);
+        emit_segment(dst, n.c1, HSTEPS, 8, dm, hidrow);
+        emit_segment(dst, n.c2, HSTEPS, 4, 0, hidrow);
+    } else {
+        emit_segment(dst, n.c2, g.dir_steps, 4, 0, dirrow);
+        emit_segment(dst, n.c2, HSTEPS, 4, dm, hidrow);
+    }
+    // wrap-around tail: the first RING records again
+    memcpy(dst, out, sizeof(float) * RING * REC_FLOATS);
+    dst += RING * REC_FLOATS;
+
+    // aux block
+    float *aux = dst;
+    memset(aux, 0, sizeof(float) * g.aux_floats);
+    auto put_bias = [&](int layer, const Layer &l) {
+        for (int h = 0; h < 2; ++h)
+            for (int s = 0; s < l.out / 2; ++s) aux[layer * AUX_BIAS_STRIDE + h * 128 + s] = l.b[hidden_row(s, h)];
+    };
+    for (int i = 0; i < DEPTH; ++i) put_bias(i, n.trunk[i]);
+    put_bias(8, n.feature);
+    if (n.has_c1) put_bias(9, n.c1);
+    put_bias(10, n.c2);
+    for (int h = 0; h < 2; ++h)
+        for (int s = 0; s < HSTEPS; ++s) aux[aux_alpha_off() + h * 128 + s] = n.alpha.w[hidden_row(s, h)];
+    aux[aux_alpha_off() + 256] = n.alpha.b[0];
+    for (int c = 0; c < 3; ++c) {
+        for (int h = 0; h < 2; ++h)
+            for (int s = 0; s < 64; ++s) aux[aux_rgb_off() + (c * 2 + h) * 64 + s] = n.rgb.w[hidden_row(s, h) * 3 + c];
+        aux[aux_rgb_off() + 384 + c] = n.rgb.b[c];
+    }
+}
+
+static size_t packed_floats(const Variant &v) {
+    const Geometry g = make_geometry(v.n_geo, v.n_app, v.cd);
+    return (size_t)(g.stream_records + RING) * REC_FLOATS + g.aux_floats;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct ntx_ctx {
+    int variant;
+    int device;
+    int n_cus;
+    int n_wgs;
+    float *packed;        // device: stream | tail | aux
+    size_t stream_floats; // incl. tail
+    size_t n_packed;
+    ntx_model_desc desc;
+};
+
+template <class CFG>
+static hipError_t launch_render(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
+    render_kernel<CFG><<<dim3(c->n_wgs), dim3(256), 0, st>>>(a);
+    return hipGetLastError();
+}
+template <class CFG>
+static hipError_t launch_mlp(const ntx_ctx *c, MlpArgs &a, hipStream_t st) {
+    mlp_kernel<CFG><<<dim3(c->n_wgs), dim3(256), 0, st>>>(a);
+    return hipGetLastError();
+}
+
+#define NTX_DISPATCH(variant, FN, ...)                           \
+    ((variant) == 0   ? FN<Cfg<1, 6, 1>>(__VA_ARGS__)            \
+     : (variant) == 1 ? FN<Cfg<1, 4, 1>>(__VA_ARGS__)            \
+     : (variant) == 2 ? FN<Cfg<2, 3, 1>>(__VA_ARGS__)            \
+                      : FN<Cfg<0, 0, 0>>(__VA_ARGS__))
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int ntx_abi_version(void) { return NTX_ABI_VERSION; }
+const char *ntx_last_error(void) { return g_err; }
+
+size_t ntx_weight_count(const ntx_model_desc *desc) {
+    const int v = find_variant(desc);
+    if (v < 0) { unsupported(desc); return 0; }
+    return view_blob(kVariants[v], nullptr).count;
+}
+
+size_t ntx_packed_count(const ntx_model_desc *desc) {
+    const int v = find_variant(desc);
+    if (v < 0) { unsupported(desc); return 0; }
+    return packed_floats(kVariants[v]);
+}
+
+int ntx_pack_weights(const ntx_model_desc *desc, const float *weights_host, size_t n_floats, float *packed_out,
+                     size_t n_packed) {
+    const int v = find_variant(desc);
+    if (v < 0) return unsupported(desc);
+    if (!weights_host || !packed_out) return fail(NTX_E_INVALID, "NULL buffer");
+    if (n_floats != view_blob(kVariants[v], nullptr).count)
+        return fail(NTX_E_INVALID, "weight blob has %zu floats, model needs %zu", n_floats,
+                    view_blob(kVariants[v], nullptr).count);
+    if (n_packed != packed_floats(kVariants[v]))
+        return fail(NTX_E_INVALID, "packed buffer has %zu floats, needs %zu", n_packed, packed_floats(kVariants[v]));
+    pack(kVariants[v], weights_host, packed_out);
+    return NTX_OK;
+}
+
+int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_floats, int device, ntx_ctx **out) {
+    if (!out) return fail(NTX_E_INVALID, "out is NULL");
+    *out = nullptr;
+    const int v = find_variant(desc);
+    if (v < 0) return unsupported(desc);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NTX_E_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(NTX_E_INVALID, "device %d out of range [0,%d)", device, ndev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(NTX_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    ntx_ctx *c = new ntx_ctx();
+    c->variant = v;
+    c->device = device;
+    c->n_cus = prop.multiProcessorCount;
+    c->n_wgs = prop.multiProcessorCount;   // one 4-wave workgroup per CU: each wave owns a SIMD's register file
+    c->desc = *desc;
+    c->n_packed = packed_floats(kVariants[v]);
+    c->stream_floats = c->n_packed - make_geometry(kVariants[v].n_geo, kVariants[v].n_app, kVariants[v].cd).aux_floats;
+    c->packed = nullptr;
+    hipError_t e = hipMalloc((void **)&c->packed, c->n_packed * sizeof(float));
+    if (e != hipSuccess) {
+        const size_t bytes = c->n_packed * sizeof(float);
+        delete c;
+        return fail(NTX_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    *out = c;
+    if (weights_host) {
+        const int rc = ntx_set_weights(c, weights_host, n_floats);
+        if (rc != NTX_OK) {
+            ntx_destroy(c);
+            *out = nullptr;
+            return rc;
+        }
+    } else {
+        HIP_TRY(hipMemset(c->packed, 0, c->n_packed * sizeof(float)));
+    }
+    return NTX_OK;
+}
+
+int ntx_set_weights(ntx_ctx *ctx, const float *weights_host, size_t n_floats) {
+    if (!ctx || !weights_host) return fail(NTX_E_INVALID, "NULL argument");
+    std::vector<float> packed(ctx->n_packed);
+    const int rc = ntx_pack_weights(&ctx->desc, weights_host, n_floats, packed.data(), packed.size());
+    if (rc != NTX_OK) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(ctx->packed, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    return NTX_OK;
+}
+
+int ntx_destroy(ntx_ctx *ctx) {
+    if (!ctx) return NTX_OK;
+    if (ctx->packed) (void)hipFree(ctx->packed);
+    delete ctx;
+    return NTX_OK;
+}
+
+int ntx_kernel_info(ntx_ctx *ctx, int *n_workgroups, int *threads_per_workgroup, int *n_cus) {
+    if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
+    if (n_workgroups) *n_workgroups = ctx->n_wgs;
+    if (threads_per_workgroup) *threads_per_workgroup = 256;
+    if (n_cus) *n_cus = ctx->n_cus;
+    return NTX_OK;
+}
+
+int ntx_generate_rays(const float *c2w, int height, int width, float focal, int64_t pixel0, int64_t n_pixels,
+                      int mode, const float *b0, const float *b1, float near_t, float far_t, float *rays_o,
+                      float *rays_d, float *t, float *cone_scale, ntx_stream stream) {
+    if (!c2w || !rays_o || !rays_d || !t || !cone_scale) return fail(NTX_E_INVALID, "NULL buffer");
+    if (height <= 0 || width <= 0 || n_pixels < 0 || pixel0 < 0 || pixel0 + n_pixels > (int64_t)height * width)
+        return fail(NTX_E_INVALID, "pixel range [%lld,+%lld) outside %dx%d", (long long)pixel0, (long long)n_pixels,
+                    height, width);
+    if (mode != 0 && mode != 1) return fail(NTX_E_INVALID, "mode must be 0 (Proxy/AABB) or 1 (Frustum)");
+    if (mode == 0 && (!b0 || !b1)) return fail(NTX_E_INVALID, "AABB bounds are NULL");
+    if (n_pixels == 0) return NTX_OK;
+    RaygenArgs a{};
+    memcpy(a.c2w, c2w, sizeof(a.c2w));
+    if (mode == 0) { memcpy(a.b0, b0, sizeof(a.b0)); memcpy(a.b1, b1, sizeof(a.b1)); }
+    a.focal = focal;
+    a.half_w = (float)(.5 * width);   // `.5 * width` is evaluated by python, then cast (ray_sampler.py:41)
+    a.half_h = (float)(.5 * height);
+    a.near_t = near_t; a.far_t = far_t;
+    a.width = width; a.mode = mode;
+    a.pixel0 = pixel0; a.n = n_pixels;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.cone = cone_scale;
+    const int64_t nb = (n_pixels + 255) / 256;
+    raygen_kernel<<<dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return NTX_OK;
+}
+
+int ntx_fourier_features(const float *x, int64_t m, int d, int n_freq, float *out, ntx_stream stream) {
+    if (m < 0 || d <= 0 || n_freq < 0 || n_freq > 30) return fail(NTX_E_INVALID, "bad shape m=%lld d=%d n_freq=%d", (long long)m, d, n_freq);
+    if (m == 0) return NTX_OK;
+    if (!x || !out) return fail(NTX_E_INVALID, "NULL buffer");
+    const int64_t nb = (m * d + 255) / 256;
+    fourier_kernel<<<dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream>>>(x, m, d, n_freq, out);
+    HIP_TRY(hipGetLastError());
+    return NTX_OK;
+}
+
+int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const float *params, int64_t m,
+                    float *color_out, float *sigma_out, ntx_stream stream) {
+    if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
+    if (m < 0) return fail(NTX_E_INVALID, "m < 0");
+    if (m == 0) return NTX_OK;
+    const Variant &v = kVariants[ctx->variant];
+    if (!pos || !dirs || !color_out || !sigma_out || (!params && v.n_geo + v.n_app > 0))
+        return fail(NTX_E_INVALID, "NULL buffer");
+    MlpArgs a{};
+    a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed);
+    a.stream_bytes = (uint32_t)(ctx->stream_floats * sizeof(float));
+    a.aux = ctx->packed + ctx->stream_floats;
+    a.pos = pos; a.dirs = dirs; a.params = params;
+    a.color_out = color_out; a.sigma_out = sigma_out;
+    a.m = m;
+    HIP_TRY(NTX_DISPATCH(ctx->variant, launch_mlp, ctx, a, (hipStream_t)stream));
+    return NTX_OK;
+}
+
+int ntx_composite(const float *color, const float *sigma, const float *z_vals, const float *rays_d, int64_t n_rays,
+                  int n_samples, uint32_t flags, const float *bkgd, float *color_out, float *alpha_out,
+                  float *weights_out, ntx_stream stream) {
+    if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
+    if (n_samples < 2) return fail(NTX_E_INVALID, "n_samples must be >= 2 (renderer.py:174-177 needs a previous step)");
+    if (n_rays == 0) return NTX_OK;
+    if (!color || !sigma || !z_vals || !rays_d || !color_out || !alpha_out) return fail(NTX_E_INVALID, "NULL buffer");
+    CompositeArgs a{};
+    a.color = color; a.sigma = sigma; a.z = z_vals; a.rays_d = rays_d;
+    a.color_out = color_out; a.alpha_out = alpha_out; a.weights_out = weights_out;
+    a.n_rays = n_rays; a.n_samples = n_samples; a.flags = flags;
+    for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
+    int64_t nb = (n_rays + 3) / 4;
+    if (nb > 256 * 8) nb = 256 * 8;   // 8 workgroups per CU, grid-stride over rays
+    composite_kernel<<<dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return NTX_OK;
+}
+
+int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, const float *t, const float *params,
+                    int64_t rays_per_param_row, const float *cone_scale, int64_t n_rays, int n_samples, int blur_idx,
+                    uint32_t flags, const float *bkgd, const float *z_vals, float *color_out, float *alpha_out,
+                    int32_t *status_flag, ntx_stream stream) {
+    if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
+    if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
+    if (n_samples < 2) return fail(NTX_E_INVALID, "n_samples must be >= 2 (renderer.py:174-177 needs a previous step)");
+    if (n_rays == 0) return NTX_OK;
+    const Variant &v = kVariants[ctx->variant];
+    const int np = v.n_geo + v.n_app;
+    if (!rays_o || !rays_d || !t || !color_out || !alpha_out || (!params && np > 0))
+        return fail(NTX_E_INVALID, "NULL buffer");
+    if (rays_per_param_row < 1) return fail(NTX_E_INVALID, "rays_per_param_row must be >= 1");
+    if (blur_idx < -1 || blur_idx >= np) return fail(NTX_E_INVALID, "blur_idx %d outside [-1,%d)", blur_idx, np);
+    if (blur_idx >= 0 && !cone_scale) return fail(NTX_E_INVALID, "blur_idx set but cone_scale is NULL");
+    RenderArgs a{};
+    a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed);
+    a.stream_bytes = (uint32_t)(ctx->stream_floats * sizeof(float));
+    a.aux = ctx->packed + ctx->stream_floats;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.params = params; a.cone = cone_scale; a.z_vals = z_vals;
+    a.color_out = color_out; a.alpha_out = alpha_out; a.status = status_flag;
+    a.n_rays = n_rays; a.rays_per_row = rays_per_param_row;
+    a.n_samples = n_samples; a.blur_idx = blur_idx; a.flags = flags;
+    a.delta = (1.0f - 0.0f) / (float)(n_samples - 1);
+    for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
+    HIP_TRY(NTX_DISPATCH(ctx->variant, launch_render, ctx, a, (hipStream_t)stream));
+    return NTX_OK;
+}
+
+}  // extern "C"

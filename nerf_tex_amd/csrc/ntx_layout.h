@@ -1,0 +1,140 @@
+// ntx_layout.h -- operand layout shared by the host weight packer and the gfx950 kernels.
+//
+// The fused MLP keeps a batch of 32 samples per wave64 entirely in registers and computes every
+// Dense layer TRANSPOSED with v_mfma_f32_32x32x2_f32:   out^T[feat, sample] = W^T[feat, k] * h^T[k, sample]
+//   A operand (1 VGPR) : lane l holds W[row(step, half=l>>5)][32*mtile + (l&31)]      (weights)
+//   B operand (1 VGPR) : lane l holds h[sample l&31][feature row(step, half=l>>5)]   (activations)
+//   C/D (16 regs)      : lane l, reg r holds out feature 32*mtile + (r&3) + 8*(r>>2) + 4*(l>>5)
+//                        of sample l&31
+// Because the order of the k-summation is free, the k-steps of the NEXT layer are defined so that
+// step s = 16*mtile + r pairs exactly the two features a lane pair (l, l+32) holds in register r of
+// tile mtile: an accumulator register, after bias+ReLU, IS the next layer's B operand -- activations
+// never move between lanes, never touch LDS and never leave the register file.
+// `hidden_row` is that map; `pos_row` / `dir_row` are the analogous maps for the positional-encoding
+// segments, chosen so that one k-step = {sin(2^f x), cos(2^f x)} = one sin() evaluation per lane
+// with a quadrant shift in the upper half-wave.
+#pragma once
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define NTX_HD __host__ __device__
+#else
+#define NTX_HD
+#endif
+
+namespace ntx {
+
+constexpr int POS_FREQ = 10;   // n_freq_bands of pos_embedding in every reference config
+constexpr int DIR_FREQ = 4;
+constexpr int PAR_FREQ = 4;
+constexpr int WIDTH = 256;
+constexpr int DEPTH = 8;
+constexpr int SKIP = 4;
+constexpr int HSTEPS = WIDTH / 2;       // k-steps of a 256-wide hidden input
+constexpr int RING = 8;                 // weight records (64 lanes x float4) kept in flight per wave
+constexpr int REC_FLOATS = 256;         // one record = 64 lanes x 4 floats = 1 KiB
+
+NTX_HD constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// feature index (within a hidden activation vector) that half-wave `h` holds for k-step `s`
+NTX_HD constexpr int hidden_row(int s, int h) {
+    return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h;
+}
+
+// ---- position segment: pos_map = [FF(pos,10) (63) | FF(params[:n_geo],4) (9*n_geo)]  (model.py:77,88-93)
+NTX_HD constexpr int pos_id_values(int n_geo) { return 3 + n_geo; }
+NTX_HD constexpr int pos_id_steps(int n_geo) { return (pos_id_values(n_geo) + 1) / 2; }
+NTX_HD constexpr int pos_steps_raw(int n_geo) { return pos_id_steps(n_geo) + 3 * POS_FREQ + n_geo * PAR_FREQ; }
+// padded so that a segment is a whole number of ring turns (see RING): multiple of 4 steps x 2 records
+NTX_HD constexpr int pos_steps(int n_geo) { return round_up(pos_steps_raw(n_geo), 4); }
+NTX_HD constexpr int pos_map_dim(int n_geo) { return 3 * (1 + 2 * POS_FREQ) + n_geo * (1 + 2 * PAR_FREQ); }
+
+// row of the reference's pos_map that (step s, half h) carries, or -1 for a zero pad
+NTX_HD constexpr int pos_row(int n_geo, int s, int h) {
+    const int nid = pos_id_steps(n_geo);
+    if (s < nid) {
+        const int v = 2 * s + h;
+        if (v >= pos_id_values(n_geo)) return -1;
+        return v < 3 ? v : 3 * (1 + 2 * POS_FREQ) + (v - 3);
+    }
+    int q = s - nid;
+    if (q < 3 * POS_FREQ) return 3 + 6 * (q / 3) + 3 * h + (q % 3);
+    q -= 3 * POS_FREQ;
+    if (q < n_geo * PAR_FREQ) {
+        const int f = q / n_geo, g = q % n_geo;
+        return 3 * (1 + 2 * POS_FREQ) + n_geo + 2 * f * n_geo + h * n_geo + g;
+    }
+    return -1;
+}
+
+// ---- direction segment: dir_map = [FF(dir,4) (27) | FF(params[n_geo:],4) (9*n_app)]  (model.py:78,96-101)
+NTX_HD constexpr int dir_id_values(int n_app) { return 3 + n_app; }
+NTX_HD constexpr int dir_id_steps(int n_app) { return (dir_id_values(n_app) + 1) / 2; }
+NTX_HD constexpr int dir_steps_raw(int n_app) { return dir_id_steps(n_app) + 3 * DIR_FREQ + n_app * PAR_FREQ; }
+NTX_HD constexpr int dir_steps(int n_app, int align) { return round_up(dir_steps_raw(n_app), align); }
+NTX_HD constexpr int dir_map_dim(int n_app) { return 3 * (1 + 2 * DIR_FREQ) + n_app * (1 + 2 * PAR_FREQ); }
+
+NTX_HD constexpr int dir_row(int n_app, int s, int h) {
+    const int nid = dir_id_steps(n_app);
+    if (s < nid) {
+        const int v = 2 * s + h;
+        if (v >= dir_id_values(n_app)) return -1;
+        return v < 3 ? v : 3 * (1 + 2 * DIR_FREQ) + (v - 3);
+    }
+    int q = s - nid;
+    if (q < 3 * DIR_FREQ) return 3 + 6 * (q / 3) + 3 * h + (q % 3);
+    q -= 3 * DIR_FREQ;
+    if (q < n_app * PAR_FREQ) {
+        const int f = q / n_app, a = q % n_app;
+        return 3 * (1 + 2 * DIR_FREQ) + n_app + 2 * f * n_app + h * n_app + a;
+    }
+    return -1;
+}
+
+// ---- packed image geometry -----------------------------------------------------------------
+// Weight STREAM (consumed strictly in order by every wave, RING records ahead):
+//   L0   : pos segment, 8 M-tiles            pos_steps * 2 records
+//   L1-4 : hidden segment                    HSTEPS * 2 records each
+//   L5   : pos segment then hidden segment
+//   L6-7 : hidden
+//   F    : hidden (linear "feature" layer, model.py:114)
+//   ParamNerf: C1 = dir segment (8 tiles) + hidden ; C2 = hidden input, 4 M-tiles (HSTEPS records)
+//   Nerf     : C2 = dir segment (4 tiles) + hidden (4 tiles)
+//   tail : a copy of the first RING records (so the prefetch ring wraps into the next batch)
+// AUX block (read through LDS): biases in accumulator order, alpha head, rgb head.
+struct Geometry {
+    int n_geo, n_app, color_depth;   // color_depth: 1 = ParamNerf, 0 = Nerf
+    int pos_steps, dir_steps;
+    int stream_records;              // without the wrap-around tail
+    int aux_floats;
+};
+
+constexpr int N_BIAS_LAYERS_MAX = 12;   // L0..L7, F, C1, C2 (+1 spare)
+constexpr int AUX_BIAS_STRIDE = 2 * 128;  // [half][128] per layer (C2 uses the first 64 of each half)
+
+NTX_HD constexpr int aux_alpha_off() { return N_BIAS_LAYERS_MAX * AUX_BIAS_STRIDE; }   // [half][128] + bias
+NTX_HD constexpr int aux_rgb_off() { return aux_alpha_off() + 2 * 128 + 4; }             // [3][half][64] + bias[3]
+NTX_HD constexpr int aux_total() { return round_up(aux_rgb_off() + 3 * 2 * 64 + 4, 64); }
+
+NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth) {
+    Geometry g{};
+    g.n_geo = n_geo; g.n_app = n_app; g.color_depth = color_depth;
+    g.pos_steps = pos_steps(n_geo);
+    g.dir_steps = dir_steps(n_app, color_depth ? 4 : 8);
+    int rec = 0;
+    rec += g.pos_steps * 2;                 // L0
+    rec += 4 * HSTEPS * 2;                  // L1-4
+    rec += g.pos_steps * 2 + HSTEPS * 2;    // L5
+    rec += 2 * HSTEPS * 2;                  // L6-7
+    rec += HSTEPS * 2;                      // F
+    if (color_depth) {
+        rec += g.dir_steps * 2 + HSTEPS * 2;  // C1
+        rec += HSTEPS;                         // C2
+    } else {
+        rec += g.dir_steps + HSTEPS;           // C2 (4 tiles)
+    }
+    g.stream_records = rec;
+    g.aux_floats = aux_total();
+    return g;
+}
+
+}  // namespace ntx

@@ -1,0 +1,198 @@
+"""Model containers (reference: network/model.py).
+
+`ParamNerf` / `Nerf` / `CoarseFine` keep the reference's signatures and return `{name: model}`
+exactly like model.py:45,56,125, so `renderer_config.update(model)` (render.py:24) works unchanged.
+The model object holds the weights in the reference's own layout (Keras `get_weights()` order:
+kernel[in,out], bias[out] per Dense layer in creation order) and, per device, a context of the HIP
+library holding the packed image.  Calling it runs the fused MLP kernel (`ntx_mlp_forward`).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Sequence, Tuple, Union
+
+import numpy as np
+
+from .layer import n_freq_bands_of
+
+KIND_PARAMNERF, KIND_NERF = 0, 1
+
+
+class NerfModel:
+    """Stand-in for the `tf.keras.Model` the reference builds (model.py:125)."""
+
+    def __init__(self, kind: int, n_parameters: Sequence[int], n_pos: int, pos_freq: int, dir_freq: int,
+                 param_freq: int, depth: int, width: int, skips: Sequence[int], color_depth: int, name: str) -> None:
+        self.kind = kind
+        self.n_geo, self.n_app = (0, 0) if kind == KIND_NERF else (int(n_parameters[0]), int(n_parameters[1]))
+        self.n_pos, self.pos_freq, self.dir_freq, self.param_freq = n_pos, pos_freq, dir_freq, param_freq
+        self.depth, self.width, self.skips, self.color_depth = depth, width, tuple(skips), color_depth
+        self.name = name
+        self._ctx: Dict[int, int] = {}
+        self._blob = np.zeros(self.n_weight_floats(), dtype=np.float32)
+        self.initialize()
+
+    # ---- architecture ------------------------------------------------------------------
+    @property
+    def n_params(self) -> int:
+        return self.n_geo + self.n_app
+
+    @property
+    def pos_map_dim(self) -> int:
+        return self.n_pos * (1 + 2 * self.pos_freq) + self.n_geo * (1 + 2 * self.param_freq)
+
+    @property
+    def dir_map_dim(self) -> int:
+        return 3 * (1 + 2 * self.dir_freq) + self.n_app * (1 + 2 * self.param_freq)
+
+    def layer_table(self) -> List[Tuple[str, int, int]]:
+        """(name, in, out) per Dense layer in creation order (model.py:104-123 / 28-43)."""
+        rows, k = [], self.pos_map_dim
+        for i in range(self.depth):
+            rows.append((f"trunk{i}", k, self.width))
+            k = self.width + (self.pos_map_dim if i in self.skips else 0)
+        rows.append(("alpha", k, 1))
+        rows.append(("feature", k, self.width))
+        k = self.width + self.dir_map_dim
+        if self.kind == KIND_PARAMNERF:
+            for i in range(self.color_depth):
+                rows.append((f"color_hidden{i}", k, self.width))
+                k = self.width
+        rows.append(("color_half", k, self.width // 2))
+        rows.append(("color", self.width // 2, 3))
+        return rows
+
+    def n_weight_floats(self) -> int:
+        return sum(i * o + o for _, i, o in self.layer_table())
+
+    def macs_per_sample(self) -> int:
+        return sum(i * o for _, i, o in self.layer_table())
+
+    def desc(self):
+        from . import _lib
+        if len(self.skips) != 1:
+            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, f"skips={self.skips}: the HIP kernels implement one skip layer")
+        return _lib.ModelDesc(self.kind, self.n_geo, self.n_app, self.n_pos, self.pos_freq, self.dir_freq,
+                              self.param_freq, self.depth, self.width, self.skips[0], self.color_depth)
+
+    # ---- weights -----------------------------------------------------------------------
+    def initialize(self) -> None:
+        """Keras defaults (model.py uses none other): glorot_uniform kernels, zero biases.  Draws
+        from numpy's global RNG, which `main.py:30` seeds from the config."""
+        parts = []
+        for _, i, o in self.layer_table():
+            lim = np.sqrt(6.0 / (i + o))
+            parts.append(np.random.uniform(-lim, lim, size=i * o).astype(np.float32))
+            parts.append(np.zeros(o, dtype=np.float32))
+        self.set_blob(np.concatenate(parts))
+
+    def get_weights(self) -> List[np.ndarray]:
+        out, p = [], 0
+        for _, i, o in self.layer_table():
+            out.append(self._blob[p:p + i * o].reshape(i, o).copy()); p += i * o
+            out.append(self._blob[p:p + o].copy()); p += o
+        return out
+
+    def set_weights(self, weights: Sequence[np.ndarray]) -> None:
+        table = self.layer_table()
+        if len(weights) != 2 * len(table):
+            raise ValueError(f"expected {2 * len(table)} arrays, got {len(weights)}")
+        flat = []
+        for (name, i, o), k, b in zip(table, weights[0::2], weights[1::2]):
+            k = np.asarray(k, dtype=np.float32); b = np.asarray(b, dtype=np.float32)
+            if k.shape != (i, o) or b.shape != (o,):
+                raise ValueError(f"layer {name}: expected kernel {(i, o)} bias {(o,)}, got {k.shape} {b.shape}")
+            flat += [k.ravel(), b.ravel()]
+        self.set_blob(np.concatenate(flat))
+
+    def get_blob(self) -> np.ndarray:
+        return self._blob.copy()
+
+    def set_blob(self, blob: np.ndarray) -> None:
+        blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
+        if blob.size != self.n_weight_floats():
+            raise ValueError(f"blob has {blob.size} floats, model needs {self.n_weight_floats()}")
+        self._blob = blob.copy()
+        if self._ctx:
+            from . import _lib
+            for ctx in self._ctx.values():
+                _lib.check(_lib.lib.ntx_set_weights(ctx, self._blob.ctypes.data_as(C.POINTER(C.c_float)), self._blob.size))
+
+    # ---- device ------------------------------------------------------------------------
+    def ctx(self, device_index: int) -> int:
+        """Context of the HIP library for `device_index`, created on first use."""
+        from . import _lib
+        if device_index not in self._ctx:
+            handle = C.c_void_p()
+            desc = self.desc()
+            _lib.check(_lib.lib.ntx_create(C.byref(desc), self._blob.ctypes.data_as(C.POINTER(C.c_float)),
+                                           self._blob.size, device_index, C.byref(handle)))
+            self._ctx[device_index] = handle.value
+        return self._ctx[device_index]
+
+    def close(self) -> None:
+        if self._ctx:
+            from . import _lib
+            for ctx in self._ctx.values():
+                _lib.lib.ntx_destroy(ctx)
+            self._ctx = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __call__(self, inputs, training: bool = False):
+        """model((pos[M,n_pos], dirs[M,3], params[M,P]), training) -> (color[M,3], alpha[M,1])
+        (renderer.py:161).  Inputs are CUDA(ROCm) float32 tensors."""
+        import torch
+        from . import _lib
+        pos, dirs, params = inputs
+        pos = pos.contiguous().float(); dirs = dirs.contiguous().float()
+        m = pos.shape[0]
+        if self.n_params > 0:
+            params = params.contiguous().float()
+            if params.shape != (m, self.n_params):
+                raise ValueError(f"params must be [{m},{self.n_params}], got {tuple(params.shape)}")
+        dev = pos.device
+        color = torch.empty((m, 3), device=dev, dtype=torch.float32)
+        alpha = torch.empty((m, 1), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib.ntx_mlp_forward(self.ctx(dev.index or 0), pos.data_ptr(), dirs.data_ptr(),
+                                            params.data_ptr() if self.n_params > 0 else None, m,
+                                            color.data_ptr(), alpha.data_ptr(),
+                                            torch.cuda.current_stream(dev).cuda_stream))
+        return color, alpha
+
+
+def Nerf(pos_embedding, dir_embedding, depth: int = 8, width: int = 256, skips: list = [4], name: str = "model",
+         **kwargs) -> dict:
+    """network.model.Nerf (model.py:9-45)."""
+    return {name: NerfModel(KIND_NERF, (0, 0), 3, n_freq_bands_of(pos_embedding), n_freq_bands_of(dir_embedding),
+                            0, depth, width, skips, 0, name)}
+
+
+def ParamNerf(pos_embedding, dir_embedding, param_embedding, n_parameters: Union[int, list], n_pos: int = 3,
+              param_depth: int = 0, param_width: int = 128, depth: int = 8, width: int = 256, skips: list = [4],
+              color_depth: int = 1, embedding_config=None, include_param_dims: bool = False,
+              name: str = "model") -> dict:
+    """network.model.ParamNerf (model.py:58-125)."""
+    if isinstance(n_parameters, int):
+        n_parameters = [n_parameters, 0]                                    # model.py:63-64
+    if param_depth != 0 or embedding_config is not None:
+        raise NotImplementedError("param_depth > 0 / embedding_config are used by no reference config and have no HIP kernel")
+    return {name: NerfModel(KIND_PARAMNERF, n_parameters, n_pos, n_freq_bands_of(pos_embedding),
+                            n_freq_bands_of(dir_embedding), n_freq_bands_of(param_embedding), depth, width, skips,
+                            color_depth, name)}
+
+
+def CoarseFine(model_config, **kwargs) -> dict:
+    """network.model.CoarseFine (model.py:47-56)."""
+    from . import util
+    for key, value in kwargs.items():
+        model_config.setdefault(key, value)
+    model_coarse = util.instantiate(model_config)
+    model_config["name"] = next(iter(model_coarse)) + "_fine"
+    model_fine = util.instantiate(model_config)
+    return dict(model_coarse, **model_fine)

@@ -1,0 +1,54 @@
+"""Ray generation (reference: network/ray_sampler.py)."""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Tuple
+
+import numpy as np
+
+
+def _generate(pixel_range: Tuple[int, int], height: int, width: int, focal: float, c2w, mode: int, b0, b1,
+              near: float, far: float, device=None):
+    import torch
+    from . import _lib
+    first, count = pixel_range
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    rays_o = torch.empty((count, 3), device=dev, dtype=torch.float32)
+    rays_d = torch.empty((count, 3), device=dev, dtype=torch.float32)
+    t = torch.empty((count, 2), device=dev, dtype=torch.float32)
+    cone = torch.empty((count, 1), device=dev, dtype=torch.float32)
+    c2w_h = np.ascontiguousarray(np.asarray(c2w.detach().cpu() if hasattr(c2w, "detach") else c2w, dtype=np.float32))
+    if c2w_h.shape != (4, 4):
+        raise ValueError(f"c2w must be 4x4, got {c2w_h.shape}")
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib.ntx_generate_rays(c2w_h.ctypes.data_as(C.POINTER(C.c_float)), height, width,
+                                              float(np.float32(focal)), first, count, mode,
+                                              _lib.f3(b0) if b0 is not None else None,
+                                              _lib.f3(b1) if b1 is not None else None, float(near), float(far),
+                                              rays_o.data_ptr(), rays_d.data_ptr(), t.data_ptr(), cone.data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream))
+    return rays_o, rays_d, t, cone
+
+
+class Frustum:
+    """network.ray_sampler.Frustum (ray_sampler.py:6-21)."""
+
+    def __init__(self, height: int, width: int, focal: float, near: float, far: float, **kwargs) -> None:
+        self.height, self.width, self.focal, self.near, self.far = height, width, focal, near, far
+
+    def __call__(self, image_plane_loc, c2w, device=None):
+        return _generate(image_plane_loc, self.height, self.width, self.focal, c2w, 1, None, None, self.near,
+                         self.far, device)
+
+
+class Proxy:
+    """network.ray_sampler.Proxy (ray_sampler.py:23-37): normalised rays_d and the proxy's t-range."""
+
+    def __init__(self, height: int, width: int, focal: float, proxy: Any, **kwargs) -> None:
+        self.height, self.width, self.focal, self.proxy = height, width, focal, proxy
+
+    def __call__(self, image_plane_loc, c2w, device=None):
+        """`image_plane_loc` is the (first_pixel, n_pixels) range produced by `pixel_sampler.Full`."""
+        return _generate(image_plane_loc, self.height, self.width, self.focal, c2w, 0, self.proxy.b_0,
+                         self.proxy.b_1, 0.0, 0.0, device)

@@ -1,0 +1,51 @@
+"""Render harness (reference: network/render.py `Render` + the render half of network/logger.py).
+
+`Render` builds dataset -> model -> renderer exactly as render.py:16-25 does and then plays the
+part of `Logger.render_images` (logger.py:88-137): loop over views, call the renderer, pack RGBA.
+Checkpoint restore and PNG/EXR writing are the reference's I/O layer and are out of scope; images
+are returned (and optionally saved as .npy).
+"""
+
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+from . import util
+
+
+def render_image(renderer, dataset, data: dict):
+    """logger.Logger.render_image (logger.py:121-126): premultiplied RGBA [H, W, 4]."""
+    import torch
+    pred = renderer(**data, composite_bkgd=dataset.composite_bkgd, bkgd_color=dataset.bkgd_color, training=False)
+    img = torch.cat([pred["color_pred"].reshape(-1, 3), pred["alpha_pred"].reshape(-1, 1)], -1)
+    return img.reshape(-1, dataset.height, dataset.width, 4)
+
+
+def Render(target_path: Optional[str], test_dataset_config, model_config, renderer_config, logger_config=None,
+           source_path: str = None, override: bool = True, weights=None, return_imgs: bool = True, **kwargs) -> List:
+    """network.render.Render (render.py:6-29)."""
+    test_dataset = util.instantiate(test_dataset_config)
+    model_config.setdefault("n_parameters", test_dataset.n_parameters)                  # render.py:20
+    model = util.instantiate(model_config)
+    if weights is not None:                      # stands in for the checkpoint restore of logger.py:33-39
+        next(iter(model.values())).set_blob(weights)
+    renderer_config.update(model)                                                      # render.py:24
+    renderer = util.instantiate(renderer_config)
+    imgs = []
+    for i, data in enumerate(test_dataset):
+        img = render_image(renderer, test_dataset, data)
+        renderer.raise_if_nonfinite()
+        if target_path is not None:
+            import numpy as np
+            os.makedirs(os.path.join(target_path, "media", "test"), exist_ok=True)
+            np.save(os.path.join(target_path, "media", "test", util_format(i, len(test_dataset))), img.cpu().numpy())
+        if return_imgs:
+            imgs.append(img)
+    return imgs
+
+
+def util_format(idx: int, max_idx: int) -> str:
+    import math
+    n_chars = max(1, math.ceil(math.log10(max_idx + 1)))                               # util.py:56-62
+    return ("{:0" + str(n_chars) + "d}").format(idx) + ".npy"

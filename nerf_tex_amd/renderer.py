@@ -1,0 +1,127 @@
+"""Volumetric ray marcher (reference: network/renderer.py, class Renderer).
+
+Same constructor kwargs and call contract as the reference (renderer.py:34, 47); the whole of
+`__call__` -> `render_rays` -> `evaluate_model` -> `map_model_output` (renderer.py:47-213) is ONE
+launch of the fused HIP kernel (`ntx_render_rays`): culling of t == inf rays, sample placement,
+positional encoding, the 8x256 MLP on the matrix cores and the per-ray composite scan.
+Inputs/outputs are torch tensors on the GPU instead of tf.Tensors.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+from . import _lib
+
+
+class Renderer:
+    """network.renderer.Renderer (renderer.py:31-213)."""
+
+    def __init__(self, model, model_fine=None, n_samples: int = 64, n_importance: int = 0, perturb: bool = True,
+                 raw_noise_std: float = 0, render_chunk: int = 32768, net_chunk: int = 65536,
+                 downsampling_factor: int = 1, blur_idx: Optional[int] = None, map_exr: bool = False,
+                 check_numerics: bool = True, **kwargs) -> None:
+        self.model = model
+        self.model_fine = model_fine
+        self.n_samples = n_samples
+        self.n_importance = n_importance
+        self.perturb = perturb
+        self.raw_noise_std = raw_noise_std
+        # render_chunk / net_chunk bound TensorFlow's activation memory (renderer.py:72,160); the fused
+        # kernel keeps activations in registers, so they are accepted and have no effect on results.
+        self.render_chunk = render_chunk
+        self.net_chunk = net_chunk
+        self.downsampling_factor = downsampling_factor
+        self.blur_idx = blur_idx
+        self.map_exr = map_exr
+        self.check_numerics = check_numerics     # tf.debugging.check_numerics, renderer.py:140-141
+        if n_importance > 0:
+            raise NotImplementedError("hierarchical sampling (n_importance > 0, renderer.py:125-138) is used by no "
+                                      "reference config and has no HIP kernel yet")
+        if raw_noise_std > 0:
+            raise NotImplementedError("raw_noise_std > 0 (renderer.py:190-192) is a training regulariser; the render path has no kernel for it")
+
+    def __call__(self, rays_o, rays_d, t, parameters, cone_scale, composite_bkgd: bool = False,
+                 bkgd_color=[1, 1, 1.], training: bool = True, z_vals=None, **kwargs) -> dict:
+        """rays_o/rays_d [B,HW,3], t [B,HW,2], parameters [B,P], cone_scale [B,HW,1]
+        -> {'color_pred': [B,HW,3], 'alpha_pred': [B,HW]}  (renderer.py:47-90)."""
+        import torch
+        dev = rays_o.device
+        if dev.type != "cuda":
+            raise _lib.NtxError(_lib.NTX_E_NODEVICE, "Renderer inputs must live on the GPU; there is no CPU path")
+        B, HW = rays_o.shape[0], rays_o.shape[1]
+        n = B * HW
+        rays_o = rays_o.reshape(n, 3).contiguous().float()
+        rays_d = rays_d.reshape(n, 3).contiguous().float()
+        t = t.reshape(n, 2).contiguous().float()
+        cone = cone_scale.reshape(n).contiguous().float()
+        P = self.model.n_params
+        params = None
+        if P > 0:
+            params = parameters.reshape(B, -1).contiguous().float().to(dev)
+            if params.shape[1] != P:
+                raise ValueError(f"parameters must be [B,{P}], got {tuple(parameters.shape)}")
+        S = self.n_samples
+        z = None
+        if z_vals is not None:
+            z = z_vals.reshape(n, S).contiguous().float()
+        elif self.perturb:
+            z = self._jitter(t, S)                                           # renderer.py:106-111
+        color = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        alpha = torch.empty((n,), device=dev, dtype=torch.float32)
+        flags = (_lib.FLAG_MAP_EXR if self.map_exr else 0) | (_lib.FLAG_COMPOSITE_BKGD if composite_bkgd else 0)
+        status = None
+        if self.check_numerics:
+            flags |= _lib.FLAG_CHECK_NUMERICS
+            status = torch.zeros(1, device=dev, dtype=torch.int32)
+        bk = bkgd_color.detach().cpu().tolist() if hasattr(bkgd_color, "detach") else list(bkgd_color)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.ntx_render_rays(
+                self.model.ctx(dev.index or 0), rays_o.data_ptr(), rays_d.data_ptr(), t.data_ptr(),
+                params.data_ptr() if params is not None else None, HW, cone.data_ptr(), n, S,
+                -1 if self.blur_idx is None else int(self.blur_idx), flags, _lib.f3(bk),
+                z.data_ptr() if z is not None else None, color.data_ptr(), alpha.data_ptr(),
+                status.data_ptr() if status is not None else None, torch.cuda.current_stream(dev).cuda_stream))
+        out = {"color_pred": color.reshape(B, HW, 3), "alpha_pred": alpha.reshape(B, HW)}
+        if status is not None:
+            self._status = status          # read lazily: `raise_if_nonfinite()` syncs
+        return out
+
+    def raise_if_nonfinite(self) -> None:
+        """The reference raises InvalidArgumentError inside render_rays (renderer.py:140-141); here the
+        kernel sets a device flag and this (synchronising) call turns it into an exception."""
+        st = getattr(self, "_status", None)
+        if st is not None and int(st.item()) != 0:
+            raise FloatingPointError("NaN or Inf encountered in color_pred/alpha_pred")
+
+    @staticmethod
+    def _jitter(t, n_samples: int):
+        """Stratified jitter of renderer.py:101-111 (torch RNG stands in for tf.random.uniform; the
+        two streams cannot agree, so parity runs use perturb=False)."""
+        import torch
+        t_vals = torch.linspace(0., 1., n_samples, device=t.device, dtype=torch.float32)
+        z = t[:, None, 0] * (1 - t_vals) + t[:, None, 1] * t_vals
+        z = torch.where(torch.isfinite(z), z, torch.zeros_like(z))           # culled rays: never read
+        mids = .5 * (z[..., 1:] + z[..., :-1])
+        upper = torch.cat([mids, z[..., -1:]], -1)
+        lower = torch.cat([z[..., :1], mids], -1)
+        return (lower + (upper - lower) * torch.rand_like(z)).contiguous()
+
+    def map_model_output(self, color, alpha, z_vals, rays_d, composite_bkgd: bool, bkgd_color):
+        """Renderer.map_model_output (renderer.py:170-213) on its own (`ntx_composite`):
+        color [n,S,3], alpha [n,S], z_vals [n,S], rays_d [n,3] -> (color_map, alpha_map, weights)."""
+        import torch
+        dev = color.device
+        n, S = alpha.shape
+        color = color.contiguous().float(); alpha = alpha.contiguous().float()
+        z_vals = z_vals.contiguous().float(); rays_d = rays_d.contiguous().float()
+        c_out = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        a_out = torch.empty((n,), device=dev, dtype=torch.float32)
+        w_out = torch.empty((n, S), device=dev, dtype=torch.float32)
+        flags = (_lib.FLAG_MAP_EXR if self.map_exr else 0) | (_lib.FLAG_COMPOSITE_BKGD if composite_bkgd else 0)
+        bk = bkgd_color.detach().cpu().tolist() if hasattr(bkgd_color, "detach") else list(bkgd_color)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.ntx_composite(color.data_ptr(), alpha.data_ptr(), z_vals.data_ptr(), rays_d.data_ptr(),
+                                              n, S, flags, _lib.f3(bk), c_out.data_ptr(), a_out.data_ptr(),
+                                              w_out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        return c_out, a_out, w_out

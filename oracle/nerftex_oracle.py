@@ -1,0 +1,422 @@
+"""CPU oracle for the NeRF-Tex volumetric render path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy restatement of the reference's algorithm for the hot path named in
+BASELINE.json.  It is the *checker* for the HIP product code: only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it.  The
+product package (`nerf_tex_amd/`) never imports, links or executes anything in `oracle/`.
+
+PARITY UNPINNED (arithmetic).  The reference (`/root/reference`, hbaatz/nerf-tex) ships no
+tests, golden vectors or fixtures for this path, and every file on the path imports
+`tensorflow` (pinned `tensorflow-gpu=2.4.1`, reference `environment.yml:12`), which is not
+installed here and cannot be installed (no network).  So the arithmetic below is restated from
+reading the reference source, not checked against outputs of the reference.  What IS pinned:
+camera poses / material parameters, which come from the reference's TF-free modules
+(`data/distribution.py`, `data/sampler.py`, `configs/*.py`) run in this container by
+`oracle/gen_golden.py` and committed under `tests/golden/`.
+
+TensorFlow semantics taken on trust (cannot be executed here):
+  * `tf.linspace(0., 1., S)` (TF 2.4 `math_ops.linspace_nd`): interior points are
+    `start + ((stop-start)/(S-1)) * k` evaluated in the tensor dtype, end points exact.
+  * Keras `Dense` on rank-2 input: `matmul(x, kernel) + bias`, then the activation;
+    `kernel` is `[in, out]` row-major; accumulation order unspecified.
+  * `tf.math.cumprod(x, exclusive=True)`: sequential left-to-right product with leading 1.
+  * `tf.where(c, a, b)`, `tf.gather_nd`, `tf.scatter_nd` (zeros where not scattered).
+
+Every function takes `dtype` (np.float64 = the truth the parity gate is measured against,
+np.float32 = what a float32 TF-CPU run would compute, up to summation order) and cites the
+reference file:line it follows.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from math import tan
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+F64 = np.float64
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------------------
+# Model description (what `model_config` of a reference config file holds)
+# --------------------------------------------------------------------------------------
+@dataclass
+class ModelSpec:
+    """Mirror of the kwargs of `network.model.ParamNerf` (model.py:58) / `Nerf` (model.py:9)."""
+
+    kind: str = "ParamNerf"              # "ParamNerf" | "Nerf"
+    n_parameters: Tuple[int, int] = (1, 6)  # [geometry, appearance]  (model.py:63-64)
+    n_pos: int = 3
+    pos_freq: int = 10                   # pos_embedding.n_freq_bands
+    dir_freq: int = 4                    # dir_embedding.n_freq_bands
+    param_freq: int = 4                  # param_embedding.n_freq_bands
+    depth: int = 8
+    width: int = 256
+    skips: Tuple[int, ...] = (4,)
+    color_depth: int = 1                 # ParamNerf only (model.py:118); Nerf has none
+
+    @property
+    def n_geo(self) -> int:
+        return 0 if self.kind == "Nerf" else int(self.n_parameters[0])
+
+    @property
+    def n_app(self) -> int:
+        return 0 if self.kind == "Nerf" else int(self.n_parameters[1])
+
+    @property
+    def n_params(self) -> int:
+        return self.n_geo + self.n_app
+
+    @property
+    def pos_map_dim(self) -> int:
+        return self.n_pos * (1 + 2 * self.pos_freq) + self.n_geo * (1 + 2 * self.param_freq)
+
+    @property
+    def dir_map_dim(self) -> int:
+        return 3 * (1 + 2 * self.dir_freq) + self.n_app * (1 + 2 * self.param_freq)
+
+
+def layer_table(spec: ModelSpec) -> List[Tuple[str, int, int]]:
+    """(name, in, out) of every Dense layer in Keras creation order (= `model.get_weights()` order,
+    each contributing kernel[in,out] then bias[out]).  model.py:104-123 (ParamNerf), 28-43 (Nerf)."""
+    rows = []
+    k = spec.pos_map_dim
+    for i in range(spec.depth):
+        rows.append((f"trunk{i}", k, spec.width))
+        k = spec.width + (spec.pos_map_dim if i in spec.skips else 0)
+    rows.append(("alpha", k, 1))
+    rows.append(("feature", k, spec.width))
+    k = spec.width + spec.dir_map_dim
+    if spec.kind == "ParamNerf":
+        for i in range(spec.color_depth):
+            rows.append((f"color_hidden{i}", k, spec.width))
+            k = spec.width
+    rows.append(("color_half", k, spec.width // 2))
+    rows.append(("color", spec.width // 2, 3))
+    return rows
+
+
+def macs_per_sample(spec: ModelSpec) -> int:
+    return sum(i * o for _, i, o in layer_table(spec))
+
+
+def n_weight_floats(spec: ModelSpec) -> int:
+    return sum(i * o + o for _, i, o in layer_table(spec))
+
+
+def split_blob(spec: ModelSpec, blob: np.ndarray) -> List[np.ndarray]:
+    """Flat float32 blob (kernel, bias, kernel, bias, ... in `layer_table` order) -> list of arrays."""
+    out, p = [], 0
+    for _, i, o in layer_table(spec):
+        out.append(blob[p:p + i * o].reshape(i, o)); p += i * o
+        out.append(blob[p:p + o]); p += o
+    assert p == blob.size, (p, blob.size)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Camera / ray generation
+# --------------------------------------------------------------------------------------
+def full_pixels(height: int, width: int) -> np.ndarray:
+    """pixel_sampler.Full.__call__  (pixel_sampler.py:14-15): all pixels, row-major (row i, col j)."""
+    k = np.arange(height * width, dtype=np.int32)
+    return np.stack([k // width, k % width], -1)
+
+
+def focal_from_angle(width: int, angle: float) -> float:
+    """dataset.GenerateData return value (dataset.py:229): width / tan(angle / 2) / 2 (python float)."""
+    return width / tan(angle / 2) / 2
+
+
+def _normalize(v):
+    return v / np.sqrt(np.sum(v * v))
+
+
+def look_at(pos, to=(0., 0., 0.), offset=(0., 0., 0.), eps=1e-6, dtype=F32) -> np.ndarray:
+    """dataset.look_at (dataset.py:231-238).  `pos` arrives as float64 numpy from the pose
+    distribution; `pos - to + eps` with `to` a float32 tf.constant makes TF convert `pos` to
+    float32, so the whole function runs in float32 in the reference; dtype=F64 gives the truth."""
+    pos = np.asarray(pos, dtype=dtype)
+    to = np.asarray(to, dtype=dtype)
+    offset = np.asarray(offset, dtype=dtype)
+    e = dtype(eps)
+    v_forward = _normalize(pos - to + e)
+    v_right = _normalize(np.cross(np.asarray([0, 0, 1.], dtype=dtype), v_forward) + e)
+    v_up = _normalize(np.cross(v_forward, v_right) + e)
+    top = np.stack([v_right, v_up, v_forward, pos + offset], axis=1)          # [3,4]
+    return np.concatenate([top, np.asarray([[0, 0, 0, 1.]], dtype=dtype)], axis=0)
+
+
+def rays_from_camera(image_plane_loc, height: int, width: int, focal: float, c2w, dtype=F32):
+    """ray_sampler.rays_from_camera (ray_sampler.py:39-48)."""
+    loc = np.asarray(image_plane_loc).astype(dtype)
+    c2w = np.asarray(c2w, dtype=dtype)
+    f = dtype(focal)
+    half_w = dtype(.5 * width)          # `.5 * width` is python arithmetic, then cast
+    half_h = dtype(.5 * height)
+    dirs = np.stack([(loc[:, 1] + dtype(.5) - half_w) / f,
+                     -(loc[:, 0] + dtype(.5) - half_h) / f,
+                     -np.ones(loc.shape[0], dtype=dtype)], -1)
+    rays_d = np.sum(dirs[:, None, :] * c2w[:3, :3], -1)
+    rays_o = np.broadcast_to(c2w[:3, -1], rays_d.shape).copy()
+    norm_xy = np.sqrt(np.sum(dirs[:, :2] * dirs[:, :2], -1))
+    norm = np.sqrt(np.sum(dirs * dirs, -1))
+    cone_scale = np.cos(np.arctan(norm_xy)) / norm / f
+    return rays_o, rays_d, cone_scale[:, None]
+
+
+def aabb(rays_o, rays_d, b_0, b_1, dtype=F32):
+    """proxy.AABB.__call__ (proxy.py:13-35): slab test, [inf, inf] on a miss.  1/0 -> +-inf and
+    0*inf -> NaN follow IEEE exactly as in the reference (no special-casing)."""
+    o = np.asarray(rays_o, dtype=dtype)
+    d = np.asarray(rays_d, dtype=dtype)
+    b_0 = np.asarray(b_0, dtype=dtype)
+    b_1 = np.asarray(b_1, dtype=dtype)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = dtype(1.) / d
+        t_0 = (b_0 - o) * inv
+        t_1 = (b_1 - o) * inv
+        t_0_tmp = t_0
+        t_0 = np.where(t_0 < t_1, t_0, t_1)
+        t_1 = np.where(t_0_tmp > t_1, t_0_tmp, t_1)
+        # tf.reduce_max / reduce_min propagate NaN like numpy's max/min
+        t_0 = np.max(t_0, axis=1)
+        t_1 = np.min(t_1, axis=1)
+        t_0_tmp = t_0
+        inf = dtype(np.inf)
+        t_0 = np.where(t_0 < t_1, t_0, inf)
+        t_1 = np.where(t_0_tmp < t_1, t_1, inf)
+    return np.stack([t_0, t_1], -1).astype(dtype)
+
+
+def proxy_rays(image_plane_loc, height, width, focal, c2w, b_0, b_1, dtype=F32):
+    """ray_sampler.Proxy.__call__ (ray_sampler.py:32-37): normalise rays_d, then AABB t-range."""
+    rays_o, rays_d, cone_scale = rays_from_camera(image_plane_loc, height, width, focal, c2w, dtype)
+    rays_d = rays_d / np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True))
+    t = aabb(rays_o, rays_d, b_0, b_1, dtype)
+    return rays_o, rays_d, t, cone_scale
+
+
+def frustum_rays(image_plane_loc, height, width, focal, c2w, near, far, dtype=F32):
+    """ray_sampler.Frustum.__call__ (ray_sampler.py:15-21): un-normalised rays_d, constant t."""
+    rays_o, rays_d, cone_scale = rays_from_camera(image_plane_loc, height, width, focal, c2w, dtype)
+    n = rays_o.shape[0]
+    t = np.stack([np.full(n, near, dtype=dtype), np.full(n, far, dtype=dtype)], -1)
+    return rays_o, rays_d, t, cone_scale
+
+
+# --------------------------------------------------------------------------------------
+# Model
+# --------------------------------------------------------------------------------------
+def fourier_features(x, n_freq_bands: int, dtype=F32):
+    """layer.FourierFeatures.call (layer.py:8-23): [x | sin(2^0 x) | cos(2^0 x) | sin(2^1 x) | ...],
+    every block the full D-vector; `freq * x` is rounded in the tensor dtype before sin/cos."""
+    x = np.asarray(x, dtype=dtype)
+    out = [x]
+    for k in range(n_freq_bands):
+        freq = dtype(2.0 ** k)
+        out.append(np.sin(freq * x))
+        out.append(np.cos(freq * x))
+    return np.concatenate(out, -1)
+
+
+def _dense(x, kernel, bias, dtype, relu):
+    y = x @ np.asarray(kernel, dtype=dtype) + np.asarray(bias, dtype=dtype)
+    return np.maximum(y, dtype(0)) if relu else y
+
+
+def model_forward(weights: Sequence[np.ndarray], spec: ModelSpec, pos, dirs, params, dtype=F32,
+                  return_intermediates: bool = False):
+    """network.model.ParamNerf (model.py:58-125) / Nerf (model.py:9-45) forward on rank-2 inputs.
+    weights = [k0, b0, k1, b1, ...] in `layer_table(spec)` order.  Returns (color[M,3], alpha[M,1])."""
+    pos = np.asarray(pos, dtype=dtype)
+    dirs = np.asarray(dirs, dtype=dtype)
+    params = np.asarray(params, dtype=dtype).reshape(pos.shape[0], -1)
+    g, a = spec.n_geo, spec.n_app
+    inter = {}
+
+    pos_map = fourier_features(pos, spec.pos_freq, dtype)                       # model.py:77
+    dir_map = fourier_features(dirs, spec.dir_freq, dtype)                      # model.py:78
+    if g > 0:                                                                  # model.py:88-93
+        pos_map = np.concatenate([pos_map, fourier_features(params[:, :g], spec.param_freq, dtype)], -1)
+    if a > 0:                                                                  # model.py:96-101
+        dir_map = np.concatenate([dir_map, fourier_features(params[:, g:g + a], spec.param_freq, dtype)], -1)
+    inter["pos_map"], inter["dir_map"] = pos_map, dir_map
+
+    w = list(weights)
+    it = iter(range(0, len(w), 2))
+    h = pos_map
+    for i in range(spec.depth):                                                # model.py:104-108
+        j = next(it)
+        h = _dense(h, w[j], w[j + 1], dtype, relu=True)
+        inter[f"trunk{i}"] = h
+        if i in spec.skips:
+            h = np.concatenate([pos_map, h], -1)
+    j = next(it)
+    alpha = _dense(h, w[j], w[j + 1], dtype, relu=False)                       # model.py:111
+    j = next(it)
+    h = _dense(h, w[j], w[j + 1], dtype, relu=False)                           # model.py:114
+    inter["feature"] = h
+    h = np.concatenate([dir_map, h], -1)                                       # model.py:115
+    if spec.kind == "ParamNerf":
+        for i in range(spec.color_depth):                                      # model.py:118-119
+            j = next(it)
+            h = _dense(h, w[j], w[j + 1], dtype, relu=True)
+            inter[f"color_hidden{i}"] = h
+    j = next(it)
+    h = _dense(h, w[j], w[j + 1], dtype, relu=True)                            # model.py:122
+    inter["color_half"] = h
+    j = next(it)
+    color = _dense(h, w[j], w[j + 1], dtype, relu=False)                       # model.py:123
+    if return_intermediates:
+        return color, alpha, inter
+    return color, alpha
+
+
+# --------------------------------------------------------------------------------------
+# Renderer
+# --------------------------------------------------------------------------------------
+def linspace_tf(n: int, dtype=F32):
+    """tf.linspace(0., 1., n) as TF 2.4 evaluates it (see module docstring)."""
+    if n == 1:
+        return np.zeros(1, dtype=dtype)
+    delta = (dtype(1.) - dtype(0.)) / dtype(n - 1)
+    inner = dtype(0.) + delta * np.arange(1, n - 1).astype(dtype)
+    return np.concatenate([np.zeros(1, dtype), inner.astype(dtype), np.ones(1, dtype)])
+
+
+def z_values(t, n_samples: int, dtype=F32):
+    """renderer.py:101-103 (no jitter)."""
+    t = np.asarray(t, dtype=dtype)
+    t_vals = linspace_tf(n_samples, dtype)
+    return t[:, None, 0] * (dtype(1) - t_vals) + t[:, None, 1] * t_vals
+
+
+def jitter_bounds(z_vals):
+    """renderer.py:107-109: the [lower, upper] interval a perturbed sample is drawn from;
+    z = lower + (upper - lower) * U[0,1) (renderer.py:110-111)."""
+    mids = z_vals.dtype.type(.5) * (z_vals[..., 1:] + z_vals[..., :-1])
+    upper = np.concatenate([mids, z_vals[..., -1:]], -1)
+    lower = np.concatenate([z_vals[..., :1], mids], -1)
+    return lower, upper
+
+
+def evaluate_model(weights, spec, pts, dirs, parameters, cone_scale, z_vals, blur_idx, net_chunk, dtype=F32):
+    """Renderer.evaluate_model (renderer.py:145-168)."""
+    n, S = pts.shape[0], pts.shape[1]
+    pos_flat = pts.reshape(-1, pts.shape[-1])
+    dirs_flat = np.repeat(dirs, S, axis=0)
+    params_flat = np.repeat(parameters, S, axis=0)
+    if blur_idx is not None:                                                   # renderer.py:155-158
+        blur_scale = cone_scale[..., None, :] * z_vals[..., :, None]
+        blur_scale_flat = blur_scale.reshape(-1, 1)
+        params_flat = np.concatenate([params_flat[:, :blur_idx],
+                                      params_flat[:, blur_idx, None] * blur_scale_flat,
+                                      params_flat[:, blur_idx + 1:]], -1)
+    color, alpha = [], []
+    for i in range(0, pos_flat.shape[0], net_chunk):                           # renderer.py:160-163
+        c, a = model_forward(weights, spec, pos_flat[i:i + net_chunk], dirs_flat[i:i + net_chunk],
+                             params_flat[i:i + net_chunk], dtype)
+        color.append(c); alpha.append(a)
+    color = np.concatenate(color, 0); alpha = np.concatenate(alpha, 0)
+    return color.reshape(n, S, 3), alpha.reshape(n, S)
+
+
+def map_model_output(color, alpha, z_vals, rays_d, composite_bkgd, bkgd_color, map_exr=False,
+                     noise=None, dtype=F32):
+    """Renderer.map_model_output (renderer.py:170-213).  `noise` = the N(0, raw_noise_std) draw
+    (renderer.py:190-192) supplied by the caller, or None."""
+    color = np.asarray(color, dtype=dtype); alpha = np.asarray(alpha, dtype=dtype)
+    z_vals = np.asarray(z_vals, dtype=dtype); rays_d = np.asarray(rays_d, dtype=dtype)
+    dists = z_vals[..., 1:] - z_vals[..., :-1]                                  # :174
+    dists = np.concatenate([dists, dists[..., -1:]], -1)                        # :177 (copy, not 1e10)
+    dists = dists * np.sqrt(np.sum(rays_d[..., None, :] ** 2, -1))              # :180
+    if map_exr:                                                                 # :182-187
+        with np.errstate(over="ignore"):
+            color_map = np.where(color > 0, color, np.exp(np.minimum(color, dtype(0))) - dtype(1)) + dtype(1)
+    else:
+        with np.errstate(over="ignore"):
+            color_map = dtype(1) / (dtype(1) + np.exp(-color))
+    if noise is not None:
+        alpha = alpha + np.asarray(noise, dtype=dtype)
+    alpha_map = dtype(1) - np.exp(-np.maximum(alpha, dtype(0)) * dists)         # :195
+    trans = (dtype(1.) - alpha_map) + dtype(1e-10)                              # `1.-alpha_map + 1e-10`
+    cum = np.cumprod(trans, axis=-1, dtype=dtype)
+    excl = np.concatenate([np.ones_like(cum[..., :1]), cum[..., :-1]], -1)      # exclusive=True
+    weights = alpha_map * excl                                                  # :198
+    color_out = np.sum(weights[..., None] * color_map, axis=-2, dtype=dtype)    # :201
+    depth = np.sum(weights * z_vals, axis=-1, dtype=dtype)                      # :204 (not returned)
+    alpha_out = np.sum(weights, -1, dtype=dtype)                                # :207
+    if composite_bkgd:                                                          # :210-211
+        color_out = color_out + (dtype(1.) - alpha_out[..., None]) * np.asarray(bkgd_color, dtype=dtype)
+    return color_out.astype(dtype), alpha_out.astype(dtype), weights.astype(dtype), depth
+
+
+def render_rays(weights, spec, rays_o, rays_d, t, parameters, cone_scale, n_samples, composite_bkgd,
+                bkgd_color, blur_idx=None, map_exr=False, net_chunk=65536, z_override=None, dtype=F32,
+                return_aux=False):
+    """Renderer.render_rays (renderer.py:92-143) with perturb=False, raw_noise_std=0, n_importance=0
+    (TF's RNG stream cannot be reproduced).  `z_override` [n,S] replaces z_vals, standing in for
+    the jittered samples of renderer.py:106-111 when the caller draws them itself."""
+    rays_o = np.asarray(rays_o, dtype=dtype); rays_d = np.asarray(rays_d, dtype=dtype)
+    t = np.asarray(t, dtype=dtype); parameters = np.asarray(parameters, dtype=dtype)
+    cone_scale = np.asarray(cone_scale, dtype=dtype)
+    rays_d_n = rays_d / np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True))     # :98
+    z_vals = z_values(t, n_samples, dtype) if z_override is None else np.asarray(z_override, dtype=dtype)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]    # :114 (un-normalised d)
+    color, alpha = evaluate_model(weights, spec, pts, rays_d_n, parameters, cone_scale, z_vals,
+                                  blur_idx, net_chunk, dtype)
+    color_map, alpha_map, w, _ = map_model_output(color, alpha, z_vals, rays_d, composite_bkgd,
+                                                  bkgd_color, map_exr, None, dtype)
+    out = {"color_pred": color_map, "alpha_pred": alpha_map}
+    if return_aux:
+        out.update({"z_vals": z_vals, "pts": pts, "raw_color": color, "raw_alpha": alpha, "weights": w})
+    return out
+
+
+def renderer_call(weights, spec, rays_o, rays_d, t, parameters, cone_scale, n_samples=64,
+                  composite_bkgd=False, bkgd_color=(1., 1., 1.), blur_idx=None, map_exr=False,
+                  render_chunk=32768, net_chunk=65536, dtype=F32):
+    """Renderer.__call__ (renderer.py:47-90): inputs are batched [B, HW, ...], `parameters` [B, P]."""
+    rays_o = np.asarray(rays_o, dtype=dtype); rays_d = np.asarray(rays_d, dtype=dtype)
+    t = np.asarray(t, dtype=dtype); parameters = np.asarray(parameters, dtype=dtype)
+    cone_scale = np.asarray(cone_scale, dtype=dtype)
+    B, HW = rays_o.shape[0], rays_o.shape[1]
+    o_f = rays_o.reshape(-1, 3); d_f = rays_d.reshape(-1, 3); t_f = t.reshape(-1, 2)
+    p_f = np.repeat(parameters, HW, axis=0)                                     # :54
+    c_f = cone_scale.reshape(-1, cone_scale.shape[-1])
+    hit = t_f[:, 0] != np.inf                                                   # :58 (NaN counts as hit)
+    idxs = np.nonzero(hit)[0]
+    outs = {}
+    for i in range(0, idxs.shape[0], render_chunk):                             # :72-77
+        sl = idxs[i:i + render_chunk]
+        o = render_rays(weights, spec, o_f[sl], d_f[sl], t_f[sl], p_f[sl], c_f[sl], n_samples,
+                        composite_bkgd, bkgd_color, blur_idx, map_exr, net_chunk, None, dtype)
+        for k, v in o.items():
+            outs.setdefault(k, []).append(v)
+    result = {}
+    keys = outs.keys() if outs else ("color_pred", "alpha_pred")
+    for k in keys:
+        tail = (3,) if "color" in k else ()
+        full = np.zeros((B * HW,) + tail, dtype=dtype)                          # scatter_nd zeros :83
+        if outs:
+            full[idxs] = np.concatenate(outs[k], 0)
+        if composite_bkgd and "color" in k:                                     # :85-86
+            full[~hit] += np.asarray(bkgd_color, dtype=dtype)
+        result[k] = full.reshape((B, HW) + tail)                                # :87
+    return result
+
+
+def render_image_rgba(pred, height, width):
+    """logger.Logger.render_image packing only (logger.py:126): [H, W, 4] premultiplied RGBA."""
+    return np.concatenate([pred["color_pred"].reshape(-1, 3), pred["alpha_pred"].reshape(-1, 1)], -1) \
+             .reshape(height, width, 4)
+
+
+def rel_linf(out, ref) -> float:
+    """The parity metric of BASELINE.json: max|out - ref| / max|ref|."""
+    out = np.asarray(out, dtype=F64); ref = np.asarray(ref, dtype=F64)
+    denom = float(np.max(np.abs(ref)))
+    return float(np.max(np.abs(out - ref))) / (denom if denom > 0 else 1.0)

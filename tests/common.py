@@ -1,0 +1,43 @@
+"""Shared helpers of the test-suite: seeded inputs for both sides, spec conversion."""
+
+import numpy as np
+
+from oracle import nerftex_oracle as orc
+from nerf_tex_amd import synthetic
+from nerf_tex_amd.model import ParamNerf, Nerf
+
+EMB = lambda n: {"module": "network.model.FourierFeatures", "n_freq_bands": n}   # as in the reference configs
+
+TOL = 1e-4   # BASELINE.json north_star: <= 1e-4 relative L-inf (float32) vs the reference render
+
+
+def make_model(n_parameters=(1, 6), kind="ParamNerf", seed=0, dense_media=False):
+    """(product model with synthetic weights, oracle spec, oracle weight list)"""
+    if kind == "Nerf":
+        model = Nerf(EMB(10), EMB(4))["model"]
+        spec = orc.ModelSpec(kind="Nerf", n_parameters=(0, 0))
+    else:
+        model = ParamNerf(EMB(10), EMB(4), EMB(4), list(n_parameters))["model"]
+        spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(n_parameters))
+    assert model.layer_table() == orc.layer_table(spec)
+    blob = synthetic.synthetic_weights(model.layer_table(), seed=seed, dense_media=dense_media)
+    model.set_blob(blob)
+    return model, spec, orc.split_blob(spec, blob)
+
+
+def random_samples(m, n_params, seed=3, box=1.5):
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-box, box, size=(m, 3)).astype(np.float32)
+    d = rng.normal(size=(m, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    params = rng.uniform(0, 1, size=(m, max(n_params, 0))).astype(np.float32)
+    return pos, d.astype(np.float32), params
+
+
+def camera_rays(family, height, width, dtype=np.float32, angle_scale=2.5):
+    """The camera grid of a BASELINE config family; the field of view is widened by `angle_scale`
+    so that the grid holds rays that miss the AABB as well as rays that hit it."""
+    fam = synthetic.FAMILIES[family]
+    c2w = orc.look_at(fam["cam"], dtype=np.float32)
+    focal = orc.focal_from_angle(width, fam["angle"] * angle_scale)
+    loc = orc.full_pixels(height, width)
+    return orc.proxy_rays(loc, height, width, focal, c2w, fam["b_0"], fam["b_1"], dtype), c2w, focal
