@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Throughput of the NeRF-Tex render path on MI355X (BASELINE.json metric: ray-samples/sec through
+PE + MLP + composite at 800x800x64).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload carpet|grass|fur|grass_filtered]
+
+One step = one pass of the fused HIP render kernel over one 800x800 image worth of synthetic
+all-hit rays (640 000 rays x 64 samples = 40.96 M ray-samples), inputs
+already resident in HBM, followed (N > 1) by the one gather of the finished RGBA to rank 0.  With
+N > 1 each rank renders its own 800x800 band of an (800 N) x 800 image (weak scaling, one process per
+GPU, launched by torch.distributed.run); `value` is the whole-job aggregate.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant (only) kernel: algorithmic FLOPs =
+2 * MACs(model) per ray-sample / average launch duration measured with HIP
+events on the launch stream.  `cpu_baseline` times the float32 numpy restatement in oracle/ on a
+bounded sample of the same workload on this host's cores (rank 0, N = 1 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+WORKLOADS = {   # name -> (family, H, W, samples per ray)
+    "carpet": ("carpet", 800, 800, 64),             # BASELINE configs[1] -- the metric's configuration
+    "grass": ("grass", 800, 800, 128),              # configs[2]
+    "fur": ("fur", 800, 800, 64),                   # configs[3] per-GPU share when sharded
+    "grass_filtered": ("grass_filtered", 800, 800, 128),
+}
+
+
+def cpu_baseline(family: str, n_samples: int, target_seconds: float = 12.0):
+    """float32 oracle (numpy + BLAS threads) on a bounded number of rays of the same workload."""
+    from oracle import nerftex_oracle as orc
+    from nerf_tex_amd import synthetic
+    fam = synthetic.FAMILIES[family]
+    spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(fam["n_parameters"]))
+    w = orc.split_blob(spec, synthetic.synthetic_weights(orc.layer_table(spec), seed=0))
+    params = np.asarray([fam["params"]], np.float32)
+
+    def run(n_rays):
+        ro, rd, t, cone = synthetic.all_hit_rays(n_rays, fam["b_0"], fam["b_1"], fam["cam"])
+        t0 = time.perf_counter()
+        orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], n_samples, False, (1, 1, 1.),
+                          fam["blur_idx"], False, render_chunk=32768, net_chunk=65536, dtype=np.float32)
+        return time.perf_counter() - t0
+
+    run(256)                                   # warm BLAS
+    n = 2048
+    dt = run(n)
+    rate = n * n_samples / dt
+    n2 = int(min(32768, max(n, rate * target_seconds / n_samples)))   # at most one reference render_chunk
+    if n2 > n:
+        dt = run(n2); n = n2
+    try:
+        import threadpoolctl
+        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": n * n_samples / dt, "unit": "ray-samples/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} rays x {n_samples} samples of the same workload, float32 numpy restatement (oracle/), "
+                      f"reference chunking 32768/65536, {dt:.2f} s, host has {os.cpu_count()} logical cpus"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.dist import gather_image
+    from nerf_tex_amd.model import ParamNerf
+    from nerf_tex_amd.renderer import Renderer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)       # nccl backend == RCCL on ROCm
+
+    family, H, W, S = WORKLOADS[args.workload]
+    fam = synthetic.FAMILIES[family]
+    emb = lambda n: {"module": "network.model.FourierFeatures", "n_freq_bands": n}
+    model = ParamNerf(emb(10), emb(4), emb(4), list(fam["n_parameters"]))["model"]
+    model.set_blob(synthetic.synthetic_weights(model.layer_table(), seed=0))
+    renderer = Renderer(model=model, n_samples=S, perturb=False, blur_idx=fam["blur_idx"], check_numerics=False)
+
+    n_rays = H * W                                           # per GPU (weak scaling)
+    ro, rd, t, cone = synthetic.all_hit_rays(n_rays, fam["b_0"], fam["b_1"], fam["cam"], seed=1 + rank)
+    d = lambda a: torch.as_tensor(a, device=dev)[None]
+    batch = dict(rays_o=d(ro), rays_d=d(rd), t=d(t), cone_scale=d(cone),
+                 parameters=torch.as_tensor(np.asarray([fam["params"]], np.float32), device=dev))
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev0[i].record()
+        out = renderer(**batch)
+        if i is not None:
+            ev1[i].record()                                  # same stream the kernel was launched on
+        rgba = torch.cat([out["color_pred"][0], out["alpha_pred"][0][:, None]], -1)
+        if world > 1:
+            return gather_image(rgba, n_rays * world)        # the one collective: RGBA -> rank 0
+        return rgba
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        img = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+    if rank == 0:
+        samples_per_step = n_rays * S * world
+        flops_per_sample = 2 * model.macs_per_sample()
+        achieved = n_rays * S * flops_per_sample / (kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "ray-samples/sec (MLP+composite) at 800x800x64",
+            "value": samples_per_step * args.steps / elapsed,
+            "unit": "ray-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} {H}x{W}x{S}: {n_rays} all-hit rays x {S} samples per GPU "
+                                   f"(BASELINE configs[{ {'carpet': 1, 'grass': 2, 'fur': 3, 'grass_filtered': 4}[args.workload] }]), "
+                                   f"ParamNerf n_parameters={list(fam['n_parameters'])}, seeded glorot weights, "
+                                   f"inputs resident in HBM, fused PE+MLP+composite"
+                                   + (", + gather of RGBA to rank 0" if world > 1 else ""),
+                       "rays_per_gpu": n_rays, "samples_per_ray": S, "flops_per_sample": flops_per_sample},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "ntx::render_kernel", "kernel_ms": kernel_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(family, S)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
