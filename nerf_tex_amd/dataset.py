@@ -54,6 +54,15 @@ def GenerateData(height: int = 256, width: int = 256, angle: float = .7,
     return data, height, width, width / tan(angle / 2) / 2, composite_bkgd, bkgd_color
 
 
+def FromViews(views: list, height: int = 256, width: int = 256, angle: float = .7, composite_bkgd: bool = False,
+              bkgd_color=[1, 1, 1.]):
+    """Data loader with explicit views (`[{'pose': c2w 4x4, 'parameters': [...]}, ...]`): same return tuple
+    as GenerateData (dataset.py:229) without the pose/parameter distributions, which stay the reference's."""
+    data = [{"pose": np.asarray(v["pose"], dtype=np.float32), "parameters": np.asarray(v["parameters"], dtype=np.float32)}
+            for v in views]
+    return data, height, width, width / tan(angle / 2) / 2, composite_bkgd, bkgd_color
+
+
 class Dataset:
     """dataset.Dataset (dataset.py:10-75) for ray-only datasets: iterating yields one batch dict per
     `batchsize` views.  Attributes `height/width/focal/composite_bkgd/bkgd_color/n_samples/n_parameters`

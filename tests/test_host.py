@@ -1,0 +1,168 @@
+"""CPU tests of the host side: plugin mechanism, model container, the C ABI's exported symbols and
+the host-only weight packer, ray sharding and the world_size-2 gather (gloo)."""
+
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from nerf_tex_amd import _lib
+    header = open(os.path.join(ROOT, "include", "nerftex.h")).read()
+    declared = set(re.findall(r"\b(ntx_[a-z_]+)\s*\(", header))
+    declared -= {"ntx_ctx", "ntx_stream"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert _lib.lib.ntx_abi_version() == 1
+
+
+def test_create_without_gpu_reports_no_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this is the CPU-container check")
+    from nerf_tex_amd import _lib
+    d = _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1)
+    h = C.c_void_p()
+    rc = _lib.lib.ntx_create(C.byref(d), None, 0, 0, C.byref(h))
+    assert rc in (_lib.NTX_E_NODEVICE, _lib.NTX_E_HIP) and _lib.lib.ntx_last_error()
+
+
+def test_unsupported_desc_is_rejected_on_host():
+    from nerf_tex_amd import _lib
+    for bad in (_lib.ModelDesc(0, 3, 3, 3, 10, 4, 4, 8, 256, 4, 1), _lib.ModelDesc(0, 1, 6, 3, 8, 4, 4, 8, 256, 4, 1),
+                _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 6, 256, 4, 1), _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 128, 4, 1)):
+        assert _lib.lib.ntx_weight_count(C.byref(bad)) == 0
+        assert b"unsupported" in _lib.lib.ntx_last_error()
+
+
+@pytest.mark.parametrize("desc,count", [((0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1), 683524), ((0, 1, 4, 3, 10, 4, 4, 8, 256, 4, 1), 678916),
+                                        ((0, 2, 3, 3, 10, 4, 4, 8, 256, 4, 1), 681220), ((1, 0, 0, 3, 10, 4, 0, 8, 256, 4, 0), 593408 + 8 * 256 + 1 + 256 + 128 + 3)])
+def test_pack_weights_is_a_permutation_with_wraparound_tail(desc, count):
+    """Host-only packer: every reference weight lands in the stream exactly once (rest is zero pad),
+    the tail repeats the first 8 records, biases/heads land in the aux block."""
+    from nerf_tex_amd import _lib
+    d = _lib.ModelDesc(*desc)
+    n = _lib.lib.ntx_weight_count(C.byref(d))
+    assert n == count
+    npk = _lib.lib.ntx_packed_count(C.byref(d))
+    rng = np.random.default_rng(0)
+    blob = (rng.permutation(n) + 1).astype(np.float32)            # distinct, non-zero, exactly representable
+    out = np.empty(npk, np.float32)
+    fp = C.POINTER(C.c_float)
+    assert _lib.lib.ntx_pack_weights(C.byref(d), blob.ctypes.data_as(fp), n, out.ctypes.data_as(fp), npk) == 0
+    aux_floats = 3776                                             # ntx_layout.h aux_total(): 12*256 bias + 260 alpha + 388 rgb, rounded to 64
+    stream = out[:npk - aux_floats]
+    head, tail = stream[:8 * 256], stream[-8 * 256:]
+    np.testing.assert_array_equal(head, tail)
+    body = stream[:-8 * 256]
+    vals = np.concatenate([body[body != 0], out[npk - aux_floats:][out[npk - aux_floats:] != 0]])
+    assert vals.size == n and np.array_equal(np.sort(vals), np.sort(blob))
+    assert _lib.lib.ntx_pack_weights(C.byref(d), blob.ctypes.data_as(fp), n - 1, out.ctypes.data_as(fp), npk) == _lib.NTX_E_INVALID
+
+
+def test_instantiate_and_reference_config_remap():
+    from nerf_tex_amd import util
+    cfg = {"module": "network.model.ParamNerf",
+           "pos_embedding": {"module": "network.model.FourierFeatures", "n_freq_bands": 10},
+           "dir_embedding": {"module": "network.model.FourierFeatures", "n_freq_bands": 4},
+           "param_embedding": {"module": "network.model.FourierFeatures", "n_freq_bands": 4},
+           "n_parameters": [1, 6]}
+    mapped = util.remap_reference_config(cfg)
+    assert mapped.module == "nerf_tex_amd.model.ParamNerf" and cfg["module"] == "network.model.ParamNerf"
+    assert mapped.pos_embedding.module == "nerf_tex_amd.layer.FourierFeatures"
+    np.random.seed(0)
+    model = util.instantiate(mapped)
+    assert list(model) == ["model"]
+    m = model["model"]
+    assert m.pos_map_dim == 72 and m.dir_map_dim == 81 and m.macs_per_sample() == 680832
+    assert util.instantiate(None) is None
+    ws = m.get_weights()
+    assert len(ws) == 26 and ws[0].shape == (72, 256) and ws[10].shape == (328, 256) and ws[16].shape == (256, 1)
+    assert np.all(ws[1] == 0) and abs(float(ws[0].max())) <= np.sqrt(6 / (72 + 256))      # glorot_uniform / zeros
+    ws[3] = ws[3] + 1
+    m.set_weights(ws)
+    np.testing.assert_array_equal(m.get_weights()[3], ws[3])
+    with pytest.raises(ValueError):
+        m.set_weights(ws[:-1])
+
+
+def test_reference_render_config_runs_through_remap():
+    """A reference config file (if the reference tree is present) maps onto this package's modules."""
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree only exists in the build container")
+    sys.path.insert(0, ref)
+    try:
+        import importlib
+        cfg = importlib.import_module("configs.config_carpet_render").config
+    finally:
+        sys.path.remove(ref)
+    from nerf_tex_amd import util
+    m = util.remap_reference_config(cfg)
+    assert m.module == "nerf_tex_amd.render.Render"
+    assert m.test_dataset_config.module == "nerf_tex_amd.dataset.Dataset"
+    assert m.test_dataset_config.proxy_config.module == "nerf_tex_amd.proxy.AABB"
+    assert m.renderer_config.module == "network.renderer.InstanceRenderer"      # out of scope: left untouched
+
+
+def test_renderer_kwargs_mirror_reference():
+    import inspect
+    from nerf_tex_amd.renderer import Renderer
+    sig = inspect.signature(Renderer.__init__)
+    for k, dflt in [("model_fine", None), ("n_samples", 64), ("n_importance", 0), ("perturb", True), ("raw_noise_std", 0),
+                    ("render_chunk", 32768), ("net_chunk", 65536), ("downsampling_factor", 1), ("blur_idx", None), ("map_exr", False)]:
+        assert sig.parameters[k].default == dflt                               # renderer.py:34
+    call = inspect.signature(Renderer.__call__)
+    assert list(call.parameters)[1:6] == ["rays_o", "rays_d", "t", "parameters", "cone_scale"]   # renderer.py:47
+    assert call.parameters["composite_bkgd"].default is False and call.parameters["training"].default is True
+    with pytest.raises(NotImplementedError):
+        Renderer(model=None, n_importance=64)
+
+
+def test_shard_range_partitions():
+    from nerf_tex_amd.dist import shard_range
+    for n in (0, 1, 7, 640000, 640001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (f0, c0), (f1, _) in zip(spans[:-1], spans[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def _gather_worker(rank, world, port, n_total, q):
+    import torch
+    import torch.distributed as dist
+    from nerf_tex_amd.dist import gather_image, shard_range
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = shard_range(n_total, rank, world)
+    full = torch.arange(n_total * 4, dtype=torch.float32).reshape(n_total, 4)
+    img = gather_image(full[first:first + count].clone(), n_total)
+    ok = (img is None) if rank != 0 else bool(torch.equal(img, full))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [64, 101])
+def test_gather_image_world2_gloo(n_total):
+    """N > 1 path on CPU: contiguous shards, one gather, image on rank 0 equals the unsharded one."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in procs)
+    [p.join(60) for p in procs]
+    assert res == [(0, True), (1, True)]

@@ -1,0 +1,201 @@
+"""CPU tests of the oracle itself: against the committed goldens (drift pin), numpy vs the independent
+C restatement, float32 vs float64, and properties of the reference's math."""
+
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from oracle import c_oracle, nerftex_oracle as orc
+from nerf_tex_amd import synthetic
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+FAMILIES = ["carpet", "grass", "fur", "grass_filtered"]
+
+
+def load(family):
+    g = np.load(os.path.join(G, f"golden_{family}.npz"))
+    spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(int(v) for v in g["n_parameters"]))
+    blob = synthetic.synthetic_weights(orc.layer_table(spec), seed=int(g["weights_seed"]), dense_media=bool(g["weights_dense_media"]))
+    assert hashlib.sha256(blob.tobytes()).hexdigest() == str(g["weights_sha256"]), "seeded weights drifted"
+    return g, spec, blob, orc.split_blob(spec, blob)
+
+
+def test_macs_and_weight_counts_match_survey():
+    # MACs / sample and bias counts per config family
+    for npar, macs in [((1, 6), 680832), ((1, 4), 676224), ((2, 3), 678528)]:
+        spec = orc.ModelSpec(n_parameters=npar)
+        assert orc.macs_per_sample(spec) == macs
+        assert orc.n_weight_floats(spec) == macs + 2692
+    assert orc.macs_per_sample(orc.ModelSpec(kind="Nerf")) == 593408
+
+
+def test_camera_fixtures_from_reference_modules():
+    """The poses/params the reference's own TF-free code emitted (gen_golden.py part 1)."""
+    cam = json.load(open(os.path.join(G, "cameras_carpet.json")))
+    p = np.asarray([v["pose_dist_sample"] for v in cam["views"]])
+    assert p.shape == (5, 3)
+    np.testing.assert_allclose(p[:, 2], 0.4, atol=1e-12)                 # latitude u = .3 -> z = 1 - 2u
+    np.testing.assert_allclose(np.linalg.norm(p, axis=1), 1.0, atol=1e-12)
+    np.testing.assert_allclose(p[0], [0.9165151389911681, 0.0, 0.4], atol=1e-12)
+    np.testing.assert_allclose(p[1], [0.2832, 0.8717, 0.4], atol=1e-4)   # values recorded in SURVEY.md 8c
+    assert cam["views"][0]["parameters"] == [1, 1, 1, .1, 0, 0, 1]
+    assert cam["views"][0]["radius"] == 6.0
+    # look_at restatement: orthonormal right-handed frame looking at the origin
+    c2w = np.asarray(cam["views"][1]["c2w_oracle_look_at_f32"])
+    R = c2w[:3, :3]
+    np.testing.assert_allclose(R.T @ R, np.eye(3), atol=1e-5)
+    np.testing.assert_allclose(c2w[:3, 3], p[1] * 6.0, atol=1e-6)
+    np.testing.assert_allclose(R[:, 2], p[1], atol=1e-5)                 # forward = normalised position
+
+
+def test_product_look_at_matches_fixture():
+    from nerf_tex_amd.dataset import look_at
+    for fam in ("carpet", "grass", "plush"):
+        cam = json.load(open(os.path.join(G, f"cameras_{fam}.json")))
+        for v in cam["views"]:
+            c2w = look_at(np.asarray(v["pose_dist_sample"]) * v["radius"])
+            np.testing.assert_allclose(c2w, np.asarray(v["c2w_oracle_look_at_f32"]), atol=2e-7)
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+def test_oracle_reproduces_golden(family):
+    g, spec, blob, w = load(family)
+    S = int(g["n_samples"]); bi = None if int(g["blur_idx"]) < 0 else int(g["blur_idx"])
+    hit = g["hit"]
+    ro, rd, t, cone = orc.proxy_rays(orc.full_pixels(int(g["height"]), int(g["width"])), int(g["height"]), int(g["width"]),
+                                     float(g["focal"]), g["c2w"], g["b_0"], g["b_1"], np.float32)
+    for a, b in ((ro, g["rays_o"]), (rd, g["rays_d"]), (t, g["t"]), (cone, g["cone_scale"])):
+        np.testing.assert_array_equal(a, b)
+    aux = orc.render_rays(w, spec, ro[hit], rd[hit], t[hit], np.repeat(g["parameters"], hit.sum(), 0), cone[hit], S,
+                          False, (1, 1, 1.), bi, dtype=np.float64, return_aux=True)
+    np.testing.assert_allclose(aux["z_vals"], g["z_vals"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(aux["raw_color"], g["raw_color"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(aux["weights"], g["weights"], rtol=1e-9, atol=1e-12)
+    full = orc.renderer_call(w, spec, ro[None], rd[None], t[None], g["parameters"], cone[None], S, True, tuple(g["bkgd"]),
+                             bi, dtype=np.float64)
+    np.testing.assert_allclose(full["color_pred"], g["color_pred_bkgd"], rtol=1e-9, atol=1e-11)
+    assert np.all(full["alpha_pred"][0][~hit] == 0) and np.all(full["color_pred"][0][~hit] == g["bkgd"])
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+def test_numpy_and_c_restatements_agree(family):
+    """Two independent readings of the reference source must give the same numbers."""
+    g, spec, blob, w = load(family)
+    S = int(g["n_samples"]); bi = None if int(g["blur_idx"]) < 0 else int(g["blur_idx"])
+    c, a = c_oracle.model(spec, blob, g["m_pos"], g["m_dirs"], g["m_params"], np.float64)
+    np.testing.assert_allclose(c, g["m_color"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(a, g["m_alpha"], rtol=1e-10, atol=1e-12)
+    hit = g["hit"]
+    cc, aa = c_oracle.render_rays(spec, blob, g["rays_o"][hit], g["rays_d"][hit], g["t"][hit],
+                                  np.repeat(g["parameters"], hit.sum(), 0), g["cone_scale"][hit], S, bi, dtype=np.float64)
+    np.testing.assert_allclose(cc, g["color_pred"][0][hit], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(aa, g["alpha_pred"][0][hit], rtol=1e-9, atol=1e-12)
+    # float32 builds of both restatements stay inside the north-star gate
+    c32, a32 = c_oracle.render_rays(spec, blob, g["rays_o"][hit], g["rays_d"][hit], g["t"][hit],
+                                    np.repeat(g["parameters"], hit.sum(), 0), g["cone_scale"][hit], S, bi, dtype=np.float32)
+    ref = np.concatenate([g["color_pred"][0][hit], g["alpha_pred"][0][hit][:, None]], -1)
+    assert orc.rel_linf(np.concatenate([c32, a32[:, None]], -1), ref) <= 1e-4
+    n32 = orc.render_rays(w, spec, g["rays_o"][hit], g["rays_d"][hit], g["t"][hit], np.repeat(g["parameters"], hit.sum(), 0),
+                          g["cone_scale"][hit], S, False, (1, 1, 1.), bi, dtype=np.float32)
+    assert orc.rel_linf(np.concatenate([n32["color_pred"], n32["alpha_pred"][:, None]], -1), ref) <= 1e-4
+
+
+def test_edge_golden_and_c_composite():
+    g = np.load(os.path.join(G, "golden_edge.npz"))
+    for exr in (0, 1):
+        for bk in (0, 1):
+            c, a, w, _ = orc.map_model_output(g["color"], g["sigma"], g["z"], g["rays_d"], bool(bk), tuple(g["bkgd"]), bool(exr), None, np.float64)
+            np.testing.assert_allclose(c, g[f"color_exr{exr}_bk{bk}"], rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(a, g[f"alpha_exr{exr}_bk{bk}"], rtol=1e-12, atol=1e-14)
+            cc, ca, cw = c_oracle.composite(g["color"], g["sigma"], g["z"], g["rays_d"], exr, bk, g["bkgd"], np.float64)
+            np.testing.assert_allclose(cc, c, rtol=1e-10, atol=1e-13)
+            np.testing.assert_allclose(cw, w, rtol=1e-10, atol=1e-13)
+    a = g["alpha_exr0_bk0"]; w = g["weights_exr0_bk0"]
+    assert abs(w[0, 0] - 1.0) < 1e-12 and abs(w[0, 1] - 1e-10) < 1e-18      # opaque ray: the 1e-10 floor
+    assert a[1] == 0 and a[2] == 0                                            # relu(sigma) = 0
+    assert np.all(w[6] == 0)                                                  # zero-length steps
+    assert np.count_nonzero(w[3]) == 1 and w[3, -1] > 0                       # last sample uses the copied dist
+
+
+def test_plumbing_image_crop():
+    """BASELINE configs[0] (carpet 200x200x32): recompute a 10-row band in float32 and float64."""
+    g = np.load(os.path.join(G, "golden_plumbing.npz"))
+    spec = orc.ModelSpec(n_parameters=(1, 6))
+    blob = synthetic.synthetic_weights(orc.layer_table(spec), seed=0, dense_media=True)
+    assert hashlib.sha256(blob.tobytes()).hexdigest() == str(g["weights_sha256"])
+    w = orc.split_blob(spec, blob)
+    H, W, S = int(g["height"]), int(g["width"]), int(g["n_samples"])
+    rows = slice(95 * W, 105 * W)
+    ro, rd, t, cone = orc.proxy_rays(orc.full_pixels(H, W)[rows], H, W, float(g["focal"]), g["c2w"], g["b_0"], g["b_1"], np.float32)
+    ref = g["rgba"].reshape(-1, 4)[rows]
+    for dtype, tol in ((np.float64, 2e-7), (np.float32, 1e-4)):     # 2e-7: the fixture is stored as float32
+        pred = orc.renderer_call(w, spec, ro[None], rd[None], t[None], g["parameters"], cone[None], S, dtype=dtype)
+        got = np.concatenate([pred["color_pred"][0], pred["alpha_pred"][0][:, None]], -1)
+        assert orc.rel_linf(got, ref) <= tol
+
+
+# ---- properties -----------------------------------------------------------------------------
+def test_fourier_layout():
+    x = np.asarray([[0.25, -1.0, 2.0]], np.float64)
+    o = orc.fourier_features(x, 3, np.float64)[0]
+    assert o.shape == (21,)
+    np.testing.assert_array_equal(o[:3], x[0])
+    np.testing.assert_allclose(o[3:6], np.sin(x[0])); np.testing.assert_allclose(o[6:9], np.cos(x[0]))
+    np.testing.assert_allclose(o[15:18], np.sin(4 * x[0])); np.testing.assert_allclose(o[18:21], np.cos(4 * x[0]))
+
+
+def test_linspace_tf_endpoints_and_step():
+    for n in (2, 3, 32, 64, 128, 257):
+        v = orc.linspace_tf(n, np.float32)
+        assert v.dtype == np.float32 and v[0] == 0 and v[-1] == 1 and np.all(np.diff(v) > 0)
+        assert np.max(np.abs(v - np.linspace(0, 1, n))) <= 2e-7      # delta rounded once, then k*delta rounded
+
+
+def test_aabb_hit_miss_and_ieee():
+    o = np.asarray([[0, 0, 5.], [0, 0, 5.], [3, 0, 5.], [0, 0, 5.]], np.float32)
+    d = np.asarray([[0, 0, -1.], [0, 1, 0.], [0, 0, -1.], [1e-3, 0, -1.]], np.float32)
+    t = orc.aabb(o, d, [-1, -1, -1.], [1, 1, 1.], np.float32)
+    np.testing.assert_allclose(t[0], [4, 6])        # axis-aligned: 1/0 = inf handled by the slab test
+    assert np.all(np.isinf(t[1])) and np.all(np.isinf(t[2]))
+    assert np.isfinite(t[3]).all()
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(2, 70), st.integers(0, 2 ** 31 - 1), st.booleans())
+def test_composite_properties(S, seed, exr):
+    rng = np.random.default_rng(seed)
+    n = 5
+    color = rng.normal(size=(n, S, 3)) * 4; sigma = rng.normal(size=(n, S)) * 30
+    z = np.sort(rng.uniform(0.5, 9, size=(n, S)), -1); d = rng.normal(size=(n, 3))
+    c, a, w, _ = orc.map_model_output(color, sigma, z, d, False, (1, 1, 1.), exr, None, np.float64)
+    assert np.all(w >= 0) and np.all(a <= 1 + S * 1e-10) and np.all(a >= 0)
+    if not exr:
+        assert np.all(c <= a[:, None] + 1e-12) and np.all(c >= 0)           # sigmoid colours, premultiplied
+    cb, ab, _, _ = orc.map_model_output(color, sigma, z, d, True, (.3, .2, .1), exr, None, np.float64)
+    np.testing.assert_allclose(cb, c + (1 - a)[:, None] * np.asarray([.3, .2, .1]), atol=1e-14)
+    # scaling rays_d and dividing the densities leaves the result unchanged (dists are world-space, :180)
+    c2, a2, _, _ = orc.map_model_output(color, sigma / 3.0, z, d * 3.0, False, (1, 1, 1.), exr, None, np.float64)
+    np.testing.assert_allclose(a2, a, rtol=1e-9, atol=1e-12)
+
+
+@settings(max_examples=15, deadline=None)
+@given(st.integers(0, 2 ** 31 - 1))
+def test_renderer_call_is_per_ray(seed):
+    """Nothing couples two rays (what ray sharding relies on): rendering a permutation of the rays gives
+    the permuted image; culled rays are zero."""
+    rng = np.random.default_rng(seed)
+    spec = orc.ModelSpec(kind="Nerf")
+    w = orc.split_blob(spec, synthetic.synthetic_weights(orc.layer_table(spec), seed=1))
+    n, S = 12, 8
+    ro, rd, t, cone = synthetic.all_hit_rays(n, (-1, -1, -1), (1, 1, 1), (0, 0, 4), seed=seed % 1000)
+    t[rng.integers(0, n, 3)] = np.inf
+    prm = np.zeros((1, 0), np.float32)
+    a = orc.renderer_call(w, spec, ro[None], rd[None], t[None], prm, cone[None], S, dtype=np.float64)
+    perm = rng.permutation(n)
+    b = orc.renderer_call(w, spec, ro[None, perm], rd[None, perm], t[None, perm], prm, cone[None, perm], S, dtype=np.float64)
+    np.testing.assert_allclose(b["color_pred"][0], a["color_pred"][0][perm], rtol=1e-12, atol=1e-15)
+    assert np.all(a["alpha_pred"][0][np.isinf(t[:, 0])] == 0)
