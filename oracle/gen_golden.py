@@ -12,7 +12,7 @@
       64 camera rays x 32 samples (weights are regenerated from the seed; their sha256 is stored).
   (3) golden_edge.npz         -- composite edge cases.
   (4) golden_plumbing.npz     -- BASELINE configs[0]: carpet 200x200x32 image, float64 oracle, stored
-      as float32 RGBA.
+      as float32 RGBA, plus the float32 oracle's image and its rel-Linf distance from the float64 one.
 Parts (2)-(4) are outputs of THIS repo's oracle (parity unpinned, see nerftex_oracle.py): they pin the
 oracle against drift and give the GPU tests fixed vectors, they do not pin it to TensorFlow."""
 
@@ -153,7 +153,14 @@ def plumbing():
     params = np.asarray([v["parameters"]], np.float32)
     pred = orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], S, dtype=np.float64)
     rgba = orc.render_image_rgba(pred, H, W)
-    np.savez_compressed(os.path.join(OUT, "golden_plumbing.npz"), rgba=rgba.astype(np.float32), c2w=c2w, focal=focal,
+    # the same image from the float32 restatement = what a float32 TF-CPU run would produce up to summation
+    # order; its distance from the float64 truth is the float32 noise floor of this workload
+    pred32 = orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], S, dtype=np.float32)
+    rgba32 = orc.render_image_rgba(pred32, H, W)
+    floor = orc.rel_linf(rgba32, rgba)
+    print("plumbing float32-vs-float64 floor: rel-Linf", floor)
+    np.savez_compressed(os.path.join(OUT, "golden_plumbing.npz"), rgba=rgba.astype(np.float32), rgba_f32=rgba32.astype(np.float32),
+                        f32_floor_rel_linf=floor, c2w=c2w, focal=focal,
                         parameters=params, b_0=np.asarray(cam["b_0"]), b_1=np.asarray(cam["b_1"]), height=H, width=W,
                         n_samples=S, weights_sha256=hashlib.sha256(blob.tobytes()).hexdigest(),
                         rgba_f64_sum=float(rgba.sum()), rgba_f64_max=float(rgba.max()))

@@ -105,7 +105,15 @@ def test_golden_plumbing_image_through_render_harness():
     assert len(imgs) == 1
     rgba = imgs[0][0].cpu().numpy()
     assert rgba.shape == (200, 200, 4)
-    ref = g["rgba"]
-    # hit/miss may flip only on rays grazing the box, where the contribution is ~0 anyway
-    assert orc.rel_linf(rgba, ref) <= TOL
+    # North-star gate: match the reference's FLOAT32 render within 1e-4 rel-Linf.  TensorFlow cannot run, so
+    # the float32 numpy restatement stands in for it (same float32 sample positions and encoder arguments).
+    err32 = orc.rel_linf(rgba, g["rgba_f32"])
+    # Against the float64 truth the float32 restatement itself is `floor` away (1.03e-4 on this image: the
+    # dense-media weights amplify the float32 rounding of the sample positions through sin(2^9 x)); the HIP
+    # path must not be worse than that floor by more than a quarter.
+    err64 = orc.rel_linf(rgba, g["rgba"])
+    floor = float(g["f32_floor_rel_linf"])
+    print(f"plumbing image: HIP vs f32 oracle {err32:.3e}, HIP vs f64 oracle {err64:.3e}, f32 floor {floor:.3e}")
+    assert err32 <= TOL, err32
+    assert err64 <= max(TOL, 1.25 * floor), (err64, floor)
     assert abs(float(rgba.astype(np.float64).sum()) - float(g["rgba_f64_sum"])) / float(g["rgba_f64_sum"]) <= 1e-5
