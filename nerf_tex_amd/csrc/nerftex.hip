@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "ntx_device.h"
+#include "ntx_small_kernels.h"
 
 using namespace ntx;
 
@@ -152,7 +153,8 @@ static void pack(const Variant &v, const float *blob, float *out) {
         emit_segment(dst, n.c2, g.dir_steps, 4, 0, dirrow);
         emit_segment(dst, n.c2, HSTEPS, 4, dm, hidrow);
     }
-    // wrap-around tail: the first RING records again
+    // zero pad up to a whole number of ring turns, then the wrap-around tail: the first RING records again
+    for (int i = g.stream_records; i < g.padded_records; ++i) { memset(dst, 0, sizeof(float) * REC_FLOATS); dst += REC_FLOATS; }
     memcpy(dst, out, sizeof(float) * RING * REC_FLOATS);
     dst += RING * REC_FLOATS;
 
@@ -179,7 +181,7 @@ static void pack(const Variant &v, const float *blob, float *out) {
 
 static size_t packed_floats(const Variant &v) {
     const Geometry g = make_geometry(v.n_geo, v.n_app, v.cd);
-    return (size_t)(g.stream_records + RING) * REC_FLOATS + g.aux_floats;
+    return (size_t)(g.padded_records + RING) * REC_FLOATS + g.aux_floats;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -196,22 +198,38 @@ struct ntx_ctx {
     ntx_model_desc desc;
 };
 
-template <class CFG>
-static hipError_t launch_render(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
-    render_kernel<CFG><<<dim3(c->n_wgs), dim3(256), 0, st>>>(a);
-    return hipGetLastError();
-}
-template <class CFG>
-static hipError_t launch_mlp(const ntx_ctx *c, MlpArgs &a, hipStream_t st) {
-    mlp_kernel<CFG><<<dim3(c->n_wgs), dim3(256), 0, st>>>(a);
-    return hipGetLastError();
-}
+// The two big kernels of each model family live in their own translation unit (ntx_variant.hip compiled
+// with -DNTX_VARIANT=k) so that the build parallelises; this file only dispatches to them.
+namespace ntx {
+#define NTX_DECL(k)                                                            \
+    hipError_t launch_render_v##k(int n_wgs, RenderArgs &a, hipStream_t st);   \
+    hipError_t launch_mlp_v##k(int n_wgs, MlpArgs &a, hipStream_t st);
+NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3)
+#undef NTX_DECL
+}  // namespace ntx
 
-#define NTX_DISPATCH(variant, FN, ...)                           \
-    ((variant) == 0   ? FN<Cfg<1, 6, 1>>(__VA_ARGS__)            \
-     : (variant) == 1 ? FN<Cfg<1, 4, 1>>(__VA_ARGS__)            \
-     : (variant) == 2 ? FN<Cfg<2, 3, 1>>(__VA_ARGS__)            \
-                      : FN<Cfg<0, 0, 0>>(__VA_ARGS__))
+static hipError_t launch_render(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
+    switch (c->variant) {
+        case 0: return launch_render_v0(c->n_wgs, a, st);
+#ifndef NTX_DEV_ONLY_CARPET   // development builds link only the carpet family (compile time)
+        case 1: return launch_render_v1(c->n_wgs, a, st);
+        case 2: return launch_render_v2(c->n_wgs, a, st);
+        case 3: return launch_render_v3(c->n_wgs, a, st);
+#endif
+        default: return hipErrorNotSupported;
+    }
+}
+static hipError_t launch_mlp(const ntx_ctx *c, MlpArgs &a, hipStream_t st) {
+    switch (c->variant) {
+        case 0: return launch_mlp_v0(c->n_wgs, a, st);
+#ifndef NTX_DEV_ONLY_CARPET
+        case 1: return launch_mlp_v1(c->n_wgs, a, st);
+        case 2: return launch_mlp_v2(c->n_wgs, a, st);
+        case 3: return launch_mlp_v3(c->n_wgs, a, st);
+#endif
+        default: return hipErrorNotSupported;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // C ABI
@@ -365,7 +383,7 @@ int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const flo
     a.pos = pos; a.dirs = dirs; a.params = params;
     a.color_out = color_out; a.sigma_out = sigma_out;
     a.m = m;
-    HIP_TRY(NTX_DISPATCH(ctx->variant, launch_mlp, ctx, a, (hipStream_t)stream));
+    HIP_TRY(launch_mlp(ctx, a, (hipStream_t)stream));
     return NTX_OK;
 }
 
@@ -413,7 +431,7 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     a.n_samples = n_samples; a.blur_idx = blur_idx; a.flags = flags;
     a.delta = (1.0f - 0.0f) / (float)(n_samples - 1);
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
-    HIP_TRY(NTX_DISPATCH(ctx->variant, launch_render, ctx, a, (hipStream_t)stream));
+    HIP_TRY(launch_render(ctx, a, (hipStream_t)stream));
     return NTX_OK;
 }
 

@@ -14,7 +14,22 @@
 #include <type_traits>
 #include <utility>
 
+#include "nerftex.h"   // NTX_FLAG_*
 #include "ntx_layout.h"
+
+// Experiment switches, kept because the measurement is instructive (MI355X, carpet 800x800x64, ms per launch):
+//   CONV=0 PE=0  377.4   <- default: VALU work in BLOCKS (layer epilogue as one block, one sin() per k-step after
+//   CONV=0 PE=1  383.3      that step's first MFMA)
+//   CONV=1 PE=0  388.6
+//   CONV=1 PE=1  397.5   <- everything spread thinly between MFMAs
+// A wave's own VALU instructions do not hide under its own v_mfma_f32_32x32x2_f32 stream: every VALU<->MFMA
+// alternation costs issue time, so fewer, larger VALU blocks win.  Hiding them needs a second wave per SIMD.
+#ifndef NTX_INTERLEAVE_CONV
+#define NTX_INTERLEAVE_CONV 0   // 1: move layer n's activations out of the accumulators inside layer n+1's MFMA stream
+#endif
+#ifndef NTX_STAGED_PE
+#define NTX_STAGED_PE 0         // 1: spread the encoder's sin() over the MFMA slots of the previous k-step
+#endif
 
 namespace ntx {
 
@@ -71,87 +86,159 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct WStream {
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t soff;   // wave-uniform byte offset of the next record to consume
     uint32_t voff;   // lane * 16
-    f32x4 ring[RING];
+    f32x4 ring[RING];   // record n of the stream lives in slot n % RING (all indices are compile-time)
 };
 
-NTX_DEV f32x4 ws_load(const WStream &ws, uint32_t rec_ahead) {
-    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, ws.soff + rec_ahead * 1024u, 0);
+// the whole network is straight-line code, so every record index is a constant: the scalar offset of a
+// load is an immediate / s_mov, not arithmetic
+NTX_DEV f32x4 ws_load(const WStream &ws, uint32_t rec) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, rec * 1024u, 0);
     return __builtin_bit_cast(f32x4, v);
 }
 
 NTX_DEV void ws_prime(WStream &ws, const f32x4 *base, uint32_t stream_bytes, int lane) {
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(base), 0, stream_bytes, 0x00020000);
-    ws.soff = 0;
     ws.voff = (uint32_t)lane * 16u;
     static_for<RING>([&](auto I) { ws.ring[I] = ws_load(ws, I); });
+}
+
+// records [REC0, REC0+N) are padding: keep the ring turning without multiplying them
+template <int N, int REC0>
+NTX_DEV void skip_records(WStream &ws) {
+    static_for<N>([&](auto I) {
+        constexpr int rec = REC0 + decltype(I)::value;
+        ws.ring[rec % RING] = ws_load(ws, rec + RING);
+    });
 }
 
 NTX_DEV f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// acc[mt] += W_segment^T * B over NSTEPS k-steps; bfn(integral_constant<s>) is this lane's B value.
-template <int NSTEPS, int NMT, class BFn>
-NTX_DEV void run_segment(f32x16 (&acc)[8], WStream &ws, BFn &&bfn) {
-    constexpr int RPS = NMT / 4;
-    static_assert((NSTEPS * RPS) % RING == 0, "segment must be a whole number of ring turns");
-    float b = bfn(std::integral_constant<int, 0>{});
-    static_for<NSTEPS>([&](auto S) {
-        constexpr int s = S;
-        // B value of the NEXT k-step is produced inside this step's scheduling region, so its VALU
-        // work (positional encoding) can interleave with this step's MFMAs
-        float bn = 0.0f;
-        if constexpr (s + 1 < NSTEPS) bn = bfn(std::integral_constant<int, s + 1>{});
-        static_for<RPS>([&](auto Q) {
-            constexpr int q = Q;
-            constexpr int rec = s * RPS + q;
-            constexpr int slot = rec % RING;
-            const f32x4 w = ws.ring[slot];
-            ws.ring[slot] = ws_load(ws, rec + RING);
-            acc[4 * q + 0] = mfma32(w.x, b, acc[4 * q + 0]);
-            acc[4 * q + 1] = mfma32(w.y, b, acc[4 * q + 1]);
-            acc[4 * q + 2] = mfma32(w.z, b, acc[4 * q + 2]);
-            acc[4 * q + 3] = mfma32(w.w, b, acc[4 * q + 3]);
-        });
-        b = bn;
-        // Nothing may be scheduled across a k-step boundary: hipcc otherwise sinks every prefetch
-        // load down to its first use (load; s_waitcnt vmcnt(0); mfma) and the ring collapses.
-        __builtin_amdgcn_sched_barrier(0);
-    });
-    ws.soff += NSTEPS * RPS * 1024u;
+// ---------------------------------------------------------------------------------------------
+// B-operand generators.  A generator produces, for k-step S of its segment, this lane's B value in
+// up to 8 STAGES; run_segment executes stage i of step S+1 in the shadow of MFMA i of step S.
+// ---------------------------------------------------------------------------------------------
+struct SinState {
+    float x, n, r, r2, ps, pc, sv, cv, t0;
+    int qi;
+};
+
+// sin(x + q*pi/2) of sin_q(), cut into 8 stages of <= 3 VALU instructions
+template <int ST>
+NTX_DEV void sin_stage(SinState &g, int q, float &out) {
+    if constexpr (ST == 0) {
+        g.n = __builtin_rintf(g.x * 0x1.45f306p-1f);
+        g.r = __builtin_fmaf(-g.n, 0x1.921fb6p+0f, g.x);
+    } else if constexpr (ST == 1) {
+        g.r = __builtin_fmaf(-g.n, -0x1.777a5cp-25f, g.r);
+        g.r = __builtin_fmaf(-g.n, -0x1.ee59dap-50f, g.r);
+        g.qi = (int)g.n + q;
+    } else if constexpr (ST == 2) {
+        g.r2 = g.r * g.r;
+        g.ps = __builtin_fmaf(g.r2, -1.9515295891e-4f, 8.3321608736e-3f);
+        g.pc = __builtin_fmaf(g.r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    } else if constexpr (ST == 3) {
+        g.ps = __builtin_fmaf(g.r2, g.ps, -1.6666654611e-1f);
+        g.pc = __builtin_fmaf(g.r2, g.pc, 4.166664568298827e-2f);
+        g.t0 = g.r * g.r2;
+    } else if constexpr (ST == 4) {
+        g.sv = __builtin_fmaf(g.t0, g.ps, g.r);
+        g.t0 = __builtin_fmaf(g.r2, -0.5f, 1.0f);
+        g.r2 = g.r2 * g.r2;
+    } else if constexpr (ST == 5) {
+        g.cv = __builtin_fmaf(g.r2, g.pc, g.t0);
+    } else if constexpr (ST == 6) {
+        g.sv = (g.qi & 1) ? g.cv : g.sv;
+    } else {
+        out = (g.qi & 2) ? -g.sv : g.sv;
+    }
 }
 
-// accumulators <- bias, straight from the LDS copy of the aux block ([half][128] per layer)
+// activations of the previous layer, already in registers
+struct HiddenGen {
+    const float (&hin)[128];
+    template <int S, int ST>
+    NTX_DEV void stage() {}
+    template <int S>
+    NTX_DEV float value() const { return hin[S]; }
+};
+
+// accumulator tile <- bias, straight from the LDS copy of the aux block ([half][128] per layer).
+// A tile is always (re)defined as ONE 16-wide value: defining it a few registers at a time is a partial
+// write of a register tuple and makes the allocator copy whole tiles around.
+template <int MT>
+NTX_DEV void init_bias_tile(f32x16 (&acc)[8], const float *aux, int layer, int h) {
+    const f32x4 *b = reinterpret_cast<const f32x4 *>(aux + layer * AUX_BIAS_STRIDE + h * 128) + MT * 4;
+    const f32x4 v0 = b[0], v1 = b[1], v2 = b[2], v3 = b[3];
+    acc[MT] = f32x16{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+}
 template <int NMT>
 NTX_DEV void init_bias(f32x16 (&acc)[8], const float *aux, int layer, int h) {
-    const f32x4 *b = reinterpret_cast<const f32x4 *>(aux + layer * AUX_BIAS_STRIDE + h * 128);
-    static_for<NMT>([&](auto MT) {
-        constexpr int mt = MT;
-        static_for<4>([&](auto Q) {
-            constexpr int q = Q;
-            const f32x4 v = b[mt * 4 + q];
-            acc[mt][4 * q + 0] = v.x; acc[mt][4 * q + 1] = v.y;
-            acc[mt][4 * q + 2] = v.z; acc[mt][4 * q + 3] = v.w;
-        });
-    });
+    static_for<NMT>([&](auto MT) { init_bias_tile<decltype(MT)::value>(acc, aux, layer, h); });
+}
+
+// max(x, 0) as ONE v_max_f32: fmaxf() on an MFMA result makes hipcc emit a canonicalising
+// v_max_f32 x, x, x in front of the real one (3 instead of 2 instructions per activation).
+NTX_DEV float relu1(float v) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// hin[V] <- act(previous layer's accumulator V): register r of tile V/16 is feature hidden_row(V, half)
+template <int V, bool RELU>
+NTX_DEV void convert_one(float (&hin)[128], const f32x16 (&prev)[8]) {
+    const float v = prev[V >> 4][V & 15];
+    hin[V] = RELU ? relu1(v) : v;
 }
 
 template <int NMT, bool RELU>
 NTX_DEV void store_act(float (&hin)[128], const f32x16 (&acc)[8]) {
-    static_for<NMT>([&](auto MT) {
-        constexpr int mt = MT;
-        static_for<16>([&](auto R) {
-            constexpr int r = R;
-            const float v = acc[mt][r];
-            hin[16 * mt + r] = RELU ? __builtin_fmaxf(v, 0.0f) : v;
+    static_for<NMT * 16>([&](auto V) { convert_one<decltype(V)::value, RELU>(hin, acc); });
+}
+
+// ---------------------------------------------------------------------------------------------
+// one segment: acc[mt] += W_segment^T * B over NSTEPS k-steps, one MFMA per (step, tile) SLOT.
+//   gen   : B-operand generator; stages of step S+1 run in the slots of step S
+//   extra : extra(S, MT) = additional VALU/LDS work to place in the shadow of slot (S, MT)
+// A sched_barrier after every slot pins the order hipcc emits: without it the scheduler sinks the
+// prefetch loads to their first use (collapsing the ring) and bunches the VALU work in front of the MFMAs.
+// REC0 = index of the segment's first record in the stream.
+// ---------------------------------------------------------------------------------------------
+template <int NSTEPS, int NMT, int REC0, class Gen, class Extra>
+NTX_DEV void run_segment(f32x16 (&acc)[8], WStream &ws, Gen &gen, Extra &&extra) {
+    constexpr int RPS = NMT / 4;
+    constexpr int SPS = 8 / NMT;   // generator stages per slot (8 stages over NMT slots)
+    static_for<8>([&](auto ST) { gen.template stage<0, decltype(ST)::value>(); });   // step 0: not hidden
+    float b = gen.template value<0>();
+    static_for<NSTEPS>([&](auto S) {
+        constexpr int s = S;
+        f32x4 w;
+        static_for<NMT>([&](auto MT) {
+            constexpr int mt = MT;
+            if constexpr (mt % 4 == 0) {
+                constexpr int rec = REC0 + s * RPS + mt / 4;
+                w = ws.ring[rec % RING];
+                ws.ring[rec % RING] = ws_load(ws, rec + RING);
+            }
+            acc[mt] = mfma32(w[mt % 4], b, acc[mt]);
+            if constexpr (s + 1 < NSTEPS) {
+                if constexpr (NTX_STAGED_PE)
+                    static_for<SPS>([&](auto K) { gen.template stage<s + 1, mt * SPS + decltype(K)::value>(); });
+                else if constexpr (mt == 0)
+                    static_for<8>([&](auto K) { gen.template stage<s + 1, decltype(K)::value>(); });
+            }
+            extra(S, MT);
+            __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (s + 1 < NSTEPS) b = gen.template value<s + 1>();
     });
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-lane inputs of one sample and the positional-encoding k-steps (layer.py:8-23)
+// per-lane inputs of one sample and the positional-encoding generators (layer.py:8-23)
 // ---------------------------------------------------------------------------------------------
 template <int NGEO, int NAPP>
 struct SampleIn {
@@ -161,9 +248,8 @@ struct SampleIn {
 };
 
 // Copy of the inputs whose values the optimiser cannot relate to the original: without it, CSE keeps
-// the 36-44 encoded position features alive from layer 0 to the skip layer and LICM hoists the
-// direction features out of the layer loop (~80 VGPRs), pushing the kernel into spill/serialise
-// mode.  Recomputing them in place costs VALU slots that sit in the shadow of the MFMAs.
+// the encoded position features alive from layer 0 to the skip layer (~40 VGPRs) instead of
+// recomputing them in the shadow of the MFMAs.
 template <int NGEO, int NAPP>
 NTX_DEV SampleIn<NGEO, NAPP> launder(const SampleIn<NGEO, NAPP> &in) {
     SampleIn<NGEO, NAPP> o = in;
@@ -192,39 +278,66 @@ NTX_DEV float dir_id_value(const SampleIn<NGEO, NAPP> &in) {
     else return 0.0f;
 }
 
-template <int NGEO, int NAPP, int S>
-NTX_DEV float pos_feature(const SampleIn<NGEO, NAPP> &in, int h) {
-    constexpr int nid = pos_id_steps(NGEO);
-    if constexpr (S < nid) {
-        const float lo = pos_id_value<NGEO, NAPP, 2 * S>(in), hi = pos_id_value<NGEO, NAPP, 2 * S + 1>(in);
-        return h ? hi : lo;
-    } else if constexpr (S - nid < 3 * POS_FREQ) {
-        constexpr int q = S - nid, f = q / 3, c = q % 3;
-        return sin_q(in.pos[c] * (float)(1 << f), h);
-    } else if constexpr (S - nid - 3 * POS_FREQ < NGEO * PAR_FREQ) {
-        constexpr int q = S - nid - 3 * POS_FREQ, f = q / NGEO, g = q % NGEO;
-        return sin_q(in.par[g] * (float)(1 << f), h);
-    } else {
-        return 0.0f;
+// k-step S of the position segment: identity pairs, then {sin,cos}(2^f pos_c), then {sin,cos}(2^f geo_g)
+template <int NGEO, int NAPP>
+struct PosGen {
+    const SampleIn<NGEO, NAPP> &in;
+    int h;
+    SinState g;
+    float out;
+    template <int S, int ST>
+    NTX_DEV void stage() {
+        constexpr int nid = pos_id_steps(NGEO);
+        if constexpr (S < nid) {
+            if constexpr (ST == 0) {
+                const float lo = pos_id_value<NGEO, NAPP, 2 * S>(in), hi = pos_id_value<NGEO, NAPP, 2 * S + 1>(in);
+                out = h ? hi : lo;
+            }
+        } else if constexpr (S - nid < 3 * POS_FREQ) {
+            constexpr int q = S - nid, f = q / 3, c = q % 3;
+            if constexpr (ST == 0) g.x = in.pos[c] * (float)(1 << f);
+            sin_stage<ST>(g, h, out);
+        } else if constexpr (S - nid - 3 * POS_FREQ < NGEO * PAR_FREQ) {
+            constexpr int q = S - nid - 3 * POS_FREQ, f = q / (NGEO > 0 ? NGEO : 1), gi = q % (NGEO > 0 ? NGEO : 1);
+            if constexpr (ST == 0) g.x = in.par[gi] * (float)(1 << f);
+            sin_stage<ST>(g, h, out);
+        } else {
+            if constexpr (ST == 0) out = 0.0f;
+        }
     }
-}
+    template <int S>
+    NTX_DEV float value() const { return out; }
+};
 
-template <int NGEO, int NAPP, int S>
-NTX_DEV float dir_feature(const SampleIn<NGEO, NAPP> &in, int h) {
-    constexpr int nid = dir_id_steps(NAPP);
-    if constexpr (S < nid) {
-        const float lo = dir_id_value<NGEO, NAPP, 2 * S>(in), hi = dir_id_value<NGEO, NAPP, 2 * S + 1>(in);
-        return h ? hi : lo;
-    } else if constexpr (S - nid < 3 * DIR_FREQ) {
-        constexpr int q = S - nid, f = q / 3, c = q % 3;
-        return sin_q(in.dir[c] * (float)(1 << f), h);
-    } else if constexpr (S - nid - 3 * DIR_FREQ < NAPP * PAR_FREQ) {
-        constexpr int q = S - nid - 3 * DIR_FREQ, f = q / NAPP, a = q % NAPP;
-        return sin_q(in.par[NGEO + a] * (float)(1 << f), h);
-    } else {
-        return 0.0f;
+template <int NGEO, int NAPP>
+struct DirGen {
+    const SampleIn<NGEO, NAPP> &in;
+    int h;
+    SinState g;
+    float out;
+    template <int S, int ST>
+    NTX_DEV void stage() {
+        constexpr int nid = dir_id_steps(NAPP);
+        if constexpr (S < nid) {
+            if constexpr (ST == 0) {
+                const float lo = dir_id_value<NGEO, NAPP, 2 * S>(in), hi = dir_id_value<NGEO, NAPP, 2 * S + 1>(in);
+                out = h ? hi : lo;
+            }
+        } else if constexpr (S - nid < 3 * DIR_FREQ) {
+            constexpr int q = S - nid, f = q / 3, c = q % 3;
+            if constexpr (ST == 0) g.x = in.dir[c] * (float)(1 << f);
+            sin_stage<ST>(g, h, out);
+        } else if constexpr (S - nid - 3 * DIR_FREQ < NAPP * PAR_FREQ) {
+            constexpr int q = S - nid - 3 * DIR_FREQ, f = q / (NAPP > 0 ? NAPP : 1), a = q % (NAPP > 0 ? NAPP : 1);
+            if constexpr (ST == 0) g.x = in.par[NGEO + a] * (float)(1 << f);
+            sin_stage<ST>(g, h, out);
+        } else {
+            if constexpr (ST == 0) out = 0.0f;
+        }
     }
-}
+    template <int S>
+    NTX_DEV float value() const { return out; }
+};
 
 // ---------------------------------------------------------------------------------------------
 // the MLP on one batch of 32 samples (model.py:58-125 / 9-45); lanes l and l+32 hold sample l&31
@@ -234,72 +347,141 @@ struct Cfg {
     static constexpr int NGEO = NGEO_, NAPP = NAPP_, CD = CD_;
     static constexpr int NP = NGEO_ + NAPP_;
     static constexpr int PS = pos_steps(NGEO_);
-    static constexpr int DS = dir_steps(NAPP_, CD_ ? 4 : 8);
+    static constexpr int DS = dir_steps(NAPP_);
+    // first record of hidden pass li (1..8 = L1..L7, F; 9 = C1) and of the colour-half layer
+    static constexpr int rec_pass(int li) {
+        return PS * 2 + (li - 1) * HSTEPS * 2 + (li > SKIP + 1 ? PS * 2 : 0) + (CD_ && li > 9 ? DS * 2 : 0);
+    }
+    static constexpr int REC_C2 = rec_pass(9 + (CD_ ? 1 : 0));
+    static constexpr int REC_END = make_geometry(NGEO_, NAPP_, CD_).stream_records;
+    static constexpr int REC_PAD = make_geometry(NGEO_, NAPP_, CD_).padded_records;
 };
 
+// Two accumulator sets (2 x 128 AGPRs) alternate between layers.  While layer n+1 accumulates into one
+// set, the other still holds layer n's result: its bias+ReLU'd values are moved into `hin` 16 k-steps
+// ahead of their use, one per k-step, in the shadow of layer n+1's MFMAs, and each drained tile is
+// re-initialised with the bias of layer n+2.  Only the first 16 activations of a layer (and its first
+// encoder value) are produced with the matrix pipe idle.
 template <class CFG>
 NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
                        const float *aux_in, int lane, float &sigma, float (&rgb)[3]) {
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
     const int h = lane >> 5;
     // The aux block in LDS never changes, so the optimiser would hoist every bias / head-weight
-    // read out of the batch loop and then spill ~600 values to scratch.  Laundering the pointer
-    // keeps each ds_read next to its use.
+    // read out of the batch loop and then spill ~600 values to scratch.  An opaque OFFSET (not an
+    // opaque pointer, which would lose the LDS address space) keeps each ds_read next to its use.
     uint32_t opaque_zero = 0;
-    asm volatile("" : "+v"(opaque_zero));   // an opaque OFFSET (not pointer) keeps the LDS address space
+    asm volatile("" : "+v"(opaque_zero));
     const float *aux = aux_in + opaque_zero;
-    f32x16 acc[8];
+
+    f32x16 accA[8], accB[8];
     float hin[128];
+    auto none = [](auto, auto) {};
 
-    // ---- trunk layer 0: pos_map -> 256 (model.py:104-106)
-    init_bias<8>(acc, aux, 0, h);
-    run_segment<CFG::PS, 8>(acc, ws, [&](auto S) { return pos_feature<NGEO, NAPP, decltype(S)::value>(in, h); });
-    store_act<8, true>(hin, acc);
+    // ---- trunk layer 0: pos_map -> 256 (model.py:104-106) into set A; set B <- bias of layer 1
+    init_bias<8>(accA, aux, 0, h);
+    {
+        PosGen<NGEO, NAPP> gen{in, h, {}, 0.0f};
+        run_segment<CFG::PS, 8, 0>(accA, ws, gen, [&](auto S, auto MT) {
+            constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
+            if constexpr (mt == 1 && s % 4 == 0 && s < 32) init_bias_tile<s / 4>(accB, aux, 1, h);
+        });
+    }
 
-    // ---- hidden passes: L1..L7, then F (linear), then (ParamNerf) C1.  One 1024-MFMA body.
+    // ---- hidden passes li = 1..NPASS: L1..L7, F (linear), and for ParamNerf C1
     constexpr int NPASS = 8 + (CFG::CD ? 1 : 0);
-    for (int li = 1; li <= NPASS; ++li) {
-        init_bias<8>(acc, aux, li, h);
-        if (li == SKIP + 1) {   // input = concat[pos_map, h]  (model.py:107-108)
+    float sig_part = 0.0f;
+    auto hidden_pass = [&](auto LI, f32x16 (&cur)[8], f32x16 (&prev)[8]) {
+        constexpr int li = decltype(LI)::value;
+        constexpr bool relu_in = li != 9;          // the input of C1 is the linear "feature" layer (model.py:114)
+        constexpr int rec0 = CFG::rec_pass(li);
+        constexpr bool has_pos = li == SKIP + 1, has_dir = CFG::CD != 0 && li == 9;
+        constexpr int pre_steps = has_pos ? CFG::PS : (has_dir ? CFG::DS : 0);
+        constexpr int next_bias = li + 1;          // layer that will accumulate into `prev` next (8 = F, 9 = C1, 10 = C2)
+        constexpr bool init_next = li < NPASS;     // the colour-half layer initialises its own 4 tiles
+        // re-initialise tile T of the drained set (free from k-step 16 T on) with the next layer's bias
+        auto reinit = [&](auto S, auto MT) {
+            constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
+            if constexpr (init_next && mt == 1 && (s & 15) == 0) init_bias_tile<(s >> 4)>(prev, aux, next_bias, h);
+        };
+        // alpha head (model.py:111) rides on pass F, which consumes the same activations relu(L7)
+        auto alpha_head = [&](auto S, auto MT) {
+            constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
+            if constexpr (li == DEPTH && mt == 2)
+                sig_part = __builtin_fmaf(hin[s], aux[aux_alpha_off() + h * 128 + s], sig_part);
+        };
+        if constexpr (pre_steps > 0) {
+            // encoder segment first: all 128 activations are converted in its shadow
+            constexpr int per_step = (128 + pre_steps - 1) / pre_steps;
+            if constexpr (!NTX_INTERLEAVE_CONV) store_act<8, relu_in>(hin, prev);
+            auto conv = [&](auto S, auto MT) {
+                constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
+                if constexpr (NTX_INTERLEAVE_CONV && mt == 0)
+                    static_for<per_step>([&](auto K) {
+                        constexpr int v = s * per_step + decltype(K)::value;
+                        if constexpr (v < 128) convert_one<v, relu_in>(hin, prev);
+                    });
+            };
             const SampleIn<NGEO, NAPP> in2 = launder(in);
-            run_segment<CFG::PS, 8>(acc, ws, [&](auto S) { return pos_feature<NGEO, NAPP, decltype(S)::value>(in2, h); });
-        }
-        if constexpr (CFG::CD != 0)
-            if (li == 9) {   // input = concat[dir_map, feature]  (model.py:115)
-                const SampleIn<NGEO, NAPP> in2 = launder(in);
-                run_segment<CFG::DS, 8>(acc, ws, [&](auto S) { return dir_feature<NGEO, NAPP, decltype(S)::value>(in2, h); });
+            if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
+                PosGen<NGEO, NAPP> gen{in2, h, {}, 0.0f};
+                run_segment<pre_steps, 8, rec0>(cur, ws, gen, conv);
+            } else {                   // input = concat[dir_map, feature]  (model.py:115)
+                DirGen<NGEO, NAPP> gen{in2, h, {}, 0.0f};
+                run_segment<pre_steps, 8, rec0>(cur, ws, gen, conv);
             }
-        run_segment<HSTEPS, 8>(acc, ws, [&](auto S) { return hin[decltype(S)::value]; });
-        if (li == 8) {
-            store_act<8, false>(hin, acc);   // "feature" layer has no activation (model.py:114)
+            HiddenGen hg{hin};
+            run_segment<HSTEPS, 8, rec0 + pre_steps * 2>(cur, ws, hg, [&](auto S, auto MT) { reinit(S, MT); alpha_head(S, MT); });
         } else {
-            store_act<8, true>(hin, acc);
-        }
-        if (li == DEPTH - 1) {
-            // alpha head on the output of trunk layer 7 (model.py:111), on the VALU:
-            // each half-wave holds 128 of the 256 features of its sample
-            const f32x4 *wa = reinterpret_cast<const f32x4 *>(aux + aux_alpha_off() + h * 128);
-            float p = 0.0f;
-            static_for<32>([&](auto I) {
-                constexpr int i = I;
-                const f32x4 w = wa[i];
-                p = __builtin_fmaf(hin[4 * i + 0], w.x, p);
-                p = __builtin_fmaf(hin[4 * i + 1], w.y, p);
-                p = __builtin_fmaf(hin[4 * i + 2], w.z, p);
-                p = __builtin_fmaf(hin[4 * i + 3], w.w, p);
+            static_for<NTX_INTERLEAVE_CONV ? 16 : 128>([&](auto V) { convert_one<decltype(V)::value, relu_in>(hin, prev); });   // not hidden
+            HiddenGen hg{hin};
+            run_segment<HSTEPS, 8, rec0>(cur, ws, hg, [&](auto S, auto MT) {
+                constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
+                if constexpr (NTX_INTERLEAVE_CONV && mt == 0 && s + 16 < 128) convert_one<s + 16, relu_in>(hin, prev);
+                reinit(S, MT);
+                alpha_head(S, MT);
             });
-            sigma = p + __shfl_xor(p, 32, 64) + aux[aux_alpha_off() + 256];
         }
-    }
+    };
+    static_for<NPASS>([&](auto I) {
+        constexpr int li = decltype(I)::value + 1;
+        if constexpr (li & 1) hidden_pass(std::integral_constant<int, li>{}, accB, accA);
+        else hidden_pass(std::integral_constant<int, li>{}, accA, accB);
+    });
+    sigma = sig_part + __shfl_xor(sig_part, 32, 64) + aux[aux_alpha_off() + 256];
 
-    // ---- colour half layer (-> 128, relu; model.py:122 / 42), 4 M-tiles
-    init_bias<4>(acc, aux, 10, h);
-    if constexpr (CFG::CD == 0) {   // plain Nerf: input = concat[dir_map, feature]  (model.py:39-42)
-        const SampleIn<NGEO, NAPP> in2 = launder(in);
-        run_segment<CFG::DS, 4>(acc, ws, [&](auto S) { return dir_feature<NGEO, NAPP, decltype(S)::value>(in2, h); });
-    }
-    run_segment<HSTEPS, 4>(acc, ws, [&](auto S) { return hin[decltype(S)::value]; });
-    store_act<4, true>(hin, acc);
+    // ---- colour half layer (-> 128, relu; model.py:122 / 42), 4 M-tiles.
+    // ParamNerf: input relu(C1) from set B, output set A.  Nerf: input [dir_map, F (linear, set A)], output set B.
+    auto color_half = [&](f32x16 (&cur)[8], f32x16 (&prev)[8]) {
+        init_bias<4>(cur, aux, 10, h);
+        if constexpr (CFG::CD == 0) {   // plain Nerf: input = concat[dir_map, feature]  (model.py:39-42)
+            constexpr int per_step = (128 + CFG::DS - 1) / CFG::DS;
+            const SampleIn<NGEO, NAPP> in2 = launder(in);
+            DirGen<NGEO, NAPP> gen{in2, h, {}, 0.0f};
+            run_segment<CFG::DS, 4, CFG::REC_C2>(cur, ws, gen, [&](auto S, auto MT) {
+                constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
+                if constexpr (mt == 0)
+                    static_for<per_step>([&](auto K) {
+                        constexpr int v = s * per_step + decltype(K)::value;
+                        if constexpr (v < 128) convert_one<v, false>(hin, prev);
+                    });
+            });
+            HiddenGen hg{hin};
+            run_segment<HSTEPS, 4, CFG::REC_C2 + CFG::DS>(cur, ws, hg, none);
+        } else {
+            static_for<NTX_INTERLEAVE_CONV ? 16 : 128>([&](auto V) { convert_one<decltype(V)::value, true>(hin, prev); });
+            HiddenGen hg{hin};
+            run_segment<HSTEPS, 4, CFG::REC_C2>(cur, ws, hg, [&](auto S, auto MT) {
+                constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
+                if constexpr (NTX_INTERLEAVE_CONV && mt == 0 && s + 16 < 128) convert_one<s + 16, true>(hin, prev);
+            });
+        }
+        store_act<4, true>(hin, cur);
+    };
+    if constexpr (NPASS & 1) color_half(accA, accB);   // last pass wrote set B
+    else color_half(accB, accA);
+    static_assert(CFG::REC_C2 + (CFG::CD == 0 ? CFG::DS : 0) + HSTEPS == CFG::REC_END, "stream bookkeeping");
+    skip_records<CFG::REC_PAD - CFG::REC_END, CFG::REC_END>(ws);
 
     // ---- rgb head (128 -> 3, linear; model.py:123) on the VALU
     static_for<3>([&](auto C) {
@@ -316,9 +498,8 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
         });
         rgb[c] = p + __shfl_xor(p, 32, 64) + aux[aux_rgb_off() + 384 + c];
     });
-
-    // the stream's tail replicates its first RING records, so the ring already holds the head
-    ws.soff = 0;
+    // the stream's tail replicates its first RING records and REC_PAD % RING == 0, so the ring now holds
+    // records 0..RING-1 in slots 0..RING-1: the next batch starts without a bubble
 }
 
 NTX_DEV void load_aux(float *lds, const float *aux_g, int n) {
@@ -491,134 +672,6 @@ __global__ __launch_bounds__(256) void mlp_kernel(MlpArgs a) {
             a.color_out[3 * m + 0] = raw[0]; a.color_out[3 * m + 1] = raw[1]; a.color_out[3 * m + 2] = raw[2];
             a.sigma_out[m] = sigma;
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// stand-alone composite: one wave64 per ray, lane = sample, chunks of 64 with carry
-// ---------------------------------------------------------------------------------------------
-struct CompositeArgs {
-    const float *color, *sigma, *z, *rays_d;
-    float *color_out, *alpha_out, *weights_out;
-    int64_t n_rays;
-    int n_samples;
-    uint32_t flags;
-    float bkgd[3];
-};
-
-__global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const int S = a.n_samples;
-    for (int64_t ray = wave; ray < a.n_rays; ray += nwaves) {
-        const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
-        const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
-        const float *zr = a.z + ray * S;
-        RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        for (int base = 0; base < S; base += 64) {
-            const int i = base + lane;
-            const bool valid = i < S;
-            const int ic = valid ? i : S - 1;
-            const float z = zr[ic];
-            const float zn = zr[ic < S - 1 ? ic + 1 : ic - 1];
-            const float dist = (ic < S - 1 ? zn - z : z - zn) * dnorm;
-            const float sg = a.sigma[ray * S + ic];
-            float raw[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) raw[k] = a.color[(ray * S + ic) * 3 + k];
-            composite_step<64>(ra, sg, raw, dist, valid, a.flags, lane,
-                               a.weights_out ? a.weights_out + ray * S + ic : nullptr);
-        }
-        float out[4] = {ra.c0, ra.c1, ra.c2, ra.a};
-        if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) out[k] = out[k] + (1.0f - ra.a) * a.bkgd[k];
-        }
-        if (lane == 0) {
-            a.color_out[3 * ray + 0] = out[0]; a.color_out[3 * ray + 1] = out[1];
-            a.color_out[3 * ray + 2] = out[2]; a.alpha_out[ray] = out[3];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// ray generation (pixel_sampler.py:14-15, ray_sampler.py:23-48, proxy.py:13-35)
-// ---------------------------------------------------------------------------------------------
-struct RaygenArgs {
-    float c2w[16];
-    float b0[3], b1[3];
-    float focal, half_w, half_h, near_t, far_t;
-    int width, mode;
-    int64_t pixel0, n;
-    float *rays_o, *rays_d, *t, *cone;
-};
-
-__global__ __launch_bounds__(256) void raygen_kernel(RaygenArgs a) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.n) return;
-    const int64_t pix = a.pixel0 + k;
-    const float li = (float)(pix / a.width), lj = (float)(pix % a.width);   // (row, col), Full sampler
-    const float d0 = (lj + 0.5f - a.half_w) / a.focal;                       // ray_sampler.py:41
-    const float d1 = -(li + 0.5f - a.half_h) / a.focal;
-    const float d2 = -1.0f;
-    float rd[3], ro[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        rd[r] = (d0 * a.c2w[4 * r + 0] + d1 * a.c2w[4 * r + 1]) + d2 * a.c2w[4 * r + 2];   // :42
-        ro[r] = a.c2w[4 * r + 3];                                                            // :43
-    }
-    const float nxy = __builtin_sqrtf(d0 * d0 + d1 * d1);
-    const float nrm = __builtin_sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
-    const float cone = cosf(atanf(nxy)) / nrm / a.focal;                                    // :46
-    float t0, t1;
-    if (a.mode == 0) {
-        const float n = __builtin_sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);  // :34
-#pragma unroll
-        for (int r = 0; r < 3; ++r) rd[r] = rd[r] / n;
-        // proxy.py:16-33; comparisons written exactly as tf.where does them so NaNs fall the same way
-        float tmax = 0.0f, tmin = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float inv = 1.0f / rd[r];
-            const float ta = (a.b0[r] - ro[r]) * inv, tb = (a.b1[r] - ro[r]) * inv;
-            const float lo = ta < tb ? ta : tb;
-            const float hi = ta > tb ? ta : tb;
-            if (r == 0) { tmax = lo; tmin = hi; }
-            else {
-                // reduce_max / reduce_min propagate NaN
-                tmax = (lo != lo || tmax != tmax) ? __builtin_nanf("") : (lo > tmax ? lo : tmax);
-                tmin = (hi != hi || tmin != tmin) ? __builtin_nanf("") : (hi < tmin ? hi : tmin);
-            }
-        }
-        const bool hit = tmax < tmin;
-        t0 = hit ? tmax : __builtin_inff();
-        t1 = hit ? tmin : __builtin_inff();
-    } else {
-        t0 = a.near_t; t1 = a.far_t;
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) { a.rays_o[3 * k + r] = ro[r]; a.rays_d[3 * k + r] = rd[r]; }
-    a.t[2 * k] = t0; a.t[2 * k + 1] = t1;
-    a.cone[k] = cone;
-}
-
-// ---------------------------------------------------------------------------------------------
-// FourierFeatures alone (layer.py:8-23): thread per (row, component)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fourier_kernel(const float *x, int64_t m, int d, int nf, float *out) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= m * d) return;
-    const int64_t row = k / d;
-    const int c = (int)(k % d);
-    const float v = x[k];
-    float *o = out + row * (int64_t)(d * (1 + 2 * nf));
-    o[c] = v;
-    float f = 1.0f;
-    for (int i = 0; i < nf; ++i) {
-        o[d + 2 * i * d + c] = sin_q(f * v, 0);
-        o[d + (2 * i + 1) * d + c] = sin_q(f * v, 1);
-        f *= 2.0f;
     }
 }
 

@@ -30,7 +30,10 @@ constexpr int WIDTH = 256;
 constexpr int DEPTH = 8;
 constexpr int SKIP = 4;
 constexpr int HSTEPS = WIDTH / 2;       // k-steps of a 256-wide hidden input
-constexpr int RING = 8;                 // weight records (64 lanes x float4) kept in flight per wave
+#ifndef NTX_RING
+#define NTX_RING 8
+#endif
+constexpr int RING = NTX_RING;          // weight records (64 lanes x float4) kept in flight per wave
 constexpr int REC_FLOATS = 256;         // one record = 64 lanes x 4 floats = 1 KiB
 
 NTX_HD constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -44,8 +47,7 @@ NTX_HD constexpr int hidden_row(int s, int h) {
 NTX_HD constexpr int pos_id_values(int n_geo) { return 3 + n_geo; }
 NTX_HD constexpr int pos_id_steps(int n_geo) { return (pos_id_values(n_geo) + 1) / 2; }
 NTX_HD constexpr int pos_steps_raw(int n_geo) { return pos_id_steps(n_geo) + 3 * POS_FREQ + n_geo * PAR_FREQ; }
-// padded so that a segment is a whole number of ring turns (see RING): multiple of 4 steps x 2 records
-NTX_HD constexpr int pos_steps(int n_geo) { return round_up(pos_steps_raw(n_geo), 4); }
+NTX_HD constexpr int pos_steps(int n_geo) { return pos_steps_raw(n_geo); }
 NTX_HD constexpr int pos_map_dim(int n_geo) { return 3 * (1 + 2 * POS_FREQ) + n_geo * (1 + 2 * PAR_FREQ); }
 
 // row of the reference's pos_map that (step s, half h) carries, or -1 for a zero pad
@@ -70,7 +72,7 @@ NTX_HD constexpr int pos_row(int n_geo, int s, int h) {
 NTX_HD constexpr int dir_id_values(int n_app) { return 3 + n_app; }
 NTX_HD constexpr int dir_id_steps(int n_app) { return (dir_id_values(n_app) + 1) / 2; }
 NTX_HD constexpr int dir_steps_raw(int n_app) { return dir_id_steps(n_app) + 3 * DIR_FREQ + n_app * PAR_FREQ; }
-NTX_HD constexpr int dir_steps(int n_app, int align) { return round_up(dir_steps_raw(n_app), align); }
+NTX_HD constexpr int dir_steps(int n_app) { return dir_steps_raw(n_app); }
 NTX_HD constexpr int dir_map_dim(int n_app) { return 3 * (1 + 2 * DIR_FREQ) + n_app * (1 + 2 * PAR_FREQ); }
 
 NTX_HD constexpr int dir_row(int n_app, int s, int h) {
@@ -99,12 +101,15 @@ NTX_HD constexpr int dir_row(int n_app, int s, int h) {
 //   F    : hidden (linear "feature" layer, model.py:114)
 //   ParamNerf: C1 = dir segment (8 tiles) + hidden ; C2 = hidden input, 4 M-tiles (HSTEPS records)
 //   Nerf     : C2 = dir segment (4 tiles) + hidden (4 tiles)
+//   pad  : zero records up to a multiple of RING (skipped, never multiplied), so that the compile-time
+//          ring phase is 0 again when the next batch starts
 //   tail : a copy of the first RING records (so the prefetch ring wraps into the next batch)
 // AUX block (read through LDS): biases in accumulator order, alpha head, rgb head.
 struct Geometry {
     int n_geo, n_app, color_depth;   // color_depth: 1 = ParamNerf, 0 = Nerf
     int pos_steps, dir_steps;
-    int stream_records;              // without the wrap-around tail
+    int stream_records;              // without pad and wrap-around tail
+    int padded_records;              // rounded up to a multiple of RING
     int aux_floats;
 };
 
@@ -119,7 +124,7 @@ NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth) {
     Geometry g{};
     g.n_geo = n_geo; g.n_app = n_app; g.color_depth = color_depth;
     g.pos_steps = pos_steps(n_geo);
-    g.dir_steps = dir_steps(n_app, color_depth ? 4 : 8);
+    g.dir_steps = dir_steps(n_app);
     int rec = 0;
     rec += g.pos_steps * 2;                 // L0
     rec += 4 * HSTEPS * 2;                  // L1-4
@@ -133,6 +138,7 @@ NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth) {
         rec += g.dir_steps + HSTEPS;           // C2 (4 tiles)
     }
     g.stream_records = rec;
+    g.padded_records = round_up(rec, RING);
     g.aux_floats = aux_total();
     return g;
 }

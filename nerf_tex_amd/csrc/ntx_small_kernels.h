@@ -1,0 +1,137 @@
+// ntx_small_kernels.h -- the bandwidth-bound stand-alone kernels (composite, ray generation, Fourier
+// features).  Included by nerftex.hip only; the MFMA kernels are in ntx_device.h / ntx_variant.hip.
+#pragma once
+
+#include "ntx_device.h"
+
+namespace ntx {
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone composite: one wave64 per ray, lane = sample, chunks of 64 with carry
+// ---------------------------------------------------------------------------------------------
+struct CompositeArgs {
+    const float *color, *sigma, *z, *rays_d;
+    float *color_out, *alpha_out, *weights_out;
+    int64_t n_rays;
+    int n_samples;
+    uint32_t flags;
+    float bkgd[3];
+};
+
+__global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int S = a.n_samples;
+    for (int64_t ray = wave; ray < a.n_rays; ray += nwaves) {
+        const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+        const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+        const float *zr = a.z + ray * S;
+        RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int base = 0; base < S; base += 64) {
+            const int i = base + lane;
+            const bool valid = i < S;
+            const int ic = valid ? i : S - 1;
+            const float z = zr[ic];
+            const float zn = zr[ic < S - 1 ? ic + 1 : ic - 1];
+            const float dist = (ic < S - 1 ? zn - z : z - zn) * dnorm;
+            const float sg = a.sigma[ray * S + ic];
+            float raw[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) raw[k] = a.color[(ray * S + ic) * 3 + k];
+            composite_step<64>(ra, sg, raw, dist, valid, a.flags, lane,
+                               a.weights_out ? a.weights_out + ray * S + ic : nullptr);
+        }
+        float out[4] = {ra.c0, ra.c1, ra.c2, ra.a};
+        if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out[k] = out[k] + (1.0f - ra.a) * a.bkgd[k];
+        }
+        if (lane == 0) {
+            a.color_out[3 * ray + 0] = out[0]; a.color_out[3 * ray + 1] = out[1];
+            a.color_out[3 * ray + 2] = out[2]; a.alpha_out[ray] = out[3];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ray generation (pixel_sampler.py:14-15, ray_sampler.py:23-48, proxy.py:13-35)
+// ---------------------------------------------------------------------------------------------
+struct RaygenArgs {
+    float c2w[16];
+    float b0[3], b1[3];
+    float focal, half_w, half_h, near_t, far_t;
+    int width, mode;
+    int64_t pixel0, n;
+    float *rays_o, *rays_d, *t, *cone;
+};
+
+__global__ __launch_bounds__(256) void raygen_kernel(RaygenArgs a) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n) return;
+    const int64_t pix = a.pixel0 + k;
+    const float li = (float)(pix / a.width), lj = (float)(pix % a.width);   // (row, col), Full sampler
+    const float d0 = (lj + 0.5f - a.half_w) / a.focal;                       // ray_sampler.py:41
+    const float d1 = -(li + 0.5f - a.half_h) / a.focal;
+    const float d2 = -1.0f;
+    float rd[3], ro[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        rd[r] = (d0 * a.c2w[4 * r + 0] + d1 * a.c2w[4 * r + 1]) + d2 * a.c2w[4 * r + 2];   // :42
+        ro[r] = a.c2w[4 * r + 3];                                                            // :43
+    }
+    const float nxy = __builtin_sqrtf(d0 * d0 + d1 * d1);
+    const float nrm = __builtin_sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+    const float cone = cosf(atanf(nxy)) / nrm / a.focal;                                    // :46
+    float t0, t1;
+    if (a.mode == 0) {
+        const float n = __builtin_sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);  // :34
+#pragma unroll
+        for (int r = 0; r < 3; ++r) rd[r] = rd[r] / n;
+        // proxy.py:16-33; comparisons written exactly as tf.where does them so NaNs fall the same way
+        float tmax = 0.0f, tmin = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float inv = 1.0f / rd[r];
+            const float ta = (a.b0[r] - ro[r]) * inv, tb = (a.b1[r] - ro[r]) * inv;
+            const float lo = ta < tb ? ta : tb;
+            const float hi = ta > tb ? ta : tb;
+            if (r == 0) { tmax = lo; tmin = hi; }
+            else {
+                // reduce_max / reduce_min propagate NaN
+                tmax = (lo != lo || tmax != tmax) ? __builtin_nanf("") : (lo > tmax ? lo : tmax);
+                tmin = (hi != hi || tmin != tmin) ? __builtin_nanf("") : (hi < tmin ? hi : tmin);
+            }
+        }
+        const bool hit = tmax < tmin;
+        t0 = hit ? tmax : __builtin_inff();
+        t1 = hit ? tmin : __builtin_inff();
+    } else {
+        t0 = a.near_t; t1 = a.far_t;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { a.rays_o[3 * k + r] = ro[r]; a.rays_d[3 * k + r] = rd[r]; }
+    a.t[2 * k] = t0; a.t[2 * k + 1] = t1;
+    a.cone[k] = cone;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FourierFeatures alone (layer.py:8-23): thread per (row, component)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fourier_kernel(const float *x, int64_t m, int d, int nf, float *out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m * d) return;
+    const int64_t row = k / d;
+    const int c = (int)(k % d);
+    const float v = x[k];
+    float *o = out + row * (int64_t)(d * (1 + 2 * nf));
+    o[c] = v;
+    float f = 1.0f;
+    for (int i = 0; i < nf; ++i) {
+        o[d + 2 * i * d + c] = sin_q(f * v, 0);
+        o[d + (2 * i + 1) * d + c] = sin_q(f * v, 1);
+        f *= 2.0f;
+    }
+}
+
+}  // namespace ntx
