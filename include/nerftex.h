@@ -124,6 +124,31 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
                     const float *z_vals, float *color_out, float *alpha_out, int32_t *status_flag,
                     ntx_stream stream);
 
+/* Replaces InstanceRenderer.evaluate_model + map_model_output (renderer.py:247-354) DOWNSTREAM of the
+ * instancer: the arguments are the buffers instancer.get_model_input returns (instancer.pyx:38-54), on the
+ * device:  rays_d_map[N,S,3], pts[N,S,3], t[N,S], dists[N,S], color_last[N,3], alpha_last[N],
+ * alpha_weight[N,S] (NULL = density_reweighting off), instance_id[N,S] int32, hit[N] uint8 (the rays in
+ * `idxs`), params_map[N,S,P], cone_scale[N].  Samples with dists <= 0 are skipped (renderer.py:284-288);
+ * sigma *= alpha_weight * density_scale (:300); alpha = 1 - exp(-relu(sigma) * dists / patch_scale) (:339);
+ * one extra sample (color_last as is, alpha_last as an alpha) closes every ray (:331,339).
+ * instance_color[n_instances,3] != NULL = the false-colour mode (:306-307).  Rays with hit == 0 get 0, also
+ * under NTX_FLAG_COMPOSITE_BKGD (:313-314).  1 <= n_samples <= 4096. */
+int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts, const float *t,
+                         const float *dists, const float *color_last, const float *alpha_last,
+                         const float *alpha_weight, const int32_t *instance_id, const uint8_t *hit,
+                         const float *params_map, const float *cone_scale, int64_t n_rays, int n_samples,
+                         int blur_idx, float patch_scale, float density_scale, uint32_t flags,
+                         const float *bkgd, const float *instance_color, float *color_out, float *alpha_out,
+                         int32_t *status_flag, ntx_stream stream);
+
+/* Replaces the image post-processing of logger.Logger.render_image / write_image (logger.py:128-144) and
+ * util.interpolate.filtered_downsample (interpolate.py:68-82): rgba[H,W,4] premultiplied (DEVICE) ->
+ * optional gaussian low-pass (size 3*factor, std factor/2) + stride-`factor` downsample with TF 'SAME' padding,
+ * optional rgb / (a + 1e-5), written as float32 out_f32[ceil(H/f),ceil(W/f),4] and/or uint8 out_u8 (saturating
+ * x*255.5, what tf.image.convert_image_dtype does before encode_png).  Either output may be NULL. */
+int ntx_image_epilogue(const float *rgba, int height, int width, int downsampling_factor, int unpremultiply,
+                       float *out_f32, uint8_t *out_u8, ntx_stream stream);
+
 /* Introspection for benches/tests: name and launch geometry of the fused kernel in `ctx`. */
 int ntx_kernel_info(ntx_ctx *ctx, int *n_workgroups, int *threads_per_workgroup, int *n_cus);
 

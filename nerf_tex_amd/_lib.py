@@ -48,6 +48,9 @@ SYMBOLS = {
     "ntx_composite": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_uint32, _fp, _vp, _vp, _vp, _vp]),
     "ntx_render_rays": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, C.c_int, C.c_uint32,
                                   _fp, _vp, _vp, _vp, _vp, _vp]),
+    "ntx_render_instanced": (C.c_int, [_vp] * 12 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, _fp,
+                                        _vp, _vp, _vp, _vp, _vp]),
+    "ntx_image_epilogue": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "ntx_kernel_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ntx_packed_count": (C.c_size_t, [C.POINTER(ModelDesc)]),
     "ntx_pack_weights": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, _fp, C.c_size_t]),

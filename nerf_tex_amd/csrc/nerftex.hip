@@ -203,7 +203,8 @@ struct ntx_ctx {
 namespace ntx {
 #define NTX_DECL(k)                                                            \
     hipError_t launch_render_v##k(int n_wgs, RenderArgs &a, hipStream_t st);   \
-    hipError_t launch_mlp_v##k(int n_wgs, MlpArgs &a, hipStream_t st);
+    hipError_t launch_mlp_v##k(int n_wgs, MlpArgs &a, hipStream_t st);         \
+    hipError_t launch_instance_v##k(int n_wgs, InstanceArgs &a, hipStream_t st);
 NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3)
 #undef NTX_DECL
 }  // namespace ntx
@@ -215,6 +216,17 @@ static hipError_t launch_render(const ntx_ctx *c, RenderArgs &a, hipStream_t st)
         case 1: return launch_render_v1(c->n_wgs, a, st);
         case 2: return launch_render_v2(c->n_wgs, a, st);
         case 3: return launch_render_v3(c->n_wgs, a, st);
+#endif
+        default: return hipErrorNotSupported;
+    }
+}
+static hipError_t launch_instance(const ntx_ctx *c, InstanceArgs &a, hipStream_t st) {
+    switch (c->variant) {
+        case 0: return launch_instance_v0(c->n_wgs, a, st);
+#ifndef NTX_DEV_ONLY_CARPET
+        case 1: return launch_instance_v1(c->n_wgs, a, st);
+        case 2: return launch_instance_v2(c->n_wgs, a, st);
+        case 3: return launch_instance_v3(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -432,6 +444,72 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     a.delta = (1.0f - 0.0f) / (float)(n_samples - 1);
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
     HIP_TRY(launch_render(ctx, a, (hipStream_t)stream));
+    return NTX_OK;
+}
+
+int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts, const float *t, const float *dists,
+                         const float *color_last, const float *alpha_last, const float *alpha_weight,
+                         const int32_t *instance_id, const uint8_t *hit, const float *params_map, const float *cone_scale,
+                         int64_t n_rays, int n_samples, int blur_idx, float patch_scale, float density_scale,
+                         uint32_t flags, const float *bkgd, const float *instance_color, float *color_out,
+                         float *alpha_out, int32_t *status_flag, ntx_stream stream) {
+    if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
+    if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
+    if (n_samples < 1 || n_samples > MAX_INSTANCE_SAMPLES)
+        return fail(NTX_E_INVALID, "n_samples %d outside [1,%d]", n_samples, MAX_INSTANCE_SAMPLES);
+    if (n_rays == 0) return NTX_OK;
+    const Variant &v = kVariants[ctx->variant];
+    const int np = v.n_geo + v.n_app;
+    if (!rays_d_map || !pts || !dists || !color_last || !alpha_last || !hit || !color_out || !alpha_out ||
+        (!params_map && np > 0))
+        return fail(NTX_E_INVALID, "NULL buffer");
+    if (blur_idx < -1 || blur_idx >= np) return fail(NTX_E_INVALID, "blur_idx %d outside [-1,%d)", blur_idx, np);
+    if (blur_idx >= 0 && (!cone_scale || !t)) return fail(NTX_E_INVALID, "blur_idx set but cone_scale / t is NULL");
+    if (instance_color && !instance_id) return fail(NTX_E_INVALID, "instance_color given without instance_id");
+    if (!(patch_scale > 0.0f)) return fail(NTX_E_INVALID, "patch_scale must be > 0");
+    InstanceArgs a{};
+    a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed);
+    a.stream_bytes = (uint32_t)(ctx->stream_floats * sizeof(float));
+    a.aux = ctx->packed + ctx->stream_floats;
+    a.rays_d_map = rays_d_map; a.pts = pts; a.t = t; a.dists = dists; a.color_last = color_last;
+    a.alpha_last = alpha_last; a.alpha_weight = alpha_weight; a.params_map = params_map; a.cone = cone_scale;
+    a.instance_color = instance_color; a.instance_id = instance_id; a.hit = hit;
+    a.color_out = color_out; a.alpha_out = alpha_out; a.status = status_flag;
+    a.n_rays = n_rays; a.n_samples = n_samples; a.blur_idx = blur_idx; a.flags = flags;
+    a.patch_scale = patch_scale; a.density_scale = density_scale;
+    for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
+    HIP_TRY(launch_instance(ctx, a, (hipStream_t)stream));
+    return NTX_OK;
+}
+
+int ntx_image_epilogue(const float *rgba, int height, int width, int downsampling_factor, int unpremultiply,
+                       float *out_f32, uint8_t *out_u8, ntx_stream stream) {
+    if (!rgba || (!out_f32 && !out_u8)) return fail(NTX_E_INVALID, "NULL buffer");
+    if (height <= 0 || width <= 0) return fail(NTX_E_INVALID, "bad image size %dx%d", height, width);
+    const int f = downsampling_factor;
+    if (f < 1 || f * 3 > MAX_EPILOGUE_TAPS) return fail(NTX_E_INVALID, "downsampling_factor %d outside [1,%d]", f, MAX_EPILOGUE_TAPS / 3);
+    EpilogueArgs a{};
+    a.rgba = rgba; a.out_f32 = out_f32; a.out_u8 = out_u8;
+    a.h = height; a.w = width; a.factor = f; a.unpremultiply = unpremultiply;
+    a.oh = (height + f - 1) / f; a.ow = (width + f - 1) / f;
+    if (f > 1) {
+        const float stdv = (float)(f * .5);                     // filtered_downsample(std=.5): factor * std
+        const int K = (int)(f * .5 * 6);                        // interpolate.py:81
+        a.taps = K;
+        float sum = 0.0f;
+        for (int i = 0; i < K; ++i) {                           // interpolate.py:71-72 (+0.5 shift for even sizes)
+            const float x = (float)(-(K - 1) / 2.0 + i) + (K % 2 == 0 ? 0.5f : 0.0f);
+            const float q = x / stdv;
+            a.k1[i] = expf(-.5f * (q * q));
+            sum += a.k1[i];
+        }
+        for (int i = 0; i < K; ++i) a.k1[i] /= sum;             // (k1 (x) k1) / sum(k1 (x) k1) = (k1/S) (x) (k1/S)
+        const int ph = (a.oh - 1) * f + K - height, pw = (a.ow - 1) * f + K - width;   // TF 'SAME'
+        a.pad_top = (ph > 0 ? ph : 0) / 2; a.pad_left = (pw > 0 ? pw : 0) / 2;
+    }
+    const int n = a.oh * a.ow;
+    epilogue_kernel<<<dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
     return NTX_OK;
 }
 

@@ -523,14 +523,10 @@ NTX_DEV float wave_sum(float v) {
     return v;
 }
 
+// the scan itself: `a` = this sample's alpha in [0,1], `c` = its mapped colour
 template <int W>
-NTX_DEV void composite_step(RayAccum &ra, float sigma, const float (&raw)[3], float dist, bool valid,
-                            uint32_t flags, int j, float *w_out) {
-    float c[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) c[k] = (flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[k]) : sigmoidf_(raw[k]);
-    const float a = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * dist) : 0.0f;   // :195
-    const float trans = (1.0f - a) + 1e-10f;                                          // :198
+NTX_DEV void composite_core(RayAccum &ra, float a, const float (&c)[3], bool valid, int j, float *w_out) {
+    const float trans = (1.0f - a) + 1e-10f;                                          // renderer.py:198 / 342
     float P = trans;   // inclusive product scan over the W lanes of the batch
 #pragma unroll
     for (int d = 1; d < W; d <<= 1) {
@@ -546,6 +542,16 @@ NTX_DEV void composite_step(RayAccum &ra, float sigma, const float (&raw)[3], fl
     ra.c2 += wave_sum<W>(valid ? w * c[2] : 0.0f);
     ra.a += wave_sum<W>(valid ? w : 0.0f);
     ra.T *= __shfl(P, W - 1, W);
+}
+
+template <int W>
+NTX_DEV void composite_step(RayAccum &ra, float sigma, const float (&raw)[3], float dist, bool valid,
+                            uint32_t flags, int j, float *w_out) {
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = (flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[k]) : sigmoidf_(raw[k]);   // :182-187
+    const float a = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * dist) : 0.0f;                  // :195
+    composite_core<W>(ra, a, c, valid, j, w_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -632,6 +638,117 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
                 if (!(__builtin_fabsf(s) <= 3.0e38f)) atomicOr(a.status, 1);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// InstanceRenderer tail (renderer.py:247-354) on the buffers of instancer.get_model_input
+// (instancer.pyx:38-54).  One wave per hit ray: (1) wave-level compaction of the in-patch samples
+// (dists > 0, renderer.py:284-288) into an index list in LDS, (2) the MLP on 32 compacted samples at a
+// time with per-sample directions and parameters, (3) the scan, (4) the appended sample
+// (color_last, alpha_last; renderer.py:331,339).  Skipped samples have alpha 0, i.e. a transmittance
+// factor (1-0)+1e-10 == 1.0f in float32, so leaving them out of the scan is exact.
+// ---------------------------------------------------------------------------------------------
+constexpr int MAX_INSTANCE_SAMPLES = 4096;
+
+struct InstanceArgs {
+    const f32x4 *wstream;
+    uint32_t stream_bytes;
+    const float *aux;
+    const float *rays_d_map, *pts, *t, *dists, *color_last, *alpha_last, *alpha_weight, *params_map, *cone;
+    const float *instance_color;
+    const int32_t *instance_id;
+    const uint8_t *hit;
+    float *color_out, *alpha_out;
+    int32_t *status;
+    int64_t n_rays;
+    int n_samples, blur_idx;
+    uint32_t flags;
+    float patch_scale, density_scale;
+    float bkgd[3];
+};
+
+template <class CFG>
+__global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
+    __shared__ __attribute__((aligned(16))) float aux[aux_total()];
+    __shared__ uint16_t sidx_all[4][MAX_INSTANCE_SAMPLES];
+    load_aux(aux, a.aux, aux_total());
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int nwaves = gridDim.x * 4;
+    const int S = a.n_samples;
+    uint16_t *sidx = sidx_all[wv];
+    WStream ws;
+    ws_prime(ws, a.wstream, a.stream_bytes, lane);
+
+    for (int64_t ray = wave; ray < a.n_rays; ray += nwaves) {
+        if (!a.hit[ray]) {   // renderer.py:265-272, 313-314: stays 0, also under composite_bkgd
+            if (lane < 3) a.color_out[3 * ray + lane] = 0.0f;
+            if (lane == 3) a.alpha_out[ray] = 0.0f;
+            continue;
+        }
+        const float *drow = a.dists + ray * S;
+        int count = 0;
+        for (int base = 0; base < S; base += 64) {
+            const int i = base + lane;
+            const bool v = i < S && drow[i] > 0.0f;
+            const unsigned long long m = __ballot(v);
+            if (v) sidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            count += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float cone = a.cone ? a.cone[ray] : 0.0f;
+        RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        const int nb = (count + 31) >> 5;
+        for (int b = 0; b < nb; ++b) {
+            const int k = 32 * b + j;
+            const bool valid = k < count;
+            const int64_t sm = ray * S + sidx[valid ? k : 0];
+            SampleIn<CFG::NGEO, CFG::NAPP> in;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { in.pos[c] = a.pts[3 * sm + c]; in.dir[c] = a.rays_d_map[3 * sm + c]; }
+#pragma unroll
+            for (int c = 0; c < CFG::NP; ++c) {
+                float p = a.params_map[CFG::NP * sm + c];
+                if (c == a.blur_idx) p = p * (cone * a.t[sm] / a.patch_scale);                     // renderer.py:259-262
+                in.par[c] = p;
+            }
+            float sigma, raw[3];
+            mlp_batch<CFG>(in, ws, aux, lane, sigma, raw);
+            const float wgt = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // :300
+            sigma = sigma * wgt;
+            float col[3];
+            if (a.instance_color) {                                                                // :306-307, 322-323
+                const int id = a.instance_id[sm];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) col[c] = a.instance_color[3 * id + c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) col[c] = (a.flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[c]) : sigmoidf_(raw[c]);
+            }
+            const float al = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * a.dists[sm] / a.patch_scale) : 0.0f;   // :339
+            composite_core<32>(ra, al, col, valid, j, nullptr);
+        }
+        // the appended sample: colour taken as is, alpha_last is an alpha (not a density)
+        const float wl = a.alpha_last[ray] * ra.T;
+        float out[4] = {ra.c0 + wl * a.color_last[3 * ray], ra.c1 + wl * a.color_last[3 * ray + 1],
+                        ra.c2 + wl * a.color_last[3 * ray + 2], ra.a + wl};
+        if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {   // renderer.py:351-352
+            const float A = out[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[c] = out[c] + (1.0f - A) * a.bkgd[c];
+        }
+        if (lane == 0) {
+            a.color_out[3 * ray + 0] = out[0]; a.color_out[3 * ray + 1] = out[1];
+            a.color_out[3 * ray + 2] = out[2]; a.alpha_out[ray] = out[3];
+            if ((a.flags & NTX_FLAG_CHECK_NUMERICS) && a.status) {
+                const float sm_ = out[0] + out[1] + out[2] + out[3];
+                if (!(__builtin_fabsf(sm_) <= 3.0e38f)) atomicOr(a.status, 1);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // the index list is rewritten by the next ray
     }
 }
 

@@ -134,4 +134,56 @@ __global__ __launch_bounds__(256) void fourier_kernel(const float *x, int64_t m,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// image epilogue (logger.py:128-144, util/interpolate.py:68-82): separable gaussian taps, stride = factor,
+// TensorFlow 'SAME' zero padding, un-premultiply, optional uint8.  One thread per output pixel.
+// ---------------------------------------------------------------------------------------------
+constexpr int MAX_EPILOGUE_TAPS = 48;
+
+struct EpilogueArgs {
+    const float *rgba;
+    float *out_f32;
+    uint8_t *out_u8;
+    int h, w, oh, ow, factor, taps, pad_top, pad_left;
+    int unpremultiply;
+    float k1[MAX_EPILOGUE_TAPS];   // normalised 1-D gaussian: the 2-D kernel is k1[i]*k1[j]
+};
+
+__global__ __launch_bounds__(256) void epilogue_kernel(EpilogueArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.oh * a.ow) return;
+    const int oy = idx / a.ow, ox = idx % a.ow;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.factor > 1) {
+        for (int i = 0; i < a.taps; ++i) {
+            const int y = oy * a.factor + i - a.pad_top;
+            if (y < 0 || y >= a.h) continue;
+            for (int j = 0; j < a.taps; ++j) {
+                const int x = ox * a.factor + j - a.pad_left;
+                if (x < 0 || x >= a.w) continue;
+                const float wgt = a.k1[i] * a.k1[j];
+                const f32x4 p = reinterpret_cast<const f32x4 *>(a.rgba)[(int64_t)y * a.w + x];
+                acc[0] = __builtin_fmaf(wgt, p.x, acc[0]); acc[1] = __builtin_fmaf(wgt, p.y, acc[1]);
+                acc[2] = __builtin_fmaf(wgt, p.z, acc[2]); acc[3] = __builtin_fmaf(wgt, p.w, acc[3]);
+            }
+        }
+    } else {
+        const f32x4 p = reinterpret_cast<const f32x4 *>(a.rgba)[idx];
+        acc[0] = p.x; acc[1] = p.y; acc[2] = p.z; acc[3] = p.w;
+    }
+    if (a.unpremultiply) {   // logger.py:133-135
+        const float d = acc[3] + 1e-5f;
+        acc[0] = acc[0] / d; acc[1] = acc[1] / d; acc[2] = acc[2] / d;
+    }
+    if (a.out_f32) reinterpret_cast<f32x4 *>(a.out_f32)[idx] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    if (a.out_u8) {          // tf.image.convert_image_dtype: saturate(x * 255.5), truncated
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = acc[c] * 255.5f;
+            v = v != v ? 0.0f : __builtin_fminf(__builtin_fmaxf(v, 0.0f), 255.0f);
+            a.out_u8[4 * (int64_t)idx + c] = (uint8_t)v;
+        }
+    }
+}
+
 }  // namespace ntx

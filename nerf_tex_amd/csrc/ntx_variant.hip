@@ -29,6 +29,11 @@ hipError_t NTX_FN(launch_render)(int n_wgs, RenderArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
+hipError_t NTX_FN(launch_instance)(int n_wgs, InstanceArgs &a, hipStream_t st) {
+    instance_kernel<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
+    return hipGetLastError();
+}
+
 hipError_t NTX_FN(launch_mlp)(int n_wgs, MlpArgs &a, hipStream_t st) {
     mlp_kernel<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
     return hipGetLastError();

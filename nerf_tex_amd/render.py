@@ -15,11 +15,30 @@ from . import util
 
 
 def render_image(renderer, dataset, data: dict):
-    """logger.Logger.render_image (logger.py:121-126): premultiplied RGBA [H, W, 4]."""
+    """logger.Logger.render_image up to the packing (logger.py:121-126): premultiplied RGBA [B, H, W, 4]."""
     import torch
     pred = renderer(**data, composite_bkgd=dataset.composite_bkgd, bkgd_color=dataset.bkgd_color, training=False)
     img = torch.cat([pred["color_pred"].reshape(-1, 3), pred["alpha_pred"].reshape(-1, 1)], -1)
     return img.reshape(-1, dataset.height, dataset.width, 4)
+
+
+def image_epilogue(rgba, downsampling_factor: int = 1, write_exr: bool = False, uint8: bool = False):
+    """The rest of logger.Logger.render_image / write_image (logger.py:128-144) on one [H,W,4] premultiplied
+    image: filtered downsample (util/interpolate.py:78-82), un-premultiply unless EXR, optional uint8
+    (`ntx_image_epilogue`).  Returns the float32 image, or (float32, uint8) when `uint8`."""
+    import torch
+    from . import _lib
+    rgba = rgba.contiguous().float()
+    h, w = rgba.shape[0], rgba.shape[1]
+    f = int(downsampling_factor)
+    oh, ow = -(-h // f), -(-w // f)
+    out = torch.empty((oh, ow, 4), device=rgba.device, dtype=torch.float32)
+    u8 = torch.empty((oh, ow, 4), device=rgba.device, dtype=torch.uint8) if uint8 else None
+    with torch.cuda.device(rgba.device):
+        _lib.check(_lib.lib.ntx_image_epilogue(rgba.data_ptr(), h, w, f, 0 if write_exr else 1, out.data_ptr(),
+                                               u8.data_ptr() if uint8 else None,
+                                               torch.cuda.current_stream(rgba.device).cuda_stream))
+    return (out, u8) if uint8 else out
 
 
 def Render(target_path: Optional[str], test_dataset_config, model_config, renderer_config, logger_config=None,

@@ -125,3 +125,96 @@ class Renderer:
                                               n, S, flags, _lib.f3(bk), c_out.data_ptr(), a_out.data_ptr(),
                                               w_out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
         return c_out, a_out, w_out
+
+
+class InstanceRenderer(Renderer):
+    """network.renderer.InstanceRenderer (renderer.py:215-354): the renderer the shipped render configs use.
+
+    The patch instancer itself (C++/Embree, instancer/) is outside this package; what is implemented here is
+    everything downstream of `instancer.get_model_input(rays_o, rays_d, parameters, n_samples, step_size)`
+    (instancer.pyx:38-54), fused into one launch of `ntx_render_instanced` per render chunk.  `instancer` is
+    any object with that method (the reference's Cython `Instancer`, or a stand-in) returning, as numpy arrays
+    or tensors: rays_d_map [n,S,3], pts [n,S,3], t [n,S], dists [n,S], color_last [n,1,3], alpha_last [n,1],
+    alpha_weight [n,S], instance_id [n,S] int32, idxs (indices of the hit rays, `tf.where(hit)`-shaped [k,1]
+    or a bool mask [n]), params_map [n,S,P]."""
+
+    def __init__(self, instancer_config=None, step_size: float = 0.002, density_scale: float = 1,
+                 density_reweighting: bool = True, false_color: bool = False, instancer=None, patch_scale=None,
+                 **kwargs) -> None:
+        kwargs.setdefault("perturb", False)       # the instancer, not the renderer, places the samples
+        super().__init__(**kwargs)
+        if instancer is None:
+            from . import util
+            instancer = util.instantiate(instancer_config)
+        self.instancer = instancer
+        self.step_size = step_size
+        self.density_scale = density_scale
+        self.density_reweighting = density_reweighting
+        self.false_color = false_color
+        self.instance_color = None
+        if false_color:                                                       # renderer.py:226-227
+            import numpy as np
+            self.instance_color = np.random.uniform(size=(self.instancer.n_instances(), 3)).astype("float32")
+        self.patch_scale = float(patch_scale if patch_scale is not None else instancer_config["patch_scale"])   # :228
+
+    def __call__(self, rays_o, rays_d, t, parameters, cone_scale, composite_bkgd: bool = False,
+                 bkgd_color=[1, 1, 1.], training: bool = False, **kwargs) -> dict:
+        import numpy as np
+        import torch
+        assert training is False, "InstanceRenderer can only be used for evaluation (renderer.py:233)"
+        dev = rays_o.device
+        B, HW = rays_o.shape[0], rays_o.shape[1]
+        n = B * HW
+        o_f = rays_o.reshape(n, 3).float(); d_f = rays_d.reshape(n, 3).float(); t_f = t.reshape(n, 2).float()
+        c_f = cone_scale.reshape(n).float()
+        p_f = parameters.reshape(B, -1).float().repeat_interleave(HW, dim=0)                    # renderer.py:54
+        keep = (t_f[:, 0] != float("inf")).nonzero(as_tuple=False)[:, 0]                        # renderer.py:58
+        color = torch.zeros((n, 3), device=dev, dtype=torch.float32)
+        alpha = torch.zeros((n,), device=dev, dtype=torch.float32)
+        bk = bkgd_color.detach().cpu().tolist() if hasattr(bkgd_color, "detach") else list(bkgd_color)
+        flags = (_lib.FLAG_MAP_EXR if self.map_exr else 0) | (_lib.FLAG_COMPOSITE_BKGD if composite_bkgd else 0)
+        status = None
+        if self.check_numerics:
+            flags |= _lib.FLAG_CHECK_NUMERICS
+            status = torch.zeros(1, device=dev, dtype=torch.int32)
+        inst_col = None
+        if self.instance_color is not None:
+            inst_col = torch.as_tensor(self.instance_color, device=dev)
+        S = self.n_samples
+        up = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(np.asarray(a)), device=dev).to(dt).contiguous()
+        for i in range(0, keep.shape[0], self.render_chunk):                                    # renderer.py:72-73
+            sl = keep[i:i + self.render_chunk]
+            k = sl.shape[0]
+            ro_c, rd_c, p_c = o_f[sl], d_f[sl], p_f[sl]
+            (rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map) = \
+                self.instancer.get_model_input(ro_c.cpu().numpy(), rd_c.cpu().numpy(), p_c.cpu().numpy(), S, self.step_size)
+            idxs = np.asarray(idxs)
+            hit = np.zeros(k, dtype=np.uint8)
+            if idxs.dtype == np.bool_:
+                hit[idxs.reshape(-1)] = 1
+            else:
+                hit[idxs.reshape(-1).astype(np.int64)] = 1
+            bufs = dict(rays_d_map=up(rays_d_map), pts=up(pts), t=up(tt), dists=up(dists),
+                        color_last=up(color_last).reshape(k, 3), alpha_last=up(alpha_last).reshape(k),
+                        alpha_weight=up(alpha_weight) if self.density_reweighting else None,
+                        instance_id=up(instance_id, torch.int32), hit=up(hit, torch.uint8), params_map=up(params_map))
+            c_c = c_f[sl].contiguous()
+            col_c = torch.empty((k, 3), device=dev, dtype=torch.float32)
+            al_c = torch.empty((k,), device=dev, dtype=torch.float32)
+            ptr = lambda x: x.data_ptr() if x is not None else None
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib.ntx_render_instanced(
+                    self.model.ctx(dev.index or 0), ptr(bufs["rays_d_map"]), ptr(bufs["pts"]), ptr(bufs["t"]),
+                    ptr(bufs["dists"]), ptr(bufs["color_last"]), ptr(bufs["alpha_last"]), ptr(bufs["alpha_weight"]),
+                    ptr(bufs["instance_id"]), ptr(bufs["hit"]), ptr(bufs["params_map"]) if self.model.n_params else None,
+                    ptr(c_c), k, S, -1 if self.blur_idx is None else int(self.blur_idx), self.patch_scale,
+                    float(self.density_scale), flags, _lib.f3(bk), ptr(inst_col), ptr(col_c), ptr(al_c), ptr(status),
+                    torch.cuda.current_stream(dev).cuda_stream))
+            color[sl] = col_c                                                                  # scatter_nd, renderer.py:83
+            alpha[sl] = al_c
+        if composite_bkgd:                                                                     # renderer.py:85-86
+            miss = torch.ones(n, dtype=torch.bool, device=dev); miss[keep] = False
+            color[miss] += torch.as_tensor(bk, device=dev, dtype=torch.float32)
+        if status is not None:
+            self._status = status
+        return {"color_pred": color.reshape(B, HW, 3), "alpha_pred": alpha.reshape(B, HW)}

@@ -409,10 +409,134 @@ def renderer_call(weights, spec, rays_o, rays_d, t, parameters, cone_scale, n_sa
     return result
 
 
+def instance_map_model_output(color, color_last, alpha, alpha_last, dists, patch_scale, composite_bkgd, bkgd_color,
+                              map_exr=False, false_color=False, dtype=F32):
+    """InstanceRenderer.map_model_output (renderer.py:318-354): S marched samples plus ONE appended
+    sample (color_last [n,1,3] taken as is, alpha_last [n,1] taken as an alpha, not a density)."""
+    color = np.asarray(color, dtype=dtype); alpha = np.asarray(alpha, dtype=dtype)
+    dists = np.asarray(dists, dtype=dtype)
+    color_last = np.asarray(color_last, dtype=dtype); alpha_last = np.asarray(alpha_last, dtype=dtype)
+    if false_color:                                                              # :322-323
+        color_map = np.concatenate([color, color_last], axis=1)
+    else:
+        with np.errstate(over="ignore"):
+            if map_exr:                                                          # :325-327
+                cm = np.where(color > 0, color, np.exp(np.minimum(color, dtype(0))) - dtype(1)) + dtype(1)
+            else:                                                                # :329-330
+                cm = dtype(1) / (dtype(1) + np.exp(-color))
+        color_map = np.concatenate([cm, color_last], axis=1)                     # :331
+    alpha_map = np.concatenate([dtype(1) - np.exp(-np.maximum(alpha, dtype(0)) * dists / dtype(patch_scale)),
+                                alpha_last], axis=1)                             # :339
+    trans = (dtype(1.) - alpha_map) + dtype(1e-10)
+    cum = np.cumprod(trans, axis=-1, dtype=dtype)
+    excl = np.concatenate([np.ones_like(cum[..., :1]), cum[..., :-1]], -1)
+    weights = alpha_map * excl                                                   # :342
+    color_out = np.sum(weights[..., None] * color_map, axis=-2, dtype=dtype)     # :345
+    alpha_out = np.sum(weights, -1, dtype=dtype)                                 # :348
+    if composite_bkgd:                                                           # :351-352
+        color_out = color_out + (dtype(1.) - alpha_out[..., None]) * np.asarray(bkgd_color, dtype=dtype)
+    return color_out.astype(dtype), alpha_out.astype(dtype)
+
+
+def instance_evaluate_model(weights, spec, rays_d_map, pts, t, dists, color_last, alpha_last, alpha_weight, instance_id,
+                            hit, params_map, cone_scale, blur_idx=None, patch_scale=1.0, density_scale=1.0,
+                            density_reweighting=True, map_exr=False, composite_bkgd=False, bkgd_color=(1., 1., 1.),
+                            instance_color=None, net_chunk=65536, dtype=F32):
+    """InstanceRenderer.evaluate_model (renderer.py:247-316) downstream of `instancer.get_model_input`
+    (instancer.pyx:38-54), whose buffers are the arguments: rays_d_map/pts [n,S,3], t/dists/alpha_weight [n,S],
+    color_last [n,1,3], alpha_last [n,1], instance_id [n,S] int32, hit [n] bool, params_map [n,S,P].
+    `instance_color` [n_instances,3] switches on the false-colour mode (renderer.py:226-227, 309-310)."""
+    n_rays, S = dists.shape
+    rays_d_map = np.asarray(rays_d_map, dtype=dtype); pts = np.asarray(pts, dtype=dtype)
+    t = np.asarray(t, dtype=dtype); dists = np.asarray(dists, dtype=dtype)
+    params_map = np.asarray(params_map, dtype=dtype); cone_scale = np.asarray(cone_scale, dtype=dtype).reshape(n_rays, 1)
+    idxs = np.nonzero(np.asarray(hit))[0]
+    if idxs.shape[0] == 0:                                                       # :255-256
+        return np.zeros((n_rays, 3), dtype), np.zeros((n_rays,), dtype)
+    if blur_idx is not None:                                                     # :259-262
+        blur_scale = cone_scale[..., None, :] * t[..., :, None] / dtype(patch_scale)
+        params_map = np.concatenate([params_map[..., :blur_idx], params_map[..., blur_idx, None] * blur_scale,
+                                     params_map[..., blur_idx + 1:]], axis=-1)
+    g = lambda a: np.asarray(a)[idxs]                                            # :265-272
+    rays_d_map, pts, dists, params_map = g(rays_d_map), g(pts), g(dists), g(params_map)
+    color_last, alpha_last = g(np.asarray(color_last, dtype=dtype)), g(np.asarray(alpha_last, dtype=dtype))
+    alpha_weight, instance_id = g(np.asarray(alpha_weight, dtype=dtype)), g(instance_id)
+    pos_flat = pts.reshape(-1, 3); dirs_flat = rays_d_map.reshape(-1, 3)
+    params_flat = params_map.reshape(pos_flat.shape[0], params_map.shape[-1])
+    n_pts = pos_flat.shape[0]
+    idxs_pts = np.nonzero(dists.reshape(-1) > 0)[0]                              # :284
+    color = np.zeros((n_pts, 3), dtype); alpha = np.zeros((n_pts, 1), dtype)     # scatter_nd zeros :296-298 / :302-303
+    if idxs_pts.shape[0] > 0:
+        cs, as_ = [], []
+        for i in range(0, idxs_pts.shape[0], net_chunk):                         # :290-293
+            sl = idxs_pts[i:i + net_chunk]
+            c, a = model_forward(weights, spec, pos_flat[sl], dirs_flat[sl], params_flat[sl], dtype)
+            cs.append(c); as_.append(a)
+        color[idxs_pts] = np.concatenate(cs, 0); alpha[idxs_pts] = np.concatenate(as_, 0)
+        alpha = alpha.reshape(pts.shape[:-1])
+        alpha = alpha * (alpha_weight if density_reweighting else dtype(1)) * dtype(density_scale)   # :300
+    else:
+        alpha = alpha.reshape(pts.shape[:-1])
+    color = color.reshape(pts.shape)
+    if instance_color is not None:                                               # :306-307
+        color = np.asarray(instance_color, dtype=dtype)[instance_id.reshape(-1)].reshape(color.shape)
+    cm, am = instance_map_model_output(color, color_last, alpha, alpha_last, dists, patch_scale, composite_bkgd,
+                                       bkgd_color, map_exr, instance_color is not None, dtype)
+    color_map = np.zeros((n_rays, 3), dtype); alpha_map = np.zeros((n_rays,), dtype)   # :313-314: culled rays stay 0,
+    color_map[idxs] = cm; alpha_map[idxs] = am                                         # even with composite_bkgd
+    return color_map, alpha_map
+
+
 def render_image_rgba(pred, height, width):
     """logger.Logger.render_image packing only (logger.py:126): [H, W, 4] premultiplied RGBA."""
     return np.concatenate([pred["color_pred"].reshape(-1, 3), pred["alpha_pred"].reshape(-1, 1)], -1) \
              .reshape(height, width, 4)
+
+
+def gaussian_kernel_1d(size: int, std: float, dtype=F32):
+    """util.interpolate.gaussian_kernel (interpolate.py:68-76), 1-D factor before normalisation.  Note the
+    reference shifts the taps by +0.5 when `size` is even (line 71)."""
+    x = np.linspace(-(size - 1) / 2, (size - 1) / 2, size).astype(dtype) + dtype(.5 if size % 2 == 0 else 0)
+    return np.exp(dtype(-.5) * (x / dtype(std)) ** 2).astype(dtype)
+
+
+def filtered_downsample(img, downsampling_factor: int, std: float = .5, dtype=F32):
+    """util.interpolate.filtered_downsample (interpolate.py:78-82): depthwise 2-D cross-correlation with the
+    normalised gaussian, stride = factor, TensorFlow 'SAME' zero padding.  img [H,W,C] -> [ceil(H/f),ceil(W/f),C]."""
+    img = np.asarray(img, dtype=dtype)
+    f = int(downsampling_factor)
+    K = int(f * std * 6)
+    k1 = gaussian_kernel_1d(K, f * std, dtype)
+    k2 = np.tensordot(k1, k1, axes=0)
+    k2 = (k2 / np.sum(k2, dtype=dtype)).astype(dtype)
+    H, W, C = img.shape
+    oh, ow = -(-H // f), -(-W // f)
+    ph = max((oh - 1) * f + K - H, 0); pw = max((ow - 1) * f + K - W, 0)
+    pad = np.zeros((H + ph, W + pw, C), dtype)
+    pad[ph // 2:ph // 2 + H, pw // 2:pw // 2 + W] = img
+    out = np.zeros((oh, ow, C), dtype)
+    for i in range(K):
+        for j in range(K):
+            out += k2[i, j] * pad[i:i + (oh - 1) * f + 1:f, j:j + (ow - 1) * f + 1:f]
+    return out
+
+
+def image_epilogue(rgba, downsampling_factor: int = 1, write_exr: bool = False, dtype=F32):
+    """logger.Logger.render_image after the renderer (logger.py:128-137): optional filtered downsample, then
+    (unless EXR output) premultiplied -> straight colour, rgb / (a + 1e-5)."""
+    img = np.asarray(rgba, dtype=dtype)
+    if downsampling_factor > 1:                                                  # :129-130
+        img = filtered_downsample(img, downsampling_factor, dtype=dtype)
+    if not write_exr:                                                            # :133-135
+        img = np.concatenate([img[..., :3] / (img[..., 3:] + dtype(1e-5)), img[..., 3:]], axis=-1)
+    return img
+
+
+def to_uint8(img):
+    """tf.image.convert_image_dtype(float32 -> uint8) as logger.write_image uses it (logger.py:144):
+    saturating cast of x * 255.5 (truncation)."""
+    x = np.asarray(img, dtype=F32) * F32(255.5)
+    return np.clip(np.nan_to_num(x, nan=0.0), 0, 255).astype(np.uint8)
 
 
 def rel_linf(out, ref) -> float:

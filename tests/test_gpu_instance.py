@@ -1,0 +1,88 @@
+"""InstanceRenderer tail against the oracle, with a synthetic instancer standing in
+for the reference's Embree one (its output contract: instancer.pyx:38-54).  `-m gpu`."""
+
+import numpy as np
+import pytest
+
+from oracle import nerftex_oracle as orc
+from tests.common import TOL, make_model
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class FakeInstancer:
+    """Random in-patch segments per ray: exactly the buffer shapes/dtypes of instancer.get_model_input."""
+
+    def __init__(self, n_params, seed=0, p_hit=0.8, p_in=0.35, n_inst=7):
+        self.rng = np.random.default_rng(seed)
+        self.n_params, self.p_hit, self.p_in, self.n_inst = n_params, p_hit, p_in, n_inst
+        self.last = None
+
+    def n_instances(self):
+        return self.n_inst
+
+    def get_model_input(self, rays_o, rays_d, parameters, n_samples, step_size):
+        rng = self.rng
+        n, S = rays_o.shape[0], n_samples
+        rays_d_map = rng.normal(size=(n, S, 3)); rays_d_map /= np.linalg.norm(rays_d_map, axis=-1, keepdims=True)
+        pts = rng.uniform(-1.2, 1.2, size=(n, S, 3))
+        t = np.sort(rng.uniform(2, 8, size=(n, S)), -1)
+        inside = rng.uniform(size=(n, S)) < self.p_in
+        dists = np.where(inside, rng.uniform(0.5, 2.0, size=(n, S)) * step_size, 0.0)
+        dists[rng.uniform(size=(n, S)) < 0.05] = -step_size          # "outside" can also be negative
+        hit = rng.uniform(size=n) < self.p_hit
+        if n > 3:
+            hit[0] = True; inside[0] = False; dists[0] = 0.0          # hit ray with no in-patch sample
+            hit[1] = False
+        color_last = rng.uniform(0, 1, size=(n, 1, 3)); alpha_last = (rng.uniform(size=(n, 1)) < 0.5).astype(np.float64)
+        alpha_weight = 1.0 / rng.integers(1, 4, size=(n, S))
+        instance_id = rng.integers(0, self.n_inst, size=(n, S)).astype(np.int32)
+        params_map = np.repeat(parameters[:, None, :], S, axis=1) * rng.uniform(0.5, 1.0, size=(n, S, 1))
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        out = (f(rays_d_map), f(pts), f(t), f(dists), f(color_last), f(alpha_last), f(alpha_weight), instance_id,
+               np.nonzero(hit)[0][:, None], f(params_map))
+        self.last = out + (hit,)
+        return out
+
+
+@pytest.mark.parametrize("npar,blur", [((1, 6), None), ((2, 3), 0), ((1, 4), None)])
+@pytest.mark.parametrize("S", [40, 200])
+@pytest.mark.parametrize("opts", [dict(), dict(composite_bkgd=True, map_exr=True), dict(density_reweighting=False, density_scale=30.0),
+                                  dict(false_color=True)])
+def test_instance_renderer(npar, blur, S, opts):
+    from nerf_tex_amd.renderer import InstanceRenderer
+    opts = dict(opts)
+    bk = opts.pop("composite_bkgd", False)
+    model, spec, w = make_model(npar, dense_media=True)
+    P = sum(npar)
+    inst = FakeInstancer(P, seed=S + P)
+    patch_scale, step = 0.09, 0.002
+    r = InstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=patch_scale, step_size=step, blur_idx=blur,
+                         render_chunk=10_000, density_scale=opts.pop("density_scale", 400.0), **opts)
+    rng = np.random.default_rng(1)
+    n = 61
+    ro = rng.normal(size=(1, n, 3)).astype(np.float32); rd = rng.normal(size=(1, n, 3)).astype(np.float32)
+    t = np.tile(np.asarray([[1.0, 2.0]], np.float32), (1, n, 1)); t[0, 5] = np.inf      # one ray culled by the proxy
+    params = rng.uniform(0.2, 1, size=(1, P)).astype(np.float32)
+    cone = rng.uniform(1e-3, 5e-3, size=(1, n, 1)).astype(np.float32)
+    dv = torch.device("cuda", 0)
+    d = lambda a: torch.as_tensor(a, device=dv)
+    out = r(d(ro), d(rd), d(t), parameters=d(params), cone_scale=d(cone), composite_bkgd=bk, bkgd_color=[.3, .6, .9])
+    r.raise_if_nonfinite()
+    # oracle on the very buffers the fake instancer handed out (it saw the n-1 rays that survive the t cull)
+    rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map, hit = inst.last
+    keep = np.isfinite(t[0, :, 0])
+    rc, ra = orc.instance_evaluate_model(w, spec, rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id,
+                                         hit, params_map, cone[0][keep], blur, patch_scale, r.density_scale, r.density_reweighting,
+                                         r.map_exr, bk, (.3, .6, .9), r.instance_color, dtype=np.float64)
+    want_c = np.zeros((n, 3)); want_a = np.zeros(n)
+    want_c[keep] = rc; want_a[keep] = ra
+    if bk:
+        want_c[~keep] = (.3, .6, .9)                                  # renderer.py:85-86: only proxy-culled rays
+    got = np.concatenate([out["color_pred"][0].cpu().numpy(), out["alpha_pred"][0].cpu().numpy()[:, None]], -1)
+    want = np.concatenate([want_c, want_a[:, None]], -1)
+    assert orc.rel_linf(got, want) <= TOL
+    kept = np.nonzero(keep)[0]
+    assert np.all(got[kept[~hit]] == 0.0)                             # un-hit rays stay 0, even with background (:313-314)
+    assert float(want_a.max()) > 0.3

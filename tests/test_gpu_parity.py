@@ -203,3 +203,20 @@ def test_full_size_properties():
     got = np.concatenate([c[idx].cpu().numpy(), a[idx].cpu().numpy()[:, None]], -1)
     want = np.concatenate([ref["color_pred"], ref["alpha_pred"][:, None]], -1)
     assert orc.rel_linf(got, want) <= TOL
+
+
+@pytest.mark.parametrize("h,w,f", [(64, 48, 1), (64, 48, 2), (50, 37, 2), (96, 96, 4), (33, 65, 3)])
+@pytest.mark.parametrize("exr", [False, True])
+def test_image_epilogue(h, w, f, exr):
+    """logger.py:128-144 + interpolate.py:68-82."""
+    from nerf_tex_amd.render import image_epilogue
+    rng = np.random.default_rng(h * w + f)
+    a = rng.uniform(0, 1, size=(h, w, 1)); a[rng.uniform(size=(h, w, 1)) < 0.3] = 0.0
+    rgba = np.concatenate([rng.uniform(0, 1, size=(h, w, 3)) * a, a], -1).astype(np.float32)
+    out, u8 = image_epilogue(to_dev(rgba)[0], f, write_exr=exr, uint8=True)
+    ref = orc.image_epilogue(rgba, f, exr, np.float64)
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out.cpu().numpy() - ref)) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+    ref8 = orc.to_uint8(ref)
+    d8 = np.abs(u8.cpu().numpy().astype(int) - ref8.astype(int))
+    assert d8.max() <= 1 and (d8 > 0).mean() < 0.01          # float32 vs float64 may straddle a truncation boundary

@@ -199,3 +199,43 @@ def test_renderer_call_is_per_ray(seed):
     b = orc.renderer_call(w, spec, ro[None, perm], rd[None, perm], t[None, perm], prm, cone[None, perm], S, dtype=np.float64)
     np.testing.assert_allclose(b["color_pred"][0], a["color_pred"][0][perm], rtol=1e-12, atol=1e-15)
     assert np.all(a["alpha_pred"][0][np.isinf(t[:, 0])] == 0)
+
+
+def test_filtered_downsample_and_epilogue():
+    """interpolate.py:68-82 / logger.py:128-144 restatement: normalisation, SAME output size, even-size shift."""
+    for f, K in ((2, 6), (3, 9), (4, 12)):
+        k1 = orc.gaussian_kernel_1d(K, f * .5, np.float64)
+        assert k1.shape == (K,)
+        if K % 2 == 0:
+            assert np.argmax(k1) == K // 2 - 1 or k1[K // 2 - 1] > k1[K // 2]   # +0.5 shift: asymmetric taps (reference quirk)
+    img = np.ones((37, 50, 4))
+    out = orc.filtered_downsample(img, 2, dtype=np.float64)
+    assert out.shape == (19, 25, 4)
+    np.testing.assert_allclose(out[3:-3, 3:-3], 1.0, atol=1e-12)                # interior: kernel sums to 1
+    assert out[0, 0, 0] < 1.0                                                    # zero padding at the border
+    rgba = np.zeros((4, 4, 4)); rgba[..., :3] = 0.25; rgba[..., 3] = 0.5
+    e = orc.image_epilogue(rgba, 1, False, np.float64)
+    np.testing.assert_allclose(e[..., :3], 0.25 / (0.5 + 1e-5)); np.testing.assert_allclose(e[..., 3], 0.5)
+    np.testing.assert_array_equal(orc.image_epilogue(rgba, 1, True, np.float64), rgba)
+    np.testing.assert_array_equal(orc.to_uint8(np.asarray([0.0, 1.0, 0.5, -1.0, 2.0, 0.999])), [0, 255, 127, 0, 255, 255])
+
+
+def test_instance_tail_properties():
+    """InstanceRenderer tail (renderer.py:247-354): a ray with no in-patch sample returns its appended sample;
+    skipped samples never contribute; un-hit rays are 0 even with a background."""
+    spec = orc.ModelSpec(kind="Nerf")
+    w = orc.split_blob(spec, synthetic.synthetic_weights(orc.layer_table(spec), seed=2))
+    rng = np.random.default_rng(0)
+    n, S = 6, 9
+    rd = rng.normal(size=(n, S, 3)); pts = rng.normal(size=(n, S, 3)); t = rng.uniform(1, 2, size=(n, S))
+    dists = rng.uniform(0.001, 0.003, size=(n, S)); dists[0] = 0; dists[1, ::2] = -1
+    cl = rng.uniform(size=(n, 1, 3)); al = np.ones((n, 1)); aw = np.ones((n, S)); ids = np.zeros((n, S), np.int32)
+    hit = np.array([1, 1, 1, 0, 1, 1], bool); prm = np.zeros((n, S, 0)); cone = np.zeros((n, 1))
+    c, a = orc.instance_evaluate_model(w, spec, rd, pts, t, dists, cl, al, aw, ids, hit, prm, cone, None, 0.09, 50.0, True,
+                                       False, True, (1, 1, 1.), None, dtype=np.float64)
+    np.testing.assert_allclose(c[0], cl[0, 0], atol=1e-9); assert abs(a[0] - 1) < 1e-9     # only the opaque appended sample
+    assert np.all(c[3] == 0) and a[3] == 0                                                # un-hit: 0 despite composite_bkgd
+    pts2 = pts.copy(); pts2[1, ::2] = 1e3                                                 # moving skipped samples changes nothing
+    c2, a2 = orc.instance_evaluate_model(w, spec, rd, pts2, t, dists, cl, al, aw, ids, hit, prm, cone, None, 0.09, 50.0, True,
+                                         False, True, (1, 1, 1.), None, dtype=np.float64)
+    np.testing.assert_array_equal(c2, c)
