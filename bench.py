@@ -72,6 +72,21 @@ def cpu_baseline(family: str, n_samples: int, target_seconds: float = 12.0):
                       f"reference chunking 32768/65536, {dt:.2f} s, host has {os.cpu_count()} logical cpus"}
 
 
+def measured_traffic(workload: str):
+    """HBM-side bytes per launch of the render kernel from the committed rocprofv3 PMC summary of this very
+    command (separate --pmc passes, FETCH_SIZE x2 for gfx950's wide reads; tools/summarize_profile.py).
+    PMC collection cannot run inside the timed bench, so the latest committed profile is quoted; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"bench_{workload}_*pmc_summary.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))["derived"]
+    rd, wr = d.get("hbm_side_read_bytes_corrected"), d.get("hbm_side_write_bytes_uncalibrated")
+    if rd is None:
+        return None, None
+    return float(rd) + float(wr or 0.0), os.path.relpath(files[-1], ROOT)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,7 +181,9 @@ def main() -> None:
                                    + (", + gather of RGBA to rank 0" if world > 1 else ""),
                        "rays_per_gpu": n_rays, "samples_per_ray": S, "flops_per_sample": flops_per_sample},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": measured_traffic(args.workload)[0],
+                         "traffic_unit": "bytes/launch (HBM side, rocprofv3 PMC)", "traffic_source": measured_traffic(args.workload)[1],
+                         "algorithmic_bytes": n_rays * (4 * (3 + 3 + 2 + 1 + 4) + 0) + 4 * model.n_params,
                          "kernel": "ntx::render_kernel", "kernel_ms": kernel_ms},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -17,19 +17,14 @@
 #include "nerftex.h"   // NTX_FLAG_*
 #include "ntx_layout.h"
 
-// Experiment switches, kept because the measurement is instructive (MI355X, carpet 800x800x64, ms per launch):
-//   CONV=0 PE=0  377.4   <- default: VALU work in BLOCKS (layer epilogue as one block, one sin() per k-step after
-//   CONV=0 PE=1  383.3      that step's first MFMA)
-//   CONV=1 PE=0  388.6
-//   CONV=1 PE=1  397.5   <- everything spread thinly between MFMAs
-// A wave's own VALU instructions do not hide under its own v_mfma_f32_32x32x2_f32 stream: every VALU<->MFMA
-// alternation costs issue time, so fewer, larger VALU blocks win.  Hiding them needs a second wave per SIMD.
-#ifndef NTX_INTERLEAVE_CONV
-#define NTX_INTERLEAVE_CONV 0   // 1: move layer n's activations out of the accumulators inside layer n+1's MFMA stream
-#endif
-#ifndef NTX_STAGED_PE
-#define NTX_STAGED_PE 0         // 1: spread the encoder's sin() over the MFMA slots of the previous k-step
-#endif
+// Measured on MI355X (carpet 800x800x64, ms per launch) while deciding where VALU work goes:
+//   layer epilogue and encoder as BLOCKS of VALU work                    377.4
+//   encoder sin() spread over the MFMA slots of the previous k-step       383.3
+//   layer epilogue spread over the next layer's k-steps                   388.6
+//   both spread                                                           397.5
+// A wave's VALU instructions do not hide under v_mfma_f32_32x32x2_f32 (nor do a second wave's:
+// tools/ubench/mfma_valu_overlap.hip) -- the f32 MFMA runs on the FP32 lanes -- so VALU work is kept in
+// few, dense, well-pipelined blocks.
 
 namespace ntx {
 
@@ -117,50 +112,19 @@ NTX_DEV f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// B-operand generators.  A generator produces, for k-step S of its segment, this lane's B value in
-// up to 8 STAGES; run_segment executes stage i of step S+1 in the shadow of MFMA i of step S.
+// B-operand generators.  A generator hands run_segment this lane's B value for k-step S.  Encoder
+// generators evaluate PE_GROUP consecutive k-steps at once: the f32 MFMA and the VALU share the FP32 lanes
+// on gfx950 (VALU time simply adds to MFMA time, measured in tools/ubench/mfma_valu_overlap.hip), so the
+// only thing to gain is VALU issue efficiency -- PE_GROUP independent sin() chains interleave instead of
+// one 24-deep dependent chain per step.
 // ---------------------------------------------------------------------------------------------
-struct SinState {
-    float x, n, r, r2, ps, pc, sv, cv, t0;
-    int qi;
-};
-
-// sin(x + q*pi/2) of sin_q(), cut into 8 stages of <= 3 VALU instructions
-template <int ST>
-NTX_DEV void sin_stage(SinState &g, int q, float &out) {
-    if constexpr (ST == 0) {
-        g.n = __builtin_rintf(g.x * 0x1.45f306p-1f);
-        g.r = __builtin_fmaf(-g.n, 0x1.921fb6p+0f, g.x);
-    } else if constexpr (ST == 1) {
-        g.r = __builtin_fmaf(-g.n, -0x1.777a5cp-25f, g.r);
-        g.r = __builtin_fmaf(-g.n, -0x1.ee59dap-50f, g.r);
-        g.qi = (int)g.n + q;
-    } else if constexpr (ST == 2) {
-        g.r2 = g.r * g.r;
-        g.ps = __builtin_fmaf(g.r2, -1.9515295891e-4f, 8.3321608736e-3f);
-        g.pc = __builtin_fmaf(g.r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    } else if constexpr (ST == 3) {
-        g.ps = __builtin_fmaf(g.r2, g.ps, -1.6666654611e-1f);
-        g.pc = __builtin_fmaf(g.r2, g.pc, 4.166664568298827e-2f);
-        g.t0 = g.r * g.r2;
-    } else if constexpr (ST == 4) {
-        g.sv = __builtin_fmaf(g.t0, g.ps, g.r);
-        g.t0 = __builtin_fmaf(g.r2, -0.5f, 1.0f);
-        g.r2 = g.r2 * g.r2;
-    } else if constexpr (ST == 5) {
-        g.cv = __builtin_fmaf(g.r2, g.pc, g.t0);
-    } else if constexpr (ST == 6) {
-        g.sv = (g.qi & 1) ? g.cv : g.sv;
-    } else {
-        out = (g.qi & 2) ? -g.sv : g.sv;
-    }
-}
+constexpr int PE_GROUP = 4;
 
 // activations of the previous layer, already in registers
 struct HiddenGen {
     const float (&hin)[128];
-    template <int S, int ST>
-    NTX_DEV void stage() {}
+    template <int S, int N>
+    NTX_DEV void prepare() {}
     template <int S>
     NTX_DEV float value() const { return hin[S]; }
 };
@@ -179,24 +143,32 @@ NTX_DEV void init_bias(f32x16 (&acc)[8], const float *aux, int layer, int h) {
     static_for<NMT>([&](auto MT) { init_bias_tile<decltype(MT)::value>(acc, aux, layer, h); });
 }
 
-// max(x, 0) as ONE v_max_f32: fmaxf() on an MFMA result makes hipcc emit a canonicalising
-// v_max_f32 x, x, x in front of the real one (3 instead of 2 instructions per activation).
-NTX_DEV float relu1(float v) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
-
-// hin[V] <- act(previous layer's accumulator V): register r of tile V/16 is feature hidden_row(V, half)
-template <int V, bool RELU>
-NTX_DEV void convert_one(float (&hin)[128], const f32x16 (&prev)[8]) {
-    const float v = prev[V >> 4][V & 15];
-    hin[V] = RELU ? relu1(v) : v;
+// hin[V0..V0+8) <- relu(previous layer's accumulators): 8 v_accvgpr_read into 8 different registers, then 8
+// v_max_f32 in place.  (fmaxf() on an MFMA result makes hipcc emit a canonicalising v_max x,x,x first, and a
+// per-value read/max pair re-uses one temporary 128 times: a serial chain.)  Register r of tile V/16 is
+// feature hidden_row(V, half).
+template <int V0, bool RELU>
+NTX_DEV void convert8(float (&hin)[128], const f32x16 (&prev)[8]) {
+    constexpr int T = V0 >> 4, R = V0 & 15;
+    static_assert(R % 8 == 0, "blocks of 8 within a tile");
+    if constexpr (RELU) {
+        asm("v_accvgpr_read_b32 %0, %8\n\tv_accvgpr_read_b32 %1, %9\n\tv_accvgpr_read_b32 %2, %10\n\t"
+            "v_accvgpr_read_b32 %3, %11\n\tv_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\t"
+            "v_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15\n\t"
+            "v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1\n\tv_max_f32 %2, 0, %2\n\tv_max_f32 %3, 0, %3\n\t"
+            "v_max_f32 %4, 0, %4\n\tv_max_f32 %5, 0, %5\n\tv_max_f32 %6, 0, %6\n\tv_max_f32 %7, 0, %7"
+            : "=&v"(hin[V0 + 0]), "=&v"(hin[V0 + 1]), "=&v"(hin[V0 + 2]), "=&v"(hin[V0 + 3]), "=&v"(hin[V0 + 4]),
+              "=&v"(hin[V0 + 5]), "=&v"(hin[V0 + 6]), "=&v"(hin[V0 + 7])
+            : "a"(prev[T][R + 0]), "a"(prev[T][R + 1]), "a"(prev[T][R + 2]), "a"(prev[T][R + 3]), "a"(prev[T][R + 4]),
+              "a"(prev[T][R + 5]), "a"(prev[T][R + 6]), "a"(prev[T][R + 7]));
+    } else {
+        static_for<8>([&](auto K) { hin[V0 + decltype(K)::value] = prev[T][R + decltype(K)::value]; });
+    }
 }
 
 template <int NMT, bool RELU>
 NTX_DEV void store_act(float (&hin)[128], const f32x16 (&acc)[8]) {
-    static_for<NMT * 16>([&](auto V) { convert_one<decltype(V)::value, RELU>(hin, acc); });
+    static_for<NMT * 2>([&](auto V) { convert8<decltype(V)::value * 8, RELU>(hin, acc); });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -210,8 +182,7 @@ NTX_DEV void store_act(float (&hin)[128], const f32x16 (&acc)[8]) {
 template <int NSTEPS, int NMT, int REC0, class Gen, class Extra>
 NTX_DEV void run_segment(f32x16 (&acc)[8], WStream &ws, Gen &gen, Extra &&extra) {
     constexpr int RPS = NMT / 4;
-    constexpr int SPS = 8 / NMT;   // generator stages per slot (8 stages over NMT slots)
-    static_for<8>([&](auto ST) { gen.template stage<0, decltype(ST)::value>(); });   // step 0: not hidden
+    gen.template prepare<0, (NSTEPS < PE_GROUP ? NSTEPS : PE_GROUP)>();   // first group: before the first MFMA
     float b = gen.template value<0>();
     static_for<NSTEPS>([&](auto S) {
         constexpr int s = S;
@@ -224,12 +195,9 @@ NTX_DEV void run_segment(f32x16 (&acc)[8], WStream &ws, Gen &gen, Extra &&extra)
                 ws.ring[rec % RING] = ws_load(ws, rec + RING);
             }
             acc[mt] = mfma32(w[mt % 4], b, acc[mt]);
-            if constexpr (s + 1 < NSTEPS) {
-                if constexpr (NTX_STAGED_PE)
-                    static_for<SPS>([&](auto K) { gen.template stage<s + 1, mt * SPS + decltype(K)::value>(); });
-                else if constexpr (mt == 0)
-                    static_for<8>([&](auto K) { gen.template stage<s + 1, decltype(K)::value>(); });
-            }
+            // the B values of the next PE_GROUP k-steps, as ONE block of VALU work after this step's first MFMA
+            if constexpr (mt == 0 && (s + 1) % PE_GROUP == 0 && s + 1 < NSTEPS)
+                gen.template prepare<s + 1, (NSTEPS - s - 1 < PE_GROUP ? NSTEPS - s - 1 : PE_GROUP)>();
             extra(S, MT);
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -279,64 +247,64 @@ NTX_DEV float dir_id_value(const SampleIn<NGEO, NAPP> &in) {
 }
 
 // k-step S of the position segment: identity pairs, then {sin,cos}(2^f pos_c), then {sin,cos}(2^f geo_g)
+template <int NGEO, int NAPP, int S>
+NTX_DEV float pos_feature(const SampleIn<NGEO, NAPP> &in, int h) {
+    constexpr int nid = pos_id_steps(NGEO);
+    if constexpr (S < nid) {
+        const float lo = pos_id_value<NGEO, NAPP, 2 * S>(in), hi = pos_id_value<NGEO, NAPP, 2 * S + 1>(in);
+        return h ? hi : lo;
+    } else if constexpr (S - nid < 3 * POS_FREQ) {
+        constexpr int q = S - nid, f = q / 3, c = q % 3;
+        return sin_q(in.pos[c] * (float)(1 << f), h);
+    } else if constexpr (S - nid - 3 * POS_FREQ < NGEO * PAR_FREQ) {
+        constexpr int q = S - nid - 3 * POS_FREQ, f = q / (NGEO > 0 ? NGEO : 1), g = q % (NGEO > 0 ? NGEO : 1);
+        return sin_q(in.par[g] * (float)(1 << f), h);
+    } else {
+        return 0.0f;
+    }
+}
+
+template <int NGEO, int NAPP, int S>
+NTX_DEV float dir_feature(const SampleIn<NGEO, NAPP> &in, int h) {
+    constexpr int nid = dir_id_steps(NAPP);
+    if constexpr (S < nid) {
+        const float lo = dir_id_value<NGEO, NAPP, 2 * S>(in), hi = dir_id_value<NGEO, NAPP, 2 * S + 1>(in);
+        return h ? hi : lo;
+    } else if constexpr (S - nid < 3 * DIR_FREQ) {
+        constexpr int q = S - nid, f = q / 3, c = q % 3;
+        return sin_q(in.dir[c] * (float)(1 << f), h);
+    } else if constexpr (S - nid - 3 * DIR_FREQ < NAPP * PAR_FREQ) {
+        constexpr int q = S - nid - 3 * DIR_FREQ, f = q / (NAPP > 0 ? NAPP : 1), a = q % (NAPP > 0 ? NAPP : 1);
+        return sin_q(in.par[NGEO + a] * (float)(1 << f), h);
+    } else {
+        return 0.0f;
+    }
+}
+
 template <int NGEO, int NAPP>
 struct PosGen {
     const SampleIn<NGEO, NAPP> &in;
     int h;
-    SinState g;
-    float out;
-    template <int S, int ST>
-    NTX_DEV void stage() {
-        constexpr int nid = pos_id_steps(NGEO);
-        if constexpr (S < nid) {
-            if constexpr (ST == 0) {
-                const float lo = pos_id_value<NGEO, NAPP, 2 * S>(in), hi = pos_id_value<NGEO, NAPP, 2 * S + 1>(in);
-                out = h ? hi : lo;
-            }
-        } else if constexpr (S - nid < 3 * POS_FREQ) {
-            constexpr int q = S - nid, f = q / 3, c = q % 3;
-            if constexpr (ST == 0) g.x = in.pos[c] * (float)(1 << f);
-            sin_stage<ST>(g, h, out);
-        } else if constexpr (S - nid - 3 * POS_FREQ < NGEO * PAR_FREQ) {
-            constexpr int q = S - nid - 3 * POS_FREQ, f = q / (NGEO > 0 ? NGEO : 1), gi = q % (NGEO > 0 ? NGEO : 1);
-            if constexpr (ST == 0) g.x = in.par[gi] * (float)(1 << f);
-            sin_stage<ST>(g, h, out);
-        } else {
-            if constexpr (ST == 0) out = 0.0f;
-        }
+    float vals[PE_GROUP];
+    template <int S, int N>
+    NTX_DEV void prepare() {   // B values of k-steps S .. S+N-1 (S is a multiple of PE_GROUP)
+        static_for<N>([&](auto K) { vals[(S + decltype(K)::value) % PE_GROUP] = pos_feature<NGEO, NAPP, S + decltype(K)::value>(in, h); });
     }
     template <int S>
-    NTX_DEV float value() const { return out; }
+    NTX_DEV float value() const { return vals[S % PE_GROUP]; }
 };
 
 template <int NGEO, int NAPP>
 struct DirGen {
     const SampleIn<NGEO, NAPP> &in;
     int h;
-    SinState g;
-    float out;
-    template <int S, int ST>
-    NTX_DEV void stage() {
-        constexpr int nid = dir_id_steps(NAPP);
-        if constexpr (S < nid) {
-            if constexpr (ST == 0) {
-                const float lo = dir_id_value<NGEO, NAPP, 2 * S>(in), hi = dir_id_value<NGEO, NAPP, 2 * S + 1>(in);
-                out = h ? hi : lo;
-            }
-        } else if constexpr (S - nid < 3 * DIR_FREQ) {
-            constexpr int q = S - nid, f = q / 3, c = q % 3;
-            if constexpr (ST == 0) g.x = in.dir[c] * (float)(1 << f);
-            sin_stage<ST>(g, h, out);
-        } else if constexpr (S - nid - 3 * DIR_FREQ < NAPP * PAR_FREQ) {
-            constexpr int q = S - nid - 3 * DIR_FREQ, f = q / (NAPP > 0 ? NAPP : 1), a = q % (NAPP > 0 ? NAPP : 1);
-            if constexpr (ST == 0) g.x = in.par[NGEO + a] * (float)(1 << f);
-            sin_stage<ST>(g, h, out);
-        } else {
-            if constexpr (ST == 0) out = 0.0f;
-        }
+    float vals[PE_GROUP];
+    template <int S, int N>
+    NTX_DEV void prepare() {
+        static_for<N>([&](auto K) { vals[(S + decltype(K)::value) % PE_GROUP] = dir_feature<NGEO, NAPP, S + decltype(K)::value>(in, h); });
     }
     template <int S>
-    NTX_DEV float value() const { return out; }
+    NTX_DEV float value() const { return vals[S % PE_GROUP]; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -357,11 +325,9 @@ struct Cfg {
     static constexpr int REC_PAD = make_geometry(NGEO_, NAPP_, CD_).padded_records;
 };
 
-// Two accumulator sets (2 x 128 AGPRs) alternate between layers.  While layer n+1 accumulates into one
-// set, the other still holds layer n's result: its bias+ReLU'd values are moved into `hin` 16 k-steps
-// ahead of their use, one per k-step, in the shadow of layer n+1's MFMAs, and each drained tile is
-// re-initialised with the bias of layer n+2.  Only the first 16 activations of a layer (and its first
-// encoder value) are produced with the matrix pipe idle.
+// Two accumulator sets (2 x 128 AGPRs) alternate between layers: layer n's result is moved out of one set
+// (bias already in, ReLU, into `hin`) in one dense block before layer n+1 starts accumulating into the
+// other, and the drained set is re-initialised tile by tile with the bias of layer n+2 while layer n+1 runs.
 template <class CFG>
 NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
                        const float *aux_in, int lane, float &sigma, float (&rgb)[3]) {
@@ -381,7 +347,7 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
     // ---- trunk layer 0: pos_map -> 256 (model.py:104-106) into set A; set B <- bias of layer 1
     init_bias<8>(accA, aux, 0, h);
     {
-        PosGen<NGEO, NAPP> gen{in, h, {}, 0.0f};
+        PosGen<NGEO, NAPP> gen{in, h, {}};
         run_segment<CFG::PS, 8, 0>(accA, ws, gen, [&](auto S, auto MT) {
             constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
             if constexpr (mt == 1 && s % 4 == 0 && s < 32) init_bias_tile<s / 4>(accB, aux, 1, h);
@@ -411,36 +377,22 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
                 sig_part = __builtin_fmaf(hin[s], aux[aux_alpha_off() + h * 128 + s], sig_part);
         };
         if constexpr (pre_steps > 0) {
-            // encoder segment first: all 128 activations are converted in its shadow
-            constexpr int per_step = (128 + pre_steps - 1) / pre_steps;
-            if constexpr (!NTX_INTERLEAVE_CONV) store_act<8, relu_in>(hin, prev);
-            auto conv = [&](auto S, auto MT) {
-                constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
-                if constexpr (NTX_INTERLEAVE_CONV && mt == 0)
-                    static_for<per_step>([&](auto K) {
-                        constexpr int v = s * per_step + decltype(K)::value;
-                        if constexpr (v < 128) convert_one<v, relu_in>(hin, prev);
-                    });
-            };
+            store_act<8, relu_in>(hin, prev);
+            auto conv = none;
             const SampleIn<NGEO, NAPP> in2 = launder(in);
             if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
-                PosGen<NGEO, NAPP> gen{in2, h, {}, 0.0f};
+                PosGen<NGEO, NAPP> gen{in2, h, {}};
                 run_segment<pre_steps, 8, rec0>(cur, ws, gen, conv);
             } else {                   // input = concat[dir_map, feature]  (model.py:115)
-                DirGen<NGEO, NAPP> gen{in2, h, {}, 0.0f};
+                DirGen<NGEO, NAPP> gen{in2, h, {}};
                 run_segment<pre_steps, 8, rec0>(cur, ws, gen, conv);
             }
             HiddenGen hg{hin};
             run_segment<HSTEPS, 8, rec0 + pre_steps * 2>(cur, ws, hg, [&](auto S, auto MT) { reinit(S, MT); alpha_head(S, MT); });
         } else {
-            static_for<NTX_INTERLEAVE_CONV ? 16 : 128>([&](auto V) { convert_one<decltype(V)::value, relu_in>(hin, prev); });   // not hidden
+            store_act<8, relu_in>(hin, prev);
             HiddenGen hg{hin};
-            run_segment<HSTEPS, 8, rec0>(cur, ws, hg, [&](auto S, auto MT) {
-                constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
-                if constexpr (NTX_INTERLEAVE_CONV && mt == 0 && s + 16 < 128) convert_one<s + 16, relu_in>(hin, prev);
-                reinit(S, MT);
-                alpha_head(S, MT);
-            });
+            run_segment<HSTEPS, 8, rec0>(cur, ws, hg, [&](auto S, auto MT) { reinit(S, MT); alpha_head(S, MT); });
         }
     };
     static_for<NPASS>([&](auto I) {
@@ -455,26 +407,16 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
     auto color_half = [&](f32x16 (&cur)[8], f32x16 (&prev)[8]) {
         init_bias<4>(cur, aux, 10, h);
         if constexpr (CFG::CD == 0) {   // plain Nerf: input = concat[dir_map, feature]  (model.py:39-42)
-            constexpr int per_step = (128 + CFG::DS - 1) / CFG::DS;
+            store_act<8, false>(hin, prev);
             const SampleIn<NGEO, NAPP> in2 = launder(in);
-            DirGen<NGEO, NAPP> gen{in2, h, {}, 0.0f};
-            run_segment<CFG::DS, 4, CFG::REC_C2>(cur, ws, gen, [&](auto S, auto MT) {
-                constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
-                if constexpr (mt == 0)
-                    static_for<per_step>([&](auto K) {
-                        constexpr int v = s * per_step + decltype(K)::value;
-                        if constexpr (v < 128) convert_one<v, false>(hin, prev);
-                    });
-            });
+            DirGen<NGEO, NAPP> gen{in2, h, {}};
+            run_segment<CFG::DS, 4, CFG::REC_C2>(cur, ws, gen, none);
             HiddenGen hg{hin};
             run_segment<HSTEPS, 4, CFG::REC_C2 + CFG::DS>(cur, ws, hg, none);
         } else {
-            static_for<NTX_INTERLEAVE_CONV ? 16 : 128>([&](auto V) { convert_one<decltype(V)::value, true>(hin, prev); });
+            store_act<8, true>(hin, prev);
             HiddenGen hg{hin};
-            run_segment<HSTEPS, 4, CFG::REC_C2>(cur, ws, hg, [&](auto S, auto MT) {
-                constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
-                if constexpr (NTX_INTERLEAVE_CONV && mt == 0 && s + 16 < 128) convert_one<s + 16, true>(hin, prev);
-            });
+            run_segment<HSTEPS, 4, CFG::REC_C2>(cur, ws, hg, none);
         }
         store_act<4, true>(hin, cur);
     };

@@ -47,8 +47,14 @@ def Render(target_path: Optional[str], test_dataset_config, model_config, render
     test_dataset = util.instantiate(test_dataset_config)
     model_config.setdefault("n_parameters", test_dataset.n_parameters)                  # render.py:20
     model = util.instantiate(model_config)
-    if weights is not None:                      # stands in for the checkpoint restore of logger.py:33-39
+    if weights is not None:                      # explicit blob (Keras get_weights() order) wins
         next(iter(model.values())).set_blob(weights)
+    else:                                        # logger.py:30-39: restore the newest ckpt-* under <source>/checkpoints
+        ckpt_dir = os.path.join(source_path if source_path is not None else (target_path or ""), "checkpoints")
+        if os.path.isdir(ckpt_dir) and any(f.endswith(".index") for f in os.listdir(ckpt_dir)):
+            from .checkpoint import load_checkpoint
+            for name, m in model.items():
+                print("Restored model from {}.".format(load_checkpoint(m, ckpt_dir, root=name)))
     renderer_config.update(model)                                                      # render.py:24
     renderer = util.instantiate(renderer_config)
     imgs = []

@@ -376,6 +376,49 @@ def render_rays(weights, spec, rays_o, rays_d, t, parameters, cone_scale, n_samp
     return out
 
 
+def sample_pdf(bins, weights, n_samples: int, det: bool = False, u=None, dtype=F32):
+    """renderer.sample_pdf (renderer.py:589-617): inverse-CDF sampling of the piecewise-constant pdf given by
+    `weights` over `bins`.  det=True uses u = tf.linspace(0, 1, n); otherwise the caller supplies the
+    uniform draws `u` [n_rays, n_samples] (TF's RNG stream cannot be reproduced)."""
+    bins = np.asarray(bins, dtype=dtype)
+    w = np.asarray(weights, dtype=dtype) + dtype(1e-5)                           # :593
+    pdf = w / np.sum(w, -1, keepdims=True, dtype=dtype)
+    cdf = np.cumsum(pdf, -1, dtype=dtype)
+    cdf = np.concatenate([np.zeros_like(cdf[..., :1]), cdf], -1)                 # :596
+    if det:                                                                      # :599-601
+        u = np.broadcast_to(linspace_tf(n_samples, dtype), cdf.shape[:-1] + (n_samples,))
+    else:
+        u = np.asarray(u, dtype=dtype)
+    inds = np.stack([np.searchsorted(c, uu, side="right") for c, uu in zip(cdf, u)])   # :606
+    below = np.maximum(0, inds - 1)
+    above = np.minimum(cdf.shape[-1] - 1, inds)
+    cdf_g0 = np.take_along_axis(cdf, below, -1); cdf_g1 = np.take_along_axis(cdf, above, -1)
+    bins_g0 = np.take_along_axis(bins, below, -1); bins_g1 = np.take_along_axis(bins, above, -1)
+    denom = cdf_g1 - cdf_g0
+    denom = np.where(denom < dtype(1e-5), np.ones_like(denom), denom)            # :614
+    t = (u - cdf_g0) / denom
+    return (bins_g0 + t * (bins_g1 - bins_g0)).astype(dtype)                     # :616
+
+
+def render_rays_hierarchical(weights_coarse, weights_fine, spec, rays_o, rays_d, t, parameters, cone_scale, n_samples,
+                             n_importance, composite_bkgd, bkgd_color, perturb=True, u=None, blur_idx=None,
+                             map_exr=False, net_chunk=65536, dtype=F32):
+    """Renderer.render_rays with n_importance > 0 (renderer.py:92-143), jitter of the coarse samples left out.
+    Note the reference quirk `det=self.perturb` (:128): perturb=True gives the DETERMINISTIC u."""
+    coarse = render_rays(weights_coarse, spec, rays_o, rays_d, t, parameters, cone_scale, n_samples, composite_bkgd,
+                         bkgd_color, blur_idx, map_exr, net_chunk, None, dtype, return_aux=True)
+    z_vals, w = coarse["z_vals"], coarse["weights"]
+    z_mid = dtype(.5) * (z_vals[..., 1:] + z_vals[..., :-1])                     # :127
+    z_samples = sample_pdf(z_mid, w[..., 1:-1], n_importance, det=perturb, u=u, dtype=dtype)   # :128
+    z_all = np.sort(np.concatenate([z_vals, z_samples], -1), -1)                 # :130
+    fine = render_rays(weights_fine if weights_fine is not None else weights_coarse, spec, rays_o, rays_d, t,
+                       parameters, cone_scale, n_samples + n_importance, composite_bkgd, bkgd_color, blur_idx, map_exr,
+                       net_chunk, z_all, dtype)                                  # :131-136
+    return {"color_pred": fine["color_pred"], "alpha_pred": fine["alpha_pred"],
+            "color_pred_coarse": coarse["color_pred"], "alpha_pred_coarse": coarse["alpha_pred"],
+            "z_vals": z_all, "z_samples": z_samples}
+
+
 def renderer_call(weights, spec, rays_o, rays_d, t, parameters, cone_scale, n_samples=64,
                   composite_bkgd=False, bkgd_color=(1., 1., 1.), blur_idx=None, map_exr=False,
                   render_chunk=32768, net_chunk=65536, dtype=F32):

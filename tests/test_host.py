@@ -166,3 +166,47 @@ def test_gather_image_world2_gloo(n_total):
     res = sorted(q.get(timeout=120) for _ in procs)
     [p.join(60) for p in procs]
     assert res == [(0, True), (1, True)]
+
+
+def test_checkpoint_reader_round_trip(tmp_path):
+    """nerf_tex_amd/checkpoint.py against the independent writer in tests/bundle_writer.py:
+    multi-block table, prefix-compressed keys, Keras object-graph names with the heads in DEPTH order."""
+    from nerf_tex_amd import checkpoint as ck
+    from nerf_tex_amd.model import ParamNerf
+    from tests.bundle_writer import write_bundle
+    from tests.common import EMB
+    assert ck.crc32c(b"123456789") == 0xE3069283                      # the standard CRC-32C check value
+    np.random.seed(3)
+    src = ParamNerf(EMB(10), EMB(4), EMB(4), [1, 6])["model"]
+    ws = src.get_weights()
+    names = [n for n, _, _ in src.layer_table()]
+    # model.layers order of a functional Keras model is by depth: trunk0-7, feature, colour layers, then the two heads
+    order = [n for n in names if n.startswith("trunk")] + ["feature", "color_hidden0", "color_half", "alpha", "color"]
+    tensors = {"save_counter/.ATTRIBUTES/VARIABLE_VALUE": np.asarray(7, np.int64), "step/.ATTRIBUTES/VARIABLE_VALUE": np.asarray(5000, np.int64)}
+    for i, n in enumerate(order):
+        k = names.index(n)
+        tensors[f"model/layer_with_weights-{i}/kernel/.ATTRIBUTES/VARIABLE_VALUE"] = ws[2 * k]
+        tensors[f"model/layer_with_weights-{i}/bias/.ATTRIBUTES/VARIABLE_VALUE"] = ws[2 * k + 1] + np.float32(0.01 * i)
+        tensors[f"optimizer/iter/{i}"] = np.asarray([i], np.int32)
+    d = tmp_path / "checkpoints"; d.mkdir()
+    write_bundle(str(d / "ckpt-1000"), {"model/layer_with_weights-0/bias/.ATTRIBUTES/VARIABLE_VALUE": ws[1]})
+    write_bundle(str(d / "ckpt-5000"), tensors)
+    assert ck.latest_checkpoint(str(d)).endswith("ckpt-5000")
+    got = ck.read_bundle(str(d / "ckpt-5000"))
+    assert set(got) == set(tensors) and int(got["step/.ATTRIBUTES/VARIABLE_VALUE"]) == 5000
+    dst = ParamNerf(EMB(10), EMB(4), EMB(4), [1, 6])["model"]
+    ck.load_checkpoint(dst, str(d))
+    for k, (a, b) in enumerate(zip(dst.get_weights(), ws)):
+        if k % 2 == 0:
+            np.testing.assert_array_equal(a, b)
+        else:
+            np.testing.assert_array_equal(a, b + np.float32(0.01 * order.index(names[k // 2])))
+    # integrity: a flipped data byte is caught by the tensor checksum, a flipped index byte by the block checksum
+    p = str(d / "ckpt-5000.data-00000-of-00001"); raw = bytearray(open(p, "rb").read()); raw[100] ^= 1; open(p, "wb").write(raw)
+    with pytest.raises(ValueError, match="checksum"):
+        ck.read_bundle(str(d / "ckpt-5000"))
+    with pytest.raises(KeyError):
+        ck.model_weights_from_bundle(got, dst.layer_table(), root="model_fine")
+    other = ParamNerf(EMB(10), EMB(4), EMB(4), [1, 4])["model"]
+    with pytest.raises(KeyError):
+        ck.model_weights_from_bundle(got, other.layer_table())
