@@ -117,12 +117,22 @@ int ntx_composite(const float *color, const float *sigma, const float *z_vals, c
  *   z_vals: NULL, or DEVICE [N,S] sample depths replacing renderer.py:101-103 (the caller's own
  *       stratified jitter, renderer.py:106-111)
  *   status_flag: NULL, or DEVICE int32 OR-ed with 1 when NTX_FLAG_CHECK_NUMERICS finds NaN/Inf
- * Outputs (DEVICE): color_out[N,3] (premultiplied), alpha_out[N]; culled rays get 0 (or bkgd). */
+ * Outputs (DEVICE): color_out[N,3] (premultiplied), alpha_out[N]; culled rays get 0 (or bkgd);
+ *   weights_out: NULL, or [N,S] the compositing weights of renderer.py:198 (input of sample_pdf; rows of
+ *   culled rays are left untouched). */
 int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, const float *t,
                     const float *params, int64_t rays_per_param_row, const float *cone_scale,
                     int64_t n_rays, int n_samples, int blur_idx, uint32_t flags, const float *bkgd,
-                    const float *z_vals, float *color_out, float *alpha_out, int32_t *status_flag,
-                    ntx_stream stream);
+                    const float *z_vals, float *color_out, float *alpha_out, float *weights_out,
+                    int32_t *status_flag, ntx_stream stream);
+
+/* Replaces the importance-sampling step of Renderer.render_rays (renderer.py:125-130) incl. sample_pdf
+ * (renderer.py:589-617): bins = midpoints of the coarse depths, pdf = weights[:,1:-1] + 1e-5, n_importance
+ * depths by inverse CDF at u (NULL = tf.linspace(0,1,n_importance), the `det` branch; else DEVICE [N,n_imp]
+ * uniform draws), merged with the coarse depths and sorted -> z_out[N, S + n_importance] (DEVICE).
+ * The coarse depths are z_vals[N,S], or (NULL) recomputed from t exactly as ntx_render_rays places them. */
+int ntx_sample_pdf(const float *t, const float *z_vals, const float *weights, const float *u, int64_t n_rays,
+                   int n_samples, int n_importance, float *z_out, ntx_stream stream);
 
 /* Replaces InstanceRenderer.evaluate_model + map_model_output (renderer.py:247-354) DOWNSTREAM of the
  * instancer: the arguments are the buffers instancer.get_model_input returns (instancer.pyx:38-54), on the

@@ -47,7 +47,8 @@ SYMBOLS = {
     "ntx_mlp_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "ntx_composite": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_uint32, _fp, _vp, _vp, _vp, _vp]),
     "ntx_render_rays": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, C.c_int, C.c_uint32,
-                                  _fp, _vp, _vp, _vp, _vp, _vp]),
+                                  _fp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ntx_sample_pdf": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp]),
     "ntx_render_instanced": (C.c_int, [_vp] * 12 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, _fp,
                                         _vp, _vp, _vp, _vp, _vp]),
     "ntx_image_epilogue": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),

@@ -421,7 +421,7 @@ int ntx_composite(const float *color, const float *sigma, const float *z_vals, c
 int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, const float *t, const float *params,
                     int64_t rays_per_param_row, const float *cone_scale, int64_t n_rays, int n_samples, int blur_idx,
                     uint32_t flags, const float *bkgd, const float *z_vals, float *color_out, float *alpha_out,
-                    int32_t *status_flag, ntx_stream stream) {
+                    float *weights_out, int32_t *status_flag, ntx_stream stream) {
     if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
     if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
     if (n_samples < 2) return fail(NTX_E_INVALID, "n_samples must be >= 2 (renderer.py:174-177 needs a previous step)");
@@ -438,7 +438,7 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     a.stream_bytes = (uint32_t)(ctx->stream_floats * sizeof(float));
     a.aux = ctx->packed + ctx->stream_floats;
     a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.params = params; a.cone = cone_scale; a.z_vals = z_vals;
-    a.color_out = color_out; a.alpha_out = alpha_out; a.status = status_flag;
+    a.color_out = color_out; a.alpha_out = alpha_out; a.weights_out = weights_out; a.status = status_flag;
     a.n_rays = n_rays; a.rays_per_row = rays_per_param_row;
     a.n_samples = n_samples; a.blur_idx = blur_idx; a.flags = flags;
     a.delta = (1.0f - 0.0f) / (float)(n_samples - 1);
@@ -479,6 +479,25 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     a.patch_scale = patch_scale; a.density_scale = density_scale;
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
     HIP_TRY(launch_instance(ctx, a, (hipStream_t)stream));
+    return NTX_OK;
+}
+
+int ntx_sample_pdf(const float *t, const float *z_vals, const float *weights, const float *u, int64_t n_rays,
+                   int n_samples, int n_importance, float *z_out, ntx_stream stream) {
+    if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
+    if (n_samples < 3 || n_samples > MAX_PDF_SAMPLES) return fail(NTX_E_INVALID, "n_samples %d outside [3,%d]", n_samples, MAX_PDF_SAMPLES);
+    if (n_importance < 1 || n_importance > MAX_PDF_SAMPLES) return fail(NTX_E_INVALID, "n_importance %d outside [1,%d]", n_importance, MAX_PDF_SAMPLES);
+    if (n_rays == 0) return NTX_OK;
+    if (!t || !weights || !z_out) return fail(NTX_E_INVALID, "NULL buffer");
+    SamplePdfArgs a{};
+    a.t = t; a.z_vals = z_vals; a.weights = weights; a.u = u; a.z_out = z_out;
+    a.n_rays = n_rays; a.n_samples = n_samples; a.n_imp = n_importance;
+    a.delta = 1.0f / (float)(n_samples - 1);
+    a.delta_u = n_importance > 1 ? 1.0f / (float)(n_importance - 1) : 0.0f;
+    int64_t nb = (n_rays + 3) / 4;
+    if (nb > 256 * 8) nb = 256 * 8;
+    sample_pdf_kernel<<<dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
     return NTX_OK;
 }
 

@@ -504,7 +504,7 @@ struct RenderArgs {
     uint32_t stream_bytes;   // stream + wrap-around tail
     const float *aux;
     const float *rays_o, *rays_d, *t, *params, *cone, *z_vals;
-    float *color_out, *alpha_out;
+    float *color_out, *alpha_out, *weights_out;   // weights_out: NULL or [N,S] per-sample compositing weights
     int32_t *status;
     int64_t n_rays, rays_per_row;
     int n_samples, blur_idx;
@@ -565,7 +565,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             }
             float sigma, raw[3];
             mlp_batch<CFG>(in, ws, aux, lane, sigma, raw);
-            composite_step<32>(ra, sigma, raw, dist, valid, a.flags, j, nullptr);
+            composite_step<32>(ra, sigma, raw, dist, valid, a.flags, j,
+                               a.weights_out ? a.weights_out + ray * S + ic : nullptr);
         }
         float out[4] = {ra.c0, ra.c1, ra.c2, ra.a};
         if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {   // renderer.py:210-211

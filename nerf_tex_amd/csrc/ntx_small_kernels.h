@@ -186,4 +186,88 @@ __global__ __launch_bounds__(256) void epilogue_kernel(EpilogueArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// hierarchical sampling (renderer.py:125-130 + sample_pdf 589-617): per ray, invert the CDF of the coarse
+// weights at n_imp positions and merge the new depths into the sorted coarse ones.  One wave per ray.
+// ---------------------------------------------------------------------------------------------
+constexpr int MAX_PDF_SAMPLES = 512;   // coarse samples and importance samples each
+
+struct SamplePdfArgs {
+    const float *t, *z_vals, *weights, *u;
+    float *z_out;
+    int64_t n_rays;
+    int n_samples, n_imp;
+    float delta, delta_u;   // float32 steps of tf.linspace(0,1,S) and tf.linspace(0,1,n_imp)
+};
+
+__global__ __launch_bounds__(256) void sample_pdf_kernel(SamplePdfArgs a) {
+    __shared__ float cdf_all[4][MAX_PDF_SAMPLES], bins_all[4][MAX_PDF_SAMPLES], vals_all[4][2 * MAX_PDF_SAMPLES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *cdf = cdf_all[wv], *bins = bins_all[wv], *vals = vals_all[wv];
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    const int S = a.n_samples, NI = a.n_imp, NB = S - 1, NT = S + NI;
+    for (int64_t ray = wave; ray < a.n_rays; ray += nwaves) {
+        const float t0 = a.t[2 * ray], t1 = a.t[2 * ray + 1];
+        float *zo = a.z_out + ray * NT;
+        if (t0 == __builtin_inff()) {   // culled ray: no weights exist; the fused kernel never reads its depths
+            for (int i = lane; i < NT; i += 64) zo[i] = 0.0f;
+            continue;
+        }
+        auto z_at = [&](int i) -> float {
+            if (a.z_vals) return a.z_vals[ray * S + i];
+            const float tv = i == 0 ? 0.0f : (i == S - 1 ? 1.0f : a.delta * (float)i);
+            return t0 * (1.0f - tv) + t1 * tv;
+        };
+        const float *w = a.weights + ray * S;
+        // pdf over the S-2 interior weights (+1e-5), cdf with a leading 0: S-1 entries; bins = S-1 midpoints
+        float part = 0.0f;
+        for (int i = lane; i < S - 2; i += 64) part += w[i + 1] + 1e-5f;
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        const float total = part;
+        float carry = 0.0f;
+        for (int base = 0; base < S - 2; base += 64) {
+            const int i = base + lane;
+            float p = i < S - 2 ? (w[i + 1] + 1e-5f) / total : 0.0f;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float v = __shfl_up(p, d, 64);
+                if (lane >= d) p += v;
+            }
+            if (i < S - 2) cdf[i + 1] = carry + p;
+            carry += __shfl(p, 63, 64);
+        }
+        if (lane == 0) cdf[0] = 0.0f;
+        for (int i = lane; i < NB; i += 64) bins[i] = 0.5f * (z_at(i + 1) + z_at(i));
+        for (int i = lane; i < S; i += 64) vals[i] = z_at(i);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < NI; k += 64) {
+            const float u = a.u ? a.u[ray * NI + k] : (k == 0 ? 0.0f : (k == NI - 1 ? 1.0f : a.delta_u * (float)k));
+            int lo = 0, hi = NB;                       // searchsorted(cdf, u, side='right')
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+            }
+            const int below = lo - 1 > 0 ? lo - 1 : 0, above = lo < NB - 1 ? lo : NB - 1;
+            float denom = cdf[above] - cdf[below];
+            if (denom < 1e-5f) denom = 1.0f;
+            const float tt = (u - cdf[below]) / denom;
+            vals[S + k] = bins[below] + tt * (bins[above] - bins[below]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // tf.sort(concat): rank of every value = #smaller + #equal-with-lower-index
+        for (int i = lane; i < NT; i += 64) {
+            const float v = vals[i];
+            int rank = 0;
+            for (int jx = 0; jx < NT; ++jx) {
+                const float o = vals[jx];
+                rank += (o < v) || (o == v && jx < i);
+            }
+            zo[rank] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace ntx

@@ -35,9 +35,6 @@ class Renderer:
         self.blur_idx = blur_idx
         self.map_exr = map_exr
         self.check_numerics = check_numerics     # tf.debugging.check_numerics, renderer.py:140-141
-        if n_importance > 0:
-            raise NotImplementedError("hierarchical sampling (n_importance > 0, renderer.py:125-138) is used by no "
-                                      "reference config and has no HIP kernel yet")
         if raw_noise_std > 0:
             raise NotImplementedError("raw_noise_std > 0 (renderer.py:190-192) is a training regulariser; the render path has no kernel for it")
 
@@ -67,22 +64,44 @@ class Renderer:
             z = z_vals.reshape(n, S).contiguous().float()
         elif self.perturb:
             z = self._jitter(t, S)                                           # renderer.py:106-111
-        color = torch.empty((n, 3), device=dev, dtype=torch.float32)
-        alpha = torch.empty((n,), device=dev, dtype=torch.float32)
         flags = (_lib.FLAG_MAP_EXR if self.map_exr else 0) | (_lib.FLAG_COMPOSITE_BKGD if composite_bkgd else 0)
         status = None
         if self.check_numerics:
             flags |= _lib.FLAG_CHECK_NUMERICS
             status = torch.zeros(1, device=dev, dtype=torch.int32)
         bk = bkgd_color.detach().cpu().tolist() if hasattr(bkgd_color, "detach") else list(bkgd_color)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib.ntx_render_rays(
-                self.model.ctx(dev.index or 0), rays_o.data_ptr(), rays_d.data_ptr(), t.data_ptr(),
-                params.data_ptr() if params is not None else None, HW, cone.data_ptr(), n, S,
-                -1 if self.blur_idx is None else int(self.blur_idx), flags, _lib.f3(bk),
-                z.data_ptr() if z is not None else None, color.data_ptr(), alpha.data_ptr(),
-                status.data_ptr() if status is not None else None, torch.cuda.current_stream(dev).cuda_stream))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        blur = -1 if self.blur_idx is None else int(self.blur_idx)
+
+        def launch(model, n_s, z_in, want_weights):
+            color = torch.empty((n, 3), device=dev, dtype=torch.float32)
+            alpha = torch.empty((n,), device=dev, dtype=torch.float32)
+            wts = torch.empty((n, n_s), device=dev, dtype=torch.float32) if want_weights else None
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib.ntx_render_rays(
+                    model.ctx(dev.index or 0), rays_o.data_ptr(), rays_d.data_ptr(), t.data_ptr(),
+                    params.data_ptr() if params is not None else None, HW, cone.data_ptr(), n, n_s, blur, flags,
+                    _lib.f3(bk), z_in.data_ptr() if z_in is not None else None, color.data_ptr(), alpha.data_ptr(),
+                    wts.data_ptr() if wts is not None else None, status.data_ptr() if status is not None else None, stream))
+            return color, alpha, wts
+
+        color, alpha, wts = launch(self.model, S, z, self.n_importance > 0)
         out = {"color_pred": color.reshape(B, HW, 3), "alpha_pred": alpha.reshape(B, HW)}
+        if self.n_importance > 0:                                            # renderer.py:125-138
+            NI = self.n_importance
+            # `det=self.perturb` (renderer.py:128): perturb=True -> deterministic u, else uniform draws
+            u = None if self.perturb else torch.rand((n, NI), device=dev, dtype=torch.float32)
+            if kwargs.get("u") is not None:
+                u = kwargs["u"].reshape(n, NI).contiguous().float()
+            z_all = torch.empty((n, S + NI), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib.ntx_sample_pdf(t.data_ptr(), z.data_ptr() if z is not None else None, wts.data_ptr(),
+                                                   u.data_ptr() if u is not None else None, n, S, NI, z_all.data_ptr(), stream))
+            model_imp = self.model if self.model_fine is None else self.model_fine
+            c2, a2, _ = launch(model_imp, S + NI, z_all, False)
+            out = {"color_pred": c2.reshape(B, HW, 3), "alpha_pred": a2.reshape(B, HW),
+                   "color_pred_coarse": out["color_pred"], "alpha_pred_coarse": out["alpha_pred"]}
+            self._last_z = z_all
         if status is not None:
             self._status = status          # read lazily: `raise_if_nonfinite()` syncs
         return out

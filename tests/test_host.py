@@ -124,7 +124,7 @@ def test_renderer_kwargs_mirror_reference():
     assert list(call.parameters)[1:6] == ["rays_o", "rays_d", "t", "parameters", "cone_scale"]   # renderer.py:47
     assert call.parameters["composite_bkgd"].default is False and call.parameters["training"].default is True
     with pytest.raises(NotImplementedError):
-        Renderer(model=None, n_importance=64)
+        Renderer(model=None, raw_noise_std=1.0)
 
 
 def test_shard_range_partitions():

@@ -239,3 +239,18 @@ def test_instance_tail_properties():
     c2, a2 = orc.instance_evaluate_model(w, spec, rd, pts2, t, dists, cl, al, aw, ids, hit, prm, cone, None, 0.09, 50.0, True,
                                          False, True, (1, 1, 1.), None, dtype=np.float64)
     np.testing.assert_array_equal(c2, c)
+
+
+def test_sample_pdf_properties():
+    """renderer.py:589-617: samples stay inside the bins, follow the mass, and det=True is monotone."""
+    rng = np.random.default_rng(0)
+    z = np.sort(rng.uniform(2, 6, (4, 20)), -1); mid = .5 * (z[:, 1:] + z[:, :-1])
+    w = np.zeros((4, 20)); w[:, 7] = 1.0                         # all mass in one interior weight
+    zs = orc.sample_pdf(mid, w[:, 1:-1], 64, det=True, dtype=np.float64)
+    assert np.all(np.diff(zs, axis=-1) >= 0) and np.all(zs >= mid[:, :1]) and np.all(zs <= mid[:, -1:])
+    inside = (zs >= mid[:, 6:7]) & (zs <= mid[:, 7:8])           # weight 7 spans bins[6]..bins[7]
+    assert inside.mean() > 0.9
+    u = rng.uniform(size=(4, 33))
+    a = orc.sample_pdf(mid, w[:, 1:-1], 33, det=False, u=u, dtype=np.float64)
+    b = orc.sample_pdf(mid, w[:, 1:-1], 33, det=False, u=u, dtype=np.float32)
+    assert np.max(np.abs(a - b)) < 1e-4
