@@ -513,6 +513,16 @@ struct RenderArgs {
     float bkgd[3];
 };
 
+// the by-value kernel argument struct, addressed in the kernarg segment (device pass only)
+template <class T>
+NTX_DEV const T *kernargs() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (const T *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return nullptr;
+#endif
+}
+
 NTX_DEV float z_of(const RenderArgs &a, int64_t ray, int i, float t0, float t1) {
     if (a.z_vals) return a.z_vals[ray * a.n_samples + i];
     const float tv = i == 0 ? 0.0f : (i == a.n_samples - 1 ? 1.0f : a.delta * (float)i);
@@ -532,27 +542,37 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     ws_prime(ws, a.wstream, a.stream_bytes, lane);
 
     for (int64_t ray = wave; ray < a.n_rays; ray += nwaves) {
-        const float t0 = a.t[2 * ray], t1 = a.t[2 * ray + 1];
-        if (t0 == __builtin_inff()) {   // culled ray (renderer.py:58-67, 81-86); NaN counts as a hit
+        if (a.t[2 * ray] == __builtin_inff()) {   // culled ray (renderer.py:58-67, 81-86); NaN counts as a hit
             if (lane < 3) a.color_out[3 * ray + lane] = (a.flags & NTX_FLAG_COMPOSITE_BKGD) ? a.bkgd[lane] : 0.0f;
             if (lane == 3) a.alpha_out[ray] = 0.0f;
             continue;
         }
-        const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
-        const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
-        const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);   // renderer.py:98, 180
-        const float cone = a.cone ? a.cone[ray] : 0.0f;
-        const float *prow = a.params + (ray / a.rays_per_row) * CFG::NP;
-
         RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         for (int b = 0; b < nb; ++b) {
+            // The ray's own data is re-read (scalar loads, L2-resident) for every batch instead of staying live
+            // across the ~10 600-MFMA body, where it cost ~10 spilled registers per ray (1.3 GB of scratch
+            // stores per 800x800 launch).  The opaque copy of the index stops LICM from hoisting the loads back.
+            int64_t r = ray;
+            asm volatile("" : "+s"(r));
+            // same for the kernel arguments: read them from the kernarg segment through an opaque pointer at the
+            // point of use, so a dozen argument pointers are not held in SGPRs (spilled into VGPR lanes) all along
+            const RenderArgs *ap = kernargs<RenderArgs>();
+            asm volatile("" : "+s"(ap));
+            const RenderArgs &q = *ap;
+            const float t0 = q.t[2 * r], t1 = q.t[2 * r + 1];
+            const float ox = q.rays_o[3 * r], oy = q.rays_o[3 * r + 1], oz = q.rays_o[3 * r + 2];
+            const float dx = q.rays_d[3 * r], dy = q.rays_d[3 * r + 1], dz = q.rays_d[3 * r + 2];
+            const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);   // renderer.py:98, 180
+            const float cone = q.cone ? q.cone[r] : 0.0f;
+            const float *prow = q.params + (r / q.rays_per_row) * CFG::NP;
             const int i = 32 * b + j;
             const bool valid = i < S;
             const int ic = valid ? i : S - 1;
-            const float z = z_of(a, ray, ic, t0, t1);
+            const float z = z_of(q, r, ic, t0, t1);
             // dists: z[i+1]-z[i], the last one a copy of the previous (renderer.py:174-177), times |d| (:180)
-            const float zn = z_of(a, ray, ic < S - 1 ? ic + 1 : ic - 1, t0, t1);
+            const float zn = z_of(q, r, ic < S - 1 ? ic + 1 : ic - 1, t0, t1);
             const float dist = (ic < S - 1 ? zn - z : z - zn) * dnorm;
+            const int blur_idx = q.blur_idx;
 
             SampleIn<CFG::NGEO, CFG::NAPP> in;
             in.pos[0] = ox + dx * z; in.pos[1] = oy + dy * z; in.pos[2] = oz + dz * z;   // renderer.py:114
@@ -560,13 +580,15 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
 #pragma unroll
             for (int k = 0; k < CFG::NP; ++k) {
                 float p = prow[k];
-                if (k == a.blur_idx) p = p * (cone * z);                                  // renderer.py:155-158
+                if (k == blur_idx) p = p * (cone * z);                                    // renderer.py:155-158
                 in.par[k] = p;
             }
             float sigma, raw[3];
             mlp_batch<CFG>(in, ws, aux, lane, sigma, raw);
-            composite_step<32>(ra, sigma, raw, dist, valid, a.flags, j,
-                               a.weights_out ? a.weights_out + ray * S + ic : nullptr);
+            const RenderArgs *ap2 = kernargs<RenderArgs>();
+            asm volatile("" : "+s"(ap2));
+            composite_step<32>(ra, sigma, raw, dist, valid, ap2->flags, j,
+                               ap2->weights_out ? ap2->weights_out + ray * S + ic : nullptr);
         }
         float out[4] = {ra.c0, ra.c1, ra.c2, ra.a};
         if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {   // renderer.py:210-211
