@@ -440,6 +440,15 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
         });
         rgb[c] = p + __shfl_xor(p, 32, 64) + aux[aux_rgb_off() + 384 + c];
     });
+    // v_max_f32(0, NaN) is 0, so the first ReLU would swallow a NaN/Inf input that TensorFlow's relu propagates
+    // (and tf.debugging.check_numerics then reports, renderer.py:140-141): chk - chk is 0 for finite inputs, NaN else
+    float chk = in.pos[0] + in.pos[1] + in.pos[2] + in.dir[0] + in.dir[1] + in.dir[2];
+#pragma unroll
+    for (int k = 0; k < CFG::NP; ++k) chk += in.par[k];
+    chk = chk - chk;
+    sigma += chk;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] += chk;
     // the stream's tail replicates its first RING records and REC_PAD % RING == 0, so the ring now holds
     // records 0..RING-1 in slots 0..RING-1: the next batch starts without a bubble
 }

@@ -277,3 +277,40 @@ def test_hierarchical_sampling(family, S, NI, fine, det):
     want_e = np.concatenate([ref["color_pred"], ref["alpha_pred"][:, None]], -1)
     assert orc.rel_linf(got[same], want_e[same]) <= 2e-3
     assert np.all(out["alpha_pred"][0].cpu().numpy()[~hit] == 0)
+
+
+def test_edge_cases_empty_culled_minimal():
+    """Empty input, every ray culled, the smallest legal sample count, a sample count with a ragged last batch,
+    NaN inputs raising through the check_numerics flag, n_samples < 2 refused."""
+    from nerf_tex_amd import _lib, synthetic
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES["carpet"]
+    model, spec, w = make_model((1, 6), dense_media=True)
+    params = to_dev(np.asarray([fam["params"]], np.float32))[0]
+    r = Renderer(model=model, n_samples=64, perturb=False)
+    z3 = lambda n, k: torch.zeros((1, n, k), device=dev())
+    out = r(z3(0, 3), z3(0, 3), z3(0, 2), parameters=params, cone_scale=z3(0, 1))                    # no rays at all
+    assert out["color_pred"].shape == (1, 0, 3) and out["alpha_pred"].shape == (1, 0)
+    ro, rd, t, cone = synthetic.all_hit_rays(37, fam["b_0"], fam["b_1"], fam["cam"])
+    tinf = np.full_like(t, np.inf)
+    out = r(*to_dev(ro[None], rd[None], tinf[None]), parameters=params, cone_scale=to_dev(cone[None])[0], composite_bkgd=True,
+            bkgd_color=[.2, .4, .6])
+    assert torch.all(out["alpha_pred"] == 0) and torch.allclose(out["color_pred"][0], torch.tensor([.2, .4, .6], device=dev()).expand(37, 3))
+    for S in (2, 3, 33, 97):                                                                       # ragged batches of 32
+        rr = Renderer(model=model, n_samples=S, perturb=False)
+        o = rr(*to_dev(ro[None], rd[None], t[None]), parameters=params, cone_scale=to_dev(cone[None])[0])
+        got = np.concatenate([o["color_pred"][0].cpu().numpy(), o["alpha_pred"][0].cpu().numpy()[:, None]], -1)
+        # few samples -> nearly empty image (max |ref| ~ 0.2), where the float32 floor of the dense-media weights is
+        # visible: gate against the float32 restatement at 1e-4 and against the float64 truth at 3x that
+        for dtype, tol in ((np.float32, TOL), (np.float64, 3 * TOL)):
+            ref = orc.render_rays(w, spec, ro, rd, t, np.repeat(np.asarray([fam["params"]], np.float32), 37, 0), cone, S, False,
+                                  (1, 1, 1.), dtype=dtype)
+            assert orc.rel_linf(got, np.concatenate([ref["color_pred"], ref["alpha_pred"][:, None]], -1)) <= tol, (S, dtype)
+    bad = ro.copy(); bad[5, 0] = np.nan
+    o = r(*to_dev(bad[None], rd[None], t[None]), parameters=params, cone_scale=to_dev(cone[None])[0])
+    with pytest.raises(FloatingPointError):                                                        # renderer.py:140-141
+        r.raise_if_nonfinite()
+    with pytest.raises(_lib.NtxError) as e:
+        Renderer(model=model, n_samples=1, perturb=False)(*to_dev(ro[None], rd[None], t[None]), parameters=params,
+                                                          cone_scale=to_dev(cone[None])[0])
+    assert e.value.code == _lib.NTX_E_INVALID
