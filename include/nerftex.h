@@ -45,6 +45,8 @@ typedef enum ntx_status {
 
 /* Model architecture = the kwargs of network.model.ParamNerf (model.py:58) / Nerf (model.py:9). */
 typedef enum ntx_model_kind { NTX_MODEL_PARAMNERF = 0, NTX_MODEL_NERF = 1 } ntx_model_kind;
+/* layer.FourierFeatures (layer.py:8-23) / layer.IntegratedPositionalEncoding (layer.py:25-41) */
+typedef enum ntx_pos_encoding { NTX_POS_FOURIER = 0, NTX_POS_IPE = 1 } ntx_pos_encoding;
 
 typedef struct ntx_model_desc {
     int32_t kind;        /* ntx_model_kind */
@@ -58,6 +60,7 @@ typedef struct ntx_model_desc {
     int32_t width;       /* 256 */
     int32_t skip;        /* index of the single skip layer, 4 (model.py:107-108) */
     int32_t color_depth; /* ParamNerf: 1 (model.py:118); ignored for Nerf */
+    int32_t pos_encoding;/* ntx_pos_encoding of pos_embedding: FourierFeatures (n_pos 3) or IntegratedPositionalEncoding (n_pos 6) */
 } ntx_model_desc;
 
 /* flags of ntx_composite / ntx_render_rays */

@@ -21,7 +21,7 @@ FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS = 1, 2, 4
 class ModelDesc(C.Structure):
     """struct ntx_model_desc"""
     _fields_ = [(n, C.c_int32) for n in ("kind", "n_geo", "n_app", "n_pos", "pos_freq", "dir_freq",
-                                          "param_freq", "depth", "width", "skip", "color_depth")]
+                                          "param_freq", "depth", "width", "skip", "color_depth", "pos_encoding")]
 
 
 class NtxError(RuntimeError):

@@ -38,25 +38,28 @@ static int fail(int code, const char *fmt, ...) {
 // supported architectures = the kernels instantiated below
 // ---------------------------------------------------------------------------------------------
 struct Variant {
-    int n_geo, n_app, cd;
+    int n_geo, n_app, cd, ipe;
 };
 static const Variant kVariants[] = {
-    {1, 6, 1},   // carpet          (configs/config_carpet_render.py:59-72)
-    {1, 4, 1},   // grass, fur, plush
-    {2, 3, 1},   // grass_filtered
-    {0, 0, 0},   // plain Nerf      (model.py:9-45)
+    {1, 6, 1, 0},   // carpet          (configs/config_carpet_render.py:59-72)
+    {1, 4, 1, 0},   // grass, fur, plush
+    {2, 3, 1, 0},   // grass_filtered
+    {0, 0, 0, 0},   // plain Nerf      (model.py:9-45)
+    {1, 3, 1, 1},   // mip variant of grass_filtered: IPE on (mean, cov), blur parameter spliced out (renderer.py:385-386)
 };
 
 static int find_variant(const ntx_model_desc *d) {
     if (!d) return -1;
-    if (d->n_pos != 3 || d->pos_freq != POS_FREQ || d->dir_freq != DIR_FREQ || d->depth != DEPTH ||
+    const int ipe = d->pos_encoding == NTX_POS_IPE;
+    if (d->pos_encoding != NTX_POS_FOURIER && d->pos_encoding != NTX_POS_IPE) return -1;
+    if (d->n_pos != (ipe ? 6 : 3) || d->pos_freq != POS_FREQ || d->dir_freq != DIR_FREQ || d->depth != DEPTH ||
         d->width != WIDTH || d->skip != SKIP)
         return -1;
     const bool nerf = d->kind == NTX_MODEL_NERF;
     const int g = nerf ? 0 : d->n_geo, a = nerf ? 0 : d->n_app, cd = nerf ? 0 : d->color_depth;
     if (!nerf && (g + a > 0) && d->param_freq != PAR_FREQ) return -1;
     for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]); ++i)
-        if (kVariants[i].n_geo == g && kVariants[i].n_app == a && kVariants[i].cd == cd) return (int)i;
+        if (kVariants[i].n_geo == g && kVariants[i].n_app == a && kVariants[i].cd == cd && kVariants[i].ipe == ipe) return (int)i;
     return -1;
 }
 
@@ -64,9 +67,10 @@ static int unsupported(const ntx_model_desc *d) {
     if (!d) return fail(NTX_E_INVALID, "model descriptor is NULL");
     return fail(NTX_E_UNSUPPORTED,
                 "unsupported model: kind=%d n_parameters=[%d,%d] n_pos=%d freqs=%d/%d/%d depth=%d width=%d "
-                "skip=%d color_depth=%d (built: ParamNerf [1,6] [1,4] [2,3] and Nerf, 10/4/4 bands, 8x256, skip 4)",
+                "skip=%d color_depth=%d pos_encoding=%d (built: ParamNerf [1,6] [1,4] [2,3], Nerf, and ParamNerf [1,3] with "
+                "IntegratedPositionalEncoding on 6-D positions; 10/4/4 bands, 8x256, skip 4)",
                 d->kind, d->n_geo, d->n_app, d->n_pos, d->pos_freq, d->dir_freq, d->param_freq, d->depth,
-                d->width, d->skip, d->color_depth);
+                d->width, d->skip, d->color_depth, d->pos_encoding);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -85,7 +89,7 @@ struct Net {
 
 static Net view_blob(const Variant &v, const float *blob) {
     Net n{};
-    const int pm = pos_map_dim(v.n_geo), dm = dir_map_dim(v.n_app);
+    const int pm = pos_map_dim(v.n_geo, v.ipe), dm = dir_map_dim(v.n_app);
     size_t p = 0;
     auto take = [&](int in, int out) {
         Layer l{blob ? blob + p : nullptr, blob ? blob + p + (size_t)in * out : nullptr, in, out};
@@ -127,11 +131,11 @@ static void emit_segment(float *&dst, const Layer &l, int nsteps, int nmt, int r
 }
 
 static void pack(const Variant &v, const float *blob, float *out) {
-    const Geometry g = make_geometry(v.n_geo, v.n_app, v.cd);
+    const Geometry g = make_geometry(v.n_geo, v.n_app, v.cd, v.ipe);
     const Net n = view_blob(v, blob);
-    const int pm = pos_map_dim(v.n_geo), dm = dir_map_dim(v.n_app);
+    const int pm = pos_map_dim(v.n_geo, v.ipe), dm = dir_map_dim(v.n_app);
     float *dst = out;
-    auto posrow = [&](int s, int h) { return pos_row(v.n_geo, s, h); };
+    auto posrow = [&](int s, int h) { return pos_row(v.n_geo, s, h, v.ipe); };
     auto dirrow = [&](int s, int h) { return dir_row(v.n_app, s, h); };
     auto hidrow = [&](int s, int h) { return hidden_row(s, h); };
 
@@ -180,7 +184,7 @@ static void pack(const Variant &v, const float *blob, float *out) {
 }
 
 static size_t packed_floats(const Variant &v) {
-    const Geometry g = make_geometry(v.n_geo, v.n_app, v.cd);
+    const Geometry g = make_geometry(v.n_geo, v.n_app, v.cd, v.ipe);
     return (size_t)(g.padded_records + RING) * REC_FLOATS + g.aux_floats;
 }
 
@@ -205,7 +209,7 @@ namespace ntx {
     hipError_t launch_render_v##k(int n_wgs, RenderArgs &a, hipStream_t st);   \
     hipError_t launch_mlp_v##k(int n_wgs, MlpArgs &a, hipStream_t st);         \
     hipError_t launch_instance_v##k(int n_wgs, InstanceArgs &a, hipStream_t st);
-NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3)
+NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4)
 #undef NTX_DECL
 }  // namespace ntx
 
@@ -216,6 +220,7 @@ static hipError_t launch_render(const ntx_ctx *c, RenderArgs &a, hipStream_t st)
         case 1: return launch_render_v1(c->n_wgs, a, st);
         case 2: return launch_render_v2(c->n_wgs, a, st);
         case 3: return launch_render_v3(c->n_wgs, a, st);
+        case 4: return launch_render_v4(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -227,6 +232,7 @@ static hipError_t launch_instance(const ntx_ctx *c, InstanceArgs &a, hipStream_t
         case 1: return launch_instance_v1(c->n_wgs, a, st);
         case 2: return launch_instance_v2(c->n_wgs, a, st);
         case 3: return launch_instance_v3(c->n_wgs, a, st);
+        case 4: return launch_instance_v4(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -238,6 +244,7 @@ static hipError_t launch_mlp(const ntx_ctx *c, MlpArgs &a, hipStream_t st) {
         case 1: return launch_mlp_v1(c->n_wgs, a, st);
         case 2: return launch_mlp_v2(c->n_wgs, a, st);
         case 3: return launch_mlp_v3(c->n_wgs, a, st);
+        case 4: return launch_mlp_v4(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -297,7 +304,7 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     c->n_wgs = prop.multiProcessorCount;   // one 4-wave workgroup per CU: each wave owns a SIMD's register file
     c->desc = *desc;
     c->n_packed = packed_floats(kVariants[v]);
-    c->stream_floats = c->n_packed - make_geometry(kVariants[v].n_geo, kVariants[v].n_app, kVariants[v].cd).aux_floats;
+    c->stream_floats = c->n_packed - make_geometry(kVariants[v].n_geo, kVariants[v].n_app, kVariants[v].cd, kVariants[v].ipe).aux_floats;
     c->packed = nullptr;
     hipError_t e = hipMalloc((void **)&c->packed, c->n_packed * sizeof(float));
     if (e != hipSuccess) {
@@ -427,11 +434,12 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     if (n_samples < 2) return fail(NTX_E_INVALID, "n_samples must be >= 2 (renderer.py:174-177 needs a previous step)");
     if (n_rays == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
-    const int np = v.n_geo + v.n_app;
+    const int np = v.n_geo + v.n_app + v.ipe;   // parameters per row at the ABI (mip: incl. the spliced-out blur parameter)
     if (!rays_o || !rays_d || !t || !color_out || !alpha_out || (!params && np > 0))
         return fail(NTX_E_INVALID, "NULL buffer");
     if (rays_per_param_row < 1) return fail(NTX_E_INVALID, "rays_per_param_row must be >= 1");
     if (blur_idx < -1 || blur_idx >= np) return fail(NTX_E_INVALID, "blur_idx %d outside [-1,%d)", blur_idx, np);
+    if (v.ipe && blur_idx < 0) return fail(NTX_E_INVALID, "an IPE (mip) model needs blur_idx: the cone radius parameter (renderer.py:385)");
     if (blur_idx >= 0 && !cone_scale) return fail(NTX_E_INVALID, "blur_idx set but cone_scale is NULL");
     RenderArgs a{};
     a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed);
@@ -441,7 +449,7 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     a.color_out = color_out; a.alpha_out = alpha_out; a.weights_out = weights_out; a.status = status_flag;
     a.n_rays = n_rays; a.rays_per_row = rays_per_param_row;
     a.n_samples = n_samples; a.blur_idx = blur_idx; a.flags = flags;
-    a.delta = (1.0f - 0.0f) / (float)(n_samples - 1);
+    a.delta = (1.0f - 0.0f) / (float)(n_samples - 1 + v.ipe);   // mip: S+1 segment edges (renderer.py:374)
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
     HIP_TRY(launch_render(ctx, a, (hipStream_t)stream));
     return NTX_OK;
@@ -459,7 +467,8 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
         return fail(NTX_E_INVALID, "n_samples %d outside [1,%d]", n_samples, MAX_INSTANCE_SAMPLES);
     if (n_rays == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
-    const int np = v.n_geo + v.n_app;
+    const int np = v.n_geo + v.n_app + v.ipe;
+    if (v.ipe && (blur_idx < 0 || !t)) return fail(NTX_E_INVALID, "an IPE (mip) model needs blur_idx and t (renderer.py:511, 575)");
     if (!rays_d_map || !pts || !dists || !color_last || !alpha_last || !hit || !color_out || !alpha_out ||
         (!params_map && np > 0))
         return fail(NTX_E_INVALID, "NULL buffer");

@@ -211,6 +211,7 @@ NTX_DEV void run_segment(f32x16 (&acc)[8], WStream &ws, Gen &gen, Extra &&extra)
 template <int NGEO, int NAPP>
 struct SampleIn {
     float pos[3];
+    float cov[3];   // diagonal covariance of the cone-segment gaussian (IPE models only; dead otherwise)
     float dir[3];
     float par[NGEO + NAPP > 0 ? NGEO + NAPP : 1];
 };
@@ -224,6 +225,7 @@ NTX_DEV SampleIn<NGEO, NAPP> launder(const SampleIn<NGEO, NAPP> &in) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         asm volatile("" : "+v"(o.pos[k]));
+        asm volatile("" : "+v"(o.cov[k]));
         asm volatile("" : "+v"(o.dir[k]));
     }
 #pragma unroll
@@ -246,16 +248,19 @@ NTX_DEV float dir_id_value(const SampleIn<NGEO, NAPP> &in) {
     else return 0.0f;
 }
 
-// k-step S of the position segment: identity pairs, then {sin,cos}(2^f pos_c), then {sin,cos}(2^f geo_g)
-template <int NGEO, int NAPP, int S>
+// k-step S of the position segment: identity pairs, then {sin,cos}(2^f pos_c), then {sin,cos}(2^f geo_g).
+// IPE (layer.py:25-41): no identity for the position, and every pair is damped by exp(-0.5 * 4^f * cov_c).
+template <int NGEO, int NAPP, int IPE, int S>
 NTX_DEV float pos_feature(const SampleIn<NGEO, NAPP> &in, int h) {
-    constexpr int nid = pos_id_steps(NGEO);
+    constexpr int nid = pos_id_steps(NGEO, IPE), n3 = IPE ? 0 : 3;
     if constexpr (S < nid) {
-        const float lo = pos_id_value<NGEO, NAPP, 2 * S>(in), hi = pos_id_value<NGEO, NAPP, 2 * S + 1>(in);
+        const float lo = pos_id_value<NGEO, NAPP, 2 * S + (3 - n3)>(in), hi = pos_id_value<NGEO, NAPP, 2 * S + 1 + (3 - n3)>(in);
         return h ? hi : lo;
     } else if constexpr (S - nid < 3 * POS_FREQ) {
         constexpr int q = S - nid, f = q / 3, c = q % 3;
-        return sin_q(in.pos[c] * (float)(1 << f), h);
+        const float v = sin_q(in.pos[c] * (float)(1 << f), h);
+        if constexpr (IPE) return v * expf(-0.5f * (in.cov[c] * (float)(1 << (2 * f))));
+        else return v;
     } else if constexpr (S - nid - 3 * POS_FREQ < NGEO * PAR_FREQ) {
         constexpr int q = S - nid - 3 * POS_FREQ, f = q / (NGEO > 0 ? NGEO : 1), g = q % (NGEO > 0 ? NGEO : 1);
         return sin_q(in.par[g] * (float)(1 << f), h);
@@ -281,14 +286,14 @@ NTX_DEV float dir_feature(const SampleIn<NGEO, NAPP> &in, int h) {
     }
 }
 
-template <int NGEO, int NAPP>
+template <int NGEO, int NAPP, int IPE>
 struct PosGen {
     const SampleIn<NGEO, NAPP> &in;
     int h;
     float vals[PE_GROUP];
     template <int S, int N>
     NTX_DEV void prepare() {   // B values of k-steps S .. S+N-1 (S is a multiple of PE_GROUP)
-        static_for<N>([&](auto K) { vals[(S + decltype(K)::value) % PE_GROUP] = pos_feature<NGEO, NAPP, S + decltype(K)::value>(in, h); });
+        static_for<N>([&](auto K) { vals[(S + decltype(K)::value) % PE_GROUP] = pos_feature<NGEO, NAPP, IPE, S + decltype(K)::value>(in, h); });
     }
     template <int S>
     NTX_DEV float value() const { return vals[S % PE_GROUP]; }
@@ -310,19 +315,21 @@ struct DirGen {
 // ---------------------------------------------------------------------------------------------
 // the MLP on one batch of 32 samples (model.py:58-125 / 9-45); lanes l and l+32 hold sample l&31
 // ---------------------------------------------------------------------------------------------
-template <int NGEO_, int NAPP_, int CD_>
+template <int NGEO_, int NAPP_, int CD_, int IPE_ = 0>
 struct Cfg {
-    static constexpr int NGEO = NGEO_, NAPP = NAPP_, CD = CD_;
-    static constexpr int NP = NGEO_ + NAPP_;
-    static constexpr int PS = pos_steps(NGEO_);
+    static constexpr int NGEO = NGEO_, NAPP = NAPP_, CD = CD_, IPE = IPE_;
+    static constexpr int NP = NGEO_ + NAPP_;          // parameters the MODEL sees
+    static constexpr int NP_IN = NP + IPE_;           // parameters per row at the ABI: mip renderers splice the blur
+                                                      // parameter out before the model (renderer.py:385-386, 511-512)
+    static constexpr int PS = pos_steps(NGEO_, IPE_);
     static constexpr int DS = dir_steps(NAPP_);
     // first record of hidden pass li (1..8 = L1..L7, F; 9 = C1) and of the colour-half layer
     static constexpr int rec_pass(int li) {
         return PS * 2 + (li - 1) * HSTEPS * 2 + (li > SKIP + 1 ? PS * 2 : 0) + (CD_ && li > 9 ? DS * 2 : 0);
     }
     static constexpr int REC_C2 = rec_pass(9 + (CD_ ? 1 : 0));
-    static constexpr int REC_END = make_geometry(NGEO_, NAPP_, CD_).stream_records;
-    static constexpr int REC_PAD = make_geometry(NGEO_, NAPP_, CD_).padded_records;
+    static constexpr int REC_END = make_geometry(NGEO_, NAPP_, CD_, IPE_).stream_records;
+    static constexpr int REC_PAD = make_geometry(NGEO_, NAPP_, CD_, IPE_).padded_records;
 };
 
 // Two accumulator sets (2 x 128 AGPRs) alternate between layers: layer n's result is moved out of one set
@@ -347,7 +354,7 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
     // ---- trunk layer 0: pos_map -> 256 (model.py:104-106) into set A; set B <- bias of layer 1
     init_bias<8>(accA, aux, 0, h);
     {
-        PosGen<NGEO, NAPP> gen{in, h, {}};
+        PosGen<NGEO, NAPP, CFG::IPE> gen{in, h, {}};
         run_segment<CFG::PS, 8, 0>(accA, ws, gen, [&](auto S, auto MT) {
             constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
             if constexpr (mt == 1 && s % 4 == 0 && s < 32) init_bias_tile<s / 4>(accB, aux, 1, h);
@@ -381,7 +388,7 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
             auto conv = none;
             const SampleIn<NGEO, NAPP> in2 = launder(in);
             if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
-                PosGen<NGEO, NAPP> gen{in2, h, {}};
+                PosGen<NGEO, NAPP, CFG::IPE> gen{in2, h, {}};
                 run_segment<pre_steps, 8, rec0>(cur, ws, gen, conv);
             } else {                   // input = concat[dir_map, feature]  (model.py:115)
                 DirGen<NGEO, NAPP> gen{in2, h, {}};
@@ -443,6 +450,7 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
     // v_max_f32(0, NaN) is 0, so the first ReLU would swallow a NaN/Inf input that TensorFlow's relu propagates
     // (and tf.debugging.check_numerics then reports, renderer.py:140-141): chk - chk is 0 for finite inputs, NaN else
     float chk = in.pos[0] + in.pos[1] + in.pos[2] + in.dir[0] + in.dir[1] + in.dir[2];
+    if constexpr (CFG::IPE != 0) chk += in.cov[0] + in.cov[1] + in.cov[2];
 #pragma unroll
     for (int k = 0; k < CFG::NP; ++k) chk += in.par[k];
     chk = chk - chk;
@@ -508,6 +516,23 @@ NTX_DEV void composite_step(RayAccum &ra, float sigma, const float (&raw)[3], fl
 // ---------------------------------------------------------------------------------------------
 // fused render kernel: one wave per ray, S/32 batches per ray (renderer.py:47-213)
 // ---------------------------------------------------------------------------------------------
+// mip-NeRF cone-segment gaussian (renderer.py:416-424 / 575-578): moments along the ray and across it
+NTX_DEV void cone_moments(float mu, float hw, float radii, float &t_mean, float &t_var, float &r_var) {
+    const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2, den = 3.0f * mu2 + hw2;
+    t_mean = mu + (2.0f * mu * hw2) / den;
+    t_var = hw2 / 3.0f - (4.0f / 15.0f) * ((hw4 * (12.0f * mu2 - hw2)) / (den * den));
+    r_var = (radii * radii) * (mu2 / 4.0f + (5.0f / 12.0f) * hw2 - 4.0f / 15.0f * hw4 / den);
+}
+// diagonal covariance in world space (renderer.py:429-435 / 581-586)
+NTX_DEV void cone_cov(float t_var, float r_var, const float (&d)[3], float (&cov)[3]) {
+    const float mag = __builtin_fmaxf(1e-10f, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float dd = d[c] * d[c];
+        cov[c] = t_var * dd + r_var * (1.0f - dd / mag);
+    }
+}
+
 struct RenderArgs {
     const f32x4 *wstream;
     uint32_t stream_bytes;   // stream + wrap-around tail
@@ -532,9 +557,11 @@ NTX_DEV const T *kernargs() {
 #endif
 }
 
-NTX_DEV float z_of(const RenderArgs &a, int64_t ray, int i, float t0, float t1) {
-    if (a.z_vals) return a.z_vals[ray * a.n_samples + i];
-    const float tv = i == 0 ? 0.0f : (i == a.n_samples - 1 ? 1.0f : a.delta * (float)i);
+// depth i of the npts points of tf.linspace between t0 and t1 (npts = S samples, or S+1 segment edges for the mip
+// renderer, renderer.py:374-376); a.delta = float32(1 / (npts - 1))
+NTX_DEV float z_of(const RenderArgs &a, int64_t ray, int i, float t0, float t1, int npts) {
+    if (a.z_vals) return a.z_vals[ray * npts + i];
+    const float tv = i == 0 ? 0.0f : (i == npts - 1 ? 1.0f : a.delta * (float)i);
     return t0 * (1.0f - tv) + t1 * tv;   // renderer.py:102
 }
 
@@ -573,24 +600,40 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             const float dx = q.rays_d[3 * r], dy = q.rays_d[3 * r + 1], dz = q.rays_d[3 * r + 2];
             const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);   // renderer.py:98, 180
             const float cone = q.cone ? q.cone[r] : 0.0f;
-            const float *prow = q.params + (r / q.rays_per_row) * CFG::NP;
+            const float *prow = q.params + (r / q.rays_per_row) * CFG::NP_IN;
             const int i = 32 * b + j;
             const bool valid = i < S;
             const int ic = valid ? i : S - 1;
-            const float z = z_of(q, r, ic, t0, t1);
-            // dists: z[i+1]-z[i], the last one a copy of the previous (renderer.py:174-177), times |d| (:180)
-            const float zn = z_of(q, r, ic < S - 1 ? ic + 1 : ic - 1, t0, t1);
-            const float dist = (ic < S - 1 ? zn - z : z - zn) * dnorm;
             const int blur_idx = q.blur_idx;
-
             SampleIn<CFG::NGEO, CFG::NAPP> in;
-            in.pos[0] = ox + dx * z; in.pos[1] = oy + dy * z; in.pos[2] = oz + dz * z;   // renderer.py:114
             in.dir[0] = dx / dnorm; in.dir[1] = dy / dnorm; in.dir[2] = dz / dnorm;      // rays_d_n
+            float dist;
+            if constexpr (CFG::IPE == 0) {
+                const float z = z_of(q, r, ic, t0, t1, S);
+                // dists: z[i+1]-z[i], the last one a copy of the previous (renderer.py:174-177), times |d| (:180)
+                const float zn = z_of(q, r, ic < S - 1 ? ic + 1 : ic - 1, t0, t1, S);
+                dist = (ic < S - 1 ? zn - z : z - zn) * dnorm;
+                in.pos[0] = ox + dx * z; in.pos[1] = oy + dy * z; in.pos[2] = oz + dz * z;   // renderer.py:114
+                in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
 #pragma unroll
-            for (int k = 0; k < CFG::NP; ++k) {
-                float p = prow[k];
-                if (k == blur_idx) p = p * (cone * z);                                    // renderer.py:155-158
-                in.par[k] = p;
+                for (int k = 0; k < CFG::NP; ++k) {
+                    float p = prow[k];
+                    if (k == blur_idx) p = p * (cone * z);                                // renderer.py:155-158
+                    in.par[k] = p;
+                }
+            } else {
+                // MipRenderer.render_rays (renderer.py:365-409): sample i = the cone segment between edges i and i+1 of
+                // S+1 depths, encoded by its gaussian (mean, diagonal covariance); the blur parameter times cone_scale
+                // is the cone radius and is spliced out of the model's parameters; dists need no copy (:441-444)
+                const float e0 = z_of(q, r, ic, t0, t1, S + 1), e1 = z_of(q, r, ic + 1, t0, t1, S + 1);
+                dist = (e1 - e0) * dnorm;
+                float t_mean, t_var, r_var;
+                cone_moments((e0 + e1) / 2.0f, (e1 - e0) / 2.0f, prow[blur_idx] * cone, t_mean, t_var, r_var);
+                in.pos[0] = ox + dx * t_mean; in.pos[1] = oy + dy * t_mean; in.pos[2] = oz + dz * t_mean;
+                const float dd[3] = {dx, dy, dz};
+                cone_cov(t_var, r_var, dd, in.cov);
+#pragma unroll
+                for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[k < blur_idx ? k : k + 1];
             }
             float sigma, raw[3];
             mlp_batch<CFG>(in, ws, aux, lane, sigma, raw);
@@ -683,11 +726,23 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
             SampleIn<CFG::NGEO, CFG::NAPP> in;
 #pragma unroll
             for (int c = 0; c < 3; ++c) { in.pos[c] = a.pts[3 * sm + c]; in.dir[c] = a.rays_d_map[3 * sm + c]; }
+            if constexpr (CFG::IPE == 0) {
+                in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
 #pragma unroll
-            for (int c = 0; c < CFG::NP; ++c) {
-                float p = a.params_map[CFG::NP * sm + c];
-                if (c == a.blur_idx) p = p * (cone * a.t[sm] / a.patch_scale);                     // renderer.py:259-262
-                in.par[c] = p;
+                for (int c = 0; c < CFG::NP; ++c) {
+                    float p = a.params_map[CFG::NP * sm + c];
+                    if (c == a.blur_idx) p = p * (cone * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
+                    in.par[c] = p;
+                }
+            } else {
+                // MipInstanceRenderer (renderer.py:510-540, 570-587): radius = blur parameter * cone_scale / patch_scale,
+                // spliced out of the parameters; gaussian with mu = t and (sic) hw = dists; the mean is the sample point
+                const float *pr = a.params_map + CFG::NP_IN * sm;
+                float t_mean, t_var, r_var;
+                cone_moments(a.t[sm], a.dists[sm], pr[a.blur_idx] * cone / a.patch_scale, t_mean, t_var, r_var);
+                cone_cov(t_var, r_var, in.dir, in.cov);
+#pragma unroll
+                for (int c = 0; c < CFG::NP; ++c) in.par[c] = pr[c < a.blur_idx ? c : c + 1];
             }
             float sigma, raw[3];
             mlp_batch<CFG>(in, ws, aux, lane, sigma, raw);
@@ -754,7 +809,11 @@ __global__ __launch_bounds__(256) void mlp_kernel(MlpArgs a) {
         const int64_t mc = valid ? m : a.m - 1;
         SampleIn<CFG::NGEO, CFG::NAPP> in;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { in.pos[k] = a.pos[3 * mc + k]; in.dir[k] = a.dirs[3 * mc + k]; }
+        for (int k = 0; k < 3; ++k) {   // IPE models take pos[M,6] = (mean, diagonal covariance)
+            in.pos[k] = a.pos[(CFG::IPE ? 6 : 3) * mc + k];
+            in.cov[k] = CFG::IPE ? a.pos[6 * mc + 3 + k] : 0.0f;
+            in.dir[k] = a.dirs[3 * mc + k];
+        }
 #pragma unroll
         for (int k = 0; k < CFG::NP; ++k) in.par[k] = a.params[CFG::NP * mc + k];
         float sigma, raw[3];

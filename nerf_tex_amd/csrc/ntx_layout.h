@@ -44,26 +44,29 @@ NTX_HD constexpr int hidden_row(int s, int h) {
 }
 
 // ---- position segment: pos_map = [FF(pos,10) (63) | FF(params[:n_geo],4) (9*n_geo)]  (model.py:77,88-93)
-NTX_HD constexpr int pos_id_values(int n_geo) { return 3 + n_geo; }
-NTX_HD constexpr int pos_id_steps(int n_geo) { return (pos_id_values(n_geo) + 1) / 2; }
-NTX_HD constexpr int pos_steps_raw(int n_geo) { return pos_id_steps(n_geo) + 3 * POS_FREQ + n_geo * PAR_FREQ; }
-NTX_HD constexpr int pos_steps(int n_geo) { return pos_steps_raw(n_geo); }
-NTX_HD constexpr int pos_map_dim(int n_geo) { return 3 * (1 + 2 * POS_FREQ) + n_geo * (1 + 2 * PAR_FREQ); }
+// ipe = 1: the position embedding is mip-NeRF's IntegratedPositionalEncoding (layer.py:25-41) of a 6-D input
+// (mean, diagonal covariance): 6*POS_FREQ features [sin(y) e^(-var/2) (3L) | sin(y + pi/2) e^(-var/2) (3L)] with
+// y index f*3+c, NO identity block.
+NTX_HD constexpr int pos_emb_dim(int ipe) { return ipe ? 6 * POS_FREQ : 3 * (1 + 2 * POS_FREQ); }
+NTX_HD constexpr int pos_id_values(int n_geo, int ipe = 0) { return (ipe ? 0 : 3) + n_geo; }
+NTX_HD constexpr int pos_id_steps(int n_geo, int ipe = 0) { return (pos_id_values(n_geo, ipe) + 1) / 2; }
+NTX_HD constexpr int pos_steps(int n_geo, int ipe = 0) { return pos_id_steps(n_geo, ipe) + 3 * POS_FREQ + n_geo * PAR_FREQ; }
+NTX_HD constexpr int pos_map_dim(int n_geo, int ipe = 0) { return pos_emb_dim(ipe) + n_geo * (1 + 2 * PAR_FREQ); }
 
 // row of the reference's pos_map that (step s, half h) carries, or -1 for a zero pad
-NTX_HD constexpr int pos_row(int n_geo, int s, int h) {
-    const int nid = pos_id_steps(n_geo);
+NTX_HD constexpr int pos_row(int n_geo, int s, int h, int ipe = 0) {
+    const int nid = pos_id_steps(n_geo, ipe), base = pos_emb_dim(ipe), n3 = ipe ? 0 : 3;
     if (s < nid) {
         const int v = 2 * s + h;
-        if (v >= pos_id_values(n_geo)) return -1;
-        return v < 3 ? v : 3 * (1 + 2 * POS_FREQ) + (v - 3);
+        if (v >= pos_id_values(n_geo, ipe)) return -1;
+        return v < n3 ? v : base + (v - n3);
     }
     int q = s - nid;
-    if (q < 3 * POS_FREQ) return 3 + 6 * (q / 3) + 3 * h + (q % 3);
+    if (q < 3 * POS_FREQ) return ipe ? h * 3 * POS_FREQ + q : 3 + 6 * (q / 3) + 3 * h + (q % 3);
     q -= 3 * POS_FREQ;
     if (q < n_geo * PAR_FREQ) {
         const int f = q / n_geo, g = q % n_geo;
-        return 3 * (1 + 2 * POS_FREQ) + n_geo + 2 * f * n_geo + h * n_geo + g;
+        return base + n_geo + 2 * f * n_geo + h * n_geo + g;
     }
     return -1;
 }
@@ -106,7 +109,7 @@ NTX_HD constexpr int dir_row(int n_app, int s, int h) {
 //   tail : a copy of the first RING records (so the prefetch ring wraps into the next batch)
 // AUX block (read through LDS): biases in accumulator order, alpha head, rgb head.
 struct Geometry {
-    int n_geo, n_app, color_depth;   // color_depth: 1 = ParamNerf, 0 = Nerf
+    int n_geo, n_app, color_depth, ipe;   // color_depth: 1 = ParamNerf, 0 = Nerf
     int pos_steps, dir_steps;
     int stream_records;              // without pad and wrap-around tail
     int padded_records;              // rounded up to a multiple of RING
@@ -120,10 +123,10 @@ NTX_HD constexpr int aux_alpha_off() { return N_BIAS_LAYERS_MAX * AUX_BIAS_STRID
 NTX_HD constexpr int aux_rgb_off() { return aux_alpha_off() + 2 * 128 + 4; }             // [3][half][64] + bias[3]
 NTX_HD constexpr int aux_total() { return round_up(aux_rgb_off() + 3 * 2 * 64 + 4, 64); }
 
-NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth) {
+NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth, int ipe = 0) {
     Geometry g{};
-    g.n_geo = n_geo; g.n_app = n_app; g.color_depth = color_depth;
-    g.pos_steps = pos_steps(n_geo);
+    g.n_geo = n_geo; g.n_app = n_app; g.color_depth = color_depth; g.ipe = ipe;
+    g.pos_steps = pos_steps(n_geo, ipe);
     g.dir_steps = dir_steps(n_app);
     int rec = 0;
     rec += g.pos_steps * 2;                 // L0

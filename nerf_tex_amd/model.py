@@ -14,7 +14,7 @@ from typing import Dict, List, Sequence, Tuple, Union
 
 import numpy as np
 
-from .layer import n_freq_bands_of
+from .layer import embedding_kind, n_freq_bands_of
 
 KIND_PARAMNERF, KIND_NERF = 0, 1
 
@@ -23,8 +23,10 @@ class NerfModel:
     """Stand-in for the `tf.keras.Model` the reference builds (model.py:125)."""
 
     def __init__(self, kind: int, n_parameters: Sequence[int], n_pos: int, pos_freq: int, dir_freq: int,
-                 param_freq: int, depth: int, width: int, skips: Sequence[int], color_depth: int, name: str) -> None:
+                 param_freq: int, depth: int, width: int, skips: Sequence[int], color_depth: int, name: str,
+                 pos_encoding: str = "fourier") -> None:
         self.kind = kind
+        self.pos_encoding = pos_encoding          # "fourier" | "ipe" (IntegratedPositionalEncoding on n_pos = 6)
         self.n_geo, self.n_app = (0, 0) if kind == KIND_NERF else (int(n_parameters[0]), int(n_parameters[1]))
         self.n_pos, self.pos_freq, self.dir_freq, self.param_freq = n_pos, pos_freq, dir_freq, param_freq
         self.depth, self.width, self.skips, self.color_depth = depth, width, tuple(skips), color_depth
@@ -40,7 +42,8 @@ class NerfModel:
 
     @property
     def pos_map_dim(self) -> int:
-        return self.n_pos * (1 + 2 * self.pos_freq) + self.n_geo * (1 + 2 * self.param_freq)
+        emb = 6 * self.pos_freq if self.pos_encoding == "ipe" else self.n_pos * (1 + 2 * self.pos_freq)
+        return emb + self.n_geo * (1 + 2 * self.param_freq)
 
     @property
     def dir_map_dim(self) -> int:
@@ -74,7 +77,8 @@ class NerfModel:
         if len(self.skips) != 1:
             raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, f"skips={self.skips}: the HIP kernels implement one skip layer")
         return _lib.ModelDesc(self.kind, self.n_geo, self.n_app, self.n_pos, self.pos_freq, self.dir_freq,
-                              self.param_freq, self.depth, self.width, self.skips[0], self.color_depth)
+                              self.param_freq, self.depth, self.width, self.skips[0], self.color_depth,
+                              1 if self.pos_encoding == "ipe" else 0)
 
     # ---- weights -----------------------------------------------------------------------
     def initialize(self) -> None:
@@ -152,6 +156,8 @@ class NerfModel:
         pos, dirs, params = inputs
         pos = pos.contiguous().float(); dirs = dirs.contiguous().float()
         m = pos.shape[0]
+        if pos.shape[1] != self.n_pos:
+            raise ValueError(f"pos must be [{m},{self.n_pos}], got {tuple(pos.shape)}")
         if self.n_params > 0:
             params = params.contiguous().float()
             if params.shape != (m, self.n_params):
@@ -184,7 +190,7 @@ def ParamNerf(pos_embedding, dir_embedding, param_embedding, n_parameters: Union
         raise NotImplementedError("param_depth > 0 / embedding_config are used by no reference config and have no HIP kernel")
     return {name: NerfModel(KIND_PARAMNERF, n_parameters, n_pos, n_freq_bands_of(pos_embedding),
                             n_freq_bands_of(dir_embedding), n_freq_bands_of(param_embedding), depth, width, skips,
-                            color_depth, name)}
+                            color_depth, name, embedding_kind(pos_embedding))}
 
 
 def CoarseFine(model_config, **kwargs) -> dict:

@@ -52,18 +52,22 @@ class Renderer:
         rays_d = rays_d.reshape(n, 3).contiguous().float()
         t = t.reshape(n, 2).contiguous().float()
         cone = cone_scale.reshape(n).contiguous().float()
-        P = self.model.n_params
+        mip = getattr(self.model, "pos_encoding", "fourier") == "ipe"
+        if mip != isinstance(self, MipRenderer):
+            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, "IPE models go with MipRenderer, FourierFeatures models with Renderer")
+        P = self.model.n_params + (1 if mip else 0)        # mip: the row still holds the blur parameter (renderer.py:385-386)
         params = None
         if P > 0:
             params = parameters.reshape(B, -1).contiguous().float().to(dev)
             if params.shape[1] != P:
                 raise ValueError(f"parameters must be [B,{P}], got {tuple(parameters.shape)}")
         S = self.n_samples
+        n_z = S + 1 if mip else S                          # mip: S+1 segment edges (renderer.py:374)
         z = None
         if z_vals is not None:
-            z = z_vals.reshape(n, S).contiguous().float()
+            z = z_vals.reshape(n, n_z).contiguous().float()
         elif self.perturb:
-            z = self._jitter(t, S)                                           # renderer.py:106-111
+            z = self._jitter(t, n_z)                                         # renderer.py:106-111 / 379-383
         flags = (_lib.FLAG_MAP_EXR if self.map_exr else 0) | (_lib.FLAG_COMPOSITE_BKGD if composite_bkgd else 0)
         status = None
         if self.check_numerics:
@@ -146,6 +150,21 @@ class Renderer:
         return c_out, a_out, w_out
 
 
+class MipRenderer(Renderer):
+    """network.renderer.MipRenderer (renderer.py:356-473): cone-segment gaussians + integrated positional encoding.
+    `model` must be an IPE ParamNerf (pos_embedding = IntegratedPositionalEncoding, n_pos = 6); `parameters` keep
+    the blur parameter at `blur_idx` (it becomes the cone radius and is spliced out before the model).  Everything
+    runs in the same fused kernel (`ntx_render_rays`) as the base renderer."""
+
+    def __init__(self, blur_idx: int = None, **kwargs):
+        if blur_idx is None:
+            raise ValueError("MipRenderer needs blur_idx (renderer.py:385 indexes the parameters with it)")
+        if kwargs.get("n_importance", 0) > 0:
+            raise NotImplementedError("Importance sampling for mip-NeRF style rendering is not implemented in the reference either (renderer.py:403-404)")
+        super().__init__(blur_idx=blur_idx, **kwargs)
+        self.blur_idx_mip = blur_idx
+
+
 class InstanceRenderer(Renderer):
     """network.renderer.InstanceRenderer (renderer.py:215-354): the renderer the shipped render configs use.
 
@@ -225,7 +244,7 @@ class InstanceRenderer(Renderer):
                 _lib.check(_lib.lib.ntx_render_instanced(
                     self.model.ctx(dev.index or 0), ptr(bufs["rays_d_map"]), ptr(bufs["pts"]), ptr(bufs["t"]),
                     ptr(bufs["dists"]), ptr(bufs["color_last"]), ptr(bufs["alpha_last"]), ptr(bufs["alpha_weight"]),
-                    ptr(bufs["instance_id"]), ptr(bufs["hit"]), ptr(bufs["params_map"]) if self.model.n_params else None,
+                    ptr(bufs["instance_id"]), ptr(bufs["hit"]), ptr(bufs["params_map"]) if bufs["params_map"].numel() else None,
                     ptr(c_c), k, S, -1 if self.blur_idx is None else int(self.blur_idx), self.patch_scale,
                     float(self.density_scale), flags, _lib.f3(bk), ptr(inst_col), ptr(col_c), ptr(al_c), ptr(status),
                     torch.cuda.current_stream(dev).cuda_stream))
@@ -237,3 +256,17 @@ class InstanceRenderer(Renderer):
         if status is not None:
             self._status = status
         return {"color_pred": color.reshape(B, HW, 3), "alpha_pred": alpha.reshape(B, HW)}
+
+
+class MipInstanceRenderer(InstanceRenderer):
+    """network.renderer.MipInstanceRenderer (renderer.py:475-587): the InstanceRenderer tail with an IPE model fed
+    (sample point, cone covariance from t / dists / blur * cone_scale / patch_scale).  `params_map` rows keep the blur
+    parameter at `blur_idx`."""
+
+    def __init__(self, blur_idx: int = None, **kwargs):
+        if blur_idx is None:
+            raise ValueError("MipInstanceRenderer needs blur_idx (renderer.py:511)")
+        super().__init__(blur_idx=blur_idx, **kwargs)
+        self.blur_idx_mip = blur_idx
+        if getattr(self.model, "pos_encoding", "fourier") != "ipe":
+            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, "MipInstanceRenderer needs an IPE model")

@@ -60,6 +60,11 @@ _REMAP = {
     "network.model.CoarseFine": "nerf_tex_amd.model.CoarseFine",
     "network.model.FourierFeatures": "nerf_tex_amd.layer.FourierFeatures",
     "network.layer.FourierFeatures": "nerf_tex_amd.layer.FourierFeatures",
+    "network.model.IntegratedPositionalEncoding": "nerf_tex_amd.layer.IntegratedPositionalEncoding",
+    "network.layer.IntegratedPositionalEncoding": "nerf_tex_amd.layer.IntegratedPositionalEncoding",
+    "network.renderer.InstanceRenderer": "nerf_tex_amd.renderer.InstanceRenderer",
+    "network.renderer.MipRenderer": "nerf_tex_amd.renderer.MipRenderer",
+    "network.renderer.MipInstanceRenderer": "nerf_tex_amd.renderer.MipInstanceRenderer",
     "network.ray_sampler.Proxy": "nerf_tex_amd.ray_sampler.Proxy",
     "network.ray_sampler.Frustum": "nerf_tex_amd.ray_sampler.Frustum",
     "network.proxy.AABB": "nerf_tex_amd.proxy.AABB",

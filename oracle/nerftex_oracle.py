@@ -56,6 +56,7 @@ class ModelSpec:
     width: int = 256
     skips: Tuple[int, ...] = (4,)
     color_depth: int = 1                 # ParamNerf only (model.py:118); Nerf has none
+    pos_encoding: str = "fourier"        # "fourier" = FourierFeatures; "ipe" = IntegratedPositionalEncoding (n_pos = 6)
 
     @property
     def n_geo(self) -> int:
@@ -71,7 +72,8 @@ class ModelSpec:
 
     @property
     def pos_map_dim(self) -> int:
-        return self.n_pos * (1 + 2 * self.pos_freq) + self.n_geo * (1 + 2 * self.param_freq)
+        emb = 6 * self.pos_freq if self.pos_encoding == "ipe" else self.n_pos * (1 + 2 * self.pos_freq)
+        return emb + self.n_geo * (1 + 2 * self.param_freq)
 
     @property
     def dir_map_dim(self) -> int:
@@ -222,6 +224,18 @@ def fourier_features(x, n_freq_bands: int, dtype=F32):
     return np.concatenate(out, -1)
 
 
+def integrated_positional_encoding(x, n_freq_bands: int, dtype=F32):
+    """layer.IntegratedPositionalEncoding.call (layer.py:25-41): x = [mean(3) | diagonal covariance(3)] ->
+    [sin(y) e^(-y_var/2) | sin(y + pi/2) e^(-y_var/2)], y and y_var laid out frequency-major (index f*3+c)."""
+    x = np.asarray(x, dtype=dtype)
+    freq = (2.0 ** np.arange(n_freq_bands)).astype(dtype)
+    y = (x[..., None, :3] * freq[:, None]).reshape(-1, 3 * n_freq_bands)             # :33
+    y_var = (x[..., None, 3:] * freq[:, None] ** 2).reshape(-1, 3 * n_freq_bands)    # :34
+    xx = np.concatenate([y, y + dtype(.5 * np.pi)], axis=-1)                           # :36
+    vv = np.concatenate([y_var, y_var], axis=-1)
+    return (np.sin(xx) * np.exp(dtype(-.5) * vv)).astype(dtype)                        # :38-41
+
+
 def _dense(x, kernel, bias, dtype, relu):
     y = x @ np.asarray(kernel, dtype=dtype) + np.asarray(bias, dtype=dtype)
     return np.maximum(y, dtype(0)) if relu else y
@@ -237,7 +251,10 @@ def model_forward(weights: Sequence[np.ndarray], spec: ModelSpec, pos, dirs, par
     g, a = spec.n_geo, spec.n_app
     inter = {}
 
-    pos_map = fourier_features(pos, spec.pos_freq, dtype)                       # model.py:77
+    if spec.pos_encoding == "ipe":
+        pos_map = integrated_positional_encoding(pos, spec.pos_freq, dtype)
+    else:
+        pos_map = fourier_features(pos, spec.pos_freq, dtype)                   # model.py:77
     dir_map = fourier_features(dirs, spec.dir_freq, dtype)                      # model.py:78
     if g > 0:                                                                  # model.py:88-93
         pos_map = np.concatenate([pos_map, fourier_features(params[:, :g], spec.param_freq, dtype)], -1)
@@ -417,6 +434,93 @@ def render_rays_hierarchical(weights_coarse, weights_fine, spec, rays_o, rays_d,
     return {"color_pred": fine["color_pred"], "alpha_pred": fine["alpha_pred"],
             "color_pred_coarse": coarse["color_pred"], "alpha_pred_coarse": coarse["alpha_pred"],
             "z_vals": z_all, "z_samples": z_samples}
+
+
+def cone_segment_gaussians(rays_o, rays_d, t_vals, radii, dtype=F32):
+    """MipRenderer.get_cone_segment_gaussians (renderer.py:411-437): t_vals [n,S+1] edges, radii [n,1]."""
+    t0 = t_vals[..., :-1]; t1 = t_vals[..., 1:]
+    mu = (t0 + t1) / dtype(2); hw = (t1 - t0) / dtype(2)
+    t_mean = mu + (dtype(2) * mu * hw ** 2) / (dtype(3) * mu ** 2 + hw ** 2)
+    t_var = (hw ** 2) / dtype(3) - dtype(4 / 15) * ((hw ** 4 * (dtype(12) * mu ** 2 - hw ** 2)) / (dtype(3) * mu ** 2 + hw ** 2) ** 2)
+    r_var = radii ** 2 * ((mu ** 2) / dtype(4) + dtype(5 / 12) * hw ** 2 - dtype(4 / 15) * (hw ** 4) / (dtype(3) * mu ** 2 + hw ** 2))
+    mean = rays_o[..., None, :] + rays_d[..., None, :] * t_mean[..., None]
+    d_mag_sq = np.maximum(dtype(1e-10), np.sum(rays_d ** 2, axis=-1, keepdims=True))
+    d_outer_diag = rays_d ** 2
+    null_outer_diag = dtype(1) - d_outer_diag / d_mag_sq
+    cov_diag = t_var[..., None] * d_outer_diag[..., None, :] + r_var[..., None] * null_outer_diag[..., None, :]
+    return mean.astype(dtype), cov_diag.astype(dtype)
+
+
+def mip_render_rays(weights, spec, rays_o, rays_d, t, parameters, cone_scale, n_samples, blur_idx, composite_bkgd,
+                    bkgd_color, map_exr=False, net_chunk=65536, z_override=None, dtype=F32):
+    """MipRenderer.render_rays + map_model_output (renderer.py:365-473), perturb=False.  `parameters` [n, P+1]
+    still holds the blur parameter at `blur_idx`; the model (`spec`, an IPE ParamNerf) sees the other P."""
+    rays_o = np.asarray(rays_o, dtype=dtype); rays_d = np.asarray(rays_d, dtype=dtype)
+    t = np.asarray(t, dtype=dtype); parameters = np.asarray(parameters, dtype=dtype)
+    cone_scale = np.asarray(cone_scale, dtype=dtype).reshape(rays_o.shape[0], 1)
+    rays_d_n = rays_d / np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True))
+    z_vals = z_values(t, n_samples + 1, dtype) if z_override is None else np.asarray(z_override, dtype=dtype)   # :374-376
+    blur = parameters[..., blur_idx, None] * cone_scale                                                       # :385
+    params = np.concatenate([parameters[..., :blur_idx], parameters[..., blur_idx + 1:]], axis=-1)          # :386
+    mean, cov = cone_segment_gaussians(rays_o, rays_d, z_vals, blur, dtype)
+    pts = np.concatenate([mean, cov], axis=-1)                                                                # :390
+    color, alpha = evaluate_model(weights, spec, pts, rays_d_n, params, None, None, None, net_chunk, dtype)
+    dists = (z_vals[..., 1:] - z_vals[..., :-1]) * np.sqrt(np.sum(rays_d[..., None, :] ** 2, -1))            # :441-444
+    with np.errstate(over="ignore"):
+        cm = (np.where(color > 0, color, np.exp(np.minimum(color, dtype(0))) - dtype(1)) + dtype(1)) if map_exr \
+            else dtype(1) / (dtype(1) + np.exp(-color))
+    am = dtype(1) - np.exp(-np.maximum(alpha, dtype(0)) * dists)                                              # :459
+    trans = (dtype(1.) - am) + dtype(1e-10)
+    cum = np.cumprod(trans, axis=-1, dtype=dtype)
+    w = am * np.concatenate([np.ones_like(cum[..., :1]), cum[..., :-1]], -1)                                  # :462
+    c = np.sum(w[..., None] * cm, axis=-2, dtype=dtype); a = np.sum(w, -1, dtype=dtype)
+    if composite_bkgd:
+        c = c + (dtype(1.) - a[..., None]) * np.asarray(bkgd_color, dtype=dtype)
+    return {"color_pred": c.astype(dtype), "alpha_pred": a.astype(dtype), "z_vals": z_vals}
+
+
+def mip_instance_cov(rays_d, t_vals, radii, dists, dtype=F32):
+    """MipInstanceRenderer.get_cone_segment_gaussians (renderer.py:570-587) on flat samples: mu = t, hw = dists."""
+    mu, hw = t_vals, dists
+    t_var = (hw ** 2) / dtype(3) - dtype(4 / 15) * ((hw ** 4 * (dtype(12) * mu ** 2 - hw ** 2)) / (dtype(3) * mu ** 2 + hw ** 2) ** 2)
+    r_var = radii ** 2 * ((mu ** 2) / dtype(4) + dtype(5 / 12) * hw ** 2 - dtype(4 / 15) * (hw ** 4) / (dtype(3) * mu ** 2 + hw ** 2))
+    d_mag_sq = np.maximum(dtype(1e-10), np.sum(rays_d ** 2, axis=-1, keepdims=True))
+    d_outer_diag = rays_d ** 2
+    return (t_var[:, None] * d_outer_diag + r_var[:, None] * (dtype(1) - d_outer_diag / d_mag_sq)).astype(dtype)
+
+
+def mip_instance_evaluate_model(weights, spec, rays_d_map, pts, t, dists, color_last, alpha_last, alpha_weight, hit,
+                                params_map, cone_scale, blur_idx, patch_scale=1.0, density_scale=1.0,
+                                density_reweighting=True, map_exr=False, composite_bkgd=False, bkgd_color=(1., 1., 1.),
+                                dtype=F32):
+    """MipInstanceRenderer.evaluate_model (renderer.py:485-568): the InstanceRenderer tail with the model fed
+    (sample point, cone covariance) and the blur parameter spliced out."""
+    n_rays, S = dists.shape
+    f = lambda a: np.asarray(a, dtype=dtype)
+    rays_d_map, pts, t, dists, params_map = f(rays_d_map), f(pts), f(t), f(dists), f(params_map)
+    cone_scale = f(cone_scale).reshape(n_rays, 1)
+    idxs = np.nonzero(np.asarray(hit))[0]
+    if idxs.shape[0] == 0:
+        return np.zeros((n_rays, 3), dtype), np.zeros((n_rays,), dtype)
+    g = lambda a: np.asarray(a)[idxs]
+    rays_d_map, pts, t, dists, params_map, cone = g(rays_d_map), g(pts), g(t), g(dists), g(params_map), g(cone_scale)
+    color_last, alpha_last, alpha_weight = g(f(color_last)), g(f(alpha_last)), g(f(alpha_weight))
+    blur = params_map[..., blur_idx] * cone[..., None, 0] / dtype(patch_scale)                               # :511
+    params_map = np.concatenate([params_map[..., :blur_idx], params_map[..., blur_idx + 1:]], axis=-1)      # :512
+    pos_flat = pts.reshape(-1, 3); dirs_flat = rays_d_map.reshape(-1, 3)
+    params_flat = params_map.reshape(pos_flat.shape[0], params_map.shape[-1])
+    sel = np.nonzero(dists.reshape(-1) > 0)[0]                                                               # :526
+    color = np.zeros((pos_flat.shape[0], 3), dtype); alpha = np.zeros((pos_flat.shape[0], 1), dtype)
+    if sel.shape[0] > 0:
+        cov = mip_instance_cov(dirs_flat[sel], t.reshape(-1)[sel], blur.reshape(-1)[sel], dists.reshape(-1)[sel], dtype)
+        c, a = model_forward(weights, spec, np.concatenate([pos_flat[sel], cov], -1), dirs_flat[sel], params_flat[sel], dtype)
+        color[sel] = c; alpha[sel] = a
+    alpha = alpha.reshape(pts.shape[:-1]) * (alpha_weight if density_reweighting else dtype(1)) * dtype(density_scale)
+    cm, am = instance_map_model_output(color.reshape(pts.shape), color_last, alpha, alpha_last, dists, patch_scale,
+                                       composite_bkgd, bkgd_color, map_exr, False, dtype)
+    color_map = np.zeros((n_rays, 3), dtype); alpha_map = np.zeros((n_rays,), dtype)
+    color_map[idxs] = cm; alpha_map[idxs] = am
+    return color_map, alpha_map
 
 
 def renderer_call(weights, spec, rays_o, rays_d, t, parameters, cone_scale, n_samples=64,

@@ -13,7 +13,11 @@ TOL = 1e-4   # BASELINE.json north_star: <= 1e-4 relative L-inf (float32) vs the
 
 def make_model(n_parameters=(1, 6), kind="ParamNerf", seed=0, dense_media=False):
     """(product model with synthetic weights, oracle spec, oracle weight list)"""
-    if kind == "Nerf":
+    if kind == "IPE":                      # mip variant: IntegratedPositionalEncoding on (mean, covariance)
+        ipe = {"module": "network.layer.IntegratedPositionalEncoding", "n_freq_bands": 10}
+        model = ParamNerf(ipe, EMB(4), EMB(4), list(n_parameters), n_pos=6)["model"]
+        spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(n_parameters), n_pos=6, pos_encoding="ipe")
+    elif kind == "Nerf":
         model = Nerf(EMB(10), EMB(4))["model"]
         spec = orc.ModelSpec(kind="Nerf", n_parameters=(0, 0))
     else:

@@ -1,0 +1,82 @@
+"""mip-NeRF variants: IntegratedPositionalEncoding model, MipRenderer, MipInstanceRenderer
+against the oracle restatements of layer.py:25-41 and renderer.py:356-587.  `-m gpu`."""
+
+import numpy as np
+import pytest
+
+from oracle import nerftex_oracle as orc
+from tests.common import TOL, make_model
+from tests.test_gpu_instance import FakeInstancer
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def d(a):
+    return torch.as_tensor(np.asarray(a), device=torch.device("cuda", 0))
+
+
+@pytest.mark.parametrize("m", [1, 33, 3000])
+def test_ipe_model_forward(m):
+    model, spec, w = make_model((1, 3), "IPE")
+    rng = np.random.default_rng(m)
+    mean = rng.uniform(-2, 2, size=(m, 3)); cov = rng.uniform(0, 1, size=(m, 3)) * 10.0 ** rng.uniform(-7, -2, size=(m, 3))
+    cov[0] = 0.0                                              # zero covariance: IPE reduces to plain sin / cos features
+    pos = np.concatenate([mean, cov], -1).astype(np.float32)
+    dirs = rng.normal(size=(m, 3)); dirs = (dirs / np.linalg.norm(dirs, axis=-1, keepdims=True)).astype(np.float32)
+    prm = rng.uniform(0, 1, size=(m, 4)).astype(np.float32)
+    c, a = model((d(pos), d(dirs), d(prm)))
+    rc, ra = orc.model_forward(w, spec, pos, dirs, prm, np.float64)
+    got = np.concatenate([c.cpu().numpy(), a.cpu().numpy()], -1)
+    # the reference rounds y + pi/2 in float32 before the sine (layer.py:36); the kernel shifts the quadrant exactly, as
+    # the float64 truth does -- both are within the gate
+    assert orc.rel_linf(got, np.concatenate([rc, ra], -1)) <= 5e-5
+
+
+@pytest.mark.parametrize("S", [32, 64, 45])
+@pytest.mark.parametrize("bk", [False, True])
+def test_mip_renderer(S, bk):
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.renderer import MipRenderer, Renderer
+    from nerf_tex_amd import _lib
+    fam = synthetic.FAMILIES["grass_filtered"]
+    model, spec, w = make_model((1, 3), "IPE", dense_media=True)
+    n = 150
+    ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"])
+    rd = (rd * 1.7).astype(np.float32)                        # |d| != 1: t_cov uses d^2, null space uses d^2/|d|^2
+    t[7] = np.inf
+    params = np.asarray([[8.0, 0.3, 0.0, -.707, .707]], np.float32)   # [blur, geo, app x3], blur_idx 0
+    r = MipRenderer(model=model, n_samples=S, perturb=False, blur_idx=0)
+    out = r(d(ro[None]), d(rd[None]), d(t[None]), parameters=d(params), cone_scale=d(cone[None]), composite_bkgd=bk, bkgd_color=[.1, .2, .3])
+    r.raise_if_nonfinite()
+    hit = np.isfinite(t[:, 0])
+    ref = orc.mip_render_rays(w, spec, ro[hit], rd[hit], t[hit], np.repeat(params, hit.sum(), 0), cone[hit], S, 0, bk, (.1, .2, .3), dtype=np.float64)
+    got = np.concatenate([out["color_pred"][0].cpu().numpy(), out["alpha_pred"][0].cpu().numpy()[:, None]], -1)
+    want = np.concatenate([ref["color_pred"], ref["alpha_pred"][:, None]], -1)
+    assert orc.rel_linf(got[hit], want) <= TOL
+    assert np.all(got[~hit][:, 3] == 0) and np.allclose(got[~hit][:, :3], (.1, .2, .3) if bk else 0.0)
+    assert float(want[:, 3].max()) > 0.3
+    with pytest.raises(_lib.NtxError):                        # an IPE model cannot be driven by the plain renderer
+        Renderer(model=model, n_samples=S, perturb=False, blur_idx=0)(d(ro[None]), d(rd[None]), d(t[None]), parameters=d(params), cone_scale=d(cone[None]))
+
+
+@pytest.mark.parametrize("S", [40, 130])
+def test_mip_instance_renderer(S):
+    from nerf_tex_amd.renderer import MipInstanceRenderer
+    model, spec, w = make_model((1, 3), "IPE", dense_media=True)
+    inst = FakeInstancer(5, seed=S)
+    r = MipInstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=0.09, step_size=0.002, blur_idx=0, density_scale=400.0,
+                            render_chunk=10_000)
+    rng = np.random.default_rng(2)
+    n = 50
+    ro = rng.normal(size=(1, n, 3)).astype(np.float32); rd = rng.normal(size=(1, n, 3)).astype(np.float32)
+    t = np.tile(np.asarray([[1.0, 2.0]], np.float32), (1, n, 1))
+    params = rng.uniform(0.2, 1, size=(1, 5)).astype(np.float32); params[0, 0] = 6.0
+    cone = rng.uniform(1e-3, 5e-3, size=(1, n, 1)).astype(np.float32)
+    out = r(d(ro), d(rd), d(t), parameters=d(params), cone_scale=d(cone), composite_bkgd=True, bkgd_color=[.3, .6, .9])
+    r.raise_if_nonfinite()
+    rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map, hit = inst.last
+    rc, ra = orc.mip_instance_evaluate_model(w, spec, rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, hit, params_map,
+                                             cone[0], 0, 0.09, 400.0, True, False, True, (.3, .6, .9), dtype=np.float64)
+    got = np.concatenate([out["color_pred"][0].cpu().numpy(), out["alpha_pred"][0].cpu().numpy()[:, None]], -1)
+    assert orc.rel_linf(got, np.concatenate([rc, ra[:, None]], -1)) <= TOL

@@ -29,7 +29,7 @@ def test_create_without_gpu_reports_no_device():
     if torch.cuda.is_available():
         pytest.skip("this is the CPU-container check")
     from nerf_tex_amd import _lib
-    d = _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1)
+    d = _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, 0)
     h = C.c_void_p()
     rc = _lib.lib.ntx_create(C.byref(d), None, 0, 0, C.byref(h))
     assert rc in (_lib.NTX_E_NODEVICE, _lib.NTX_E_HIP) and _lib.lib.ntx_last_error()
@@ -37,14 +37,16 @@ def test_create_without_gpu_reports_no_device():
 
 def test_unsupported_desc_is_rejected_on_host():
     from nerf_tex_amd import _lib
-    for bad in (_lib.ModelDesc(0, 3, 3, 3, 10, 4, 4, 8, 256, 4, 1), _lib.ModelDesc(0, 1, 6, 3, 8, 4, 4, 8, 256, 4, 1),
-                _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 6, 256, 4, 1), _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 128, 4, 1)):
+    for bad in (_lib.ModelDesc(0, 3, 3, 3, 10, 4, 4, 8, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 6, 3, 8, 4, 4, 8, 256, 4, 1, 0),
+                _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 6, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 128, 4, 1, 0),
+                _lib.ModelDesc(0, 1, 3, 3, 10, 4, 4, 8, 256, 4, 1, 1), _lib.ModelDesc(0, 1, 6, 6, 10, 4, 4, 8, 256, 4, 1, 1)):
         assert _lib.lib.ntx_weight_count(C.byref(bad)) == 0
         assert b"unsupported" in _lib.lib.ntx_last_error()
 
 
-@pytest.mark.parametrize("desc,count", [((0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1), 683524), ((0, 1, 4, 3, 10, 4, 4, 8, 256, 4, 1), 678916),
-                                        ((0, 2, 3, 3, 10, 4, 4, 8, 256, 4, 1), 681220), ((1, 0, 0, 3, 10, 4, 0, 8, 256, 4, 0), 593408 + 8 * 256 + 1 + 256 + 128 + 3)])
+@pytest.mark.parametrize("desc,count", [((0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, 0), 683524), ((0, 1, 4, 3, 10, 4, 4, 8, 256, 4, 1, 0), 678916),
+                                        ((0, 2, 3, 3, 10, 4, 4, 8, 256, 4, 1, 0), 681220), ((1, 0, 0, 3, 10, 4, 0, 8, 256, 4, 0, 0), 593408 + 8 * 256 + 1 + 256 + 128 + 3),
+                                        ((0, 1, 3, 6, 10, 4, 4, 8, 256, 4, 1, 1), 675076)])
 def test_pack_weights_is_a_permutation_with_wraparound_tail(desc, count):
     """Host-only packer: every reference weight lands in the stream exactly once (rest is zero pad),
     the tail repeats the first 8 records, biases/heads land in the aux block."""
@@ -110,7 +112,9 @@ def test_reference_render_config_runs_through_remap():
     assert m.module == "nerf_tex_amd.render.Render"
     assert m.test_dataset_config.module == "nerf_tex_amd.dataset.Dataset"
     assert m.test_dataset_config.proxy_config.module == "nerf_tex_amd.proxy.AABB"
-    assert m.renderer_config.module == "network.renderer.InstanceRenderer"      # out of scope: left untouched
+    assert m.renderer_config.module == "nerf_tex_amd.renderer.InstanceRenderer"
+    assert m.renderer_config.instancer_config.module == "instancer.instancer.Instancer"   # the Embree instancer stays the reference's
+    assert m.logger_config.module == "network.logger.Logger"                               # out of scope: left untouched
 
 
 def test_renderer_kwargs_mirror_reference():

@@ -254,3 +254,21 @@ def test_sample_pdf_properties():
     a = orc.sample_pdf(mid, w[:, 1:-1], 33, det=False, u=u, dtype=np.float64)
     b = orc.sample_pdf(mid, w[:, 1:-1], 33, det=False, u=u, dtype=np.float32)
     assert np.max(np.abs(a - b)) < 1e-4
+
+
+def test_ipe_and_cone_gaussians():
+    """layer.py:25-41 and renderer.py:411-437: zero covariance gives plain [sin | cos] (frequency-major), large covariance
+    damps to 0; a degenerate cone (radius 0) has covariance only along the ray."""
+    x = np.asarray([[0.3, -1.2, 2.0, 0, 0, 0]])
+    e = orc.integrated_positional_encoding(x, 4, np.float64)[0]
+    assert e.shape == (24,)
+    y = (x[0, None, :3] * (2.0 ** np.arange(4))[:, None]).reshape(-1)
+    np.testing.assert_allclose(e[:12], np.sin(y), atol=1e-15); np.testing.assert_allclose(e[12:], np.cos(y), atol=1e-12)
+    x[0, 3:] = 50.0
+    assert np.max(np.abs(orc.integrated_positional_encoding(x, 4, np.float64))) < 1e-10
+    o = np.zeros((1, 3)); dd = np.asarray([[0., 0., 2.]]); tv = np.asarray([[1.0, 1.5, 2.5]])
+    mean, cov = orc.cone_segment_gaussians(o, dd, tv, np.zeros((1, 1)), np.float64)
+    assert mean.shape == (1, 2, 3) and np.all(cov[..., :2] == 0) and np.all(cov[..., 2] > 0)
+    assert np.all(mean[0, :, 2] > 2 * tv[0, :-1]) and np.all(mean[0, :, 2] < 2 * tv[0, 1:])
+    _, cov_r = orc.cone_segment_gaussians(o, dd, tv, np.full((1, 1), 0.01), np.float64)
+    assert np.all(cov_r[..., :2] > 0) and np.allclose(cov_r[..., 2], cov[..., 2])    # radius only widens the null space of d
