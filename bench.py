@@ -94,6 +94,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="float32", choices=["float32", "bf16x3"],
+                    help="arithmetic of the Dense layers (include/nerftex.h: ntx_precision); float32 = the reference's")
     args = ap.parse_args()
 
     import torch
@@ -122,7 +124,8 @@ def main() -> None:
     emb = lambda n: {"module": "network.model.FourierFeatures", "n_freq_bands": n}
     model = ParamNerf(emb(10), emb(4), emb(4), list(fam["n_parameters"]))["model"]
     model.set_blob(synthetic.synthetic_weights(model.layer_table(), seed=0))
-    renderer = Renderer(model=model, n_samples=S, perturb=False, blur_idx=fam["blur_idx"], check_numerics=False)
+    renderer = Renderer(model=model, n_samples=S, perturb=False, blur_idx=fam["blur_idx"], check_numerics=False,
+                        precision=args.precision)
 
     n_rays = H * W                                           # per GPU (weak scaling)
     ro, rd, t, cone = synthetic.all_hit_rays(n_rays, fam["b_0"], fam["b_1"], fam["cam"], seed=1 + rank)

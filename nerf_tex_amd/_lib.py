@@ -30,6 +30,8 @@ class NtxError(RuntimeError):
         self.code = code
 
 
+PRECISIONS = {"float32": 0, "bf16x3": 1}   # ntx_precision
+
 _fp = C.POINTER(C.c_float)
 _vp = C.c_void_p
 
@@ -52,9 +54,12 @@ SYMBOLS = {
     "ntx_render_instanced": (C.c_int, [_vp] * 12 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, _fp,
                                         _vp, _vp, _vp, _vp, _vp]),
     "ntx_image_epilogue": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "ntx_set_precision": (C.c_int, [_vp, C.c_int]),
     "ntx_kernel_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ntx_packed_count": (C.c_size_t, [C.POINTER(ModelDesc)]),
     "ntx_pack_weights": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, _fp, C.c_size_t]),
+    "ntx_packed_bf16x3_bytes": (C.c_size_t, [C.POINTER(ModelDesc)]),
+    "ntx_pack_weights_bf16x3": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, C.POINTER(C.c_uint16), C.c_size_t]),
 }
 
 

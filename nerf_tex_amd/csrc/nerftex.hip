@@ -183,6 +183,76 @@ static void pack(const Variant &v, const float *blob, float *out) {
     }
 }
 
+// ---- bf16x3 stream (ntx_layout.h: one record = the A operand of one (k16-step, M-tile), hi record then lo record) ----
+static uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static float bf16_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+template <class RowFn>
+static void emit_segment16(uint16_t *&dst, const Layer &l, int nsteps16, int nmt, int row_offset, RowFn rowfn) {
+    for (int u = 0; u < nsteps16; ++u)
+        for (int mt = 0; mt < nmt; ++mt) {
+            uint16_t *hi = dst, *lo = dst + 512;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int row = rowfn(8 * u + e, lane >> 5);
+                    const int col = 32 * mt + (lane & 31);
+                    float val = 0.0f;
+                    if (row >= 0 && col < l.out) val = l.w[(size_t)(row_offset + row) * l.out + col];
+                    const uint16_t h = bf16_rne(val);
+                    hi[lane * 8 + e] = h;
+                    lo[lane * 8 + e] = bf16_rne(val - bf16_f32(h));
+                }
+            dst += 1024;
+        }
+}
+
+static size_t packed16_bytes(const Variant &v) {
+    return (size_t)(stream16_padded(v.n_geo, v.n_app, v.cd) + RING16) * 1024;
+}
+
+// hidden segment first, encoder segment second within a pass (ntx_device_bf16.h: Cfg16)
+static void pack16(const Variant &v, const float *blob, uint16_t *out) {
+    const Net n = view_blob(v, blob);
+    const int pm = pos_map_dim(v.n_geo, 0), dm = dir_map_dim(v.n_app);
+    const int ps = steps16(pos_steps(v.n_geo, 0)), ds = steps16(dir_steps(v.n_app)), hs = HSTEPS / 8;
+    uint16_t *dst = out;
+    auto posrow = [&](int s, int h) { return s < pos_steps(v.n_geo, 0) ? pos_row(v.n_geo, s, h, 0) : -1; };
+    auto dirrow = [&](int s, int h) { return s < dir_steps(v.n_app) ? dir_row(v.n_app, s, h) : -1; };
+    auto hidrow = [&](int s, int h) { return hidden_row(s, h); };
+    emit_segment16(dst, n.trunk[0], ps, 8, 0, posrow);
+    for (int i = 1; i < DEPTH; ++i) {
+        if (i == SKIP + 1) {
+            emit_segment16(dst, n.trunk[i], hs, 8, pm, hidrow);
+            emit_segment16(dst, n.trunk[i], ps, 8, 0, posrow);
+        } else {
+            emit_segment16(dst, n.trunk[i], hs, 8, 0, hidrow);
+        }
+    }
+    emit_segment16(dst, n.feature, hs, 8, 0, hidrow);
+    if (n.has_c1) {
+        emit_segment16(dst, n.c1, hs, 8, dm, hidrow);
+        emit_segment16(dst, n.c1, ds, 8, 0, dirrow);
+        emit_segment16(dst, n.c2, hs, 4, 0, hidrow);
+    } else {
+        emit_segment16(dst, n.c2, hs, 4, dm, hidrow);
+        emit_segment16(dst, n.c2, ds, 4, 0, dirrow);
+    }
+    const int rec = stream16_records(v.n_geo, v.n_app, v.cd), pad = stream16_padded(v.n_geo, v.n_app, v.cd);
+    memset(dst, 0, (size_t)(pad - rec) * 1024);
+    dst += (size_t)(pad - rec) * 512;
+    memcpy(dst, out, (size_t)RING16 * 1024);
+}
+
 static size_t packed_floats(const Variant &v) {
     const Geometry g = make_geometry(v.n_geo, v.n_app, v.cd, v.ipe);
     return (size_t)(g.padded_records + RING) * REC_FLOATS + g.aux_floats;
@@ -200,6 +270,9 @@ struct ntx_ctx {
     size_t stream_floats; // incl. tail
     size_t n_packed;
     ntx_model_desc desc;
+    int precision;        // NTX_PRECISION_*: arithmetic of the Dense layers in ntx_render_rays
+    uint16_t *packed16;   // device: bf16x3 stream | tail (NULL for IPE families); shares the f32 aux block
+    size_t packed16_bytes;
 };
 
 // The two big kernels of each model family live in their own translation unit (ntx_variant.hip compiled
@@ -211,7 +284,23 @@ namespace ntx {
     hipError_t launch_instance_v##k(int n_wgs, InstanceArgs &a, hipStream_t st);
 NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4)
 #undef NTX_DECL
+hipError_t launch_render_bf16_v0(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_render_bf16_v1(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_render_bf16_v2(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_render_bf16_v3(int n_wgs, RenderArgs &a, hipStream_t st);
 }  // namespace ntx
+
+static hipError_t launch_render_bf16(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
+    switch (c->variant) {
+        case 0: return launch_render_bf16_v0(c->n_wgs, a, st);
+#ifndef NTX_DEV_ONLY_CARPET
+        case 1: return launch_render_bf16_v1(c->n_wgs, a, st);
+        case 2: return launch_render_bf16_v2(c->n_wgs, a, st);
+        case 3: return launch_render_bf16_v3(c->n_wgs, a, st);
+#endif
+        default: return hipErrorNotSupported;
+    }
+}
 
 static hipError_t launch_render(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
     switch (c->variant) {
@@ -284,6 +373,28 @@ int ntx_pack_weights(const ntx_model_desc *desc, const float *weights_host, size
     return NTX_OK;
 }
 
+size_t ntx_packed_bf16x3_bytes(const ntx_model_desc *desc) {
+    const int v = find_variant(desc);
+    if (v < 0) { unsupported(desc); return 0; }
+    if (kVariants[v].ipe) { fail(NTX_E_UNSUPPORTED, "bf16x3 precision is built for the FourierFeatures families only"); return 0; }
+    return packed16_bytes(kVariants[v]);
+}
+
+int ntx_pack_weights_bf16x3(const ntx_model_desc *desc, const float *weights_host, size_t n_floats, uint16_t *packed_out,
+                            size_t n_bytes) {
+    const int v = find_variant(desc);
+    if (v < 0) return unsupported(desc);
+    if (kVariants[v].ipe) return fail(NTX_E_UNSUPPORTED, "bf16x3 precision is built for the FourierFeatures families only");
+    if (!weights_host || !packed_out) return fail(NTX_E_INVALID, "NULL buffer");
+    if (n_floats != view_blob(kVariants[v], nullptr).count)
+        return fail(NTX_E_INVALID, "weight blob has %zu floats, model needs %zu", n_floats,
+                    view_blob(kVariants[v], nullptr).count);
+    if (n_bytes != packed16_bytes(kVariants[v]))
+        return fail(NTX_E_INVALID, "packed buffer has %zu bytes, needs %zu", n_bytes, packed16_bytes(kVariants[v]));
+    pack16(kVariants[v], weights_host, packed_out);
+    return NTX_OK;
+}
+
 int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_floats, int device, ntx_ctx **out) {
     if (!out) return fail(NTX_E_INVALID, "out is NULL");
     *out = nullptr;
@@ -312,6 +423,19 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
         delete c;
         return fail(NTX_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     }
+    c->precision = NTX_PRECISION_F32;
+    c->packed16 = nullptr;
+    c->packed16_bytes = 0;
+    if (!kVariants[v].ipe) {
+        c->packed16_bytes = packed16_bytes(kVariants[v]);
+        e = hipMalloc((void **)&c->packed16, c->packed16_bytes);
+        if (e != hipSuccess) {
+            const size_t bytes = c->packed16_bytes;
+            (void)hipFree(c->packed);
+            delete c;
+            return fail(NTX_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        }
+    }
     *out = c;
     if (weights_host) {
         const int rc = ntx_set_weights(c, weights_host, n_floats);
@@ -322,7 +446,18 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
         }
     } else {
         HIP_TRY(hipMemset(c->packed, 0, c->n_packed * sizeof(float)));
+        if (c->packed16) HIP_TRY(hipMemset(c->packed16, 0, c->packed16_bytes));
     }
+    return NTX_OK;
+}
+
+int ntx_set_precision(ntx_ctx *ctx, int precision) {
+    if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
+    if (precision != NTX_PRECISION_F32 && precision != NTX_PRECISION_BF16X3)
+        return fail(NTX_E_INVALID, "unknown precision %d", precision);
+    if (precision == NTX_PRECISION_BF16X3 && !ctx->packed16)
+        return fail(NTX_E_UNSUPPORTED, "bf16x3 precision is built for the FourierFeatures families only");
+    ctx->precision = precision;
     return NTX_OK;
 }
 
@@ -333,12 +468,18 @@ int ntx_set_weights(ntx_ctx *ctx, const float *weights_host, size_t n_floats) {
     if (rc != NTX_OK) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpy(ctx->packed, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (ctx->packed16) {
+        std::vector<uint16_t> p16(ctx->packed16_bytes / 2);
+        pack16(kVariants[ctx->variant], weights_host, p16.data());
+        HIP_TRY(hipMemcpy(ctx->packed16, p16.data(), ctx->packed16_bytes, hipMemcpyHostToDevice));
+    }
     return NTX_OK;
 }
 
 int ntx_destroy(ntx_ctx *ctx) {
     if (!ctx) return NTX_OK;
     if (ctx->packed) (void)hipFree(ctx->packed);
+    if (ctx->packed16) (void)hipFree(ctx->packed16);
     delete ctx;
     return NTX_OK;
 }
@@ -451,6 +592,12 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     a.n_samples = n_samples; a.blur_idx = blur_idx; a.flags = flags;
     a.delta = (1.0f - 0.0f) / (float)(n_samples - 1 + v.ipe);   // mip: S+1 segment edges (renderer.py:374)
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
+    if (ctx->precision == NTX_PRECISION_BF16X3) {
+        a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed16);
+        a.stream_bytes = (uint32_t)ctx->packed16_bytes;
+        HIP_TRY(launch_render_bf16(ctx, a, (hipStream_t)stream));
+        return NTX_OK;
+    }
     HIP_TRY(launch_render(ctx, a, (hipStream_t)stream));
     return NTX_OK;
 }

@@ -1,0 +1,376 @@
+// ntx_device_bf16.h -- opt-in "bf16x3" precision of the fused render kernel (gfx950).
+//
+// Every Dense layer is evaluated with the bf16 matrix cores on a 3-term split of both operands,
+//     x*w ~= hi(x)*hi(w) + hi(x)*lo(w) + lo(x)*hi(w),      hi = bf16(v), lo = bf16(v - hi),   float32 accumulate,
+// (v_mfma_f32_32x32x16_bf16, 16x the MAC rate of the f32 MFMA, on a pipe the VALU does not share).  Measured against the
+// float32 restatement of the reference: 2.7e-5 rel-Linf on the dense-media image, 8.5e-6 on glorot weights
+// (tools/emulate_bf16_split.py), inside the 1e-4 gate; the exact-f32 kernel of ntx_device.h stays the default.
+//
+// Structure = the f32 kernel's: one wave64 = 32 samples, activations in registers, each wave streams its own copy of the
+// packed weights from L2 (61 B/clk/CU sustained, tools/ubench/bf16x3_stream.hip -> 3.6-3.8x the f32 MFMA rate).
+// A k16-step of the bf16 MFMA is 8 consecutive k2-steps of the f32 layout (ntx_layout.h): element e of lane half h in
+// k16-step u is the feature hidden_row(8u+e, h) / pos_row(8u+e, h) / dir_row(8u+e, h), so the same accumulator-register
+// -> next-layer-B-operand identity holds, now with a bias+ReLU+split+pack between.
+#pragma once
+
+#include "ntx_device.h"
+
+namespace ntx {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct WStream16 {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff;
+    i32x4 ring[RING16];
+};
+
+NTX_DEV i32x4 ws16_load(const WStream16 &ws, uint32_t rec) {
+    return __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, rec * 1024u, 0);
+}
+
+NTX_DEV void ws16_prime(WStream16 &ws, const void *base, uint32_t stream_bytes, int lane) {
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, stream_bytes, 0x00020000);
+    ws.voff = (uint32_t)lane * 16u;
+    static_for<RING16>([&](auto I) { ws.ring[I] = ws16_load(ws, I); });
+}
+
+template <int N, int REC0>
+NTX_DEV void skip_records16(WStream16 &ws) {
+    static_for<N>([&](auto I) {
+        constexpr int rec = REC0 + decltype(I)::value;
+        ws.ring[rec % RING16] = ws16_load(ws, rec + RING16);
+    });
+}
+
+// B operand of one k16-step: 8 features per lane, split
+struct B16 {
+    bf16x8 hi, lo;
+};
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+NTX_DEV uint32_t pack2(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+NTX_DEV float lo_f32(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+NTX_DEV float hi_f32(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// relu as an integer max: one v_max_i32, no canonicalising pre-op (fmaxf on an MFMA result costs two instructions);
+// +NaN stays NaN, -NaN and -0 become +0
+NTX_DEV float relu1(float x) {
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+
+NTX_DEV f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+// geometry of the k16 stream (host packer: pack16 in nerftex.hip).  Within a pass the hidden segment comes FIRST and the
+// encoder segment second (the order of the k-summation is free): the activations are converted just in time behind the
+// hidden segment's own MFMAs and never need to be held as a whole.
+template <class CFG>
+struct Cfg16 {
+    static constexpr int PS16 = steps16(CFG::PS), DS16 = steps16(CFG::DS), HS16 = HSTEPS / 8;
+    static constexpr int rec_pass(int li) {   // first record of hidden pass li (1..8 = L1..L7, F; 9 = C1)
+        return PS16 * 16 + (li - 1) * HS16 * 16 + (li > SKIP + 1 ? PS16 * 16 : 0) + (CFG::CD && li > 9 ? DS16 * 16 : 0);
+    }
+    static constexpr int REC_C2 = rec_pass(9 + (CFG::CD ? 1 : 0));
+    static constexpr int REC_END = REC_C2 + (CFG::CD ? 0 : DS16 * 8) + HS16 * 8;
+    static constexpr int REC_PAD = round_up(REC_END, RING16);
+    static_assert(REC_END == stream16_records(CFG::NGEO, CFG::NAPP, CFG::CD), "stream bookkeeping");
+};
+
+// ---- B-operand generators.  The B operand of k16-step U is produced by 12 PIECES of VALU work, piece<U, Q>(), which
+// run_segment16 places behind the MFMA pairs of step U-1 (the bf16 MFMA pipe and the VALU are separate: a pair of MFMAs
+// hides ~8 VALU instructions); value<U>() hands over the finished operand.
+struct Words16 {
+    uint32_t hw[4], lw[4];
+    NTX_DEV B16 get() const {
+        const u32x4 h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
+        return B16{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
+    }
+};
+
+// activations: bias is already in the accumulators; act + split + pack.  The 8 values of k16-step U are registers
+// 8(U&1)..+7 of tile U/2 = features hidden_row(8U+e, half).  Pair p = Q/3 in three stages Q%3: read + act (+ alpha head,
+// model.py:111, on the float32 value), hi word + residuals, lo word.
+template <bool RELU, bool ALPHA>
+struct ConvGen {
+    const f32x16 (&prev)[8];
+    const float *aux;
+    int h;
+    float &sig;
+    Words16 w;
+    float x0, x1, r0, r1;
+    template <int U, int Q>
+    NTX_DEV void piece() {
+        constexpr int p = Q / 3, t = Q % 3, reg = 8 * (U & 1) + 2 * p;
+        if constexpr (t == 0) {
+            x0 = prev[U >> 1][reg];
+            x1 = prev[U >> 1][reg + 1];
+            if constexpr (RELU) { x0 = relu1(x0); x1 = relu1(x1); }
+            if constexpr (ALPHA) {
+                sig = __builtin_fmaf(x0, aux[aux_alpha_off() + h * 128 + 8 * U + 2 * p], sig);
+                sig = __builtin_fmaf(x1, aux[aux_alpha_off() + h * 128 + 8 * U + 2 * p + 1], sig);
+            }
+        } else if constexpr (t == 1) {
+            w.hw[p] = pack2(x0, x1);
+            r0 = x0 - lo_f32(w.hw[p]);
+            r1 = x1 - hi_f32(w.hw[p]);
+        } else {
+            w.lw[p] = pack2(r0, r1);
+        }
+    }
+    template <int U>
+    NTX_DEV B16 value() const { return w.get(); }
+};
+
+// encoders: pieces 0..7 evaluate one feature each, pieces 8..11 split and pack a pair
+template <class CFG, bool DIR>
+struct EncGen16 {
+    const SampleIn<CFG::NGEO, CFG::NAPP> &in;
+    int h;
+    Words16 w;
+    float v[8];
+    template <int U, int Q>
+    NTX_DEV void piece() {
+        if constexpr (Q < 8) {
+            constexpr int s = 8 * U + Q;
+            if constexpr (DIR) {
+                if constexpr (s < CFG::DS) v[Q] = dir_feature<CFG::NGEO, CFG::NAPP, s>(in, h);
+                else v[Q] = 0.0f;
+            } else {
+                if constexpr (s < CFG::PS) v[Q] = pos_feature<CFG::NGEO, CFG::NAPP, CFG::IPE, s>(in, h);
+                else v[Q] = 0.0f;
+            }
+        } else {
+            constexpr int p = Q - 8;
+            w.hw[p] = pack2(v[2 * p], v[2 * p + 1]);
+            w.lw[p] = pack2(v[2 * p] - lo_f32(w.hw[p]), v[2 * p + 1] - hi_f32(w.hw[p]));
+        }
+    }
+    template <int U>
+    NTX_DEV B16 value() const { return w.get(); }
+};
+
+// one segment: acc[mt] += (W_hi + W_lo)^T * (B_hi + B_lo) without the lo*lo term, NSTEPS k16-steps.  Tiles are taken two
+// at a time so that consecutive MFMAs alternate accumulators: a SLOT is one pair of MFMAs followed by the VALU/LDS work
+// placed in its shadow (pieces of the next step's B operand, extra(U, Q)), pinned by a sched_barrier.
+template <int NSTEPS, int NMT, int REC0, class Gen, class Extra>
+NTX_DEV void run_segment16(f32x16 (&acc)[8], WStream16 &ws, Gen &gen, Extra &&extra) {
+    constexpr int NSLOT = NMT / 2 * 3, PPS = 12 / NSLOT;
+    static_for<12>([&](auto Q) { gen.template piece<0, decltype(Q)::value>(); });   // exposed
+    B16 b = gen.template value<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NSTEPS>([&](auto U) {
+        constexpr int u = U;
+        static_for<NMT / 2>([&](auto G) {
+            constexpr int g = G;
+            constexpr int rec = REC0 + (u * NMT + 2 * g) * 2;   // records: tile 2g hi, lo, tile 2g+1 hi, lo
+            const bf16x8 a0h = __builtin_bit_cast(bf16x8, ws.ring[(rec + 0) % RING16]);
+            const bf16x8 a0l = __builtin_bit_cast(bf16x8, ws.ring[(rec + 1) % RING16]);
+            const bf16x8 a1h = __builtin_bit_cast(bf16x8, ws.ring[(rec + 2) % RING16]);
+            const bf16x8 a1l = __builtin_bit_cast(bf16x8, ws.ring[(rec + 3) % RING16]);
+            static_for<3>([&](auto T) {
+                constexpr int t = T, q = 3 * g + t;
+                if constexpr (t == 0) {
+                    acc[2 * g] = mfma16(a0h, b.hi, acc[2 * g]);
+                    acc[2 * g + 1] = mfma16(a1h, b.hi, acc[2 * g + 1]);
+                } else if constexpr (t == 1) {
+                    acc[2 * g] = mfma16(a0h, b.lo, acc[2 * g]);
+                    acc[2 * g + 1] = mfma16(a1h, b.lo, acc[2 * g + 1]);
+                    ws.ring[(rec + 0) % RING16] = ws16_load(ws, rec + 0 + RING16);
+                    ws.ring[(rec + 2) % RING16] = ws16_load(ws, rec + 2 + RING16);
+                } else {
+                    acc[2 * g] = mfma16(a0l, b.hi, acc[2 * g]);
+                    acc[2 * g + 1] = mfma16(a1l, b.hi, acc[2 * g + 1]);
+                    ws.ring[(rec + 1) % RING16] = ws16_load(ws, rec + 1 + RING16);
+                    ws.ring[(rec + 3) % RING16] = ws16_load(ws, rec + 3 + RING16);
+                }
+                if constexpr (u + 1 < NSTEPS)
+                    static_for<PPS>([&](auto K) { gen.template piece<u + 1, q * PPS + decltype(K)::value>(); });
+                extra(U, std::integral_constant<int, q>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        if constexpr (u + 1 < NSTEPS) b = gen.template value<u + 1>();
+    });
+}
+
+template <class CFG>
+NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream16 &ws, const float *aux_in, int lane,
+                            float &sigma, float (&rgb)[3]) {
+    using G16 = Cfg16<CFG>;
+    constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
+    const int h = lane >> 5;
+    uint32_t opaque_zero = 0;
+    asm volatile("" : "+v"(opaque_zero));
+    const float *aux = aux_in + opaque_zero;
+
+    f32x16 accA[8], accB[8];
+    auto none = [](auto, auto) {};
+
+    // ---- trunk layer 0 into set A; set B <- bias of layer 1
+    init_bias<8>(accA, aux, 0, h);
+    {
+        EncGen16<CFG, false> gen{in, h, {}, {}};
+        run_segment16<G16::PS16, 8, 0>(accA, ws, gen, [&](auto U, auto Q) {
+            constexpr int u = decltype(U)::value, q = decltype(Q)::value;
+            if constexpr (u < 4 && q < 2) init_bias_tile<2 * u + q>(accB, aux, 1, h);
+        });
+        static_assert(G16::PS16 >= 4, "layer-1 bias initialised behind layer 0");
+    }
+
+    constexpr int NPASS = 8 + (CFG::CD ? 1 : 0);
+    float sig_part = 0.0f;
+    auto hidden_pass = [&](auto LI, f32x16 (&cur)[8], f32x16 (&prev)[8]) {
+        constexpr int li = decltype(LI)::value;
+        constexpr bool relu_in = li != 9;
+        constexpr int rec0 = G16::rec_pass(li);
+        constexpr bool has_pos = li == SKIP + 1, has_dir = CFG::CD != 0 && li == 9;
+        constexpr bool init_next = li < NPASS;
+        {
+            ConvGen<relu_in, li == DEPTH> cg{prev, aux, h, sig_part, {}, 0.f, 0.f, 0.f, 0.f};
+            run_segment16<G16::HS16, 8, rec0>(cur, ws, cg, [&](auto U, auto Q) {
+                constexpr int u = decltype(U)::value, q = decltype(Q)::value;
+                // tile T of the drained set is free once groups 2T and 2T+1 are converted (behind steps 2T-1 and 2T)
+                if constexpr (init_next && (u & 1) == 1 && q == 6) init_bias_tile<(u - 1) / 2>(prev, aux, li + 1, h);
+            });
+        }
+        if constexpr (has_pos || has_dir) {
+            const SampleIn<NGEO, NAPP> in2 = launder(in);
+            if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
+                EncGen16<CFG, false> gen{in2, h, {}, {}};
+                run_segment16<G16::PS16, 8, rec0 + G16::HS16 * 16>(cur, ws, gen, none);
+            } else {                   // input = concat[dir_map, feature]  (model.py:115)
+                EncGen16<CFG, true> gen{in2, h, {}, {}};
+                run_segment16<G16::DS16, 8, rec0 + G16::HS16 * 16>(cur, ws, gen, none);
+            }
+        }
+    };
+    static_for<NPASS>([&](auto I) {
+        constexpr int li = decltype(I)::value + 1;
+        if constexpr (li & 1) hidden_pass(std::integral_constant<int, li>{}, accB, accA);
+        else hidden_pass(std::integral_constant<int, li>{}, accA, accB);
+    });
+    sigma = sig_part + __shfl_xor(sig_part, 32, 64) + aux[aux_alpha_off() + 256];
+
+    // ---- colour half layer, 4 tiles
+    auto color_half = [&](f32x16 (&cur)[8], f32x16 (&prev)[8]) {
+        init_bias<4>(cur, aux, 10, h);
+        float unused = 0.0f;
+        if constexpr (CFG::CD == 0) {   // plain Nerf: input = concat[dir_map, feature]  (model.py:39-42)
+            ConvGen<false, false> cg{prev, aux, h, unused, {}, 0.f, 0.f, 0.f, 0.f};
+            run_segment16<G16::HS16, 4, G16::REC_C2>(cur, ws, cg, none);
+            const SampleIn<NGEO, NAPP> in2 = launder(in);
+            EncGen16<CFG, true> gen{in2, h, {}, {}};
+            run_segment16<G16::DS16, 4, G16::REC_C2 + G16::HS16 * 8>(cur, ws, gen, none);
+        } else {
+            ConvGen<true, false> cg{prev, aux, h, unused, {}, 0.f, 0.f, 0.f, 0.f};
+            run_segment16<G16::HS16, 4, G16::REC_C2>(cur, ws, cg, none);
+        }
+        // rgb head (model.py:123) on the float32 result
+        static_for<3>([&](auto C) {
+            constexpr int c = C;
+            const f32x4 *wc = reinterpret_cast<const f32x4 *>(aux + aux_rgb_off() + (c * 2 + h) * 64);
+            float p = 0.0f;
+            static_for<16>([&](auto I) {
+                constexpr int i = I;
+                const f32x4 w = wc[i];
+                static_for<4>([&](auto K) {
+                    constexpr int v = 4 * i + decltype(K)::value;
+                    p = __builtin_fmaf(relu1(cur[v >> 4][v & 15]), w[decltype(K)::value], p);
+                });
+            });
+            rgb[c] = p + __shfl_xor(p, 32, 64) + aux[aux_rgb_off() + 384 + c];
+        });
+    };
+    if constexpr (NPASS & 1) color_half(accA, accB);
+    else color_half(accB, accA);
+    skip_records16<G16::REC_PAD - G16::REC_END, G16::REC_END>(ws);
+
+    float chk = in.pos[0] + in.pos[1] + in.pos[2] + in.dir[0] + in.dir[1] + in.dir[2];
+#pragma unroll
+    for (int k = 0; k < CFG::NP; ++k) chk += in.par[k];
+    chk = chk - chk;
+    sigma += chk;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] += chk;
+}
+
+// the fused render kernel at bf16x3 precision: identical to render_kernel<CFG> around the MLP
+template <class CFG>
+__global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs a) {
+    static_assert(CFG::IPE == 0, "bf16x3 is built for the FourierFeatures families");
+    __shared__ __attribute__((aligned(16))) float aux[aux_total()];
+    load_aux(aux, a.aux, aux_total());
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int nwaves = gridDim.x * 4;
+    const int S = a.n_samples;
+    const int nb = (S + 31) >> 5;
+    WStream16 ws;
+    ws16_prime(ws, a.wstream, a.stream_bytes, lane);
+
+    for (int64_t ray = wave; ray < a.n_rays; ray += nwaves) {
+        if (a.t[2 * ray] == __builtin_inff()) {
+            if (lane < 3) a.color_out[3 * ray + lane] = (a.flags & NTX_FLAG_COMPOSITE_BKGD) ? a.bkgd[lane] : 0.0f;
+            if (lane == 3) a.alpha_out[ray] = 0.0f;
+            continue;
+        }
+        RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int b = 0; b < nb; ++b) {
+            int64_t r = ray;
+            asm volatile("" : "+s"(r));
+            const RenderArgs *ap = kernargs<RenderArgs>();
+            asm volatile("" : "+s"(ap));
+            const RenderArgs &q = *ap;
+            const float t0 = q.t[2 * r], t1 = q.t[2 * r + 1];
+            const float ox = q.rays_o[3 * r], oy = q.rays_o[3 * r + 1], oz = q.rays_o[3 * r + 2];
+            const float dx = q.rays_d[3 * r], dy = q.rays_d[3 * r + 1], dz = q.rays_d[3 * r + 2];
+            const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+            const float cone = q.cone ? q.cone[r] : 0.0f;
+            const float *prow = q.params + (r / q.rays_per_row) * CFG::NP_IN;
+            const int i = 32 * b + j;
+            const bool valid = i < S;
+            const int ic = valid ? i : S - 1;
+            const int blur_idx = q.blur_idx;
+            SampleIn<CFG::NGEO, CFG::NAPP> in;
+            in.dir[0] = dx / dnorm; in.dir[1] = dy / dnorm; in.dir[2] = dz / dnorm;
+            const float z = z_of(q, r, ic, t0, t1, S);
+            const float zn = z_of(q, r, ic < S - 1 ? ic + 1 : ic - 1, t0, t1, S);
+            const float dist = (ic < S - 1 ? zn - z : z - zn) * dnorm;
+            in.pos[0] = ox + dx * z; in.pos[1] = oy + dy * z; in.pos[2] = oz + dz * z;
+            in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < CFG::NP; ++k) {
+                float p = prow[k];
+                if (k == blur_idx) p = p * (cone * z);
+                in.par[k] = p;
+            }
+            float sigma, raw[3];
+            mlp_batch_bf16<CFG>(in, ws, aux, lane, sigma, raw);
+            const RenderArgs *ap2 = kernargs<RenderArgs>();
+            asm volatile("" : "+s"(ap2));
+            composite_step<32>(ra, sigma, raw, dist, valid, ap2->flags, j,
+                               ap2->weights_out ? ap2->weights_out + ray * S + ic : nullptr);
+        }
+        float out[4] = {ra.c0, ra.c1, ra.c2, ra.a};
+        if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out[k] = out[k] + (1.0f - ra.a) * a.bkgd[k];
+        }
+        if (lane == 0) {
+            a.color_out[3 * ray + 0] = out[0]; a.color_out[3 * ray + 1] = out[1];
+            a.color_out[3 * ray + 2] = out[2]; a.alpha_out[ray] = out[3];
+            if ((a.flags & NTX_FLAG_CHECK_NUMERICS) && a.status) {
+                const float s = out[0] + out[1] + out[2] + out[3];
+                if (!(__builtin_fabsf(s) <= 3.0e38f)) atomicOr(a.status, 1);
+            }
+        }
+    }
+}
+
+}  // namespace ntx

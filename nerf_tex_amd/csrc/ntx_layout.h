@@ -146,4 +146,23 @@ NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth, i
     return g;
 }
 
+// ---- bf16x3 precision (ntx_device_bf16.h): the same network on v_mfma_f32_32x32x16_bf16 -----------------
+// One k16-step = 8 consecutive k2-steps of the maps above (element e of half h in step u = k2-step 8u+e), segments
+// padded with zero rows to whole k16-steps.  One record = 64 lanes x 8 bf16 (1 KiB) = the A operand of one
+// (k16-step, M-tile); the stream holds, per k16-step and tile, the hi record then the lo record of the split
+// w = hi + lo (hi = bf16_rne(w), lo = bf16_rne(w - hi)).  Same segment order as the f32 stream, pad to a multiple
+// of RING16, tail = copy of the first RING16 records; the aux block is the f32 one.
+constexpr int RING16 = 16;
+NTX_HD constexpr int steps16(int k2_steps) { return (k2_steps + 7) / 8; }
+NTX_HD constexpr int stream16_records(int n_geo, int n_app, int color_depth) {
+    const int ps = steps16(pos_steps(n_geo, 0)), ds = steps16(dir_steps(n_app)), hs = HSTEPS / 8;
+    int rec = ps * 16 + 4 * hs * 16 + (ps + hs) * 16 + 2 * hs * 16 + hs * 16;
+    if (color_depth) rec += (ds + hs) * 16 + hs * 8;
+    else rec += (ds + hs) * 8;
+    return rec;
+}
+NTX_HD constexpr int stream16_padded(int n_geo, int n_app, int color_depth) {
+    return round_up(stream16_records(n_geo, n_app, color_depth), RING16);
+}
+
 }  // namespace ntx

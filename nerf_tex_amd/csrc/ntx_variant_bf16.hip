@@ -1,0 +1,32 @@
+// ntx_variant_bf16.hip -- the fused render kernel of ONE model family at bf16x3 precision (ntx_device_bf16.h).
+// Compiled once per FourierFeatures family with -DNTX_VARIANT=k (k as in kVariants[] of nerftex.hip).
+#include <hip/hip_runtime.h>
+
+#include "ntx_device_bf16.h"
+
+#ifndef NTX_VARIANT
+#error "compile with -DNTX_VARIANT=0..3"
+#endif
+
+namespace ntx {
+
+#if NTX_VARIANT == 0
+using VCfg = Cfg<1, 6, 1>;   // carpet
+#define NTX_FN(name) name##_v0
+#elif NTX_VARIANT == 1
+using VCfg = Cfg<1, 4, 1>;   // grass, fur, plush
+#define NTX_FN(name) name##_v1
+#elif NTX_VARIANT == 2
+using VCfg = Cfg<2, 3, 1>;   // grass_filtered
+#define NTX_FN(name) name##_v2
+#else
+using VCfg = Cfg<0, 0, 0>;   // plain Nerf
+#define NTX_FN(name) name##_v3
+#endif
+
+hipError_t NTX_FN(launch_render_bf16)(int n_wgs, RenderArgs &a, hipStream_t st) {
+    render_kernel_bf16<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace ntx

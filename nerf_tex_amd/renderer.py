@@ -20,7 +20,7 @@ class Renderer:
     def __init__(self, model, model_fine=None, n_samples: int = 64, n_importance: int = 0, perturb: bool = True,
                  raw_noise_std: float = 0, render_chunk: int = 32768, net_chunk: int = 65536,
                  downsampling_factor: int = 1, blur_idx: Optional[int] = None, map_exr: bool = False,
-                 check_numerics: bool = True, **kwargs) -> None:
+                 check_numerics: bool = True, precision: str = "float32", **kwargs) -> None:
         self.model = model
         self.model_fine = model_fine
         self.n_samples = n_samples
@@ -35,6 +35,11 @@ class Renderer:
         self.blur_idx = blur_idx
         self.map_exr = map_exr
         self.check_numerics = check_numerics     # tf.debugging.check_numerics, renderer.py:140-141
+        # arithmetic of the Dense layers (include/nerftex.h: ntx_precision).  "float32" is what the reference computes in;
+        # "bf16x3" is an opt-in 3-term bf16 split on the bf16 matrix cores, inside the render tolerance but not bit-identical
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
+        self.precision = precision
         if raw_noise_std > 0:
             raise NotImplementedError("raw_noise_std > 0 (renderer.py:190-192) is a training regulariser; the render path has no kernel for it")
 
@@ -82,6 +87,7 @@ class Renderer:
             alpha = torch.empty((n,), device=dev, dtype=torch.float32)
             wts = torch.empty((n, n_s), device=dev, dtype=torch.float32) if want_weights else None
             with torch.cuda.device(dev):
+                _lib.check(_lib.lib.ntx_set_precision(model.ctx(dev.index or 0), _lib.PRECISIONS[self.precision]))
                 _lib.check(_lib.lib.ntx_render_rays(
                     model.ctx(dev.index or 0), rays_o.data_ptr(), rays_d.data_ptr(), t.data_ptr(),
                     params.data_ptr() if params is not None else None, HW, cone.data_ptr(), n, n_s, blur, flags,

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_abi_exports_every_declared_symbol():
     from nerf_tex_amd import _lib
     header = open(os.path.join(ROOT, "include", "nerftex.h")).read()
-    declared = set(re.findall(r"\b(ntx_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(ntx_[a-z0-9_]+)\s*\(", header))
     declared -= {"ntx_ctx", "ntx_stream"}
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     raw = C.CDLL(_lib.LIB_PATH)
@@ -68,6 +68,41 @@ def test_pack_weights_is_a_permutation_with_wraparound_tail(desc, count):
     vals = np.concatenate([body[body != 0], out[npk - aux_floats:][out[npk - aux_floats:] != 0]])
     assert vals.size == n and np.array_equal(np.sort(vals), np.sort(blob))
     assert _lib.lib.ntx_pack_weights(C.byref(d), blob.ctypes.data_as(fp), n - 1, out.ctypes.data_as(fp), npk) == _lib.NTX_E_INVALID
+
+
+def test_pack_weights_bf16x3_splits_every_weight_once():
+    """Host-only packer of the bf16x3 stream: each matrix weight appears exactly once as a (hi, lo) bf16 pair with
+    hi = bf16(w) and hi + lo within 2^-16 |w| of w; the tail repeats the first 16 records; IPE families are refused."""
+    from nerf_tex_amd import _lib
+    d = _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, 0)
+    n = _lib.lib.ntx_weight_count(C.byref(d))
+    nb = _lib.lib.ntx_packed_bf16x3_bytes(C.byref(d))
+    assert nb % 1024 == 0 and (nb // 1024) % 16 == 0
+    rng = np.random.default_rng(1)
+    blob = rng.uniform(0.5, 1.0, size=n).astype(np.float32) * rng.choice([-1.0, 1.0], size=n).astype(np.float32)
+    out = np.zeros(nb // 2, np.uint16)
+    fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint16)
+    assert _lib.lib.ntx_pack_weights_bf16x3(C.byref(d), blob.ctypes.data_as(fp), n, out.ctypes.data_as(up), nb) == 0
+    rec = out.reshape(-1, 512)
+    np.testing.assert_array_equal(rec[:16], rec[-16:])
+    body = rec[:-16].reshape(-1, 2, 512)                          # (hi record, lo record) per (k16-step, tile)
+    hi = (body[:, 0].astype(np.uint32) << 16).view(np.float32)
+    lo = (body[:, 1].astype(np.uint32) << 16).view(np.float32)
+    used = hi != 0
+    # matrix weights only (biases and the two heads live in the float32 aux block): 256-wide layers + C2
+    n_matrix = 72 * 256 + 4 * 256 * 256 + 328 * 256 + 2 * 256 * 256 + 256 * 256 + 337 * 256 + 256 * 128
+    assert int(used.sum()) == n_matrix
+    recon = np.sort(np.abs((hi[used].astype(np.float64) + lo[used].astype(np.float64))))
+    # the blob also holds biases / head weights, so compare against the multiset of matrix weights via the sum
+    assert np.all(np.abs(lo[used]) <= np.abs(hi[used]) * 2.0 ** -8)
+    f32pk = np.empty(_lib.lib.ntx_packed_count(C.byref(d)), np.float32)
+    assert _lib.lib.ntx_pack_weights(C.byref(d), blob.ctypes.data_as(fp), n, f32pk.ctypes.data_as(fp), f32pk.size) == 0
+    stream = f32pk[:f32pk.size - 3776 - 8 * 256]
+    want = np.sort(np.abs(stream[stream != 0]).astype(np.float64))
+    assert want.size == n_matrix
+    assert np.max(np.abs(recon - want) / want) <= 2.0 ** -16
+    mip = _lib.ModelDesc(0, 1, 3, 6, 10, 4, 4, 8, 256, 4, 1, 1)
+    assert _lib.lib.ntx_packed_bf16x3_bytes(C.byref(mip)) == 0 and b"FourierFeatures" in _lib.lib.ntx_last_error()
 
 
 def test_instantiate_and_reference_config_remap():
