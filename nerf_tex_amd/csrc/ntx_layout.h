@@ -152,7 +152,10 @@ NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth, i
 // (k16-step, M-tile); the stream holds, per k16-step and tile, the hi record then the lo record of the split
 // w = hi + lo (hi = bf16_rne(w), lo = bf16_rne(w - hi)).  Same segment order as the f32 stream, pad to a multiple
 // of RING16, tail = copy of the first RING16 records; the aux block is the f32 one.
-constexpr int RING16 = 16;
+#ifndef NTX_RING16
+#define NTX_RING16 16
+#endif
+constexpr int RING16 = NTX_RING16;   // records in flight per wave
 NTX_HD constexpr int steps16(int k2_steps) { return (k2_steps + 7) / 8; }
 NTX_HD constexpr int stream16_records(int n_geo, int n_app, int color_depth) {
     const int ps = steps16(pos_steps(n_geo, 0)), ds = steps16(dir_steps(n_app)), hs = HSTEPS / 8;

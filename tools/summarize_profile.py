@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
 """gpurun_out/<prefix>_{kt,pmc1,pmc2,pmc3}/ (rocprofv3 CSV output) -> profiles/<round>/<name>_*.{csv,json}.
 
-    python tools/summarize_profile.py prof2 r01 bench_carpet_v2
+    python tools/summarize_profile.py prof2 r01 bench_carpet_v2 [kernel-substring, default "render_kernel<"]
 
 Copies the kernel-stats CSV of the --kernel-trace --stats pass and reduces the separate --pmc passes to
 per-launch means for the render kernel, with the derived quantities DESIGN.md quotes."""
 import collections, csv, glob, json, os, shutil, sys
 
 prefix, rnd, name = sys.argv[1:4]
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "render_kernel<"   # "render_kernel_bf16<" for the bf16x3 precision
 O, P = "gpurun_out", os.path.join("profiles", rnd)
 os.makedirs(P, exist_ok=True)
 shutil.copy(glob.glob(f"{O}/{prefix}_kt/*kernel_stats.csv")[0], f"{P}/{name}_kernel_stats.csv")
 summ, info = {}, {}
 for f in sorted(glob.glob(f"{O}/{prefix}_pmc*/*counter_collection.csv")):
-    rows = [r for r in csv.DictReader(open(f)) if "render_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
     agg = collections.defaultdict(list)
     for r in rows:
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -23,13 +24,13 @@ for f in sorted(glob.glob(f"{O}/{prefix}_pmc*/*counter_collection.csv")):
         info = {k: rows[0][k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size",
                                        "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
 g = lambda k: summ[k]["mean_per_launch"]
-stats = [r for r in csv.DictReader(open(f"{P}/{name}_kernel_stats.csv")) if "render_kernel" in r["Name"]][0]
+stats = [r for r in csv.DictReader(open(f"{P}/{name}_kernel_stats.csv")) if KERNEL in r["Name"]][0]
 avg_s = float(stats["AverageNs"]) * 1e-9
 n_simd = 256 * 4
 derived = {
     "kernel_avg_ms_kernel_trace": avg_s * 1e3,
     "shader_clock_GHz": g("GRBM_GUI_ACTIVE") / 8 / avg_s / 1e9 if "GRBM_GUI_ACTIVE" in summ else None,
-    # SQ_VALU_MFMA_BUSY_CYCLES counts 64 cycles per v_mfma_f32_32x32x2_f32, summed over SIMDs
+    # SQ_VALU_MFMA_BUSY_CYCLES counts 64 cycles per v_mfma_f32_32x32x2_f32 (32 per v_mfma_f32_32x32x16_bf16), summed over SIMDs
     "mfma_util": g("SQ_VALU_MFMA_BUSY_CYCLES") / (n_simd * g("GRBM_GUI_ACTIVE") / 8) if "GRBM_GUI_ACTIVE" in summ else None,
     "frac_wave_cycles_in_s_waitcnt": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES") if "SQ_WAIT_ANY" in summ else None,
     # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 reports half the bytes of wide coalesced reads (x2, MI355X_MICROARCH.md)
