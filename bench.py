@@ -185,15 +185,18 @@ def main() -> None:
         alt = {"precision": "bf16x3 (3-term bf16 split of weights and activations on v_mfma_f32_32x32x16_bf16, f32 accumulate)",
                "value": n_rays * S / (ms2 * 1e-3), "unit": "ray-samples/s", "kernel_ms": ms2,
                "rel_linf_vs_float32_kernel": float((rgba2 - img).abs().max() / img.abs().max()),
-               "mfma_frac_of_bf16_peak": 3 * n_rays * S * 2 * model.macs_per_sample() / (ms2 * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+               # canonical FLOPs (2 * MACs per ray-sample) over the bf16 dense peak; the kernel issues 3 bf16 MFMA products
+               # per canonical MAC, so the matrix pipe is 3x busier than this fraction
+               "canonical_frac_of_bf16_peak": n_rays * S * 2 * model.macs_per_sample() / (ms2 * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+               "mfma_products_per_mac": 3}
 
     if rank == 0:
         samples_per_step = n_rays * S * world
         flops_per_sample = 2 * model.macs_per_sample()
         achieved = n_rays * S * flops_per_sample / (kernel_ms * 1e-3) / 1e12
-        peak = F32_MFMA_PEAK_TFLOPS
-        if args.precision == "bf16x3":       # 3 bf16 MFMA products per algorithmic MAC, priced against the bf16 peak
-            achieved, peak = 3 * achieved, BF16_MFMA_PEAK_TFLOPS
+        # canonical FLOPs (2 * MACs per ray-sample; split-precision multiplicity does not count) against the
+        # dense peak of the issued MFMA dtype
+        peak = F32_MFMA_PEAK_TFLOPS if args.precision == "float32" else BF16_MFMA_PEAK_TFLOPS
         line = {
             "metric": "ray-samples/sec (MLP+composite) at 800x800x64",
             "value": samples_per_step * args.steps / elapsed,

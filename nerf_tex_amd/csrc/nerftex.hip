@@ -10,7 +10,7 @@
 #include <cstring>
 #include <vector>
 
-#include "ntx_device.h"
+#include "ntx_device_bf16.h"
 #include "ntx_small_kernels.h"
 
 using namespace ntx;
@@ -217,7 +217,7 @@ static void emit_segment16(uint16_t *&dst, const Layer &l, int nsteps16, int nmt
 }
 
 static size_t packed16_bytes(const Variant &v) {
-    return (size_t)(stream16_padded(v.n_geo, v.n_app, v.cd) + RING16) * 1024;
+    return (size_t)stream16_padded(v.n_geo, v.n_app, v.cd) * 1024;
 }
 
 // hidden segment first, encoder segment second within a pass (ntx_device_bf16.h: Cfg16)
@@ -249,8 +249,6 @@ static void pack16(const Variant &v, const float *blob, uint16_t *out) {
     }
     const int rec = stream16_records(v.n_geo, v.n_app, v.cd), pad = stream16_padded(v.n_geo, v.n_app, v.cd);
     memset(dst, 0, (size_t)(pad - rec) * 1024);
-    dst += (size_t)(pad - rec) * 512;
-    memcpy(dst, out, (size_t)RING16 * 1024);
 }
 
 static size_t packed_floats(const Variant &v) {
@@ -271,8 +269,11 @@ struct ntx_ctx {
     size_t n_packed;
     ntx_model_desc desc;
     int precision;        // NTX_PRECISION_*: arithmetic of the Dense layers in ntx_render_rays
-    uint16_t *packed16;   // device: bf16x3 stream | tail (NULL for IPE families); shares the f32 aux block
+    uint16_t *packed16;   // device: bf16x3 stream (NULL for IPE families); shares the f32 aux block
     size_t packed16_bytes;
+    int32_t *hit_list;    // device scratch of the bf16x3 render kernel: compacted hit-ray indices, grown on demand
+    size_t hit_cap;
+    int32_t *hit_count;   // device scalar
 };
 
 // The two big kernels of each model family live in their own translation unit (ntx_variant.hip compiled
@@ -284,13 +285,13 @@ namespace ntx {
     hipError_t launch_instance_v##k(int n_wgs, InstanceArgs &a, hipStream_t st);
 NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4)
 #undef NTX_DECL
-hipError_t launch_render_bf16_v0(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_render_bf16_v1(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_render_bf16_v2(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_render_bf16_v3(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_render_bf16_v0(int n_wgs, RenderArgs16 &a, hipStream_t st);
+hipError_t launch_render_bf16_v1(int n_wgs, RenderArgs16 &a, hipStream_t st);
+hipError_t launch_render_bf16_v2(int n_wgs, RenderArgs16 &a, hipStream_t st);
+hipError_t launch_render_bf16_v3(int n_wgs, RenderArgs16 &a, hipStream_t st);
 }  // namespace ntx
 
-static hipError_t launch_render_bf16(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
+static hipError_t launch_render_bf16(const ntx_ctx *c, RenderArgs16 &a, hipStream_t st) {
     switch (c->variant) {
         case 0: return launch_render_bf16_v0(c->n_wgs, a, st);
 #ifndef NTX_DEV_ONLY_CARPET
@@ -426,6 +427,7 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     c->precision = NTX_PRECISION_F32;
     c->packed16 = nullptr;
     c->packed16_bytes = 0;
+    c->hit_list = nullptr; c->hit_cap = 0; c->hit_count = nullptr;
     if (!kVariants[v].ipe) {
         c->packed16_bytes = packed16_bytes(kVariants[v]);
         e = hipMalloc((void **)&c->packed16, c->packed16_bytes);
@@ -480,6 +482,8 @@ int ntx_destroy(ntx_ctx *ctx) {
     if (!ctx) return NTX_OK;
     if (ctx->packed) (void)hipFree(ctx->packed);
     if (ctx->packed16) (void)hipFree(ctx->packed16);
+    if (ctx->hit_list) (void)hipFree(ctx->hit_list);
+    if (ctx->hit_count) (void)hipFree(ctx->hit_count);
     delete ctx;
     return NTX_OK;
 }
@@ -593,9 +597,25 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     a.delta = (1.0f - 0.0f) / (float)(n_samples - 1 + v.ipe);   // mip: S+1 segment edges (renderer.py:374)
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
     if (ctx->precision == NTX_PRECISION_BF16X3) {
+        // lockstep kernel over the compacted hit list (ntx_device_bf16.h); the scratch lives in the context, so
+        // bf16x3 launches on one context must be stream-ordered
+        if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "bf16x3: n_rays %lld exceeds int32", (long long)n_rays);
+        if (ctx->hit_cap < (size_t)n_rays) {
+            if (ctx->hit_list) HIP_TRY(hipFree(ctx->hit_list));
+            ctx->hit_list = nullptr; ctx->hit_cap = 0;
+            HIP_TRY(hipMalloc((void **)&ctx->hit_list, (size_t)n_rays * sizeof(int32_t)));
+            ctx->hit_cap = (size_t)n_rays;
+        }
+        if (!ctx->hit_count) HIP_TRY(hipMalloc((void **)&ctx->hit_count, sizeof(int32_t)));
+        hipStream_t st = (hipStream_t)stream;
+        HIP_TRY(hipMemsetAsync(ctx->hit_count, 0, sizeof(int32_t), st));
+        compact_hits_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st>>>(
+            t, n_rays, ctx->hit_list, ctx->hit_count, color_out, alpha_out, flags, a.bkgd[0], a.bkgd[1], a.bkgd[2]);
+        HIP_TRY(hipGetLastError());
         a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed16);
         a.stream_bytes = (uint32_t)ctx->packed16_bytes;
-        HIP_TRY(launch_render_bf16(ctx, a, (hipStream_t)stream));
+        RenderArgs16 a16{a, ctx->hit_list, ctx->hit_count};
+        HIP_TRY(launch_render_bf16(ctx, a16, st));
         return NTX_OK;
     }
     HIP_TRY(launch_render(ctx, a, (hipStream_t)stream));

@@ -6,8 +6,18 @@
 // float32 restatement of the reference: 2.7e-5 rel-Linf on the dense-media image, 8.5e-6 on glorot weights
 // (tools/emulate_bf16_split.py), inside the 1e-4 gate; the exact-f32 kernel of ntx_device.h stays the default.
 //
-// Structure = the f32 kernel's: one wave64 = 32 samples, activations in registers, each wave streams its own copy of the
-// packed weights from L2 (61 B/clk/CU sustained, tools/ubench/bf16x3_stream.hip -> 3.6-3.8x the f32 MFMA rate).
+// Structure: one wave64 = 32 samples with activations in registers, as in the f32 kernel -- but the 4 waves of a
+// workgroup SHARE one copy of the weight stream through an LDS ring.  (Every wave streaming its own copy from L2, the
+// f32 kernel's structure, tops out at the L1/TA's 64 B/clk/CU: 84% TA-busy at 62% MFMA utilisation, measured; the shared
+// ring moves that traffic to the LDS -- tools/ubench/bf16x3_stream.hip: 6.44 vs 8.3 us per 256x256 layer.)
+//   * the stream is cut into STAGES of 16 records (16 KiB = one k16-step of an 8-tile layer); the ring holds 4 stages;
+//   * each wave fetches its quarter of a stage with 4 LDS-DMA loads (buffer_load_dwordx4 ... lds: L2 -> LDS, no VGPRs),
+//     three stages ahead of the one being multiplied;
+//   * one s_waitcnt vmcnt + s_barrier per stage: at the end of stage s every wave has its quarter of stage s+2 landed and
+//     has finished reading stage s, whose slot the next stage's fetch overwrites;
+//   * A operands come back with ds_read_b128, one MFMA pair-group (4 records) ahead.
+// The waves of a workgroup therefore run in lockstep: the kernel walks a COMPACTED list of hit rays (built by
+// compact_hits_kernel, ntx_small_kernels.h) so that every wave has the same trip count.
 // A k16-step of the bf16 MFMA is 8 consecutive k2-steps of the f32 layout (ntx_layout.h): element e of lane half h in
 // k16-step u is the feature hidden_row(8u+e, h) / pos_row(8u+e, h) / dir_row(8u+e, h), so the same accumulator-register
 // -> next-layer-B-operand identity holds, now with a bias+ReLU+split+pack between.
@@ -18,29 +28,71 @@
 namespace ntx {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) char lds_char;
 
-struct WStream16 {
-    __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t voff;
-    i32x4 ring[RING16];
+constexpr int vmcnt_imm(int n) { return (n & 0xF) | (7 << 4) | (0xF << 8) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
+
+struct WShared {
+    i32x4 rsrc;           // buffer descriptor of the stream (SGPRs)
+    uint32_t voff;        // lane * 16: global side of the DMA
+    uint32_t woff;        // (wave in workgroup) * 4096: this wave's quarter of every stage
+    uint32_t ring;        // LDS byte address of the ring: NSTAGE16 x 16 KiB
+    const lds_char *lane16;   // ring + lane * 16: LDS side of the reads
+    bf16x8 a[4];          // A operands of the upcoming MFMA pair-group: tile 2g hi, lo, tile 2g+1 hi, lo
 };
 
-NTX_DEV i32x4 ws16_load(const WStream16 &ws, uint32_t rec) {
-    return __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, rec * 1024u, 0);
+// this wave's quarter of stage ST (modulo the padded stream) -> its ring slot: four LDS-DMA loads, M0 = LDS address of
+// lane 0's 16 bytes (the hardware adds lane * 16).  Inline asm on purpose: given the intrinsic, hipcc's waitcnt pass
+// assumes every later ds_read may alias the DMA's destination and puts s_waitcnt vmcnt(0) in front of it, which
+// serialises fetch and compute; the landing of a stage is ordered by stage_end() instead.
+template <int ST, int NST>
+NTX_DEV void stage_fetch(const WShared &ws) {
+    constexpr int st = ST % NST, slot = st % NSTAGE16;
+    static_assert(NST % NSTAGE16 == 0, "whole ring turns per batch");
+    uint32_t soff;
+    asm volatile("s_add_u32 m0, %[woff], %[lds]\n\t"
+                 "s_add_u32 %[soff], %[woff], %[goff]\n\t"
+                 "buffer_load_dwordx4 %[voff], %[rsrc], %[soff] offen lds\n\t"
+                 "buffer_load_dwordx4 %[voff], %[rsrc], %[soff] offen offset:1024 lds\n\t"
+                 "buffer_load_dwordx4 %[voff], %[rsrc], %[soff] offen offset:2048 lds\n\t"
+                 "buffer_load_dwordx4 %[voff], %[rsrc], %[soff] offen offset:3072 lds"
+                 : [soff] "=&s"(soff)
+                 : [woff] "s"(ws.woff), [lds] "s"(ws.ring + slot * (STAGE16 * 1024)), [goff] "s"(st * (STAGE16 * 1024)),
+                   [voff] "v"(ws.voff), [rsrc] "s"(ws.rsrc)
+                 : "memory", "scc");
 }
 
-NTX_DEV void ws16_prime(WStream16 &ws, const void *base, uint32_t stream_bytes, int lane) {
-    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, stream_bytes, 0x00020000);
+// end of a stage: my quarter of the stage after next has landed (only the newest fetch may still be in flight), and
+// everybody is done reading this one
+NTX_DEV void stage_end() {
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(4));
+    __builtin_amdgcn_s_barrier();
+}
+
+// records REC .. REC+3 (one pair-group; never straddles a stage) -> registers
+template <int REC, int NST>
+NTX_DEV void read_group(const WShared &ws, bf16x8 (&n)[4]) {
+    constexpr int rec = REC % (NST * STAGE16), slot = (rec / STAGE16) % NSTAGE16, r0 = rec % STAGE16;
+    static_assert(r0 % 4 == 0, "pair-groups are 4 records");
+    const lds_char *p = ws.lane16 + (slot * STAGE16 + r0) * 1024;
+    static_for<4>([&](auto K) { n[K] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>(p + decltype(K)::value * 1024); });
+}
+
+template <int NST>
+NTX_DEV void ws_prime(WShared &ws, const void *base, uint32_t stream_bytes, lds_char *ring, int lane, int wave_in_wg) {
+    // raw buffer descriptor: base, stride 0, num_records = bytes, untyped dword format (as make_buffer_rsrc(.., 0x00020000))
+    const uint64_t b = (uint64_t)base;
+    ws.rsrc = i32x4{__builtin_amdgcn_readfirstlane((int)(uint32_t)b), __builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32) & 0xffff),
+                    __builtin_amdgcn_readfirstlane((int)stream_bytes), 0x00020000};
     ws.voff = (uint32_t)lane * 16u;
-    static_for<RING16>([&](auto I) { ws.ring[I] = ws16_load(ws, I); });
-}
-
-template <int N, int REC0>
-NTX_DEV void skip_records16(WStream16 &ws) {
-    static_for<N>([&](auto I) {
-        constexpr int rec = REC0 + decltype(I)::value;
-        ws.ring[rec % RING16] = ws16_load(ws, rec + RING16);
-    });
+    ws.woff = (uint32_t)wave_in_wg * 4096u;
+    ws.ring = (uint32_t)(uintptr_t)ring;
+    ws.lane16 = ring + lane * 16;
+    stage_fetch<0, NST>(ws);
+    stage_fetch<1, NST>(ws);
+    stage_fetch<2, NST>(ws);
+    stage_end();            // stages 0 and 1 are in
+    read_group<0, NST>(ws, ws.a);
 }
 
 // B operand of one k16-step: 8 features per lane, split
@@ -78,8 +130,10 @@ struct Cfg16 {
     }
     static constexpr int REC_C2 = rec_pass(9 + (CFG::CD ? 1 : 0));
     static constexpr int REC_END = REC_C2 + (CFG::CD ? 0 : DS16 * 8) + HS16 * 8;
-    static constexpr int REC_PAD = round_up(REC_END, RING16);
+    static constexpr int REC_PAD = stream16_padded(CFG::NGEO, CFG::NAPP, CFG::CD);
+    static constexpr int NST = REC_PAD / STAGE16;   // stages per batch
     static_assert(REC_END == stream16_records(CFG::NGEO, CFG::NAPP, CFG::CD), "stream bookkeeping");
+    static_assert(REC_END % 8 == 0 && REC_PAD % (STAGE16 * NSTAGE16) == 0, "pair-groups and ring turns");
 };
 
 // ---- B-operand generators.  The B operand of k16-step U is produced by 12 PIECES of VALU work, piece<U, Q>(), which
@@ -156,10 +210,12 @@ struct EncGen16 {
 };
 
 // one segment: acc[mt] += (W_hi + W_lo)^T * (B_hi + B_lo) without the lo*lo term, NSTEPS k16-steps.  Tiles are taken two
-// at a time so that consecutive MFMAs alternate accumulators: a SLOT is one pair of MFMAs followed by the VALU/LDS work
-// placed in its shadow (pieces of the next step's B operand, extra(U, Q)), pinned by a sched_barrier.
-template <int NSTEPS, int NMT, int REC0, class Gen, class Extra>
-NTX_DEV void run_segment16(f32x16 (&acc)[8], WStream16 &ws, Gen &gen, Extra &&extra) {
+// at a time (a pair-group = 4 records = 6 MFMAs) so that consecutive MFMAs alternate accumulators: a SLOT is one pair of
+// MFMAs followed by the VALU/LDS work placed in its shadow (pieces of the next step's B operand, extra(U, Q)), pinned by
+// a sched_barrier.  The A operands of the NEXT pair-group are read from the LDS ring before this one's MFMAs; stage
+// fetches and barriers fall where the record index says.
+template <int NSTEPS, int NMT, int REC0, int NST, class Gen, class Extra>
+NTX_DEV void run_segment16(f32x16 (&acc)[8], WShared &ws, Gen &gen, Extra &&extra) {
     constexpr int NSLOT = NMT / 2 * 3, PPS = 12 / NSLOT;
     static_for<12>([&](auto Q) { gen.template piece<0, decltype(Q)::value>(); });   // exposed
     B16 b = gen.template value<0>();
@@ -169,10 +225,10 @@ NTX_DEV void run_segment16(f32x16 (&acc)[8], WStream16 &ws, Gen &gen, Extra &&ex
         static_for<NMT / 2>([&](auto G) {
             constexpr int g = G;
             constexpr int rec = REC0 + (u * NMT + 2 * g) * 2;   // records: tile 2g hi, lo, tile 2g+1 hi, lo
-            const bf16x8 a0h = __builtin_bit_cast(bf16x8, ws.ring[(rec + 0) % RING16]);
-            const bf16x8 a0l = __builtin_bit_cast(bf16x8, ws.ring[(rec + 1) % RING16]);
-            const bf16x8 a1h = __builtin_bit_cast(bf16x8, ws.ring[(rec + 2) % RING16]);
-            const bf16x8 a1l = __builtin_bit_cast(bf16x8, ws.ring[(rec + 3) % RING16]);
+            if constexpr (rec % STAGE16 == 0) stage_fetch<rec / STAGE16 + NSTAGE16 - 1, NST>(ws);
+            const bf16x8 a0h = ws.a[0], a0l = ws.a[1], a1h = ws.a[2], a1l = ws.a[3];
+            read_group<rec + 4, NST>(ws, ws.a);
+            __builtin_amdgcn_sched_barrier(0);
             static_for<3>([&](auto T) {
                 constexpr int t = T, q = 3 * g + t;
                 if constexpr (t == 0) {
@@ -181,26 +237,31 @@ NTX_DEV void run_segment16(f32x16 (&acc)[8], WStream16 &ws, Gen &gen, Extra &&ex
                 } else if constexpr (t == 1) {
                     acc[2 * g] = mfma16(a0h, b.lo, acc[2 * g]);
                     acc[2 * g + 1] = mfma16(a1h, b.lo, acc[2 * g + 1]);
-                    ws.ring[(rec + 0) % RING16] = ws16_load(ws, rec + 0 + RING16);
-                    ws.ring[(rec + 2) % RING16] = ws16_load(ws, rec + 2 + RING16);
                 } else {
                     acc[2 * g] = mfma16(a0l, b.hi, acc[2 * g]);
                     acc[2 * g + 1] = mfma16(a1l, b.hi, acc[2 * g + 1]);
-                    ws.ring[(rec + 1) % RING16] = ws16_load(ws, rec + 1 + RING16);
-                    ws.ring[(rec + 3) % RING16] = ws16_load(ws, rec + 3 + RING16);
                 }
                 if constexpr (u + 1 < NSTEPS)
                     static_for<PPS>([&](auto K) { gen.template piece<u + 1, q * PPS + decltype(K)::value>(); });
                 extra(U, std::integral_constant<int, q>{});
                 __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (rec % STAGE16 == STAGE16 - 4) { stage_end(); __builtin_amdgcn_sched_barrier(0); }
         });
         if constexpr (u + 1 < NSTEPS) b = gen.template value<u + 1>();
     });
 }
 
+// a stage of zero padding at the end of the stream: keep the fetch / barrier pipeline turning, multiply nothing
+template <int ST, int NST>
+NTX_DEV void skip_stage(WShared &ws) {
+    stage_fetch<ST + NSTAGE16 - 1, NST>(ws);
+    stage_end();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <class CFG>
-NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream16 &ws, const float *aux_in, int lane,
+NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &ws, const float *aux_in, int lane,
                             float &sigma, float (&rgb)[3]) {
     using G16 = Cfg16<CFG>;
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
@@ -216,7 +277,7 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream16 
     init_bias<8>(accA, aux, 0, h);
     {
         EncGen16<CFG, false> gen{in, h, {}, {}};
-        run_segment16<G16::PS16, 8, 0>(accA, ws, gen, [&](auto U, auto Q) {
+        run_segment16<G16::PS16, 8, 0, G16::NST>(accA, ws, gen, [&](auto U, auto Q) {
             constexpr int u = decltype(U)::value, q = decltype(Q)::value;
             if constexpr (u < 4 && q < 2) init_bias_tile<2 * u + q>(accB, aux, 1, h);
         });
@@ -233,7 +294,7 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream16 
         constexpr bool init_next = li < NPASS;
         {
             ConvGen<relu_in, li == DEPTH> cg{prev, aux, h, sig_part, {}, 0.f, 0.f, 0.f, 0.f};
-            run_segment16<G16::HS16, 8, rec0>(cur, ws, cg, [&](auto U, auto Q) {
+            run_segment16<G16::HS16, 8, rec0, G16::NST>(cur, ws, cg, [&](auto U, auto Q) {
                 constexpr int u = decltype(U)::value, q = decltype(Q)::value;
                 // tile T of the drained set is free once groups 2T and 2T+1 are converted (behind steps 2T-1 and 2T)
                 if constexpr (init_next && (u & 1) == 1 && q == 6) init_bias_tile<(u - 1) / 2>(prev, aux, li + 1, h);
@@ -243,10 +304,10 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream16 
             const SampleIn<NGEO, NAPP> in2 = launder(in);
             if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
                 EncGen16<CFG, false> gen{in2, h, {}, {}};
-                run_segment16<G16::PS16, 8, rec0 + G16::HS16 * 16>(cur, ws, gen, none);
+                run_segment16<G16::PS16, 8, rec0 + G16::HS16 * 16, G16::NST>(cur, ws, gen, none);
             } else {                   // input = concat[dir_map, feature]  (model.py:115)
                 EncGen16<CFG, true> gen{in2, h, {}, {}};
-                run_segment16<G16::DS16, 8, rec0 + G16::HS16 * 16>(cur, ws, gen, none);
+                run_segment16<G16::DS16, 8, rec0 + G16::HS16 * 16, G16::NST>(cur, ws, gen, none);
             }
         }
     };
@@ -263,13 +324,13 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream16 
         float unused = 0.0f;
         if constexpr (CFG::CD == 0) {   // plain Nerf: input = concat[dir_map, feature]  (model.py:39-42)
             ConvGen<false, false> cg{prev, aux, h, unused, {}, 0.f, 0.f, 0.f, 0.f};
-            run_segment16<G16::HS16, 4, G16::REC_C2>(cur, ws, cg, none);
+            run_segment16<G16::HS16, 4, G16::REC_C2, G16::NST>(cur, ws, cg, none);
             const SampleIn<NGEO, NAPP> in2 = launder(in);
             EncGen16<CFG, true> gen{in2, h, {}, {}};
-            run_segment16<G16::DS16, 4, G16::REC_C2 + G16::HS16 * 8>(cur, ws, gen, none);
+            run_segment16<G16::DS16, 4, G16::REC_C2 + G16::HS16 * 8, G16::NST>(cur, ws, gen, none);
         } else {
             ConvGen<true, false> cg{prev, aux, h, unused, {}, 0.f, 0.f, 0.f, 0.f};
-            run_segment16<G16::HS16, 4, G16::REC_C2>(cur, ws, cg, none);
+            run_segment16<G16::HS16, 4, G16::REC_C2, G16::NST>(cur, ws, cg, none);
         }
         // rgb head (model.py:123) on the float32 result
         static_for<3>([&](auto C) {
@@ -289,7 +350,10 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream16 
     };
     if constexpr (NPASS & 1) color_half(accA, accB);
     else color_half(accB, accA);
-    skip_records16<G16::REC_PAD - G16::REC_END, G16::REC_END>(ws);
+    // zero-pad stages, then the first pair-group of the next batch (the prefetch of the last real group read padding)
+    static_for<(G16::REC_PAD - G16::REC_END) / STAGE16>([&](auto I) { skip_stage<G16::REC_END / STAGE16 + decltype(I)::value, G16::NST>(ws); });
+    if constexpr (G16::REC_PAD != G16::REC_END) read_group<0, G16::NST>(ws, ws.a);
+    static_assert(G16::REC_END % STAGE16 == 0, "the stream ends on a stage boundary");
 
     float chk = in.pos[0] + in.pos[1] + in.pos[2] + in.dir[0] + in.dir[1] + in.dir[2];
 #pragma unroll
@@ -300,33 +364,45 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream16 
     for (int c = 0; c < 3; ++c) rgb[c] += chk;
 }
 
-// the fused render kernel at bf16x3 precision: identical to render_kernel<CFG> around the MLP
+// the fused render kernel at bf16x3 precision.  Same per-ray work as render_kernel<CFG> around the MLP, but over the
+// compacted hit list and in workgroup lockstep: iteration `it` gives wave w of workgroup g the hit ray number
+// it * (4 * gridDim) + 4 g + w; waves past the end of the list go through the motions on the last hit ray and store nothing.
+struct RenderArgs16 {
+    RenderArgs r;
+    const int32_t *hit_list;    // [n_hit] indices of the rays with t0 != inf (any order)
+    const int32_t *hit_count;   // device scalar n_hit
+};
+
 template <class CFG>
-__global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs a) {
+__global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs16 args) {
     static_assert(CFG::IPE == 0, "bf16x3 is built for the FourierFeatures families");
+    using G16 = Cfg16<CFG>;
+    __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
     __shared__ __attribute__((aligned(16))) float aux[aux_total()];
+    const RenderArgs &a = args.r;
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int nwaves = gridDim.x * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.n_samples;
     const int nb = (S + 31) >> 5;
-    WStream16 ws;
-    ws16_prime(ws, a.wstream, a.stream_bytes, lane);
+    const int n_hit = *args.hit_count;
+    const int per_it = gridDim.x * 4;
+    const int iters = (n_hit + per_it - 1) / per_it;
+    if (iters == 0) return;   // uniform over the grid
+    WShared ws;
+    ws_prime<G16::NST>(ws, a.wstream, a.stream_bytes, (lds_char *)ring, lane, wv);
 
-    for (int64_t ray = wave; ray < a.n_rays; ray += nwaves) {
-        if (a.t[2 * ray] == __builtin_inff()) {
-            if (lane < 3) a.color_out[3 * ray + lane] = (a.flags & NTX_FLAG_COMPOSITE_BKGD) ? a.bkgd[lane] : 0.0f;
-            if (lane == 3) a.alpha_out[ray] = 0.0f;
-            continue;
-        }
+    for (int it = 0; it < iters; ++it) {
+        const int idx = it * per_it + blockIdx.x * 4 + wv;
+        const bool live = idx < n_hit;
+        const int64_t ray = args.hit_list[live ? idx : n_hit - 1];
         RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         for (int b = 0; b < nb; ++b) {
             int64_t r = ray;
             asm volatile("" : "+s"(r));
-            const RenderArgs *ap = kernargs<RenderArgs>();
+            const RenderArgs16 *ap = kernargs<RenderArgs16>();
             asm volatile("" : "+s"(ap));
-            const RenderArgs &q = *ap;
+            const RenderArgs &q = ap->r;
             const float t0 = q.t[2 * r], t1 = q.t[2 * r + 1];
             const float ox = q.rays_o[3 * r], oy = q.rays_o[3 * r + 1], oz = q.rays_o[3 * r + 2];
             const float dx = q.rays_d[3 * r], dy = q.rays_d[3 * r + 1], dz = q.rays_d[3 * r + 2];
@@ -352,17 +428,17 @@ __global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs a) {
             }
             float sigma, raw[3];
             mlp_batch_bf16<CFG>(in, ws, aux, lane, sigma, raw);
-            const RenderArgs *ap2 = kernargs<RenderArgs>();
+            const RenderArgs16 *ap2 = kernargs<RenderArgs16>();
             asm volatile("" : "+s"(ap2));
-            composite_step<32>(ra, sigma, raw, dist, valid, ap2->flags, j,
-                               ap2->weights_out ? ap2->weights_out + ray * S + ic : nullptr);
+            composite_step<32>(ra, sigma, raw, dist, valid && live, ap2->r.flags, j,
+                               ap2->r.weights_out ? ap2->r.weights_out + r * S + ic : nullptr);
         }
         float out[4] = {ra.c0, ra.c1, ra.c2, ra.a};
         if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) out[k] = out[k] + (1.0f - ra.a) * a.bkgd[k];
         }
-        if (lane == 0) {
+        if (lane == 0 && live) {
             a.color_out[3 * ray + 0] = out[0]; a.color_out[3 * ray + 1] = out[1];
             a.color_out[3 * ray + 2] = out[2]; a.alpha_out[ray] = out[3];
             if ((a.flags & NTX_FLAG_CHECK_NUMERICS) && a.status) {

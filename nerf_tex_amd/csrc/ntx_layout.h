@@ -150,12 +150,12 @@ NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth, i
 // One k16-step = 8 consecutive k2-steps of the maps above (element e of half h in step u = k2-step 8u+e), segments
 // padded with zero rows to whole k16-steps.  One record = 64 lanes x 8 bf16 (1 KiB) = the A operand of one
 // (k16-step, M-tile); the stream holds, per k16-step and tile, the hi record then the lo record of the split
-// w = hi + lo (hi = bf16_rne(w), lo = bf16_rne(w - hi)).  Same segment order as the f32 stream, pad to a multiple
-// of RING16, tail = copy of the first RING16 records; the aux block is the f32 one.
-#ifndef NTX_RING16
-#define NTX_RING16 16
-#endif
-constexpr int RING16 = NTX_RING16;   // records in flight per wave
+// w = hi + lo (hi = bf16_rne(w), lo = bf16_rne(w - hi)).  Within a pass the hidden segment comes first, the encoder
+// segment second.  The 4 waves of a workgroup share the stream through an LDS ring of NSTAGE16 STAGES of STAGE16
+// records (one k16-step of an 8-tile layer); the stream is zero-padded to a whole number of ring turns, so the stage ->
+// ring-slot map is the same for every batch and the prefetch simply wraps to stage 0.  The aux block is the f32 one.
+constexpr int STAGE16 = 16;    // records per stage
+constexpr int NSTAGE16 = 4;    // stages in the LDS ring (64 KiB)
 NTX_HD constexpr int steps16(int k2_steps) { return (k2_steps + 7) / 8; }
 NTX_HD constexpr int stream16_records(int n_geo, int n_app, int color_depth) {
     const int ps = steps16(pos_steps(n_geo, 0)), ds = steps16(dir_steps(n_app)), hs = HSTEPS / 8;
@@ -165,7 +165,7 @@ NTX_HD constexpr int stream16_records(int n_geo, int n_app, int color_depth) {
     return rec;
 }
 NTX_HD constexpr int stream16_padded(int n_geo, int n_app, int color_depth) {
-    return round_up(stream16_records(n_geo, n_app, color_depth), RING16);
+    return round_up(stream16_records(n_geo, n_app, color_depth), STAGE16 * NSTAGE16);
 }
 
 }  // namespace ntx

@@ -270,4 +270,27 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(SamplePdfArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// hit-ray compaction for the lockstep bf16x3 render kernel (ntx_device_bf16.h): rays culled by the proxy (t0 == inf,
+// renderer.py:58-67) get their final value here (0, or the background colour: renderer.py:81-86); the indices of the
+// others are appended to hit_list (wave-aggregated atomic; the order is irrelevant, results are stored per ray).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compact_hits_kernel(const float *t, int64_t n_rays, int32_t *hit_list, int32_t *hit_count,
+                                                           float *color_out, float *alpha_out, uint32_t flags, float b0, float b1, float b2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool in = i < n_rays;
+    const bool hit = in && !(t[2 * i] == __builtin_inff());   // NaN counts as a hit, as in render_kernel
+    const uint64_t m = __ballot(hit);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(hit_count, (int)__builtin_popcountll(m));
+    base = __shfl(base, 0, 64);
+    if (hit) hit_list[base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+    if (in && !hit) {
+        const bool bk = (flags & NTX_FLAG_COMPOSITE_BKGD) != 0;
+        color_out[3 * i + 0] = bk ? b0 : 0.0f; color_out[3 * i + 1] = bk ? b1 : 0.0f; color_out[3 * i + 2] = bk ? b2 : 0.0f;
+        alpha_out[i] = 0.0f;
+    }
+}
+
 }  // namespace ntx
