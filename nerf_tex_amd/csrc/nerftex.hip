@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -274,6 +275,9 @@ struct ntx_ctx {
     int32_t *hit_list;    // device scratch of the bf16x3 render kernel: compacted hit-ray indices, grown on demand
     size_t hit_cap;
     int32_t *hit_count;   // device scalar
+    float *ray_bias;      // device scratch of the float32 render kernel: per-ray colour-layer bias incl. the direction
+    size_t ray_bias_cap;  // features (dirbias_kernel), [rays][2][128], grown on demand
+    bool hoist_dir;       // false when NERFTEX_NO_DIR_HOIST is set at ntx_create (A/B knob for tests: same bits either way)
 };
 
 // The two big kernels of each model family live in their own translation unit (ntx_variant.hip compiled
@@ -282,7 +286,9 @@ namespace ntx {
 #define NTX_DECL(k)                                                            \
     hipError_t launch_render_v##k(int n_wgs, RenderArgs &a, hipStream_t st);   \
     hipError_t launch_mlp_v##k(int n_wgs, MlpArgs &a, hipStream_t st);         \
-    hipError_t launch_instance_v##k(int n_wgs, InstanceArgs &a, hipStream_t st);
+    hipError_t launch_instance_v##k(int n_wgs, InstanceArgs &a, hipStream_t st); \
+    hipError_t launch_dirbias_v##k(int n_wgs, DirBiasArgs &a, hipStream_t st);  \
+    hipError_t launch_render_hoist_v##k(int n_wgs, RenderArgs &a, hipStream_t st);
 NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4)
 #undef NTX_DECL
 hipError_t launch_render_bf16_v0(int n_wgs, RenderArgs16 &a, hipStream_t st);
@@ -311,6 +317,28 @@ static hipError_t launch_render(const ntx_ctx *c, RenderArgs &a, hipStream_t st)
         case 2: return launch_render_v2(c->n_wgs, a, st);
         case 3: return launch_render_v3(c->n_wgs, a, st);
         case 4: return launch_render_v4(c->n_wgs, a, st);
+#endif
+        default: return hipErrorNotSupported;
+    }
+}
+static hipError_t launch_render_hoist(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
+    switch (c->variant) {
+        case 0: return launch_render_hoist_v0(c->n_wgs, a, st);
+#ifndef NTX_DEV_ONLY_CARPET
+        case 1: return launch_render_hoist_v1(c->n_wgs, a, st);
+        case 2: return launch_render_hoist_v2(c->n_wgs, a, st);
+        case 4: return launch_render_hoist_v4(c->n_wgs, a, st);
+#endif
+        default: return hipErrorNotSupported;
+    }
+}
+static hipError_t launch_dirbias(const ntx_ctx *c, DirBiasArgs &a, hipStream_t st) {
+    switch (c->variant) {
+        case 0: return launch_dirbias_v0(c->n_wgs, a, st);
+#ifndef NTX_DEV_ONLY_CARPET
+        case 1: return launch_dirbias_v1(c->n_wgs, a, st);
+        case 2: return launch_dirbias_v2(c->n_wgs, a, st);
+        case 4: return launch_dirbias_v4(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -428,6 +456,8 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     c->packed16 = nullptr;
     c->packed16_bytes = 0;
     c->hit_list = nullptr; c->hit_cap = 0; c->hit_count = nullptr;
+    c->ray_bias = nullptr; c->ray_bias_cap = 0;
+    c->hoist_dir = getenv("NERFTEX_NO_DIR_HOIST") == nullptr;
     if (!kVariants[v].ipe) {
         c->packed16_bytes = packed16_bytes(kVariants[v]);
         e = hipMalloc((void **)&c->packed16, c->packed16_bytes);
@@ -484,6 +514,7 @@ int ntx_destroy(ntx_ctx *ctx) {
     if (ctx->packed16) (void)hipFree(ctx->packed16);
     if (ctx->hit_list) (void)hipFree(ctx->hit_list);
     if (ctx->hit_count) (void)hipFree(ctx->hit_count);
+    if (ctx->ray_bias) (void)hipFree(ctx->ray_bias);
     delete ctx;
     return NTX_OK;
 }
@@ -617,6 +648,28 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
         RenderArgs16 a16{a, ctx->hit_list, ctx->hit_count};
         HIP_TRY(launch_render_bf16(ctx, a16, st));
         return NTX_OK;
+    }
+    // Direction features and appearance parameters are per-ray constants (renderer.py:152-154) unless the blur scaling
+    // hits an appearance parameter (:155-158): compute the colour layer's direction segment once per ray (dirbias_kernel)
+    // instead of once per sample.  Scratch: 1 KiB per ray in the context; if it cannot be had, the kernel evaluates the
+    // segment per sample as before -- same bits either way.
+    if (ctx->hoist_dir && v.cd && (blur_idx < 0 || blur_idx < v.n_geo || v.ipe)) {
+        if (ctx->ray_bias_cap < (size_t)n_rays) {
+            if (ctx->ray_bias) HIP_TRY(hipFree(ctx->ray_bias));
+            ctx->ray_bias = nullptr; ctx->ray_bias_cap = 0;
+            if (hipMalloc((void **)&ctx->ray_bias, (size_t)n_rays * 256 * sizeof(float)) == hipSuccess) ctx->ray_bias_cap = (size_t)n_rays;
+            else { ctx->ray_bias = nullptr; (void)hipGetLastError(); }
+        }
+        if (ctx->ray_bias) {
+            DirBiasArgs d{};
+            d.wstream = a.wstream; d.stream_bytes = a.stream_bytes; d.aux = a.aux;
+            d.rays_d = rays_d; d.params = params; d.ray_bias = ctx->ray_bias;
+            d.n_rays = n_rays; d.rays_per_row = rays_per_param_row; d.blur_idx = blur_idx;
+            HIP_TRY(launch_dirbias(ctx, d, (hipStream_t)stream));
+            a.ray_bias = ctx->ray_bias;
+            HIP_TRY(launch_render_hoist(ctx, a, (hipStream_t)stream));
+            return NTX_OK;
+        }
     }
     HIP_TRY(launch_render(ctx, a, (hipStream_t)stream));
     return NTX_OK;

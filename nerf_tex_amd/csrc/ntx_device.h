@@ -138,6 +138,15 @@ NTX_DEV void init_bias_tile(f32x16 (&acc)[8], const float *aux, int layer, int h
     const f32x4 v0 = b[0], v1 = b[1], v2 = b[2], v3 = b[3];
     acc[MT] = f32x16{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
 }
+// same from a row in GLOBAL memory ([128] floats of this lane's half-wave, accumulator order): the colour layer's bias,
+// which for hoisted direction features is a per-ray vector (dirbias_kernel)
+template <int MT>
+NTX_DEV void init_bias_tile_g(f32x16 (&acc)[8], const float *row) {
+    typedef const __attribute__((address_space(1))) f32x4 *gptr;   // global_load, not flat_load (the pointer comes out of the kernarg struct)
+    const gptr b = (gptr)(uintptr_t)row + MT * 4;
+    const f32x4 v0 = b[0], v1 = b[1], v2 = b[2], v3 = b[3];
+    acc[MT] = f32x16{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+}
 template <int NMT>
 NTX_DEV void init_bias(f32x16 (&acc)[8], const float *aux, int layer, int h) {
     static_for<NMT>([&](auto MT) { init_bias_tile<decltype(MT)::value>(acc, aux, layer, h); });
@@ -335,9 +344,14 @@ struct Cfg {
 // Two accumulator sets (2 x 128 AGPRs) alternate between layers: layer n's result is moved out of one set
 // (bias already in, ReLU, into `hin`) in one dense block before layer n+1 starts accumulating into the
 // other, and the drained set is re-initialised tile by tile with the bias of layer n+2 while layer n+1 runs.
-template <class CFG>
+// HOIST (render kernel, ParamNerf): the accumulators of the colour layer C1 start from `c1_row` in global memory
+// ([half][128], accumulator order) = the per-ray vector bias_C1 + W_dir^T dir_map that dirbias_kernel computed with this
+// very code, and the direction segment is skipped (its records are still fetched, to keep the ring phase).  A
+// compile-time variant, not a run-time branch: a branch around the segment made hipcc spill 1 KiB per lane.
+template <class CFG, bool HOIST = false>
 NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
-                       const float *aux_in, int lane, float &sigma, float (&rgb)[3]) {
+                       const float *aux_in, int lane, float &sigma, float (&rgb)[3],
+                       const float *c1_row = nullptr) {
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
     const int h = lane >> 5;
     // The aux block in LDS never changes, so the optimiser would hoist every bias / head-weight
@@ -375,7 +389,10 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
         // re-initialise tile T of the drained set (free from k-step 16 T on) with the next layer's bias
         auto reinit = [&](auto S, auto MT) {
             constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
-            if constexpr (init_next && mt == 1 && (s & 15) == 0) init_bias_tile<(s >> 4)>(prev, aux, next_bias, h);
+            if constexpr (init_next && mt == 1 && (s & 15) == 0) {
+                if constexpr (HOIST && CFG::CD != 0 && next_bias == 9) init_bias_tile_g<(s >> 4)>(prev, c1_row + h * 128);
+                else init_bias_tile<(s >> 4)>(prev, aux, next_bias, h);
+            }
         };
         // alpha head (model.py:111) rides on pass F, which consumes the same activations relu(L7)
         auto alpha_head = [&](auto S, auto MT) {
@@ -391,8 +408,12 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
                 PosGen<NGEO, NAPP, CFG::IPE> gen{in2, h, {}};
                 run_segment<pre_steps, 8, rec0>(cur, ws, gen, conv);
             } else {                   // input = concat[dir_map, feature]  (model.py:115)
-                DirGen<NGEO, NAPP> gen{in2, h, {}};
-                run_segment<pre_steps, 8, rec0>(cur, ws, gen, conv);
+                if constexpr (HOIST) {
+                    skip_records<pre_steps * 2, rec0>(ws);   // already in the accumulators, through c1_row
+                } else {
+                    DirGen<NGEO, NAPP> gen{in2, h, {}};
+                    run_segment<pre_steps, 8, rec0>(cur, ws, gen, conv);
+                }
             }
             HiddenGen hg{hin};
             run_segment<HSTEPS, 8, rec0 + pre_steps * 2>(cur, ws, hg, [&](auto S, auto MT) { reinit(S, MT); alpha_head(S, MT); });
@@ -545,6 +566,7 @@ struct RenderArgs {
     uint32_t flags;
     float delta;   // float32(1 / (S - 1)): the step of tf.linspace(0., 1., S)
     float bkgd[3];
+    const float *ray_bias;   // NULL, or [n_rays][2][128]: per-ray bias of the colour layer incl. the direction features (dirbias_kernel)
 };
 
 // the by-value kernel argument struct, addressed in the kernarg segment (device pass only)
@@ -565,8 +587,9 @@ NTX_DEV float z_of(const RenderArgs &a, int64_t ray, int i, float t0, float t1, 
     return t0 * (1.0f - tv) + t1 * tv;   // renderer.py:102
 }
 
-template <class CFG>
+template <class CFG, bool HOIST = false>
 __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
+    static_assert(!HOIST || CFG::CD != 0, "direction hoisting is for the ParamNerf families");
     __shared__ __attribute__((aligned(16))) float aux[aux_total()];
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
@@ -636,7 +659,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
                 for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[k < blur_idx ? k : k + 1];
             }
             float sigma, raw[3];
-            mlp_batch<CFG>(in, ws, aux, lane, sigma, raw);
+            if constexpr (HOIST) mlp_batch<CFG, true>(in, ws, aux, lane, sigma, raw, q.ray_bias + r * 256);
+            else mlp_batch<CFG>(in, ws, aux, lane, sigma, raw);
             const RenderArgs *ap2 = kernargs<RenderArgs>();
             asm volatile("" : "+s"(ap2));
             composite_step<32>(ra, sigma, raw, dist, valid, ap2->flags, j,
@@ -654,6 +678,68 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
                 const float s = out[0] + out[1] + out[2] + out[3];
                 if (!(__builtin_fabsf(s) <= 3.0e38f)) atomicOr(a.status, 1);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-ray-constant direction features hoisted out of the per-sample network.  In Renderer.evaluate_model the view
+// direction and the appearance parameters are repeated for every sample of a ray (renderer.py:152-154), so the
+// direction segment of the colour layer, W_C1[:dir_map]^T dir_map, is one [256] vector per ray.  This kernel computes
+// bias_C1 + that vector for 32 RAYS per wave (lane = ray) with the very code the fused kernel runs per sample
+// (init_bias + run_segment over the same records with the same generator), so the fused kernel starting its C1
+// accumulators from the stored vector is bit-identical to evaluating the segment per sample -- 328 of 10 638 MFMAs and
+// 41 of 113 encoder k-steps per 32-sample batch less.  Not applicable when blur_idx scales an APPEARANCE parameter per
+// sample (renderer.py:155-158); the host then leaves ray_bias NULL.
+// ---------------------------------------------------------------------------------------------
+struct DirBiasArgs {
+    const f32x4 *wstream;
+    uint32_t stream_bytes;
+    const float *aux;
+    const float *rays_d, *params;
+    float *ray_bias;          // [n_rays][2][128]
+    int64_t n_rays, rays_per_row;
+    int blur_idx;             // mip families: the parameter spliced out of the model's inputs (renderer.py:385-386)
+};
+
+template <class CFG>
+__global__ __launch_bounds__(256) void dirbias_kernel(DirBiasArgs a) {
+    static_assert(CFG::CD != 0, "ParamNerf families");
+    __shared__ __attribute__((aligned(16))) float aux[aux_total()];
+    load_aux(aux, a.aux, aux_total());
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int nwaves = gridDim.x * 4;
+    constexpr int REC0 = CFG::rec_pass(9);
+    WStream ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(a.wstream), 0, a.stream_bytes, 0x00020000);
+    ws.voff = (uint32_t)lane * 16u;
+    auto none = [](auto, auto) {};
+    for (int64_t blk = wave; blk * 32 < a.n_rays; blk += nwaves) {
+        const int64_t ray = blk * 32 + j < a.n_rays ? blk * 32 + j : a.n_rays - 1;
+        const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+        const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);   // as render_kernel (renderer.py:98)
+        SampleIn<CFG::NGEO, CFG::NAPP> in;
+        in.pos[0] = in.pos[1] = in.pos[2] = 0.0f;
+        in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
+        in.dir[0] = dx / dnorm; in.dir[1] = dy / dnorm; in.dir[2] = dz / dnorm;
+        const float *prow = a.params + (ray / a.rays_per_row) * CFG::NP_IN;
+#pragma unroll
+        for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[(CFG::IPE != 0 && k >= a.blur_idx) ? k + 1 : k];
+        f32x16 acc[8];
+        init_bias<8>(acc, aux, 9, h);
+        static_for<RING>([&](auto I) { ws.ring[(REC0 + I) % RING] = ws_load(ws, REC0 + I); });
+        DirGen<CFG::NGEO, CFG::NAPP> gen{in, h, {}};
+        run_segment<CFG::DS, 8, REC0>(acc, ws, gen, none);
+        if (blk * 32 + j < a.n_rays) {
+            f32x4 *o = reinterpret_cast<f32x4 *>(a.ray_bias + ray * 256 + h * 128);
+            static_for<8>([&](auto T) {
+                constexpr int t = T;
+                static_for<4>([&](auto Q) {
+                    constexpr int q = Q;
+                    o[t * 4 + q] = f32x4{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                });
+            });
         }
     }
 }

@@ -27,6 +27,18 @@ using VCfg = Cfg<1, 3, 1, 1>;   // mip: IPE position encoding, grass_filtered wi
 #define NTX_FN(name) name##_v4
 #endif
 
+#ifdef NTX_HOIST
+// second translation unit of the family (-DNTX_HOIST): the render kernel with the direction segment hoisted per ray
+hipError_t NTX_FN(launch_render_hoist)(int n_wgs, RenderArgs &a, hipStream_t st) {
+    render_kernel<VCfg, true><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t NTX_FN(launch_dirbias)(int n_wgs, DirBiasArgs &a, hipStream_t st) {
+    dirbias_kernel<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
+    return hipGetLastError();
+}
+#else
 hipError_t NTX_FN(launch_render)(int n_wgs, RenderArgs &a, hipStream_t st) {
     render_kernel<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
     return hipGetLastError();
@@ -41,5 +53,6 @@ hipError_t NTX_FN(launch_mlp)(int n_wgs, MlpArgs &a, hipStream_t st) {
     mlp_kernel<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
     return hipGetLastError();
 }
+#endif
 
 }  // namespace ntx

@@ -314,3 +314,37 @@ def test_edge_cases_empty_culled_minimal():
         Renderer(model=model, n_samples=1, perturb=False)(*to_dev(ro[None], rd[None], t[None]), parameters=params,
                                                           cone_scale=to_dev(cone[None])[0])
     assert e.value.code == _lib.NTX_E_INVALID
+
+
+@pytest.mark.parametrize("family", ["carpet", "grass_filtered"])
+def test_direction_hoisting_is_bit_identical(family, monkeypatch):
+    """ntx_render_rays evaluates the colour layer's direction segment once per ray (dirbias_kernel) instead of once per
+    sample; a context created with NERFTEX_NO_DIR_HOIST evaluates it per sample.  Same bits, and a blur_idx on an
+    APPEARANCE parameter (per-sample scaling, renderer.py:155-158) takes the per-sample path by itself."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES[family]
+    h, wd, S = 20, 24, 64
+    (ro, rd, t, cone), _, _ = camera_rays(family, h, wd)
+    params = np.asarray([fam["params"]], np.float32)
+    args = to_dev(ro[None], rd[None], t[None])
+    kw = dict(parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0])
+
+    def render(blur_idx):
+        model, spec, w = make_model(fam["n_parameters"], dense_media=True)
+        out = Renderer(model=model, n_samples=S, perturb=False, blur_idx=blur_idx)(*args, **kw)
+        return torch.cat([out["color_pred"][0], out["alpha_pred"][0][:, None]], -1).cpu().numpy(), spec, w
+
+    got, spec, w = render(fam["blur_idx"])
+    monkeypatch.setenv("NERFTEX_NO_DIR_HOIST", "1")
+    plain, _, _ = render(fam["blur_idx"])
+    monkeypatch.delenv("NERFTEX_NO_DIR_HOIST")
+    assert np.array_equal(got, plain)
+    # blur on the last (appearance) parameter: not hoistable
+    bi = sum(fam["n_parameters"]) - 1
+    got2, _, _ = render(bi)
+    ref = orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], S, False, (1., 1., 1.), bi, False,
+                            dtype=np.float64)
+    want = np.concatenate([ref["color_pred"][0], ref["alpha_pred"][0][:, None]], -1)
+    assert orc.rel_linf(got2, want) <= TOL
+    assert not np.array_equal(got2, got)
