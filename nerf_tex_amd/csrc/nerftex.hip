@@ -241,8 +241,7 @@ static void pack16(const Variant &v, const float *blob, uint16_t *out) {
     }
     emit_segment16(dst, n.feature, hs, 8, 0, hidrow);
     if (n.has_c1) {
-        emit_segment16(dst, n.c1, hs, 8, dm, hidrow);
-        emit_segment16(dst, n.c1, ds, 8, 0, dirrow);
+        emit_segment16(dst, n.c1, hs, 8, dm, hidrow);   // its direction rows are applied per ray by dirbias_kernel
         emit_segment16(dst, n.c2, hs, 4, 0, hidrow);
     } else {
         emit_segment16(dst, n.c2, hs, 4, dm, hidrow);
@@ -631,6 +630,23 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
         // lockstep kernel over the compacted hit list (ntx_device_bf16.h); the scratch lives in the context, so
         // bf16x3 launches on one context must be stream-ordered
         if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "bf16x3: n_rays %lld exceeds int32", (long long)n_rays);
+        // ParamNerf: the colour layer's direction segment always enters as the per-ray bias of dirbias_kernel (float32)
+        if (v.cd) {
+            if (blur_idx >= v.n_geo)
+                return fail(NTX_E_UNSUPPORTED, "bf16x3: blur_idx %d scales an appearance parameter per sample; use NTX_PRECISION_F32", blur_idx);
+            if (ctx->ray_bias_cap < (size_t)n_rays) {
+                if (ctx->ray_bias) HIP_TRY(hipFree(ctx->ray_bias));
+                ctx->ray_bias = nullptr; ctx->ray_bias_cap = 0;
+                HIP_TRY(hipMalloc((void **)&ctx->ray_bias, (size_t)n_rays * 256 * sizeof(float)));
+                ctx->ray_bias_cap = (size_t)n_rays;
+            }
+            DirBiasArgs d{};
+            d.wstream = a.wstream; d.stream_bytes = a.stream_bytes; d.aux = a.aux;   // the float32 stream
+            d.rays_d = rays_d; d.params = params; d.ray_bias = ctx->ray_bias;
+            d.n_rays = n_rays; d.rays_per_row = rays_per_param_row; d.blur_idx = blur_idx;
+            HIP_TRY(launch_dirbias(ctx, d, (hipStream_t)stream));
+            a.ray_bias = ctx->ray_bias;
+        }
         if (ctx->hit_cap < (size_t)n_rays) {
             if (ctx->hit_list) HIP_TRY(hipFree(ctx->hit_list));
             ctx->hit_list = nullptr; ctx->hit_cap = 0;

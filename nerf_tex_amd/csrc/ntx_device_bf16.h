@@ -126,7 +126,7 @@ template <class CFG>
 struct Cfg16 {
     static constexpr int PS16 = steps16(CFG::PS), DS16 = steps16(CFG::DS), HS16 = HSTEPS / 8;
     static constexpr int rec_pass(int li) {   // first record of hidden pass li (1..8 = L1..L7, F; 9 = C1)
-        return PS16 * 16 + (li - 1) * HS16 * 16 + (li > SKIP + 1 ? PS16 * 16 : 0) + (CFG::CD && li > 9 ? DS16 * 16 : 0);
+        return PS16 * 16 + (li - 1) * HS16 * 16 + (li > SKIP + 1 ? PS16 * 16 : 0);   // C1 has no direction segment here
     }
     static constexpr int REC_C2 = rec_pass(9 + (CFG::CD ? 1 : 0));
     static constexpr int REC_END = REC_C2 + (CFG::CD ? 0 : DS16 * 8) + HS16 * 8;
@@ -262,7 +262,7 @@ NTX_DEV void skip_stage(WShared &ws) {
 
 template <class CFG>
 NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &ws, const float *aux_in, int lane,
-                            float &sigma, float (&rgb)[3]) {
+                            float &sigma, float (&rgb)[3], const float *c1_row) {
     using G16 = Cfg16<CFG>;
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
     const int h = lane >> 5;
@@ -290,25 +290,26 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &w
         constexpr int li = decltype(LI)::value;
         constexpr bool relu_in = li != 9;
         constexpr int rec0 = G16::rec_pass(li);
-        constexpr bool has_pos = li == SKIP + 1, has_dir = CFG::CD != 0 && li == 9;
+        constexpr bool has_pos = li == SKIP + 1;
         constexpr bool init_next = li < NPASS;
+        // ParamNerf's colour layer C1 (li = 9) starts from the per-ray vector bias_C1 + W_dir^T dir_map (dirbias_kernel,
+        // float32): its direction segment is not evaluated per sample
+        constexpr bool next_is_c1 = CFG::CD != 0 && li + 1 == 9;
         {
             ConvGen<relu_in, li == DEPTH> cg{prev, aux, h, sig_part, {}, 0.f, 0.f, 0.f, 0.f};
             run_segment16<G16::HS16, 8, rec0, G16::NST>(cur, ws, cg, [&](auto U, auto Q) {
                 constexpr int u = decltype(U)::value, q = decltype(Q)::value;
                 // tile T of the drained set is free once groups 2T and 2T+1 are converted (behind steps 2T-1 and 2T)
-                if constexpr (init_next && (u & 1) == 1 && q == 6) init_bias_tile<(u - 1) / 2>(prev, aux, li + 1, h);
+                if constexpr (init_next && (u & 1) == 1 && q == 6) {
+                    if constexpr (next_is_c1) init_bias_tile_g<(u - 1) / 2>(prev, c1_row + h * 128);
+                    else init_bias_tile<(u - 1) / 2>(prev, aux, li + 1, h);
+                }
             });
         }
-        if constexpr (has_pos || has_dir) {
+        if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
             const SampleIn<NGEO, NAPP> in2 = launder(in);
-            if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
-                EncGen16<CFG, false> gen{in2, h, {}, {}};
-                run_segment16<G16::PS16, 8, rec0 + G16::HS16 * 16, G16::NST>(cur, ws, gen, none);
-            } else {                   // input = concat[dir_map, feature]  (model.py:115)
-                EncGen16<CFG, true> gen{in2, h, {}, {}};
-                run_segment16<G16::DS16, 8, rec0 + G16::HS16 * 16, G16::NST>(cur, ws, gen, none);
-            }
+            EncGen16<CFG, false> gen{in2, h, {}, {}};
+            run_segment16<G16::PS16, 8, rec0 + G16::HS16 * 16, G16::NST>(cur, ws, gen, none);
         }
     };
     static_for<NPASS>([&](auto I) {
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs16 args) {
                 in.par[k] = p;
             }
             float sigma, raw[3];
-            mlp_batch_bf16<CFG>(in, ws, aux, lane, sigma, raw);
+            mlp_batch_bf16<CFG>(in, ws, aux, lane, sigma, raw, CFG::CD != 0 ? q.ray_bias + r * 256 : nullptr);
             const RenderArgs16 *ap2 = kernargs<RenderArgs16>();
             asm volatile("" : "+s"(ap2));
             composite_step<32>(ra, sigma, raw, dist, valid && live, ap2->r.flags, j,

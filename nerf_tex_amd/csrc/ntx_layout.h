@@ -151,7 +151,8 @@ NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth, i
 // padded with zero rows to whole k16-steps.  One record = 64 lanes x 8 bf16 (1 KiB) = the A operand of one
 // (k16-step, M-tile); the stream holds, per k16-step and tile, the hi record then the lo record of the split
 // w = hi + lo (hi = bf16_rne(w), lo = bf16_rne(w - hi)).  Within a pass the hidden segment comes first, the encoder
-// segment second.  The 4 waves of a workgroup share the stream through an LDS ring of NSTAGE16 STAGES of STAGE16
+// segment second; the direction segment of ParamNerf's colour layer C1 is NOT in the stream: it is a per-ray constant
+// and enters through the per-ray bias vector of dirbias_kernel (float32).  The 4 waves of a workgroup share the stream through an LDS ring of NSTAGE16 STAGES of STAGE16
 // records (one k16-step of an 8-tile layer); the stream is zero-padded to a whole number of ring turns, so the stage ->
 // ring-slot map is the same for every batch and the prefetch simply wraps to stage 0.  The aux block is the f32 one.
 constexpr int STAGE16 = 16;    // records per stage
@@ -160,8 +161,8 @@ NTX_HD constexpr int steps16(int k2_steps) { return (k2_steps + 7) / 8; }
 NTX_HD constexpr int stream16_records(int n_geo, int n_app, int color_depth) {
     const int ps = steps16(pos_steps(n_geo, 0)), ds = steps16(dir_steps(n_app)), hs = HSTEPS / 8;
     int rec = ps * 16 + 4 * hs * 16 + (ps + hs) * 16 + 2 * hs * 16 + hs * 16;
-    if (color_depth) rec += (ds + hs) * 16 + hs * 8;
-    else rec += (ds + hs) * 8;
+    if (color_depth) rec += hs * 16 + hs * 8;   // ParamNerf: C1 without its direction segment (hoisted per ray), C2
+    else rec += (ds + hs) * 8;                  // plain Nerf: C2 = hidden + direction segment, 4 tiles
     return rec;
 }
 NTX_HD constexpr int stream16_padded(int n_geo, int n_app, int color_depth) {

@@ -111,6 +111,12 @@ def test_bf16x3_nan_propagates_and_unsupported_family():
         r.raise_if_nonfinite()
     with pytest.raises(ValueError):
         Renderer(model=model, precision="fp8")
+    # a blur_idx on an appearance parameter is a per-sample scaling of a direction-side input: float32 only
+    rb = Renderer(model=model, n_samples=S, perturb=False, precision="bf16x3", blur_idx=4)
+    ro[5, 1] = 0.0
+    with pytest.raises(_lib.NtxError) as e:
+        rb(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0])
+    assert e.value.code == _lib.NTX_E_UNSUPPORTED
     mip, _, _ = make_model((1, 3), kind="IPE")
     mr = MipRenderer(model=mip, n_samples=S, perturb=False, blur_idx=2, precision="bf16x3")
     par = np.asarray([[0.5, 0.1, 0.3, 0.2, 0.7]], np.float32)
