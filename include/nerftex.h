@@ -131,7 +131,12 @@ int ntx_composite(const float *color, const float *sigma, const float *z_vals, c
  *   status_flag: NULL, or DEVICE int32 OR-ed with 1 when NTX_FLAG_CHECK_NUMERICS finds NaN/Inf
  * Outputs (DEVICE): color_out[N,3] (premultiplied), alpha_out[N]; culled rays get 0 (or bkgd);
  *   weights_out: NULL, or [N,S] the compositing weights of renderer.py:198 (input of sample_pdf; rows of
- *   culled rays are left untouched). */
+ *   culled rays are left untouched).
+ * Context scratch (device memory owned by ctx, grown to the largest n_rays seen, then reused; freed by ntx_destroy):
+ *   1 KiB per ray for ParamNerf models -- the view direction and the appearance parameters are constant along a ray
+ *   (renderer.py:152-154), so the direction segment of the colour layer is evaluated once per ray by a pre-kernel instead
+ *   of once per sample, bit-identically; not when blur_idx scales an appearance parameter -- and 4 B per ray at
+ *   NTX_PRECISION_BF16X3 (compacted hit list).  Calls on one context must therefore be stream-ordered. */
 int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, const float *t,
                     const float *params, int64_t rays_per_param_row, const float *cone_scale,
                     int64_t n_rays, int n_samples, int blur_idx, uint32_t flags, const float *bkgd,

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(SamplePdfArgs a) {
 // ---------------------------------------------------------------------------------------------
 // hit-ray compaction for the lockstep bf16x3 render kernel (ntx_device_bf16.h): rays culled by the proxy (t0 == inf,
 // renderer.py:58-67) get their final value here (0, or the background colour: renderer.py:81-86); the indices of the
-// others are appended to hit_list (wave-aggregated atomic; the order is irrelevant, results are stored per ray).
+// others are appended to hit_list (the order across workgroups is irrelevant, results are stored per ray).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void compact_hits_kernel(const float *t, int64_t n_rays, int32_t *hit_list, int32_t *hit_count,
                                                            float *color_out, float *alpha_out, uint32_t flags, float b0, float b1, float b2) {
@@ -281,10 +281,20 @@ __global__ __launch_bounds__(256) void compact_hits_kernel(const float *t, int64
     const int lane = threadIdx.x & 63;
     const bool in = i < n_rays;
     const bool hit = in && !(t[2 * i] == __builtin_inff());   // NaN counts as a hit, as in render_kernel
+    // block-aggregated append: ranks within the wave by ballot, wave offsets through LDS, ONE atomic per workgroup
+    // (640 000 rays = 2 500 atomics on the one counter instead of 10 000)
+    __shared__ int wave_count[4], block_base;
     const uint64_t m = __ballot(hit);
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(hit_count, (int)__builtin_popcountll(m));
-    base = __shfl(base, 0, 64);
+    const int wv = threadIdx.x >> 6;
+    if (lane == 0) wave_count[wv] = (int)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        block_base = total ? atomicAdd(hit_count, total) : 0;
+    }
+    __syncthreads();
+    int base = block_base;
+    for (int k = 0; k < wv; ++k) base += wave_count[k];
     if (hit) hit_list[base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
     if (in && !hit) {
         const bool bk = (flags & NTX_FLAG_COMPOSITE_BKGD) != 0;

@@ -124,3 +124,36 @@ def test_bf16x3_nan_propagates_and_unsupported_family():
     with pytest.raises(_lib.NtxError) as e:
         mr(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(par)[0], cone_scale=to_dev(cone[None])[0])
     assert e.value.code == _lib.NTX_E_UNSUPPORTED
+
+
+def test_bf16x3_full_size_is_split_invariant():
+    """BASELINE config 1 size at bf16x3: the lockstep kernel hands rays to waves through a compacted list whose order
+    depends on the launch, yet each ray's result depends only on the ray -- bit-identical however the rays are split
+    across calls (what sharding across GPUs relies on), alpha in [0,1], premultiplied colours below alpha."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES["carpet"]
+    model, spec, w = make_model((1, 6), dense_media=True)
+    n, S = 800 * 800, 64
+    ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"])
+    t = t.copy(); t[::7] = np.inf                      # every 7th ray culled: the hit list is a real compaction
+    params = to_dev(np.asarray([fam["params"]], np.float32))[0]
+    r = Renderer(model=model, n_samples=S, perturb=False, precision="bf16x3")
+    dro, drd, dt, dcone = to_dev(ro, rd, t, cone)
+    full = r(dro[None], drd[None], dt[None], parameters=params, cone_scale=dcone[None])
+    c, a = full["color_pred"][0], full["alpha_pred"][0]
+    assert torch.isfinite(c).all() and torch.isfinite(a).all()
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 + 1e-6 and bool((c <= a[:, None] + 1e-6).all())
+    assert bool((a[::7] == 0).all()) and bool((c[::7] == 0).all())
+    cuts = [0, 100_003, 400_001, n]
+    pc, pa = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        o = r(dro[None, lo:hi], drd[None, lo:hi], dt[None, lo:hi], parameters=params, cone_scale=dcone[None, lo:hi])
+        pc.append(o["color_pred"][0]); pa.append(o["alpha_pred"][0])
+    assert torch.equal(torch.cat(pc), c) and torch.equal(torch.cat(pa), a)
+    idx = np.random.default_rng(0).choice(np.where(np.isfinite(t[:, 0]))[0], 256, replace=False)
+    ref = orc.render_rays(w, spec, ro[idx], rd[idx], t[idx], np.repeat(np.asarray([fam["params"]], np.float32), 256, 0), cone[idx],
+                          S, False, (1, 1, 1.), dtype=np.float64)
+    got = np.concatenate([c[idx].cpu().numpy(), a[idx].cpu().numpy()[:, None]], -1)
+    want = np.concatenate([ref["color_pred"], ref["alpha_pred"][:, None]], -1)
+    assert orc.rel_linf(got, want) <= TOL
