@@ -88,16 +88,89 @@ def measured_traffic(workload: str, precision: str = "float32"):
     return float(rd) + float(wr or 0.0), os.path.relpath(files[-1], ROOT)
 
 
+def bench_instanced(args) -> None:
+    """`--workload carpet_instanced`: the InstanceRenderer tail (what config_carpet_render.py runs) on one
+    render chunk of synthetic instancer output resident in HBM: 16 384 rays x 1024 marching samples
+    (config_carpet_render.py:78-79), 1/8 of them inside a patch (dists > 0) in runs of 16, i.e. ~128 network
+    evaluations per ray after the in-kernel compaction.  value = in-patch ray-samples/s; N = 1 only (the patch instancer
+    that feeds this path is CPU code outside the hot path)."""
+    import torch
+    from nerf_tex_amd import _lib, synthetic
+    from nerf_tex_amd.model import ParamNerf
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("carpet_instanced is a single-GPU workload")
+    if args.precision != "float32":
+        raise SystemExit("ntx_render_instanced computes in float32")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    fam = synthetic.FAMILIES["carpet"]
+    emb = lambda n: {"module": "network.model.FourierFeatures", "n_freq_bands": n}
+    model = ParamNerf(emb(10), emb(4), emb(4), list(fam["n_parameters"]))["model"]
+    model.set_blob(synthetic.synthetic_weights(model.layer_table(), seed=0))
+    n, S, P = 16384, 1024, model.n_params
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    u = lambda *shape: torch.rand(*shape, device=dev, generator=g)
+    rays_d_map = torch.nn.functional.normalize(u(n, S, 3) - 0.5, dim=-1).contiguous()
+    pts = (u(n, S, 3) * 2.4 - 1.2).contiguous()
+    t = torch.sort(u(n, S) * 6 + 2, dim=-1).values.contiguous()
+    inside = (u(n, S // 16) < 0.125).repeat_interleave(16, dim=1)              # runs of 16 marching steps inside a patch
+    dists = torch.where(inside, (u(n, S) * 1.5 + 0.5) * 0.002, torch.zeros((), device=dev)).contiguous()
+    color_last = u(n, 3).contiguous(); alpha_last = (u(n) < 0.5).float().contiguous()
+    alpha_weight = (1.0 / torch.randint(1, 4, (n, S), device=dev, generator=g)).float().contiguous()
+    instance_id = torch.randint(0, 7, (n, S), device=dev, generator=g, dtype=torch.int32).contiguous()
+    hit = torch.ones(n, device=dev, dtype=torch.uint8)
+    params_map = (torch.as_tensor(fam["params"], device=dev, dtype=torch.float32)[None, None, :] * (u(n, S, 1) * 0.5 + 0.5)).contiguous()
+    cone = (u(n) * 4e-3 + 1e-3).contiguous()
+    color = torch.empty((n, 3), device=dev); alpha = torch.empty((n,), device=dev)
+    n_in = int(inside.sum().item())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        _lib.check(_lib.lib.ntx_render_instanced(
+            model.ctx(0), rays_d_map.data_ptr(), pts.data_ptr(), t.data_ptr(), dists.data_ptr(), color_last.data_ptr(),
+            alpha_last.data_ptr(), alpha_weight.data_ptr(), instance_id.data_ptr(), hit.data_ptr(), params_map.data_ptr(),
+            cone.data_ptr(), n, S, -1, 0.09, 400.0, 0, _lib.f3([1, 1, 1.]), None, color.data_ptr(), alpha.data_ptr(), None, stream))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(); step(); b.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    flops_per_sample = 2 * model.macs_per_sample()
+    achieved = n_in * flops_per_sample / (kernel_ms * 1e-3) / 1e12
+    in_bytes = n * S * 4 * (3 + 3 + 1 + 1 + 1 + 1 + P)
+    print(json.dumps({
+        "metric": "in-patch ray-samples/sec (InstanceRenderer tail: compaction + MLP + composite)",
+        "value": n_in * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"carpet_instanced: one render chunk of {n} rays x {S} marching samples of synthetic instancer "
+                               f"output (config_carpet_render.py:78-98), {n_in} in-patch samples ({n_in / n:.1f} per ray, runs of 16), "
+                               f"ParamNerf n_parameters={list(fam['n_parameters'])}, buffers resident in HBM",
+                   "rays": n, "marching_samples_per_ray": S, "in_patch_samples": n_in, "flops_per_sample": flops_per_sample},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "algorithmic_bytes": in_bytes, "algorithmic_GBps": in_bytes / (kernel_ms * 1e-3) / 1e9,
+                     "kernel": "ntx::instance_kernel", "kernel_ms": kernel_ms}}), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS) + ["carpet_instanced"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="float32", choices=["float32", "bf16x3"],
                     help="arithmetic of the Dense layers (include/nerftex.h: ntx_precision); float32 = the reference's")
     args = ap.parse_args()
+    if args.workload == "carpet_instanced":
+        return bench_instanced(args)
 
     import torch
     import torch.distributed as dist

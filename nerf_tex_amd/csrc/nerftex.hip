@@ -273,7 +273,7 @@ struct ntx_ctx {
     size_t packed16_bytes;
     int32_t *hit_list;    // device scratch of the bf16x3 render kernel: compacted hit-ray indices, grown on demand
     size_t hit_cap;
-    int32_t *hit_count;   // device scalar
+    int32_t *hit_count;   // device int32[2]: [0] number of hit rays, [1] work counter of the instance kernel
     float *ray_bias;      // device scratch of the float32 render kernel: per-ray colour-layer bias incl. the direction
     size_t ray_bias_cap;  // features (dirbias_kernel), [rays][2][128], grown on demand
     bool hoist_dir;       // false when NERFTEX_NO_DIR_HOIST is set at ntx_create (A/B knob for tests: same bits either way)
@@ -290,13 +290,13 @@ namespace ntx {
     hipError_t launch_render_hoist_v##k(int n_wgs, RenderArgs &a, hipStream_t st);
 NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4)
 #undef NTX_DECL
-hipError_t launch_render_bf16_v0(int n_wgs, RenderArgs16 &a, hipStream_t st);
-hipError_t launch_render_bf16_v1(int n_wgs, RenderArgs16 &a, hipStream_t st);
-hipError_t launch_render_bf16_v2(int n_wgs, RenderArgs16 &a, hipStream_t st);
-hipError_t launch_render_bf16_v3(int n_wgs, RenderArgs16 &a, hipStream_t st);
+hipError_t launch_render_bf16_v0(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_render_bf16_v1(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_render_bf16_v2(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_render_bf16_v3(int n_wgs, RenderArgs &a, hipStream_t st);
 }  // namespace ntx
 
-static hipError_t launch_render_bf16(const ntx_ctx *c, RenderArgs16 &a, hipStream_t st) {
+static hipError_t launch_render_bf16(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
     switch (c->variant) {
         case 0: return launch_render_bf16_v0(c->n_wgs, a, st);
 #ifndef NTX_DEV_ONLY_CARPET
@@ -626,10 +626,24 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     a.n_samples = n_samples; a.blur_idx = blur_idx; a.flags = flags;
     a.delta = (1.0f - 0.0f) / (float)(n_samples - 1 + v.ipe);   // mip: S+1 segment edges (renderer.py:374)
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
+    // Hit-ray compaction (both precisions): culled rays get their final value here, the render kernel walks the list.
+    // The scratch lives in the context, so launches on one context must be stream-ordered.
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "n_rays %lld exceeds int32", (long long)n_rays);
+    if (ctx->hit_cap < (size_t)n_rays) {
+        if (ctx->hit_list) HIP_TRY(hipFree(ctx->hit_list));
+        ctx->hit_list = nullptr; ctx->hit_cap = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->hit_list, (size_t)n_rays * sizeof(int32_t)));
+        ctx->hit_cap = (size_t)n_rays;
+    }
+    if (!ctx->hit_count) HIP_TRY(hipMalloc((void **)&ctx->hit_count, 2 * sizeof(int32_t)));   // [0] hits, [1] instance work counter
+    HIP_TRY(hipMemsetAsync(ctx->hit_count, 0, sizeof(int32_t), st));
+    compact_hits_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st>>>(
+        t, n_rays, ctx->hit_list, ctx->hit_count, color_out, alpha_out, flags, a.bkgd[0], a.bkgd[1], a.bkgd[2]);
+    HIP_TRY(hipGetLastError());
+    a.hit_list = ctx->hit_list; a.hit_count = ctx->hit_count;
+
     if (ctx->precision == NTX_PRECISION_BF16X3) {
-        // lockstep kernel over the compacted hit list (ntx_device_bf16.h); the scratch lives in the context, so
-        // bf16x3 launches on one context must be stream-ordered
-        if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "bf16x3: n_rays %lld exceeds int32", (long long)n_rays);
         // ParamNerf: the colour layer's direction segment always enters as the per-ray bias of dirbias_kernel (float32)
         if (v.cd) {
             if (blur_idx >= v.n_geo)
@@ -644,25 +658,12 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
             d.wstream = a.wstream; d.stream_bytes = a.stream_bytes; d.aux = a.aux;   // the float32 stream
             d.rays_d = rays_d; d.params = params; d.ray_bias = ctx->ray_bias;
             d.n_rays = n_rays; d.rays_per_row = rays_per_param_row; d.blur_idx = blur_idx;
-            HIP_TRY(launch_dirbias(ctx, d, (hipStream_t)stream));
+            HIP_TRY(launch_dirbias(ctx, d, st));
             a.ray_bias = ctx->ray_bias;
         }
-        if (ctx->hit_cap < (size_t)n_rays) {
-            if (ctx->hit_list) HIP_TRY(hipFree(ctx->hit_list));
-            ctx->hit_list = nullptr; ctx->hit_cap = 0;
-            HIP_TRY(hipMalloc((void **)&ctx->hit_list, (size_t)n_rays * sizeof(int32_t)));
-            ctx->hit_cap = (size_t)n_rays;
-        }
-        if (!ctx->hit_count) HIP_TRY(hipMalloc((void **)&ctx->hit_count, sizeof(int32_t)));
-        hipStream_t st = (hipStream_t)stream;
-        HIP_TRY(hipMemsetAsync(ctx->hit_count, 0, sizeof(int32_t), st));
-        compact_hits_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st>>>(
-            t, n_rays, ctx->hit_list, ctx->hit_count, color_out, alpha_out, flags, a.bkgd[0], a.bkgd[1], a.bkgd[2]);
-        HIP_TRY(hipGetLastError());
         a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed16);
         a.stream_bytes = (uint32_t)ctx->packed16_bytes;
-        RenderArgs16 a16{a, ctx->hit_list, ctx->hit_count};
-        HIP_TRY(launch_render_bf16(ctx, a16, st));
+        HIP_TRY(launch_render_bf16(ctx, a, st));
         return NTX_OK;
     }
     // Direction features and appearance parameters are per-ray constants (renderer.py:152-154) unless the blur scaling
@@ -723,6 +724,11 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     a.n_rays = n_rays; a.n_samples = n_samples; a.blur_idx = blur_idx; a.flags = flags;
     a.patch_scale = patch_scale; a.density_scale = density_scale;
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
+    if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "n_rays %lld exceeds int32", (long long)n_rays);
+    // dynamic ray hand-out: a device counter owned by the context (stream-ordered use, like the other scratch)
+    if (!ctx->hit_count) HIP_TRY(hipMalloc((void **)&ctx->hit_count, 2 * sizeof(int32_t)));   // [0] hits, [1] this counter
+    HIP_TRY(hipMemsetAsync(ctx->hit_count + 1, 0, sizeof(int32_t), (hipStream_t)stream));
+    a.work_counter = ctx->hit_count + 1;
     HIP_TRY(launch_instance(ctx, a, (hipStream_t)stream));
     return NTX_OK;
 }

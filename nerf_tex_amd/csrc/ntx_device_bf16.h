@@ -368,25 +368,18 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &w
 // the fused render kernel at bf16x3 precision.  Same per-ray work as render_kernel<CFG> around the MLP, but over the
 // compacted hit list and in workgroup lockstep: iteration `it` gives wave w of workgroup g the hit ray number
 // it * (4 * gridDim) + 4 g + w; waves past the end of the list go through the motions on the last hit ray and store nothing.
-struct RenderArgs16 {
-    RenderArgs r;
-    const int32_t *hit_list;    // [n_hit] indices of the rays with t0 != inf (any order)
-    const int32_t *hit_count;   // device scalar n_hit
-};
-
 template <class CFG>
-__global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs16 args) {
+__global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs a) {
     static_assert(CFG::IPE == 0, "bf16x3 is built for the FourierFeatures families");
     using G16 = Cfg16<CFG>;
     __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
     __shared__ __attribute__((aligned(16))) float aux[aux_total()];
-    const RenderArgs &a = args.r;
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.n_samples;
     const int nb = (S + 31) >> 5;
-    const int n_hit = *args.hit_count;
+    const int n_hit = *a.hit_count;
     const int per_it = gridDim.x * 4;
     const int iters = (n_hit + per_it - 1) / per_it;
     if (iters == 0) return;   // uniform over the grid
@@ -396,14 +389,14 @@ __global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs16 args) {
     for (int it = 0; it < iters; ++it) {
         const int idx = it * per_it + blockIdx.x * 4 + wv;
         const bool live = idx < n_hit;
-        const int64_t ray = args.hit_list[live ? idx : n_hit - 1];
+        const int64_t ray = a.hit_list[live ? idx : n_hit - 1];
         RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         for (int b = 0; b < nb; ++b) {
             int64_t r = ray;
             asm volatile("" : "+s"(r));
-            const RenderArgs16 *ap = kernargs<RenderArgs16>();
+            const RenderArgs *ap = kernargs<RenderArgs>();
             asm volatile("" : "+s"(ap));
-            const RenderArgs &q = ap->r;
+            const RenderArgs &q = *ap;
             const float t0 = q.t[2 * r], t1 = q.t[2 * r + 1];
             const float ox = q.rays_o[3 * r], oy = q.rays_o[3 * r + 1], oz = q.rays_o[3 * r + 2];
             const float dx = q.rays_d[3 * r], dy = q.rays_d[3 * r + 1], dz = q.rays_d[3 * r + 2];
@@ -429,10 +422,10 @@ __global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs16 args) {
             }
             float sigma, raw[3];
             mlp_batch_bf16<CFG>(in, ws, aux, lane, sigma, raw, CFG::CD != 0 ? q.ray_bias + r * 256 : nullptr);
-            const RenderArgs16 *ap2 = kernargs<RenderArgs16>();
+            const RenderArgs *ap2 = kernargs<RenderArgs>();
             asm volatile("" : "+s"(ap2));
-            composite_step<32>(ra, sigma, raw, dist, valid && live, ap2->r.flags, j,
-                               ap2->r.weights_out ? ap2->r.weights_out + r * S + ic : nullptr);
+            composite_step<32>(ra, sigma, raw, dist, valid && live, ap2->flags, j,
+                               ap2->weights_out ? ap2->weights_out + r * S + ic : nullptr);
         }
         float out[4] = {ra.c0, ra.c1, ra.c2, ra.a};
         if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {

@@ -24,7 +24,7 @@ using VCfg = Cfg<0, 0, 0>;   // plain Nerf
 #define NTX_FN(name) name##_v3
 #endif
 
-hipError_t NTX_FN(launch_render_bf16)(int n_wgs, RenderArgs16 &a, hipStream_t st) {
+hipError_t NTX_FN(launch_render_bf16)(int n_wgs, RenderArgs &a, hipStream_t st) {
     render_kernel_bf16<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
     return hipGetLastError();
 }
