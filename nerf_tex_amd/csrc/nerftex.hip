@@ -630,6 +630,7 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     // The scratch lives in the context, so launches on one context must be stream-ordered.
     hipStream_t st = (hipStream_t)stream;
     if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "n_rays %lld exceeds int32", (long long)n_rays);
+    HIP_TRY(hipSetDevice(ctx->device));   // scratch must live on the context's device whatever the caller's current one is
     if (ctx->hit_cap < (size_t)n_rays) {
         if (ctx->hit_list) HIP_TRY(hipFree(ctx->hit_list));
         ctx->hit_list = nullptr; ctx->hit_cap = 0;
@@ -726,6 +727,7 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
     if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "n_rays %lld exceeds int32", (long long)n_rays);
     // dynamic ray hand-out: a device counter owned by the context (stream-ordered use, like the other scratch)
+    HIP_TRY(hipSetDevice(ctx->device));
     if (!ctx->hit_count) HIP_TRY(hipMalloc((void **)&ctx->hit_count, 2 * sizeof(int32_t)));   // [0] hits, [1] this counter
     HIP_TRY(hipMemsetAsync(ctx->hit_count + 1, 0, sizeof(int32_t), (hipStream_t)stream));
     a.work_counter = ctx->hit_count + 1;

@@ -569,7 +569,7 @@ struct RenderArgs {
     const float *ray_bias;   // NULL, or [n_rays][2][128]: per-ray bias of the colour layer incl. the direction features (dirbias_kernel)
     // NULL, or the compacted indices of the rays with t0 != inf and their number (compact_hits_kernel, which has then
     // already written the culled rays): every wave gets the same number of rays to march, however the misses are
-    // distributed over the image (a static ray -> wave map loses ~10 % on a half-empty camera grid)
+    // distributed over the image
     const int32_t *hit_list, *hit_count;
 };
 
