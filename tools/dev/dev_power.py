@@ -2,7 +2,7 @@
 with the seeded glorot weights, with all-zero weights, and with constant weights."""
 import sys, os
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nerf_tex_amd import synthetic
 from nerf_tex_amd.model import ParamNerf
 from nerf_tex_amd.renderer import Renderer
