@@ -99,8 +99,6 @@ def bench_instanced(args) -> None:
     from nerf_tex_amd.model import ParamNerf
     if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
         raise SystemExit("carpet_instanced is a single-GPU workload")
-    if args.precision != "float32":
-        raise SystemExit("ntx_render_instanced computes in float32")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     fam = synthetic.FAMILIES["carpet"]
@@ -125,6 +123,8 @@ def bench_instanced(args) -> None:
     n_in = int(inside.sum().item())
     stream = torch.cuda.current_stream(dev).cuda_stream
 
+    _lib.check(_lib.lib.ntx_set_precision(model.ctx(0), _lib.PRECISIONS[args.precision]))
+
     def step():
         _lib.check(_lib.lib.ntx_render_instanced(
             model.ctx(0), rays_d_map.data_ptr(), pts.data_ptr(), t.data_ptr(), dists.data_ptr(), color_last.data_ptr(),
@@ -143,20 +143,22 @@ def bench_instanced(args) -> None:
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     flops_per_sample = 2 * model.macs_per_sample()
     achieved = n_in * flops_per_sample / (kernel_ms * 1e-3) / 1e12
+    peak = F32_MFMA_PEAK_TFLOPS if args.precision == "float32" else BF16_MFMA_PEAK_TFLOPS
     in_bytes = n * S * 4 * (3 + 3 + 1 + 1 + 1 + 1 + P)
     print(json.dumps({
         "metric": "in-patch ray-samples/sec (InstanceRenderer tail: compaction + MLP + composite)",
         "value": n_in * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == "float32" else "bf16x3 (f32 accumulate)", "data": "synthetic",
         "config": {"workload": f"carpet_instanced: one render chunk of {n} rays x {S} marching samples of synthetic instancer "
                                f"output (config_carpet_render.py:78-98), {n_in} in-patch samples ({n_in / n:.1f} per ray, runs of 16), "
                                f"ParamNerf n_parameters={list(fam['n_parameters'])}, buffers resident in HBM",
                    "rays": n, "marching_samples_per_ray": S, "in_patch_samples": n_in, "flops_per_sample": flops_per_sample},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "traffic": None,
                      "algorithmic_bytes": in_bytes, "algorithmic_GBps": in_bytes / (kernel_ms * 1e-3) / 1e9,
-                     "kernel": "ntx::instance_kernel", "kernel_ms": kernel_ms}}), flush=True)
+                     "kernel": "ntx::instance_kernel" if args.precision == "float32" else "ntx::instance_kernel_bf16",
+                     "kernel_ms": kernel_ms}}), flush=True)
 
 
 def main() -> None:

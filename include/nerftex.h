@@ -68,13 +68,14 @@ typedef struct ntx_model_desc {
 #define NTX_FLAG_COMPOSITE_BKGD 2u  /* renderer.py:210-211 and 85-86: add (1-A)*bkgd; culled rays = bkgd */
 #define NTX_FLAG_CHECK_NUMERICS 4u  /* renderer.py:140-141: set *status_flag |= 1 on NaN/Inf outputs */
 
-/* Arithmetic of the Dense layers inside ntx_render_rays (everything else -- encoders, heads' accumulation, compositing --
+/* Arithmetic of the Dense layers inside ntx_render_rays and ntx_render_instanced (everything else -- encoders, heads' accumulation, compositing --
  * is float32 either way).  The reference computes in float32 (TensorFlow's default dtype, model.py:104-123):
  *   NTX_PRECISION_F32    float32 matrix cores (v_mfma_f32_32x32x2_f32), the default; 1.7e-6 from the float32 reference.
  *   NTX_PRECISION_BF16X3 opt-in: weights and activations split as v = hi + lo (two bf16) and multiplied as
  *                        hi*hi + hi*lo + lo*hi on the bf16 matrix cores with float32 accumulation; the dropped lo*lo
  *                        term is ~2^-16 relative per product.  Within the 1e-4 render tolerance, not bit-identical to
- *                        NTX_PRECISION_F32.  FourierFeatures families only. */
+ *                        NTX_PRECISION_F32.  FourierFeatures families only (ntx_render_instanced: ParamNerf only);
+ *                        ntx_mlp_forward always computes in float32. */
 typedef enum ntx_precision { NTX_PRECISION_F32 = 0, NTX_PRECISION_BF16X3 = 1 } ntx_precision;
 
 int ntx_abi_version(void);
@@ -176,7 +177,7 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
 int ntx_image_epilogue(const float *rgba, int height, int width, int downsampling_factor, int unpremultiply,
                        float *out_f32, uint8_t *out_u8, ntx_stream stream);
 
-/* Selects the arithmetic of subsequent ntx_render_rays calls on `ctx` (see ntx_precision).  NTX_E_UNSUPPORTED for a
+/* Selects the arithmetic of subsequent ntx_render_rays / ntx_render_instanced calls on `ctx` (see ntx_precision).  NTX_E_UNSUPPORTED for a
  * model family without a bf16x3 kernel; the setting is per context and not thread-safe against concurrent launches. */
 int ntx_set_precision(ntx_ctx *ctx, int precision);
 

@@ -217,12 +217,13 @@ static void emit_segment16(uint16_t *&dst, const Layer &l, int nsteps16, int nmt
         }
 }
 
-static size_t packed16_bytes(const Variant &v) {
-    return (size_t)stream16_padded(v.n_geo, v.n_app, v.cd) * 1024;
+static size_t packed16_bytes(const Variant &v, int with_dir = 0) {
+    return (size_t)stream16_padded(v.n_geo, v.n_app, v.cd, with_dir) * 1024;
 }
 
 // hidden segment first, encoder segment second within a pass (ntx_device_bf16.h: Cfg16)
-static void pack16(const Variant &v, const float *blob, uint16_t *out) {
+// with_dir: the instanced kernel's stream, where C1 keeps its direction segment (directions are per sample there)
+static void pack16(const Variant &v, const float *blob, uint16_t *out, int with_dir = 0) {
     const Net n = view_blob(v, blob);
     const int pm = pos_map_dim(v.n_geo, 0), dm = dir_map_dim(v.n_app);
     const int ps = steps16(pos_steps(v.n_geo, 0)), ds = steps16(dir_steps(v.n_app)), hs = HSTEPS / 8;
@@ -241,13 +242,14 @@ static void pack16(const Variant &v, const float *blob, uint16_t *out) {
     }
     emit_segment16(dst, n.feature, hs, 8, 0, hidrow);
     if (n.has_c1) {
-        emit_segment16(dst, n.c1, hs, 8, dm, hidrow);   // its direction rows are applied per ray by dirbias_kernel
+        emit_segment16(dst, n.c1, hs, 8, dm, hidrow);   // render kernel: its direction rows are applied per ray by dirbias_kernel
+        if (with_dir) emit_segment16(dst, n.c1, ds, 8, 0, dirrow);
         emit_segment16(dst, n.c2, hs, 4, 0, hidrow);
     } else {
         emit_segment16(dst, n.c2, hs, 4, dm, hidrow);
         emit_segment16(dst, n.c2, ds, 4, 0, dirrow);
     }
-    const int rec = stream16_records(v.n_geo, v.n_app, v.cd), pad = stream16_padded(v.n_geo, v.n_app, v.cd);
+    const int rec = stream16_records(v.n_geo, v.n_app, v.cd, with_dir), pad = stream16_padded(v.n_geo, v.n_app, v.cd, with_dir);
     memset(dst, 0, (size_t)(pad - rec) * 1024);
 }
 
@@ -271,6 +273,8 @@ struct ntx_ctx {
     int precision;        // NTX_PRECISION_*: arithmetic of the Dense layers in ntx_render_rays
     uint16_t *packed16;   // device: bf16x3 stream (NULL for IPE families); shares the f32 aux block
     size_t packed16_bytes;
+    uint16_t *packed16i;  // device: bf16x3 stream of the instanced kernel (C1 with its direction segment); ParamNerf only
+    size_t packed16i_bytes;
     int32_t *hit_list;    // device scratch of the bf16x3 render kernel: compacted hit-ray indices, grown on demand
     size_t hit_cap;
     int32_t *hit_count;   // device int32[2]: [0] number of hit rays, [1] work counter of the instance kernel
@@ -294,6 +298,9 @@ hipError_t launch_render_bf16_v0(int n_wgs, RenderArgs &a, hipStream_t st);
 hipError_t launch_render_bf16_v1(int n_wgs, RenderArgs &a, hipStream_t st);
 hipError_t launch_render_bf16_v2(int n_wgs, RenderArgs &a, hipStream_t st);
 hipError_t launch_render_bf16_v3(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_instance_bf16_v0(int n_wgs, InstanceArgs &a, hipStream_t st);
+hipError_t launch_instance_bf16_v1(int n_wgs, InstanceArgs &a, hipStream_t st);
+hipError_t launch_instance_bf16_v2(int n_wgs, InstanceArgs &a, hipStream_t st);
 }  // namespace ntx
 
 static hipError_t launch_render_bf16(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
@@ -316,6 +323,16 @@ static hipError_t launch_render(const ntx_ctx *c, RenderArgs &a, hipStream_t st)
         case 2: return launch_render_v2(c->n_wgs, a, st);
         case 3: return launch_render_v3(c->n_wgs, a, st);
         case 4: return launch_render_v4(c->n_wgs, a, st);
+#endif
+        default: return hipErrorNotSupported;
+    }
+}
+static hipError_t launch_instance_bf16(const ntx_ctx *c, InstanceArgs &a, hipStream_t st) {
+    switch (c->variant) {
+        case 0: return launch_instance_bf16_v0(c->n_wgs, a, st);
+#ifndef NTX_DEV_ONLY_CARPET
+        case 1: return launch_instance_bf16_v1(c->n_wgs, a, st);
+        case 2: return launch_instance_bf16_v2(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -454,6 +471,7 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     c->precision = NTX_PRECISION_F32;
     c->packed16 = nullptr;
     c->packed16_bytes = 0;
+    c->packed16i = nullptr; c->packed16i_bytes = 0;
     c->hit_list = nullptr; c->hit_cap = 0; c->hit_count = nullptr;
     c->ray_bias = nullptr; c->ray_bias_cap = 0;
     c->hoist_dir = getenv("NERFTEX_NO_DIR_HOIST") == nullptr;
@@ -463,6 +481,16 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
         if (e != hipSuccess) {
             const size_t bytes = c->packed16_bytes;
             (void)hipFree(c->packed);
+            delete c;
+            return fail(NTX_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        }
+    }
+    if (c->packed16 && kVariants[v].cd) {
+        c->packed16i_bytes = packed16_bytes(kVariants[v], 1);
+        e = hipMalloc((void **)&c->packed16i, c->packed16i_bytes);
+        if (e != hipSuccess) {
+            const size_t bytes = c->packed16i_bytes;
+            (void)hipFree(c->packed); (void)hipFree(c->packed16);
             delete c;
             return fail(NTX_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
         }
@@ -478,6 +506,7 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     } else {
         HIP_TRY(hipMemset(c->packed, 0, c->n_packed * sizeof(float)));
         if (c->packed16) HIP_TRY(hipMemset(c->packed16, 0, c->packed16_bytes));
+        if (c->packed16i) HIP_TRY(hipMemset(c->packed16i, 0, c->packed16i_bytes));
     }
     return NTX_OK;
 }
@@ -504,6 +533,11 @@ int ntx_set_weights(ntx_ctx *ctx, const float *weights_host, size_t n_floats) {
         pack16(kVariants[ctx->variant], weights_host, p16.data());
         HIP_TRY(hipMemcpy(ctx->packed16, p16.data(), ctx->packed16_bytes, hipMemcpyHostToDevice));
     }
+    if (ctx->packed16i) {
+        std::vector<uint16_t> p16(ctx->packed16i_bytes / 2);
+        pack16(kVariants[ctx->variant], weights_host, p16.data(), 1);
+        HIP_TRY(hipMemcpy(ctx->packed16i, p16.data(), ctx->packed16i_bytes, hipMemcpyHostToDevice));
+    }
     return NTX_OK;
 }
 
@@ -511,6 +545,7 @@ int ntx_destroy(ntx_ctx *ctx) {
     if (!ctx) return NTX_OK;
     if (ctx->packed) (void)hipFree(ctx->packed);
     if (ctx->packed16) (void)hipFree(ctx->packed16);
+    if (ctx->packed16i) (void)hipFree(ctx->packed16i);
     if (ctx->hit_list) (void)hipFree(ctx->hit_list);
     if (ctx->hit_count) (void)hipFree(ctx->hit_count);
     if (ctx->ray_bias) (void)hipFree(ctx->ray_bias);
@@ -731,6 +766,14 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     if (!ctx->hit_count) HIP_TRY(hipMalloc((void **)&ctx->hit_count, 2 * sizeof(int32_t)));   // [0] hits, [1] this counter
     HIP_TRY(hipMemsetAsync(ctx->hit_count + 1, 0, sizeof(int32_t), (hipStream_t)stream));
     a.work_counter = ctx->hit_count + 1;
+    if (ctx->precision == NTX_PRECISION_BF16X3) {
+        if (!ctx->packed16i)
+            return fail(NTX_E_UNSUPPORTED, "bf16x3 instanced rendering is built for ParamNerf with FourierFeatures");
+        a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed16i);
+        a.stream_bytes = (uint32_t)ctx->packed16i_bytes;
+        HIP_TRY(launch_instance_bf16(ctx, a, (hipStream_t)stream));
+        return NTX_OK;
+    }
     HIP_TRY(launch_instance(ctx, a, (hipStream_t)stream));
     return NTX_OK;
 }

@@ -122,17 +122,17 @@ NTX_DEV f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mf
 // geometry of the k16 stream (host packer: pack16 in nerftex.hip).  Within a pass the hidden segment comes FIRST and the
 // encoder segment second (the order of the k-summation is free): the activations are converted just in time behind the
 // hidden segment's own MFMAs and never need to be held as a whole.
-template <class CFG>
+template <class CFG, bool WD = false>   // WD: with the direction segment of C1 in the stream (instanced kernel)
 struct Cfg16 {
     static constexpr int PS16 = steps16(CFG::PS), DS16 = steps16(CFG::DS), HS16 = HSTEPS / 8;
     static constexpr int rec_pass(int li) {   // first record of hidden pass li (1..8 = L1..L7, F; 9 = C1)
-        return PS16 * 16 + (li - 1) * HS16 * 16 + (li > SKIP + 1 ? PS16 * 16 : 0);   // C1 has no direction segment here
+        return PS16 * 16 + (li - 1) * HS16 * 16 + (li > SKIP + 1 ? PS16 * 16 : 0) + (CFG::CD && WD && li > 9 ? DS16 * 16 : 0);
     }
     static constexpr int REC_C2 = rec_pass(9 + (CFG::CD ? 1 : 0));
     static constexpr int REC_END = REC_C2 + (CFG::CD ? 0 : DS16 * 8) + HS16 * 8;
-    static constexpr int REC_PAD = stream16_padded(CFG::NGEO, CFG::NAPP, CFG::CD);
+    static constexpr int REC_PAD = stream16_padded(CFG::NGEO, CFG::NAPP, CFG::CD, WD);
     static constexpr int NST = REC_PAD / STAGE16;   // stages per batch
-    static_assert(REC_END == stream16_records(CFG::NGEO, CFG::NAPP, CFG::CD), "stream bookkeeping");
+    static_assert(REC_END == stream16_records(CFG::NGEO, CFG::NAPP, CFG::CD, WD), "stream bookkeeping");
     static_assert(REC_END % 8 == 0 && REC_PAD % (STAGE16 * NSTAGE16) == 0, "pair-groups and ring turns");
 };
 
@@ -260,10 +260,12 @@ NTX_DEV void skip_stage(WShared &ws) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <class CFG>
+// WD = false (render kernel): the colour layer C1 starts from the per-ray vector `c1_row` (dirbias_kernel) and has no
+// direction segment; WD = true (instanced kernel, per-sample directions): static bias, direction segment evaluated.
+template <class CFG, bool WD = false>
 NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &ws, const float *aux_in, int lane,
                             float &sigma, float (&rgb)[3], const float *c1_row) {
-    using G16 = Cfg16<CFG>;
+    using G16 = Cfg16<CFG, WD>;
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
     const int h = lane >> 5;
     uint32_t opaque_zero = 0;
@@ -294,7 +296,8 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &w
         constexpr bool init_next = li < NPASS;
         // ParamNerf's colour layer C1 (li = 9) starts from the per-ray vector bias_C1 + W_dir^T dir_map (dirbias_kernel,
         // float32): its direction segment is not evaluated per sample
-        constexpr bool next_is_c1 = CFG::CD != 0 && li + 1 == 9;
+        constexpr bool next_is_c1 = CFG::CD != 0 && !WD && li + 1 == 9;
+        constexpr bool has_dir = CFG::CD != 0 && WD && li == 9;
         {
             ConvGen<relu_in, li == DEPTH> cg{prev, aux, h, sig_part, {}, 0.f, 0.f, 0.f, 0.f};
             run_segment16<G16::HS16, 8, rec0, G16::NST>(cur, ws, cg, [&](auto U, auto Q) {
@@ -310,6 +313,11 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &w
             const SampleIn<NGEO, NAPP> in2 = launder(in);
             EncGen16<CFG, false> gen{in2, h, {}, {}};
             run_segment16<G16::PS16, 8, rec0 + G16::HS16 * 16, G16::NST>(cur, ws, gen, none);
+        }
+        if constexpr (has_dir) {   // input = concat[dir_map, feature]  (model.py:115), directions per sample
+            const SampleIn<NGEO, NAPP> in2 = launder(in);
+            EncGen16<CFG, true> gen{in2, h, {}, {}};
+            run_segment16<G16::DS16, 8, rec0 + G16::HS16 * 16, G16::NST>(cur, ws, gen, none);
         }
     };
     static_for<NPASS>([&](auto I) {
@@ -438,6 +446,123 @@ __global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs a) {
             if ((a.flags & NTX_FLAG_CHECK_NUMERICS) && a.status) {
                 const float s = out[0] + out[1] + out[2] + out[3];
                 if (!(__builtin_fabsf(s) <= 3.0e38f)) atomicOr(a.status, 1);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// InstanceRenderer tail at bf16x3 (instance_kernel<CFG> of ntx_device.h is the float32 one).  Rays cost a different
+// number of 32-sample batches each, and the workgroup shares one weight stream in lockstep, so the workgroup proceeds in
+// ROUNDS of one batch per wave: a wave that has finished its ray takes the next unclaimed one (device work counter) and
+// compacts its in-patch samples before the round starts; a wave that finds none left keeps its place in the barriers
+// with idle batches until its three neighbours are done (at most one ray's worth at the very end).
+// ---------------------------------------------------------------------------------------------
+template <class CFG>
+__global__ __launch_bounds__(256) void instance_kernel_bf16(InstanceArgs a) {
+    static_assert(CFG::IPE == 0 && CFG::CD != 0, "bf16x3 instanced: ParamNerf with FourierFeatures");
+    using G16 = Cfg16<CFG, true>;
+    __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
+    __shared__ __attribute__((aligned(16))) float aux[aux_total()];
+    __shared__ uint16_t sidx_all[4][MAX_INSTANCE_SAMPLES];
+    __shared__ int busy[4];
+    load_aux(aux, a.aux, aux_total());
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = a.n_samples;
+    uint16_t *sidx = sidx_all[wv];
+    WShared ws;
+    ws_prime<G16::NST>(ws, a.wstream, a.stream_bytes, (lds_char *)ring, lane, wv);
+
+    auto finish = [&](int64_t ray, const RayAccum &ra) {   // the appended sample and the store (renderer.py:323-352)
+        const float wl = a.alpha_last[ray] * ra.T;
+        float out[4] = {ra.c0 + wl * a.color_last[3 * ray], ra.c1 + wl * a.color_last[3 * ray + 1],
+                        ra.c2 + wl * a.color_last[3 * ray + 2], ra.a + wl};
+        if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {
+            const float A = out[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[c] = out[c] + (1.0f - A) * a.bkgd[c];
+        }
+        if (lane == 0) {
+            a.color_out[3 * ray + 0] = out[0]; a.color_out[3 * ray + 1] = out[1];
+            a.color_out[3 * ray + 2] = out[2]; a.alpha_out[ray] = out[3];
+            if ((a.flags & NTX_FLAG_CHECK_NUMERICS) && a.status) {
+                const float sm_ = out[0] + out[1] + out[2] + out[3];
+                if (!(__builtin_fabsf(sm_) <= 3.0e38f)) atomicOr(a.status, 1);
+            }
+        }
+    };
+
+    int64_t ray = -1;          // the ray this wave is marching, -1 = none
+    int count = 0, b = 0;
+    bool exhausted = false;
+    float cone = 0.0f;
+    RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (;;) {
+        while (ray < 0 && !exhausted) {
+            int r32 = 0;
+            if (lane == 0) r32 = atomicAdd(a.work_counter, 1);
+            const int64_t r = (int64_t)__builtin_amdgcn_readfirstlane(r32);
+            if (r >= a.n_rays) { exhausted = true; break; }
+            if (!a.hit[r]) {   // renderer.py:265-272, 313-314: stays 0, also under composite_bkgd
+                if (lane < 3) a.color_out[3 * r + lane] = 0.0f;
+                if (lane == 3) a.alpha_out[r] = 0.0f;
+                continue;
+            }
+            const float *drow = a.dists + r * S;
+            int n = 0;
+            for (int base = 0; base < S; base += 64) {
+                const int i = base + lane;
+                const bool v = i < S && drow[i] > 0.0f;
+                const unsigned long long m = __ballot(v);
+                if (v) sidx[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+                n += __popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            ra = RayAccum{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (n == 0) { finish(r, ra); continue; }   // a hit ray without in-patch samples: the appended sample alone
+            ray = r; count = n; b = 0;
+            cone = a.cone ? a.cone[r] : 0.0f;
+        }
+        if (lane == 0) busy[wv] = ray >= 0;
+        __syncthreads();
+        const bool any = (busy[0] | busy[1] | busy[2] | busy[3]) != 0;
+        if (!any) break;                               // the same for the four waves
+        const bool live = ray >= 0;
+        const int k = 32 * b + j;
+        const bool valid = live && k < count;
+        const int64_t sm = (live ? ray : 0) * S + (valid ? sidx[k] : (live ? sidx[0] : 0));
+        SampleIn<CFG::NGEO, CFG::NAPP> in;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { in.pos[c] = a.pts[3 * sm + c]; in.dir[c] = a.rays_d_map[3 * sm + c]; }
+        in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CFG::NP; ++c) {
+            float p = a.params_map[CFG::NP * sm + c];
+            if (c == a.blur_idx) p = p * (cone * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
+            in.par[c] = p;
+        }
+        float sigma, raw[3];
+        mlp_batch_bf16<CFG, true>(in, ws, aux, lane, sigma, raw, nullptr);
+        if (live) {
+            const float wgt = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // :300
+            sigma = sigma * wgt;
+            float col[3];
+            if (a.instance_color) {                                                                // :306-307, 322-323
+                const int id = a.instance_id[sm];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) col[c] = a.instance_color[3 * id + c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) col[c] = (a.flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[c]) : sigmoidf_(raw[c]);
+            }
+            const float al = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * a.dists[sm] / a.patch_scale) : 0.0f;   // :339
+            composite_core<32>(ra, al, col, valid, j, nullptr);
+            if (++b * 32 >= count) {
+                finish(ray, ra);
+                __builtin_amdgcn_wave_barrier();   // the index list is rewritten by the next ray
+                ray = -1;
             }
         }
     }

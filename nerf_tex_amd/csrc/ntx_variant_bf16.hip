@@ -29,4 +29,11 @@ hipError_t NTX_FN(launch_render_bf16)(int n_wgs, RenderArgs &a, hipStream_t st) 
     return hipGetLastError();
 }
 
+#if NTX_VARIANT != 3
+hipError_t NTX_FN(launch_instance_bf16)(int n_wgs, InstanceArgs &a, hipStream_t st) {
+    instance_kernel_bf16<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
+    return hipGetLastError();
+}
+#endif
+
 }  // namespace ntx

@@ -247,6 +247,7 @@ class InstanceRenderer(Renderer):
             al_c = torch.empty((k,), device=dev, dtype=torch.float32)
             ptr = lambda x: x.data_ptr() if x is not None else None
             with torch.cuda.device(dev):
+                _lib.check(_lib.lib.ntx_set_precision(self.model.ctx(dev.index or 0), _lib.PRECISIONS[self.precision]))
                 _lib.check(_lib.lib.ntx_render_instanced(
                     self.model.ctx(dev.index or 0), ptr(bufs["rays_d_map"]), ptr(bufs["pts"]), ptr(bufs["t"]),
                     ptr(bufs["dists"]), ptr(bufs["color_last"]), ptr(bufs["alpha_last"]), ptr(bufs["alpha_weight"]),
