@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(SamplePdfArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// hit-ray compaction for the lockstep bf16x3 render kernel (ntx_device_bf16.h): rays culled by the proxy (t0 == inf,
+// hit-ray compaction, first step of ntx_render_rays at both precisions: rays culled by the proxy (t0 == inf,
 // renderer.py:58-67) get their final value here (0, or the background colour: renderer.py:81-86); the indices of the
 // others are appended to hit_list (the order across workgroups is irrelevant, results are stored per ray).
 // ---------------------------------------------------------------------------------------------
