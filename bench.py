@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak (~2.5 PF, no sparsity)
+F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_{f16,bf16} dense peak (~2.5 PF, no sparsity)
 
 WORKLOADS = {   # name -> (family, H, W, samples per ray)
     "carpet": ("carpet", 800, 800, 64),             # BASELINE configs[1] -- the metric's configuration
@@ -78,7 +78,7 @@ def measured_traffic(workload: str, precision: str = "float32"):
     command (separate --pmc passes, FETCH_SIZE x2 for gfx950's wide reads; tools/summarize_profile.py).
     PMC collection cannot run inside the timed bench, so the latest committed profile is quoted; None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", ("bench_" if precision == "float32" else "benchbf16_") + f"{workload}_*pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", ("bench_" if precision == "float32" else "benchx3_") + f"{workload}_*pmc_summary.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))["derived"]
@@ -143,13 +143,13 @@ def bench_instanced(args) -> None:
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     flops_per_sample = 2 * model.macs_per_sample()
     achieved = n_in * flops_per_sample / (kernel_ms * 1e-3) / 1e12
-    peak = F32_MFMA_PEAK_TFLOPS if args.precision == "float32" else BF16_MFMA_PEAK_TFLOPS
+    peak = F32_MFMA_PEAK_TFLOPS if args.precision == "float32" else F16_MFMA_PEAK_TFLOPS
     in_bytes = n * S * 4 * (3 + 3 + 1 + 1 + 1 + 1 + P)
     print(json.dumps({
         "metric": "in-patch ray-samples/sec (InstanceRenderer tail: compaction + MLP + composite)",
         "value": n_in * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "float32" else "bf16x3 (f32 accumulate)", "data": "synthetic",
+        "dtype": "f32" if args.precision == "float32" else "fp16x3 (f32 accumulate)", "data": "synthetic",
         "config": {"workload": f"carpet_instanced: one render chunk of {n} rays x {S} marching samples of synthetic instancer "
                                f"output (config_carpet_render.py:78-98), {n_in} in-patch samples ({n_in / n:.1f} per ray, runs of 16), "
                                f"ParamNerf n_parameters={list(fam['n_parameters'])}, buffers resident in HBM",
@@ -157,7 +157,7 @@ def bench_instanced(args) -> None:
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "traffic": None,
                      "algorithmic_bytes": in_bytes, "algorithmic_GBps": in_bytes / (kernel_ms * 1e-3) / 1e9,
-                     "kernel": "ntx::instance_kernel" if args.precision == "float32" else "ntx::instance_kernel_bf16",
+                     "kernel": "ntx::instance_kernel" if args.precision == "float32" else "ntx::instance_kernel_x3",
                      "kernel_ms": kernel_ms}}), flush=True)
 
 
@@ -168,7 +168,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS) + ["carpet_instanced"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="float32", choices=["float32", "bf16x3"],
+    ap.add_argument("--precision", default="float32", choices=["float32", "fp16x3"],
                     help="arithmetic of the Dense layers (include/nerftex.h: ntx_precision); float32 = the reference's")
     args = ap.parse_args()
     if args.workload == "carpet_instanced":
@@ -241,12 +241,12 @@ def main() -> None:
         elapsed = float(tt.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
 
-    # the opt-in bf16x3 precision on the same inputs, outside the timed region (rank 0, N = 1): a second, clearly
+    # the opt-in fp16x3 precision on the same inputs, outside the timed region (rank 0, N = 1): a second, clearly
     # labelled figure next to the float32 headline -- never `value`
     alt = None
     if world == 1 and args.precision == "float32":
         r2 = Renderer(model=model, n_samples=S, perturb=False, blur_idx=fam["blur_idx"], check_numerics=False,
-                      precision="bf16x3")
+                      precision="fp16x3")
         o2 = r2(**batch)
         torch.cuda.synchronize()
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -257,12 +257,12 @@ def main() -> None:
         torch.cuda.synchronize()
         ms2 = a0.elapsed_time(a1) / args.steps
         rgba2 = torch.cat([o2["color_pred"][0], o2["alpha_pred"][0][:, None]], -1)
-        alt = {"precision": "bf16x3 (3-term bf16 split of weights and activations on v_mfma_f32_32x32x16_bf16, f32 accumulate)",
+        alt = {"precision": "fp16x3 (3-term split of weights and activations into IEEE halves on v_mfma_f32_32x32x16_f16, f32 accumulate)",
                "value": n_rays * S / (ms2 * 1e-3), "unit": "ray-samples/s", "kernel_ms": ms2,
                "rel_linf_vs_float32_kernel": float((rgba2 - img).abs().max() / img.abs().max()),
-               # canonical FLOPs (2 * MACs per ray-sample) over the bf16 dense peak; the kernel issues 3 bf16 MFMA products
+               # canonical FLOPs (2 * MACs per ray-sample) over the 16-bit dense peak; the kernel issues 3 half-precision MFMA products
                # per canonical MAC, so the matrix pipe is 3x busier than this fraction
-               "canonical_frac_of_bf16_peak": n_rays * S * 2 * model.macs_per_sample() / (ms2 * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+               "canonical_frac_of_f16_peak": n_rays * S * 2 * model.macs_per_sample() / (ms2 * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
                "mfma_products_per_mac": 3}
 
     if rank == 0:
@@ -271,7 +271,7 @@ def main() -> None:
         achieved = n_rays * S * flops_per_sample / (kernel_ms * 1e-3) / 1e12
         # canonical FLOPs (2 * MACs per ray-sample; split-precision multiplicity does not count) against the
         # dense peak of the issued MFMA dtype
-        peak = F32_MFMA_PEAK_TFLOPS if args.precision == "float32" else BF16_MFMA_PEAK_TFLOPS
+        peak = F32_MFMA_PEAK_TFLOPS if args.precision == "float32" else F16_MFMA_PEAK_TFLOPS
         line = {
             "metric": "ray-samples/sec (MLP+composite) at 800x800x64",
             "value": samples_per_step * args.steps / elapsed,
@@ -279,7 +279,7 @@ def main() -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "float32" else "bf16x3 (f32 accumulate)", "data": "synthetic",
+            "dtype": "f32" if args.precision == "float32" else "fp16x3 (f32 accumulate)", "data": "synthetic",
             "config": {"workload": f"{args.workload} {H}x{W}x{S}: {n_rays} all-hit rays x {S} samples per GPU "
                                    f"(BASELINE configs[{ {'carpet': 1, 'grass': 2, 'fur': 3, 'grass_filtered': 4}[args.workload] }]), "
                                    f"ParamNerf n_parameters={list(fam['n_parameters'])}, seeded glorot weights, "
@@ -290,11 +290,11 @@ def main() -> None:
                          "frac": achieved / peak, "traffic": measured_traffic(args.workload, args.precision)[0],
                          "traffic_unit": "bytes/launch (HBM side, rocprofv3 PMC)", "traffic_source": measured_traffic(args.workload, args.precision)[1],
                          "algorithmic_bytes": n_rays * (4 * (3 + 3 + 2 + 1 + 4) + 0) + 4 * model.n_params,
-                         "kernel": "ntx::render_kernel" if args.precision == "float32" else "ntx::render_kernel_bf16",
+                         "kernel": "ntx::render_kernel" if args.precision == "float32" else "ntx::render_kernel_x3",
                          "kernel_ms": kernel_ms},
         }
         if alt is not None:
-            line["bf16x3"] = alt
+            line["fp16x3"] = alt
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(family, S)
         print(json.dumps(line), flush=True)

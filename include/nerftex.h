@@ -68,15 +68,18 @@ typedef struct ntx_model_desc {
 #define NTX_FLAG_COMPOSITE_BKGD 2u  /* renderer.py:210-211 and 85-86: add (1-A)*bkgd; culled rays = bkgd */
 #define NTX_FLAG_CHECK_NUMERICS 4u  /* renderer.py:140-141: set *status_flag |= 1 on NaN/Inf outputs */
 
-/* Arithmetic of the Dense layers inside ntx_render_rays and ntx_render_instanced (everything else -- encoders, heads' accumulation, compositing --
- * is float32 either way).  The reference computes in float32 (TensorFlow's default dtype, model.py:104-123):
+/* Arithmetic of the Dense layers inside ntx_render_rays and ntx_render_instanced (everything else -- encoders, heads,
+ * compositing -- is float32 either way).  The reference computes in float32 (TensorFlow's default dtype, model.py:104-123):
  *   NTX_PRECISION_F32    float32 matrix cores (v_mfma_f32_32x32x2_f32), the default; 1.7e-6 from the float32 reference.
- *   NTX_PRECISION_BF16X3 opt-in: weights and activations split as v = hi + lo (two bf16) and multiplied as
- *                        hi*hi + hi*lo + lo*hi on the bf16 matrix cores with float32 accumulation; the dropped lo*lo
- *                        term is ~2^-16 relative per product.  Within the 1e-4 render tolerance, not bit-identical to
- *                        NTX_PRECISION_F32.  FourierFeatures families only (ntx_render_instanced: ParamNerf only);
- *                        ntx_mlp_forward always computes in float32. */
-typedef enum ntx_precision { NTX_PRECISION_F32 = 0, NTX_PRECISION_BF16X3 = 1 } ntx_precision;
+ *   NTX_PRECISION_FP16X3 opt-in: weights and activations split as v = hi + lo (two IEEE halves, round to nearest even,
+ *                        subnormals kept) and multiplied as hi*hi + hi*lo + lo*hi on the 16-bit matrix cores
+ *                        (v_mfma_f32_32x32x16_f16) with float32 accumulation.  hi + lo carries 22 mantissa bits and a
+ *                        product of two halves is exact in float32, so only the lo*lo term and the rounding of lo are lost,
+ *                        ~2^-22 relative per product: 2.8e-6 from the float32 kernel on the bench image, ~2.8x faster.  Not
+ *                        bit-identical to NTX_PRECISION_F32.  Range: |activation| and |weight| <= 65504, beyond that the
+ *                        sample becomes inf/NaN (reported through NTX_FLAG_CHECK_NUMERICS).  FourierFeatures families
+ *                        only (ntx_render_instanced: ParamNerf only); ntx_mlp_forward always computes in float32. */
+typedef enum ntx_precision { NTX_PRECISION_F32 = 0, NTX_PRECISION_FP16X3 = 1 } ntx_precision;
 
 int ntx_abi_version(void);
 const char *ntx_last_error(void);
@@ -137,7 +140,7 @@ int ntx_composite(const float *color, const float *sigma, const float *z_vals, c
  *   1 KiB per ray for ParamNerf models -- the view direction and the appearance parameters are constant along a ray
  *   (renderer.py:152-154), so the direction segment of the colour layer is evaluated once per ray by a pre-kernel instead
  *   of once per sample, bit-identically; not when blur_idx scales an appearance parameter -- and 4 B per ray at
- *   NTX_PRECISION_BF16X3 (compacted hit list).  Calls on one context must therefore be stream-ordered. */
+ *   NTX_PRECISION_FP16X3 (compacted hit list).  Calls on one context must therefore be stream-ordered. */
 int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, const float *t,
                     const float *params, int64_t rays_per_param_row, const float *cone_scale,
                     int64_t n_rays, int n_samples, int blur_idx, uint32_t flags, const float *bkgd,
@@ -178,7 +181,7 @@ int ntx_image_epilogue(const float *rgba, int height, int width, int downsamplin
                        float *out_f32, uint8_t *out_u8, ntx_stream stream);
 
 /* Selects the arithmetic of subsequent ntx_render_rays / ntx_render_instanced calls on `ctx` (see ntx_precision).  NTX_E_UNSUPPORTED for a
- * model family without a bf16x3 kernel; the setting is per context and not thread-safe against concurrent launches. */
+ * model family without a fp16x3 kernel; the setting is per context and not thread-safe against concurrent launches. */
 int ntx_set_precision(ntx_ctx *ctx, int precision);
 
 /* Introspection for benches/tests: name and launch geometry of the fused kernel in `ctx`. */
@@ -190,9 +193,9 @@ size_t ntx_packed_count(const ntx_model_desc *desc);
 int ntx_pack_weights(const ntx_model_desc *desc, const float *weights_host, size_t n_floats,
                      float *packed_out, size_t n_packed);
 
-/* Same for the bf16x3 weight stream: its size in bytes (0 + error for families without one) and the packing. */
-size_t ntx_packed_bf16x3_bytes(const ntx_model_desc *desc);
-int ntx_pack_weights_bf16x3(const ntx_model_desc *desc, const float *weights_host, size_t n_floats,
+/* Same for the fp16x3 weight stream: its size in bytes (0 + error for families without one) and the packing. */
+size_t ntx_packed_fp16x3_bytes(const ntx_model_desc *desc);
+int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_host, size_t n_floats,
                             uint16_t *packed_out, size_t n_bytes);
 
 #ifdef __cplusplus

@@ -30,7 +30,7 @@ class NtxError(RuntimeError):
         self.code = code
 
 
-PRECISIONS = {"float32": 0, "bf16x3": 1}   # ntx_precision
+PRECISIONS = {"float32": 0, "fp16x3": 1}   # ntx_precision
 
 _fp = C.POINTER(C.c_float)
 _vp = C.c_void_p
@@ -58,8 +58,8 @@ SYMBOLS = {
     "ntx_kernel_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ntx_packed_count": (C.c_size_t, [C.POINTER(ModelDesc)]),
     "ntx_pack_weights": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, _fp, C.c_size_t]),
-    "ntx_packed_bf16x3_bytes": (C.c_size_t, [C.POINTER(ModelDesc)]),
-    "ntx_pack_weights_bf16x3": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, C.POINTER(C.c_uint16), C.c_size_t]),
+    "ntx_packed_fp16x3_bytes": (C.c_size_t, [C.POINTER(ModelDesc)]),
+    "ntx_pack_weights_fp16x3": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, C.POINTER(C.c_uint16), C.c_size_t]),
 }
 
 

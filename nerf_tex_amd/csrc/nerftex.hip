@@ -11,7 +11,7 @@
 #include <cstring>
 #include <vector>
 
-#include "ntx_device_bf16.h"
+#include "ntx_device_x3.h"
 #include "ntx_small_kernels.h"
 
 using namespace ntx;
@@ -184,15 +184,37 @@ static void pack(const Variant &v, const float *blob, float *out) {
     }
 }
 
-// ---- bf16x3 stream (ntx_layout.h: one record = the A operand of one (k16-step, M-tile), hi record then lo record) ----
-static uint16_t bf16_rne(float f) {
+// ---- fp16x3 stream (ntx_layout.h: one record = the A operand of one (k16-step, M-tile), hi record then lo record) ----
+// float32 -> IEEE half, round to nearest even, subnormals kept, overflow to inf (what v_cvt_f16_f32 does)
+static uint16_t f16_rne(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    u &= 0x7fffffffu;
+    if (u >= 0x47800000u) return sign | (u > 0x7f800000u ? 0x7e00 : 0x7c00);   // >= 65536: inf, or NaN
+    if (u < 0x38800000u) {                                                       // < 2^-14: subnormal half or zero
+        // adding 0.5f aligns the value so that float addition rounds it (RNE) to a multiple of 2^-24
+        float t;
+        memcpy(&t, &u, 4);
+        t += 0.5f;
+        uint32_t r;
+        memcpy(&r, &t, 4);
+        return sign | (uint16_t)(r - 0x3f000000u);
+    }
+    const uint32_t odd = (u >> 13) & 1u;
+    u += 0xc8000fffu + odd;        // rebias the exponent by -112 and round the 13 dropped bits to nearest even
+    return sign | (uint16_t)(u >> 13);                                           // 65520..65535.99 carries into inf
 }
-static float bf16_f32(uint16_t h) {
-    const uint32_t u = (uint32_t)h << 16;
+static float f16_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, em = h & 0x7fffu;
+    uint32_t u;
+    if (em >= 0x7c00u) u = sign | 0x7f800000u | ((em & 0x3ffu) << 13);
+    else if (em >= 0x0400u) u = sign | ((em << 13) + 0x38000000u);
+    else {                                                                       // subnormal: em * 2^-24
+        const float t = (float)em * 5.9604644775390625e-08f;
+        memcpy(&u, &t, 4);
+        u |= sign;
+    }
     float f;
     memcpy(&f, &u, 4);
     return f;
@@ -209,9 +231,9 @@ static void emit_segment16(uint16_t *&dst, const Layer &l, int nsteps16, int nmt
                     const int col = 32 * mt + (lane & 31);
                     float val = 0.0f;
                     if (row >= 0 && col < l.out) val = l.w[(size_t)(row_offset + row) * l.out + col];
-                    const uint16_t h = bf16_rne(val);
+                    const uint16_t h = f16_rne(val);
                     hi[lane * 8 + e] = h;
-                    lo[lane * 8 + e] = bf16_rne(val - bf16_f32(h));
+                    lo[lane * 8 + e] = f16_rne(val - f16_f32(h));
                 }
             dst += 1024;
         }
@@ -221,7 +243,7 @@ static size_t packed16_bytes(const Variant &v, int with_dir = 0) {
     return (size_t)stream16_padded(v.n_geo, v.n_app, v.cd, with_dir) * 1024;
 }
 
-// hidden segment first, encoder segment second within a pass (ntx_device_bf16.h: Cfg16)
+// hidden segment first, encoder segment second within a pass (ntx_device_x3.h: Cfg16)
 // with_dir: the instanced kernel's stream, where C1 keeps its direction segment (directions are per sample there)
 static void pack16(const Variant &v, const float *blob, uint16_t *out, int with_dir = 0) {
     const Net n = view_blob(v, blob);
@@ -271,11 +293,11 @@ struct ntx_ctx {
     size_t n_packed;
     ntx_model_desc desc;
     int precision;        // NTX_PRECISION_*: arithmetic of the Dense layers in ntx_render_rays
-    uint16_t *packed16;   // device: bf16x3 stream (NULL for IPE families); shares the f32 aux block
+    uint16_t *packed16;   // device: fp16x3 stream (NULL for IPE families); shares the f32 aux block
     size_t packed16_bytes;
-    uint16_t *packed16i;  // device: bf16x3 stream of the instanced kernel (C1 with its direction segment); ParamNerf only
+    uint16_t *packed16i;  // device: fp16x3 stream of the instanced kernel (C1 with its direction segment); ParamNerf only
     size_t packed16i_bytes;
-    int32_t *hit_list;    // device scratch of the bf16x3 render kernel: compacted hit-ray indices, grown on demand
+    int32_t *hit_list;    // device scratch of the fp16x3 render kernel: compacted hit-ray indices, grown on demand
     size_t hit_cap;
     int32_t *hit_count;   // device int32[2]: [0] number of hit rays, [1] work counter of the instance kernel
     float *ray_bias;      // device scratch of the float32 render kernel: per-ray colour-layer bias incl. the direction
@@ -294,22 +316,22 @@ namespace ntx {
     hipError_t launch_render_hoist_v##k(int n_wgs, RenderArgs &a, hipStream_t st);
 NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4)
 #undef NTX_DECL
-hipError_t launch_render_bf16_v0(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_render_bf16_v1(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_render_bf16_v2(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_render_bf16_v3(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_instance_bf16_v0(int n_wgs, InstanceArgs &a, hipStream_t st);
-hipError_t launch_instance_bf16_v1(int n_wgs, InstanceArgs &a, hipStream_t st);
-hipError_t launch_instance_bf16_v2(int n_wgs, InstanceArgs &a, hipStream_t st);
+hipError_t launch_render_x3_v0(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_render_x3_v1(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_render_x3_v2(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_render_x3_v3(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_instance_x3_v0(int n_wgs, InstanceArgs &a, hipStream_t st);
+hipError_t launch_instance_x3_v1(int n_wgs, InstanceArgs &a, hipStream_t st);
+hipError_t launch_instance_x3_v2(int n_wgs, InstanceArgs &a, hipStream_t st);
 }  // namespace ntx
 
-static hipError_t launch_render_bf16(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
+static hipError_t launch_render_x3(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
     switch (c->variant) {
-        case 0: return launch_render_bf16_v0(c->n_wgs, a, st);
+        case 0: return launch_render_x3_v0(c->n_wgs, a, st);
 #ifndef NTX_DEV_ONLY_CARPET
-        case 1: return launch_render_bf16_v1(c->n_wgs, a, st);
-        case 2: return launch_render_bf16_v2(c->n_wgs, a, st);
-        case 3: return launch_render_bf16_v3(c->n_wgs, a, st);
+        case 1: return launch_render_x3_v1(c->n_wgs, a, st);
+        case 2: return launch_render_x3_v2(c->n_wgs, a, st);
+        case 3: return launch_render_x3_v3(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -327,12 +349,12 @@ static hipError_t launch_render(const ntx_ctx *c, RenderArgs &a, hipStream_t st)
         default: return hipErrorNotSupported;
     }
 }
-static hipError_t launch_instance_bf16(const ntx_ctx *c, InstanceArgs &a, hipStream_t st) {
+static hipError_t launch_instance_x3(const ntx_ctx *c, InstanceArgs &a, hipStream_t st) {
     switch (c->variant) {
-        case 0: return launch_instance_bf16_v0(c->n_wgs, a, st);
+        case 0: return launch_instance_x3_v0(c->n_wgs, a, st);
 #ifndef NTX_DEV_ONLY_CARPET
-        case 1: return launch_instance_bf16_v1(c->n_wgs, a, st);
-        case 2: return launch_instance_bf16_v2(c->n_wgs, a, st);
+        case 1: return launch_instance_x3_v1(c->n_wgs, a, st);
+        case 2: return launch_instance_x3_v2(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -418,18 +440,18 @@ int ntx_pack_weights(const ntx_model_desc *desc, const float *weights_host, size
     return NTX_OK;
 }
 
-size_t ntx_packed_bf16x3_bytes(const ntx_model_desc *desc) {
+size_t ntx_packed_fp16x3_bytes(const ntx_model_desc *desc) {
     const int v = find_variant(desc);
     if (v < 0) { unsupported(desc); return 0; }
-    if (kVariants[v].ipe) { fail(NTX_E_UNSUPPORTED, "bf16x3 precision is built for the FourierFeatures families only"); return 0; }
+    if (kVariants[v].ipe) { fail(NTX_E_UNSUPPORTED, "fp16x3 precision is built for the FourierFeatures families only"); return 0; }
     return packed16_bytes(kVariants[v]);
 }
 
-int ntx_pack_weights_bf16x3(const ntx_model_desc *desc, const float *weights_host, size_t n_floats, uint16_t *packed_out,
+int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_host, size_t n_floats, uint16_t *packed_out,
                             size_t n_bytes) {
     const int v = find_variant(desc);
     if (v < 0) return unsupported(desc);
-    if (kVariants[v].ipe) return fail(NTX_E_UNSUPPORTED, "bf16x3 precision is built for the FourierFeatures families only");
+    if (kVariants[v].ipe) return fail(NTX_E_UNSUPPORTED, "fp16x3 precision is built for the FourierFeatures families only");
     if (!weights_host || !packed_out) return fail(NTX_E_INVALID, "NULL buffer");
     if (n_floats != view_blob(kVariants[v], nullptr).count)
         return fail(NTX_E_INVALID, "weight blob has %zu floats, model needs %zu", n_floats,
@@ -513,10 +535,10 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
 
 int ntx_set_precision(ntx_ctx *ctx, int precision) {
     if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
-    if (precision != NTX_PRECISION_F32 && precision != NTX_PRECISION_BF16X3)
+    if (precision != NTX_PRECISION_F32 && precision != NTX_PRECISION_FP16X3)
         return fail(NTX_E_INVALID, "unknown precision %d", precision);
-    if (precision == NTX_PRECISION_BF16X3 && !ctx->packed16)
-        return fail(NTX_E_UNSUPPORTED, "bf16x3 precision is built for the FourierFeatures families only");
+    if (precision == NTX_PRECISION_FP16X3 && !ctx->packed16)
+        return fail(NTX_E_UNSUPPORTED, "fp16x3 precision is built for the FourierFeatures families only");
     ctx->precision = precision;
     return NTX_OK;
 }
@@ -679,11 +701,11 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     HIP_TRY(hipGetLastError());
     a.hit_list = ctx->hit_list; a.hit_count = ctx->hit_count;
 
-    if (ctx->precision == NTX_PRECISION_BF16X3) {
+    if (ctx->precision == NTX_PRECISION_FP16X3) {
         // ParamNerf: the colour layer's direction segment always enters as the per-ray bias of dirbias_kernel (float32)
         if (v.cd) {
             if (blur_idx >= v.n_geo)
-                return fail(NTX_E_UNSUPPORTED, "bf16x3: blur_idx %d scales an appearance parameter per sample; use NTX_PRECISION_F32", blur_idx);
+                return fail(NTX_E_UNSUPPORTED, "fp16x3: blur_idx %d scales an appearance parameter per sample; use NTX_PRECISION_F32", blur_idx);
             if (ctx->ray_bias_cap < (size_t)n_rays) {
                 if (ctx->ray_bias) HIP_TRY(hipFree(ctx->ray_bias));
                 ctx->ray_bias = nullptr; ctx->ray_bias_cap = 0;
@@ -699,7 +721,7 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
         }
         a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed16);
         a.stream_bytes = (uint32_t)ctx->packed16_bytes;
-        HIP_TRY(launch_render_bf16(ctx, a, st));
+        HIP_TRY(launch_render_x3(ctx, a, st));
         return NTX_OK;
     }
     // Direction features and appearance parameters are per-ray constants (renderer.py:152-154) unless the blur scaling
@@ -766,12 +788,12 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     if (!ctx->hit_count) HIP_TRY(hipMalloc((void **)&ctx->hit_count, 2 * sizeof(int32_t)));   // [0] hits, [1] this counter
     HIP_TRY(hipMemsetAsync(ctx->hit_count + 1, 0, sizeof(int32_t), (hipStream_t)stream));
     a.work_counter = ctx->hit_count + 1;
-    if (ctx->precision == NTX_PRECISION_BF16X3) {
+    if (ctx->precision == NTX_PRECISION_FP16X3) {
         if (!ctx->packed16i)
-            return fail(NTX_E_UNSUPPORTED, "bf16x3 instanced rendering is built for ParamNerf with FourierFeatures");
+            return fail(NTX_E_UNSUPPORTED, "fp16x3 instanced rendering is built for ParamNerf with FourierFeatures");
         a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed16i);
         a.stream_bytes = (uint32_t)ctx->packed16i_bytes;
-        HIP_TRY(launch_instance_bf16(ctx, a, (hipStream_t)stream));
+        HIP_TRY(launch_instance_x3(ctx, a, (hipStream_t)stream));
         return NTX_OK;
     }
     HIP_TRY(launch_instance(ctx, a, (hipStream_t)stream));

@@ -1,15 +1,19 @@
-// ntx_device_bf16.h -- opt-in "bf16x3" precision of the fused render kernel (gfx950).
+// ntx_device_x3.h -- opt-in "fp16x3" precision of the fused render kernels (gfx950).
 //
-// Every Dense layer is evaluated with the bf16 matrix cores on a 3-term split of both operands,
-//     x*w ~= hi(x)*hi(w) + hi(x)*lo(w) + lo(x)*hi(w),      hi = bf16(v), lo = bf16(v - hi),   float32 accumulate,
-// (v_mfma_f32_32x32x16_bf16, 16x the MAC rate of the f32 MFMA, on a pipe the VALU does not share).  Measured against the
-// float32 restatement of the reference: 2.7e-5 rel-Linf on the dense-media image, 8.5e-6 on glorot weights
-// (tools/emulate_bf16_split.py), inside the 1e-4 gate; the exact-f32 kernel of ntx_device.h stays the default.
+// Every Dense layer is evaluated with the 16-bit matrix cores on a 3-term split of both operands into IEEE halves,
+//     x*w ~= hi(x)*hi(w) + hi(x)*lo(w) + lo(x)*hi(w),      hi = fp16(v), lo = fp16(v - hi),   float32 accumulate,
+// (v_mfma_f32_32x32x16_f16: 16x the MAC rate of the f32 MFMA, on a pipe the VALU does not share; it keeps subnormal
+// inputs, checked on the hardware, so lo parts below 6e-5 are not flushed).  hi + lo carries 22 mantissa bits and each
+// product of two halves is exact in float32, so what is lost is the lo*lo term and the rounding of lo: ~2^-22 relative
+// per product.  Measured: 2.5e-6 rel-Linf from the float32 restatement of the reference on the plumbing image
+// (tools/emulate_bf16_split.py fp16; the float32 kernel itself: 1.7e-6).  The same scheme with bfloat16 halves (what this
+// file did first) is 10x less accurate at the same cost.  Range: |activation|, |weight| <= 65504, else inf -> flagged by
+// NTX_FLAG_CHECK_NUMERICS.  The exact-f32 kernel of ntx_device.h stays the default.
 //
 // Structure: one wave64 = 32 samples with activations in registers, as in the f32 kernel -- but the 4 waves of a
 // workgroup SHARE one copy of the weight stream through an LDS ring.  (Every wave streaming its own copy from L2, the
 // f32 kernel's structure, tops out at the L1/TA's 64 B/clk/CU: 84% TA-busy at 62% MFMA utilisation, measured; the shared
-// ring moves that traffic to the LDS -- tools/ubench/bf16x3_stream.hip: 6.44 vs 8.3 us per 256x256 layer.)
+// ring moves that traffic to the LDS -- tools/ubench/fp16x3_stream.hip: 6.44 vs 8.3 us per 256x256 layer.)
 //   * the stream is cut into STAGES of 16 records (16 KiB = one k16-step of an 8-tile layer); the ring holds 4 stages;
 //   * each wave fetches its quarter of a stage with 4 LDS-DMA loads (buffer_load_dwordx4 ... lds: L2 -> LDS, no VGPRs),
 //     three stages ahead of the one being multiplied;
@@ -18,7 +22,7 @@
 //   * A operands come back with ds_read_b128, one MFMA pair-group (4 records) ahead.
 // The waves of a workgroup therefore run in lockstep: the kernel walks a COMPACTED list of hit rays (built by
 // compact_hits_kernel, ntx_small_kernels.h) so that every wave has the same trip count.
-// A k16-step of the bf16 MFMA is 8 consecutive k2-steps of the f32 layout (ntx_layout.h): element e of lane half h in
+// A k16-step of the f16 MFMA is 8 consecutive k2-steps of the f32 layout (ntx_layout.h): element e of lane half h in
 // k16-step u is the feature hidden_row(8u+e, h) / pos_row(8u+e, h) / dir_row(8u+e, h), so the same accumulator-register
 // -> next-layer-B-operand identity holds, now with a bias+ReLU+split+pack between.
 #pragma once
@@ -27,7 +31,7 @@
 
 namespace ntx {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) char lds_char;
 
 constexpr int vmcnt_imm(int n) { return (n & 0xF) | (7 << 4) | (0xF << 8) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
@@ -38,7 +42,7 @@ struct WShared {
     uint32_t woff;        // (wave in workgroup) * 4096: this wave's quarter of every stage
     uint32_t ring;        // LDS byte address of the ring: NSTAGE16 x 16 KiB
     const lds_char *lane16;   // ring + lane * 16: LDS side of the reads
-    bf16x8 a[4];          // A operands of the upcoming MFMA pair-group: tile 2g hi, lo, tile 2g+1 hi, lo
+    half8 a[4];          // A operands of the upcoming MFMA pair-group: tile 2g hi, lo, tile 2g+1 hi, lo
 };
 
 // this wave's quarter of stage ST (modulo the padded stream) -> its ring slot: four LDS-DMA loads, M0 = LDS address of
@@ -71,11 +75,11 @@ NTX_DEV void stage_end() {
 
 // records REC .. REC+3 (one pair-group; never straddles a stage) -> registers
 template <int REC, int NST>
-NTX_DEV void read_group(const WShared &ws, bf16x8 (&n)[4]) {
+NTX_DEV void read_group(const WShared &ws, half8 (&n)[4]) {
     constexpr int rec = REC % (NST * STAGE16), slot = (rec / STAGE16) % NSTAGE16, r0 = rec % STAGE16;
     static_assert(r0 % 4 == 0, "pair-groups are 4 records");
     const lds_char *p = ws.lane16 + (slot * STAGE16 + r0) * 1024;
-    static_for<4>([&](auto K) { n[K] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>(p + decltype(K)::value * 1024); });
+    static_for<4>([&](auto K) { n[K] = *reinterpret_cast<const __attribute__((address_space(3))) half8 *>(p + decltype(K)::value * 1024); });
 }
 
 template <int NST>
@@ -97,18 +101,20 @@ NTX_DEV void ws_prime(WShared &ws, const void *base, uint32_t stream_bytes, lds_
 
 // B operand of one k16-step: 8 features per lane, split
 struct B16 {
-    bf16x8 hi, lo;
+    half8 hi, lo;
 };
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-NTX_DEV uint32_t pack2(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
-    const bf16x2 v = {(__bf16)a, (__bf16)b};
+// two floats -> two IEEE halves in one dword, round to nearest even (v_cvt_f16_f32 x2 + v_pack_b32_f16; NOT v_cvt_pkrtz).
+// Values beyond 65504 become inf and poison the sample, which NTX_FLAG_CHECK_NUMERICS reports.
+NTX_DEV uint32_t pack2(float a, float b) {
+    const half2_t v = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(uint32_t, v);
 }
-NTX_DEV float lo_f32(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
-NTX_DEV float hi_f32(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+NTX_DEV float lo_f32(uint32_t w) { return (float)__builtin_bit_cast(half2_t, w)[0]; }
+NTX_DEV float hi_f32(uint32_t w) { return (float)__builtin_bit_cast(half2_t, w)[1]; }
 
 // relu as an integer max: one v_max_i32, no canonicalising pre-op (fmaxf on an MFMA result costs two instructions);
 // +NaN stays NaN, -NaN and -0 become +0
@@ -117,7 +123,7 @@ NTX_DEV float relu1(float x) {
     return __builtin_bit_cast(float, i > 0 ? i : 0);
 }
 
-NTX_DEV f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+NTX_DEV f32x16 mfma16(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // geometry of the k16 stream (host packer: pack16 in nerftex.hip).  Within a pass the hidden segment comes FIRST and the
 // encoder segment second (the order of the k-summation is free): the activations are converted just in time behind the
@@ -137,13 +143,13 @@ struct Cfg16 {
 };
 
 // ---- B-operand generators.  The B operand of k16-step U is produced by 12 PIECES of VALU work, piece<U, Q>(), which
-// run_segment16 places behind the MFMA pairs of step U-1 (the bf16 MFMA pipe and the VALU are separate: a pair of MFMAs
+// run_segment16 places behind the MFMA pairs of step U-1 (the 16-bit MFMA pipe and the VALU are separate: a pair of MFMAs
 // hides ~8 VALU instructions); value<U>() hands over the finished operand.
 struct Words16 {
     uint32_t hw[4], lw[4];
     NTX_DEV B16 get() const {
         const u32x4 h = {hw[0], hw[1], hw[2], hw[3]}, l = {lw[0], lw[1], lw[2], lw[3]};
-        return B16{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
+        return B16{__builtin_bit_cast(half8, h), __builtin_bit_cast(half8, l)};
     }
 };
 
@@ -162,8 +168,10 @@ struct ConvGen {
     NTX_DEV void piece() {
         constexpr int p = Q / 3, t = Q % 3, reg = 8 * (U & 1) + 2 * p;
         if constexpr (t == 0) {
-            x0 = prev[U >> 1][reg];
-            x1 = prev[U >> 1][reg + 1];
+            // read the two accumulator registers HERE: left to the register allocator, all 128 values of the drained set
+            // are copied to VGPRs at the top of the pass and stay live through it, which tips the kernel into spilling
+            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3"
+                         : "=&v"(x0), "=&v"(x1) : "a"(prev[U >> 1][reg]), "a"(prev[U >> 1][reg + 1]));
             if constexpr (RELU) { x0 = relu1(x0); x1 = relu1(x1); }
             if constexpr (ALPHA) {
                 sig = __builtin_fmaf(x0, aux[aux_alpha_off() + h * 128 + 8 * U + 2 * p], sig);
@@ -226,7 +234,7 @@ NTX_DEV void run_segment16(f32x16 (&acc)[8], WShared &ws, Gen &gen, Extra &&extr
             constexpr int g = G;
             constexpr int rec = REC0 + (u * NMT + 2 * g) * 2;   // records: tile 2g hi, lo, tile 2g+1 hi, lo
             if constexpr (rec % STAGE16 == 0) stage_fetch<rec / STAGE16 + NSTAGE16 - 1, NST>(ws);
-            const bf16x8 a0h = ws.a[0], a0l = ws.a[1], a1h = ws.a[2], a1l = ws.a[3];
+            const half8 a0h = ws.a[0], a0l = ws.a[1], a1h = ws.a[2], a1l = ws.a[3];
             read_group<rec + 4, NST>(ws, ws.a);
             __builtin_amdgcn_sched_barrier(0);
             static_for<3>([&](auto T) {
@@ -260,11 +268,13 @@ NTX_DEV void skip_stage(WShared &ws) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// WD = false (render kernel): the colour layer C1 starts from the per-ray vector `c1_row` (dirbias_kernel) and has no
+// WD = false (render kernel): the colour layer C1 starts from the per-ray vector (dirbias_kernel) that the caller has
+// staged in LDS at aux[c1_off .. c1_off + 256) ([half][128], accumulator order; reading it from global memory inside
+// the pass made hipcc park whole bias tiles in scratch, 30 GB per launch) and has no
 // direction segment; WD = true (instanced kernel, per-sample directions): static bias, direction segment evaluated.
 template <class CFG, bool WD = false>
-NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &ws, const float *aux_in, int lane,
-                            float &sigma, float (&rgb)[3], const float *c1_row) {
+NTX_DEV void mlp_batch_x3(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &ws, const float *aux_in, int lane,
+                            float &sigma, float (&rgb)[3], int c1_off) {
     using G16 = Cfg16<CFG, WD>;
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
     const int h = lane >> 5;
@@ -304,7 +314,7 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &w
                 constexpr int u = decltype(U)::value, q = decltype(Q)::value;
                 // tile T of the drained set is free once groups 2T and 2T+1 are converted (behind steps 2T-1 and 2T)
                 if constexpr (init_next && (u & 1) == 1 && q == 6) {
-                    if constexpr (next_is_c1) init_bias_tile_g<(u - 1) / 2>(prev, c1_row + h * 128);
+                    if constexpr (next_is_c1) init_bias_tile<(u - 1) / 2>(prev, aux + c1_off, 0, h);
                     else init_bias_tile<(u - 1) / 2>(prev, aux, li + 1, h);
                 }
             });
@@ -373,15 +383,15 @@ NTX_DEV void mlp_batch_bf16(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &w
     for (int c = 0; c < 3; ++c) rgb[c] += chk;
 }
 
-// the fused render kernel at bf16x3 precision.  Same per-ray work as render_kernel<CFG> around the MLP, but over the
+// the fused render kernel at fp16x3 precision.  Same per-ray work as render_kernel<CFG> around the MLP, but over the
 // compacted hit list and in workgroup lockstep: iteration `it` gives wave w of workgroup g the hit ray number
 // it * (4 * gridDim) + 4 g + w; waves past the end of the list go through the motions on the last hit ray and store nothing.
 template <class CFG>
-__global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs a) {
-    static_assert(CFG::IPE == 0, "bf16x3 is built for the FourierFeatures families");
+__global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
+    static_assert(CFG::IPE == 0, "fp16x3 is built for the FourierFeatures families");
     using G16 = Cfg16<CFG>;
     __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
-    __shared__ __attribute__((aligned(16))) float aux[aux_total()];
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * 256];   // + one per-ray C1 vector per wave
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -429,7 +439,12 @@ __global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs a) {
                 in.par[k] = p;
             }
             float sigma, raw[3];
-            mlp_batch_bf16<CFG>(in, ws, aux, lane, sigma, raw, CFG::CD != 0 ? q.ray_bias + r * 256 : nullptr);
+            if constexpr (CFG::CD != 0) {   // this ray's [2][128] vector: 64 lanes x 16 bytes, global -> LDS
+                reinterpret_cast<f32x4 *>(aux + aux_total() + wv * 256)[lane] = reinterpret_cast<const f32x4 *>(q.ray_bias + r * 256)[lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            mlp_batch_x3<CFG>(in, ws, aux, lane, sigma, raw, aux_total() + wv * 256);
             const RenderArgs *ap2 = kernargs<RenderArgs>();
             asm volatile("" : "+s"(ap2));
             composite_step<32>(ra, sigma, raw, dist, valid && live, ap2->flags, j,
@@ -452,15 +467,15 @@ __global__ __launch_bounds__(256) void render_kernel_bf16(RenderArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// InstanceRenderer tail at bf16x3 (instance_kernel<CFG> of ntx_device.h is the float32 one).  Rays cost a different
+// InstanceRenderer tail at fp16x3 (instance_kernel<CFG> of ntx_device.h is the float32 one).  Rays cost a different
 // number of 32-sample batches each, and the workgroup shares one weight stream in lockstep, so the workgroup proceeds in
 // ROUNDS of one batch per wave: a wave that has finished its ray takes the next unclaimed one (device work counter) and
 // compacts its in-patch samples before the round starts; a wave that finds none left keeps its place in the barriers
 // with idle batches until its three neighbours are done (at most one ray's worth at the very end).
 // ---------------------------------------------------------------------------------------------
 template <class CFG>
-__global__ __launch_bounds__(256) void instance_kernel_bf16(InstanceArgs a) {
-    static_assert(CFG::IPE == 0 && CFG::CD != 0, "bf16x3 instanced: ParamNerf with FourierFeatures");
+__global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
+    static_assert(CFG::IPE == 0 && CFG::CD != 0, "fp16x3 instanced: ParamNerf with FourierFeatures");
     using G16 = Cfg16<CFG, true>;
     __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
     __shared__ __attribute__((aligned(16))) float aux[aux_total()];
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(256) void instance_kernel_bf16(InstanceArgs a) {
             in.par[c] = p;
         }
         float sigma, raw[3];
-        mlp_batch_bf16<CFG, true>(in, ws, aux, lane, sigma, raw, nullptr);
+        mlp_batch_x3<CFG, true>(in, ws, aux, lane, sigma, raw, 0);
         if (live) {
             const float wgt = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // :300
             sigma = sigma * wgt;

@@ -146,11 +146,11 @@ NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth, i
     return g;
 }
 
-// ---- bf16x3 precision (ntx_device_bf16.h): the same network on v_mfma_f32_32x32x16_bf16 -----------------
+// ---- fp16x3 precision (ntx_device_x3.h): the same network on v_mfma_f32_32x32x16_f16 -----------------
 // One k16-step = 8 consecutive k2-steps of the maps above (element e of half h in step u = k2-step 8u+e), segments
-// padded with zero rows to whole k16-steps.  One record = 64 lanes x 8 bf16 (1 KiB) = the A operand of one
+// padded with zero rows to whole k16-steps.  One record = 64 lanes x 8 halves (1 KiB) = the A operand of one
 // (k16-step, M-tile); the stream holds, per k16-step and tile, the hi record then the lo record of the split
-// w = hi + lo (hi = bf16_rne(w), lo = bf16_rne(w - hi)).  Within a pass the hidden segment comes first, the encoder
+// w = hi + lo (hi = fp16_rne(w), lo = fp16_rne(w - hi), IEEE half with subnormals).  Within a pass the hidden segment comes first, the encoder
 // segment second; the direction segment of ParamNerf's colour layer C1 is NOT in the stream: it is a per-ray constant
 // and enters through the per-ray bias vector of dirbias_kernel (float32).  The 4 waves of a workgroup share the stream through an LDS ring of NSTAGE16 STAGES of STAGE16
 // records (one k16-step of an 8-tile layer); the stream is zero-padded to a whole number of ring turns, so the stage ->

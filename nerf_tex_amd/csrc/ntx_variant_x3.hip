@@ -1,8 +1,8 @@
-// ntx_variant_bf16.hip -- the fused render kernel of ONE model family at bf16x3 precision (ntx_device_bf16.h).
+// ntx_variant_x3.hip -- the fused render kernel of ONE model family at fp16x3 precision (ntx_device_x3.h).
 // Compiled once per FourierFeatures family with -DNTX_VARIANT=k (k as in kVariants[] of nerftex.hip).
 #include <hip/hip_runtime.h>
 
-#include "ntx_device_bf16.h"
+#include "ntx_device_x3.h"
 
 #ifndef NTX_VARIANT
 #error "compile with -DNTX_VARIANT=0..3"
@@ -24,14 +24,14 @@ using VCfg = Cfg<0, 0, 0>;   // plain Nerf
 #define NTX_FN(name) name##_v3
 #endif
 
-hipError_t NTX_FN(launch_render_bf16)(int n_wgs, RenderArgs &a, hipStream_t st) {
-    render_kernel_bf16<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
+hipError_t NTX_FN(launch_render_x3)(int n_wgs, RenderArgs &a, hipStream_t st) {
+    render_kernel_x3<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
     return hipGetLastError();
 }
 
 #if NTX_VARIANT != 3
-hipError_t NTX_FN(launch_instance_bf16)(int n_wgs, InstanceArgs &a, hipStream_t st) {
-    instance_kernel_bf16<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
+hipError_t NTX_FN(launch_instance_x3)(int n_wgs, InstanceArgs &a, hipStream_t st) {
+    instance_kernel_x3<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
     return hipGetLastError();
 }
 #endif

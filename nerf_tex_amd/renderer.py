@@ -36,7 +36,8 @@ class Renderer:
         self.map_exr = map_exr
         self.check_numerics = check_numerics     # tf.debugging.check_numerics, renderer.py:140-141
         # arithmetic of the Dense layers (include/nerftex.h: ntx_precision).  "float32" is what the reference computes in;
-        # "bf16x3" is an opt-in 3-term bf16 split on the bf16 matrix cores, inside the render tolerance but not bit-identical
+        # "fp16x3" is an opt-in 3-term split into IEEE halves on the 16-bit matrix cores: float32-grade (2.8e-6 from the float32
+        # kernel on the bench image) but not bit-identical, and limited to |activation| <= 65504
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
         self.precision = precision

@@ -1,4 +1,4 @@
-"""The opt-in bf16x3 precision of the fused render kernel (include/nerftex.h: ntx_precision) against the oracle.  `-m gpu`.
+"""The opt-in fp16x3 precision of the fused render kernel (include/nerftex.h: ntx_precision) against the oracle.  `-m gpu`.
 
 Same bar as the float32 kernel: rel-L-inf <= 1e-4 against the float64 restatement of the reference.  The float32
 kernel stays the default; these tests also bound the distance between the two precisions.
@@ -30,14 +30,14 @@ def _render(model, precision, S, ro, rd, t, params, cone, bk=False, blur_idx=Non
 
 @pytest.mark.parametrize("family,S", [("carpet", 64), ("carpet", 33), ("grass", 128), ("fur", 2), ("grass_filtered", 48)])
 @pytest.mark.parametrize("dense", [True, False])
-def test_bf16x3_render_rays_camera(family, S, dense):
+def test_fp16x3_render_rays_camera(family, S, dense):
     from nerf_tex_amd import synthetic
     fam = synthetic.FAMILIES[family]
     model, spec, w = make_model(fam["n_parameters"], dense_media=dense)
     h, wd = 24, 20
     (ro, rd, t, cone), _, _ = camera_rays(family, h, wd)
     params = np.asarray([fam["params"]], np.float32)
-    got = _render(model, "bf16x3", S, ro, rd, t, params, cone, bk=True, blur_idx=fam["blur_idx"])
+    got = _render(model, "fp16x3", S, ro, rd, t, params, cone, bk=True, blur_idx=fam["blur_idx"])
     f32 = _render(model, "float32", S, ro, rd, t, params, cone, bk=True, blur_idx=fam["blur_idx"])
     ref = orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], S, True, (1., 1., 1.),
                             fam["blur_idx"], False, dtype=np.float64)
@@ -51,22 +51,22 @@ def test_bf16x3_render_rays_camera(family, S, dense):
     assert not np.array_equal(got, f32) or S == 2      # it really is the other kernel
 
 
-def test_bf16x3_plain_nerf_and_exr():
+def test_fp16x3_plain_nerf_and_exr():
     from nerf_tex_amd import synthetic
     fam = synthetic.FAMILIES["carpet"]
     model, spec, w = make_model((0, 0), kind="Nerf", dense_media=True)
     n, S = 300, 64
     ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"])
     params = np.zeros((1, 0), np.float32)
-    got = _render(model, "bf16x3", S, ro, rd, t, params, cone, map_exr=True)
+    got = _render(model, "fp16x3", S, ro, rd, t, params, cone, map_exr=True)
     ref = orc.render_rays(w, spec, ro, rd, t, np.zeros((n, 0), np.float32), cone, S, False, (1, 1, 1.), map_exr=True,
                           dtype=np.float64)
     want = np.concatenate([ref["color_pred"], ref["alpha_pred"][:, None]], -1)
     assert orc.rel_linf(got, want) <= TOL
 
 
-def test_bf16x3_zvals_and_weights():
-    """caller-supplied depths and the per-sample compositing weights (hierarchical path) at bf16x3"""
+def test_fp16x3_zvals_and_weights():
+    """caller-supplied depths and the per-sample compositing weights (hierarchical path) at fp16x3"""
     from nerf_tex_amd import synthetic
     from nerf_tex_amd.renderer import Renderer
     fam = synthetic.FAMILIES["carpet"]
@@ -74,7 +74,7 @@ def test_bf16x3_zvals_and_weights():
     n, S, NI = 200, 32, 32
     ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"])
     params = np.asarray([fam["params"]], np.float32)
-    r = Renderer(model=model, n_samples=S, n_importance=NI, perturb=True, precision="bf16x3")
+    r = Renderer(model=model, n_samples=S, n_importance=NI, perturb=True, precision="fp16x3")
     z0 = orc.z_values(t, S, np.float32)
     out = r(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0],
             z_vals=to_dev(z0)[0])
@@ -94,7 +94,7 @@ def test_bf16x3_zvals_and_weights():
     assert orc.rel_linf(gotf, wantf) <= TOL
 
 
-def test_bf16x3_nan_propagates_and_unsupported_family():
+def test_fp16x3_nan_propagates_and_unsupported_family():
     from nerf_tex_amd import synthetic, _lib
     from nerf_tex_amd.renderer import Renderer, MipRenderer
     fam = synthetic.FAMILIES["carpet"]
@@ -103,7 +103,7 @@ def test_bf16x3_nan_propagates_and_unsupported_family():
     ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"])
     ro = ro.copy(); ro[5, 1] = np.nan
     params = np.asarray([fam["params"]], np.float32)
-    r = Renderer(model=model, n_samples=S, perturb=False, precision="bf16x3")
+    r = Renderer(model=model, n_samples=S, perturb=False, precision="fp16x3")
     out = r(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0])
     c = out["color_pred"][0].cpu().numpy()
     assert np.isnan(c[5]).all() and np.isfinite(np.delete(c, 5, 0)).all()
@@ -112,13 +112,13 @@ def test_bf16x3_nan_propagates_and_unsupported_family():
     with pytest.raises(ValueError):
         Renderer(model=model, precision="fp8")
     # a blur_idx on an appearance parameter is a per-sample scaling of a direction-side input: float32 only
-    rb = Renderer(model=model, n_samples=S, perturb=False, precision="bf16x3", blur_idx=4)
+    rb = Renderer(model=model, n_samples=S, perturb=False, precision="fp16x3", blur_idx=4)
     ro[5, 1] = 0.0
     with pytest.raises(_lib.NtxError) as e:
         rb(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0])
     assert e.value.code == _lib.NTX_E_UNSUPPORTED
     mip, _, _ = make_model((1, 3), kind="IPE")
-    mr = MipRenderer(model=mip, n_samples=S, perturb=False, blur_idx=2, precision="bf16x3")
+    mr = MipRenderer(model=mip, n_samples=S, perturb=False, blur_idx=2, precision="fp16x3")
     par = np.asarray([[0.5, 0.1, 0.3, 0.2, 0.7]], np.float32)
     ro[5, 1] = 0.0
     with pytest.raises(_lib.NtxError) as e:
@@ -126,8 +126,8 @@ def test_bf16x3_nan_propagates_and_unsupported_family():
     assert e.value.code == _lib.NTX_E_UNSUPPORTED
 
 
-def test_bf16x3_full_size_is_split_invariant():
-    """BASELINE config 1 size at bf16x3: the lockstep kernel hands rays to waves through a compacted list whose order
+def test_fp16x3_full_size_is_split_invariant():
+    """BASELINE config 1 size at fp16x3: the lockstep kernel hands rays to waves through a compacted list whose order
     depends on the launch, yet each ray's result depends only on the ray -- bit-identical however the rays are split
     across calls (what sharding across GPUs relies on), alpha in [0,1], premultiplied colours below alpha."""
     from nerf_tex_amd import synthetic
@@ -138,7 +138,7 @@ def test_bf16x3_full_size_is_split_invariant():
     ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"])
     t = t.copy(); t[::7] = np.inf                      # every 7th ray culled: the hit list is a real compaction
     params = to_dev(np.asarray([fam["params"]], np.float32))[0]
-    r = Renderer(model=model, n_samples=S, perturb=False, precision="bf16x3")
+    r = Renderer(model=model, n_samples=S, perturb=False, precision="fp16x3")
     dro, drd, dt, dcone = to_dev(ro, rd, t, cone)
     full = r(dro[None], drd[None], dt[None], parameters=params, cone_scale=dcone[None])
     c, a = full["color_pred"][0], full["alpha_pred"][0]

@@ -10,11 +10,10 @@ from tests.common import TOL, make_model
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-# The opt-in bf16x3 precision carries ~1e-5 of relative error in the raw density; the instanced path multiplies the density
-# by density_scale * alpha_weight (400 here) and by dists / patch_scale before the exponential (renderer.py:300, 339), and
-# the dense-media test weights scale the alpha head by another 32: measured 1.1e-4 on these cases against 4e-6 for the
-# float32 kernel.  Float32 is gated at the north-star 1e-4; bf16x3 on this path at 3e-4, stated here.
-TOL_BF16X3_INSTANCED = 3e-4
+# The instanced path multiplies the raw density by density_scale * alpha_weight (400 here) and by dists / patch_scale before
+# the exponential (renderer.py:300, 339), which amplifies whatever error the density carries; the fp16x3 split is accurate
+# enough (2^-22 per product) to stay inside the same 1e-4 gate as float32.
+TOL_FP16X3_INSTANCED = 1e-4
 
 
 class FakeInstancer:
@@ -56,7 +55,7 @@ class FakeInstancer:
 @pytest.mark.parametrize("S", [40, 200])
 @pytest.mark.parametrize("opts", [dict(), dict(composite_bkgd=True, map_exr=True), dict(density_reweighting=False, density_scale=30.0),
                                   dict(false_color=True)])
-@pytest.mark.parametrize("precision", ["float32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["float32", "fp16x3"])
 def test_instance_renderer(npar, blur, S, opts, precision):
     from nerf_tex_amd.renderer import InstanceRenderer
     opts = dict(opts, precision=precision)
@@ -89,14 +88,14 @@ def test_instance_renderer(npar, blur, S, opts, precision):
         want_c[~keep] = (.3, .6, .9)                                  # renderer.py:85-86: only proxy-culled rays
     got = np.concatenate([out["color_pred"][0].cpu().numpy(), out["alpha_pred"][0].cpu().numpy()[:, None]], -1)
     want = np.concatenate([want_c, want_a[:, None]], -1)
-    assert orc.rel_linf(got, want) <= (TOL if precision == "float32" else TOL_BF16X3_INSTANCED)
+    assert orc.rel_linf(got, want) <= (TOL if precision == "float32" else TOL_FP16X3_INSTANCED)
     kept = np.nonzero(keep)[0]
     assert np.all(got[kept[~hit]] == 0.0)                             # un-hit rays stay 0, even with background (:313-314)
     assert float(want_a.max()) > 0.3
 
 
-def test_instance_renderer_bf16x3_many_rays_lockstep():
-    """More rays than waves and very uneven rays (0 .. 300 in-patch samples): the bf16x3 instanced kernel runs its four
+def test_instance_renderer_fp16x3_many_rays_lockstep():
+    """More rays than waves and very uneven rays (0 .. 300 in-patch samples): the fp16x3 instanced kernel runs its four
     waves per workgroup in lockstep rounds while each wave marches its own ray; result = the float32 kernel's within
     the tolerance, un-hit and sample-less rays included."""
     from nerf_tex_amd.renderer import InstanceRenderer
@@ -122,14 +121,14 @@ def test_instance_renderer_bf16x3_many_rays_lockstep():
     dv = torch.device("cuda", 0)
     d = lambda a: torch.as_tensor(a, device=dv)
     res = {}
-    for prec in ("float32", "bf16x3"):
+    for prec in ("float32", "fp16x3"):
         inst = Uneven(7, seed=11, p_in=0.9)
         r = InstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=0.09, step_size=0.002, density_scale=400.0,
                              render_chunk=100_000, precision=prec)
         out = r(d(ro), d(rd), d(t), parameters=d(params), cone_scale=d(cone))
         r.raise_if_nonfinite()
         res[prec] = np.concatenate([out["color_pred"][0].cpu().numpy(), out["alpha_pred"][0].cpu().numpy()[:, None]], -1)
-    assert orc.rel_linf(res["bf16x3"], res["float32"]) <= TOL_BF16X3_INSTANCED
-    assert not np.array_equal(res["bf16x3"], res["float32"])
+    assert orc.rel_linf(res["fp16x3"], res["float32"]) <= TOL_FP16X3_INSTANCED
+    assert not np.array_equal(res["fp16x3"], res["float32"])
     hit = inst.last[-1]
-    assert np.all(res["bf16x3"][~hit] == 0.0)
+    assert np.all(res["fp16x3"][~hit] == 0.0)

@@ -70,43 +70,42 @@ def test_pack_weights_is_a_permutation_with_wraparound_tail(desc, count):
     assert _lib.lib.ntx_pack_weights(C.byref(d), blob.ctypes.data_as(fp), n - 1, out.ctypes.data_as(fp), npk) == _lib.NTX_E_INVALID
 
 
-def test_pack_weights_bf16x3_splits_every_weight_once():
-    """Host-only packer of the bf16x3 stream: each matrix weight appears exactly once as a (hi, lo) bf16 pair with
-    hi = bf16(w) and hi + lo within 2^-16 |w| of w; the stream is a whole number of LDS ring turns (64 records);
-    IPE families are refused."""
+def test_pack_weights_fp16x3_splits_every_weight_once():
+    """Host-only packer of the fp16x3 stream: each matrix weight appears exactly once as a (hi, lo) pair of IEEE halves with
+    hi = float16(w) and lo = float16(w - hi) exactly as numpy rounds them (round to nearest even, subnormals kept, tiny and
+    huge weights included); the stream is a whole number of LDS ring turns (64 records); IPE families are refused."""
     from nerf_tex_amd import _lib
     d = _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, 0)
     n = _lib.lib.ntx_weight_count(C.byref(d))
-    nb = _lib.lib.ntx_packed_bf16x3_bytes(C.byref(d))
+    nb = _lib.lib.ntx_packed_fp16x3_bytes(C.byref(d))
     assert nb % 1024 == 0 and (nb // 1024) % 64 == 0
     rng = np.random.default_rng(1)
-    blob = rng.uniform(0.5, 1.0, size=n).astype(np.float32) * rng.choice([-1.0, 1.0], size=n).astype(np.float32)
+    mag = np.exp2(rng.uniform(-30, 4, size=n))                  # spans half subnormals (lo parts well below 2^-24 too)
+    blob = (mag * rng.choice([-1.0, 1.0], size=n)).astype(np.float32)
+    blob[:8] = [65504.0, -65504.0, 65519.0, 65520.0, 1e9, 2.0 ** -14, 2.0 ** -24, 2.0 ** -25]   # L0 kernel, first rows
     out = np.zeros(nb // 2, np.uint16)
     fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint16)
-    assert _lib.lib.ntx_pack_weights_bf16x3(C.byref(d), blob.ctypes.data_as(fp), n, out.ctypes.data_as(up), nb) == 0
-    rec = out.reshape(-1, 512)
-    body = rec.reshape(-1, 2, 512)                          # (hi record, lo record) per (k16-step, tile)
-    hi = (body[:, 0].astype(np.uint32) << 16).view(np.float32)
-    lo = (body[:, 1].astype(np.uint32) << 16).view(np.float32)
-    used = hi != 0
-    # matrix weights only (biases and the two heads live in the float32 aux block): 256-wide layers + C2
-    # (the 81 direction rows of C1 are not in this stream: they are applied per ray in float32 by dirbias_kernel)
-    n_matrix = 72 * 256 + 4 * 256 * 256 + 328 * 256 + 2 * 256 * 256 + 256 * 256 + 256 * 256 + 256 * 128
-    assert int(used.sum()) == n_matrix
-    recon = np.sort(np.abs((hi[used].astype(np.float64) + lo[used].astype(np.float64))))
-    # the blob also holds biases / head weights, so compare against the multiset of matrix weights via the sum
-    assert np.all(np.abs(lo[used]) <= np.abs(hi[used]) * 2.0 ** -8)
+    assert _lib.lib.ntx_pack_weights_fp16x3(C.byref(d), blob.ctypes.data_as(fp), n, out.ctypes.data_as(up), nb) == 0
+    body = out.reshape(-1, 2, 512)                               # (hi record, lo record) per (k16-step, tile)
+    hi, lo = body[:, 0].ravel(), body[:, 1].ravel()
+    # the float32 packer puts the same weights in a stream of its own: every (hi, lo) must be the numpy split of one of them
     f32pk = np.empty(_lib.lib.ntx_packed_count(C.byref(d)), np.float32)
     assert _lib.lib.ntx_pack_weights(C.byref(d), blob.ctypes.data_as(fp), n, f32pk.ctypes.data_as(fp), f32pk.size) == 0
     stream = f32pk[:f32pk.size - 3776 - 8 * 256]
-    want = np.sort(np.abs(stream[stream != 0]).astype(np.float64))
-    assert want.size == n_matrix + 81 * 256
-    # every reconstructed weight is one of the float32 stream's weights
-    idx = np.clip(np.searchsorted(want, recon), 1, want.size - 1)
-    near = np.minimum(np.abs(want[idx] - recon), np.abs(want[idx - 1] - recon))
-    assert np.max(near / recon) <= 2.0 ** -16
+    w = stream[stream != 0]
+    with np.errstate(over="ignore", invalid="ignore"):
+        wh = w.astype(np.float16)
+        wl = (w - wh.astype(np.float32)).astype(np.float16)
+    want = set(zip(wh.view(np.uint16).tolist(), wl.view(np.uint16).tolist()))
+    used = (hi != 0) | (lo != 0)
+    got = set(zip(hi[used].tolist(), lo[used].tolist()))
+    assert got <= want
+    # (the 81 direction rows of C1 are not in this stream: they are applied per ray in float32 by dirbias_kernel)
+    n_matrix = 72 * 256 + 4 * 256 * 256 + 328 * 256 + 2 * 256 * 256 + 256 * 256 + 256 * 256 + 256 * 128
+    underflow = int(np.sum((wh.view(np.uint16) & 0x7fff) == 0))          # |w| < 2^-25 rounds to (0, 0): not counted as used
+    assert n_matrix - underflow - 300 <= int(used.sum()) <= n_matrix
     mip = _lib.ModelDesc(0, 1, 3, 6, 10, 4, 4, 8, 256, 4, 1, 1)
-    assert _lib.lib.ntx_packed_bf16x3_bytes(C.byref(mip)) == 0 and b"FourierFeatures" in _lib.lib.ntx_last_error()
+    assert _lib.lib.ntx_packed_fp16x3_bytes(C.byref(mip)) == 0 and b"FourierFeatures" in _lib.lib.ntx_last_error()
 
 
 def test_instantiate_and_reference_config_remap():

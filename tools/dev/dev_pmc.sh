@@ -10,6 +10,6 @@ O=os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/pmc_dev"
 for f in sorted(glob.glob(O+"/*/*counter_collection.csv")):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if ("render_kernel_bf16<" if os.environ.get("PREC") == "bf16x3" else "render_kernel<") in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if ("render_kernel_x3<" if os.environ.get("PREC") == "fp16x3" else "render_kernel<") in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in sorted(agg.items()): print("PMC %-28s %.5g"%(k,sum(v)/len(v)))
 PY

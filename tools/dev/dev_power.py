@@ -1,4 +1,4 @@
-"""dev helper (GPU box): is the bf16x3 kernel's time data-dependent (power throttling)?  Times the carpet bench launch
+"""dev helper (GPU box): is the fp16x3 kernel's time data-dependent (power throttling)?  Times the carpet bench launch
 with the seeded glorot weights, with all-zero weights, and with constant weights."""
 import sys, os
 import numpy as np, torch
@@ -15,7 +15,7 @@ ro, rd, t, cone = synthetic.all_hit_rays(n_rays, fam["b_0"], fam["b_1"], fam["ca
 d = lambda a: torch.as_tensor(a, device=dev)[None]
 batch = dict(rays_o=d(ro), rays_d=d(rd), t=d(t), cone_scale=d(cone),
              parameters=torch.as_tensor(np.asarray([fam["params"]], np.float32), device=dev))
-for prec in sys.argv[1:] or ["bf16x3", "float32"]:
+for prec in sys.argv[1:] or ["fp16x3", "float32"]:
     for name in ("glorot", "zero", "const"):
         model = ParamNerf(emb(10), emb(4), emb(4), list(fam["n_parameters"]))["model"]
         blob = synthetic.synthetic_weights(model.layer_table(), seed=0)

@@ -10,8 +10,11 @@ def bf16(x):  # round-to-nearest-even to bfloat16, returned as float32
     u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
     r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
     return r.astype(np.uint32).view(np.float32)
+def fp16(x):  # round-to-nearest-even to IEEE half (subnormals kept, as v_mfma_f32_32x32x16_f16 does on gfx950), as float32
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+FMT = bf16
 def split(x):
-    hi = bf16(x); lo = bf16((x - hi).astype(np.float32)); return hi, lo
+    hi = FMT(x); lo = FMT((x - hi).astype(np.float32)); return hi, lo
 def dense3(x, W, b, relu, terms=3):
     xh, xl = split(x); Wh, Wl = split(W)
     y = xh @ Wh
@@ -37,6 +40,9 @@ def model3(w, spec, pos, dirs, params, terms):
     return color, alpha
 g=np.load("tests/golden/golden_plumbing.npz")
 spec=orc.ModelSpec(n_parameters=(1,6))
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == "fp16":
+    FMT = fp16
 for dense in (True, False):
     blob=synthetic.synthetic_weights(orc.layer_table(spec),seed=0,dense_media=dense); w=orc.split_blob(spec,blob)
     H=W=200;S=32; rows=slice(90*W,110*W)

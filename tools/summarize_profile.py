@@ -8,7 +8,7 @@ per-launch means for the render kernel, with the derived quantities DESIGN.md qu
 import collections, csv, glob, json, os, shutil, sys
 
 prefix, rnd, name = sys.argv[1:4]
-KERNEL = sys.argv[4] if len(sys.argv) > 4 else "render_kernel<"   # "render_kernel_bf16<" for the bf16x3 precision
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "render_kernel<"   # "render_kernel_x3<" for the fp16x3 precision
 O, P = "gpurun_out", os.path.join("profiles", rnd)
 os.makedirs(P, exist_ok=True)
 shutil.copy(glob.glob(f"{O}/{prefix}_kt/*kernel_stats.csv")[0], f"{P}/{name}_kernel_stats.csv")
@@ -30,7 +30,7 @@ n_simd = 256 * 4
 derived = {
     "kernel_avg_ms_kernel_trace": avg_s * 1e3,
     "shader_clock_GHz": g("GRBM_GUI_ACTIVE") / 8 / avg_s / 1e9 if "GRBM_GUI_ACTIVE" in summ else None,
-    # SQ_VALU_MFMA_BUSY_CYCLES counts 64 cycles per v_mfma_f32_32x32x2_f32 (32 per v_mfma_f32_32x32x16_bf16), summed over SIMDs
+    # SQ_VALU_MFMA_BUSY_CYCLES counts 64 cycles per v_mfma_f32_32x32x2_f32 (32 per v_mfma_f32_32x32x16_f16), summed over SIMDs
     "mfma_util": g("SQ_VALU_MFMA_BUSY_CYCLES") / (n_simd * g("GRBM_GUI_ACTIVE") / 8) if "GRBM_GUI_ACTIVE" in summ else None,
     "frac_wave_cycles_in_s_waitcnt": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES") if "SQ_WAIT_ANY" in summ else None,
     # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 reports half the bytes of wide coalesced reads (x2, MI355X_MICROARCH.md)
