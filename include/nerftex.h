@@ -68,7 +68,7 @@ typedef struct ntx_model_desc {
 #define NTX_FLAG_COMPOSITE_BKGD 2u  /* renderer.py:210-211 and 85-86: add (1-A)*bkgd; culled rays = bkgd */
 #define NTX_FLAG_CHECK_NUMERICS 4u  /* renderer.py:140-141: set *status_flag |= 1 on NaN/Inf outputs */
 
-/* Arithmetic of the Dense layers inside ntx_render_rays and ntx_render_instanced (everything else -- encoders, heads,
+/* Arithmetic of the Dense layers inside ntx_render_rays, ntx_render_instanced and ntx_mlp_forward (everything else -- encoders, heads,
  * compositing -- is float32 either way).  The reference computes in float32 (TensorFlow's default dtype, model.py:104-123):
  *   NTX_PRECISION_F32    float32 matrix cores (v_mfma_f32_32x32x2_f32), the default; 1.7e-6 from the float32 reference.
  *   NTX_PRECISION_FP16X3 opt-in: weights and activations split as v = hi + lo (two IEEE halves, round to nearest even,
@@ -78,7 +78,7 @@ typedef struct ntx_model_desc {
  *                        ~2^-22 relative per product: 2.8e-6 from the float32 kernel on the bench image, ~2.8x faster.  Not
  *                        bit-identical to NTX_PRECISION_F32.  Range: |activation| and |weight| <= 65504, beyond that the
  *                        sample becomes inf/NaN (reported through NTX_FLAG_CHECK_NUMERICS).  FourierFeatures families
- *                        only (ntx_render_instanced: ParamNerf only); ntx_mlp_forward always computes in float32. */
+ *                        only (ntx_render_instanced: ParamNerf only). */
 typedef enum ntx_precision { NTX_PRECISION_F32 = 0, NTX_PRECISION_FP16X3 = 1 } ntx_precision;
 
 int ntx_abi_version(void);
@@ -180,7 +180,7 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
 int ntx_image_epilogue(const float *rgba, int height, int width, int downsampling_factor, int unpremultiply,
                        float *out_f32, uint8_t *out_u8, ntx_stream stream);
 
-/* Selects the arithmetic of subsequent ntx_render_rays / ntx_render_instanced calls on `ctx` (see ntx_precision).  NTX_E_UNSUPPORTED for a
+/* Selects the arithmetic of subsequent ntx_render_rays / ntx_render_instanced / ntx_mlp_forward calls on `ctx` (see ntx_precision).  NTX_E_UNSUPPORTED for a
  * model family without a fp16x3 kernel; the setting is per context and not thread-safe against concurrent launches. */
 int ntx_set_precision(ntx_ctx *ctx, int precision);
 

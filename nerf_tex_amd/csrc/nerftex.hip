@@ -320,6 +320,10 @@ hipError_t launch_render_x3_v0(int n_wgs, RenderArgs &a, hipStream_t st);
 hipError_t launch_render_x3_v1(int n_wgs, RenderArgs &a, hipStream_t st);
 hipError_t launch_render_x3_v2(int n_wgs, RenderArgs &a, hipStream_t st);
 hipError_t launch_render_x3_v3(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_mlp_x3_v0(int n_wgs, MlpArgs &a, hipStream_t st);
+hipError_t launch_mlp_x3_v1(int n_wgs, MlpArgs &a, hipStream_t st);
+hipError_t launch_mlp_x3_v2(int n_wgs, MlpArgs &a, hipStream_t st);
+hipError_t launch_mlp_x3_v3(int n_wgs, MlpArgs &a, hipStream_t st);
 hipError_t launch_instance_x3_v0(int n_wgs, InstanceArgs &a, hipStream_t st);
 hipError_t launch_instance_x3_v1(int n_wgs, InstanceArgs &a, hipStream_t st);
 hipError_t launch_instance_x3_v2(int n_wgs, InstanceArgs &a, hipStream_t st);
@@ -345,6 +349,17 @@ static hipError_t launch_render(const ntx_ctx *c, RenderArgs &a, hipStream_t st)
         case 2: return launch_render_v2(c->n_wgs, a, st);
         case 3: return launch_render_v3(c->n_wgs, a, st);
         case 4: return launch_render_v4(c->n_wgs, a, st);
+#endif
+        default: return hipErrorNotSupported;
+    }
+}
+static hipError_t launch_mlp_x3(const ntx_ctx *c, MlpArgs &a, hipStream_t st) {
+    switch (c->variant) {
+        case 0: return launch_mlp_x3_v0(c->n_wgs, a, st);
+#ifndef NTX_DEV_ONLY_CARPET
+        case 1: return launch_mlp_x3_v1(c->n_wgs, a, st);
+        case 2: return launch_mlp_x3_v2(c->n_wgs, a, st);
+        case 3: return launch_mlp_x3_v3(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -634,6 +649,17 @@ int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const flo
     a.pos = pos; a.dirs = dirs; a.params = params;
     a.color_out = color_out; a.sigma_out = sigma_out;
     a.m = m;
+    if (ctx->precision == NTX_PRECISION_FP16X3) {
+        // directions are per sample: ParamNerf uses the stream that keeps C1's direction segment; plain Nerf's one stream
+        // has it in C2 anyway
+        const uint16_t *s16 = v.cd ? ctx->packed16i : ctx->packed16;
+        const size_t b16 = v.cd ? ctx->packed16i_bytes : ctx->packed16_bytes;
+        if (!s16) return fail(NTX_E_UNSUPPORTED, "fp16x3 precision is built for the FourierFeatures families only");
+        a.wstream = reinterpret_cast<const f32x4 *>(s16);
+        a.stream_bytes = (uint32_t)b16;
+        HIP_TRY(launch_mlp_x3(ctx, a, (hipStream_t)stream));
+        return NTX_OK;
+    }
     HIP_TRY(launch_mlp(ctx, a, (hipStream_t)stream));
     return NTX_OK;
 }

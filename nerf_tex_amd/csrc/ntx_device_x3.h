@@ -583,4 +583,47 @@ __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// stand-alone MLP at fp16x3 (mlp_kernel<CFG> of ntx_device.h is the float32 one): samples are independent, 32 per wave;
+// the workgroup's four waves take batches 4i .. 4i+3 of each round, waves past the end run an idle batch to keep their
+// place in the stream's barriers.  Directions are per sample: the stream that keeps C1's direction segment.
+// ---------------------------------------------------------------------------------------------
+template <class CFG>
+__global__ __launch_bounds__(256) void mlp_kernel_x3(MlpArgs a) {
+    static_assert(CFG::IPE == 0, "fp16x3 is built for the FourierFeatures families");
+    using G16 = Cfg16<CFG, true>;
+    __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
+    __shared__ __attribute__((aligned(16))) float aux[aux_total()];
+    load_aux(aux, a.aux, aux_total());
+    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nbatch = (a.m + 31) >> 5;
+    const int64_t per_it = (int64_t)gridDim.x * 4;
+    const int64_t iters = (nbatch + per_it - 1) / per_it;
+    if (iters == 0) return;
+    WShared ws;
+    ws_prime<G16::NST>(ws, a.wstream, a.stream_bytes, (lds_char *)ring, lane, wv);
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t b = it * per_it + (int64_t)blockIdx.x * 4 + wv;
+        const int64_t m = b * 32 + j;
+        const bool valid = b < nbatch && m < a.m;
+        const int64_t mc = valid ? m : a.m - 1;
+        SampleIn<CFG::NGEO, CFG::NAPP> in;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            in.pos[k] = a.pos[3 * mc + k];
+            in.cov[k] = 0.0f;
+            in.dir[k] = a.dirs[3 * mc + k];
+        }
+#pragma unroll
+        for (int k = 0; k < CFG::NP; ++k) in.par[k] = a.params[CFG::NP * mc + k];
+        float sigma, raw[3];
+        mlp_batch_x3<CFG, true>(in, ws, aux, lane, sigma, raw, 0);
+        if (valid && lane < 32) {
+            a.color_out[3 * m + 0] = raw[0]; a.color_out[3 * m + 1] = raw[1]; a.color_out[3 * m + 2] = raw[2];
+            a.sigma_out[m] = sigma;
+        }
+    }
+}
+
 }  // namespace ntx

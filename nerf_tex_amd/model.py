@@ -165,6 +165,8 @@ class NerfModel:
         dev = pos.device
         color = torch.empty((m, 3), device=dev, dtype=torch.float32)
         alpha = torch.empty((m, 1), device=dev, dtype=torch.float32)
+        # `self.precision` ("float32" default, or "fp16x3"): arithmetic of the Dense layers for direct calls of the model
+        _lib.check(_lib.lib.ntx_set_precision(self.ctx(dev.index or 0), _lib.PRECISIONS[getattr(self, "precision", "float32")]))
         _lib.check(_lib.lib.ntx_mlp_forward(self.ctx(dev.index or 0), pos.data_ptr(), dirs.data_ptr(),
                                             params.data_ptr() if self.n_params > 0 else None, m,
                                             color.data_ptr(), alpha.data_ptr(),

@@ -157,3 +157,23 @@ def test_fp16x3_full_size_is_split_invariant():
     got = np.concatenate([c[idx].cpu().numpy(), a[idx].cpu().numpy()[:, None]], -1)
     want = np.concatenate([ref["color_pred"], ref["alpha_pred"][:, None]], -1)
     assert orc.rel_linf(got, want) <= TOL
+
+
+@pytest.mark.parametrize("kind,npar", [("ParamNerf", (1, 6)), ("ParamNerf", (2, 3)), ("Nerf", (0, 0))])
+@pytest.mark.parametrize("m", [1, 33, 4096 * 3 + 5])
+def test_fp16x3_mlp_forward(kind, npar, m):
+    """model((pos, dirs, params)) alone at fp16x3 (the lockstep stand-alone MLP kernel): raw colour and density against the
+    float64 restatement at the float32 kernel's own gate."""
+    from tests.common import random_samples
+    model, spec, w = make_model(npar, kind=kind)
+    model.precision = "fp16x3"
+    pos, dirs, params = random_samples(m, sum(npar))
+    c, a = model(tuple(to_dev(pos, dirs, params)))
+    rc, ra = orc.model_forward(w, spec, pos, dirs, params, dtype=np.float64)
+    got = np.concatenate([c.cpu().numpy(), a.cpu().numpy().reshape(m, 1)], -1)
+    want = np.concatenate([rc, np.asarray(ra).reshape(m, 1)], -1)
+    assert orc.rel_linf(got, want) <= 2e-5
+    model.precision = "float32"
+    c32, a32 = model(tuple(to_dev(pos, dirs, params)))
+    got32 = np.concatenate([c32.cpu().numpy(), a32.cpu().numpy().reshape(m, 1)], -1)
+    assert orc.rel_linf(got, got32) <= 5e-6 and (m < 33 or not np.array_equal(got, got32))
