@@ -1,8 +1,9 @@
-"""Numerical emulation (numpy) of a 3-term bf16 split of the Dense layers -- hi*hi + hi*lo + lo*hi with float32
-accumulation -- against the float32 and float64 oracles on BASELINE configs[0].  Evidence for DESIGN.md section 4.1:
-   dense-media weights: 1 term 1.2e-2, 3 terms 2.7e-5, 4 terms 1.9e-5 rel-Linf vs the float32 restatement (gate 1e-4)
-   glorot weights:      1 term 4.5e-3, 3 terms 8.5e-6
-Run from the repo root: PYTHONPATH=. python tools/emulate_bf16_split.py  (imports oracle/: test infrastructure)."""
+"""Numerical emulation (numpy) of a 3-term split of the Dense layers into 16-bit halves -- hi*hi + hi*lo + lo*hi with
+float32 accumulation -- against the float32 and float64 oracles on BASELINE configs[0].  Evidence for DESIGN.md section 4.1b
+(rel-Linf vs the float32 restatement, gate 1e-4):
+   bfloat16 halves (default):  dense-media weights 1 term 1.2e-2, 3 terms 2.7e-5, 4 terms 1.9e-5;  glorot 3 terms 8.5e-6
+   IEEE halves (argument fp16): dense-media weights 1 term 2.0e-3, 3 terms 2.5e-6, 4 terms 2.4e-6;  glorot 3 terms 2.5e-6
+Run from the repo root: PYTHONPATH=. python tools/emulate_bf16_split.py [fp16]  (imports oracle/: test infrastructure)."""
 import numpy as np, time
 from oracle import nerftex_oracle as orc
 from nerf_tex_amd import synthetic
