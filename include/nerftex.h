@@ -77,8 +77,8 @@ typedef struct ntx_model_desc {
  *                        product of two halves is exact in float32, so only the lo*lo term and the rounding of lo are lost,
  *                        ~2^-22 relative per product: 2.8e-6 from the float32 kernel on the bench image, ~2.8x faster.  Not
  *                        bit-identical to NTX_PRECISION_F32.  Range: |activation| and |weight| <= 65504, beyond that the
- *                        sample becomes inf/NaN (reported through NTX_FLAG_CHECK_NUMERICS).  FourierFeatures families
- *                        only (ntx_render_instanced: ParamNerf only). */
+ *                        sample becomes inf/NaN (reported through NTX_FLAG_CHECK_NUMERICS).  Every family and all three
+ *                        entry points (ntx_render_instanced: the ParamNerf families, as at float32). */
 typedef enum ntx_precision { NTX_PRECISION_F32 = 0, NTX_PRECISION_FP16X3 = 1 } ntx_precision;
 
 int ntx_abi_version(void);

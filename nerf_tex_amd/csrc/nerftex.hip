@@ -240,17 +240,17 @@ static void emit_segment16(uint16_t *&dst, const Layer &l, int nsteps16, int nmt
 }
 
 static size_t packed16_bytes(const Variant &v, int with_dir = 0) {
-    return (size_t)stream16_padded(v.n_geo, v.n_app, v.cd, with_dir) * 1024;
+    return (size_t)stream16_padded(v.n_geo, v.n_app, v.cd, with_dir, v.ipe) * 1024;
 }
 
 // hidden segment first, encoder segment second within a pass (ntx_device_x3.h: Cfg16)
 // with_dir: the instanced kernel's stream, where C1 keeps its direction segment (directions are per sample there)
 static void pack16(const Variant &v, const float *blob, uint16_t *out, int with_dir = 0) {
     const Net n = view_blob(v, blob);
-    const int pm = pos_map_dim(v.n_geo, 0), dm = dir_map_dim(v.n_app);
-    const int ps = steps16(pos_steps(v.n_geo, 0)), ds = steps16(dir_steps(v.n_app)), hs = HSTEPS / 8;
+    const int pm = pos_map_dim(v.n_geo, v.ipe), dm = dir_map_dim(v.n_app);
+    const int ps = steps16(pos_steps(v.n_geo, v.ipe)), ds = steps16(dir_steps(v.n_app)), hs = HSTEPS / 8;
     uint16_t *dst = out;
-    auto posrow = [&](int s, int h) { return s < pos_steps(v.n_geo, 0) ? pos_row(v.n_geo, s, h, 0) : -1; };
+    auto posrow = [&](int s, int h) { return s < pos_steps(v.n_geo, v.ipe) ? pos_row(v.n_geo, s, h, v.ipe) : -1; };
     auto dirrow = [&](int s, int h) { return s < dir_steps(v.n_app) ? dir_row(v.n_app, s, h) : -1; };
     auto hidrow = [&](int s, int h) { return hidden_row(s, h); };
     emit_segment16(dst, n.trunk[0], ps, 8, 0, posrow);
@@ -271,7 +271,7 @@ static void pack16(const Variant &v, const float *blob, uint16_t *out, int with_
         emit_segment16(dst, n.c2, hs, 4, dm, hidrow);
         emit_segment16(dst, n.c2, ds, 4, 0, dirrow);
     }
-    const int rec = stream16_records(v.n_geo, v.n_app, v.cd, with_dir), pad = stream16_padded(v.n_geo, v.n_app, v.cd, with_dir);
+    const int rec = stream16_records(v.n_geo, v.n_app, v.cd, with_dir, v.ipe), pad = stream16_padded(v.n_geo, v.n_app, v.cd, with_dir, v.ipe);
     memset(dst, 0, (size_t)(pad - rec) * 1024);
 }
 
@@ -320,6 +320,9 @@ hipError_t launch_render_x3_v0(int n_wgs, RenderArgs &a, hipStream_t st);
 hipError_t launch_render_x3_v1(int n_wgs, RenderArgs &a, hipStream_t st);
 hipError_t launch_render_x3_v2(int n_wgs, RenderArgs &a, hipStream_t st);
 hipError_t launch_render_x3_v3(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_render_x3_v4(int n_wgs, RenderArgs &a, hipStream_t st);
+hipError_t launch_mlp_x3_v4(int n_wgs, MlpArgs &a, hipStream_t st);
+hipError_t launch_instance_x3_v4(int n_wgs, InstanceArgs &a, hipStream_t st);
 hipError_t launch_mlp_x3_v0(int n_wgs, MlpArgs &a, hipStream_t st);
 hipError_t launch_mlp_x3_v1(int n_wgs, MlpArgs &a, hipStream_t st);
 hipError_t launch_mlp_x3_v2(int n_wgs, MlpArgs &a, hipStream_t st);
@@ -336,6 +339,7 @@ static hipError_t launch_render_x3(const ntx_ctx *c, RenderArgs &a, hipStream_t 
         case 1: return launch_render_x3_v1(c->n_wgs, a, st);
         case 2: return launch_render_x3_v2(c->n_wgs, a, st);
         case 3: return launch_render_x3_v3(c->n_wgs, a, st);
+        case 4: return launch_render_x3_v4(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -360,6 +364,7 @@ static hipError_t launch_mlp_x3(const ntx_ctx *c, MlpArgs &a, hipStream_t st) {
         case 1: return launch_mlp_x3_v1(c->n_wgs, a, st);
         case 2: return launch_mlp_x3_v2(c->n_wgs, a, st);
         case 3: return launch_mlp_x3_v3(c->n_wgs, a, st);
+        case 4: return launch_mlp_x3_v4(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -370,6 +375,7 @@ static hipError_t launch_instance_x3(const ntx_ctx *c, InstanceArgs &a, hipStrea
 #ifndef NTX_DEV_ONLY_CARPET
         case 1: return launch_instance_x3_v1(c->n_wgs, a, st);
         case 2: return launch_instance_x3_v2(c->n_wgs, a, st);
+        case 4: return launch_instance_x3_v4(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
     }
@@ -458,7 +464,6 @@ int ntx_pack_weights(const ntx_model_desc *desc, const float *weights_host, size
 size_t ntx_packed_fp16x3_bytes(const ntx_model_desc *desc) {
     const int v = find_variant(desc);
     if (v < 0) { unsupported(desc); return 0; }
-    if (kVariants[v].ipe) { fail(NTX_E_UNSUPPORTED, "fp16x3 precision is built for the FourierFeatures families only"); return 0; }
     return packed16_bytes(kVariants[v]);
 }
 
@@ -466,7 +471,6 @@ int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_hos
                             size_t n_bytes) {
     const int v = find_variant(desc);
     if (v < 0) return unsupported(desc);
-    if (kVariants[v].ipe) return fail(NTX_E_UNSUPPORTED, "fp16x3 precision is built for the FourierFeatures families only");
     if (!weights_host || !packed_out) return fail(NTX_E_INVALID, "NULL buffer");
     if (n_floats != view_blob(kVariants[v], nullptr).count)
         return fail(NTX_E_INVALID, "weight blob has %zu floats, model needs %zu", n_floats,
@@ -512,7 +516,7 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     c->hit_list = nullptr; c->hit_cap = 0; c->hit_count = nullptr;
     c->ray_bias = nullptr; c->ray_bias_cap = 0;
     c->hoist_dir = getenv("NERFTEX_NO_DIR_HOIST") == nullptr;
-    if (!kVariants[v].ipe) {
+    {
         c->packed16_bytes = packed16_bytes(kVariants[v]);
         e = hipMalloc((void **)&c->packed16, c->packed16_bytes);
         if (e != hipSuccess) {
@@ -553,7 +557,7 @@ int ntx_set_precision(ntx_ctx *ctx, int precision) {
     if (precision != NTX_PRECISION_F32 && precision != NTX_PRECISION_FP16X3)
         return fail(NTX_E_INVALID, "unknown precision %d", precision);
     if (precision == NTX_PRECISION_FP16X3 && !ctx->packed16)
-        return fail(NTX_E_UNSUPPORTED, "fp16x3 precision is built for the FourierFeatures families only");
+        return fail(NTX_E_UNSUPPORTED, "fp16x3 precision is not built for this model family");
     ctx->precision = precision;
     return NTX_OK;
 }
@@ -730,7 +734,7 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     if (ctx->precision == NTX_PRECISION_FP16X3) {
         // ParamNerf: the colour layer's direction segment always enters as the per-ray bias of dirbias_kernel (float32)
         if (v.cd) {
-            if (blur_idx >= v.n_geo)
+            if (!v.ipe && blur_idx >= v.n_geo)
                 return fail(NTX_E_UNSUPPORTED, "fp16x3: blur_idx %d scales an appearance parameter per sample; use NTX_PRECISION_F32", blur_idx);
             if (ctx->ray_bias_cap < (size_t)n_rays) {
                 if (ctx->ray_bias) HIP_TRY(hipFree(ctx->ray_bias));

@@ -136,9 +136,9 @@ struct Cfg16 {
     }
     static constexpr int REC_C2 = rec_pass(9 + (CFG::CD ? 1 : 0));
     static constexpr int REC_END = REC_C2 + (CFG::CD ? 0 : DS16 * 8) + HS16 * 8;
-    static constexpr int REC_PAD = stream16_padded(CFG::NGEO, CFG::NAPP, CFG::CD, WD);
+    static constexpr int REC_PAD = stream16_padded(CFG::NGEO, CFG::NAPP, CFG::CD, WD, CFG::IPE);
     static constexpr int NST = REC_PAD / STAGE16;   // stages per batch
-    static_assert(REC_END == stream16_records(CFG::NGEO, CFG::NAPP, CFG::CD, WD), "stream bookkeeping");
+    static_assert(REC_END == stream16_records(CFG::NGEO, CFG::NAPP, CFG::CD, WD, CFG::IPE), "stream bookkeeping");
     static_assert(REC_END % 8 == 0 && REC_PAD % (STAGE16 * NSTAGE16) == 0, "pair-groups and ring turns");
 };
 
@@ -375,6 +375,7 @@ NTX_DEV void mlp_batch_x3(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &ws,
     static_assert(G16::REC_END % STAGE16 == 0, "the stream ends on a stage boundary");
 
     float chk = in.pos[0] + in.pos[1] + in.pos[2] + in.dir[0] + in.dir[1] + in.dir[2];
+    if constexpr (CFG::IPE != 0) chk += in.cov[0] + in.cov[1] + in.cov[2];
 #pragma unroll
     for (int k = 0; k < CFG::NP; ++k) chk += in.par[k];
     chk = chk - chk;
@@ -388,7 +389,6 @@ NTX_DEV void mlp_batch_x3(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &ws,
 // it * (4 * gridDim) + 4 g + w; waves past the end of the list go through the motions on the last hit ray and store nothing.
 template <class CFG>
 __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
-    static_assert(CFG::IPE == 0, "fp16x3 is built for the FourierFeatures families");
     using G16 = Cfg16<CFG>;
     __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
     __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * 256];   // + one per-ray C1 vector per wave
@@ -427,16 +427,29 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
             const int blur_idx = q.blur_idx;
             SampleIn<CFG::NGEO, CFG::NAPP> in;
             in.dir[0] = dx / dnorm; in.dir[1] = dy / dnorm; in.dir[2] = dz / dnorm;
-            const float z = z_of(q, r, ic, t0, t1, S);
-            const float zn = z_of(q, r, ic < S - 1 ? ic + 1 : ic - 1, t0, t1, S);
-            const float dist = (ic < S - 1 ? zn - z : z - zn) * dnorm;
-            in.pos[0] = ox + dx * z; in.pos[1] = oy + dy * z; in.pos[2] = oz + dz * z;
-            in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
+            float dist;
+            if constexpr (CFG::IPE == 0) {
+                const float z = z_of(q, r, ic, t0, t1, S);
+                const float zn = z_of(q, r, ic < S - 1 ? ic + 1 : ic - 1, t0, t1, S);
+                dist = (ic < S - 1 ? zn - z : z - zn) * dnorm;
+                in.pos[0] = ox + dx * z; in.pos[1] = oy + dy * z; in.pos[2] = oz + dz * z;
+                in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
 #pragma unroll
-            for (int k = 0; k < CFG::NP; ++k) {
-                float p = prow[k];
-                if (k == blur_idx) p = p * (cone * z);
-                in.par[k] = p;
+                for (int k = 0; k < CFG::NP; ++k) {
+                    float p = prow[k];
+                    if (k == blur_idx) p = p * (cone * z);
+                    in.par[k] = p;
+                }
+            } else {   // MipRenderer.render_rays (renderer.py:365-409), as in render_kernel<CFG>
+                const float e0 = z_of(q, r, ic, t0, t1, S + 1), e1 = z_of(q, r, ic + 1, t0, t1, S + 1);
+                dist = (e1 - e0) * dnorm;
+                float t_mean, t_var, r_var;
+                cone_moments((e0 + e1) / 2.0f, (e1 - e0) / 2.0f, prow[blur_idx] * cone, t_mean, t_var, r_var);
+                in.pos[0] = ox + dx * t_mean; in.pos[1] = oy + dy * t_mean; in.pos[2] = oz + dz * t_mean;
+                const float dd[3] = {dx, dy, dz};
+                cone_cov(t_var, r_var, dd, in.cov);
+#pragma unroll
+                for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[k < blur_idx ? k : k + 1];
             }
             float sigma, raw[3];
             if constexpr (CFG::CD != 0) {   // this ray's [2][128] vector: 64 lanes x 16 bytes, global -> LDS
@@ -475,7 +488,7 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <class CFG>
 __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
-    static_assert(CFG::IPE == 0 && CFG::CD != 0, "fp16x3 instanced: ParamNerf with FourierFeatures");
+    static_assert(CFG::CD != 0, "fp16x3 instanced: ParamNerf families");
     using G16 = Cfg16<CFG, true>;
     __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
     __shared__ __attribute__((aligned(16))) float aux[aux_total()];
@@ -551,12 +564,21 @@ __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
         SampleIn<CFG::NGEO, CFG::NAPP> in;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { in.pos[c] = a.pts[3 * sm + c]; in.dir[c] = a.rays_d_map[3 * sm + c]; }
-        in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
+        if constexpr (CFG::IPE == 0) {
+            in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
 #pragma unroll
-        for (int c = 0; c < CFG::NP; ++c) {
-            float p = a.params_map[CFG::NP * sm + c];
-            if (c == a.blur_idx) p = p * (cone * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
-            in.par[c] = p;
+            for (int c = 0; c < CFG::NP; ++c) {
+                float p = a.params_map[CFG::NP * sm + c];
+                if (c == a.blur_idx) p = p * (cone * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
+                in.par[c] = p;
+            }
+        } else {   // MipInstanceRenderer (renderer.py:510-540, 570-587), as in instance_kernel<CFG>
+            const float *pr = a.params_map + CFG::NP_IN * sm;
+            float t_mean, t_var, r_var;
+            cone_moments(a.t[sm], a.dists[sm], pr[a.blur_idx] * cone / a.patch_scale, t_mean, t_var, r_var);
+            cone_cov(t_var, r_var, in.dir, in.cov);
+#pragma unroll
+            for (int c = 0; c < CFG::NP; ++c) in.par[c] = pr[c < a.blur_idx ? c : c + 1];
         }
         float sigma, raw[3];
         mlp_batch_x3<CFG, true>(in, ws, aux, lane, sigma, raw, 0);
@@ -590,7 +612,6 @@ __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <class CFG>
 __global__ __launch_bounds__(256) void mlp_kernel_x3(MlpArgs a) {
-    static_assert(CFG::IPE == 0, "fp16x3 is built for the FourierFeatures families");
     using G16 = Cfg16<CFG, true>;
     __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
     __shared__ __attribute__((aligned(16))) float aux[aux_total()];
@@ -610,9 +631,9 @@ __global__ __launch_bounds__(256) void mlp_kernel_x3(MlpArgs a) {
         const int64_t mc = valid ? m : a.m - 1;
         SampleIn<CFG::NGEO, CFG::NAPP> in;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            in.pos[k] = a.pos[3 * mc + k];
-            in.cov[k] = 0.0f;
+        for (int k = 0; k < 3; ++k) {   // IPE models take pos[M,6] = (mean, diagonal covariance)
+            in.pos[k] = a.pos[(CFG::IPE ? 6 : 3) * mc + k];
+            in.cov[k] = CFG::IPE ? a.pos[6 * mc + 3 + k] : 0.0f;
             in.dir[k] = a.dirs[3 * mc + k];
         }
 #pragma unroll

@@ -160,15 +160,15 @@ constexpr int NSTAGE16 = 4;    // stages in the LDS ring (64 KiB)
 NTX_HD constexpr int steps16(int k2_steps) { return (k2_steps + 7) / 8; }
 // with_dir: the stream of the INSTANCED kernel, whose directions are per sample (renderer.py:247-262): C1 keeps its
 // direction segment (after its hidden segment)
-NTX_HD constexpr int stream16_records(int n_geo, int n_app, int color_depth, int with_dir = 0) {
-    const int ps = steps16(pos_steps(n_geo, 0)), ds = steps16(dir_steps(n_app)), hs = HSTEPS / 8;
+NTX_HD constexpr int stream16_records(int n_geo, int n_app, int color_depth, int with_dir = 0, int ipe = 0) {
+    const int ps = steps16(pos_steps(n_geo, ipe)), ds = steps16(dir_steps(n_app)), hs = HSTEPS / 8;
     int rec = ps * 16 + 4 * hs * 16 + (ps + hs) * 16 + 2 * hs * 16 + hs * 16;
     if (color_depth) rec += hs * 16 + (with_dir ? ds * 16 : 0) + hs * 8;   // ParamNerf: C1 (direction segment hoisted per ray unless with_dir), C2
     else rec += (ds + hs) * 8;                  // plain Nerf: C2 = hidden + direction segment, 4 tiles
     return rec;
 }
-NTX_HD constexpr int stream16_padded(int n_geo, int n_app, int color_depth, int with_dir = 0) {
-    return round_up(stream16_records(n_geo, n_app, color_depth, with_dir), STAGE16 * NSTAGE16);
+NTX_HD constexpr int stream16_padded(int n_geo, int n_app, int color_depth, int with_dir = 0, int ipe = 0) {
+    return round_up(stream16_records(n_geo, n_app, color_depth, with_dir, ipe), STAGE16 * NSTAGE16);
 }
 
 }  // namespace ntx

@@ -1,11 +1,11 @@
-// ntx_variant_x3.hip -- the fused render kernel of ONE model family at fp16x3 precision (ntx_device_x3.h).
-// Compiled once per FourierFeatures family with -DNTX_VARIANT=k (k as in kVariants[] of nerftex.hip).
+// ntx_variant_x3.hip -- the three MFMA kernels of ONE model family at fp16x3 precision (ntx_device_x3.h).
+// Compiled once per family with -DNTX_VARIANT=k (k as in kVariants[] of nerftex.hip).
 #include <hip/hip_runtime.h>
 
 #include "ntx_device_x3.h"
 
 #ifndef NTX_VARIANT
-#error "compile with -DNTX_VARIANT=0..3"
+#error "compile with -DNTX_VARIANT=0..4"
 #endif
 
 namespace ntx {
@@ -19,9 +19,12 @@ using VCfg = Cfg<1, 4, 1>;   // grass, fur, plush
 #elif NTX_VARIANT == 2
 using VCfg = Cfg<2, 3, 1>;   // grass_filtered
 #define NTX_FN(name) name##_v2
-#else
+#elif NTX_VARIANT == 3
 using VCfg = Cfg<0, 0, 0>;   // plain Nerf
 #define NTX_FN(name) name##_v3
+#else
+using VCfg = Cfg<1, 3, 1, 1>;   // mip: IPE position encoding, grass_filtered with the blur parameter spliced out
+#define NTX_FN(name) name##_v4
 #endif
 
 hipError_t NTX_FN(launch_render_x3)(int n_wgs, RenderArgs &a, hipStream_t st) {

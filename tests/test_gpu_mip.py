@@ -16,9 +16,11 @@ def d(a):
     return torch.as_tensor(np.asarray(a), device=torch.device("cuda", 0))
 
 
+@pytest.mark.parametrize("precision", ["float32", "fp16x3"])
 @pytest.mark.parametrize("m", [1, 33, 3000])
-def test_ipe_model_forward(m):
+def test_ipe_model_forward(m, precision):
     model, spec, w = make_model((1, 3), "IPE")
+    model.precision = precision
     rng = np.random.default_rng(m)
     mean = rng.uniform(-2, 2, size=(m, 3)); cov = rng.uniform(0, 1, size=(m, 3)) * 10.0 ** rng.uniform(-7, -2, size=(m, 3))
     cov[0] = 0.0                                              # zero covariance: IPE reduces to plain sin / cos features
@@ -33,9 +35,10 @@ def test_ipe_model_forward(m):
     assert orc.rel_linf(got, np.concatenate([rc, ra], -1)) <= 5e-5
 
 
+@pytest.mark.parametrize("precision", ["float32", "fp16x3"])
 @pytest.mark.parametrize("S", [32, 64, 45])
 @pytest.mark.parametrize("bk", [False, True])
-def test_mip_renderer(S, bk):
+def test_mip_renderer(S, bk, precision):
     from nerf_tex_amd import synthetic
     from nerf_tex_amd.renderer import MipRenderer, Renderer
     from nerf_tex_amd import _lib
@@ -46,7 +49,7 @@ def test_mip_renderer(S, bk):
     rd = (rd * 1.7).astype(np.float32)                        # |d| != 1: t_cov uses d^2, null space uses d^2/|d|^2
     t[7] = np.inf
     params = np.asarray([[8.0, 0.3, 0.0, -.707, .707]], np.float32)   # [blur, geo, app x3], blur_idx 0
-    r = MipRenderer(model=model, n_samples=S, perturb=False, blur_idx=0)
+    r = MipRenderer(model=model, n_samples=S, perturb=False, blur_idx=0, precision=precision)
     out = r(d(ro[None]), d(rd[None]), d(t[None]), parameters=d(params), cone_scale=d(cone[None]), composite_bkgd=bk, bkgd_color=[.1, .2, .3])
     r.raise_if_nonfinite()
     hit = np.isfinite(t[:, 0])
@@ -60,12 +63,13 @@ def test_mip_renderer(S, bk):
         Renderer(model=model, n_samples=S, perturb=False, blur_idx=0)(d(ro[None]), d(rd[None]), d(t[None]), parameters=d(params), cone_scale=d(cone[None]))
 
 
+@pytest.mark.parametrize("precision", ["float32", "fp16x3"])
 @pytest.mark.parametrize("S", [40, 130])
-def test_mip_instance_renderer(S):
+def test_mip_instance_renderer(S, precision):
     from nerf_tex_amd.renderer import MipInstanceRenderer
     model, spec, w = make_model((1, 3), "IPE", dense_media=True)
     inst = FakeInstancer(5, seed=S)
-    r = MipInstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=0.09, step_size=0.002, blur_idx=0, density_scale=400.0,
+    r = MipInstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=0.09, step_size=0.002, blur_idx=0, density_scale=400.0, precision=precision,
                             render_chunk=10_000)
     rng = np.random.default_rng(2)
     n = 50
