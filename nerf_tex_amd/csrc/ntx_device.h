@@ -295,14 +295,26 @@ NTX_DEV float dir_feature(const SampleIn<NGEO, NAPP> &in, int h) {
     }
 }
 
-template <int NGEO, int NAPP, int IPE>
+// KEEP = 1: evaluate and keep every value in this lane's LDS column pe[step * 64]; KEEP = 2: read them back instead of
+// evaluating again (the skip layer re-concatenates the same pos_map, model.py:107-108: one sin() per k-step saved, and
+// on gfx950 VALU time is not hidden behind the f32 MFMAs); KEEP = 0: evaluate, no LDS.
+template <int NGEO, int NAPP, int IPE, int KEEP = 0>
 struct PosGen {
     const SampleIn<NGEO, NAPP> &in;
     int h;
     float vals[PE_GROUP];
+    float *pe;
     template <int S, int N>
     NTX_DEV void prepare() {   // B values of k-steps S .. S+N-1 (S is a multiple of PE_GROUP)
-        static_for<N>([&](auto K) { vals[(S + decltype(K)::value) % PE_GROUP] = pos_feature<NGEO, NAPP, IPE, S + decltype(K)::value>(in, h); });
+        static_for<N>([&](auto K) {
+            constexpr int s = S + decltype(K)::value;
+            if constexpr (KEEP == 2) {
+                vals[s % PE_GROUP] = pe[s * 64];
+            } else {
+                vals[s % PE_GROUP] = pos_feature<NGEO, NAPP, IPE, s>(in, h);
+                if constexpr (KEEP == 1) pe[s * 64] = vals[s % PE_GROUP];
+            }
+        });
     }
     template <int S>
     NTX_DEV float value() const { return vals[S % PE_GROUP]; }
@@ -351,7 +363,7 @@ struct Cfg {
 template <class CFG, bool HOIST = false>
 NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
                        const float *aux_in, int lane, float &sigma, float (&rgb)[3],
-                       const float *c1_row = nullptr) {
+                       const float *c1_row = nullptr, float *pe = nullptr) {
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
     const int h = lane >> 5;
     // The aux block in LDS never changes, so the optimiser would hoist every bias / head-weight
@@ -368,7 +380,7 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
     // ---- trunk layer 0: pos_map -> 256 (model.py:104-106) into set A; set B <- bias of layer 1
     init_bias<8>(accA, aux, 0, h);
     {
-        PosGen<NGEO, NAPP, CFG::IPE> gen{in, h, {}};
+        PosGen<NGEO, NAPP, CFG::IPE, 1> gen{in, h, {}, pe};
         run_segment<CFG::PS, 8, 0>(accA, ws, gen, [&](auto S, auto MT) {
             constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
             if constexpr (mt == 1 && s % 4 == 0 && s < 32) init_bias_tile<s / 4>(accB, aux, 1, h);
@@ -405,7 +417,7 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
             auto conv = none;
             const SampleIn<NGEO, NAPP> in2 = launder(in);
             if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
-                PosGen<NGEO, NAPP, CFG::IPE> gen{in2, h, {}};
+                PosGen<NGEO, NAPP, CFG::IPE, 2> gen{in2, h, {}, pe};   // the values layer 0 kept
                 run_segment<pre_steps, 8, rec0>(cur, ws, gen, conv);
             } else {                   // input = concat[dir_map, feature]  (model.py:115)
                 if constexpr (HOIST) {
@@ -486,6 +498,14 @@ NTX_DEV void load_aux(float *lds, const float *aux_g, int n) {
     for (int i = threadIdx.x; i < n / 4; i += blockDim.x)
         reinterpret_cast<f32x4 *>(lds)[i] = reinterpret_cast<const f32x4 *>(aux_g)[i];
     __syncthreads();
+}
+
+// LDS behind the aux block: one column of position-segment values per lane and wave (PosGen KEEP)
+constexpr int PE_KEEP_FLOATS = 41 * 64;   // pos_steps <= 41 over the built families
+template <class CFG>
+NTX_DEV float *pe_column(float *aux, int wave_in_wg, int lane) {
+    static_assert(CFG::PS * 64 <= PE_KEEP_FLOATS, "position segment fits its LDS column");
+    return aux + aux_total() + wave_in_wg * PE_KEEP_FLOATS + lane;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -594,7 +614,7 @@ NTX_DEV float z_of(const RenderArgs &a, int64_t ray, int i, float t0, float t1, 
 template <class CFG, bool HOIST = false>
 __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     static_assert(!HOIST || CFG::CD != 0, "direction hoisting is for the ParamNerf families");
-    __shared__ __attribute__((aligned(16))) float aux[aux_total()];
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * PE_KEEP_FLOATS];
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -665,8 +685,9 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
                 for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[k < blur_idx ? k : k + 1];
             }
             float sigma, raw[3];
-            if constexpr (HOIST) mlp_batch<CFG, true>(in, ws, aux, lane, sigma, raw, q.ray_bias + r * 256);
-            else mlp_batch<CFG>(in, ws, aux, lane, sigma, raw);
+            float *pe = pe_column<CFG>(aux, threadIdx.x >> 6, lane);
+            if constexpr (HOIST) mlp_batch<CFG, true>(in, ws, aux, lane, sigma, raw, q.ray_bias + r * 256, pe);
+            else mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe);
             const RenderArgs *ap2 = kernargs<RenderArgs>();
             asm volatile("" : "+s"(ap2));
             composite_step<32>(ra, sigma, raw, dist, valid, ap2->flags, j,
@@ -780,7 +801,7 @@ struct InstanceArgs {
 
 template <class CFG>
 __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
-    __shared__ __attribute__((aligned(16))) float aux[aux_total()];
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * PE_KEEP_FLOATS];
     __shared__ uint16_t sidx_all[4][MAX_INSTANCE_SAMPLES];
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
@@ -843,7 +864,7 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
                 for (int c = 0; c < CFG::NP; ++c) in.par[c] = pr[c < a.blur_idx ? c : c + 1];
             }
             float sigma, raw[3];
-            mlp_batch<CFG>(in, ws, aux, lane, sigma, raw);
+            mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe_column<CFG>(aux, wv, lane));
             const float wgt = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // :300
             sigma = sigma * wgt;
             float col[3];
@@ -893,7 +914,7 @@ struct MlpArgs {
 
 template <class CFG>
 __global__ __launch_bounds__(256) void mlp_kernel(MlpArgs a) {
-    __shared__ __attribute__((aligned(16))) float aux[aux_total()];
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * PE_KEEP_FLOATS];
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -915,7 +936,7 @@ __global__ __launch_bounds__(256) void mlp_kernel(MlpArgs a) {
 #pragma unroll
         for (int k = 0; k < CFG::NP; ++k) in.par[k] = a.params[CFG::NP * mc + k];
         float sigma, raw[3];
-        mlp_batch<CFG>(in, ws, aux, lane, sigma, raw);
+        mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe_column<CFG>(aux, threadIdx.x >> 6, lane));
         if (valid && lane < 32) {
             a.color_out[3 * m + 0] = raw[0]; a.color_out[3 * m + 1] = raw[1]; a.color_out[3 * m + 2] = raw[2];
             a.sigma_out[m] = sigma;
