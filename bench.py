@@ -290,6 +290,8 @@ def main() -> None:
                          "frac": achieved / peak, "traffic": measured_traffic(args.workload, args.precision)[0],
                          "traffic_unit": "bytes/launch (HBM side, rocprofv3 PMC)", "traffic_source": measured_traffic(args.workload, args.precision)[1],
                          "algorithmic_bytes": n_rays * (4 * (3 + 3 + 2 + 1 + 4) + 0) + 4 * model.n_params,
+                         "traffic_note": "the render kernel re-reads each ray's 1 KiB direction vector (dirbias_kernel output, "
+                                         f"{n_rays * 1024} B per launch) once per 32-sample batch, mostly from L2/MALL; bound is MFMA, not HBM",
                          "kernel": "ntx::render_kernel" if args.precision == "float32" else "ntx::render_kernel_x3",
                          "kernel_ms": kernel_ms},
         }
