@@ -78,7 +78,7 @@ typedef struct ntx_model_desc {
  *                        ~2^-22 relative per product: 2.8e-6 from the float32 kernel on the bench image, ~2.8x faster.  Not
  *                        bit-identical to NTX_PRECISION_F32.  Range: |activation| and |weight| <= 65504, beyond that the
  *                        sample becomes inf/NaN (reported through NTX_FLAG_CHECK_NUMERICS).  Every family and all three
- *                        entry points (ntx_render_instanced at fp16x3: the ParamNerf families). */
+ *                        entry points. */
 typedef enum ntx_precision { NTX_PRECISION_F32 = 0, NTX_PRECISION_FP16X3 = 1 } ntx_precision;
 
 int ntx_abi_version(void);

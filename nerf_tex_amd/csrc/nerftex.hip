@@ -330,6 +330,7 @@ hipError_t launch_mlp_x3_v3(int n_wgs, MlpArgs &a, hipStream_t st);
 hipError_t launch_instance_x3_v0(int n_wgs, InstanceArgs &a, hipStream_t st);
 hipError_t launch_instance_x3_v1(int n_wgs, InstanceArgs &a, hipStream_t st);
 hipError_t launch_instance_x3_v2(int n_wgs, InstanceArgs &a, hipStream_t st);
+hipError_t launch_instance_x3_v3(int n_wgs, InstanceArgs &a, hipStream_t st);
 }  // namespace ntx
 
 static hipError_t launch_render_x3(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
@@ -375,6 +376,7 @@ static hipError_t launch_instance_x3(const ntx_ctx *c, InstanceArgs &a, hipStrea
 #ifndef NTX_DEV_ONLY_CARPET
         case 1: return launch_instance_x3_v1(c->n_wgs, a, st);
         case 2: return launch_instance_x3_v2(c->n_wgs, a, st);
+        case 3: return launch_instance_x3_v3(c->n_wgs, a, st);
         case 4: return launch_instance_x3_v4(c->n_wgs, a, st);
 #endif
         default: return hipErrorNotSupported;
@@ -819,10 +821,12 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     HIP_TRY(hipMemsetAsync(ctx->hit_count + 1, 0, sizeof(int32_t), (hipStream_t)stream));
     a.work_counter = ctx->hit_count + 1;
     if (ctx->precision == NTX_PRECISION_FP16X3) {
-        if (!ctx->packed16i)
-            return fail(NTX_E_UNSUPPORTED, "fp16x3 instanced rendering is built for ParamNerf with FourierFeatures");
-        a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed16i);
-        a.stream_bytes = (uint32_t)ctx->packed16i_bytes;
+        // directions are per sample: ParamNerf uses the stream that keeps C1's direction segment; plain Nerf's one stream
+        // has it in C2 anyway
+        const uint16_t *s16 = v.cd ? ctx->packed16i : ctx->packed16;
+        if (!s16) return fail(NTX_E_UNSUPPORTED, "fp16x3 precision is not built for this model family");
+        a.wstream = reinterpret_cast<const f32x4 *>(s16);
+        a.stream_bytes = (uint32_t)(v.cd ? ctx->packed16i_bytes : ctx->packed16_bytes);
         HIP_TRY(launch_instance_x3(ctx, a, (hipStream_t)stream));
         return NTX_OK;
     }

@@ -488,7 +488,6 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <class CFG>
 __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
-    static_assert(CFG::CD != 0, "fp16x3 instanced: ParamNerf families");
     using G16 = Cfg16<CFG, true>;
     __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
     __shared__ __attribute__((aligned(16))) float aux[aux_total()];

@@ -37,11 +37,9 @@ hipError_t NTX_FN(launch_mlp_x3)(int n_wgs, MlpArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
-#if NTX_VARIANT != 3
 hipError_t NTX_FN(launch_instance_x3)(int n_wgs, InstanceArgs &a, hipStream_t st) {
     instance_kernel_x3<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
     return hipGetLastError();
 }
-#endif
 
 }  // namespace ntx

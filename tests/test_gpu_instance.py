@@ -132,3 +132,31 @@ def test_instance_renderer_fp16x3_many_rays_lockstep():
     assert not np.array_equal(res["fp16x3"], res["float32"])
     hit = inst.last[-1]
     assert np.all(res["fp16x3"][~hit] == 0.0)
+
+
+@pytest.mark.parametrize("precision", ["float32", "fp16x3"])
+def test_instance_renderer_plain_nerf(precision):
+    """The instanced tail with a plain Nerf model (no material parameters: params_map is [n,S,0])."""
+    from nerf_tex_amd.renderer import InstanceRenderer
+    model, spec, w = make_model((0, 0), kind="Nerf", dense_media=True)
+    inst = FakeInstancer(0, seed=5)
+    S, n = 70, 45
+    r = InstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=0.09, step_size=0.002, density_scale=400.0,
+                         precision=precision)
+    rng = np.random.default_rng(3)
+    ro = rng.normal(size=(1, n, 3)).astype(np.float32); rd = rng.normal(size=(1, n, 3)).astype(np.float32)
+    t = np.tile(np.asarray([[1.0, 2.0]], np.float32), (1, n, 1))
+    params = np.zeros((1, 0), np.float32)
+    cone = rng.uniform(1e-3, 5e-3, size=(1, n, 1)).astype(np.float32)
+    dv = torch.device("cuda", 0)
+    d = lambda a: torch.as_tensor(a, device=dv)
+    out = r(d(ro), d(rd), d(t), parameters=d(params), cone_scale=d(cone))
+    r.raise_if_nonfinite()
+    rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map, hit = inst.last
+    rc, ra = orc.instance_evaluate_model(w, spec, rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id,
+                                         hit, params_map, cone[0], None, 0.09, r.density_scale, r.density_reweighting,
+                                         r.map_exr, False, (1., 1., 1.), r.instance_color, dtype=np.float64)
+    got = np.concatenate([out["color_pred"][0].cpu().numpy(), out["alpha_pred"][0].cpu().numpy()[:, None]], -1)
+    want = np.concatenate([rc, ra[:, None]], -1)
+    assert orc.rel_linf(got, want) <= TOL
+    assert float(np.max(ra)) > 0.3
