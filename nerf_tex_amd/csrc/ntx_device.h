@@ -826,12 +826,18 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
         }
         const float *drow = a.dists + ray * S;
         int count = 0;
-        for (int base = 0; base < S; base += 64) {
-            const int i = base + lane;
-            const bool v = i < S && drow[i] > 0.0f;
-            const unsigned long long m = __ballot(v);
-            if (v) sidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
-            count += __popcll(m);
+        for (int base0 = 0; base0 < S; base0 += 512) {   // 8 independent loads in flight, then their 8 ballots
+            float dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = base0 + 64 * u + lane; dv[u] = i < S ? drow[i] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base0 + 64 * u + lane;
+                const bool v = dv[u] > 0.0f;
+                const unsigned long long m = __ballot(v);
+                if (v) sidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+                count += __popcll(m);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
