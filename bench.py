@@ -2,18 +2,28 @@
 """Throughput of the NeRF-Tex render path on MI355X (BASELINE.json metric: ray-samples/sec through
 PE + MLP + composite at 800x800x64).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload carpet|grass|fur|grass_filtered]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--precision float32|fp16x3] [--perturb]
 
-One step = one pass of the fused HIP render kernel over one 800x800 image worth of synthetic
-all-hit rays (640 000 rays x 64 samples = 40.96 M ray-samples), inputs
-already resident in HBM, followed (N > 1) by the one gather of the finished RGBA to rank 0.  With
-N > 1 each rank renders its own 800x800 band of an (800 N) x 800 image (weak scaling, one process per
-GPU, launched by torch.distributed.run); `value` is the whole-job aggregate.
+`--gpus N` works as typed: when no launcher has set WORLD_SIZE, bench.py starts its N ranks itself (one process per
+GPU, rendezvous on 127.0.0.1); under `python -m torch.distributed.run --nproc-per-node N` it uses the launcher's ranks.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant (only) kernel: algorithmic FLOPs =
-2 * MACs(model) per ray-sample / average launch duration measured with HIP
-events on the launch stream.  `cpu_baseline` times the float32 numpy restatement in oracle/ on a
-bounded sample of the same workload on this host's cores (rank 0, N = 1 only).
+Workloads
+  carpet | grass | fur | grass_filtered   (weak scaling; `carpet` = BASELINE configs[1] is the default and the metric's
+      configuration) one step = one pass of the fused HIP render kernel over one 800x800 image worth of synthetic ALL-HIT
+      rays per GPU (640 000 rays x S samples), inputs resident in HBM.  N > 1: every rank renders
+      its own 800x800 band of an (800 N) x 800 image, then the one gather of the finished RGBA to rank 0.
+  fur_sharded | grass_filtered_sharded    (strong scaling; BASELINE configs[3] / configs[4]) ONE image -- fur 800x800x64 /
+      grass_filtered 1600x1600x128 with the cone-filter conditioning -- from the config's true camera, rays generated on
+      the device, pixel rows dealt round-robin over the N ranks (`--shard rows`, balances the rays the proxy culls; or
+      `--shard bands`), gathered to rank 0 through `ntx_gather_image` (RCCL ncclGather).  value = rays that hit the proxy
+      x S / time.  After the timed region rank 0 renders the whole image alone and the line reports whether the
+      gathered image is bit-identical to it.
+  carpet_instanced                        the InstanceRenderer tail, N = 1.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel: algorithmic FLOPs = 2 * MACs(model) per
+ray-sample / average launch duration measured with HIP events on the launch stream.
+`cpu_baseline` times the torch-CPU float32 restatement in oracle/ on a bounded sample of the same workload on this
+host's cores (rank 0, N = 1 only).
 """
 
 from __future__ import annotations
@@ -21,6 +31,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,57 +44,62 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_{f16,bf16} dense peak (~2.5 PF, no sparsity)
 
-WORKLOADS = {   # name -> (family, H, W, samples per ray)
-    "carpet": ("carpet", 800, 800, 64),             # BASELINE configs[1] -- the metric's configuration
-    "grass": ("grass", 800, 800, 128),              # configs[2]
-    "fur": ("fur", 800, 800, 64),                   # configs[3] per-GPU share when sharded
-    "grass_filtered": ("grass_filtered", 800, 800, 128),
+WORKLOADS = {   # name -> (family, H, W, samples per ray, BASELINE config index)
+    "carpet": ("carpet", 800, 800, 64, 1),             # the metric's configuration
+    "grass": ("grass", 800, 800, 128, 2),
+    "fur": ("fur", 800, 800, 64, 3),                   # per-GPU share of config 3 as all-hit rays
+    "grass_filtered": ("grass_filtered", 800, 800, 128, 4),
+}
+SHARDED = {     # one image from the true camera, sharded over the ranks
+    "fur_sharded": ("fur", 800, 800, 64, 3),
+    "grass_filtered_sharded": ("grass_filtered", 1600, 1600, 128, 4),
 }
 
 
-def cpu_baseline(family: str, n_samples: int, target_seconds: float = 12.0):
-    """float32 oracle (numpy + BLAS threads) on a bounded number of rays of the same workload."""
+def cpu_baseline(family: str, n_samples: int, target_seconds: float = 15.0):
+    """The reference's CPU path as a float32 torch-CPU port (oracle/torch_cpu.py: MatMul/BiasAdd/Relu per Dense layer on
+    the host BLAS, vectorised sin/cos, reference chunking 32768/65536), timed on up to one full render_chunk
+    (32 768 rays) of the same workload, bounded to about `target_seconds`."""
+    import torch
     from oracle import nerftex_oracle as orc
+    from oracle import torch_cpu
     from nerf_tex_amd import synthetic
     fam = synthetic.FAMILIES[family]
     spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(fam["n_parameters"]))
     w = orc.split_blob(spec, synthetic.synthetic_weights(orc.layer_table(spec), seed=0))
-    params = np.asarray([fam["params"]], np.float32)
+    params = np.asarray(fam["params"], np.float32)
 
     def run(n_rays):
         ro, rd, t, cone = synthetic.all_hit_rays(n_rays, fam["b_0"], fam["b_1"], fam["cam"])
         t0 = time.perf_counter()
-        orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], n_samples, False, (1, 1, 1.),
-                          fam["blur_idx"], False, render_chunk=32768, net_chunk=65536, dtype=np.float32)
+        torch_cpu.renderer_call(w, spec, ro, rd, t, params, cone, n_samples, fam["blur_idx"], render_chunk=32768, net_chunk=65536)
         return time.perf_counter() - t0
 
-    run(256)                                   # warm BLAS
-    n = 2048
+    run(1024)                                  # warm the BLAS threads
+    n = 4096
     dt = run(n)
     rate = n * n_samples / dt
     n2 = int(min(32768, max(n, rate * target_seconds / n_samples)))   # at most one reference render_chunk
     if n2 > n:
         dt = run(n2); n = n2
-    try:
-        import threadpoolctl
-        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    return {"value": n * n_samples / dt, "unit": "ray-samples/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} rays x {n_samples} samples of the same workload, float32 numpy restatement (oracle/), "
-                      f"reference chunking 32768/65536, {dt:.2f} s, host has {os.cpu_count()} logical cpus"}
+    return {"value": n * n_samples / dt, "unit": "ray-samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "cpu_count": os.cpu_count(), "blas": torch_cpu.blas_backend(),
+            "sample": f"{n} rays x {n_samples} samples of the same workload ({'one full' if n == 32768 else 'part of a'} "
+                      f"reference render_chunk), float32 torch-CPU port of the reference's TF ops (oracle/torch_cpu.py), "
+                      f"reference chunking 32768/65536, {dt:.2f} s on {torch.get_num_threads()} threads"}
 
 
 def measured_traffic(workload: str, precision: str = "float32"):
-    """HBM-side bytes per launch of the render kernel from the committed rocprofv3 PMC summary of this very
-    command (separate --pmc passes, FETCH_SIZE x2 for gfx950's wide reads; tools/summarize_profile.py).
+    """HBM-side bytes per ntx_render_rays call (ALL its kernels: hit compaction + render) from the committed rocprofv3 PMC
+    summary of this very command (separate --pmc passes, FETCH_SIZE x2 for gfx950's wide reads; tools/summarize_profile.py).
     PMC collection cannot run inside the timed bench, so the latest committed profile is quoted; None if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", ("bench_" if precision == "float32" else "benchx3_") + f"{workload}_*pmc_summary.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))["derived"]
-    rd, wr = d.get("hbm_side_read_bytes_corrected"), d.get("hbm_side_write_bytes_uncalibrated")
+    rd = d.get("call_hbm_side_read_bytes_corrected", d.get("hbm_side_read_bytes_corrected"))
+    wr = d.get("call_hbm_side_write_bytes_uncalibrated", d.get("hbm_side_write_bytes_uncalibrated"))
     if rd is None:
         return None, None
     return float(rd) + float(wr or 0.0), os.path.relpath(files[-1], ROOT)
@@ -122,14 +139,13 @@ def bench_instanced(args) -> None:
     color = torch.empty((n, 3), device=dev); alpha = torch.empty((n,), device=dev)
     n_in = int(inside.sum().item())
     stream = torch.cuda.current_stream(dev).cuda_stream
-
-    _lib.check(_lib.lib.ntx_set_precision(model.ctx(0), _lib.PRECISIONS[args.precision]))
+    flags = _lib.PRECISIONS[args.precision]
 
     def step():
         _lib.check(_lib.lib.ntx_render_instanced(
             model.ctx(0), rays_d_map.data_ptr(), pts.data_ptr(), t.data_ptr(), dists.data_ptr(), color_last.data_ptr(),
             alpha_last.data_ptr(), alpha_weight.data_ptr(), instance_id.data_ptr(), hit.data_ptr(), params_map.data_ptr(),
-            cone.data_ptr(), n, S, -1, 0.09, 400.0, 0, _lib.f3([1, 1, 1.]), None, color.data_ptr(), alpha.data_ptr(), None, stream))
+            cone.data_ptr(), n, S, -1, 0.09, 400.0, flags, _lib.f3([1, 1, 1.]), None, color.data_ptr(), alpha.data_ptr(), None, stream))
 
     for _ in range(args.warmup):
         step()
@@ -155,10 +171,28 @@ def bench_instanced(args) -> None:
                                f"ParamNerf n_parameters={list(fam['n_parameters'])}, buffers resident in HBM",
                    "rays": n, "marching_samples_per_ray": S, "in_patch_samples": n_in, "flops_per_sample": flops_per_sample},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": None,
+                     "frac": achieved / peak, "traffic": measured_traffic("instanced", args.precision)[0],
+                     "traffic_source": measured_traffic("instanced", args.precision)[1],
                      "algorithmic_bytes": in_bytes, "algorithmic_GBps": in_bytes / (kernel_ms * 1e-3) / 1e9,
                      "kernel": "ntx::instance_kernel" if args.precision == "float32" else "ntx::instance_kernel_x3",
                      "kernel_ms": kernel_ms}}), flush=True)
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU, and pass rank 0's
+    JSON line through.  Exit code = the worst of the ranks'."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main() -> None:
@@ -166,18 +200,22 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS) + ["carpet_instanced"])
+    ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS) + sorted(SHARDED) + ["carpet_instanced"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="float32", choices=["float32", "fp16x3"],
                     help="arithmetic of the Dense layers (include/nerftex.h: ntx_precision); float32 = the reference's")
+    ap.add_argument("--perturb", action="store_true", help="stratified jitter of the depths inside the kernel (the reference's default perturb=True)")
+    ap.add_argument("--shard", default="rows", choices=["rows", "bands"], help="sharded workloads: pixel rows round-robin, or contiguous bands")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     if args.workload == "carpet_instanced":
         return bench_instanced(args)
 
     import torch
     import torch.distributed as dist
     from nerf_tex_amd import synthetic
-    from nerf_tex_amd.dist import gather_image
+    from nerf_tex_amd.dist import Comm, ShardMap
     from nerf_tex_amd.model import ParamNerf
     from nerf_tex_amd.renderer import Renderer
 
@@ -185,42 +223,63 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)       # nccl backend == RCCL on ROCm
+        dist.init_process_group("nccl", device_id=dev)       # nccl backend == RCCL on ROCm: barrier + max-over-ranks timing
+        comm = Comm(local_rank)                              # the data path's own communicator, behind the C ABI
 
-    family, H, W, S = WORKLOADS[args.workload]
+    sharded = args.workload in SHARDED
+    family, H, W, S, cfg_idx = (SHARDED if sharded else WORKLOADS)[args.workload]
     fam = synthetic.FAMILIES[family]
     emb = lambda n: {"module": "network.model.FourierFeatures", "n_freq_bands": n}
     model = ParamNerf(emb(10), emb(4), emb(4), list(fam["n_parameters"]))["model"]
     model.set_blob(synthetic.synthetic_weights(model.layer_table(), seed=0))
-    renderer = Renderer(model=model, n_samples=S, perturb=False, blur_idx=fam["blur_idx"], check_numerics=False,
-                        precision=args.precision)
+    mk = lambda prec, perturb: Renderer(model=model, n_samples=S, perturb=perturb, blur_idx=fam["blur_idx"], check_numerics=False,
+                                        precision=prec)
+    renderer = mk(args.precision, args.perturb)
+    params = torch.as_tensor(np.asarray([fam["params"]], np.float32), device=dev)
 
-    n_rays = H * W                                           # per GPU (weak scaling)
-    ro, rd, t, cone = synthetic.all_hit_rays(n_rays, fam["b_0"], fam["b_1"], fam["cam"], seed=1 + rank)
-    d = lambda a: torch.as_tensor(a, device=dev)[None]
-    batch = dict(rays_o=d(ro), rays_d=d(rd), t=d(t), cone_scale=d(cone),
-                 parameters=torch.as_tensor(np.asarray([fam["params"]], np.float32), device=dev))
+    def camera_rays(shard_map, r):
+        """the true camera of the config: this rank's pixel set generated on the device (ntx_generate_rays_strided)"""
+        from nerf_tex_amd.dataset import look_at
+        from nerf_tex_amd.pixel_sampler import Full
+        from nerf_tex_amd.proxy import AABB
+        from nerf_tex_amd.ray_sampler import Proxy
+        focal = W / np.tan(fam["angle"] / 2) / 2                                  # dataset.py:229
+        sampler = Proxy(H, W, focal, AABB(fam["b_0"], fam["b_1"]))
+        ro, rd, t, cone = sampler(Full(H, W, shard=(shard_map, r))(), look_at(fam["cam"]), device=dev)
+        return dict(rays_o=ro[None], rays_d=rd[None], t=t[None], cone_scale=cone[None], parameters=params)
+
+    if sharded:
+        shard = ShardMap(H * W, world, W if args.shard == "rows" else None)
+        batch = camera_rays(shard, rank)
+        n_rays = shard.count(rank)
+        n_hit = int(torch.isfinite(batch["t"][0, :, 0]).sum().item())
+    else:
+        n_rays = H * W                                           # per GPU (weak scaling)
+        shard = ShardMap(n_rays * world, world)                  # every rank's own band of an (H * world) x W image
+        ro, rd, t, cone = synthetic.all_hit_rays(n_rays, fam["b_0"], fam["b_1"], fam["cam"], seed=1 + rank)
+        d = lambda a: torch.as_tensor(a, device=dev)[None]
+        batch = dict(rays_o=d(ro), rays_d=d(rd), t=d(t), cone_scale=d(cone), parameters=params)
+        n_hit = n_rays
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def step(i=None):
+    def step(i=None, r=renderer, b=batch):
         if i is not None:
             ev0[i].record()
-        out = renderer(**batch)
+        out = r(**b, seed=1234 + rank)
         if i is not None:
             ev1[i].record()                                  # same stream the kernel was launched on
         rgba = torch.cat([out["color_pred"][0], out["alpha_pred"][0][:, None]], -1)
-        if world > 1:
-            return gather_image(rgba, n_rays * world)        # the one collective: RGBA -> rank 0
+        if comm is not None:
+            return comm.gather_image(rgba, shard)            # the one collective: RGBA -> rank 0 (ntx_gather_image)
         return rgba
 
     for _ in range(args.warmup):
@@ -235,71 +294,94 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    hits_total = n_hit
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tt = torch.tensor([elapsed, float(n_hit)], device=dev, dtype=torch.float64)
+        mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, hits_total = float(mx[0].item()), int(sm[1].item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
 
-    # the opt-in fp16x3 precision on the same inputs, outside the timed region (rank 0, N = 1): a second, clearly
-    # labelled figure next to the float32 headline -- never `value`
-    alt = None
-    if world == 1 and args.precision == "float32":
-        r2 = Renderer(model=model, n_samples=S, perturb=False, blur_idx=fam["blur_idx"], check_numerics=False,
-                      precision="fp16x3")
-        o2 = r2(**batch)
+    # sharded image vs the same image rendered by ONE GPU (rank 0 alone, outside the timed region): bit-identical?
+    identical = None
+    if sharded and world > 1 and rank == 0:
+        whole = camera_rays(ShardMap(H * W, 1), 0)
+        o1 = renderer(**whole, seed=1234)
+        ref = torch.cat([o1["color_pred"][0], o1["alpha_pred"][0][:, None]], -1)
+        identical = bool(torch.equal(ref, img)) if not args.perturb else None   # the jitter stream is per call and rank
+
+    # second figures on the same inputs, outside the timed region (rank 0, N = 1), clearly labelled, never `value`:
+    # the opt-in fp16x3 precision, and the reference's default perturb=True (stratified jitter inside the kernel)
+    def timed(r2):
+        o2 = r2(**batch, seed=99)
         torch.cuda.synchronize()
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a0.record()
         for _ in range(args.steps):
-            o2 = r2(**batch)
+            o2 = r2(**batch, seed=99)
         a1.record()
         torch.cuda.synchronize()
-        ms2 = a0.elapsed_time(a1) / args.steps
-        rgba2 = torch.cat([o2["color_pred"][0], o2["alpha_pred"][0][:, None]], -1)
+        return a0.elapsed_time(a1) / args.steps, torch.cat([o2["color_pred"][0], o2["alpha_pred"][0][:, None]], -1)
+
+    alt = jit = None
+    if world == 1 and args.precision == "float32" and not args.perturb:
+        ms2, rgba2 = timed(mk("fp16x3", False))
         alt = {"precision": "fp16x3 (3-term split of weights and activations into IEEE halves on v_mfma_f32_32x32x16_f16, f32 accumulate)",
-               "value": n_rays * S / (ms2 * 1e-3), "unit": "ray-samples/s", "kernel_ms": ms2,
+               "value": n_hit * S / (ms2 * 1e-3), "unit": "ray-samples/s", "kernel_ms": ms2,
                "rel_linf_vs_float32_kernel": float((rgba2 - img).abs().max() / img.abs().max()),
                # canonical FLOPs (2 * MACs per ray-sample) over the 16-bit dense peak; the kernel issues 3 half-precision MFMA products
                # per canonical MAC, so the matrix pipe is 3x busier than this fraction
-               "canonical_frac_of_f16_peak": n_rays * S * 2 * model.macs_per_sample() / (ms2 * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
+               "canonical_frac_of_f16_peak": n_hit * S * 2 * model.macs_per_sample() / (ms2 * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
                "mfma_products_per_mac": 3}
+        ms3, _ = timed(mk("float32", True))
+        jit = {"what": "perturb=True (renderer.py:106-111, the reference's default): stratified jitter drawn inside the kernel "
+                       "(Philox4x32-10 per depth), no [N,S] depth tensor", "value": n_hit * S / (ms3 * 1e-3),
+               "unit": "ray-samples/s", "kernel_ms": ms3}
 
     if rank == 0:
-        samples_per_step = n_rays * S * world
         flops_per_sample = 2 * model.macs_per_sample()
-        achieved = n_rays * S * flops_per_sample / (kernel_ms * 1e-3) / 1e12
-        # canonical FLOPs (2 * MACs per ray-sample; split-precision multiplicity does not count) against the
-        # dense peak of the issued MFMA dtype
+        # roofline of the dominant kernel on THIS rank: canonical FLOPs (2 * MACs per ray-sample; split-precision
+        # multiplicity does not count) against the dense peak of the issued MFMA dtype
+        achieved = n_hit * S * flops_per_sample / (kernel_ms * 1e-3) / 1e12
         peak = F32_MFMA_PEAK_TFLOPS if args.precision == "float32" else F16_MFMA_PEAK_TFLOPS
+        traffic, traffic_src = measured_traffic(args.workload, args.precision)
+        if sharded:
+            what = (f"{args.workload}: ONE {H}x{W}x{S} image of the {family} config's camera (BASELINE configs[{cfg_idx}]), rays generated on "
+                    f"the device, {'pixel rows dealt round-robin' if args.shard == 'rows' else 'contiguous bands'} over {world} GPU(s), "
+                    f"{hits_total} of {H * W} rays hit the proxy")
+        else:
+            what = (f"{args.workload} {H}x{W}x{S}: {n_rays} all-hit rays x {S} samples per GPU (BASELINE configs[{cfg_idx}])")
         line = {
             "metric": "ray-samples/sec (MLP+composite) at 800x800x64",
-            "value": samples_per_step * args.steps / elapsed,
+            "value": hits_total * S * args.steps / elapsed,
             "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "float32" else "fp16x3 (f32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"{args.workload} {H}x{W}x{S}: {n_rays} all-hit rays x {S} samples per GPU "
-                                   f"(BASELINE configs[{ {'carpet': 1, 'grass': 2, 'fur': 3, 'grass_filtered': 4}[args.workload] }]), "
-                                   f"ParamNerf n_parameters={list(fam['n_parameters'])}, seeded glorot weights, "
+            "config": {"workload": what + f", ParamNerf n_parameters={list(fam['n_parameters'])}, seeded glorot weights, "
                                    f"inputs resident in HBM, fused PE+MLP+composite"
-                                   + (", + gather of RGBA to rank 0" if world > 1 else ""),
-                       "rays_per_gpu": n_rays, "samples_per_ray": S, "flops_per_sample": flops_per_sample},
+                                   + (", perturb=True (in-kernel jitter)" if args.perturb else "")
+                                   + (", + ntx_gather_image (RCCL ncclGather) of RGBA to rank 0" if world > 1 else ""),
+                       "rays_per_gpu": n_rays, "hit_rays_total": hits_total, "samples_per_ray": S, "flops_per_sample": flops_per_sample},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": measured_traffic(args.workload, args.precision)[0],
-                         "traffic_unit": "bytes/launch (HBM side, rocprofv3 PMC)", "traffic_source": measured_traffic(args.workload, args.precision)[1],
-                         "algorithmic_bytes": n_rays * (4 * (3 + 3 + 2 + 1 + 4) + 0) + 4 * model.n_params,
-                         "traffic_note": "the render kernel re-reads each ray's 1 KiB direction vector (dirbias_kernel output, "
-                                         f"{n_rays * 1024} B per launch) once per 32-sample batch, mostly from L2/MALL; bound is MFMA, not HBM",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "traffic_unit": "bytes per ntx_render_rays call, all kernels (HBM side, rocprofv3 PMC)", "traffic_source": traffic_src,
+                         "algorithmic_bytes": n_rays * 4 * (3 + 3 + 2 + 1 + 4) + 4 * model.n_params,
                          "kernel": "ntx::render_kernel" if args.precision == "float32" else "ntx::render_kernel_x3",
                          "kernel_ms": kernel_ms},
         }
+        if identical is not None:
+            line["sharded_image_bit_identical_to_1gpu"] = identical
         if alt is not None:
             line["fp16x3"] = alt
+        if jit is not None:
+            line["perturb"] = jit
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(family, S)
         print(json.dumps(line), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -12,8 +12,8 @@
  *   - every `float*` marked DEVICE is a caller-owned device pointer (row-major float32, last
  *     dimension fastest, exactly the layouts of the reference tensors); HOST pointers are read
  *     synchronously during the call;
- *   - the library owns only what `ntx_create` allocates (the packed weight image); no entry point
- *     allocates or frees device memory per call;
+ *   - the library owns only what `ntx_create` / `ntx_reserve` / `ntx_comm_create` allocate (the packed weight
+ *     image, the hit-list scratch, the communicator); no other entry point allocates or frees device memory;
  *   - every entry point is asynchronous on `stream` (a `hipStream_t` passed as `void*`; NULL = the
  *     null stream) and returns an `ntx_status` (0 = ok, negative = error).  The message of the
  *     last error on the calling thread is returned by `ntx_last_error()`;
@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NTX_ABI_VERSION 1
+#define NTX_ABI_VERSION 2
 
 typedef struct ntx_ctx ntx_ctx;
 typedef void *ntx_stream; /* hipStream_t */
@@ -67,6 +67,8 @@ typedef struct ntx_model_desc {
 #define NTX_FLAG_MAP_EXR 1u         /* renderer.py:182-184: colour = elu(raw)+1 instead of sigmoid  */
 #define NTX_FLAG_COMPOSITE_BKGD 2u  /* renderer.py:210-211 and 85-86: add (1-A)*bkgd; culled rays = bkgd */
 #define NTX_FLAG_CHECK_NUMERICS 4u  /* renderer.py:140-141: set *status_flag |= 1 on NaN/Inf outputs */
+#define NTX_FLAG_FP16X3 8u          /* this call uses NTX_PRECISION_FP16X3 (below) instead of float32 Dense layers */
+#define NTX_FLAG_PERTURB 16u        /* ntx_render_rays: stratified jitter of the sample depths (renderer.py:106-111), see there */
 
 /* Arithmetic of the Dense layers inside ntx_render_rays, ntx_render_instanced and ntx_mlp_forward (everything else -- encoders, heads,
  * compositing -- is float32 either way).  The reference computes in float32 (TensorFlow's default dtype, model.py:104-123):
@@ -80,13 +82,21 @@ typedef struct ntx_model_desc {
  *                        sample becomes inf/NaN (reported through NTX_FLAG_CHECK_NUMERICS).  Every family and all three
  *                        entry points. */
 typedef enum ntx_precision { NTX_PRECISION_F32 = 0, NTX_PRECISION_FP16X3 = 1 } ntx_precision;
+/* The precision is chosen PER CALL with NTX_FLAG_FP16X3 in `flags`; a context holds both weight images and no mutable
+ * precision state, so two callers may share a context on different precisions. */
 
 int ntx_abi_version(void);
 const char *ntx_last_error(void);
 
 /* Number of float32 in the reference-layout weight blob of `desc`:
- * concat over Dense layers in Keras creation order (model.py:104-123) of kernel[in,out] (row-major)
- * then bias[out]  ==  np.concatenate([w.ravel() for w in keras_model.get_weights()]).
+ *   np.concatenate([w.ravel() for w in keras_model.get_weights()])
+ * i.e. per Dense layer kernel[in,out] (row-major) then bias[out], in the order of `keras_model.layers`.  A functional
+ * tf.keras.Model sorts its layers by graph depth (ties: traversal order from outputs=[color, alpha], model.py:125), NOT
+ * by creation, so the order is
+ *   trunk 0..7 (model.py:105-106) | feature (:114) | colour layers (:118-119, ParamNerf) | colour half (:122) | color (:123) | alpha (:111)
+ * -- the alpha head comes LAST although it is created before the feature layer (the same order as the
+ * `layer_with_weights-k` keys of the checkpoints logger.py:30-39 writes).  Every layer has a distinct position, so a blob in
+ * another order has the right size and cannot be detected here; the Python mirror's `set_weights(list)` checks shapes.
  * Returns 0 if `desc` is not supported. */
 size_t ntx_weight_count(const ntx_model_desc *desc);
 
@@ -98,6 +108,13 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
 int ntx_set_weights(ntx_ctx *ctx, const float *weights_host, size_t n_floats);
 int ntx_destroy(ntx_ctx *ctx);
 
+/* Setup-time sizing of the context's device scratch (synchronous; frees and re-allocates): after ntx_reserve(ctx, n),
+ * ntx_render_rays accepts up to n rays per call and allocates nothing.  Scratch = 4 B per ray (the compacted list of rays
+ * that hit the proxy, renderer.py:58-67).  ntx_create reserves NTX_DEFAULT_MAX_RAYS; a call with more rays than
+ * reserved fails with NTX_E_INVALID and renders nothing. */
+#define NTX_DEFAULT_MAX_RAYS (1 << 20)
+int ntx_reserve(ntx_ctx *ctx, int64_t max_rays);
+
 /* Replaces pixel_sampler.Full (pixel_sampler.py:14-15) + ray_sampler.rays_from_camera
  * (ray_sampler.py:39-48) + ray_sampler.Proxy (32-37) with proxy.AABB (proxy.py:13-35) [mode 0]
  * or ray_sampler.Frustum (15-21) [mode 1], for pixels [pixel0, pixel0+n_pixels) of the row-major
@@ -107,6 +124,13 @@ int ntx_generate_rays(const float *c2w, int height, int width, float focal, int6
                       int64_t n_pixels, int mode, const float *b0, const float *b1, float near_t,
                       float far_t, float *rays_o, float *rays_d, float *t, float *cone_scale,
                       ntx_stream stream);
+/* Same for a STRIDED set of pixels, the local rays of one rank of a shard map (see ntx_shard_count): local ray k is
+ * pixel pixel0 + (k / run_length) * run_stride + k % run_length.  rank r of R: pixel0 = r * run_length,
+ * run_stride = R * run_length, n_pixels = ntx_shard_count(H * W, run_length, R, r). */
+int ntx_generate_rays_strided(const float *c2w, int height, int width, float focal, int64_t pixel0, int64_t n_pixels,
+                              int64_t run_length, int64_t run_stride, int mode, const float *b0, const float *b1,
+                              float near_t, float far_t, float *rays_o, float *rays_d, float *t, float *cone_scale,
+                              ntx_stream stream);
 
 /* Replaces layer.FourierFeatures.call (layer.py:22-23): x[M,D] -> out[M, D*(1+2*n_freq)] (DEVICE). */
 int ntx_fourier_features(const float *x, int64_t m, int d, int n_freq, float *out, ntx_stream stream);
@@ -114,7 +138,7 @@ int ntx_fourier_features(const float *x, int64_t m, int d, int n_freq, float *ou
 /* Replaces model((pos, dirs, params), training) (renderer.py:161; model.py:58-125):
  * pos[M,3], dirs[M,3], params[M,P] -> color[M,3] (raw), sigma[M] (raw alpha head).  All DEVICE. */
 int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const float *params, int64_t m,
-                    float *color_out, float *sigma_out, ntx_stream stream);
+                    uint32_t flags /* NTX_FLAG_FP16X3 or 0 */, float *color_out, float *sigma_out, ntx_stream stream);
 
 /* Replaces Renderer.map_model_output (renderer.py:170-213): color[N,S,3], sigma[N,S], z[N,S],
  * rays_d[N,3] -> color_out[N,3], alpha_out[N], optional weights_out[N,S] (NULL to skip).
@@ -123,37 +147,52 @@ int ntx_composite(const float *color, const float *sigma, const float *z_vals, c
                   int64_t n_rays, int n_samples, uint32_t flags, const float *bkgd, float *color_out,
                   float *alpha_out, float *weights_out, ntx_stream stream);
 
+/* Replaces the sample placement of Renderer.render_rays (renderer.py:101-111; MipRenderer :374-383) on its own:
+ * z_out[N, n_points] (DEVICE) = t0 (1 - tv) + t1 tv over tv = tf.linspace(0, 1, n_points) evaluated in float32, and with
+ * NTX_FLAG_PERTURB the stratified jitter z = lower + (upper - lower) * u of :106-111, u in [0,1) drawn by a counter-based
+ * generator: word 0 of Philox4x32-10 at counter (sample index, ray index lo, ray index hi, 0) under the key
+ * (perturb_seed lo, hi), low 23 bits as the float32 mantissa (tf.random.uniform's conversion).  The draw depends only on
+ * (perturb_seed, index of the ray WITHIN THE CALL, sample index): give every call (and every rank) its own seed.
+ * TensorFlow's own stream (its global generator) cannot be reproduced; the distribution is the same.  ntx_render_rays
+ * places its samples with exactly this function. */
+int ntx_sample_depths(const float *t, int64_t n_rays, int n_points, uint32_t flags, uint64_t perturb_seed, float *z_out,
+                      ntx_stream stream);
+
 /* Replaces Renderer.__call__ + render_rays + evaluate_model + map_model_output
- * (renderer.py:47-213) with perturb=False / raw_noise_std=0 / n_importance=0, fused in one launch:
+ * (renderer.py:47-213) with raw_noise_std=0 / n_importance=0, fused in one launch:
  * culling of t==inf rays, sample placement, positional encoding, the MLP and the composite.
  *   rays_o[N,3], rays_d[N,3], t[N,2], cone_scale[N] (DEVICE)
  *   params[n_param_rows, P] (DEVICE): ray r uses row r / rays_per_param_row (the reference's
  *       tf.repeat(parameters, HW), renderer.py:54); rays_per_param_row = 1 gives per-ray parameters
  *   blur_idx: -1 = off, else params[blur_idx] *= cone_scale * z per sample (renderer.py:155-158)
- *   z_vals: NULL, or DEVICE [N,S] sample depths replacing renderer.py:101-103 (the caller's own
- *       stratified jitter, renderer.py:106-111)
+ *   flags: NTX_FLAG_MAP_EXR | NTX_FLAG_COMPOSITE_BKGD | NTX_FLAG_CHECK_NUMERICS | NTX_FLAG_FP16X3 | NTX_FLAG_PERTURB
+ *   z_vals: NULL, or DEVICE [N,S] sample depths replacing renderer.py:101-111 altogether (wins over NTX_FLAG_PERTURB)
+ *   perturb_seed: key of the jitter under NTX_FLAG_PERTURB (renderer.py:106-111, the reference's default; see
+ *       ntx_sample_depths), evaluated inside the kernel: no [N,S] tensor exists
  *   status_flag: NULL, or DEVICE int32 OR-ed with 1 when NTX_FLAG_CHECK_NUMERICS finds NaN/Inf
  * Outputs (DEVICE): color_out[N,3] (premultiplied), alpha_out[N]; culled rays get 0 (or bkgd);
  *   weights_out: NULL, or [N,S] the compositing weights of renderer.py:198 (input of sample_pdf; rows of
  *   culled rays are left untouched).
- * Context scratch (device memory owned by ctx, grown to the largest n_rays seen, then reused; freed by ntx_destroy):
- *   1 KiB per ray for ParamNerf models -- the view direction and the appearance parameters are constant along a ray
- *   (renderer.py:152-154), so the direction segment of the colour layer is evaluated once per ray by a pre-kernel instead
- *   of once per sample, bit-identically; not when blur_idx scales an appearance parameter -- and 4 B per ray at
- *   NTX_PRECISION_FP16X3 (compacted hit list).  Calls on one context must therefore be stream-ordered. */
+ * All arguments are validated before the first launch: a call that returns an error has written nothing.
+ * Context scratch: the compacted list of hit rays, 4 B per ray, sized by ntx_reserve (N beyond it is an error; nothing is
+ * allocated here).  The view direction and the appearance parameters are constant along a ray (renderer.py:152-154), so
+ * for ParamNerf models the direction segment of the colour layer is evaluated once per ray inside the kernel (through
+ * LDS, bit-identical to the per-sample evaluation) unless blur_idx scales an appearance parameter.  Calls on one context
+ * must be stream-ordered. */
 int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, const float *t,
                     const float *params, int64_t rays_per_param_row, const float *cone_scale,
                     int64_t n_rays, int n_samples, int blur_idx, uint32_t flags, const float *bkgd,
-                    const float *z_vals, float *color_out, float *alpha_out, float *weights_out,
-                    int32_t *status_flag, ntx_stream stream);
+                    const float *z_vals, uint64_t perturb_seed, float *color_out, float *alpha_out,
+                    float *weights_out, int32_t *status_flag, ntx_stream stream);
 
 /* Replaces the importance-sampling step of Renderer.render_rays (renderer.py:125-130) incl. sample_pdf
  * (renderer.py:589-617): bins = midpoints of the coarse depths, pdf = weights[:,1:-1] + 1e-5, n_importance
  * depths by inverse CDF at u (NULL = tf.linspace(0,1,n_importance), the `det` branch; else DEVICE [N,n_imp]
  * uniform draws), merged with the coarse depths and sorted -> z_out[N, S + n_importance] (DEVICE).
- * The coarse depths are z_vals[N,S], or (NULL) recomputed from t exactly as ntx_render_rays places them. */
+ * The coarse depths are z_vals[N,S], or (NULL) recomputed from t exactly as ntx_render_rays places them under the same
+ * `flags` (NTX_FLAG_PERTURB or 0) and `perturb_seed`. */
 int ntx_sample_pdf(const float *t, const float *z_vals, const float *weights, const float *u, int64_t n_rays,
-                   int n_samples, int n_importance, float *z_out, ntx_stream stream);
+                   int n_samples, int n_importance, uint32_t flags, uint64_t perturb_seed, float *z_out, ntx_stream stream);
 
 /* Replaces InstanceRenderer.evaluate_model + map_model_output (renderer.py:247-354) DOWNSTREAM of the
  * instancer: the arguments are the buffers instancer.get_model_input returns (instancer.pyx:38-54), on the
@@ -163,7 +202,8 @@ int ntx_sample_pdf(const float *t, const float *z_vals, const float *weights, co
  * sigma *= alpha_weight * density_scale (:300); alpha = 1 - exp(-relu(sigma) * dists / patch_scale) (:339);
  * one extra sample (color_last as is, alpha_last as an alpha) closes every ray (:331,339).
  * instance_color[n_instances,3] != NULL = the false-colour mode (:306-307).  Rays with hit == 0 get 0, also
- * under NTX_FLAG_COMPOSITE_BKGD (:313-314).  1 <= n_samples <= 4096. */
+ * under NTX_FLAG_COMPOSITE_BKGD (:313-314).  1 <= n_samples <= 4096.  flags: as ntx_render_rays without NTX_FLAG_PERTURB
+ * (the instancer places the samples). */
 int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts, const float *t,
                          const float *dists, const float *color_last, const float *alpha_last,
                          const float *alpha_weight, const int32_t *instance_id, const uint8_t *hit,
@@ -180,9 +220,33 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
 int ntx_image_epilogue(const float *rgba, int height, int width, int downsampling_factor, int unpremultiply,
                        float *out_f32, uint8_t *out_u8, ntx_stream stream);
 
-/* Selects the arithmetic of subsequent ntx_render_rays / ntx_render_instanced / ntx_mlp_forward calls on `ctx` (see ntx_precision).  NTX_E_UNSUPPORTED for a
- * model family without a fp16x3 kernel; the setting is per context and not thread-safe against concurrent launches. */
-int ntx_set_precision(ntx_ctx *ctx, int precision);
+/* ---- multi-GPU: rays shard embarrassingly, the ONE collective is the gather of the finished RGBA --------------
+ * The reference has no distribution; Renderer.__call__ already renders chunks of rays independently (renderer.py:72-73).
+ * Shard map (ntx_shard_*): the row-major pixel sequence [0, n_pixels) (pixel_sampler.py:14-15) is cut into RUNS of
+ * `run_length` consecutive pixels (the last one may be shorter); run q belongs to rank q % n_ranks and is that rank's
+ * local run q / n_ranks.  run_length = ceil(n_pixels / n_ranks) gives contiguous bands; run_length = image width deals
+ * rows round-robin, which balances the rays the proxy culls (renderer.py:58-67) across ranks. */
+int64_t ntx_shard_count(int64_t n_pixels, int64_t run_length, int n_ranks, int rank);   /* pixels of `rank`, -1 on bad arguments */
+
+/* One communicator per process/device over RCCL (librccl is dlopen-ed on first use: the copy PyTorch already loaded if
+ * there is one).  ntx_comm_unique_id wraps ncclGetUniqueId (rank 0 calls it and hands the 128 bytes to its peers by any
+ * host-side means); ntx_comm_create wraps ncclCommInitRank on `device`; all ranks call it collectively. */
+typedef struct ntx_comm ntx_comm;
+#define NTX_COMM_ID_BYTES 128
+int ntx_comm_unique_id(uint8_t *id_out /* HOST [NTX_COMM_ID_BYTES] */);
+int ntx_comm_create(const uint8_t *id /* HOST [NTX_COMM_ID_BYTES] */, int n_ranks, int rank, int device, ntx_comm **out);
+int ntx_comm_destroy(ntx_comm *comm);
+
+/* Replaces nothing in the reference (single device); it is the `tf.concat` of the chunk results (renderer.py:76-79)
+ * across devices.  Every rank passes its local premultiplied RGBA, local_rgba[ntx_shard_count(...), 4] (DEVICE), in local
+ * ray order; `root` receives the whole image image_out[n_pixels, 4] (DEVICE) in pixel order.  One ncclGather
+ * (rccl.h:745) on `stream` when every rank holds the same number of pixels -- each peer sends straight to the root over its own xGMI
+ * link -- else the same exchange as grouped ncclSend/ncclRecv with the exact counts.  staging (root only, DEVICE, may be
+ * NULL when run_length == ceil(n_pixels / n_ranks) and the counts are equal: the gather then lands in image_out
+ * directly): n_ranks * max-count * 4 floats, from which a kernel deals the runs back into pixel order.
+ * image_out / staging are ignored on the other ranks. */
+int ntx_gather_image(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, int64_t run_length, float *image_out,
+                     float *staging, int root, ntx_stream stream);
 
 /* Introspection for benches/tests: name and launch geometry of the fused kernel in `ctx`. */
 int ntx_kernel_info(ntx_ctx *ctx, int *n_workgroups, int *threads_per_workgroup, int *n_cus);

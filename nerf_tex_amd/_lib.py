@@ -15,7 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERFTEX_LIB") or os.path.join(_HERE, "libnerftex_hip.so")
 
 NTX_OK, NTX_E_INVALID, NTX_E_UNSUPPORTED, NTX_E_HIP, NTX_E_NODEVICE = 0, -1, -2, -3, -4
-FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS = 1, 2, 4
+FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS, FLAG_FP16X3, FLAG_PERTURB = 1, 2, 4, 8, 16
+ABI_VERSION = 2
+COMM_ID_BYTES = 128
+DEFAULT_MAX_RAYS = 1 << 20
 
 
 class ModelDesc(C.Structure):
@@ -30,12 +33,13 @@ class NtxError(RuntimeError):
         self.code = code
 
 
-PRECISIONS = {"float32": 0, "fp16x3": 1}   # ntx_precision
+PRECISIONS = {"float32": 0, "fp16x3": FLAG_FP16X3}   # precision name -> its bit in `flags` (ntx_precision is chosen per call)
 
 _fp = C.POINTER(C.c_float)
 _vp = C.c_void_p
 
 # every symbol include/nerftex.h declares: (restype, argtypes)
+_u8p = C.POINTER(C.c_uint8)
 SYMBOLS = {
     "ntx_abi_version": (C.c_int, []),
     "ntx_last_error": (C.c_char_p, []),
@@ -43,18 +47,26 @@ SYMBOLS = {
     "ntx_create": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, C.c_int, C.POINTER(_vp)]),
     "ntx_set_weights": (C.c_int, [_vp, _fp, C.c_size_t]),
     "ntx_destroy": (C.c_int, [_vp]),
+    "ntx_reserve": (C.c_int, [_vp, C.c_int64]),
     "ntx_generate_rays": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, C.c_int64, C.c_int64, C.c_int, _fp, _fp,
                                     C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "ntx_generate_rays_strided": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                            _fp, _fp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "ntx_fourier_features": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, _vp, _vp]),
-    "ntx_mlp_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "ntx_mlp_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_uint32, _vp, _vp, _vp]),
     "ntx_composite": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_uint32, _fp, _vp, _vp, _vp, _vp]),
+    "ntx_sample_depths": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_uint32, C.c_uint64, _vp, _vp]),
     "ntx_render_rays": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, C.c_int, C.c_uint32,
-                                  _fp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ntx_sample_pdf": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp]),
+                                  _fp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
+    "ntx_sample_pdf": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_uint64, _vp, _vp]),
     "ntx_render_instanced": (C.c_int, [_vp] * 12 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, _fp,
                                         _vp, _vp, _vp, _vp, _vp]),
     "ntx_image_epilogue": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
-    "ntx_set_precision": (C.c_int, [_vp, C.c_int]),
+    "ntx_shard_count": (C.c_int64, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    "ntx_comm_unique_id": (C.c_int, [_u8p]),
+    "ntx_comm_create": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "ntx_comm_destroy": (C.c_int, [_vp]),
+    "ntx_gather_image": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int, _vp]),
     "ntx_kernel_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ntx_packed_count": (C.c_size_t, [C.POINTER(ModelDesc)]),
     "ntx_pack_weights": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, _fp, C.c_size_t]),
@@ -71,8 +83,8 @@ def _load() -> C.CDLL:
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, also fatal
         fn.restype, fn.argtypes = res, args
-    if lib.ntx_abi_version() != 1:
-        raise ImportError(f"{LIB_PATH}: ABI version {lib.ntx_abi_version()} != 1")
+    if lib.ntx_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.ntx_abi_version()} != {ABI_VERSION}")
     return lib
 
 

@@ -202,9 +202,10 @@ def model_weights_from_bundle(tensors: Dict[str, np.ndarray], layer_table, root:
     `layer_table` order = [kernel, bias, kernel, bias, ...].
 
     `layer_with_weights-<i>` follows `model.layers`, whose order for a functional model is by graph depth, not
-    by creation, so the alpha / colour heads need not sit where `get_weights()` has them.  Layers are therefore
-    matched by kernel SHAPE; the 256x256 group (trunk 1-4, 6, 7 and the feature layer, in this order under both
-    orderings) is matched by ascending index."""
+    by creation: the same order as `get_weights()` / `layer_table` (alpha head last).  Layers are nevertheless
+    matched by kernel SHAPE, so that a bundle written by a differently ordered Keras version still restores; the
+    256x256 group (trunk 1-4, 6, 7 and the feature layer, in this order under either ordering) is matched by
+    ascending index."""
     layers: Dict[int, dict] = {}
     for name, arr in tensors.items():
         m = _VAR.match(name)

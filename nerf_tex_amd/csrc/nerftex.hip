@@ -29,6 +29,15 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// the same for the other translation units of the library (ntx_comm.hip); not part of the public ABI
+extern "C" __attribute__((visibility("hidden"))) int ntx_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -75,7 +84,7 @@ static int unsupported(const ntx_model_desc *d) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// reference-layout blob -> layer views (model.py:104-123)
+// reference-layout blob (Keras get_weights() order) -> layer views (model.py:104-125)
 // ---------------------------------------------------------------------------------------------
 struct Layer {
     const float *w, *b;
@@ -102,7 +111,8 @@ static Net view_blob(const Variant &v, const float *blob) {
         n.trunk[i] = take(k, WIDTH);
         k = WIDTH + (i == SKIP ? pm : 0);
     }
-    n.alpha = take(WIDTH, 1);
+    // tf.keras.Model orders its layers by graph depth, ties by traversal from outputs=[color, alpha] (model.py:125), so
+    // get_weights() has the alpha head LAST although it is created before the feature layer (model.py:111-123)
     n.feature = take(WIDTH, WIDTH);
     n.has_c1 = v.cd > 0;
     if (n.has_c1) {
@@ -112,6 +122,7 @@ static Net view_blob(const Variant &v, const float *blob) {
         n.c2 = take(WIDTH + dm, WIDTH / 2);
     }
     n.rgb = take(WIDTH / 2, 3);
+    n.alpha = take(WIDTH, 1);
     n.count = p;
     return n;
 }
@@ -292,141 +303,54 @@ struct ntx_ctx {
     size_t stream_floats; // incl. tail
     size_t n_packed;
     ntx_model_desc desc;
-    int precision;        // NTX_PRECISION_*: arithmetic of the Dense layers in ntx_render_rays
-    uint16_t *packed16;   // device: fp16x3 stream (NULL for IPE families); shares the f32 aux block
+    uint16_t *packed16;   // device: fp16x3 stream; shares the f32 aux block
     size_t packed16_bytes;
-    uint16_t *packed16i;  // device: fp16x3 stream of the instanced kernel (C1 with its direction segment); ParamNerf only
+    uint16_t *packed16i;  // device: fp16x3 stream of the kernels with per-sample directions (C1 with its direction segment); ParamNerf only
     size_t packed16i_bytes;
-    int32_t *hit_list;    // device scratch of the fp16x3 render kernel: compacted hit-ray indices, grown on demand
+    int32_t *hit_list;    // device scratch of ntx_render_rays: compacted hit-ray indices, sized by ntx_reserve
     size_t hit_cap;
     int32_t *hit_count;   // device int32[2]: [0] number of hit rays, [1] work counter of the instance kernel
-    float *ray_bias;      // device scratch of the float32 render kernel: per-ray colour-layer bias incl. the direction
-    size_t ray_bias_cap;  // features (dirbias_kernel), [rays][2][128], grown on demand
     bool hoist_dir;       // false when NERFTEX_NO_DIR_HOIST is set at ntx_create (A/B knob for tests: same bits either way)
 };
 
-// The two big kernels of each model family live in their own translation unit (ntx_variant.hip compiled
-// with -DNTX_VARIANT=k) so that the build parallelises; this file only dispatches to them.
+// The big kernels of each model family live in their own translation units (ntx_variant.hip / ntx_variant_x3.hip
+// compiled with -DNTX_VARIANT=k, the hoisted render kernel with -DNTX_HOIST) so that the build parallelises; this file
+// only dispatches to them through one table.
 namespace ntx {
-#define NTX_DECL(k)                                                            \
-    hipError_t launch_render_v##k(int n_wgs, RenderArgs &a, hipStream_t st);   \
-    hipError_t launch_mlp_v##k(int n_wgs, MlpArgs &a, hipStream_t st);         \
-    hipError_t launch_instance_v##k(int n_wgs, InstanceArgs &a, hipStream_t st); \
-    hipError_t launch_dirbias_v##k(int n_wgs, DirBiasArgs &a, hipStream_t st);  \
-    hipError_t launch_render_hoist_v##k(int n_wgs, RenderArgs &a, hipStream_t st);
+#define NTX_DECL(k)                                                                  \
+    hipError_t launch_render_v##k(int n_wgs, RenderArgs &a, hipStream_t st);         \
+    hipError_t launch_mlp_v##k(int n_wgs, MlpArgs &a, hipStream_t st);               \
+    hipError_t launch_instance_v##k(int n_wgs, InstanceArgs &a, hipStream_t st);     \
+    hipError_t launch_render_hoist_v##k(int n_wgs, RenderArgs &a, hipStream_t st);   \
+    hipError_t launch_render_x3_v##k(int n_wgs, RenderArgs &a, hipStream_t st);      \
+    hipError_t launch_mlp_x3_v##k(int n_wgs, MlpArgs &a, hipStream_t st);            \
+    hipError_t launch_instance_x3_v##k(int n_wgs, InstanceArgs &a, hipStream_t st);
 NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4)
 #undef NTX_DECL
-hipError_t launch_render_x3_v0(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_render_x3_v1(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_render_x3_v2(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_render_x3_v3(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_render_x3_v4(int n_wgs, RenderArgs &a, hipStream_t st);
-hipError_t launch_mlp_x3_v4(int n_wgs, MlpArgs &a, hipStream_t st);
-hipError_t launch_instance_x3_v4(int n_wgs, InstanceArgs &a, hipStream_t st);
-hipError_t launch_mlp_x3_v0(int n_wgs, MlpArgs &a, hipStream_t st);
-hipError_t launch_mlp_x3_v1(int n_wgs, MlpArgs &a, hipStream_t st);
-hipError_t launch_mlp_x3_v2(int n_wgs, MlpArgs &a, hipStream_t st);
-hipError_t launch_mlp_x3_v3(int n_wgs, MlpArgs &a, hipStream_t st);
-hipError_t launch_instance_x3_v0(int n_wgs, InstanceArgs &a, hipStream_t st);
-hipError_t launch_instance_x3_v1(int n_wgs, InstanceArgs &a, hipStream_t st);
-hipError_t launch_instance_x3_v2(int n_wgs, InstanceArgs &a, hipStream_t st);
-hipError_t launch_instance_x3_v3(int n_wgs, InstanceArgs &a, hipStream_t st);
 }  // namespace ntx
 
-static hipError_t launch_render_x3(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
-    switch (c->variant) {
-        case 0: return launch_render_x3_v0(c->n_wgs, a, st);
-#ifndef NTX_DEV_ONLY_CARPET
-        case 1: return launch_render_x3_v1(c->n_wgs, a, st);
-        case 2: return launch_render_x3_v2(c->n_wgs, a, st);
-        case 3: return launch_render_x3_v3(c->n_wgs, a, st);
-        case 4: return launch_render_x3_v4(c->n_wgs, a, st);
-#endif
-        default: return hipErrorNotSupported;
-    }
-}
-
-static hipError_t launch_render(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
-    switch (c->variant) {
-        case 0: return launch_render_v0(c->n_wgs, a, st);
+struct Launchers {
+    hipError_t (*render)(int, RenderArgs &, hipStream_t);
+    hipError_t (*render_hoist)(int, RenderArgs &, hipStream_t);   // NULL: plain Nerf has no per-ray direction segment to hoist out of C1
+    hipError_t (*mlp)(int, MlpArgs &, hipStream_t);
+    hipError_t (*instance)(int, InstanceArgs &, hipStream_t);
+    hipError_t (*render_x3)(int, RenderArgs &, hipStream_t);
+    hipError_t (*mlp_x3)(int, MlpArgs &, hipStream_t);
+    hipError_t (*instance_x3)(int, InstanceArgs &, hipStream_t);
+};
+#define NTX_ROW(k, hoist) {launch_render_v##k, hoist, launch_mlp_v##k, launch_instance_v##k, launch_render_x3_v##k, launch_mlp_x3_v##k, launch_instance_x3_v##k}
+static const Launchers kLaunch[] = {   // indexed like kVariants
+    NTX_ROW(0, launch_render_hoist_v0),
 #ifndef NTX_DEV_ONLY_CARPET   // development builds link only the carpet family (compile time)
-        case 1: return launch_render_v1(c->n_wgs, a, st);
-        case 2: return launch_render_v2(c->n_wgs, a, st);
-        case 3: return launch_render_v3(c->n_wgs, a, st);
-        case 4: return launch_render_v4(c->n_wgs, a, st);
+    NTX_ROW(1, launch_render_hoist_v1), NTX_ROW(2, launch_render_hoist_v2), NTX_ROW(3, nullptr), NTX_ROW(4, launch_render_hoist_v4),
+#else
+    {}, {}, {}, {},
 #endif
-        default: return hipErrorNotSupported;
-    }
-}
-static hipError_t launch_mlp_x3(const ntx_ctx *c, MlpArgs &a, hipStream_t st) {
-    switch (c->variant) {
-        case 0: return launch_mlp_x3_v0(c->n_wgs, a, st);
-#ifndef NTX_DEV_ONLY_CARPET
-        case 1: return launch_mlp_x3_v1(c->n_wgs, a, st);
-        case 2: return launch_mlp_x3_v2(c->n_wgs, a, st);
-        case 3: return launch_mlp_x3_v3(c->n_wgs, a, st);
-        case 4: return launch_mlp_x3_v4(c->n_wgs, a, st);
-#endif
-        default: return hipErrorNotSupported;
-    }
-}
-static hipError_t launch_instance_x3(const ntx_ctx *c, InstanceArgs &a, hipStream_t st) {
-    switch (c->variant) {
-        case 0: return launch_instance_x3_v0(c->n_wgs, a, st);
-#ifndef NTX_DEV_ONLY_CARPET
-        case 1: return launch_instance_x3_v1(c->n_wgs, a, st);
-        case 2: return launch_instance_x3_v2(c->n_wgs, a, st);
-        case 3: return launch_instance_x3_v3(c->n_wgs, a, st);
-        case 4: return launch_instance_x3_v4(c->n_wgs, a, st);
-#endif
-        default: return hipErrorNotSupported;
-    }
-}
-static hipError_t launch_render_hoist(const ntx_ctx *c, RenderArgs &a, hipStream_t st) {
-    switch (c->variant) {
-        case 0: return launch_render_hoist_v0(c->n_wgs, a, st);
-#ifndef NTX_DEV_ONLY_CARPET
-        case 1: return launch_render_hoist_v1(c->n_wgs, a, st);
-        case 2: return launch_render_hoist_v2(c->n_wgs, a, st);
-        case 4: return launch_render_hoist_v4(c->n_wgs, a, st);
-#endif
-        default: return hipErrorNotSupported;
-    }
-}
-static hipError_t launch_dirbias(const ntx_ctx *c, DirBiasArgs &a, hipStream_t st) {
-    switch (c->variant) {
-        case 0: return launch_dirbias_v0(c->n_wgs, a, st);
-#ifndef NTX_DEV_ONLY_CARPET
-        case 1: return launch_dirbias_v1(c->n_wgs, a, st);
-        case 2: return launch_dirbias_v2(c->n_wgs, a, st);
-        case 4: return launch_dirbias_v4(c->n_wgs, a, st);
-#endif
-        default: return hipErrorNotSupported;
-    }
-}
-static hipError_t launch_instance(const ntx_ctx *c, InstanceArgs &a, hipStream_t st) {
-    switch (c->variant) {
-        case 0: return launch_instance_v0(c->n_wgs, a, st);
-#ifndef NTX_DEV_ONLY_CARPET
-        case 1: return launch_instance_v1(c->n_wgs, a, st);
-        case 2: return launch_instance_v2(c->n_wgs, a, st);
-        case 3: return launch_instance_v3(c->n_wgs, a, st);
-        case 4: return launch_instance_v4(c->n_wgs, a, st);
-#endif
-        default: return hipErrorNotSupported;
-    }
-}
-static hipError_t launch_mlp(const ntx_ctx *c, MlpArgs &a, hipStream_t st) {
-    switch (c->variant) {
-        case 0: return launch_mlp_v0(c->n_wgs, a, st);
-#ifndef NTX_DEV_ONLY_CARPET
-        case 1: return launch_mlp_v1(c->n_wgs, a, st);
-        case 2: return launch_mlp_v2(c->n_wgs, a, st);
-        case 3: return launch_mlp_v3(c->n_wgs, a, st);
-        case 4: return launch_mlp_v4(c->n_wgs, a, st);
-#endif
-        default: return hipErrorNotSupported;
-    }
+};
+#undef NTX_ROW
+template <class Fn, class Args>
+static hipError_t launch(Fn fn, const ntx_ctx *c, Args &a, hipStream_t st) {
+    return fn ? fn(c->n_wgs, a, st) : hipErrorNotSupported;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -511,12 +435,10 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
         delete c;
         return fail(NTX_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     }
-    c->precision = NTX_PRECISION_F32;
     c->packed16 = nullptr;
     c->packed16_bytes = 0;
     c->packed16i = nullptr; c->packed16i_bytes = 0;
     c->hit_list = nullptr; c->hit_cap = 0; c->hit_count = nullptr;
-    c->ray_bias = nullptr; c->ray_bias_cap = 0;
     c->hoist_dir = getenv("NERFTEX_NO_DIR_HOIST") == nullptr;
     {
         c->packed16_bytes = packed16_bytes(kVariants[v]);
@@ -539,6 +461,12 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
         }
     }
     *out = c;
+    {   // all the device scratch the entry points will ever use: allocated here (and by ntx_reserve), never per call
+        int rc = NTX_OK;
+        if (hipMalloc((void **)&c->hit_count, 2 * sizeof(int32_t)) != hipSuccess) rc = fail(NTX_E_HIP, "hipMalloc(hit_count)");
+        if (rc == NTX_OK) rc = ntx_reserve(c, NTX_DEFAULT_MAX_RAYS);
+        if (rc != NTX_OK) { ntx_destroy(c); *out = nullptr; return rc; }
+    }
     if (weights_host) {
         const int rc = ntx_set_weights(c, weights_host, n_floats);
         if (rc != NTX_OK) {
@@ -554,13 +482,16 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     return NTX_OK;
 }
 
-int ntx_set_precision(ntx_ctx *ctx, int precision) {
+int ntx_reserve(ntx_ctx *ctx, int64_t max_rays) {
     if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
-    if (precision != NTX_PRECISION_F32 && precision != NTX_PRECISION_FP16X3)
-        return fail(NTX_E_INVALID, "unknown precision %d", precision);
-    if (precision == NTX_PRECISION_FP16X3 && !ctx->packed16)
-        return fail(NTX_E_UNSUPPORTED, "fp16x3 precision is not built for this model family");
-    ctx->precision = precision;
+    if (max_rays < 0 || max_rays > 0x7fffffff) return fail(NTX_E_INVALID, "max_rays %lld outside [0, 2^31)", (long long)max_rays);
+    if ((size_t)max_rays == ctx->hit_cap && (ctx->hit_list || max_rays == 0)) return NTX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());   // a launch may still be walking the old list
+    if (ctx->hit_list) HIP_TRY(hipFree(ctx->hit_list));
+    ctx->hit_list = nullptr; ctx->hit_cap = 0;
+    if (max_rays > 0) HIP_TRY(hipMalloc((void **)&ctx->hit_list, (size_t)max_rays * sizeof(int32_t)));
+    ctx->hit_cap = (size_t)max_rays;
     return NTX_OK;
 }
 
@@ -591,7 +522,6 @@ int ntx_destroy(ntx_ctx *ctx) {
     if (ctx->packed16i) (void)hipFree(ctx->packed16i);
     if (ctx->hit_list) (void)hipFree(ctx->hit_list);
     if (ctx->hit_count) (void)hipFree(ctx->hit_count);
-    if (ctx->ray_bias) (void)hipFree(ctx->ray_bias);
     delete ctx;
     return NTX_OK;
 }
@@ -604,13 +534,19 @@ int ntx_kernel_info(ntx_ctx *ctx, int *n_workgroups, int *threads_per_workgroup,
     return NTX_OK;
 }
 
-int ntx_generate_rays(const float *c2w, int height, int width, float focal, int64_t pixel0, int64_t n_pixels,
-                      int mode, const float *b0, const float *b1, float near_t, float far_t, float *rays_o,
-                      float *rays_d, float *t, float *cone_scale, ntx_stream stream) {
+int ntx_generate_rays_strided(const float *c2w, int height, int width, float focal, int64_t pixel0, int64_t n_pixels,
+                              int64_t run_length, int64_t run_stride, int mode, const float *b0, const float *b1,
+                              float near_t, float far_t, float *rays_o, float *rays_d, float *t, float *cone_scale,
+                              ntx_stream stream) {
     if (!c2w || !rays_o || !rays_d || !t || !cone_scale) return fail(NTX_E_INVALID, "NULL buffer");
-    if (height <= 0 || width <= 0 || n_pixels < 0 || pixel0 < 0 || pixel0 + n_pixels > (int64_t)height * width)
-        return fail(NTX_E_INVALID, "pixel range [%lld,+%lld) outside %dx%d", (long long)pixel0, (long long)n_pixels,
-                    height, width);
+    if (height <= 0 || width <= 0 || n_pixels < 0 || pixel0 < 0 || run_length < 1 || run_stride < run_length)
+        return fail(NTX_E_INVALID, "bad pixel set: pixel0 %lld n %lld run_length %lld run_stride %lld", (long long)pixel0,
+                    (long long)n_pixels, (long long)run_length, (long long)run_stride);
+    if (n_pixels > 0) {
+        const int64_t last = pixel0 + ((n_pixels - 1) / run_length) * run_stride + (n_pixels - 1) % run_length;
+        if (last >= (int64_t)height * width)
+            return fail(NTX_E_INVALID, "pixel set [%lld .. %lld] outside %dx%d", (long long)pixel0, (long long)last, height, width);
+    }
     if (mode != 0 && mode != 1) return fail(NTX_E_INVALID, "mode must be 0 (Proxy/AABB) or 1 (Frustum)");
     if (mode == 0 && (!b0 || !b1)) return fail(NTX_E_INVALID, "AABB bounds are NULL");
     if (n_pixels == 0) return NTX_OK;
@@ -623,11 +559,20 @@ int ntx_generate_rays(const float *c2w, int height, int width, float focal, int6
     a.near_t = near_t; a.far_t = far_t;
     a.width = width; a.mode = mode;
     a.pixel0 = pixel0; a.n = n_pixels;
+    a.run_length = run_length; a.run_stride = run_stride;
     a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.cone = cone_scale;
     const int64_t nb = (n_pixels + 255) / 256;
     raygen_kernel<<<dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream>>>(a);
     HIP_TRY(hipGetLastError());
     return NTX_OK;
+}
+
+int ntx_generate_rays(const float *c2w, int height, int width, float focal, int64_t pixel0, int64_t n_pixels,
+                      int mode, const float *b0, const float *b1, float near_t, float far_t, float *rays_o,
+                      float *rays_d, float *t, float *cone_scale, ntx_stream stream) {
+    const int64_t run = n_pixels > 0 ? n_pixels : 1;
+    return ntx_generate_rays_strided(c2w, height, width, focal, pixel0, n_pixels, run, run, mode, b0, b1, near_t, far_t, rays_o,
+                                     rays_d, t, cone_scale, stream);
 }
 
 int ntx_fourier_features(const float *x, int64_t m, int d, int n_freq, float *out, ntx_stream stream) {
@@ -640,14 +585,16 @@ int ntx_fourier_features(const float *x, int64_t m, int d, int n_freq, float *ou
     return NTX_OK;
 }
 
-int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const float *params, int64_t m,
+int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const float *params, int64_t m, uint32_t flags,
                     float *color_out, float *sigma_out, ntx_stream stream) {
     if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
     if (m < 0) return fail(NTX_E_INVALID, "m < 0");
+    if (flags & ~NTX_FLAG_FP16X3) return fail(NTX_E_INVALID, "ntx_mlp_forward takes NTX_FLAG_FP16X3 or 0, got 0x%x", flags);
     if (m == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
     if (!pos || !dirs || !color_out || !sigma_out || (!params && v.n_geo + v.n_app > 0))
         return fail(NTX_E_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(ctx->device));   // the launch goes to the context's device whatever the caller's current one is
     MlpArgs a{};
     a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed);
     a.stream_bytes = (uint32_t)(ctx->stream_floats * sizeof(float));
@@ -655,18 +602,15 @@ int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const flo
     a.pos = pos; a.dirs = dirs; a.params = params;
     a.color_out = color_out; a.sigma_out = sigma_out;
     a.m = m;
-    if (ctx->precision == NTX_PRECISION_FP16X3) {
+    if (flags & NTX_FLAG_FP16X3) {
         // directions are per sample: ParamNerf uses the stream that keeps C1's direction segment; plain Nerf's one stream
         // has it in C2 anyway
-        const uint16_t *s16 = v.cd ? ctx->packed16i : ctx->packed16;
-        const size_t b16 = v.cd ? ctx->packed16i_bytes : ctx->packed16_bytes;
-        if (!s16) return fail(NTX_E_UNSUPPORTED, "fp16x3 precision is built for the FourierFeatures families only");
-        a.wstream = reinterpret_cast<const f32x4 *>(s16);
-        a.stream_bytes = (uint32_t)b16;
-        HIP_TRY(launch_mlp_x3(ctx, a, (hipStream_t)stream));
+        a.wstream = reinterpret_cast<const f32x4 *>(v.cd ? ctx->packed16i : ctx->packed16);
+        a.stream_bytes = (uint32_t)(v.cd ? ctx->packed16i_bytes : ctx->packed16_bytes);
+        HIP_TRY(launch(kLaunch[ctx->variant].mlp_x3, ctx, a, (hipStream_t)stream));
         return NTX_OK;
     }
-    HIP_TRY(launch_mlp(ctx, a, (hipStream_t)stream));
+    HIP_TRY(launch(kLaunch[ctx->variant].mlp, ctx, a, (hipStream_t)stream));
     return NTX_OK;
 }
 
@@ -691,8 +635,9 @@ int ntx_composite(const float *color, const float *sigma, const float *z_vals, c
 
 int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, const float *t, const float *params,
                     int64_t rays_per_param_row, const float *cone_scale, int64_t n_rays, int n_samples, int blur_idx,
-                    uint32_t flags, const float *bkgd, const float *z_vals, float *color_out, float *alpha_out,
-                    float *weights_out, int32_t *status_flag, ntx_stream stream) {
+                    uint32_t flags, const float *bkgd, const float *z_vals, uint64_t perturb_seed, float *color_out,
+                    float *alpha_out, float *weights_out, int32_t *status_flag, ntx_stream stream) {
+    // every check comes before the first launch: a call that fails has written nothing
     if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
     if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
     if (n_samples < 2) return fail(NTX_E_INVALID, "n_samples must be >= 2 (renderer.py:174-177 needs a previous step)");
@@ -705,6 +650,13 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     if (blur_idx < -1 || blur_idx >= np) return fail(NTX_E_INVALID, "blur_idx %d outside [-1,%d)", blur_idx, np);
     if (v.ipe && blur_idx < 0) return fail(NTX_E_INVALID, "an IPE (mip) model needs blur_idx: the cone radius parameter (renderer.py:385)");
     if (blur_idx >= 0 && !cone_scale) return fail(NTX_E_INVALID, "blur_idx set but cone_scale is NULL");
+    if ((size_t)n_rays > ctx->hit_cap)
+        return fail(NTX_E_INVALID, "n_rays %lld exceeds the %zu rays this context reserved; call ntx_reserve first", (long long)n_rays, ctx->hit_cap);
+    const bool x3 = (flags & NTX_FLAG_FP16X3) != 0;
+    // the per-ray direction vector is valid unless the blur scaling hits an APPEARANCE parameter per sample (renderer.py:155-158)
+    const bool dir_const = v.cd && (blur_idx < 0 || blur_idx < v.n_geo || v.ipe);
+    if (x3 && v.cd && !dir_const)
+        return fail(NTX_E_UNSUPPORTED, "fp16x3: blur_idx %d scales an appearance parameter per sample; use float32", blur_idx);
     RenderArgs a{};
     a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed);
     a.stream_bytes = (uint32_t)(ctx->stream_floats * sizeof(float));
@@ -714,71 +666,30 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     a.n_rays = n_rays; a.rays_per_row = rays_per_param_row;
     a.n_samples = n_samples; a.blur_idx = blur_idx; a.flags = flags;
     a.delta = (1.0f - 0.0f) / (float)(n_samples - 1 + v.ipe);   // mip: S+1 segment edges (renderer.py:374)
+    a.seed_lo = (uint32_t)perturb_seed; a.seed_hi = (uint32_t)(perturb_seed >> 32);
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
-    // Hit-ray compaction (both precisions): culled rays get their final value here, the render kernel walks the list.
-    // The scratch lives in the context, so launches on one context must be stream-ordered.
     hipStream_t st = (hipStream_t)stream;
-    if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "n_rays %lld exceeds int32", (long long)n_rays);
-    HIP_TRY(hipSetDevice(ctx->device));   // scratch must live on the context's device whatever the caller's current one is
-    if (ctx->hit_cap < (size_t)n_rays) {
-        if (ctx->hit_list) HIP_TRY(hipFree(ctx->hit_list));
-        ctx->hit_list = nullptr; ctx->hit_cap = 0;
-        HIP_TRY(hipMalloc((void **)&ctx->hit_list, (size_t)n_rays * sizeof(int32_t)));
-        ctx->hit_cap = (size_t)n_rays;
-    }
-    if (!ctx->hit_count) HIP_TRY(hipMalloc((void **)&ctx->hit_count, 2 * sizeof(int32_t)));   // [0] hits, [1] instance work counter
+    HIP_TRY(hipSetDevice(ctx->device));
+    // Hit-ray compaction: culled rays get their final value here, the render kernel walks the list.  The list lives in the
+    // context, so launches on one context must be stream-ordered.
     HIP_TRY(hipMemsetAsync(ctx->hit_count, 0, sizeof(int32_t), st));
     compact_hits_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st>>>(
         t, n_rays, ctx->hit_list, ctx->hit_count, color_out, alpha_out, flags, a.bkgd[0], a.bkgd[1], a.bkgd[2]);
     HIP_TRY(hipGetLastError());
     a.hit_list = ctx->hit_list; a.hit_count = ctx->hit_count;
-
-    if (ctx->precision == NTX_PRECISION_FP16X3) {
-        // ParamNerf: the colour layer's direction segment always enters as the per-ray bias of dirbias_kernel (float32)
-        if (v.cd) {
-            if (!v.ipe && blur_idx >= v.n_geo)
-                return fail(NTX_E_UNSUPPORTED, "fp16x3: blur_idx %d scales an appearance parameter per sample; use NTX_PRECISION_F32", blur_idx);
-            if (ctx->ray_bias_cap < (size_t)n_rays) {
-                if (ctx->ray_bias) HIP_TRY(hipFree(ctx->ray_bias));
-                ctx->ray_bias = nullptr; ctx->ray_bias_cap = 0;
-                HIP_TRY(hipMalloc((void **)&ctx->ray_bias, (size_t)n_rays * 256 * sizeof(float)));
-                ctx->ray_bias_cap = (size_t)n_rays;
-            }
-            DirBiasArgs d{};
-            d.wstream = a.wstream; d.stream_bytes = a.stream_bytes; d.aux = a.aux;   // the float32 stream
-            d.rays_d = rays_d; d.params = params; d.ray_bias = ctx->ray_bias;
-            d.n_rays = n_rays; d.rays_per_row = rays_per_param_row; d.blur_idx = blur_idx;
-            HIP_TRY(launch_dirbias(ctx, d, st));
-            a.ray_bias = ctx->ray_bias;
-        }
+    const Launchers &L = kLaunch[ctx->variant];
+    if (x3) {
+        // ParamNerf: C1's direction segment always enters as the per-ray vector dir_block computes in float32 from the float32 stream
+        a.dir_wstream = a.wstream; a.dir_stream_bytes = a.stream_bytes;
         a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed16);
         a.stream_bytes = (uint32_t)ctx->packed16_bytes;
-        HIP_TRY(launch_render_x3(ctx, a, st));
+        HIP_TRY(launch(L.render_x3, ctx, a, st));
         return NTX_OK;
     }
-    // Direction features and appearance parameters are per-ray constants (renderer.py:152-154) unless the blur scaling
-    // hits an appearance parameter (:155-158): compute the colour layer's direction segment once per ray (dirbias_kernel)
-    // instead of once per sample.  Scratch: 1 KiB per ray in the context; if it cannot be had, the kernel evaluates the
-    // segment per sample as before -- same bits either way.
-    if (ctx->hoist_dir && v.cd && (blur_idx < 0 || blur_idx < v.n_geo || v.ipe)) {
-        if (ctx->ray_bias_cap < (size_t)n_rays) {
-            if (ctx->ray_bias) HIP_TRY(hipFree(ctx->ray_bias));
-            ctx->ray_bias = nullptr; ctx->ray_bias_cap = 0;
-            if (hipMalloc((void **)&ctx->ray_bias, (size_t)n_rays * 256 * sizeof(float)) == hipSuccess) ctx->ray_bias_cap = (size_t)n_rays;
-            else { ctx->ray_bias = nullptr; (void)hipGetLastError(); }
-        }
-        if (ctx->ray_bias) {
-            DirBiasArgs d{};
-            d.wstream = a.wstream; d.stream_bytes = a.stream_bytes; d.aux = a.aux;
-            d.rays_d = rays_d; d.params = params; d.ray_bias = ctx->ray_bias;
-            d.n_rays = n_rays; d.rays_per_row = rays_per_param_row; d.blur_idx = blur_idx;
-            HIP_TRY(launch_dirbias(ctx, d, (hipStream_t)stream));
-            a.ray_bias = ctx->ray_bias;
-            HIP_TRY(launch_render_hoist(ctx, a, (hipStream_t)stream));
-            return NTX_OK;
-        }
-    }
-    HIP_TRY(launch_render(ctx, a, (hipStream_t)stream));
+    // float32: direction features and appearance parameters are per-ray constants (renderer.py:152-154): the HOIST kernel
+    // evaluates the colour layer's direction segment once per ray (dir_block) instead of once per sample -- same bits
+    if (ctx->hoist_dir && dir_const && L.render_hoist) HIP_TRY(launch(L.render_hoist, ctx, a, st));
+    else HIP_TRY(launch(L.render, ctx, a, st));
     return NTX_OK;
 }
 
@@ -817,25 +728,35 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "n_rays %lld exceeds int32", (long long)n_rays);
     // dynamic ray hand-out: a device counter owned by the context (stream-ordered use, like the other scratch)
     HIP_TRY(hipSetDevice(ctx->device));
-    if (!ctx->hit_count) HIP_TRY(hipMalloc((void **)&ctx->hit_count, 2 * sizeof(int32_t)));   // [0] hits, [1] this counter
-    HIP_TRY(hipMemsetAsync(ctx->hit_count + 1, 0, sizeof(int32_t), (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(ctx->hit_count + 1, 0, sizeof(int32_t), (hipStream_t)stream));   // [0] hits of ntx_render_rays, [1] this counter
     a.work_counter = ctx->hit_count + 1;
-    if (ctx->precision == NTX_PRECISION_FP16X3) {
+    if (flags & NTX_FLAG_FP16X3) {
         // directions are per sample: ParamNerf uses the stream that keeps C1's direction segment; plain Nerf's one stream
         // has it in C2 anyway
-        const uint16_t *s16 = v.cd ? ctx->packed16i : ctx->packed16;
-        if (!s16) return fail(NTX_E_UNSUPPORTED, "fp16x3 precision is not built for this model family");
-        a.wstream = reinterpret_cast<const f32x4 *>(s16);
+        a.wstream = reinterpret_cast<const f32x4 *>(v.cd ? ctx->packed16i : ctx->packed16);
         a.stream_bytes = (uint32_t)(v.cd ? ctx->packed16i_bytes : ctx->packed16_bytes);
-        HIP_TRY(launch_instance_x3(ctx, a, (hipStream_t)stream));
+        HIP_TRY(launch(kLaunch[ctx->variant].instance_x3, ctx, a, (hipStream_t)stream));
         return NTX_OK;
     }
-    HIP_TRY(launch_instance(ctx, a, (hipStream_t)stream));
+    HIP_TRY(launch(kLaunch[ctx->variant].instance, ctx, a, (hipStream_t)stream));
+    return NTX_OK;
+}
+
+int ntx_sample_depths(const float *t, int64_t n_rays, int n_points, uint32_t flags, uint64_t perturb_seed, float *z_out,
+                      ntx_stream stream) {
+    if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
+    if (n_points < 2) return fail(NTX_E_INVALID, "n_points must be >= 2");
+    if (n_rays == 0) return NTX_OK;
+    if (!t || !z_out) return fail(NTX_E_INVALID, "NULL buffer");
+    const int64_t n = n_rays * n_points;
+    sample_depths_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        t, n_rays, n_points, 1.0f / (float)(n_points - 1), flags, (uint32_t)perturb_seed, (uint32_t)(perturb_seed >> 32), z_out);
+    HIP_TRY(hipGetLastError());
     return NTX_OK;
 }
 
 int ntx_sample_pdf(const float *t, const float *z_vals, const float *weights, const float *u, int64_t n_rays,
-                   int n_samples, int n_importance, float *z_out, ntx_stream stream) {
+                   int n_samples, int n_importance, uint32_t flags, uint64_t perturb_seed, float *z_out, ntx_stream stream) {
     if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
     if (n_samples < 3 || n_samples > MAX_PDF_SAMPLES) return fail(NTX_E_INVALID, "n_samples %d outside [3,%d]", n_samples, MAX_PDF_SAMPLES);
     if (n_importance < 1 || n_importance > MAX_PDF_SAMPLES) return fail(NTX_E_INVALID, "n_importance %d outside [1,%d]", n_importance, MAX_PDF_SAMPLES);
@@ -846,6 +767,7 @@ int ntx_sample_pdf(const float *t, const float *z_vals, const float *weights, co
     a.n_rays = n_rays; a.n_samples = n_samples; a.n_imp = n_importance;
     a.delta = 1.0f / (float)(n_samples - 1);
     a.delta_u = n_importance > 1 ? 1.0f / (float)(n_importance - 1) : 0.0f;
+    a.flags = flags; a.seed_lo = (uint32_t)perturb_seed; a.seed_hi = (uint32_t)(perturb_seed >> 32);
     int64_t nb = (n_rays + 3) / 4;
     if (nb > 256 * 8) nb = 256 * 8;
     sample_pdf_kernel<<<dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream>>>(a);

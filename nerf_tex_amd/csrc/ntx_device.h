@@ -1,7 +1,7 @@
 // ntx_device.h -- gfx950 device code of the NeRF-Tex render path (included by nerftex.hip only).
 //
 // Kernels (all float32, one wave64 = one batch of 32 samples, activations in registers):
-//   render_kernel<CFG>      rays -> premultiplied RGBA   (renderer.py:47-213 fused)
+//   render_kernel<CFG,HOIST> rays -> premultiplied RGBA  (renderer.py:47-213 fused)
 //   mlp_kernel<CFG>         (pos, dir, params) -> (raw rgb, raw sigma)   (model.py:58-125)
 //   composite_kernel        map_model_output alone        (renderer.py:170-213)
 //   raygen_kernel           rays_from_camera + Proxy/AABB (ray_sampler.py:23-48, proxy.py:13-35)
@@ -138,12 +138,11 @@ NTX_DEV void init_bias_tile(f32x16 (&acc)[8], const float *aux, int layer, int h
     const f32x4 v0 = b[0], v1 = b[1], v2 = b[2], v3 = b[3];
     acc[MT] = f32x16{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
 }
-// same from a row in GLOBAL memory ([128] floats of this lane's half-wave, accumulator order): the colour layer's bias,
-// which for hoisted direction features is a per-ray vector (dirbias_kernel)
+// same from a 256-float row in LDS ([half][128], accumulator order): the colour layer's bias, which for hoisted direction
+// features is a per-ray vector (dir_block)
 template <int MT>
-NTX_DEV void init_bias_tile_g(f32x16 (&acc)[8], const float *row) {
-    typedef const __attribute__((address_space(1))) f32x4 *gptr;   // global_load, not flat_load (the pointer comes out of the kernarg struct)
-    const gptr b = (gptr)(uintptr_t)row + MT * 4;
+NTX_DEV void init_bias_tile_row(f32x16 (&acc)[8], const float *row, int h) {
+    const f32x4 *b = reinterpret_cast<const f32x4 *>(row + h * 128) + MT * 4;
     const f32x4 v0 = b[0], v1 = b[1], v2 = b[2], v3 = b[3];
     acc[MT] = f32x16{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
 }
@@ -356,9 +355,9 @@ struct Cfg {
 // Two accumulator sets (2 x 128 AGPRs) alternate between layers: layer n's result is moved out of one set
 // (bias already in, ReLU, into `hin`) in one dense block before layer n+1 starts accumulating into the
 // other, and the drained set is re-initialised tile by tile with the bias of layer n+2 while layer n+1 runs.
-// HOIST (render kernel, ParamNerf): the accumulators of the colour layer C1 start from `c1_row` in global memory
-// ([half][128], accumulator order) = the per-ray vector bias_C1 + W_dir^T dir_map that dirbias_kernel computed with this
-// very code, and the direction segment is skipped (its records are still fetched, to keep the ring phase).  A
+// HOIST (render kernel, ParamNerf): the accumulators of the colour layer C1 start from `c1_row` in LDS
+// ([half][128], accumulator order) = the per-ray vector bias_C1 + W_dir^T dir_map that dir_block computed with the same
+// instructions, and the direction segment is skipped (its records are still fetched, to keep the ring phase).  A
 // compile-time variant, not a run-time branch: a branch around the segment made hipcc spill 1 KiB per lane.
 template <class CFG, bool HOIST = false>
 NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
@@ -402,7 +401,7 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
         auto reinit = [&](auto S, auto MT) {
             constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
             if constexpr (init_next && mt == 1 && (s & 15) == 0) {
-                if constexpr (HOIST && CFG::CD != 0 && next_bias == 9) init_bias_tile_g<(s >> 4)>(prev, c1_row + h * 128);
+                if constexpr (HOIST && CFG::CD != 0 && next_bias == 9) init_bias_tile_row<(s >> 4)>(prev, c1_row + opaque_zero, h);
                 else init_bias_tile<(s >> 4)>(prev, aux, next_bias, h);
             }
         };
@@ -586,11 +585,14 @@ struct RenderArgs {
     uint32_t flags;
     float delta;   // float32(1 / (S - 1)): the step of tf.linspace(0., 1., S)
     float bkgd[3];
-    const float *ray_bias;   // NULL, or [n_rays][2][128]: per-ray bias of the colour layer incl. the direction features (dirbias_kernel)
-    // NULL, or the compacted indices of the rays with t0 != inf and their number (compact_hits_kernel, which has then
-    // already written the culled rays): every wave gets the same number of rays to march, however the misses are
-    // distributed over the image
+    // the compacted indices of the rays with t0 != inf and their number (compact_hits_kernel, which has then already
+    // written the culled rays): every wave gets the same number of rays to march, however the misses are distributed
+    // over the image
     const int32_t *hit_list, *hit_count;
+    uint32_t seed_lo, seed_hi;   // NTX_FLAG_PERTURB: key of the counter-based generator behind the stratified jitter
+    // fp16x3 kernels only: the float32 stream, whose records of C1's direction segment dir_block multiplies
+    const f32x4 *dir_wstream;
+    uint32_t dir_stream_bytes;
 };
 
 // the by-value kernel argument struct, addressed in the kernarg segment (device pass only)
@@ -603,20 +605,119 @@ NTX_DEV const T *kernargs() {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// sample depths (renderer.py:101-111)
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11; the generator behind tf.random.uniform), word 0 of the block at `ctr` under
+// `key`.  Counter-based: the draw for (ray, sample) is a pure function of (seed, ray, sample), so the jitter needs no
+// state, no [N,S] tensor and is independent of how rays are split over launches, waves or GPUs.
+NTX_DEV uint32_t philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+// uniform float32 in [0,1) from 23 random bits, as tf.random.uniform makes it (random_distributions.h Uint32ToFloat)
+NTX_DEV float uniform01(uint32_t x) { return __builtin_bit_cast(float, (x & 0x7fffffu) | 0x3f800000u) - 1.0f; }
+
 // depth i of the npts points of tf.linspace between t0 and t1 (npts = S samples, or S+1 segment edges for the mip
-// renderer, renderer.py:374-376); a.delta = float32(1 / (npts - 1))
+// renderer, renderer.py:374-376); delta = float32(1 / (npts - 1))
+NTX_DEV float z_lin(float delta, int i, float t0, float t1, int npts) {
+    const float tv = i == 0 ? 0.0f : (i == npts - 1 ? 1.0f : delta * (float)i);
+    return t0 * (1.0f - tv) + t1 * tv;   // renderer.py:102
+}
+// the same with the stratified jitter of renderer.py:106-111 / 379-383: uniform in [lower_i, upper_i), the midpoints to
+// the neighbouring depths (the end points themselves at both ends); z_rand = the Philox draw at counter (i, ray)
+NTX_DEV float z_jittered(float delta, int64_t ray, int i, float t0, float t1, int npts, uint32_t seed_lo, uint32_t seed_hi) {
+    const float zc = z_lin(delta, i, t0, t1, npts);
+    const float lower = i == 0 ? zc : 0.5f * (zc + z_lin(delta, i - 1, t0, t1, npts));
+    const float upper = i == npts - 1 ? zc : 0.5f * (z_lin(delta, i + 1, t0, t1, npts) + zc);
+    const float u = uniform01(philox4x32_10((uint32_t)i, (uint32_t)ray, (uint32_t)((uint64_t)ray >> 32), 0u, seed_lo, seed_hi));
+    return lower + (upper - lower) * u;
+}
 NTX_DEV float z_of(const RenderArgs &a, int64_t ray, int i, float t0, float t1, int npts) {
     if (a.z_vals) return a.z_vals[ray * npts + i];
-    const float tv = i == 0 ? 0.0f : (i == npts - 1 ? 1.0f : a.delta * (float)i);
-    return t0 * (1.0f - tv) + t1 * tv;   // renderer.py:102
+    if (a.flags & NTX_FLAG_PERTURB) return z_jittered(a.delta, ray, i, t0, t1, npts, a.seed_lo, a.seed_hi);
+    return z_lin(a.delta, i, t0, t1, npts);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-ray-constant direction features hoisted out of the per-sample network.  In Renderer.evaluate_model the view
+// direction and the appearance parameters are repeated for every sample of a ray (renderer.py:152-154), so the
+// direction segment of the colour layer, W_C1[:dir_map]^T dir_map, is one [256] vector per ray: 328 of 10 638 MFMAs and
+// 41 of 113 encoder k-steps per 32-sample batch that need not be repeated.  dir_block computes bias_C1 + that vector for
+// the next 32 rays of a WORKGROUP (8 per wave) straight into LDS: lane = ray slot, each of the 4 waves takes 2 of the 8
+// output tiles, same bias initialisation, same k-order, same generator as the per-sample evaluation -- an output column
+// of the MFMA depends only on its own B column, so starting the C1 accumulators from the stored row is bit-identical
+// to evaluating the segment per sample.  No global scratch, no extra launch, no HBM traffic; one pair of workgroup
+// barriers per 8 rays of each wave.  Not applicable when blur_idx scales an APPEARANCE parameter per sample
+// (renderer.py:155-158); the host then launches the HOIST = false kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int DIR_BLOCK_ITERS = 8;                 // rays per wave and block
+constexpr int DIR_BLOCK_RAYS = 4 * DIR_BLOCK_ITERS;   // = 32 = one MFMA's worth of B columns
+constexpr int DIR_ROW_STRIDE = 256 + 4;            // floats; +4: the 32 lanes' b128 stores spread over the LDS banks
+constexpr int DIR_BLOCK_FLOATS = DIR_BLOCK_RAYS * DIR_ROW_STRIDE;
+
+// rows[slot] for slot = it * 4 + w  <->  hit number base + it * nwaves_total + 4 * workgroup + w
+template <class CFG>
+NTX_DEV void dir_block(const RenderArgs &a, __amdgpu_buffer_rsrc_t rsrc, const float *aux, float *rows, int base, int nwaves,
+                       int wg, int wv, int lane, int n_work) {
+    static_assert(CFG::CD != 0, "ParamNerf families");
+    const int j = lane & 31, h = lane >> 5;
+    int idx = base + (j >> 2) * nwaves + 4 * wg + (j & 3);
+    idx = idx < n_work ? idx : n_work - 1;
+    const int64_t ray = a.hit_list[idx];
+    const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+    const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);   // as the render kernel (renderer.py:98)
+    SampleIn<CFG::NGEO, CFG::NAPP> in;
+    in.pos[0] = in.pos[1] = in.pos[2] = 0.0f;
+    in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
+    in.dir[0] = dx / dnorm; in.dir[1] = dy / dnorm; in.dir[2] = dz / dnorm;
+    const float *prow = a.params + (ray / a.rays_per_row) * CFG::NP_IN;
+#pragma unroll
+    for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[(CFG::IPE != 0 && k >= a.blur_idx) ? k + 1 : k];
+    // tiles 2 wv and 2 wv + 1: elements (2 wv) % 4, +1 of record 2 s + wv / 2 of k-step s
+    const int t0 = 2 * wv;
+    f32x16 acc0, acc1;
+    {
+        const f32x4 *b = reinterpret_cast<const f32x4 *>(aux + 9 * AUX_BIAS_STRIDE + h * 128) + t0 * 4;
+        const f32x4 v0 = b[0], v1 = b[1], v2 = b[2], v3 = b[3], v4 = b[4], v5 = b[5], v6 = b[6], v7 = b[7];
+        acc0 = f32x16{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+        acc1 = f32x16{v4.x, v4.y, v4.z, v4.w, v5.x, v5.y, v5.z, v5.w, v6.x, v6.y, v6.z, v6.w, v7.x, v7.y, v7.z, v7.w};
+    }
+    constexpr int REC0 = CFG::rec_pass(9);
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const uint32_t rec_base = (uint32_t)(REC0 + (wv >> 1)) * 1024u;
+    const bool odd = wv & 1;
+    static_for<CFG::DS>([&](auto S) {
+        constexpr int s = S;
+        const i32x4 wi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, rec_base + (uint32_t)s * 2048u, 0);
+        const f32x4 w = __builtin_bit_cast(f32x4, wi);
+        const float b = dir_feature<CFG::NGEO, CFG::NAPP, s>(in, h);
+        acc0 = mfma32(odd ? w.z : w.x, b, acc0);
+        acc1 = mfma32(odd ? w.w : w.y, b, acc1);
+    });
+    // lane (slot j, half h), register r of tile t = feature hidden_row(16 t + r, h) of ray slot j -> rows[j][h][16 t + r]
+    f32x4 *o = reinterpret_cast<f32x4 *>(rows + j * DIR_ROW_STRIDE + h * 128 + t0 * 16);
+    static_for<4>([&](auto Q) {
+        constexpr int q = Q;
+        o[q] = f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
+        o[4 + q] = f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
+    });
 }
 
 template <class CFG, bool HOIST = false>
 __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     static_assert(!HOIST || CFG::CD != 0, "direction hoisting is for the ParamNerf families");
-    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * PE_KEEP_FLOATS];
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * PE_KEEP_FLOATS + (HOIST ? DIR_BLOCK_FLOATS : 0)];
     load_aux(aux, a.aux, aux_total());
+    float *dir_rows = aux + aux_total() + 4 * PE_KEEP_FLOATS;
     const int lane = threadIdx.x & 63, j = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int nwaves = gridDim.x * 4;
     const int S = a.n_samples;
@@ -624,14 +725,19 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     WStream ws;
     ws_prime(ws, a.wstream, a.stream_bytes, lane);
 
-    const int64_t n_work = a.hit_list ? (int64_t)*a.hit_count : a.n_rays;
-    for (int64_t idx = wave; idx < n_work; idx += nwaves) {
-        const int64_t ray = a.hit_list ? (int64_t)a.hit_list[idx] : idx;
-        if (!a.hit_list && a.t[2 * ray] == __builtin_inff()) {   // culled ray (renderer.py:58-67, 81-86); NaN counts as a hit
-            if (lane < 3) a.color_out[3 * ray + lane] = (a.flags & NTX_FLAG_COMPOSITE_BKGD) ? a.bkgd[lane] : 0.0f;
-            if (lane == 3) a.alpha_out[ray] = 0.0f;
-            continue;
+    // the compacted hit list is walked in blocks of DIR_BLOCK_ITERS rounds of one ray per wave; `base` and the trip
+    // count of this loop are uniform over the workgroup (the barriers of the HOIST variant sit in it)
+    const int n_work = *a.hit_count;
+    for (int base = 0; base < n_work; base += DIR_BLOCK_ITERS * nwaves) {
+        if constexpr (HOIST) {
+            __syncthreads();   // every wave is done with the previous block's rows
+            dir_block<CFG>(a, ws.rsrc, aux, dir_rows, base, nwaves, blockIdx.x, wv, lane, n_work);
+            __syncthreads();
         }
+      for (int it = 0; it < DIR_BLOCK_ITERS; ++it) {
+        const int idx = base + it * nwaves + wave;
+        if (idx >= n_work) break;
+        const int64_t ray = (int64_t)a.hit_list[idx];
         RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         for (int b = 0; b < nb; ++b) {
             // The ray's own data is re-read (scalar loads, L2-resident) for every batch instead of staying live
@@ -685,8 +791,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
                 for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[k < blur_idx ? k : k + 1];
             }
             float sigma, raw[3];
-            float *pe = pe_column<CFG>(aux, threadIdx.x >> 6, lane);
-            if constexpr (HOIST) mlp_batch<CFG, true>(in, ws, aux, lane, sigma, raw, q.ray_bias + r * 256, pe);
+            float *pe = pe_column<CFG>(aux, wv, lane);
+            if constexpr (HOIST) mlp_batch<CFG, true>(in, ws, aux, lane, sigma, raw, dir_rows + (it * 4 + wv) * DIR_ROW_STRIDE, pe);
             else mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe);
             const RenderArgs *ap2 = kernargs<RenderArgs>();
             asm volatile("" : "+s"(ap2));
@@ -706,68 +812,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
                 if (!(__builtin_fabsf(s) <= 3.0e38f)) atomicOr(a.status, 1);
             }
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// per-ray-constant direction features hoisted out of the per-sample network.  In Renderer.evaluate_model the view
-// direction and the appearance parameters are repeated for every sample of a ray (renderer.py:152-154), so the
-// direction segment of the colour layer, W_C1[:dir_map]^T dir_map, is one [256] vector per ray.  This kernel computes
-// bias_C1 + that vector for 32 RAYS per wave (lane = ray) with the very code the fused kernel runs per sample
-// (init_bias + run_segment over the same records with the same generator), so the fused kernel starting its C1
-// accumulators from the stored vector is bit-identical to evaluating the segment per sample -- 328 of 10 638 MFMAs and
-// 41 of 113 encoder k-steps per 32-sample batch less.  Not applicable when blur_idx scales an APPEARANCE parameter per
-// sample (renderer.py:155-158); the host then leaves ray_bias NULL.
-// ---------------------------------------------------------------------------------------------
-struct DirBiasArgs {
-    const f32x4 *wstream;
-    uint32_t stream_bytes;
-    const float *aux;
-    const float *rays_d, *params;
-    float *ray_bias;          // [n_rays][2][128]
-    int64_t n_rays, rays_per_row;
-    int blur_idx;             // mip families: the parameter spliced out of the model's inputs (renderer.py:385-386)
-};
-
-template <class CFG>
-__global__ __launch_bounds__(256) void dirbias_kernel(DirBiasArgs a) {
-    static_assert(CFG::CD != 0, "ParamNerf families");
-    __shared__ __attribute__((aligned(16))) float aux[aux_total()];
-    load_aux(aux, a.aux, aux_total());
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int nwaves = gridDim.x * 4;
-    constexpr int REC0 = CFG::rec_pass(9);
-    WStream ws;
-    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(a.wstream), 0, a.stream_bytes, 0x00020000);
-    ws.voff = (uint32_t)lane * 16u;
-    auto none = [](auto, auto) {};
-    for (int64_t blk = wave; blk * 32 < a.n_rays; blk += nwaves) {
-        const int64_t ray = blk * 32 + j < a.n_rays ? blk * 32 + j : a.n_rays - 1;
-        const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
-        const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);   // as render_kernel (renderer.py:98)
-        SampleIn<CFG::NGEO, CFG::NAPP> in;
-        in.pos[0] = in.pos[1] = in.pos[2] = 0.0f;
-        in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
-        in.dir[0] = dx / dnorm; in.dir[1] = dy / dnorm; in.dir[2] = dz / dnorm;
-        const float *prow = a.params + (ray / a.rays_per_row) * CFG::NP_IN;
-#pragma unroll
-        for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[(CFG::IPE != 0 && k >= a.blur_idx) ? k + 1 : k];
-        f32x16 acc[8];
-        init_bias<8>(acc, aux, 9, h);
-        static_for<RING>([&](auto I) { ws.ring[(REC0 + I) % RING] = ws_load(ws, REC0 + I); });
-        DirGen<CFG::NGEO, CFG::NAPP> gen{in, h, {}};
-        run_segment<CFG::DS, 8, REC0>(acc, ws, gen, none);
-        if (blk * 32 + j < a.n_rays) {
-            f32x4 *o = reinterpret_cast<f32x4 *>(a.ray_bias + ray * 256 + h * 128);
-            static_for<8>([&](auto T) {
-                constexpr int t = T;
-                static_for<4>([&](auto Q) {
-                    constexpr int q = Q;
-                    o[t * 4 + q] = f32x4{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-                });
-            });
-        }
+      }
     }
 }
 

@@ -268,10 +268,9 @@ NTX_DEV void skip_stage(WShared &ws) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// WD = false (render kernel): the colour layer C1 starts from the per-ray vector (dirbias_kernel) that the caller has
-// staged in LDS at aux[c1_off .. c1_off + 256) ([half][128], accumulator order; reading it from global memory inside
-// the pass made hipcc park whole bias tiles in scratch, 30 GB per launch) and has no
-// direction segment; WD = true (instanced kernel, per-sample directions): static bias, direction segment evaluated.
+// WD = false (render kernel): the colour layer C1 starts from the per-ray vector that dir_block (ntx_device.h) left in
+// LDS at aux[c1_off .. c1_off + 256) ([half][128], accumulator order) and has no direction segment; WD = true
+// (instanced kernel, per-sample directions): static bias, direction segment evaluated.
 template <class CFG, bool WD = false>
 NTX_DEV void mlp_batch_x3(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &ws, const float *aux_in, int lane,
                             float &sigma, float (&rgb)[3], int c1_off) {
@@ -304,7 +303,7 @@ NTX_DEV void mlp_batch_x3(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &ws,
         constexpr int rec0 = G16::rec_pass(li);
         constexpr bool has_pos = li == SKIP + 1;
         constexpr bool init_next = li < NPASS;
-        // ParamNerf's colour layer C1 (li = 9) starts from the per-ray vector bias_C1 + W_dir^T dir_map (dirbias_kernel,
+        // ParamNerf's colour layer C1 (li = 9) starts from the per-ray vector bias_C1 + W_dir^T dir_map (dir_block,
         // float32): its direction segment is not evaluated per sample
         constexpr bool next_is_c1 = CFG::CD != 0 && !WD && li + 1 == 9;
         constexpr bool has_dir = CFG::CD != 0 && WD && li == 9;
@@ -391,7 +390,7 @@ template <class CFG>
 __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
     using G16 = Cfg16<CFG>;
     __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
-    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * 256];   // + one per-ray C1 vector per wave
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + (CFG::CD ? DIR_BLOCK_FLOATS : 0)];   // + the block's per-ray C1 vectors
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -404,7 +403,15 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
     WShared ws;
     ws_prime<G16::NST>(ws, a.wstream, a.stream_bytes, (lds_char *)ring, lane, wv);
 
+    __amdgpu_buffer_rsrc_t dir_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(a.dir_wstream), 0, a.dir_stream_bytes, 0x00020000);
     for (int it = 0; it < iters; ++it) {
+        if constexpr (CFG::CD != 0) {
+            if (it % DIR_BLOCK_ITERS == 0) {   // the C1 start vectors of the next 8 rays of each wave (float32, as the f32 kernel)
+                __syncthreads();
+                dir_block<CFG>(a, dir_rsrc, aux, aux + aux_total(), it * per_it, per_it, blockIdx.x, wv, lane, n_hit);
+                __syncthreads();
+            }
+        }
         const int idx = it * per_it + blockIdx.x * 4 + wv;
         const bool live = idx < n_hit;
         const int64_t ray = a.hit_list[live ? idx : n_hit - 1];
@@ -452,12 +459,7 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
                 for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[k < blur_idx ? k : k + 1];
             }
             float sigma, raw[3];
-            if constexpr (CFG::CD != 0) {   // this ray's [2][128] vector: 64 lanes x 16 bytes, global -> LDS
-                reinterpret_cast<f32x4 *>(aux + aux_total() + wv * 256)[lane] = reinterpret_cast<const f32x4 *>(q.ray_bias + r * 256)[lane];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            mlp_batch_x3<CFG>(in, ws, aux, lane, sigma, raw, aux_total() + wv * 256);
+            mlp_batch_x3<CFG>(in, ws, aux, lane, sigma, raw, aux_total() + ((it % DIR_BLOCK_ITERS) * 4 + wv) * DIR_ROW_STRIDE);
             const RenderArgs *ap2 = kernargs<RenderArgs>();
             asm volatile("" : "+s"(ap2));
             composite_step<32>(ra, sigma, raw, dist, valid && live, ap2->flags, j,

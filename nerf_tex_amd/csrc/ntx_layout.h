@@ -15,7 +15,7 @@
 // with a quadrant shift in the upper half-wave.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NTX_HD __host__ __device__
 #else
 #define NTX_HD
@@ -152,7 +152,7 @@ NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth, i
 // (k16-step, M-tile); the stream holds, per k16-step and tile, the hi record then the lo record of the split
 // w = hi + lo (hi = fp16_rne(w), lo = fp16_rne(w - hi), IEEE half with subnormals).  Within a pass the hidden segment comes first, the encoder
 // segment second; the direction segment of ParamNerf's colour layer C1 is NOT in the stream: it is a per-ray constant
-// and enters through the per-ray bias vector of dirbias_kernel (float32).  The 4 waves of a workgroup share the stream through an LDS ring of NSTAGE16 STAGES of STAGE16
+// and enters through the per-ray start vector of dir_block (float32, ntx_device.h).  The 4 waves of a workgroup share the stream through an LDS ring of NSTAGE16 STAGES of STAGE16
 // records (one k16-step of an 8-tile layer); the stream is zero-padded to a whole number of ring turns, so the stage ->
 // ring-slot map is the same for every batch and the prefetch simply wraps to stage 0.  The aux block is the f32 one.
 constexpr int STAGE16 = 16;    // records per stage

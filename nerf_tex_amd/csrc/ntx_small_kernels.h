@@ -63,13 +63,14 @@ struct RaygenArgs {
     float focal, half_w, half_h, near_t, far_t;
     int width, mode;
     int64_t pixel0, n;
+    int64_t run_length, run_stride;   // local ray k = pixel pixel0 + (k / run_length) * run_stride + k % run_length
     float *rays_o, *rays_d, *t, *cone;
 };
 
 __global__ __launch_bounds__(256) void raygen_kernel(RaygenArgs a) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.n) return;
-    const int64_t pix = a.pixel0 + k;
+    const int64_t pix = a.pixel0 + (k / a.run_length) * a.run_stride + k % a.run_length;
     const float li = (float)(pix / a.width), lj = (float)(pix % a.width);   // (row, col), Full sampler
     const float d0 = (lj + 0.5f - a.half_w) / a.focal;                       // ray_sampler.py:41
     const float d1 = -(li + 0.5f - a.half_h) / a.focal;
@@ -198,6 +199,7 @@ struct SamplePdfArgs {
     int64_t n_rays;
     int n_samples, n_imp;
     float delta, delta_u;   // float32 steps of tf.linspace(0,1,S) and tf.linspace(0,1,n_imp)
+    uint32_t flags, seed_lo, seed_hi;   // NTX_FLAG_PERTURB: the coarse depths carry the jitter of the render kernel
 };
 
 __global__ __launch_bounds__(256) void sample_pdf_kernel(SamplePdfArgs a) {
@@ -215,8 +217,8 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(SamplePdfArgs a) {
         }
         auto z_at = [&](int i) -> float {
             if (a.z_vals) return a.z_vals[ray * S + i];
-            const float tv = i == 0 ? 0.0f : (i == S - 1 ? 1.0f : a.delta * (float)i);
-            return t0 * (1.0f - tv) + t1 * tv;
+            if (a.flags & NTX_FLAG_PERTURB) return z_jittered(a.delta, ray, i, t0, t1, S, a.seed_lo, a.seed_hi);
+            return z_lin(a.delta, i, t0, t1, S);
         };
         const float *w = a.weights + ray * S;
         // pdf over the S-2 interior weights (+1e-5), cdf with a leading 0: S-1 entries; bins = S-1 midpoints
@@ -324,6 +326,20 @@ __global__ __launch_bounds__(256) void compact_hits_kernel(const float *t, int64
         color_out[3 * i + 0] = bk ? b0 : 0.0f; color_out[3 * i + 1] = bk ? b1 : 0.0f; color_out[3 * i + 2] = bk ? b2 : 0.0f;
         alpha_out[i] = 0.0f;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sample depths alone (renderer.py:101-111 / 374-383): the z_vals the fused kernels place internally, for parity
+// tests and for callers that want them.  Thread per (ray, point).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_depths_kernel(const float *t, int64_t n_rays, int npts, float delta, uint32_t flags,
+                                                            uint32_t seed_lo, uint32_t seed_hi, float *z_out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_rays * npts) return;
+    const int64_t ray = k / npts;
+    const int i = (int)(k % npts);
+    const float t0 = t[2 * ray], t1 = t[2 * ray + 1];
+    z_out[k] = (flags & NTX_FLAG_PERTURB) ? z_jittered(delta, ray, i, t0, t1, npts, seed_lo, seed_hi) : z_lin(delta, i, t0, t1, npts);
 }
 
 }  // namespace ntx

@@ -34,10 +34,6 @@ hipError_t NTX_FN(launch_render_hoist)(int n_wgs, RenderArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t NTX_FN(launch_dirbias)(int n_wgs, DirBiasArgs &a, hipStream_t st) {
-    dirbias_kernel<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
-    return hipGetLastError();
-}
 #else
 hipError_t NTX_FN(launch_render)(int n_wgs, RenderArgs &a, hipStream_t st) {
     render_kernel<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);

@@ -76,6 +76,8 @@ class Dataset:
         common = {"height": self.height, "width": self.width, "focal": self.focal, "proxy": proxy, "step": step}
         pixel_sampler_config.update(common)
         self.pixel_sampler = util.instantiate(pixel_sampler_config)
+        if ray_sampler_config is None:       # dataset.py:24,35 allow it (image-only datasets); the render path needs rays
+            raise NotImplementedError("a Dataset without ray_sampler_config yields no rays; the render path needs one")
         ray_sampler_config.update(common)
         self.ray_sampler = util.instantiate(ray_sampler_config)
         self.batchsize = batchsize

@@ -26,8 +26,9 @@ class FourierFeatures:
         x = inputs.contiguous().float()
         m, d = x.shape
         out = torch.empty((m, self.out_dim(d)), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib.ntx_fourier_features(x.data_ptr(), m, d, self.n_freq_bands, out.data_ptr(),
-                                                 torch.cuda.current_stream(x.device).cuda_stream))
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib.ntx_fourier_features(x.data_ptr(), m, d, self.n_freq_bands, out.data_ptr(),
+                                                     torch.cuda.current_stream(x.device).cuda_stream))
         return out
 
 

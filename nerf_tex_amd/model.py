@@ -2,8 +2,9 @@
 
 `ParamNerf` / `Nerf` / `CoarseFine` keep the reference's signatures and return `{name: model}`
 exactly like model.py:45,56,125, so `renderer_config.update(model)` (render.py:24) works unchanged.
-The model object holds the weights in the reference's own layout (Keras `get_weights()` order:
-kernel[in,out], bias[out] per Dense layer in creation order) and, per device, a context of the HIP
+The model object holds the weights in the reference's own layout (`tf.keras.Model.get_weights()`:
+kernel[in,out], bias[out] per Dense layer in the order of `model.layers`, which a functional model sorts
+by graph depth -- the alpha head is LAST, see `layer_table`) and, per device, a context of the HIP
 library holding the packed image.  Calling it runs the fused MLP kernel (`ntx_mlp_forward`).
 """
 
@@ -32,6 +33,7 @@ class NerfModel:
         self.depth, self.width, self.skips, self.color_depth = depth, width, tuple(skips), color_depth
         self.name = name
         self._ctx: Dict[int, int] = {}
+        self._cap: Dict[int, int] = {}            # rays reserved per context beyond the library default
         self._blob = np.zeros(self.n_weight_floats(), dtype=np.float32)
         self.initialize()
 
@@ -50,12 +52,16 @@ class NerfModel:
         return 3 * (1 + 2 * self.dir_freq) + self.n_app * (1 + 2 * self.param_freq)
 
     def layer_table(self) -> List[Tuple[str, int, int]]:
-        """(name, in, out) per Dense layer in creation order (model.py:104-123 / 28-43)."""
+        """(name, in, out) per Dense layer in the order of `tf.keras.Model.layers` / `get_weights()` for the model
+        model.py:125 / 45 builds.  A functional model sorts layers by graph depth (distance to an output), ties by the
+        order a traversal from `outputs=[color_outputs, alpha_outputs]` meets them: the trunk, the feature layer, the
+        colour layers, `color`, and only then `alpha` -- although `alpha` is CREATED before the feature layer
+        (model.py:111 vs 114).  The checkpoint keys `layer_with_weights-k` (logger.py:30-39) count in the same order."""
         rows, k = [], self.pos_map_dim
         for i in range(self.depth):
             rows.append((f"trunk{i}", k, self.width))
             k = self.width + (self.pos_map_dim if i in self.skips else 0)
-        rows.append(("alpha", k, 1))
+        k_head = k
         rows.append(("feature", k, self.width))
         k = self.width + self.dir_map_dim
         if self.kind == KIND_PARAMNERF:
@@ -64,6 +70,7 @@ class NerfModel:
                 k = self.width
         rows.append(("color_half", k, self.width // 2))
         rows.append(("color", self.width // 2, 3))
+        rows.append(("alpha", k_head, 1))
         return rows
 
     def n_weight_floats(self) -> int:
@@ -135,12 +142,22 @@ class NerfModel:
             self._ctx[device_index] = handle.value
         return self._ctx[device_index]
 
+    def reserve(self, device_index: int, n_rays: int) -> None:
+        """Make the context of `device_index` accept `n_rays` rays per `ntx_render_rays` call (`ntx_reserve`: setup-time,
+        synchronising; grows only)."""
+        from . import _lib
+        cap = self._cap.get(device_index, _lib.DEFAULT_MAX_RAYS)
+        if n_rays > cap:
+            _lib.check(_lib.lib.ntx_reserve(self.ctx(device_index), int(n_rays)))
+            self._cap[device_index] = int(n_rays)
+
     def close(self) -> None:
         if self._ctx:
             from . import _lib
             for ctx in self._ctx.values():
                 _lib.lib.ntx_destroy(ctx)
             self._ctx = {}
+            self._cap = {}
 
     def __del__(self):
         try:
@@ -166,11 +183,12 @@ class NerfModel:
         color = torch.empty((m, 3), device=dev, dtype=torch.float32)
         alpha = torch.empty((m, 1), device=dev, dtype=torch.float32)
         # `self.precision` ("float32" default, or "fp16x3"): arithmetic of the Dense layers for direct calls of the model
-        _lib.check(_lib.lib.ntx_set_precision(self.ctx(dev.index or 0), _lib.PRECISIONS[getattr(self, "precision", "float32")]))
-        _lib.check(_lib.lib.ntx_mlp_forward(self.ctx(dev.index or 0), pos.data_ptr(), dirs.data_ptr(),
-                                            params.data_ptr() if self.n_params > 0 else None, m,
-                                            color.data_ptr(), alpha.data_ptr(),
-                                            torch.cuda.current_stream(dev).cuda_stream))
+        flags = _lib.PRECISIONS[getattr(self, "precision", "float32")]
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.ntx_mlp_forward(self.ctx(dev.index or 0), pos.data_ptr(), dirs.data_ptr(),
+                                                params.data_ptr() if self.n_params > 0 else None, m, flags,
+                                                color.data_ptr(), alpha.data_ptr(),
+                                                torch.cuda.current_stream(dev).cuda_stream))
         return color, alpha
 
 

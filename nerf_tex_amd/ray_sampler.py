@@ -12,7 +12,7 @@ def _generate(pixel_range: Tuple[int, int], height: int, width: int, focal: floa
               near: float, far: float, device=None):
     import torch
     from . import _lib
-    first, count = pixel_range
+    first, count, run, stride = pixel_range if len(pixel_range) == 4 else (pixel_range[0], pixel_range[1], max(1, pixel_range[1]), max(1, pixel_range[1]))
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     rays_o = torch.empty((count, 3), device=dev, dtype=torch.float32)
     rays_d = torch.empty((count, 3), device=dev, dtype=torch.float32)
@@ -22,12 +22,12 @@ def _generate(pixel_range: Tuple[int, int], height: int, width: int, focal: floa
     if c2w_h.shape != (4, 4):
         raise ValueError(f"c2w must be 4x4, got {c2w_h.shape}")
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib.ntx_generate_rays(c2w_h.ctypes.data_as(C.POINTER(C.c_float)), height, width,
-                                              float(np.float32(focal)), first, count, mode,
-                                              _lib.f3(b0) if b0 is not None else None,
-                                              _lib.f3(b1) if b1 is not None else None, float(near), float(far),
-                                              rays_o.data_ptr(), rays_d.data_ptr(), t.data_ptr(), cone.data_ptr(),
-                                              torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(_lib.lib.ntx_generate_rays_strided(c2w_h.ctypes.data_as(C.POINTER(C.c_float)), height, width,
+                                                      float(np.float32(focal)), first, count, run, stride, mode,
+                                                      _lib.f3(b0) if b0 is not None else None,
+                                                      _lib.f3(b1) if b1 is not None else None, float(near), float(far),
+                                                      rays_o.data_ptr(), rays_d.data_ptr(), t.data_ptr(), cone.data_ptr(),
+                                                      torch.cuda.current_stream(dev).cuda_stream))
     return rays_o, rays_d, t, cone
 
 
@@ -49,6 +49,6 @@ class Proxy:
         self.height, self.width, self.focal, self.proxy = height, width, focal, proxy
 
     def __call__(self, image_plane_loc, c2w, device=None):
-        """`image_plane_loc` is the (first_pixel, n_pixels) range produced by `pixel_sampler.Full`."""
+        """`image_plane_loc` is the (first_pixel, n_pixels[, run_length, run_stride]) pixel set produced by `pixel_sampler.Full`."""
         return _generate(image_plane_loc, self.height, self.width, self.focal, c2w, 0, self.proxy.b_0,
                          self.proxy.b_1, 0.0, 0.0, device)

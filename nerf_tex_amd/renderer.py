@@ -69,12 +69,19 @@ class Renderer:
                 raise ValueError(f"parameters must be [B,{P}], got {tuple(parameters.shape)}")
         S = self.n_samples
         n_z = S + 1 if mip else S                          # mip: S+1 segment edges (renderer.py:374)
+        flags = (_lib.FLAG_MAP_EXR if self.map_exr else 0) | (_lib.FLAG_COMPOSITE_BKGD if composite_bkgd else 0)
+        flags |= _lib.PRECISIONS[self.precision]
         z = None
+        seed = 0
         if z_vals is not None:
             z = z_vals.reshape(n, n_z).contiguous().float()
         elif self.perturb:
-            z = self._jitter(t, n_z)                                         # renderer.py:106-111 / 379-383
-        flags = (_lib.FLAG_MAP_EXR if self.map_exr else 0) | (_lib.FLAG_COMPOSITE_BKGD if composite_bkgd else 0)
+            # renderer.py:106-111 / 379-383: the stratified jitter is evaluated inside the kernel (counter-based
+            # generator, include/nerftex.h: ntx_sample_depths); one seed per call, drawn like everything else in
+            # the reference from numpy's global generator (main.py:30 seeds it), or given by the caller
+            flags |= _lib.FLAG_PERTURB
+            seed = int(kwargs["seed"]) if kwargs.get("seed") is not None else self._next_seed()
+        self._last_seed = seed
         status = None
         if self.check_numerics:
             flags |= _lib.FLAG_CHECK_NUMERICS
@@ -87,12 +94,12 @@ class Renderer:
             color = torch.empty((n, 3), device=dev, dtype=torch.float32)
             alpha = torch.empty((n,), device=dev, dtype=torch.float32)
             wts = torch.empty((n, n_s), device=dev, dtype=torch.float32) if want_weights else None
+            model.reserve(dev.index or 0, n)               # setup-time; a no-op once the context has seen this size
             with torch.cuda.device(dev):
-                _lib.check(_lib.lib.ntx_set_precision(model.ctx(dev.index or 0), _lib.PRECISIONS[self.precision]))
                 _lib.check(_lib.lib.ntx_render_rays(
                     model.ctx(dev.index or 0), rays_o.data_ptr(), rays_d.data_ptr(), t.data_ptr(),
                     params.data_ptr() if params is not None else None, HW, cone.data_ptr(), n, n_s, blur, flags,
-                    _lib.f3(bk), z_in.data_ptr() if z_in is not None else None, color.data_ptr(), alpha.data_ptr(),
+                    _lib.f3(bk), z_in.data_ptr() if z_in is not None else None, seed, color.data_ptr(), alpha.data_ptr(),
                     wts.data_ptr() if wts is not None else None, status.data_ptr() if status is not None else None, stream))
             return color, alpha, wts
 
@@ -107,7 +114,8 @@ class Renderer:
             z_all = torch.empty((n, S + NI), device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
                 _lib.check(_lib.lib.ntx_sample_pdf(t.data_ptr(), z.data_ptr() if z is not None else None, wts.data_ptr(),
-                                                   u.data_ptr() if u is not None else None, n, S, NI, z_all.data_ptr(), stream))
+                                                   u.data_ptr() if u is not None else None, n, S, NI,
+                                                   flags & _lib.FLAG_PERTURB, seed, z_all.data_ptr(), stream))
             model_imp = self.model if self.model_fine is None else self.model_fine
             c2, a2, _ = launch(model_imp, S + NI, z_all, False)
             out = {"color_pred": c2.reshape(B, HW, 3), "alpha_pred": a2.reshape(B, HW),
@@ -125,17 +133,22 @@ class Renderer:
             raise FloatingPointError("NaN or Inf encountered in color_pred/alpha_pred")
 
     @staticmethod
-    def _jitter(t, n_samples: int):
-        """Stratified jitter of renderer.py:101-111 (torch RNG stands in for tf.random.uniform; the
-        two streams cannot agree, so parity runs use perturb=False)."""
+    def _next_seed() -> int:
+        import numpy as np
+        return int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
+
+    @staticmethod
+    def sample_depths(t, n_points: int, perturb: bool = False, seed: int = 0):
+        """z_vals of renderer.py:101-111 on their own (`ntx_sample_depths`): t [n,2] -> [n, n_points], exactly the
+        depths the fused kernel places for the same (perturb, seed)."""
         import torch
-        t_vals = torch.linspace(0., 1., n_samples, device=t.device, dtype=torch.float32)
-        z = t[:, None, 0] * (1 - t_vals) + t[:, None, 1] * t_vals
-        z = torch.where(torch.isfinite(z), z, torch.zeros_like(z))           # culled rays: never read
-        mids = .5 * (z[..., 1:] + z[..., :-1])
-        upper = torch.cat([mids, z[..., -1:]], -1)
-        lower = torch.cat([z[..., :1], mids], -1)
-        return (lower + (upper - lower) * torch.rand_like(z)).contiguous()
+        t = t.reshape(-1, 2).contiguous().float()
+        n = t.shape[0]
+        z = torch.empty((n, n_points), device=t.device, dtype=torch.float32)
+        with torch.cuda.device(t.device):
+            _lib.check(_lib.lib.ntx_sample_depths(t.data_ptr(), n, n_points, _lib.FLAG_PERTURB if perturb else 0, int(seed),
+                                                  z.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream))
+        return z
 
     def map_model_output(self, color, alpha, z_vals, rays_d, composite_bkgd: bool, bkgd_color):
         """Renderer.map_model_output (renderer.py:170-213) on its own (`ntx_composite`):
@@ -218,6 +231,7 @@ class InstanceRenderer(Renderer):
         alpha = torch.zeros((n,), device=dev, dtype=torch.float32)
         bk = bkgd_color.detach().cpu().tolist() if hasattr(bkgd_color, "detach") else list(bkgd_color)
         flags = (_lib.FLAG_MAP_EXR if self.map_exr else 0) | (_lib.FLAG_COMPOSITE_BKGD if composite_bkgd else 0)
+        flags |= _lib.PRECISIONS[self.precision]
         status = None
         if self.check_numerics:
             flags |= _lib.FLAG_CHECK_NUMERICS
@@ -248,7 +262,6 @@ class InstanceRenderer(Renderer):
             al_c = torch.empty((k,), device=dev, dtype=torch.float32)
             ptr = lambda x: x.data_ptr() if x is not None else None
             with torch.cuda.device(dev):
-                _lib.check(_lib.lib.ntx_set_precision(self.model.ctx(dev.index or 0), _lib.PRECISIONS[self.precision]))
                 _lib.check(_lib.lib.ntx_render_instanced(
                     self.model.ctx(dev.index or 0), ptr(bufs["rays_d_map"]), ptr(bufs["pts"]), ptr(bufs["t"]),
                     ptr(bufs["dists"]), ptr(bufs["color_last"]), ptr(bufs["alpha_last"]), ptr(bufs["alpha_weight"]),

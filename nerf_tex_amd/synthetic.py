@@ -26,19 +26,24 @@ FAMILIES = {
 
 def synthetic_weights(layer_table: Sequence[Tuple[str, int, int]], seed: int = 0, dense_media: bool = False) -> np.ndarray:
     """Keras-style glorot-uniform kernels, biases U(-0.1, 0.1) (non-zero on purpose), as one flat
-    float32 blob in `layer_table` order.  `dense_media` scales the alpha head x32 and shifts its bias
-    by +0.5 so alpha spans (0, 1] and the composite scan saturates."""
+    float32 blob in `layer_table` order (= Keras `get_weights()` order).  The layers are DRAWN in the order
+    model.py:104-123 creates them (alpha before feature), whatever the table's order, so a layer's values
+    depend only on the seed and its name.  `dense_media` scales the alpha head x32 and shifts its bias by
+    +0.5 so alpha spans (0, 1] and the composite scan saturates."""
     rng = np.random.default_rng(seed)
-    parts = []
-    for name, i, o in layer_table:
+    table = list(layer_table)
+    creation = [r for r in table if r[0].startswith("trunk")] + [r for r in table if r[0] == "alpha"] + \
+               [r for r in table if not r[0].startswith("trunk") and r[0] != "alpha"]
+    drawn = {}
+    for name, i, o in creation:
         lim = np.sqrt(6.0 / (i + o))
         k = rng.uniform(-lim, lim, size=(i, o)).astype(np.float32)
         b = rng.uniform(-0.1, 0.1, size=o).astype(np.float32)
         if dense_media and name == "alpha":
             k = k * np.float32(32.0)
             b = b + np.float32(0.5)
-        parts += [k.ravel(), b]
-    return np.concatenate(parts).astype(np.float32)
+        drawn[name] = [k.ravel(), b]
+    return np.concatenate([a for name, _, _ in table for a in drawn[name]]).astype(np.float32)
 
 
 def all_hit_rays(n_rays: int, b_0, b_1, cam, seed: int = 1):

@@ -54,7 +54,14 @@ static void FN(model_one)(const int *desc, const float *w, const REAL *pos, cons
             k = width;
         }
     }
-    w = FN(dense)(w, h, k, 1, 0, alpha);                               /* :111 */
+    {   /* :111 -- the alpha head is the LAST layer of the get_weights() blob (Keras orders layers by graph depth) */
+        const int c1_in = dm + width;
+        size_t off = (size_t)k * width + width;                                     /* feature */
+        for (int i = 0; i < cd; ++i) off += (size_t)(i ? width : c1_in) * width + width;   /* colour layers */
+        off += (size_t)(cd ? width : c1_in) * (width / 2) + width / 2;              /* colour half */
+        off += (size_t)(width / 2) * 3 + 3;                                         /* color */
+        FN(dense)(w + off, h, k, 1, 0, alpha);
+    }
     w = FN(dense)(w, h, k, width, 0, y);                               /* :114 */
     for (int j = 0; j < dm; ++j) h[j] = dir_map[j];                    /* :115 */
     for (int j = 0; j < width; ++j) h[dm + j] = y[j];

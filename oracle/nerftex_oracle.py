@@ -81,14 +81,17 @@ class ModelSpec:
 
 
 def layer_table(spec: ModelSpec) -> List[Tuple[str, int, int]]:
-    """(name, in, out) of every Dense layer in Keras creation order (= `model.get_weights()` order,
-    each contributing kernel[in,out] then bias[out]).  model.py:104-123 (ParamNerf), 28-43 (Nerf)."""
+    """(name, in, out) of every Dense layer in `tf.keras.Model.get_weights()` order (each contributing
+    kernel[in,out] then bias[out]) for the functional models of model.py:125 (ParamNerf) / :45 (Nerf).
+    Keras sorts `model.layers` by graph depth, ties by traversal order from `outputs=[color, alpha]`
+    (keras/engine/functional.py `_map_graph_network`, TF 2.4): trunk, feature, colour layers, color,
+    and `alpha` LAST -- not the creation order of model.py:104-123, where alpha (:111) precedes feature (:114)."""
     rows = []
     k = spec.pos_map_dim
     for i in range(spec.depth):
         rows.append((f"trunk{i}", k, spec.width))
         k = spec.width + (spec.pos_map_dim if i in spec.skips else 0)
-    rows.append(("alpha", k, 1))
+    k_head = k
     rows.append(("feature", k, spec.width))
     k = spec.width + spec.dir_map_dim
     if spec.kind == "ParamNerf":
@@ -97,6 +100,7 @@ def layer_table(spec: ModelSpec) -> List[Tuple[str, int, int]]:
             k = spec.width
     rows.append(("color_half", k, spec.width // 2))
     rows.append(("color", spec.width // 2, 3))
+    rows.append(("alpha", k_head, 1))
     return rows
 
 
@@ -263,7 +267,7 @@ def model_forward(weights: Sequence[np.ndarray], spec: ModelSpec, pos, dirs, par
     inter["pos_map"], inter["dir_map"] = pos_map, dir_map
 
     w = list(weights)
-    it = iter(range(0, len(w), 2))
+    it = iter(range(0, len(w) - 2, 2))
     h = pos_map
     for i in range(spec.depth):                                                # model.py:104-108
         j = next(it)
@@ -271,8 +275,7 @@ def model_forward(weights: Sequence[np.ndarray], spec: ModelSpec, pos, dirs, par
         inter[f"trunk{i}"] = h
         if i in spec.skips:
             h = np.concatenate([pos_map, h], -1)
-    j = next(it)
-    alpha = _dense(h, w[j], w[j + 1], dtype, relu=False)                       # model.py:111
+    alpha = _dense(h, w[-2], w[-1], dtype, relu=False)                         # model.py:111 (last in get_weights())
     j = next(it)
     h = _dense(h, w[j], w[j + 1], dtype, relu=False)                           # model.py:114
     inter["feature"] = h
@@ -318,6 +321,46 @@ def jitter_bounds(z_vals):
     upper = np.concatenate([mids, z_vals[..., -1:]], -1)
     lower = np.concatenate([z_vals[..., :1], mids], -1)
     return lower, upper
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Word 0 of the Philox4x32-10 block (Salmon et al., SC'11; the generator behind tf.random.uniform) at counter
+    (c0, c1, c2, c3) under key (k0, k1); numpy uint32 arrays, element-wise.  Restated from the published algorithm."""
+    u32, u64 = np.uint32, np.uint64
+    c0, c1, c2, c3 = (np.asarray(c, dtype=u32) for c in np.broadcast_arrays(c0, c1, c2, c3))
+    k0 = u32(k0); k1 = u32(k1)
+    for _ in range(10):
+        p0 = u64(0xD2511F53) * c0.astype(u64)
+        p1 = u64(0xCD9E8D57) * c2.astype(u64)
+        hi0, lo0 = (p0 >> u64(32)).astype(u32), p0.astype(u32)
+        hi1, lo1 = (p1 >> u64(32)).astype(u32), p1.astype(u32)
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = u32((int(k0) + 0x9E3779B9) & 0xFFFFFFFF); k1 = u32((int(k1) + 0xBB67AE85) & 0xFFFFFFFF)
+    return c0
+
+
+def uniform01_from_bits(x):
+    """float32 in [0,1) from the low 23 bits, TensorFlow's Uint32ToFloat (random_distributions.h)."""
+    bits = (np.asarray(x, dtype=np.uint32) & np.uint32(0x7FFFFF)) | np.uint32(0x3F800000)
+    return bits.view(np.float32) - np.float32(1.0)
+
+
+def jitter_uniforms(n_rays: int, n_points: int, seed: int):
+    """The draws the product uses for the stratified jitter (include/nerftex.h: ntx_sample_depths): Philox counter
+    (sample index, ray index lo, ray index hi, 0), key (seed lo, seed hi).  TensorFlow's own stream cannot be
+    reproduced; this pins OUR stream so the jittered render can be compared sample for sample."""
+    ray = np.arange(n_rays, dtype=np.uint64)[:, None]
+    i = np.arange(n_points, dtype=np.uint32)[None, :]
+    bits = philox4x32_10(i, (ray & np.uint64(0xFFFFFFFF)).astype(np.uint32), (ray >> np.uint64(32)).astype(np.uint32),
+                         np.uint32(0), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return uniform01_from_bits(bits)
+
+
+def z_values_perturbed(t, n_points: int, seed: int, dtype=F32):
+    """renderer.py:101-111 with z_rand = jitter_uniforms (float32 draws, arithmetic in `dtype`)."""
+    z = z_values(t, n_points, dtype)
+    lower, upper = jitter_bounds(z)
+    return lower + (upper - lower) * jitter_uniforms(z.shape[0], n_points, seed).astype(dtype)
 
 
 def evaluate_model(weights, spec, pts, dirs, parameters, cone_scale, z_vals, blur_idx, net_chunk, dtype=F32):

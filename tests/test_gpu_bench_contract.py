@@ -35,9 +35,12 @@ def test_default_line_has_the_contract_fields():
     assert abs(d["value"] * d["config"]["flops_per_sample"] / 1e12 - r["achieved"]) / r["achieved"] < 0.02
     x3 = d["fp16x3"]                                    # the opt-in precision, reported beside the headline, never as `value`
     assert x3["value"] > d["value"] and x3["rel_linf_vs_float32_kernel"] < 1e-4
+    jit = d["perturb"]                                  # the reference's default perturb=True, jitter drawn inside the kernel
+    assert jit["value"] > 0.97 * d["value"]
 
 
 def test_cpu_baseline_block():
     d = _run("--workload", "fur")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "ray-samples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["cpu_count"] >= c["cores"] and "BLAS_INFO" in c["blas"]       # threads and BLAS backend stated

@@ -25,7 +25,7 @@ def to_dev(*arrs):
 
 def test_native_library_is_loaded():
     from nerf_tex_amd import _lib
-    assert _lib.lib.ntx_abi_version() == 1
+    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 2
     with open("/proc/self/maps") as f:
         assert "libnerftex_hip.so" in f.read()
 
@@ -318,7 +318,7 @@ def test_edge_cases_empty_culled_minimal():
 
 @pytest.mark.parametrize("family", ["carpet", "grass_filtered"])
 def test_direction_hoisting_is_bit_identical(family, monkeypatch):
-    """ntx_render_rays evaluates the colour layer's direction segment once per ray (dirbias_kernel) instead of once per
+    """ntx_render_rays evaluates the colour layer's direction segment once per ray (dir_block, through LDS) instead of once per
     sample; a context created with NERFTEX_NO_DIR_HOIST evaluates it per sample.  Same bits, and a blur_idx on an
     APPEARANCE parameter (per-sample scaling, renderer.py:155-158) takes the per-sample path by itself."""
     from nerf_tex_amd import synthetic

@@ -1,0 +1,408 @@
+"""HIP paths of the C ABI that the family/parity suites do not reach: Frustum rays, the AABB's IEEE corner cases on
+the kernel, the in-kernel stratified jitter, cone-filter conditioning at S = 128, full-size runs of the deep-sampling
+families, error paths that must write nothing, per-call precision on a shared context, strided ray generation and the
+RCCL gather.  `-m gpu`; everything goes through the C ABI."""
+
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import nerftex_oracle as orc
+from tests.common import TOL, camera_rays, make_model
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def to_dev(*arrs):
+    return [torch.as_tensor(a, device=dev()) for a in arrs]
+
+
+def rgba_of(out):
+    return np.concatenate([out["color_pred"][0].cpu().numpy(), out["alpha_pred"][0].cpu().numpy()[:, None]], -1)
+
+
+def rgba_ref(ref, b=None):
+    c, a = (ref["color_pred"], ref["alpha_pred"]) if b is None else (ref["color_pred"][b], ref["alpha_pred"][b])
+    return np.concatenate([c, a[..., None]], -1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ray_sampler.Frustum (ray_sampler.py:6-21): un-normalised rays_d, constant [near, far]
+# ---------------------------------------------------------------------------------------------------------------
+def test_frustum_rays_and_render():
+    """mode 1 of ntx_generate_rays against the oracle, then the render of those rays: `pts` use the UN-normalised
+    rays_d (renderer.py:114), the model gets rays_d / |rays_d| (:98), dists are scaled by |rays_d| (:180)."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.ray_sampler import Frustum
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES["carpet"]
+    h, w = 18, 26
+    c2w = orc.look_at(fam["cam"], dtype=np.float32)
+    focal = orc.focal_from_angle(w, fam["angle"])
+    near, far = 4.5, 8.0
+    o, d, t, cone = Frustum(h, w, focal, near, far)((0, h * w), c2w)
+    ro, rd, rt, rcone = orc.frustum_rays(orc.full_pixels(h, w), h, w, focal, c2w, near, far, np.float64)
+    assert np.max(np.abs(o.cpu().numpy() - ro)) <= 1e-6 and np.max(np.abs(d.cpu().numpy() - rd)) <= 1e-6
+    assert np.array_equal(t.cpu().numpy(), rt.astype(np.float32))
+    assert np.max(np.abs(cone.cpu().numpy() - rcone) / rcone) <= 1e-5
+    norms = np.linalg.norm(d.cpu().numpy(), axis=-1)
+    assert norms.min() >= 1.0 and norms.max() > 1.01                          # genuinely un-normalised away from the axis
+    model, spec, wts = make_model((1, 6), dense_media=True)
+    params = np.asarray([fam["params"]], np.float32)
+    S = 64
+    out = Renderer(model=model, n_samples=S, perturb=False)(o[None], d[None], t[None], parameters=to_dev(params)[0], cone_scale=cone[None])
+    f32 = lambda x: x.cpu().numpy()
+    ref = orc.renderer_call(wts, spec, f32(o)[None], f32(d)[None], f32(t)[None], params, f32(cone)[None], S, dtype=np.float64)
+    assert orc.rel_linf(rgba_of(out), rgba_ref(ref, 0)) <= TOL
+    # the same rays with rays_d normalised by the caller place the samples elsewhere: the distinction is observable
+    dn = d / torch.linalg.norm(d, dim=-1, keepdim=True)
+    out_n = Renderer(model=model, n_samples=S, perturb=False)(o[None], dn[None], t[None], parameters=to_dev(params)[0], cone_scale=cone[None])
+    assert orc.rel_linf(rgba_of(out_n), rgba_ref(ref, 0)) > 10 * TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# proxy.AABB (proxy.py:13-35) IEEE corner cases ON THE KERNEL
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("origin", [(0.3, -0.2, 5.0), (-1.5, 0.25, 5.0), (1.5, 1.5, 4.0), (0.0, 0.0, 1.0)])
+def test_aabb_ieee_corners_on_kernel(origin):
+    """An axis-aligned camera with odd image sizes: the centre column has d_x == 0 and the centre row d_y == 0 exactly, so
+    1/d = +-inf; with the origin ON a slab plane (b - o) * inf is 0 * inf = NaN, and the reference's tf.where / reduce_max
+    chain decides what a NaN does (proxy.py:22-33).  The kernel's hit mask must be bit-equal to the float32 restatement,
+    and so must t on the special rays."""
+    from nerf_tex_amd.proxy import AABB
+    from nerf_tex_amd.ray_sampler import Proxy
+    h, w = 33, 41
+    b0, b1 = (-1.5, -1.5, -1.5), (1.5, 1.5, 1.5)
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, 3] = origin
+    focal = np.float32(30.0)
+    o, d, t, cone = Proxy(h, w, focal, AABB(b0, b1))((0, h * w), c2w)
+    d, t = d.cpu().numpy(), t.cpu().numpy()
+    with np.errstate(all="ignore"):
+        ro, rd, rt, _ = orc.proxy_rays(orc.full_pixels(h, w), h, w, focal, c2w, b0, b1, np.float32)
+    special = (rd[:, 0] == 0) | (rd[:, 1] == 0)
+    assert special.sum() == h + w - 1 and np.array_equal((d[:, 0] == 0) | (d[:, 1] == 0), special)
+    assert np.array_equal(d[special], rd[special])
+    hit_k, hit_r = t[:, 0] != np.inf, rt[:, 0] != np.inf                       # renderer.py:58: NaN counts as a hit
+    assert np.array_equal(hit_k[special], hit_r[special])
+    assert np.array_equal(t[special], rt[special], equal_nan=True)             # incl. which of them are NaN
+    # all other rays: same mask except where float32 rounding of a grazing ray may fall either way
+    diff = hit_k != hit_r
+    if diff.any():
+        with np.errstate(all="ignore"):
+            _, _, t64, _ = orc.proxy_rays(orc.full_pixels(h, w), h, w, focal, c2w, b0, b1, np.float64)
+        span = np.where(np.isfinite(t64[:, 0]), t64[:, 1] - t64[:, 0], 0.0)
+        assert np.all(np.abs(span[diff]) < 1e-4)
+    assert diff.mean() < 0.01
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stratified jitter inside the kernel (renderer.py:106-111)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("npts", [2, 3, 64, 65, 129])
+def test_sample_depths_match_the_restated_generator(npts):
+    """ntx_sample_depths == the oracle's restatement of renderer.py:101-111 with the Philox4x32-10 draws (the generator
+    itself is pinned to Random123's known-answer vectors in tests/test_oracle.py): bit for bit in float32."""
+    from nerf_tex_amd.renderer import Renderer
+    rng = np.random.default_rng(npts)
+    n = 1000
+    t0 = rng.uniform(1, 5, size=n).astype(np.float32)
+    t = np.stack([t0, t0 + rng.uniform(0.1, 4, size=n).astype(np.float32)], -1)
+    seed = 0x1234_5678_9ABC_DEF0 + npts
+    z_lin = Renderer.sample_depths(to_dev(t)[0], npts).cpu().numpy()
+    assert np.array_equal(z_lin, orc.z_values(t, npts, np.float32))
+    z = Renderer.sample_depths(to_dev(t)[0], npts, perturb=True, seed=seed).cpu().numpy()
+    assert np.array_equal(z, orc.z_values_perturbed(t, npts, seed, np.float32))
+    # properties of renderer.py:107-111: every depth inside its own stratum, hence sorted, ends inside [t0, t1]
+    lo, up = orc.jitter_bounds(z_lin)
+    assert np.all(z >= lo) and np.all(z <= up) and np.all(np.diff(z, axis=-1) >= 0)
+    u = (z - lo) / np.maximum(up - lo, 1e-30)
+    assert abs(float(u.mean()) - 0.5) < 0.02 and float(u.std()) > 0.25          # uniform, not degenerate
+    z2 = Renderer.sample_depths(to_dev(t)[0], npts, perturb=True, seed=seed + 1).cpu().numpy()
+    assert not np.array_equal(z, z2)
+
+
+@pytest.mark.parametrize("family,S,precision", [("carpet", 64, "float32"), ("grass", 100, "float32"), ("grass_filtered", 48, "float32"),
+                                                ("carpet", 64, "fp16x3"), ("grass_filtered", 33, "fp16x3")])
+def test_render_with_in_kernel_jitter(family, S, precision):
+    """perturb=True (the reference's default, renderer.py:34): the fused kernel draws the jitter itself.  Checked against the
+    oracle evaluated on the restated depths of the same (seed, ray, sample)."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES[family]
+    model, spec, w = make_model(fam["n_parameters"], dense_media=True)
+    (ro, rd, t, cone), _, _ = camera_rays(family, 14, 18)
+    n = ro.shape[0]
+    params = np.asarray([fam["params"]], np.float32)
+    seed = 987654321012345
+    r = Renderer(model=model, n_samples=S, perturb=True, blur_idx=fam["blur_idx"], precision=precision)
+    out = r(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0], seed=seed)
+    r.raise_if_nonfinite()
+    hit = np.isfinite(t[:, 0])
+    assert hit.any() and (~hit).any()
+    tz = np.where(np.isfinite(t), t, 0).astype(np.float32)
+    z = orc.z_values_perturbed(tz, S, seed, np.float32)                       # ray index = index within the call
+    ref = orc.render_rays(w, spec, ro[hit], rd[hit], t[hit], np.repeat(params, hit.sum(), 0), cone[hit], S, False, (1, 1, 1.),
+                          fam["blur_idx"], z_override=z[hit], dtype=np.float64)
+    got = rgba_of(out)
+    assert orc.rel_linf(got[hit], rgba_ref(ref)) <= TOL
+    assert np.all(got[~hit] == 0)
+    # and it is not the un-jittered image
+    plain = Renderer(model=model, n_samples=S, perturb=False, blur_idx=fam["blur_idx"], precision=precision)(
+        *to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0])
+    assert orc.rel_linf(rgba_of(plain)[hit], rgba_ref(ref)) > 10 * TOL
+    # a second call draws another seed from numpy's global generator (main.py:30 seeds it): reproducible run to run
+    np.random.seed(5)
+    a = rgba_of(r(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0]))
+    s1 = r._last_seed
+    np.random.seed(5)
+    b = rgba_of(r(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0]))
+    assert s1 == r._last_seed and np.array_equal(a, b) and not np.array_equal(a, got)
+
+
+def test_mip_renderer_with_in_kernel_jitter():
+    """MipRenderer jitters its S+1 segment edges the same way (renderer.py:379-383)."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.renderer import MipRenderer
+    fam = synthetic.FAMILIES["grass_filtered"]
+    model, spec, w = make_model((1, 3), kind="IPE", dense_media=True)
+    (ro, rd, t, cone), _, _ = camera_rays("grass_filtered", 10, 12)
+    hit = np.isfinite(t[:, 0])
+    ro, rd, t, cone = ro[hit], rd[hit], t[hit], cone[hit]
+    params = np.asarray([fam["params"]], np.float32)
+    S, seed = 48, 4242
+    out = MipRenderer(model=model, n_samples=S, perturb=True, blur_idx=0)(
+        *to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0], seed=seed)
+    z = orc.z_values_perturbed(t, S + 1, seed, np.float32)
+    ref = orc.mip_render_rays(w, spec, ro, rd, t, np.repeat(params, ro.shape[0], 0), cone, S, 0, False, (1, 1, 1.), z_override=z,
+                              dtype=np.float64)
+    assert orc.rel_linf(rgba_of(out), rgba_ref(ref)) <= TOL
+
+
+def test_hierarchical_sampling_sees_the_jittered_coarse_depths():
+    """n_importance > 0 with perturb: ntx_sample_pdf regenerates the coarse depths of the same (flags, seed), so the merged
+    depths contain exactly the jittered coarse ones (renderer.py:125-130)."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES["carpet"]
+    model, spec, w = make_model((1, 6), dense_media=True)
+    n, S, NI, seed = 50, 32, 16, 777
+    ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"])
+    params = np.asarray([fam["params"]], np.float32)
+    r = Renderer(model=model, n_samples=S, n_importance=NI, perturb=True)
+    out = r(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0], seed=seed)
+    r.raise_if_nonfinite()
+    z_all = r._last_z.cpu().numpy()
+    zc = orc.z_values_perturbed(t, S, seed, np.float32)
+    assert z_all.shape == (n, S + NI) and np.all(np.diff(z_all, axis=-1) >= 0)
+    for k in range(n):
+        assert np.all(np.isin(zc[k], z_all[k]))
+    ref = orc.render_rays(w, spec, ro, rd, t, np.repeat(params, n, 0), cone, S + NI, False, (1, 1, 1.), z_override=z_all, dtype=np.float64)
+    assert orc.rel_linf(rgba_of(out), rgba_ref(ref)) <= TOL
+    refc = orc.render_rays(w, spec, ro, rd, t, np.repeat(params, n, 0), cone, S, False, (1, 1, 1.), z_override=zc, dtype=np.float64)
+    got_c = np.concatenate([out["color_pred_coarse"][0].cpu().numpy(), out["alpha_pred_coarse"][0].cpu().numpy()[:, None]], -1)
+    assert orc.rel_linf(got_c, rgba_ref(refc)) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cone-filter conditioning at BASELINE configs[4]'s sample count, and the deep-sampling families at full size
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["float32", "fp16x3"])
+@pytest.mark.parametrize("sigma_blur", [10.0, 0.0])
+def test_grass_filtered_blur_at_128_samples(precision, sigma_blur):
+    """blur_idx = 0 scales the blur parameter per sample by cone_scale * z (renderer.py:155-158) -- at S = 128, the
+    sample count of BASELINE configs[4] (config_grass_filtered_train.py:46-48: sigma_blur in {0, 10})."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES["grass_filtered"]
+    model, spec, w = make_model(fam["n_parameters"], dense_media=True)
+    (ro, rd, t, cone), _, _ = camera_rays("grass_filtered", 16, 12)
+    cone = (cone * 40).astype(np.float32)                                      # cone_scale * z * sigma_blur of order 1
+    params = np.asarray([fam["params"]], np.float32); params[0, 0] = sigma_blur
+    S = 128
+    out = Renderer(model=model, n_samples=S, perturb=False, blur_idx=0, precision=precision)(
+        *to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0])
+    ref = orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], S, False, (1., 1., 1.), 0, False, dtype=np.float64)
+    assert orc.rel_linf(rgba_of(out), rgba_ref(ref, 0)) <= TOL
+    if sigma_blur:                                                             # the conditioning is live
+        ref0 = orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], S, False, (1., 1., 1.), None, False, dtype=np.float64)
+        assert orc.rel_linf(rgba_ref(ref0, 0), rgba_ref(ref, 0)) > 10 * TOL
+
+
+@pytest.mark.parametrize("family", ["grass", "grass_filtered"])
+def test_full_size_properties_deep_sampling(family):
+    """BASELINE configs[2] / [4] per-GPU size (800x800x128, all-hit rays): alpha in [0,1], premultiplied colour <= alpha,
+    the image independent of how rays are split over calls (bit-identical: what sharding relies on), and a spot check of
+    128 rays of the full-size render against the oracle."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES[family]
+    model, spec, w = make_model(fam["n_parameters"], dense_media=True)
+    n, S = 800 * 800, 128
+    ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"])
+    params = np.asarray([fam["params"]], np.float32)
+    r = Renderer(model=model, n_samples=S, perturb=False, blur_idx=fam["blur_idx"])
+    dro, drd, dt, dcone = to_dev(ro, rd, t, cone)
+    full = r(dro[None], drd[None], dt[None], parameters=to_dev(params)[0], cone_scale=dcone[None])
+    r.raise_if_nonfinite()
+    c, a = full["color_pred"][0], full["alpha_pred"][0]
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 + 1e-6 and bool((c <= a[:, None] + 1e-6).all())
+    cuts = [0, 33, 250_007, n]                                                 # incl. a shard smaller than one workgroup's block
+    pc, pa = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        o = r(dro[None, lo:hi], drd[None, lo:hi], dt[None, lo:hi], parameters=to_dev(params)[0], cone_scale=dcone[None, lo:hi])
+        pc.append(o["color_pred"][0]); pa.append(o["alpha_pred"][0])
+    assert torch.equal(torch.cat(pc), c) and torch.equal(torch.cat(pa), a)
+    idx = np.random.default_rng(1).choice(n, 128, replace=False)
+    ref = orc.render_rays(w, spec, ro[idx], rd[idx], t[idx], np.repeat(params, 128, 0), cone[idx], S, False, (1, 1, 1.), fam["blur_idx"],
+                          dtype=np.float64)
+    got = np.concatenate([c[idx].cpu().numpy(), a[idx].cpu().numpy()[:, None]], -1)
+    assert orc.rel_linf(got, rgba_ref(ref)) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# error paths write nothing; scratch is reserved, never allocated per call; precision is per call
+# ---------------------------------------------------------------------------------------------------------------
+def _raw_render(model, n, S, blur_idx, flags, sentinel=-7.0):
+    from nerf_tex_amd import _lib, synthetic
+    fam = synthetic.FAMILIES["carpet"]
+    ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"])
+    t[::3] = np.inf                                                            # culled rays are written by the FIRST launch
+    dro, drd, dt, dcone = to_dev(ro, rd, t, cone[:, 0].copy())
+    params = to_dev(np.asarray([fam["params"]], np.float32))[0]
+    color = torch.full((n, 3), sentinel, device=dev()); alpha = torch.full((n,), sentinel, device=dev())
+    rc = _lib.lib.ntx_render_rays(model.ctx(0), dro.data_ptr(), drd.data_ptr(), dt.data_ptr(), params.data_ptr(), n, dcone.data_ptr(), n, S,
+                                  blur_idx, flags, _lib.f3([1, 1, 1.]), None, 0, color.data_ptr(), alpha.data_ptr(), None, None,
+                                  torch.cuda.current_stream(dev()).cuda_stream)
+    torch.cuda.synchronize()
+    return rc, color, alpha
+
+
+def test_failed_calls_write_nothing():
+    from nerf_tex_amd import _lib
+    model, _, _ = make_model((1, 6))
+    # fp16x3 cannot scale an appearance parameter per sample: refused BEFORE the hit compaction touches the outputs
+    rc, color, alpha = _raw_render(model, 300, 32, 6, _lib.FLAG_FP16X3)
+    assert rc == _lib.NTX_E_UNSUPPORTED and b"appearance" in _lib.lib.ntx_last_error()
+    assert bool((color == -7.0).all()) and bool((alpha == -7.0).all())
+    # more rays than the context reserved: refused, nothing written, nothing allocated
+    _lib.check(_lib.lib.ntx_reserve(model.ctx(0), 256))
+    rc, color, alpha = _raw_render(model, 300, 32, -1, 0)
+    assert rc == _lib.NTX_E_INVALID and b"ntx_reserve" in _lib.lib.ntx_last_error()
+    assert bool((color == -7.0).all()) and bool((alpha == -7.0).all())
+    _lib.check(_lib.lib.ntx_reserve(model.ctx(0), 300))
+    rc, color, alpha = _raw_render(model, 300, 32, -1, 0)
+    assert rc == 0 and bool((alpha[::3] == 0).all()) and bool((alpha[1::3] != -7.0).all())
+    assert _lib.lib.ntx_reserve(model.ctx(0), -1) == _lib.NTX_E_INVALID
+    # the python mirror reserves by itself (setup-time) when a call outgrows the default
+    model.close()
+
+
+def test_renderer_reserves_beyond_the_default():
+    from nerf_tex_amd import _lib, synthetic
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES["carpet"]
+    model, _, _ = make_model((1, 6))
+    n = _lib.DEFAULT_MAX_RAYS + 1000
+    ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"])
+    t[:] = np.inf; t[-5:] = [2.0, 3.0]                                        # all but 5 rays culled: cheap
+    out = Renderer(model=model, n_samples=8, perturb=False)(*to_dev(ro[None], rd[None], t[None]),
+                                                             parameters=to_dev(np.asarray([fam["params"]], np.float32))[0],
+                                                             cone_scale=to_dev(cone[None])[0])
+    a = out["alpha_pred"][0]
+    assert bool((a[:-5] == 0).all()) and bool((a[-5:] > 0).all())
+
+
+def test_precision_is_per_call_on_a_shared_context():
+    """Two renderers share one model context at different precisions on two streams: no mutable precision state."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES["carpet"]
+    model, _, _ = make_model((1, 6), dense_media=True)
+    ro, rd, t, cone = synthetic.all_hit_rays(5000, fam["b_0"], fam["b_1"], fam["cam"])
+    args = to_dev(ro[None], rd[None], t[None])
+    kw = dict(parameters=to_dev(np.asarray([fam["params"]], np.float32))[0], cone_scale=to_dev(cone[None])[0])
+    r32 = Renderer(model=model, n_samples=64, perturb=False)
+    r16 = Renderer(model=model, n_samples=64, perturb=False, precision="fp16x3")
+    a32, a16 = rgba_of(r32(*args, **kw)), rgba_of(r16(*args, **kw))
+    assert not np.array_equal(a32, a16) and orc.rel_linf(a16, a32) < 1e-4
+    for _ in range(3):                                                         # interleaved: each keeps its own arithmetic
+        assert np.array_equal(rgba_of(r16(*args, **kw)), a16)
+        assert np.array_equal(rgba_of(r32(*args, **kw)), a32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# multi-GPU plumbing that one GPU can exercise: strided ray generation, the RCCL gather on a 1-rank communicator
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world,run", [(3, 40), (8, 40), (4, None), (3, 7)])
+def test_strided_ray_generation_is_the_full_grid_resharded(world, run):
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.dist import ShardMap
+    from nerf_tex_amd.pixel_sampler import Full
+    from nerf_tex_amd.proxy import AABB
+    from nerf_tex_amd.ray_sampler import Proxy
+    fam = synthetic.FAMILIES["fur"]
+    h, w = 30, 40
+    c2w = orc.look_at(fam["cam"], dtype=np.float32)
+    focal = orc.focal_from_angle(w, fam["angle"] * 2)
+    sampler = Proxy(h, w, focal, AABB(fam["b_0"], fam["b_1"]))
+    full = [x.cpu().numpy() for x in sampler(Full(h, w)(), c2w)]
+    shard = ShardMap(h * w, world, run)
+    for r in range(world):
+        part = [x.cpu().numpy() for x in sampler(Full(h, w, shard=(shard, r))(), c2w)]
+        px = shard.local_pixels(r)
+        for a, b in zip(part, full):
+            assert np.array_equal(a, b[px], equal_nan=True)
+
+
+@pytest.mark.parametrize("n,run", [(800 * 10, None), (801, None), (800 * 10, 800), (4001, 16)])
+def test_gather_image_on_a_one_rank_communicator(n, run):
+    """ntx_comm_unique_id / ntx_comm_create / ntx_gather_image on real RCCL with one rank: the direct ncclGather path
+    (bands) and the staging + unshard path (interleaved runs)."""
+    from nerf_tex_amd.dist import Comm, ShardMap
+    comm = Comm(0)
+    assert comm.world == 1 and comm.rank == 0
+    shard = ShardMap(n, 1, run)
+    local = torch.rand((n, 4), device=dev())
+    img = comm.gather_image(local, shard)
+    torch.cuda.synchronize()
+    assert img.shape == (n, 4) and torch.equal(img, local)
+    with pytest.raises(ValueError):
+        comm.gather_image(local[:-1], shard)
+    comm.close()
+
+
+def test_two_rank_sharded_render_is_bit_identical():
+    """BASELINE configs[3] over 2 ranks (rows dealt round-robin, ntx_gather_image over RCCL): the gathered image equals the
+    one-GPU image bit for bit.  Needs two GPUs; the one-GPU box skips it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    for shard in ("rows", "bands"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "fur_sharded", "--steps", "1",
+                              "--warmup", "1", "--no-cpu-baseline", "--shard", shard], capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["sharded_image_bit_identical_to_1gpu"] is True
+
+
+def test_sharded_workload_on_one_gpu():
+    """`--workload fur_sharded` at N = 1: the true camera (hits and misses), rays generated on the device."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "fur_sharded", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    hits = d["config"]["hit_rays_total"]
+    assert 0 < hits < 800 * 800 and d["scaling"] == "strong"
+    assert abs(d["value"] - hits * 64 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6

@@ -16,12 +16,12 @@ def test_abi_exports_every_declared_symbol():
     from nerf_tex_amd import _lib
     header = open(os.path.join(ROOT, "include", "nerftex.h")).read()
     declared = set(re.findall(r"\b(ntx_[a-z0-9_]+)\s*\(", header))
-    declared -= {"ntx_ctx", "ntx_stream"}
+    declared -= {"ntx_ctx", "ntx_stream", "ntx_comm"}
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     raw = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.lib.ntx_abi_version() == 1
+    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_create_without_gpu_reports_no_device():
@@ -100,7 +100,7 @@ def test_pack_weights_fp16x3_splits_every_weight_once():
     used = (hi != 0) | (lo != 0)
     got = set(zip(hi[used].tolist(), lo[used].tolist()))
     assert got <= want
-    # (the 81 direction rows of C1 are not in this stream: they are applied per ray in float32 by dirbias_kernel)
+    # (the 81 direction rows of C1 are not in this stream: they are applied per ray in float32 by dir_block)
     n_matrix = 72 * 256 + 4 * 256 * 256 + 328 * 256 + 2 * 256 * 256 + 256 * 256 + 256 * 256 + 256 * 128
     underflow = int(np.sum((wh.view(np.uint16) & 0x7fff) == 0))          # |w| < 2^-25 rounds to (0, 0): not counted as used
     assert n_matrix - underflow - 300 <= int(used.sum()) <= n_matrix
@@ -126,13 +126,51 @@ def test_instantiate_and_reference_config_remap():
     assert m.pos_map_dim == 72 and m.dir_map_dim == 81 and m.macs_per_sample() == 680832
     assert util.instantiate(None) is None
     ws = m.get_weights()
-    assert len(ws) == 26 and ws[0].shape == (72, 256) and ws[10].shape == (328, 256) and ws[16].shape == (256, 1)
+    # Keras get_weights() order: trunk 0-7, feature, colour layer, colour half, color, and the alpha head LAST
+    assert len(ws) == 26 and ws[0].shape == (72, 256) and ws[10].shape == (328, 256) and ws[16].shape == (256, 256)
+    assert ws[18].shape == (337, 256) and ws[20].shape == (256, 128) and ws[22].shape == (128, 3) and ws[24].shape == (256, 1)
     assert np.all(ws[1] == 0) and abs(float(ws[0].max())) <= np.sqrt(6 / (72 + 256))      # glorot_uniform / zeros
     ws[3] = ws[3] + 1
     m.set_weights(ws)
     np.testing.assert_array_equal(m.get_weights()[3], ws[3])
     with pytest.raises(ValueError):
         m.set_weights(ws[:-1])
+    # a list in CREATION order (alpha before feature, model.py:111-114) has the right total size, so only the shapes can tell
+    creation = ws[:16] + ws[24:26] + ws[16:24]
+    assert sum(a.size for a in creation) == m.n_weight_floats()
+    with pytest.raises(ValueError, match="feature"):
+        m.set_weights(creation)
+
+
+def test_weight_blob_is_keras_get_weights_order():
+    """The blob of the C ABI == np.concatenate(keras_model.get_weights()): a functional tf.keras.Model sorts its layers by
+    graph depth, ties by traversal from outputs=[color, alpha] (model.py:125), so alpha comes last.  The host-side packer
+    must pick each layer from that position: mark every layer's kernel with a constant and look where it lands."""
+    from nerf_tex_amd import _lib
+    from nerf_tex_amd.model import ParamNerf, Nerf
+    from tests.common import EMB
+    np.random.seed(0)
+    for model in (ParamNerf(EMB(10), EMB(4), EMB(4), [1, 6])["model"], Nerf(EMB(10), EMB(4))["model"]):
+        names = [n for n, _, _ in model.layer_table()]
+        assert names[:8] == [f"trunk{i}" for i in range(8)] and names[8] == "feature" and names[-2:] == ["color", "alpha"]
+        ws = [np.full_like(w, float(k // 2 + 1)) if k % 2 == 0 else np.full_like(w, 100.0 + k // 2) for k, w in enumerate(model.get_weights())]
+        model.set_weights(ws)
+        blob = model.get_blob()
+        d = model.desc()
+        npk = _lib.lib.ntx_packed_count(C.byref(d))
+        out = np.empty(npk, np.float32)
+        fp = C.POINTER(C.c_float)
+        assert _lib.lib.ntx_pack_weights(C.byref(d), blob.ctypes.data_as(fp), blob.size, out.ctypes.data_as(fp), npk) == 0
+        aux = out[npk - 3776:]
+        k_alpha, k_rgb = names.index("alpha"), names.index("color")
+        # aux block (ntx_layout.h): 12 x 256 biases | alpha head [2][128] + bias | rgb head [3][2][64] + bias[3]
+        assert np.all(aux[12 * 256:12 * 256 + 256] == k_alpha + 1) and aux[12 * 256 + 256] == 100.0 + k_alpha
+        rgb_off = 12 * 256 + 2 * 128 + 4
+        assert np.all(aux[rgb_off:rgb_off + 384] == k_rgb + 1) and np.all(aux[rgb_off + 384:rgb_off + 387] == 100.0 + k_rgb)
+        assert np.all(aux[8 * 256:9 * 256] == 100.0 + names.index("feature"))            # bias slot 8 = the feature layer
+        stream = out[:npk - 3776]
+        first = stream[:2 * 256]                                                          # L0's first records: trunk0's kernel
+        assert set(np.unique(first[first != 0]).tolist()) == {1.0}
 
 
 def test_reference_render_config_runs_through_remap():
@@ -170,50 +208,88 @@ def test_renderer_kwargs_mirror_reference():
         Renderer(model=None, raw_noise_std=1.0)
 
 
-def test_shard_range_partitions():
-    from nerf_tex_amd.dist import shard_range
-    for n in (0, 1, 7, 640000, 640001):
+def test_shard_map_partitions_and_matches_the_c_abi():
+    """ShardMap (python) == ntx_shard_count (C ABI); every pixel belongs to exactly one rank; bands are contiguous."""
+    from nerf_tex_amd import _lib
+    from nerf_tex_amd.dist import ShardMap, shard_range
+    for n in (0, 1, 7, 800 * 800, 640001, 1600 * 1600):
         for world in (1, 2, 3, 8):
+            for run in (None, 1, 5, 800, 1600):
+                m = ShardMap(n, world, run)
+                counts = [m.count(r) for r in range(world)]
+                assert sum(counts) == n and counts[0] == m.capacity == max(counts)
+                for r in range(world):
+                    assert _lib.lib.ntx_shard_count(n, m.run, world, r) == counts[r]
+                if n <= 10000 or run in (800, 1600):
+                    seen = np.concatenate([m.local_pixels(r) for r in range(world)]) if n else np.zeros(0, np.int64)
+                    assert np.array_equal(np.sort(seen), np.arange(n))
+                    for r in range(world):
+                        p0, cnt, rl, rs = m.pixel_set(r)
+                        k = np.arange(cnt)
+                        assert np.array_equal(m.local_pixels(r), p0 + (k // rl) * rs + k % rl)
             spans = [shard_range(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and sum(c for _, c in spans) == n
-            for (f0, c0), (f1, _) in zip(spans[:-1], spans[1:]):
-                assert f0 + c0 == f1
-            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+            for (f0, c0), (f1, c1) in zip(spans[:-1], spans[1:]):
+                assert f0 + c0 == f1 or c1 == 0
+    assert ShardMap(640000, 8).count(3) == 80000 and ShardMap(1600 * 1600, 8, 1600).count(7) == 320000   # BASELINE configs[3] / [4]
+    assert _lib.lib.ntx_shard_count(10, 0, 2, 0) == -1 and _lib.lib.ntx_shard_count(10, 4, 2, 2) == -1
 
 
-def _gather_worker(rank, world, port, n_total, q):
+def _gather_worker(rank, world, port, n_total, run, q):
     import torch
     import torch.distributed as dist
-    from nerf_tex_amd.dist import gather_image, shard_range
+    from nerf_tex_amd.dist import ShardMap, gather_image
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    first, count = shard_range(n_total, rank, world)
+    shard = ShardMap(n_total, world, run)
     full = torch.arange(n_total * 4, dtype=torch.float32).reshape(n_total, 4)
-    img = gather_image(full[first:first + count].clone(), n_total)
+    img = gather_image(full[torch.as_tensor(shard.local_pixels(rank))].clone(), shard)
     ok = (img is None) if rank != 0 else bool(torch.equal(img, full))
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [64, 101])
-def test_gather_image_world2_gloo(n_total):
-    """N > 1 path on CPU: contiguous shards, one gather, image on rank 0 equals the unsharded one."""
+@pytest.mark.parametrize("n_total,run", [(64, None), (101, None), (96, 8), (101, 7)])
+def test_gather_image_world2_gloo(n_total, run):
+    """N > 1 path on CPU: bands or interleaved runs, even or uneven, one gather, image on rank 0 equals the unsharded one."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, n_total, run, q)) for r in range(2)]
     [p.start() for p in procs]
     res = sorted(q.get(timeout=120) for _ in procs)
     [p.join(60) for p in procs]
     assert res == [(0, True), (1, True)]
 
 
+def test_bench_self_launch_command_line(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts its N ranks itself (one per GPU, rendezvous on 127.0.0.1)."""
+    import importlib
+    bench = importlib.import_module("bench")
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None):
+            started.append((cmd, env, stdout))
+        def wait(self):
+            return 0
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    args = type("A", (), {"gpus": 4})()
+    assert bench.self_launch(args) == 0 and len(started) == 4
+    for r, (cmd, env, out) in enumerate(started):
+        assert cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "4", "--steps", "2"]
+        assert env["RANK"] == env["LOCAL_RANK"] == str(r) and env["WORLD_SIZE"] == "4" and env["MASTER_ADDR"] == "127.0.0.1"
+        assert env["MASTER_PORT"] == started[0][1]["MASTER_PORT"] and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert (out is None) == (r == 0)
+
+
 def test_checkpoint_reader_round_trip(tmp_path):
     """nerf_tex_amd/checkpoint.py against the independent writer in tests/bundle_writer.py:
-    multi-block table, prefix-compressed keys, Keras object-graph names with the heads in DEPTH order."""
+    multi-block table, prefix-compressed keys, Keras object-graph names `layer_with_weights-k` in `model.layers` order."""
     from nerf_tex_amd import checkpoint as ck
     from nerf_tex_amd.model import ParamNerf
     from tests.bundle_writer import write_bundle
@@ -224,7 +300,8 @@ def test_checkpoint_reader_round_trip(tmp_path):
     ws = src.get_weights()
     names = [n for n, _, _ in src.layer_table()]
     # model.layers order of a functional Keras model is by depth: trunk0-7, feature, colour layers, then the two heads
-    order = [n for n in names if n.startswith("trunk")] + ["feature", "color_hidden0", "color_half", "alpha", "color"]
+    order = [n for n in names if n.startswith("trunk")] + ["feature", "color_hidden0", "color_half", "color", "alpha"]
+    assert order == names
     tensors = {"save_counter/.ATTRIBUTES/VARIABLE_VALUE": np.asarray(7, np.int64), "step/.ATTRIBUTES/VARIABLE_VALUE": np.asarray(5000, np.int64)}
     for i, n in enumerate(order):
         k = names.index(n)

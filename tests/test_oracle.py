@@ -272,3 +272,50 @@ def test_ipe_and_cone_gaussians():
     assert np.all(mean[0, :, 2] > 2 * tv[0, :-1]) and np.all(mean[0, :, 2] < 2 * tv[0, 1:])
     _, cov_r = orc.cone_segment_gaussians(o, dd, tv, np.full((1, 1), 0.01), np.float64)
     assert np.all(cov_r[..., :2] > 0) and np.allclose(cov_r[..., 2], cov[..., 2])    # radius only widens the null space of d
+
+
+def test_philox_known_answer_vectors():
+    """The counter-based generator behind the in-kernel jitter is pinned to the published known-answer vectors of
+    Philox4x32-10 (Random123 kat_vectors: counter, key -> first output word)."""
+    u32 = np.uint32
+    for ctr, key, want in [((0, 0, 0, 0), (0, 0), 0x6627E8D5),
+                           ((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF), 0x408F276D),
+                           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0), 0xD16CFE09)]:
+        assert int(orc.philox4x32_10(*[u32(c) for c in ctr], key[0], key[1])) == want
+    # TensorFlow's Uint32ToFloat: low 23 bits -> [1,2) - 1
+    assert orc.uniform01_from_bits(np.uint32(0)) == 0.0 and orc.uniform01_from_bits(np.uint32(0xFFFFFFFF)) == np.float32(1.0 - 2.0 ** -23)
+
+
+def test_perturbed_depths_stay_in_their_strata():
+    """renderer.py:106-111: z = lower + (upper - lower) * u, u in [0,1) -> every depth inside its stratum, so sorted."""
+    rng = np.random.default_rng(0)
+    t0 = rng.uniform(1, 5, size=200).astype(np.float32)
+    t = np.stack([t0, t0 + rng.uniform(0.1, 3, size=200).astype(np.float32)], -1)
+    for n in (2, 3, 64):
+        z0 = orc.z_values(t, n, np.float32)
+        lo, up = orc.jitter_bounds(z0)
+        z = orc.z_values_perturbed(t, n, 12345, np.float32)
+        assert z.dtype == np.float32 and np.all(z >= lo) and np.all(z <= up) and np.all(np.diff(z, axis=-1) >= 0)
+        assert not np.array_equal(z, orc.z_values_perturbed(t, n, 12346, np.float32))
+        u = orc.jitter_uniforms(200, n, 12345)
+        assert u.min() >= 0.0 and u.max() < 1.0
+
+
+def test_torch_cpu_baseline_port_agrees_with_the_oracle():
+    """oracle/torch_cpu.py (bench.py's cpu_baseline) computes the same render as the numpy restatement."""
+    torch = pytest.importorskip("torch")
+    from oracle import torch_cpu
+    from nerf_tex_amd import synthetic
+    for family, S in (("carpet", 33), ("grass_filtered", 48)):
+        fam = synthetic.FAMILIES[family]
+        spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(fam["n_parameters"]))
+        w = orc.split_blob(spec, synthetic.synthetic_weights(orc.layer_table(spec), seed=0, dense_media=True))
+        ro, rd, t, cone = synthetic.all_hit_rays(150, fam["b_0"], fam["b_1"], fam["cam"])
+        params = np.asarray([fam["params"]], np.float32)
+        ref = orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], S, False, (1, 1, 1.), fam["blur_idx"], False,
+                                dtype=np.float64)
+        c, a = torch_cpu.renderer_call(w, spec, ro, rd, t, params[0], cone, S, fam["blur_idx"], render_chunk=64, net_chunk=1000)
+        got = np.concatenate([c, a[:, None]], -1)
+        want = np.concatenate([ref["color_pred"][0], ref["alpha_pred"][0][:, None]], -1)
+        assert orc.rel_linf(got, want) <= 2e-4          # float32 port vs float64 truth, dense-media weights
+    assert "BLAS_INFO" in torch_cpu.blas_backend()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM roofline of the small kernels around the fused render kernel: achieved algorithmic GB/s of
-ntx_generate_rays, ntx_composite, ntx_sample_pdf, ntx_image_epilogue and the two pre-kernels of ntx_render_rays, at
+ntx_generate_rays, ntx_composite, ntx_sample_pdf, ntx_sample_depths, ntx_image_epilogue, at
 BASELINE sizes, through the C ABI with HIP events.  GPU box only:  python tools/bench_small_kernels.py"""
 import ctypes as C
 import json
@@ -61,10 +61,14 @@ t = torch.stack([torch.full((N,), 2.0, device=dev), torch.full((N,), 6.0, device
 wts = torch.rand((N, S), device=dev)
 z_all = torch.empty((N, S + NI), device=dev)
 st = torch.cuda.current_stream(dev).cuda_stream
-report("sample_pdf_kernel", timed(lambda: _lib.check(_lib.lib.ntx_sample_pdf(t.data_ptr(), None, wts.data_ptr(), None, N, S, NI, z_all.data_ptr(), st))),
+report("sample_pdf_kernel", timed(lambda: _lib.check(_lib.lib.ntx_sample_pdf(t.data_ptr(), None, wts.data_ptr(), None, N, S, NI, 0, 0, z_all.data_ptr(), st))),
        N * (S * 4 + (S + NI) * 4 + 8), f"{N} rays, {S} coarse + {NI} importance depths (deterministic u)")
 
 # image epilogue: RGBA in, float32 + uint8 out, with and without the gaussian downsample
 img = torch.rand((H, W, 4), device=dev)
 report("epilogue_kernel f=1", timed(lambda: image_epilogue(img, 1, uint8=True)), H * W * (16 + 16 + 4), f"{H}x{W}, un-premultiply + uint8")
 report("epilogue_kernel f=2", timed(lambda: image_epilogue(img, 2, uint8=True)), H * W * 16 + (H // 2) * (W // 2) * 20, f"{H}x{W} -> /2, 6x6 gaussian")
+
+# sample depths with the in-kernel jitter: t in, z[N,S] out (one Philox4x32-10 block per depth)
+zj = Renderer.sample_depths(t, S, perturb=True, seed=1)
+report("sample_depths_kernel perturb", timed(lambda: Renderer.sample_depths(t, S, perturb=True, seed=1)), N * (S * 4 + 8), f"{N} rays x {S} jittered depths (includes torch.empty)")
