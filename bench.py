@@ -75,6 +75,8 @@ def cpu_baseline(family: str, n_samples: int, target_seconds: float = 15.0):
         torch_cpu.renderer_call(w, spec, ro, rd, t, params, cone, n_samples, fam["blur_idx"], render_chunk=32768, net_chunk=65536)
         return time.perf_counter() - t0
 
+    cores = torch_cpu.effective_cpus()         # affinity mask capped by the cgroup CPU quota of this container
+    torch.set_num_threads(cores)
     run(1024)                                  # warm the BLAS threads
     n = 4096
     dt = run(n)
@@ -83,10 +85,11 @@ def cpu_baseline(family: str, n_samples: int, target_seconds: float = 15.0):
     if n2 > n:
         dt = run(n2); n = n2
     return {"value": n * n_samples / dt, "unit": "ray-samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "cpu_count": os.cpu_count(), "blas": torch_cpu.blas_backend(),
+            "cpu_count": os.cpu_count(), "cpu_quota": cores, "blas": torch_cpu.blas_backend(),
             "sample": f"{n} rays x {n_samples} samples of the same workload ({'one full' if n == 32768 else 'part of a'} "
                       f"reference render_chunk), float32 torch-CPU port of the reference's TF ops (oracle/torch_cpu.py), "
-                      f"reference chunking 32768/65536, {dt:.2f} s on {torch.get_num_threads()} threads"}
+                      f"reference chunking 32768/65536, {dt:.2f} s on {torch.get_num_threads()} threads (host: {os.cpu_count()} logical CPUs, "
+                      f"this container may use {cores})"}
 
 
 def measured_traffic(workload: str, precision: str = "float32"):
@@ -122,7 +125,7 @@ def bench_instanced(args) -> None:
     emb = lambda n: {"module": "network.model.FourierFeatures", "n_freq_bands": n}
     model = ParamNerf(emb(10), emb(4), emb(4), list(fam["n_parameters"]))["model"]
     model.set_blob(synthetic.synthetic_weights(model.layer_table(), seed=0))
-    n, S, P = 16384, 1024, model.n_params
+    n, S, P = int(os.environ.get("NTX_INSTANCED_RAYS", "16384")), 1024, model.n_params   # (the env knob is for scaling experiments)
     g = torch.Generator(device=dev); g.manual_seed(0)
     u = lambda *shape: torch.rand(*shape, device=dev, generator=g)
     rays_d_map = torch.nn.functional.normalize(u(n, S, 3) - 0.5, dim=-1).contiguous()
@@ -205,6 +208,7 @@ def main() -> None:
     ap.add_argument("--precision", default="float32", choices=["float32", "fp16x3"],
                     help="arithmetic of the Dense layers (include/nerftex.h: ntx_precision); float32 = the reference's")
     ap.add_argument("--perturb", action="store_true", help="stratified jitter of the depths inside the kernel (the reference's default perturb=True)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp16x3 / perturb second figures (profiling runs: one kernel flavour per process)")
     ap.add_argument("--shard", default="rows", choices=["rows", "bands"], help="sharded workloads: pixel rows round-robin, or contiguous bands")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -324,7 +328,7 @@ def main() -> None:
         return a0.elapsed_time(a1) / args.steps, torch.cat([o2["color_pred"][0], o2["alpha_pred"][0][:, None]], -1)
 
     alt = jit = None
-    if world == 1 and args.precision == "float32" and not args.perturb:
+    if world == 1 and args.precision == "float32" and not args.perturb and not args.no_extras:
         ms2, rgba2 = timed(mk("fp16x3", False))
         alt = {"precision": "fp16x3 (3-term split of weights and activations into IEEE halves on v_mfma_f32_32x32x16_f16, f32 accumulate)",
                "value": n_hit * S / (ms2 * 1e-3), "unit": "ray-samples/s", "kernel_ms": ms2,

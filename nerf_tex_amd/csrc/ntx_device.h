@@ -657,8 +657,11 @@ NTX_DEV float z_of(const RenderArgs &a, int64_t ray, int i, float t0, float t1, 
 // barriers per 8 rays of each wave.  Not applicable when blur_idx scales an APPEARANCE parameter per sample
 // (renderer.py:155-158); the host then launches the HOIST = false kernel.
 // ---------------------------------------------------------------------------------------------
-constexpr int DIR_BLOCK_ITERS = 8;                 // rays per wave and block
-constexpr int DIR_BLOCK_RAYS = 4 * DIR_BLOCK_ITERS;   // = 32 = one MFMA's worth of B columns
+#ifndef NTX_DIR_BLOCK_ITERS
+#define NTX_DIR_BLOCK_ITERS 8
+#endif
+constexpr int DIR_BLOCK_ITERS = NTX_DIR_BLOCK_ITERS;   // rays per wave and block
+constexpr int DIR_BLOCK_RAYS = 4 * DIR_BLOCK_ITERS;   // a multiple of 32 = one MFMA's worth of B columns
 constexpr int DIR_ROW_STRIDE = 256 + 4;            // floats; +4: the 32 lanes' b128 stores spread over the LDS banks
 constexpr int DIR_BLOCK_FLOATS = DIR_BLOCK_RAYS * DIR_ROW_STRIDE;
 
@@ -667,7 +670,10 @@ template <class CFG>
 NTX_DEV void dir_block(const RenderArgs &a, __amdgpu_buffer_rsrc_t rsrc, const float *aux, float *rows, int base, int nwaves,
                        int wg, int wv, int lane, int n_work) {
     static_assert(CFG::CD != 0, "ParamNerf families");
-    const int j = lane & 31, h = lane >> 5;
+    const int h = lane >> 5;
+    static_assert(DIR_BLOCK_RAYS % 32 == 0, "whole MFMA column sets");
+  for (int j = lane & 31; j < DIR_BLOCK_RAYS; j += 32) {   // 32 ray slots per MFMA column set
+    if (j >= 32 && base + (j >> 5) * 8 * nwaves >= n_work) break;   // (wave-uniform) the rest of the block lies past the end of the list
     int idx = base + (j >> 2) * nwaves + 4 * wg + (j & 3);
     idx = idx < n_work ? idx : n_work - 1;
     const int64_t ray = a.hit_list[idx];
@@ -708,6 +714,7 @@ NTX_DEV void dir_block(const RenderArgs &a, __amdgpu_buffer_rsrc_t rsrc, const f
         o[q] = f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
         o[4 + q] = f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
     });
+  }
 }
 
 template <class CFG, bool HOIST = false>
@@ -844,93 +851,68 @@ struct InstanceArgs {
     int32_t *work_counter;   // device scalar, zero at launch: rays are handed out dynamically (their cost varies 0..S/32 batches)
 };
 
+// Tail packing.  A ray's in-patch samples fill count / 32 whole batches and leave a TAIL of count % 32 samples; run as a
+// batch of its own the tail wastes half a batch per ray on average (6 % of the carpet_instanced workload).  Tails of
+// successive rays of a wave are therefore collected (up to 32 samples, up to PEND_MAX rays) and evaluated in ONE batch,
+// each ray a SEGMENT of consecutive lanes.  The composite of a segment is written so that its result does not depend on
+// where in the batch the segment sits or on what shares the batch: samples outside the segment enter as alpha = 0,
+// i.e. as transmittance factors and weights that are exactly 1.0f / 0.0f, the scans associate relative to each lane,
+// and every total is read at the segment's last lane.  Which rays meet in a batch depends on the dynamic ray hand-out;
+// the image does not.
+constexpr int PEND_MAX = 8;
+
+struct InstancePending {          // per wave, in LDS
+    uint16_t idx[32];             // marching-sample index of each packed lane
+    uint8_t slot[32];             // its segment
+    int32_t ray[PEND_MAX];        // per segment: ray, last lane, cone_scale, the accumulator after the ray's whole batches
+    int32_t last[PEND_MAX];
+    float cone[PEND_MAX];
+    float acc[PEND_MAX][5];
+};
+
+// one segment of a packed batch: `a` is this sample's alpha for lanes of the segment and 0 elsewhere; e = its last lane
+NTX_DEV void composite_segment(RayAccum &ra, float a, const float (&c)[3], int j, int e) {
+    const float trans = (1.0f - a) + 1e-10f;                                          // renderer.py:342; 1.0f outside the segment
+    float P = trans;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const float v = __shfl_up(P, d, 32);
+        if (j >= d) P = v * P;
+    }
+    float E = __shfl_up(P, 1, 32);
+    if (j == 0) E = 1.0f;
+    const float w = a * (ra.T * E);
+    float q[4] = {w * c[0], w * c[1], w * c[2], w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float sacc = q[k];
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const float v = __shfl_up(sacc, d, 32);
+            if (j >= d) sacc = v + sacc;
+        }
+        q[k] = __shfl(sacc, e, 32);
+    }
+    ra.c0 += q[0]; ra.c1 += q[1]; ra.c2 += q[2]; ra.a += q[3];
+    ra.T *= __shfl(P, e, 32);
+}
+
 template <class CFG>
 __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
     __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * PE_KEEP_FLOATS];
     __shared__ uint16_t sidx_all[4][MAX_INSTANCE_SAMPLES];
+    __shared__ InstancePending pend_all[4];
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.n_samples;
     uint16_t *sidx = sidx_all[wv];
+    InstancePending &pend = pend_all[wv];
     WStream ws;
     ws_prime(ws, a.wstream, a.stream_bytes, lane);
 
-    // The number of in-patch samples differs from ray to ray (0 .. S), so a static ray -> wave map leaves waves idle at the
-    // end (19 % on the carpet_instanced bench workload): each wave takes the next unclaimed ray instead.
-    auto next_ray = [&]() -> int64_t {
-        int r = 0;
-        if (lane == 0) r = atomicAdd(a.work_counter, 1);
-        return (int64_t)__builtin_amdgcn_readfirstlane(r);
-    };
-    for (int64_t ray = next_ray(); ray < a.n_rays; ray = next_ray()) {
-        if (!a.hit[ray]) {   // renderer.py:265-272, 313-314: stays 0, also under composite_bkgd
-            if (lane < 3) a.color_out[3 * ray + lane] = 0.0f;
-            if (lane == 3) a.alpha_out[ray] = 0.0f;
-            continue;
-        }
-        const float *drow = a.dists + ray * S;
-        int count = 0;
-        for (int base0 = 0; base0 < S; base0 += 512) {   // 8 independent loads in flight, then their 8 ballots
-            float dv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = base0 + 64 * u + lane; dv[u] = i < S ? drow[i] : 0.0f; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base0 + 64 * u + lane;
-                const bool v = dv[u] > 0.0f;
-                const unsigned long long m = __ballot(v);
-                if (v) sidx[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
-                count += __popcll(m);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const float cone = a.cone ? a.cone[ray] : 0.0f;
-        RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        const int nb = (count + 31) >> 5;
-        for (int b = 0; b < nb; ++b) {
-            const int k = 32 * b + j;
-            const bool valid = k < count;
-            const int64_t sm = ray * S + sidx[valid ? k : 0];
-            SampleIn<CFG::NGEO, CFG::NAPP> in;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { in.pos[c] = a.pts[3 * sm + c]; in.dir[c] = a.rays_d_map[3 * sm + c]; }
-            if constexpr (CFG::IPE == 0) {
-                in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
-#pragma unroll
-                for (int c = 0; c < CFG::NP; ++c) {
-                    float p = a.params_map[CFG::NP * sm + c];
-                    if (c == a.blur_idx) p = p * (cone * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
-                    in.par[c] = p;
-                }
-            } else {
-                // MipInstanceRenderer (renderer.py:510-540, 570-587): radius = blur parameter * cone_scale / patch_scale,
-                // spliced out of the parameters; gaussian with mu = t and (sic) hw = dists; the mean is the sample point
-                const float *pr = a.params_map + CFG::NP_IN * sm;
-                float t_mean, t_var, r_var;
-                cone_moments(a.t[sm], a.dists[sm], pr[a.blur_idx] * cone / a.patch_scale, t_mean, t_var, r_var);
-                cone_cov(t_var, r_var, in.dir, in.cov);
-#pragma unroll
-                for (int c = 0; c < CFG::NP; ++c) in.par[c] = pr[c < a.blur_idx ? c : c + 1];
-            }
-            float sigma, raw[3];
-            mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe_column<CFG>(aux, wv, lane));
-            const float wgt = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // :300
-            sigma = sigma * wgt;
-            float col[3];
-            if (a.instance_color) {                                                                // :306-307, 322-323
-                const int id = a.instance_id[sm];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) col[c] = a.instance_color[3 * id + c];
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) col[c] = (a.flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[c]) : sigmoidf_(raw[c]);
-            }
-            const float al = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * a.dists[sm] / a.patch_scale) : 0.0f;   // :339
-            composite_core<32>(ra, al, col, valid, j, nullptr);
-        }
-        // the appended sample: colour taken as is, alpha_last is an alpha (not a density)
+    // the appended sample (colour taken as is, alpha_last is an alpha, not a density: renderer.py:323-339) and the store
+    auto finish = [&](int64_t ray, const RayAccum &ra) {
         const float wl = a.alpha_last[ray] * ra.T;
         float out[4] = {ra.c0 + wl * a.color_last[3 * ray], ra.c1 + wl * a.color_last[3 * ray + 1],
                         ra.c2 + wl * a.color_last[3 * ray + 2], ra.a + wl};
@@ -947,7 +929,135 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
                 if (!(__builtin_fabsf(sm_) <= 3.0e38f)) atomicOr(a.status, 1);
             }
         }
-        __builtin_amdgcn_wave_barrier();   // the index list is rewritten by the next ray
+    };
+
+    // The number of in-patch samples differs from ray to ray (0 .. S), so a static ray -> wave map leaves waves idle at the
+    // end (19 % on the carpet_instanced bench workload): each wave takes the next unclaimed ray instead.
+    int64_t cur = -1;            // the ray whose whole batches are being marched, -1 = none
+    int count = 0, nfull = 0, b = 0, pend_n = 0, pend_k = 0;
+    bool exhausted = false;
+    float cone = 0.0f;
+    RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (;;) {
+        // ---- scheduler (wave-uniform): advance until a batch is due.  mode 1 = a whole batch of `cur`, 2 = the packed tails
+        int mode = 0;
+        for (;;) {
+            if (cur >= 0 && b < nfull) { mode = 1; break; }
+            if (cur >= 0) {
+                const int r = count - 32 * nfull;
+                if (r == 0) { finish(cur, ra); cur = -1; continue; }
+                if (pend_n + r <= 32 && pend_k < PEND_MAX) {   // the tail joins the pending batch as segment pend_k
+                    if (lane < r) { pend.idx[pend_n + lane] = sidx[32 * nfull + lane]; pend.slot[pend_n + lane] = (uint8_t)pend_k; }
+                    if (lane == 0) {
+                        pend.ray[pend_k] = (int32_t)cur; pend.last[pend_k] = pend_n + r - 1; pend.cone[pend_k] = cone;
+                        pend.acc[pend_k][0] = ra.T; pend.acc[pend_k][1] = ra.c0; pend.acc[pend_k][2] = ra.c1;
+                        pend.acc[pend_k][3] = ra.c2; pend.acc[pend_k][4] = ra.a;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    pend_n += r; ++pend_k; cur = -1;
+                    continue;
+                }
+                mode = 2; break;   // no room: flush the pending batch first, `cur` joins the next one
+            }
+            if (!exhausted) {
+                int r32 = 0;
+                if (lane == 0) r32 = atomicAdd(a.work_counter, 1);
+                const int64_t ray = (int64_t)__builtin_amdgcn_readfirstlane(r32);
+                if (ray >= a.n_rays) { exhausted = true; continue; }
+                if (!a.hit[ray]) {   // renderer.py:265-272, 313-314: stays 0, also under composite_bkgd
+                    if (lane < 3) a.color_out[3 * ray + lane] = 0.0f;
+                    if (lane == 3) a.alpha_out[ray] = 0.0f;
+                    continue;
+                }
+                const float *drow = a.dists + ray * S;
+                int n = 0;
+                for (int base0 = 0; base0 < S; base0 += 512) {   // 8 independent loads in flight, then their 8 ballots
+                    float dv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int i = base0 + 64 * u + lane; dv[u] = i < S ? drow[i] : 0.0f; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = base0 + 64 * u + lane;
+                        const bool v = dv[u] > 0.0f;
+                        const unsigned long long m = __ballot(v);
+                        if (v) sidx[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+                        n += __popcll(m);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                cur = ray; count = n; nfull = n >> 5; b = 0;
+                cone = a.cone ? a.cone[ray] : 0.0f;
+                ra = RayAccum{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                continue;
+            }
+            if (pend_n > 0) mode = 2;
+            break;
+        }
+        if (mode == 0) break;
+
+        // ---- this lane's sample
+        bool valid = true;
+        int slot = 0;
+        int64_t sm;
+        float cone_l = cone;
+        if (mode == 1) {
+            sm = cur * S + sidx[32 * b + j];
+        } else {
+            valid = j < pend_n;
+            const int jc = valid ? j : 0;
+            slot = pend.slot[jc];
+            sm = (int64_t)pend.ray[slot] * S + pend.idx[jc];
+            cone_l = pend.cone[slot];
+        }
+        SampleIn<CFG::NGEO, CFG::NAPP> in;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { in.pos[c] = a.pts[3 * sm + c]; in.dir[c] = a.rays_d_map[3 * sm + c]; }
+        if constexpr (CFG::IPE == 0) {
+            in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CFG::NP; ++c) {
+                float p = a.params_map[CFG::NP * sm + c];
+                if (c == a.blur_idx) p = p * (cone_l * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
+                in.par[c] = p;
+            }
+        } else {
+            // MipInstanceRenderer (renderer.py:510-540, 570-587): radius = blur parameter * cone_scale / patch_scale,
+            // spliced out of the parameters; gaussian with mu = t and (sic) hw = dists; the mean is the sample point
+            const float *pr = a.params_map + CFG::NP_IN * sm;
+            float t_mean, t_var, r_var;
+            cone_moments(a.t[sm], a.dists[sm], pr[a.blur_idx] * cone_l / a.patch_scale, t_mean, t_var, r_var);
+            cone_cov(t_var, r_var, in.dir, in.cov);
+#pragma unroll
+            for (int c = 0; c < CFG::NP; ++c) in.par[c] = pr[c < a.blur_idx ? c : c + 1];
+        }
+        float sigma, raw[3];
+        mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe_column<CFG>(aux, wv, lane));
+        const float wgt = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // :300
+        sigma = sigma * wgt;
+        float col[3];
+        if (a.instance_color) {                                                                // :306-307, 322-323
+            const int id = a.instance_id[sm];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) col[c] = a.instance_color[3 * id + c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) col[c] = (a.flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[c]) : sigmoidf_(raw[c]);
+        }
+        const float al = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * a.dists[sm] / a.patch_scale) : 0.0f;   // :339
+        if (mode == 1) {
+            composite_core<32>(ra, al, col, true, j, nullptr);
+            ++b;
+        } else {
+            for (int k = 0; k < pend_k; ++k) {
+                RayAccum rk{pend.acc[k][0], pend.acc[k][1], pend.acc[k][2], pend.acc[k][3], pend.acc[k][4]};
+                composite_segment(rk, (valid && slot == k) ? al : 0.0f, col, j, pend.last[k]);
+                finish(pend.ray[k], rk);
+            }
+            __builtin_amdgcn_wave_barrier();   // the pending batch is rewritten from here on
+            pend_n = 0; pend_k = 0;
+        }
     }
 }
 

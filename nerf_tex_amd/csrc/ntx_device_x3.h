@@ -484,9 +484,10 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
 // ---------------------------------------------------------------------------------------------
 // InstanceRenderer tail at fp16x3 (instance_kernel<CFG> of ntx_device.h is the float32 one).  Rays cost a different
 // number of 32-sample batches each, and the workgroup shares one weight stream in lockstep, so the workgroup proceeds in
-// ROUNDS of one batch per wave: a wave that has finished its ray takes the next unclaimed one (device work counter) and
-// compacts its in-patch samples before the round starts; a wave that finds none left keeps its place in the barriers
-// with idle batches until its three neighbours are done (at most one ray's worth at the very end).
+// ROUNDS of one batch per wave: before each round every wave runs the scheduler of instance_kernel<CFG> (take the next
+// unclaimed ray off the device work counter, compact its in-patch samples, collect tails of successive rays into one
+// packed batch); a wave that finds nothing left keeps its place in the barriers with idle batches until its three
+// neighbours are done (at most one ray's worth at the very end).
 // ---------------------------------------------------------------------------------------------
 template <class CFG>
 __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
@@ -494,20 +495,23 @@ __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
     __shared__ __attribute__((aligned(1024))) char ring[NSTAGE16 * STAGE16 * 1024];
     __shared__ __attribute__((aligned(16))) float aux[aux_total()];
     __shared__ uint16_t sidx_all[4][MAX_INSTANCE_SAMPLES];
+    __shared__ InstancePending pend_all[4];
     __shared__ int busy[4];
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.n_samples;
     uint16_t *sidx = sidx_all[wv];
+    InstancePending &pend = pend_all[wv];
     WShared ws;
     ws_prime<G16::NST>(ws, a.wstream, a.stream_bytes, (lds_char *)ring, lane, wv);
 
-    auto finish = [&](int64_t ray, const RayAccum &ra) {   // the appended sample and the store (renderer.py:323-352)
+    // the appended sample (colour taken as is, alpha_last is an alpha, not a density: renderer.py:323-339) and the store
+    auto finish = [&](int64_t ray, const RayAccum &ra) {
         const float wl = a.alpha_last[ray] * ra.T;
         float out[4] = {ra.c0 + wl * a.color_last[3 * ray], ra.c1 + wl * a.color_last[3 * ray + 1],
                         ra.c2 + wl * a.color_last[3 * ray + 2], ra.a + wl};
-        if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {
+        if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {   // renderer.py:351-352
             const float A = out[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) out[c] = out[c] + (1.0f - A) * a.bkgd[c];
@@ -522,52 +526,91 @@ __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
         }
     };
 
-    int64_t ray = -1;          // the ray this wave is marching, -1 = none
-    int count = 0, b = 0;
+    // The number of in-patch samples differs from ray to ray (0 .. S), so a static ray -> wave map leaves waves idle at the
+    // end (19 % on the carpet_instanced bench workload): each wave takes the next unclaimed ray instead.
+    int64_t cur = -1;            // the ray whose whole batches are being marched, -1 = none
+    int count = 0, nfull = 0, b = 0, pend_n = 0, pend_k = 0;
     bool exhausted = false;
     float cone = 0.0f;
     RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (;;) {
-        while (ray < 0 && !exhausted) {
-            int r32 = 0;
-            if (lane == 0) r32 = atomicAdd(a.work_counter, 1);
-            const int64_t r = (int64_t)__builtin_amdgcn_readfirstlane(r32);
-            if (r >= a.n_rays) { exhausted = true; break; }
-            if (!a.hit[r]) {   // renderer.py:265-272, 313-314: stays 0, also under composite_bkgd
-                if (lane < 3) a.color_out[3 * r + lane] = 0.0f;
-                if (lane == 3) a.alpha_out[r] = 0.0f;
+        // ---- scheduler (wave-uniform): advance until a batch is due.  mode 1 = a whole batch of `cur`, 2 = the packed tails
+        int mode = 0;
+        for (;;) {
+            if (cur >= 0 && b < nfull) { mode = 1; break; }
+            if (cur >= 0) {
+                const int r = count - 32 * nfull;
+                if (r == 0) { finish(cur, ra); cur = -1; continue; }
+                if (pend_n + r <= 32 && pend_k < PEND_MAX) {   // the tail joins the pending batch as segment pend_k
+                    if (lane < r) { pend.idx[pend_n + lane] = sidx[32 * nfull + lane]; pend.slot[pend_n + lane] = (uint8_t)pend_k; }
+                    if (lane == 0) {
+                        pend.ray[pend_k] = (int32_t)cur; pend.last[pend_k] = pend_n + r - 1; pend.cone[pend_k] = cone;
+                        pend.acc[pend_k][0] = ra.T; pend.acc[pend_k][1] = ra.c0; pend.acc[pend_k][2] = ra.c1;
+                        pend.acc[pend_k][3] = ra.c2; pend.acc[pend_k][4] = ra.a;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    pend_n += r; ++pend_k; cur = -1;
+                    continue;
+                }
+                mode = 2; break;   // no room: flush the pending batch first, `cur` joins the next one
+            }
+            if (!exhausted) {
+                int r32 = 0;
+                if (lane == 0) r32 = atomicAdd(a.work_counter, 1);
+                const int64_t ray = (int64_t)__builtin_amdgcn_readfirstlane(r32);
+                if (ray >= a.n_rays) { exhausted = true; continue; }
+                if (!a.hit[ray]) {   // renderer.py:265-272, 313-314: stays 0, also under composite_bkgd
+                    if (lane < 3) a.color_out[3 * ray + lane] = 0.0f;
+                    if (lane == 3) a.alpha_out[ray] = 0.0f;
+                    continue;
+                }
+                const float *drow = a.dists + ray * S;
+                int n = 0;
+                for (int base0 = 0; base0 < S; base0 += 512) {   // 8 independent loads in flight, then their 8 ballots
+                    float dv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int i = base0 + 64 * u + lane; dv[u] = i < S ? drow[i] : 0.0f; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = base0 + 64 * u + lane;
+                        const bool v = dv[u] > 0.0f;
+                        const unsigned long long m = __ballot(v);
+                        if (v) sidx[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+                        n += __popcll(m);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                cur = ray; count = n; nfull = n >> 5; b = 0;
+                cone = a.cone ? a.cone[ray] : 0.0f;
+                ra = RayAccum{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                 continue;
             }
-            const float *drow = a.dists + r * S;
-            int n = 0;
-            for (int base0 = 0; base0 < S; base0 += 512) {   // 8 independent loads in flight, then their 8 ballots
-                float dv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const int i = base0 + 64 * u + lane; dv[u] = i < S ? drow[i] : 0.0f; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = base0 + 64 * u + lane;
-                    const bool v = dv[u] > 0.0f;
-                    const unsigned long long m = __ballot(v);
-                    if (v) sidx[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
-                    n += __popcll(m);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            ra = RayAccum{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            if (n == 0) { finish(r, ra); continue; }   // a hit ray without in-patch samples: the appended sample alone
-            ray = r; count = n; b = 0;
-            cone = a.cone ? a.cone[r] : 0.0f;
+            if (pend_n > 0) mode = 2;
+            break;
         }
-        if (lane == 0) busy[wv] = ray >= 0;
+        // the four waves share the weight stream in lockstep ROUNDS of one batch each: a wave with nothing left keeps its
+        // place in the stream's barriers with an idle batch on sample 0 until its three neighbours are done too
+        if (lane == 0) busy[wv] = mode != 0;
         __syncthreads();
-        const bool any = (busy[0] | busy[1] | busy[2] | busy[3]) != 0;
+        const bool any = (busy[0] | busy[1] | busy[2] | busy[3]) != 0;   // (rewritten only after the batch's own barriers)
         if (!any) break;                               // the same for the four waves
-        const bool live = ray >= 0;
-        const int k = 32 * b + j;
-        const bool valid = live && k < count;
-        const int64_t sm = (live ? ray : 0) * S + (valid ? sidx[k] : (live ? sidx[0] : 0));
+
+        // ---- this lane's sample
+        bool valid = mode != 0;
+        int slot = 0;
+        int64_t sm = 0;
+        float cone_l = cone;
+        if (mode == 1) {
+            sm = cur * S + sidx[32 * b + j];
+        } else if (mode == 2) {
+            valid = j < pend_n;
+            const int jc = valid ? j : 0;
+            slot = pend.slot[jc];
+            sm = (int64_t)pend.ray[slot] * S + pend.idx[jc];
+            cone_l = pend.cone[slot];
+        }
         SampleIn<CFG::NGEO, CFG::NAPP> in;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { in.pos[c] = a.pts[3 * sm + c]; in.dir[c] = a.rays_d_map[3 * sm + c]; }
@@ -576,38 +619,45 @@ __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
 #pragma unroll
             for (int c = 0; c < CFG::NP; ++c) {
                 float p = a.params_map[CFG::NP * sm + c];
-                if (c == a.blur_idx) p = p * (cone * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
+                if (c == a.blur_idx) p = p * (cone_l * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
                 in.par[c] = p;
             }
-        } else {   // MipInstanceRenderer (renderer.py:510-540, 570-587), as in instance_kernel<CFG>
+        } else {
+            // MipInstanceRenderer (renderer.py:510-540, 570-587): radius = blur parameter * cone_scale / patch_scale,
+            // spliced out of the parameters; gaussian with mu = t and (sic) hw = dists; the mean is the sample point
             const float *pr = a.params_map + CFG::NP_IN * sm;
             float t_mean, t_var, r_var;
-            cone_moments(a.t[sm], a.dists[sm], pr[a.blur_idx] * cone / a.patch_scale, t_mean, t_var, r_var);
+            cone_moments(a.t[sm], a.dists[sm], pr[a.blur_idx] * cone_l / a.patch_scale, t_mean, t_var, r_var);
             cone_cov(t_var, r_var, in.dir, in.cov);
 #pragma unroll
             for (int c = 0; c < CFG::NP; ++c) in.par[c] = pr[c < a.blur_idx ? c : c + 1];
         }
         float sigma, raw[3];
         mlp_batch_x3<CFG, true>(in, ws, aux, lane, sigma, raw, 0);
-        if (live) {
-            const float wgt = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // :300
-            sigma = sigma * wgt;
-            float col[3];
-            if (a.instance_color) {                                                                // :306-307, 322-323
-                const int id = a.instance_id[sm];
+        if (mode == 0) continue;
+        const float wgt = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // :300
+        sigma = sigma * wgt;
+        float col[3];
+        if (a.instance_color) {                                                                // :306-307, 322-323
+            const int id = a.instance_id[sm];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) col[c] = a.instance_color[3 * id + c];
-            } else {
+            for (int c = 0; c < 3; ++c) col[c] = a.instance_color[3 * id + c];
+        } else {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) col[c] = (a.flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[c]) : sigmoidf_(raw[c]);
+            for (int c = 0; c < 3; ++c) col[c] = (a.flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[c]) : sigmoidf_(raw[c]);
+        }
+        const float al = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * a.dists[sm] / a.patch_scale) : 0.0f;   // :339
+        if (mode == 1) {
+            composite_core<32>(ra, al, col, true, j, nullptr);
+            ++b;
+        } else {
+            for (int k = 0; k < pend_k; ++k) {
+                RayAccum rk{pend.acc[k][0], pend.acc[k][1], pend.acc[k][2], pend.acc[k][3], pend.acc[k][4]};
+                composite_segment(rk, (valid && slot == k) ? al : 0.0f, col, j, pend.last[k]);
+                finish(pend.ray[k], rk);
             }
-            const float al = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * a.dists[sm] / a.patch_scale) : 0.0f;   // :339
-            composite_core<32>(ra, al, col, valid, j, nullptr);
-            if (++b * 32 >= count) {
-                finish(ray, ra);
-                __builtin_amdgcn_wave_barrier();   // the index list is rewritten by the next ray
-                ray = -1;
-            }
+            __builtin_amdgcn_wave_barrier();   // the pending batch is rewritten from here on
+            pend_n = 0; pend_k = 0;
         }
     }
 }

@@ -97,6 +97,25 @@ def renderer_call(w_np: List[np.ndarray], spec, rays_o, rays_d, t, parameters_ro
         return torch.cat(cols, 0).numpy(), torch.cat(alps, 0).numpy()
 
 
+def effective_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (cpu.max / cfs_quota_us) --
+    on a container with 256 visible CPUs and a 16-CPU quota, 128 BLAS threads run several times slower than 16."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def blas_backend() -> str:
     cfg = torch.__config__.show()
     keys = [ln.strip() for ln in cfg.splitlines() if any(k in ln for k in ("BLAS_INFO", "LAPACK_INFO", "USE_MKL=", "USE_MKLDNN=", "MKL ", "oneAPI", "OpenBLAS"))]

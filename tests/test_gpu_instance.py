@@ -160,3 +160,52 @@ def test_instance_renderer_plain_nerf(precision):
     want = np.concatenate([rc, ra[:, None]], -1)
     assert orc.rel_linf(got, want) <= TOL
     assert float(np.max(ra)) > 0.3
+
+
+@pytest.mark.parametrize("precision", ["float32", "fp16x3"])
+def test_packed_tails_do_not_depend_on_the_company(precision):
+    """The instanced kernels evaluate the tails (count % 32 samples) of successive rays of a wave in ONE packed batch; which
+    rays meet there depends on the dynamic ray hand-out.  The image must not: every ray's result is bit-identical from run
+    to run, under any permutation of the rays, and when the ray is rendered on its own."""
+    from nerf_tex_amd import _lib
+    model, spec, w = make_model((1, 6), dense_media=True)
+    inst = FakeInstancer(7, seed=21, p_hit=0.9, p_in=0.3)
+    n, S = 1500, 150                                      # in-patch counts ~45 +- 6: every kind of tail
+    rng = np.random.default_rng(4)
+    params = rng.uniform(0.2, 1, size=(n, 7)).astype(np.float32)
+    bufs = inst.get_model_input(np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), params, S, 0.002)
+    rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map = bufs
+    hit = np.zeros(n, np.uint8); hit[idxs[:, 0]] = 1
+    cone = rng.uniform(1e-3, 5e-3, size=n).astype(np.float32)
+    dv = torch.device("cuda", 0)
+    flags = _lib.PRECISIONS[precision]
+
+    def render(order):
+        d = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a[order]), device=dv).to(dt).contiguous()
+        t_ = dict(rd=d(rays_d_map), pts=d(pts), t=d(tt), dists=d(dists), cl=d(color_last.reshape(n, 3)), al=d(alpha_last.reshape(n)),
+                  aw=d(alpha_weight), iid=d(instance_id, torch.int32), hit=d(hit, torch.uint8), pm=d(params_map), cone=d(cone))
+        k = len(order)
+        col = torch.empty((k, 3), device=dv); alp = torch.empty((k,), device=dv)
+        _lib.check(_lib.lib.ntx_render_instanced(
+            model.ctx(0), t_["rd"].data_ptr(), t_["pts"].data_ptr(), t_["t"].data_ptr(), t_["dists"].data_ptr(), t_["cl"].data_ptr(),
+            t_["al"].data_ptr(), t_["aw"].data_ptr(), t_["iid"].data_ptr(), t_["hit"].data_ptr(), t_["pm"].data_ptr(), t_["cone"].data_ptr(),
+            k, S, -1, 0.09, 400.0, flags, _lib.f3([1, 1, 1.]), None, col.data_ptr(), alp.data_ptr(), None,
+            torch.cuda.current_stream(dv).cuda_stream))
+        torch.cuda.synchronize()
+        return np.concatenate([col.cpu().numpy(), alp.cpu().numpy()[:, None]], -1)
+
+    ident = np.arange(n)
+    base = render(ident)
+    for _ in range(3):
+        assert np.array_equal(render(ident), base)                                   # run to run
+    perm = np.random.default_rng(9).permutation(n)
+    assert np.array_equal(render(perm), base[perm])                                  # any neighbours
+    some = np.asarray([5, 17, 333, 1499])
+    for r in some:
+        assert np.array_equal(render(np.asarray([r]))[0], base[r])                   # alone
+    counts = (dists > 0).sum(-1)
+    assert len(set((counts[hit == 1] % 32).tolist())) > 20 and (counts[hit == 1] >= 32).any()
+    rc, ra = orc.instance_evaluate_model(w, spec, rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id,
+                                         hit.astype(bool), params_map, cone[:, None], None, 0.09, 400.0, True, False, False, (1., 1., 1.),
+                                         None, dtype=np.float64)
+    assert orc.rel_linf(base, np.concatenate([rc, ra[:, None]], -1)) <= TOL

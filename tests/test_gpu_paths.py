@@ -314,15 +314,16 @@ def test_renderer_reserves_beyond_the_default():
     from nerf_tex_amd import _lib, synthetic
     from nerf_tex_amd.renderer import Renderer
     fam = synthetic.FAMILIES["carpet"]
-    model, _, _ = make_model((1, 6))
+    model, _, _ = make_model((1, 6), dense_media=True)
     n = _lib.DEFAULT_MAX_RAYS + 1000
     ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"])
-    t[:] = np.inf; t[-5:] = [2.0, 3.0]                                        # all but 5 rays culled: cheap
-    out = Renderer(model=model, n_samples=8, perturb=False)(*to_dev(ro[None], rd[None], t[None]),
-                                                             parameters=to_dev(np.asarray([fam["params"]], np.float32))[0],
-                                                             cone_scale=to_dev(cone[None])[0])
+    t[:-5] = np.inf                                                            # all but 5 rays culled: cheap
+    params = to_dev(np.asarray([fam["params"]], np.float32))[0]
+    r = Renderer(model=model, n_samples=8, perturb=False)
+    out = r(*to_dev(ro[None], rd[None], t[None]), parameters=params, cone_scale=to_dev(cone[None])[0])
     a = out["alpha_pred"][0]
-    assert bool((a[:-5] == 0).all()) and bool((a[-5:] > 0).all())
+    alone = r(*to_dev(ro[None, -5:], rd[None, -5:], t[None, -5:]), parameters=params, cone_scale=to_dev(cone[None, -5:])[0])
+    assert bool((a[:-5] == 0).all()) and bool((a[-5:] > 0).any()) and torch.equal(a[-5:], alone["alpha_pred"][0])
 
 
 def test_precision_is_per_call_on_a_shared_context():
