@@ -109,9 +109,10 @@ int ntx_set_weights(ntx_ctx *ctx, const float *weights_host, size_t n_floats);
 int ntx_destroy(ntx_ctx *ctx);
 
 /* Setup-time sizing of the context's device scratch (synchronous; frees and re-allocates): after ntx_reserve(ctx, n),
- * ntx_render_rays accepts up to n rays per call and allocates nothing.  Scratch = 4 B per ray (the compacted list of rays
- * that hit the proxy, renderer.py:58-67).  ntx_create reserves NTX_DEFAULT_MAX_RAYS; a call with more rays than
- * reserved fails with NTX_E_INVALID and renders nothing. */
+ * ntx_render_rays / ntx_render_instanced accept up to n rays per call and allocate nothing.  Scratch = 8 B per ray (the
+ * compacted list of rays that hit the proxy, renderer.py:58-67; the cost-ordered ray list of the instanced kernels).
+ * ntx_create reserves NTX_DEFAULT_MAX_RAYS; a call with more rays than reserved fails with NTX_E_INVALID and renders
+ * nothing. */
 #define NTX_DEFAULT_MAX_RAYS (1 << 20)
 int ntx_reserve(ntx_ctx *ctx, int64_t max_rays);
 

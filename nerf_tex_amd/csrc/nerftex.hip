@@ -490,7 +490,8 @@ int ntx_reserve(ntx_ctx *ctx, int64_t max_rays) {
     HIP_TRY(hipDeviceSynchronize());   // a launch may still be walking the old list
     if (ctx->hit_list) HIP_TRY(hipFree(ctx->hit_list));
     ctx->hit_list = nullptr; ctx->hit_cap = 0;
-    if (max_rays > 0) HIP_TRY(hipMalloc((void **)&ctx->hit_list, (size_t)max_rays * sizeof(int32_t)));
+    // ntx_render_rays: hit_list[max_rays]; ntx_render_instanced: order[max_rays] | count[max_rays] | bins[INST_BINS]
+    if (max_rays > 0) HIP_TRY(hipMalloc((void **)&ctx->hit_list, ((size_t)max_rays * 2 + INST_BINS) * sizeof(int32_t)));
     ctx->hit_cap = (size_t)max_rays;
     return NTX_OK;
 }
@@ -727,9 +728,21 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
     if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "n_rays %lld exceeds int32", (long long)n_rays);
     // dynamic ray hand-out: a device counter owned by the context (stream-ordered use, like the other scratch)
+    if ((size_t)n_rays > ctx->hit_cap)
+        return fail(NTX_E_INVALID, "n_rays %lld exceeds the %zu rays this context reserved; call ntx_reserve first", (long long)n_rays, ctx->hit_cap);
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemsetAsync(ctx->hit_count + 1, 0, sizeof(int32_t), (hipStream_t)stream));   // [0] hits of ntx_render_rays, [1] this counter
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(ctx->hit_count + 1, 0, sizeof(int32_t), st));   // [0] hits of ntx_render_rays, [1] this counter
     a.work_counter = ctx->hit_count + 1;
+    {   // hand the rays out costliest first (ntx_small_kernels.h: inst_*_kernel); scratch reserved in the context
+        int32_t *order = ctx->hit_list, *count = ctx->hit_list + ctx->hit_cap, *bins = ctx->hit_list + 2 * ctx->hit_cap;
+        HIP_TRY(hipMemsetAsync(bins, 0, INST_BINS * sizeof(int32_t), st));
+        inst_count_kernel<<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st>>>(dists, hit, n_rays, n_samples, count, bins);
+        inst_offsets_kernel<<<dim3(1), dim3(INST_BINS), 0, st>>>(bins);
+        inst_scatter_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st>>>(count, n_rays, bins, order);
+        HIP_TRY(hipGetLastError());
+        a.order = order;
+    }
     if (flags & NTX_FLAG_FP16X3) {
         // directions are per sample: ParamNerf uses the stream that keeps C1's direction segment; plain Nerf's one stream
         // has it in C2 anyway

@@ -849,6 +849,7 @@ struct InstanceArgs {
     float patch_scale, density_scale;
     float bkgd[3];
     int32_t *work_counter;   // device scalar, zero at launch: rays are handed out dynamically (their cost varies 0..S/32 batches)
+    const int32_t *order;    // the rays, costliest first (inst_*_kernel, ntx_small_kernels.h): claim k marches ray order[k]
 };
 
 // Tail packing.  A ray's in-patch samples fill count / 32 whole batches and leave a TAIL of count % 32 samples; run as a
@@ -963,8 +964,9 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
             if (!exhausted) {
                 int r32 = 0;
                 if (lane == 0) r32 = atomicAdd(a.work_counter, 1);
-                const int64_t ray = (int64_t)__builtin_amdgcn_readfirstlane(r32);
-                if (ray >= a.n_rays) { exhausted = true; continue; }
+                const int64_t claim = (int64_t)__builtin_amdgcn_readfirstlane(r32);
+                if (claim >= a.n_rays) { exhausted = true; continue; }
+                const int64_t ray = a.order[claim];
                 if (!a.hit[ray]) {   // renderer.py:265-272, 313-314: stays 0, also under composite_bkgd
                     if (lane < 3) a.color_out[3 * ray + lane] = 0.0f;
                     if (lane == 3) a.alpha_out[ray] = 0.0f;

@@ -558,8 +558,9 @@ __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
             if (!exhausted) {
                 int r32 = 0;
                 if (lane == 0) r32 = atomicAdd(a.work_counter, 1);
-                const int64_t ray = (int64_t)__builtin_amdgcn_readfirstlane(r32);
-                if (ray >= a.n_rays) { exhausted = true; continue; }
+                const int64_t claim = (int64_t)__builtin_amdgcn_readfirstlane(r32);
+                if (claim >= a.n_rays) { exhausted = true; continue; }
+                const int64_t ray = a.order[claim];
                 if (!a.hit[ray]) {   // renderer.py:265-272, 313-314: stays 0, also under composite_bkgd
                     if (lane < 3) a.color_out[3 * ray + lane] = 0.0f;
                     if (lane == 3) a.alpha_out[ray] = 0.0f;

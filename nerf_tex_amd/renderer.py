@@ -261,6 +261,7 @@ class InstanceRenderer(Renderer):
             col_c = torch.empty((k, 3), device=dev, dtype=torch.float32)
             al_c = torch.empty((k,), device=dev, dtype=torch.float32)
             ptr = lambda x: x.data_ptr() if x is not None else None
+            self.model.reserve(dev.index or 0, k)          # setup-time; a no-op once the context has seen this size
             with torch.cuda.device(dev):
                 _lib.check(_lib.lib.ntx_render_instanced(
                     self.model.ctx(dev.index or 0), ptr(bufs["rays_d_map"]), ptr(bufs["pts"]), ptr(bufs["t"]),
