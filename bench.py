@@ -384,6 +384,8 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(family, S)
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()                                       # rank 0 may still be rendering its reference image
     if comm is not None:
         comm.close()
     if world > 1:

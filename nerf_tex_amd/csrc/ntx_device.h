@@ -717,6 +717,15 @@ NTX_DEV void dir_block(const RenderArgs &a, __amdgpu_buffer_rsrc_t rsrc, const f
   }
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup w runs on XCD w % 8), each XCD with its own L2.  Rays are
+// handed out by a VIRTUAL workgroup number that is XCD-major, so that in every round the workgroups of one XCD take one
+// contiguous run of the hit list: neighbouring rays share the cache lines of rays_o / rays_d / t / cone (12 + 12 + 8 + 4
+// bytes per ray), and a line is then fetched into ONE L2 instead of up to eight.
+NTX_DEV int xcd_major_workgroup(int wg, int n_wgs) {
+    constexpr int XCDS = 8;
+    return (n_wgs % XCDS) ? wg : (wg % XCDS) * (n_wgs / XCDS) + wg / XCDS;
+}
+
 template <class CFG, bool HOIST = false>
 __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     static_assert(!HOIST || CFG::CD != 0, "direction hoisting is for the ParamNerf families");
@@ -725,7 +734,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     float *dir_rows = aux + aux_total() + 4 * PE_KEEP_FLOATS;
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int vwg = xcd_major_workgroup(blockIdx.x, gridDim.x);
+    const int wave = __builtin_amdgcn_readfirstlane(vwg * 4 + (threadIdx.x >> 6));
     const int nwaves = gridDim.x * 4;
     const int S = a.n_samples;
     const int nb = (S + 31) >> 5;
@@ -738,7 +748,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     for (int base = 0; base < n_work; base += DIR_BLOCK_ITERS * nwaves) {
         if constexpr (HOIST) {
             __syncthreads();   // every wave is done with the previous block's rows
-            dir_block<CFG>(a, ws.rsrc, aux, dir_rows, base, nwaves, blockIdx.x, wv, lane, n_work);
+            dir_block<CFG>(a, ws.rsrc, aux, dir_rows, base, nwaves, vwg, wv, lane, n_work);
             __syncthreads();
         }
       for (int it = 0; it < DIR_BLOCK_ITERS; ++it) {

@@ -384,7 +384,7 @@ NTX_DEV void mlp_batch_x3(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WShared &ws,
 }
 
 // the fused render kernel at fp16x3 precision.  Same per-ray work as render_kernel<CFG> around the MLP, but over the
-// compacted hit list and in workgroup lockstep: iteration `it` gives wave w of workgroup g the hit ray number
+// compacted hit list and in workgroup lockstep: iteration `it` gives wave w of (virtual, XCD-major) workgroup g the hit ray number
 // it * (4 * gridDim) + 4 g + w; waves past the end of the list go through the motions on the last hit ray and store nothing.
 template <class CFG>
 __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
@@ -403,16 +403,17 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
     WShared ws;
     ws_prime<G16::NST>(ws, a.wstream, a.stream_bytes, (lds_char *)ring, lane, wv);
 
+    const int vwg = xcd_major_workgroup(blockIdx.x, gridDim.x);   // rays are handed out XCD-major (ntx_device.h)
     __amdgpu_buffer_rsrc_t dir_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(a.dir_wstream), 0, a.dir_stream_bytes, 0x00020000);
     for (int it = 0; it < iters; ++it) {
         if constexpr (CFG::CD != 0) {
             if (it % DIR_BLOCK_ITERS == 0) {   // the C1 start vectors of the next 8 rays of each wave (float32, as the f32 kernel)
                 __syncthreads();
-                dir_block<CFG>(a, dir_rsrc, aux, aux + aux_total(), it * per_it, per_it, blockIdx.x, wv, lane, n_hit);
+                dir_block<CFG>(a, dir_rsrc, aux, aux + aux_total(), it * per_it, per_it, vwg, wv, lane, n_hit);
                 __syncthreads();
             }
         }
-        const int idx = it * per_it + blockIdx.x * 4 + wv;
+        const int idx = it * per_it + vwg * 4 + wv;
         const bool live = idx < n_hit;
         const int64_t ray = a.hit_list[live ? idx : n_hit - 1];
         RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
