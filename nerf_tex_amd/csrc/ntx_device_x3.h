@@ -69,8 +69,12 @@ NTX_DEV void stage_fetch(const WShared &ws) {
 // end of a stage: my quarter of the stage after next has landed (only the newest fetch may still be in flight), and
 // everybody is done reading this one
 NTX_DEV void stage_end() {
+#ifndef NTX_X3_EXPERIMENT_NO_VMWAIT     // timing experiments only (results are then wrong): DESIGN.md section 4.1b
     __builtin_amdgcn_s_waitcnt(vmcnt_imm(4));
+#endif
+#ifndef NTX_X3_EXPERIMENT_NO_BARRIER
     __builtin_amdgcn_s_barrier();
+#endif
 }
 
 // records REC .. REC+3 (one pair-group; never straddles a stage) -> registers
