@@ -216,6 +216,13 @@ def main() -> None:
     if args.workload == "carpet_instanced":
         return bench_instanced(args)
 
+    # The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL writes its version banner with printf
+    # when a communicator is created), so from here on file descriptor 1 goes to stderr and the line is written to the
+    # original stdout at the end.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from nerf_tex_amd import synthetic
@@ -383,7 +390,8 @@ def main() -> None:
             line["perturb"] = jit
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(family, S)
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if world > 1:
         dist.barrier()                                       # rank 0 may still be rendering its reference image
     if comm is not None:

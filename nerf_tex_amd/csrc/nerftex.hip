@@ -715,6 +715,7 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     if (blur_idx >= 0 && (!cone_scale || !t)) return fail(NTX_E_INVALID, "blur_idx set but cone_scale / t is NULL");
     if (instance_color && !instance_id) return fail(NTX_E_INVALID, "instance_color given without instance_id");
     if (!(patch_scale > 0.0f)) return fail(NTX_E_INVALID, "patch_scale must be > 0");
+    if (flags & NTX_FLAG_PERTURB) return fail(NTX_E_INVALID, "NTX_FLAG_PERTURB: the instancer places the samples of this path, there is nothing to jitter");
     InstanceArgs a{};
     a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed);
     a.stream_bytes = (uint32_t)(ctx->stream_floats * sizeof(float));

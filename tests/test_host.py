@@ -235,6 +235,23 @@ def test_shard_map_partitions_and_matches_the_c_abi():
     assert _lib.lib.ntx_shard_count(10, 0, 2, 0) == -1 and _lib.lib.ntx_shard_count(10, 4, 2, 2) == -1
 
 
+def test_unshard_formula_of_the_gather_kernel():
+    """ntx_unshard_kernel (ntx_comm.hip) on the root: image[p] = staging[(q % R) * cap + (q / R) * L + p % L], q = p / L, with
+    every rank's shard at staging[rank * cap ...] in its local ray order.  Emulated here on the shard maps of BASELINE
+    configs[3] / [4] and on ragged ones (no multi-GPU box is available to run the kernel with R > 1)."""
+    from nerf_tex_amd.dist import ShardMap
+    for n, R, L in [(800 * 800, 8, 800), (1600 * 1600, 8, 1600), (1000, 3, 7), (37, 4, 5), (640000, 8, None), (101, 2, None)]:
+        m = ShardMap(n, R, L)
+        cap = m.capacity
+        full = np.arange(n, dtype=np.int64) * 3 + 1
+        staging = np.full(R * cap, -1, np.int64)
+        for r in range(R):
+            staging[r * cap: r * cap + m.count(r)] = full[m.local_pixels(r)]
+        p = np.arange(n)
+        q = p // m.run
+        assert np.array_equal(staging[(q % R) * cap + (q // R) * m.run + p % m.run], full)
+
+
 def _gather_worker(rank, world, port, n_total, run, q):
     import torch
     import torch.distributed as dist
