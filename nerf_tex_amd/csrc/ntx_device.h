@@ -179,6 +179,15 @@ NTX_DEV void store_act(float (&hin)[128], const f32x16 (&acc)[8]) {
     static_for<NMT * 2>([&](auto V) { convert8<decltype(V)::value * 8, RELU>(hin, acc); });
 }
 
+// per-ray rows (dir_block, below) live in LDS, 32 ray slots of a workgroup at a time
+#ifndef NTX_DIR_BLOCK_ITERS
+#define NTX_DIR_BLOCK_ITERS 8
+#endif
+constexpr int DIR_BLOCK_ITERS = NTX_DIR_BLOCK_ITERS;   // rays per wave and block
+constexpr int DIR_BLOCK_RAYS = 4 * DIR_BLOCK_ITERS;   // a multiple of 32 = one MFMA's worth of B columns
+constexpr int DIR_ROW_STRIDE = 256 + 4;            // floats; +4: the 32 lanes' b128 stores spread over the LDS banks
+constexpr int DIR_BLOCK_FLOATS = DIR_BLOCK_RAYS * DIR_ROW_STRIDE;
+
 // ---------------------------------------------------------------------------------------------
 // one segment: acc[mt] += W_segment^T * B over NSTEPS k-steps, one MFMA per (step, tile) SLOT.
 //   gen   : B-operand generator; stages of step S+1 run in the slots of step S
@@ -241,13 +250,6 @@ NTX_DEV SampleIn<NGEO, NAPP> launder(const SampleIn<NGEO, NAPP> &in) {
     return o;
 }
 
-// identity value v of the position segment: [pos(3) | geometry params]
-template <int NGEO, int NAPP, int V>
-NTX_DEV float pos_id_value(const SampleIn<NGEO, NAPP> &in) {
-    if constexpr (V < 3) return in.pos[V];
-    else if constexpr (V - 3 < NGEO) return in.par[V - 3];
-    else return 0.0f;
-}
 // identity value v of the direction segment: [dir(3) | appearance params]
 template <int NGEO, int NAPP, int V>
 NTX_DEV float dir_id_value(const SampleIn<NGEO, NAPP> &in) {
@@ -256,22 +258,29 @@ NTX_DEV float dir_id_value(const SampleIn<NGEO, NAPP> &in) {
     else return 0.0f;
 }
 
-// k-step S of the position segment: identity pairs, then {sin,cos}(2^f pos_c), then {sin,cos}(2^f geo_g).
-// IPE (layer.py:25-41): no identity for the position, and every pair is damped by exp(-0.5 * 4^f * cov_c).
+// k-step S of the position segment (ntx_layout.h: geometry-parameter block first, then the position block).
+// IPE (layer.py:25-41): no identity for the position, and every position pair is damped by exp(-0.5 * 4^f * cov_c).
 template <int NGEO, int NAPP, int IPE, int S>
 NTX_DEV float pos_feature(const SampleIn<NGEO, NAPP> &in, int h) {
-    constexpr int nid = pos_id_steps(NGEO, IPE), n3 = IPE ? 0 : 3;
-    if constexpr (S < nid) {
-        const float lo = pos_id_value<NGEO, NAPP, 2 * S + (3 - n3)>(in), hi = pos_id_value<NGEO, NAPP, 2 * S + 1 + (3 - n3)>(in);
+    constexpr int ngid = (NGEO + 1) / 2, ngs = NGEO * PAR_FREQ, npid = IPE ? 0 : 2;
+    if constexpr (S < ngid) {
+        float lo = 0.0f, hi = 0.0f;
+        if constexpr (2 * S < NGEO) lo = in.par[2 * S];
+        if constexpr (2 * S + 1 < NGEO) hi = in.par[2 * S + 1];
         return h ? hi : lo;
-    } else if constexpr (S - nid < 3 * POS_FREQ) {
-        constexpr int q = S - nid, f = q / 3, c = q % 3;
+    } else if constexpr (S - ngid < ngs) {
+        constexpr int q = S - ngid, f = q / (NGEO > 0 ? NGEO : 1), g = q % (NGEO > 0 ? NGEO : 1);
+        return sin_q(in.par[g] * (float)(1 << f), h);
+    } else if constexpr (S - ngid - ngs < npid) {
+        constexpr int q = S - ngid - ngs;
+        float lo = in.pos[2 * q < 3 ? 2 * q : 0], hi = 0.0f;
+        if constexpr (2 * q + 1 < 3) hi = in.pos[2 * q + 1];
+        return h ? hi : lo;
+    } else if constexpr (S - ngid - ngs - npid < 3 * POS_FREQ) {
+        constexpr int q = S - ngid - ngs - npid, f = q / 3, c = q % 3;
         const float v = sin_q(in.pos[c] * (float)(1 << f), h);
         if constexpr (IPE) return v * expf(-0.5f * (in.cov[c] * (float)(1 << (2 * f))));
         else return v;
-    } else if constexpr (S - nid - 3 * POS_FREQ < NGEO * PAR_FREQ) {
-        constexpr int q = S - nid - 3 * POS_FREQ, f = q / (NGEO > 0 ? NGEO : 1), g = q % (NGEO > 0 ? NGEO : 1);
-        return sin_q(in.par[g] * (float)(1 << f), h);
     } else {
         return 0.0f;
     }
@@ -297,7 +306,8 @@ NTX_DEV float dir_feature(const SampleIn<NGEO, NAPP> &in, int h) {
 // KEEP = 1: evaluate and keep every value in this lane's LDS column pe[step * 64]; KEEP = 2: read them back instead of
 // evaluating again (the skip layer re-concatenates the same pos_map, model.py:107-108: one sin() per k-step saved, and
 // on gfx950 VALU time is not hidden behind the f32 MFMAs); KEEP = 0: evaluate, no LDS.
-template <int NGEO, int NAPP, int IPE, int KEEP = 0>
+// OFF: the segment starts at k-step OFF (the geometry-parameter block before it is evaluated per ray, HOIST = 2).
+template <int NGEO, int NAPP, int IPE, int KEEP = 0, int OFF = 0>
 struct PosGen {
     const SampleIn<NGEO, NAPP> &in;
     int h;
@@ -308,10 +318,10 @@ struct PosGen {
         static_for<N>([&](auto K) {
             constexpr int s = S + decltype(K)::value;
             if constexpr (KEEP == 2) {
-                vals[s % PE_GROUP] = pe[s * 64];
+                vals[s % PE_GROUP] = pe[(s + OFF) * 64];
             } else {
-                vals[s % PE_GROUP] = pos_feature<NGEO, NAPP, IPE, s>(in, h);
-                if constexpr (KEEP == 1) pe[s * 64] = vals[s % PE_GROUP];
+                vals[s % PE_GROUP] = pos_feature<NGEO, NAPP, IPE, s + OFF>(in, h);
+                if constexpr (KEEP == 1) pe[(s + OFF) * 64] = vals[s % PE_GROUP];
             }
         });
     }
@@ -359,11 +369,15 @@ struct Cfg {
 // ([half][128], accumulator order) = the per-ray vector bias_C1 + W_dir^T dir_map that dir_block computed with the same
 // instructions, and the direction segment is skipped (its records are still fetched, to keep the ring phase).  A
 // compile-time variant, not a run-time branch: a branch around the segment made hipcc spill 1 KiB per lane.
-template <class CFG, bool HOIST = false>
+// HOIST = 2 (no blur_idx): the geometry-parameter block of the position segments of L0 and L5 is per-ray constant too; L0
+// and L5 start from the rows dir_block left behind the C1 row (c1_row + DIR_BLOCK_FLOATS, + 2 DIR_BLOCK_FLOATS) and run only
+// the position block.
+template <class CFG, int HOIST = 0>
 NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
                        const float *aux_in, int lane, float &sigma, float (&rgb)[3],
                        const float *c1_row = nullptr, float *pe = nullptr) {
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
+    constexpr int GS = HOIST == 2 ? pos_geo_steps(NGEO) : 0;   // k-steps of the position segments evaluated per ray
     const int h = lane >> 5;
     // The aux block in LDS never changes, so the optimiser would hoist every bias / head-weight
     // read out of the batch loop and then spill ~600 values to scratch.  An opaque OFFSET (not an
@@ -377,10 +391,16 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
     auto none = [](auto, auto) {};
 
     // ---- trunk layer 0: pos_map -> 256 (model.py:104-106) into set A; set B <- bias of layer 1
-    init_bias<8>(accA, aux, 0, h);
+    if constexpr (HOIST == 2) {
+        static_for<8>([&](auto T) { init_bias_tile_row<decltype(T)::value>(accA, c1_row + DIR_BLOCK_FLOATS + opaque_zero, h); });
+        skip_records<GS * 2, 0>(ws);   // the geometry block's records: already in the accumulators, through the row
+    } else {
+        init_bias<8>(accA, aux, 0, h);
+    }
     {
-        PosGen<NGEO, NAPP, CFG::IPE, 1> gen{in, h, {}, pe};
-        run_segment<CFG::PS, 8, 0>(accA, ws, gen, [&](auto S, auto MT) {
+        PosGen<NGEO, NAPP, CFG::IPE, 1, GS> gen{in, h, {}, pe};
+        static_assert(CFG::PS - GS >= 29, "layer-1 bias initialised behind layer 0");
+        run_segment<CFG::PS - GS, 8, GS * 2>(accA, ws, gen, [&](auto S, auto MT) {
             constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
             if constexpr (mt == 1 && s % 4 == 0 && s < 32) init_bias_tile<s / 4>(accB, aux, 1, h);
         });
@@ -401,7 +421,8 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
         auto reinit = [&](auto S, auto MT) {
             constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
             if constexpr (init_next && mt == 1 && (s & 15) == 0) {
-                if constexpr (HOIST && CFG::CD != 0 && next_bias == 9) init_bias_tile_row<(s >> 4)>(prev, c1_row + opaque_zero, h);
+                if constexpr (HOIST != 0 && CFG::CD != 0 && next_bias == 9) init_bias_tile_row<(s >> 4)>(prev, c1_row + opaque_zero, h);
+                else if constexpr (HOIST == 2 && next_bias == SKIP + 1) init_bias_tile_row<(s >> 4)>(prev, c1_row + 2 * DIR_BLOCK_FLOATS + opaque_zero, h);
                 else init_bias_tile<(s >> 4)>(prev, aux, next_bias, h);
             }
         };
@@ -416,10 +437,11 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
             auto conv = none;
             const SampleIn<NGEO, NAPP> in2 = launder(in);
             if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
-                PosGen<NGEO, NAPP, CFG::IPE, 2> gen{in2, h, {}, pe};   // the values layer 0 kept
-                run_segment<pre_steps, 8, rec0>(cur, ws, gen, conv);
+                PosGen<NGEO, NAPP, CFG::IPE, 2, GS> gen{in2, h, {}, pe};   // the values layer 0 kept
+                if constexpr (GS > 0) skip_records<GS * 2, rec0>(ws);
+                run_segment<pre_steps - GS, 8, rec0 + GS * 2>(cur, ws, gen, conv);
             } else {                   // input = concat[dir_map, feature]  (model.py:115)
-                if constexpr (HOIST) {
+                if constexpr (HOIST != 0) {
                     skip_records<pre_steps * 2, rec0>(ws);   // already in the accumulators, through c1_row
                 } else {
                     DirGen<NGEO, NAPP> gen{in2, h, {}};
@@ -655,55 +677,29 @@ NTX_DEV float z_of(const RenderArgs &a, int64_t ray, int i, float t0, float t1, 
 // of the MFMA depends only on its own B column, so starting the C1 accumulators from the stored row is bit-identical
 // to evaluating the segment per sample.  No global scratch, no extra launch, no HBM traffic; one pair of workgroup
 // barriers per 8 rays of each wave.  Not applicable when blur_idx scales an APPEARANCE parameter per sample
-// (renderer.py:155-158); the host then launches the HOIST = false kernel.
+// (renderer.py:155-158); the host then launches the HOIST = 0 kernel.
 // ---------------------------------------------------------------------------------------------
-#ifndef NTX_DIR_BLOCK_ITERS
-#define NTX_DIR_BLOCK_ITERS 8
-#endif
-constexpr int DIR_BLOCK_ITERS = NTX_DIR_BLOCK_ITERS;   // rays per wave and block
-constexpr int DIR_BLOCK_RAYS = 4 * DIR_BLOCK_ITERS;   // a multiple of 32 = one MFMA's worth of B columns
-constexpr int DIR_ROW_STRIDE = 256 + 4;            // floats; +4: the 32 lanes' b128 stores spread over the LDS banks
-constexpr int DIR_BLOCK_FLOATS = DIR_BLOCK_RAYS * DIR_ROW_STRIDE;
-
-// rows[slot] for slot = it * 4 + w  <->  hit number base + it * nwaves_total + 4 * workgroup + w
-template <class CFG>
-NTX_DEV void dir_block(const RenderArgs &a, __amdgpu_buffer_rsrc_t rsrc, const float *aux, float *rows, int base, int nwaves,
-                       int wg, int wv, int lane, int n_work) {
-    static_assert(CFG::CD != 0, "ParamNerf families");
-    const int h = lane >> 5;
-    static_assert(DIR_BLOCK_RAYS % 32 == 0, "whole MFMA column sets");
-  for (int j = lane & 31; j < DIR_BLOCK_RAYS; j += 32) {   // 32 ray slots per MFMA column set
-    if (j >= 32 && base + (j >> 5) * 8 * nwaves >= n_work) break;   // (wave-uniform) the rest of the block lies past the end of the list
-    int idx = base + (j >> 2) * nwaves + 4 * wg + (j & 3);
-    idx = idx < n_work ? idx : n_work - 1;
-    const int64_t ray = a.hit_list[idx];
-    const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
-    const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);   // as the render kernel (renderer.py:98)
-    SampleIn<CFG::NGEO, CFG::NAPP> in;
-    in.pos[0] = in.pos[1] = in.pos[2] = 0.0f;
-    in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
-    in.dir[0] = dx / dnorm; in.dir[1] = dy / dnorm; in.dir[2] = dz / dnorm;
-    const float *prow = a.params + (ray / a.rays_per_row) * CFG::NP_IN;
-#pragma unroll
-    for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[(CFG::IPE != 0 && k >= a.blur_idx) ? k + 1 : k];
+// one family of rows: acc = bias[BIAS_LAYER] + sum over k-steps 0 .. NSTEPS-1 of the segment whose first record is REC0, B
+// operand from FEAT(step); this wave's 2 output tiles of the 32 ray slots -> rows[slot][half][16 t + r]
+template <int NSTEPS, int REC0, int BIAS_LAYER, class Feat>
+NTX_DEV void ray_rows(__amdgpu_buffer_rsrc_t rsrc, const float *aux, float *rows, int j, int h, int wv, int lane, Feat &&feat) {
     // tiles 2 wv and 2 wv + 1: elements (2 wv) % 4, +1 of record 2 s + wv / 2 of k-step s
     const int t0 = 2 * wv;
     f32x16 acc0, acc1;
     {
-        const f32x4 *b = reinterpret_cast<const f32x4 *>(aux + 9 * AUX_BIAS_STRIDE + h * 128) + t0 * 4;
+        const f32x4 *b = reinterpret_cast<const f32x4 *>(aux + BIAS_LAYER * AUX_BIAS_STRIDE + h * 128) + t0 * 4;
         const f32x4 v0 = b[0], v1 = b[1], v2 = b[2], v3 = b[3], v4 = b[4], v5 = b[5], v6 = b[6], v7 = b[7];
         acc0 = f32x16{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
         acc1 = f32x16{v4.x, v4.y, v4.z, v4.w, v5.x, v5.y, v5.z, v5.w, v6.x, v6.y, v6.z, v6.w, v7.x, v7.y, v7.z, v7.w};
     }
-    constexpr int REC0 = CFG::rec_pass(9);
     const uint32_t voff = (uint32_t)lane * 16u;
     const uint32_t rec_base = (uint32_t)(REC0 + (wv >> 1)) * 1024u;
     const bool odd = wv & 1;
-    static_for<CFG::DS>([&](auto S) {
+    static_for<NSTEPS>([&](auto S) {
         constexpr int s = S;
         const i32x4 wi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, rec_base + (uint32_t)s * 2048u, 0);
         const f32x4 w = __builtin_bit_cast(f32x4, wi);
-        const float b = dir_feature<CFG::NGEO, CFG::NAPP, s>(in, h);
+        const float b = feat(S);
         acc0 = mfma32(odd ? w.z : w.x, b, acc0);
         acc1 = mfma32(odd ? w.w : w.y, b, acc1);
     });
@@ -714,7 +710,40 @@ NTX_DEV void dir_block(const RenderArgs &a, __amdgpu_buffer_rsrc_t rsrc, const f
         o[q] = f32x4{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
         o[4 + q] = f32x4{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
     });
-  }
+}
+
+// rows[slot] for slot = it * 4 + w  <->  hit number base + it * nwaves_total + 4 * workgroup + w.
+// GEO: also the rows of L0 and L5 (bias + the geometry-parameter block of their position segments), at rows +
+// DIR_BLOCK_FLOATS and rows + 2 DIR_BLOCK_FLOATS (render_kernel<CFG, 2>)
+template <class CFG, bool GEO = false>
+NTX_DEV void dir_block(const RenderArgs &a, __amdgpu_buffer_rsrc_t rsrc, const float *aux, float *rows, int base, int nwaves,
+                       int wg, int wv, int lane, int n_work) {
+    static_assert(CFG::CD != 0, "ParamNerf families");
+    const int h = lane >> 5;
+    static_assert(DIR_BLOCK_RAYS % 32 == 0, "whole MFMA column sets");
+    for (int j = lane & 31; j < DIR_BLOCK_RAYS; j += 32) {   // 32 ray slots per MFMA column set
+        if (j >= 32 && base + (j >> 5) * 8 * nwaves >= n_work) break;   // (wave-uniform) the rest of the block lies past the end of the list
+        int idx = base + (j >> 2) * nwaves + 4 * wg + (j & 3);
+        idx = idx < n_work ? idx : n_work - 1;
+        const int64_t ray = a.hit_list[idx];
+        const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+        const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);   // as the render kernel (renderer.py:98)
+        SampleIn<CFG::NGEO, CFG::NAPP> in;
+        in.pos[0] = in.pos[1] = in.pos[2] = 0.0f;
+        in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
+        in.dir[0] = dx / dnorm; in.dir[1] = dy / dnorm; in.dir[2] = dz / dnorm;
+        const float *prow = a.params + (ray / a.rays_per_row) * CFG::NP_IN;
+#pragma unroll
+        for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[(CFG::IPE != 0 && k >= a.blur_idx) ? k + 1 : k];
+        ray_rows<CFG::DS, CFG::rec_pass(9), 9>(rsrc, aux, rows, j, h, wv, lane,
+                                               [&](auto S) { return dir_feature<CFG::NGEO, CFG::NAPP, decltype(S)::value>(in, h); });
+        if constexpr (GEO) {
+            constexpr int GS = pos_geo_steps(CFG::NGEO);
+            auto geo = [&](auto S) { return pos_feature<CFG::NGEO, CFG::NAPP, CFG::IPE, decltype(S)::value>(in, h); };
+            ray_rows<GS, 0, 0>(rsrc, aux, rows + DIR_BLOCK_FLOATS, j, h, wv, lane, geo);
+            ray_rows<GS, CFG::rec_pass(SKIP + 1), SKIP + 1>(rsrc, aux, rows + 2 * DIR_BLOCK_FLOATS, j, h, wv, lane, geo);
+        }
+    }
 }
 
 // Workgroups are dealt to the 8 XCDs round-robin (workgroup w runs on XCD w % 8), each XCD with its own L2.  Rays are
@@ -726,10 +755,13 @@ NTX_DEV int xcd_major_workgroup(int wg, int n_wgs) {
     return (n_wgs % XCDS) ? wg : (wg % XCDS) * (n_wgs / XCDS) + wg / XCDS;
 }
 
-template <class CFG, bool HOIST = false>
+// HOIST: 0 = everything per sample; 1 = the direction segment of C1 per ray; 2 = also the geometry-parameter block of the
+// position segments of L0 and L5 (no blur_idx)
+template <class CFG, int HOIST = 0>
 __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
-    static_assert(!HOIST || CFG::CD != 0, "direction hoisting is for the ParamNerf families");
-    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * PE_KEEP_FLOATS + (HOIST ? DIR_BLOCK_FLOATS : 0)];
+    static_assert(HOIST == 0 || CFG::CD != 0, "hoisting is for the ParamNerf families");
+    static_assert(HOIST != 2 || (CFG::IPE == 0 && CFG::NGEO > 0), "geometry hoisting: FourierFeatures families with geometry parameters");
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * PE_KEEP_FLOATS + (HOIST == 2 ? 3 : HOIST) * DIR_BLOCK_FLOATS];
     load_aux(aux, a.aux, aux_total());
     float *dir_rows = aux + aux_total() + 4 * PE_KEEP_FLOATS;
     const int lane = threadIdx.x & 63, j = lane & 31;
@@ -746,9 +778,9 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     // count of this loop are uniform over the workgroup (the barriers of the HOIST variant sit in it)
     const int n_work = *a.hit_count;
     for (int base = 0; base < n_work; base += DIR_BLOCK_ITERS * nwaves) {
-        if constexpr (HOIST) {
+        if constexpr (HOIST != 0) {
             __syncthreads();   // every wave is done with the previous block's rows
-            dir_block<CFG>(a, ws.rsrc, aux, dir_rows, base, nwaves, vwg, wv, lane, n_work);
+            dir_block<CFG, HOIST == 2>(a, ws.rsrc, aux, dir_rows, base, nwaves, vwg, wv, lane, n_work);
             __syncthreads();
         }
       for (int it = 0; it < DIR_BLOCK_ITERS; ++it) {
@@ -809,7 +841,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             }
             float sigma, raw[3];
             float *pe = pe_column<CFG>(aux, wv, lane);
-            if constexpr (HOIST) mlp_batch<CFG, true>(in, ws, aux, lane, sigma, raw, dir_rows + (it * 4 + wv) * DIR_ROW_STRIDE, pe);
+            if constexpr (HOIST != 0) mlp_batch<CFG, HOIST>(in, ws, aux, lane, sigma, raw, dir_rows + (it * 4 + wv) * DIR_ROW_STRIDE, pe);
             else mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe);
             const RenderArgs *ap2 = kernargs<RenderArgs>();
             asm volatile("" : "+s"(ap2));

@@ -48,26 +48,39 @@ NTX_HD constexpr int hidden_row(int s, int h) {
 // (mean, diagonal covariance): 6*POS_FREQ features [sin(y) e^(-var/2) (3L) | sin(y + pi/2) e^(-var/2) (3L)] with
 // y index f*3+c, NO identity block.
 NTX_HD constexpr int pos_emb_dim(int ipe) { return ipe ? 6 * POS_FREQ : 3 * (1 + 2 * POS_FREQ); }
-NTX_HD constexpr int pos_id_values(int n_geo, int ipe = 0) { return (ipe ? 0 : 3) + n_geo; }
-NTX_HD constexpr int pos_id_steps(int n_geo, int ipe = 0) { return (pos_id_values(n_geo, ipe) + 1) / 2; }
-NTX_HD constexpr int pos_steps(int n_geo, int ipe = 0) { return pos_id_steps(n_geo, ipe) + 3 * POS_FREQ + n_geo * PAR_FREQ; }
+// k-steps of the position segment, GEOMETRY PARAMETERS FIRST (the order of the k-summation is free):
+//   geo identity  ceil(n_geo / 2) steps   pairs (g0, g1), zero pad
+//   geo sin/cos   n_geo * PAR_FREQ steps  {sin, cos}(2^f g)
+//   pos identity  2 steps                 (x, y), (z, pad)            [IPE: none]
+//   pos sin/cos   3 * POS_FREQ steps      {sin, cos}(2^f x_c)         [IPE: damped by exp(-4^f var_c / 2)]
+// The geometry parameters are constant along a ray (renderer.py:154) unless blur_idx scales one per sample (:155-158), so
+// their block leads the segment: a kernel that evaluates it once per ray starts its accumulators from bias + that block
+// and runs only the position steps per sample -- same summation order, same bits (render_kernel<CFG, 2>).
+NTX_HD constexpr int pos_geo_steps(int n_geo) { return (n_geo + 1) / 2 + n_geo * PAR_FREQ; }
+NTX_HD constexpr int pos_steps(int n_geo, int ipe = 0) { return pos_geo_steps(n_geo) + (ipe ? 0 : 2) + 3 * POS_FREQ; }
 NTX_HD constexpr int pos_map_dim(int n_geo, int ipe = 0) { return pos_emb_dim(ipe) + n_geo * (1 + 2 * PAR_FREQ); }
 
 // row of the reference's pos_map that (step s, half h) carries, or -1 for a zero pad
 NTX_HD constexpr int pos_row(int n_geo, int s, int h, int ipe = 0) {
-    const int nid = pos_id_steps(n_geo, ipe), base = pos_emb_dim(ipe), n3 = ipe ? 0 : 3;
-    if (s < nid) {
+    const int base = pos_emb_dim(ipe), ngid = (n_geo + 1) / 2;
+    if (s < ngid) {
         const int v = 2 * s + h;
-        if (v >= pos_id_values(n_geo, ipe)) return -1;
-        return v < n3 ? v : base + (v - n3);
+        return v < n_geo ? base + v : -1;
     }
-    int q = s - nid;
-    if (q < 3 * POS_FREQ) return ipe ? h * 3 * POS_FREQ + q : 3 + 6 * (q / 3) + 3 * h + (q % 3);
-    q -= 3 * POS_FREQ;
+    int q = s - ngid;
     if (q < n_geo * PAR_FREQ) {
         const int f = q / n_geo, g = q % n_geo;
         return base + n_geo + 2 * f * n_geo + h * n_geo + g;
     }
+    q -= n_geo * PAR_FREQ;
+    if (!ipe) {
+        if (q < 2) {
+            const int v = 2 * q + h;
+            return v < 3 ? v : -1;
+        }
+        q -= 2;
+    }
+    if (q < 3 * POS_FREQ) return ipe ? h * 3 * POS_FREQ + q : 3 + 6 * (q / 3) + 3 * h + (q % 3);
     return -1;
 }
 

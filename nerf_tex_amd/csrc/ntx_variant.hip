@@ -28,12 +28,19 @@ using VCfg = Cfg<1, 3, 1, 1>;   // mip: IPE position encoding, grass_filtered wi
 #endif
 
 #ifdef NTX_HOIST
-// second translation unit of the family (-DNTX_HOIST): the render kernel with the direction segment hoisted per ray
-hipError_t NTX_FN(launch_render_hoist)(int n_wgs, RenderArgs &a, hipStream_t st) {
-    render_kernel<VCfg, true><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
+// further translation units of the family: -DNTX_HOIST=1 the render kernel with the direction segment hoisted per ray,
+// -DNTX_HOIST=2 with the geometry-parameter block of the position segments hoisted as well
+#if NTX_HOIST == 2
+hipError_t NTX_FN(launch_render_hoist2)(int n_wgs, RenderArgs &a, hipStream_t st) {
+    render_kernel<VCfg, 2><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
     return hipGetLastError();
 }
-
+#else
+hipError_t NTX_FN(launch_render_hoist)(int n_wgs, RenderArgs &a, hipStream_t st) {
+    render_kernel<VCfg, 1><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
+    return hipGetLastError();
+}
+#endif
 #else
 hipError_t NTX_FN(launch_render)(int n_wgs, RenderArgs &a, hipStream_t st) {
     render_kernel<VCfg><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
