@@ -92,18 +92,23 @@ NTX_DEV f32x4 ws_load(const WStream &ws, uint32_t rec) {
     return __builtin_bit_cast(f32x4, v);
 }
 
+// M = the record map of the kernel flavour (RecMap<CFG, HOIST> below): every wave consumes a LOGICAL stream, the packed
+// (physical) stream with the segments its flavour evaluates per ray left out; M::phys(logical) is a compile-time constant,
+// so skipping a segment costs nothing at run time -- fetching the skipped records through the ring to keep its phase, as
+// the first hoisting kernels did, put a burst of up to 82 loads and an exposed L2 latency in front of the next MFMA.
+template <class M>
 NTX_DEV void ws_prime(WStream &ws, const f32x4 *base, uint32_t stream_bytes, int lane) {
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(base), 0, stream_bytes, 0x00020000);
     ws.voff = (uint32_t)lane * 16u;
-    static_for<RING>([&](auto I) { ws.ring[I] = ws_load(ws, I); });
+    static_for<RING>([&](auto I) { ws.ring[I] = ws_load(ws, M::phys(I)); });
 }
 
-// records [REC0, REC0+N) are padding: keep the ring turning without multiplying them
-template <int N, int REC0>
+// logical records [REC0, REC0+N) are padding: keep the ring turning without multiplying them
+template <class M, int N, int REC0>
 NTX_DEV void skip_records(WStream &ws) {
     static_for<N>([&](auto I) {
         constexpr int rec = REC0 + decltype(I)::value;
-        ws.ring[rec % RING] = ws_load(ws, rec + RING);
+        ws.ring[rec % RING] = ws_load(ws, M::phys(rec + RING));
     });
 }
 
@@ -194,9 +199,9 @@ constexpr int DIR_BLOCK_FLOATS = DIR_BLOCK_RAYS * DIR_ROW_STRIDE;
 //   extra : extra(S, MT) = additional VALU/LDS work to place in the shadow of slot (S, MT)
 // A sched_barrier after every slot pins the order hipcc emits: without it the scheduler sinks the
 // prefetch loads to their first use (collapsing the ring) and bunches the VALU work in front of the MFMAs.
-// REC0 = index of the segment's first record in the stream.
+// REC0 = LOGICAL index of the segment's first record (M::log_of(physical index)).
 // ---------------------------------------------------------------------------------------------
-template <int NSTEPS, int NMT, int REC0, class Gen, class Extra>
+template <class M, int NSTEPS, int NMT, int REC0, class Gen, class Extra>
 NTX_DEV void run_segment(f32x16 (&acc)[8], WStream &ws, Gen &gen, Extra &&extra) {
     constexpr int RPS = NMT / 4;
     gen.template prepare<0, (NSTEPS < PE_GROUP ? NSTEPS : PE_GROUP)>();   // first group: before the first MFMA
@@ -209,7 +214,7 @@ NTX_DEV void run_segment(f32x16 (&acc)[8], WStream &ws, Gen &gen, Extra &&extra)
             if constexpr (mt % 4 == 0) {
                 constexpr int rec = REC0 + s * RPS + mt / 4;
                 w = ws.ring[rec % RING];
-                ws.ring[rec % RING] = ws_load(ws, rec + RING);
+                ws.ring[rec % RING] = ws_load(ws, M::phys(rec + RING));
             }
             acc[mt] = mfma32(w[mt % 4], b, acc[mt]);
             // the B values of the next PE_GROUP k-steps, as ONE block of VALU work after this step's first MFMA
@@ -362,6 +367,29 @@ struct Cfg {
     static constexpr int REC_PAD = make_geometry(NGEO_, NAPP_, CD_, IPE_).padded_records;
 };
 
+// Logical <-> physical record indices of one kernel flavour.  Removed from the logical stream: with HOIST >= 1 the direction
+// segment of C1 (ParamNerf), with HOIST = 2 also the geometry-parameter blocks that lead the position segments of L0 and L5.
+// The logical stream is padded to whole ring turns and wraps into itself (no use of the packed stream's tail copy).
+template <class CFG, int HOIST>
+struct RecMap {
+    static constexpr int GS2 = (HOIST == 2 ? pos_geo_steps(CFG::NGEO) : 0) * 2;
+    static constexpr int DS2 = (HOIST != 0 && CFG::CD != 0 ? CFG::DS : 0) * 2;
+    static constexpr int A5 = CFG::rec_pass(SKIP + 1), A9 = CFG::rec_pass(9);   // physical starts of L5's and C1's leading segments
+    static constexpr int LOG_END = CFG::REC_END - 2 * GS2 - DS2;
+    static constexpr int LOG_PAD = round_up(LOG_END, RING);
+    static constexpr int phys(int l) {
+        l %= LOG_PAD;
+        if (l >= LOG_END) return 0;          // padding of the last ring turn: fetched, never multiplied
+        int p = l + GS2;
+        if (p >= A5) p += GS2;
+        if (p >= A9) p += DS2;
+        return p;
+    }
+    static constexpr int log_of(int p) {     // p: a physical record outside the removed ranges
+        return p - (p >= GS2 ? GS2 : 0) - (p >= A5 + GS2 ? GS2 : 0) - (p >= A9 + DS2 ? DS2 : 0);
+    }
+};
+
 // Two accumulator sets (2 x 128 AGPRs) alternate between layers: layer n's result is moved out of one set
 // (bias already in, ReLU, into `hin`) in one dense block before layer n+1 starts accumulating into the
 // other, and the drained set is re-initialised tile by tile with the bias of layer n+2 while layer n+1 runs.
@@ -378,6 +406,7 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
                        const float *c1_row = nullptr, float *pe = nullptr) {
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
     constexpr int GS = HOIST == 2 ? pos_geo_steps(NGEO) : 0;   // k-steps of the position segments evaluated per ray
+    using M = RecMap<CFG, HOIST>;
     const int h = lane >> 5;
     // The aux block in LDS never changes, so the optimiser would hoist every bias / head-weight
     // read out of the batch loop and then spill ~600 values to scratch.  An opaque OFFSET (not an
@@ -393,14 +422,13 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
     // ---- trunk layer 0: pos_map -> 256 (model.py:104-106) into set A; set B <- bias of layer 1
     if constexpr (HOIST == 2) {
         static_for<8>([&](auto T) { init_bias_tile_row<decltype(T)::value>(accA, c1_row + DIR_BLOCK_FLOATS + opaque_zero, h); });
-        skip_records<GS * 2, 0>(ws);   // the geometry block's records: already in the accumulators, through the row
     } else {
         init_bias<8>(accA, aux, 0, h);
     }
     {
         PosGen<NGEO, NAPP, CFG::IPE, 1, GS> gen{in, h, {}, pe};
         static_assert(CFG::PS - GS >= 29, "layer-1 bias initialised behind layer 0");
-        run_segment<CFG::PS - GS, 8, GS * 2>(accA, ws, gen, [&](auto S, auto MT) {
+        run_segment<M, CFG::PS - GS, 8, M::log_of(GS * 2)>(accA, ws, gen, [&](auto S, auto MT) {
             constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
             if constexpr (mt == 1 && s % 4 == 0 && s < 32) init_bias_tile<s / 4>(accB, aux, 1, h);
         });
@@ -438,22 +466,19 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
             const SampleIn<NGEO, NAPP> in2 = launder(in);
             if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
                 PosGen<NGEO, NAPP, CFG::IPE, 2, GS> gen{in2, h, {}, pe};   // the values layer 0 kept
-                if constexpr (GS > 0) skip_records<GS * 2, rec0>(ws);
-                run_segment<pre_steps - GS, 8, rec0 + GS * 2>(cur, ws, gen, conv);
+                run_segment<M, pre_steps - GS, 8, M::log_of(rec0 + GS * 2)>(cur, ws, gen, conv);
             } else {                   // input = concat[dir_map, feature]  (model.py:115)
-                if constexpr (HOIST != 0) {
-                    skip_records<pre_steps * 2, rec0>(ws);   // already in the accumulators, through c1_row
-                } else {
+                if constexpr (HOIST == 0) {   // (hoisted: already in the accumulators through c1_row, and not in the logical stream)
                     DirGen<NGEO, NAPP> gen{in2, h, {}};
-                    run_segment<pre_steps, 8, rec0>(cur, ws, gen, conv);
+                    run_segment<M, pre_steps, 8, M::log_of(rec0)>(cur, ws, gen, conv);
                 }
             }
             HiddenGen hg{hin};
-            run_segment<HSTEPS, 8, rec0 + pre_steps * 2>(cur, ws, hg, [&](auto S, auto MT) { reinit(S, MT); alpha_head(S, MT); });
+            run_segment<M, HSTEPS, 8, M::log_of(rec0 + pre_steps * 2)>(cur, ws, hg, [&](auto S, auto MT) { reinit(S, MT); alpha_head(S, MT); });
         } else {
             store_act<8, relu_in>(hin, prev);
             HiddenGen hg{hin};
-            run_segment<HSTEPS, 8, rec0>(cur, ws, hg, [&](auto S, auto MT) { reinit(S, MT); alpha_head(S, MT); });
+            run_segment<M, HSTEPS, 8, M::log_of(rec0)>(cur, ws, hg, [&](auto S, auto MT) { reinit(S, MT); alpha_head(S, MT); });
         }
     };
     static_for<NPASS>([&](auto I) {
@@ -471,20 +496,21 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
             store_act<8, false>(hin, prev);
             const SampleIn<NGEO, NAPP> in2 = launder(in);
             DirGen<NGEO, NAPP> gen{in2, h, {}};
-            run_segment<CFG::DS, 4, CFG::REC_C2>(cur, ws, gen, none);
+            run_segment<M, CFG::DS, 4, M::log_of(CFG::REC_C2)>(cur, ws, gen, none);
             HiddenGen hg{hin};
-            run_segment<HSTEPS, 4, CFG::REC_C2 + CFG::DS>(cur, ws, hg, none);
+            run_segment<M, HSTEPS, 4, M::log_of(CFG::REC_C2 + CFG::DS)>(cur, ws, hg, none);
         } else {
             store_act<8, true>(hin, prev);
             HiddenGen hg{hin};
-            run_segment<HSTEPS, 4, CFG::REC_C2>(cur, ws, hg, none);
+            run_segment<M, HSTEPS, 4, M::log_of(CFG::REC_C2)>(cur, ws, hg, none);
         }
         store_act<4, true>(hin, cur);
     };
     if constexpr (NPASS & 1) color_half(accA, accB);   // last pass wrote set B
     else color_half(accB, accA);
     static_assert(CFG::REC_C2 + (CFG::CD == 0 ? CFG::DS : 0) + HSTEPS == CFG::REC_END, "stream bookkeeping");
-    skip_records<CFG::REC_PAD - CFG::REC_END, CFG::REC_END>(ws);
+    static_assert(M::log_of(CFG::REC_END) == M::LOG_END, "logical stream bookkeeping");
+    skip_records<M, M::LOG_PAD - M::LOG_END, M::LOG_END>(ws);
 
     // ---- rgb head (128 -> 3, linear; model.py:123) on the VALU
     static_for<3>([&](auto C) {
@@ -511,8 +537,8 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
     sigma += chk;
 #pragma unroll
     for (int c = 0; c < 3; ++c) rgb[c] += chk;
-    // the stream's tail replicates its first RING records and REC_PAD % RING == 0, so the ring now holds
-    // records 0..RING-1 in slots 0..RING-1: the next batch starts without a bubble
+    // LOG_PAD % RING == 0 and the logical stream wraps into itself, so the ring now holds the first RING logical records
+    // in slots 0..RING-1: the next batch starts without a bubble
 }
 
 NTX_DEV void load_aux(float *lds, const float *aux_g, int n) {
@@ -772,7 +798,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     const int S = a.n_samples;
     const int nb = (S + 31) >> 5;
     WStream ws;
-    ws_prime(ws, a.wstream, a.stream_bytes, lane);
+    ws_prime<RecMap<CFG, HOIST>>(ws, a.wstream, a.stream_bytes, lane);
 
     // the compacted hit list is walked in blocks of DIR_BLOCK_ITERS rounds of one ray per wave; `base` and the trip
     // count of this loop are uniform over the workgroup (the barriers of the HOIST variant sit in it)
@@ -952,7 +978,7 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
     uint16_t *sidx = sidx_all[wv];
     InstancePending &pend = pend_all[wv];
     WStream ws;
-    ws_prime(ws, a.wstream, a.stream_bytes, lane);
+    ws_prime<RecMap<CFG, 0>>(ws, a.wstream, a.stream_bytes, lane);
 
     // the appended sample (colour taken as is, alpha_last is an alpha, not a density: renderer.py:323-339) and the store
     auto finish = [&](int64_t ray, const RayAccum &ra) {
@@ -1125,7 +1151,7 @@ __global__ __launch_bounds__(256) void mlp_kernel(MlpArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int nwaves = gridDim.x * 4;
     WStream ws;
-    ws_prime(ws, a.wstream, a.stream_bytes, lane);
+    ws_prime<RecMap<CFG, 0>>(ws, a.wstream, a.stream_bytes, lane);
     const int64_t nbatch = (a.m + 31) >> 5;
     for (int64_t b = wave; b < nbatch; b += nwaves) {
         const int64_t m = b * 32 + j;
