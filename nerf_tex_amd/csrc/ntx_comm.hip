@@ -107,7 +107,7 @@ int ntx_comm_unique_id(uint8_t *id_out) {
     static_assert(NTX_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
     if (!id_out) return ntx_set_error(NTX_E_INVALID, "id_out is NULL");
     const Rccl *R = rccl();
-    if (!R) return ntx_set_error(NTX_E_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", dlerror());
+    if (!R) return ntx_set_error(NTX_E_UNSUPPORTED, "librccl.so.1 could not be loaded (or lacks a symbol of rccl.h)");
     ncclUniqueId id;
     RCCL_TRY(R->GetUniqueId(&id));
     memcpy(id_out, id.internal, NTX_COMM_ID_BYTES);
@@ -119,7 +119,7 @@ int ntx_comm_create(const uint8_t *id, int n_ranks, int rank, int device, ntx_co
     *out = nullptr;
     if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return ntx_set_error(NTX_E_INVALID, "bad communicator arguments");
     const Rccl *R = rccl();
-    if (!R) return ntx_set_error(NTX_E_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", dlerror());
+    if (!R) return ntx_set_error(NTX_E_UNSUPPORTED, "librccl.so.1 could not be loaded (or lacks a symbol of rccl.h)");
     HIP_TRY(hipSetDevice(device));
     ncclUniqueId uid;
     memcpy(uid.internal, id, NTX_COMM_ID_BYTES);
@@ -161,19 +161,22 @@ int ntx_gather_image(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, 
         // the one collective of the render path: every peer sends its shard straight to the root
         RCCL_TRY(R->Gather(local_rgba, dst, (size_t)cap * 4, ncclFloat, root, comm->comm, st));
     } else {
-        // same exchange with the exact per-rank counts
+        // same exchange with the exact per-rank counts; the group is always closed, also on an error inside it
+        if (me == root && mine > 0)
+            HIP_TRY(hipMemcpyAsync(dst + (size_t)me * cap * 4, local_rgba, (size_t)mine * 16, hipMemcpyDeviceToDevice, st));
         RCCL_TRY(R->GroupStart());
+        ncclResult_t rc = ncclSuccess;
         if (me == root) {
-            for (int r = 0; r < R_; ++r) {
+            for (int r = 0; r < R_ && rc == ncclSuccess; ++r) {
                 const int64_t cnt = shard_count(n_pixels, run_length, R_, r);
-                if (cnt == 0) continue;
-                if (r == me) HIP_TRY(hipMemcpyAsync(dst + (size_t)r * cap * 4, local_rgba, (size_t)cnt * 16, hipMemcpyDeviceToDevice, st));
-                else RCCL_TRY(R->Recv(dst + (size_t)r * cap * 4, (size_t)cnt * 4, ncclFloat, r, comm->comm, st));
+                if (cnt > 0 && r != me) rc = R->Recv(dst + (size_t)r * cap * 4, (size_t)cnt * 4, ncclFloat, r, comm->comm, st);
             }
         } else if (mine > 0) {
-            RCCL_TRY(R->Send(local_rgba, (size_t)mine * 4, ncclFloat, root, comm->comm, st));
+            rc = R->Send(local_rgba, (size_t)mine * 4, ncclFloat, root, comm->comm, st);
         }
-        RCCL_TRY(R->GroupEnd());
+        const ncclResult_t rc_end = R->GroupEnd();
+        RCCL_TRY(rc);
+        RCCL_TRY(rc_end);
     }
     if (me == root && !direct) {
         ntx_unshard_kernel<<<dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, st>>>(
