@@ -97,7 +97,7 @@ def measured_traffic(workload: str, precision: str = "float32"):
     summary of this very command (separate --pmc passes, FETCH_SIZE x2 for gfx950's wide reads; tools/summarize_profile.py).
     PMC collection cannot run inside the timed bench, so the latest committed profile is quoted; None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", ("bench_" if precision == "float32" else "benchx3_") + f"{workload}_*pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", ("bench_" if precision == "float32" else "benchx3_") + f"{workload}_v[0-9]*pmc_summary.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))["derived"]
