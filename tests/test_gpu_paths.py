@@ -3,7 +3,6 @@ the kernel, the in-kernel stratified jitter, cone-filter conditioning at S = 128
 families, error paths that must write nothing, per-call precision on a shared context, strided ray generation and the
 RCCL gather.  `-m gpu`; everything goes through the C ABI."""
 
-import ctypes as C
 import json
 import os
 import subprocess

@@ -2,7 +2,6 @@
 """HBM roofline of the small kernels around the fused render kernel: achieved algorithmic GB/s of
 ntx_generate_rays, ntx_composite, ntx_sample_pdf, ntx_sample_depths, ntx_image_epilogue, at
 BASELINE sizes, through the C ABI with HIP events.  GPU box only:  python tools/bench_small_kernels.py"""
-import ctypes as C
 import json
 import os
 import sys
