@@ -60,3 +60,43 @@ def test_fuzz_render_rays(seed, precision):
         floor = float(np.max(np.abs(w32 - want[hit]))) / scale
         assert float(np.max(np.abs(got[hit] - w32))) / scale <= TOL
         assert float(np.max(np.abs(got - want))) / scale <= max(TOL, 1.25 * floor)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_around_the_direction_blocks(seed):
+    """Ray counts around the 8192-ray blocks in which a launch hands out the hit list (32 rays per workgroup and block, their
+    per-ray rows computed into LDS by dir_block): partial last blocks, most rays culled, in-kernel jitter on and off, both
+    precisions (60 more seeds: tools/dev/fuzz_more.py)."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.renderer import Renderer
+    rng = np.random.default_rng(5000 + seed)
+    family = ["carpet", "grass", "grass_filtered", "fur"][seed % 4]
+    fam = synthetic.FAMILIES[family]
+    model, spec, w = make_model(fam["n_parameters"], seed=seed, dense_media=bool(seed & 1))
+    n = [8191, 8193, 16385, 9000, 24577, 8192][seed]
+    S = [17, 33, 32, 2, 40, 32][seed]
+    ro, rd, t, cone = synthetic.all_hit_rays(n, fam["b_0"], fam["b_1"], fam["cam"], seed=seed)
+    t = t.copy(); t[rng.uniform(size=n) < [0.0, 0.4, 0.97][seed % 3]] = np.inf
+    params = (rng.uniform(0, 1, size=(1, sum(fam["n_parameters"]))) * np.asarray(fam["params"], np.float32)).astype(np.float32)
+    perturb = bool(seed % 2)
+    hit = np.isfinite(t[:, 0])
+    tz = np.where(np.isfinite(t), t, 0).astype(np.float32)
+    z = orc.z_values_perturbed(tz, S, 77 + seed, np.float32) if perturb else None
+    kw = dict(z_override=None if z is None else z[hit])
+    pr = np.repeat(params, hit.sum(), 0)
+    ref = orc.render_rays(w, spec, ro[hit], rd[hit], t[hit], pr, cone[hit], S, False, (1, 1, 1.), fam["blur_idx"], dtype=np.float64, **kw)
+    ref32 = orc.render_rays(w, spec, ro[hit], rd[hit], t[hit], pr, cone[hit], S, False, (1, 1, 1.), fam["blur_idx"], dtype=np.float32, **kw)
+    want = np.concatenate([ref["color_pred"], ref["alpha_pred"][:, None]], -1)
+    w32 = np.concatenate([ref32["color_pred"], ref32["alpha_pred"][:, None]], -1)
+    scale = max(float(np.abs(want).max()), 1e-3)
+    floor = float(np.abs(w32 - want).max()) / scale
+    dv = torch.device("cuda", 0)
+    d = lambda a: torch.as_tensor(a, device=dv)
+    for prec in ("float32", "fp16x3"):
+        r = Renderer(model=model, n_samples=S, perturb=perturb, blur_idx=fam["blur_idx"], precision=prec)
+        out = r(d(ro[None]), d(rd[None]), d(t[None]), parameters=d(params), cone_scale=d(cone[None]), seed=77 + seed)
+        r.raise_if_nonfinite()
+        got = np.concatenate([out["color_pred"][0].cpu().numpy(), out["alpha_pred"][0].cpu().numpy()[:, None]], -1)
+        assert np.all(got[~hit] == 0)
+        assert float(np.abs(got[hit] - w32).max()) / scale <= TOL                       # vs the float32 restatement
+        assert float(np.abs(got[hit] - want).max()) / scale <= max(TOL, 1.25 * floor)    # vs float64, at that restatement's own distance
