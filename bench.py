@@ -226,7 +226,7 @@ def main() -> None:
     import torch
     import torch.distributed as dist
     from nerf_tex_amd import synthetic
-    from nerf_tex_amd.dist import Comm, ShardMap
+    from nerf_tex_amd.dist import Comm, ShardMap, gather_image
     from nerf_tex_amd.model import ParamNerf
     from nerf_tex_amd.renderer import Renderer
 
@@ -239,10 +239,27 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    comm = None
+    comm, gather_how = None, None
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)       # nccl backend == RCCL on ROCm: barrier + max-over-ranks timing
-        comm = Comm(local_rank)                              # the data path's own communicator, behind the C ABI
+        # the data path's own communicator, behind the C ABI.  All ranks must agree on the route: if ntx_comm_create fails
+        # anywhere (it has only ever run with one rank, this environment has no multi-GPU box), every rank falls back to
+        # torch.distributed.gather on the same RCCL, and the line says so.
+        err = None
+        try:
+            comm = Comm(local_rank)
+        except Exception as e:                               # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        flag = torch.tensor([0 if err is None else 1], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            if comm is not None:
+                comm.close()
+            comm = None
+            gather_how = "torch.distributed.gather (fallback: ntx_comm_create failed on some rank" + (f"; here: {err})" if err else ")")
+            print("bench.py: " + gather_how, file=sys.stderr)
+        else:
+            gather_how = "ntx_gather_image (RCCL ncclGather through the C ABI)"
 
     sharded = args.workload in SHARDED
     family, H, W, S, cfg_idx = (SHARDED if sharded else WORKLOADS)[args.workload]
@@ -289,8 +306,8 @@ def main() -> None:
         if i is not None:
             ev1[i].record()                                  # same stream the kernel was launched on
         rgba = torch.cat([out["color_pred"][0], out["alpha_pred"][0][:, None]], -1)
-        if comm is not None:
-            return comm.gather_image(rgba, shard)            # the one collective: RGBA -> rank 0 (ntx_gather_image)
+        if world > 1:
+            return gather_image(rgba, shard, comm=comm)      # the one collective: RGBA -> rank 0 (ntx_gather_image)
         return rgba
 
     for _ in range(args.warmup):
@@ -373,7 +390,7 @@ def main() -> None:
             "config": {"workload": what + f", ParamNerf n_parameters={list(fam['n_parameters'])}, seeded glorot weights, "
                                    f"inputs resident in HBM, fused PE+MLP+composite"
                                    + (", perturb=True (in-kernel jitter)" if args.perturb else "")
-                                   + (", + ntx_gather_image (RCCL ncclGather) of RGBA to rank 0" if world > 1 else ""),
+                                   + (f", + gather of RGBA to rank 0: {gather_how}" if world > 1 else ""),
                        "rays_per_gpu": n_rays, "hit_rays_total": hits_total, "samples_per_ray": S, "flops_per_sample": flops_per_sample},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,

@@ -117,28 +117,28 @@ class Comm:
 
 def gather_image(local_rgba, shard, dst: int = 0, group=None, comm: Optional[Comm] = None):
     """Gather every rank's RGBA shard to `dst` in pixel order.  `shard`: a ShardMap (or an int n_total = contiguous
-    bands).  CUDA tensors go through `comm` (ntx_gather_image / RCCL); CPU tensors through torch.distributed (gloo) --
-    the plumbing tests.  Returns the [n_total, 4] image on `dst`, None elsewhere."""
+    bands).  With `comm` (GPU shards): ntx_gather_image / RCCL behind the C ABI.  Without: torch.distributed.gather (gloo in
+    the CPU plumbing tests).  Returns the [n_total, 4] image on `dst`, None elsewhere."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if not isinstance(shard, ShardMap):
         shard = ShardMap(int(shard), world)
-    if local_rgba.is_cuda:
-        if comm is None:
-            raise ValueError("GPU shards are gathered through a dist.Comm (RCCL behind the C ABI)")
+    if local_rgba.is_cuda and comm is not None:
         return comm.gather_image(local_rgba, shard, dst)
+    # no C-ABI communicator: the same exchange through torch.distributed (gloo for the CPU plumbing tests; for GPU shards
+    # only as the caller's explicit choice, e.g. bench.py when ntx_comm_create fails on a box -- it says so in its line)
     if world == 1:
         return local_rgba
     cap = shard.capacity
-    pad = torch.zeros((cap,) + tuple(local_rgba.shape[1:]), dtype=local_rgba.dtype)
+    pad = torch.zeros((cap,) + tuple(local_rgba.shape[1:]), dtype=local_rgba.dtype, device=local_rgba.device)
     pad[: local_rgba.shape[0]] = local_rgba
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     dist.gather(pad, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    image = torch.empty((shard.n,) + tuple(local_rgba.shape[1:]), dtype=local_rgba.dtype)
+    image = torch.empty((shard.n,) + tuple(local_rgba.shape[1:]), dtype=local_rgba.dtype, device=local_rgba.device)
     for r in range(world):
-        image[torch.as_tensor(shard.local_pixels(r))] = bufs[r][: shard.count(r)]
+        image[torch.as_tensor(shard.local_pixels(r), device=local_rgba.device)] = bufs[r][: shard.count(r)]
     return image
