@@ -48,6 +48,10 @@ typedef enum ntx_model_kind { NTX_MODEL_PARAMNERF = 0, NTX_MODEL_NERF = 1 } ntx_
 /* layer.FourierFeatures (layer.py:8-23) / layer.IntegratedPositionalEncoding (layer.py:25-41) */
 typedef enum ntx_pos_encoding { NTX_POS_FOURIER = 0, NTX_POS_IPE = 1 } ntx_pos_encoding;
 
+/* Built: ParamNerf with n_parameters = [g, a], g <= 4, a <= 8 (tuned kernel families for the shipped configs [1,6], [1,4], [2,3];
+ * every other combination runs on one generic family whose rows for the absent parameters are zero, ~2 % more matrix work),
+ * plain Nerf, and one IntegratedPositionalEncoding family [1,3]; 10/4/4 frequency bands, depth 8, width 256, skip 4,
+ * color_depth 1, param_depth 0, no embedding_config.  Anything else: NTX_E_UNSUPPORTED. */
 typedef struct ntx_model_desc {
     int32_t kind;        /* ntx_model_kind */
     int32_t n_geo;       /* n_parameters[0]: parameters concatenated to the position embedding (model.py:88-93) */

@@ -48,15 +48,26 @@ extern "C" __attribute__((visibility("hidden"))) int ntx_set_error(int code, con
 // supported architectures = the kernels instantiated below
 // ---------------------------------------------------------------------------------------------
 struct Variant {
-    int n_geo, n_app, cd, ipe;
+    int n_geo, n_app, cd, ipe;   // the kernel family's layout (for the generic family: its parameter SLOTS)
+    int gen;
 };
 static const Variant kVariants[] = {
-    {1, 6, 1, 0},   // carpet          (configs/config_carpet_render.py:59-72)
-    {1, 4, 1, 0},   // grass, fur, plush
-    {2, 3, 1, 0},   // grass_filtered
-    {0, 0, 0, 0},   // plain Nerf      (model.py:9-45)
-    {1, 3, 1, 1},   // mip variant of grass_filtered: IPE on (mean, cov), blur parameter spliced out (renderer.py:385-386)
+    {1, 6, 1, 0, 0},   // carpet          (configs/config_carpet_render.py:59-72)
+    {1, 4, 1, 0, 0},   // grass, fur, plush
+    {2, 3, 1, 0, 0},   // grass_filtered
+    {0, 0, 0, 0, 0},   // plain Nerf      (model.py:9-45)
+    {1, 3, 1, 1, 0},   // mip variant of grass_filtered: IPE on (mean, cov), blur parameter spliced out (renderer.py:385-386)
+    {GEN_NGEO, GEN_NAPP, 1, 0, 1},   // generic: any other ParamNerf n_parameters = [g <= 4, a <= 8]; absent parameters = zero rows
 };
+
+// the model's own parameter counts (the generic family has more slots than the model has parameters)
+struct Dims {
+    int g, a;
+};
+static Dims dims_of(const ntx_model_desc *d) {
+    const bool nerf = d->kind == NTX_MODEL_NERF;
+    return Dims{nerf ? 0 : d->n_geo, nerf ? 0 : d->n_app};
+}
 
 static int find_variant(const ntx_model_desc *d) {
     if (!d) return -1;
@@ -67,9 +78,13 @@ static int find_variant(const ntx_model_desc *d) {
         return -1;
     const bool nerf = d->kind == NTX_MODEL_NERF;
     const int g = nerf ? 0 : d->n_geo, a = nerf ? 0 : d->n_app, cd = nerf ? 0 : d->color_depth;
+    if (g < 0 || a < 0) return -1;
     if (!nerf && (g + a > 0) && d->param_freq != PAR_FREQ) return -1;
+    const bool force_generic = getenv("NERFTEX_FORCE_GENERIC") != nullptr;   // A/B knob for tests: a tuned family's model on the generic kernels
+    for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]) && !(force_generic && !nerf && !ipe); ++i)
+        if (!kVariants[i].gen && kVariants[i].n_geo == g && kVariants[i].n_app == a && kVariants[i].cd == cd && kVariants[i].ipe == ipe) return (int)i;
     for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]); ++i)
-        if (kVariants[i].n_geo == g && kVariants[i].n_app == a && kVariants[i].cd == cd && kVariants[i].ipe == ipe) return (int)i;
+        if (kVariants[i].gen && !nerf && g <= kVariants[i].n_geo && a <= kVariants[i].n_app && kVariants[i].cd == cd && kVariants[i].ipe == ipe) return (int)i;
     return -1;
 }
 
@@ -77,8 +92,8 @@ static int unsupported(const ntx_model_desc *d) {
     if (!d) return fail(NTX_E_INVALID, "model descriptor is NULL");
     return fail(NTX_E_UNSUPPORTED,
                 "unsupported model: kind=%d n_parameters=[%d,%d] n_pos=%d freqs=%d/%d/%d depth=%d width=%d "
-                "skip=%d color_depth=%d pos_encoding=%d (built: ParamNerf [1,6] [1,4] [2,3], Nerf, and ParamNerf [1,3] with "
-                "IntegratedPositionalEncoding on 6-D positions; 10/4/4 bands, 8x256, skip 4)",
+                "skip=%d color_depth=%d pos_encoding=%d (built: ParamNerf with n_parameters [g<=4, a<=8] -- tuned kernels for [1,6] [1,4] "
+                "[2,3] --, Nerf, and ParamNerf [1,3] with IntegratedPositionalEncoding on 6-D positions; 10/4/4 bands, 8x256, skip 4, color_depth 1)",
                 d->kind, d->n_geo, d->n_app, d->n_pos, d->pos_freq, d->dir_freq, d->param_freq, d->depth,
                 d->width, d->skip, d->color_depth, d->pos_encoding);
 }
@@ -97,9 +112,9 @@ struct Net {
     size_t count;
 };
 
-static Net view_blob(const Variant &v, const float *blob) {
+static Net view_blob(const Variant &v, Dims m, const float *blob) {
     Net n{};
-    const int pm = pos_map_dim(v.n_geo, v.ipe), dm = dir_map_dim(v.n_app);
+    const int pm = pos_map_dim(m.g, v.ipe), dm = dir_map_dim(m.a);
     size_t p = 0;
     auto take = [&](int in, int out) {
         Layer l{blob ? blob + p : nullptr, blob ? blob + p + (size_t)in * out : nullptr, in, out};
@@ -142,13 +157,13 @@ static void emit_segment(float *&dst, const Layer &l, int nsteps, int nmt, int r
                 }
 }
 
-static void pack(const Variant &v, const float *blob, float *out) {
+static void pack(const Variant &v, Dims m, const float *blob, float *out) {
     const Geometry g = make_geometry(v.n_geo, v.n_app, v.cd, v.ipe);
-    const Net n = view_blob(v, blob);
-    const int pm = pos_map_dim(v.n_geo, v.ipe), dm = dir_map_dim(v.n_app);
+    const Net n = view_blob(v, m, blob);
+    const int pm = pos_map_dim(m.g, v.ipe), dm = dir_map_dim(m.a);
     float *dst = out;
-    auto posrow = [&](int s, int h) { return pos_row(v.n_geo, s, h, v.ipe); };
-    auto dirrow = [&](int s, int h) { return dir_row(v.n_app, s, h); };
+    auto posrow = [&](int s, int h) { return pos_row(v.n_geo, s, h, v.ipe, m.g); };
+    auto dirrow = [&](int s, int h) { return dir_row(v.n_app, s, h, m.a); };
     auto hidrow = [&](int s, int h) { return hidden_row(s, h); };
 
     emit_segment(dst, n.trunk[0], g.pos_steps, 8, 0, posrow);
@@ -256,13 +271,13 @@ static size_t packed16_bytes(const Variant &v, int with_dir = 0) {
 
 // hidden segment first, encoder segment second within a pass (ntx_device_x3.h: Cfg16)
 // with_dir: the instanced kernel's stream, where C1 keeps its direction segment (directions are per sample there)
-static void pack16(const Variant &v, const float *blob, uint16_t *out, int with_dir = 0) {
-    const Net n = view_blob(v, blob);
-    const int pm = pos_map_dim(v.n_geo, v.ipe), dm = dir_map_dim(v.n_app);
+static void pack16(const Variant &v, Dims m, const float *blob, uint16_t *out, int with_dir = 0) {
+    const Net n = view_blob(v, m, blob);
+    const int pm = pos_map_dim(m.g, v.ipe), dm = dir_map_dim(m.a);
     const int ps = steps16(pos_steps(v.n_geo, v.ipe)), ds = steps16(dir_steps(v.n_app)), hs = HSTEPS / 8;
     uint16_t *dst = out;
-    auto posrow = [&](int s, int h) { return s < pos_steps(v.n_geo, v.ipe) ? pos_row(v.n_geo, s, h, v.ipe) : -1; };
-    auto dirrow = [&](int s, int h) { return s < dir_steps(v.n_app) ? dir_row(v.n_app, s, h) : -1; };
+    auto posrow = [&](int s, int h) { return s < pos_steps(v.n_geo, v.ipe) ? pos_row(v.n_geo, s, h, v.ipe, m.g) : -1; };
+    auto dirrow = [&](int s, int h) { return s < dir_steps(v.n_app) ? dir_row(v.n_app, s, h, m.a) : -1; };
     auto hidrow = [&](int s, int h) { return hidden_row(s, h); };
     emit_segment16(dst, n.trunk[0], ps, 8, 0, posrow);
     for (int i = 1; i < DEPTH; ++i) {
@@ -326,7 +341,7 @@ namespace ntx {
     hipError_t launch_render_x3_v##k(int n_wgs, RenderArgs &a, hipStream_t st);      \
     hipError_t launch_mlp_x3_v##k(int n_wgs, MlpArgs &a, hipStream_t st);            \
     hipError_t launch_instance_x3_v##k(int n_wgs, InstanceArgs &a, hipStream_t st);
-NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4)
+NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4) NTX_DECL(5)
 #undef NTX_DECL
 }  // namespace ntx
 
@@ -345,15 +360,34 @@ static const Launchers kLaunch[] = {   // indexed like kVariants
     NTX_ROW(0, launch_render_hoist_v0, launch_render_hoist2_v0),
 #ifndef NTX_DEV_ONLY_CARPET   // development builds link only the carpet family (compile time)
     NTX_ROW(1, launch_render_hoist_v1, launch_render_hoist2_v1), NTX_ROW(2, launch_render_hoist_v2, nullptr), NTX_ROW(3, nullptr, nullptr),
-    NTX_ROW(4, launch_render_hoist_v4, nullptr),
+    NTX_ROW(4, launch_render_hoist_v4, nullptr), NTX_ROW(5, launch_render_hoist_v5, nullptr),
 #else
-    {}, {}, {}, {},
+    {}, {}, {}, {}, {},
 #endif
 };
 #undef NTX_ROW
 template <class Fn, class Args>
 static hipError_t launch(Fn fn, const ntx_ctx *c, Args &a, hipStream_t st) {
     return fn ? fn(c->n_wgs, a, st) : hipErrorNotSupported;
+}
+
+// parameter slots of the kernel family <- columns of the caller's parameter rows (identity for the tuned families; the
+// generic family has GEN_NGEO + GEN_NAPP slots and feeds 0 into those the model does not have)
+template <class Args>
+static void fill_param_map(const ntx_ctx *c, Args &a) {
+    const Variant &v = kVariants[c->variant];
+    const Dims m = dims_of(&c->desc);
+    a.np_in = m.g + m.a + v.ipe;
+    for (int k = 0; k < MAX_PARAM_SLOTS; ++k) a.pmap[k] = -1;
+    for (int k = 0; k < v.n_geo && k < MAX_PARAM_SLOTS; ++k) a.pmap[k] = k < m.g ? (int8_t)k : (int8_t)-1;
+    for (int j = 0; j < v.n_app && v.n_geo + j < MAX_PARAM_SLOTS; ++j) a.pmap[v.n_geo + j] = j < m.a ? (int8_t)(m.g + j) : (int8_t)-1;
+}
+// blur_idx (a column of the caller's rows) -> the slot the kernel compares with
+static int blur_slot(const ntx_ctx *c, int blur_idx) {
+    const Variant &v = kVariants[c->variant];
+    const Dims m = dims_of(&c->desc);
+    if (blur_idx < 0 || !v.gen) return blur_idx;
+    return blur_idx < m.g ? blur_idx : v.n_geo + (blur_idx - m.g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -367,7 +401,7 @@ const char *ntx_last_error(void) { return g_err; }
 size_t ntx_weight_count(const ntx_model_desc *desc) {
     const int v = find_variant(desc);
     if (v < 0) { unsupported(desc); return 0; }
-    return view_blob(kVariants[v], nullptr).count;
+    return view_blob(kVariants[v], dims_of(desc), nullptr).count;
 }
 
 size_t ntx_packed_count(const ntx_model_desc *desc) {
@@ -381,12 +415,12 @@ int ntx_pack_weights(const ntx_model_desc *desc, const float *weights_host, size
     const int v = find_variant(desc);
     if (v < 0) return unsupported(desc);
     if (!weights_host || !packed_out) return fail(NTX_E_INVALID, "NULL buffer");
-    if (n_floats != view_blob(kVariants[v], nullptr).count)
+    if (n_floats != view_blob(kVariants[v], dims_of(desc), nullptr).count)
         return fail(NTX_E_INVALID, "weight blob has %zu floats, model needs %zu", n_floats,
-                    view_blob(kVariants[v], nullptr).count);
+                    view_blob(kVariants[v], dims_of(desc), nullptr).count);
     if (n_packed != packed_floats(kVariants[v]))
         return fail(NTX_E_INVALID, "packed buffer has %zu floats, needs %zu", n_packed, packed_floats(kVariants[v]));
-    pack(kVariants[v], weights_host, packed_out);
+    pack(kVariants[v], dims_of(desc), weights_host, packed_out);
     return NTX_OK;
 }
 
@@ -401,12 +435,12 @@ int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_hos
     const int v = find_variant(desc);
     if (v < 0) return unsupported(desc);
     if (!weights_host || !packed_out) return fail(NTX_E_INVALID, "NULL buffer");
-    if (n_floats != view_blob(kVariants[v], nullptr).count)
+    if (n_floats != view_blob(kVariants[v], dims_of(desc), nullptr).count)
         return fail(NTX_E_INVALID, "weight blob has %zu floats, model needs %zu", n_floats,
-                    view_blob(kVariants[v], nullptr).count);
+                    view_blob(kVariants[v], dims_of(desc), nullptr).count);
     if (n_bytes != packed16_bytes(kVariants[v]))
         return fail(NTX_E_INVALID, "packed buffer has %zu bytes, needs %zu", n_bytes, packed16_bytes(kVariants[v]));
-    pack16(kVariants[v], weights_host, packed_out);
+    pack16(kVariants[v], dims_of(desc), weights_host, packed_out);
     return NTX_OK;
 }
 
@@ -508,12 +542,12 @@ int ntx_set_weights(ntx_ctx *ctx, const float *weights_host, size_t n_floats) {
     HIP_TRY(hipMemcpy(ctx->packed, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
     if (ctx->packed16) {
         std::vector<uint16_t> p16(ctx->packed16_bytes / 2);
-        pack16(kVariants[ctx->variant], weights_host, p16.data());
+        pack16(kVariants[ctx->variant], dims_of(&ctx->desc), weights_host, p16.data());
         HIP_TRY(hipMemcpy(ctx->packed16, p16.data(), ctx->packed16_bytes, hipMemcpyHostToDevice));
     }
     if (ctx->packed16i) {
         std::vector<uint16_t> p16(ctx->packed16i_bytes / 2);
-        pack16(kVariants[ctx->variant], weights_host, p16.data(), 1);
+        pack16(kVariants[ctx->variant], dims_of(&ctx->desc), weights_host, p16.data(), 1);
         HIP_TRY(hipMemcpy(ctx->packed16i, p16.data(), ctx->packed16i_bytes, hipMemcpyHostToDevice));
     }
     return NTX_OK;
@@ -596,7 +630,8 @@ int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const flo
     if (flags & ~NTX_FLAG_FP16X3) return fail(NTX_E_INVALID, "ntx_mlp_forward takes NTX_FLAG_FP16X3 or 0, got 0x%x", flags);
     if (m == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
-    if (!pos || !dirs || !color_out || !sigma_out || (!params && v.n_geo + v.n_app > 0))
+    const Dims dm_ = dims_of(&ctx->desc);
+    if (!pos || !dirs || !color_out || !sigma_out || (!params && dm_.g + dm_.a > 0))
         return fail(NTX_E_INVALID, "NULL buffer");
     HIP_TRY(hipSetDevice(ctx->device));   // the launch goes to the context's device whatever the caller's current one is
     MlpArgs a{};
@@ -606,6 +641,7 @@ int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const flo
     a.pos = pos; a.dirs = dirs; a.params = params;
     a.color_out = color_out; a.sigma_out = sigma_out;
     a.m = m;
+    fill_param_map(ctx, a);
     if (flags & NTX_FLAG_FP16X3) {
         // directions are per sample: ParamNerf uses the stream that keeps C1's direction segment; plain Nerf's one stream
         // has it in C2 anyway
@@ -647,7 +683,8 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     if (n_samples < 2) return fail(NTX_E_INVALID, "n_samples must be >= 2 (renderer.py:174-177 needs a previous step)");
     if (n_rays == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
-    const int np = v.n_geo + v.n_app + v.ipe;   // parameters per row at the ABI (mip: incl. the spliced-out blur parameter)
+    const Dims dm_ = dims_of(&ctx->desc);
+    const int np = dm_.g + dm_.a + v.ipe;   // parameters per row at the ABI (mip: incl. the spliced-out blur parameter)
     if (!rays_o || !rays_d || !t || !color_out || !alpha_out || (!params && np > 0))
         return fail(NTX_E_INVALID, "NULL buffer");
     if (rays_per_param_row < 1) return fail(NTX_E_INVALID, "rays_per_param_row must be >= 1");
@@ -658,7 +695,7 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
         return fail(NTX_E_INVALID, "n_rays %lld exceeds the %zu rays this context reserved; call ntx_reserve first", (long long)n_rays, ctx->hit_cap);
     const bool x3 = (flags & NTX_FLAG_FP16X3) != 0;
     // the per-ray direction vector is valid unless the blur scaling hits an APPEARANCE parameter per sample (renderer.py:155-158)
-    const bool dir_const = v.cd && (blur_idx < 0 || blur_idx < v.n_geo || v.ipe);
+    const bool dir_const = v.cd && (blur_idx < 0 || blur_idx < dm_.g || v.ipe);
     if (x3 && v.cd && !dir_const)
         return fail(NTX_E_UNSUPPORTED, "fp16x3: blur_idx %d scales an appearance parameter per sample; use float32", blur_idx);
     RenderArgs a{};
@@ -668,7 +705,8 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.params = params; a.cone = cone_scale; a.z_vals = z_vals;
     a.color_out = color_out; a.alpha_out = alpha_out; a.weights_out = weights_out; a.status = status_flag;
     a.n_rays = n_rays; a.rays_per_row = rays_per_param_row;
-    a.n_samples = n_samples; a.blur_idx = blur_idx; a.flags = flags;
+    a.n_samples = n_samples; a.blur_idx = blur_slot(ctx, blur_idx); a.flags = flags;
+    fill_param_map(ctx, a);
     a.delta = (1.0f - 0.0f) / (float)(n_samples - 1 + v.ipe);   // mip: S+1 segment edges (renderer.py:374)
     a.seed_lo = (uint32_t)perturb_seed; a.seed_hi = (uint32_t)(perturb_seed >> 32);
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
@@ -712,7 +750,8 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
         return fail(NTX_E_INVALID, "n_samples %d outside [1,%d]", n_samples, MAX_INSTANCE_SAMPLES);
     if (n_rays == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
-    const int np = v.n_geo + v.n_app + v.ipe;
+    const Dims dm_ = dims_of(&ctx->desc);
+    const int np = dm_.g + dm_.a + v.ipe;
     if (v.ipe && (blur_idx < 0 || !t)) return fail(NTX_E_INVALID, "an IPE (mip) model needs blur_idx and t (renderer.py:511, 575)");
     if (!rays_d_map || !pts || !dists || !color_last || !alpha_last || !hit || !color_out || !alpha_out ||
         (!params_map && np > 0))
@@ -730,7 +769,8 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     a.alpha_last = alpha_last; a.alpha_weight = alpha_weight; a.params_map = params_map; a.cone = cone_scale;
     a.instance_color = instance_color; a.instance_id = instance_id; a.hit = hit;
     a.color_out = color_out; a.alpha_out = alpha_out; a.status = status_flag;
-    a.n_rays = n_rays; a.n_samples = n_samples; a.blur_idx = blur_idx; a.flags = flags;
+    a.n_rays = n_rays; a.n_samples = n_samples; a.blur_idx = blur_slot(ctx, blur_idx); a.flags = flags;
+    fill_param_map(ctx, a);
     a.patch_scale = patch_scale; a.density_scale = density_scale;
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
     if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "n_rays %lld exceeds int32", (long long)n_rays);

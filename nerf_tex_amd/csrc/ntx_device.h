@@ -350,9 +350,11 @@ struct DirGen {
 // ---------------------------------------------------------------------------------------------
 // the MLP on one batch of 32 samples (model.py:58-125 / 9-45); lanes l and l+32 hold sample l&31
 // ---------------------------------------------------------------------------------------------
-template <int NGEO_, int NAPP_, int CD_, int IPE_ = 0>
+// GEN: the generic family (ntx_layout.h): the model may have fewer parameters than the NGEO_ + NAPP_ slots of the kernel;
+// slot k reads column pmap[k] of the caller's parameter rows (or 0), rows are np_in wide (both in the kernel arguments)
+template <int NGEO_, int NAPP_, int CD_, int IPE_ = 0, int GEN_ = 0>
 struct Cfg {
-    static constexpr int NGEO = NGEO_, NAPP = NAPP_, CD = CD_, IPE = IPE_;
+    static constexpr int NGEO = NGEO_, NAPP = NAPP_, CD = CD_, IPE = IPE_, GEN = GEN_;
     static constexpr int NP = NGEO_ + NAPP_;          // parameters the MODEL sees
     static constexpr int NP_IN = NP + IPE_;           // parameters per row at the ABI: mip renderers splice the blur
                                                       // parameter out before the model (renderer.py:385-386, 511-512)
@@ -548,11 +550,27 @@ NTX_DEV void load_aux(float *lds, const float *aux_g, int n) {
 }
 
 // LDS behind the aux block: one column of position-segment values per lane and wave (PosGen KEEP)
-constexpr int PE_KEEP_FLOATS = 41 * 64;   // pos_steps <= 41 over the built families
+template <class CFG>
+constexpr int pe_keep_floats() { return CFG::PS * 64; }
 template <class CFG>
 NTX_DEV float *pe_column(float *aux, int wave_in_wg, int lane) {
-    static_assert(CFG::PS * 64 <= PE_KEEP_FLOATS, "position segment fits its LDS column");
-    return aux + aux_total() + wave_in_wg * PE_KEEP_FLOATS + lane;
+    return aux + aux_total() + wave_in_wg * pe_keep_floats<CFG>() + lane;
+}
+
+// slot k of the kernel's parameter vector from a row of the caller's parameters, and the width of those rows
+template <class CFG, class Args>
+NTX_DEV float param_at(const Args &a, const float *row, int k) {
+    if constexpr (CFG::GEN != 0) {
+        const int c = a.pmap[k];
+        return c >= 0 ? row[c] : 0.0f;
+    } else {
+        return row[k];
+    }
+}
+template <class CFG, class Args>
+NTX_DEV int param_stride(const Args &a) {
+    if constexpr (CFG::GEN != 0) return a.np_in;
+    else return CFG::NP_IN;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -641,6 +659,8 @@ struct RenderArgs {
     // fp16x3 kernels only: the float32 stream, whose records of C1's direction segment dir_block multiplies
     const f32x4 *dir_wstream;
     uint32_t dir_stream_bytes;
+    int np_in;                        // generic family: width of the caller's parameter rows, and the column of every slot (-1: absent)
+    int8_t pmap[MAX_PARAM_SLOTS];
 };
 
 // the by-value kernel argument struct, addressed in the kernarg segment (device pass only)
@@ -758,9 +778,9 @@ NTX_DEV void dir_block(const RenderArgs &a, __amdgpu_buffer_rsrc_t rsrc, const f
         in.pos[0] = in.pos[1] = in.pos[2] = 0.0f;
         in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
         in.dir[0] = dx / dnorm; in.dir[1] = dy / dnorm; in.dir[2] = dz / dnorm;
-        const float *prow = a.params + (ray / a.rays_per_row) * CFG::NP_IN;
+        const float *prow = a.params + (ray / a.rays_per_row) * param_stride<CFG>(a);
 #pragma unroll
-        for (int k = 0; k < CFG::NP; ++k) in.par[k] = prow[(CFG::IPE != 0 && k >= a.blur_idx) ? k + 1 : k];
+        for (int k = 0; k < CFG::NP; ++k) in.par[k] = param_at<CFG>(a, prow, (CFG::IPE != 0 && k >= a.blur_idx) ? k + 1 : k);
         ray_rows<CFG::DS, CFG::rec_pass(9), 9>(rsrc, aux, rows, j, h, wv, lane,
                                                [&](auto S) { return dir_feature<CFG::NGEO, CFG::NAPP, decltype(S)::value>(in, h); });
         if constexpr (GEO) {
@@ -787,9 +807,9 @@ template <class CFG, int HOIST = 0>
 __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     static_assert(HOIST == 0 || CFG::CD != 0, "hoisting is for the ParamNerf families");
     static_assert(HOIST != 2 || (CFG::IPE == 0 && CFG::NGEO > 0), "geometry hoisting: FourierFeatures families with geometry parameters");
-    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * PE_KEEP_FLOATS + (HOIST == 2 ? 3 : HOIST) * DIR_BLOCK_FLOATS];
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * pe_keep_floats<CFG>() + (HOIST == 2 ? 3 : HOIST) * DIR_BLOCK_FLOATS];
     load_aux(aux, a.aux, aux_total());
-    float *dir_rows = aux + aux_total() + 4 * PE_KEEP_FLOATS;
+    float *dir_rows = aux + aux_total() + 4 * pe_keep_floats<CFG>();
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int vwg = xcd_major_workgroup(blockIdx.x, gridDim.x);
@@ -830,7 +850,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             const float dx = q.rays_d[3 * r], dy = q.rays_d[3 * r + 1], dz = q.rays_d[3 * r + 2];
             const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);   // renderer.py:98, 180
             const float cone = q.cone ? q.cone[r] : 0.0f;
-            const float *prow = q.params + (r / q.rays_per_row) * CFG::NP_IN;
+            const float *prow = q.params + (r / q.rays_per_row) * param_stride<CFG>(q);
             const int i = 32 * b + j;
             const bool valid = i < S;
             const int ic = valid ? i : S - 1;
@@ -847,7 +867,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
                 in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
 #pragma unroll
                 for (int k = 0; k < CFG::NP; ++k) {
-                    float p = prow[k];
+                    float p = param_at<CFG>(q, prow, k);
                     if (k == blur_idx) p = p * (cone * z);                                // renderer.py:155-158
                     in.par[k] = p;
                 }
@@ -918,6 +938,8 @@ struct InstanceArgs {
     float bkgd[3];
     int32_t *work_counter;   // device scalar, zero at launch: rays are handed out dynamically (their cost varies 0..S/32 batches)
     const int32_t *order;    // the rays, costliest first (inst_*_kernel, ntx_small_kernels.h): claim k marches ray order[k]
+    int np_in;               // generic family, as RenderArgs
+    int8_t pmap[MAX_PARAM_SLOTS];
 };
 
 // Tail packing.  A ray's in-patch samples fill count / 32 whole batches and leave a TAIL of count % 32 samples; run as a
@@ -968,7 +990,7 @@ NTX_DEV void composite_segment(RayAccum &ra, float a, const float (&c)[3], int j
 
 template <class CFG>
 __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
-    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * PE_KEEP_FLOATS];
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * pe_keep_floats<CFG>()];
     __shared__ uint16_t sidx_all[4][MAX_INSTANCE_SAMPLES];
     __shared__ InstancePending pend_all[4];
     load_aux(aux, a.aux, aux_total());
@@ -1088,7 +1110,7 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
             in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
 #pragma unroll
             for (int c = 0; c < CFG::NP; ++c) {
-                float p = a.params_map[CFG::NP * sm + c];
+                float p = param_at<CFG>(a, a.params_map + param_stride<CFG>(a) * sm, c);
                 if (c == a.blur_idx) p = p * (cone_l * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
                 in.par[c] = p;
             }
@@ -1141,11 +1163,13 @@ struct MlpArgs {
     const float *pos, *dirs, *params;
     float *color_out, *sigma_out;
     int64_t m;
+    int np_in;               // generic family, as RenderArgs
+    int8_t pmap[MAX_PARAM_SLOTS];
 };
 
 template <class CFG>
 __global__ __launch_bounds__(256) void mlp_kernel(MlpArgs a) {
-    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * PE_KEEP_FLOATS];
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * pe_keep_floats<CFG>()];
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1165,7 +1189,8 @@ __global__ __launch_bounds__(256) void mlp_kernel(MlpArgs a) {
             in.dir[k] = a.dirs[3 * mc + k];
         }
 #pragma unroll
-        for (int k = 0; k < CFG::NP; ++k) in.par[k] = a.params[CFG::NP * mc + k];
+        for (int k = 0; k < CFG::NP; ++k)   // the MODEL's parameters, [M, NP] (an IPE model's caller has spliced the blur parameter out)
+            in.par[k] = param_at<CFG>(a, a.params + (CFG::GEN != 0 ? a.np_in : CFG::NP) * mc, k);
         float sigma, raw[3];
         mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe_column<CFG>(aux, threadIdx.x >> 6, lane));
         if (valid && lane < 32) {

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
             const float dx = q.rays_d[3 * r], dy = q.rays_d[3 * r + 1], dz = q.rays_d[3 * r + 2];
             const float dnorm = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
             const float cone = q.cone ? q.cone[r] : 0.0f;
-            const float *prow = q.params + (r / q.rays_per_row) * CFG::NP_IN;
+            const float *prow = q.params + (r / q.rays_per_row) * param_stride<CFG>(q);
             const int i = 32 * b + j;
             const bool valid = i < S;
             const int ic = valid ? i : S - 1;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
                 in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
 #pragma unroll
                 for (int k = 0; k < CFG::NP; ++k) {
-                    float p = prow[k];
+                    float p = param_at<CFG>(q, prow, k);
                     if (k == blur_idx) p = p * (cone * z);
                     in.par[k] = p;
                 }
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
             in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
 #pragma unroll
             for (int c = 0; c < CFG::NP; ++c) {
-                float p = a.params_map[CFG::NP * sm + c];
+                float p = param_at<CFG>(a, a.params_map + param_stride<CFG>(a) * sm, c);
                 if (c == a.blur_idx) p = p * (cone_l * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
                 in.par[c] = p;
             }
@@ -700,7 +700,8 @@ __global__ __launch_bounds__(256) void mlp_kernel_x3(MlpArgs a) {
             in.dir[k] = a.dirs[3 * mc + k];
         }
 #pragma unroll
-        for (int k = 0; k < CFG::NP; ++k) in.par[k] = a.params[CFG::NP * mc + k];
+        for (int k = 0; k < CFG::NP; ++k)   // the MODEL's parameters, [M, NP] (an IPE model's caller has spliced the blur parameter out)
+            in.par[k] = param_at<CFG>(a, a.params + (CFG::GEN != 0 ? a.np_in : CFG::NP) * mc, k);
         float sigma, raw[3];
         mlp_batch_x3<CFG, true>(in, ws, aux, lane, sigma, raw, 0);
         if (valid && lane < 32) {

@@ -60,17 +60,19 @@ NTX_HD constexpr int pos_geo_steps(int n_geo) { return (n_geo + 1) / 2 + n_geo *
 NTX_HD constexpr int pos_steps(int n_geo, int ipe = 0) { return pos_geo_steps(n_geo) + (ipe ? 0 : 2) + 3 * POS_FREQ; }
 NTX_HD constexpr int pos_map_dim(int n_geo, int ipe = 0) { return pos_emb_dim(ipe) + n_geo * (1 + 2 * PAR_FREQ); }
 
-// row of the reference's pos_map that (step s, half h) carries, or -1 for a zero pad
-NTX_HD constexpr int pos_row(int n_geo, int s, int h, int ipe = 0) {
+// row of the reference's pos_map that (step s, half h) carries, or -1 for a zero pad.  n_geo lays out the k-steps; a model
+// with FEWER geometry parameters (n_act < n_geo, the generic family) leaves the steps of the missing ones as zero rows.
+NTX_HD constexpr int pos_row(int n_geo, int s, int h, int ipe = 0, int n_act = -1) {
+    if (n_act < 0) n_act = n_geo;
     const int base = pos_emb_dim(ipe), ngid = (n_geo + 1) / 2;
     if (s < ngid) {
         const int v = 2 * s + h;
-        return v < n_geo ? base + v : -1;
+        return v < n_act ? base + v : -1;
     }
     int q = s - ngid;
     if (q < n_geo * PAR_FREQ) {
         const int f = q / n_geo, g = q % n_geo;
-        return base + n_geo + 2 * f * n_geo + h * n_geo + g;
+        return g < n_act ? base + n_act + 2 * f * n_act + h * n_act + g : -1;
     }
     q -= n_geo * PAR_FREQ;
     if (!ipe) {
@@ -91,22 +93,29 @@ NTX_HD constexpr int dir_steps_raw(int n_app) { return dir_id_steps(n_app) + 3 *
 NTX_HD constexpr int dir_steps(int n_app) { return dir_steps_raw(n_app); }
 NTX_HD constexpr int dir_map_dim(int n_app) { return 3 * (1 + 2 * DIR_FREQ) + n_app * (1 + 2 * PAR_FREQ); }
 
-NTX_HD constexpr int dir_row(int n_app, int s, int h) {
+NTX_HD constexpr int dir_row(int n_app, int s, int h, int n_act = -1) {   // n_act < n_app: as pos_row
+    if (n_act < 0) n_act = n_app;
     const int nid = dir_id_steps(n_app);
     if (s < nid) {
         const int v = 2 * s + h;
         if (v >= dir_id_values(n_app)) return -1;
-        return v < 3 ? v : 3 * (1 + 2 * DIR_FREQ) + (v - 3);
+        if (v < 3) return v;
+        return v - 3 < n_act ? 3 * (1 + 2 * DIR_FREQ) + (v - 3) : -1;
     }
     int q = s - nid;
     if (q < 3 * DIR_FREQ) return 3 + 6 * (q / 3) + 3 * h + (q % 3);
     q -= 3 * DIR_FREQ;
     if (q < n_app * PAR_FREQ) {
         const int f = q / n_app, a = q % n_app;
-        return 3 * (1 + 2 * DIR_FREQ) + n_app + 2 * f * n_app + h * n_app + a;
+        return a < n_act ? 3 * (1 + 2 * DIR_FREQ) + n_act + 2 * f * n_act + h * n_act + a : -1;
     }
     return -1;
 }
+
+// the generic family: any ParamNerf n_parameters = [g, a] with g <= GEN_NGEO, a <= GEN_NAPP runs on the kernels of
+// Cfg<GEN_NGEO, GEN_NAPP>; the rows of the parameters it does not have are zero and their inputs are fed as 0
+constexpr int GEN_NGEO = 4, GEN_NAPP = 8;
+constexpr int MAX_PARAM_SLOTS = 16;
 
 // ---- packed image geometry -----------------------------------------------------------------
 // Weight STREAM (consumed strictly in order by every wave, RING records ahead):

@@ -5,7 +5,7 @@
 #include "ntx_device_x3.h"
 
 #ifndef NTX_VARIANT
-#error "compile with -DNTX_VARIANT=0..4"
+#error "compile with -DNTX_VARIANT=0..5"
 #endif
 
 namespace ntx {
@@ -22,9 +22,12 @@ using VCfg = Cfg<2, 3, 1>;   // grass_filtered
 #elif NTX_VARIANT == 3
 using VCfg = Cfg<0, 0, 0>;   // plain Nerf
 #define NTX_FN(name) name##_v3
-#else
+#elif NTX_VARIANT == 4
 using VCfg = Cfg<1, 3, 1, 1>;   // mip: IPE position encoding, grass_filtered with the blur parameter spliced out
 #define NTX_FN(name) name##_v4
+#else
+using VCfg = Cfg<GEN_NGEO, GEN_NAPP, 1, 0, 1>;   // generic: any ParamNerf n_parameters = [g <= 4, a <= 8] (absent parameters = zero rows)
+#define NTX_FN(name) name##_v5
 #endif
 
 hipError_t NTX_FN(launch_render_x3)(int n_wgs, RenderArgs &a, hipStream_t st) {

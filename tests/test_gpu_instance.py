@@ -51,7 +51,7 @@ class FakeInstancer:
         return out
 
 
-@pytest.mark.parametrize("npar,blur", [((1, 6), None), ((2, 3), 0), ((1, 4), None)])
+@pytest.mark.parametrize("npar,blur", [((1, 6), None), ((2, 3), 0), ((1, 4), None), ((2, 5), 1)])   # (2, 5): the generic family
 @pytest.mark.parametrize("S", [40, 200])
 @pytest.mark.parametrize("opts", [dict(), dict(composite_bkgd=True, map_exr=True), dict(density_reweighting=False, density_scale=30.0),
                                   dict(false_color=True)])

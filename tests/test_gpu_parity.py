@@ -165,7 +165,7 @@ def test_unsupported_model_fails_loudly():
     from nerf_tex_amd import _lib
     from nerf_tex_amd.model import ParamNerf
     from tests.common import EMB
-    m = ParamNerf(EMB(10), EMB(4), EMB(4), [3, 3])["model"]
+    m = ParamNerf(EMB(10), EMB(4), EMB(4), [5, 3])["model"]        # more geometry parameters than the generic family's 4 slots
     with pytest.raises(_lib.NtxError) as e:
         m.ctx(0)
     assert e.value.code == _lib.NTX_E_UNSUPPORTED

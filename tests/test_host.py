@@ -37,7 +37,8 @@ def test_create_without_gpu_reports_no_device():
 
 def test_unsupported_desc_is_rejected_on_host():
     from nerf_tex_amd import _lib
-    for bad in (_lib.ModelDesc(0, 3, 3, 3, 10, 4, 4, 8, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 6, 3, 8, 4, 4, 8, 256, 4, 1, 0),
+    for bad in (_lib.ModelDesc(0, 5, 3, 3, 10, 4, 4, 8, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 9, 3, 10, 4, 4, 8, 256, 4, 1, 0),
+                _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 2, 0), _lib.ModelDesc(0, 1, 6, 3, 8, 4, 4, 8, 256, 4, 1, 0),
                 _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 6, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 128, 4, 1, 0),
                 _lib.ModelDesc(0, 1, 3, 3, 10, 4, 4, 8, 256, 4, 1, 1), _lib.ModelDesc(0, 1, 6, 6, 10, 4, 4, 8, 256, 4, 1, 1)):
         assert _lib.lib.ntx_weight_count(C.byref(bad)) == 0
@@ -45,6 +46,8 @@ def test_unsupported_desc_is_rejected_on_host():
 
 
 @pytest.mark.parametrize("desc,count", [((0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, 0), 683524), ((0, 1, 4, 3, 10, 4, 4, 8, 256, 4, 1, 0), 678916),
+                                        ((0, 3, 3, 3, 10, 4, 4, 8, 256, 4, 1, 0), None), ((0, 0, 2, 3, 10, 4, 4, 8, 256, 4, 1, 0), None),
+                                        ((0, 4, 8, 3, 10, 4, 4, 8, 256, 4, 1, 0), None),
                                         ((0, 2, 3, 3, 10, 4, 4, 8, 256, 4, 1, 0), 681220), ((1, 0, 0, 3, 10, 4, 0, 8, 256, 4, 0, 0), 593408 + 8 * 256 + 1 + 256 + 128 + 3),
                                         ((0, 1, 3, 6, 10, 4, 4, 8, 256, 4, 1, 1), 675076)])
 def test_pack_weights_is_a_permutation_with_wraparound_tail(desc, count):
@@ -53,6 +56,11 @@ def test_pack_weights_is_a_permutation_with_wraparound_tail(desc, count):
     from nerf_tex_amd import _lib
     d = _lib.ModelDesc(*desc)
     n = _lib.lib.ntx_weight_count(C.byref(d))
+    if count is None:        # the generic family (any [g <= 4, a <= 8]): the count follows the model's own dimensions
+        g, a = desc[1], desc[2]
+        pm, dm = 63 + 9 * g, 27 + 9 * a
+        count = pm * 256 + 256 + 4 * (256 * 256 + 256) + (256 + pm) * 256 + 256 + 2 * (256 * 256 + 256) + (256 * 256 + 256) \
+            + (256 + dm) * 256 + 256 + 256 * 128 + 128 + 128 * 3 + 3 + 256 + 1
     assert n == count
     npk = _lib.lib.ntx_packed_count(C.byref(d))
     rng = np.random.default_rng(0)
