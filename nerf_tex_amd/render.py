@@ -47,8 +47,12 @@ def Render(target_path: Optional[str], test_dataset_config, model_config, render
     test_dataset = util.instantiate(test_dataset_config)
     model_config.setdefault("n_parameters", test_dataset.n_parameters)                  # render.py:20
     model = util.instantiate(model_config)
-    if weights is not None:                      # explicit blob (Keras get_weights() order) wins
-        next(iter(model.values())).set_blob(weights)
+    if weights is not None:                      # explicit weights win: `keras_model.get_weights()` as it is (a list: every
+        m0 = next(iter(model.values()))          # layer's shape is checked), or the same flattened into one blob
+        if isinstance(weights, (list, tuple)):
+            m0.set_weights(weights)
+        else:
+            m0.set_blob(weights)
     else:                                        # logger.py:30-39: restore the newest ckpt-* under <source>/checkpoints
         ckpt_dir = os.path.join(source_path if source_path is not None else (target_path or ""), "checkpoints")
         if os.path.isdir(ckpt_dir) and any(f.endswith(".index") for f in os.listdir(ckpt_dir)):

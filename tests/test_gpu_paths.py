@@ -491,3 +491,23 @@ def test_generic_family_matches_a_tuned_family_on_its_own_dimensions(monkeypatch
     monkeypatch.delenv("NERFTEX_FORCE_GENERIC")
     # the zero rows contribute exact zeros and the non-zero k-steps keep their relative order: not merely close, the same bits
     assert np.array_equal(tuned, generic)
+
+
+def test_gather_image_argument_errors():
+    """ntx_gather_image refuses bad arguments before any RCCL call: NULL communicator, root out of range, an interleaved
+    shard map without a staging buffer on the root."""
+    from nerf_tex_amd import _lib
+    from nerf_tex_amd.dist import Comm
+    comm = Comm(0)
+    n = 4000
+    local = torch.rand((n, 4), device=dev()); image = torch.empty((n, 4), device=dev())
+    st = torch.cuda.current_stream(dev()).cuda_stream
+    call = lambda h, run, root, staging: _lib.lib.ntx_gather_image(h, local.data_ptr(), n, run, image.data_ptr(), staging, root, st)
+    assert call(None, n, 0, None) == _lib.NTX_E_INVALID
+    assert call(comm.handle, n, 1, None) == _lib.NTX_E_INVALID
+    assert call(comm.handle, 0, 0, None) == _lib.NTX_E_INVALID
+    assert call(comm.handle, 100, 0, None) == _lib.NTX_E_INVALID and b"staging" in _lib.lib.ntx_last_error()
+    assert call(comm.handle, n, 0, None) == 0                      # bands on one rank: straight into image_out
+    torch.cuda.synchronize()
+    assert torch.equal(image, local)
+    comm.close()
