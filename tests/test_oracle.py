@@ -319,3 +319,56 @@ def test_torch_cpu_baseline_port_agrees_with_the_oracle():
         want = np.concatenate([ref["color_pred"][0], ref["alpha_pred"][0][:, None]], -1)
         assert orc.rel_linf(got, want) <= 2e-4          # float32 port vs float64 truth, dense-media weights
     assert "BLAS_INFO" in torch_cpu.blas_backend()
+
+
+def test_layer_order_follows_keras_graph_depth_rule():
+    """`layer_table` claims to be `tf.keras.Model.get_weights()` order.  TensorFlow cannot run here, so the rule is restated:
+    keras/engine/functional.py `_map_graph_network` (TF 2.4) visits the graph depth-first from `outputs` in order (giving every
+    layer a traversal index at its FIRST visit, before its inputs), assigns each layer depth = longest path to an output, and
+    lists layers by decreasing depth, ties by traversal index.  Applied to the graph model.py:58-125 builds, with
+    outputs=[color_outputs, alpha_outputs] (model.py:125), it must give the order of `layer_table`."""
+    def order_of(kind, color_depth, depth=8, skips=(4,)):
+        inputs_of = {}                                    # layer -> list of input layers, as model.py wires them
+        def dense(name, src):
+            inputs_of[name] = [src]; return name
+        for n in ("pos", "dir", "params"):
+            inputs_of[n] = []
+        inputs_of["pos_map"] = ["pos", "params"] if kind == "ParamNerf" else ["pos"]       # FourierFeatures + concat (weightless)
+        inputs_of["dir_map"] = ["dir", "params"] if kind == "ParamNerf" else ["dir"]
+        h = "pos_map"
+        for i in range(depth):                                                            # model.py:104-108
+            h = dense(f"trunk{i}", h)
+            if i in skips:
+                inputs_of[f"skipcat{i}"] = ["pos_map", h]; h = f"skipcat{i}"
+        alpha = dense("alpha", h)                                                         # :111
+        f = dense("feature", h)                                                           # :114
+        inputs_of["dircat"] = ["dir_map", f]; h = "dircat"                                # :115
+        if kind == "ParamNerf":
+            for i in range(color_depth):                                                  # :118-119
+                h = dense(f"color_hidden{i}", h)
+        h = dense("color_half", h)                                                        # :122
+        color = dense("color", h)                                                         # :123
+        outputs = [color, alpha]                                                          # :125
+        index, depth_of = {}, {}
+        def visit(layer):
+            if layer not in index:
+                index[layer] = len(index)
+            for src in inputs_of[layer]:
+                visit(src)
+        for o in outputs:
+            visit(o)
+        def longest(layer, d):
+            if depth_of.get(layer, -1) >= d:
+                return
+            depth_of[layer] = d
+            for src in inputs_of[layer]:
+                longest(src, d + 1)
+        for o in outputs:
+            longest(o, 0)
+        layers = sorted(index, key=lambda l: (-depth_of[l], index[l]))
+        weighted = lambda l: l.startswith(("trunk", "color")) or l in ("alpha", "feature")
+        return [l for l in layers if weighted(l)]
+
+    assert order_of("ParamNerf", 1) == [n for n, _, _ in orc.layer_table(orc.ModelSpec(kind="ParamNerf", n_parameters=(1, 6)))]
+    assert order_of("Nerf", 0) == [n for n, _, _ in orc.layer_table(orc.ModelSpec(kind="Nerf", n_parameters=(0, 0)))]
+    assert order_of("ParamNerf", 1)[-2:] == ["color", "alpha"] and order_of("ParamNerf", 1)[8] == "feature"
