@@ -1,0 +1,76 @@
+"""Entry point (reference: main.py): `python -m nerf_tex_amd.main <config.py>` loads a config file written for the reference,
+points its hot-path modules at this package (`util.remap_reference_config`) and instantiates the top-level module.
+
+What main.py does for a render config is kept: the config is a python file with a `config` dict (main.py:17-23), the random
+seed is set from it (main.py:30-32; numpy only -- it drives the pose / parameter distributions, the initial weights and the
+stratified jitter's seeds), the target folder is created and the config copied into it (main.py:35-42).  Training configs
+(`network.train.Train`) are out of scope and refused.  The reference's TF-free `data.distribution` / `data.sampler` modules are
+used as they are when the config names them: pass `--reference-root` (the directory holding `data/` and `util/`) or run from it.
+
+    python -m nerf_tex_amd.main configs/example_carpet_render.py
+    python -m nerf_tex_amd.main /path/to/nerf-tex/configs/config_carpet_render.py --reference-root /path/to/nerf-tex --volumetric
+"""
+
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import os
+import shutil
+import sys
+
+import numpy as np
+
+from . import util
+
+
+def load_config(path: str) -> util.EasyDict:
+    """main.py:17-23: the `config` dict of a python file (given as a path, with or without `.py`)."""
+    path = path if path.endswith(".py") else path + ".py"
+    spec = importlib.util.spec_from_file_location("_ntx_config", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return util.EasyDict(mod.config)
+
+
+def prepare(config: dict, volumetric: bool = False) -> util.EasyDict:
+    """Remap a reference config for this package.  `volumetric`: the shipped render configs name `InstanceRenderer`, which
+    needs the reference's Embree instancer (out of scope); render the bare volume inside the proxy with `Renderer` instead."""
+    cfg = util.remap_reference_config(config)
+    if "train" in str(cfg.get("module", "")).lower():
+        raise NotImplementedError("training (network.train.Train) is outside the render path this package implements")
+    if volumetric:
+        rc = cfg.renderer_config
+        if rc.module.endswith("InstanceRenderer"):
+            rc.module = rc.module.replace("MipInstanceRenderer", "MipRenderer").replace("InstanceRenderer", "Renderer")
+            for k in ("instancer_config", "step_size", "density_scale", "density_reweighting", "false_color"):
+                rc.pop(k, None)
+            rc.n_samples = min(int(rc.get("n_samples", 64)), 128)          # marching steps of the instancer -> samples in the proxy
+    cfg.pop("seed", None); cfg.pop("override", None)
+    return cfg
+
+
+def main(argv=None) -> list:
+    ap = argparse.ArgumentParser(description="Render as specified in a (reference) config file.")
+    ap.add_argument("config", help="Path to config file.")
+    ap.add_argument("--reference-root", default=None, help="directory of the reference tree (for its data.* / util.* modules)")
+    ap.add_argument("--volumetric", action="store_true", help="replace InstanceRenderer by Renderer (no Embree instancer)")
+    args = ap.parse_args(argv)
+    if args.reference_root:
+        sys.path.insert(0, os.path.abspath(args.reference_root))
+    raw = load_config(args.config)
+    if raw.get("seed") is not None:                                        # main.py:30-32
+        np.random.seed(raw["seed"])
+    target = raw.get("target_path")
+    if target:                                                             # main.py:35-42
+        os.makedirs(target, exist_ok=bool(raw.get("override", True)))
+        dst = os.path.join(target, "config_render.py")
+        src = args.config if args.config.endswith(".py") else args.config + ".py"
+        if os.path.abspath(src) != os.path.abspath(dst):
+            shutil.copy(src, dst)
+    return util.instantiate(prepare(raw, args.volumetric))                 # main.py:50
+
+
+if __name__ == "__main__":
+    imgs = main()
+    print(f"rendered {len(imgs)} image(s)")

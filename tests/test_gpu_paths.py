@@ -511,3 +511,16 @@ def test_gather_image_argument_errors():
     torch.cuda.synchronize()
     assert torch.equal(image, local)
     comm.close()
+
+
+def test_main_entry_point_renders_the_example_config(tmp_path, monkeypatch):
+    """`python -m nerf_tex_amd.main configs/example_carpet_render.py` (reference: main.py + render.py): two 128x128 views,
+    perturb=True by default (in-kernel jitter), images returned and saved under <target_path>/media/test."""
+    from nerf_tex_amd import main as m
+    monkeypatch.chdir(tmp_path)
+    imgs = m.main([os.path.join(ROOT, "configs", "example_carpet_render.py")])
+    assert len(imgs) == 2 and tuple(imgs[0].shape) == (1, 128, 128, 4)
+    a = imgs[0][0, ..., 3]
+    assert bool(torch.isfinite(imgs[0]).all()) and float(a.max()) > 0.0 and float(a.min()) == 0.0      # object and empty background
+    saved = sorted(os.listdir(tmp_path / "logs" / "example_carpet" / "media" / "test"))
+    assert saved == ["0.npy", "1.npy"] and os.path.exists(tmp_path / "logs" / "example_carpet" / "config_render.py")

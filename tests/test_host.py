@@ -355,3 +355,25 @@ def test_checkpoint_reader_round_trip(tmp_path):
     other = ParamNerf(EMB(10), EMB(4), EMB(4), [1, 4])["model"]
     with pytest.raises(KeyError):
         ck.model_weights_from_bundle(got, other.layer_table())
+
+
+def test_main_entry_point_prepares_reference_configs():
+    """nerf_tex_amd.main (reference: main.py): config file -> remapped config; `--volumetric` swaps the Embree-backed
+    InstanceRenderer for the volumetric Renderer; training configs are refused."""
+    from nerf_tex_amd import main as m
+    cfg = m.prepare(m.load_config(os.path.join(ROOT, "configs", "example_carpet_render.py")))
+    assert cfg.module == "nerf_tex_amd.render.Render" and cfg.renderer_config.module == "nerf_tex_amd.renderer.Renderer"
+    assert "seed" not in cfg and len(cfg.test_dataset_config.data_loader_config.views) == 2
+    with pytest.raises(NotImplementedError):
+        m.prepare({"module": "network.train.Train"})
+    ref = "/root/reference/configs/config_carpet_render.py"
+    if os.path.exists(ref):
+        sys.path.insert(0, "/root/reference")
+        try:
+            raw = m.load_config(ref)
+        finally:
+            sys.path.remove("/root/reference")
+        assert raw.renderer_config.module == "network.renderer.InstanceRenderer"
+        vol = m.prepare(raw, volumetric=True)
+        assert vol.renderer_config.module == "nerf_tex_amd.renderer.Renderer" and "instancer_config" not in vol.renderer_config
+        assert m.prepare(raw).renderer_config.module == "nerf_tex_amd.renderer.InstanceRenderer"
