@@ -290,7 +290,7 @@ static void pack16(const Variant &v, Dims m, const float *blob, uint16_t *out, i
     }
     emit_segment16(dst, n.feature, hs, 8, 0, hidrow);
     if (n.has_c1) {
-        emit_segment16(dst, n.c1, hs, 8, dm, hidrow);   // render kernel: its direction rows are applied per ray by dirbias_kernel
+        emit_segment16(dst, n.c1, hs, 8, dm, hidrow);   // render kernel: its direction rows are applied per ray by dir_block (float32)
         if (with_dir) emit_segment16(dst, n.c1, ds, 8, 0, dirrow);
         emit_segment16(dst, n.c2, hs, 4, 0, hidrow);
     } else {
