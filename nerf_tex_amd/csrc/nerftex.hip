@@ -338,6 +338,7 @@ namespace ntx {
     hipError_t launch_instance_v##k(int n_wgs, InstanceArgs &a, hipStream_t st);     \
     hipError_t launch_render_hoist_v##k(int n_wgs, RenderArgs &a, hipStream_t st);   \
     hipError_t launch_render_hoist2_v##k(int n_wgs, RenderArgs &a, hipStream_t st);  \
+    hipError_t launch_render_hoist3_v##k(int n_wgs, RenderArgs &a, hipStream_t st);  \
     hipError_t launch_render_x3_v##k(int n_wgs, RenderArgs &a, hipStream_t st);      \
     hipError_t launch_mlp_x3_v##k(int n_wgs, MlpArgs &a, hipStream_t st);            \
     hipError_t launch_instance_x3_v##k(int n_wgs, InstanceArgs &a, hipStream_t st);
@@ -348,19 +349,20 @@ NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4) NTX_DECL(5)
 struct Launchers {
     hipError_t (*render)(int, RenderArgs &, hipStream_t);
     hipError_t (*render_hoist)(int, RenderArgs &, hipStream_t);   // NULL: plain Nerf has no per-ray direction segment to hoist out of C1
-    hipError_t (*render_hoist2)(int, RenderArgs &, hipStream_t);  // + the geometry-parameter block of L0 / L5 per ray; NULL: not built for the family
+    hipError_t (*render_hoist2)(int, RenderArgs &, hipStream_t);  // + the geometry-parameter blocks of L0 / L5 per ray; NULL: not built for the family
+    hipError_t (*render_hoist3)(int, RenderArgs &, hipStream_t);  // + all of them but parameter 0's (blur_idx = 0); NULL: not built
     hipError_t (*mlp)(int, MlpArgs &, hipStream_t);
     hipError_t (*instance)(int, InstanceArgs &, hipStream_t);
     hipError_t (*render_x3)(int, RenderArgs &, hipStream_t);
     hipError_t (*mlp_x3)(int, MlpArgs &, hipStream_t);
     hipError_t (*instance_x3)(int, InstanceArgs &, hipStream_t);
 };
-#define NTX_ROW(k, hoist, hoist2) {launch_render_v##k, hoist, hoist2, launch_mlp_v##k, launch_instance_v##k, launch_render_x3_v##k, launch_mlp_x3_v##k, launch_instance_x3_v##k}
+#define NTX_ROW(k, hoist, hoist2, hoist3) {launch_render_v##k, hoist, hoist2, hoist3, launch_mlp_v##k, launch_instance_v##k, launch_render_x3_v##k, launch_mlp_x3_v##k, launch_instance_x3_v##k}
 static const Launchers kLaunch[] = {   // indexed like kVariants
-    NTX_ROW(0, launch_render_hoist_v0, launch_render_hoist2_v0),
+    NTX_ROW(0, launch_render_hoist_v0, launch_render_hoist2_v0, nullptr),
 #ifndef NTX_DEV_ONLY_CARPET   // development builds link only the carpet family (compile time)
-    NTX_ROW(1, launch_render_hoist_v1, launch_render_hoist2_v1), NTX_ROW(2, launch_render_hoist_v2, nullptr), NTX_ROW(3, nullptr, nullptr),
-    NTX_ROW(4, launch_render_hoist_v4, nullptr), NTX_ROW(5, launch_render_hoist_v5, nullptr),
+    NTX_ROW(1, launch_render_hoist_v1, launch_render_hoist2_v1, nullptr), NTX_ROW(2, launch_render_hoist_v2, nullptr, launch_render_hoist3_v2),
+    NTX_ROW(3, nullptr, nullptr, nullptr), NTX_ROW(4, launch_render_hoist_v4, nullptr, nullptr), NTX_ROW(5, launch_render_hoist_v5, nullptr, nullptr),
 #else
     {}, {}, {}, {}, {},
 #endif
@@ -732,7 +734,9 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     // evaluates the colour layer's direction segment once per ray (dir_block) instead of once per sample -- same bits
     // -- and without a blur_idx the geometry parameters are per-ray constants as well: HOIST = 2 also starts L0 and L5 from
     // per-ray rows (bias + the geometry block of their position segments)
+    // -- and with blur_idx = 0 all of them but parameter 0's: HOIST = 3 (its block comes last in the layout)
     if (ctx->hoist_dir && dir_const && blur_idx < 0 && L.render_hoist2) HIP_TRY(launch(L.render_hoist2, ctx, a, st));
+    else if (ctx->hoist_dir && dir_const && blur_idx == 0 && dm_.g >= 2 && L.render_hoist3) HIP_TRY(launch(L.render_hoist3, ctx, a, st));
     else if (ctx->hoist_dir && dir_const && L.render_hoist) HIP_TRY(launch(L.render_hoist, ctx, a, st));
     else HIP_TRY(launch(L.render, ctx, a, st));
     return NTX_OK;

@@ -263,19 +263,15 @@ NTX_DEV float dir_id_value(const SampleIn<NGEO, NAPP> &in) {
     else return 0.0f;
 }
 
-// k-step S of the position segment (ntx_layout.h: geometry-parameter block first, then the position block).
+// k-step S of the position segment (ntx_layout.h: one block per geometry parameter, last parameter first, then the position block).
 // IPE (layer.py:25-41): no identity for the position, and every position pair is damped by exp(-0.5 * 4^f * cov_c).
 template <int NGEO, int NAPP, int IPE, int S>
 NTX_DEV float pos_feature(const SampleIn<NGEO, NAPP> &in, int h) {
-    constexpr int ngid = (NGEO + 1) / 2, ngs = NGEO * PAR_FREQ, npid = IPE ? 0 : 2;
-    if constexpr (S < ngid) {
-        float lo = 0.0f, hi = 0.0f;
-        if constexpr (2 * S < NGEO) lo = in.par[2 * S];
-        if constexpr (2 * S + 1 < NGEO) hi = in.par[2 * S + 1];
-        return h ? hi : lo;
-    } else if constexpr (S - ngid < ngs) {
-        constexpr int q = S - ngid, f = q / (NGEO > 0 ? NGEO : 1), g = q % (NGEO > 0 ? NGEO : 1);
-        return sin_q(in.par[g] * (float)(1 << f), h);
+    constexpr int ngid = 0, ngs = pos_geo_steps(NGEO), npid = IPE ? 0 : 2;
+    if constexpr (S < ngs) {                                   // block of parameter p: (g_p, pad), {sin, cos}(2^f g_p)
+        constexpr int p = NGEO - 1 - S / GEO_BLOCK, j = S % GEO_BLOCK;
+        if constexpr (j == 0) return h ? 0.0f : in.par[p];
+        else return sin_q(in.par[p] * (float)(1 << (j - 1)), h);
     } else if constexpr (S - ngid - ngs < npid) {
         constexpr int q = S - ngid - ngs;
         float lo = in.pos[2 * q < 3 ? 2 * q : 0], hi = 0.0f;
@@ -372,9 +368,16 @@ struct Cfg {
 // Logical <-> physical record indices of one kernel flavour.  Removed from the logical stream: with HOIST >= 1 the direction
 // segment of C1 (ParamNerf), with HOIST = 2 also the geometry-parameter blocks that lead the position segments of L0 and L5.
 // The logical stream is padded to whole ring turns and wraps into itself (no use of the packed stream's tail copy).
+// leading k-steps of the position segments that a HOIST level evaluates once per ray: all geometry blocks (2), or all but
+// the last one, parameter 0's, which blur_idx = 0 scales per sample (3)
+template <class CFG, int HOIST>
+constexpr int hoisted_geo_steps() {
+    return HOIST == 2 ? pos_geo_steps(CFG::NGEO) : HOIST == 3 ? pos_geo_steps(CFG::NGEO - 1) : 0;
+}
+
 template <class CFG, int HOIST>
 struct RecMap {
-    static constexpr int GS2 = (HOIST == 2 ? pos_geo_steps(CFG::NGEO) : 0) * 2;
+    static constexpr int GS2 = hoisted_geo_steps<CFG, HOIST>() * 2;
     static constexpr int DS2 = (HOIST != 0 && CFG::CD != 0 ? CFG::DS : 0) * 2;
     static constexpr int A5 = CFG::rec_pass(SKIP + 1), A9 = CFG::rec_pass(9);   // physical starts of L5's and C1's leading segments
     static constexpr int LOG_END = CFG::REC_END - 2 * GS2 - DS2;
@@ -399,15 +402,15 @@ struct RecMap {
 // ([half][128], accumulator order) = the per-ray vector bias_C1 + W_dir^T dir_map that dir_block computed with the same
 // instructions, and the direction segment is skipped (its records are still fetched, to keep the ring phase).  A
 // compile-time variant, not a run-time branch: a branch around the segment made hipcc spill 1 KiB per lane.
-// HOIST = 2 (no blur_idx): the geometry-parameter block of the position segments of L0 and L5 is per-ray constant too; L0
-// and L5 start from the rows dir_block left behind the C1 row (c1_row + DIR_BLOCK_FLOATS, + 2 DIR_BLOCK_FLOATS) and run only
-// the position block.
+// HOIST = 2 (no blur_idx) / 3 (blur_idx = 0): the geometry-parameter blocks of the position segments of L0 and L5 (all / all
+// but parameter 0's) are per-ray constant too; L0 and L5 start from the rows dir_block left behind the C1 row (c1_row +
+// DIR_BLOCK_FLOATS, + 2 DIR_BLOCK_FLOATS) and run only the rest.
 template <class CFG, int HOIST = 0>
 NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
                        const float *aux_in, int lane, float &sigma, float (&rgb)[3],
                        const float *c1_row = nullptr, float *pe = nullptr) {
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
-    constexpr int GS = HOIST == 2 ? pos_geo_steps(NGEO) : 0;   // k-steps of the position segments evaluated per ray
+    constexpr int GS = hoisted_geo_steps<CFG, HOIST>();        // k-steps of the position segments evaluated per ray
     using M = RecMap<CFG, HOIST>;
     const int h = lane >> 5;
     // The aux block in LDS never changes, so the optimiser would hoist every bias / head-weight
@@ -422,7 +425,7 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
     auto none = [](auto, auto) {};
 
     // ---- trunk layer 0: pos_map -> 256 (model.py:104-106) into set A; set B <- bias of layer 1
-    if constexpr (HOIST == 2) {
+    if constexpr (HOIST >= 2) {
         static_for<8>([&](auto T) { init_bias_tile_row<decltype(T)::value>(accA, c1_row + DIR_BLOCK_FLOATS + opaque_zero, h); });
     } else {
         init_bias<8>(accA, aux, 0, h);
@@ -452,7 +455,7 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
             constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
             if constexpr (init_next && mt == 1 && (s & 15) == 0) {
                 if constexpr (HOIST != 0 && CFG::CD != 0 && next_bias == 9) init_bias_tile_row<(s >> 4)>(prev, c1_row + opaque_zero, h);
-                else if constexpr (HOIST == 2 && next_bias == SKIP + 1) init_bias_tile_row<(s >> 4)>(prev, c1_row + 2 * DIR_BLOCK_FLOATS + opaque_zero, h);
+                else if constexpr (HOIST >= 2 && next_bias == SKIP + 1) init_bias_tile_row<(s >> 4)>(prev, c1_row + 2 * DIR_BLOCK_FLOATS + opaque_zero, h);
                 else init_bias_tile<(s >> 4)>(prev, aux, next_bias, h);
             }
         };
@@ -759,9 +762,9 @@ NTX_DEV void ray_rows(__amdgpu_buffer_rsrc_t rsrc, const float *aux, float *rows
 }
 
 // rows[slot] for slot = it * 4 + w  <->  hit number base + it * nwaves_total + 4 * workgroup + w.
-// GEO: also the rows of L0 and L5 (bias + the geometry-parameter block of their position segments), at rows +
-// DIR_BLOCK_FLOATS and rows + 2 DIR_BLOCK_FLOATS (render_kernel<CFG, 2>)
-template <class CFG, bool GEO = false>
+// GS > 0: also the rows of L0 and L5 (bias + the first GS k-steps of their position segments: geometry blocks), at rows +
+// DIR_BLOCK_FLOATS and rows + 2 DIR_BLOCK_FLOATS (render_kernel<CFG, 2 | 3>)
+template <class CFG, int GS = 0>   // GS: leading geometry k-steps of the position segments to evaluate too
 NTX_DEV void dir_block(const RenderArgs &a, __amdgpu_buffer_rsrc_t rsrc, const float *aux, float *rows, int base, int nwaves,
                        int wg, int wv, int lane, int n_work) {
     static_assert(CFG::CD != 0, "ParamNerf families");
@@ -783,8 +786,7 @@ NTX_DEV void dir_block(const RenderArgs &a, __amdgpu_buffer_rsrc_t rsrc, const f
         for (int k = 0; k < CFG::NP; ++k) in.par[k] = param_at<CFG>(a, prow, (CFG::IPE != 0 && k >= a.blur_idx) ? k + 1 : k);
         ray_rows<CFG::DS, CFG::rec_pass(9), 9>(rsrc, aux, rows, j, h, wv, lane,
                                                [&](auto S) { return dir_feature<CFG::NGEO, CFG::NAPP, decltype(S)::value>(in, h); });
-        if constexpr (GEO) {
-            constexpr int GS = pos_geo_steps(CFG::NGEO);
+        if constexpr (GS > 0) {
             auto geo = [&](auto S) { return pos_feature<CFG::NGEO, CFG::NAPP, CFG::IPE, decltype(S)::value>(in, h); };
             ray_rows<GS, 0, 0>(rsrc, aux, rows + DIR_BLOCK_FLOATS, j, h, wv, lane, geo);
             ray_rows<GS, CFG::rec_pass(SKIP + 1), SKIP + 1>(rsrc, aux, rows + 2 * DIR_BLOCK_FLOATS, j, h, wv, lane, geo);
@@ -801,13 +803,14 @@ NTX_DEV int xcd_major_workgroup(int wg, int n_wgs) {
     return (n_wgs % XCDS) ? wg : (wg % XCDS) * (n_wgs / XCDS) + wg / XCDS;
 }
 
-// HOIST: 0 = everything per sample; 1 = the direction segment of C1 per ray; 2 = also the geometry-parameter block of the
-// position segments of L0 and L5 (no blur_idx)
+// HOIST: 0 = everything per sample; 1 = the direction segment of C1 per ray; 2 = also the geometry-parameter blocks of the
+// position segments of L0 and L5 (no blur_idx); 3 = all of them but parameter 0's (blur_idx = 0)
 template <class CFG, int HOIST = 0>
 __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     static_assert(HOIST == 0 || CFG::CD != 0, "hoisting is for the ParamNerf families");
-    static_assert(HOIST != 2 || (CFG::IPE == 0 && CFG::NGEO > 0), "geometry hoisting: FourierFeatures families with geometry parameters");
-    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * pe_keep_floats<CFG>() + (HOIST == 2 ? 3 : HOIST) * DIR_BLOCK_FLOATS];
+    static_assert(HOIST < 2 || (CFG::IPE == 0 && CFG::NGEO > 0), "geometry hoisting: FourierFeatures families with geometry parameters");
+    static_assert(HOIST != 3 || CFG::NGEO >= 2, "HOIST 3 keeps parameter 0's block per sample and hoists the others");
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * pe_keep_floats<CFG>() + (HOIST >= 2 ? 3 : HOIST) * DIR_BLOCK_FLOATS];
     load_aux(aux, a.aux, aux_total());
     float *dir_rows = aux + aux_total() + 4 * pe_keep_floats<CFG>();
     const int lane = threadIdx.x & 63, j = lane & 31;
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     for (int base = 0; base < n_work; base += DIR_BLOCK_ITERS * nwaves) {
         if constexpr (HOIST != 0) {
             __syncthreads();   // every wave is done with the previous block's rows
-            dir_block<CFG, HOIST == 2>(a, ws.rsrc, aux, dir_rows, base, nwaves, vwg, wv, lane, n_work);
+            dir_block<CFG, hoisted_geo_steps<CFG, HOIST>()>(a, ws.rsrc, aux, dir_rows, base, nwaves, vwg, wv, lane, n_work);
             __syncthreads();
         }
       for (int it = 0; it < DIR_BLOCK_ITERS; ++it) {

@@ -48,15 +48,17 @@ NTX_HD constexpr int hidden_row(int s, int h) {
 // (mean, diagonal covariance): 6*POS_FREQ features [sin(y) e^(-var/2) (3L) | sin(y + pi/2) e^(-var/2) (3L)] with
 // y index f*3+c, NO identity block.
 NTX_HD constexpr int pos_emb_dim(int ipe) { return ipe ? 6 * POS_FREQ : 3 * (1 + 2 * POS_FREQ); }
-// k-steps of the position segment, GEOMETRY PARAMETERS FIRST (the order of the k-summation is free):
-//   geo identity  ceil(n_geo / 2) steps   pairs (g0, g1), zero pad
-//   geo sin/cos   n_geo * PAR_FREQ steps  {sin, cos}(2^f g)
+// k-steps of the position segment, GEOMETRY PARAMETERS FIRST (the order of the k-summation is free), one block of
+// GEO_BLOCK = 1 + PAR_FREQ steps per parameter, LAST parameter first:
+//   block b = parameter p = n_geo - 1 - b:   (g_p, pad), then {sin, cos}(2^f g_p), f = 0 .. PAR_FREQ-1
 //   pos identity  2 steps                 (x, y), (z, pad)            [IPE: none]
 //   pos sin/cos   3 * POS_FREQ steps      {sin, cos}(2^f x_c)         [IPE: damped by exp(-4^f var_c / 2)]
 // The geometry parameters are constant along a ray (renderer.py:154) unless blur_idx scales one per sample (:155-158), so
-// their block leads the segment: a kernel that evaluates it once per ray starts its accumulators from bias + that block
-// and runs only the position steps per sample -- same summation order, same bits (render_kernel<CFG, 2>).
-NTX_HD constexpr int pos_geo_steps(int n_geo) { return (n_geo + 1) / 2 + n_geo * PAR_FREQ; }
+// their blocks lead the segment: a kernel that evaluates a PREFIX of them once per ray starts its accumulators from bias +
+// those blocks and runs the rest per sample -- same summation order, same bits.  render_kernel<CFG, 2> hoists all of them
+// (no blur_idx); <CFG, 3> all but the block of parameter 0, which therefore comes last (blur_idx = 0: grass_filtered).
+constexpr int GEO_BLOCK = 1 + PAR_FREQ;
+NTX_HD constexpr int pos_geo_steps(int n_geo) { return n_geo * GEO_BLOCK; }
 NTX_HD constexpr int pos_steps(int n_geo, int ipe = 0) { return pos_geo_steps(n_geo) + (ipe ? 0 : 2) + 3 * POS_FREQ; }
 NTX_HD constexpr int pos_map_dim(int n_geo, int ipe = 0) { return pos_emb_dim(ipe) + n_geo * (1 + 2 * PAR_FREQ); }
 
@@ -64,17 +66,14 @@ NTX_HD constexpr int pos_map_dim(int n_geo, int ipe = 0) { return pos_emb_dim(ip
 // with FEWER geometry parameters (n_act < n_geo, the generic family) leaves the steps of the missing ones as zero rows.
 NTX_HD constexpr int pos_row(int n_geo, int s, int h, int ipe = 0, int n_act = -1) {
     if (n_act < 0) n_act = n_geo;
-    const int base = pos_emb_dim(ipe), ngid = (n_geo + 1) / 2;
-    if (s < ngid) {
-        const int v = 2 * s + h;
-        return v < n_act ? base + v : -1;
+    const int base = pos_emb_dim(ipe);
+    if (s < pos_geo_steps(n_geo)) {
+        const int p = n_geo - 1 - s / GEO_BLOCK, j = s % GEO_BLOCK;
+        if (p >= n_act) return -1;
+        if (j == 0) return h == 0 ? base + p : -1;
+        return base + n_act + 2 * (j - 1) * n_act + h * n_act + p;
     }
-    int q = s - ngid;
-    if (q < n_geo * PAR_FREQ) {
-        const int f = q / n_geo, g = q % n_geo;
-        return g < n_act ? base + n_act + 2 * f * n_act + h * n_act + g : -1;
-    }
-    q -= n_geo * PAR_FREQ;
+    int q = s - pos_geo_steps(n_geo);
     if (!ipe) {
         if (q < 2) {
             const int v = 2 * q + h;

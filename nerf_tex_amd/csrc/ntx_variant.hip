@@ -32,10 +32,15 @@ using VCfg = Cfg<GEN_NGEO, GEN_NAPP, 1, 0, 1>;   // generic: any ParamNerf n_par
 
 #ifdef NTX_HOIST
 // further translation units of the family: -DNTX_HOIST=1 the render kernel with the direction segment hoisted per ray,
-// -DNTX_HOIST=2 with the geometry-parameter block of the position segments hoisted as well
+// -DNTX_HOIST=2 with the geometry-parameter blocks of the position segments hoisted as well, =3 all but parameter 0's
 #if NTX_HOIST == 2
 hipError_t NTX_FN(launch_render_hoist2)(int n_wgs, RenderArgs &a, hipStream_t st) {
     render_kernel<VCfg, 2><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
+    return hipGetLastError();
+}
+#elif NTX_HOIST == 3
+hipError_t NTX_FN(launch_render_hoist3)(int n_wgs, RenderArgs &a, hipStream_t st) {
+    render_kernel<VCfg, 3><<<dim3(n_wgs), dim3(256), 0, st>>>(a);
     return hipGetLastError();
 }
 #else
