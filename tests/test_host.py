@@ -377,3 +377,25 @@ def test_main_entry_point_prepares_reference_configs():
         vol = m.prepare(raw, volumetric=True)
         assert vol.renderer_config.module == "nerf_tex_amd.renderer.Renderer" and "instancer_config" not in vol.renderer_config
         assert m.prepare(raw).renderer_config.module == "nerf_tex_amd.renderer.InstanceRenderer"
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/nerftex.h is a C99 header (no C++ / torch types) and a C program links against libnerftex_hip.so: the drop-in
+    boundary is a C ABI, ctypes is only one of its clients."""
+    import shutil
+    import subprocess
+    from nerf_tex_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "nerftex.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    ntx_model_desc d = {NTX_MODEL_PARAMNERF, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, NTX_POS_FOURIER};\n'
+                   '    printf("%d %zu %lld\\n", ntx_abi_version(), ntx_weight_count(&d), (long long)ntx_shard_count(640000, 800, 8, 3));\n'
+                   '    return ntx_abi_version() == NTX_ABI_VERSION ? 0 : 1;\n}\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["2", "683524", "80000"]
