@@ -23,7 +23,16 @@ Workloads
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel: algorithmic FLOPs = 2 * MACs(model) per
 ray-sample / average launch duration measured with HIP events on the launch stream.
 `cpu_baseline` times the torch-CPU float32 restatement in oracle/ on a bounded sample of the same workload on this
-host's cores (rank 0, N = 1 only).
+host's cores (rank 0, N = 1 only).  `parity` is the second half of the metric: rel-Linf of 256 seeded rays of the image the
+timed region just produced against the float64 and float32 restatements (oracle/, the checker).  `with_ray_setup` repeats the
+step with ray generation (`ntx_generate_rays`) inside the timed loop ("with and without ray setup").
+N > 1 adds `per_rank` (kernel / gather time, rays, hits of every rank), `gather_bytes`, `imbalance` and an efficiency figure
+against rank 0 re-timed alone after the barrier.
+
+A multi-rank run is BOUNDED: the self-launcher polls its ranks, ends the others as soon as one fails, enforces an overall
+deadline (`--deadline`, default 600 s) and keeps every rank's stderr in `logs/rank<r>.err` (tail echoed on failure); under an
+external launcher every rank arms a watchdog that dumps its stacks and exits after the same deadline, so a rank stuck in a
+collective cannot hold the node.
 """
 
 from __future__ import annotations
@@ -112,8 +121,12 @@ def bench_instanced(args) -> None:
     """`--workload carpet_instanced`: the InstanceRenderer tail (what config_carpet_render.py runs) on one
     render chunk of synthetic instancer output resident in HBM: 16 384 rays x 1024 marching samples
     (config_carpet_render.py:78-79), 1/8 of them inside a patch (dists > 0) in runs of 16, i.e. ~128 network
-    evaluations per ray after the in-kernel compaction.  value = in-patch ray-samples/s; N = 1 only (the patch instancer
-    that feeds this path is CPU code outside the hot path)."""
+    evaluations per ray after the in-kernel compaction.  As the reference's instancer fills its buffers
+    (instancer/src/instancer.cpp:889-960), the direction in the patch frame, the light direction and the other appearance
+    parameters are constant along a run (one patch instance: getDir(ray, instance)), while the position and the texture-mapped
+    geometry parameter change from sample to sample (`--instanced-per-sample-dirs`: the round-2 workload, every sample its own
+    direction and parameters).  value = in-patch ray-samples/s; N = 1 only (the patch instancer that feeds this path is CPU
+    code outside the hot path)."""
     import torch
     from nerf_tex_amd import _lib, synthetic
     from nerf_tex_amd.model import ParamNerf
@@ -128,7 +141,8 @@ def bench_instanced(args) -> None:
     n, S, P = int(os.environ.get("NTX_INSTANCED_RAYS", "16384")), 1024, model.n_params   # (the env knob is for scaling experiments)
     g = torch.Generator(device=dev); g.manual_seed(0)
     u = lambda *shape: torch.rand(*shape, device=dev, generator=g)
-    rays_d_map = torch.nn.functional.normalize(u(n, S, 3) - 0.5, dim=-1).contiguous()
+    per_run = (lambda *tail: u(n, S // 16, *tail).repeat_interleave(16, dim=1)) if not args.instanced_per_sample_dirs else (lambda *tail: u(n, S, *tail))
+    rays_d_map = torch.nn.functional.normalize(per_run(3) - 0.5, dim=-1).contiguous()
     pts = (u(n, S, 3) * 2.4 - 1.2).contiguous()
     t = torch.sort(u(n, S) * 6 + 2, dim=-1).values.contiguous()
     inside = (u(n, S // 16) < 0.125).repeat_interleave(16, dim=1)              # runs of 16 marching steps inside a patch
@@ -137,7 +151,11 @@ def bench_instanced(args) -> None:
     alpha_weight = (1.0 / torch.randint(1, 4, (n, S), device=dev, generator=g)).float().contiguous()
     instance_id = torch.randint(0, 7, (n, S), device=dev, generator=g, dtype=torch.int32).contiguous()
     hit = torch.ones(n, device=dev, dtype=torch.uint8)
-    params_map = (torch.as_tensor(fam["params"], device=dev, dtype=torch.float32)[None, None, :] * (u(n, S, 1) * 0.5 + 0.5)).contiguous()
+    params_map = torch.as_tensor(fam["params"], device=dev, dtype=torch.float32)[None, None, :].repeat(n, S, 1)
+    g_ = fam["n_parameters"][0]
+    params_map[..., :g_] *= u(n, S, 1) * 0.5 + 0.5                 # geometry (fibre length: texture-mapped, instancer.cpp:913-918): per sample
+    params_map[..., g_:] *= per_run(1) * 0.5 + 0.5                 # appearance (colour, light direction in the patch frame): per run
+    params_map = params_map.contiguous()
     cone = (u(n) * 4e-3 + 1e-3).contiguous()
     color = torch.empty((n, 3), device=dev); alpha = torch.empty((n,), device=dev)
     n_in = int(inside.sum().item())
@@ -148,7 +166,7 @@ def bench_instanced(args) -> None:
         _lib.check(_lib.lib.ntx_render_instanced(
             model.ctx(0), rays_d_map.data_ptr(), pts.data_ptr(), t.data_ptr(), dists.data_ptr(), color_last.data_ptr(),
             alpha_last.data_ptr(), alpha_weight.data_ptr(), instance_id.data_ptr(), hit.data_ptr(), params_map.data_ptr(),
-            cone.data_ptr(), n, S, -1, 0.09, 400.0, flags, _lib.f3([1, 1, 1.]), None, color.data_ptr(), alpha.data_ptr(), None, stream))
+            cone.data_ptr(), n, S, -1, 0.09, 400.0, flags, _lib.f3([1, 1, 1.]), None, None, color.data_ptr(), alpha.data_ptr(), None, stream))
 
     for _ in range(args.warmup):
         step()
@@ -170,7 +188,10 @@ def bench_instanced(args) -> None:
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "float32" else "fp16x3 (f32 accumulate)", "data": "synthetic",
         "config": {"workload": f"carpet_instanced: one render chunk of {n} rays x {S} marching samples of synthetic instancer "
-                               f"output (config_carpet_render.py:78-98), {n_in} in-patch samples ({n_in / n:.1f} per ray, runs of 16), "
+                               f"output (config_carpet_render.py:78-98), {n_in} in-patch samples ({n_in / n:.1f} per ray, runs of 16; "
+                               + ("direction / appearance parameters per SAMPLE" if args.instanced_per_sample_dirs else
+                                  "direction / appearance parameters per run = per patch instance, geometry parameter and position per sample, as instancer.cpp:889-960 fills them")
+                               + f"), "
                                f"ParamNerf n_parameters={list(fam['n_parameters'])}, buffers resident in HBM",
                    "rays": n, "marching_samples_per_ray": S, "in_patch_samples": n_in, "flops_per_sample": flops_per_sample},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -181,21 +202,109 @@ def bench_instanced(args) -> None:
                      "kernel_ms": kernel_ms}}), flush=True)
 
 
+def launch_ranks(cmds, envs, deadline_s: float, log_dir: str, poll_s: float = 0.2, label: str = "bench.py") -> int:
+    """Start one process per rank (own session each, so a rank's children die with it), rank 0's stdout passed through, every
+    rank's stderr in `log_dir/rank<r>.err`.  Poll them: the first non-zero exit ends the others (SIGTERM, SIGKILL after 5 s); so
+    does the deadline (exit code 124).  On failure the tail of every rank's log is echoed, labelled.  Returns the exit code."""
+    import signal
+    os.makedirs(log_dir, exist_ok=True)
+    procs, logs = [], []
+    for r, (cmd, env) in enumerate(zip(cmds, envs)):
+        f = open(os.path.join(log_dir, f"rank{r}.err"), "wb")
+        logs.append(f)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL, stderr=f, start_new_session=True))
+
+    def end_all():
+        for sig, grace in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+            alive = [p for p in procs if p.poll() is None]
+            if not alive:
+                return
+            for p in alive:
+                try:
+                    os.killpg(p.pid, sig)                    # exactly the sessions started above
+                except (ProcessLookupError, PermissionError):
+                    pass
+            t_end = time.monotonic() + grace
+            while time.monotonic() < t_end and any(p.poll() is None for p in alive):
+                time.sleep(0.05)
+
+    t0 = time.monotonic()
+    rc, why = 0, None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if failed:
+                r, c = failed[0]
+                rc, why = (abs(c) if abs(c) < 256 else 1) or 1, f"rank {r} exited with {c}; ending the other ranks"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() - t0 > deadline_s:
+                rc, why = 124, f"deadline of {deadline_s:.0f} s exceeded; ending all ranks"
+                break
+            time.sleep(poll_s)
+    finally:
+        end_all()
+        for f in logs:
+            f.close()
+    if rc != 0:
+        print(f"{label}: {why}", file=sys.stderr)
+        for r in range(len(procs)):
+            try:
+                with open(os.path.join(log_dir, f"rank{r}.err"), "rb") as f:
+                    tail = f.read()[-3000:].decode("utf-8", "replace")
+            except OSError:
+                tail = ""
+            for line in tail.splitlines()[-25:]:
+                print(f"[rank {r}] {line}", file=sys.stderr)
+    return rc
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU, and pass rank 0's
-    JSON line through.  Exit code = the worst of the ranks'."""
+    JSON line through (launch_ranks: bounded, siblings ended on the first failure, per-rank logs)."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
+    cmds, envs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+        cmds.append([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]); envs.append(env)
+    return launch_ranks(cmds, envs, args.deadline, os.path.join(ROOT, "logs"))
+
+
+def parity_block(renderer, model, family, batch, rgba, S, n_check=256, seed=7):
+    """The second half of BASELINE.json's metric.  `n_check` seeded rays of the batch the timed region rendered, recomputed by the
+    float64 ("truth") and float32 ("what TF-CPU float32 computes, up to summation order") restatements of renderer.py:47-213
+    in oracle/ -- the checker, here and nowhere in the timed path -- and compared with the image the GPU produced:
+    rel-Linf = max|out - ref| / max|ref| over [color_pred, alpha_pred] of those rays."""
+    import torch
+    from oracle import nerftex_oracle as orc
+    from nerf_tex_amd import synthetic
+    fam = synthetic.FAMILIES[family]
+    spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(fam["n_parameters"]))
+    w = orc.split_blob(spec, model.get_blob())
+    n = batch["rays_o"].shape[1]
+    idx = np.sort(np.random.default_rng(seed).choice(n, size=min(n_check, n), replace=False))
+    ti = torch.as_tensor(idx, device=rgba.device)
+    g = lambda k: batch[k][0][ti].double().cpu().numpy()
+    ro, rd, t, cone = g("rays_o"), g("rays_d"), g("t"), g("cone_scale").reshape(len(idx), 1)
+    params = batch["parameters"].double().cpu().numpy()
+    got = rgba[ti].double().cpu().numpy()
+    out = {"rays": int(len(idx)), "what": "rel-Linf over [color_pred, alpha_pred] of seeded rays of the timed image vs the numpy "
+           "restatement of renderer.py:47-213 (oracle/nerftex_oracle.py; float64 = truth, float32 = the reference's arithmetic up "
+           "to summation order); TensorFlow itself cannot run here: parity is pinned to the restatement, not to a TF run",
+           "tolerance": 1e-4}
+    t0 = time.perf_counter()
+    for name, dt in (("rel_linf_f64", np.float64), ("rel_linf_f32", np.float32)):
+        ref = orc.renderer_call(w, spec, ro[None].astype(dt), rd[None].astype(dt), t[None].astype(dt), params.astype(dt), cone[None].astype(dt),
+                                S, blur_idx=fam["blur_idx"], dtype=dt)
+        want = np.concatenate([ref["color_pred"][0], ref["alpha_pred"][0][:, None]], -1).astype(np.float64)
+        out[name] = float(orc.rel_linf(got, want))
+    out["oracle_seconds"] = round(time.perf_counter() - t0, 2)
+    out["ok"] = bool(out["rel_linf_f32"] <= 1e-4)
+    return out
 
 
 def main() -> None:
@@ -210,6 +319,11 @@ def main() -> None:
     ap.add_argument("--perturb", action="store_true", help="stratified jitter of the depths inside the kernel (the reference's default perturb=True)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp16x3 / perturb second figures (profiling runs: one kernel flavour per process)")
     ap.add_argument("--shard", default="rows", choices=["rows", "bands"], help="sharded workloads: pixel rows round-robin, or contiguous bands")
+    ap.add_argument("--deadline", type=float, default=float(os.environ.get("NTX_BENCH_DEADLINE", "600")),
+                    help="multi-rank runs: seconds after which the launcher ends all ranks / every rank's watchdog exits")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of 256 rays after the timed region")
+    ap.add_argument("--instanced-per-sample-dirs", action="store_true",
+                    help="carpet_instanced: every marching sample its own direction and appearance parameters (the round-2 workload) instead of one per run")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -241,10 +355,15 @@ def main() -> None:
     dev = torch.device("cuda", local_rank)
     comm, gather_how = None, None
     if world > 1:
+        # a rank stuck in a collective (a peer died, ncclCommInitRank never completes ...) must not hold the node: after the
+        # deadline this rank dumps its stacks to stderr and exits, whatever the main thread is blocked in
+        import faulthandler
+        faulthandler.dump_traceback_later(args.deadline, exit=True)
         dist.init_process_group("nccl", device_id=dev)       # nccl backend == RCCL on ROCm: barrier + max-over-ranks timing
-        # the data path's own communicator, behind the C ABI.  All ranks must agree on the route: if ntx_comm_create fails
-        # anywhere (it has only ever run with one rank, this environment has no multi-GPU box), every rank falls back to
-        # torch.distributed.gather on the same RCCL, and the line says so.
+        # the data path's own communicator, behind the C ABI.  Comm() agrees among the ranks BEFORE anyone enters
+        # ncclCommInitRank and raises on every rank alike (dist.CommUnavailable) when one of them cannot go ahead; an error out
+        # of ncclCommInitRank itself is agreed on below.  Either way every rank falls back to the same exchange through
+        # torch.distributed on the same RCCL, and the line says so.
         err = None
         try:
             comm = Comm(local_rank)
@@ -256,10 +375,10 @@ def main() -> None:
             if comm is not None:
                 comm.close()
             comm = None
-            gather_how = "torch.distributed.gather (fallback: ntx_comm_create failed on some rank" + (f"; here: {err})" if err else ")")
+            gather_how = "torch.distributed gather/send/recv of the same plan (fallback: no ntx_comm on some rank" + (f"; here: {err})" if err else ")")
             print("bench.py: " + gather_how, file=sys.stderr)
         else:
-            gather_how = "ntx_gather_image (RCCL ncclGather through the C ABI)"
+            gather_how = f"ntx_gather_image (RCCL through the C ABI, {comm.library})"
 
     sharded = args.workload in SHARDED
     family, H, W, S, cfg_idx = (SHARDED if sharded else WORKLOADS)[args.workload]
@@ -281,7 +400,8 @@ def main() -> None:
         focal = W / np.tan(fam["angle"] / 2) / 2                                  # dataset.py:229
         sampler = Proxy(H, W, focal, AABB(fam["b_0"], fam["b_1"]))
         ro, rd, t, cone = sampler(Full(H, W, shard=(shard_map, r))(), look_at(fam["cam"]), device=dev)
-        return dict(rays_o=ro[None], rays_d=rd[None], t=t[None], cone_scale=cone[None], parameters=params)
+        # ray_index: jitter / noise are keyed by the PIXEL, so the sharded image equals the 1-GPU image also under --perturb
+        return dict(rays_o=ro[None], rays_d=rd[None], t=t[None], cone_scale=cone[None], parameters=params, ray_index=shard_map.ray_index(r))
 
     if sharded:
         shard = ShardMap(H * W, world, W if args.shard == "rows" else None)
@@ -293,21 +413,23 @@ def main() -> None:
         shard = ShardMap(n_rays * world, world)                  # every rank's own band of an (H * world) x W image
         ro, rd, t, cone = synthetic.all_hit_rays(n_rays, fam["b_0"], fam["b_1"], fam["cam"], seed=1 + rank)
         d = lambda a: torch.as_tensor(a, device=dev)[None]
-        batch = dict(rays_o=d(ro), rays_d=d(rd), t=d(t), cone_scale=d(cone), parameters=params)
+        batch = dict(rays_o=d(ro), rays_d=d(rd), t=d(t), cone_scale=d(cone), parameters=params, ray_index=shard.ray_index(rank))
         n_hit = n_rays
 
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    mkev = lambda: [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev0, ev1, ev2 = mkev(), mkev(), mkev()
 
-    def step(i=None, r=renderer, b=batch):
+    def step(i=None, r=renderer, b=batch, gather=True):
         if i is not None:
             ev0[i].record()
-        out = r(**b, seed=1234 + rank)
+        out = r(**b, seed=1234)                              # one seed for the image; the ray index map tells the shards apart
         if i is not None:
             ev1[i].record()                                  # same stream the kernel was launched on
         rgba = torch.cat([out["color_pred"][0], out["alpha_pred"][0][:, None]], -1)
-        if world > 1:
-            return gather_image(rgba, shard, comm=comm)      # the one collective: RGBA -> rank 0 (ntx_gather_image)
+        if world > 1 and gather:
+            rgba = gather_image(rgba, shard, comm=comm)      # the one collective: RGBA -> rank 0 (ntx_gather_image)
+        if i is not None:
+            ev2[i].record()
         return rgba
 
     for _ in range(args.warmup):
@@ -323,20 +445,42 @@ def main() -> None:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     hits_total = n_hit
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev1, ev2)]))   # torch.cat + the gather (+ un-shard on the root)
+    per_rank = None
     if world > 1:
         tt = torch.tensor([elapsed, float(n_hit)], device=dev, dtype=torch.float64)
         mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, hits_total = float(mx[0].item()), int(sm[1].item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+        mine = torch.tensor([kernel_ms, gather_ms, float(n_rays), float(n_hit)], device=dev, dtype=torch.float64)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r, "kernel_ms": float(v[0]), "gather_ms": float(v[1]), "rays": int(v[2]), "hits": int(v[3])} for r, v in enumerate(every)]
+
+    # rank 0 re-times its own shard ALONE (no gather, the other ranks wait at the barrier below): what one GPU takes for the same
+    # rays when its 7 neighbours are idle -- the reference point of the efficiency figure in the line
+    alone_ms = None
+    if world > 1 and rank == 0:
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        step(gather=False); torch.cuda.synchronize()
+        a0.record()
+        for _ in range(args.steps):
+            step(gather=False)
+        a1.record(); torch.cuda.synchronize()
+        alone_ms = a0.elapsed_time(a1) / args.steps
 
     # sharded image vs the same image rendered by ONE GPU (rank 0 alone, outside the timed region): bit-identical?
-    identical = None
+    identical, whole_ms = None, None
     if sharded and world > 1 and rank == 0:
         whole = camera_rays(ShardMap(H * W, 1), 0)
+        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0.record()
         o1 = renderer(**whole, seed=1234)
+        w1.record(); torch.cuda.synchronize()
+        whole_ms = w0.elapsed_time(w1)                       # the whole image on ONE GPU: the strong-scaling reference
         ref = torch.cat([o1["color_pred"][0], o1["alpha_pred"][0][:, None]], -1)
-        identical = bool(torch.equal(ref, img)) if not args.perturb else None   # the jitter stream is per call and rank
+        identical = bool(torch.equal(ref, img))              # also under --perturb: the generators are keyed by the pixel
 
     # second figures on the same inputs, outside the timed region (rank 0, N = 1), clearly labelled, never `value`:
     # the opt-in fp16x3 precision, and the reference's default perturb=True (stratified jitter inside the kernel)
@@ -365,6 +509,44 @@ def main() -> None:
         jit = {"what": "perturb=True (renderer.py:106-111, the reference's default): stratified jitter drawn inside the kernel "
                        "(Philox4x32-10 per depth), no [N,S] depth tensor", "value": n_hit * S / (ms3 * 1e-3),
                "unit": "ray-samples/s", "kernel_ms": ms3}
+
+    # SURVEY 8d "both with and without ray setup": the same step with ray generation inside the timed loop (rank 0; for the
+    # all-hit workloads the generated camera grid is the config's own camera and is NOT what is rendered -- the rendered rays are
+    # the synthetic all-hit set -- so this prices ntx_generate_rays next to the render, nothing else)
+    setup = None
+    if rank == 0 and not args.no_extras:
+        from nerf_tex_amd.dataset import look_at
+        from nerf_tex_amd.pixel_sampler import Full
+        from nerf_tex_amd.proxy import AABB
+        from nerf_tex_amd.ray_sampler import Proxy
+        focal = W / np.tan(fam["angle"] / 2) / 2
+        sampler = Proxy(H, W, focal, AABB(fam["b_0"], fam["b_1"]))
+        c2w = look_at(fam["cam"])
+        pix = Full(H, W, shard=(shard, rank))() if sharded else Full(H, W)()
+
+        def step_with_setup():
+            ro, rd, tt_, cone_ = sampler(pix, c2w, device=dev)
+            b2 = dict(batch, rays_o=ro[None], rays_d=rd[None], t=tt_[None], cone_scale=cone_[None]) if sharded else batch
+            return renderer(**b2, seed=1234)
+
+        step_with_setup(); torch.cuda.synchronize()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for _ in range(args.steps):
+            step_with_setup()
+        s1.record(); torch.cuda.synchronize()
+        ms_setup = s0.elapsed_time(s1) / args.steps
+        setup = {"value": n_hit * S / (ms_setup * 1e-3), "unit": "ray-samples/s", "ms": ms_setup, "ms_without": kernel_ms,
+                 "what": (f"this rank's step with its rays regenerated on the device every step: ntx_generate_rays_strided ({pix[1]} pixels of the "
+                          f"{H}x{W} camera grid: pixel_sampler.Full + rays_from_camera + Proxy/AABB, ray_sampler.py:32-48) + the render of those rays"
+                          if sharded else
+                          f"ntx_generate_rays of the {H}x{W} grid of the config's camera (pixel_sampler.Full + rays_from_camera + Proxy/AABB, "
+                          f"ray_sampler.py:32-48) + the render of the workload's all-hit rays, per step")}
+
+    parity = None
+    if rank == 0 and not args.no_parity:
+        local = step(gather=False)                           # this rank's own rays as the timed region rendered them
+        parity = parity_block(renderer, model, family, batch, local, S) if not args.perturb else None
 
     if rank == 0:
         flops_per_sample = 2 * model.macs_per_sample()
@@ -399,8 +581,26 @@ def main() -> None:
                          "kernel": "ntx::render_kernel" if args.precision == "float32" else "ntx::render_kernel_x3",
                          "kernel_ms": kernel_ms},
         }
+        if per_rank is not None:
+            kms = [p_["kernel_ms"] for p_ in per_rank]
+            line["per_rank"] = per_rank
+            line["gather_bytes"] = int(sum(p_["rays"] for p_ in per_rank[1:]) * 16)      # RGBA float32 of every peer -> rank 0
+            line["gather_how"] = gather_how
+            line["imbalance"] = max(kms) / (sum(kms) / len(kms))                          # max / mean kernel_ms over the ranks
+            line["rank0_alone_ms"] = alone_ms
+            if sharded:
+                # strong scaling: one GPU's time for the whole image / (N x the job's time per step)
+                line["whole_image_1gpu_ms"] = whole_ms
+                line["efficiency_vs_1gpu"] = whole_ms / (world * elapsed / args.steps * 1e3) if whole_ms else None
+            else:
+                # weak scaling: every rank has rank 0's work; ideal = the job takes what rank 0 takes alone
+                line["efficiency_vs_rank0_alone"] = alone_ms / (elapsed / args.steps * 1e3)
         if identical is not None:
             line["sharded_image_bit_identical_to_1gpu"] = identical
+        if parity is not None:
+            line["parity"] = parity
+        if setup is not None:
+            line["with_ray_setup"] = setup
         if alt is not None:
             line["fp16x3"] = alt
         if jit is not None:

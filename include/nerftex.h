@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NTX_ABI_VERSION 2
+#define NTX_ABI_VERSION 3
 
 typedef struct ntx_ctx ntx_ctx;
 typedef void *ntx_stream; /* hipStream_t */
@@ -73,6 +73,28 @@ typedef struct ntx_model_desc {
 #define NTX_FLAG_CHECK_NUMERICS 4u  /* renderer.py:140-141: set *status_flag |= 1 on NaN/Inf outputs */
 #define NTX_FLAG_FP16X3 8u          /* this call uses NTX_PRECISION_FP16X3 (below) instead of float32 Dense layers */
 #define NTX_FLAG_PERTURB 16u        /* ntx_render_rays: stratified jitter of the sample depths (renderer.py:106-111), see there */
+#define NTX_FLAG_RAW_NOISE 32u      /* ABI v3: sigma += N(0, raw_noise_std) per sample before the relu (renderer.py:190-192, 335-337); ntx_render_opts */
+
+/* ABI v3: optional extras of ntx_render_rays / ntx_render_instanced / ntx_sample_depths / ntx_sample_pdf (HOST struct, read during
+ * the call; NULL = all defaults).  `size` = sizeof(ntx_render_opts) of the caller's header, so that later versions can append.
+ *   raw_noise_std  with NTX_FLAG_RAW_NOISE: the density regulariser of map_model_output (renderer.py:190-192; InstanceRenderer
+ *                  :335-337).  The draw for (ray, sample) is the first output of tf.random.normal's Box-Muller transform
+ *                  (u1 clamped to 1e-7; sqrt(-2 ln u1) sin(2 pi u2)) of words 0 and 1 of Philox4x32-10 at counter
+ *                  (sample index, ray index lo, ray index hi, 1) under the call's seed: a pure function of (seed, ray, sample) like
+ *                  the jitter (whose counter ends in 0).  TensorFlow's own stream cannot be reproduced; the distribution is the same.
+ *   noise_seed     the seed of ntx_render_instanced, which has no perturb_seed (the others key the noise with perturb_seed).
+ *   ray_index0, ray_run_length, ray_run_stride
+ *                  the index that keys both generators: local ray k of the call counts as ray
+ *                      ray_index0 + (k / ray_run_length) * ray_run_stride + k % ray_run_length
+ *                  -- the pixel-set arithmetic of ntx_generate_rays_strided.  All zero = k itself.  A caller that renders an
+ *                  image in chunks passes the chunk's first ray as ray_index0; rank r of a shard map passes its pixel set
+ *                  (r * run_length, run_length, n_ranks * run_length): the image then does not depend on how it was split. */
+typedef struct ntx_render_opts {
+    uint32_t size;
+    float raw_noise_std;
+    uint64_t noise_seed;
+    int64_t ray_index0, ray_run_length, ray_run_stride;
+} ntx_render_opts;
 
 /* Arithmetic of the Dense layers inside ntx_render_rays, ntx_render_instanced and ntx_mlp_forward (everything else -- encoders, heads,
  * compositing -- is float32 either way).  The reference computes in float32 (TensorFlow's default dtype, model.py:104-123):
@@ -157,20 +179,22 @@ int ntx_composite(const float *color, const float *sigma, const float *z_vals, c
  * NTX_FLAG_PERTURB the stratified jitter z = lower + (upper - lower) * u of :106-111, u in [0,1) drawn by a counter-based
  * generator: word 0 of Philox4x32-10 at counter (sample index, ray index lo, ray index hi, 0) under the key
  * (perturb_seed lo, hi), low 23 bits as the float32 mantissa (tf.random.uniform's conversion).  The draw depends only on
- * (perturb_seed, index of the ray WITHIN THE CALL, sample index): give every call (and every rank) its own seed.
+ * (perturb_seed, ray index, sample index); the ray index is the index within the call unless `opts` maps it to a global one
+ * (ntx_render_opts: chunks and shards of one image then draw what the whole image draws under one seed).
  * TensorFlow's own stream (its global generator) cannot be reproduced; the distribution is the same.  ntx_render_rays
  * places its samples with exactly this function. */
-int ntx_sample_depths(const float *t, int64_t n_rays, int n_points, uint32_t flags, uint64_t perturb_seed, float *z_out,
-                      ntx_stream stream);
+int ntx_sample_depths(const float *t, int64_t n_rays, int n_points, uint32_t flags, uint64_t perturb_seed,
+                      const ntx_render_opts *opts /* ray index map; may be NULL */, float *z_out, ntx_stream stream);
 
 /* Replaces Renderer.__call__ + render_rays + evaluate_model + map_model_output
- * (renderer.py:47-213) with raw_noise_std=0 / n_importance=0, fused in one launch:
+ * (renderer.py:47-213) with n_importance=0, fused in one launch:
  * culling of t==inf rays, sample placement, positional encoding, the MLP and the composite.
  *   rays_o[N,3], rays_d[N,3], t[N,2], cone_scale[N] (DEVICE)
  *   params[n_param_rows, P] (DEVICE): ray r uses row r / rays_per_param_row (the reference's
  *       tf.repeat(parameters, HW), renderer.py:54); rays_per_param_row = 1 gives per-ray parameters
  *   blur_idx: -1 = off, else params[blur_idx] *= cone_scale * z per sample (renderer.py:155-158)
- *   flags: NTX_FLAG_MAP_EXR | NTX_FLAG_COMPOSITE_BKGD | NTX_FLAG_CHECK_NUMERICS | NTX_FLAG_FP16X3 | NTX_FLAG_PERTURB
+ *   flags: NTX_FLAG_MAP_EXR | NTX_FLAG_COMPOSITE_BKGD | NTX_FLAG_CHECK_NUMERICS | NTX_FLAG_FP16X3 | NTX_FLAG_PERTURB | NTX_FLAG_RAW_NOISE
+ *   opts: NULL, or HOST ntx_render_opts: raw_noise_std (with NTX_FLAG_RAW_NOISE, keyed by perturb_seed) and the global ray index map
  *   z_vals: NULL, or DEVICE [N,S] sample depths replacing renderer.py:101-111 altogether (wins over NTX_FLAG_PERTURB)
  *   perturb_seed: key of the jitter under NTX_FLAG_PERTURB (renderer.py:106-111, the reference's default; see
  *       ntx_sample_depths), evaluated inside the kernel: no [N,S] tensor exists
@@ -187,17 +211,18 @@ int ntx_sample_depths(const float *t, int64_t n_rays, int n_points, uint32_t fla
 int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, const float *t,
                     const float *params, int64_t rays_per_param_row, const float *cone_scale,
                     int64_t n_rays, int n_samples, int blur_idx, uint32_t flags, const float *bkgd,
-                    const float *z_vals, uint64_t perturb_seed, float *color_out, float *alpha_out,
-                    float *weights_out, int32_t *status_flag, ntx_stream stream);
+                    const float *z_vals, uint64_t perturb_seed, const ntx_render_opts *opts, float *color_out,
+                    float *alpha_out, float *weights_out, int32_t *status_flag, ntx_stream stream);
 
 /* Replaces the importance-sampling step of Renderer.render_rays (renderer.py:125-130) incl. sample_pdf
  * (renderer.py:589-617): bins = midpoints of the coarse depths, pdf = weights[:,1:-1] + 1e-5, n_importance
  * depths by inverse CDF at u (NULL = tf.linspace(0,1,n_importance), the `det` branch; else DEVICE [N,n_imp]
  * uniform draws), merged with the coarse depths and sorted -> z_out[N, S + n_importance] (DEVICE).
  * The coarse depths are z_vals[N,S], or (NULL) recomputed from t exactly as ntx_render_rays places them under the same
- * `flags` (NTX_FLAG_PERTURB or 0) and `perturb_seed`. */
+ * `flags` (NTX_FLAG_PERTURB or 0), `perturb_seed` and ray index map. */
 int ntx_sample_pdf(const float *t, const float *z_vals, const float *weights, const float *u, int64_t n_rays,
-                   int n_samples, int n_importance, uint32_t flags, uint64_t perturb_seed, float *z_out, ntx_stream stream);
+                   int n_samples, int n_importance, uint32_t flags, uint64_t perturb_seed,
+                   const ntx_render_opts *opts /* ray index map; may be NULL */, float *z_out, ntx_stream stream);
 
 /* Replaces InstanceRenderer.evaluate_model + map_model_output (renderer.py:247-354) DOWNSTREAM of the
  * instancer: the arguments are the buffers instancer.get_model_input returns (instancer.pyx:38-54), on the
@@ -208,14 +233,15 @@ int ntx_sample_pdf(const float *t, const float *z_vals, const float *weights, co
  * one extra sample (color_last as is, alpha_last as an alpha) closes every ray (:331,339).
  * instance_color[n_instances,3] != NULL = the false-colour mode (:306-307).  Rays with hit == 0 get 0, also
  * under NTX_FLAG_COMPOSITE_BKGD (:313-314).  1 <= n_samples <= 4096.  flags: as ntx_render_rays without NTX_FLAG_PERTURB
- * (the instancer places the samples). */
+ * (the instancer places the samples).  opts: NULL, or raw_noise_std + noise_seed (NTX_FLAG_RAW_NOISE, added to the scaled
+ * density of the in-patch samples: at dists == 0 the reference's draw has no effect either) and the ray index map. */
 int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts, const float *t,
                          const float *dists, const float *color_last, const float *alpha_last,
                          const float *alpha_weight, const int32_t *instance_id, const uint8_t *hit,
                          const float *params_map, const float *cone_scale, int64_t n_rays, int n_samples,
                          int blur_idx, float patch_scale, float density_scale, uint32_t flags,
-                         const float *bkgd, const float *instance_color, float *color_out, float *alpha_out,
-                         int32_t *status_flag, ntx_stream stream);
+                         const float *bkgd, const float *instance_color, const ntx_render_opts *opts, float *color_out,
+                         float *alpha_out, int32_t *status_flag, ntx_stream stream);
 
 /* Replaces the image post-processing of logger.Logger.render_image / write_image (logger.py:128-144) and
  * util.interpolate.filtered_downsample (interpolate.py:68-82): rgba[H,W,4] premultiplied (DEVICE) ->
@@ -238,6 +264,11 @@ int64_t ntx_shard_count(int64_t n_pixels, int64_t run_length, int n_ranks, int r
  * host-side means); ntx_comm_create wraps ncclCommInitRank on `device`; all ranks call it collectively. */
 typedef struct ntx_comm ntx_comm;
 #define NTX_COMM_ID_BYTES 128
+/* ABI v3.  ntx_comm_preflight: everything of ntx_comm_create that can fail WITHOUT a peer (librccl loadable with every symbol,
+ * `device` valid), so that ranks can agree to go ahead before any of them blocks in ncclCommInitRank.  ntx_comm_library: path of the
+ * librccl the symbols were bound from ("" = none). */
+int ntx_comm_preflight(int device);
+const char *ntx_comm_library(void);
 int ntx_comm_unique_id(uint8_t *id_out /* HOST [NTX_COMM_ID_BYTES] */);
 int ntx_comm_create(const uint8_t *id /* HOST [NTX_COMM_ID_BYTES] */, int n_ranks, int rank, int device, ntx_comm **out);
 int ntx_comm_destroy(ntx_comm *comm);
@@ -252,6 +283,15 @@ int ntx_comm_destroy(ntx_comm *comm);
  * image_out / staging are ignored on the other ranks. */
 int ntx_gather_image(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, int64_t run_length, float *image_out,
                      float *staging, int root, ntx_stream stream);
+
+/* ABI v3, host only (no device, no communicator): the exchange ntx_gather_image performs for a shard map, as numbers -- rank r
+ * holds counts_out[r] pixels and its block starts at pixel slot offsets_out[r] of the destination; *equal_out = one ncclGather
+ * (else grouped Send/Recv with the exact counts); *direct_out = the destination is image_out itself (else `staging`, followed by
+ * the un-shard pass).  ntx_unshard_map: src_out[p] = the staging pixel slot that holds pixel p (what the un-shard kernel reads).
+ * Both run the very code of the device path (csrc/ntx_shard.h), so CPU tests can execute the plan through another transport. */
+int ntx_gather_plan(int64_t n_pixels, int64_t run_length, int n_ranks, int64_t *counts_out /* [n_ranks] or NULL */,
+                    int64_t *offsets_out /* [n_ranks] or NULL */, int *equal_out, int *direct_out);
+int ntx_unshard_map(int64_t n_pixels, int64_t run_length, int n_ranks, int64_t *src_out /* HOST [n_pixels] */);
 
 /* Introspection for benches/tests: name and launch geometry of the fused kernel in `ctx`. */
 int ntx_kernel_info(ntx_ctx *ctx, int *n_workgroups, int *threads_per_workgroup, int *n_cus);

@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERFTEX_LIB") or os.path.join(_HERE, "libnerftex_hip.so")
 
 NTX_OK, NTX_E_INVALID, NTX_E_UNSUPPORTED, NTX_E_HIP, NTX_E_NODEVICE = 0, -1, -2, -3, -4
-FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS, FLAG_FP16X3, FLAG_PERTURB = 1, 2, 4, 8, 16
-ABI_VERSION = 2
+FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS, FLAG_FP16X3, FLAG_PERTURB, FLAG_RAW_NOISE = 1, 2, 4, 8, 16, 32
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
 DEFAULT_MAX_RAYS = 1 << 20
 
@@ -25,6 +25,19 @@ class ModelDesc(C.Structure):
     """struct ntx_model_desc"""
     _fields_ = [(n, C.c_int32) for n in ("kind", "n_geo", "n_app", "n_pos", "pos_freq", "dir_freq",
                                           "param_freq", "depth", "width", "skip", "color_depth", "pos_encoding")]
+
+
+class RenderOpts(C.Structure):
+    """struct ntx_render_opts (ABI v3): raw_noise_std / noise_seed and the global ray index map of the generators"""
+    _fields_ = [("size", C.c_uint32), ("raw_noise_std", C.c_float), ("noise_seed", C.c_uint64),
+                ("ray_index0", C.c_int64), ("ray_run_length", C.c_int64), ("ray_run_stride", C.c_int64)]
+
+
+def render_opts(raw_noise_std: float = 0.0, noise_seed: int = 0, ray_index=None) -> "RenderOpts":
+    """`ray_index` = (index0, run_length, run_stride) of the call's rays (ShardMap.pixel_set(rank)[0, 2, 3]; a chunk that starts at
+    ray k0 of a larger call: (k0, n, n)), or None = the index within the call."""
+    i0, run, stride = (0, 0, 0) if ray_index is None else (int(v) for v in ray_index)
+    return RenderOpts(C.sizeof(RenderOpts), float(raw_noise_std), int(noise_seed) & (2 ** 64 - 1), i0, run, stride)
 
 
 class NtxError(RuntimeError):
@@ -40,6 +53,8 @@ _vp = C.c_void_p
 
 # every symbol include/nerftex.h declares: (restype, argtypes)
 _u8p = C.POINTER(C.c_uint8)
+_op = C.POINTER(RenderOpts)
+_i64p = C.POINTER(C.c_int64)
 SYMBOLS = {
     "ntx_abi_version": (C.c_int, []),
     "ntx_last_error": (C.c_char_p, []),
@@ -55,14 +70,18 @@ SYMBOLS = {
     "ntx_fourier_features": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, _vp, _vp]),
     "ntx_mlp_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_uint32, _vp, _vp, _vp]),
     "ntx_composite": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_uint32, _fp, _vp, _vp, _vp, _vp]),
-    "ntx_sample_depths": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_uint32, C.c_uint64, _vp, _vp]),
+    "ntx_sample_depths": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_uint32, C.c_uint64, _op, _vp, _vp]),
     "ntx_render_rays": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, C.c_int, C.c_uint32,
-                                  _fp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
-    "ntx_sample_pdf": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_uint64, _vp, _vp]),
+                                  _fp, _vp, C.c_uint64, _op, _vp, _vp, _vp, _vp, _vp]),
+    "ntx_sample_pdf": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_uint64, _op, _vp, _vp]),
     "ntx_render_instanced": (C.c_int, [_vp] * 12 + [C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, _fp,
-                                        _vp, _vp, _vp, _vp, _vp]),
+                                        _vp, _op, _vp, _vp, _vp, _vp]),
     "ntx_image_epilogue": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "ntx_shard_count": (C.c_int64, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    "ntx_comm_preflight": (C.c_int, [C.c_int]),
+    "ntx_comm_library": (C.c_char_p, []),
+    "ntx_gather_plan": (C.c_int, [C.c_int64, C.c_int64, C.c_int, _i64p, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ntx_unshard_map": (C.c_int, [C.c_int64, C.c_int64, C.c_int, _i64p]),
     "ntx_comm_unique_id": (C.c_int, [_u8p]),
     "ntx_comm_create": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "ntx_comm_destroy": (C.c_int, [_vp]),

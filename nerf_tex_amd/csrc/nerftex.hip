@@ -392,6 +392,32 @@ static int blur_slot(const ntx_ctx *c, int blur_idx) {
     return blur_idx < m.g ? blur_idx : v.n_geo + (blur_idx - m.g);
 }
 
+// ntx_render_opts (ABI v3) -> the generator's ray index map; identity when opts is NULL or the map is all zero
+struct IndexMap {
+    int64_t idx0, stride;
+    uint32_t run;
+};
+static int index_map_of(const ntx_render_opts *o, IndexMap *m) {
+    *m = IndexMap{0, 0, 0xffffffffu};
+    if (!o) return NTX_OK;
+    if (o->size < sizeof(ntx_render_opts)) return fail(NTX_E_INVALID, "ntx_render_opts.size %u < %zu: set it to sizeof(ntx_render_opts)", o->size, sizeof(ntx_render_opts));
+    if (o->ray_index0 == 0 && o->ray_run_length == 0 && o->ray_run_stride == 0) return NTX_OK;
+    if (o->ray_index0 < 0 || o->ray_run_length < 1 || o->ray_run_stride < o->ray_run_length)
+        return fail(NTX_E_INVALID, "bad ray index map: index0 %lld run_length %lld run_stride %lld", (long long)o->ray_index0,
+                    (long long)o->ray_run_length, (long long)o->ray_run_stride);
+    m->idx0 = o->ray_index0; m->stride = o->ray_run_stride;
+    m->run = o->ray_run_length > 0xffffffffLL ? 0xffffffffu : (uint32_t)o->ray_run_length;   // local rays are < 2^31: one run then
+    return NTX_OK;
+}
+static int noise_of(const ntx_render_opts *o, uint32_t flags, float *std_out) {
+    *std_out = 0.0f;
+    if (!(flags & NTX_FLAG_RAW_NOISE)) return NTX_OK;
+    if (!o) return fail(NTX_E_INVALID, "NTX_FLAG_RAW_NOISE needs ntx_render_opts.raw_noise_std");
+    if (!(o->raw_noise_std >= 0.0f) || std::isinf(o->raw_noise_std)) return fail(NTX_E_INVALID, "raw_noise_std must be finite and >= 0");
+    *std_out = o->raw_noise_std;
+    return NTX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
@@ -677,8 +703,8 @@ int ntx_composite(const float *color, const float *sigma, const float *z_vals, c
 
 int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, const float *t, const float *params,
                     int64_t rays_per_param_row, const float *cone_scale, int64_t n_rays, int n_samples, int blur_idx,
-                    uint32_t flags, const float *bkgd, const float *z_vals, uint64_t perturb_seed, float *color_out,
-                    float *alpha_out, float *weights_out, int32_t *status_flag, ntx_stream stream) {
+                    uint32_t flags, const float *bkgd, const float *z_vals, uint64_t perturb_seed, const ntx_render_opts *opts,
+                    float *color_out, float *alpha_out, float *weights_out, int32_t *status_flag, ntx_stream stream) {
     // every check comes before the first launch: a call that fails has written nothing
     if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
     if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
@@ -695,6 +721,10 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     if (blur_idx >= 0 && !cone_scale) return fail(NTX_E_INVALID, "blur_idx set but cone_scale is NULL");
     if ((size_t)n_rays > ctx->hit_cap)
         return fail(NTX_E_INVALID, "n_rays %lld exceeds the %zu rays this context reserved; call ntx_reserve first", (long long)n_rays, ctx->hit_cap);
+    IndexMap im;
+    float noise_std;
+    if (int rc = index_map_of(opts, &im)) return rc;
+    if (int rc = noise_of(opts, flags, &noise_std)) return rc;
     const bool x3 = (flags & NTX_FLAG_FP16X3) != 0;
     // the per-ray direction vector is valid unless the blur scaling hits an APPEARANCE parameter per sample (renderer.py:155-158)
     const bool dir_const = v.cd && (blur_idx < 0 || blur_idx < dm_.g || v.ipe);
@@ -711,6 +741,7 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     fill_param_map(ctx, a);
     a.delta = (1.0f - 0.0f) / (float)(n_samples - 1 + v.ipe);   // mip: S+1 segment edges (renderer.py:374)
     a.seed_lo = (uint32_t)perturb_seed; a.seed_hi = (uint32_t)(perturb_seed >> 32);
+    a.raw_noise_std = noise_std; a.idx0 = im.idx0; a.idx_run = im.run; a.idx_stride = im.stride;
     for (int k = 0; k < 3; ++k) a.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -746,8 +777,8 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
                          const float *color_last, const float *alpha_last, const float *alpha_weight,
                          const int32_t *instance_id, const uint8_t *hit, const float *params_map, const float *cone_scale,
                          int64_t n_rays, int n_samples, int blur_idx, float patch_scale, float density_scale,
-                         uint32_t flags, const float *bkgd, const float *instance_color, float *color_out,
-                         float *alpha_out, int32_t *status_flag, ntx_stream stream) {
+                         uint32_t flags, const float *bkgd, const float *instance_color, const ntx_render_opts *opts,
+                         float *color_out, float *alpha_out, int32_t *status_flag, ntx_stream stream) {
     if (!ctx) return fail(NTX_E_INVALID, "ctx is NULL");
     if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
     if (n_samples < 1 || n_samples > MAX_INSTANCE_SAMPLES)
@@ -765,7 +796,14 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     if (instance_color && !instance_id) return fail(NTX_E_INVALID, "instance_color given without instance_id");
     if (!(patch_scale > 0.0f)) return fail(NTX_E_INVALID, "patch_scale must be > 0");
     if (flags & NTX_FLAG_PERTURB) return fail(NTX_E_INVALID, "NTX_FLAG_PERTURB: the instancer places the samples of this path, there is nothing to jitter");
+    IndexMap im;
+    float noise_std;
+    if (int rc = index_map_of(opts, &im)) return rc;
+    if (int rc = noise_of(opts, flags, &noise_std)) return rc;
     InstanceArgs a{};
+    a.raw_noise_std = noise_std; a.idx0 = im.idx0; a.idx_run = im.run; a.idx_stride = im.stride;
+    a.seed_lo = opts ? (uint32_t)opts->noise_seed : 0u; a.seed_hi = opts ? (uint32_t)(opts->noise_seed >> 32) : 0u;
+    a.run_hoist = ctx->hoist_dir ? 1 : 0;
     a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed);
     a.stream_bytes = (uint32_t)(ctx->stream_floats * sizeof(float));
     a.aux = ctx->packed + ctx->stream_floats;
@@ -806,22 +844,30 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     return NTX_OK;
 }
 
-int ntx_sample_depths(const float *t, int64_t n_rays, int n_points, uint32_t flags, uint64_t perturb_seed, float *z_out,
-                      ntx_stream stream) {
+int ntx_sample_depths(const float *t, int64_t n_rays, int n_points, uint32_t flags, uint64_t perturb_seed,
+                      const ntx_render_opts *opts, float *z_out, ntx_stream stream) {
     if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
     if (n_points < 2) return fail(NTX_E_INVALID, "n_points must be >= 2");
+    IndexMap im;
+    if (int rc = index_map_of(opts, &im)) return rc;
+    if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "n_rays %lld exceeds int32", (long long)n_rays);
     if (n_rays == 0) return NTX_OK;
     if (!t || !z_out) return fail(NTX_E_INVALID, "NULL buffer");
     const int64_t n = n_rays * n_points;
     sample_depths_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        t, n_rays, n_points, 1.0f / (float)(n_points - 1), flags, (uint32_t)perturb_seed, (uint32_t)(perturb_seed >> 32), z_out);
+        t, n_rays, n_points, 1.0f / (float)(n_points - 1), flags, (uint32_t)perturb_seed, (uint32_t)(perturb_seed >> 32), im.idx0, im.run,
+        im.stride, z_out);
     HIP_TRY(hipGetLastError());
     return NTX_OK;
 }
 
 int ntx_sample_pdf(const float *t, const float *z_vals, const float *weights, const float *u, int64_t n_rays,
-                   int n_samples, int n_importance, uint32_t flags, uint64_t perturb_seed, float *z_out, ntx_stream stream) {
+                   int n_samples, int n_importance, uint32_t flags, uint64_t perturb_seed, const ntx_render_opts *opts, float *z_out,
+                   ntx_stream stream) {
     if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
+    IndexMap im;
+    if (int rc = index_map_of(opts, &im)) return rc;
+    if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "n_rays %lld exceeds int32", (long long)n_rays);
     if (n_samples < 3 || n_samples > MAX_PDF_SAMPLES) return fail(NTX_E_INVALID, "n_samples %d outside [3,%d]", n_samples, MAX_PDF_SAMPLES);
     if (n_importance < 1 || n_importance > MAX_PDF_SAMPLES) return fail(NTX_E_INVALID, "n_importance %d outside [1,%d]", n_importance, MAX_PDF_SAMPLES);
     if (n_rays == 0) return NTX_OK;
@@ -832,6 +878,7 @@ int ntx_sample_pdf(const float *t, const float *z_vals, const float *weights, co
     a.delta = 1.0f / (float)(n_samples - 1);
     a.delta_u = n_importance > 1 ? 1.0f / (float)(n_importance - 1) : 0.0f;
     a.flags = flags; a.seed_lo = (uint32_t)perturb_seed; a.seed_hi = (uint32_t)(perturb_seed >> 32);
+    a.idx0 = im.idx0; a.idx_run = im.run; a.idx_stride = im.stride;
     int64_t nb = (n_rays + 3) / 4;
     if (nb > 256 * 8) nb = 256 * 8;
     sample_pdf_kernel<<<dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream>>>(a);

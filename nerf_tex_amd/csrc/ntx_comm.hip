@@ -2,6 +2,7 @@
 // RCCL is dlopen-ed on first use -- the copy PyTorch has already loaded when there is one, so that a process never
 // holds two RCCL instances -- and only its public C API (rccl.h) is used.  gfx950 only.
 #include "nerftex.h"
+#include "ntx_shard.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -20,8 +21,7 @@ __global__ __launch_bounds__(256) void ntx_unshard_kernel(const f32x4 *staging, 
                                                           int64_t rank_stride, f32x4 *image) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
-    const int64_t q = p / run_length;
-    image[p] = staging[(q % n_ranks) * rank_stride + (q / n_ranks) * run_length + p % run_length];
+    image[p] = staging[ntx_shard::staging_index(p, run_length, n_ranks, rank_stride)];
 }
 
 extern "C" int ntx_set_error(int code, const char *fmt, ...);   // nerftex.hip: per-thread message behind ntx_last_error()
@@ -39,21 +39,20 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    char path[512] = "";
 };
 
-// NULL + message when librccl cannot be had
-const Rccl *rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.handle ? &r : nullptr;
-    tried = true;
+// librccl is bound once per process (function-local static: initialisation is thread-safe).  The copy PyTorch has already
+// loaded is preferred (RTLD_NOLOAD matches its soname librccl.so.1), so that a process never holds two RCCL instances.
+Rccl load_rccl() {
+    Rccl r;
     const char *names[] = {"librccl.so.1", "librccl.so"};
     for (const char *n : names)   // already in the process (PyTorch links its own copy)?
         if ((r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
     if (!r.handle)
         for (const char *n : names)
             if ((r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!r.handle) return nullptr;
+    if (!r.handle) return r;
     bool ok = true;
     auto sym = [&](auto &fn, const char *name) {
         fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(r.handle, name));
@@ -62,17 +61,19 @@ const Rccl *rccl() {
     sym(r.GetUniqueId, "ncclGetUniqueId"); sym(r.CommInitRank, "ncclCommInitRank"); sym(r.CommDestroy, "ncclCommDestroy");
     sym(r.Gather, "ncclGather"); sym(r.Send, "ncclSend"); sym(r.Recv, "ncclRecv");
     sym(r.GroupStart, "ncclGroupStart"); sym(r.GroupEnd, "ncclGroupEnd"); sym(r.GetErrorString, "ncclGetErrorString");
-    if (!ok) r.handle = nullptr;
+    if (!ok) { r.handle = nullptr; return r; }
+    Dl_info info;   // which file the symbols really come from (diagnostics: ntx_comm_library)
+    if (dladdr(reinterpret_cast<void *>(r.Gather), &info) && info.dli_fname) snprintf(r.path, sizeof(r.path), "%s", info.dli_fname);
+    return r;
+}
+
+// NULL when librccl cannot be had
+const Rccl *rccl() {
+    static const Rccl r = load_rccl();
     return r.handle ? &r : nullptr;
 }
 
-int64_t shard_count(int64_t n, int64_t L, int R, int rank) {
-    const int64_t runs = (n + L - 1) / L;                    // run q -> rank q % R
-    if (runs <= rank) return 0;
-    const int64_t mine = (runs - 1 - rank) / R + 1;          // runs rank, rank + R, ...
-    const int64_t last = rank + (mine - 1) * R;              // only the very last run of the image can be short
-    return mine * L - (last == runs - 1 ? runs * L - n : 0);
-}
+using ntx_shard::shard_count;
 
 }  // namespace
 
@@ -101,6 +102,27 @@ int64_t ntx_shard_count(int64_t n_pixels, int64_t run_length, int n_ranks, int r
         return -1;
     }
     return shard_count(n_pixels, run_length, n_ranks, rank);
+}
+
+int ntx_unshard_map(int64_t n_pixels, int64_t run_length, int n_ranks, int64_t *src_out) {
+    if (n_pixels < 0 || run_length < 1 || n_ranks < 1 || (!src_out && n_pixels > 0))
+        return ntx_set_error(NTX_E_INVALID, "bad shard map: n_pixels %lld run_length %lld n_ranks %d", (long long)n_pixels, (long long)run_length, n_ranks);
+    const int64_t cap = shard_count(n_pixels, run_length, n_ranks, 0);
+    for (int64_t p = 0; p < n_pixels; ++p) src_out[p] = ntx_shard::staging_index(p, run_length, n_ranks, cap);
+    return NTX_OK;
+}
+
+const char *ntx_comm_library(void) {
+    const Rccl *R = rccl();
+    return R ? R->path : "";
+}
+
+int ntx_comm_preflight(int device) {
+    if (!rccl()) return ntx_set_error(NTX_E_UNSUPPORTED, "librccl.so.1 could not be loaded (or lacks a symbol of rccl.h): %s", dlerror() ? dlerror() : "no dlerror");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return ntx_set_error(NTX_E_INVALID, "device %d out of range [0,%d)", device, ndev);
+    return NTX_OK;
 }
 
 int ntx_comm_unique_id(uint8_t *id_out) {
@@ -137,6 +159,20 @@ int ntx_comm_destroy(ntx_comm *comm) {
     return NTX_OK;
 }
 
+int ntx_gather_plan(int64_t n_pixels, int64_t run_length, int n_ranks, int64_t *counts_out, int64_t *offsets_out, int *equal_out,
+                    int *direct_out) {
+    if (n_pixels < 0 || run_length < 1 || n_ranks < 1)
+        return ntx_set_error(NTX_E_INVALID, "bad shard map: n_pixels %lld run_length %lld n_ranks %d", (long long)n_pixels, (long long)run_length, n_ranks);
+    const ntx_shard::Plan pl = ntx_shard::plan(n_pixels, run_length, n_ranks);
+    for (int r = 0; r < n_ranks; ++r) {
+        if (counts_out) counts_out[r] = shard_count(n_pixels, run_length, n_ranks, r);
+        if (offsets_out) offsets_out[r] = ntx_shard::rank_block(r, pl.cap);
+    }
+    if (equal_out) *equal_out = pl.equal;
+    if (direct_out) *direct_out = pl.direct;
+    return NTX_OK;
+}
+
 int ntx_gather_image(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, int64_t run_length, float *image_out,
                      float *staging, int root, ntx_stream stream) {
     if (!comm) return ntx_set_error(NTX_E_INVALID, "comm is NULL");
@@ -145,31 +181,31 @@ int ntx_gather_image(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, 
     if (n_pixels == 0) return NTX_OK;
     const Rccl *R = rccl();
     if (!R) return ntx_set_error(NTX_E_UNSUPPORTED, "librccl.so.1 could not be loaded");
-    const int64_t mine = shard_count(n_pixels, run_length, R_, me);
-    const int64_t cap = shard_count(n_pixels, run_length, R_, 0);                 // rank 0 always holds the most
-    bool equal = true;
-    for (int r = 1; r < R_; ++r) equal = equal && shard_count(n_pixels, run_length, R_, r) == cap;
-    const bool contiguous = run_length * R_ >= n_pixels;                          // at most one run per rank: bands
+    // the plan (ntx_shard.h; ntx_gather_plan hands the same numbers to host code): rank r's count, its block at pixel slot
+    // rank_block(r, cap) of the destination, and whether the blocks already are the image
+    const ntx_shard::Plan pl = ntx_shard::plan(n_pixels, run_length, R_);
+    const int64_t mine = shard_count(n_pixels, run_length, R_, me), cap = pl.cap;
     if (!local_rgba && mine > 0) return ntx_set_error(NTX_E_INVALID, "local_rgba is NULL");
-    const bool direct = equal && contiguous;                                      // the gather lands in pixel order
+    const bool direct = pl.direct;                                                // the gather lands in pixel order
     if (me == root && (!image_out || (!direct && !staging)))
         return ntx_set_error(NTX_E_INVALID, "root needs image_out%s", direct ? "" : " and staging (uneven or interleaved shards)");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(comm->device));
     float *dst = direct ? image_out : staging;
-    if (equal) {
-        // the one collective of the render path: every peer sends its shard straight to the root
+    if (pl.equal) {
+        // the one collective of the render path: every peer sends its shard straight to the root (block r at r * cap)
         RCCL_TRY(R->Gather(local_rgba, dst, (size_t)cap * 4, ncclFloat, root, comm->comm, st));
     } else {
         // same exchange with the exact per-rank counts; the group is always closed, also on an error inside it
         if (me == root && mine > 0)
-            HIP_TRY(hipMemcpyAsync(dst + (size_t)me * cap * 4, local_rgba, (size_t)mine * 16, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(dst + (size_t)ntx_shard::rank_block(me, cap) * 4, local_rgba, (size_t)mine * 16, hipMemcpyDeviceToDevice, st));
         RCCL_TRY(R->GroupStart());
         ncclResult_t rc = ncclSuccess;
         if (me == root) {
             for (int r = 0; r < R_ && rc == ncclSuccess; ++r) {
                 const int64_t cnt = shard_count(n_pixels, run_length, R_, r);
-                if (cnt > 0 && r != me) rc = R->Recv(dst + (size_t)r * cap * 4, (size_t)cnt * 4, ncclFloat, r, comm->comm, st);
+                if (cnt > 0 && r != me)
+                    rc = R->Recv(dst + (size_t)ntx_shard::rank_block(r, cap) * 4, (size_t)cnt * 4, ncclFloat, r, comm->comm, st);
             }
         } else if (mine > 0) {
             rc = R->Send(local_rgba, (size_t)mine * 4, ncclFloat, root, comm->comm, st);

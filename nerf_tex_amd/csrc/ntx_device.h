@@ -26,6 +26,11 @@
 // tools/ubench/mfma_valu_overlap.hip) -- the f32 MFMA runs on the FP32 lanes -- so VALU work is kept in
 // few, dense, well-pipelined blocks.
 
+// The kernel objects do not depend on include/nerftex.h in the Makefile (a comment there must not cost an hour of
+// hipcc); the flag values they compile in are frozen instead -- appended to, never renumbered:
+static_assert(NTX_FLAG_MAP_EXR == 1u && NTX_FLAG_COMPOSITE_BKGD == 2u && NTX_FLAG_CHECK_NUMERICS == 4u && NTX_FLAG_FP16X3 == 8u &&
+              NTX_FLAG_PERTURB == 16u && NTX_FLAG_RAW_NOISE == 32u, "NTX_FLAG_* values are part of the built kernels");
+
 namespace ntx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -405,11 +410,17 @@ struct RecMap {
 // HOIST = 2 (no blur_idx) / 3 (blur_idx = 0): the geometry-parameter blocks of the position segments of L0 and L5 (all / all
 // but parameter 0's) are per-ray constant too; L0 and L5 start from the rows dir_block left behind the C1 row (c1_row +
 // DIR_BLOCK_FLOATS, + 2 DIR_BLOCK_FLOATS) and run only the rest.
-template <class CFG, int HOIST = 0>
+// HOIST = 4 (instance kernel): as 1, but every LANE has its own row -- c1_row is the wave's block of rows (leader_rows) and
+// lane_slots[sample] the row of each sample of the batch, read from LDS where the row is needed (nothing more lives across
+// the network).
+// KEEP_PE = false: no LDS column for the position features, the skip layer evaluates them again (the instance kernel, whose LDS
+// holds 32 rows per wave instead).
+template <class CFG, int HOIST = 0, bool KEEP_PE = true>
 NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
                        const float *aux_in, int lane, float &sigma, float (&rgb)[3],
-                       const float *c1_row = nullptr, float *pe = nullptr) {
+                       const float *c1_row = nullptr, float *pe = nullptr, const uint8_t *lane_slots = nullptr) {
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
+    constexpr bool GEO_ROWS = HOIST == 2 || HOIST == 3;
     constexpr int GS = hoisted_geo_steps<CFG, HOIST>();        // k-steps of the position segments evaluated per ray
     using M = RecMap<CFG, HOIST>;
     const int h = lane >> 5;
@@ -425,13 +436,13 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
     auto none = [](auto, auto) {};
 
     // ---- trunk layer 0: pos_map -> 256 (model.py:104-106) into set A; set B <- bias of layer 1
-    if constexpr (HOIST >= 2) {
+    if constexpr (GEO_ROWS) {
         static_for<8>([&](auto T) { init_bias_tile_row<decltype(T)::value>(accA, c1_row + DIR_BLOCK_FLOATS + opaque_zero, h); });
     } else {
         init_bias<8>(accA, aux, 0, h);
     }
     {
-        PosGen<NGEO, NAPP, CFG::IPE, 1, GS> gen{in, h, {}, pe};
+        PosGen<NGEO, NAPP, CFG::IPE, KEEP_PE ? 1 : 0, GS> gen{in, h, {}, pe};
         static_assert(CFG::PS - GS >= 29, "layer-1 bias initialised behind layer 0");
         run_segment<M, CFG::PS - GS, 8, M::log_of(GS * 2)>(accA, ws, gen, [&](auto S, auto MT) {
             constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
@@ -454,8 +465,10 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
         auto reinit = [&](auto S, auto MT) {
             constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
             if constexpr (init_next && mt == 1 && (s & 15) == 0) {
-                if constexpr (HOIST != 0 && CFG::CD != 0 && next_bias == 9) init_bias_tile_row<(s >> 4)>(prev, c1_row + opaque_zero, h);
-                else if constexpr (HOIST >= 2 && next_bias == SKIP + 1) init_bias_tile_row<(s >> 4)>(prev, c1_row + 2 * DIR_BLOCK_FLOATS + opaque_zero, h);
+                if constexpr (HOIST == 4 && CFG::CD != 0 && next_bias == 9)
+                    init_bias_tile_row<(s >> 4)>(prev, c1_row + (int)lane_slots[(lane & 31) + opaque_zero] * DIR_ROW_STRIDE, h);
+                else if constexpr (HOIST != 0 && CFG::CD != 0 && next_bias == 9) init_bias_tile_row<(s >> 4)>(prev, c1_row + opaque_zero, h);
+                else if constexpr (GEO_ROWS && next_bias == SKIP + 1) init_bias_tile_row<(s >> 4)>(prev, c1_row + 2 * DIR_BLOCK_FLOATS + opaque_zero, h);
                 else init_bias_tile<(s >> 4)>(prev, aux, next_bias, h);
             }
         };
@@ -470,7 +483,7 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
             auto conv = none;
             const SampleIn<NGEO, NAPP> in2 = launder(in);
             if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
-                PosGen<NGEO, NAPP, CFG::IPE, 2, GS> gen{in2, h, {}, pe};   // the values layer 0 kept
+                PosGen<NGEO, NAPP, CFG::IPE, KEEP_PE ? 2 : 0, GS> gen{in2, h, {}, pe};   // the values layer 0 kept
                 run_segment<M, pre_steps - GS, 8, M::log_of(rec0 + GS * 2)>(cur, ws, gen, conv);
             } else {                   // input = concat[dir_map, feature]  (model.py:115)
                 if constexpr (HOIST == 0) {   // (hoisted: already in the accumulators through c1_row, and not in the logical stream)
@@ -612,13 +625,14 @@ NTX_DEV void composite_core(RayAccum &ra, float a, const float (&c)[3], bool val
     ra.T *= __shfl(P, W - 1, W);
 }
 
+// `noise` = this sample's N(0, raw_noise_std) draw (renderer.py:190-192), 0 when the regulariser is off
 template <int W>
 NTX_DEV void composite_step(RayAccum &ra, float sigma, const float (&raw)[3], float dist, bool valid,
-                            uint32_t flags, int j, float *w_out) {
+                            uint32_t flags, int j, float *w_out, float noise = 0.0f) {
     float c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) c[k] = (flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[k]) : sigmoidf_(raw[k]);   // :182-187
-    const float a = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * dist) : 0.0f;                  // :195
+    const float a = valid ? 1.0f - expf(-__builtin_fmaxf(sigma + noise, 0.0f) * dist) : 0.0f;          // :195
     composite_core<W>(ra, a, c, valid, j, w_out);
 }
 
@@ -664,7 +678,21 @@ struct RenderArgs {
     uint32_t dir_stream_bytes;
     int np_in;                        // generic family: width of the caller's parameter rows, and the column of every slot (-1: absent)
     int8_t pmap[MAX_PARAM_SLOTS];
+    // ABI v3.  The counter of the jitter / noise generator is the GLOBAL index of a ray,
+    //   idx0 + (k / idx_run) * idx_stride + k % idx_run   for local ray k (ntx_render_opts; identity: 0, 0xffffffff, 0),
+    // so a sharded or chunked image draws what the whole image draws.
+    float raw_noise_std;              // NTX_FLAG_RAW_NOISE: sigma += raw_noise_std * N(0,1) per sample (renderer.py:190-192)
+    uint32_t idx_run;
+    int64_t idx0, idx_stride;
 };
+
+// this lane's index within its wave64, recomputed where it is called (v_mbcnt on an opaque zero: not hoistable, not CSE-able
+// with the kernel's own `lane`), for code that runs rarely between long register-starved stretches
+NTX_DEV int fresh_lane_id() {
+    uint32_t zero = 0;
+    asm volatile("" : "+v"(zero));
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+}
 
 // the by-value kernel argument struct, addressed in the kernarg segment (device pass only)
 template <class T>
@@ -682,7 +710,7 @@ NTX_DEV const T *kernargs() {
 // Philox4x32-10 (Salmon et al., SC'11; the generator behind tf.random.uniform), word 0 of the block at `ctr` under
 // `key`.  Counter-based: the draw for (ray, sample) is a pure function of (seed, ray, sample), so the jitter needs no
 // state, no [N,S] tensor and is independent of how rays are split over launches, waves or GPUs.
-NTX_DEV uint32_t philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+NTX_DEV uint32_t philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *word1 = nullptr) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
@@ -690,10 +718,21 @@ NTX_DEV uint32_t philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
         c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
+    if (word1) *word1 = c1;
     return c0;
 }
 // uniform float32 in [0,1) from 23 random bits, as tf.random.uniform makes it (random_distributions.h Uint32ToFloat)
 NTX_DEV float uniform01(uint32_t x) { return __builtin_bit_cast(float, (x & 0x7fffffu) | 0x3f800000u) - 1.0f; }
+// N(0,1) from words 0 and 1 of the Philox block at counter (sample, ray lo, ray hi, 1): the first output of the Box-Muller
+// transform tf.random.normal applies to two uniforms (random_distributions.h BoxMullerFloat: u1 clamped to 1e-7,
+// sqrt(-2 ln u1) sin(2 pi u2)).  Counter word 3 = 1 keeps the stream apart from the jitter's (word 3 = 0).
+NTX_DEV float normal01(int64_t gray, int i, uint32_t seed_lo, uint32_t seed_hi) {
+    uint32_t x1;
+    const uint32_t x0 = philox4x32_10((uint32_t)i, (uint32_t)gray, (uint32_t)((uint64_t)gray >> 32), 1u, seed_lo, seed_hi, &x1);
+    const float u1 = __builtin_fmaxf(uniform01(x0), 1.0e-7f);
+    const float v1 = 6.28318530717958647692f * uniform01(x1);
+    return sinf(v1) * __builtin_sqrtf(-2.0f * logf(u1));
+}
 
 // depth i of the npts points of tf.linspace between t0 and t1 (npts = S samples, or S+1 segment edges for the mip
 // renderer, renderer.py:374-376); delta = float32(1 / (npts - 1))
@@ -710,9 +749,15 @@ NTX_DEV float z_jittered(float delta, int64_t ray, int i, float t0, float t1, in
     const float u = uniform01(philox4x32_10((uint32_t)i, (uint32_t)ray, (uint32_t)((uint64_t)ray >> 32), 0u, seed_lo, seed_hi));
     return lower + (upper - lower) * u;
 }
-NTX_DEV float z_of(const RenderArgs &a, int64_t ray, int i, float t0, float t1, int npts) {
+// global index of local ray k under the index map (idx0, idx_run, idx_stride); k < 2^31 (ntx_reserve)
+NTX_DEV int64_t global_index(int64_t idx0, uint32_t idx_run, int64_t idx_stride, int64_t k) {
+    const uint32_t r = (uint32_t)k, q = r / idx_run;
+    return idx0 + (int64_t)q * idx_stride + (int64_t)(r - q * idx_run);
+}
+// `ray` indexes the call's arrays, `gray` = its global index keys the generator
+NTX_DEV float z_of(const RenderArgs &a, int64_t ray, int64_t gray, int i, float t0, float t1, int npts) {
     if (a.z_vals) return a.z_vals[ray * npts + i];
-    if (a.flags & NTX_FLAG_PERTURB) return z_jittered(a.delta, ray, i, t0, t1, npts, a.seed_lo, a.seed_hi);
+    if (a.flags & NTX_FLAG_PERTURB) return z_jittered(a.delta, gray, i, t0, t1, npts, a.seed_lo, a.seed_hi);
     return z_lin(a.delta, i, t0, t1, npts);
 }
 
@@ -829,7 +874,14 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     for (int base = 0; base < n_work; base += DIR_BLOCK_ITERS * nwaves) {
         if constexpr (HOIST != 0) {
             __syncthreads();   // every wave is done with the previous block's rows
-            dir_block<CFG, hoisted_geo_steps<CFG, HOIST>()>(a, ws.rsrc, aux, dir_rows, base, nwaves, vwg, wv, lane, n_work);
+            // dir_block's lane-derived addresses and its view of the arguments are loop invariants that LICM would carry
+            // across the ~10 000-MFMA body below, where every register is taken: 4 dwords of scratch per lane (r2 profiles:
+            // Scratch_Size 20).  A lane index read afresh from the hardware and an opaque view of the arguments make it
+            // recompute them here, once per 8 rays.
+            const int lane_o = fresh_lane_id();
+            const RenderArgs *apd = kernargs<RenderArgs>();
+            asm volatile("" : "+s"(apd));
+            dir_block<CFG, hoisted_geo_steps<CFG, HOIST>()>(*apd, ws.rsrc, aux, dir_rows, base, nwaves, vwg, wv, lane_o, n_work);
             __syncthreads();
         }
       for (int it = 0; it < DIR_BLOCK_ITERS; ++it) {
@@ -858,13 +910,15 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             const bool valid = i < S;
             const int ic = valid ? i : S - 1;
             const int blur_idx = q.blur_idx;
+            // the generator's counter is the ray's global index (a scalar division, only when something is drawn)
+            const int64_t gr = (q.flags & (NTX_FLAG_PERTURB | NTX_FLAG_RAW_NOISE)) ? global_index(q.idx0, q.idx_run, q.idx_stride, r) : r;
             SampleIn<CFG::NGEO, CFG::NAPP> in;
             in.dir[0] = dx / dnorm; in.dir[1] = dy / dnorm; in.dir[2] = dz / dnorm;      // rays_d_n
             float dist;
             if constexpr (CFG::IPE == 0) {
-                const float z = z_of(q, r, ic, t0, t1, S);
+                const float z = z_of(q, r, gr, ic, t0, t1, S);
                 // dists: z[i+1]-z[i], the last one a copy of the previous (renderer.py:174-177), times |d| (:180)
-                const float zn = z_of(q, r, ic < S - 1 ? ic + 1 : ic - 1, t0, t1, S);
+                const float zn = z_of(q, r, gr, ic < S - 1 ? ic + 1 : ic - 1, t0, t1, S);
                 dist = (ic < S - 1 ? zn - z : z - zn) * dnorm;
                 in.pos[0] = ox + dx * z; in.pos[1] = oy + dy * z; in.pos[2] = oz + dz * z;   // renderer.py:114
                 in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
@@ -878,7 +932,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
                 // MipRenderer.render_rays (renderer.py:365-409): sample i = the cone segment between edges i and i+1 of
                 // S+1 depths, encoded by its gaussian (mean, diagonal covariance); the blur parameter times cone_scale
                 // is the cone radius and is spliced out of the model's parameters; dists need no copy (:441-444)
-                const float e0 = z_of(q, r, ic, t0, t1, S + 1), e1 = z_of(q, r, ic + 1, t0, t1, S + 1);
+                const float e0 = z_of(q, r, gr, ic, t0, t1, S + 1), e1 = z_of(q, r, gr, ic + 1, t0, t1, S + 1);
                 dist = (e1 - e0) * dnorm;
                 float t_mean, t_var, r_var;
                 cone_moments((e0 + e1) / 2.0f, (e1 - e0) / 2.0f, prow[blur_idx] * cone, t_mean, t_var, r_var);
@@ -894,8 +948,11 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             else mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe);
             const RenderArgs *ap2 = kernargs<RenderArgs>();
             asm volatile("" : "+s"(ap2));
+            float noise = 0.0f;   // renderer.py:190-192; drawn after the network: nothing more lives across its ~10 000 MFMAs
+            if (ap2->flags & NTX_FLAG_RAW_NOISE)
+                noise = ap2->raw_noise_std * normal01(global_index(ap2->idx0, ap2->idx_run, ap2->idx_stride, ray), ic, ap2->seed_lo, ap2->seed_hi);
             composite_step<32>(ra, sigma, raw, dist, valid, ap2->flags, j,
-                               ap2->weights_out ? ap2->weights_out + ray * S + ic : nullptr);
+                               ap2->weights_out ? ap2->weights_out + ray * S + ic : nullptr, noise);
         }
         float out[4] = {ra.c0, ra.c1, ra.c2, ra.a};
         if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {   // renderer.py:210-211
@@ -943,6 +1000,12 @@ struct InstanceArgs {
     const int32_t *order;    // the rays, costliest first (inst_*_kernel, ntx_small_kernels.h): claim k marches ray order[k]
     int np_in;               // generic family, as RenderArgs
     int8_t pmap[MAX_PARAM_SLOTS];
+    // ABI v3: NTX_FLAG_RAW_NOISE (renderer.py:335-337), counter = (marching-sample index, global ray index, 1) as RenderArgs
+    float raw_noise_std;
+    uint32_t seed_lo, seed_hi, idx_run;
+    int64_t idx0, idx_stride;
+    int run_hoist;           // 0: every sample is its own run (A/B knob: NERFTEX_NO_DIR_HOIST at ntx_create)
+    uint16_t *sidx_scratch;  // [n_workgroups * 4][MAX_INSTANCE_SAMPLES]: every wave's compacted index list of the ray in flight (context scratch)
 };
 
 // Tail packing.  A ray's in-patch samples fill count / 32 whole batches and leave a TAIL of count % 32 samples; run as a
@@ -991,19 +1054,99 @@ NTX_DEV void composite_segment(RayAccum &ra, float a, const float (&c)[3], int j
     ra.T *= __shfl(P, e, 32);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direction features once per instance RUN.  The instancer hands every marching sample its own direction and parameters
+// (instancer.pyx:41-54), but it fills them per (ray, patch instance): rays_d_map = getDir(ray direction, instance) and the
+// light direction likewise (instancer.cpp:943-960), the other appearance parameters are the view's constants -- so along the
+// run of consecutive in-patch samples of one instance the inputs of C1's direction segment (model.py:96-101, 115) do not
+// change; what varies per sample is the position and the texture-mapped GEOMETRY parameter (instancer.cpp:913-918).  As in
+// render_kernel<CFG, 1>, the segment W_C1[:dir_map]^T dir_map (328 of 10 648 MFMAs and 41 sin() per lane and batch) is then a
+// vector per run: when a ray's samples are compacted, the first sample of every run (inputs bit-different from its
+// predecessor's) is flagged; the runs of the next batches of the ray -- as many batches as lead_slots() rows can serve -- are
+// evaluated in ONE pass of the segment (leader_rows: lane = run, same bias initialisation, k-order and generator as the
+// per-sample evaluation, so the same bits) into rows in LDS, and every batch of the group starts its C1 accumulators from its
+// samples' rows (mlp_batch<CFG, 4>).  Nothing is assumed: a batch whose runs do not fit (e.g. per-sample directions), the
+// packed tail batches and a blur_idx on an appearance parameter take the per-sample kernel, bit-identical either way.
+// ---------------------------------------------------------------------------------------------
+constexpr int LEAD_FLAG = 0x8000;       // bit 15 of a compacted sample index (marching indices are < 4096)
+constexpr int LEAD_GROUP_MAX = 16;      // batches one group of rows may serve
+constexpr int SIDX_WINDOW = 1024;       // entries of a ray's compacted index list kept in LDS (the list itself lives in global scratch)
+template <class CFG>
+constexpr int lead_slots() { return CFG::CD == 0 ? 0 : 32; }   // rows per wave: one per sample of a batch, so EVERY batch can be served
+
+// direction and appearance parameters of marching sample sm as the instancer delivered them (the run flags compare THESE; a
+// blur_idx on an appearance parameter scales it per sample, renderer.py:259-262, and then every sample is its own run)
+template <class CFG>
+NTX_DEV void dir_inputs(const InstanceArgs &a, int64_t sm, SampleIn<CFG::NGEO, CFG::NAPP> &in) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) in.dir[c] = a.rays_d_map[3 * sm + c];
+    if constexpr (CFG::IPE == 0) {
+#pragma unroll
+        for (int c = CFG::NGEO; c < CFG::NP; ++c) in.par[c] = param_at<CFG>(a, a.params_map + param_stride<CFG>(a) * sm, c);
+    } else {
+        const float *pr = a.params_map + CFG::NP_IN * sm;
+#pragma unroll
+        for (int c = CFG::NGEO; c < CFG::NP; ++c) in.par[c] = pr[c < a.blur_idx ? c : c + 1];
+    }
+}
+
+// rows[slot] = bias_C1 + W_C1[:dir_map]^T dir_map(in of lane `slot`), all 8 output tiles by this wave: the direction segment
+// of run_segment<.., CFG::DS, 8, rec_pass(9)> with the weights loaded straight from the stream
+template <class CFG, int NSLOT>
+NTX_DEV void leader_rows(__amdgpu_buffer_rsrc_t rsrc, const float *aux, float *rows, const SampleIn<CFG::NGEO, CFG::NAPP> &in, int lane) {
+    const int h = lane >> 5, j = lane & 31;
+    f32x16 acc[8];
+    init_bias<8>(acc, aux, 9, h);
+    const uint32_t voff = (uint32_t)lane * 16u;
+    static_for<CFG::DS>([&](auto S) {
+        constexpr int s = S;
+        constexpr uint32_t rec = (uint32_t)(CFG::rec_pass(9) + 2 * s);
+        const f32x4 w0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, rec * 1024u, 0));
+        const f32x4 w1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (rec + 1u) * 1024u, 0));
+        const float b = dir_feature<CFG::NGEO, CFG::NAPP, s>(in, h);
+        static_for<4>([&](auto E) { acc[decltype(E)::value] = mfma32(w0[decltype(E)::value], b, acc[decltype(E)::value]); });
+        static_for<4>([&](auto E) { acc[4 + decltype(E)::value] = mfma32(w1[decltype(E)::value], b, acc[4 + decltype(E)::value]); });
+    });
+    if (j < NSLOT) {   // lane (slot j, half h), register r of tile t -> rows[j][h][16 t + r]  (the layout init_bias_tile_row reads)
+        f32x4 *o = reinterpret_cast<f32x4 *>(rows + j * DIR_ROW_STRIDE + h * 128);
+        static_for<8>([&](auto T) {
+            constexpr int t = T;
+            static_for<4>([&](auto Q) {
+                constexpr int q = Q;
+                o[4 * t + q] = f32x4{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+            });
+        });
+    }
+}
+
 template <class CFG>
 __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
-    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * pe_keep_floats<CFG>()];
-    __shared__ uint16_t sidx_all[4][MAX_INSTANCE_SAMPLES];
+    constexpr int NSLOT = lead_slots<CFG>();
+    constexpr bool ROWS = NSLOT > 0;            // ParamNerf: C1 always starts from rows; plain Nerf has no C1 (per-sample kernel as before)
+    __shared__ __attribute__((aligned(16))) float aux[aux_total() + (ROWS ? 4 * NSLOT * DIR_ROW_STRIDE : 4 * pe_keep_floats<CFG>())];
+    __shared__ uint16_t win_all[4][SIDX_WINDOW];
     __shared__ InstancePending pend_all[4];
+    __shared__ uint8_t slot_all[4][32];         // row of each sample of the batch in flight
+    __shared__ uint16_t lead_all[4][32];        // position (in the compacted list) of the group's run leaders
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.n_samples;
-    uint16_t *sidx = sidx_all[wv];
+    // the compacted index list of the ray in flight: global scratch of the context (L2-resident, 8 KiB per wave), read through a
+    // window in LDS; entry = marching index | LEAD_FLAG
+    uint16_t *gsidx = a.sidx_scratch + ((size_t)blockIdx.x * 4 + wv) * MAX_INSTANCE_SAMPLES;
+    uint16_t *win = win_all[wv];
     InstancePending &pend = pend_all[wv];
+    float *rows = aux + aux_total() + wv * NSLOT * DIR_ROW_STRIDE;
+    float *pe_col = ROWS ? nullptr : pe_column<CFG>(aux, wv, lane);
+    uint8_t *slots = slot_all[wv];
+    uint16_t *lead_pos = lead_all[wv];
     WStream ws;
-    ws_prime<RecMap<CFG, 0>>(ws, a.wstream, a.stream_bytes, lane);
+    ws_prime<RecMap<CFG, ROWS ? 4 : 0>>(ws, a.wstream, a.stream_bytes, lane);
+    // runs are looked for unless switched off (A/B knob of the host) or blur_idx scales an appearance parameter per sample;
+    // without them every sample is its own run (the rows of a batch are then evaluated for that batch alone: the work of the
+    // per-sample kernel, bit-identical results)
+    const bool runs_on = ROWS && a.run_hoist != 0 && !(a.blur_idx >= CFG::NGEO && CFG::IPE == 0);
 
     // the appended sample (colour taken as is, alpha_last is an alpha, not a density: renderer.py:323-339) and the store
     auto finish = [&](int64_t ray, const RayAccum &ra) {
@@ -1025,13 +1168,19 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
         }
     };
 
-    // The number of in-patch samples differs from ray to ray (0 .. S), so a static ray -> wave map leaves waves idle at the
-    // end (19 % on the carpet_instanced bench workload): each wave takes the next unclaimed ray instead.
     int64_t cur = -1;            // the ray whose whole batches are being marched, -1 = none
     int count = 0, nfull = 0, b = 0, pend_n = 0, pend_k = 0;
+    int win0 = 0;                                  // the window holds list entries [win0, win0 + SIDX_WINDOW)
+    int grp_b0 = 0, grp_end = 0, slot_base = 0;    // rows in LDS serve batches [grp_b0, grp_end) of `cur`; next free row of the group
     bool exhausted = false;
     float cone = 0.0f;
     RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    auto win_load = [&](int p0) {
+        win0 = p0;
+        for (int k = lane; k < SIDX_WINDOW && p0 + k < count; k += 64) win[k] = gsidx[p0 + k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     for (;;) {
         // ---- scheduler (wave-uniform): advance until a batch is due.  mode 1 = a whole batch of `cur`, 2 = the packed tails
         int mode = 0;
@@ -1041,7 +1190,8 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
                 const int r = count - 32 * nfull;
                 if (r == 0) { finish(cur, ra); cur = -1; continue; }
                 if (pend_n + r <= 32 && pend_k < PEND_MAX) {   // the tail joins the pending batch as segment pend_k
-                    if (lane < r) { pend.idx[pend_n + lane] = sidx[32 * nfull + lane]; pend.slot[pend_n + lane] = (uint8_t)pend_k; }
+                    if (32 * nfull < win0 || count > win0 + SIDX_WINDOW) win_load(32 * nfull);
+                    if (lane < r) { pend.idx[pend_n + lane] = win[32 * nfull - win0 + lane] & (LEAD_FLAG - 1); pend.slot[pend_n + lane] = (uint8_t)pend_k; }
                     if (lane == 0) {
                         pend.ray[pend_k] = (int32_t)cur; pend.last[pend_k] = pend_n + r - 1; pend.cone[pend_k] = cone;
                         pend.acc[pend_k][0] = ra.T; pend.acc[pend_k][1] = ra.c0; pend.acc[pend_k][2] = ra.c1;
@@ -1065,6 +1215,8 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
                     if (lane == 3) a.alpha_out[ray] = 0.0f;
                     continue;
                 }
+                // The number of in-patch samples differs from ray to ray (0 .. S), so a static ray -> wave map leaves waves idle at
+                // the end (19 % on the carpet_instanced bench workload): each wave takes the next unclaimed ray instead.
                 const float *drow = a.dists + ray * S;
                 int n = 0;
                 for (int base0 = 0; base0 < S; base0 += 512) {   // 8 independent loads in flight, then their 8 ballots
@@ -1076,13 +1228,40 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
                         const int i = base0 + 64 * u + lane;
                         const bool v = dv[u] > 0.0f;
                         const unsigned long long m = __ballot(v);
-                        if (v) sidx[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+                        if (v) gsidx[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
                         n += __popcll(m);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                if (runs_on && n >= 32) {
+                    // flag the first sample of every run of the whole batches: direction / appearance inputs bit-different from the
+                    // previous in-patch sample's (64 samples per step; lane 0 compares with the previous step's last sample)
+                    constexpr int NV = 3 + CFG::NAPP;
+                    uint32_t carry[NV] = {};
+                    for (int k0 = 0; k0 < (n & ~31); k0 += 64) {
+                        const int k = k0 + lane;
+                        const bool v = k < (n & ~31);
+                        const int idx = gsidx[v ? k : 0];
+                        SampleIn<CFG::NGEO, CFG::NAPP> din;
+                        dir_inputs<CFG>(a, ray * S + idx, din);
+                        bool diff = k == 0;
+#pragma unroll
+                        for (int c = 0; c < NV; ++c) {
+                            const uint32_t bits = __builtin_bit_cast(uint32_t, c < 3 ? din.dir[c < 3 ? c : 0] : din.par[CFG::NGEO + (c < 3 ? 0 : c - 3)]);
+                            uint32_t pv = (uint32_t)__shfl_up((int)bits, 1, 64);
+                            if (lane == 0) pv = carry[c];
+                            diff = diff || pv != bits;
+                            carry[c] = (uint32_t)__shfl((int)bits, 63, 64);
+                        }
+                        if (v && diff) gsidx[k] = (uint16_t)(idx | LEAD_FLAG);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
                 cur = ray; count = n; nfull = n >> 5; b = 0;
+                grp_b0 = grp_end = 0;
+                win_load(0);
                 cone = a.cone ? a.cone[ray] : 0.0f;
                 ra = RayAccum{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                 continue;
@@ -1097,8 +1276,12 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
         int slot = 0;
         int64_t sm;
         float cone_l = cone;
+        const bool grouped = ROWS && runs_on && mode == 1;   // (wave-uniform) this batch takes its rows from a group of runs
         if (mode == 1) {
-            sm = cur * S + sidx[32 * b + j];
+            // a group never looks past the window: slide it when the batches a new group may cover would
+            if ((grouped ? b >= grp_end && 32 * (b + LEAD_GROUP_MAX) > win0 + SIDX_WINDOW : 32 * (b + 1) > win0 + SIDX_WINDOW) && count > win0 + SIDX_WINDOW)
+                win_load(32 * b);
+            sm = cur * S + (win[32 * b - win0 + j] & (LEAD_FLAG - 1));
         } else {
             valid = j < pend_n;
             const int jc = valid ? j : 0;
@@ -1127,8 +1310,47 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
 #pragma unroll
             for (int c = 0; c < CFG::NP; ++c) in.par[c] = pr[c < a.blur_idx ? c : c + 1];
         }
+
+        // ---- the rows this batch starts C1 from
+        if constexpr (ROWS) {
+            if (grouped) {
+                if (b >= grp_end) {
+                    // new group from batch b: row 0 = the run in progress at its first sample, then every flagged sample of as many
+                    // batches as the 32 rows can serve (at least this one)
+                    int nlead = 1, covered = 0;
+                    if (lane == 0) lead_pos[0] = (uint16_t)(32 * b);
+                    for (int bb = b; bb < nfull && covered < LEAD_GROUP_MAX; ++bb) {
+                        const bool f = (win[32 * bb - win0 + j] & LEAD_FLAG) != 0 && !(bb == b && j == 0);
+                        const uint32_t m = (uint32_t)__ballot(f);              // lanes j and j + 32 agree: the low word has it
+                        const int d = __popc(m);
+                        if (nlead + d > NSLOT) break;
+                        if (f && lane < 32) lead_pos[nlead + __popc(m & ((1u << j) - 1u))] = (uint16_t)(32 * bb + j);
+                        nlead += d; ++covered;
+                    }
+                    grp_b0 = b; grp_end = b + covered; slot_base = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    SampleIn<CFG::NGEO, CFG::NAPP> lin = in;   // (only dir and the appearance parameters are read)
+                    dir_inputs<CFG>(a, cur * S + (win[lead_pos[j < nlead ? j : 0] - win0] & (LEAD_FLAG - 1)), lin);
+                    leader_rows<CFG, NSLOT>(ws.rsrc, aux, rows, lin, lane);
+                }
+                const bool f = (win[32 * b - win0 + j] & LEAD_FLAG) != 0 && !(b == grp_b0 && j == 0);
+                const uint32_t m = (uint32_t)__ballot(f);
+                if (lane < 32) slots[j] = (uint8_t)(slot_base + __popc(m & ((2u << j) - 1u)));
+                slot_base += __popc(m);
+            } else {
+                // every sample its own row (packed tails: up to 8 rays meet in the batch; runs switched off)
+                if (lane < 32) slots[j] = (uint8_t)j;
+                leader_rows<CFG, NSLOT>(ws.rsrc, aux, rows, in, lane);
+                grp_end = b;                                  // whatever group there was is overwritten
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
         float sigma, raw[3];
-        mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe_column<CFG>(aux, wv, lane));
+        if constexpr (ROWS) mlp_batch<CFG, 4, false>(in, ws, aux, lane, sigma, raw, rows, nullptr, slots);
+        else mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe_col);
         const float wgt = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // :300
         sigma = sigma * wgt;
         float col[3];
@@ -1139,6 +1361,10 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
         } else {
 #pragma unroll
             for (int c = 0; c < 3; ++c) col[c] = (a.flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[c]) : sigmoidf_(raw[c]);
+        }
+        if (a.flags & NTX_FLAG_RAW_NOISE) {                                                       // :335-337
+            const int64_t ray_l = sm / S;
+            sigma += a.raw_noise_std * normal01(global_index(a.idx0, a.idx_run, a.idx_stride, ray_l), (int)(sm - ray_l * S), a.seed_lo, a.seed_hi);
         }
         const float al = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * a.dists[sm] / a.patch_scale) : 0.0f;   // :339
         if (mode == 1) {

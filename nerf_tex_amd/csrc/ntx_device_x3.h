@@ -413,7 +413,10 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
         if constexpr (CFG::CD != 0) {
             if (it % DIR_BLOCK_ITERS == 0) {   // the C1 start vectors of the next 8 rays of each wave (float32, as the f32 kernel)
                 __syncthreads();
-                dir_block<CFG>(a, dir_rsrc, aux, aux + aux_total(), it * per_it, per_it, vwg, wv, lane, n_hit);
+                const int lane_o = fresh_lane_id();   // dir_block's loop invariants are not carried across the MFMA body (ntx_device.h)
+                const RenderArgs *apd = kernargs<RenderArgs>();
+                asm volatile("" : "+s"(apd));
+                dir_block<CFG>(*apd, dir_rsrc, aux, aux + aux_total(), it * per_it, per_it, vwg, wv, lane_o, n_hit);
                 __syncthreads();
             }
         }
@@ -437,12 +440,13 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
             const bool valid = i < S;
             const int ic = valid ? i : S - 1;
             const int blur_idx = q.blur_idx;
+            const int64_t gr = (q.flags & (NTX_FLAG_PERTURB | NTX_FLAG_RAW_NOISE)) ? global_index(q.idx0, q.idx_run, q.idx_stride, r) : r;
             SampleIn<CFG::NGEO, CFG::NAPP> in;
             in.dir[0] = dx / dnorm; in.dir[1] = dy / dnorm; in.dir[2] = dz / dnorm;
             float dist;
             if constexpr (CFG::IPE == 0) {
-                const float z = z_of(q, r, ic, t0, t1, S);
-                const float zn = z_of(q, r, ic < S - 1 ? ic + 1 : ic - 1, t0, t1, S);
+                const float z = z_of(q, r, gr, ic, t0, t1, S);
+                const float zn = z_of(q, r, gr, ic < S - 1 ? ic + 1 : ic - 1, t0, t1, S);
                 dist = (ic < S - 1 ? zn - z : z - zn) * dnorm;
                 in.pos[0] = ox + dx * z; in.pos[1] = oy + dy * z; in.pos[2] = oz + dz * z;
                 in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
                     in.par[k] = p;
                 }
             } else {   // MipRenderer.render_rays (renderer.py:365-409), as in render_kernel<CFG>
-                const float e0 = z_of(q, r, ic, t0, t1, S + 1), e1 = z_of(q, r, ic + 1, t0, t1, S + 1);
+                const float e0 = z_of(q, r, gr, ic, t0, t1, S + 1), e1 = z_of(q, r, gr, ic + 1, t0, t1, S + 1);
                 dist = (e1 - e0) * dnorm;
                 float t_mean, t_var, r_var;
                 cone_moments((e0 + e1) / 2.0f, (e1 - e0) / 2.0f, prow[blur_idx] * cone, t_mean, t_var, r_var);
@@ -467,8 +471,11 @@ __global__ __launch_bounds__(256) void render_kernel_x3(RenderArgs a) {
             mlp_batch_x3<CFG>(in, ws, aux, lane, sigma, raw, aux_total() + ((it % DIR_BLOCK_ITERS) * 4 + wv) * DIR_ROW_STRIDE);
             const RenderArgs *ap2 = kernargs<RenderArgs>();
             asm volatile("" : "+s"(ap2));
+            float noise = 0.0f;   // renderer.py:190-192, as render_kernel<CFG>
+            if (ap2->flags & NTX_FLAG_RAW_NOISE)
+                noise = ap2->raw_noise_std * normal01(global_index(ap2->idx0, ap2->idx_run, ap2->idx_stride, ray), ic, ap2->seed_lo, ap2->seed_hi);
             composite_step<32>(ra, sigma, raw, dist, valid && live, ap2->flags, j,
-                               ap2->weights_out ? ap2->weights_out + r * S + ic : nullptr);
+                               ap2->weights_out ? ap2->weights_out + r * S + ic : nullptr, noise);
         }
         float out[4] = {ra.c0, ra.c1, ra.c2, ra.a};
         if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {
@@ -651,6 +658,10 @@ __global__ __launch_bounds__(256) void instance_kernel_x3(InstanceArgs a) {
         } else {
 #pragma unroll
             for (int c = 0; c < 3; ++c) col[c] = (a.flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[c]) : sigmoidf_(raw[c]);
+        }
+        if (a.flags & NTX_FLAG_RAW_NOISE) {                                                       // :335-337
+            const int64_t ray_l = sm / S;
+            sigma += a.raw_noise_std * normal01(global_index(a.idx0, a.idx_run, a.idx_stride, ray_l), (int)(sm - ray_l * S), a.seed_lo, a.seed_hi);
         }
         const float al = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * a.dists[sm] / a.patch_scale) : 0.0f;   // :339
         if (mode == 1) {

@@ -200,6 +200,8 @@ struct SamplePdfArgs {
     int n_samples, n_imp;
     float delta, delta_u;   // float32 steps of tf.linspace(0,1,S) and tf.linspace(0,1,n_imp)
     uint32_t flags, seed_lo, seed_hi;   // NTX_FLAG_PERTURB: the coarse depths carry the jitter of the render kernel
+    uint32_t idx_run;                   // ... keyed by the ray's global index (RenderArgs)
+    int64_t idx0, idx_stride;
 };
 
 __global__ __launch_bounds__(256) void sample_pdf_kernel(SamplePdfArgs a) {
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(SamplePdfArgs a) {
         }
         auto z_at = [&](int i) -> float {
             if (a.z_vals) return a.z_vals[ray * S + i];
-            if (a.flags & NTX_FLAG_PERTURB) return z_jittered(a.delta, ray, i, t0, t1, S, a.seed_lo, a.seed_hi);
+            if (a.flags & NTX_FLAG_PERTURB)
+                return z_jittered(a.delta, global_index(a.idx0, a.idx_run, a.idx_stride, ray), i, t0, t1, S, a.seed_lo, a.seed_hi);
             return z_lin(a.delta, i, t0, t1, S);
         };
         const float *w = a.weights + ray * S;
@@ -380,13 +383,15 @@ __global__ __launch_bounds__(256) void inst_scatter_kernel(const int32_t *count,
 // tests and for callers that want them.  Thread per (ray, point).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sample_depths_kernel(const float *t, int64_t n_rays, int npts, float delta, uint32_t flags,
-                                                            uint32_t seed_lo, uint32_t seed_hi, float *z_out) {
+                                                            uint32_t seed_lo, uint32_t seed_hi, int64_t idx0, uint32_t idx_run,
+                                                            int64_t idx_stride, float *z_out) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_rays * npts) return;
     const int64_t ray = k / npts;
     const int i = (int)(k % npts);
     const float t0 = t[2 * ray], t1 = t[2 * ray + 1];
-    z_out[k] = (flags & NTX_FLAG_PERTURB) ? z_jittered(delta, ray, i, t0, t1, npts, seed_lo, seed_hi) : z_lin(delta, i, t0, t1, npts);
+    z_out[k] = (flags & NTX_FLAG_PERTURB) ? z_jittered(delta, global_index(idx0, idx_run, idx_stride, ray), i, t0, t1, npts, seed_lo, seed_hi)
+                                          : z_lin(delta, i, t0, t1, npts);
 }
 
 }  // namespace ntx

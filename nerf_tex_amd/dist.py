@@ -8,8 +8,10 @@ renders chunks of rays independently), so the sharded image is bit-identical to 
 `run_length` pixels, run q belongs to rank q % world.  `run_length = ceil(n / world)` = contiguous bands;
 `run_length = image width` deals rows round-robin, which balances the rays the proxy culls.  On the GPU the gather is
 `ntx_gather_image` (RCCL `ncclGather` through the C ABI, communicator created from a `ncclUniqueId` that rank 0
-broadcasts over the existing torch.distributed group); CPU tensors (the gloo tests) go through `torch.distributed.gather`
-with the same map.
+broadcasts over the existing torch.distributed group).  Without a communicator (CPU tensors in the gloo tests; GPU shards
+only as a caller's explicit fallback) the SAME plan -- `ntx_gather_plan`: per-rank counts and block offsets, one gather when
+the counts are equal, else exact-count send/recv; `ntx_unshard_map`: the staging slot of every pixel -- is executed through
+`torch.distributed`, so the library's index arithmetic runs in both cases.
 """
 
 from __future__ import annotations
@@ -49,6 +51,27 @@ class ShardMap:
         """(pixel0, n_pixels, run_length, run_stride) of `rank` for `ntx_generate_rays_strided`."""
         return rank * self.run, self.count(rank), self.run, self.world * self.run
 
+    def ray_index(self, rank: int) -> Tuple[int, int, int]:
+        """(index0, run_length, run_stride): the global index of `rank`'s local rays, for `Renderer(..., ray_index=...)` /
+        `ntx_render_opts` -- the generators behind jitter and noise are keyed by the PIXEL, not by its place in a shard."""
+        return rank * self.run, self.run, self.world * self.run
+
+    def plan(self):
+        """`ntx_gather_plan` of this map: (counts [world], block offsets [world] in pixel slots, equal, direct)."""
+        from . import _lib
+        counts = (C.c_int64 * self.world)(); offs = (C.c_int64 * self.world)()
+        eq, direct = C.c_int(), C.c_int()
+        _lib.check(_lib.lib.ntx_gather_plan(self.n, self.run, self.world, counts, offs, C.byref(eq), C.byref(direct)))
+        return list(counts), list(offs), bool(eq.value), bool(direct.value)
+
+    def unshard_map(self):
+        """`ntx_unshard_map`: for every pixel, the pixel slot of the gather destination that holds it (numpy int64 [n])."""
+        import numpy as np
+        from . import _lib
+        src = np.empty(self.n, dtype=np.int64)
+        _lib.check(_lib.lib.ntx_unshard_map(self.n, self.run, self.world, src.ctypes.data_as(C.POINTER(C.c_int64))))
+        return src
+
     def local_pixels(self, rank: int):
         """global pixel index of every local ray of `rank` (numpy int64)."""
         import numpy as np
@@ -62,9 +85,19 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return min(rank * m.run, n), m.count(rank)
 
 
+class CommUnavailable(RuntimeError):
+    """Raised by `Comm(...)` on EVERY rank alike when any rank cannot create its communicator."""
+
+
 class Comm:
     """`ntx_comm` (RCCL communicator of the C ABI) of this process, bootstrapped over torch.distributed: rank 0 draws
-    the ncclUniqueId (`ntx_comm_unique_id`) and broadcasts its 128 bytes."""
+    the ncclUniqueId (`ntx_comm_unique_id`) and broadcasts its 128 bytes.
+
+    The ranks AGREE before any of them enters `ncclCommInitRank` (which blocks until all peers have joined): every rank runs
+    `ntx_comm_preflight` (librccl loadable, device valid), rank 0 also draws the id, and one all_gather of (ok, message)
+    decides for everybody -- a rank whose librccl cannot be loaded, or a rank 0 that cannot draw the id, makes ALL ranks raise
+    `CommUnavailable` instead of leaving its peers in mismatched collectives.  What is left is a failure inside
+    ncclCommInitRank itself; callers bound that with a deadline (bench.py: watchdog per rank + launcher timeout)."""
 
     def __init__(self, device_index: int, group=None):
         import torch
@@ -72,17 +105,27 @@ class Comm:
         from . import _lib
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.handle = None
         ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
-        if self.rank == 0:
-            _lib.check(_lib.lib.ntx_comm_unique_id(ident))
+        err = None
+        if _lib.lib.ntx_comm_preflight(device_index) != _lib.NTX_OK:
+            err = _lib.lib.ntx_last_error().decode("utf-8", "replace")
+        elif self.rank == 0 and _lib.lib.ntx_comm_unique_id(ident) != _lib.NTX_OK:
+            err = _lib.lib.ntx_last_error().decode("utf-8", "replace")
         if self.world > 1:
-            box = [bytes(ident)]
-            dist.broadcast_object_list(box, src=0, group=group)
-            ident = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(box[0])
+            votes = [None] * self.world
+            dist.all_gather_object(votes, (err, bytes(ident) if self.rank == 0 else None), group=group)
+            bad = {r: v[0] for r, v in enumerate(votes) if v[0] is not None}
+            if bad:
+                raise CommUnavailable("; ".join(f"rank {r}: {m}" for r, m in sorted(bad.items())))
+            ident = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(votes[0][1])
+        elif err is not None:
+            raise CommUnavailable(f"rank 0: {err}")
         handle = C.c_void_p()
         _lib.check(_lib.lib.ntx_comm_create(ident, self.world, self.rank, device_index, C.byref(handle)))
         self.handle = handle.value
         self.device = torch.device("cuda", device_index)
+        self.library = _lib.lib.ntx_comm_library().decode("utf-8", "replace")
         self._staging = None
 
     def gather_image(self, local_rgba, shard: ShardMap, dst: int = 0):
@@ -127,18 +170,32 @@ def gather_image(local_rgba, shard, dst: int = 0, group=None, comm: Optional[Com
         shard = ShardMap(int(shard), world)
     if local_rgba.is_cuda and comm is not None:
         return comm.gather_image(local_rgba, shard, dst)
-    # no C-ABI communicator: the same exchange through torch.distributed (gloo for the CPU plumbing tests; for GPU shards
-    # only as the caller's explicit choice, e.g. bench.py when ntx_comm_create fails on a box -- it says so in its line)
+    # no C-ABI communicator: the plan of ntx_gather_image (counts, block offsets, gather vs exact-count send/recv, un-shard map
+    # -- all from the library, csrc/ntx_shard.h) through torch.distributed (gloo for the CPU plumbing tests; for GPU shards only as
+    # the caller's explicit choice, e.g. bench.py when ntx_comm_create fails on a box -- it says so in its line)
     if world == 1:
         return local_rgba
-    cap = shard.capacity
-    pad = torch.zeros((cap,) + tuple(local_rgba.shape[1:]), dtype=local_rgba.dtype, device=local_rgba.device)
-    pad[: local_rgba.shape[0]] = local_rgba
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst, group=group)
+    counts, offs, equal, direct = shard.plan()
+    if local_rgba.shape[0] != counts[rank]:
+        raise ValueError(f"rank {rank} must pass {counts[rank]} rows, got {tuple(local_rgba.shape)}")
+    tail = tuple(local_rgba.shape[1:])
+    local_rgba = local_rgba.contiguous()
+    cap = counts[0]
+    staging = None
+    if rank == dst:
+        staging = torch.zeros((world * cap,) + tail, dtype=local_rgba.dtype, device=local_rgba.device)
+    if equal:                                                # one gather: block r lands at offs[r] = r * cap
+        bufs = [staging[offs[r]: offs[r] + cap] for r in range(world)] if rank == dst else None
+        dist.gather(local_rgba, bufs, dst=dst, group=group)
+    elif rank == dst:                                        # exact counts: recv block r at offs[r]  (ncclRecv in ntx_gather_image)
+        staging[offs[dst]: offs[dst] + counts[dst]] = local_rgba
+        reqs = [dist.irecv(staging[offs[r]: offs[r] + counts[r]], src=r, group=group) for r in range(world) if r != dst and counts[r] > 0]
+        for q in reqs:
+            q.wait()
+    elif counts[rank] > 0:
+        dist.send(local_rgba, dst=dst, group=group)
     if rank != dst:
         return None
-    image = torch.empty((shard.n,) + tuple(local_rgba.shape[1:]), dtype=local_rgba.dtype, device=local_rgba.device)
-    for r in range(world):
-        image[torch.as_tensor(shard.local_pixels(r), device=local_rgba.device)] = bufs[r][: shard.count(r)]
-    return image
+    if direct:                                               # the blocks in rank order are the image
+        return staging[: shard.n]
+    return staging[torch.as_tensor(shard.unshard_map(), device=local_rgba.device)]

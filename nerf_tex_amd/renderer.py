@@ -41,13 +41,21 @@ class Renderer:
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
         self.precision = precision
-        if raw_noise_std > 0:
-            raise NotImplementedError("raw_noise_std > 0 (renderer.py:190-192) is a training regulariser; the render path has no kernel for it")
+        if raw_noise_std < 0:
+            raise ValueError("raw_noise_std must be >= 0")
+        # The reference draws jitter and noise from TensorFlow's generator and leaves numpy's alone; so does this class: the
+        # per-call seeds come from a private generator, seeded ONCE (lazily, on the first draw) from numpy's global state
+        # (main.py:30 seeds it from the config), so data.distribution / data.sampler see the same np.random stream as under
+        # the reference however many images are rendered in between.
+        self._seed_rng = None
 
     def __call__(self, rays_o, rays_d, t, parameters, cone_scale, composite_bkgd: bool = False,
                  bkgd_color=[1, 1, 1.], training: bool = True, z_vals=None, **kwargs) -> dict:
         """rays_o/rays_d [B,HW,3], t [B,HW,2], parameters [B,P], cone_scale [B,HW,1]
-        -> {'color_pred': [B,HW,3], 'alpha_pred': [B,HW]}  (renderer.py:47-90)."""
+        -> {'color_pred': [B,HW,3], 'alpha_pred': [B,HW]}  (renderer.py:47-90).
+        Beyond the reference: `seed` (int) fixes the jitter / noise stream of the call; `ray_index` = (index0, run_length,
+        run_stride) maps the call's rays to the global ray indices that key the generators (a rank of a `dist.ShardMap` passes
+        `shard.ray_index(rank)`), so that a sharded or chunked image draws exactly what the whole image draws."""
         import torch
         dev = rays_o.device
         if dev.type != "cuda":
@@ -80,7 +88,14 @@ class Renderer:
             # generator, include/nerftex.h: ntx_sample_depths); one seed per call, drawn like everything else in
             # the reference from numpy's global generator (main.py:30 seeds it), or given by the caller
             flags |= _lib.FLAG_PERTURB
+        noise = float(self.raw_noise_std)
+        if noise > 0:                                      # renderer.py:190-192, inside the kernel (one N(0,1) per sample)
+            flags |= _lib.FLAG_RAW_NOISE
+        if flags & (_lib.FLAG_PERTURB | _lib.FLAG_RAW_NOISE):
             seed = int(kwargs["seed"]) if kwargs.get("seed") is not None else self._next_seed()
+        opts = None
+        if noise > 0 or kwargs.get("ray_index") is not None:
+            opts = _lib.render_opts(noise, seed, kwargs.get("ray_index"))
         self._last_seed = seed
         status = None
         if self.check_numerics:
@@ -99,7 +114,7 @@ class Renderer:
                 _lib.check(_lib.lib.ntx_render_rays(
                     model.ctx(dev.index or 0), rays_o.data_ptr(), rays_d.data_ptr(), t.data_ptr(),
                     params.data_ptr() if params is not None else None, HW, cone.data_ptr(), n, n_s, blur, flags,
-                    _lib.f3(bk), z_in.data_ptr() if z_in is not None else None, seed, color.data_ptr(), alpha.data_ptr(),
+                    _lib.f3(bk), z_in.data_ptr() if z_in is not None else None, seed, opts, color.data_ptr(), alpha.data_ptr(),
                     wts.data_ptr() if wts is not None else None, status.data_ptr() if status is not None else None, stream))
             return color, alpha, wts
 
@@ -115,12 +130,12 @@ class Renderer:
             with torch.cuda.device(dev):
                 _lib.check(_lib.lib.ntx_sample_pdf(t.data_ptr(), z.data_ptr() if z is not None else None, wts.data_ptr(),
                                                    u.data_ptr() if u is not None else None, n, S, NI,
-                                                   flags & _lib.FLAG_PERTURB, seed, z_all.data_ptr(), stream))
+                                                   flags & _lib.FLAG_PERTURB, seed, opts, z_all.data_ptr(), stream))
             model_imp = self.model if self.model_fine is None else self.model_fine
             c2, a2, _ = launch(model_imp, S + NI, z_all, False)
             out = {"color_pred": c2.reshape(B, HW, 3), "alpha_pred": a2.reshape(B, HW),
                    "color_pred_coarse": out["color_pred"], "alpha_pred_coarse": out["alpha_pred"]}
-            self._last_z = z_all
+            self._last_z, self._last_weights = z_all, wts       # (tests: the sampler's input and output)
         if status is not None:
             self._status = status          # read lazily: `raise_if_nonfinite()` syncs
         return out
@@ -132,21 +147,25 @@ class Renderer:
         if st is not None and int(st.item()) != 0:
             raise FloatingPointError("NaN or Inf encountered in color_pred/alpha_pred")
 
-    @staticmethod
-    def _next_seed() -> int:
+    def _next_seed(self) -> int:
         import numpy as np
-        return int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
+        if self._seed_rng is None:
+            # np.random.get_state() reads the global generator without advancing it
+            key = np.random.get_state()[1]
+            self._seed_rng = np.random.Generator(np.random.Philox(key=[int(key[0]) | (int(key[1]) << 32), int(key[2]) | (int(key[3]) << 32)]))
+        return int(self._seed_rng.integers(0, 2 ** 63 - 1, dtype=np.int64))
 
     @staticmethod
-    def sample_depths(t, n_points: int, perturb: bool = False, seed: int = 0):
+    def sample_depths(t, n_points: int, perturb: bool = False, seed: int = 0, ray_index=None):
         """z_vals of renderer.py:101-111 on their own (`ntx_sample_depths`): t [n,2] -> [n, n_points], exactly the
-        depths the fused kernel places for the same (perturb, seed)."""
+        depths the fused kernel places for the same (perturb, seed, ray_index)."""
         import torch
         t = t.reshape(-1, 2).contiguous().float()
         n = t.shape[0]
         z = torch.empty((n, n_points), device=t.device, dtype=torch.float32)
         with torch.cuda.device(t.device):
             _lib.check(_lib.lib.ntx_sample_depths(t.data_ptr(), n, n_points, _lib.FLAG_PERTURB if perturb else 0, int(seed),
+                                                  _lib.render_opts(ray_index=ray_index) if ray_index is not None else None,
                                                   z.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream))
         return z
 
@@ -239,6 +258,12 @@ class InstanceRenderer(Renderer):
         inst_col = None
         if self.instance_color is not None:
             inst_col = torch.as_tensor(self.instance_color, device=dev)
+        noise = float(self.raw_noise_std)                                                       # renderer.py:335-337
+        noise_seed = 0
+        if noise > 0:
+            flags |= _lib.FLAG_RAW_NOISE
+            noise_seed = int(kwargs["seed"]) if kwargs.get("seed") is not None else self._next_seed()
+        self._last_seed = noise_seed
         S = self.n_samples
         up = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(np.asarray(a)), device=dev).to(dt).contiguous()
         for i in range(0, keep.shape[0], self.render_chunk):                                    # renderer.py:72-73
@@ -268,7 +293,9 @@ class InstanceRenderer(Renderer):
                     ptr(bufs["dists"]), ptr(bufs["color_last"]), ptr(bufs["alpha_last"]), ptr(bufs["alpha_weight"]),
                     ptr(bufs["instance_id"]), ptr(bufs["hit"]), ptr(bufs["params_map"]) if bufs["params_map"].numel() else None,
                     ptr(c_c), k, S, -1 if self.blur_idx is None else int(self.blur_idx), self.patch_scale,
-                    float(self.density_scale), flags, _lib.f3(bk), ptr(inst_col), ptr(col_c), ptr(al_c), ptr(status),
+                    float(self.density_scale), flags, _lib.f3(bk), ptr(inst_col),
+                    _lib.render_opts(noise, noise_seed, (i, k, k)) if noise > 0 else None,   # chunk i.. of the hit rays keys the draws
+                    ptr(col_c), ptr(al_c), ptr(status),
                     torch.cuda.current_stream(dev).cuda_stream))
             color[sl] = col_c                                                                  # scatter_nd, renderer.py:83
             alpha[sl] = al_c

@@ -12,7 +12,8 @@
       64 camera rays x 32 samples (weights are regenerated from the seed; their sha256 is stored).
   (3) golden_edge.npz         -- composite edge cases.
   (4) golden_plumbing.npz     -- BASELINE configs[0]: carpet 200x200x32 image, float64 oracle, stored
-      as float32 RGBA, plus the float32 oracle's image and its rel-Linf distance from the float64 one.
+      as float32 RGBA, plus the float32 oracle's image and its rel-Linf distance from the float64 one, plus the image of
+      the float64 network on the float32 sample points (`rgba_net64`; nerftex_oracle.render_rays: points_dtype).
 Parts (2)-(4) are outputs of THIS repo's oracle (parity unpinned, see nerftex_oracle.py): they pin the
 oracle against drift and give the GPU tests fixed vectors, they do not pin it to TensorFlow."""
 
@@ -159,7 +160,14 @@ def plumbing():
     rgba32 = orc.render_image_rgba(pred32, H, W)
     floor = orc.rel_linf(rgba32, rgba)
     print("plumbing float32-vs-float64 floor: rel-Linf", floor)
+    # the exact (float64) network and composite on the sample points a float32 run evaluates (render_rays: points_dtype): what
+    # separates the float32 rounding of the INPUTS, which the floor above consists of, from the arithmetic of the network
+    pred_net = orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], S, dtype=np.float64, points_dtype=np.float32)
+    rgba_net = orc.render_image_rgba(pred_net, H, W)
+    print("plumbing: float32 restatement vs exact network on float32 points", orc.rel_linf(rgba32, rgba_net),
+          "; input-rounding floor", orc.rel_linf(rgba_net, rgba))
     np.savez_compressed(os.path.join(OUT, "golden_plumbing.npz"), rgba=rgba.astype(np.float32), rgba_f32=rgba32.astype(np.float32),
+                        rgba_net64=rgba_net.astype(np.float32), input_floor_rel_linf=orc.rel_linf(rgba_net, rgba),
                         f32_floor_rel_linf=floor, c2w=c2w, focal=focal,
                         parameters=params, b_0=np.asarray(cam["b_0"]), b_1=np.asarray(cam["b_1"]), height=H, width=W,
                         n_samples=S, weights_sha256=hashlib.sha256(blob.tobytes()).hexdigest(),
@@ -169,6 +177,9 @@ def plumbing():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["plumbing"]:                   # regenerate part (4) alone
+        plumbing()
+        sys.exit(0)
     cameras()
     for fam in ("carpet", "grass", "fur", "grass_filtered"):
         small(fam)

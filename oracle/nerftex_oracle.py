@@ -323,9 +323,10 @@ def jitter_bounds(z_vals):
     return lower, upper
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Word 0 of the Philox4x32-10 block (Salmon et al., SC'11; the generator behind tf.random.uniform) at counter
-    (c0, c1, c2, c3) under key (k0, k1); numpy uint32 arrays, element-wise.  Restated from the published algorithm."""
+def philox4x32_10(c0, c1, c2, c3, k0, k1, words: int = 1):
+    """Word 0 (words=1) or words (0, 1) (words=2) of the Philox4x32-10 block (Salmon et al., SC'11; the generator behind
+    tf.random.uniform / tf.random.normal) at counter (c0, c1, c2, c3) under key (k0, k1); numpy uint32 arrays, element-wise.
+    Restated from the published algorithm."""
     u32, u64 = np.uint32, np.uint64
     c0, c1, c2, c3 = (np.asarray(c, dtype=u32) for c in np.broadcast_arrays(c0, c1, c2, c3))
     k0 = u32(k0); k1 = u32(k1)
@@ -336,7 +337,7 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
         hi1, lo1 = (p1 >> u64(32)).astype(u32), p1.astype(u32)
         c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
         k0 = u32((int(k0) + 0x9E3779B9) & 0xFFFFFFFF); k1 = u32((int(k1) + 0xBB67AE85) & 0xFFFFFFFF)
-    return c0
+    return c0 if words == 1 else (c0, c1)
 
 
 def uniform01_from_bits(x):
@@ -345,26 +346,51 @@ def uniform01_from_bits(x):
     return bits.view(np.float32) - np.float32(1.0)
 
 
-def jitter_uniforms(n_rays: int, n_points: int, seed: int):
+def global_ray_index(n_rays: int, ray_index=None):
+    """The ray index that keys the product's generators (include/nerftex.h: ntx_render_opts): local ray k counts as
+    index0 + (k // run_length) * run_stride + k % run_length; None = k itself."""
+    k = np.arange(n_rays, dtype=np.int64)
+    if ray_index is None:
+        return k
+    i0, run, stride = (int(v) for v in ray_index)
+    return i0 + (k // run) * stride + k % run
+
+
+def jitter_uniforms(n_rays: int, n_points: int, seed: int, ray_index=None):
     """The draws the product uses for the stratified jitter (include/nerftex.h: ntx_sample_depths): Philox counter
     (sample index, ray index lo, ray index hi, 0), key (seed lo, seed hi).  TensorFlow's own stream cannot be
     reproduced; this pins OUR stream so the jittered render can be compared sample for sample."""
-    ray = np.arange(n_rays, dtype=np.uint64)[:, None]
+    ray = global_ray_index(n_rays, ray_index).astype(np.uint64)[:, None]
     i = np.arange(n_points, dtype=np.uint32)[None, :]
     bits = philox4x32_10(i, (ray & np.uint64(0xFFFFFFFF)).astype(np.uint32), (ray >> np.uint64(32)).astype(np.uint32),
                          np.uint32(0), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     return uniform01_from_bits(bits)
 
 
-def z_values_perturbed(t, n_points: int, seed: int, dtype=F32):
+def noise_normals(n_rays: int, n_points: int, seed: int, ray_index=None, dtype=F32):
+    """The N(0,1) draws the product uses for raw_noise_std (renderer.py:190-192 / 335-337; include/nerftex.h:
+    ntx_render_opts): words 0 and 1 of the Philox block at counter (sample index, ray index lo, ray index hi, 1) through the
+    first output of tf.random.normal's Box-Muller transform (random_distributions.h BoxMullerFloat: u1 = max(U(x0), 1e-7),
+    sqrt(-2 ln u1) * sin(2 pi U(x1))).  The uniforms are float32 as in TensorFlow; the transform is evaluated in `dtype`."""
+    ray = global_ray_index(n_rays, ray_index).astype(np.uint64)[:, None]
+    i = np.arange(n_points, dtype=np.uint32)[None, :]
+    x0, x1 = philox4x32_10(i, (ray & np.uint64(0xFFFFFFFF)).astype(np.uint32), (ray >> np.uint64(32)).astype(np.uint32),
+                           np.uint32(1), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, words=2)
+    u1 = np.maximum(uniform01_from_bits(x0), np.float32(1.0e-7)).astype(dtype)
+    v1 = dtype(2.0 * np.pi) * uniform01_from_bits(x1).astype(dtype) if dtype is F64 else np.float32(6.2831855) * uniform01_from_bits(x1)
+    return (np.sin(v1) * np.sqrt(dtype(-2.0) * np.log(u1))).astype(dtype)
+
+
+def z_values_perturbed(t, n_points: int, seed: int, dtype=F32, ray_index=None):
     """renderer.py:101-111 with z_rand = jitter_uniforms (float32 draws, arithmetic in `dtype`)."""
     z = z_values(t, n_points, dtype)
     lower, upper = jitter_bounds(z)
-    return lower + (upper - lower) * jitter_uniforms(z.shape[0], n_points, seed).astype(dtype)
+    return lower + (upper - lower) * jitter_uniforms(z.shape[0], n_points, seed, ray_index).astype(dtype)
 
 
 def evaluate_model(weights, spec, pts, dirs, parameters, cone_scale, z_vals, blur_idx, net_chunk, dtype=F32):
-    """Renderer.evaluate_model (renderer.py:145-168)."""
+    """Renderer.evaluate_model (renderer.py:145-168).  The blur product of :155-158 is evaluated in the dtype its operands
+    arrive in (render_rays' `points_dtype`), the model in `dtype`."""
     n, S = pts.shape[0], pts.shape[1]
     pos_flat = pts.reshape(-1, pts.shape[-1])
     dirs_flat = np.repeat(dirs, S, axis=0)
@@ -375,6 +401,7 @@ def evaluate_model(weights, spec, pts, dirs, parameters, cone_scale, z_vals, blu
         params_flat = np.concatenate([params_flat[:, :blur_idx],
                                       params_flat[:, blur_idx, None] * blur_scale_flat,
                                       params_flat[:, blur_idx + 1:]], -1)
+    pos_flat, dirs_flat, params_flat = (np.asarray(a, dtype=dtype) for a in (pos_flat, dirs_flat, params_flat))
     color, alpha = [], []
     for i in range(0, pos_flat.shape[0], net_chunk):                           # renderer.py:160-163
         c, a = model_forward(weights, spec, pos_flat[i:i + net_chunk], dirs_flat[i:i + net_chunk],
@@ -416,30 +443,49 @@ def map_model_output(color, alpha, z_vals, rays_d, composite_bkgd, bkgd_color, m
 
 def render_rays(weights, spec, rays_o, rays_d, t, parameters, cone_scale, n_samples, composite_bkgd,
                 bkgd_color, blur_idx=None, map_exr=False, net_chunk=65536, z_override=None, dtype=F32,
-                return_aux=False):
-    """Renderer.render_rays (renderer.py:92-143) with perturb=False, raw_noise_std=0, n_importance=0
-    (TF's RNG stream cannot be reproduced).  `z_override` [n,S] replaces z_vals, standing in for
-    the jittered samples of renderer.py:106-111 when the caller draws them itself."""
-    rays_o = np.asarray(rays_o, dtype=dtype); rays_d = np.asarray(rays_d, dtype=dtype)
-    t = np.asarray(t, dtype=dtype); parameters = np.asarray(parameters, dtype=dtype)
-    cone_scale = np.asarray(cone_scale, dtype=dtype)
+                return_aux=False, noise=None, points_dtype=None):
+    """Renderer.render_rays (renderer.py:92-143) with perturb=False, n_importance=0 (TF's RNG stream cannot be
+    reproduced).  `z_override` [n,S] replaces z_vals, standing in for the jittered samples of renderer.py:106-111 when the
+    caller draws them itself; `noise` [n,S] = raw_noise_std * N(0,1), standing in for tf.random.normal of :190-192.
+
+    `points_dtype` (default = `dtype`): the precision of the ELEMENTWISE ray arithmetic in front of the network -- rays_d_n (:98),
+    z_vals (:101-102), pts (:114), the blur product (:155-158).  These float32 operations have no summation order: any float32
+    run of the reference, whatever its BLAS, feeds the network exactly these bits.  `dtype=float64, points_dtype=float32` is
+    therefore "the exact network and composite on the sample points a float32 run evaluates": it separates the rounding of the
+    inputs (sample positions rounded to float32 in front of sin(2^9 x), which no float32 implementation can avoid) from the
+    arithmetic of the network and the composite (which an implementation answers for)."""
+    pd = dtype if points_dtype is None else points_dtype
+    rays_o = np.asarray(rays_o, dtype=pd); rays_d = np.asarray(rays_d, dtype=pd)
+    t = np.asarray(t, dtype=pd); parameters = np.asarray(parameters, dtype=pd)
+    cone_scale = np.asarray(cone_scale, dtype=pd)
     rays_d_n = rays_d / np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True))     # :98
-    z_vals = z_values(t, n_samples, dtype) if z_override is None else np.asarray(z_override, dtype=dtype)
+    z_vals = z_values(t, n_samples, pd) if z_override is None else np.asarray(z_override, dtype=pd)
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]    # :114 (un-normalised d)
     color, alpha = evaluate_model(weights, spec, pts, rays_d_n, parameters, cone_scale, z_vals,
                                   blur_idx, net_chunk, dtype)
+    z_vals = np.asarray(z_vals, dtype=dtype); rays_d = np.asarray(rays_d, dtype=dtype)
     color_map, alpha_map, w, _ = map_model_output(color, alpha, z_vals, rays_d, composite_bkgd,
-                                                  bkgd_color, map_exr, None, dtype)
+                                                  bkgd_color, map_exr, noise, dtype)
     out = {"color_pred": color_map, "alpha_pred": alpha_map}
     if return_aux:
         out.update({"z_vals": z_vals, "pts": pts, "raw_color": color, "raw_alpha": alpha, "weights": w})
     return out
 
 
-def sample_pdf(bins, weights, n_samples: int, det: bool = False, u=None, dtype=F32):
+def sample_pdf(bins, weights, n_samples: int, det: bool = False, u=None, dtype=F32, return_conditioning: bool = False):
     """renderer.sample_pdf (renderer.py:589-617): inverse-CDF sampling of the piecewise-constant pdf given by
     `weights` over `bins`.  det=True uses u = tf.linspace(0, 1, n); otherwise the caller supplies the
-    uniform draws `u` [n_rays, n_samples] (TF's RNG stream cannot be reproduced)."""
+    uniform draws `u` [n_rays, n_samples] (TF's RNG stream cannot be reproduced).
+
+    return_conditioning: also `allowed` [n, n_samples], how far a FLOAT32 evaluation of this very function may place each sample
+    from the value returned here (call it with dtype=float64) -- an error model of the reference's own arithmetic, not of any
+    implementation.  t = (u - cdf[below]) / denom with cdf a float32 running sum of n_bins terms <= 1: each entry carries up to
+    eps_c = n_bins * 2^-24, so t moves by up to 2 eps_c / denom and the sample by that times the bin width -- negligible in a bin
+    that holds real weight (denom ~ 1e-2: 1e-5 of a bin) and the WHOLE bin where the weight is 1e-5-ish, i.e. in the empty bins of a
+    dense medium, where the pdf is 1e-5 / sum(w) by construction (:593).  There the reference is also discontinuous: `denom < 1e-5
+    -> 1` (:613-614) sits exactly on those bins and snaps every u to the lower edge, so whether a u within eps_c of a cdf entry --
+    tf.linspace hits the flat stretches exactly -- lands in this bin or the next (`searchsorted`, :606), i.e. one bin width lower or
+    higher, is decided by the last bit.  Two correct float32 implementations (TensorFlow on two BLAS builds) differ by this much."""
     bins = np.asarray(bins, dtype=dtype)
     w = np.asarray(weights, dtype=dtype) + dtype(1e-5)                           # :593
     pdf = w / np.sum(w, -1, keepdims=True, dtype=dtype)
@@ -454,29 +500,44 @@ def sample_pdf(bins, weights, n_samples: int, det: bool = False, u=None, dtype=F
     above = np.minimum(cdf.shape[-1] - 1, inds)
     cdf_g0 = np.take_along_axis(cdf, below, -1); cdf_g1 = np.take_along_axis(cdf, above, -1)
     bins_g0 = np.take_along_axis(bins, below, -1); bins_g1 = np.take_along_axis(bins, above, -1)
-    denom = cdf_g1 - cdf_g0
-    denom = np.where(denom < dtype(1e-5), np.ones_like(denom), denom)            # :614
+    denom_raw = cdf_g1 - cdf_g0
+    denom = np.where(denom_raw < dtype(1e-5), np.ones_like(denom_raw), denom_raw)   # :614
     t = (u - cdf_g0) / denom
-    return (bins_g0 + t * (bins_g1 - bins_g0)).astype(dtype)                     # :616
+    samples = (bins_g0 + t * (bins_g1 - bins_g0)).astype(dtype)                  # :616
+    if not return_conditioning:
+        return samples
+    n_bins = cdf.shape[-1]
+    eps_c = n_bins * 2.0 ** -24
+    width = np.abs(bins_g1 - bins_g0)
+    nb = bins.shape[-1]
+    w_lo = np.abs(np.take_along_axis(bins, np.maximum(below - 1, 0), -1) - bins_g0)          # the neighbouring bins' widths
+    w_hi = np.abs(np.take_along_axis(bins, np.minimum(above + 1, nb - 1), -1) - bins_g1)
+    allowed = width * np.minimum(1.0, 2 * eps_c / np.maximum(denom_raw, 1e-30))
+    near_switch = np.abs(denom_raw / 1e-5 - 1) <= 2 * eps_c / 1e-5                # either side of :613 -> anywhere in the bin
+    allowed = np.where(near_switch, width, allowed)
+    allowed = allowed + np.where(np.abs(u - cdf_g0) <= 2 * eps_c, w_lo, 0) + np.where(np.abs(cdf_g1 - u) <= 2 * eps_c, w_hi + width, 0)
+    allowed = allowed + 4 * 2.0 ** -24 * np.abs(samples)                          # rounding of the result itself
+    return samples, allowed.astype(np.float64)
 
 
 def render_rays_hierarchical(weights_coarse, weights_fine, spec, rays_o, rays_d, t, parameters, cone_scale, n_samples,
                              n_importance, composite_bkgd, bkgd_color, perturb=True, u=None, blur_idx=None,
                              map_exr=False, net_chunk=65536, dtype=F32):
     """Renderer.render_rays with n_importance > 0 (renderer.py:92-143), jitter of the coarse samples left out.
-    Note the reference quirk `det=self.perturb` (:128): perturb=True gives the DETERMINISTIC u."""
+    Note the reference quirk `det=self.perturb` (:128): perturb=True gives the DETERMINISTIC u.
+    "z_allowed" [n, n_importance]: sample_pdf's float32 conditioning of every importance depth (see there)."""
     coarse = render_rays(weights_coarse, spec, rays_o, rays_d, t, parameters, cone_scale, n_samples, composite_bkgd,
                          bkgd_color, blur_idx, map_exr, net_chunk, None, dtype, return_aux=True)
     z_vals, w = coarse["z_vals"], coarse["weights"]
     z_mid = dtype(.5) * (z_vals[..., 1:] + z_vals[..., :-1])                     # :127
-    z_samples = sample_pdf(z_mid, w[..., 1:-1], n_importance, det=perturb, u=u, dtype=dtype)   # :128
+    z_samples, allowed = sample_pdf(z_mid, w[..., 1:-1], n_importance, det=perturb, u=u, dtype=dtype, return_conditioning=True)   # :128
     z_all = np.sort(np.concatenate([z_vals, z_samples], -1), -1)                 # :130
     fine = render_rays(weights_fine if weights_fine is not None else weights_coarse, spec, rays_o, rays_d, t,
                        parameters, cone_scale, n_samples + n_importance, composite_bkgd, bkgd_color, blur_idx, map_exr,
                        net_chunk, z_all, dtype)                                  # :131-136
     return {"color_pred": fine["color_pred"], "alpha_pred": fine["alpha_pred"],
             "color_pred_coarse": coarse["color_pred"], "alpha_pred_coarse": coarse["alpha_pred"],
-            "z_vals": z_all, "z_samples": z_samples}
+            "z_vals": z_all, "z_samples": z_samples, "z_allowed": allowed}
 
 
 def cone_segment_gaussians(rays_o, rays_d, t_vals, radii, dtype=F32):
@@ -568,7 +629,7 @@ def mip_instance_evaluate_model(weights, spec, rays_d_map, pts, t, dists, color_
 
 def renderer_call(weights, spec, rays_o, rays_d, t, parameters, cone_scale, n_samples=64,
                   composite_bkgd=False, bkgd_color=(1., 1., 1.), blur_idx=None, map_exr=False,
-                  render_chunk=32768, net_chunk=65536, dtype=F32):
+                  render_chunk=32768, net_chunk=65536, dtype=F32, points_dtype=None):
     """Renderer.__call__ (renderer.py:47-90): inputs are batched [B, HW, ...], `parameters` [B, P]."""
     rays_o = np.asarray(rays_o, dtype=dtype); rays_d = np.asarray(rays_d, dtype=dtype)
     t = np.asarray(t, dtype=dtype); parameters = np.asarray(parameters, dtype=dtype)
@@ -583,7 +644,7 @@ def renderer_call(weights, spec, rays_o, rays_d, t, parameters, cone_scale, n_sa
     for i in range(0, idxs.shape[0], render_chunk):                             # :72-77
         sl = idxs[i:i + render_chunk]
         o = render_rays(weights, spec, o_f[sl], d_f[sl], t_f[sl], p_f[sl], c_f[sl], n_samples,
-                        composite_bkgd, bkgd_color, blur_idx, map_exr, net_chunk, None, dtype)
+                        composite_bkgd, bkgd_color, blur_idx, map_exr, net_chunk, None, dtype, points_dtype=points_dtype)
         for k, v in o.items():
             outs.setdefault(k, []).append(v)
     result = {}
@@ -600,7 +661,7 @@ def renderer_call(weights, spec, rays_o, rays_d, t, parameters, cone_scale, n_sa
 
 
 def instance_map_model_output(color, color_last, alpha, alpha_last, dists, patch_scale, composite_bkgd, bkgd_color,
-                              map_exr=False, false_color=False, dtype=F32):
+                              map_exr=False, false_color=False, dtype=F32, noise=None):
     """InstanceRenderer.map_model_output (renderer.py:318-354): S marched samples plus ONE appended
     sample (color_last [n,1,3] taken as is, alpha_last [n,1] taken as an alpha, not a density)."""
     color = np.asarray(color, dtype=dtype); alpha = np.asarray(alpha, dtype=dtype)
@@ -615,6 +676,8 @@ def instance_map_model_output(color, color_last, alpha, alpha_last, dists, patch
             else:                                                                # :329-330
                 cm = dtype(1) / (dtype(1) + np.exp(-color))
         color_map = np.concatenate([cm, color_last], axis=1)                     # :331
+    if noise is not None:                                                        # :335-337: raw_noise_std * N(0,1), [n,S]
+        alpha = alpha + np.asarray(noise, dtype=dtype)
     alpha_map = np.concatenate([dtype(1) - np.exp(-np.maximum(alpha, dtype(0)) * dists / dtype(patch_scale)),
                                 alpha_last], axis=1)                             # :339
     trans = (dtype(1.) - alpha_map) + dtype(1e-10)
@@ -631,7 +694,7 @@ def instance_map_model_output(color, color_last, alpha, alpha_last, dists, patch
 def instance_evaluate_model(weights, spec, rays_d_map, pts, t, dists, color_last, alpha_last, alpha_weight, instance_id,
                             hit, params_map, cone_scale, blur_idx=None, patch_scale=1.0, density_scale=1.0,
                             density_reweighting=True, map_exr=False, composite_bkgd=False, bkgd_color=(1., 1., 1.),
-                            instance_color=None, net_chunk=65536, dtype=F32):
+                            instance_color=None, net_chunk=65536, dtype=F32, noise=None):
     """InstanceRenderer.evaluate_model (renderer.py:247-316) downstream of `instancer.get_model_input`
     (instancer.pyx:38-54), whose buffers are the arguments: rays_d_map/pts [n,S,3], t/dists/alpha_weight [n,S],
     color_last [n,1,3], alpha_last [n,1], instance_id [n,S] int32, hit [n] bool, params_map [n,S,P].
@@ -671,7 +734,8 @@ def instance_evaluate_model(weights, spec, rays_d_map, pts, t, dists, color_last
     if instance_color is not None:                                               # :306-307
         color = np.asarray(instance_color, dtype=dtype)[instance_id.reshape(-1)].reshape(color.shape)
     cm, am = instance_map_model_output(color, color_last, alpha, alpha_last, dists, patch_scale, composite_bkgd,
-                                       bkgd_color, map_exr, instance_color is not None, dtype)
+                                       bkgd_color, map_exr, instance_color is not None, dtype,
+                                       None if noise is None else np.asarray(noise)[idxs])   # `noise` [n_rays,S] like dists
     color_map = np.zeros((n_rays, 3), dtype); alpha_map = np.zeros((n_rays,), dtype)   # :313-314: culled rays stay 0,
     color_map[idxs] = cm; alpha_map[idxs] = am                                         # even with composite_bkgd
     return color_map, alpha_map

@@ -45,3 +45,19 @@ def camera_rays(family, height, width, dtype=np.float32, angle_scale=2.5):
     focal = orc.focal_from_angle(width, fam["angle"] * angle_scale)
     loc = orc.full_pixels(height, width)
     return orc.proxy_rays(loc, height, width, focal, c2w, fam["b_0"], fam["b_1"], dtype), c2w, focal
+
+
+def importance_depths(z_merged, z_coarse):
+    """The n_importance depths of a merged, sorted [n, S + NI] array (renderer.py:130) given the S coarse ones it contains
+    (multiset difference per ray, order kept)."""
+    out = []
+    for m, c in zip(np.asarray(z_merged), np.asarray(z_coarse)):
+        res, i = [], 0
+        for v in m:
+            if i < len(c) and v == c[i]:
+                i += 1
+            else:
+                res.append(v)
+        assert i == len(c), "the merged depths do not contain the coarse ones"
+        out.append(res)
+    return np.asarray(out)

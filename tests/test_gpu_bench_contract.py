@@ -37,6 +37,38 @@ def test_default_line_has_the_contract_fields():
     assert x3["value"] > d["value"] and x3["rel_linf_vs_float32_kernel"] < 1e-4
     jit = d["perturb"]                                  # the reference's default perturb=True, jitter drawn inside the kernel
     assert jit["value"] > 0.97 * d["value"]
+    p = d["parity"]                                     # the second half of the metric: rel-Linf of the timed image vs the restatement
+    assert p["rays"] == 256 and p["ok"] is True and p["rel_linf_f32"] <= 1e-4 and p["tolerance"] == 1e-4 and p["rel_linf_f64"] < 5e-4
+    s_ = d["with_ray_setup"]                            # with and without ray setup
+    assert s_["unit"] == "ray-samples/s" and 0.97 * d["value"] < s_["value"] <= 1.01 * d["value"] and s_["ms"] >= s_["ms_without"] * 0.999
+
+
+def test_sharded_workload_line_at_one_gpu():
+    """BASELINE configs[3] through the bench at N = 1: rays generated on the device per step in `with_ray_setup`, parity block on the
+    true camera's rays (hits and misses), the multi-rank fields absent."""
+    d = _run("--workload", "fur_sharded", "--no-cpu-baseline")
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and "per_rank" not in d and "gather_bytes" not in d
+    assert d["parity"]["ok"] is True and d["parity"]["rel_linf_f32"] <= 1e-4
+    assert "ntx_generate_rays_strided" in d["with_ray_setup"]["what"] and d["with_ray_setup"]["value"] > 0.95 * d["value"]
+
+
+MULTI_RANK_FIELDS = ("per_rank", "gather_bytes", "gather_how", "imbalance", "rank0_alone_ms")
+
+
+def test_multi_rank_line_schema():
+    """The fields an N > 1 line carries (per-rank kernel / gather times, gather bytes, imbalance, efficiency against rank 0
+    alone), checked on the 2-GPU run when the box has two GPUs; on a 1-GPU box the launcher must give up cleanly instead of hanging."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--deadline", "240",
+                              "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode != 0 and "[rank " in out.stderr      # rank 1 has no GPU: its failure ends rank 0 too, labelled tails echoed
+        return
+    d = _run("--gpus", "2", "--no-cpu-baseline")
+    for k in MULTI_RANK_FIELDS + ("efficiency_vs_rank0_alone",):
+        assert k in d, k
+    assert len(d["per_rank"]) == 2 and all(set(p) >= {"rank", "kernel_ms", "gather_ms", "rays", "hits"} for p in d["per_rank"])
+    assert d["gather_bytes"] == 640000 * 16 and 1.0 <= d["imbalance"] < 1.1 and 0.8 < d["efficiency_vs_rank0_alone"] <= 1.05
 
 
 def test_cpu_baseline_block():

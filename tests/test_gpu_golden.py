@@ -108,12 +108,18 @@ def test_golden_plumbing_image_through_render_harness():
     # North-star gate: match the reference's FLOAT32 render within 1e-4 rel-Linf.  TensorFlow cannot run, so
     # the float32 numpy restatement stands in for it (same float32 sample positions and encoder arguments).
     err32 = orc.rel_linf(rgba, g["rgba_f32"])
-    # Against the float64 truth the float32 restatement itself is `floor` away (1.03e-4 on this image: the
-    # dense-media weights amplify the float32 rounding of the sample positions through sin(2^9 x)); the HIP
-    # path must not be worse than that floor by more than a quarter.
+    # The arithmetic the kernel answers for, against the truth: the float64 network and composite on the float32 sample
+    # points (elementwise float32 ray arithmetic has no summation order: every float32 run of the reference feeds its network
+    # these bits; oracle render_rays: points_dtype).  Same strict gate.
+    err_net = orc.rel_linf(rgba, g["rgba_net64"])
+    # Against the all-float64 image there is, on top, the rounding of the INPUTS -- sample positions |x| <= 6 rounded to
+    # float32 (|dx| <= 2^-24 |x| per operation of o + d z) in front of sin(2^9 x): an error model of the reference's own
+    # float32, measured between the two float64 images (no kernel involved): 1.0e-4 on this image.
     err64 = orc.rel_linf(rgba, g["rgba"])
-    floor = float(g["f32_floor_rel_linf"])
-    print(f"plumbing image: HIP vs f32 oracle {err32:.3e}, HIP vs f64 oracle {err64:.3e}, f32 floor {floor:.3e}")
+    input_floor = float(g["input_floor_rel_linf"])
+    print(f"plumbing image: HIP vs f32 restatement {err32:.3e}, vs f64 network on f32 points {err_net:.3e}, vs all-f64 {err64:.3e} "
+          f"(input-rounding floor {input_floor:.3e})")
     assert err32 <= TOL, err32
-    assert err64 <= max(TOL, 1.25 * floor), (err64, floor)
+    assert err_net <= TOL, err_net
+    assert err64 <= err_net + input_floor * (1 + 1e-6) + 1e-9, (err64, err_net, input_floor)   # the triangle inequality of that model, nothing looser
     assert abs(float(rgba.astype(np.float64).sum()) - float(g["rgba_f64_sum"])) / float(g["rgba_f64_sum"]) <= 1e-5

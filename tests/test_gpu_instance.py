@@ -19,9 +19,10 @@ TOL_FP16X3_INSTANCED = 1e-4
 class FakeInstancer:
     """Random in-patch segments per ray: exactly the buffer shapes/dtypes of instancer.get_model_input."""
 
-    def __init__(self, n_params, seed=0, p_hit=0.8, p_in=0.35, n_inst=7):
+    def __init__(self, n_params, seed=0, p_hit=0.8, p_in=0.35, n_inst=7, run_len=None, n_geo=1):
         self.rng = np.random.default_rng(seed)
         self.n_params, self.p_hit, self.p_in, self.n_inst = n_params, p_hit, p_in, n_inst
+        self.run_len, self.n_geo = run_len, n_geo
         self.last = None
 
     def n_instances(self):
@@ -44,6 +45,36 @@ class FakeInstancer:
         alpha_weight = 1.0 / rng.integers(1, 4, size=(n, S))
         instance_id = rng.integers(0, self.n_inst, size=(n, S)).astype(np.int32)
         params_map = np.repeat(parameters[:, None, :], S, axis=1) * rng.uniform(0.5, 1.0, size=(n, S, 1))
+        if self.run_len is not None:
+            # What the reference's instancer really hands out (instancer.cpp:889-960): the marching samples of a ray fall into RUNS,
+            # one patch instance each; direction (getDir(ray, instance)), light direction and the other appearance parameters are
+            # constant along a run, the texture-mapped geometry parameters and the position vary per sample.  Runs of 1 ..
+            # run_len samples, in or out of a patch as a whole; a run may be followed by one of the SAME instance (same inputs).
+            seg = np.zeros((n, S), np.int64)
+            for r in range(n):
+                k = 0; q = 0
+                while k < S:
+                    ln = int(rng.integers(1, self.run_len + 1))
+                    seg[r, k:k + ln] = q; k += ln; q += 1
+            nseg = int(seg.max()) + 1
+            per = lambda shape: rng.uniform(size=(n, nseg) + shape)
+            sd = rng.normal(size=(n, nseg, 3)); sd /= np.linalg.norm(sd, axis=-1, keepdims=True)
+            same = rng.uniform(size=(n, nseg)) < 0.15                    # this run repeats its predecessor's instance
+            for q in range(1, nseg):
+                sd[:, q][same[:, q]] = sd[:, q - 1][same[:, q]]
+            app = 0.5 + 0.5 * per((1,))
+            for q in range(1, nseg):
+                app[:, q][same[:, q]] = app[:, q - 1][same[:, q]]
+            take = lambda a: np.take_along_axis(a, seg[..., None], 1)
+            rays_d_map = take(sd)
+            params_map = np.repeat(parameters[:, None, :], S, axis=1).astype(np.float64)
+            params_map[..., self.n_geo:] *= take(app)                                       # appearance: per run
+            params_map[..., :self.n_geo] *= rng.uniform(0.5, 1.0, size=(n, S, 1))            # geometry: per sample
+            inside = np.take_along_axis(rng.uniform(size=(n, nseg)) < self.p_in, seg, 1)
+            dists = np.where(inside, rng.uniform(0.5, 2.0, size=(n, S)) * step_size, 0.0)
+            instance_id = np.take_along_axis(rng.integers(0, self.n_inst, size=(n, nseg)), seg, 1).astype(np.int32)
+            if n > 3:
+                dists[0] = 0.0
         f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
         out = (f(rays_d_map), f(pts), f(t), f(dists), f(color_last), f(alpha_last), f(alpha_weight), instance_id,
                np.nonzero(hit)[0][:, None], f(params_map))
@@ -92,6 +123,115 @@ def test_instance_renderer(npar, blur, S, opts, precision):
     kept = np.nonzero(keep)[0]
     assert np.all(got[kept[~hit]] == 0.0)                             # un-hit rays stay 0, even with background (:313-314)
     assert float(want_a.max()) > 0.3
+
+
+def _render_instanced_raw(model, bufs, hit, cone, S, precision="float32", blur=-1):
+    from nerf_tex_amd import _lib
+    rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map = bufs
+    n = dists.shape[0]
+    dv = torch.device("cuda", 0)
+    d = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), device=dv).to(dt).contiguous()
+    t_ = dict(rd=d(rays_d_map), pts=d(pts), t=d(tt), dists=d(dists), cl=d(color_last.reshape(n, 3)), al=d(alpha_last.reshape(n)),
+              aw=d(alpha_weight), iid=d(instance_id, torch.int32), hit=d(hit, torch.uint8), pm=d(params_map), cone=d(cone))
+    col = torch.empty((n, 3), device=dv); alp = torch.empty((n,), device=dv)
+    model.reserve(0, n)
+    _lib.check(_lib.lib.ntx_render_instanced(
+        model.ctx(0), t_["rd"].data_ptr(), t_["pts"].data_ptr(), t_["t"].data_ptr(), t_["dists"].data_ptr(), t_["cl"].data_ptr(),
+        t_["al"].data_ptr(), t_["aw"].data_ptr(), t_["iid"].data_ptr(), t_["hit"].data_ptr(), t_["pm"].data_ptr(), t_["cone"].data_ptr(),
+        n, S, blur, 0.09, 400.0, _lib.PRECISIONS[precision], _lib.f3([1, 1, 1.]), None, None, col.data_ptr(), alp.data_ptr(), None,
+        torch.cuda.current_stream(dv).cuda_stream))
+    torch.cuda.synchronize()
+    return np.concatenate([col.cpu().numpy(), alp.cpu().numpy()[:, None]], -1)
+
+
+@pytest.mark.parametrize("npar,blur,run_len,S", [((1, 6), None, 40, 600), ((1, 6), None, 5, 300), ((2, 3), 0, 24, 400), ((1, 4), None, 100, 1024),
+                                                 ((2, 5), 1, 16, 300), ((1, 6), 3, 16, 200)])
+def test_instance_runs_share_their_direction_features(npar, blur, run_len, S, monkeypatch):
+    """The instancer fills direction and appearance parameters per (ray, patch instance) (instancer.cpp:943-960), so they are
+    constant along a run of in-patch samples; instance_kernel evaluates C1's direction segment once per run (leader_rows) and the
+    samples start from their run's row.  Synthetic instancer output with that structure -- runs of 1 .. run_len samples, runs that
+    cross batches, repeated instances, per-sample geometry parameters; blur_idx on a geometry parameter and (last case) on an
+    APPEARANCE parameter, which makes every sample its own run -- against the float64 oracle, and bit for bit against a context
+    created under NERFTEX_NO_DIR_HOIST, which treats every sample as its own run."""
+    model, spec, w = make_model(npar, dense_media=True)
+    P = sum(npar)
+    inst = FakeInstancer(P, seed=run_len + S, p_hit=0.9, p_in=0.5, run_len=run_len, n_geo=npar[0])
+    n = 700
+    rng = np.random.default_rng(8)
+    params = rng.uniform(0.2, 1, size=(n, P)).astype(np.float32)
+    bufs = inst.get_model_input(np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), params, S, 0.002)
+    rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map = bufs
+    hit = np.zeros(n, np.uint8); hit[idxs[:, 0]] = 1
+    cone = rng.uniform(1e-3, 5e-3, size=n).astype(np.float32)
+    b = -1 if blur is None else blur
+    got = _render_instanced_raw(model, bufs, hit, cone, S, blur=b)
+    rc, ra = orc.instance_evaluate_model(w, spec, rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id,
+                                         hit.astype(bool), params_map, cone[:, None], blur, 0.09, 400.0, True, False, False, (1., 1., 1.),
+                                         None, dtype=np.float64)
+    assert orc.rel_linf(got, np.concatenate([rc, ra[:, None]], -1)) <= TOL
+    monkeypatch.setenv("NERFTEX_NO_DIR_HOIST", "1")
+    model2, _, _ = make_model(npar, dense_media=True)
+    assert np.array_equal(_render_instanced_raw(model2, bufs, hit, cone, S, blur=b), got)
+    monkeypatch.delenv("NERFTEX_NO_DIR_HOIST")
+    # the runs are really there: consecutive in-patch samples mostly share their direction
+    ins = dists > 0
+    same = (rays_d_map[:, 1:] == rays_d_map[:, :-1]).all(-1) & ins[:, 1:] & ins[:, :-1]
+    assert same.sum() > 0.5 * (ins[:, 1:] & ins[:, :-1]).sum()
+
+
+@pytest.mark.parametrize("precision", ["float32", "fp16x3"])
+def test_instance_renderer_raw_noise(precision):
+    """InstanceRenderer.map_model_output adds raw_noise_std * N(0,1) to the (scaled) density before the relu (renderer.py:335-337);
+    drawn inside the kernel from the restated generator, keyed by (seed, ray among the proxy-hit rays, marching sample)."""
+    from nerf_tex_amd.renderer import InstanceRenderer
+    model, spec, w = make_model((1, 6), dense_media=True)
+    inst = FakeInstancer(7, seed=13, run_len=20)
+    S, n, std, seed = 120, 90, 25.0, 4711                       # the density is scaled by 400 before the noise: std of that order
+    r = InstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=0.09, step_size=0.002, density_scale=400.0,
+                         raw_noise_std=std, precision=precision)
+    rng = np.random.default_rng(3)
+    ro = rng.normal(size=(1, n, 3)).astype(np.float32); rd = rng.normal(size=(1, n, 3)).astype(np.float32)
+    t = np.tile(np.asarray([[1.0, 2.0]], np.float32), (1, n, 1)); t[0, 7] = np.inf
+    params = rng.uniform(0.2, 1, size=(1, 7)).astype(np.float32)
+    cone = rng.uniform(1e-3, 5e-3, size=(1, n, 1)).astype(np.float32)
+    dv = torch.device("cuda", 0)
+    d = lambda a: torch.as_tensor(a, device=dv)
+    out = r(d(ro), d(rd), d(t), parameters=d(params), cone_scale=d(cone), seed=seed)
+    r.raise_if_nonfinite()
+    rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map, hit = inst.last
+    keep = np.isfinite(t[0, :, 0])
+    noise = std * orc.noise_normals(int(keep.sum()), S, seed, dtype=np.float64)
+    args = (w, spec, rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, hit, params_map, cone[0][keep], None,
+            0.09, 400.0, True, False, False, (1., 1., 1.), None)
+    rc, ra = orc.instance_evaluate_model(*args, dtype=np.float64, noise=noise)
+    got = np.concatenate([out["color_pred"][0].cpu().numpy()[keep], out["alpha_pred"][0].cpu().numpy()[keep][:, None]], -1)
+    assert orc.rel_linf(got, np.concatenate([rc, ra[:, None]], -1)) <= TOL
+    rc0, ra0 = orc.instance_evaluate_model(*args, dtype=np.float64)
+    assert orc.rel_linf(got, np.concatenate([rc0, ra0[:, None]], -1)) > 10 * TOL
+
+
+def test_instance_rays_longer_than_the_index_window():
+    """A ray's compacted index list lives in the context's global scratch and is read through a 1024-entry window in LDS; rays
+    with up to 4096 in-patch samples slide it (also at the tail, and while groups of runs look ahead)."""
+    model, spec, w = make_model((1, 6), dense_media=True)
+    S, n = 4096, 24
+    inst = FakeInstancer(7, seed=77, p_hit=1.0, p_in=0.8, run_len=60)
+    rng = np.random.default_rng(5)
+    params = rng.uniform(0.2, 1, size=(n, 7)).astype(np.float32)
+    bufs = list(inst.get_model_input(np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), params, S, 0.002))
+    bufs[3][1] = np.abs(bufs[3][1]) + 1e-4                      # one ray with all 4096 samples inside
+    bufs[3][2, 1100:] = 0.0                                     # one that just crosses the window
+    bufs[3] = bufs[3] * 0.02                                    # thin media: the far samples still count
+    rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map = bufs
+    hit = np.zeros(n, np.uint8); hit[idxs[:, 0]] = 1
+    cone = rng.uniform(1e-3, 5e-3, size=n).astype(np.float32)
+    got = _render_instanced_raw(model, bufs, hit, cone, S)
+    assert (dists > 0).sum(-1).max() == 4096 and ((dists > 0).sum(-1) > 1024).sum() > 10
+    rc, ra = orc.instance_evaluate_model(w, spec, rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id,
+                                         hit.astype(bool), params_map, cone[:, None], None, 0.09, 400.0, True, False, False, (1., 1., 1.),
+                                         None, dtype=np.float64)
+    assert orc.rel_linf(got, np.concatenate([rc, ra[:, None]], -1)) <= TOL
+    assert np.array_equal(_render_instanced_raw(model, bufs, hit, cone, S), got)
 
 
 def test_instance_renderer_fp16x3_many_rays_lockstep():
@@ -189,7 +329,7 @@ def test_packed_tails_do_not_depend_on_the_company(precision):
         _lib.check(_lib.lib.ntx_render_instanced(
             model.ctx(0), t_["rd"].data_ptr(), t_["pts"].data_ptr(), t_["t"].data_ptr(), t_["dists"].data_ptr(), t_["cl"].data_ptr(),
             t_["al"].data_ptr(), t_["aw"].data_ptr(), t_["iid"].data_ptr(), t_["hit"].data_ptr(), t_["pm"].data_ptr(), t_["cone"].data_ptr(),
-            k, S, -1, 0.09, 400.0, flags, _lib.f3([1, 1, 1.]), None, col.data_ptr(), alp.data_ptr(), None,
+            k, S, -1, 0.09, 400.0, flags, _lib.f3([1, 1, 1.]), None, None, col.data_ptr(), alp.data_ptr(), None,
             torch.cuda.current_stream(dv).cuda_stream))
         torch.cuda.synchronize()
         return np.concatenate([col.cpu().numpy(), alp.cpu().numpy()[:, None]], -1)

@@ -162,13 +162,93 @@ def test_render_with_in_kernel_jitter(family, S, precision):
     plain = Renderer(model=model, n_samples=S, perturb=False, blur_idx=fam["blur_idx"], precision=precision)(
         *to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0])
     assert orc.rel_linf(rgba_of(plain)[hit], rgba_ref(ref)) > 10 * TOL
-    # a second call draws another seed from numpy's global generator (main.py:30 seeds it): reproducible run to run
+    # calls without `seed` draw from the renderer's private generator, seeded once from numpy's global state (main.py:30 seeds that
+    # from the config) and never advancing it: reproducible run to run, a new seed per call, np.random untouched
+    mk = lambda: Renderer(model=model, n_samples=S, perturb=True, blur_idx=fam["blur_idx"], precision=precision)
+    args = (to_dev(ro[None], rd[None], t[None]), dict(parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0]))
     np.random.seed(5)
-    a = rgba_of(r(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0]))
-    s1 = r._last_seed
+    r1 = mk()
+    a = rgba_of(r1(*args[0], **args[1])); s1 = r1._last_seed
+    a2 = rgba_of(r1(*args[0], **args[1])); s2 = r1._last_seed
+    state = np.random.get_state()[1].copy()
     np.random.seed(5)
-    b = rgba_of(r(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0]))
-    assert s1 == r._last_seed and np.array_equal(a, b) and not np.array_equal(a, got)
+    assert np.array_equal(np.random.get_state()[1], state)                  # the global stream was not consumed
+    r2 = mk()
+    b = rgba_of(r2(*args[0], **args[1]))
+    assert s1 == r2._last_seed and s1 != s2 and np.array_equal(a, b) and not np.array_equal(a, got) and not np.array_equal(a, a2)
+
+
+@pytest.mark.parametrize("family,S,precision,perturb", [("carpet", 64, "float32", False), ("grass_filtered", 40, "float32", True),
+                                                        ("fur", 33, "fp16x3", False)])
+def test_render_with_raw_noise(family, S, precision, perturb):
+    """raw_noise_std > 0 (renderer.py:190-192; configs/config_grass_filtered_train.py:99): sigma += std * N(0,1) before the relu,
+    drawn inside the kernel.  Checked against the oracle fed with the restated draws of the same (seed, ray, sample) -- Box-Muller
+    of two Philox words, counter word 3 = 1 -- on top of the restated jitter when perturb is on."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES[family]
+    model, spec, w = make_model(fam["n_parameters"], dense_media=True)
+    (ro, rd, t, cone), _, _ = camera_rays(family, 12, 16)
+    n = ro.shape[0]
+    params = np.asarray([fam["params"]], np.float32)
+    seed, std = 20240929, 0.75
+    kw = dict(parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0])
+    r = Renderer(model=model, n_samples=S, perturb=perturb, raw_noise_std=std, blur_idx=fam["blur_idx"], precision=precision)
+    out = r(*to_dev(ro[None], rd[None], t[None]), seed=seed, **kw)
+    r.raise_if_nonfinite()
+    hit = np.isfinite(t[:, 0])
+    tz = np.where(np.isfinite(t), t, 0).astype(np.float32)
+    z = orc.z_values_perturbed(tz, S, seed, np.float32)[hit] if perturb else None
+    noise = std * orc.noise_normals(n, S, seed, dtype=np.float64)[hit]         # ray index = index within the call
+    ref = orc.render_rays(w, spec, ro[hit], rd[hit], t[hit], np.repeat(params, hit.sum(), 0), cone[hit], S, False, (1, 1, 1.),
+                          fam["blur_idx"], z_override=z, dtype=np.float64, noise=noise)
+    got = rgba_of(out)
+    assert orc.rel_linf(got[hit], rgba_ref(ref)) <= TOL
+    assert np.all(got[~hit] == 0)
+    quiet = Renderer(model=model, n_samples=S, perturb=perturb, blur_idx=fam["blur_idx"], precision=precision)(
+        *to_dev(ro[None], rd[None], t[None]), seed=seed, **kw)
+    assert orc.rel_linf(rgba_of(quiet)[hit], rgba_ref(ref)) > 10 * TOL      # the noise is really in
+    again = r(*to_dev(ro[None], rd[None], t[None]), seed=seed, **kw)
+    other = r(*to_dev(ro[None], rd[None], t[None]), seed=seed + 1, **kw)
+    assert np.array_equal(rgba_of(again), got) and not np.array_equal(rgba_of(other), got)
+
+
+def test_jitter_and_noise_are_keyed_by_the_global_ray():
+    """the generators' counter used to be the ray index WITHIN THE CALL, so a chunked or sharded image repeated its
+    pattern in every part and could not be reproduced on one GPU.  With the ray index map of ntx_render_opts (Renderer: ray_index)
+    the image is bit-identical however it is split: contiguous chunks, and the interleaved pixel sets of a 3-rank shard map."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.dist import ShardMap
+    from nerf_tex_amd.renderer import Renderer
+    fam = synthetic.FAMILIES["carpet"]
+    model, spec, w = make_model((1, 6), dense_media=True)
+    H, W, S = 20, 26, 40
+    (ro, rd, t, cone), _, _ = camera_rays("carpet", H, W)
+    n = H * W
+    params = to_dev(np.asarray([fam["params"]], np.float32))[0]
+    r = Renderer(model=model, n_samples=S, perturb=True, raw_noise_std=0.4)
+    sub = lambda idx, **kw: rgba_of(r(*to_dev(ro[None, idx], rd[None, idx], t[None, idx]), parameters=params,
+                                      cone_scale=to_dev(cone[None, idx])[0], seed=99, **kw))
+    whole = sub(np.arange(n))
+    parts = np.concatenate([sub(np.arange(k0, min(k0 + 173, n)), ray_index=(k0, 173, 173)) for k0 in range(0, n, 173)])
+    assert np.array_equal(parts, whole)
+    assert not np.array_equal(np.concatenate([sub(np.arange(k0, min(k0 + 173, n))) for k0 in range(0, n, 173)]), whole)
+    for run in (W, 7, None):                               # rows round-robin, ragged runs, bands
+        shard = ShardMap(n, 3, run)
+        img = np.zeros_like(whole)
+        for rank in range(3):
+            pix = shard.local_pixels(rank)
+            img[pix] = sub(pix, ray_index=shard.ray_index(rank))
+        assert np.array_equal(img, whole), run
+    # the depths alone, against the restatement of the same map
+    from nerf_tex_amd.renderer import Renderer as R
+    shard = ShardMap(n, 4, 5)
+    tz = np.where(np.isfinite(t), t, 1).astype(np.float32)
+    for rank in range(4):
+        pix = shard.local_pixels(rank)
+        z = R.sample_depths(to_dev(tz[pix])[0], S, perturb=True, seed=31, ray_index=shard.ray_index(rank)).cpu().numpy()
+        assert np.array_equal(z, orc.z_values_perturbed(tz[pix], S, 31, np.float32, ray_index=shard.ray_index(rank)))
+        assert np.array_equal(z, orc.z_values_perturbed(tz, S, 31, np.float32)[pix])
 
 
 def test_mip_renderer_with_in_kernel_jitter():
@@ -283,7 +363,7 @@ def _raw_render(model, n, S, blur_idx, flags, sentinel=-7.0):
     params = to_dev(np.asarray([fam["params"]], np.float32))[0]
     color = torch.full((n, 3), sentinel, device=dev()); alpha = torch.full((n,), sentinel, device=dev())
     rc = _lib.lib.ntx_render_rays(model.ctx(0), dro.data_ptr(), drd.data_ptr(), dt.data_ptr(), params.data_ptr(), n, dcone.data_ptr(), n, S,
-                                  blur_idx, flags, _lib.f3([1, 1, 1.]), None, 0, color.data_ptr(), alpha.data_ptr(), None, None,
+                                  blur_idx, flags, _lib.f3([1, 1, 1.]), None, 0, None, color.data_ptr(), alpha.data_ptr(), None, None,
                                   torch.cuda.current_stream(dev()).cuda_stream)
     torch.cuda.synchronize()
     return rc, color, alpha

@@ -276,12 +276,14 @@ def test_ipe_and_cone_gaussians():
 
 def test_philox_known_answer_vectors():
     """The counter-based generator behind the in-kernel jitter is pinned to the published known-answer vectors of
-    Philox4x32-10 (Random123 kat_vectors: counter, key -> first output word)."""
+    Philox4x32-10 (Random123 kat_vectors: counter, key -> first two output words; the noise draw uses both)."""
     u32 = np.uint32
-    for ctr, key, want in [((0, 0, 0, 0), (0, 0), 0x6627E8D5),
-                           ((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF), 0x408F276D),
-                           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0), 0xD16CFE09)]:
+    for ctr, key, want, want1 in [((0, 0, 0, 0), (0, 0), 0x6627E8D5, 0xE169C58D),
+                                  ((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF), 0x408F276D, 0x41C83B0E),
+                                  ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0), 0xD16CFE09, 0x94FDCCEB)]:
         assert int(orc.philox4x32_10(*[u32(c) for c in ctr], key[0], key[1])) == want
+        w0, w1 = orc.philox4x32_10(*[u32(c) for c in ctr], key[0], key[1], words=2)
+        assert (int(w0), int(w1)) == (want, want1)
     # TensorFlow's Uint32ToFloat: low 23 bits -> [1,2) - 1
     assert orc.uniform01_from_bits(np.uint32(0)) == 0.0 and orc.uniform01_from_bits(np.uint32(0xFFFFFFFF)) == np.float32(1.0 - 2.0 ** -23)
 
@@ -299,6 +301,27 @@ def test_perturbed_depths_stay_in_their_strata():
         assert not np.array_equal(z, orc.z_values_perturbed(t, n, 12346, np.float32))
         u = orc.jitter_uniforms(200, n, 12345)
         assert u.min() >= 0.0 and u.max() < 1.0
+
+
+def test_noise_normals_are_standard_normal_and_keyed_by_the_global_ray():
+    """raw_noise_std (renderer.py:190-192): Box-Muller of two Philox words -> N(0,1); the stream is apart from the jitter's and
+    is a function of the GLOBAL ray index, so a shard draws what the whole image draws."""
+    n = orc.noise_normals(4000, 64, 2024)
+    assert n.dtype == np.float32 and abs(n.mean()) < 0.01 and abs(n.std() - 1) < 0.01
+    assert abs((n ** 3).mean()) < 0.05 and abs((n ** 4).mean() - 3) < 0.1 and np.abs(n).max() < 6.0    # sqrt(-2 ln 1e-7) = 5.68
+    assert np.abs(orc.noise_normals(100, 8, 2024, dtype=np.float64) - n[:100, :8]).max() < 1e-5
+    whole = orc.noise_normals(96, 5, 7)
+    for rank in range(4):                                     # rows of 8 pixels dealt round-robin over 4 ranks
+        k = np.arange(24)
+        pix = rank * 8 + (k // 8) * 32 + k % 8
+        assert np.array_equal(orc.noise_normals(24, 5, 7, (rank * 8, 8, 32)), whole[pix])
+        assert np.array_equal(orc.jitter_uniforms(24, 5, 7, (rank * 8, 8, 32)), orc.jitter_uniforms(96, 5, 7)[pix])
+    assert not np.array_equal(orc.noise_normals(4, 4, 7), orc.noise_normals(4, 4, 8))
+    # noise enters before the relu (renderer.py:195): sigma = -1 with noise +3 is as dense as sigma = 2
+    col = np.zeros((1, 2, 3)); z = np.array([[1., 2.]]); d = np.array([[0., 0., 1.]])
+    a = orc.map_model_output(col, np.array([[-1., -1.]]), z, d, False, (1, 1, 1), noise=np.array([[3., 0.]]), dtype=np.float64)
+    b = orc.map_model_output(col, np.array([[2., -1.]]), z, d, False, (1, 1, 1), dtype=np.float64)
+    assert np.array_equal(a[1], b[1]) and a[1][0] > 0.8
 
 
 def test_torch_cpu_baseline_port_agrees_with_the_oracle():

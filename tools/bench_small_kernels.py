@@ -60,7 +60,7 @@ t = torch.stack([torch.full((N,), 2.0, device=dev), torch.full((N,), 6.0, device
 wts = torch.rand((N, S), device=dev)
 z_all = torch.empty((N, S + NI), device=dev)
 st = torch.cuda.current_stream(dev).cuda_stream
-report("sample_pdf_kernel", timed(lambda: _lib.check(_lib.lib.ntx_sample_pdf(t.data_ptr(), None, wts.data_ptr(), None, N, S, NI, 0, 0, z_all.data_ptr(), st))),
+report("sample_pdf_kernel", timed(lambda: _lib.check(_lib.lib.ntx_sample_pdf(t.data_ptr(), None, wts.data_ptr(), None, N, S, NI, 0, 0, None, z_all.data_ptr(), st))),
        N * (S * 4 + (S + NI) * 4 + 8), f"{N} rays, {S} coarse + {NI} importance depths (deterministic u)")
 
 # image epilogue: RGBA in, float32 + uint8 out, with and without the gaussian downsample
