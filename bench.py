@@ -322,6 +322,7 @@ def main() -> None:
     ap.add_argument("--deadline", type=float, default=float(os.environ.get("NTX_BENCH_DEADLINE", "600")),
                     help="multi-rank runs: seconds after which the launcher ends all ranks / every rank's watchdog exits")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of 256 rays after the timed region")
+    ap.add_argument("--raw-noise-std", type=float, default=0.0, help="raw_noise_std of the renderer (renderer.py:190-192), drawn inside the kernel")
     ap.add_argument("--instanced-per-sample-dirs", action="store_true",
                     help="carpet_instanced: every marching sample its own direction and appearance parameters (the round-2 workload) instead of one per run")
     args = ap.parse_args()
@@ -387,7 +388,7 @@ def main() -> None:
     model = ParamNerf(emb(10), emb(4), emb(4), list(fam["n_parameters"]))["model"]
     model.set_blob(synthetic.synthetic_weights(model.layer_table(), seed=0))
     mk = lambda prec, perturb: Renderer(model=model, n_samples=S, perturb=perturb, blur_idx=fam["blur_idx"], check_numerics=False,
-                                        precision=prec)
+                                        precision=prec, raw_noise_std=args.raw_noise_std)
     renderer = mk(args.precision, args.perturb)
     params = torch.as_tensor(np.asarray([fam["params"]], np.float32), device=dev)
 
@@ -546,7 +547,7 @@ def main() -> None:
     parity = None
     if rank == 0 and not args.no_parity:
         local = step(gather=False)                           # this rank's own rays as the timed region rendered them
-        parity = parity_block(renderer, model, family, batch, local, S) if not args.perturb else None
+        parity = parity_block(renderer, model, family, batch, local, S) if not (args.perturb or args.raw_noise_std > 0) else None
 
     if rank == 0:
         flops_per_sample = 2 * model.macs_per_sample()
@@ -572,6 +573,7 @@ def main() -> None:
             "config": {"workload": what + f", ParamNerf n_parameters={list(fam['n_parameters'])}, seeded glorot weights, "
                                    f"inputs resident in HBM, fused PE+MLP+composite"
                                    + (", perturb=True (in-kernel jitter)" if args.perturb else "")
+                                   + (f", raw_noise_std={args.raw_noise_std} (in-kernel N(0,1) per sample)" if args.raw_noise_std > 0 else "")
                                    + (f", + gather of RGBA to rank 0: {gather_how}" if world > 1 else ""),
                        "rays_per_gpu": n_rays, "hit_rays_total": hits_total, "samples_per_ray": S, "flops_per_sample": flops_per_sample},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

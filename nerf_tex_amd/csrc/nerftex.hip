@@ -326,6 +326,7 @@ struct ntx_ctx {
     size_t hit_cap;
     int32_t *hit_count;   // device int32[2]: [0] number of hit rays, [1] work counter of the instance kernel
     bool hoist_dir;       // false when NERFTEX_NO_DIR_HOIST is set at ntx_create (A/B knob for tests: same bits either way)
+    uint16_t *inst_sidx;  // device scratch of ntx_render_instanced: per wave, the compacted index list of its ray in flight (8 KiB each)
 };
 
 // The big kernels of each model family live in their own translation units (ntx_variant.hip / ntx_variant_x3.hip
@@ -503,7 +504,7 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     c->packed16 = nullptr;
     c->packed16_bytes = 0;
     c->packed16i = nullptr; c->packed16i_bytes = 0;
-    c->hit_list = nullptr; c->hit_cap = 0; c->hit_count = nullptr;
+    c->hit_list = nullptr; c->hit_cap = 0; c->hit_count = nullptr; c->inst_sidx = nullptr;
     c->hoist_dir = getenv("NERFTEX_NO_DIR_HOIST") == nullptr;
     {
         c->packed16_bytes = packed16_bytes(kVariants[v]);
@@ -529,6 +530,8 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     {   // all the device scratch the entry points will ever use: allocated here (and by ntx_reserve), never per call
         int rc = NTX_OK;
         if (hipMalloc((void **)&c->hit_count, 2 * sizeof(int32_t)) != hipSuccess) rc = fail(NTX_E_HIP, "hipMalloc(hit_count)");
+        if (rc == NTX_OK && hipMalloc((void **)&c->inst_sidx, (size_t)c->n_wgs * 4 * MAX_INSTANCE_SAMPLES * sizeof(uint16_t)) != hipSuccess)
+            rc = fail(NTX_E_HIP, "hipMalloc(inst_sidx)");
         if (rc == NTX_OK) rc = ntx_reserve(c, NTX_DEFAULT_MAX_RAYS);
         if (rc != NTX_OK) { ntx_destroy(c); *out = nullptr; return rc; }
     }
@@ -588,6 +591,7 @@ int ntx_destroy(ntx_ctx *ctx) {
     if (ctx->packed16i) (void)hipFree(ctx->packed16i);
     if (ctx->hit_list) (void)hipFree(ctx->hit_list);
     if (ctx->hit_count) (void)hipFree(ctx->hit_count);
+    if (ctx->inst_sidx) (void)hipFree(ctx->inst_sidx);
     delete ctx;
     return NTX_OK;
 }
@@ -804,6 +808,8 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     a.raw_noise_std = noise_std; a.idx0 = im.idx0; a.idx_run = im.run; a.idx_stride = im.stride;
     a.seed_lo = opts ? (uint32_t)opts->noise_seed : 0u; a.seed_hi = opts ? (uint32_t)(opts->noise_seed >> 32) : 0u;
     a.run_hoist = ctx->hoist_dir ? 1 : 0;
+    if (const char *dbg = getenv("NERFTEX_DEBUG_RUNS")) a.run_hoist = atoi(dbg);   // development: ntx_device.h instance_kernel
+    a.sidx_scratch = ctx->inst_sidx;
     a.wstream = reinterpret_cast<const f32x4 *>(ctx->packed);
     a.stream_bytes = (uint32_t)(ctx->stream_floats * sizeof(float));
     a.aux = ctx->packed + ctx->stream_floats;

@@ -1146,7 +1146,8 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
     // runs are looked for unless switched off (A/B knob of the host) or blur_idx scales an appearance parameter per sample;
     // without them every sample is its own run (the rows of a batch are then evaluated for that batch alone: the work of the
     // per-sample kernel, bit-identical results)
-    const bool runs_on = ROWS && a.run_hoist != 0 && !(a.blur_idx >= CFG::NGEO && CFG::IPE == 0);
+    const bool runs_on = ROWS && (a.run_hoist & 1) != 0 && !(a.blur_idx >= CFG::NGEO && CFG::IPE == 0);
+    const int group_max = (a.run_hoist & 4) ? 1 : LEAD_GROUP_MAX;   // (development knobs: bit 1 = flags only, bit 2 = one batch per group)
 
     // the appended sample (colour taken as is, alpha_last is an alpha, not a density: renderer.py:323-339) and the store
     auto finish = [&](int64_t ray, const RayAccum &ra) {
@@ -1242,7 +1243,7 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
                     for (int k0 = 0; k0 < (n & ~31); k0 += 64) {
                         const int k = k0 + lane;
                         const bool v = k < (n & ~31);
-                        const int idx = gsidx[v ? k : 0];
+                        const int idx = gsidx[v ? k : 0] & (LEAD_FLAG - 1);   // (entry 0 is flagged from the first step on)
                         SampleIn<CFG::NGEO, CFG::NAPP> din;
                         dir_inputs<CFG>(a, ray * S + idx, din);
                         bool diff = k == 0;
@@ -1276,7 +1277,7 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
         int slot = 0;
         int64_t sm;
         float cone_l = cone;
-        const bool grouped = ROWS && runs_on && mode == 1;   // (wave-uniform) this batch takes its rows from a group of runs
+        const bool grouped = ROWS && runs_on && mode == 1 && !(a.run_hoist & 2);   // (wave-uniform) this batch takes its rows from a group of runs
         if (mode == 1) {
             // a group never looks past the window: slide it when the batches a new group may cover would
             if ((grouped ? b >= grp_end && 32 * (b + LEAD_GROUP_MAX) > win0 + SIDX_WINDOW : 32 * (b + 1) > win0 + SIDX_WINDOW) && count > win0 + SIDX_WINDOW)
@@ -1319,7 +1320,7 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
                     // batches as the 32 rows can serve (at least this one)
                     int nlead = 1, covered = 0;
                     if (lane == 0) lead_pos[0] = (uint16_t)(32 * b);
-                    for (int bb = b; bb < nfull && covered < LEAD_GROUP_MAX; ++bb) {
+                    for (int bb = b; bb < nfull && covered < group_max; ++bb) {
                         const bool f = (win[32 * bb - win0 + j] & LEAD_FLAG) != 0 && !(bb == b && j == 0);
                         const uint32_t m = (uint32_t)__ballot(f);              // lanes j and j + 32 agree: the low word has it
                         const int d = __popc(m);
