@@ -806,18 +806,21 @@ NTX_DEV void ray_rows(__amdgpu_buffer_rsrc_t rsrc, const float *aux, float *rows
     });
 }
 
-// rows[slot] for slot = it * 4 + w  <->  hit number base + it * nwaves_total + 4 * workgroup + w.
+// CONSEC (render_kernel): a workgroup takes DIR_BLOCK_RAYS CONSECUTIVE hits of a block, wave w the DIR_BLOCK_ITERS from w *
+//   DIR_BLOCK_ITERS on: rows[slot]  <->  hit number base + DIR_BLOCK_RAYS * workgroup + slot.
+// else (render_kernel_x3): rows[slot] for slot = it * 4 + w  <->  hit number base + it * nwaves_total + 4 * workgroup + w.
 // GS > 0: also the rows of L0 and L5 (bias + the first GS k-steps of their position segments: geometry blocks), at rows +
 // DIR_BLOCK_FLOATS and rows + 2 DIR_BLOCK_FLOATS (render_kernel<CFG, 2 | 3>)
-template <class CFG, int GS = 0>   // GS: leading geometry k-steps of the position segments to evaluate too
+template <class CFG, int GS = 0, bool CONSEC = false>   // GS: leading geometry k-steps of the position segments to evaluate too
 NTX_DEV void dir_block(const RenderArgs &a, __amdgpu_buffer_rsrc_t rsrc, const float *aux, float *rows, int base, int nwaves,
                        int wg, int wv, int lane, int n_work) {
     static_assert(CFG::CD != 0, "ParamNerf families");
     const int h = lane >> 5;
     static_assert(DIR_BLOCK_RAYS % 32 == 0, "whole MFMA column sets");
     for (int j = lane & 31; j < DIR_BLOCK_RAYS; j += 32) {   // 32 ray slots per MFMA column set
-        if (j >= 32 && base + (j >> 5) * 8 * nwaves >= n_work) break;   // (wave-uniform) the rest of the block lies past the end of the list
-        int idx = base + (j >> 2) * nwaves + 4 * wg + (j & 3);
+        // (wave-uniform) the rest of the block lies past the end of the list
+        if (j >= 32 && (CONSEC ? base + DIR_BLOCK_RAYS * wg + (j & ~31) : base + (j >> 5) * 8 * nwaves) >= n_work) break;
+        int idx = CONSEC ? base + DIR_BLOCK_RAYS * wg + j : base + (j >> 2) * nwaves + 4 * wg + (j & 3);
         idx = idx < n_work ? idx : n_work - 1;
         const int64_t ray = a.hit_list[idx];
         const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
@@ -856,6 +859,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     static_assert(HOIST < 2 || (CFG::IPE == 0 && CFG::NGEO > 0), "geometry hoisting: FourierFeatures families with geometry parameters");
     static_assert(HOIST != 3 || CFG::NGEO >= 2, "HOIST 3 keeps parameter 0's block per sample and hoists the others");
     __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * pe_keep_floats<CFG>() + (HOIST >= 2 ? 3 : HOIST) * DIR_BLOCK_FLOATS];
+    __shared__ __attribute__((aligned(16))) float out_all[4][DIR_BLOCK_ITERS][4];   // the RGBA of a wave's rays of the block ...
     load_aux(aux, a.aux, aux_total());
     float *dir_rows = aux + aux_total() + 4 * pe_keep_floats<CFG>();
     const int lane = threadIdx.x & 63, j = lane & 31;
@@ -868,8 +872,12 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     WStream ws;
     ws_prime<RecMap<CFG, HOIST>>(ws, a.wstream, a.stream_bytes, lane);
 
-    // the compacted hit list is walked in blocks of DIR_BLOCK_ITERS rounds of one ray per wave; `base` and the trip
-    // count of this loop are uniform over the workgroup (the barriers of the HOIST variant sit in it)
+    // The compacted hit list is walked in blocks of DIR_BLOCK_ITERS rays per wave; `base` and the trip count of this loop are
+    // uniform over the workgroup (the barriers of the HOIST variant sit in it).  Within a block a wave takes DIR_BLOCK_ITERS
+    // CONSECUTIVE hits (the workgroup 32, its XCD 1024): their RGBA is collected in LDS and written by ONE store instruction
+    // per block -- 24 + 8 lanes, 96 + 32 contiguous bytes where the hits are neighbouring pixels -- instead of 4 scalar stores of
+    // lane 0 per ray scattered over the image (round 2: WRITE_SIZE 36 MB for 10 MB of RGBA on fur_sharded, partial lines
+    // evicted one by one from an L2 the weight stream keeps turning over).
     const int n_work = *a.hit_count;
     for (int base = 0; base < n_work; base += DIR_BLOCK_ITERS * nwaves) {
         if constexpr (HOIST != 0) {
@@ -881,11 +889,11 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             const int lane_o = fresh_lane_id();
             const RenderArgs *apd = kernargs<RenderArgs>();
             asm volatile("" : "+s"(apd));
-            dir_block<CFG, hoisted_geo_steps<CFG, HOIST>()>(*apd, ws.rsrc, aux, dir_rows, base, nwaves, vwg, wv, lane_o, n_work);
+            dir_block<CFG, hoisted_geo_steps<CFG, HOIST>(), true>(*apd, ws.rsrc, aux, dir_rows, base, nwaves, vwg, wv, lane_o, n_work);
             __syncthreads();
         }
       for (int it = 0; it < DIR_BLOCK_ITERS; ++it) {
-        const int idx = base + it * nwaves + wave;
+        const int idx = base + wave * DIR_BLOCK_ITERS + it;
         if (idx >= n_work) break;
         const int64_t ray = (int64_t)a.hit_list[idx];
         RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -893,8 +901,11 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             // The ray's own data is re-read (scalar loads, L2-resident) for every batch instead of staying live
             // across the ~10 600-MFMA body, where it cost ~10 spilled registers per ray (1.3 GB of scratch
             // stores per 800x800 launch).  The opaque copy of the index stops LICM from hoisting the loads back.
-            int64_t r = ray;
-            asm volatile("" : "+s"(r));
+            // (readfirstlane: with the RGBA buffer below hipcc may keep `ray` in a vector register, and an "s" operand cannot be
+            //  copied out of one -- "illegal VGPR to SGPR copy"; hit indices are < 2^31)
+            int r32 = __builtin_amdgcn_readfirstlane((int)ray);
+            asm volatile("" : "+s"(r32));
+            int64_t r = r32;
             // same for the kernel arguments: read them from the kernarg segment through an opaque pointer at the
             // point of use, so a dozen argument pointers are not held in SGPRs (spilled into VGPR lanes) all along
             const RenderArgs *ap = kernargs<RenderArgs>();
@@ -944,7 +955,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             }
             float sigma, raw[3];
             float *pe = pe_column<CFG>(aux, wv, lane);
-            if constexpr (HOIST != 0) mlp_batch<CFG, HOIST>(in, ws, aux, lane, sigma, raw, dir_rows + (it * 4 + wv) * DIR_ROW_STRIDE, pe);
+            if constexpr (HOIST != 0) mlp_batch<CFG, HOIST>(in, ws, aux, lane, sigma, raw, dir_rows + (wv * DIR_BLOCK_ITERS + it) * DIR_ROW_STRIDE, pe);
             else mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe);
             const RenderArgs *ap2 = kernargs<RenderArgs>();
             asm volatile("" : "+s"(ap2));
@@ -960,14 +971,34 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
             for (int k = 0; k < 3; ++k) out[k] = out[k] + (1.0f - ra.a) * a.bkgd[k];
         }
         if (lane == 0) {
-            a.color_out[3 * ray + 0] = out[0]; a.color_out[3 * ray + 1] = out[1];
-            a.color_out[3 * ray + 2] = out[2]; a.alpha_out[ray] = out[3];
+            *reinterpret_cast<f32x4 *>(out_all[wv][it]) = f32x4{out[0], out[1], out[2], out[3]};   // (the arrays are indexed in place: a pointer
+                                                                                                      //  variable decays to a flat address)
             if ((a.flags & NTX_FLAG_CHECK_NUMERICS) && a.status) {
                 const float s = out[0] + out[1] + out[2] + out[3];
                 if (!(__builtin_fabsf(s) <= 3.0e38f)) atomicOr(a.status, 1);
             }
         }
       }
+        // flush the block's RGBA: lane l = (ray l / 4, component l % 4).  Everything it needs is recomputed here (the number of
+        // rays done from the loop bounds, the lane index afresh, the arguments from the kernarg segment): a counter or a pointer
+        // carried through the loop above is a spilled register in the families that have none to spare.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        static_assert(DIR_BLOCK_ITERS * 4 <= 64, "one lane per output float");
+        {
+            const RenderArgs *apo = kernargs<RenderArgs>();
+            asm volatile("" : "+s"(apo));
+            const int first = base + wave * DIR_BLOCK_ITERS, left = n_work - first;
+            const int n_done = left < 0 ? 0 : (left < DIR_BLOCK_ITERS ? left : DIR_BLOCK_ITERS);
+            const int lane_o = fresh_lane_id();
+            if (lane_o < 4 * n_done) {
+                const int64_t oray = apo->hit_list[first + (lane_o >> 2)];
+                const int c = lane_o & 3;
+                float *dst = c < 3 ? apo->color_out + 3 * oray + c : apo->alpha_out + oray;
+                *dst = out_all[wv][lane_o >> 2][c];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // the buffer is rewritten in the next block
     }
 }
 
@@ -1128,10 +1159,12 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
     __shared__ InstancePending pend_all[4];
     __shared__ uint8_t slot_all[4][32];         // row of each sample of the batch in flight
     __shared__ uint16_t lead_all[4][32];        // position (in the compacted list) of the group's run leaders
+    __shared__ float park_all[4][32][2];        // dists and density weight of the batch in flight (no register survives the network)
     load_aux(aux, a.aux, aux_total());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.n_samples;
+    float (*park)[2] = park_all[wv];
     // the compacted index list of the ray in flight: global scratch of the context (L2-resident, 8 KiB per wave), read through a
     // window in LDS; entry = marching index | LEAD_FLAG
     uint16_t *gsidx = a.sidx_scratch + ((size_t)blockIdx.x * 4 + wv) * MAX_INSTANCE_SAMPLES;
@@ -1311,6 +1344,13 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
 #pragma unroll
             for (int c = 0; c < CFG::NP; ++c) in.par[c] = pr[c < a.blur_idx ? c : c + 1];
         }
+        // what the composite needs of this sample is fetched with the rest (one exposed latency per batch instead of two) and parked
+        if (lane < 32) {
+            park[j][0] = a.dists[sm];
+            park[j][1] = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // renderer.py:300
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 
         // ---- the rows this batch starts C1 from
         if constexpr (ROWS) {
@@ -1352,7 +1392,7 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
         float sigma, raw[3];
         if constexpr (ROWS) mlp_batch<CFG, 4, false>(in, ws, aux, lane, sigma, raw, rows, nullptr, slots);
         else mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe_col);
-        const float wgt = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // :300
+        const float wgt = park[j][1], dist_l = park[j][0];
         sigma = sigma * wgt;
         float col[3];
         if (a.instance_color) {                                                                // :306-307, 322-323
@@ -1367,7 +1407,7 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
             const int64_t ray_l = sm / S;
             sigma += a.raw_noise_std * normal01(global_index(a.idx0, a.idx_run, a.idx_stride, ray_l), (int)(sm - ray_l * S), a.seed_lo, a.seed_hi);
         }
-        const float al = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * a.dists[sm] / a.patch_scale) : 0.0f;   // :339
+        const float al = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * dist_l / a.patch_scale) : 0.0f;   // :339
         if (mode == 1) {
             composite_core<32>(ra, al, col, true, j, nullptr);
             ++b;

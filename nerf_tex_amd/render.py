@@ -42,8 +42,11 @@ def image_epilogue(rgba, downsampling_factor: int = 1, write_exr: bool = False, 
 
 
 def Render(target_path: Optional[str], test_dataset_config, model_config, renderer_config, logger_config=None,
-           source_path: str = None, override: bool = True, weights=None, return_imgs: bool = True, **kwargs) -> List:
-    """network.render.Render (render.py:6-29)."""
+           source_path: str = None, override: bool = True, weights=None, weights_order: str = None, return_imgs: bool = True,
+           **kwargs) -> List:
+    """network.render.Render (render.py:6-29).  `weights`: `keras_model.get_weights()` as it is (a list), or the same flattened
+    -- and then `weights_order="keras_get_weights"` must say so: the flat blob of ABI v1 had the alpha head after the trunk, v2+ has
+    it last (Keras' order), both have the same size, and a blob in the other order renders garbage without any error."""
     test_dataset = util.instantiate(test_dataset_config)
     model_config.setdefault("n_parameters", test_dataset.n_parameters)                  # render.py:20
     model = util.instantiate(model_config)
@@ -51,6 +54,10 @@ def Render(target_path: Optional[str], test_dataset_config, model_config, render
         m0 = next(iter(model.values()))          # layer's shape is checked), or the same flattened into one blob
         if isinstance(weights, (list, tuple)):
             m0.set_weights(weights)
+        elif weights_order != "keras_get_weights":
+            raise ValueError("Render(weights=<flat array>) needs weights_order='keras_get_weights': the blob is np.concatenate([w.ravel() for w in "
+                             "keras_model.get_weights()]) -- trunk 0-7, feature, colour layers, color, alpha head LAST (ABI v1 had the alpha head after "
+                             "the trunk; same size, so the order cannot be checked).  Pass the get_weights() list itself to have every layer's shape checked.")
         else:
             m0.set_blob(weights)
     else:                                        # logger.py:30-39: restore the newest ckpt-* under <source>/checkpoints

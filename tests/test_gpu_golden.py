@@ -101,7 +101,9 @@ def test_golden_plumbing_image_through_render_harness():
         "renderer_config": {"module": "network.renderer.Renderer", "n_samples": 32, "perturb": False},
         "logger_config": {"module": "network.logger.Logger"},
     }
-    imgs = util.instantiate(dict(util.remap_reference_config(config), weights=blob))
+    with pytest.raises(ValueError, match="weights_order"):      # a flat blob must say which order it is in (ABI v1's differed, same size)
+        util.instantiate(dict(util.remap_reference_config(config), weights=blob))
+    imgs = util.instantiate(dict(util.remap_reference_config(config), weights=blob, weights_order="keras_get_weights"))
     assert len(imgs) == 1
     rgba = imgs[0][0].cpu().numpy()
     assert rgba.shape == (200, 200, 4)

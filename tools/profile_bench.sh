@@ -4,10 +4,11 @@
 # --kernel-trace --stats in its own pass; the PMC counters in separate passes (never combined with tracing).
 # Reduce with: python tools/summarize_profile.py <prefix> <round> <name> [kernel-substring]
 P=$1; shift
-ONLY=${ONLY:-kt pmc1 pmc2 pmc3 pmc4 pmc5}   # subset of passes to run
+ONLY=${ONLY:-kt pmc1 pmc2 pmc3 pmc4 pmc5}   # subset of passes to run; STEPS / WARMUP: launches per pass (short kernels: more, so that
+                                            # the first, cold launch does not carry the average)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-parity $*"
+B="python $R/bench.py --steps ${STEPS:-3} --warmup ${WARMUP:-1} --no-cpu-baseline --no-extras --no-parity $*"
 for p in $ONLY; do rm -rf $O/${P}_$p; done
 [[ " $ONLY " == *" kt "* ]] && timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${P}_kt -o kt -- $B > $O/${P}_kt.log 2>&1
 [[ " $ONLY " == *" pmc1 "* ]] && timeout 420 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/${P}_pmc1 -o p -- $B > $O/${P}_pmc1.log 2>&1
