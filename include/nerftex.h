@@ -50,8 +50,12 @@ typedef enum ntx_pos_encoding { NTX_POS_FOURIER = 0, NTX_POS_IPE = 1 } ntx_pos_e
 
 /* Built: ParamNerf with n_parameters = [g, a], g <= 4, a <= 8 (tuned kernel families for the shipped configs [1,6], [1,4], [2,3];
  * every other combination runs on one generic family whose rows for the absent parameters are zero, ~2 % more matrix work),
- * plain Nerf, and one IntegratedPositionalEncoding family [1,3]; 10/4/4 frequency bands, depth 8, width 256, skip 4,
- * color_depth 1, param_depth 0, no embedding_config.  Anything else: NTX_E_UNSUPPORTED. */
+ * plain Nerf, and one IntegratedPositionalEncoding family [1,3] -- these at the architecture every reference config uses: depth 8,
+ * width 256, skips [4], color_depth 1.  Any OTHER architecture of model.py:58 / :9 with FourierFeatures embeddings -- depth 1..24,
+ * width 2..256, color_depth 0..4, any skips below depth-1 -- runs on the "flex" family: the same MFMA segments in a loop over layers
+ * (narrower layers zero-padded to 256), float32 only (NTX_FLAG_FP16X3: NTX_E_UNSUPPORTED), nothing hoisted per ray.  10/4/4
+ * frequency bands, param_depth 0, no embedding_config.  Anything else: NTX_E_UNSUPPORTED. */
+#define NTX_SKIP_MASK 0x40000000   /* ntx_model_desc.skip = NTX_SKIP_MASK | mask: several skip layers (bit i: i in skips) */
 typedef struct ntx_model_desc {
     int32_t kind;        /* ntx_model_kind */
     int32_t n_geo;       /* n_parameters[0]: parameters concatenated to the position embedding (model.py:88-93) */
@@ -60,10 +64,11 @@ typedef struct ntx_model_desc {
     int32_t pos_freq;    /* pos_embedding.n_freq_bands   (layer.py:11) */
     int32_t dir_freq;    /* dir_embedding.n_freq_bands */
     int32_t param_freq;  /* param_embedding.n_freq_bands */
-    int32_t depth;       /* 8 */
-    int32_t width;       /* 256 */
-    int32_t skip;        /* index of the single skip layer, 4 (model.py:107-108) */
-    int32_t color_depth; /* ParamNerf: 1 (model.py:118); ignored for Nerf */
+    int32_t depth;       /* 8; flex family: 1..24 */
+    int32_t width;       /* 256; flex family: 2..256 */
+    int32_t skip;        /* `skips`: the index of the single skip layer, 4 (model.py:107-108); -1 = none; or NTX_SKIP_MASK | (bit i set for
+                          * every i in skips) */
+    int32_t color_depth; /* ParamNerf: 1 (model.py:118), flex family: 0..4; ignored for Nerf */
     int32_t pos_encoding;/* ntx_pos_encoding of pos_embedding: FourierFeatures (n_pos 3) or IntegratedPositionalEncoding (n_pos 6) */
 } ntx_model_desc;
 

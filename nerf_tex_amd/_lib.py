@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("NERFTEX_LIB") or os.path.join(_HERE, "libnerftex_hip.
 NTX_OK, NTX_E_INVALID, NTX_E_UNSUPPORTED, NTX_E_HIP, NTX_E_NODEVICE = 0, -1, -2, -3, -4
 FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS, FLAG_FP16X3, FLAG_PERTURB, FLAG_RAW_NOISE = 1, 2, 4, 8, 16, 32
 ABI_VERSION = 3
+SKIP_MASK = 0x40000000          # NTX_SKIP_MASK: ntx_model_desc.skip carries a mask of skip-layer indices
 COMM_ID_BYTES = 128
 DEFAULT_MAX_RAYS = 1 << 20
 

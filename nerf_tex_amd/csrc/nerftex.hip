@@ -50,6 +50,7 @@ extern "C" __attribute__((visibility("hidden"))) int ntx_set_error(int code, con
 struct Variant {
     int n_geo, n_app, cd, ipe;   // the kernel family's layout (for the generic family: its parameter SLOTS)
     int gen;
+    int flex;                    // the architecture is read from the model descriptor (ntx_layout.h "flex family")
 };
 static const Variant kVariants[] = {
     {1, 6, 1, 0, 0},   // carpet          (configs/config_carpet_render.py:59-72)
@@ -58,7 +59,10 @@ static const Variant kVariants[] = {
     {0, 0, 0, 0, 0},   // plain Nerf      (model.py:9-45)
     {1, 3, 1, 1, 0},   // mip variant of grass_filtered: IPE on (mean, cov), blur parameter spliced out (renderer.py:385-386)
     {GEN_NGEO, GEN_NAPP, 1, 0, 1},   // generic: any other ParamNerf n_parameters = [g <= 4, a <= 8]; absent parameters = zero rows
+    {GEN_NGEO, GEN_NAPP, 1, 0, 1, 1},   // flex: any depth <= 24, width <= 256, skips, color_depth <= 4 (model.py:58), float32 kernels only
 };
+constexpr int kFlexVariant = 6;
+static_assert(NTX_SKIP_MASK == (unsigned)NTX_SKIP_MASK_BIT, "skip encoding of the ABI header and of ntx_layout.h");
 
 // the model's own parameter counts (the generic family has more slots than the model has parameters)
 struct Dims {
@@ -69,23 +73,46 @@ static Dims dims_of(const ntx_model_desc *d) {
     return Dims{nerf ? 0 : d->n_geo, nerf ? 0 : d->n_app};
 }
 
+// the model's `skips` as a mask of layer indices: ntx_model_desc.skip is one index (-1: none) or NTX_SKIP_MASK | mask
+static unsigned skip_mask_of(const ntx_model_desc *d) {
+    if (d->skip < 0) return 0u;
+    if (d->skip & NTX_SKIP_MASK) return (unsigned)d->skip & (NTX_SKIP_MASK - 1u);
+    return d->skip < 30 ? 1u << d->skip : 0u;
+}
+static FlexArch flex_arch_of(const ntx_model_desc *d) {
+    // a skip index >= depth - 1 .. : `i in skips` never fires for i >= depth (model.py:107); i = depth - 1 is refused in find_variant
+    return FlexArch{d->depth, d->width, d->kind == NTX_MODEL_NERF ? 0 : d->color_depth, skip_mask_of(d) & ((1u << (d->depth > 1 ? d->depth - 1 : 0)) - 1u)};
+}
+static bool default_arch(const ntx_model_desc *d) {
+    const bool nerf = d->kind == NTX_MODEL_NERF;
+    return d->depth == DEPTH && d->width == WIDTH && d->skip == SKIP && (nerf || d->color_depth == 1);
+}
+
 static int find_variant(const ntx_model_desc *d) {
     if (!d) return -1;
     const int ipe = d->pos_encoding == NTX_POS_IPE;
     if (d->pos_encoding != NTX_POS_FOURIER && d->pos_encoding != NTX_POS_IPE) return -1;
-    if (d->n_pos != (ipe ? 6 : 3) || d->pos_freq != POS_FREQ || d->dir_freq != DIR_FREQ || d->depth != DEPTH ||
-        d->width != WIDTH || d->skip != SKIP)
-        return -1;
+    if (d->n_pos != (ipe ? 6 : 3) || d->pos_freq != POS_FREQ || d->dir_freq != DIR_FREQ) return -1;
     const bool nerf = d->kind == NTX_MODEL_NERF;
     const int g = nerf ? 0 : d->n_geo, a = nerf ? 0 : d->n_app, cd = nerf ? 0 : d->color_depth;
     if (g < 0 || a < 0) return -1;
     if (!nerf && (g + a > 0) && d->param_freq != PAR_FREQ) return -1;
-    const bool force_generic = getenv("NERFTEX_FORCE_GENERIC") != nullptr;   // A/B knob for tests: a tuned family's model on the generic kernels
-    for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]) && !(force_generic && !nerf && !ipe); ++i)
-        if (!kVariants[i].gen && kVariants[i].n_geo == g && kVariants[i].n_app == a && kVariants[i].cd == cd && kVariants[i].ipe == ipe) return (int)i;
-    for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]); ++i)
-        if (kVariants[i].gen && !nerf && g <= kVariants[i].n_geo && a <= kVariants[i].n_app && kVariants[i].cd == cd && kVariants[i].ipe == ipe) return (int)i;
-    return -1;
+    const bool force_flex = getenv("NERFTEX_FORCE_FLEX") != nullptr;         // A/B knobs for tests: a tuned family's model on the
+    const bool force_generic = getenv("NERFTEX_FORCE_GENERIC") != nullptr;   // flex / generic kernels
+    if (default_arch(d) && !(force_flex && !ipe)) {
+        for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]) && !(force_generic && !nerf && !ipe); ++i)
+            if (!kVariants[i].gen && kVariants[i].n_geo == g && kVariants[i].n_app == a && kVariants[i].cd == cd && kVariants[i].ipe == ipe) return (int)i;
+        for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]); ++i)
+            if (kVariants[i].gen && !kVariants[i].flex && !nerf && g <= kVariants[i].n_geo && a <= kVariants[i].n_app && kVariants[i].cd == cd && kVariants[i].ipe == ipe) return (int)i;
+        return -1;
+    }
+    // any other architecture: the layer loop of the flex family
+    if (ipe || g > GEN_NGEO || a > GEN_NAPP) return -1;
+    if (d->depth < 1 || d->depth > FLEX_MAX_DEPTH || d->width < 2 || d->width > WIDTH || cd < 0 || cd > FLEX_MAX_COLOR) return -1;
+    if (d->skip >= 0 && !(d->skip & NTX_SKIP_MASK) && d->skip >= 30) return -1;
+    // a skip behind the LAST trunk layer widens the inputs of the alpha head and of the feature layer (model.py:107-114): not built
+    if ((skip_mask_of(d) >> (d->depth - 1)) & 1u) return -1;
+    return kFlexVariant;
 }
 
 static int unsupported(const ntx_model_desc *d) {
@@ -93,7 +120,8 @@ static int unsupported(const ntx_model_desc *d) {
     return fail(NTX_E_UNSUPPORTED,
                 "unsupported model: kind=%d n_parameters=[%d,%d] n_pos=%d freqs=%d/%d/%d depth=%d width=%d "
                 "skip=%d color_depth=%d pos_encoding=%d (built: ParamNerf with n_parameters [g<=4, a<=8] -- tuned kernels for [1,6] [1,4] "
-                "[2,3] --, Nerf, and ParamNerf [1,3] with IntegratedPositionalEncoding on 6-D positions; 10/4/4 bands, 8x256, skip 4, color_depth 1)",
+                "[2,3] at 8x256 / skips [4] / color_depth 1 --, Nerf, and ParamNerf [1,3] with IntegratedPositionalEncoding on 6-D positions; "
+                "other architectures (FourierFeatures only): depth 1..24, width 2..256, color_depth 0..4, skips below depth-1; 10/4/4 bands)",
                 d->kind, d->n_geo, d->n_app, d->n_pos, d->pos_freq, d->dir_freq, d->param_freq, d->depth,
                 d->width, d->skip, d->color_depth, d->pos_encoding);
 }
@@ -210,6 +238,119 @@ static void pack(const Variant &v, Dims m, const float *blob, float *out) {
     }
 }
 
+// ---- flex family (ntx_layout.h): any depth / width <= 256 / skips / color_depth ---------------------------------------------------
+struct FlexNet {
+    std::vector<Layer> trunk, colour;   // colour: the color_depth hidden colour layers
+    Layer alpha, feature, c2, rgb;
+    size_t count;
+};
+// get_weights() order of the functional model for ANY architecture (layer_table of nerf_tex_amd/model.py): trunk, feature, colour
+// layers, colour half, color, alpha
+static FlexNet view_blob_flex(const FlexArch &f, Dims m, const float *blob) {
+    FlexNet n{};
+    const int pm = pos_map_dim(m.g), dm = dir_map_dim(m.a);
+    size_t p = 0;
+    auto take = [&](int in, int out) {
+        Layer l{blob ? blob + p : nullptr, blob ? blob + p + (size_t)in * out : nullptr, in, out};
+        p += (size_t)in * out + out;
+        return l;
+    };
+    int k = pm;
+    for (int i = 0; i < f.depth; ++i) {
+        n.trunk.push_back(take(k, f.width));
+        k = f.width + (((f.skip_mask >> i) & 1u) ? pm : 0);
+    }
+    const int k_head = k;
+    n.feature = take(k, f.width);
+    k = f.width + dm;
+    for (int i = 0; i < f.color_depth; ++i) {
+        n.colour.push_back(take(k, f.width));
+        k = f.width;
+    }
+    n.c2 = take(k, f.width / 2);
+    n.rgb = take(f.width / 2, 3);
+    n.alpha = take(k_head, 1);
+    n.count = p;
+    return n;
+}
+
+// emit_segment with the rows of a narrower layer (width < 256: hidden rows >= `rows` are zero) and zero records up to PADREC
+template <class RowFn>
+static void emit_segment_flex(float *&dst, const Layer &l, int nsteps, int nmt, int row_offset, int rows, RowFn rowfn) {
+    float *const start = dst;
+    emit_segment(dst, l, nsteps, nmt, row_offset, [&](int s, int h) { const int r = rowfn(s, h); return r < rows ? r : -1; });
+    const int pad = flex_seg_records(nsteps, nmt) - nsteps * (nmt / 4);
+    memset(dst, 0, sizeof(float) * REC_FLOATS * pad);
+    dst += (size_t)REC_FLOATS * pad;
+    (void)start;
+}
+
+static size_t packed_floats_flex(const FlexArch &f) {
+    return (size_t)(flex_stream_records(f) + RING) * REC_FLOATS + aux_total() + flex_floats();
+}
+
+static void pack_flex(const FlexArch &f, Dims m, const float *blob, float *out) {
+    const FlexNet n = view_blob_flex(f, m, blob);
+    const int pm = pos_map_dim(m.g), dm = dir_map_dim(m.a);
+    const int ps = pos_steps(GEN_NGEO), ds = dir_steps(GEN_NAPP);
+    float *dst = out;
+    auto posrow = [&](int s, int h) { return pos_row(GEN_NGEO, s, h, 0, m.g); };
+    auto dirrow = [&](int s, int h) { return dir_row(GEN_NAPP, s, h, m.a); };
+    auto hidrow = [&](int s, int h) { return hidden_row(s, h); };
+    const int W = f.width;
+    emit_segment_flex(dst, n.trunk[0], ps, 8, 0, pm, posrow);
+    for (int i = 1; i < f.depth; ++i) {
+        const bool skip_in = (f.skip_mask >> (i - 1)) & 1u;
+        if (skip_in) emit_segment_flex(dst, n.trunk[i], ps, 8, 0, pm, posrow);
+        emit_segment_flex(dst, n.trunk[i], HSTEPS, 8, skip_in ? pm : 0, W, hidrow);
+    }
+    emit_segment_flex(dst, n.feature, HSTEPS, 8, 0, W, hidrow);
+    if (f.color_depth > 0) {
+        emit_segment_flex(dst, n.colour[0], ds, 8, 0, dm, dirrow);
+        emit_segment_flex(dst, n.colour[0], HSTEPS, 8, dm, W, hidrow);
+        for (int i = 1; i < f.color_depth; ++i) emit_segment_flex(dst, n.colour[i], HSTEPS, 8, 0, W, hidrow);
+        emit_segment_flex(dst, n.c2, HSTEPS, 4, 0, W, hidrow);
+    } else {
+        emit_segment_flex(dst, n.c2, ds, 4, 0, dm, dirrow);
+        emit_segment_flex(dst, n.c2, HSTEPS, 4, dm, W, hidrow);
+    }
+    memcpy(dst, out, sizeof(float) * RING * REC_FLOATS);   // wrap-around tail
+    dst += RING * REC_FLOATS;
+
+    // aux block: the tuned layout (only its alpha / rgb heads are used), then [descriptor | bias slots]
+    float *aux = dst;
+    memset(aux, 0, sizeof(float) * (aux_total() + flex_floats()));
+    for (int h = 0; h < 2; ++h)
+        for (int s = 0; s < HSTEPS; ++s) {
+            const int r = hidden_row(s, h);
+            aux[aux_alpha_off() + h * 128 + s] = r < W ? n.alpha.w[r] : 0.0f;
+        }
+    aux[aux_alpha_off() + 256] = n.alpha.b[0];
+    for (int c = 0; c < 3; ++c) {
+        for (int h = 0; h < 2; ++h)
+            for (int s = 0; s < 64; ++s) {
+                const int r = hidden_row(s, h);
+                aux[aux_rgb_off() + (c * 2 + h) * 64 + s] = r < W / 2 ? n.rgb.w[r * 3 + c] : 0.0f;
+            }
+        aux[aux_rgb_off() + 384 + c] = n.rgb.b[c];
+    }
+    int32_t *desc = reinterpret_cast<int32_t *>(aux + aux_total());
+    desc[0] = f.depth; desc[1] = (int32_t)f.skip_mask; desc[2] = f.color_depth;
+    float *bias = aux + aux_total() + FLEX_DESC_FLOATS;
+    auto put_bias = [&](int slot, const Layer &l) {
+        for (int h = 0; h < 2; ++h)
+            for (int s = 0; s < HSTEPS; ++s) {
+                const int r = hidden_row(s, h);
+                bias[slot * AUX_BIAS_STRIDE + h * 128 + s] = r < l.out ? l.b[r] : 0.0f;
+            }
+    };
+    int slot = 0;
+    for (int i = 0; i < f.depth; ++i) put_bias(slot++, n.trunk[i]);
+    put_bias(slot++, n.feature);
+    for (int i = 0; i < f.color_depth; ++i) put_bias(slot++, n.colour[i]);
+    put_bias(slot++, n.c2);
+}
+
 // ---- fp16x3 stream (ntx_layout.h: one record = the A operand of one (k16-step, M-tile), hi record then lo record) ----
 // float32 -> IEEE half, round to nearest even, subnormals kept, overflow to inf (what v_cvt_f16_f32 does)
 static uint16_t f16_rne(float f) {
@@ -305,6 +446,21 @@ static size_t packed_floats(const Variant &v) {
     const Geometry g = make_geometry(v.n_geo, v.n_app, v.cd, v.ipe);
     return (size_t)(g.padded_records + RING) * REC_FLOATS + g.aux_floats;
 }
+// the same through the model descriptor, whose architecture sizes the flex family's image
+static size_t weight_count_of(int v, const ntx_model_desc *d) {
+    return kVariants[v].flex ? view_blob_flex(flex_arch_of(d), dims_of(d), nullptr).count : view_blob(kVariants[v], dims_of(d), nullptr).count;
+}
+static size_t packed_floats_of(int v, const ntx_model_desc *d) {
+    return kVariants[v].flex ? packed_floats_flex(flex_arch_of(d)) : packed_floats(kVariants[v]);
+}
+static size_t aux_floats_of_variant(int v) {
+    const Variant &k = kVariants[v];
+    return k.flex ? (size_t)aux_total() + flex_floats() : (size_t)make_geometry(k.n_geo, k.n_app, k.cd, k.ipe).aux_floats;
+}
+static int no_fp16x3(const Variant &v) {
+    return v.flex ? fail(NTX_E_UNSUPPORTED, "fp16x3 is built for the 8x256 / skips [4] / color_depth 1 families only; this model's architecture runs on "
+                                            "the float32 layer-loop kernels") : NTX_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -343,7 +499,7 @@ namespace ntx {
     hipError_t launch_render_x3_v##k(int n_wgs, RenderArgs &a, hipStream_t st);      \
     hipError_t launch_mlp_x3_v##k(int n_wgs, MlpArgs &a, hipStream_t st);            \
     hipError_t launch_instance_x3_v##k(int n_wgs, InstanceArgs &a, hipStream_t st);
-NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4) NTX_DECL(5)
+NTX_DECL(0) NTX_DECL(1) NTX_DECL(2) NTX_DECL(3) NTX_DECL(4) NTX_DECL(5) NTX_DECL(6)
 #undef NTX_DECL
 }  // namespace ntx
 
@@ -364,8 +520,9 @@ static const Launchers kLaunch[] = {   // indexed like kVariants
 #ifndef NTX_DEV_ONLY_CARPET   // development builds link only the carpet family (compile time)
     NTX_ROW(1, launch_render_hoist_v1, launch_render_hoist2_v1, nullptr), NTX_ROW(2, launch_render_hoist_v2, nullptr, launch_render_hoist3_v2),
     NTX_ROW(3, nullptr, nullptr, nullptr), NTX_ROW(4, launch_render_hoist_v4, nullptr, nullptr), NTX_ROW(5, launch_render_hoist_v5, nullptr, nullptr),
+    {launch_render_v6, nullptr, nullptr, nullptr, launch_mlp_v6, launch_instance_v6, nullptr, nullptr, nullptr},   // flex: float32, everything per sample
 #else
-    {}, {}, {}, {}, {},
+    {}, {}, {}, {}, {}, {},
 #endif
 };
 #undef NTX_ROW
@@ -430,13 +587,13 @@ const char *ntx_last_error(void) { return g_err; }
 size_t ntx_weight_count(const ntx_model_desc *desc) {
     const int v = find_variant(desc);
     if (v < 0) { unsupported(desc); return 0; }
-    return view_blob(kVariants[v], dims_of(desc), nullptr).count;
+    return weight_count_of(v, desc);
 }
 
 size_t ntx_packed_count(const ntx_model_desc *desc) {
     const int v = find_variant(desc);
     if (v < 0) { unsupported(desc); return 0; }
-    return packed_floats(kVariants[v]);
+    return packed_floats_of(v, desc);
 }
 
 int ntx_pack_weights(const ntx_model_desc *desc, const float *weights_host, size_t n_floats, float *packed_out,
@@ -444,18 +601,19 @@ int ntx_pack_weights(const ntx_model_desc *desc, const float *weights_host, size
     const int v = find_variant(desc);
     if (v < 0) return unsupported(desc);
     if (!weights_host || !packed_out) return fail(NTX_E_INVALID, "NULL buffer");
-    if (n_floats != view_blob(kVariants[v], dims_of(desc), nullptr).count)
-        return fail(NTX_E_INVALID, "weight blob has %zu floats, model needs %zu", n_floats,
-                    view_blob(kVariants[v], dims_of(desc), nullptr).count);
-    if (n_packed != packed_floats(kVariants[v]))
-        return fail(NTX_E_INVALID, "packed buffer has %zu floats, needs %zu", n_packed, packed_floats(kVariants[v]));
-    pack(kVariants[v], dims_of(desc), weights_host, packed_out);
+    if (n_floats != weight_count_of(v, desc))
+        return fail(NTX_E_INVALID, "weight blob has %zu floats, model needs %zu", n_floats, weight_count_of(v, desc));
+    if (n_packed != packed_floats_of(v, desc))
+        return fail(NTX_E_INVALID, "packed buffer has %zu floats, needs %zu", n_packed, packed_floats_of(v, desc));
+    if (kVariants[v].flex) pack_flex(flex_arch_of(desc), dims_of(desc), weights_host, packed_out);
+    else pack(kVariants[v], dims_of(desc), weights_host, packed_out);
     return NTX_OK;
 }
 
 size_t ntx_packed_fp16x3_bytes(const ntx_model_desc *desc) {
     const int v = find_variant(desc);
     if (v < 0) { unsupported(desc); return 0; }
+    if (no_fp16x3(kVariants[v])) return 0;
     return packed16_bytes(kVariants[v]);
 }
 
@@ -463,6 +621,7 @@ int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_hos
                             size_t n_bytes) {
     const int v = find_variant(desc);
     if (v < 0) return unsupported(desc);
+    if (int rc = no_fp16x3(kVariants[v])) return rc;
     if (!weights_host || !packed_out) return fail(NTX_E_INVALID, "NULL buffer");
     if (n_floats != view_blob(kVariants[v], dims_of(desc), nullptr).count)
         return fail(NTX_E_INVALID, "weight blob has %zu floats, model needs %zu", n_floats,
@@ -492,8 +651,8 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     c->n_cus = prop.multiProcessorCount;
     c->n_wgs = prop.multiProcessorCount;   // one 4-wave workgroup per CU: each wave owns a SIMD's register file
     c->desc = *desc;
-    c->n_packed = packed_floats(kVariants[v]);
-    c->stream_floats = c->n_packed - make_geometry(kVariants[v].n_geo, kVariants[v].n_app, kVariants[v].cd, kVariants[v].ipe).aux_floats;
+    c->n_packed = packed_floats_of(v, desc);
+    c->stream_floats = c->n_packed - aux_floats_of_variant(v);
     c->packed = nullptr;
     hipError_t e = hipMalloc((void **)&c->packed, c->n_packed * sizeof(float));
     if (e != hipSuccess) {
@@ -506,7 +665,7 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     c->packed16i = nullptr; c->packed16i_bytes = 0;
     c->hit_list = nullptr; c->hit_cap = 0; c->hit_count = nullptr; c->inst_sidx = nullptr;
     c->hoist_dir = getenv("NERFTEX_NO_DIR_HOIST") == nullptr;
-    {
+    if (!kVariants[v].flex) {   // (the flex family has float32 kernels only)
         c->packed16_bytes = packed16_bytes(kVariants[v]);
         e = hipMalloc((void **)&c->packed16, c->packed16_bytes);
         if (e != hipSuccess) {
@@ -542,6 +701,10 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
             *out = nullptr;
             return rc;
         }
+    } else if (kVariants[v].flex) {   // all-zero weights, but the image carries the architecture
+        const std::vector<float> zeros(weight_count_of(v, desc), 0.0f);
+        const int rc = ntx_set_weights(c, zeros.data(), zeros.size());
+        if (rc != NTX_OK) { ntx_destroy(c); *out = nullptr; return rc; }
     } else {
         HIP_TRY(hipMemset(c->packed, 0, c->n_packed * sizeof(float)));
         if (c->packed16) HIP_TRY(hipMemset(c->packed16, 0, c->packed16_bytes));
@@ -662,6 +825,7 @@ int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const flo
     if (flags & ~NTX_FLAG_FP16X3) return fail(NTX_E_INVALID, "ntx_mlp_forward takes NTX_FLAG_FP16X3 or 0, got 0x%x", flags);
     if (m == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
+    if (flags & NTX_FLAG_FP16X3) if (int rc = no_fp16x3(v)) return rc;
     const Dims dm_ = dims_of(&ctx->desc);
     if (!pos || !dirs || !color_out || !sigma_out || (!params && dm_.g + dm_.a > 0))
         return fail(NTX_E_INVALID, "NULL buffer");
@@ -715,6 +879,7 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     if (n_samples < 2) return fail(NTX_E_INVALID, "n_samples must be >= 2 (renderer.py:174-177 needs a previous step)");
     if (n_rays == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
+    if (flags & NTX_FLAG_FP16X3) if (int rc = no_fp16x3(v)) return rc;
     const Dims dm_ = dims_of(&ctx->desc);
     const int np = dm_.g + dm_.a + v.ipe;   // parameters per row at the ABI (mip: incl. the spliced-out blur parameter)
     if (!rays_o || !rays_d || !t || !color_out || !alpha_out || (!params && np > 0))
@@ -789,6 +954,7 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
         return fail(NTX_E_INVALID, "n_samples %d outside [1,%d]", n_samples, MAX_INSTANCE_SAMPLES);
     if (n_rays == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
+    if (flags & NTX_FLAG_FP16X3) if (int rc = no_fp16x3(v)) return rc;
     const Dims dm_ = dims_of(&ctx->desc);
     const int np = dm_.g + dm_.a + v.ipe;
     if (v.ipe && (blur_idx < 0 || !t)) return fail(NTX_E_INVALID, "an IPE (mip) model needs blur_idx and t (renderer.py:511, 575)");

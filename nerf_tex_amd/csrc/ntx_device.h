@@ -353,9 +353,11 @@ struct DirGen {
 // ---------------------------------------------------------------------------------------------
 // GEN: the generic family (ntx_layout.h): the model may have fewer parameters than the NGEO_ + NAPP_ slots of the kernel;
 // slot k reads column pmap[k] of the caller's parameter rows (or 0), rows are np_in wide (both in the kernel arguments)
-template <int NGEO_, int NAPP_, int CD_, int IPE_ = 0, int GEN_ = 0>
+// FLEX: the flex family (ntx_layout.h): depth, skips and color_depth are run-time facts read from the aux block; the compile-time
+// geometry below (records of the 8 x 256 network) then only serves the code that is shared with the tuned families
+template <int NGEO_, int NAPP_, int CD_, int IPE_ = 0, int GEN_ = 0, int FLEX_ = 0>
 struct Cfg {
-    static constexpr int NGEO = NGEO_, NAPP = NAPP_, CD = CD_, IPE = IPE_, GEN = GEN_;
+    static constexpr int NGEO = NGEO_, NAPP = NAPP_, CD = CD_, IPE = IPE_, GEN = GEN_, FLEX = FLEX_;
     static constexpr int NP = NGEO_ + NAPP_;          // parameters the MODEL sees
     static constexpr int NP_IN = NP + IPE_;           // parameters per row at the ABI: mip renderers splice the blur
                                                       // parameter out before the model (renderer.py:385-386, 511-512)
@@ -416,9 +418,9 @@ struct RecMap {
 // KEEP_PE = false: no LDS column for the position features, the skip layer evaluates them again (the instance kernel, whose LDS
 // holds 32 rows per wave instead).
 template <class CFG, int HOIST = 0, bool KEEP_PE = true>
-NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
-                       const float *aux_in, int lane, float &sigma, float (&rgb)[3],
-                       const float *c1_row = nullptr, float *pe = nullptr, const uint8_t *lane_slots = nullptr) {
+NTX_DEV void mlp_batch_tuned(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
+                             const float *aux_in, int lane, float &sigma, float (&rgb)[3],
+                             const float *c1_row = nullptr, float *pe = nullptr, const uint8_t *lane_slots = nullptr) {
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
     constexpr bool GEO_ROWS = HOIST == 2 || HOIST == 3;
     constexpr int GS = hoisted_geo_steps<CFG, HOIST>();        // k-steps of the position segments evaluated per ray
@@ -559,6 +561,181 @@ NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
     // in slots 0..RING-1: the next batch starts without a bubble
 }
 
+// ---------------------------------------------------------------------------------------------
+// flex family: the same segments in a LOOP over layers (ntx_layout.h "flex family")
+// ---------------------------------------------------------------------------------------------
+// aux block of a family in LDS: the tuned layout, for the flex family followed by [descriptor | bias slots]
+template <class CFG>
+constexpr int aux_floats_of() { return aux_total() + (CFG::FLEX != 0 ? flex_floats() : 0); }
+
+// run_segment with the segment's first record at byte offset `sbase` of the stream (a wave-uniform run-time value) and at ring
+// phase 0; PADREC >= NSTEPS * NMT / 4 records are consumed (the pad is fetched to keep the ring turning, never multiplied) and
+// sbase is advanced past them
+template <int NSTEPS, int NMT, int PADREC, class Gen, class Extra>
+NTX_DEV void run_segment_rt(f32x16 (&acc)[8], WStream &ws, uint32_t &sbase, Gen &gen, Extra &&extra) {
+    constexpr int RPS = NMT / 4;
+    static_assert(PADREC % RING == 0 && PADREC >= NSTEPS * RPS, "whole ring turns");
+    auto load = [&](int rec) {
+        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.rsrc, ws.voff, sbase + (uint32_t)rec * 1024u, 0);
+        return __builtin_bit_cast(f32x4, v);
+    };
+    gen.template prepare<0, (NSTEPS < PE_GROUP ? NSTEPS : PE_GROUP)>();
+    float b = gen.template value<0>();
+    static_for<NSTEPS>([&](auto S) {
+        constexpr int s = S;
+        f32x4 w;
+        static_for<NMT>([&](auto MT) {
+            constexpr int mt = MT;
+            if constexpr (mt % 4 == 0) {
+                constexpr int rec = s * RPS + mt / 4;
+                w = ws.ring[rec % RING];
+                ws.ring[rec % RING] = load(rec + RING);
+            }
+            acc[mt] = mfma32(w[mt % 4], b, acc[mt]);
+            if constexpr (mt == 0 && (s + 1) % PE_GROUP == 0 && s + 1 < NSTEPS)
+                gen.template prepare<s + 1, (NSTEPS - s - 1 < PE_GROUP ? NSTEPS - s - 1 : PE_GROUP)>();
+            extra(S, MT);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (s + 1 < NSTEPS) b = gen.template value<s + 1>();
+    });
+    static_for<PADREC - NSTEPS * RPS>([&](auto I) {
+        constexpr int rec = NSTEPS * RPS + decltype(I)::value;
+        ws.ring[rec % RING] = load(rec + RING);
+    });
+    sbase += (uint32_t)PADREC * 1024u;
+}
+
+// hin[V0..V0+8) <- max(lo, accumulators): lo = 0 is the ReLU, lo = -inf passes a linear layer through (convert8 with the bound
+// in a scalar register; a NaN accumulator becomes lo, as under the ReLU -- mlp_batch's input check restores it)
+template <int V0>
+NTX_DEV void convert8_rt(float (&hin)[128], const f32x16 (&prev)[8], float lo) {
+    constexpr int T = V0 >> 4, R = V0 & 15;
+    asm("v_accvgpr_read_b32 %0, %8\n\tv_accvgpr_read_b32 %1, %9\n\tv_accvgpr_read_b32 %2, %10\n\t"
+        "v_accvgpr_read_b32 %3, %11\n\tv_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\t"
+        "v_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15\n\t"
+        "v_max_f32 %0, %16, %0\n\tv_max_f32 %1, %16, %1\n\tv_max_f32 %2, %16, %2\n\tv_max_f32 %3, %16, %3\n\t"
+        "v_max_f32 %4, %16, %4\n\tv_max_f32 %5, %16, %5\n\tv_max_f32 %6, %16, %6\n\tv_max_f32 %7, %16, %7"
+        : "=&v"(hin[V0 + 0]), "=&v"(hin[V0 + 1]), "=&v"(hin[V0 + 2]), "=&v"(hin[V0 + 3]), "=&v"(hin[V0 + 4]),
+          "=&v"(hin[V0 + 5]), "=&v"(hin[V0 + 6]), "=&v"(hin[V0 + 7])
+        : "a"(prev[T][R + 0]), "a"(prev[T][R + 1]), "a"(prev[T][R + 2]), "a"(prev[T][R + 3]), "a"(prev[T][R + 4]),
+          "a"(prev[T][R + 5]), "a"(prev[T][R + 6]), "a"(prev[T][R + 7]), "s"(lo));
+}
+template <int NMT>
+NTX_DEV void store_act_rt(float (&hin)[128], const f32x16 (&acc)[8], float lo) {
+    static_for<NMT * 2>([&](auto V) { convert8_rt<decltype(V)::value * 8>(hin, acc, lo); });
+}
+
+// The MLP of a flex model on one batch of 32 samples (model.py:58-125 / 9-45 with depth, skips, color_depth, width <= 256 as the
+// model has them).  One accumulator set; a layer = [drain the set into `hin` under the lower bound of the input's activation]
+// [bias of the layer] [its leading encoder segment, if it has one] [hidden segment].  For the 8 x 256 / skip 4 / color_depth 1
+// model every accumulator sees the same bias, the same products in the same order as in mlp_batch_tuned: the same bits.
+template <class CFG, bool KEEP_PE>
+NTX_DEV void mlp_flex(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws, const float *aux_in, int lane, float &sigma,
+                      float (&rgb)[3], float *pe) {
+    constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
+    static_assert(CFG::IPE == 0 && CFG::GEN != 0, "flex family: FourierFeatures, generic parameter slots");
+    constexpr int PS8 = flex_seg_records(CFG::PS, 8), DS8 = flex_seg_records(CFG::DS, 8), DS4 = flex_seg_records(CFG::DS, 4);
+    constexpr int H8 = flex_seg_records(HSTEPS, 8), H4 = flex_seg_records(HSTEPS, 4);
+    const int h = lane >> 5;
+    uint32_t opaque_zero = 0;
+    asm volatile("" : "+v"(opaque_zero));   // as mlp_batch_tuned: keeps the reads of the (constant) aux block next to their use
+    const float *aux = aux_in + opaque_zero;
+    const float *fbias = aux + aux_total() + FLEX_DESC_FLOATS;
+    const int *desc = reinterpret_cast<const int *>(aux_in + aux_total());
+    const int depth = __builtin_amdgcn_readfirstlane(desc[0]);
+    const uint32_t skip_mask = (uint32_t)__builtin_amdgcn_readfirstlane(desc[1]);
+    const int cdepth = __builtin_amdgcn_readfirstlane(desc[2]);
+    const float neg_inf = __builtin_bit_cast(float, 0xff800000u);
+
+    f32x16 acc[8];
+    float hin[128];
+    uint32_t sbase = 0;
+    auto none = [](auto, auto) {};
+
+    // ---- trunk layer 0: pos_map -> width (model.py:104-106)
+    init_bias<8>(acc, fbias, 0, h);
+    {
+        PosGen<NGEO, NAPP, 0, KEEP_PE ? 1 : 0, 0> gen{in, h, {}, pe};
+        run_segment_rt<CFG::PS, 8, PS8>(acc, ws, sbase, gen, none);
+    }
+    // ---- the other 8-tile layers: trunk 1 .. depth-1, F (l = depth), colour layers (l = depth + 1 .. depth + cdepth)
+    float sig_part = 0.0f;
+    const int n8 = depth + 1 + cdepth;
+    for (int l = 1; l < n8; ++l) {
+        const bool first_colour = l == depth + 1;            // its input is the LINEAR feature layer (model.py:114-115)
+        store_act_rt<8>(hin, acc, first_colour ? neg_inf : 0.0f);
+        if (l == depth) {                                    // alpha head on relu(trunk depth-1) (model.py:111)
+            const float *wa = aux + aux_alpha_off() + h * 128;
+            static_for<128>([&](auto S) { sig_part = __builtin_fmaf(hin[decltype(S)::value], wa[decltype(S)::value], sig_part); });
+        }
+        init_bias<8>(acc, fbias, l, h);
+        if (l < depth && ((skip_mask >> (l - 1)) & 1u)) {    // input = concat[pos_map, h]  (model.py:107-108)
+            const SampleIn<NGEO, NAPP> in2 = launder(in);
+            PosGen<NGEO, NAPP, 0, KEEP_PE ? 2 : 0, 0> gen{in2, h, {}, pe};
+            run_segment_rt<CFG::PS, 8, PS8>(acc, ws, sbase, gen, none);
+        } else if (first_colour) {                           // input = concat[dir_map, feature]  (model.py:115)
+            const SampleIn<NGEO, NAPP> in2 = launder(in);
+            DirGen<NGEO, NAPP> gen{in2, h, {}};
+            run_segment_rt<CFG::DS, 8, DS8>(acc, ws, sbase, gen, none);
+        }
+        HiddenGen hg{hin};
+        run_segment_rt<HSTEPS, 8, H8>(acc, ws, sbase, hg, none);
+    }
+    sigma = sig_part + __shfl_xor(sig_part, 32, 64) + aux[aux_alpha_off() + 256];
+
+    // ---- colour half layer (-> width / 2, relu; model.py:122 / 42), 4 tiles; color_depth = 0 (and plain Nerf): on [dir_map, feature]
+    store_act_rt<8>(hin, acc, cdepth > 0 ? 0.0f : neg_inf);
+    init_bias<4>(acc, fbias, n8, h);
+    if (cdepth == 0) {
+        const SampleIn<NGEO, NAPP> in2 = launder(in);
+        DirGen<NGEO, NAPP> gen{in2, h, {}};
+        run_segment_rt<CFG::DS, 4, DS4>(acc, ws, sbase, gen, none);
+    }
+    {
+        HiddenGen hg{hin};
+        run_segment_rt<HSTEPS, 4, H4>(acc, ws, sbase, hg, none);
+    }
+    store_act<4, true>(hin, acc);
+    // the prefetches of the last segment ran into the wrap-around tail: the ring holds the first RING records again
+
+    // ---- rgb head (width / 2 -> 3, linear; model.py:123) on the VALU, and the input check, as mlp_batch_tuned
+    static_for<3>([&](auto C) {
+        constexpr int c = C;
+        const f32x4 *wc = reinterpret_cast<const f32x4 *>(aux + aux_rgb_off() + (c * 2 + h) * 64);
+        float p = 0.0f;
+        static_for<16>([&](auto I) {
+            constexpr int i = I;
+            const f32x4 w = wc[i];
+            p = __builtin_fmaf(hin[4 * i + 0], w.x, p);
+            p = __builtin_fmaf(hin[4 * i + 1], w.y, p);
+            p = __builtin_fmaf(hin[4 * i + 2], w.z, p);
+            p = __builtin_fmaf(hin[4 * i + 3], w.w, p);
+        });
+        rgb[c] = p + __shfl_xor(p, 32, 64) + aux[aux_rgb_off() + 384 + c];
+    });
+    float chk = in.pos[0] + in.pos[1] + in.pos[2] + in.dir[0] + in.dir[1] + in.dir[2];
+#pragma unroll
+    for (int k = 0; k < CFG::NP; ++k) chk += in.par[k];
+    chk = chk - chk;
+    sigma += chk;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] += chk;
+}
+
+// the network of a family on one batch: the straight-line 8 x 256 kernels, or the layer loop of the flex family
+template <class CFG, int HOIST = 0, bool KEEP_PE = true>
+NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
+                       const float *aux_in, int lane, float &sigma, float (&rgb)[3],
+                       const float *c1_row = nullptr, float *pe = nullptr, const uint8_t *lane_slots = nullptr) {
+    if constexpr (CFG::FLEX != 0) {
+        static_assert(HOIST == 0, "the flex family evaluates everything per sample");
+        mlp_flex<CFG, KEEP_PE>(in, ws, aux_in, lane, sigma, rgb, pe);
+    } else {
+        mlp_batch_tuned<CFG, HOIST, KEEP_PE>(in, ws, aux_in, lane, sigma, rgb, c1_row, pe, lane_slots);
+    }
+}
+
 NTX_DEV void load_aux(float *lds, const float *aux_g, int n) {
     for (int i = threadIdx.x; i < n / 4; i += blockDim.x)
         reinterpret_cast<f32x4 *>(lds)[i] = reinterpret_cast<const f32x4 *>(aux_g)[i];
@@ -570,7 +747,7 @@ template <class CFG>
 constexpr int pe_keep_floats() { return CFG::PS * 64; }
 template <class CFG>
 NTX_DEV float *pe_column(float *aux, int wave_in_wg, int lane) {
-    return aux + aux_total() + wave_in_wg * pe_keep_floats<CFG>() + lane;
+    return aux + aux_floats_of<CFG>() + wave_in_wg * pe_keep_floats<CFG>() + lane;
 }
 
 // slot k of the kernel's parameter vector from a row of the caller's parameters, and the width of those rows
@@ -858,10 +1035,10 @@ __global__ __launch_bounds__(256) void render_kernel(RenderArgs a) {
     static_assert(HOIST == 0 || CFG::CD != 0, "hoisting is for the ParamNerf families");
     static_assert(HOIST < 2 || (CFG::IPE == 0 && CFG::NGEO > 0), "geometry hoisting: FourierFeatures families with geometry parameters");
     static_assert(HOIST != 3 || CFG::NGEO >= 2, "HOIST 3 keeps parameter 0's block per sample and hoists the others");
-    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * pe_keep_floats<CFG>() + (HOIST >= 2 ? 3 : HOIST) * DIR_BLOCK_FLOATS];
+    __shared__ __attribute__((aligned(16))) float aux[aux_floats_of<CFG>() + 4 * pe_keep_floats<CFG>() + (HOIST >= 2 ? 3 : HOIST) * DIR_BLOCK_FLOATS];
     __shared__ __attribute__((aligned(16))) float out_all[4][DIR_BLOCK_ITERS][4];   // the RGBA of a wave's rays of the block ...
-    load_aux(aux, a.aux, aux_total());
-    float *dir_rows = aux + aux_total() + 4 * pe_keep_floats<CFG>();
+    load_aux(aux, a.aux, aux_floats_of<CFG>());
+    float *dir_rows = aux + aux_floats_of<CFG>() + 4 * pe_keep_floats<CFG>();
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int vwg = xcd_major_workgroup(blockIdx.x, gridDim.x);
@@ -1103,7 +1280,7 @@ constexpr int LEAD_FLAG = 0x8000;       // bit 15 of a compacted sample index (m
 constexpr int LEAD_GROUP_MAX = 16;      // batches one group of rows may serve
 constexpr int SIDX_WINDOW = 1024;       // entries of a ray's compacted index list kept in LDS (the list itself lives in global scratch)
 template <class CFG>
-constexpr int lead_slots() { return CFG::CD == 0 ? 0 : 32; }   // rows per wave: one per sample of a batch, so EVERY batch can be served
+constexpr int lead_slots() { return CFG::CD == 0 || CFG::FLEX != 0 ? 0 : 32; }   // (flex family: the per-sample kernel)   // rows per wave: one per sample of a batch, so EVERY batch can be served
 
 // direction and appearance parameters of marching sample sm as the instancer delivered them (the run flags compare THESE; a
 // blur_idx on an appearance parameter scales it per sample, renderer.py:259-262, and then every sample is its own run)
@@ -1154,13 +1331,13 @@ template <class CFG>
 __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
     constexpr int NSLOT = lead_slots<CFG>();
     constexpr bool ROWS = NSLOT > 0;            // ParamNerf: C1 always starts from rows; plain Nerf has no C1 (per-sample kernel as before)
-    __shared__ __attribute__((aligned(16))) float aux[aux_total() + (ROWS ? 4 * NSLOT * DIR_ROW_STRIDE : 4 * pe_keep_floats<CFG>())];
+    __shared__ __attribute__((aligned(16))) float aux[aux_floats_of<CFG>() + (ROWS ? 4 * NSLOT * DIR_ROW_STRIDE : 4 * pe_keep_floats<CFG>())];
     __shared__ uint16_t win_all[4][SIDX_WINDOW];
     __shared__ InstancePending pend_all[4];
     __shared__ uint8_t slot_all[4][32];         // row of each sample of the batch in flight
     __shared__ uint16_t lead_all[4][32];        // position (in the compacted list) of the group's run leaders
     __shared__ float park_all[4][32][2];        // dists and density weight of the batch in flight (no register survives the network)
-    load_aux(aux, a.aux, aux_total());
+    load_aux(aux, a.aux, aux_floats_of<CFG>());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.n_samples;
@@ -1170,7 +1347,7 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
     uint16_t *gsidx = a.sidx_scratch + ((size_t)blockIdx.x * 4 + wv) * MAX_INSTANCE_SAMPLES;
     uint16_t *win = win_all[wv];
     InstancePending &pend = pend_all[wv];
-    float *rows = aux + aux_total() + wv * NSLOT * DIR_ROW_STRIDE;
+    float *rows = aux + aux_floats_of<CFG>() + wv * NSLOT * DIR_ROW_STRIDE;
     float *pe_col = ROWS ? nullptr : pe_column<CFG>(aux, wv, lane);
     uint8_t *slots = slot_all[wv];
     uint16_t *lead_pos = lead_all[wv];
@@ -1439,8 +1616,8 @@ struct MlpArgs {
 
 template <class CFG>
 __global__ __launch_bounds__(256) void mlp_kernel(MlpArgs a) {
-    __shared__ __attribute__((aligned(16))) float aux[aux_total() + 4 * pe_keep_floats<CFG>()];
-    load_aux(aux, a.aux, aux_total());
+    __shared__ __attribute__((aligned(16))) float aux[aux_floats_of<CFG>() + 4 * pe_keep_floats<CFG>()];
+    load_aux(aux, a.aux, aux_floats_of<CFG>());
     const int lane = threadIdx.x & 63, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int nwaves = gridDim.x * 4;

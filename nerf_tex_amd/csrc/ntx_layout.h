@@ -167,6 +167,45 @@ NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth, i
     return g;
 }
 
+// ---- flex family: the ARCHITECTURE is a run-time fact ------------------------------------------------------------------
+// model.py:58 (ParamNerf) / :9 (Nerf): depth, width, skips, color_depth.  One kernel set (Cfg<GEN_NGEO, GEN_NAPP, 1, 0, 1, 1>, the
+// parameter slots of the generic family) runs a LOOP over 256-wide layers whose bodies are the straight-line segments of the tuned
+// kernels; what varies per model is read from a descriptor in the aux block:
+//   trunk layer 0            position segment
+//   trunk layers 1 .. D-1    [position segment, when the previous layer's index is in `skips`] + hidden segment
+//   F (linear)               hidden segment; the alpha head rides on its input relu(trunk D-1)
+//   colour layers 1 .. CD    the first one [direction segment] + hidden segment on the LINEAR F, the others hidden segments
+//   colour half (4 tiles)    hidden segment; with CD = 0 (also plain Nerf): [direction segment] + hidden segment on the linear F
+// width < 256: the missing rows / columns / biases are zero (relu(0) = 0 feeds zero rows of the next layer: exact).
+// Every segment of the flex STREAM is padded with zero records to a multiple of RING, so each body starts at ring phase 0 whatever
+// came before it; the record offset is a run-time scalar that advances body by body.  The stream ends with the same wrap-around
+// tail (the first RING records again).  Bias slots (aux block, behind the tuned aux layout whose alpha / rgb heads it keeps):
+// slot l = layer l in the order above.
+constexpr int FLEX_MAX_DEPTH = 24;      // trunk layers
+constexpr int FLEX_MAX_COLOR = 4;       // color_depth
+constexpr int FLEX_MAX_LAYERS = 32;     // bias slots: D trunk + F + CD colour + colour half <= 24 + 1 + 4 + 1
+constexpr int FLEX_DESC_FLOATS = 64;    // int32 words at the head of the flex block: [0] depth, [1] skip mask, [2] color_depth
+constexpr int NTX_SKIP_MASK_BIT = 0x40000000;   // ntx_model_desc.skip = NTX_SKIP_MASK_BIT | mask of the indices in `skips`
+
+NTX_HD constexpr int flex_floats() { return FLEX_DESC_FLOATS + FLEX_MAX_LAYERS * AUX_BIAS_STRIDE; }
+NTX_HD constexpr int flex_seg_records(int steps, int nmt) { return round_up(steps * (nmt / 4), RING); }
+
+struct FlexArch {
+    int depth, width, color_depth;   // color_depth of the MODEL (0 for plain Nerf)
+    unsigned skip_mask;              // bit i: trunk layer i + 1 takes concat[pos_map, h]  (model.py:107-108), i < depth - 1
+};
+// records of the flex stream without the wrap-around tail (a multiple of RING by construction)
+NTX_HD constexpr int flex_stream_records(const FlexArch &f) {
+    const int ps8 = flex_seg_records(pos_steps(GEN_NGEO), 8), ds8 = flex_seg_records(dir_steps(GEN_NAPP), 8),
+              ds4 = flex_seg_records(dir_steps(GEN_NAPP), 4), h8 = flex_seg_records(HSTEPS, 8), h4 = flex_seg_records(HSTEPS, 4);
+    int rec = ps8;
+    for (int i = 1; i < f.depth; ++i) rec += (((f.skip_mask >> (i - 1)) & 1u) ? ps8 : 0) + h8;
+    rec += h8;                                             // F
+    if (f.color_depth > 0) rec += ds8 + h8 + (f.color_depth - 1) * h8 + h4;
+    else rec += ds4 + h4;
+    return rec;
+}
+
 // ---- fp16x3 precision (ntx_device_x3.h): the same network on v_mfma_f32_32x32x16_f16 -----------------
 // One k16-step = 8 consecutive k2-steps of the maps above (element e of half h in step u = k2-step 8u+e), segments
 // padded with zero rows to whole k16-steps.  One record = 64 lanes x 8 halves (1 KiB) = the A operand of one

@@ -5,7 +5,7 @@
 #include "ntx_device.h"
 
 #ifndef NTX_VARIANT
-#error "compile with -DNTX_VARIANT=0..5"
+#error "compile with -DNTX_VARIANT=0..6"
 #endif
 
 namespace ntx {
@@ -25,9 +25,12 @@ using VCfg = Cfg<0, 0, 0>;   // plain Nerf
 #elif NTX_VARIANT == 4
 using VCfg = Cfg<1, 3, 1, 1>;   // mip: IPE position encoding, grass_filtered with the blur parameter spliced out
 #define NTX_FN(name) name##_v4
-#else
+#elif NTX_VARIANT == 5
 using VCfg = Cfg<GEN_NGEO, GEN_NAPP, 1, 0, 1>;   // generic: any ParamNerf n_parameters = [g <= 4, a <= 8] (absent parameters = zero rows)
 #define NTX_FN(name) name##_v5
+#else
+using VCfg = Cfg<GEN_NGEO, GEN_NAPP, 1, 0, 1, 1>;   // flex: depth, width <= 256, skips, color_depth as the model has them (a layer loop)
+#define NTX_FN(name) name##_v6
 #endif
 
 #ifdef NTX_HOIST

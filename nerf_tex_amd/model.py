@@ -81,10 +81,13 @@ class NerfModel:
 
     def desc(self):
         from . import _lib
-        if len(self.skips) != 1:
-            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, f"skips={self.skips}: the HIP kernels implement one skip layer")
+        # `skips` (model.py:107: `if i in skips` for i in range(depth)): one index as it is, none = -1, several = NTX_SKIP_MASK | bits
+        live = sorted({int(i) for i in self.skips if 0 <= int(i) < self.depth})
+        if any(i >= 30 for i in live):
+            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, f"skips={self.skips}: layer indices above 29 have no encoding in ntx_model_desc")
+        skip = -1 if not live else live[0] if len(live) == 1 else _lib.SKIP_MASK | sum(1 << i for i in live)
         return _lib.ModelDesc(self.kind, self.n_geo, self.n_app, self.n_pos, self.pos_freq, self.dir_freq,
-                              self.param_freq, self.depth, self.width, self.skips[0], self.color_depth,
+                              self.param_freq, self.depth, self.width, skip, self.color_depth,
                               1 if self.pos_encoding == "ipe" else 0)
 
     # ---- weights -----------------------------------------------------------------------

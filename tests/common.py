@@ -11,9 +11,20 @@ EMB = lambda n: {"module": "network.model.FourierFeatures", "n_freq_bands": n}  
 TOL = 1e-4   # BASELINE.json north_star: <= 1e-4 relative L-inf (float32) vs the reference render
 
 
-def make_model(n_parameters=(1, 6), kind="ParamNerf", seed=0, dense_media=False):
-    """(product model with synthetic weights, oracle spec, oracle weight list)"""
-    if kind == "IPE":                      # mip variant: IntegratedPositionalEncoding on (mean, covariance)
+def make_model(n_parameters=(1, 6), kind="ParamNerf", seed=0, dense_media=False, arch=None):
+    """(product model with synthetic weights, oracle spec, oracle weight list).  `arch`: depth / width / skips / color_depth other
+    than the reference configs' 8 / 256 / [4] / 1 (model.py:58, :9)."""
+    if arch:
+        a = dict(arch)
+        spec_kw = dict(depth=a.get("depth", 8), width=a.get("width", 256), skips=tuple(a.get("skips", (4,))))
+        if kind == "Nerf":
+            model = Nerf(EMB(10), EMB(4), depth=spec_kw["depth"], width=spec_kw["width"], skips=list(spec_kw["skips"]))["model"]
+            spec = orc.ModelSpec(kind="Nerf", n_parameters=(0, 0), **spec_kw)
+        else:
+            model = ParamNerf(EMB(10), EMB(4), EMB(4), list(n_parameters), depth=spec_kw["depth"], width=spec_kw["width"],
+                              skips=list(spec_kw["skips"]), color_depth=a.get("color_depth", 1))["model"]
+            spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(n_parameters), color_depth=a.get("color_depth", 1), **spec_kw)
+    elif kind == "IPE":                      # mip variant: IntegratedPositionalEncoding on (mean, covariance)
         ipe = {"module": "network.layer.IntegratedPositionalEncoding", "n_freq_bands": 10}
         model = ParamNerf(ipe, EMB(4), EMB(4), list(n_parameters), n_pos=6)["model"]
         spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(n_parameters), n_pos=6, pos_encoding="ipe")

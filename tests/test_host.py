@@ -38,11 +38,54 @@ def test_create_without_gpu_reports_no_device():
 def test_unsupported_desc_is_rejected_on_host():
     from nerf_tex_amd import _lib
     for bad in (_lib.ModelDesc(0, 5, 3, 3, 10, 4, 4, 8, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 9, 3, 10, 4, 4, 8, 256, 4, 1, 0),
-                _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 2, 0), _lib.ModelDesc(0, 1, 6, 3, 8, 4, 4, 8, 256, 4, 1, 0),
-                _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 6, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 128, 4, 1, 0),
-                _lib.ModelDesc(0, 1, 3, 3, 10, 4, 4, 8, 256, 4, 1, 1), _lib.ModelDesc(0, 1, 6, 6, 10, 4, 4, 8, 256, 4, 1, 1)):
+                _lib.ModelDesc(0, 1, 6, 3, 8, 4, 4, 8, 256, 4, 1, 0),
+                _lib.ModelDesc(0, 1, 3, 3, 10, 4, 4, 8, 256, 4, 1, 1), _lib.ModelDesc(0, 1, 6, 6, 10, 4, 4, 8, 256, 4, 1, 1),
+                # architectures outside the flex family's loop: too deep, too wide, too many colour layers, a skip behind the last
+                # trunk layer (it widens the alpha head and the feature layer, model.py:107-114), an IPE model off the 8x256 shape
+                _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 25, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 257, 4, 1, 0),
+                _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 5, 0), _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 256, 7, 1, 0),
+                _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 6, 128, _lib.SKIP_MASK | 0b100100, 1, 0), _lib.ModelDesc(0, 1, 3, 6, 10, 4, 4, 6, 256, 4, 1, 1),
+                _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 0, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 6, 3, 10, 4, 4, 8, 1, 4, 1, 0)):
         assert _lib.lib.ntx_weight_count(C.byref(bad)) == 0
         assert b"unsupported" in _lib.lib.ntx_last_error()
+
+
+@pytest.mark.parametrize("kind,npar,depth,width,skips,cd", [(0, (1, 6), 8, 256, (4,), 2), (0, (1, 6), 6, 256, (4,), 1), (0, (1, 6), 8, 128, (4,), 1),
+                                                            (0, (2, 3), 10, 256, (3, 6), 0), (0, (0, 0), 1, 30, (), 4), (1, (0, 0), 5, 100, (1, 2), 0),
+                                                            (0, (4, 8), 24, 256, tuple(range(23)), 4), (0, (1, 4), 8, 256, (), 1)])
+def test_pack_weights_flex_family_is_a_permutation(kind, npar, depth, width, skips, cd):
+    """Architectures other than 8 x 256 / [4] / 1 go to the flex family (ntx_layout.h): the weight count is the model's own layer
+    table (model.py:104-123 in get_weights() order), every weight lands in the packed image exactly once -- the rest is zero: rows
+    and columns of layers narrower than 256, the pads that bring every segment to whole ring turns --, the stream ends with the
+    wrap-around tail, and the descriptor behind the tuned aux layout carries depth / skip mask / color_depth."""
+    from nerf_tex_amd import _lib
+    from nerf_tex_amd.model import NerfModel
+    m = NerfModel(kind, npar, 3, 10, 4, 4 if kind == 0 else 0, depth, width, skips, cd, "model")
+    d = m.desc()
+    n = _lib.lib.ntx_weight_count(C.byref(d))
+    assert n == m.n_weight_floats() > 0, _lib.lib.ntx_last_error()
+    npk = _lib.lib.ntx_packed_count(C.byref(d))
+    blob = (np.random.default_rng(0).permutation(n) + 1).astype(np.float32)
+    out = np.empty(npk, np.float32)
+    fp = C.POINTER(C.c_float)
+    assert _lib.lib.ntx_pack_weights(C.byref(d), blob.ctypes.data_as(fp), n, out.ctypes.data_as(fp), npk) == 0
+    aux_floats = 3776 + 64 + 32 * 256                             # aux_total() + flex_floats(): descriptor words, 32 bias slots
+    stream, aux = out[:npk - aux_floats], out[npk - aux_floats:]
+    assert stream.size % (8 * 256) == 0                           # whole ring turns (every segment padded), plus the tail
+    np.testing.assert_array_equal(stream[:8 * 256], stream[-8 * 256:])
+    words = aux[3776:3776 + 64].view(np.int32)
+    live = [i for i in skips if i < depth - 1]
+    assert words[0] == depth and words[1] == sum(1 << i for i in live) and words[2] == (cd if kind == 0 else 0) and not words[3:].any()
+    body = stream[:-8 * 256]
+    rest = np.concatenate([aux[:3776], aux[3776 + 64:]])
+    vals = np.concatenate([body[body != 0], rest[rest != 0]])
+    assert vals.size == n and np.array_equal(np.sort(vals), np.sort(blob))
+    # the trunk's stream length follows the architecture: pos segment 52 k-steps -> 104 records, hidden 256, direction 50 -> 104 / 56
+    n8 = depth - 1 + 1 + (cd if kind == 0 else 0)
+    cdm = cd if kind == 0 else 0
+    want_rec = 104 + n8 * 256 + 104 * len(live) + (104 + 128 if cdm > 0 else 56 + 128)
+    assert body.size == want_rec * 256
+    assert _lib.lib.ntx_packed_fp16x3_bytes(C.byref(d)) == 0 and b"fp16x3" in _lib.lib.ntx_last_error()
 
 
 @pytest.mark.parametrize("desc,count", [((0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, 0), 683524), ((0, 1, 4, 3, 10, 4, 4, 8, 256, 4, 1, 0), 678916),
@@ -602,11 +645,17 @@ def test_no_mfma_kernel_uses_scratch():
     # the exceptions, documented in DESIGN section 4.2: the instanced kernels of the two families no shipped config uses (mip / IPE
     # [1,3], and the generic family [4,8]) keep 2-4 loop-invariant dwords of their scheduler in scratch (stored once per launch,
     # reloaded once per ray, never inside the network); every kernel of the shipped families and every render / mlp kernel has none
-    known = {k for k in big if "instance_kernel" in k and ("CfgILi1ELi3ELi1ELi1ELi0" in k or "CfgILi4ELi8ELi1ELi0ELi1" in k)}
+    known = {k for k in big if "instance_kernel" in k and ("CfgILi1ELi3ELi1ELi1ELi0" in k or "CfgILi4ELi8ELi1ELi0ELi1ELi0" in k)}
+    # ... and the flex family (architectures no reference config has; a run-time loop over layers, whose counters and lane indices
+    # live across the layer bodies): <= 20 dwords stored once per launch, reloaded once per batch / per ray outside the layer loop
+    flex = {k for k in big if "CfgILi4ELi8ELi1ELi0ELi1ELi1" in k}
+    assert len(flex) == 3                                   # render, mlp, instance: float32 only
     for k, v in big.items():
         assert v["lds"] <= 160 * 1024, (k, v)
         assert v["agpr"] == 256 and v["vgpr"] <= 512, (k, v)
-        if k in known:
+        if k in flex:
+            assert v["scratch"] <= 80, (k, v)
+        elif k in known:
             assert v["scratch"] <= 16, (k, v)
         else:
             assert v["scratch"] == 0, (k, v)
