@@ -55,6 +55,28 @@ def test_mlp_forward_any_architecture(kind, npar, arch, m):
     assert err <= 3e-5, err         # what exact-f32 MFMA reaches on glorot weights (deeper trunks accumulate a little more)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_mlp_forward_random_architectures(seed):
+    """Seeded random architectures inside the family's limits: depth 1..24, width 2..256, any set of skips below depth-1,
+    color_depth 0..4, n_parameters up to [4, 8] (or plain Nerf)."""
+    rng = np.random.default_rng(1000 + seed)
+    depth = int(rng.integers(1, 25)) if seed % 3 else int(rng.integers(1, 7))
+    width = int(rng.choice([2, 7, 32, 64, 100, 128, 192, 255, 256]))
+    skips = sorted(int(i) for i in np.flatnonzero(rng.uniform(size=max(depth - 1, 0)) < 0.3))
+    kind = "Nerf" if seed % 5 == 4 else "ParamNerf"
+    npar = (0, 0) if kind == "Nerf" else (int(rng.integers(0, 5)), int(rng.integers(0, 9)))
+    arch = dict(depth=depth, width=width, skips=skips, color_depth=int(rng.integers(0, 5)))
+    if kind == "ParamNerf" and (depth, width, tuple(skips), arch["color_depth"]) == (8, 256, (4,), 1):
+        arch["color_depth"] = 2                             # (that one is the tuned families' architecture)
+    model, spec, w = make_model(npar, kind, seed=seed, arch=arch)
+    pos, dirs, params = random_samples(700 + seed, sum(npar), seed=seed)
+    color, alpha = model(tuple(to_dev(pos, dirs, params)))
+    rc, ra = orc.model_forward(w, spec, pos, dirs, params, np.float64)
+    out = np.concatenate([color.cpu().numpy(), alpha.cpu().numpy()], -1)
+    err = orc.rel_linf(out, np.concatenate([rc, ra], -1))
+    assert err <= 3e-5, (err, kind, npar, arch)
+
+
 def test_flex_kernels_give_the_tuned_kernels_bits(monkeypatch):
     """The 8 x 256 / [4] / 1 model forced onto the flex kernels (NERFTEX_FORCE_FLEX, read by ntx_create): every accumulator sees the
     same bias and the same products in the same order as in the straight-line kernels, so the network outputs and the rendered

@@ -395,3 +395,8 @@ def test_layer_order_follows_keras_graph_depth_rule():
     assert order_of("ParamNerf", 1) == [n for n, _, _ in orc.layer_table(orc.ModelSpec(kind="ParamNerf", n_parameters=(1, 6)))]
     assert order_of("Nerf", 0) == [n for n, _, _ in orc.layer_table(orc.ModelSpec(kind="Nerf", n_parameters=(0, 0)))]
     assert order_of("ParamNerf", 1)[-2:] == ["color", "alpha"] and order_of("ParamNerf", 1)[8] == "feature"
+    # ... and for the architectures of the flex family (depth, skips, color_depth other than 8 / [4] / 1): the same rule, the same table
+    for kind, cd, depth, skips in (("ParamNerf", 0, 8, (4,)), ("ParamNerf", 3, 8, (4,)), ("ParamNerf", 1, 3, (0, 1)), ("ParamNerf", 2, 10, (3, 6)),
+                                   ("ParamNerf", 1, 1, ()), ("ParamNerf", 4, 24, tuple(range(0, 23, 2))), ("Nerf", 0, 5, (1, 2)), ("Nerf", 0, 6, ())):
+        spec = orc.ModelSpec(kind=kind, n_parameters=(1, 6) if kind == "ParamNerf" else (0, 0), depth=depth, skips=skips, color_depth=cd)
+        assert order_of(kind, cd, depth, skips) == [n for n, _, _ in orc.layer_table(spec)], (kind, cd, depth, skips)
