@@ -348,14 +348,27 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Development knob (never set by the driver; the line says so): NTX_BENCH_SHARE_GPU=1 runs the N ranks on ONE GPU -- process
+    # group on gloo, the RGBA gathered through host memory by the same plan -- so that everything of an N > 1 run except RCCL
+    # itself (launcher, shard maps, per-rank fields, the bit-identity check of the sharded image) executes on a 1-GPU box.
+    # Its timings mean nothing: the ranks take turns on the GPU.
+    share_gpu = world > 1 and os.environ.get("NTX_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    sdev = torch.device("cpu") if share_gpu else dev        # where the few scalars the ranks exchange live (gloo: host)
     comm, gather_how = None, None
-    if world > 1:
+    if share_gpu:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.deadline, exit=True)
+        dist.init_process_group("gloo")
+        gather_how = "torch.distributed (gloo) through host memory: NTX_BENCH_SHARE_GPU=1, all ranks on one GPU -- timings are not a measurement"
+    elif world > 1:
         # a rank stuck in a collective (a peer died, ncclCommInitRank never completes ...) must not hold the node: after the
         # deadline this rank dumps its stacks to stderr and exits, whatever the main thread is blocked in
         import faulthandler
@@ -427,7 +440,10 @@ def main() -> None:
         if i is not None:
             ev1[i].record()                                  # same stream the kernel was launched on
         rgba = torch.cat([out["color_pred"][0], out["alpha_pred"][0][:, None]], -1)
-        if world > 1 and gather:
+        if world > 1 and gather and share_gpu:
+            g_ = gather_image(rgba.cpu(), shard)             # (development knob: the same plan through host memory)
+            rgba = g_.to(dev) if g_ is not None else None
+        elif world > 1 and gather:
             rgba = gather_image(rgba, shard, comm=comm)      # the one collective: RGBA -> rank 0 (ntx_gather_image)
         if i is not None:
             ev2[i].record()
@@ -450,11 +466,11 @@ def main() -> None:
     gather_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev1, ev2)]))   # torch.cat + the gather (+ un-shard on the root)
     per_rank = None
     if world > 1:
-        tt = torch.tensor([elapsed, float(n_hit)], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed, float(n_hit)], device=sdev, dtype=torch.float64)
         mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, hits_total = float(mx[0].item()), int(sm[1].item())
-        mine = torch.tensor([kernel_ms, gather_ms, float(n_rays), float(n_hit)], device=dev, dtype=torch.float64)
+        mine = torch.tensor([kernel_ms, gather_ms, float(n_rays), float(n_hit)], device=sdev, dtype=torch.float64)
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank = [{"rank": r, "kernel_ms": float(v[0]), "gather_ms": float(v[1]), "rays": int(v[2]), "hits": int(v[3])} for r, v in enumerate(every)]

@@ -72,6 +72,35 @@ def test_multi_rank_line_schema():
     assert d["gather_bytes"] == 640000 * 16 and 1.0 <= d["imbalance"] < 1.1 and 0.8 < d["efficiency_vs_rank0_alone"] <= 1.05
 
 
+@pytest.mark.parametrize("workload,shard", [("fur_sharded", "rows"), ("fur_sharded", "bands"), ("carpet", "rows")])
+def test_two_ranks_sharing_the_gpu_run_the_whole_multi_rank_bench(workload, shard):
+    """Everything of an N = 2 run except RCCL itself, on a 1-GPU box (development knob NTX_BENCH_SHARE_GPU: both ranks on GPU 0,
+    process group on gloo, the gather plan executed through host memory): the self-launcher, the shard maps, every N > 1 field of
+    the line, and -- the point -- the sharded image gathered from two ranks is bit-identical to the image one GPU renders."""
+    env = dict(os.environ, NTX_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--deadline", "500",
+                          "--no-cpu-baseline", "--workload", workload, "--shard", shard], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in MULTI_RANK_FIELDS:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and "NTX_BENCH_SHARE_GPU" in d["gather_how"] and "NTX_BENCH_SHARE_GPU" in d["config"]["workload"]
+    pr = d["per_rank"]
+    assert len(pr) == 2 and [p["rank"] for p in pr] == [0, 1] and all(p["kernel_ms"] > 0 for p in pr)
+    assert sum(p["hits"] for p in pr) == d["config"]["hit_rays_total"] and d["gather_bytes"] == pr[1]["rays"] * 16
+    assert d["parity"]["ok"] is True                        # rank 0's own shard against the restatement
+    if workload == "fur_sharded":
+        assert d["scaling"] == "strong" and sum(p["rays"] for p in pr) == 640000
+        assert d["sharded_image_bit_identical_to_1gpu"] is True
+        assert d["whole_image_1gpu_ms"] > 0 and d["efficiency_vs_1gpu"] > 0
+        if shard == "rows":                                 # rows dealt round-robin balance what the proxy culls
+            assert abs(pr[0]["hits"] - pr[1]["hits"]) < 0.02 * d["config"]["hit_rays_total"]
+    else:
+        assert d["scaling"] == "weak" and all(p["rays"] == 640000 for p in pr) and d["efficiency_vs_rank0_alone"] > 0
+
+
 def test_cpu_baseline_block():
     d = _run("--workload", "fur")
     c = d["cpu_baseline"]
