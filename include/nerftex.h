@@ -44,7 +44,11 @@ typedef enum ntx_status {
 } ntx_status;
 
 /* Model architecture = the kwargs of network.model.ParamNerf (model.py:58) / Nerf (model.py:9). */
-typedef enum ntx_model_kind { NTX_MODEL_PARAMNERF = 0, NTX_MODEL_NERF = 1 } ntx_model_kind;
+typedef enum ntx_model_kind {
+    NTX_MODEL_PARAMNERF = 0,
+    NTX_MODEL_NERF = 1,
+    NTX_MODEL_PARAMNERF_EX = 2   /* a ParamNerf whose descriptor is the extended struct ntx_model_desc_ex below: param_depth > 0 */
+} ntx_model_kind;
 /* layer.FourierFeatures (layer.py:8-23) / layer.IntegratedPositionalEncoding (layer.py:25-41) */
 typedef enum ntx_pos_encoding { NTX_POS_FOURIER = 0, NTX_POS_IPE = 1 } ntx_pos_encoding;
 
@@ -53,8 +57,8 @@ typedef enum ntx_pos_encoding { NTX_POS_FOURIER = 0, NTX_POS_IPE = 1 } ntx_pos_e
  * plain Nerf, and one IntegratedPositionalEncoding family [1,3] -- these at the architecture every reference config uses: depth 8,
  * width 256, skips [4], color_depth 1.  Any OTHER architecture of model.py:58 / :9 with FourierFeatures embeddings -- depth 1..24,
  * width 2..256, color_depth 0..4, any skips below depth-1 -- runs on the "flex" family: the same MFMA segments in a loop over layers
- * (narrower layers zero-padded to 256), float32 only (NTX_FLAG_FP16X3: NTX_E_UNSUPPORTED), nothing hoisted per ray.  10/4/4
- * frequency bands, param_depth 0, no embedding_config.  Anything else: NTX_E_UNSUPPORTED. */
+ * (narrower layers zero-padded to 256), float32 only (NTX_FLAG_FP16X3: NTX_E_UNSUPPORTED), nothing hoisted per ray; param_depth 1..4
+ * through ntx_model_desc_ex (below).  10/4/4 frequency bands, no embedding_config.  Anything else: NTX_E_UNSUPPORTED. */
 #define NTX_SKIP_MASK 0x40000000   /* ntx_model_desc.skip = NTX_SKIP_MASK | mask: several skip layers (bit i: i in skips) */
 typedef struct ntx_model_desc {
     int32_t kind;        /* ntx_model_kind */
@@ -71,6 +75,18 @@ typedef struct ntx_model_desc {
     int32_t color_depth; /* ParamNerf: 1 (model.py:118), flex family: 0..4; ignored for Nerf */
     int32_t pos_encoding;/* ntx_pos_encoding of pos_embedding: FourierFeatures (n_pos 3) or IntegratedPositionalEncoding (n_pos 6) */
 } ntx_model_desc;
+
+/* kind == NTX_MODEL_PARAMNERF_EX: the pointer every entry point takes as `const ntx_model_desc *` points to one of these.
+ * param_depth Dense(param_width, relu) layers shape the Fourier features of the geometry parameters and, separately, of the
+ * appearance parameters before they are concatenated to pos_map / dir_map (model.py:88-101).  Built: param_depth 1..4,
+ * param_width 2..128, on the flex family's float32 kernels (any depth / width / skips / color_depth it takes).  param_depth = 0
+ * is the plain ParamNerf. */
+typedef struct ntx_model_desc_ex {
+    ntx_model_desc base;     /* base.kind = NTX_MODEL_PARAMNERF_EX */
+    int32_t param_depth;
+    int32_t param_width;
+    int32_t reserved[6];     /* 0 */
+} ntx_model_desc_ex;
 
 /* flags of ntx_composite / ntx_render_rays */
 #define NTX_FLAG_MAP_EXR 1u         /* renderer.py:182-184: colour = elu(raw)+1 instead of sigmoid  */

@@ -17,15 +17,18 @@ LIB_PATH = os.environ.get("NERFTEX_LIB") or os.path.join(_HERE, "libnerftex_hip.
 NTX_OK, NTX_E_INVALID, NTX_E_UNSUPPORTED, NTX_E_HIP, NTX_E_NODEVICE = 0, -1, -2, -3, -4
 FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS, FLAG_FP16X3, FLAG_PERTURB, FLAG_RAW_NOISE = 1, 2, 4, 8, 16, 32
 ABI_VERSION = 3
+KIND_PARAMNERF_EX = 2           # NTX_MODEL_PARAMNERF_EX: the descriptor's param_depth / param_width count
 SKIP_MASK = 0x40000000          # NTX_SKIP_MASK: ntx_model_desc.skip carries a mask of skip-layer indices
 COMM_ID_BYTES = 128
 DEFAULT_MAX_RAYS = 1 << 20
 
 
 class ModelDesc(C.Structure):
-    """struct ntx_model_desc"""
+    """struct ntx_model_desc_ex: struct ntx_model_desc (the first twelve fields, what every entry point reads unless kind is
+    NTX_MODEL_PARAMNERF_EX = 2) followed by param_depth, param_width and six reserved words"""
     _fields_ = [(n, C.c_int32) for n in ("kind", "n_geo", "n_app", "n_pos", "pos_freq", "dir_freq",
-                                          "param_freq", "depth", "width", "skip", "color_depth", "pos_encoding")]
+                                          "param_freq", "depth", "width", "skip", "color_depth", "pos_encoding",
+                                          "param_depth", "param_width")] + [("reserved", C.c_int32 * 6)]
 
 
 class RenderOpts(C.Structure):

@@ -608,8 +608,8 @@ NTX_DEV void run_segment_rt(f32x16 (&acc)[8], WStream &ws, uint32_t &sbase, Gen 
 
 // hin[V0..V0+8) <- max(lo, accumulators): lo = 0 is the ReLU, lo = -inf passes a linear layer through (convert8 with the bound
 // in a scalar register; a NaN accumulator becomes lo, as under the ReLU -- mlp_batch's input check restores it)
-template <int V0>
-NTX_DEV void convert8_rt(float (&hin)[128], const f32x16 (&prev)[8], float lo) {
+template <int V0, int NH>
+NTX_DEV void convert8_rt(float (&hin)[NH], const f32x16 (&prev)[8], float lo) {
     constexpr int T = V0 >> 4, R = V0 & 15;
     asm("v_accvgpr_read_b32 %0, %8\n\tv_accvgpr_read_b32 %1, %9\n\tv_accvgpr_read_b32 %2, %10\n\t"
         "v_accvgpr_read_b32 %3, %11\n\tv_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\t"
@@ -621,9 +621,96 @@ NTX_DEV void convert8_rt(float (&hin)[128], const f32x16 (&prev)[8], float lo) {
         : "a"(prev[T][R + 0]), "a"(prev[T][R + 1]), "a"(prev[T][R + 2]), "a"(prev[T][R + 3]), "a"(prev[T][R + 4]),
           "a"(prev[T][R + 5]), "a"(prev[T][R + 6]), "a"(prev[T][R + 7]), "s"(lo));
 }
-template <int NMT>
-NTX_DEV void store_act_rt(float (&hin)[128], const f32x16 (&acc)[8], float lo) {
-    static_for<NMT * 2>([&](auto V) { convert8_rt<decltype(V)::value * 8>(hin, acc, lo); });
+template <int NMT, int NH>
+NTX_DEV void store_act_rt(float (&hin)[NH], const f32x16 (&acc)[8], float lo) {
+    static_assert(NMT * 16 <= NH, "one register per accumulator value");
+    static_for<NMT * 2>([&](auto V) { convert8_rt<decltype(V)::value * 8, NH>(hin, acc, lo); });
+}
+
+// ---- param_depth > 0 (model.py:88-101; Cfg FLEX = 2): the parameter features pass `param_depth` Dense(param_width <= 128, relu)
+// layers before they are concatenated to pos_map / dir_map.  A branch = FF(params) (one block of GEO_BLOCK k-steps per parameter
+// slot, last slot first, as the geometry blocks of the position segment) -> 4 tiles, then param_depth - 1 hidden segments of 64
+// k-steps x 4 tiles; its output stays in 64 registers and is the B operand of 64 more k-steps of the consuming layer.
+template <int N>
+struct ParFFGen {               // FF(par[0..N)), PAR_FREQ bands
+    const float *par;           // N values of this lane's sample (registers)
+    int h;
+    float vals[PE_GROUP];
+    template <int S>
+    NTX_DEV float feature() const {
+        constexpr int p = N - 1 - S / GEO_BLOCK, j = S % GEO_BLOCK;
+        if constexpr (j == 0) return h ? 0.0f : par[p];
+        else return sin_q(par[p] * (float)(1 << (j - 1)), h);
+    }
+    template <int S, int NN>
+    NTX_DEV void prepare() {
+        static_for<NN>([&](auto K) { vals[(S + decltype(K)::value) % PE_GROUP] = feature<S + decltype(K)::value>(); });
+    }
+    template <int S>
+    NTX_DEV float value() const { return vals[S % PE_GROUP]; }
+};
+struct Reg64Gen {               // 64 k-steps out of 64 registers (a branch's hidden activations / its output)
+    const float (&hb)[64];
+    template <int S, int N>
+    NTX_DEV void prepare() {}
+    template <int S>
+    NTX_DEV float value() const { return hb[S]; }
+};
+struct DirOnlyGen {             // FF(dir, DIR_FREQ) alone: (dx, dy), (dz, pad), {sin, cos}(2^f d_c)  =  dir_row(0, s, h)
+    const float (&dir)[3];
+    int h;
+    float vals[PE_GROUP];
+    template <int S>
+    NTX_DEV float feature() const {
+        if constexpr (S == 0) return h ? dir[1] : dir[0];
+        else if constexpr (S == 1) return h ? 0.0f : dir[2];
+        else return sin_q(dir[(S - 2) % 3] * (float)(1 << ((S - 2) / 3)), h);
+    }
+    template <int S, int NN>
+    NTX_DEV void prepare() {
+        static_for<NN>([&](auto K) { vals[(S + decltype(K)::value) % PE_GROUP] = feature<S + decltype(K)::value>(); });
+    }
+    template <int S>
+    NTX_DEV float value() const { return vals[S % PE_GROUP]; }
+};
+constexpr int BRANCH_STEPS = 64;    // k-steps of a 128-wide branch activation
+struct LdsColGen {              // 64 k-steps out of this lane's LDS column col[step * 64] (a branch's OUTPUT: it outlives the registers)
+    const float *col;
+    float vals[PE_GROUP];
+    template <int S, int N>
+    NTX_DEV void prepare() {
+        static_for<N>([&](auto K) { vals[(S + decltype(K)::value) % PE_GROUP] = col[(S + decltype(K)::value) * 64]; });
+    }
+    template <int S>
+    NTX_DEV float value() const { return vals[S % PE_GROUP]; }
+};
+
+// relu(accumulator tiles 0..3) -> this lane's LDS column, 8 values at a time (no 64 registers held next to a live `hin`)
+NTX_DEV void drain_to_col(float *col, const f32x16 (&acc)[8]) {
+    static_for<8>([&](auto V) {
+        constexpr int v0 = decltype(V)::value * 8;
+        float t[128];   // (only t[v0 .. v0+8) exist after SROA: convert8_rt indexes the array it is given)
+        convert8_rt<v0, 128>(t, acc, 0.0f);
+        static_for<8>([&](auto K) { col[(v0 + decltype(K)::value) * 64] = t[v0 + decltype(K)::value]; });
+    });
+}
+
+template <int N>
+NTX_DEV void param_branch(const float *par, int pdepth, f32x16 (&acc)[8], float *col, WStream &ws, uint32_t &sbase,
+                          const float *fbias, int slot0, int h) {
+    auto none = [](auto, auto) {};
+    init_bias<4>(acc, fbias, slot0, h);
+    {
+        ParFFGen<N> gen{par, h, {}};
+        run_segment_rt<N * GEO_BLOCK, 4, flex_seg_records(N * GEO_BLOCK, 4)>(acc, ws, sbase, gen, none);
+    }
+    for (int i = 1; i < pdepth; ++i) {
+        drain_to_col(col, acc);              // every layer's activations pass through the column: written and read by this lane only
+        init_bias<4>(acc, fbias, slot0 + i, h);
+        LdsColGen hg{col, {}};
+        run_segment_rt<BRANCH_STEPS, 4, flex_seg_records(BRANCH_STEPS, 4)>(acc, ws, sbase, hg, none);
+    }
+    drain_to_col(col, acc);
 }
 
 // The MLP of a flex model on one batch of 32 samples (model.py:58-125 / 9-45 with depth, skips, color_depth, width <= 256 as the
@@ -635,8 +722,12 @@ NTX_DEV void mlp_flex(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws, con
                       float (&rgb)[3], float *pe) {
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
     static_assert(CFG::IPE == 0 && CFG::GEN != 0, "flex family: FourierFeatures, generic parameter slots");
-    constexpr int PS8 = flex_seg_records(CFG::PS, 8), DS8 = flex_seg_records(CFG::DS, 8), DS4 = flex_seg_records(CFG::DS, 4);
+    constexpr bool PB = CFG::FLEX == 2;    // param_depth > 0: parameter branches (above); pos_map = [FF(pos) | G], dir_map = [FF(dir) | A]
+    constexpr int GOFF = PB ? pos_geo_steps(NGEO) : 0;             // PB: the position segment is its FF(pos) part alone
+    constexpr int PSTEPS = CFG::PS - GOFF, DSTEPS = PB ? dir_steps(0) : CFG::DS;
+    constexpr int PS8 = flex_seg_records(PSTEPS, 8), DS8 = flex_seg_records(DSTEPS, 8), DS4 = flex_seg_records(DSTEPS, 4);
     constexpr int H8 = flex_seg_records(HSTEPS, 8), H4 = flex_seg_records(HSTEPS, 4);
+    constexpr int B8 = flex_seg_records(BRANCH_STEPS, 8), B4 = flex_seg_records(BRANCH_STEPS, 4);
     const int h = lane >> 5;
     uint32_t opaque_zero = 0;
     asm volatile("" : "+v"(opaque_zero));   // as mlp_batch_tuned: keeps the reads of the (constant) aux block next to their use
@@ -646,22 +737,64 @@ NTX_DEV void mlp_flex(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws, con
     const int depth = __builtin_amdgcn_readfirstlane(desc[0]);
     const uint32_t skip_mask = (uint32_t)__builtin_amdgcn_readfirstlane(desc[1]);
     const int cdepth = __builtin_amdgcn_readfirstlane(desc[2]);
+    const int pdepth = PB ? __builtin_amdgcn_readfirstlane(desc[3]) : 0;
+    const bool has_geo = PB && __builtin_amdgcn_readfirstlane(desc[4]) != 0, has_app = PB && __builtin_amdgcn_readfirstlane(desc[5]) != 0;
     const float neg_inf = __builtin_bit_cast(float, 0xff800000u);
 
     f32x16 acc[8];
     float hin[128];
+    // PB: the output of the geometry branch, later of the appearance branch, lives in this lane's LDS column `pe` (64 k-steps x 64
+    // lanes per wave: the position features are not kept there then, the skip layers evaluate them again)
+    constexpr int K1 = (KEEP_PE && !PB) ? 1 : 0, K2 = (KEEP_PE && !PB) ? 2 : 0;
     uint32_t sbase = 0;
     auto none = [](auto, auto) {};
+    const int n8 = depth + 1 + cdepth;
+    // the part of pos_map behind FF(pos): 64 k-steps out of the geometry branch's registers (PB)
+    auto geo_part = [&]() {
+        if constexpr (PB) {
+            if (has_geo) {
+                LdsColGen gg{pe, {}};
+                run_segment_rt<BRANCH_STEPS, 8, B8>(acc, ws, sbase, gg, none);
+            }
+        }
+    };
 
+    if constexpr (PB) {   // geometry branch first: its output feeds trunk layer 0 and every skip layer (bias slots behind the colour half's)
+        if (has_geo) param_branch<NGEO>(in.par, pdepth, acc, pe, ws, sbase, fbias, n8 + 1, h);
+    }
     // ---- trunk layer 0: pos_map -> width (model.py:104-106)
     init_bias<8>(acc, fbias, 0, h);
     {
-        PosGen<NGEO, NAPP, 0, KEEP_PE ? 1 : 0, 0> gen{in, h, {}, pe};
-        run_segment_rt<CFG::PS, 8, PS8>(acc, ws, sbase, gen, none);
+        PosGen<NGEO, NAPP, 0, K1, GOFF> gen{in, h, {}, pe};
+        run_segment_rt<PSTEPS, 8, PS8>(acc, ws, sbase, gen, none);
+        geo_part();
     }
     // ---- the other 8-tile layers: trunk 1 .. depth-1, F (l = depth), colour layers (l = depth + 1 .. depth + cdepth)
     float sig_part = 0.0f;
-    const int n8 = depth + 1 + cdepth;
+    // the appearance branch, evaluated when the feature layer has been drained and the accumulators are free (PB)
+    auto app_branch = [&]() {
+        if constexpr (PB) {
+            if (has_app) {
+                const SampleIn<NGEO, NAPP> in2 = launder(in);
+                param_branch<NAPP>(in2.par + NGEO, pdepth, acc, pe, ws, sbase, fbias, n8 + 1 + FLEX_MAX_PARAM_DEPTH, h);
+            }
+        }
+    };
+    auto dir_part = [&](auto NMT_) {   // [FF(dir) | A] (PB) or the direction segment with the appearance features in it
+        constexpr int nmt = decltype(NMT_)::value;
+        const SampleIn<NGEO, NAPP> in2 = launder(in);
+        if constexpr (PB) {
+            DirOnlyGen gen{in2.dir, h, {}};
+            run_segment_rt<DSTEPS, nmt, (nmt == 8 ? DS8 : DS4)>(acc, ws, sbase, gen, none);
+            if (has_app) {
+                LdsColGen ag{pe, {}};
+                run_segment_rt<BRANCH_STEPS, nmt, (nmt == 8 ? B8 : B4)>(acc, ws, sbase, ag, none);
+            }
+        } else {
+            DirGen<NGEO, NAPP> gen{in2, h, {}};
+            run_segment_rt<DSTEPS, nmt, (nmt == 8 ? DS8 : DS4)>(acc, ws, sbase, gen, none);
+        }
+    };
     for (int l = 1; l < n8; ++l) {
         const bool first_colour = l == depth + 1;            // its input is the LINEAR feature layer (model.py:114-115)
         store_act_rt<8>(hin, acc, first_colour ? neg_inf : 0.0f);
@@ -669,15 +802,15 @@ NTX_DEV void mlp_flex(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws, con
             const float *wa = aux + aux_alpha_off() + h * 128;
             static_for<128>([&](auto S) { sig_part = __builtin_fmaf(hin[decltype(S)::value], wa[decltype(S)::value], sig_part); });
         }
+        if (first_colour) app_branch();
         init_bias<8>(acc, fbias, l, h);
         if (l < depth && ((skip_mask >> (l - 1)) & 1u)) {    // input = concat[pos_map, h]  (model.py:107-108)
             const SampleIn<NGEO, NAPP> in2 = launder(in);
-            PosGen<NGEO, NAPP, 0, KEEP_PE ? 2 : 0, 0> gen{in2, h, {}, pe};
-            run_segment_rt<CFG::PS, 8, PS8>(acc, ws, sbase, gen, none);
+            PosGen<NGEO, NAPP, 0, K2, GOFF> gen{in2, h, {}, pe};
+            run_segment_rt<PSTEPS, 8, PS8>(acc, ws, sbase, gen, none);
+            geo_part();
         } else if (first_colour) {                           // input = concat[dir_map, feature]  (model.py:115)
-            const SampleIn<NGEO, NAPP> in2 = launder(in);
-            DirGen<NGEO, NAPP> gen{in2, h, {}};
-            run_segment_rt<CFG::DS, 8, DS8>(acc, ws, sbase, gen, none);
+            dir_part(std::integral_constant<int, 8>{});
         }
         HiddenGen hg{hin};
         run_segment_rt<HSTEPS, 8, H8>(acc, ws, sbase, hg, none);
@@ -686,12 +819,9 @@ NTX_DEV void mlp_flex(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws, con
 
     // ---- colour half layer (-> width / 2, relu; model.py:122 / 42), 4 tiles; color_depth = 0 (and plain Nerf): on [dir_map, feature]
     store_act_rt<8>(hin, acc, cdepth > 0 ? 0.0f : neg_inf);
+    if (cdepth == 0) app_branch();
     init_bias<4>(acc, fbias, n8, h);
-    if (cdepth == 0) {
-        const SampleIn<NGEO, NAPP> in2 = launder(in);
-        DirGen<NGEO, NAPP> gen{in2, h, {}};
-        run_segment_rt<CFG::DS, 4, DS4>(acc, ws, sbase, gen, none);
-    }
+    if (cdepth == 0) dir_part(std::integral_constant<int, 4>{});
     {
         HiddenGen hg{hin};
         run_segment_rt<HSTEPS, 4, H4>(acc, ws, sbase, hg, none);
@@ -744,7 +874,7 @@ NTX_DEV void load_aux(float *lds, const float *aux_g, int n) {
 
 // LDS behind the aux block: one column of position-segment values per lane and wave (PosGen KEEP)
 template <class CFG>
-constexpr int pe_keep_floats() { return CFG::PS * 64; }
+constexpr int pe_keep_floats() { return (CFG::FLEX == 2 ? 64 /* BRANCH_STEPS: the branch outputs' column */ : CFG::PS) * 64; }
 template <class CFG>
 NTX_DEV float *pe_column(float *aux, int wave_in_wg, int lane) {
     return aux + aux_floats_of<CFG>() + wave_in_wg * pe_keep_floats<CFG>() + lane;

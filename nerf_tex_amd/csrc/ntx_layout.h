@@ -183,8 +183,10 @@ NTX_HD constexpr Geometry make_geometry(int n_geo, int n_app, int color_depth, i
 // slot l = layer l in the order above.
 constexpr int FLEX_MAX_DEPTH = 24;      // trunk layers
 constexpr int FLEX_MAX_COLOR = 4;       // color_depth
-constexpr int FLEX_MAX_LAYERS = 32;     // bias slots: D trunk + F + CD colour + colour half <= 24 + 1 + 4 + 1
-constexpr int FLEX_DESC_FLOATS = 64;    // int32 words at the head of the flex block: [0] depth, [1] skip mask, [2] color_depth
+constexpr int FLEX_MAX_PARAM_DEPTH = 4; // param_depth (the flavour with parameter branches, Cfg FLEX = 2)
+constexpr int FLEX_MAX_LAYERS = 40;     // bias slots: D trunk + F + CD colour + colour half <= 24 + 1 + 4 + 1, then 4 + 4 branch layers
+constexpr int FLEX_DESC_FLOATS = 64;    // int32 words at the head of the flex block: [0] depth, [1] skip mask, [2] color_depth,
+                                        // [3] param_depth, [4] geometry branch present, [5] appearance branch present
 constexpr int NTX_SKIP_MASK_BIT = 0x40000000;   // ntx_model_desc.skip = NTX_SKIP_MASK_BIT | mask of the indices in `skips`
 
 NTX_HD constexpr int flex_floats() { return FLEX_DESC_FLOATS + FLEX_MAX_LAYERS * AUX_BIAS_STRIDE; }
@@ -193,16 +195,35 @@ NTX_HD constexpr int flex_seg_records(int steps, int nmt) { return round_up(step
 struct FlexArch {
     int depth, width, color_depth;   // color_depth of the MODEL (0 for plain Nerf)
     unsigned skip_mask;              // bit i: trunk layer i + 1 takes concat[pos_map, h]  (model.py:107-108), i < depth - 1
+    // param_depth > 0 (model.py:88-101; Cfg FLEX = 2): Dense(param_width <= 128, relu) layers on FF(params[:g]) / FF(params[g:]) before
+    // they are concatenated to FF(pos) / FF(dir); a branch exists when the model has parameters of its kind
+    int param_depth, param_width, has_geo, has_app;
 };
+constexpr int BRANCH_K = 64;         // k-steps of a branch activation (128 wide)
+NTX_HD constexpr int parff_steps(int n_slots) { return n_slots * GEO_BLOCK; }
+// row of FF(params[0..n_act)) (layer.py:8-23: [x | sin(2^0 x) | cos(2^0 x) | ...], every block n_act wide) that (step s, half h) of a
+// branch's first segment carries: one block of GEO_BLOCK steps per parameter SLOT, last slot first, as the position segment's
+NTX_HD constexpr int parff_row(int n_slots, int s, int h, int n_act) {
+    const int p = n_slots - 1 - s / GEO_BLOCK, j = s % GEO_BLOCK;
+    if (p >= n_act) return -1;
+    if (j == 0) return h == 0 ? p : -1;
+    return n_act + 2 * (j - 1) * n_act + h * n_act + p;
+}
 // records of the flex stream without the wrap-around tail (a multiple of RING by construction)
 NTX_HD constexpr int flex_stream_records(const FlexArch &f) {
-    const int ps8 = flex_seg_records(pos_steps(GEN_NGEO), 8), ds8 = flex_seg_records(dir_steps(GEN_NAPP), 8),
-              ds4 = flex_seg_records(dir_steps(GEN_NAPP), 4), h8 = flex_seg_records(HSTEPS, 8), h4 = flex_seg_records(HSTEPS, 4);
+    const bool pb = f.param_depth > 0;
+    const int psteps = pb ? pos_steps(0) : pos_steps(GEN_NGEO), dsteps = pb ? dir_steps(0) : dir_steps(GEN_NAPP);
+    const int g8 = pb && f.has_geo ? flex_seg_records(BRANCH_K, 8) : 0;
+    const int a8 = pb && f.has_app ? flex_seg_records(BRANCH_K, 8) : 0, a4 = pb && f.has_app ? flex_seg_records(BRANCH_K, 4) : 0;
+    const int ps8 = flex_seg_records(psteps, 8) + g8, ds8 = flex_seg_records(dsteps, 8) + a8, ds4 = flex_seg_records(dsteps, 4) + a4,
+              h8 = flex_seg_records(HSTEPS, 8), h4 = flex_seg_records(HSTEPS, 4), b4 = flex_seg_records(BRANCH_K, 4);
     int rec = ps8;
     for (int i = 1; i < f.depth; ++i) rec += (((f.skip_mask >> (i - 1)) & 1u) ? ps8 : 0) + h8;
     rec += h8;                                             // F
     if (f.color_depth > 0) rec += ds8 + h8 + (f.color_depth - 1) * h8 + h4;
     else rec += ds4 + h4;
+    if (pb && f.has_geo) rec += flex_seg_records(parff_steps(GEN_NGEO), 4) + (f.param_depth - 1) * b4;
+    if (pb && f.has_app) rec += flex_seg_records(parff_steps(GEN_NAPP), 4) + (f.param_depth - 1) * b4;
     return rec;
 }
 

@@ -5,7 +5,7 @@
 #include "ntx_device.h"
 
 #ifndef NTX_VARIANT
-#error "compile with -DNTX_VARIANT=0..6"
+#error "compile with -DNTX_VARIANT=0..7"
 #endif
 
 namespace ntx {
@@ -28,9 +28,12 @@ using VCfg = Cfg<1, 3, 1, 1>;   // mip: IPE position encoding, grass_filtered wi
 #elif NTX_VARIANT == 5
 using VCfg = Cfg<GEN_NGEO, GEN_NAPP, 1, 0, 1>;   // generic: any ParamNerf n_parameters = [g <= 4, a <= 8] (absent parameters = zero rows)
 #define NTX_FN(name) name##_v5
-#else
+#elif NTX_VARIANT == 6
 using VCfg = Cfg<GEN_NGEO, GEN_NAPP, 1, 0, 1, 1>;   // flex: depth, width <= 256, skips, color_depth as the model has them (a layer loop)
 #define NTX_FN(name) name##_v6
+#else
+using VCfg = Cfg<GEN_NGEO, GEN_NAPP, 1, 0, 1, 2>;   // flex with param_depth > 0: Dense layers on the parameter features (model.py:88-101)
+#define NTX_FN(name) name##_v7
 #endif
 
 #ifdef NTX_HOIST

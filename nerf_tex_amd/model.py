@@ -25,8 +25,10 @@ class NerfModel:
 
     def __init__(self, kind: int, n_parameters: Sequence[int], n_pos: int, pos_freq: int, dir_freq: int,
                  param_freq: int, depth: int, width: int, skips: Sequence[int], color_depth: int, name: str,
-                 pos_encoding: str = "fourier") -> None:
+                 pos_encoding: str = "fourier", param_depth: int = 0, param_width: int = 128) -> None:
         self.kind = kind
+        self.param_depth = 0 if kind == KIND_NERF else int(param_depth)   # model.py:88-101: Dense(param_width, relu) on FF(params)
+        self.param_width = int(param_width)
         self.pos_encoding = pos_encoding          # "fourier" | "ipe" (IntegratedPositionalEncoding on n_pos = 6)
         self.n_geo, self.n_app = (0, 0) if kind == KIND_NERF else (int(n_parameters[0]), int(n_parameters[1]))
         self.n_pos, self.pos_freq, self.dir_freq, self.param_freq = n_pos, pos_freq, dir_freq, param_freq
@@ -42,14 +44,21 @@ class NerfModel:
     def n_params(self) -> int:
         return self.n_geo + self.n_app
 
+    def branch_dim(self, n: int) -> int:
+        """width a parameter branch adds to pos_map / dir_map (model.py:89-93, 97-101): FF(params) itself, or the output of the
+        last of the `param_depth` Dense(param_width) layers"""
+        if n == 0:
+            return 0
+        return self.param_width if self.param_depth > 0 else n * (1 + 2 * self.param_freq)
+
     @property
     def pos_map_dim(self) -> int:
         emb = 6 * self.pos_freq if self.pos_encoding == "ipe" else self.n_pos * (1 + 2 * self.pos_freq)
-        return emb + self.n_geo * (1 + 2 * self.param_freq)
+        return emb + self.branch_dim(self.n_geo)
 
     @property
     def dir_map_dim(self) -> int:
-        return 3 * (1 + 2 * self.dir_freq) + self.n_app * (1 + 2 * self.param_freq)
+        return 3 * (1 + 2 * self.dir_freq) + self.branch_dim(self.n_app)
 
     def layer_table(self) -> List[Tuple[str, int, int]]:
         """(name, in, out) per Dense layer in the order of `tf.keras.Model.layers` / `get_weights()` for the model
@@ -57,21 +66,32 @@ class NerfModel:
         order a traversal from `outputs=[color_outputs, alpha_outputs]` meets them: the trunk, the feature layer, the
         colour layers, `color`, and only then `alpha` -- although `alpha` is CREATED before the feature layer
         (model.py:111 vs 114).  The checkpoint keys `layer_with_weights-k` (logger.py:30-39) count in the same order."""
-        rows, k = [], self.pos_map_dim
-        for i in range(self.depth):
-            rows.append((f"trunk{i}", k, self.width))
-            k = self.width + (self.pos_map_dim if i in self.skips else 0)
-        k_head = k
-        rows.append(("feature", k, self.width))
-        k = self.width + self.dir_map_dim
-        if self.kind == KIND_PARAMNERF:
-            for i in range(self.color_depth):
-                rows.append((f"color_hidden{i}", k, self.width))
-                k = self.width
-        rows.append(("color_half", k, self.width // 2))
-        rows.append(("color", self.width // 2, 3))
-        rows.append(("alpha", k_head, 1))
-        return rows
+        # With param_depth > 0 the rule also places the branch layers: every Dense layer in the order the traversal first meets it
+        # (a layer before its inputs; concat([dir_map, feature]) reaches the appearance branch before the feature layer) with its
+        # graph depth (concat nodes take a level), then by decreasing depth, ties in traversal order: the geometry branch sits above
+        # the whole trunk, the appearance branch interleaves with the trunk layers of equal depth and comes first there.
+        pd, pw, w = self.param_depth, self.param_width, self.width
+        ff = lambda n: n * (1 + 2 * self.param_freq)
+        cd = self.color_depth if self.kind == KIND_PARAMNERF else 0
+        seq = [("color", w // 2, 3, 0), ("color_half", w if cd > 0 else w + self.dir_map_dim, w // 2, 1)]
+        for i in reversed(range(cd)):
+            seq.append((f"color_hidden{i}", w + self.dir_map_dim if i == 0 else w, w, 1 + cd - i))
+        d = cd + 2                                          # concat([dir_map, feature])
+        if pd > 0 and self.n_app > 0:                       # dir_map = concat([FF(dir), branch]) is a node at d + 1
+            for i in reversed(range(pd)):
+                seq.append((f"param_app{i}", ff(self.n_app) if i == 0 else pw, pw, d + 2 + (pd - 1 - i)))
+        k_head = w + (self.pos_map_dim if (self.depth - 1) in self.skips else 0)
+        d += 1
+        seq.append(("feature", k_head, w, d))
+        for i in reversed(range(self.depth)):
+            d += 1 + (1 if i in self.skips else 0)          # the concat a skip puts behind layer i
+            seq.append((f"trunk{i}", self.pos_map_dim if i == 0 else w + (self.pos_map_dim if (i - 1) in self.skips else 0), w, d))
+        if pd > 0 and self.n_geo > 0:                       # pos_map = concat([FF(pos), branch]) at depth(trunk0) + 1
+            for i in reversed(range(pd)):
+                seq.append((f"param_geo{i}", ff(self.n_geo) if i == 0 else pw, pw, d + 2 + (pd - 1 - i)))
+        seq.append(("alpha", k_head, 1, 0))
+        order = sorted(range(len(seq)), key=lambda j: (-seq[j][3], j))
+        return [seq[j][:3] for j in order]
 
     def n_weight_floats(self) -> int:
         return sum(i * o + o for _, i, o in self.layer_table())
@@ -86,9 +106,10 @@ class NerfModel:
         if any(i >= 30 for i in live):
             raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, f"skips={self.skips}: layer indices above 29 have no encoding in ntx_model_desc")
         skip = -1 if not live else live[0] if len(live) == 1 else _lib.SKIP_MASK | sum(1 << i for i in live)
-        return _lib.ModelDesc(self.kind, self.n_geo, self.n_app, self.n_pos, self.pos_freq, self.dir_freq,
+        kind = _lib.KIND_PARAMNERF_EX if self.kind == KIND_PARAMNERF and self.param_depth != 0 else self.kind
+        return _lib.ModelDesc(kind, self.n_geo, self.n_app, self.n_pos, self.pos_freq, self.dir_freq,
                               self.param_freq, self.depth, self.width, skip, self.color_depth,
-                              1 if self.pos_encoding == "ipe" else 0)
+                              1 if self.pos_encoding == "ipe" else 0, self.param_depth, self.param_width)
 
     # ---- weights -----------------------------------------------------------------------
     def initialize(self) -> None:
@@ -209,11 +230,12 @@ def ParamNerf(pos_embedding, dir_embedding, param_embedding, n_parameters: Union
     """network.model.ParamNerf (model.py:58-125)."""
     if isinstance(n_parameters, int):
         n_parameters = [n_parameters, 0]                                    # model.py:63-64
-    if param_depth != 0 or embedding_config is not None:
-        raise NotImplementedError("param_depth > 0 / embedding_config are used by no reference config and have no HIP kernel")
+    if embedding_config is not None:
+        # (the reference cannot build such a model either: network/layer.py has no embedding layer for util.instantiate to find)
+        raise NotImplementedError("embedding_config: the reference ships no embedding layer (network/layer.py) and there is no HIP kernel for one")
     return {name: NerfModel(KIND_PARAMNERF, n_parameters, n_pos, n_freq_bands_of(pos_embedding),
                             n_freq_bands_of(dir_embedding), n_freq_bands_of(param_embedding), depth, width, skips,
-                            color_depth, name, embedding_kind(pos_embedding))}
+                            color_depth, name, embedding_kind(pos_embedding), param_depth=param_depth, param_width=param_width)}
 
 
 def CoarseFine(model_config, **kwargs) -> dict:

@@ -57,6 +57,8 @@ class ModelSpec:
     skips: Tuple[int, ...] = (4,)
     color_depth: int = 1                 # ParamNerf only (model.py:118); Nerf has none
     pos_encoding: str = "fourier"        # "fourier" = FourierFeatures; "ipe" = IntegratedPositionalEncoding (n_pos = 6)
+    param_depth: int = 0                 # ParamNerf only (model.py:88-101): Dense(param_width, relu) layers on the parameter features
+    param_width: int = 128
 
     @property
     def n_geo(self) -> int:
@@ -71,13 +73,24 @@ class ModelSpec:
         return self.n_geo + self.n_app
 
     @property
+    def param_layers(self) -> int:
+        return 0 if self.kind == "Nerf" else int(self.param_depth)
+
+    def branch_dim(self, n: int) -> int:
+        """width of a parameter branch as it is concatenated to pos_map / dir_map (model.py:89-93, 97-101): FF(params) itself,
+        or the output of the last of `param_depth` Dense(param_width) layers"""
+        if n == 0:
+            return 0
+        return self.param_width if self.param_layers > 0 else n * (1 + 2 * self.param_freq)
+
+    @property
     def pos_map_dim(self) -> int:
         emb = 6 * self.pos_freq if self.pos_encoding == "ipe" else self.n_pos * (1 + 2 * self.pos_freq)
-        return emb + self.n_geo * (1 + 2 * self.param_freq)
+        return emb + self.branch_dim(self.n_geo)
 
     @property
     def dir_map_dim(self) -> int:
-        return 3 * (1 + 2 * self.dir_freq) + self.n_app * (1 + 2 * self.param_freq)
+        return 3 * (1 + 2 * self.dir_freq) + self.branch_dim(self.n_app)
 
 
 def layer_table(spec: ModelSpec) -> List[Tuple[str, int, int]]:
@@ -86,22 +99,34 @@ def layer_table(spec: ModelSpec) -> List[Tuple[str, int, int]]:
     Keras sorts `model.layers` by graph depth, ties by traversal order from `outputs=[color, alpha]`
     (keras/engine/functional.py `_map_graph_network`, TF 2.4): trunk, feature, colour layers, color,
     and `alpha` LAST -- not the creation order of model.py:104-123, where alpha (:111) precedes feature (:114)."""
-    rows = []
-    k = spec.pos_map_dim
-    for i in range(spec.depth):
-        rows.append((f"trunk{i}", k, spec.width))
-        k = spec.width + (spec.pos_map_dim if i in spec.skips else 0)
-    k_head = k
-    rows.append(("feature", k, spec.width))
-    k = spec.width + spec.dir_map_dim
-    if spec.kind == "ParamNerf":
-        for i in range(spec.color_depth):
-            rows.append((f"color_hidden{i}", k, spec.width))
-            k = spec.width
-    rows.append(("color_half", k, spec.width // 2))
-    rows.append(("color", spec.width // 2, 3))
-    rows.append(("alpha", k_head, 1))
-    return rows
+    # every Dense layer in the order a depth-first traversal from outputs=[color, alpha] FIRST meets it (a layer before its inputs,
+    # inputs in the order of the call: concat([dir_map, feature]) visits the appearance branch before the feature layer), with its
+    # graph depth = longest path to an output (concat nodes are layers too and take a level); then by decreasing depth, ties in
+    # traversal order.  For param_depth = 0 this is trunk.., feature, colour layers, color_half, color, alpha.
+    pd, pw, w = spec.param_layers, spec.param_width, spec.width
+    ff = lambda n: n * (1 + 2 * spec.param_freq)
+    cd = spec.color_depth if spec.kind == "ParamNerf" else 0
+    seq = [("color", w // 2, 3, 0), ("color_half", w if cd > 0 else w + spec.dir_map_dim, w // 2, 1)]
+    for i in reversed(range(cd)):
+        seq.append((f"color_hidden{i}", w + spec.dir_map_dim if i == 0 else w, w, 1 + cd - i))
+    d_dircat = cd + 2
+    if pd > 0 and spec.n_app > 0:               # dir_map = concat([FF(dir), app branch]) is a node of its own at d_dircat + 1
+        for i in reversed(range(pd)):
+            seq.append((f"param_app{i}", ff(spec.n_app) if i == 0 else pw, pw, d_dircat + 2 + (pd - 1 - i)))
+    d = d_dircat + 1                            # feature
+    k_in = lambda i: spec.pos_map_dim if i == 0 else w + (spec.pos_map_dim if (i - 1) in spec.skips else 0)
+    k_head = w + (spec.pos_map_dim if (spec.depth - 1) in spec.skips else 0)
+    seq.append(("feature", k_head, w, d))
+    d_alpha_path = 1                            # (alpha's own path to the trunk is shorter than the feature path: never the longest)
+    for i in reversed(range(spec.depth)):
+        d += 1 + (1 if i in spec.skips else 0)  # a skip behind layer i puts a concat node between it and its consumer
+        seq.append((f"trunk{i}", k_in(i), w, d))
+    if pd > 0 and spec.n_geo > 0:               # pos_map = concat([FF(pos), geometry branch]): a node at depth(trunk0) + 1
+        for i in reversed(range(pd)):
+            seq.append((f"param_geo{i}", ff(spec.n_geo) if i == 0 else pw, pw, d + 2 + (pd - 1 - i)))
+    seq.append(("alpha", k_head, 1, 0))
+    order = sorted(range(len(seq)), key=lambda j: (-seq[j][3], j))
+    return [seq[j][:3] for j in order]
 
 
 def macs_per_sample(spec: ModelSpec) -> int:
@@ -266,30 +291,39 @@ def model_forward(weights: Sequence[np.ndarray], spec: ModelSpec, pos, dirs, par
         dir_map = np.concatenate([dir_map, fourier_features(params[:, g:g + a], spec.param_freq, dtype)], -1)
     inter["pos_map"], inter["dir_map"] = pos_map, dir_map
 
-    w = list(weights)
-    it = iter(range(0, len(w) - 2, 2))
+    names = [n for n, _, _ in layer_table(spec)]
+    assert len(weights) == 2 * len(names), (len(weights), len(names))
+    W = {n: (weights[2 * j], weights[2 * j + 1]) for j, n in enumerate(names)}
+    dense = lambda x, name, relu: _dense(x, W[name][0], W[name][1], dtype, relu)
+    if spec.param_layers > 0:                                                  # model.py:88-101 with param_depth > 0
+        if g > 0:
+            pg = fourier_features(params[:, :g], spec.param_freq, dtype)
+            for i in range(spec.param_layers):
+                pg = dense(pg, f"param_geo{i}", True)
+            pos_map = np.concatenate([pos_map[:, :pos_map.shape[1] - g * (1 + 2 * spec.param_freq)], pg], -1)
+        if a > 0:
+            pa = fourier_features(params[:, g:g + a], spec.param_freq, dtype)
+            for i in range(spec.param_layers):
+                pa = dense(pa, f"param_app{i}", True)
+            dir_map = np.concatenate([dir_map[:, :dir_map.shape[1] - a * (1 + 2 * spec.param_freq)], pa], -1)
+        inter["pos_map"], inter["dir_map"] = pos_map, dir_map
     h = pos_map
     for i in range(spec.depth):                                                # model.py:104-108
-        j = next(it)
-        h = _dense(h, w[j], w[j + 1], dtype, relu=True)
+        h = dense(h, f"trunk{i}", True)
         inter[f"trunk{i}"] = h
         if i in spec.skips:
             h = np.concatenate([pos_map, h], -1)
-    alpha = _dense(h, w[-2], w[-1], dtype, relu=False)                         # model.py:111 (last in get_weights())
-    j = next(it)
-    h = _dense(h, w[j], w[j + 1], dtype, relu=False)                           # model.py:114
+    alpha = dense(h, "alpha", False)                                           # model.py:111 (last in get_weights())
+    h = dense(h, "feature", False)                                             # model.py:114
     inter["feature"] = h
     h = np.concatenate([dir_map, h], -1)                                       # model.py:115
     if spec.kind == "ParamNerf":
         for i in range(spec.color_depth):                                      # model.py:118-119
-            j = next(it)
-            h = _dense(h, w[j], w[j + 1], dtype, relu=True)
+            h = dense(h, f"color_hidden{i}", True)
             inter[f"color_hidden{i}"] = h
-    j = next(it)
-    h = _dense(h, w[j], w[j + 1], dtype, relu=True)                            # model.py:122
+    h = dense(h, "color_half", True)                                           # model.py:122
     inter["color_half"] = h
-    j = next(it)
-    color = _dense(h, w[j], w[j + 1], dtype, relu=False)                       # model.py:123
+    color = dense(h, "color", False)                                           # model.py:123
     if return_intermediates:
         return color, alpha, inter
     return color, alpha

@@ -21,9 +21,10 @@ def make_model(n_parameters=(1, 6), kind="ParamNerf", seed=0, dense_media=False,
             model = Nerf(EMB(10), EMB(4), depth=spec_kw["depth"], width=spec_kw["width"], skips=list(spec_kw["skips"]))["model"]
             spec = orc.ModelSpec(kind="Nerf", n_parameters=(0, 0), **spec_kw)
         else:
+            pk = dict(param_depth=a.get("param_depth", 0), param_width=a.get("param_width", 128))
             model = ParamNerf(EMB(10), EMB(4), EMB(4), list(n_parameters), depth=spec_kw["depth"], width=spec_kw["width"],
-                              skips=list(spec_kw["skips"]), color_depth=a.get("color_depth", 1))["model"]
-            spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(n_parameters), color_depth=a.get("color_depth", 1), **spec_kw)
+                              skips=list(spec_kw["skips"]), color_depth=a.get("color_depth", 1), **pk)["model"]
+            spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(n_parameters), color_depth=a.get("color_depth", 1), **spec_kw, **pk)
     elif kind == "IPE":                      # mip variant: IntegratedPositionalEncoding on (mean, covariance)
         ipe = {"module": "network.layer.IntegratedPositionalEncoding", "n_freq_bands": 10}
         model = ParamNerf(ipe, EMB(4), EMB(4), list(n_parameters), n_pos=6)["model"]

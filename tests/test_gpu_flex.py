@@ -55,6 +55,58 @@ def test_mlp_forward_any_architecture(kind, npar, arch, m):
     assert err <= 3e-5, err         # what exact-f32 MFMA reaches on glorot weights (deeper trunks accumulate a little more)
 
 
+ARCHS_PD = [   # param_depth > 0 (model.py:88-101): Dense(param_width, relu) layers on the parameter features, per branch
+    ((1, 6), dict(depth=8, width=256, skips=[4], color_depth=1, param_depth=1)),               # the reference architecture + one layer
+    ((2, 3), dict(depth=8, width=256, skips=[4], color_depth=1, param_depth=2)),
+    ((1, 4), dict(depth=4, width=128, skips=[1, 2], color_depth=0, param_depth=3, param_width=64)),   # colour half on [FF(dir) | A]
+    ((4, 8), dict(depth=6, width=200, skips=[0, 4], color_depth=2, param_depth=4, param_width=100)),  # every parameter slot in use
+    ((0, 5), dict(depth=5, width=256, skips=[2], color_depth=1, param_depth=2)),               # appearance branch only
+    ((3, 0), dict(depth=5, width=256, skips=[2], color_depth=1, param_depth=2)),               # geometry branch only
+    ((0, 0), dict(depth=5, width=256, skips=[2], color_depth=1, param_depth=2)),               # no parameters: no branches at all
+    ((1, 6), dict(depth=1, width=96, skips=[], color_depth=3, param_depth=1, param_width=2)),
+]
+
+
+@pytest.mark.parametrize("npar,arch", ARCHS_PD)
+def test_mlp_forward_with_parameter_branches(npar, arch):
+    model, spec, w = make_model(npar, "ParamNerf", arch=arch)
+    assert model.layer_table() == orc.layer_table(spec) and any(n.startswith("param_") for n, _, _ in model.layer_table()) == (sum(npar) > 0)
+    for m in (33, 2000):
+        pos, dirs, params = random_samples(m, sum(npar), seed=m)
+        color, alpha = model(tuple(to_dev(pos, dirs, params)))
+        rc, ra = orc.model_forward(w, spec, pos, dirs, params, np.float64)
+        out = np.concatenate([color.cpu().numpy(), alpha.cpu().numpy()], -1)
+        err = orc.rel_linf(out, np.concatenate([rc, ra], -1))
+        assert err <= 3e-5, (err, npar, arch)
+
+
+@pytest.mark.parametrize("blur,perturb", [(None, False), (0, True), (2, False)])
+def test_render_rays_with_parameter_branches(blur, perturb):
+    """Renderer.__call__ with param_depth = 2: blur_idx on a geometry parameter (its branch sees the scaled value per sample,
+    renderer.py:155-158) and on an appearance parameter, in-kernel jitter."""
+    from nerf_tex_amd.renderer import Renderer
+    npar, S = (2, 3), 48
+    model, spec, w = make_model(npar, "ParamNerf", dense_media=True, arch=dict(depth=6, width=256, skips=[2], color_depth=1, param_depth=2))
+    (ro, rd, t, cone), _, _ = camera_rays("carpet", 14, 12)
+    cone = (cone * 30).astype(np.float32)
+    params = np.random.default_rng(3).uniform(0.1, 1.0, size=(1, 5)).astype(np.float32)
+    r = Renderer(model=model, n_samples=S, perturb=perturb, blur_idx=blur)
+    out = r(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0], seed=5)
+    r.raise_if_nonfinite()
+    got = rgba_of(out)
+    hit = np.isfinite(t[:, 0])
+    z = orc.z_values_perturbed(np.where(np.isfinite(t), t, 0).astype(np.float32), S, 5, np.float32)[hit] if perturb else None
+    ref = {}
+    for name, dt in (("f64", np.float64), ("f32", np.float32)):
+        o = orc.render_rays(w, spec, ro[hit], rd[hit], t[hit], np.repeat(params, int(hit.sum()), 0), cone[hit], S, False, (1, 1, 1.),
+                            blur_idx=blur, z_override=z, dtype=dt)
+        full = np.zeros((t.shape[0], 4)); full[hit] = np.concatenate([o["color_pred"], o["alpha_pred"][:, None]], -1)
+        ref[name] = full
+    assert np.all(got[~hit] == 0)
+    assert orc.rel_linf(got, ref["f32"]) <= TOL
+    assert orc.rel_linf(got, ref["f64"]) <= TOL + orc.rel_linf(ref["f32"], ref["f64"])
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_mlp_forward_random_architectures(seed):
     """Seeded random architectures inside the family's limits: depth 1..24, width 2..256, any set of skips below depth-1,
@@ -183,7 +235,8 @@ def test_what_the_flex_family_refuses():
         m.ctx(0)
     assert e.value.code == _lib.NTX_E_UNSUPPORTED
     for bad in (dict(depth=25, width=64, skips=[], color_depth=1), dict(depth=4, width=512, skips=[], color_depth=1),
-                dict(depth=4, width=128, skips=[], color_depth=5)):
+                dict(depth=4, width=128, skips=[], color_depth=5), dict(param_depth=5), dict(param_depth=1, param_width=129),
+                dict(param_depth=-1)):
         m, _, _ = make_model((1, 6), arch=bad)
         with pytest.raises(_lib.NtxError) as e:
             m.ctx(0)

@@ -50,18 +50,23 @@ def test_unsupported_desc_is_rejected_on_host():
         assert b"unsupported" in _lib.lib.ntx_last_error()
 
 
-@pytest.mark.parametrize("kind,npar,depth,width,skips,cd", [(0, (1, 6), 8, 256, (4,), 2), (0, (1, 6), 6, 256, (4,), 1), (0, (1, 6), 8, 128, (4,), 1),
-                                                            (0, (2, 3), 10, 256, (3, 6), 0), (0, (0, 0), 1, 30, (), 4), (1, (0, 0), 5, 100, (1, 2), 0),
-                                                            (0, (4, 8), 24, 256, tuple(range(23)), 4), (0, (1, 4), 8, 256, (), 1)])
-def test_pack_weights_flex_family_is_a_permutation(kind, npar, depth, width, skips, cd):
+@pytest.mark.parametrize("kind,npar,depth,width,skips,cd,pd,pw", [
+    (0, (1, 6), 8, 256, (4,), 2, 0, 128), (0, (1, 6), 6, 256, (4,), 1, 0, 128), (0, (1, 6), 8, 128, (4,), 1, 0, 128),
+    (0, (2, 3), 10, 256, (3, 6), 0, 0, 128), (0, (0, 0), 1, 30, (), 4, 0, 128), (1, (0, 0), 5, 100, (1, 2), 0, 0, 128),
+    (0, (4, 8), 24, 256, tuple(range(23)), 4, 0, 128), (0, (1, 4), 8, 256, (), 1, 0, 128),
+    # param_depth > 0: parameter branches (the weights arrive in Keras' order, appearance layers interleaved with the trunk)
+    (0, (1, 6), 8, 256, (4,), 1, 1, 128), (0, (2, 3), 5, 200, (1, 3), 0, 3, 64), (0, (4, 8), 24, 256, tuple(range(23)), 4, 4, 128),
+    (0, (0, 5), 3, 64, (), 2, 2, 100), (0, (3, 0), 3, 64, (0,), 1, 2, 2), (0, (0, 0), 4, 128, (2,), 1, 2, 128)])
+def test_pack_weights_flex_family_is_a_permutation(kind, npar, depth, width, skips, cd, pd, pw):
     """Architectures other than 8 x 256 / [4] / 1 go to the flex family (ntx_layout.h): the weight count is the model's own layer
     table (model.py:104-123 in get_weights() order), every weight lands in the packed image exactly once -- the rest is zero: rows
     and columns of layers narrower than 256, the pads that bring every segment to whole ring turns --, the stream ends with the
     wrap-around tail, and the descriptor behind the tuned aux layout carries depth / skip mask / color_depth."""
     from nerf_tex_amd import _lib
     from nerf_tex_amd.model import NerfModel
-    m = NerfModel(kind, npar, 3, 10, 4, 4 if kind == 0 else 0, depth, width, skips, cd, "model")
+    m = NerfModel(kind, npar, 3, 10, 4, 4 if kind == 0 else 0, depth, width, skips, cd, "model", param_depth=pd, param_width=pw)
     d = m.desc()
+    assert d.kind == (2 if pd and kind == 0 else kind)
     n = _lib.lib.ntx_weight_count(C.byref(d))
     assert n == m.n_weight_floats() > 0, _lib.lib.ntx_last_error()
     npk = _lib.lib.ntx_packed_count(C.byref(d))
@@ -69,13 +74,15 @@ def test_pack_weights_flex_family_is_a_permutation(kind, npar, depth, width, ski
     out = np.empty(npk, np.float32)
     fp = C.POINTER(C.c_float)
     assert _lib.lib.ntx_pack_weights(C.byref(d), blob.ctypes.data_as(fp), n, out.ctypes.data_as(fp), npk) == 0
-    aux_floats = 3776 + 64 + 32 * 256                             # aux_total() + flex_floats(): descriptor words, 32 bias slots
+    aux_floats = 3776 + 64 + 40 * 256                             # aux_total() + flex_floats(): descriptor words, 40 bias slots
     stream, aux = out[:npk - aux_floats], out[npk - aux_floats:]
     assert stream.size % (8 * 256) == 0                           # whole ring turns (every segment padded), plus the tail
     np.testing.assert_array_equal(stream[:8 * 256], stream[-8 * 256:])
     words = aux[3776:3776 + 64].view(np.int32)
     live = [i for i in skips if i < depth - 1]
-    assert words[0] == depth and words[1] == sum(1 << i for i in live) and words[2] == (cd if kind == 0 else 0) and not words[3:].any()
+    branches = pd > 0 and sum(npar) > 0
+    assert words[0] == depth and words[1] == sum(1 << i for i in live) and words[2] == (cd if kind == 0 else 0)
+    assert list(words[3:6]) == ([pd, int(npar[0] > 0), int(npar[1] > 0)] if branches else [0, 0, 0]) and not words[6:].any()
     body = stream[:-8 * 256]
     rest = np.concatenate([aux[:3776], aux[3776 + 64:]])
     vals = np.concatenate([body[body != 0], rest[rest != 0]])
@@ -83,7 +90,12 @@ def test_pack_weights_flex_family_is_a_permutation(kind, npar, depth, width, ski
     # the trunk's stream length follows the architecture: pos segment 52 k-steps -> 104 records, hidden 256, direction 50 -> 104 / 56
     n8 = depth - 1 + 1 + (cd if kind == 0 else 0)
     cdm = cd if kind == 0 else 0
-    want_rec = 104 + n8 * 256 + 104 * len(live) + (104 + 128 if cdm > 0 else 56 + 128)
+    if not branches:
+        want_rec = 104 + n8 * 256 + 104 * len(live) + (104 + 128 if cdm > 0 else 56 + 128)
+    else:   # FF(pos) 32 k-steps -> 64 records (+128 over the geometry branch), FF(dir) 14 -> 32 / 16 (+128 / 64 over the appearance branch)
+        g, a = int(npar[0] > 0), int(npar[1] > 0)
+        want_rec = (64 + 128 * g) * (1 + len(live)) + n8 * 256 + ((32 + 128 * a) + 128 if cdm > 0 else (16 + 64 * a) + 128) \
+            + g * (24 + (pd - 1) * 64) + a * (40 + (pd - 1) * 64)
     assert body.size == want_rec * 256
     assert _lib.lib.ntx_packed_fp16x3_bytes(C.byref(d)) == 0 and b"fp16x3" in _lib.lib.ntx_last_error()
 
@@ -648,8 +660,8 @@ def test_no_mfma_kernel_uses_scratch():
     known = {k for k in big if "instance_kernel" in k and ("CfgILi1ELi3ELi1ELi1ELi0" in k or "CfgILi4ELi8ELi1ELi0ELi1ELi0" in k)}
     # ... and the flex family (architectures no reference config has; a run-time loop over layers, whose counters and lane indices
     # live across the layer bodies): <= 20 dwords stored once per launch, reloaded once per batch / per ray outside the layer loop
-    flex = {k for k in big if "CfgILi4ELi8ELi1ELi0ELi1ELi1" in k}
-    assert len(flex) == 3                                   # render, mlp, instance: float32 only
+    flex = {k for k in big if "CfgILi4ELi8ELi1ELi0ELi1ELi1" in k or "CfgILi4ELi8ELi1ELi0ELi1ELi2" in k}
+    assert len(flex) == 6                                   # render, mlp, instance (float32 only) x {plain, with parameter branches}
     for k, v in big.items():
         assert v["lds"] <= 160 * 1024, (k, v)
         assert v["agpr"] == 256 and v["vgpr"] <= 512, (k, v)

@@ -350,22 +350,32 @@ def test_layer_order_follows_keras_graph_depth_rule():
     layer a traversal index at its FIRST visit, before its inputs), assigns each layer depth = longest path to an output, and
     lists layers by decreasing depth, ties by traversal index.  Applied to the graph model.py:58-125 builds, with
     outputs=[color_outputs, alpha_outputs] (model.py:125), it must give the order of `layer_table`."""
-    def order_of(kind, color_depth, depth=8, skips=(4,)):
+    def order_of(kind, color_depth, depth=8, skips=(4,), param_depth=0, n_parameters=(1, 6)):
         inputs_of = {}                                    # layer -> list of input layers, as model.py wires them
         def dense(name, src):
             inputs_of[name] = [src]; return name
         for n in ("pos", "dir", "params"):
             inputs_of[n] = []
-        inputs_of["pos_map"] = ["pos", "params"] if kind == "ParamNerf" else ["pos"]       # FourierFeatures + concat (weightless)
-        inputs_of["dir_map"] = ["dir", "params"] if kind == "ParamNerf" else ["dir"]
-        h = "pos_map"
+        inputs_of["pos_ff"], inputs_of["dir_ff"] = ["pos"], ["dir"]                         # FourierFeatures layers (weightless)
+        inputs_of["pos_map"], inputs_of["dir_map"] = ["pos_ff"], ["dir_ff"]
+        if kind == "ParamNerf":
+            for branch, n, target in (("geo", n_parameters[0], "pos_map"), ("app", n_parameters[1], "dir_map")):
+                if n > 0:                                                                   # model.py:88-93 / 96-101
+                    inputs_of[f"slice_{branch}"] = ["params"]; inputs_of[f"ff_{branch}"] = [f"slice_{branch}"]
+                    b = f"ff_{branch}"
+                    for i in range(param_depth):
+                        b = dense(f"param_{branch}{i}", b)
+                    inputs_of[f"cat_{target}"] = [target, b]                                # tf.concat([pos_inputs_map, branch], -1)
+        pos_map = "cat_pos_map" if "cat_pos_map" in inputs_of else "pos_map"
+        dir_map = "cat_dir_map" if "cat_dir_map" in inputs_of else "dir_map"
+        h = pos_map
         for i in range(depth):                                                            # model.py:104-108
             h = dense(f"trunk{i}", h)
             if i in skips:
-                inputs_of[f"skipcat{i}"] = ["pos_map", h]; h = f"skipcat{i}"
+                inputs_of[f"skipcat{i}"] = [pos_map, h]; h = f"skipcat{i}"
         alpha = dense("alpha", h)                                                         # :111
         f = dense("feature", h)                                                           # :114
-        inputs_of["dircat"] = ["dir_map", f]; h = "dircat"                                # :115
+        inputs_of["dircat"] = [dir_map, f]; h = "dircat"                                  # :115
         if kind == "ParamNerf":
             for i in range(color_depth):                                                  # :118-119
                 h = dense(f"color_hidden{i}", h)
@@ -389,7 +399,7 @@ def test_layer_order_follows_keras_graph_depth_rule():
         for o in outputs:
             longest(o, 0)
         layers = sorted(index, key=lambda l: (-depth_of[l], index[l]))
-        weighted = lambda l: l.startswith(("trunk", "color")) or l in ("alpha", "feature")
+        weighted = lambda l: l.startswith(("trunk", "color", "param_")) or l in ("alpha", "feature")
         return [l for l in layers if weighted(l)]
 
     assert order_of("ParamNerf", 1) == [n for n, _, _ in orc.layer_table(orc.ModelSpec(kind="ParamNerf", n_parameters=(1, 6)))]
@@ -400,3 +410,13 @@ def test_layer_order_follows_keras_graph_depth_rule():
                                    ("ParamNerf", 1, 1, ()), ("ParamNerf", 4, 24, tuple(range(0, 23, 2))), ("Nerf", 0, 5, (1, 2)), ("Nerf", 0, 6, ())):
         spec = orc.ModelSpec(kind=kind, n_parameters=(1, 6) if kind == "ParamNerf" else (0, 0), depth=depth, skips=skips, color_depth=cd)
         assert order_of(kind, cd, depth, skips) == [n for n, _, _ in orc.layer_table(spec)], (kind, cd, depth, skips)
+    # ... and with param_depth > 0 (model.py:88-101): the Dense layers of the geometry branch sit above the whole trunk, those of the
+    # appearance branch interleave with the trunk layers of the same graph depth and come first there (the traversal reaches
+    # dir_map before the feature layer)
+    for cd, depth, skips, pd, npar in ((1, 8, (4,), 1, (1, 6)), (1, 3, (0,), 2, (1, 6)), (0, 8, (4,), 3, (2, 3)), (2, 1, (), 4, (1, 4)),
+                                       (1, 5, (1, 3), 2, (0, 3)), (1, 5, (1, 3), 2, (3, 0)), (4, 24, (), 4, (4, 8)), (1, 8, (4,), 2, (0, 0))):
+        spec = orc.ModelSpec(kind="ParamNerf", n_parameters=npar, depth=depth, skips=skips, color_depth=cd, param_depth=pd)
+        assert order_of("ParamNerf", cd, depth, skips, pd, npar) == [n for n, _, _ in orc.layer_table(spec)], (cd, depth, skips, pd, npar)
+    t = dict((n, (i, o)) for n, i, o in orc.layer_table(orc.ModelSpec(param_depth=2)))
+    assert t["param_geo0"] == (9, 128) and t["param_geo1"] == (128, 128) and t["param_app0"] == (54, 128) and t["trunk0"] == (63 + 128, 256) \
+        and t["trunk5"] == (256 + 63 + 128, 256) and t["color_hidden0"] == (256 + 27 + 128, 256)
