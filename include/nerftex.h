@@ -58,7 +58,7 @@ typedef enum ntx_pos_encoding { NTX_POS_FOURIER = 0, NTX_POS_IPE = 1 } ntx_pos_e
  * width 256, skips [4], color_depth 1.  Any OTHER architecture of model.py:58 / :9 with FourierFeatures embeddings -- depth 1..24,
  * width 2..256, color_depth 0..4, any skips below depth-1 -- runs on the "flex" family: the same MFMA segments in a loop over layers
  * (narrower layers zero-padded to 256), float32 only (NTX_FLAG_FP16X3: NTX_E_UNSUPPORTED), nothing hoisted per ray; param_depth 1..4
- * through ntx_model_desc_ex (below).  10/4/4 frequency bands, no embedding_config.  Anything else: NTX_E_UNSUPPORTED. */
+ * through the extended descriptor below (ntx_model_desc_ex).  10/4/4 frequency bands, no embedding_config.  Anything else: NTX_E_UNSUPPORTED. */
 #define NTX_SKIP_MASK 0x40000000   /* ntx_model_desc.skip = NTX_SKIP_MASK | mask: several skip layers (bit i: i in skips) */
 typedef struct ntx_model_desc {
     int32_t kind;        /* ntx_model_kind */
