@@ -172,6 +172,16 @@ int ntx_generate_rays(const float *c2w, int height, int width, float focal, int6
                       int64_t n_pixels, int mode, const float *b0, const float *b1, float near_t,
                       float far_t, float *rays_o, float *rays_d, float *t, float *cone_scale,
                       ntx_stream stream);
+/* The same for ANY set of image-plane locations -- ray_sampler.rays_from_camera (ray_sampler.py:39-48) as Proxy / Frustum call it
+ * with whatever the pixel sampler returned (pixel_sampler.py: Full, Independent, Proxy): image_plane_loc DEVICE float32 [n,2] =
+ * (row, col) per ray, the tensor the reference casts to float32 (:25, :17).  Outputs as above. */
+int ntx_generate_rays_at(const float *c2w, int height, int width, float focal, const float *image_plane_loc, int64_t n_rays, int mode,
+                         const float *b0, const float *b1, float near_t, float far_t, float *rays_o, float *rays_d, float *t,
+                         float *cone_scale, ntx_stream stream);
+/* Replaces proxy.AABB.__call__ (proxy.py:13-35) on the caller's own rays: rays_o, rays_d DEVICE [n,3] -> t DEVICE [n,2],
+ * [inf, inf] on a miss; 1/0 and 0*inf follow IEEE as in the reference.  b0, b1: HOST float[3]. */
+int ntx_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_rays, const float *b0, const float *b1, float *t,
+                       ntx_stream stream);
 /* Same for a STRIDED set of pixels, the local rays of one rank of a shard map (see ntx_shard_count): local ray k is
  * pixel pixel0 + (k / run_length) * run_stride + k % run_length.  rank r of R: pixel0 = r * run_length,
  * run_stride = R * run_length, n_pixels = ntx_shard_count(H * W, run_length, R, r). */

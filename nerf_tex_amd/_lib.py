@@ -71,6 +71,9 @@ SYMBOLS = {
                                     C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "ntx_generate_rays_strided": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                             _fp, _fp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "ntx_generate_rays_at": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, C.c_int, _fp, _fp, C.c_float, C.c_float,
+                                       _vp, _vp, _vp, _vp, _vp]),
+    "ntx_aabb_intersect": (C.c_int, [_vp, _vp, C.c_int64, _fp, _fp, _vp, _vp]),
     "ntx_fourier_features": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, _vp, _vp]),
     "ntx_mlp_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_uint32, _vp, _vp, _vp]),
     "ntx_composite": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_uint32, _fp, _vp, _vp, _vp, _vp]),

@@ -863,6 +863,42 @@ int ntx_generate_rays_strided(const float *c2w, int height, int width, float foc
     return NTX_OK;
 }
 
+int ntx_generate_rays_at(const float *c2w, int height, int width, float focal, const float *image_plane_loc, int64_t n_rays, int mode,
+                         const float *b0, const float *b1, float near_t, float far_t, float *rays_o, float *rays_d, float *t,
+                         float *cone_scale, ntx_stream stream) {
+    if (!c2w || !rays_o || !rays_d || !t || !cone_scale) return fail(NTX_E_INVALID, "NULL buffer");
+    if (height <= 0 || width <= 0 || n_rays < 0) return fail(NTX_E_INVALID, "bad shape %dx%d, n_rays %lld", height, width, (long long)n_rays);
+    if (mode != 0 && mode != 1) return fail(NTX_E_INVALID, "mode must be 0 (Proxy/AABB) or 1 (Frustum)");
+    if (mode == 0 && (!b0 || !b1)) return fail(NTX_E_INVALID, "AABB bounds are NULL");
+    if (n_rays == 0) return NTX_OK;
+    if (!image_plane_loc) return fail(NTX_E_INVALID, "image_plane_loc is NULL");
+    RaygenArgs a{};
+    memcpy(a.c2w, c2w, sizeof(a.c2w));
+    if (mode == 0) { memcpy(a.b0, b0, sizeof(a.b0)); memcpy(a.b1, b1, sizeof(a.b1)); }
+    a.focal = focal;
+    a.half_w = (float)(.5 * width); a.half_h = (float)(.5 * height);          // ray_sampler.py:41
+    a.near_t = near_t; a.far_t = far_t;
+    a.width = width; a.mode = mode;
+    a.pixel0 = 0; a.n = n_rays; a.run_length = 1; a.run_stride = 1;
+    a.loc = image_plane_loc;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.t = t; a.cone = cone_scale;
+    raygen_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return NTX_OK;
+}
+
+int ntx_aabb_intersect(const float *rays_o, const float *rays_d, int64_t n_rays, const float *b0, const float *b1, float *t,
+                       ntx_stream stream) {
+    if (n_rays < 0) return fail(NTX_E_INVALID, "n_rays < 0");
+    if (!b0 || !b1) return fail(NTX_E_INVALID, "AABB bounds are NULL");
+    if (n_rays == 0) return NTX_OK;
+    if (!rays_o || !rays_d || !t) return fail(NTX_E_INVALID, "NULL buffer");
+    aabb_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(rays_o, rays_d, n_rays, b0[0], b0[1], b0[2],
+                                                                                                b1[0], b1[1], b1[2], t);
+    HIP_TRY(hipGetLastError());
+    return NTX_OK;
+}
+
 int ntx_generate_rays(const float *c2w, int height, int width, float focal, int64_t pixel0, int64_t n_pixels,
                       int mode, const float *b0, const float *b1, float near_t, float far_t, float *rays_o,
                       float *rays_d, float *t, float *cone_scale, ntx_stream stream) {

@@ -64,14 +64,40 @@ struct RaygenArgs {
     int width, mode;
     int64_t pixel0, n;
     int64_t run_length, run_stride;   // local ray k = pixel pixel0 + (k / run_length) * run_stride + k % run_length
+    const float *loc;                 // NULL, or image_plane_loc [n,2] = (row, col) of every ray as float32 (any pixel sampler)
     float *rays_o, *rays_d, *t, *cone;
 };
+
+// proxy.AABB.__call__ (proxy.py:13-35) for one ray; comparisons written exactly as tf.where does them so NaNs fall the same way
+NTX_DEV void aabb_t(const float (&ro)[3], const float (&rd)[3], const float (&b0)[3], const float (&b1)[3], float &t0, float &t1) {
+    float tmax = 0.0f, tmin = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float inv = 1.0f / rd[r];
+        const float ta = (b0[r] - ro[r]) * inv, tb = (b1[r] - ro[r]) * inv;
+        const float lo = ta < tb ? ta : tb;
+        const float hi = ta > tb ? ta : tb;
+        if (r == 0) { tmax = lo; tmin = hi; }
+        else {
+            // reduce_max / reduce_min propagate NaN
+            tmax = (lo != lo || tmax != tmax) ? __builtin_nanf("") : (lo > tmax ? lo : tmax);
+            tmin = (hi != hi || tmin != tmin) ? __builtin_nanf("") : (hi < tmin ? hi : tmin);
+        }
+    }
+    const bool hit = tmax < tmin;
+    t0 = hit ? tmax : __builtin_inff();
+    t1 = hit ? tmin : __builtin_inff();
+}
 
 __global__ __launch_bounds__(256) void raygen_kernel(RaygenArgs a) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.n) return;
-    const int64_t pix = a.pixel0 + (k / a.run_length) * a.run_stride + k % a.run_length;
-    const float li = (float)(pix / a.width), lj = (float)(pix % a.width);   // (row, col), Full sampler
+    float li, lj;                                                             // (row, col)
+    if (a.loc) { li = a.loc[2 * k]; lj = a.loc[2 * k + 1]; }                  // the caller's image_plane_loc (ray_sampler.py:39)
+    else {                                                                    // pixel_sampler.Full
+        const int64_t pix = a.pixel0 + (k / a.run_length) * a.run_stride + k % a.run_length;
+        li = (float)(pix / a.width); lj = (float)(pix % a.width);
+    }
     const float d0 = (lj + 0.5f - a.half_w) / a.focal;                       // ray_sampler.py:41
     const float d1 = -(li + 0.5f - a.half_h) / a.focal;
     const float d2 = -1.0f;
@@ -89,24 +115,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(RaygenArgs a) {
         const float n = __builtin_sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);  // :34
 #pragma unroll
         for (int r = 0; r < 3; ++r) rd[r] = rd[r] / n;
-        // proxy.py:16-33; comparisons written exactly as tf.where does them so NaNs fall the same way
-        float tmax = 0.0f, tmin = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float inv = 1.0f / rd[r];
-            const float ta = (a.b0[r] - ro[r]) * inv, tb = (a.b1[r] - ro[r]) * inv;
-            const float lo = ta < tb ? ta : tb;
-            const float hi = ta > tb ? ta : tb;
-            if (r == 0) { tmax = lo; tmin = hi; }
-            else {
-                // reduce_max / reduce_min propagate NaN
-                tmax = (lo != lo || tmax != tmax) ? __builtin_nanf("") : (lo > tmax ? lo : tmax);
-                tmin = (hi != hi || tmin != tmin) ? __builtin_nanf("") : (hi < tmin ? hi : tmin);
-            }
-        }
-        const bool hit = tmax < tmin;
-        t0 = hit ? tmax : __builtin_inff();
-        t1 = hit ? tmin : __builtin_inff();
+        aabb_t(ro, rd, a.b0, a.b1, t0, t1);
     } else {
         t0 = a.near_t; t1 = a.far_t;
     }
@@ -114,6 +123,18 @@ __global__ __launch_bounds__(256) void raygen_kernel(RaygenArgs a) {
     for (int r = 0; r < 3; ++r) { a.rays_o[3 * k + r] = ro[r]; a.rays_d[3 * k + r] = rd[r]; }
     a.t[2 * k] = t0; a.t[2 * k + 1] = t1;
     a.cone[k] = cone;
+}
+
+// proxy.AABB.__call__ on the caller's own rays (proxy.py:13-35): thread per ray
+__global__ __launch_bounds__(256) void aabb_kernel(const float *rays_o, const float *rays_d, int64_t n, float b00, float b01, float b02,
+                                                   float b10, float b11, float b12, float *t) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float ro[3] = {rays_o[3 * k], rays_o[3 * k + 1], rays_o[3 * k + 2]}, rd[3] = {rays_d[3 * k], rays_d[3 * k + 1], rays_d[3 * k + 2]};
+    const float b0[3] = {b00, b01, b02}, b1[3] = {b10, b11, b12};
+    float t0, t1;
+    aabb_t(ro, rd, b0, b1, t0, t1);
+    t[2 * k] = t0; t[2 * k + 1] = t1;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -604,3 +604,85 @@ def test_main_entry_point_renders_the_example_config(tmp_path, monkeypatch):
     assert bool(torch.isfinite(imgs[0]).all()) and float(a.max()) > 0.0 and float(a.min()) == 0.0      # object and empty background
     saved = sorted(os.listdir(tmp_path / "logs" / "example_carpet" / "media" / "test"))
     assert saved == ["0.npy", "1.npy"] and os.path.exists(tmp_path / "logs" / "example_carpet" / "config_render.py")
+
+
+def test_rays_at_any_image_plane_locations():
+    """ray_sampler.Proxy / Frustum called with a pixel TENSOR, as the reference's pixel samplers hand it over (pixel_sampler.py:15, 29,
+    69 -> ray_sampler.py:17, 25): `ntx_generate_rays_at`.  The full grid as a tensor gives the bits of the pixel-range path; a random
+    pixel list matches the float64 restatement of rays_from_camera + AABB."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.pixel_sampler import Full, Independent
+    from nerf_tex_amd.proxy import AABB
+    from nerf_tex_amd.ray_sampler import Frustum, Proxy
+    fam = synthetic.FAMILIES["carpet"]
+    H, W = 37, 53
+    c2w = orc.look_at(fam["cam"], dtype=np.float32)
+    focal = orc.focal_from_angle(W, fam["angle"] * 2.5)
+    box = AABB(fam["b_0"], fam["b_1"])
+    for sampler in (Proxy(H, W, focal, box), Frustum(H, W, focal, 2.0, 6.0)):
+        by_range = sampler(Full(H, W)(), c2w, device=dev())
+        by_tensor = sampler(Full(H, W).as_tensor(dev()), c2w)
+        assert all(torch.equal(a, b) for a, b in zip(by_range, by_tensor))
+    g = torch.Generator(device=dev()); g.manual_seed(3)
+    pix = Independent(H, W, 500)(device=dev(), generator=g)
+    assert pix.shape == (500, 2) and pix.dtype == torch.int32 and int(pix[:, 0].max()) < H and int(pix[:, 1].max()) < W and int(pix.min()) >= 0
+    o, d, t, cone = Proxy(H, W, focal, box)(pix, c2w)
+    ro, rd, tt, cc = orc.proxy_rays(pix.cpu().numpy(), H, W, focal, c2w, fam["b_0"], fam["b_1"], np.float64)
+    assert np.max(np.abs(o.cpu().numpy() - ro)) <= 1e-6 and np.max(np.abs(d.cpu().numpy() - rd)) <= 1e-6
+    hit = np.isfinite(tt[:, 0]); got_hit = np.isfinite(t.cpu().numpy()[:, 0])
+    assert hit.any() and (~hit).any() and np.mean(hit == got_hit) > 0.99
+    ok = hit & got_hit
+    assert np.max(np.abs(t.cpu().numpy()[ok] - tt[ok]) / np.abs(tt[ok])) <= 1e-5
+    assert np.max(np.abs(cone.cpu().numpy() - cc) / cc) <= 1e-5
+    # sub-pixel locations are locations too (the reference casts image_plane_loc to float32 and never rounds it)
+    loc = torch.rand((64, 2), device=dev()) * torch.tensor([H - 1.0, W - 1.0], device=dev())
+    o2, d2, _, _ = Frustum(H, W, focal, 2.0, 6.0)(loc, c2w)
+    _, rd2, _ = orc.rays_from_camera(loc.cpu().numpy(), H, W, focal, c2w, np.float64)
+    assert np.max(np.abs(d2.cpu().numpy() - rd2)) <= 1e-6
+
+
+def test_aabb_call_is_the_reference_slab_test():
+    """proxy.AABB.__call__ (proxy.py:13-35) on the caller's rays through `ntx_aabb_intersect`: bit-equal to the float32 restatement,
+    IEEE corners included (axis-parallel rays: 1/0 = inf, 0 * inf = NaN, the tf.where comparisons decide)."""
+    from nerf_tex_amd.proxy import AABB
+    rng = np.random.default_rng(0)
+    n = 4000
+    o = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32)
+    o[np.all(np.abs(o) < 1.6, -1)] += 3.0                          # origins outside the box, as the reference assumes
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:200, 0] = 0.0; d[100:300, 1] = 0.0; d[300:320] = [0.0, 0.0, 1.0]     # axis-parallel rays
+    o[320:340, 0] = 1.5; d[320:340, 0] = 0.0                       # ... and on a face plane: (b - o) * inf = 0 * inf
+    box = AABB([-1.5, -1.5, -1.5], [1.5, 1.5, 1.5])
+    t = box(*to_dev(o, d)).cpu().numpy()
+    want = orc.aabb(o, d, box.b_0, box.b_1, np.float32)
+    assert np.array_equal(t, want, equal_nan=True)
+    assert np.isinf(t[:, 0]).any() and np.isfinite(t[:, 0]).any()
+
+
+def test_pixel_sampler_proxy_samples_hit_pixels():
+    """pixel_sampler.Proxy (pixel_sampler.py:31-69): the sampled pixels are pixels of the nearest-neighbour upsampled hit mask of the
+    coarse grid; every such pixel can be drawn; n_samples of them, all different (a permutation's head)."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.pixel_sampler import Proxy as PixelProxy
+    from nerf_tex_amd.proxy import AABB
+    fam = synthetic.FAMILIES["carpet"]
+    H, W, f = 100, 132, 8                                           # 100 is not a multiple of 8: the half-pixel-centre rule matters
+    c2w = orc.look_at(fam["cam"], dtype=np.float32)
+    focal = orc.focal_from_angle(W, fam["angle"] * 2.5)
+    ps = PixelProxy(H, W, 300, AABB(fam["b_0"], fam["b_1"]), focal, downsample_factor=f)
+    hd, wd = H // f, W // f
+    _, _, t, _ = orc.frustum_rays(orc.full_pixels(hd, wd), hd, wd, focal // f, c2w, 0.0, 0.0, np.float32)
+    ro, rd, _ = orc.rays_from_camera(orc.full_pixels(hd, wd), hd, wd, focal // f, c2w, np.float32)
+    hit = np.isfinite(orc.aabb(ro, rd, fam["b_0"], fam["b_1"], np.float32)[:, 0]).reshape(hd, wd)
+    src = lambda n_dst, n_src: np.minimum(np.floor((np.arange(n_dst, dtype=np.float32) + np.float32(0.5)) * (np.float32(n_src) / np.float32(n_dst))).astype(int), n_src - 1)
+    up = hit[src(H, hd)][:, src(W, wd)]
+    assert np.array_equal(ps.hit_mask(c2w, dev()).cpu().numpy(), up) and 0.05 < up.mean() < 0.95
+    g = torch.Generator(device=dev()); g.manual_seed(1)
+    pix = ps(c2w, device=dev(), generator=g).cpu().numpy()
+    assert pix.shape == (300, 2) and up[pix[:, 0], pix[:, 1]].all() and len({tuple(p) for p in pix}) == 300
+    seen = np.zeros_like(up)
+    for s in range(40):
+        g.manual_seed(s)
+        q = ps(c2w, device=dev(), generator=g).cpu().numpy()
+        seen[q[:, 0], q[:, 1]] = True
+    assert seen[up].mean() > 0.5 and not seen[~up].any()
