@@ -540,9 +540,9 @@ struct ntx_ctx {
     size_t packed16i_bytes;
     int32_t *hit_list;    // device scratch of ntx_render_rays: compacted hit-ray indices, sized by ntx_reserve
     size_t hit_cap;
-    int32_t *hit_count;   // device int32[2]: [0] number of hit rays, [1] work counter of the instance kernel
+    int32_t *hit_count;   // device int32[8]: [0] number of hit rays, [1] work counter of the instance kernel, [2..5] its chunk table (inst_order_kernel)
     bool hoist_dir;       // false when NERFTEX_NO_DIR_HOIST is set at ntx_create (A/B knob for tests: same bits either way)
-    uint16_t *inst_sidx;  // device scratch of ntx_render_instanced: per wave, the compacted index list of its ray in flight (8 KiB each)
+    uint16_t *inst_sidx;  // device scratch of ntx_render_instanced: per wave, the execution list of its bundle of rays in flight (8.5 KiB each)
 };
 
 // The big kernels of each model family live in their own translation units (ntx_variant.hip / ntx_variant_x3.hip
@@ -751,8 +751,8 @@ int ntx_create(const ntx_model_desc *desc, const float *weights_host, size_t n_f
     *out = c;
     {   // all the device scratch the entry points will ever use: allocated here (and by ntx_reserve), never per call
         int rc = NTX_OK;
-        if (hipMalloc((void **)&c->hit_count, 2 * sizeof(int32_t)) != hipSuccess) rc = fail(NTX_E_HIP, "hipMalloc(hit_count)");
-        if (rc == NTX_OK && hipMalloc((void **)&c->inst_sidx, (size_t)c->n_wgs * 4 * MAX_INSTANCE_SAMPLES * sizeof(uint16_t)) != hipSuccess)
+        if (hipMalloc((void **)&c->hit_count, 8 * sizeof(int32_t)) != hipSuccess) rc = fail(NTX_E_HIP, "hipMalloc(hit_count)");
+        if (rc == NTX_OK && hipMalloc((void **)&c->inst_sidx, (size_t)c->n_wgs * 4 * INST_EXEC_CAP * sizeof(uint16_t)) != hipSuccess)
             rc = fail(NTX_E_HIP, "hipMalloc(inst_sidx)");
         if (rc == NTX_OK) rc = ntx_reserve(c, NTX_DEFAULT_MAX_RAYS);
         if (rc != NTX_OK) { ntx_destroy(c); *out = nullptr; return rc; }
@@ -784,8 +784,8 @@ int ntx_reserve(ntx_ctx *ctx, int64_t max_rays) {
     HIP_TRY(hipDeviceSynchronize());   // a launch may still be walking the old list
     if (ctx->hit_list) HIP_TRY(hipFree(ctx->hit_list));
     ctx->hit_list = nullptr; ctx->hit_cap = 0;
-    // ntx_render_rays: hit_list[max_rays]; ntx_render_instanced: order[max_rays] | count[max_rays] | bins[INST_BINS]
-    if (max_rays > 0) HIP_TRY(hipMalloc((void **)&ctx->hit_list, ((size_t)max_rays * 2 + INST_BINS) * sizeof(int32_t)));
+    // ntx_render_rays: hit_list[max_rays]; ntx_render_instanced: order[max_rays] | count[max_rays]
+    if (max_rays > 0) HIP_TRY(hipMalloc((void **)&ctx->hit_list, (size_t)max_rays * 2 * sizeof(int32_t)));
     ctx->hit_cap = (size_t)max_rays;
     return NTX_OK;
 }
@@ -1092,16 +1092,20 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
         return fail(NTX_E_INVALID, "n_rays %lld exceeds the %zu rays this context reserved; call ntx_reserve first", (long long)n_rays, ctx->hit_cap);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(ctx->hit_count + 1, 0, sizeof(int32_t), st));   // [0] hits of ntx_render_rays, [1] this counter
-    a.work_counter = ctx->hit_count + 1;
+    a.work_counter = ctx->hit_count + 1;   // [0] hits of ntx_render_rays, [1] this counter (inst_order_kernel zeroes it)
     {   // hand the rays out costliest first (ntx_small_kernels.h: inst_*_kernel); scratch reserved in the context
-        int32_t *order = ctx->hit_list, *count = ctx->hit_list + ctx->hit_cap, *bins = ctx->hit_list + 2 * ctx->hit_cap;
-        HIP_TRY(hipMemsetAsync(bins, 0, INST_BINS * sizeof(int32_t), st));
-        inst_count_kernel<<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st>>>(dists, hit, n_rays, n_samples, count, bins);
-        inst_offsets_kernel<<<dim3(1), dim3(INST_BINS), 0, st>>>(bins);
-        inst_scatter_kernel<<<dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st>>>(count, n_rays, bins, order);
+        int32_t *order = ctx->hit_list, *count = ctx->hit_list + ctx->hit_cap;
+        inst_count_kernel<<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st>>>(dists, hit, n_rays, n_samples, count);
+        // chunks of the hand-out (float32 kernel): the last ta rays per wave not in fours, the last tb single; development knobs in
+        // NERFTEX_DEBUG_RUNS: bit 3 = single rays throughout, bits 8-12 / 16-20 = ta / tb
+        int ta = 6, tb = 3;
+        if ((a.run_hoist >> 8) & 31) ta = (a.run_hoist >> 8) & 31;
+        if ((a.run_hoist >> 16) & 31) tb = (a.run_hoist >> 16) & 31;
+        if (a.run_hoist & 8) ta = -1;
+        a.chunk_tab = ctx->hit_count + 2;
+        inst_order_kernel<<<dim3(1), dim3(INST_ORDER_THREADS), 0, st>>>(count, n_rays, order, a.work_counter, ctx->n_wgs * 4, ta, tb, ctx->hit_count + 2);
         HIP_TRY(hipGetLastError());
-        a.order = order;
+        a.order = order; a.count = count;
     }
     if (flags & NTX_FLAG_FP16X3) {
         // directions are per sample: ParamNerf uses the stream that keeps C1's direction segment; plain Nerf's one stream

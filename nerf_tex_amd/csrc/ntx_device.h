@@ -1336,6 +1336,8 @@ struct InstanceArgs {
     float bkgd[3];
     int32_t *work_counter;   // device scalar, zero at launch: rays are handed out dynamically (their cost varies 0..S/32 batches)
     const int32_t *order;    // the rays, costliest first (inst_*_kernel, ntx_small_kernels.h): claim k marches ray order[k]
+    const int32_t *chunk_tab;   // {r1, q0, q1, p1}: the hand-out in chunks of 1 | 2 | 4 | 2 | 1 rays of the cost order (inst_order_kernel)
+    const int32_t *count;    // in-patch samples of every ray (inst_count_kernel): the float32 kernel lays a ray's samples out before it compacts them
     int np_in;               // generic family, as RenderArgs
     int8_t pmap[MAX_PARAM_SLOTS];
     // ABI v3: NTX_FLAG_RAW_NOISE (renderer.py:335-337), counter = (marching-sample index, global ray index, 1) as RenderArgs
@@ -1343,7 +1345,7 @@ struct InstanceArgs {
     uint32_t seed_lo, seed_hi, idx_run;
     int64_t idx0, idx_stride;
     int run_hoist;           // 0: every sample is its own run (A/B knob: NERFTEX_NO_DIR_HOIST at ntx_create)
-    uint16_t *sidx_scratch;  // [n_workgroups * 4][MAX_INSTANCE_SAMPLES]: every wave's compacted index list of the ray in flight (context scratch)
+    uint16_t *sidx_scratch;  // [n_workgroups * 4][INST_EXEC_CAP]: every wave's execution list of the bundle of rays in flight (context scratch)
 };
 
 // Tail packing.  A ray's in-patch samples fill count / 32 whole batches and leave a TAIL of count % 32 samples; run as a
@@ -1457,26 +1459,68 @@ NTX_DEV void leader_rows(__amdgpu_buffer_rsrc_t rsrc, const float *aux, float *r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The work of a wave: BUNDLES of rays compiled into an EXECUTION LIST (round 3).  Until v14 a wave claimed one ray at a time
+// and everything that is paid per ray was paid for ~4 batches of work: the claim -> order -> hit -> dists -> run flags chain of
+// exposed memory latencies, one leader_rows pass (the direction segment for 32 columns, whatever the number of runs: ~27 k
+// cycles for the 8 runs of an average ray of the bench workload), and a second such pass for every packed tail batch, which
+// took per-sample rows and threw the group's rows away.  Now a wave claims up to BUNDLE_MAX rays with ONE atomic, reads their
+// facts with one round of loads (lane r = ray r) and lays their samples out in the order they will be evaluated:
+//   entry (16 bits) = marching index | slot << 12 | LEAD_FLAG;  slot = one of INST_SLOTS live rays of the wave, 7 = empty lane
+//   whole batches of ray 0 | [a packed batch that closed] | whole batches of ray 1 | ...
+// A ray's tail (count % 32 samples) joins the OPEN packed batch (kept in LDS across bundles; <= OPEN_MAX rays), which is
+// emitted into the list -- padded with empty lanes if need be -- when the next tail does not fit.  The list lives in the
+// context's scratch (L2) and is read through the window in LDS; the run flags are computed on the window.  The consumer then
+// takes 32 entries at a time, whatever they are: a batch whose 32 lanes belong to one ray is one of its whole batches
+// (sequential composite on the ray's accumulator in its slot), anything else is a packed batch of tails, each a segment of
+// consecutive lanes that finishes its ray (composite_segment: position-independent, see above).  Groups of run rows span rays
+// and packed batches alike.  Every ray still sees exactly the arithmetic it saw before -- its whole batches in order, then its
+// tail as a segment -- so the image does not depend on the bundle size, the company or the hand-out
+// (test_packed_tails_do_not_depend_on_the_company), and NERFTEX_DEBUG_RUNS bit 3 (bundles of one ray) gives the same bits.
+// Bundle size: 4 rays while many are left, 2, then 1 near the end of the cost-ordered hand-out (the ragged end is one
+// claim's worth of work per wave), and what the list can hold (rays arrive costliest first: the previous claim's count
+// bounds the next ones).
+// ---------------------------------------------------------------------------------------------
+constexpr int INST_SLOTS = 7;               // live rays of a wave (slot 7 = empty lane of a packed batch)
+constexpr int OPEN_MAX = 6;                 // rays in the open packed batch: one slot always stays free for a new ray
+constexpr int BUNDLE_MAX = 4;
+constexpr int ENTRY_IDX = 0x0fff, ENTRY_SLOT_SHIFT = 12, ENTRY_EMPTY = 7 << ENTRY_SLOT_SHIFT;
+static_assert(MAX_INSTANCE_SAMPLES <= ENTRY_IDX + 1, "marching indices take 12 bits of a list entry");
+// bundles are sized so that the list fits: 4 rays of <= 1024 + 7 samples (the order is by bins of 8) + 4 emitted packed batches
+constexpr int INST_EXEC_CAP = MAX_INSTANCE_SAMPLES + 256;
+
+struct InstanceWave {                       // per wave, in LDS
+    uint16_t open_idx[32];                  // the open packed batch: entries of the tails collected so far
+    int32_t ray[8];                         // per slot: ray, position behind its last whole batch when it has no tail (else -1),
+    int32_t fin_pos[8];                     //           cone_scale, the accumulator (T, r, g, b, a), the appended sample
+    float cone[8];
+    float acc[8][5];
+    float last[8][4];                       // color_last rgb, alpha_last (renderer.py:323-339)
+    int32_t b_ray[BUNDLE_MAX], b_n[BUNDLE_MAX];   // the claimed rays not yet compiled: ray, in-patch samples (-1: not hit), cone_scale, appended sample
+    float b_cone[BUNDLE_MAX], b_last[BUNDLE_MAX][4];
+    int32_t st[8];                          // what only next_bundle needs (kept out of the registers that live across the network):
+};                                          // open_n, open_k, open_mask, exhausted, q_i, q_n
+
 template <class CFG>
 __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
     constexpr int NSLOT = lead_slots<CFG>();
     constexpr bool ROWS = NSLOT > 0;            // ParamNerf: C1 always starts from rows; plain Nerf has no C1 (per-sample kernel as before)
     __shared__ __attribute__((aligned(16))) float aux[aux_floats_of<CFG>() + (ROWS ? 4 * NSLOT * DIR_ROW_STRIDE : 4 * pe_keep_floats<CFG>())];
     __shared__ uint16_t win_all[4][SIDX_WINDOW];
-    __shared__ InstancePending pend_all[4];
+    __shared__ InstanceWave tab_all[4];
     __shared__ uint8_t slot_all[4][32];         // row of each sample of the batch in flight
-    __shared__ uint16_t lead_all[4][32];        // position (in the compacted list) of the group's run leaders
+    __shared__ uint16_t lead_all[4][32];        // position (in the execution list) of the group's run leaders
     __shared__ float park_all[4][32][2];        // dists and density weight of the batch in flight (no register survives the network)
     load_aux(aux, a.aux, aux_floats_of<CFG>());
-    const int lane = threadIdx.x & 63, j = lane & 31;
+    int lane = threadIdx.x & 63, j = lane & 31;   // (re-read from the hardware at the top of the loop and behind the network: no lane-derived register lives across it)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.n_samples;
     float (*park)[2] = park_all[wv];
-    // the compacted index list of the ray in flight: global scratch of the context (L2-resident, 8 KiB per wave), read through a
-    // window in LDS; entry = marching index | LEAD_FLAG
-    uint16_t *gsidx = a.sidx_scratch + ((size_t)blockIdx.x * 4 + wv) * MAX_INSTANCE_SAMPLES;
+    // the execution list of the bundle in flight: global scratch of the context (L2-resident, INST_EXEC_CAP entries per wave), read
+    // through a window in LDS
+    uint16_t *gs = a.sidx_scratch + ((size_t)blockIdx.x * 4 + wv) * INST_EXEC_CAP;
     uint16_t *win = win_all[wv];
-    InstancePending &pend = pend_all[wv];
+    InstanceWave &tab = tab_all[wv];
     float *rows = aux + aux_floats_of<CFG>() + wv * NSLOT * DIR_ROW_STRIDE;
     float *pe_col = ROWS ? nullptr : pe_column<CFG>(aux, wv, lane);
     uint8_t *slots = slot_all[wv];
@@ -1487,13 +1531,17 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
     // without them every sample is its own run (the rows of a batch are then evaluated for that batch alone: the work of the
     // per-sample kernel, bit-identical results)
     const bool runs_on = ROWS && (a.run_hoist & 1) != 0 && !(a.blur_idx >= CFG::NGEO && CFG::IPE == 0);
-    const int group_max = (a.run_hoist & 4) ? 1 : LEAD_GROUP_MAX;   // (development knobs: bit 1 = flags only, bit 2 = one batch per group)
+    const int group_max = (a.run_hoist & 4) ? 1 : LEAD_GROUP_MAX;   // (development knobs: bit 1 = flags only, bit 2 = one batch per group, bit 3 = bundles of one ray)
+    const bool grouped = ROWS && runs_on && !(a.run_hoist & 2);      // (wave-uniform) batches take their rows from groups of runs
 
+    auto lds_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     // the appended sample (colour taken as is, alpha_last is an alpha, not a density: renderer.py:323-339) and the store
-    auto finish = [&](int64_t ray, const RayAccum &ra) {
-        const float wl = a.alpha_last[ray] * ra.T;
-        float out[4] = {ra.c0 + wl * a.color_last[3 * ray], ra.c1 + wl * a.color_last[3 * ray + 1],
-                        ra.c2 + wl * a.color_last[3 * ray + 2], ra.a + wl};
+    auto finish = [&](int64_t ray, const RayAccum &ra, const float *last) {
+        const float wl = last[3] * ra.T;
+        float out[4] = {ra.c0 + wl * last[0], ra.c1 + wl * last[1], ra.c2 + wl * last[2], ra.a + wl};
         if (a.flags & NTX_FLAG_COMPOSITE_BKGD) {   // renderer.py:351-352
             const float A = out[3];
 #pragma unroll
@@ -1509,127 +1557,239 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
         }
     };
 
-    int64_t cur = -1;            // the ray whose whole batches are being marched, -1 = none
-    int count = 0, nfull = 0, b = 0, pend_n = 0, pend_k = 0;
+    int p = 0, exec_len = 0;                       // the batch due is entries [p, p + 32) of a list of exec_len
     int win0 = 0;                                  // the window holds list entries [win0, win0 + SIDX_WINDOW)
-    int grp_b0 = 0, grp_end = 0, slot_base = 0;    // rows in LDS serve batches [grp_b0, grp_end) of `cur`; next free row of the group
-    bool exhausted = false;
-    float cone = 0.0f;
-    RayAccum ra{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    int grp_p0 = 0, grp_end = 0, slot_base = 0;    // rows in LDS serve the batches at positions [grp_p0, grp_end); next free row of the group
+    if (lane < 8) tab.st[lane] = 0;
+    lds_sync();
+
+    auto put = [&](int pos, int e) {
+        gs[pos] = (uint16_t)e;
+        if (pos < SIDX_WINDOW) win[pos] = (uint16_t)e;
+    };
+    // run flags of window entries [0, nwin): the first sample of every run = direction / appearance inputs bit-different from the
+    // previous entry's (or no previous entry in the window, or an empty lane before it); a flag too many costs a row, never a bit
+    auto win_flag = [&](int nwin) {
+        if (!runs_on) return;
+        constexpr int NV = 3 + CFG::NAPP;
+        uint32_t carry[NV] = {};
+        bool carry_valid = false;
+        for (int k0 = 0; k0 < nwin; k0 += 128) {   // two steps of 64 entries, their gathers in flight together
+            uint32_t bits[2][NV];
+            bool val[2];
+            int ent[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = k0 + 64 * u + lane;
+                const int e = k < nwin ? win[k] : ENTRY_EMPTY;
+                const int sl = (e >> ENTRY_SLOT_SHIFT) & 7;
+                val[u] = sl != 7; ent[u] = e;
+                SampleIn<CFG::NGEO, CFG::NAPP> din;
+                if (val[u]) {
+                    dir_inputs<CFG>(a, (int64_t)tab.ray[sl] * S + (e & ENTRY_IDX), din);
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) bits[u][c] = __builtin_bit_cast(uint32_t, c < 3 ? din.dir[c < 3 ? c : 0] : din.par[CFG::NGEO + (c < 3 ? 0 : c - 3)]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) bits[u][c] = 0u;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = k0 + 64 * u + lane;
+                int pvld = __shfl_up((int)val[u], 1, 64);
+                if (lane == 0) pvld = (int)carry_valid;
+                bool diff = !pvld;
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    uint32_t pv = (uint32_t)__shfl_up((int)bits[u][c], 1, 64);
+                    if (lane == 0) pv = carry[c];
+                    diff = diff || pv != bits[u][c];
+                    carry[c] = (uint32_t)__shfl((int)bits[u][c], 63, 64);
+                }
+                carry_valid = __shfl((int)val[u], 63, 64) != 0;
+                if (val[u] && diff && k < nwin) win[k] = (uint16_t)(ent[u] | LEAD_FLAG);
+            }
+        }
+        lds_sync();
+    };
     auto win_load = [&](int p0) {
         win0 = p0;
-        for (int k = lane; k < SIDX_WINDOW && p0 + k < count; k += 64) win[k] = gsidx[p0 + k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        const int nwin = exec_len - p0 < SIDX_WINDOW ? exec_len - p0 : SIDX_WINDOW;
+        for (int k = lane; k < nwin; k += 64) win[k] = gs[p0 + k];
+        lds_sync();
+        win_flag(nwin);
     };
-    for (;;) {
-        // ---- scheduler (wave-uniform): advance until a batch is due.  mode 1 = a whole batch of `cur`, 2 = the packed tails
-        int mode = 0;
-        for (;;) {
-            if (cur >= 0 && b < nfull) { mode = 1; break; }
-            if (cur >= 0) {
-                const int r = count - 32 * nfull;
-                if (r == 0) { finish(cur, ra); cur = -1; continue; }
-                if (pend_n + r <= 32 && pend_k < PEND_MAX) {   // the tail joins the pending batch as segment pend_k
-                    if (32 * nfull < win0 || count > win0 + SIDX_WINDOW) win_load(32 * nfull);
-                    if (lane < r) { pend.idx[pend_n + lane] = win[32 * nfull - win0 + lane] & (LEAD_FLAG - 1); pend.slot[pend_n + lane] = (uint8_t)pend_k; }
-                    if (lane == 0) {
-                        pend.ray[pend_k] = (int32_t)cur; pend.last[pend_k] = pend_n + r - 1; pend.cone[pend_k] = cone;
-                        pend.acc[pend_k][0] = ra.T; pend.acc[pend_k][1] = ra.c0; pend.acc[pend_k][2] = ra.c1;
-                        pend.acc[pend_k][3] = ra.c2; pend.acc[pend_k][4] = ra.a;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    pend_n += r; ++pend_k; cur = -1;
-                    continue;
+    // the open packed batch becomes entries [at, at + 32) of the list (empty lanes behind its samples)
+    auto emit_open = [&](int at, int &open_n, int &open_k, uint32_t &open_mask) {
+        lds_sync();
+        if (lane < 32) put(at + lane, lane < open_n ? (int)tab.open_idx[lane] : ENTRY_EMPTY);
+        open_n = 0; open_k = 0; open_mask = 0;
+    };
+
+    // ---- compile the next bundle of rays into the list (claiming a chunk when the queue is empty); false = nothing is left at all
+    auto next_bundle = [&]() -> bool {
+        p = 0; exec_len = 0; grp_p0 = grp_end = 0;
+        int open_n = __builtin_amdgcn_readfirstlane(tab.st[0]), open_k = __builtin_amdgcn_readfirstlane(tab.st[1]);   // the open packed batch: samples, rays,
+        uint32_t open_mask = (uint32_t)__builtin_amdgcn_readfirstlane(tab.st[2]);                                     // the slots of those rays
+        bool exhausted = __builtin_amdgcn_readfirstlane(tab.st[3]) != 0;
+        int q_i = __builtin_amdgcn_readfirstlane(tab.st[4]), q_n = __builtin_amdgcn_readfirstlane(tab.st[5]);         // the claimed rays still to compile
+        const bool fast = (S & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dists) & 15) == 0;   // rows of dists as 16-byte loads
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        bool any = true;
+        while (exec_len == 0) {
+            if (q_i == q_n) {
+                if (exhausted) {
+                    if (open_n == 0) { any = false; break; }
+                    emit_open(0, open_n, open_k, open_mask);
+                    exec_len = 32;
+                    break;
                 }
-                mode = 2; break;   // no room: flush the pending batch first, `cur` joins the next one
-            }
-            if (!exhausted) {
+                // The hand-out: claim c of the shared counter is a CHUNK of the cost order -- single rays, pairs, fours, pairs, single
+                // rays, a closed form of c over the ranks inst_order_kernel chose (ntx_small_kernels.h: a chunk costs at most half a
+                // wave's share, and the end of the hand-out is single cheap rays).  (A wave that sized its claim from what it saw at
+                // its previous one overshot: +5 % at 16 384 rays.)
+                const int64_t r1 = a.chunk_tab[0], q0 = a.chunk_tab[1], q1 = a.chunk_tab[2], p1 = a.chunk_tab[3];
+                const int64_t c1 = r1, c2 = c1 + (q0 - r1) / 2, c3 = c2 + (q1 - q0) / 4, c4 = c3 + (p1 - q1) / 2, n_chunks = c4 + (a.n_rays - p1);
                 int r32 = 0;
                 if (lane == 0) r32 = atomicAdd(a.work_counter, 1);
-                const int64_t claim = (int64_t)__builtin_amdgcn_readfirstlane(r32);
-                if (claim >= a.n_rays) { exhausted = true; continue; }
-                const int64_t ray = a.order[claim];
-                if (!a.hit[ray]) {   // renderer.py:265-272, 313-314: stays 0, also under composite_bkgd
+                const int64_t c = (int64_t)__builtin_amdgcn_readfirstlane(r32);
+                if (c >= n_chunks) { exhausted = true; continue; }
+                const int64_t first = c < c1 ? c : c < c2 ? r1 + 2 * (c - c1) : c < c3 ? q0 + 4 * (c - c2) : c < c4 ? q1 + 2 * (c - c3) : p1 + (c - c4);
+                const int K = c < c1 ? 1 : c < c2 ? 2 : c < c3 ? 4 : c < c4 ? 2 : 1;
+                // the rays' facts, lane r = ray r: one round of loads for the chunk.  The number of in-patch samples differs from ray
+                // to ray (0 .. S), so a static ray -> wave map leaves waves idle at the end (19 % on the carpet_instanced bench workload)
+                if (lane < K) {
+                    const int64_t ray = a.order[first + lane];
+                    tab.b_ray[lane] = (int32_t)ray;
+                    tab.b_n[lane] = a.hit[ray] ? a.count[ray] : -1;
+                    tab.b_cone[lane] = a.cone ? a.cone[ray] : 0.0f;
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) tab.b_last[lane][cc] = a.color_last[3 * ray + cc];
+                    tab.b_last[lane][3] = a.alpha_last[ray];
+                }
+                lds_sync();
+                q_i = 0; q_n = K;
+            }
+            int pos = 0;
+            uint32_t used = open_mask;
+            const int q0 = q_i;
+            bool stop = false;
+            // the rows of all queued rays in flight together when a row is one step of four 16-byte loads (S <= 1024)
+            const bool pre = fast && S <= 1024;
+            f32x4 dv[BUNDLE_MAX][4];
+            static_for<BUNDLE_MAX>([&](auto R) {
+                constexpr int r = R;
+                const bool want = pre && q0 + r < q_n && __builtin_amdgcn_readfirstlane(tab.b_n[(q0 + r) & (BUNDLE_MAX - 1)]) > 0;
+                const f32x4 *d4 = reinterpret_cast<const f32x4 *>(a.dists + (int64_t)__builtin_amdgcn_readfirstlane(tab.b_ray[(q0 + r) & (BUNDLE_MAX - 1)]) * S);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = 64 * u + lane; dv[r][u] = want && i < (S >> 2) ? d4[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+            });
+            static_for<BUNDLE_MAX>([&](auto R) {
+                constexpr int r = R;
+                if (stop || q0 + r >= q_n) return;
+                const int qi = q0 + r;
+                const int64_t ray = (int64_t)__builtin_amdgcn_readfirstlane(tab.b_ray[qi]);
+                const int n = __builtin_amdgcn_readfirstlane(tab.b_n[qi]);
+                if (n < 0) {   // renderer.py:265-272, 313-314: stays 0, also under composite_bkgd
                     if (lane < 3) a.color_out[3 * ray + lane] = 0.0f;
                     if (lane == 3) a.alpha_out[ray] = 0.0f;
-                    continue;
+                    q_i = qi + 1;
+                    return;
                 }
-                // The number of in-patch samples differs from ray to ray (0 .. S), so a static ray -> wave map leaves waves idle at
-                // the end (19 % on the carpet_instanced bench workload): each wave takes the next unclaimed ray instead.
+                if (n == 0) {   // hit, but no sample inside a patch: the appended sample alone
+                    finish(ray, RayAccum{1.0f, 0.0f, 0.0f, 0.0f, 0.0f}, tab.b_last[qi]);
+                    q_i = qi + 1;
+                    return;
+                }
+                const int nfull = n >> 5, rem = n & 31;
+                // no slot left, or the list full: the ray stays queued for the next bundle (the first ray of a bundle always fits)
+                if (__popc(used) >= INST_SLOTS || pos + 32 * nfull + 64 > INST_EXEC_CAP) { stop = true; return; }
+                if (rem > 0 && (open_n + rem > 32 || open_k == OPEN_MAX)) { emit_open(pos, open_n, open_k, open_mask); pos += 32; }
+                const int sl = __builtin_ctz(~used);
+                used |= 1u << sl;
+                const int base = pos, tbase = open_n;
+                pos += 32 * nfull;
+                if (lane == 0) {
+                    tab.ray[sl] = (int32_t)ray; tab.fin_pos[sl] = rem == 0 ? pos : -1; tab.cone[sl] = tab.b_cone[qi];
+                    tab.acc[sl][0] = 1.0f; tab.acc[sl][1] = 0.0f; tab.acc[sl][2] = 0.0f; tab.acc[sl][3] = 0.0f; tab.acc[sl][4] = 0.0f;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) tab.last[sl][cc] = tab.b_last[qi][cc];
+                }
+                // compaction: in-patch sample number k of the ray (marching index i) -> its place in the list / the open batch
+                auto place = [&](int k, int i) {
+                    if (k >= n) return;   // (n = what inst_count_kernel counted on the same row)
+                    const int e = i | (sl << ENTRY_SLOT_SHIFT);
+                    if (k < 32 * nfull) put(base + k, e);
+                    else tab.open_idx[tbase + k - 32 * nfull] = (uint16_t)e;
+                };
+                auto place4 = [&](const f32x4 &v, int i, int &cnt) {   // marching indices i .. i + 3 of this lane, lanes in index order
+                    unsigned long long m[4];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) m[cc] = __ballot(v[cc] > 0.0f);
+                    int k = cnt + __popcll(m[0] & lt) + __popcll(m[1] & lt) + __popcll(m[2] & lt) + __popcll(m[3] & lt);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) if (v[cc] > 0.0f) { place(k, i + cc); ++k; }
+                    cnt += __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
+                };
                 const float *drow = a.dists + ray * S;
-                int n = 0;
-                for (int base0 = 0; base0 < S; base0 += 512) {   // 8 independent loads in flight, then their 8 ballots
-                    float dv[8];
+                int cnt = 0;
+                if (pre) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { const int i = base0 + 64 * u + lane; dv[u] = i < S ? drow[i] : 0.0f; }
+                    for (int u = 0; u < 4; ++u) place4(dv[r][u], 4 * (64 * u + lane), cnt);
+                } else if (fast) {
+                    const f32x4 *d4 = reinterpret_cast<const f32x4 *>(drow);
+                    const int q = S >> 2;
+                    for (int i0 = 0; i0 < q; i0 += 256) {   // 4 loads of 16 bytes in flight, then their 16 ballots
+                        f32x4 w[4];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int i = base0 + 64 * u + lane;
-                        const bool v = dv[u] > 0.0f;
-                        const unsigned long long m = __ballot(v);
-                        if (v) gsidx[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
-                        n += __popcll(m);
+                        for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; w[u] = i < q ? d4[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) place4(w[u], 4 * (i0 + 64 * u + lane), cnt);
                     }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (runs_on && n >= 32) {
-                    // flag the first sample of every run of the whole batches: direction / appearance inputs bit-different from the
-                    // previous in-patch sample's (64 samples per step; lane 0 compares with the previous step's last sample)
-                    constexpr int NV = 3 + CFG::NAPP;
-                    uint32_t carry[NV] = {};
-                    for (int k0 = 0; k0 < (n & ~31); k0 += 64) {
-                        const int k = k0 + lane;
-                        const bool v = k < (n & ~31);
-                        const int idx = gsidx[v ? k : 0] & (LEAD_FLAG - 1);   // (entry 0 is flagged from the first step on)
-                        SampleIn<CFG::NGEO, CFG::NAPP> din;
-                        dir_inputs<CFG>(a, ray * S + idx, din);
-                        bool diff = k == 0;
+                } else {
+                    for (int base0 = 0; base0 < S; base0 += 512) {   // 8 independent loads in flight, then their 8 ballots
+                        float w[8];
 #pragma unroll
-                        for (int c = 0; c < NV; ++c) {
-                            const uint32_t bits = __builtin_bit_cast(uint32_t, c < 3 ? din.dir[c < 3 ? c : 0] : din.par[CFG::NGEO + (c < 3 ? 0 : c - 3)]);
-                            uint32_t pv = (uint32_t)__shfl_up((int)bits, 1, 64);
-                            if (lane == 0) pv = carry[c];
-                            diff = diff || pv != bits;
-                            carry[c] = (uint32_t)__shfl((int)bits, 63, 64);
+                        for (int u = 0; u < 8; ++u) { const int i = base0 + 64 * u + lane; w[u] = i < S ? drow[i] : 0.0f; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const bool v = w[u] > 0.0f;
+                            const unsigned long long m = __ballot(v);
+                            if (v) place(cnt + __popcll(m & lt), base0 + 64 * u + lane);
+                            cnt += __popcll(m);
                         }
-                        if (v && diff) gsidx[k] = (uint16_t)(idx | LEAD_FLAG);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
                 }
-                cur = ray; count = n; nfull = n >> 5; b = 0;
-                grp_b0 = grp_end = 0;
-                win_load(0);
-                cone = a.cone ? a.cone[ray] : 0.0f;
-                ra = RayAccum{1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                continue;
-            }
-            if (pend_n > 0) mode = 2;
-            break;
+                if (rem > 0) { open_n += rem; ++open_k; open_mask |= 1u << sl; }
+                q_i = qi + 1;
+            });
+            exec_len = pos;
         }
-        if (mode == 0) break;
+        if (lane == 0) {
+            tab.st[0] = open_n; tab.st[1] = open_k; tab.st[2] = (int32_t)open_mask; tab.st[3] = exhausted ? 1 : 0; tab.st[4] = q_i; tab.st[5] = q_n;
+        }
+        lds_sync();
+        if (!any) return false;
+        win0 = 0;
+        win_flag(exec_len < SIDX_WINDOW ? exec_len : SIDX_WINDOW);
+        return true;
+    };
 
-        // ---- this lane's sample
-        bool valid = true;
-        int slot = 0;
-        int64_t sm;
-        float cone_l = cone;
-        const bool grouped = ROWS && runs_on && mode == 1 && !(a.run_hoist & 2);   // (wave-uniform) this batch takes its rows from a group of runs
-        if (mode == 1) {
-            // a group never looks past the window: slide it when the batches a new group may cover would
-            if ((grouped ? b >= grp_end && 32 * (b + LEAD_GROUP_MAX) > win0 + SIDX_WINDOW : 32 * (b + 1) > win0 + SIDX_WINDOW) && count > win0 + SIDX_WINDOW)
-                win_load(32 * b);
-            sm = cur * S + (win[32 * b - win0 + j] & (LEAD_FLAG - 1));
-        } else {
-            valid = j < pend_n;
-            const int jc = valid ? j : 0;
-            slot = pend.slot[jc];
-            sm = (int64_t)pend.ray[slot] * S + pend.idx[jc];
-            cone_l = pend.cone[slot];
-        }
+    for (;;) {
+        lane = fresh_lane_id(); j = lane & 31;
+        if (p >= exec_len && !next_bundle()) break;
+        // a group never looks past the window: slide it when the batches a new group may cover would
+        if ((grouped ? p >= grp_end && p + 32 * LEAD_GROUP_MAX > win0 + SIDX_WINDOW : p + 32 > win0 + SIDX_WINDOW) && exec_len > win0 + SIDX_WINDOW)
+            win_load(p);
+
+        // ---- this lane's sample (an empty lane of a packed batch shadows lane 0's, which is never empty)
+        int e = win[p - win0 + j];
+        bool valid = ((e >> ENTRY_SLOT_SHIFT) & 7) != 7;
+        if (!valid) e = win[p - win0];
+        const int sl_l = (e >> ENTRY_SLOT_SHIFT) & 7;
+        const int64_t sm = (int64_t)tab.ray[sl_l] * S + (e & ENTRY_IDX);
+        const float cone_l = tab.cone[sl_l];
         SampleIn<CFG::NGEO, CFG::NAPP> in;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { in.pos[c] = a.pts[3 * sm + c]; in.dir[c] = a.rays_d_map[3 * sm + c]; }
@@ -1637,9 +1797,9 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
             in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
 #pragma unroll
             for (int c = 0; c < CFG::NP; ++c) {
-                float p = param_at<CFG>(a, a.params_map + param_stride<CFG>(a) * sm, c);
-                if (c == a.blur_idx) p = p * (cone_l * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
-                in.par[c] = p;
+                float pv = param_at<CFG>(a, a.params_map + param_stride<CFG>(a) * sm, c);
+                if (c == a.blur_idx) pv = pv * (cone_l * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
+                in.par[c] = pv;
             }
         } else {
             // MipInstanceRenderer (renderer.py:510-540, 570-587): radius = blur parameter * cone_scale / patch_scale,
@@ -1656,77 +1816,94 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
             park[j][0] = a.dists[sm];
             park[j][1] = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // renderer.py:300
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        lds_sync();
 
         // ---- the rows this batch starts C1 from
         if constexpr (ROWS) {
             if (grouped) {
-                if (b >= grp_end) {
-                    // new group from batch b: row 0 = the run in progress at its first sample, then every flagged sample of as many
+                if (p >= grp_end) {
+                    // new group from this batch: row 0 = the run in progress at its first sample, then every flagged sample of as many
                     // batches as the 32 rows can serve (at least this one)
                     int nlead = 1, covered = 0;
-                    if (lane == 0) lead_pos[0] = (uint16_t)(32 * b);
-                    for (int bb = b; bb < nfull && covered < group_max; ++bb) {
-                        const bool f = (win[32 * bb - win0 + j] & LEAD_FLAG) != 0 && !(bb == b && j == 0);
+                    if (lane == 0) lead_pos[0] = (uint16_t)p;
+                    for (int pp = p; pp < exec_len && pp + 32 <= win0 + SIDX_WINDOW && covered < group_max; pp += 32) {
+                        const bool f = (win[pp - win0 + j] & LEAD_FLAG) != 0 && !(pp == p && j == 0);
                         const uint32_t m = (uint32_t)__ballot(f);              // lanes j and j + 32 agree: the low word has it
                         const int d = __popc(m);
                         if (nlead + d > NSLOT) break;
-                        if (f && lane < 32) lead_pos[nlead + __popc(m & ((1u << j) - 1u))] = (uint16_t)(32 * bb + j);
+                        if (f && lane < 32) lead_pos[nlead + __popc(m & ((1u << j) - 1u))] = (uint16_t)(pp + j);
                         nlead += d; ++covered;
                     }
-                    grp_b0 = b; grp_end = b + covered; slot_base = 0;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                    grp_p0 = p; grp_end = p + 32 * covered; slot_base = 0;
+                    lds_sync();
                     SampleIn<CFG::NGEO, CFG::NAPP> lin = in;   // (only dir and the appearance parameters are read)
-                    dir_inputs<CFG>(a, cur * S + (win[lead_pos[j < nlead ? j : 0] - win0] & (LEAD_FLAG - 1)), lin);
+                    const int le = win[lead_pos[j < nlead ? j : 0] - win0];
+                    dir_inputs<CFG>(a, (int64_t)tab.ray[(le >> ENTRY_SLOT_SHIFT) & 7] * S + (le & ENTRY_IDX), lin);
                     leader_rows<CFG, NSLOT>(ws.rsrc, aux, rows, lin, lane);
                 }
-                const bool f = (win[32 * b - win0 + j] & LEAD_FLAG) != 0 && !(b == grp_b0 && j == 0);
+                const bool f = (win[p - win0 + j] & LEAD_FLAG) != 0 && !(p == grp_p0 && j == 0);
                 const uint32_t m = (uint32_t)__ballot(f);
                 if (lane < 32) slots[j] = (uint8_t)(slot_base + __popc(m & ((2u << j) - 1u)));
                 slot_base += __popc(m);
             } else {
-                // every sample its own row (packed tails: up to 8 rays meet in the batch; runs switched off)
+                // every sample its own row (runs switched off)
                 if (lane < 32) slots[j] = (uint8_t)j;
                 leader_rows<CFG, NSLOT>(ws.rsrc, aux, rows, in, lane);
-                grp_end = b;                                  // whatever group there was is overwritten
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            lds_sync();
         }
 
         float sigma, raw[3];
         if constexpr (ROWS) mlp_batch<CFG, 4, false>(in, ws, aux, lane, sigma, raw, rows, nullptr, slots);
         else mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe_col);
+
+        // ---- behind the network nothing of the above is alive: the lane finds its sample again
+        lane = fresh_lane_id(); j = lane & 31;
+        int e2 = win[p - win0 + j];
+        const bool valid2 = ((e2 >> ENTRY_SLOT_SHIFT) & 7) != 7;
+        if (!valid2) e2 = win[p - win0];
+        const int sl2 = (e2 >> ENTRY_SLOT_SHIFT) & 7;
+        const int64_t ray2 = tab.ray[sl2];
+        const int idx2 = e2 & ENTRY_IDX;
+        const int64_t sm2 = ray2 * S + idx2;
         const float wgt = park[j][1], dist_l = park[j][0];
         sigma = sigma * wgt;
         float col[3];
         if (a.instance_color) {                                                                // :306-307, 322-323
-            const int id = a.instance_id[sm];
+            const int id = a.instance_id[sm2];
 #pragma unroll
             for (int c = 0; c < 3; ++c) col[c] = a.instance_color[3 * id + c];
         } else {
 #pragma unroll
             for (int c = 0; c < 3; ++c) col[c] = (a.flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[c]) : sigmoidf_(raw[c]);
         }
-        if (a.flags & NTX_FLAG_RAW_NOISE) {                                                       // :335-337
-            const int64_t ray_l = sm / S;
-            sigma += a.raw_noise_std * normal01(global_index(a.idx0, a.idx_run, a.idx_stride, ray_l), (int)(sm - ray_l * S), a.seed_lo, a.seed_hi);
-        }
-        const float al = valid ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * dist_l / a.patch_scale) : 0.0f;   // :339
-        if (mode == 1) {
+        if (a.flags & NTX_FLAG_RAW_NOISE)                                                         // :335-337
+            sigma += a.raw_noise_std * normal01(global_index(a.idx0, a.idx_run, a.idx_stride, ray2), idx2, a.seed_lo, a.seed_hi);
+        const float al = valid2 ? 1.0f - expf(-__builtin_fmaxf(sigma, 0.0f) * dist_l / a.patch_scale) : 0.0f;   // :339
+        const int sl0 = __builtin_amdgcn_readfirstlane(sl2);
+        const bool whole = (uint32_t)__ballot(valid2 && sl2 == sl0) == 0xffffffffu;   // 32 lanes of one ray: tails are shorter
+        if (whole) {
+            RayAccum ra{tab.acc[sl0][0], tab.acc[sl0][1], tab.acc[sl0][2], tab.acc[sl0][3], tab.acc[sl0][4]};
             composite_core<32>(ra, al, col, true, j, nullptr);
-            ++b;
-        } else {
-            for (int k = 0; k < pend_k; ++k) {
-                RayAccum rk{pend.acc[k][0], pend.acc[k][1], pend.acc[k][2], pend.acc[k][3], pend.acc[k][4]};
-                composite_segment(rk, (valid && slot == k) ? al : 0.0f, col, j, pend.last[k]);
-                finish(pend.ray[k], rk);
+            if (p + 32 == tab.fin_pos[sl0]) {
+                finish(tab.ray[sl0], ra, tab.last[sl0]);
+            } else if (lane == 0) {
+                tab.acc[sl0][0] = ra.T; tab.acc[sl0][1] = ra.c0; tab.acc[sl0][2] = ra.c1; tab.acc[sl0][3] = ra.c2; tab.acc[sl0][4] = ra.a;
             }
-            __builtin_amdgcn_wave_barrier();   // the pending batch is rewritten from here on
-            pend_n = 0; pend_k = 0;
+        } else {
+            uint32_t todo = (uint32_t)__ballot(valid2);
+            while (todo) {   // the segments, in lane order; each is the tail of its ray and finishes it
+                const int l0 = __builtin_ctz(todo);
+                const int sk = __shfl(sl2, l0, 64);
+                const uint32_t seg = (uint32_t)__ballot(valid2 && sl2 == sk);
+                RayAccum rk{tab.acc[sk][0], tab.acc[sk][1], tab.acc[sk][2], tab.acc[sk][3], tab.acc[sk][4]};
+                composite_segment(rk, (valid2 && sl2 == sk) ? al : 0.0f, col, j, 31 - __builtin_clz(seg));
+                finish(tab.ray[sk], rk, tab.last[sk]);
+                todo &= ~seg;
+            }
         }
+        lds_sync();
+        p += 32;
     }
 }
 

@@ -357,46 +357,93 @@ __global__ __launch_bounds__(256) void compact_hits_kernel(const float *t, int64
 // waves take them off a shared counter; with ~16 rays per wave the kernel ends one average ray after its mean finishing
 // time (5.7 % of the carpet_instanced workload, measured by quadrupling the chunk).  Handing the rays out in DESCENDING
 // cost (a counting sort on the number of in-patch samples, 512 bins) leaves only the cheapest rays for the end.
-// inst_count: one wave per ray, counts dists > 0 (hit rays) and histograms; inst_offsets: one block, exclusive scan over the
-// bins from the costliest down; inst_scatter: thread per ray.  The order inside a bin is whatever the atomics make it;
+// inst_count: one wave per ray, counts dists > 0 (hit rays), the row read with 16-byte loads that are all in flight at once;
+// inst_order: ONE workgroup -- histogram, exclusive scan from the costliest bin down and scatter, all on LDS atomics (round 2
+// used global atomics, ~16 000 of them on ~20 addresses, one L2 round trip each: 110 + 53 us of a 19.5 ms call; now ~25 us in
+// all), and it zeroes the hand-out counter of the main kernel.  The order inside a bin is whatever the atomics make it;
 // results do not depend on it (instance_kernel: position-independent composite).
 // ---------------------------------------------------------------------------------------------
 constexpr int INST_BINS = 512;
 NTX_DEV int inst_bin(int count) { const int b = count >> 3; return INST_BINS - 1 - (b < INST_BINS ? b : INST_BINS - 1); }   // bin 0 = costliest
 
-__global__ __launch_bounds__(256) void inst_count_kernel(const float *dists, const uint8_t *hit, int64_t n_rays, int S, int32_t *count,
-                                                         int32_t *hist) {
+__global__ __launch_bounds__(256) void inst_count_kernel(const float *__restrict__ dists, const uint8_t *__restrict__ hit, int64_t n_rays, int S,
+                                                         int32_t *__restrict__ count) {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
     int n = 0;
     if (hit[ray]) {
         const float *drow = dists + ray * S;
-        for (int i = lane; i < S; i += 64) n += drow[i] > 0.0f ? 1 : 0;
+        if ((S & 3) == 0 && (reinterpret_cast<uintptr_t>(dists) & 15) == 0) {
+            const f32x4 *d4 = reinterpret_cast<const f32x4 *>(drow);
+            const int q = S >> 2;
+            for (int i0 = 0; i0 < q; i0 += 256) {   // 4 loads of 16 bytes in flight per lane = 4 KiB per wave and step
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; v[u] = i < q ? d4[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) n += (v[u][0] > 0.0f) + (v[u][1] > 0.0f) + (v[u][2] > 0.0f) + (v[u][3] > 0.0f);
+            }
+        } else {
+            for (int i = lane; i < S; i += 64) n += drow[i] > 0.0f ? 1 : 0;
+        }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
     }
-    if (lane == 0) { count[ray] = n; atomicAdd(&hist[inst_bin(n)], 1); }
+    if (lane == 0) count[ray] = n;
 }
 
-__global__ __launch_bounds__(INST_BINS) void inst_offsets_kernel(int32_t *hist) {   // in place: counts -> start offsets
-    __shared__ int32_t v[INST_BINS];
+// The hand-out of the float32 instance kernel is in CHUNKS of the cost order (ntx_device.h: bundles of rays share what is paid per
+// claim): 4 rays, 2 or 1.  inst_order_kernel also says where: a chunk may cost at most HALF of a wave's average share of the work
+// (a chunk of the costliest rays that is a whole share leaves its wave behind for good: +12 % at 8 rays per wave, measured), and the
+// hand-out ends in pairs and then single rays, the last tb = 3 rays per wave single, the last ta = 6 not in fours, so that the ragged end
+// stays one cheap ray's worth.  chunk_tab = {r1, q0, q1, p1}: ranks [0, r1) single, [r1, q0) pairs, [q0, q1) fours, [q1, p1) pairs,
+// [p1, n) single.  (Counts are known per bin of 8: the bin a limit falls into counts as above it.)
+constexpr int INST_ORDER_THREADS = 1024;
+__global__ __launch_bounds__(INST_ORDER_THREADS) void inst_order_kernel(const int32_t *__restrict__ count, int64_t n_rays, int32_t *__restrict__ order,
+                                                                        int32_t *__restrict__ work_counter, int n_waves, int ta, int tb,
+                                                                        int32_t *__restrict__ chunk_tab) {
+    __shared__ int32_t v[INST_BINS], off[INST_BINS];
+    __shared__ unsigned long long total;
     const int i = threadIdx.x;
-    v[i] = hist[i];
+    if (i < INST_BINS) v[i] = 0;
+    if (i == 0) { *work_counter = 0; total = 0ull; }   // the main kernel's hand-out starts from 0
     __syncthreads();
-    for (int d = 1; d < INST_BINS; d <<= 1) {
-        const int32_t add = i >= d ? v[i - d] : 0;
+    unsigned long long mine = 0ull;
+    for (int64_t r = i; r < n_rays; r += INST_ORDER_THREADS) { const int c = count[r]; mine += (unsigned long long)c; atomicAdd(&v[inst_bin(c)], 1); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((i & 63) == 0) atomicAdd(&total, mine);
+    __syncthreads();
+    if (i < INST_BINS) off[i] = v[i];
+    __syncthreads();
+    for (int d = 1; d < INST_BINS; d <<= 1) {          // inclusive scan over the bins, costliest first
+        int32_t add = 0;
+        if (i < INST_BINS && i >= d) add = off[i - d];
         __syncthreads();
-        v[i] += add;
+        if (i < INST_BINS) off[i] += add;
         __syncthreads();
     }
-    hist[i] = i ? v[i - 1] : 0;
-}
-
-__global__ __launch_bounds__(256) void inst_scatter_kernel(const int32_t *count, int64_t n_rays, int32_t *offsets, int32_t *order) {
-    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ray >= n_rays) return;
-    order[atomicAdd(&offsets[inst_bin(count[ray])], 1)] = (int32_t)ray;
+    if (i == 0) {
+        const int64_t n = n_rays, w = n_waves > 0 ? n_waves : 1;
+        const int64_t half_share = (int64_t)(total / (unsigned long long)(2 * w));     // samples
+        int64_t r1 = n, r2 = n;                                                        // ta < 0: single rays throughout
+        if (ta >= 0) {
+            r1 = off[inst_bin((int)(half_share / 2 < 0x7fffffff ? half_share / 2 : 0x7fffffff))];   // ranks below: a pair would cost more than half a share
+            r2 = off[inst_bin((int)(half_share / 4 < 0x7fffffff ? half_share / 4 : 0x7fffffff))];   // ... a four
+        }
+        auto clamp = [](int64_t x, int64_t lo, int64_t hi) { return x < lo ? lo : x > hi ? hi : x; };
+        int64_t p1 = clamp(n - tb * w, r1, n);
+        int64_t q1 = clamp(n - ta * w, r1, p1);
+        int64_t q0 = clamp(r2 > r1 ? r2 : r1, r1, q1);
+        q0 = r1 + ((q0 - r1 + 1) & ~(int64_t)1); if (q0 > q1) q0 = r1 + ((q1 - r1) & ~(int64_t)1);   // whole pairs in front of the fours
+        q1 = q0 + ((q1 - q0) & ~(int64_t)3);
+        p1 = q1 + ((p1 - q1) & ~(int64_t)1);
+        chunk_tab[0] = (int32_t)r1; chunk_tab[1] = (int32_t)q0; chunk_tab[2] = (int32_t)q1; chunk_tab[3] = (int32_t)p1;
+    }
+    if (i < INST_BINS) v[i] = off[i] - v[i];           // exclusive: the first place of bin i
+    __syncthreads();
+    for (int64_t r = i; r < n_rays; r += INST_ORDER_THREADS) order[atomicAdd(&v[inst_bin(count[r])], 1)] = (int32_t)r;
 }
 
 // ---------------------------------------------------------------------------------------------

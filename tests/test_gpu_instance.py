@@ -349,3 +349,65 @@ def test_packed_tails_do_not_depend_on_the_company(precision):
                                          hit.astype(bool), params_map, cone[:, None], None, 0.09, 400.0, True, False, False, (1., 1., 1.),
                                          None, dtype=np.float64)
     assert orc.rel_linf(base, np.concatenate([rc, ra[:, None]], -1)) <= TOL
+
+
+def test_bundles_of_rays_give_the_single_ray_bits(monkeypatch):
+    """The float32 instance kernel claims CHUNKS of the cost order (4 | 2 | 1 rays; inst_order_kernel says where) and compiles them
+    into one execution list: whole batches of each ray, packed batches of tails that close inside the bundle or stay open across
+    bundles, groups of run rows that span rays.  That only happens with many more rays than waves, so: 40 960 short rays (S = 64,
+    ~13 in-patch samples each, i.e. mostly tails; a few rays with all 64 inside, rays with exactly 32, empty and un-hit rays) --
+    the image bit for bit what single-ray claims give (NERFTEX_DEBUG_RUNS bit 3), under other chunk thresholds, under a permutation of
+    the rays and with the run rows off; 400 of the rays against the float64 oracle."""
+    from nerf_tex_amd import _lib
+    model, spec, w = make_model((1, 6), dense_media=True)
+    n, S = 40960, 64
+    inst = FakeInstancer(7, seed=31, p_hit=0.97, p_in=0.2, run_len=8)
+    rng = np.random.default_rng(12)
+    params = rng.uniform(0.2, 1, size=(n, 7)).astype(np.float32)
+    bufs = list(inst.get_model_input(np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), params, S, 0.002))
+    dists = bufs[3]
+    full = rng.choice(n, 60, replace=False)
+    dists[full] = np.abs(dists[full]) + 1e-4                                       # the heavy tail: every marching sample inside
+    half = rng.choice(n, 200, replace=False)
+    dists[half, :32] = np.abs(dists[half, :32]) + 1e-4; dists[half, 32:] = 0.0     # exactly one whole batch and no tail
+    rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map = bufs
+    hit = np.zeros(n, np.uint8); hit[idxs[:, 0]] = 1
+    cone = rng.uniform(1e-3, 5e-3, size=n).astype(np.float32)
+    dv = torch.device("cuda", 0)
+    model.reserve(0, n)
+
+    def render(order):
+        d = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a[order]), device=dv).to(dt).contiguous()
+        t_ = dict(rd=d(rays_d_map), pts=d(pts), t=d(tt), dists=d(dists), cl=d(color_last.reshape(n, 3)), al=d(alpha_last.reshape(n)),
+                  aw=d(alpha_weight), iid=d(instance_id, torch.int32), hit=d(hit, torch.uint8), pm=d(params_map), cone=d(cone))
+        k = len(order)
+        col = torch.empty((k, 3), device=dv); alp = torch.empty((k,), device=dv)
+        _lib.check(_lib.lib.ntx_render_instanced(
+            model.ctx(0), t_["rd"].data_ptr(), t_["pts"].data_ptr(), t_["t"].data_ptr(), t_["dists"].data_ptr(), t_["cl"].data_ptr(),
+            t_["al"].data_ptr(), t_["aw"].data_ptr(), t_["iid"].data_ptr(), t_["hit"].data_ptr(), t_["pm"].data_ptr(), t_["cone"].data_ptr(),
+            k, S, -1, 0.09, 400.0, 0, _lib.f3([1, 1, 1.]), None, None, col.data_ptr(), alp.data_ptr(), None,
+            torch.cuda.current_stream(dv).cuda_stream))
+        torch.cuda.synchronize()
+        return np.concatenate([col.cpu().numpy(), alp.cpu().numpy()[:, None]], -1)
+
+    ident = np.arange(n)
+    base = render(ident)                                                           # chunks of 4 | 2 | 1
+    assert np.array_equal(render(ident), base)
+    for knob in (9,                                # single rays throughout
+                 1 | (1 << 8) | (1 << 16),         # fours and pairs almost to the end
+                 1 | (20 << 8) | (10 << 16),       # pairs only, single rays early
+                 1 | 4,                            # groups of one batch
+                 0, 3):                            # run rows off / flags computed, per-sample rows
+        monkeypatch.setenv("NERFTEX_DEBUG_RUNS", str(knob))
+        assert np.array_equal(render(ident), base), knob
+    monkeypatch.delenv("NERFTEX_DEBUG_RUNS")
+    perm = np.random.default_rng(2).permutation(n)
+    assert np.array_equal(render(perm), base[perm])
+    counts = (dists > 0).sum(-1)
+    assert (counts[hit == 1] == 0).any() and (hit == 0).sum() > 100 and (counts == 64).sum() >= 60 and ((counts > 0) & (counts < 32)).mean() > 0.8
+    sub = np.concatenate([full[:20], half[:20], rng.choice(n, 360, replace=False)])
+    take = lambda a: a[sub]
+    rc, ra = orc.instance_evaluate_model(w, spec, take(rays_d_map), take(pts), take(tt), take(dists), take(color_last), take(alpha_last),
+                                         take(alpha_weight), take(instance_id), take(hit).astype(bool), take(params_map), take(cone)[:, None],
+                                         None, 0.09, 400.0, True, False, False, (1., 1., 1.), None, dtype=np.float64)
+    assert orc.rel_linf(base[sub], np.concatenate([rc, ra[:, None]], -1)) <= TOL
