@@ -417,10 +417,14 @@ struct RecMap {
 // the network).
 // KEEP_PE = false: no LDS column for the position features, the skip layer evaluates them again (the instance kernel, whose LDS
 // holds 32 rows per wave instead).
-template <class CFG, int HOIST = 0, bool KEEP_PE = true>
+// MID (instance kernel): called once behind the position segment of the skip layer, the last use of the sample's inputs -- where
+// the kernel issues the gathers of the NEXT batch's inputs into the registers those leave (the loads return under the rest of
+// the network; the compiler's vmcnt bookkeeping counts them into the ring's waits).
+struct NoMid { NTX_DEV void operator()() const {} };
+template <class CFG, int HOIST = 0, bool KEEP_PE = true, class Mid = NoMid>
 NTX_DEV void mlp_batch_tuned(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
                              const float *aux_in, int lane, float &sigma, float (&rgb)[3],
-                             const float *c1_row = nullptr, float *pe = nullptr, const uint8_t *lane_slots = nullptr) {
+                             const float *c1_row = nullptr, float *pe = nullptr, const uint8_t *lane_slots = nullptr, Mid &&mid = Mid{}) {
     constexpr int NGEO = CFG::NGEO, NAPP = CFG::NAPP;
     constexpr bool GEO_ROWS = HOIST == 2 || HOIST == 3;
     constexpr int GS = hoisted_geo_steps<CFG, HOIST>();        // k-steps of the position segments evaluated per ray
@@ -436,6 +440,17 @@ NTX_DEV void mlp_batch_tuned(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &
     f32x16 accA[8], accB[8];
     float hin[128];
     auto none = [](auto, auto) {};
+    // v_max_f32(0, NaN) is 0, so the first ReLU would swallow a NaN/Inf input that TensorFlow's relu propagates
+    // (and tf.debugging.check_numerics then reports, renderer.py:140-141): chk - chk is 0 for finite inputs, NaN else
+    auto input_check = [&]() {
+        float chk = in.pos[0] + in.pos[1] + in.pos[2] + in.dir[0] + in.dir[1] + in.dir[2];
+        if constexpr (CFG::IPE != 0) chk += in.cov[0] + in.cov[1] + in.cov[2];
+#pragma unroll
+        for (int k = 0; k < CFG::NP; ++k) chk += in.par[k];
+        return chk - chk;
+    };
+    float chk_early = 0.0f;
+    if constexpr (HOIST == 4) chk_early = input_check();   // (instance kernel: one register across the network instead of the inputs)
 
     // ---- trunk layer 0: pos_map -> 256 (model.py:104-106) into set A; set B <- bias of layer 1
     if constexpr (GEO_ROWS) {
@@ -487,6 +502,7 @@ NTX_DEV void mlp_batch_tuned(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &
             if constexpr (has_pos) {   // input = concat[pos_map, h]  (model.py:107-108)
                 PosGen<NGEO, NAPP, CFG::IPE, KEEP_PE ? 2 : 0, GS> gen{in2, h, {}, pe};   // the values layer 0 kept
                 run_segment<M, pre_steps - GS, 8, M::log_of(rec0 + GS * 2)>(cur, ws, gen, conv);
+                if constexpr (HOIST == 4) mid();
             } else {                   // input = concat[dir_map, feature]  (model.py:115)
                 if constexpr (HOIST == 0) {   // (hoisted: already in the accumulators through c1_row, and not in the logical stream)
                     DirGen<NGEO, NAPP> gen{in2, h, {}};
@@ -547,13 +563,8 @@ NTX_DEV void mlp_batch_tuned(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &
         });
         rgb[c] = p + __shfl_xor(p, 32, 64) + aux[aux_rgb_off() + 384 + c];
     });
-    // v_max_f32(0, NaN) is 0, so the first ReLU would swallow a NaN/Inf input that TensorFlow's relu propagates
-    // (and tf.debugging.check_numerics then reports, renderer.py:140-141): chk - chk is 0 for finite inputs, NaN else
-    float chk = in.pos[0] + in.pos[1] + in.pos[2] + in.dir[0] + in.dir[1] + in.dir[2];
-    if constexpr (CFG::IPE != 0) chk += in.cov[0] + in.cov[1] + in.cov[2];
-#pragma unroll
-    for (int k = 0; k < CFG::NP; ++k) chk += in.par[k];
-    chk = chk - chk;
+    float chk = chk_early;
+    if constexpr (HOIST != 4) chk = input_check();
     sigma += chk;
 #pragma unroll
     for (int c = 0; c < 3; ++c) rgb[c] += chk;
@@ -854,15 +865,15 @@ NTX_DEV void mlp_flex(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws, con
 }
 
 // the network of a family on one batch: the straight-line 8 x 256 kernels, or the layer loop of the flex family
-template <class CFG, int HOIST = 0, bool KEEP_PE = true>
+template <class CFG, int HOIST = 0, bool KEEP_PE = true, class Mid = NoMid>
 NTX_DEV void mlp_batch(const SampleIn<CFG::NGEO, CFG::NAPP> &in, WStream &ws,
                        const float *aux_in, int lane, float &sigma, float (&rgb)[3],
-                       const float *c1_row = nullptr, float *pe = nullptr, const uint8_t *lane_slots = nullptr) {
+                       const float *c1_row = nullptr, float *pe = nullptr, const uint8_t *lane_slots = nullptr, Mid &&mid = Mid{}) {
     if constexpr (CFG::FLEX != 0) {
         static_assert(HOIST == 0, "the flex family evaluates everything per sample");
         mlp_flex<CFG, KEEP_PE>(in, ws, aux_in, lane, sigma, rgb, pe);
     } else {
-        mlp_batch_tuned<CFG, HOIST, KEEP_PE>(in, ws, aux_in, lane, sigma, rgb, c1_row, pe, lane_slots);
+        mlp_batch_tuned<CFG, HOIST, KEEP_PE>(in, ws, aux_in, lane, sigma, rgb, c1_row, pe, lane_slots, static_cast<Mid &&>(mid));
     }
 }
 
@@ -1776,45 +1787,75 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
         return true;
     };
 
+    // what a sample brings from memory, as loaded: the gathers of batch b + 1 are issued in the middle of batch b's network (MID of
+    // mlp_batch_tuned: behind the skip layer's position segment, where batch b's inputs die) and land under the rest of it -- at the
+    // head of a batch they cost an exposed HBM latency per batch.  The shipped ParamNerf families only: the others have no
+    // registers to spare.  (NERFTEX_DEBUG_RUNS bit 4 switches it off; same bits either way.)
+    struct RawIn { float pos[3], dir[3], par[CFG::NP > 0 ? CFG::NP : 1], t, dist, wgt, blurp; };
+    constexpr bool PREFETCH = ROWS && CFG::GEN == 0 && CFG::IPE == 0 && CFG::FLEX == 0;
+    const bool prefetch_on = PREFETCH && !(a.run_hoist & 16);
+    auto gather = [&](int at, RawIn &r) {   // lane j's sample of the batch at list position `at` (inside the window)
+        int e = win[at - win0 + j];
+        if (((e >> ENTRY_SLOT_SHIFT) & 7) == 7) e = win[at - win0];   // an empty lane of a packed batch shadows lane 0's, which is never empty
+        const int64_t sm = (int64_t)tab.ray[(e >> ENTRY_SLOT_SHIFT) & 7] * S + (e & ENTRY_IDX);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { r.pos[c] = a.pts[3 * sm + c]; r.dir[c] = a.rays_d_map[3 * sm + c]; }
+        r.t = 0.0f; r.blurp = 0.0f;
+        if constexpr (CFG::IPE == 0) {
+#pragma unroll
+            for (int c = 0; c < CFG::NP; ++c) r.par[c] = param_at<CFG>(a, a.params_map + param_stride<CFG>(a) * sm, c);
+            if (a.blur_idx >= 0) r.t = a.t[sm];
+        } else {
+            const float *pr = a.params_map + CFG::NP_IN * sm;
+#pragma unroll
+            for (int c = 0; c < CFG::NP; ++c) r.par[c] = pr[c < a.blur_idx ? c : c + 1];
+            r.blurp = pr[a.blur_idx];
+            r.t = a.t[sm];
+        }
+        r.dist = a.dists[sm];
+        r.wgt = a.alpha_weight ? a.alpha_weight[sm] : 1.0f;
+    };
+    RawIn raw;
+    bool have_next = false;
+
     for (;;) {
         lane = fresh_lane_id(); j = lane & 31;
-        if (p >= exec_len && !next_bundle()) break;
+        if (p >= exec_len) { have_next = false; if (!next_bundle()) break; }
         // a group never looks past the window: slide it when the batches a new group may cover would
         if ((grouped ? p >= grp_end && p + 32 * LEAD_GROUP_MAX > win0 + SIDX_WINDOW : p + 32 > win0 + SIDX_WINDOW) && exec_len > win0 + SIDX_WINDOW)
             win_load(p);
 
-        // ---- this lane's sample (an empty lane of a packed batch shadows lane 0's, which is never empty)
-        int e = win[p - win0 + j];
-        bool valid = ((e >> ENTRY_SLOT_SHIFT) & 7) != 7;
-        if (!valid) e = win[p - win0];
-        const int sl_l = (e >> ENTRY_SLOT_SHIFT) & 7;
-        const int64_t sm = (int64_t)tab.ray[sl_l] * S + (e & ENTRY_IDX);
-        const float cone_l = tab.cone[sl_l];
+        // ---- this lane's sample: its inputs were gathered under the previous batch's network, or are now
+        if (!have_next) gather(p, raw);
         SampleIn<CFG::NGEO, CFG::NAPP> in;
+        {
+            int e = win[p - win0 + j];
+            if (((e >> ENTRY_SLOT_SHIFT) & 7) == 7) e = win[p - win0];
+            const float cone_l = tab.cone[(e >> ENTRY_SLOT_SHIFT) & 7];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { in.pos[c] = a.pts[3 * sm + c]; in.dir[c] = a.rays_d_map[3 * sm + c]; }
-        if constexpr (CFG::IPE == 0) {
-            in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
+            for (int c = 0; c < 3; ++c) { in.pos[c] = raw.pos[c]; in.dir[c] = raw.dir[c]; }
+            if constexpr (CFG::IPE == 0) {
+                in.cov[0] = in.cov[1] = in.cov[2] = 0.0f;
 #pragma unroll
-            for (int c = 0; c < CFG::NP; ++c) {
-                float pv = param_at<CFG>(a, a.params_map + param_stride<CFG>(a) * sm, c);
-                if (c == a.blur_idx) pv = pv * (cone_l * a.t[sm] / a.patch_scale);                 // renderer.py:259-262
-                in.par[c] = pv;
+                for (int c = 0; c < CFG::NP; ++c) {
+                    float pv = raw.par[c];
+                    if (c == a.blur_idx) pv = pv * (cone_l * raw.t / a.patch_scale);                 // renderer.py:259-262
+                    in.par[c] = pv;
+                }
+            } else {
+                // MipInstanceRenderer (renderer.py:510-540, 570-587): radius = blur parameter * cone_scale / patch_scale,
+                // spliced out of the parameters; gaussian with mu = t and (sic) hw = dists; the mean is the sample point
+                float t_mean, t_var, r_var;
+                cone_moments(raw.t, raw.dist, raw.blurp * cone_l / a.patch_scale, t_mean, t_var, r_var);
+                cone_cov(t_var, r_var, in.dir, in.cov);
+#pragma unroll
+                for (int c = 0; c < CFG::NP; ++c) in.par[c] = raw.par[c];
             }
-        } else {
-            // MipInstanceRenderer (renderer.py:510-540, 570-587): radius = blur parameter * cone_scale / patch_scale,
-            // spliced out of the parameters; gaussian with mu = t and (sic) hw = dists; the mean is the sample point
-            const float *pr = a.params_map + CFG::NP_IN * sm;
-            float t_mean, t_var, r_var;
-            cone_moments(a.t[sm], a.dists[sm], pr[a.blur_idx] * cone_l / a.patch_scale, t_mean, t_var, r_var);
-            cone_cov(t_var, r_var, in.dir, in.cov);
-#pragma unroll
-            for (int c = 0; c < CFG::NP; ++c) in.par[c] = pr[c < a.blur_idx ? c : c + 1];
-        }
-        // what the composite needs of this sample is fetched with the rest (one exposed latency per batch instead of two) and parked
-        if (lane < 32) {
-            park[j][0] = a.dists[sm];
-            park[j][1] = a.alpha_weight ? a.alpha_weight[sm] * a.density_scale : a.density_scale;   // renderer.py:300
+            // what the composite needs of this sample is fetched with the rest (one exposed latency per batch instead of two) and parked
+            if (lane < 32) {
+                park[j][0] = raw.dist;
+                park[j][1] = a.alpha_weight ? raw.wgt * a.density_scale : a.density_scale;   // renderer.py:300
+            }
         }
         lds_sync();
 
@@ -1853,9 +1894,19 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
             lds_sync();
         }
 
-        float sigma, raw[3];
-        if constexpr (ROWS) mlp_batch<CFG, 4, false>(in, ws, aux, lane, sigma, raw, rows, nullptr, slots);
-        else mlp_batch<CFG>(in, ws, aux, lane, sigma, raw, nullptr, pe_col);
+        float sigma, rgb_raw[3];
+        if constexpr (ROWS) {
+            // (wave-uniform) the next batch is known and inside the window: its gathers go out under this batch's network
+            const bool want_next = prefetch_on && p + 32 < exec_len && p + 64 <= win0 + SIDX_WINDOW;
+            mlp_batch<CFG, 4, false>(in, ws, aux, lane, sigma, rgb_raw, rows, nullptr, slots, [&]() {
+                if constexpr (PREFETCH) {
+                    if (want_next) { lane = fresh_lane_id(); j = lane & 31; gather(p + 32, raw); }
+                }
+            });
+            have_next = want_next;
+        } else {
+            mlp_batch<CFG>(in, ws, aux, lane, sigma, rgb_raw, nullptr, pe_col);
+        }
 
         // ---- behind the network nothing of the above is alive: the lane finds its sample again
         lane = fresh_lane_id(); j = lane & 31;
@@ -1875,7 +1926,7 @@ __global__ __launch_bounds__(256) void instance_kernel(InstanceArgs a) {
             for (int c = 0; c < 3; ++c) col[c] = a.instance_color[3 * id + c];
         } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) col[c] = (a.flags & NTX_FLAG_MAP_EXR) ? elu1f_(raw[c]) : sigmoidf_(raw[c]);
+            for (int c = 0; c < 3; ++c) col[c] = (a.flags & NTX_FLAG_MAP_EXR) ? elu1f_(rgb_raw[c]) : sigmoidf_(rgb_raw[c]);
         }
         if (a.flags & NTX_FLAG_RAW_NOISE)                                                         // :335-337
             sigma += a.raw_noise_std * normal01(global_index(a.idx0, a.idx_run, a.idx_stride, ray2), idx2, a.seed_lo, a.seed_hi);
