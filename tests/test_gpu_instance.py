@@ -133,7 +133,7 @@ def _render_instanced_raw(model, bufs, hit, cone, S, precision="float32", blur=-
     d = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), device=dv).to(dt).contiguous()
     t_ = dict(rd=d(rays_d_map), pts=d(pts), t=d(tt), dists=d(dists), cl=d(color_last.reshape(n, 3)), al=d(alpha_last.reshape(n)),
               aw=d(alpha_weight), iid=d(instance_id, torch.int32), hit=d(hit, torch.uint8), pm=d(params_map), cone=d(cone))
-    col = torch.empty((n, 3), device=dv); alp = torch.empty((n,), device=dv)
+    col = torch.full((n, 3), float('nan'), device=dv); alp = torch.full((n,), float('nan'), device=dv)   # a ray nobody renders shows
     model.reserve(0, n)
     _lib.check(_lib.lib.ntx_render_instanced(
         model.ctx(0), t_["rd"].data_ptr(), t_["pts"].data_ptr(), t_["t"].data_ptr(), t_["dists"].data_ptr(), t_["cl"].data_ptr(),
@@ -325,7 +325,7 @@ def test_packed_tails_do_not_depend_on_the_company(precision):
         t_ = dict(rd=d(rays_d_map), pts=d(pts), t=d(tt), dists=d(dists), cl=d(color_last.reshape(n, 3)), al=d(alpha_last.reshape(n)),
                   aw=d(alpha_weight), iid=d(instance_id, torch.int32), hit=d(hit, torch.uint8), pm=d(params_map), cone=d(cone))
         k = len(order)
-        col = torch.empty((k, 3), device=dv); alp = torch.empty((k,), device=dv)
+        col = torch.full((k, 3), float('nan'), device=dv); alp = torch.full((k,), float('nan'), device=dv)   # a ray nobody renders shows
         _lib.check(_lib.lib.ntx_render_instanced(
             model.ctx(0), t_["rd"].data_ptr(), t_["pts"].data_ptr(), t_["t"].data_ptr(), t_["dists"].data_ptr(), t_["cl"].data_ptr(),
             t_["al"].data_ptr(), t_["aw"].data_ptr(), t_["iid"].data_ptr(), t_["hit"].data_ptr(), t_["pm"].data_ptr(), t_["cone"].data_ptr(),
@@ -381,7 +381,7 @@ def test_bundles_of_rays_give_the_single_ray_bits(monkeypatch):
         t_ = dict(rd=d(rays_d_map), pts=d(pts), t=d(tt), dists=d(dists), cl=d(color_last.reshape(n, 3)), al=d(alpha_last.reshape(n)),
                   aw=d(alpha_weight), iid=d(instance_id, torch.int32), hit=d(hit, torch.uint8), pm=d(params_map), cone=d(cone))
         k = len(order)
-        col = torch.empty((k, 3), device=dv); alp = torch.empty((k,), device=dv)
+        col = torch.full((k, 3), float('nan'), device=dv); alp = torch.full((k,), float('nan'), device=dv)   # a ray nobody renders shows
         _lib.check(_lib.lib.ntx_render_instanced(
             model.ctx(0), t_["rd"].data_ptr(), t_["pts"].data_ptr(), t_["t"].data_ptr(), t_["dists"].data_ptr(), t_["cl"].data_ptr(),
             t_["al"].data_ptr(), t_["aw"].data_ptr(), t_["iid"].data_ptr(), t_["hit"].data_ptr(), t_["pm"].data_ptr(), t_["cone"].data_ptr(),
@@ -411,3 +411,28 @@ def test_bundles_of_rays_give_the_single_ray_bits(monkeypatch):
                                          take(alpha_weight), take(instance_id), take(hit).astype(bool), take(params_map), take(cone)[:, None],
                                          None, 0.09, 400.0, True, False, False, (1., 1., 1.), None, dtype=np.float64)
     assert orc.rel_linf(base[sub], np.concatenate([rc, ra[:, None]], -1)) <= TOL
+
+
+@pytest.mark.parametrize("S", [8, 72])
+def test_chunked_hand_out_renders_every_ray_once(S, monkeypatch):
+    """inst_order_kernel cuts the cost order into chunks (single rays | pairs | fours | pairs | single rays; the ranks depend on the
+    ray count, the number of waves and the cost histogram) and instance_kernel maps claim c to a chunk in closed form: at ray
+    counts around every boundary of that table (1024 waves: 2 and 6 rays per wave, +-1, odd counts) every ray is written (the
+    outputs start as NaN), and the image is bit for bit what single-ray claims give."""
+    model, spec, w = make_model((1, 4), dense_media=True)
+    rng = np.random.default_rng(S)
+    n_max = 20001
+    inst = FakeInstancer(5, seed=S, p_hit=0.95, p_in=0.3)
+    params = rng.uniform(0.2, 1, size=(n_max, 5)).astype(np.float32)
+    bufs = inst.get_model_input(np.zeros((n_max, 3), np.float32), np.zeros((n_max, 3), np.float32), params, S, 0.002)
+    hit = np.zeros(n_max, np.uint8); hit[bufs[8][:, 0]] = 1
+    cone = rng.uniform(1e-3, 5e-3, size=n_max).astype(np.float32)
+    for n in (1, 2, 3, 5, 1023, 2047, 2048, 2049, 3073, 6143, 6144, 6147, 8190, 12289, 16383, 20001):
+        sub = [b[:n] for b in bufs]
+        monkeypatch.delenv("NERFTEX_DEBUG_RUNS", raising=False)
+        got = _render_instanced_raw(model, sub, hit[:n], cone[:n], S)
+        assert np.isfinite(got).all(), n
+        assert np.all(got[hit[:n] == 0] == 0.0)
+        monkeypatch.setenv("NERFTEX_DEBUG_RUNS", "9")
+        assert np.array_equal(_render_instanced_raw(model, sub, hit[:n], cone[:n], S), got), n
+    monkeypatch.delenv("NERFTEX_DEBUG_RUNS")
