@@ -413,21 +413,25 @@ def test_bundles_of_rays_give_the_single_ray_bits(monkeypatch):
     assert orc.rel_linf(base[sub], np.concatenate([rc, ra[:, None]], -1)) <= TOL
 
 
-@pytest.mark.parametrize("S", [8, 72])
-def test_chunked_hand_out_renders_every_ray_once(S, monkeypatch):
+@pytest.mark.parametrize("kind,npar,arch,S", [("ParamNerf", (1, 4), None, 8), ("ParamNerf", (1, 4), None, 72), ("Nerf", (0, 0), None, 40),
+                                              ("ParamNerf", (2, 5), None, 40), ("ParamNerf", (1, 2), dict(depth=3, width=64, skips=(1,)), 40)])
+def test_chunked_hand_out_renders_every_ray_once(kind, npar, arch, S, monkeypatch):
     """inst_order_kernel cuts the cost order into chunks (single rays | pairs | fours | pairs | single rays; the ranks depend on the
     ray count, the number of waves and the cost histogram) and instance_kernel maps claim c to a chunk in closed form: at ray
-    counts around every boundary of that table (1024 waves: 2 and 6 rays per wave, +-1, odd counts) every ray is written (the
-    outputs start as NaN), and the image is bit for bit what single-ray claims give."""
-    model, spec, w = make_model((1, 4), dense_media=True)
+    counts around every boundary of that table (1024 waves: 3 and 6 rays per wave, +-1, odd counts) every ray is written (the
+    outputs start as NaN), and the image is bit for bit what single-ray claims give.  A tuned family at two sample counts (tails
+    only / whole batches + tails), plain Nerf and the flex family (no run rows), the generic family."""
+    model, spec, w = make_model(npar, kind=kind, dense_media=True, arch=arch)
+    P = sum(npar)
     rng = np.random.default_rng(S)
     n_max = 20001
-    inst = FakeInstancer(5, seed=S, p_hit=0.95, p_in=0.3)
-    params = rng.uniform(0.2, 1, size=(n_max, 5)).astype(np.float32)
+    inst = FakeInstancer(P, seed=S, p_hit=0.95, p_in=0.3)
+    params = rng.uniform(0.2, 1, size=(n_max, P)).astype(np.float32)
     bufs = inst.get_model_input(np.zeros((n_max, 3), np.float32), np.zeros((n_max, 3), np.float32), params, S, 0.002)
     hit = np.zeros(n_max, np.uint8); hit[bufs[8][:, 0]] = 1
     cone = rng.uniform(1e-3, 5e-3, size=n_max).astype(np.float32)
-    for n in (1, 2, 3, 5, 1023, 2047, 2048, 2049, 3073, 6143, 6144, 6147, 8190, 12289, 16383, 20001):
+    counts = (1, 2, 3, 5, 1023, 2047, 2048, 2049, 3071, 3073, 6143, 6144, 6147, 8190, 12289, 16383, 20001)
+    for n in counts if (kind, npar, arch) == ("ParamNerf", (1, 4), None) else (3, 3073, 6147, 20001):
         sub = [b[:n] for b in bufs]
         monkeypatch.delenv("NERFTEX_DEBUG_RUNS", raising=False)
         got = _render_instanced_raw(model, sub, hit[:n], cone[:n], S)
