@@ -58,16 +58,18 @@ typedef enum ntx_pos_encoding { NTX_POS_FOURIER = 0, NTX_POS_IPE = 1 } ntx_pos_e
  * width 256, skips [4], color_depth 1.  Any OTHER architecture of model.py:58 / :9 with FourierFeatures embeddings -- depth 1..24,
  * width 2..256, color_depth 0..4, any skips below depth-1 -- runs on the "flex" family: the same MFMA segments in a loop over layers
  * (narrower layers zero-padded to 256), float32 only (NTX_FLAG_FP16X3: NTX_E_UNSUPPORTED), nothing hoisted per ray; param_depth 1..4
- * through the extended descriptor below (ntx_model_desc_ex).  10/4/4 frequency bands, no embedding_config.  Anything else: NTX_E_UNSUPPORTED. */
+ * through the extended descriptor below (ntx_model_desc_ex).  n_freq_bands (layer.py:11) up to 10 / 4 / 4 for position / direction /
+ * parameters, every family and precision: the kernels evaluate their 10 / 4 / 4 bands, the ones a model does not have meet zero weight
+ * rows (exact).  No embedding_config.  Anything else: NTX_E_UNSUPPORTED. */
 #define NTX_SKIP_MASK 0x40000000   /* ntx_model_desc.skip = NTX_SKIP_MASK | mask: several skip layers (bit i: i in skips) */
 typedef struct ntx_model_desc {
     int32_t kind;        /* ntx_model_kind */
     int32_t n_geo;       /* n_parameters[0]: parameters concatenated to the position embedding (model.py:88-93) */
     int32_t n_app;       /* n_parameters[1]: parameters concatenated to the direction embedding (model.py:96-101) */
     int32_t n_pos;       /* 3 */
-    int32_t pos_freq;    /* pos_embedding.n_freq_bands   (layer.py:11) */
-    int32_t dir_freq;    /* dir_embedding.n_freq_bands */
-    int32_t param_freq;  /* param_embedding.n_freq_bands */
+    int32_t pos_freq;    /* pos_embedding.n_freq_bands   (layer.py:11): 0..10 */
+    int32_t dir_freq;    /* dir_embedding.n_freq_bands: 0..4 */
+    int32_t param_freq;  /* param_embedding.n_freq_bands: 0..4 */
     int32_t depth;       /* 8; flex family: 1..24 */
     int32_t width;       /* 256; flex family: 2..256 */
     int32_t skip;        /* `skips`: the index of the single skip layer, 4 (model.py:107-108); -1 = none; or NTX_SKIP_MASK | (bit i set for

@@ -69,10 +69,35 @@ static_assert(NTX_SKIP_MASK == (unsigned)NTX_SKIP_MASK_BIT, "skip encoding of th
 // the model's own parameter counts (the generic family has more slots than the model has parameters)
 struct Dims {
     int g, a;
+    int pf, df, qf;   // n_freq_bands of the model's position / direction / parameter embeddings (layer.py:11)
 };
 static Dims dims_of(const ntx_model_desc *d) {
     const bool nerf = d->kind == NTX_MODEL_NERF;
-    return Dims{nerf ? 0 : d->n_geo, nerf ? 0 : d->n_app};
+    return Dims{nerf ? 0 : d->n_geo, nerf ? 0 : d->n_app, d->pos_freq, d->dir_freq, nerf || d->n_geo + d->n_app <= 0 ? PAR_FREQ : d->param_freq};
+}
+// FEWER frequency bands than the kernels' 10 / 4 / 4 (FourierFeatures(n_freq_bands), layer.py:8-23): the kernels evaluate all of
+// theirs, the packers give the bands the model does not have zero weight rows -- exact, like the parameters the generic family does
+// not have.  Widths of the model's own encodings, and the model's row for row r of a 10/4/4 model's map (-1: no such band).
+static int pos_emb_m(Dims m, int ipe) { return ipe ? 6 * m.pf : 3 * (1 + 2 * m.pf); }
+static int dir_emb_m(Dims m) { return 3 * (1 + 2 * m.df); }
+static int pos_map_m(Dims m, int ipe) { return pos_emb_m(m, ipe) + m.g * (1 + 2 * m.qf); }
+static int dir_map_m(Dims m) { return dir_emb_m(m) + m.a * (1 + 2 * m.qf); }
+static int par_row_m(int idx, int n_act, int qf) {        // idx into [p (n_act) | sin f0, cos f0 (n_act each) | ...] of 4 bands
+    if (idx < n_act) return idx;
+    return (idx - n_act) / (2 * n_act) < qf ? idx : -1;
+}
+static int pos_row_m(int r, Dims m, int ipe) {
+    if (r < 0) return r;
+    const int full = pos_emb_dim(ipe);
+    if (r >= full) { const int q = par_row_m(r - full, m.g, m.qf); return q < 0 ? -1 : pos_emb_m(m, ipe) + q; }
+    if (ipe) { const int h = r / (3 * POS_FREQ), q = r % (3 * POS_FREQ); return q / 3 < m.pf ? h * 3 * m.pf + q : -1; }
+    return r < 3 || (r - 3) / 6 < m.pf ? r : -1;
+}
+static int dir_row_m(int r, Dims m) {
+    if (r < 0) return r;
+    const int full = 3 * (1 + 2 * DIR_FREQ);
+    if (r >= full) { const int q = par_row_m(r - full, m.a, m.qf); return q < 0 ? -1 : dir_emb_m(m) + q; }
+    return r < 3 || (r - 3) / 6 < m.df ? r : -1;
 }
 
 // the model's `skips` as a mask of layer indices: ntx_model_desc.skip is one index (-1: none) or NTX_SKIP_MASK | mask
@@ -105,12 +130,12 @@ static int find_variant(const ntx_model_desc *d) {
     if (!d) return -1;
     const int ipe = d->pos_encoding == NTX_POS_IPE;
     if (d->pos_encoding != NTX_POS_FOURIER && d->pos_encoding != NTX_POS_IPE) return -1;
-    if (d->n_pos != (ipe ? 6 : 3) || d->pos_freq != POS_FREQ || d->dir_freq != DIR_FREQ) return -1;
+    if (d->n_pos != (ipe ? 6 : 3) || d->pos_freq < 0 || d->pos_freq > POS_FREQ || d->dir_freq < 0 || d->dir_freq > DIR_FREQ) return -1;
     if (d->kind != NTX_MODEL_PARAMNERF && d->kind != NTX_MODEL_NERF && d->kind != NTX_MODEL_PARAMNERF_EX) return -1;
     const bool nerf = d->kind == NTX_MODEL_NERF;
     const int g = nerf ? 0 : d->n_geo, a = nerf ? 0 : d->n_app, cd = nerf ? 0 : d->color_depth;
     if (g < 0 || a < 0) return -1;
-    if (!nerf && (g + a > 0) && d->param_freq != PAR_FREQ) return -1;
+    if (!nerf && (g + a > 0) && (d->param_freq < 0 || d->param_freq > PAR_FREQ)) return -1;
     const bool force_flex = getenv("NERFTEX_FORCE_FLEX") != nullptr;         // A/B knobs for tests: a tuned family's model on the
     const bool force_generic = getenv("NERFTEX_FORCE_GENERIC") != nullptr;   // flex / generic kernels
     if (default_arch(d) && !(force_flex && !ipe)) {
@@ -141,7 +166,7 @@ static int unsupported(const ntx_model_desc *d) {
                 "skip=%d color_depth=%d pos_encoding=%d param_depth=%d param_width=%d (built: ParamNerf with n_parameters [g<=4, a<=8] -- tuned kernels for [1,6] [1,4] "
                 "[2,3] at 8x256 / skips [4] / color_depth 1 --, Nerf, and ParamNerf [1,3] with IntegratedPositionalEncoding on 6-D positions; "
                 "other architectures (FourierFeatures only): depth 1..24, width 2..256, color_depth 0..4, skips below depth-1, "
-                "param_depth 0..4 with param_width 2..128; 10/4/4 bands)",
+                "param_depth 0..4 with param_width 2..128; n_freq_bands <= 10 / 4 / 4)",
                 d->kind, d->n_geo, d->n_app, d->n_pos, d->pos_freq, d->dir_freq, d->param_freq, d->depth,
                 d->width, d->skip, d->color_depth, d->pos_encoding,
                 d->kind == NTX_MODEL_PARAMNERF_EX ? reinterpret_cast<const ntx_model_desc_ex *>(d)->param_depth : 0, param_width_of(d));
@@ -163,7 +188,7 @@ struct Net {
 
 static Net view_blob(const Variant &v, Dims m, const float *blob) {
     Net n{};
-    const int pm = pos_map_dim(m.g, v.ipe), dm = dir_map_dim(m.a);
+    const int pm = pos_map_m(m, v.ipe), dm = dir_map_m(m);
     size_t p = 0;
     auto take = [&](int in, int out) {
         Layer l{blob ? blob + p : nullptr, blob ? blob + p + (size_t)in * out : nullptr, in, out};
@@ -209,10 +234,10 @@ static void emit_segment(float *&dst, const Layer &l, int nsteps, int nmt, int r
 static void pack(const Variant &v, Dims m, const float *blob, float *out) {
     const Geometry g = make_geometry(v.n_geo, v.n_app, v.cd, v.ipe);
     const Net n = view_blob(v, m, blob);
-    const int pm = pos_map_dim(m.g, v.ipe), dm = dir_map_dim(m.a);
+    const int pm = pos_map_m(m, v.ipe), dm = dir_map_m(m);
     float *dst = out;
-    auto posrow = [&](int s, int h) { return pos_row(v.n_geo, s, h, v.ipe, m.g); };
-    auto dirrow = [&](int s, int h) { return dir_row(v.n_app, s, h, m.a); };
+    auto posrow = [&](int s, int h) { return pos_row_m(pos_row(v.n_geo, s, h, v.ipe, m.g), m, v.ipe); };
+    auto dirrow = [&](int s, int h) { return dir_row_m(dir_row(v.n_app, s, h, m.a), m); };
     auto hidrow = [&](int s, int h) { return hidden_row(s, h); };
 
     emit_segment(dst, n.trunk[0], g.pos_steps, 8, 0, posrow);
@@ -275,9 +300,9 @@ struct FlexNet {
 static FlexNet view_blob_flex(const FlexArch &f, Dims m, const float *blob) {
     FlexNet n{};
     const int pd = f.param_depth, pw = f.param_width, w = f.width;
-    const int ffdim_g = m.g * (1 + 2 * PAR_FREQ), ffdim_a = m.a * (1 + 2 * PAR_FREQ);
-    n.pos_map = pos_emb_dim(0) + (m.g > 0 ? (pd > 0 ? pw : ffdim_g) : 0);
-    n.dir_map = 3 * (1 + 2 * DIR_FREQ) + (m.a > 0 ? (pd > 0 ? pw : ffdim_a) : 0);
+    const int ffdim_g = m.g * (1 + 2 * m.qf), ffdim_a = m.a * (1 + 2 * m.qf);
+    n.pos_map = pos_emb_m(m, 0) + (m.g > 0 ? (pd > 0 ? pw : ffdim_g) : 0);
+    n.dir_map = dir_emb_m(m) + (m.a > 0 ? (pd > 0 ? pw : ffdim_a) : 0);
     struct Slot { Layer *l; int in, out, depth; };
     std::vector<Slot> seq;
     n.trunk.resize(f.depth); n.colour.resize(f.color_depth);
@@ -328,19 +353,20 @@ static size_t packed_floats_flex(const FlexArch &f) {
 static void pack_flex(const FlexArch &f, Dims m, const float *blob, float *out) {
     const FlexNet n = view_blob_flex(f, m, blob);
     const bool pb = f.param_depth > 0;
-    const int pe = pos_emb_dim(0), de = 3 * (1 + 2 * DIR_FREQ);              // FF(pos), FF(dir)
+    const int pe = pos_emb_m(m, 0), de = dir_emb_m(m);                       // FF(pos), FF(dir) as the model has them
     const int pm = n.pos_map, dm = n.dir_map;
     // without branches: the position / direction segments of the generic family (parameter features in them); with: FF(pos) /
     // FF(dir) alone, each followed by 64 k-steps over its branch's output
     const int ps = pb ? pos_steps(0) : pos_steps(GEN_NGEO), ds = pb ? dir_steps(0) : dir_steps(GEN_NAPP);
     float *dst = out;
-    auto posrow = [&](int s, int h) { return pb ? pos_row(0, s, h) : pos_row(GEN_NGEO, s, h, 0, m.g); };
-    auto dirrow = [&](int s, int h) { return pb ? dir_row(0, s, h) : dir_row(GEN_NAPP, s, h, m.a); };
+    const Dims m0{0, 0, m.pf, m.df, m.qf};                                      // with branches the segments hold FF(pos) / FF(dir) alone
+    auto posrow = [&](int s, int h) { return pb ? pos_row_m(pos_row(0, s, h), m0, 0) : pos_row_m(pos_row(GEN_NGEO, s, h, 0, m.g), m, 0); };
+    auto dirrow = [&](int s, int h) { return pb ? dir_row_m(dir_row(0, s, h), m0) : dir_row_m(dir_row(GEN_NAPP, s, h, m.a), m); };
     auto hidrow = [&](int s, int h) { return hidden_row(s, h); };
     const int W = f.width, PW = f.param_width;
     auto branch = [&](const std::vector<Layer> &ls, int n_slots, int n_act) {   // a branch's own layers, 4 tiles
         if (ls.empty()) return;
-        emit_segment_flex(dst, ls[0], parff_steps(n_slots), 4, 0, ls[0].in, [&](int s, int h) { return parff_row(n_slots, s, h, n_act); });
+        emit_segment_flex(dst, ls[0], parff_steps(n_slots), 4, 0, ls[0].in, [&](int s, int h) { const int r = parff_row(n_slots, s, h, n_act); return r < 0 ? r : par_row_m(r, n_act, m.qf); });
         for (size_t i = 1; i < ls.size(); ++i) emit_segment_flex(dst, ls[i], BRANCH_K, 4, 0, PW, hidrow);
     };
     auto pos_input = [&](const Layer &l) {                                      // concat[FF(pos) (+ parameter features) | G]
@@ -474,11 +500,11 @@ static size_t packed16_bytes(const Variant &v, int with_dir = 0) {
 // with_dir: the instanced kernel's stream, where C1 keeps its direction segment (directions are per sample there)
 static void pack16(const Variant &v, Dims m, const float *blob, uint16_t *out, int with_dir = 0) {
     const Net n = view_blob(v, m, blob);
-    const int pm = pos_map_dim(m.g, v.ipe), dm = dir_map_dim(m.a);
+    const int pm = pos_map_m(m, v.ipe), dm = dir_map_m(m);
     const int ps = steps16(pos_steps(v.n_geo, v.ipe)), ds = steps16(dir_steps(v.n_app)), hs = HSTEPS / 8;
     uint16_t *dst = out;
-    auto posrow = [&](int s, int h) { return s < pos_steps(v.n_geo, v.ipe) ? pos_row(v.n_geo, s, h, v.ipe, m.g) : -1; };
-    auto dirrow = [&](int s, int h) { return s < dir_steps(v.n_app) ? dir_row(v.n_app, s, h, m.a) : -1; };
+    auto posrow = [&](int s, int h) { return s < pos_steps(v.n_geo, v.ipe) ? pos_row_m(pos_row(v.n_geo, s, h, v.ipe, m.g), m, v.ipe) : -1; };
+    auto dirrow = [&](int s, int h) { return s < dir_steps(v.n_app) ? dir_row_m(dir_row(v.n_app, s, h, m.a), m) : -1; };
     auto hidrow = [&](int s, int h) { return hidden_row(s, h); };
     emit_segment16(dst, n.trunk[0], ps, 8, 0, posrow);
     for (int i = 1; i < DEPTH; ++i) {

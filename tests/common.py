@@ -11,10 +11,26 @@ EMB = lambda n: {"module": "network.model.FourierFeatures", "n_freq_bands": n}  
 TOL = 1e-4   # BASELINE.json north_star: <= 1e-4 relative L-inf (float32) vs the reference render
 
 
-def make_model(n_parameters=(1, 6), kind="ParamNerf", seed=0, dense_media=False, arch=None):
+def make_model(n_parameters=(1, 6), kind="ParamNerf", seed=0, dense_media=False, arch=None, freqs=None):
     """(product model with synthetic weights, oracle spec, oracle weight list).  `arch`: depth / width / skips / color_depth other
-    than the reference configs' 8 / 256 / [4] / 1 (model.py:58, :9)."""
-    if arch:
+    than the reference configs' 8 / 256 / [4] / 1 (model.py:58, :9); `freqs`: n_freq_bands of the position / direction / parameter
+    embeddings other than the configs' 10 / 4 / 4 (layer.py:11)."""
+    if freqs:
+        pf, df, qf = freqs
+        a = dict(arch or {})
+        spec_kw = dict(depth=a.get("depth", 8), width=a.get("width", 256), skips=tuple(a.get("skips", (4,))), pos_freq=pf, dir_freq=df)
+        if kind == "Nerf":
+            model = Nerf(EMB(pf), EMB(df), depth=spec_kw["depth"], width=spec_kw["width"], skips=list(spec_kw["skips"]))["model"]
+            spec = orc.ModelSpec(kind="Nerf", n_parameters=(0, 0), **spec_kw)
+        else:
+            ipe = kind == "IPE"
+            pos = {"module": "network.layer.IntegratedPositionalEncoding", "n_freq_bands": pf} if ipe else EMB(pf)
+            pk = dict(param_depth=a.get("param_depth", 0), param_width=a.get("param_width", 128))
+            model = ParamNerf(pos, EMB(df), EMB(qf), list(n_parameters), n_pos=6 if ipe else 3, depth=spec_kw["depth"], width=spec_kw["width"],
+                              skips=list(spec_kw["skips"]), color_depth=a.get("color_depth", 1), **pk)["model"]
+            spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(n_parameters), color_depth=a.get("color_depth", 1), param_freq=qf,
+                                 **(dict(n_pos=6, pos_encoding="ipe") if ipe else {}), **spec_kw, **pk)
+    elif arch:
         a = dict(arch)
         spec_kw = dict(depth=a.get("depth", 8), width=a.get("width", 256), skips=tuple(a.get("skips", (4,))))
         if kind == "Nerf":

@@ -250,3 +250,60 @@ def test_what_the_flex_family_refuses():
     with pytest.raises(_lib.NtxError) as e:
         r(*to_dev(ro[None], rd[None], t[None]), parameters=params, cone_scale=to_dev(cone[None])[0])
     assert e.value.code == _lib.NTX_E_UNSUPPORTED and "fp16x3" in str(e.value)
+
+
+FREQS = [   # (kind, n_parameters, (pos, dir, param) n_freq_bands, arch)
+    ("ParamNerf", (1, 6), (6, 2, 3), None),                                   # tuned carpet kernels
+    ("ParamNerf", (2, 3), (10, 4, 1), None),                                  # only the parameter embedding differs
+    ("ParamNerf", (1, 4), (0, 0, 0), None),                                   # identity features only
+    ("ParamNerf", (3, 2), (7, 1, 2), None),                                   # generic family
+    ("Nerf", (0, 0), (5, 3, 0), None),
+    ("IPE", (1, 3), (6, 4, 2), None),                                         # mip: [sin | cos] halves of 3 * 6 features each
+    ("ParamNerf", (1, 6), (4, 3, 2), dict(depth=5, width=128, skips=[2], color_depth=2)),                                # flex
+    ("ParamNerf", (2, 2), (9, 2, 3), dict(depth=4, width=256, skips=[1], color_depth=1, param_depth=2, param_width=64)),  # flex with branches
+]
+
+
+@pytest.mark.parametrize("kind,npar,freqs,arch", FREQS)
+@pytest.mark.parametrize("precision", ["float32", "fp16x3"])
+def test_mlp_forward_with_fewer_frequency_bands(kind, npar, freqs, arch, precision):
+    """`n_freq_bands` is a kwarg of the reference's embeddings (layer.py:11, :27); every config uses 10 / 4 / 4.  Models with FEWER
+    bands run on the same kernels -- which evaluate all of their bands -- with zero weight rows for the bands the model does not
+    have (host packers only): exact, so the same gate against the oracle of the model's own dimensions, every family, both precisions."""
+    if precision == "fp16x3" and arch:
+        pytest.skip("the flex family is float32 only")
+    model, spec, w = make_model(npar, kind, arch=arch, freqs=freqs)
+    assert model.layer_table() == orc.layer_table(spec)
+    model.precision = precision
+    m = 1000
+    pos, dirs, params = random_samples(m, sum(npar))
+    if kind == "IPE":
+        pos = np.concatenate([pos, np.random.default_rng(4).uniform(0, 2e-3, size=(m, 3)).astype(np.float32)], -1)   # (mean, diagonal covariance)
+    color, alpha = model(tuple(to_dev(pos, dirs, params)))
+    rc, ra = orc.model_forward(w, spec, pos, dirs, params, np.float64)
+    err = orc.rel_linf(np.concatenate([color.cpu().numpy(), alpha.cpu().numpy()], -1), np.concatenate([rc, ra], -1))
+    assert err <= (3e-5 if precision == "float32" else TOL), err
+
+
+@pytest.mark.parametrize("kind,npar,freqs,arch,blur", [("ParamNerf", (1, 6), (6, 2, 3), None, None), ("ParamNerf", (2, 3), (8, 3, 2), None, 0),
+                                                        ("ParamNerf", (1, 6), (4, 3, 2), dict(depth=5, width=128, skips=[2], color_depth=2), 3)])
+def test_render_rays_with_fewer_frequency_bands(kind, npar, freqs, arch, blur):
+    """Renderer.__call__ on such a model: the hoisted per-ray rows (dir_block: direction segment, geometry blocks) come from the same
+    zero-padded stream."""
+    from nerf_tex_amd.renderer import Renderer
+    model, spec, w = make_model(npar, kind, dense_media=True, arch=arch, freqs=freqs)
+    (ro, rd, t, cone), _, _ = camera_rays("carpet", 14, 12)
+    cone = (cone * 30).astype(np.float32)
+    P = sum(npar)
+    params = np.random.default_rng(P + 5).uniform(0.1, 1.0, size=(1, P)).astype(np.float32)
+    S = 48
+    r = Renderer(model=model, n_samples=S, perturb=False, blur_idx=blur)
+    out = r(*to_dev(ro[None], rd[None], t[None]), parameters=to_dev(params)[0], cone_scale=to_dev(cone[None])[0])
+    r.raise_if_nonfinite()
+    got = rgba_of(out)
+    ref = {}
+    for name, dt in (("f64", np.float64), ("f32", np.float32)):
+        o = orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], S, False, (1., 1., 1.), blur, False, dtype=dt)
+        ref[name] = np.concatenate([o["color_pred"][0], o["alpha_pred"][0][:, None]], -1).astype(np.float64)
+    assert orc.rel_linf(got, ref["f32"]) <= TOL
+    assert orc.rel_linf(got, ref["f64"]) <= TOL + orc.rel_linf(ref["f32"], ref["f64"])

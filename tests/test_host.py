@@ -38,7 +38,8 @@ def test_create_without_gpu_reports_no_device():
 def test_unsupported_desc_is_rejected_on_host():
     from nerf_tex_amd import _lib
     for bad in (_lib.ModelDesc(0, 5, 3, 3, 10, 4, 4, 8, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 9, 3, 10, 4, 4, 8, 256, 4, 1, 0),
-                _lib.ModelDesc(0, 1, 6, 3, 8, 4, 4, 8, 256, 4, 1, 0),
+                _lib.ModelDesc(0, 1, 6, 3, 11, 4, 4, 8, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 6, 3, 10, 5, 4, 8, 256, 4, 1, 0),   # MORE bands than the kernels evaluate
+                _lib.ModelDesc(0, 1, 6, 3, 10, 4, 5, 8, 256, 4, 1, 0), _lib.ModelDesc(0, 1, 6, 3, -1, 4, 4, 8, 256, 4, 1, 0),
                 _lib.ModelDesc(0, 1, 3, 3, 10, 4, 4, 8, 256, 4, 1, 1), _lib.ModelDesc(0, 1, 6, 6, 10, 4, 4, 8, 256, 4, 1, 1),
                 # architectures outside the flex family's loop: too deep, too wide, too many colour layers, a skip behind the last
                 # trunk layer (it widens the alpha head and the feature layer, model.py:107-114), an IPE model off the 8x256 shape
@@ -98,6 +99,55 @@ def test_pack_weights_flex_family_is_a_permutation(kind, npar, depth, width, ski
             + g * (24 + (pd - 1) * 64) + a * (40 + (pd - 1) * 64)
     assert body.size == want_rec * 256
     assert _lib.lib.ntx_packed_fp16x3_bytes(C.byref(d)) == 0 and b"fp16x3" in _lib.lib.ntx_last_error()
+
+
+@pytest.mark.parametrize("kind,npar,freqs,arch,ipe", [
+    (0, (1, 6), (6, 2, 3), None, 0), (0, (1, 4), (10, 4, 1), None, 0), (0, (2, 3), (0, 0, 0), None, 0), (1, (0, 0), (5, 3, 0), None, 0),
+    (0, (3, 2), (7, 1, 2), None, 0), (0, (1, 3), (6, 4, 2), None, 1),
+    (0, (1, 6), (4, 3, 2), dict(depth=5, width=128, skips=(2,), color_depth=2), 0),
+    (0, (2, 2), (9, 2, 3), dict(depth=4, width=256, skips=(1,), color_depth=1, param_depth=2, param_width=64), 0)])
+def test_pack_weights_with_fewer_frequency_bands(kind, npar, freqs, arch, ipe):
+    """FourierFeatures / IntegratedPositionalEncoding with FEWER bands than the kernels' 10 / 4 / 4 (layer.py:11: n_freq_bands is a
+    kwarg of the embedding): the kernels evaluate all of their bands, the packers give the ones the model does not have zero rows.
+    The weight count is the model's own layer table, every weight lands in the packed image exactly once, in every family (tuned,
+    generic, plain Nerf, IPE, flex with and without parameter branches) and in the fp16x3 stream; more bands are refused."""
+    from nerf_tex_amd import _lib
+    from nerf_tex_amd.model import NerfModel
+    a = dict(arch or {})
+    m = NerfModel(kind, npar, 6 if ipe else 3, freqs[0], freqs[1], freqs[2] if kind == 0 else 0, a.get("depth", 8), a.get("width", 256),
+                  a.get("skips", (4,)), a.get("color_depth", 1 if kind == 0 else 0), "model", "ipe" if ipe else "fourier",
+                  param_depth=a.get("param_depth", 0), param_width=a.get("param_width", 128))
+    d = m.desc()
+    n = _lib.lib.ntx_weight_count(C.byref(d))
+    assert n == m.n_weight_floats() > 0, _lib.lib.ntx_last_error()
+    npk = _lib.lib.ntx_packed_count(C.byref(d))
+    blob = (np.random.default_rng(1).permutation(n) + 1).astype(np.float32)
+    out = np.empty(npk, np.float32)
+    fp = C.POINTER(C.c_float)
+    assert _lib.lib.ntx_pack_weights(C.byref(d), blob.ctypes.data_as(fp), n, out.ctypes.data_as(fp), npk) == 0
+    tail = 8 * 256
+    aux_floats = 3776 + (64 + 40 * 256 if arch else 0)
+    stream, aux = out[:npk - aux_floats], out[npk - aux_floats:]
+    np.testing.assert_array_equal(stream[:tail], stream[-tail:])
+    body = stream[:-tail]
+    rest = np.concatenate([aux[:3776], aux[3776 + 64:]]) if arch else aux
+    vals = np.concatenate([body[body != 0], rest[rest != 0]])
+    assert vals.size == n and np.array_equal(np.sort(vals), np.sort(blob))
+    if not arch:   # the fp16x3 stream: the same matrix weights (all but C1's direction rows, which dir_block applies in float32), hi halves
+        nb = _lib.lib.ntx_packed_fp16x3_bytes(C.byref(d))
+        small = (np.random.default_rng(2).permutation(n) % 2047 + 1).astype(np.float32)        # exactly representable halves: lo = 0
+        out16 = np.empty(nb // 2, np.uint16)
+        assert _lib.lib.ntx_pack_weights_fp16x3(C.byref(d), small.ctypes.data_as(fp), n, out16.ctypes.data_as(C.POINTER(C.c_uint16)), nb) == 0
+        hi = out16.reshape(-1, 2, 512)[:, 0].view(np.float16).astype(np.float32).ravel()
+        assert not out16.reshape(-1, 2, 512)[:, 1].any()
+        f32pk = np.empty(npk, np.float32)
+        assert _lib.lib.ntx_pack_weights(C.byref(d), small.ctypes.data_as(fp), n, f32pk.ctypes.data_as(fp), npk) == 0
+        w32 = f32pk[:npk - 3776 - tail]
+        dir_rows = (m.dir_map_dim * 256) if kind == 0 else 0
+        assert np.count_nonzero(hi) == np.count_nonzero(w32) - dir_rows
+        assert np.isin(hi[hi != 0], w32[w32 != 0]).all()
+    more = NerfModel(kind, npar, 6 if ipe else 3, 11, 4, 4 if kind == 0 else 0, 8, 256, (4,), 1 if kind == 0 else 0, "model", "ipe" if ipe else "fourier").desc()
+    assert _lib.lib.ntx_weight_count(C.byref(more)) == 0 and b"unsupported" in _lib.lib.ntx_last_error()
 
 
 @pytest.mark.parametrize("desc,count", [((0, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, 0), 683524), ((0, 1, 4, 3, 10, 4, 4, 8, 256, 4, 1, 0), 678916),
