@@ -12,8 +12,9 @@
  *   - every `float*` marked DEVICE is a caller-owned device pointer (row-major float32, last
  *     dimension fastest, exactly the layouts of the reference tensors); HOST pointers are read
  *     synchronously during the call;
- *   - the library owns only what `ntx_create` / `ntx_reserve` / `ntx_comm_create` allocate (the packed weight
- *     image, the hit-list scratch, the communicator); no other entry point allocates or frees device memory;
+ *   - the library owns only what `ntx_create` / `ntx_reserve` / `ntx_comm_create` / `ntx_instancer_create` /
+ *     `ntx_instancer_reserve` / `ntx_instancer_set_mesh` allocate (the packed weight image, the hit-list scratch, the communicator,
+ *     the instance matrices and the instancer's hit lists); no other entry point allocates or frees device memory;
  *   - every entry point is asynchronous on `stream` (a `hipStream_t` passed as `void*`; NULL = the
  *     null stream) and returns an `ntx_status` (0 = ok, negative = error).  The message of the
  *     last error on the calling thread is returned by `ntx_last_error()`;
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NTX_ABI_VERSION 3
+#define NTX_ABI_VERSION 4
 
 typedef struct ntx_ctx ntx_ctx;
 typedef void *ntx_stream; /* hipStream_t */
@@ -339,6 +340,63 @@ int ntx_pack_weights(const ntx_model_desc *desc, const float *weights_host, size
 size_t ntx_packed_fp16x3_bytes(const ntx_model_desc *desc);
 int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_host, size_t n_floats,
                             uint16_t *packed_out, size_t n_bytes);
+
+/* ---- ABI v4: the patch instancer (what feeds ntx_render_instanced) ---------------------------------------------------------
+ * Replaces instancer.instancer.Instancer (instancer/instancer.pyx:6-54) = C_Instancer (instancer/src/instancer.hpp:10-89), the
+ * reference's only native code: Embree 3 on one CPU thread.  Built here: the constructor with explicit `transformations`
+ * (instancer.pyx:19-20 -> AddInstance, instancer.cpp:124-141), an instancer mesh given as arrays, GetNumberOfInstances (:426-428),
+ * the matrices ExportTransformations writes (:1040-1061) and GetModelInput (:751-1037) with the three patch choices, mean
+ * distances, directional and point lights.  NOT built (NTX_E_UNSUPPORTED / no entry point): shadow rays (:591-602), image
+ * textures on the instancer mesh (:640-667), auxiliary meshes with their shading (:393-417, 716-743) and
+ * DistributeInstancesOnMesh (:233-390: libigl curvature directions on LFS meshes; the reference can export what it computes
+ * there with `transformation_export_path`, and that list is what ntx_instancer_create takes).
+ *
+ * ntx_instancer_desc = the constructor arguments that survive (instancer.cpp:53-93): b_0 / b_1 the patch box in patch
+ * coordinates; n_parameters, light_dir_parameter_idx, light_strength_parameter_idx as the `textures` list defines them
+ * ("" = 1 parameter, "light" = 3 with light_dir at their start, "point" = 4: strength, then position = light_dir + 1;
+ * -1 = none); instance_sample_method 0 random / 1 nearest / 2 nearest_blend (instancer.pyx:14); patch_scale only scales
+ * nearest_blend's transition range (:697; 1 unless the patches were distributed on a mesh). */
+typedef struct ntx_instancer ntx_instancer;
+typedef struct ntx_instancer_desc {
+    uint32_t size;                       /* sizeof(ntx_instancer_desc) */
+    float b_0[3], b_1[3];
+    int32_t n_parameters, light_dir_parameter_idx, light_strength_parameter_idx;
+    int32_t instance_sample_method, use_mean_distance, cast_shadow_rays;
+    float patch_scale;
+} ntx_instancer_desc;
+#define NTX_INSTANCER_DEFAULT_MAX_RAYS (1 << 16)
+/* transformations: HOST [n_instances,4,4] row-major patch -> world, what AddInstance takes.  The instancer keeps, per instance,
+ * the inverse (world -> patch), the direction map (columns of the 3x3 block, normalised) and the origin (instancer.cpp:127-132;
+ * computed in double and rounded), plus hit-list workspace for NTX_INSTANCER_DEFAULT_MAX_RAYS rays (1.6 KB per ray). */
+int ntx_instancer_create(const ntx_instancer_desc *desc, const float *transformations, int64_t n_instances, int device,
+                         ntx_instancer **out);
+int ntx_instancer_destroy(ntx_instancer *inst);
+/* Workspace for calls of up to max_rays rays in one piece (<= 2^24); larger calls are cut into pieces of the reserved size. */
+int ntx_instancer_reserve(ntx_instancer *inst, int64_t max_rays);
+int64_t ntx_instancer_count(const ntx_instancer *inst);                       /* GetNumberOfInstances; -1 on NULL */
+/* HOST outputs, each may be NULL: world_to_patch[K,4,4] (this->transformations; its inverses are what ExportTransformations
+ * writes), directions[K,3,3] (dir_transformations), origins[K,3] (instance_origins). */
+int ntx_instancer_matrices(const ntx_instancer *inst, float *world_to_patch, float *directions, float *origins);
+/* The instancer mesh (instancer.cpp:369-389: in the scene for culling): HOST vertices[n_vertices,3], faces[n_faces,3].  A ray
+ * ends at its closest crossing of the mesh and is closed by an opaque black sample (:1013-1016).  n_faces = 0 removes it. */
+int ntx_instancer_set_mesh(ntx_instancer *inst, const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces);
+/* GetModelInput (instancer.cpp:751-1037) with the buffers of get_model_input (instancer.pyx:38-54), all DEVICE, every element of
+ * every output written: rays_o[N,3], rays_d[N,3] (per ray; the reference's [N,S,3] input is this row repeated), parameters[N,P] ->
+ * rays_d_map[N,S,3], pts[N,S,3], t[N,S], dists[N,S], color_last[N,3], alpha_last[N], alpha_weight[N,S] (density_weight),
+ * instance_id[N,S], hit[N] uint8, params_map[N,S,P]: the argument list of ntx_render_instanced.  Per ray: face crossings of every
+ * instanced box with 0 < t <= 100 (at most 200 kept, instancer.cpp:22), sorted by (t, instance); the union of the boxes is
+ * marched in steps of step_size from a random offset; a sample takes the patch it lies in (several: by
+ * instance_sample_method) and is mapped into it (point, direction, light direction / strength); samples behind the last
+ * step keep the defaults of instancer.pyx:41-50.  The reference draws from one std::mt19937 in ray order (:855, 675, 710);
+ * here the offset of a ray is U[0,1) from word 0 of Philox4x32-10 at counter (0, ray lo, ray hi, 2) under `seed`, the patch
+ * choice of (ray, step) from counter (step, ray lo, ray hi, 3); `opts` carries the ray index map (as for ntx_render_rays;
+ * NULL = the call's own indices), so chunked or sharded calls draw what the whole image draws.
+ * *status_flag (DEVICE, may be NULL) |= 1 when a ray had more than 200 face crossings (the rest were dropped, which ones is
+ * unspecified -- as in the reference), |= 2 when a point lay in more than 64 patches at once.  1 <= n_pts <= 4096. */
+int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const float *rays_d, const float *parameters, int64_t n_rays,
+                              int n_pts, float step_size, uint64_t seed, const ntx_render_opts *opts, float *rays_d_map, float *pts,
+                              float *t, float *dists, float *color_last, float *alpha_last, float *alpha_weight,
+                              int32_t *instance_id, uint8_t *hit, float *params_map, int32_t *status_flag, ntx_stream stream);
 
 #ifdef __cplusplus
 }

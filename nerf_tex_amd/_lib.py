@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("NERFTEX_LIB") or os.path.join(_HERE, "libnerftex_hip.
 
 NTX_OK, NTX_E_INVALID, NTX_E_UNSUPPORTED, NTX_E_HIP, NTX_E_NODEVICE = 0, -1, -2, -3, -4
 FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS, FLAG_FP16X3, FLAG_PERTURB, FLAG_RAW_NOISE = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 3
+ABI_VERSION = 4
 KIND_PARAMNERF_EX = 2           # NTX_MODEL_PARAMNERF_EX: the descriptor's param_depth / param_width count
 SKIP_MASK = 0x40000000          # NTX_SKIP_MASK: ntx_model_desc.skip carries a mask of skip-layer indices
 COMM_ID_BYTES = 128
@@ -42,6 +42,14 @@ def render_opts(raw_noise_std: float = 0.0, noise_seed: int = 0, ray_index=None)
     ray k0 of a larger call: (k0, n, n)), or None = the index within the call."""
     i0, run, stride = (0, 0, 0) if ray_index is None else (int(v) for v in ray_index)
     return RenderOpts(C.sizeof(RenderOpts), float(raw_noise_std), int(noise_seed) & (2 ** 64 - 1), i0, run, stride)
+
+
+class InstancerDesc(C.Structure):
+    """struct ntx_instancer_desc (ABI v4): what the constructor of the reference's instancer keeps (instancer.cpp:53-93)"""
+    _fields_ = [("size", C.c_uint32), ("b_0", C.c_float * 3), ("b_1", C.c_float * 3), ("n_parameters", C.c_int32),
+                ("light_dir_parameter_idx", C.c_int32), ("light_strength_parameter_idx", C.c_int32),
+                ("instance_sample_method", C.c_int32), ("use_mean_distance", C.c_int32), ("cast_shadow_rays", C.c_int32),
+                ("patch_scale", C.c_float)]
 
 
 class NtxError(RuntimeError):
@@ -98,6 +106,13 @@ SYMBOLS = {
     "ntx_pack_weights": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, _fp, C.c_size_t]),
     "ntx_packed_fp16x3_bytes": (C.c_size_t, [C.POINTER(ModelDesc)]),
     "ntx_pack_weights_fp16x3": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, C.POINTER(C.c_uint16), C.c_size_t]),
+    "ntx_instancer_create": (C.c_int, [C.POINTER(InstancerDesc), _fp, C.c_int64, C.c_int, C.POINTER(_vp)]),
+    "ntx_instancer_destroy": (C.c_int, [_vp]),
+    "ntx_instancer_reserve": (C.c_int, [_vp, C.c_int64]),
+    "ntx_instancer_count": (C.c_int64, [_vp]),
+    "ntx_instancer_matrices": (C.c_int, [_vp, _fp, _fp, _fp]),
+    "ntx_instancer_set_mesh": (C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_int32), C.c_int64]),
+    "ntx_instancer_model_input": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_uint64, _op] + [_vp] * 12),
 }
 
 

@@ -1,0 +1,234 @@
+"""The patch instancer on the GPU (reference: instancer/instancer.pyx `Instancer` over instancer/src/instancer.cpp `C_Instancer`).
+
+Same constructor keywords and the same `get_model_input` / `n_instances` contract as the reference's Cython class, so a render
+config names `nerf_tex_amd.instancer.Instancer` where it named `instancer.instancer.Instancer`; everything runs in
+`ntx_instancer_model_input` (include/nerftex.h) and the ten buffers stay in HBM, where `InstanceRenderer` hands them to
+`ntx_render_instanced` -- the reference walks its rays through Embree on one CPU thread and uploads ~70 bytes per (ray, step).
+
+What is built: explicit `transformations` (instancer.pyx:19-20) or the JSON file the reference's `transformation_export_path`
+writes (instancer.cpp:1040-1061), a culling mesh given as arrays, the three `instance_sampling_method`s, `use_mean_distance`,
+'' / 'light' / 'point' entries of `textures`.  What is refused (NtxError, NTX_E_UNSUPPORTED): `cast_shadow_rays`, image
+textures, `auxiliary_meshes`, and `mesh_path` without an exported transformation list (DistributeInstancesOnMesh needs libigl's
+curvature directions on meshes the reference keeps in LFS).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import Optional, Sequence
+
+from . import _lib
+
+SAMPLING_METHODS = {"random": 0, "nearest": 1, "nearest_blend": 2}        # instancer.pyx:14
+
+
+def parse_textures(textures: Sequence[str]):
+    """(n_parameters, light_dir_parameter_idx, light_strength_parameter_idx) of a `textures` list (instancer.cpp:74-92)."""
+    n, light_dir, light_strength = 0, -1, -1
+    for path in textures:
+        if path == "light":
+            light_dir = n; n += 3
+        elif path == "point":
+            light_strength = n; light_dir = n + 1; n += 4
+        elif path != "":
+            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, f"image texture {path!r}: parameter textures on the instancer mesh "
+                                "(instancer.cpp:640-667) are not built")
+        else:
+            n += 1
+    return n, light_dir, light_strength
+
+
+class Instancer:
+    """instancer.instancer.Instancer (instancer.pyx:6-54)."""
+
+    device_native = True          # InstanceRenderer: inputs and outputs are torch tensors on the GPU, nothing goes through the host
+
+    def __init__(self, b_0, b_1, cast_shadow_rays: bool = False, textures: Sequence[str] = (), transformations=(),
+                 mesh_path: Optional[str] = None, patch_scale: float = 1., patch_origins_path: str = '',
+                 min_shadow_samples: int = 4, n_shadow_samples: int = 512, min_texture_samples: int = 4,
+                 n_texture_samples: int = 512, jitter_amount: float = 0, instance_sampling_method: str = 'random',
+                 use_mean_distance: bool = False, auxiliary_meshes=(), transformation_export_path: Optional[str] = None,
+                 transformations_path: Optional[str] = None, mesh=None, seed: int = 0, device: int = 0, **kwargs) -> None:
+        import numpy as np
+        if instance_sampling_method not in SAMPLING_METHODS:
+            raise ValueError(f"instance_sampling_method must be one of {sorted(SAMPLING_METHODS)}")
+        if auxiliary_meshes:
+            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, "auxiliary meshes (instancer.cpp:393-417, 716-743) are not built")
+        n_par, light_dir, light_strength = parse_textures(textures)
+        tr = [np.asarray(m, np.float32).reshape(4, 4) for m in transformations]
+        distributed = False
+        if transformations_path is not None:           # what ExportTransformations wrote (patch -> world, instancer.cpp:1040-1061)
+            with open(transformations_path) as f:
+                tr += [np.asarray(m, np.float32).reshape(4, 4) for m in json.load(f)]
+            distributed = True
+        elif mesh_path is not None:
+            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, "mesh_path without transformations_path: DistributeInstancesOnMesh "
+                                "(instancer.cpp:233-390) is not built; export the list once with the reference's "
+                                "transformation_export_path and pass it as transformations_path")
+        self._tr = np.ascontiguousarray(np.stack(tr) if tr else np.zeros((0, 4, 4), np.float32))
+        # only DistributeInstancesOnMesh stores the scale (instancer.cpp:236); it widens nearest_blend's transition (:697)
+        self.patch_scale = float(patch_scale) if distributed else 1.0
+        self.n_parameters = n_par
+        self.device = int(device)
+        self.seed = int(seed)
+        self._calls = 0
+        desc = _lib.InstancerDesc()
+        desc.size = C.sizeof(_lib.InstancerDesc)
+        desc.b_0 = (C.c_float * 3)(*[float(v) for v in b_0]); desc.b_1 = (C.c_float * 3)(*[float(v) for v in b_1])
+        desc.n_parameters, desc.light_dir_parameter_idx, desc.light_strength_parameter_idx = n_par, light_dir, light_strength
+        desc.instance_sample_method = SAMPLING_METHODS[instance_sampling_method]
+        desc.use_mean_distance = int(bool(use_mean_distance)); desc.cast_shadow_rays = int(bool(cast_shadow_rays))
+        desc.patch_scale = self.patch_scale
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib.ntx_instancer_create(C.byref(desc), self._tr.ctypes.data_as(C.POINTER(C.c_float)), self._tr.shape[0],
+                                                 self.device, C.byref(self._h)))
+        if mesh is not None:
+            self.set_mesh(*mesh)
+        elif mesh_path is not None:
+            self.set_mesh(*read_ply(mesh_path))
+        if transformation_export_path is not None:
+            self.export_transformations(transformation_export_path)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            _lib.lib.ntx_instancer_destroy(h)
+            self._h = None
+
+    def n_instances(self) -> int:                                                        # instancer.pyx:32-33
+        return int(_lib.lib.ntx_instancer_count(self._h))
+
+    def set_mesh(self, vertices, faces) -> None:
+        """The instancer mesh (instancer.cpp:369-389): rays end at it with an opaque black sample."""
+        import numpy as np
+        v = np.ascontiguousarray(np.asarray(vertices, np.float32).reshape(-1, 3))
+        f = np.ascontiguousarray(np.asarray(faces, np.int32).reshape(-1, 3))
+        _lib.check(_lib.lib.ntx_instancer_set_mesh(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), v.shape[0],
+                                                   f.ctypes.data_as(C.POINTER(C.c_int32)), f.shape[0]))
+
+    def reserve(self, max_rays: int) -> None:
+        _lib.check(_lib.lib.ntx_instancer_reserve(self._h, int(max_rays)))
+
+    def matrices(self):
+        """(world -> patch [K,4,4], direction maps [K,3,3], origins [K,3]) as the library holds them."""
+        import numpy as np
+        k = self.n_instances()
+        w2p = np.zeros((k, 4, 4), np.float32); dirs = np.zeros((k, 3, 3), np.float32); org = np.zeros((k, 3), np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.lib.ntx_instancer_matrices(self._h, fp(w2p), fp(dirs), fp(org)))
+        return w2p, dirs, org
+
+    def export_transformations(self, file_path: str) -> None:
+        """ExportTransformations (instancer.cpp:1040-1061): the patch -> world matrices as a JSON list of 4x4 lists."""
+        with open(file_path, "w") as f:
+            json.dump([[[float(v) for v in row] for row in m] for m in self._tr], f, indent=4)
+
+    def get_model_input(self, rays_o, rays_d, parameters, n_samples: int, step_size: float, seed: Optional[int] = None,
+                        ray_index=None):
+        """instancer.pyx:38-54: rays_o [n,3], rays_d [n,3], parameters [n,P] -> (rays_d_map [n,S,3], pts [n,S,3], t [n,S],
+        dists [n,S], color [n,1,3], density [n,1], density_weight [n,S], instance_id [n,S] int32, idxs [k,1] = where(hit),
+        params_map [n,S,P]) as torch tensors on the instancer's GPU (numpy or CPU inputs are uploaded).  `seed` fixes the call's
+        draws (default: the constructor's seed and a call counter), `ray_index` = (index0, run_length, run_stride) of the rays
+        in a larger image (include/nerftex.h: ntx_render_opts)."""
+        import numpy as np
+        import torch
+        dev = torch.device("cuda", self.device)
+        to = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).to(device=dev, dtype=torch.float32).contiguous()
+        rays_o, rays_d = to(rays_o).reshape(-1, 3), to(rays_d).reshape(-1, 3)
+        n, S, P = rays_o.shape[0], int(n_samples), self.n_parameters
+        par = to(parameters).reshape(n, -1) if P > 0 else None
+        if P > 0 and par.shape[1] != P:
+            raise ValueError(f"parameters must be [n,{P}] (the textures list has {P} entries' worth), got {tuple(parameters.shape)}")
+        e = lambda *shape, dt=torch.float32: torch.empty(shape, device=dev, dtype=dt)
+        rays_d_map, pts, t, dists = e(n, S, 3), e(n, S, 3), e(n, S), e(n, S)
+        color, density, weight = e(n, 1, 3), e(n, 1), e(n, S)
+        instance_id, hit = e(n, S, dt=torch.int32), e(n, dt=torch.uint8)
+        params_map = e(n, S, P)
+        self._status = torch.zeros(1, device=dev, dtype=torch.int32)
+        if seed is None:
+            seed = (self.seed << 32) + self._calls
+            self._calls += 1
+        self.last_seed = int(seed)
+        opts = _lib.render_opts(ray_index=ray_index) if ray_index is not None else None
+        ptr = lambda x: x.data_ptr() if x is not None and x.numel() else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.ntx_instancer_model_input(
+                self._h, ptr(rays_o), ptr(rays_d), ptr(par), n, S, float(step_size), int(seed) & (2 ** 64 - 1), opts,
+                ptr(rays_d_map), ptr(pts), ptr(t), ptr(dists), ptr(color), ptr(density), ptr(weight), ptr(instance_id), ptr(hit),
+                ptr(params_map), self._status.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        self.last_hit = hit
+        idxs = hit.nonzero(as_tuple=False)                                               # tf.where(hit), instancer.pyx:54
+        return rays_d_map, pts, t, dists, color, density, weight, instance_id, idxs, params_map
+
+    def status(self) -> int:
+        """Flags of the last call (synchronises): 1 = a ray crossed more than 200 faces (MAX_TOTAL_HITS), 2 = a point lay in
+        more than 64 patches."""
+        st = getattr(self, "_status", None)
+        return 0 if st is None else int(st.item())
+
+
+def read_ply(path: str):
+    """Vertices [nv,3] float32 and triangles [nf,3] int32 of a PLY file (ascii or binary_little_endian; x/y/z of the vertex
+    element, the list property of the face element; polygons are fanned) -- what igl::readPLY hands AddMesh /
+    DistributeInstancesOnMesh for the culling mesh (instancer.cpp:241, 400)."""
+    import numpy as np
+    types = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2",
+             "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4",
+             "double": "f8", "float64": "f8"}
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, elements = None, []
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: header without end_header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok or tok[0] == "comment" or tok[0] == "obj_info":
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                elements.append([tok[1], int(tok[2]), []])
+            elif tok[0] == "property":
+                elements[-1][2].append(tuple(tok[1:]))
+            elif tok[0] == "end_header":
+                break
+        if fmt not in ("ascii", "binary_little_endian"):
+            raise ValueError(f"{path}: PLY format {fmt!r} is not supported")
+        verts, faces = None, []
+        for name, count, props in elements:
+            is_list = any(p[0] == "list" for p in props)
+            if fmt == "ascii":
+                rows = [f.readline().split() for _ in range(count)]
+                if name == "vertex":
+                    cols = [p[-1] for p in props]
+                    ix = [cols.index(c) for c in ("x", "y", "z")]
+                    verts = np.asarray([[float(r[i]) for i in ix] for r in rows], np.float32).reshape(-1, 3)
+                elif name == "face":
+                    for r in rows:
+                        k = int(r[0]); idx = [int(v) for v in r[1:1 + k]]
+                        faces += [[idx[0], idx[i], idx[i + 1]] for i in range(1, k - 1)]
+            elif not is_list:
+                dt = np.dtype([(p[-1], "<" + types[p[0]]) for p in props])
+                data = np.frombuffer(f.read(dt.itemsize * count), dtype=dt, count=count)
+                if name == "vertex":
+                    verts = np.stack([data["x"], data["y"], data["z"]], -1).astype(np.float32)
+            else:
+                for _ in range(count):
+                    idx = None
+                    for p in props:
+                        if p[0] == "list":
+                            k = int(np.frombuffer(f.read(np.dtype(types[p[1]]).itemsize), "<" + types[p[1]])[0])
+                            it = np.dtype("<" + types[p[2]])
+                            vals = np.frombuffer(f.read(it.itemsize * k), it)
+                            if idx is None and name == "face":
+                                idx = [int(v) for v in vals]
+                        else:
+                            f.read(np.dtype(types[p[0]]).itemsize)
+                    if idx is not None:
+                        faces += [[idx[0], idx[i], idx[i + 1]] for i in range(1, len(idx) - 1)]
+    if verts is None:
+        raise ValueError(f"{path}: no vertex element")
+    return verts, np.asarray(faces, np.int32).reshape(-1, 3)

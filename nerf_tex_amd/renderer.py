@@ -265,19 +265,33 @@ class InstanceRenderer(Renderer):
             noise_seed = int(kwargs["seed"]) if kwargs.get("seed") is not None else self._next_seed()
         self._last_seed = noise_seed
         S = self.n_samples
-        up = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(np.asarray(a)), device=dev).to(dt).contiguous()
+
+        def up(a, dt=torch.float32):
+            if isinstance(a, torch.Tensor):
+                return a.to(device=dev, dtype=dt).contiguous()
+            return torch.as_tensor(np.ascontiguousarray(np.asarray(a)), device=dev).to(dt).contiguous()
+
+        # an instancer of this package (nerf_tex_amd.instancer.Instancer) takes and returns tensors on the GPU: the ten buffers
+        # never leave HBM.  Any other object with the reference's get_model_input is fed numpy arrays as the reference feeds it.
+        native = bool(getattr(self.instancer, "device_native", False))
         for i in range(0, keep.shape[0], self.render_chunk):                                    # renderer.py:72-73
             sl = keep[i:i + self.render_chunk]
             k = sl.shape[0]
             ro_c, rd_c, p_c = o_f[sl], d_f[sl], p_f[sl]
-            (rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map) = \
-                self.instancer.get_model_input(ro_c.cpu().numpy(), rd_c.cpu().numpy(), p_c.cpu().numpy(), S, self.step_size)
-            idxs = np.asarray(idxs)
-            hit = np.zeros(k, dtype=np.uint8)
-            if idxs.dtype == np.bool_:
-                hit[idxs.reshape(-1)] = 1
+            if native:
+                (rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map) = \
+                    self.instancer.get_model_input(ro_c, rd_c, p_c, S, self.step_size, seed=kwargs.get("instancer_seed"),
+                                                   ray_index=(i, k, k))
+                hit = self.instancer.last_hit
             else:
-                hit[idxs.reshape(-1).astype(np.int64)] = 1
+                (rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map) = \
+                    self.instancer.get_model_input(ro_c.cpu().numpy(), rd_c.cpu().numpy(), p_c.cpu().numpy(), S, self.step_size)
+                idxs = np.asarray(idxs)
+                hit = np.zeros(k, dtype=np.uint8)
+                if idxs.dtype == np.bool_:
+                    hit[idxs.reshape(-1)] = 1
+                else:
+                    hit[idxs.reshape(-1).astype(np.int64)] = 1
             bufs = dict(rays_d_map=up(rays_d_map), pts=up(pts), t=up(tt), dists=up(dists),
                         color_last=up(color_last).reshape(k, 3), alpha_last=up(alpha_last).reshape(k),
                         alpha_weight=up(alpha_weight) if self.density_reweighting else None,

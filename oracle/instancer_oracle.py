@@ -1,0 +1,340 @@
+"""CPU restatement of the reference's patch instancer, `C_Instancer::GetModelInput` (instancer/src/instancer.cpp:751-1037)
+behind `Instancer.get_model_input` (instancer/instancer.pyx:38-54).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/ (and nothing in nerf_tex_amd/); the product is the HIP kernel
+`ntx_inst::inst_hits_kernel` / `inst_march_kernel` (nerf_tex_amd/csrc/ntx_instancer.hip) behind `ntx_instancer_model_input`.
+
+PARITY UNPINNED.  The reference's instancer is C++ on Embree 3 (+ Eigen, libigl): none of them is in this image, its four
+submodules are empty and its meshes are LFS pointers, so nothing of it can be built or run here and it ships no test vectors.
+What is restated line by line is the reference's OWN code: the hit ordering (instancer.cpp:441-452), the segment sums
+(:800-826), the step count / dists / offset (:840-859), the marching loop (:870-1010), nearest / random / blended patch choice
+(:670-713), the point / direction / light maps (:556-589) and the closing sample (:1013-1027).  What Embree does underneath
+(`rtcIntersect1` on instanced quads with an all-hits filter, :779) is restated from its published contract: every face of an
+instanced box the ray crosses with tnear < t <= tfar is reported once, at the ray parameter of the WORLD ray; here that is the
+slab test of the ray taken into patch coordinates (entry and exit parameter), evaluated in float32.  Rays through an edge or a
+corner (two faces at one t), rays starting on a face, and more than MAX_TOTAL_HITS = 200 face crossings (Embree's traversal
+order decides which are dropped, :539) are outside what this restatement can vouch for.
+
+Random numbers: the reference draws from one std::mt19937 in ray order (:855, :675, :710), which a kernel that renders rays in
+parallel cannot reproduce; the product keys a Philox4x32-10 block by (seed, global ray index, sample) instead and THIS file
+restates those draws (`offset_uniforms`, `choice_uniforms`), like `nerftex_oracle.jitter_uniforms` does for the jitter.
+
+Everything is sequential Python over numpy float32 scalars: small cases only.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import nerftex_oracle as orc
+
+F32 = np.float32
+INVALID = 0xFFFFFFFF          # RTC_INVALID_GEOMETRY_ID: the instID of a hit on a mesh (instancer.cpp:444)
+MAX_TOTAL_HITS = 200          # instancer.cpp:22
+T_NEAR, T_FAR = F32(0.0), F32(100.0)      # init_ray(..., 0, 100, ...)  instancer.cpp:776
+SAMPLE_RANDOM, SAMPLE_NEAREST, SAMPLE_NEAREST_BLEND = 0, 1, 2        # instancer.pyx:14
+
+
+@dataclass
+class InstancerSpec:
+    """What the constructor + AddInstance leave behind (instancer.cpp:53-93, 124-141)."""
+    b_0: np.ndarray                      # patch box, patch coordinates
+    b_1: np.ndarray
+    inv: np.ndarray                      # [K,4,4] world -> patch  (this->transformations)
+    dir_t: np.ndarray                    # [K,3,3] (this->dir_transformations)
+    origins: np.ndarray                  # [K,3]   (this->instance_origins)
+    n_parameters: int = 0
+    light_dir_idx: int = -1
+    light_strength_idx: int = -1
+    sample_method: int = SAMPLE_RANDOM
+    use_mean_distance: bool = False
+    patch_scale: float = 1.0             # only DistributeInstancesOnMesh sets it (instancer.cpp:236); 1 otherwise (:53)
+    mesh_v: Optional[np.ndarray] = None  # the instancer mesh (culls, closes a ray with an opaque black sample)
+    mesh_f: Optional[np.ndarray] = None
+
+
+def parse_textures(textures: Sequence[str]) -> Tuple[int, int, int]:
+    """(n_parameters, light_dir_parameter_idx, light_strength_parameter_idx) from the constructor's `textures` list
+    (instancer.cpp:74-92).  Image textures need the instancer mesh's UVs and the LFS images: not restated."""
+    n, ld, ls = 0, -1, -1
+    for path in textures:
+        if path == "light":
+            ld = n; n += 3
+        elif path == "point":
+            ls = n; ld = n + 1; n += 4
+        elif path != "":
+            raise ValueError("image textures are not restated")
+        else:
+            n += 1
+    return n, ld, ls
+
+
+def prepare_instances(transformations) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """AddInstance (instancer.cpp:124-141) for a list of patch -> world matrices [K,4,4]: (world -> patch, direction maps,
+    origins).  The inverse is taken in float64 and rounded (Eigen's float 4x4 inverse differs in the last place)."""
+    tr = np.asarray(transformations, dtype=F32).reshape(-1, 4, 4)
+    inv = np.linalg.inv(tr.astype(np.float64)).astype(F32)
+    cols = np.transpose(tr[:, :3, :3], (0, 2, 1)).astype(np.float64)           # rows of R^T
+    dir_t = (cols / np.linalg.norm(cols, axis=-1, keepdims=True)).astype(F32)   # .rowwise().normalized()
+    return inv, dir_t, tr[:, :3, 3].copy()
+
+
+def make_spec(b_0, b_1, transformations, textures=(), instance_sampling_method="random", use_mean_distance=False,
+              mesh=None, matrices=None) -> InstancerSpec:
+    n, ld, ls = parse_textures(textures)
+    inv, dir_t, org = prepare_instances(transformations) if matrices is None else matrices
+    mv = mf = None
+    if mesh is not None:
+        mv = np.asarray(mesh[0], F32).reshape(-1, 3); mf = np.asarray(mesh[1], np.int32).reshape(-1, 3)
+    return InstancerSpec(np.asarray(b_0, F32), np.asarray(b_1, F32), inv, dir_t, org, n, ld, ls,
+                         {"random": 0, "nearest": 1, "nearest_blend": 2}[instance_sampling_method], bool(use_mean_distance),
+                         1.0, mv, mf)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the product's random draws, restated
+# ------------------------------------------------------------------------------------------------------------------------------
+
+def offset_uniforms(n_rays: int, seed: int, ray_index=None) -> np.ndarray:
+    """One U[0,1) per ray for t_offset (instancer.cpp:848, 855): Philox counter (0, ray lo, ray hi, 2), key = seed."""
+    ray = orc.global_ray_index(n_rays, ray_index).astype(np.uint64)
+    bits = orc.philox4x32_10(np.uint32(0), (ray & np.uint64(0xFFFFFFFF)).astype(np.uint32), (ray >> np.uint64(32)).astype(np.uint32),
+                             np.uint32(2), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return orc.uniform01_from_bits(bits)
+
+
+def choice_uniforms(n_rays: int, n_pts: int, seed: int, ray_index=None) -> np.ndarray:
+    """One U[0,1) per (ray, step) for the random / blended patch choice (instancer.cpp:675, 710): counter (step, ray lo,
+    ray hi, 3)."""
+    ray = orc.global_ray_index(n_rays, ray_index).astype(np.uint64)[:, None]
+    i = np.arange(n_pts, dtype=np.uint32)[None, :]
+    bits = orc.philox4x32_10(i, (ray & np.uint64(0xFFFFFFFF)).astype(np.uint32), (ray >> np.uint64(32)).astype(np.uint32),
+                             np.uint32(3), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return orc.uniform01_from_bits(bits)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# geometry
+# ------------------------------------------------------------------------------------------------------------------------------
+
+def _affine(m, p):
+    """block<3,3>(0,0) * p + block<3,1>(0,3), coefficient products summed left to right (instancer.cpp:556-558)."""
+    return np.asarray([((m[r, 0] * p[0] + m[r, 1] * p[1]) + m[r, 2] * p[2]) + m[r, 3] for r in range(3)], F32)
+
+
+def _linear(m, p):
+    return np.asarray([(m[r, 0] * p[0] + m[r, 1] * p[1]) + m[r, 2] * p[2] for r in range(3)], F32)
+
+
+def _normalized(v):
+    """Eigen's normalized(): v / sqrt(squaredNorm) when the squared norm is positive."""
+    n2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]
+    return (v / np.sqrt(n2)).astype(F32) if n2 > 0 else v
+
+
+def _norm(v):
+    return np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
+
+
+def box_hits(spec: InstancerSpec, o, d) -> List[Tuple[np.float32, int]]:
+    """Face crossings of the world ray o + t d with every instanced box, as (t, instID): the ray goes into patch coordinates
+    (Embree's instance traversal), the slab test gives the entry and the exit parameter, each is a hit when tnear < t <= tfar."""
+    hits = []
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for k in range(spec.inv.shape[0]):
+            ol = _affine(spec.inv[k], o); dl = _linear(spec.inv[k], d)
+            t_in, t_out = F32(-np.inf), F32(np.inf)
+            miss = False
+            for a in range(3):
+                if dl[a] == 0:
+                    if ol[a] < spec.b_0[a] or ol[a] > spec.b_1[a]:
+                        miss = True
+                    continue
+                inv_d = F32(1.0) / dl[a]
+                t0 = (spec.b_0[a] - ol[a]) * inv_d; t1 = (spec.b_1[a] - ol[a]) * inv_d
+                lo, hi = (t0, t1) if t0 < t1 else (t1, t0)
+                t_in = lo if lo > t_in else t_in
+                t_out = hi if hi < t_out else t_out
+            if miss or not (t_in < t_out):
+                continue
+            for tt in (t_in, t_out):
+                if T_NEAR < tt <= T_FAR:
+                    hits.append((F32(tt), k))
+    return hits
+
+
+def mesh_hit(spec: InstancerSpec, o, d) -> Optional[np.float32]:
+    """Closest crossing of the instancer mesh (Moeller-Trumbore in float32, no culling, tnear < t <= tfar) or None."""
+    if spec.mesh_v is None:
+        return None
+    best = None
+    cross = lambda a, b: np.asarray([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], F32)
+    dot = lambda a, b: (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for f in spec.mesh_f:
+            v0, v1, v2 = spec.mesh_v[f[0]], spec.mesh_v[f[1]], spec.mesh_v[f[2]]
+            e1 = v1 - v0; e2 = v2 - v0
+            p = cross(d, e2); det = dot(e1, p)
+            if det == 0:
+                continue
+            inv_det = F32(1.0) / det
+            s = o - v0
+            u = dot(s, p) * inv_det
+            if u < 0 or u > 1:
+                continue
+            q = cross(s, e1)
+            v = dot(d, q) * inv_det
+            if v < 0 or u + v > 1:
+                continue
+            tt = dot(e2, q) * inv_det
+            if T_NEAR < tt <= T_FAR and (best is None or tt < best):
+                best = F32(tt)
+    return best
+
+
+def get_mean_distance(mu, hw):
+    """instancer.cpp:746-748; std::pow(float, int) promotes to double, the result is returned as float."""
+    mu = float(mu); hw = float(hw)
+    return F32(mu + 2 * mu * hw ** 2 / (3 * mu ** 2 + hw ** 2))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# GetModelInput
+# ------------------------------------------------------------------------------------------------------------------------------
+
+def get_model_input(spec: InstancerSpec, rays_o, rays_d, parameters, n_samples: int, step_size: float,
+                    u_offset: np.ndarray, u_choice: Optional[np.ndarray] = None):
+    """instancer.pyx:38-54 + instancer.cpp:751-1037.  rays_o, rays_d [n,3], parameters [n,P]; u_offset [n] and u_choice
+    [n, n_samples] are the uniform draws.  Returns the tuple of instancer.pyx:54 as numpy arrays, `hit` as a bool mask."""
+    rays_o = np.asarray(rays_o, F32); rays_d = np.asarray(rays_d, F32)
+    parameters = np.asarray(parameters, F32).reshape(rays_o.shape[0], -1)
+    n, S, P = rays_o.shape[0], int(n_samples), parameters.shape[1]
+    assert P == spec.n_parameters, "the textures list decides the width of a parameter row (instancer.cpp:755)"
+    h = F32(step_size)
+    # the buffers as instancer.pyx:41-50 allocates them
+    rays_d_map = np.repeat(rays_d[:, None, :], S, axis=1).copy()
+    t = np.zeros((n, S), F32); dists = np.zeros((n, S), F32); pts = np.zeros((n, S, 3), F32)
+    color = np.zeros((n, 1, 3), F32); density = np.zeros((n, 1), F32)
+    density_weight = np.ones((n, S), F32); instance_id = np.zeros((n, S), np.int32); hit = np.zeros(n, bool)
+    params_map = np.repeat(parameters[:, None, :], S, axis=1).copy()
+
+    def t_of(step, t_offset, segment_offset):
+        t_mu = (F32(step) * h + t_offset) + segment_offset                              # :872, :985
+        return t_mu, (get_mean_distance(t_mu, h) if spec.use_mean_distance else t_mu)
+
+    for i in range(n):
+        o, d = rays_o[i], rays_d[i]
+        # at most MAX_TOTAL_HITS box crossings are kept (:539; here the first ones of the sorted list, in the reference the
+        # first ones Embree's traversal meets -- a ray with more is flagged by the product and not comparable)
+        hits = sorted([(tt, k, False) for tt, k in box_hits(spec, o, d)], key=lambda e: (e[0], e[1]))[:MAX_TOTAL_HITS]
+        tm = mesh_hit(spec, o, d)
+        if tm is not None:
+            hits.append((tm, INVALID, True))
+        if not hits:                                                                    # :782
+            continue
+        hit[i] = True
+        hits.sort(key=lambda e: (e[0], e[1]))                                           # :787, order of :441-452
+
+        # segment lengths inside the union of the boxes (:800-826)
+        active: set = set()
+        total = F32(0.0); t_entry = F32(0.0)
+        has_mesh = False
+        for tt, k, is_mesh in hits:
+            if is_mesh:
+                if active:
+                    total = total + (tt - t_entry)
+                has_mesh = True
+                break
+            if k in active:
+                active.discard(k)
+                if not active:
+                    total = total + (tt - t_entry)
+            else:
+                if not active:
+                    t_entry = tt
+                active.add(k)
+        active = set()
+
+        default_light = params_map[i, 0, spec.light_dir_idx:spec.light_dir_idx + 3].copy() if spec.light_dir_idx >= 0 else None
+        default_str = params_map[i, 0, spec.light_strength_idx] if spec.light_strength_idx >= 0 else None
+
+        if total > 0:
+            necessary = int(np.uint32(total / h))                                       # :842
+            n_steps = min(necessary, S)
+            if n_steps == 0:
+                dists[i, 0] = total
+                t_offset = u_offset[i] * total
+                n_steps = 1
+            else:
+                dists[i, :n_steps - 1] = h
+                dists[i, n_steps - 1] = (h + total) - F32(n_steps) * h                  # :853
+                t_offset = u_offset[i] * h
+            segment_offset = F32(0.0); cleared = F32(0.0); t_entry = F32(0.0)
+            step = 0
+            for tt, k, is_mesh in hits:
+                if step >= n_steps:
+                    break
+                t_mu, t_pt = t_of(step, t_offset, segment_offset)
+                while active and t_pt < tt and step < n_steps:
+                    t[i, step] = t_mu
+                    pt = (o + t_pt * d).astype(F32)                                     # getPtOnRay :566-568
+                    ids = sorted(active)                                                # std::set iterates in ascending order
+                    if len(ids) == 1:
+                        inst = ids[0]; density_weight[i, step] = 1.0
+                    elif spec.sample_method == SAMPLE_RANDOM:                           # :672-677
+                        inst = ids[min(int(u_choice[i, step] * F32(len(ids))), len(ids) - 1)]
+                        density_weight[i, step] = F32(len(ids))
+                    elif spec.sample_method == SAMPLE_NEAREST:                          # :681-692
+                        best = F32(np.inf); inst = ids[0]
+                        for c in ids:
+                            dd = _norm(pt - spec.origins[c])
+                            if dd < best:
+                                inst = c; best = dd
+                        density_weight[i, step] = 1.0
+                    else:                                                               # :696-713
+                        tr = F32(0.2) * F32(spec.patch_scale)
+                        ds = [_norm(pt - spec.origins[c]) for c in ids]
+                        mn = min(ds)
+                        ws = [max((tr + mn) - w, F32(0.0)) for w in ds]
+                        tot = F32(0.0)
+                        for w in ws:
+                            tot = tot + w
+                        # std::discrete_distribution: the first index whose cumulative probability exceeds the draw
+                        target = u_choice[i, step] * tot
+                        acc = F32(0.0); pick = len(ids) - 1
+                        for q, w in enumerate(ws):
+                            acc = acc + w
+                            if target < acc:
+                                pick = q
+                                break
+                        inst = ids[pick]
+                        density_weight[i, step] = tot / ws[pick]                        # 1 / probability
+                    instance_id[i, step] = inst
+                    if spec.light_dir_idx >= 0:                                         # :945 ff with cast_shadow_rays = false
+                        src = (default_light - pt).astype(F32) if spec.light_strength_idx >= 0 else default_light   # :573-579
+                        params_map[i, step, spec.light_dir_idx:spec.light_dir_idx + 3] = _linear(spec.dir_t[inst], _normalized(src))
+                    if spec.light_strength_idx >= 0:                                    # :970-972, :583-588 (double)
+                        dv = (default_light - pt).astype(F32)
+                        d2 = (dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]
+                        params_map[i, step, spec.light_strength_idx] = F32(float(default_str) / (4 * np.pi * float(d2) + float(F32(1e-6))))
+                    pts[i, step] = _affine(spec.inv[inst], pt)                          # :975
+                    rays_d_map[i, step] = _linear(spec.dir_t[inst], _normalized(d))     # :976, :561-563
+                    step += 1
+                    t_mu, t_pt = t_of(step, t_offset, segment_offset)
+                if is_mesh:                                                             # :988
+                    break
+                if k in active:
+                    active.discard(k)
+                    if not active:
+                        cleared = cleared + (tt - t_entry)                              # :996
+                else:
+                    if not active:
+                        segment_offset = tt - cleared                                   # :1001
+                        t_entry = tt
+                    active.add(k)
+        if has_mesh:                                                                    # :1013-1027 (instancer mesh: black, opaque)
+            density[i, 0] = 1.0
+    return rays_d_map, pts, t, dists, color, density, density_weight, instance_id, hit, params_map

@@ -1,0 +1,201 @@
+"""The patch instancer on the GPU (`ntx_instancer_model_input`, ABI v4) against the restatement of the reference's
+C_Instancer::GetModelInput (oracle/instancer_oracle.py <- instancer/src/instancer.cpp:751-1037), through the mirror of the
+reference's Cython class (nerf_tex_amd.instancer.Instancer <- instancer/instancer.pyx).  `-m gpu`.
+
+The oracle is fed the instance matrices the library holds (`ntx_instancer_matrices`) and restates the product's Philox draws,
+and both sides spell their float32 operations in one order: every output is compared BIT FOR BIT."""
+
+import json
+
+import numpy as np
+import pytest
+
+from oracle import instancer_oracle as io
+from oracle import nerftex_oracle as orc
+from tests.common import TOL, make_model
+from tests.test_oracle_instancer import UNIT, random_rays, random_scene, translate
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+F = np.float32
+NAMES = ["rays_d_map", "pts", "t", "dists", "color", "density", "density_weight", "instance_id", "hit", "params_map"]
+
+
+def gpu_instancer(spec_kw, transformations, **kw):
+    from nerf_tex_amd.instancer import Instancer
+    return Instancer(spec_kw["b_0"], spec_kw["b_1"], transformations=[np.asarray(m).tolist() for m in transformations], **kw)
+
+
+def run_gpu(inst, o, d, params, S, h, seed, ray_index=None):
+    out = inst.get_model_input(o, d, params, S, h, seed=seed, ray_index=ray_index)
+    torch.cuda.synchronize()
+    res = [x.cpu().numpy() for x in out]
+    hit = np.zeros(o.shape[0], bool); hit[res[8][:, 0]] = True                   # idxs = where(hit)
+    res[8] = hit
+    return res
+
+
+def run_oracle(inst, box, o, d, params, S, h, seed, method="random", textures=(), mean=False, mesh=None, ray_index=None, patch_scale=1.0):
+    spec = io.make_spec(box["b_0"], box["b_1"], None, textures=textures, instance_sampling_method=method, use_mean_distance=mean,
+                        mesh=mesh, matrices=inst.matrices())
+    spec.patch_scale = patch_scale
+    n = o.shape[0]
+    return list(io.get_model_input(spec, o, d, params, S, h, io.offset_uniforms(n, seed, ray_index), io.choice_uniforms(n, S, seed, ray_index)))
+
+
+def assert_same(got, want):
+    for name, g, w in zip(NAMES, got, want):
+        assert g.shape == w.shape and g.dtype == w.dtype, (name, g.shape, w.shape, g.dtype, w.dtype)
+        if not np.array_equal(g, w):
+            bad = np.argwhere(g != w)
+            raise AssertionError(f"{name}: {len(bad)} of {g.size} elements differ, first at {bad[0].tolist()}: {g[tuple(bad[0])]!r} != {w[tuple(bad[0])]!r}")
+
+
+def test_matrices_are_add_instances():
+    rng = np.random.default_rng(0)
+    tr = []
+    for _ in range(9):
+        m = np.eye(4); m[:3, :3] = rng.normal(size=(3, 3)); m[:3, 3] = rng.normal(size=3)
+        tr.append(m.astype(F))
+    inst = gpu_instancer(UNIT, tr)
+    assert inst.n_instances() == 9                                              # GetNumberOfInstances
+    w2p, dirs, org = inst.matrices()
+    inv, dir_t, origins = io.prepare_instances(tr)
+    assert np.allclose(w2p, inv, rtol=2e-6, atol=1e-7) and np.array_equal(w2p[:, 3], np.tile(F([0, 0, 0, 1]), (9, 1)))
+    assert np.allclose(dirs, dir_t, rtol=2e-7, atol=1e-7) and np.array_equal(org, origins)
+
+
+def test_known_answers_on_the_kernel():
+    """The hand-computed cases of tests/test_oracle_instancer.py, now from the kernel."""
+    inst = gpu_instancer(UNIT, [translate(), translate(z=5)])
+    o = F([[0, 0, -5], [5, 5, -5]]); d = F([[0, 0, 1], [0, 0, 1]])
+    import nerf_tex_amd.instancer as mod
+    rd, pts, t, dists, color, dens, w, iid, hit, pm = run_gpu(inst, o, d, np.zeros((2, 0), F), 16, 0.5, seed=3)
+    u = io.offset_uniforms(2, 3)[0] * F(0.5)
+    assert np.array_equal(dists[0, :8], np.full(8, .5, F)) and not dists[0, 8:].any() and not dists[1].any()
+    want_t = np.asarray([(F(s) * F(.5) + u) + F(4) for s in range(4)] + [(F(s) * F(.5) + u) + (F(9) - F(2)) for s in range(4, 8)], F)
+    assert np.array_equal(t[0, :8], want_t) and not t[0, 8:].any()
+    assert iid[0, :8].tolist() == [0] * 4 + [1] * 4 and hit.tolist() == [True, False]
+    assert np.allclose(pts[0, :8, 2], np.r_[want_t[:4] - 5, want_t[4:] - 10], atol=1e-6)
+    assert (w == 1).all() and not dens.any() and not color.any() and np.array_equal(rd[1], np.tile(d[1], (16, 1)))
+    assert mod.Instancer.device_native and inst.status() == 0
+
+
+@pytest.mark.parametrize("method", ["random", "nearest", "nearest_blend"])
+@pytest.mark.parametrize("mesh", [False, True])
+@pytest.mark.parametrize("textures,mean", [((), False), (("", "light", ""), False), (("point", ""), True)])
+def test_model_input_bit_for_bit(method, mesh, textures, mean):
+    spec0 = random_scene(11, k=24, method=method, textures=textures, mesh=mesh)
+    box = dict(b_0=spec0.b_0.tolist(), b_1=spec0.b_1.tolist())
+    rng = np.random.default_rng(11)
+    tr = [np.linalg.inv(m.astype(np.float64)).astype(F) for m in spec0.inv]      # patch -> world of the scene
+    msh = (spec0.mesh_v, spec0.mesh_f) if mesh else None
+    inst = gpu_instancer(box, tr, textures=list(textures), instance_sampling_method=method, use_mean_distance=mean, mesh=msh)
+    n, S, h = 150, 160, 0.02
+    o, d = random_rays(11, n)
+    P = spec0.n_parameters
+    params = rng.uniform(0.2, 3.0, size=(n, P)).astype(F)
+    got = run_gpu(inst, o, d, params, S, h, seed=0x1234567812345678)
+    want = run_oracle(inst, box, o, d, params, S, h, 0x1234567812345678, method, textures, mean, msh)
+    assert want[8].sum() > 50 and (want[3] > 0).sum() > 2000 and len(np.unique(want[7])) > 10
+    if method != "nearest":
+        assert (want[6] > 1).any()                                              # overlaps were met
+    if mesh:
+        assert want[5].any()
+    assert_same(got, want)
+    assert inst.status() == 0
+
+
+def test_rays_can_be_split_and_sharded():
+    """The draws are keyed by the global ray index: two calls with an index map, and a call longer than the reserved
+    workspace (cut into pieces inside the library), give the bits of one call."""
+    spec0 = random_scene(5, k=10, method="random")
+    box = dict(b_0=spec0.b_0.tolist(), b_1=spec0.b_1.tolist())
+    tr = [np.linalg.inv(m.astype(np.float64)).astype(F) for m in spec0.inv]
+    inst = gpu_instancer(box, tr)
+    n, S, h = 96, 64, 0.03
+    o, d = random_rays(5, n)
+    par = np.zeros((n, 0), F)
+    whole = run_gpu(inst, o, d, par, S, h, seed=9)
+    a = run_gpu(inst, o[:32], d[:32], par[:32], S, h, seed=9, ray_index=(0, 32, 32))
+    b = run_gpu(inst, o[32:], d[32:], par[32:], S, h, seed=9, ray_index=(32, 64, 64))
+    assert_same([np.concatenate([x, y]) for x, y in zip(a, b)], whole)
+    assert not np.array_equal(run_gpu(inst, o, d, par, S, h, seed=10)[2], whole[2])
+    # 70 000 rays > NTX_INSTANCER_DEFAULT_MAX_RAYS = 65 536: two pieces
+    big = 70_000
+    ob, db = random_rays(6, big)
+    outb = run_gpu(inst, ob, db, np.zeros((big, 0), F), 8, 0.2, seed=4)
+    tail = run_gpu(inst, ob[65_000:], db[65_000:], np.zeros((5_000, 0), F), 8, 0.2, seed=4, ray_index=(65_000, 5_000, 5_000))
+    assert_same([x[65_000:] for x in outb], tail)
+    assert outb[8][65_536:].any()
+
+
+def test_overflow_flags_and_refusals(tmp_path):
+    from nerf_tex_amd import _lib
+    from nerf_tex_amd.instancer import Instancer
+    nested = [translate(s=1 + 0.01 * k) for k in range(120)]                     # 240 face crossings on a ray through the middle
+    inst = gpu_instancer(UNIT, nested)
+    run_gpu(inst, F([[0, 0, -5]]), F([[0, 0, 1]]), np.zeros((1, 0), F), 8, 0.5, seed=1)
+    assert inst.status() & 1
+    inst = gpu_instancer(UNIT, nested[:80])                                      # 160 crossings, 80 patches around the middle
+    out = run_gpu(inst, F([[0, 0, -5]]), F([[0, 0, 1]]), np.zeros((1, 0), F), 8, 0.5, seed=1)
+    assert inst.status() == 2 and out[8][0]
+    inst = gpu_instancer(UNIT, nested[:60])
+    out = run_gpu(inst, F([[0, 0, -5]]), F([[0, 0, 1]]), np.zeros((1, 0), F), 8, 0.5, seed=1)
+    want = run_oracle(inst, UNIT, F([[0, 0, -5]]), F([[0, 0, 1]]), np.zeros((1, 0), F), 8, 0.5, 1)
+    assert inst.status() == 0
+    assert_same(out, want)
+    assert out[6].max() == 60                                                    # density_weight = patches the point lies in
+    for kw in (dict(cast_shadow_rays=True), dict(textures=["meshes/smooth_checkerboard.png"]), dict(auxiliary_meshes=[("a.ply", "")]),
+               dict(mesh_path="meshes/cloth_mesh.ply")):
+        with pytest.raises(_lib.NtxError) as e:
+            Instancer(UNIT["b_0"], UNIT["b_1"], transformations=[translate().tolist()], **kw)
+        assert e.value.code == _lib.NTX_E_UNSUPPORTED
+    with pytest.raises(_lib.NtxError):                                           # a singular patch matrix
+        Instancer(UNIT["b_0"], UNIT["b_1"], transformations=[np.zeros((4, 4)).tolist()])
+    # the list the reference's transformation_export_path writes (instancer.cpp:1040-1061) comes back as the same instancer
+    tr = [translate(x=.3, s=.5), translate(z=1)]
+    a = Instancer(UNIT["b_0"], UNIT["b_1"], transformations=[m.tolist() for m in tr], transformation_export_path=str(tmp_path / "t.json"))
+    assert np.allclose(np.asarray(json.load(open(tmp_path / "t.json")), F), np.stack(tr))
+    b = Instancer(UNIT["b_0"], UNIT["b_1"], transformations_path=str(tmp_path / "t.json"), patch_scale=0.5)
+    assert all(np.array_equal(x, y) for x, y in zip(a.matrices(), b.matrices())) and b.patch_scale == 0.5 and a.patch_scale == 1.0
+
+
+@pytest.mark.parametrize("npar,textures,blur", [((1, 6), ["", "", "", "", "light"], None), ((2, 3), ["", "", "light"], 0)])
+def test_instance_renderer_end_to_end(npar, textures, blur):
+    """Rays -> GPU instancer -> ntx_render_instanced without leaving HBM, against oracle instancer -> float64 oracle of the
+    InstanceRenderer tail (renderer.py:247-354), through the reference-shaped classes."""
+    from nerf_tex_amd.renderer import InstanceRenderer
+    model, mspec, wts = make_model(npar, dense_media=True)
+    P = sum(npar)
+    spec0 = random_scene(21, k=30, method="nearest", mesh=True)
+    box = dict(b_0=spec0.b_0.tolist(), b_1=spec0.b_1.tolist())
+    tr = [np.linalg.inv(m.astype(np.float64)).astype(F) for m in spec0.inv]
+    msh = (spec0.mesh_v, spec0.mesh_f)
+    inst = gpu_instancer(box, tr, textures=textures, instance_sampling_method="nearest", mesh=msh)
+    patch_scale, step, S = 0.35, 0.01, 256
+    r = InstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=patch_scale, step_size=step, blur_idx=blur,
+                         render_chunk=64, density_scale=40.0)
+    n = 150
+    o, d = random_rays(21, n)
+    tt = np.tile(F([[1.0, 2.0]]), (n, 1)); tt[7] = np.inf
+    rng = np.random.default_rng(2)
+    params = rng.uniform(0.2, 1, size=(1, P)).astype(F)
+    cone = rng.uniform(1e-3, 5e-3, size=(n, 1)).astype(F)
+    dv = torch.device("cuda", 0)
+    dd = lambda a: torch.as_tensor(a, device=dv)[None]
+    out = r(dd(o), dd(d), dd(tt), parameters=torch.as_tensor(params, device=dv), cone_scale=dd(cone), instancer_seed=77)
+    r.raise_if_nonfinite()
+    got = np.concatenate([out["color_pred"][0].cpu().numpy(), out["alpha_pred"][0].cpu().numpy()[:, None]], -1)
+    keep = np.isfinite(tt[:, 0])
+    ko = np.nonzero(keep)[0]
+    pr = np.repeat(params, len(ko), 0)
+    want = np.zeros((n, 4))
+    for c0 in range(0, len(ko), 64):                                            # the renderer's chunks key the draws
+        sl = ko[c0:c0 + 64]
+        b = run_oracle(inst, box, o[sl], d[sl], pr[:len(sl)], S, step, 77, "nearest", textures, False, msh, ray_index=(c0, len(sl), len(sl)))
+        rc, ra = orc.instance_evaluate_model(wts, mspec, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9], cone[sl], blur,
+                                             patch_scale, 40.0, True, False, False, (1., 1., 1.), None, dtype=np.float64)
+        want[sl, :3] = rc; want[sl, 3] = ra
+    assert orc.rel_linf(got, want) <= TOL
+    assert want[:, 3].max() > 0.5 and (want[:, 3] > 0).sum() > 40 and np.all(got[7] == 0)

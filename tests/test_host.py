@@ -21,7 +21,7 @@ def test_abi_exports_every_declared_symbol():
     raw = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_create_without_gpu_reports_no_device():
@@ -741,6 +741,8 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                    'int main(void) {\n'
                    '    ntx_model_desc d = {NTX_MODEL_PARAMNERF, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, NTX_POS_FOURIER};\n'
                    '    ntx_render_opts o = {sizeof(ntx_render_opts), 0.5f, 7u, 100, 800, 6400};\n'
+                   '    ntx_instancer_desc q = {sizeof(ntx_instancer_desc), {-1, -1, -1}, {1, 1, 1}, 7, 4, -1, 1, 0, 0, 1.0f};\n'
+                   '    if (ntx_instancer_count(NULL) != -1 || q.n_parameters != 7) return 3;\n'
                    '    long long counts[8], offs[8]; int eq, direct;\n'
                    '    if (ntx_gather_plan(642400, 800, 8, (int64_t *)counts, (int64_t *)offs, &eq, &direct) != NTX_OK) return 2;\n'
                    '    printf("%d %zu %lld %lld %lld %d %d %u\\n", ntx_abi_version(), ntx_weight_count(&d), (long long)ntx_shard_count(640000, 800, 8, 3),\n'
@@ -752,4 +754,45 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                     "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     # 803 rows of 800 over 8 ranks: ranks 0-2 hold 101 rows, the others 100 -> exact-count Send/Recv into staging, blocks at r * 80800
-    assert out == ["3", "683524", "80000", "80800", str(7 * 80800), "0", "0", "40"]
+    assert out == ["4", "683524", "80000", "80800", str(7 * 80800), "0", "0", "40"]
+
+
+def test_instancer_host_side(tmp_path):
+    """nerf_tex_amd.instancer without a GPU: the `textures` list (instancer.cpp:74-92), the PLY reader for the culling mesh (ascii and
+    binary_little_endian, extra properties, polygons fanned), the ABI v4 symbols and argument checks that need no device."""
+    import struct
+    from nerf_tex_amd import _lib, instancer as ins
+    assert ins.parse_textures(['', '', '', '', 'light']) == (7, 4, -1)            # config_carpet_render.py:86 without its image
+    assert ins.parse_textures(['', 'point']) == (5, 2, 1)                          # config_grass_render.py:93
+    assert ins.parse_textures([]) == (0, -1, -1)
+    with pytest.raises(_lib.NtxError) as e:
+        ins.parse_textures(['meshes/smooth_checkerboard.png'])
+    assert e.value.code == _lib.NTX_E_UNSUPPORTED
+    v = np.asarray([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0.5]], np.float32)
+    a = tmp_path / "a.ply"
+    a.write_text("ply\nformat ascii 1.0\ncomment made by hand\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                 "property float nx\nelement face 2\nproperty list uchar int vertex_indices\nend_header\n"
+                 + "".join(f"{p[0]} {p[1]} {p[2]} 0.5\n" for p in v) + "3 0 1 2\n4 0 1 2 3\n")
+    va, fa = ins.read_ply(str(a))
+    assert np.array_equal(va, v) and fa.tolist() == [[0, 1, 2], [0, 1, 2], [0, 2, 3]]
+    b = tmp_path / "b.ply"
+    hdr = ("ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty double x\nproperty float y\nproperty float z\nproperty uchar red\n"
+           "element face 2\nproperty list uchar uint vertex_indices\nproperty float quality\nend_header\n").encode()
+    body = b"".join(struct.pack("<dffB", p[0], p[1], p[2], 7) for p in v)
+    body += struct.pack("<B3If", 3, 0, 1, 2, 1.0) + struct.pack("<B4If", 4, 0, 1, 2, 3, 2.0)
+    b.write_bytes(hdr + body)
+    vb, fb = ins.read_ply(str(b))
+    assert np.array_equal(vb, v) and fb.tolist() == fa.tolist()
+    with pytest.raises(ValueError):
+        ins.read_ply(__file__)
+    # the C ABI refuses bad arguments before it looks for a device
+    import ctypes as C
+    h = C.c_void_p()
+    assert _lib.lib.ntx_instancer_create(None, None, 0, 0, C.byref(h)) == _lib.NTX_E_INVALID
+    d = _lib.InstancerDesc(); d.size = C.sizeof(_lib.InstancerDesc); d.cast_shadow_rays = 1
+    d.light_dir_parameter_idx = d.light_strength_parameter_idx = -1
+    assert _lib.lib.ntx_instancer_create(C.byref(d), None, 0, 0, C.byref(h)) == _lib.NTX_E_UNSUPPORTED
+    assert b"shadow" in _lib.lib.ntx_last_error()
+    d.cast_shadow_rays = 0; d.instance_sample_method = 3
+    assert _lib.lib.ntx_instancer_create(C.byref(d), None, 0, 0, C.byref(h)) == _lib.NTX_E_INVALID
+    assert _lib.lib.ntx_instancer_count(None) == -1
