@@ -392,7 +392,7 @@ int ntx_instancer_set_mesh(ntx_instancer *inst, const float *vertices, int64_t n
  * choice of (ray, step) from counter (step, ray lo, ray hi, 3); `opts` carries the ray index map (as for ntx_render_rays;
  * NULL = the call's own indices), so chunked or sharded calls draw what the whole image draws.
  * *status_flag (DEVICE, may be NULL) |= 1 when a ray had more than 200 face crossings (the rest were dropped, which ones is
- * unspecified -- as in the reference), |= 2 when a point lay in more than 64 patches at once.  1 <= n_pts <= 4096. */
+ * unspecified -- as in the reference).  1 <= n_pts <= 4096. */
 int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const float *rays_d, const float *parameters, int64_t n_rays,
                               int n_pts, float step_size, uint64_t seed, const ntx_render_opts *opts, float *rays_d_map, float *pts,
                               float *t, float *dists, float *color_last, float *alpha_last, float *alpha_weight,

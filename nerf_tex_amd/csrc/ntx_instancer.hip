@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -38,7 +39,6 @@ namespace ntx_inst {
 
 constexpr int MAX_HITS = 200;            // MAX_TOTAL_HITS, instancer.cpp:22
 constexpr int SORT_SLOTS = 256;          // MAX_HITS rounded up to whole waves
-constexpr int MAX_ACTIVE = 64;           // patches a sample may lie in at once: one id per lane
 constexpr int MAX_PARAMS = 32;
 constexpr float T_FAR = 100.0f;          // init_ray(..., 0, 100, ...), instancer.cpp:776
 constexpr uint32_t INF_BITS = 0x7f800000u;
@@ -83,8 +83,8 @@ __device__ __forceinline__ void normalized(float &x, float &y, float &z) {   // 
 // all (ray, instance) pairs: what rtcIntersect1 with the all-hits filter reports (instancer.cpp:779, 526-541)
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int n_rays,
-                                                        const float *__restrict__ mats, int n_inst, int per_wave, Box box,
-                                                        uint32_t *__restrict__ count, uint2 *__restrict__ hits) {
+                                                        const float *__restrict__ mats, const float *__restrict__ spheres, int n_inst,
+                                                        int per_wave, Box box, uint32_t *__restrict__ count, uint2 *__restrict__ hits) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ray = blockIdx.x * 64 + lane;
@@ -94,8 +94,15 @@ __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict_
     const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
     const int k0 = (blockIdx.y * 4 + wave) * per_wave;
     const int k1 = k0 + per_wave < n_inst ? k0 + per_wave : n_inst;
+    const float dd2 = (dx * dx + dy * dy) + dz * dz;
     for (int k = k0; k < k1; ++k) {
-        const float *m = mats + (size_t)k * 12;          // wave-uniform: scalar loads
+        // a sphere around the instanced box (centre, radius^2 widened by 1e-3): when none of the wave's 64 rays comes near it the
+        // instance is skipped -- a wave holds neighbouring rays, so this is the fate of most instances
+        const float *sp = spheres + (size_t)k * 4;       // wave-uniform: scalar loads
+        const float cx = sp[0] - ox, cy = sp[1] - oy, cz = sp[2] - oz;
+        const float qx = cy * dz - cz * dy, qy = cz * dx - cx * dz, qz = cx * dy - cy * dx;
+        if (!__any((qx * qx + qy * qy) + qz * qz <= sp[3] * dd2)) continue;
+        const float *m = mats + (size_t)k * 12;
         float ol[3], dl[3];
         affine(m, ox, oy, oz, ol);
         linear34(m, dx, dy, dz, dl);
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict_
     }
 }
 
-// closest crossing of the instancer mesh per ray (Moeller-Trumbore, no culling); tris[f] = {v0, v1 - v0, v2 - v0}
+// closest crossing of the instancer mesh per ray (Moeller-Trumbore, no culling); tris[f] = {v0, v1 - v0, v2 - v0, sphere centre, radius^2}
 __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int n_rays,
                                                         const float *__restrict__ tris, int n_tri, int per_wave, uint32_t *__restrict__ t_mesh) {
     const int lane = threadIdx.x & 63;
@@ -139,8 +146,14 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
     const int f0 = (blockIdx.y * 4 + wave) * per_wave;
     const int f1 = f0 + per_wave < n_tri ? f0 + per_wave : n_tri;
     float best = INFINITY;
+    const float dd2 = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
     for (int f = f0; f < f1; ++f) {
-        const float *tr = tris + (size_t)f * 9;
+        const float *tr = tris + (size_t)f * 13;
+        {   // the triangle's sphere, as in inst_hits_kernel
+            const float cx = tr[9] - o[0], cy = tr[10] - o[1], cz = tr[11] - o[2];
+            const float qx = cy * d[2] - cz * d[1], qy = cz * d[0] - cx * d[2], qz = cx * d[1] - cy * d[0];
+            if (!__any((qx * qx + qy * qy) + qz * qz <= tr[12] * dd2)) continue;
+        }
         const float *v0 = tr, *e1 = tr + 3, *e2 = tr + 6;
         const float p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
         const float det = (e1[0] * p[0] + e1[1] * p[1]) + e1[2] * p[2];
@@ -172,29 +185,33 @@ struct MarchArgs {
     float step_size, blend_range;
     uint32_t seed_lo, seed_hi;
     int64_t idx0, idx_stride; uint32_t idx_run;
+    int debug_skip;   // development (NERFTEX_INST_DEBUG): leave parts of the kernel out to time the rest; results are then wrong
 };
 
-// the active set of instancer.cpp:800-826 / 989-1009: ascending ids, one per lane (std::set order)
-struct Active {
-    uint32_t id;      // lane l < n holds the l-th smallest id
-    int n;
-    __device__ __forceinline__ bool toggle(uint32_t x, int lane, bool *overflow) {   // true = x was inside and left
-        const uint64_t in = __ballot(lane < n && id == x);
-        if (in) {
-            const int pos = __builtin_ctzll(in);
-            const uint32_t nxt = __shfl_down(id, 1);
-            if (lane >= pos) id = nxt;
-            --n;
-            return true;
-        }
-        if (n >= MAX_ACTIVE) { *overflow = true; return false; }
-        const int pos = __builtin_popcountll(__ballot(lane < n && id < x));
-        const uint32_t prv = __shfl_up(id, 1);
-        if (lane > pos) id = prv;
-        if (lane == pos) id = x;
-        ++n;
-        return false;
-    }
+// The reference walks the sorted crossings with a std::set of the patches it is inside (instancer.cpp:800-826, 870-1010): a crossing
+// of a patch that is in the set takes it out, any other puts it in.  Here the walk is taken apart so that nothing but a few float
+// additions is left sequential:
+//   events     the sorted crossings; event e ENTERS its patch when an even number of earlier events name the same patch (lane per event)
+//   intervals  an entering event b and the next event e' of the same patch (or the end of the list): the patch is in the set in the
+//              GAPS b < j <= e', gap j being the stretch in front of event j; kept in ascending patch order (std::set's order)
+//   gaps       the number of patches in the set (a count of +-1 per event), the segment offset in force and the first marching step
+//              of the gap -- the one scalar loop, a handful of operations per event
+//   steps      lane per step: its gap by bisection of the gaps' first steps, then one pass over the intervals for the patch it is
+//              given to.  64 consecutive steps per pass whatever gaps they fall in.
+struct WaveLds {
+    float ev_t[MAX_HITS];
+    uint32_t ev_id[MAX_HITS];
+    uint32_t ev_info[MAX_HITS + 4];       // bit 0: the event enters its patch; bits 8..: patches in the set in the gap in front of it
+    float g_off[MAX_HITS + 4];            // segment_offset in force in gap j (instancer.cpp:1001)
+    union {
+        int g_step0[MAX_HITS + 4];        // first step emitted in gap j; [n_gaps] = number of steps emitted
+        struct { float ts[MAX_HITS / 2 + 2], te[MAX_HITS / 2]; } seg;   // before that: start (then offset) and end of the segments
+    } gs;
+    union {
+        struct { float t[SORT_SLOTS]; uint32_t id[SORT_SLOTS]; } raw;                        // the hit list as the hit kernel left it
+        struct { uint32_t id[MAX_HITS], be[MAX_HITS]; float ox[MAX_HITS], oy[MAX_HITS], oz[MAX_HITS]; } iv;   // intervals, by patch
+    } u;
+    float par[MAX_PARAMS];
 };
 
 __device__ __forceinline__ float mean_distance(float mu_f, float hw_f) {   // instancer.cpp:746-748 (double inside)
@@ -202,83 +219,184 @@ __device__ __forceinline__ float mean_distance(float mu_f, float hw_f) {   // in
     return (float)(mu + 2 * mu * (hw * hw) / (3 * (mu * mu) + hw * hw));
 }
 
+// fill row[f0 .. f1) with pattern[f % period] (period <= MAX_PARAMS, pattern in LDS or registers through `at`)
+template <typename At>
+__device__ __forceinline__ void fill_pattern(float *row, int f0, int f1, int period, int lane, At at) {
+    // head up to a 16-byte boundary, body as float4, tail
+    const int head = f0 + (int)(((16u - (uint32_t)((uintptr_t)(row + f0) & 15u)) & 15u) >> 2);
+    const int h1 = head < f1 ? head : f1;
+    for (int f = f0 + lane; f < h1; f += 64) __builtin_nontemporal_store(at(f % period), row + f);
+    const int nvec = (f1 - h1) >> 2;
+    if (nvec > 0) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 *vp = reinterpret_cast<f32x4 *>(row + h1);
+        int r = (h1 + 4 * lane) % period;
+        const int inc = 256 % period;
+        for (int v = lane; v < nvec; v += 64) {
+            f32x4 x;
+            int q = r;
+            x.x = at(q); q = q + 1 == period ? 0 : q + 1;
+            x.y = at(q); q = q + 1 == period ? 0 : q + 1;
+            x.z = at(q); q = q + 1 == period ? 0 : q + 1;
+            x.w = at(q);
+            __builtin_nontemporal_store(x, vp + v);
+            r += inc; r = r >= period ? r - period : r;
+        }
+    }
+    for (int f = h1 + 4 * nvec + lane; f < f1; f += 64) __builtin_nontemporal_store(at(f % period), row + f);
+}
+
 __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
-    __shared__ float s_t[4][SORT_SLOTS];
-    __shared__ uint32_t s_id[4][SORT_SLOTS];
-    __shared__ float s_ts[4][MAX_HITS];
-    __shared__ uint32_t s_ids[4][MAX_HITS];
-    __shared__ float s_par[4][MAX_PARAMS];
+    __shared__ WaveLds lds[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ray = blockIdx.x * 4 + wave;
     if (ray >= a.n_rays) return;
+    WaveLds &L = lds[wave];
     const int S = a.n_pts, P = a.n_params;
     const float h = a.step_size;
     const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
     const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
     float ndx = dx, ndy = dy, ndz = dz;
     normalized(ndx, ndy, ndz);                                             // getDir: dir.normalized(), instancer.cpp:562
-    if (lane < P) s_par[wave][lane] = a.params[(size_t)ray * P + lane];
+    if (lane < P) L.par[lane] = a.params[(size_t)ray * P + lane];
 
     // ---- the hit list, sorted by (t, instID) (instancer.cpp:441-452, 787) -------------------------------------------------
     const uint32_t raw = a.count[ray];
-    const int m = raw < (uint32_t)MAX_HITS ? (int)raw : MAX_HITS;
-    bool overflow_hits = raw > (uint32_t)MAX_HITS, overflow_active = false;
-    for (int e = lane; e < m; e += 64) {
+    const int m_all = raw < (uint32_t)MAX_HITS ? (int)raw : MAX_HITS;
+    const bool overflow_hits = raw > (uint32_t)MAX_HITS;
+    for (int e = lane; e < m_all; e += 64) {
         const uint2 hv = a.hits[(size_t)ray * MAX_HITS + e];
-        s_t[wave][e] = __builtin_bit_cast(float, hv.x);
-        s_id[wave][e] = hv.y;
+        L.u.raw.t[e] = __builtin_bit_cast(float, hv.x);
+        L.u.raw.id[e] = hv.y;
     }
-    __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < m; e += 64) {
-        const float te = s_t[wave][e];
-        const uint32_t ie = s_id[wave][e];
+    for (int e = lane; e < m_all; e += 64) {
+        const float te = L.u.raw.t[e];
+        const uint32_t ie = L.u.raw.id[e];
         int rank = 0;
-        for (int k = 0; k < m; ++k) {
-            const float tk = s_t[wave][k];
-            const uint32_t ik = s_id[wave][k];
+        #pragma unroll 8
+        for (int k = 0; k < m_all; ++k) {
+            const float tk = L.u.raw.t[k];
+            const uint32_t ik = L.u.raw.id[k];
             rank += (tk < te || (tk == te && (ik < ie || (ik == ie && k < e)))) ? 1 : 0;
         }
-        s_ts[wave][rank] = te;
-        s_ids[wave][rank] = ie;
+        L.ev_t[rank] = te;
+        L.ev_id[rank] = ie;
     }
-    __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    const float *ts = s_ts[wave];
-    const uint32_t *ids = s_ids[wave];
     const uint32_t tm_bits = a.t_mesh ? a.t_mesh[ray] : INF_BITS;
     const bool has_mesh = tm_bits != INF_BITS;
     const float t_mesh = __builtin_bit_cast(float, tm_bits);
-    const bool any_hit = m > 0 || has_mesh;
+    const bool any_hit = m_all > 0 || has_mesh;
+    // the mesh hit sorts behind the crossings at its own t (instID = invalid sorts last) and ends the walk (:804-811, 988)
+    int m = m_all;
+    if (has_mesh) {
+        int c = 0;
+        for (int e = lane; e < m_all; e += 64) c += L.ev_t[e] <= t_mesh ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        m = c;
+    }
 
-    // ---- ray segments inside the union of the boxes (instancer.cpp:800-826) -----------------------------------------------
-    Active act{0u, 0};
-    float total = 0.0f, t_entry = 0.0f;
-    for (int j = 0; j < m; ++j) {
-        const float tj = ts[j];
-        if (has_mesh && tj > t_mesh) break;             // the mesh hit sorts in front of this one (instID = invalid sorts last on ties)
-        const bool had = act.n == 0;
-        if (act.toggle(ids[j], lane, &overflow_active)) {
-            if (act.n == 0) total = total + (tj - t_entry);
-        } else if (had) {
-            t_entry = tj;
+    if (a.debug_skip & 4) return;
+    // ---- events: entering or leaving, and who pairs with whom ----------------------------------------------------------------
+    // (the raw list is dead: its memory holds the intervals from here on)
+    uint32_t my_next[4], my_enter[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q;
+        my_next[q] = (uint32_t)m; my_enter[q] = 0;
+        if (e < m) {
+            const uint32_t ie = L.ev_id[e];
+            int before = 0, next = m;
+            #pragma unroll 8
+            for (int k = 0; k < e; ++k) before += L.ev_id[k] == ie ? 1 : 0;
+            #pragma unroll 8
+            for (int k = m - 1; k > e; --k) next = L.ev_id[k] == ie ? k : next;
+            my_next[q] = (uint32_t)next; my_enter[q] = (before & 1) ? 0u : 1u;
+            L.ev_info[e] = my_enter[q];
         }
     }
-    if (has_mesh && act.n > 0) total = total + (t_mesh - t_entry);
-    act.n = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (a.debug_skip & 8) return;
+    // intervals in ascending patch order: rank of an entering event among the entering events by (patch, event)
+    uint64_t enter_mask[4];
+    int n_int = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { enter_mask[q] = __ballot(my_enter[q] != 0); n_int += __builtin_popcountll(enter_mask[q]); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q;
+        if (e < m && my_enter[q]) {
+            const uint32_t ie = L.ev_id[e];
+            int rank = 0;
+            #pragma unroll 8
+            for (int k = 0; k < m; ++k) {
+                const uint32_t ik = L.ev_id[k];
+                rank += ((L.ev_info[k] & 1u) && (ik < ie || (ik == ie && k < e))) ? 1 : 0;
+            }
+            const float *og = a.origins + (size_t)ie * 3;
+            L.u.iv.id[rank] = ie;
+            L.u.iv.be[rank] = (uint32_t)e | (my_next[q] << 16);
+            L.u.iv.ox[rank] = og[0]; L.u.iv.oy[rank] = og[1]; L.u.iv.oz[rank] = og[2];
+        }
+    }
+
+    if (a.debug_skip & 16) return;
+    // ---- gaps and segments, lane per gap ------------------------------------------------------------------------------------
+    // gap j = the stretch in front of event j (j = m: in front of the mesh hit).  Patches in the set there = 2 * (entering events
+    // before j) - j.  A SEGMENT of the union of the boxes (instancer.cpp:800-826) starts at an entering event that finds the set
+    // empty and ends at a leaving event that empties it; starts and ends are compacted by ballot and the one sequential thing
+    // left is the sum over segments (`cleared`, :996, and with the stretch up to the mesh `total_segment_length`, :808, 817).
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int cnt_q[4], seg_q[4];                       // patches in the set in gap e, the segment the gap lies in
+    int n_starts = 0, n_ends = 0;
+    {
+        int enters_before = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane + 64 * q;
+            cnt_q[q] = 2 * (enters_before + __builtin_popcountll(enter_mask[q] & lt)) - e;
+            enters_before += __builtin_popcountll(enter_mask[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane + 64 * q;
+            const bool is_start = e < m && my_enter[q] && cnt_q[q] == 0;
+            const bool is_end = e < m && !my_enter[q] && cnt_q[q] == 1;
+            const uint64_t sm = __ballot(is_start), em = __ballot(is_end);
+            const float te = e < m ? L.ev_t[e] : 0.0f;
+            if (is_start) L.gs.seg.ts[n_starts + __builtin_popcountll(sm & lt)] = te;
+            if (is_end) L.gs.seg.te[n_ends + __builtin_popcountll(em & lt)] = te;
+            seg_q[q] = n_starts + __builtin_popcountll(sm & lt) - 1;         // starts among the events before e, less one
+            n_starts += __builtin_popcountll(sm);
+            n_ends += __builtin_popcountll(em);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float total = 0.0f;
+    {
+        float cleared = 0.0f;
+        for (int i = 0; i < n_starts; ++i) {
+            const float ts = L.gs.seg.ts[i];
+            L.gs.seg.ts[i] = ts - cleared;                                   // segment_offset of the segment, :1001
+            if (i < n_ends) cleared = cleared + (L.gs.seg.te[i] - ts);      // :996 = :817
+            else if (has_mesh) { total = cleared + (t_mesh - ts); }         // :808: the mesh closes the open segment
+        }
+        if (!(n_starts > n_ends && has_mesh)) total = cleared;
+    }
+    __builtin_amdgcn_wave_barrier();
 
     // ---- number of steps, dists (instancer.cpp:840-859) -------------------------------------------------------------------
+    const int64_t gray = global_index(a.idx0, a.idx_run, a.idx_stride, ray);
     int n_steps = 0;
     float t_offset = 0.0f, last_dist = 0.0f;
-    bool single = false;
     if (total > 0.0f) {
-        const int64_t gray = global_index(a.idx0, a.idx_run, a.idx_stride, ray);
         const float u = uniform01(philox4x32_10(0u, (uint32_t)gray, (uint32_t)((uint64_t)gray >> 32), 2u, a.seed_lo, a.seed_hi));
         const uint32_t necessary = (uint32_t)(total / h);
         n_steps = necessary < (uint32_t)S ? (int)necessary : S;
         if (n_steps == 0) {
-            single = true; last_dist = total; t_offset = u * total; n_steps = 1;
+            last_dist = total; t_offset = u * total; n_steps = 1;
         } else {
             last_dist = (h + total) - (float)n_steps * h;
             t_offset = u * h;
@@ -286,148 +404,225 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
     }
     {
         float *row = a.dists + (size_t)ray * S;
-        for (int s = lane; s < S; s += 64) row[s] = s < n_steps - 1 ? h : (s == n_steps - 1 ? last_dist : 0.0f);
+        for (int s = lane; s < S; s += 64) __builtin_nontemporal_store(s < n_steps - 1 ? h : (s == n_steps - 1 ? last_dist : 0.0f), row + s);
     }
-    (void)single;
 
-    // ---- marching: steps handed out 64 at a time between two events (instancer.cpp:870-1010) ------------------------------
-    const int64_t gray = global_index(a.idx0, a.idx_run, a.idx_stride, ray);
-    const float lx = a.light_dir_idx >= 0 ? s_par[wave][a.light_dir_idx] : 0.0f;
-    const float ly = a.light_dir_idx >= 0 ? s_par[wave][a.light_dir_idx + 1] : 0.0f;
-    const float lz = a.light_dir_idx >= 0 ? s_par[wave][a.light_dir_idx + 2] : 0.0f;
-    const float lstr = a.light_strength_idx >= 0 ? s_par[wave][a.light_strength_idx] : 0.0f;
-    float segment_offset = 0.0f, cleared = 0.0f;
-    t_entry = 0.0f;
+    if (a.debug_skip & 32) return;
+    // ---- first step of every gap (the loop of instancer.cpp:870-1010 without its body) -------------------------------------
+    // The reference emits, in gap j, the steps from its running counter on while t_pt(step) < t_j.  t_pt rises with the step, so
+    // with F_j = the number of steps s >= 0 with t_pt(s) < t_j under the gap's segment offset, the counter behind gap j is
+    // max(counter, min(F_j, n_steps)): a running maximum over the gaps that lie inside a patch.
+    const int n_gaps = m + (has_mesh ? 1 : 0);
     int step = 0;
-    for (int j = 0; j <= m && step < n_steps; ++j) {
-        const bool is_mesh = j == m || (has_mesh && ts[j] > t_mesh);
-        if (is_mesh && !has_mesh) break;
-        const float tj = is_mesh ? t_mesh : ts[j];
-        while (act.n > 0) {
-            const int s = step + lane;
-            const float t_mu = ((float)s * h + t_offset) + segment_offset;
-            const float t_pt = a.use_mean ? mean_distance(t_mu, h) : t_mu;
-            const uint64_t ok = __ballot(s < n_steps && t_pt < tj);
-            const int c = ~ok == 0 ? 64 : __builtin_ctzll(~ok);
-            if (c == 0) break;
-            // every lane computes (shuffles and readlanes stay in uniform control flow); lanes < c store
-            const float px = ox + t_pt * dx, py = oy + t_pt * dy, pz = oz + t_pt * dz;          // getPtOnRay
-            uint32_t inst = (uint32_t)__builtin_amdgcn_readlane((int)act.id, 0);
-            float weight = 1.0f;
-            if (act.n > 1) {
-                if (a.method == 0) {                                                            // sampleRandom, :672-677
-                    const float uc = uniform01(philox4x32_10((uint32_t)s, (uint32_t)gray, (uint32_t)((uint64_t)gray >> 32), 3u, a.seed_lo, a.seed_hi));
-                    int pick = (int)(uc * (float)act.n);
-                    pick = pick < act.n - 1 ? pick : act.n - 1;
-                    inst = __shfl(act.id, pick);
-                    weight = (float)act.n;
-                } else {
-                    float best = INFINITY;
-                    for (int q = 0; q < act.n; ++q) {                                           // sampleNearest, :681-692
-                        const uint32_t cid = (uint32_t)__builtin_amdgcn_readlane((int)act.id, q);
-                        const float *og = a.origins + (size_t)cid * 3;
-                        const float ex = px - og[0], ey = py - og[1], ez = pz - og[2];
-                        const float dd = __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
-                        if (dd < best) { best = dd; inst = cid; }
-                    }
-                    if (a.method == 2) {                                                        // sampleNearestBlend, :696-713
-                        float tot = 0.0f;
-                        for (int q = 0; q < act.n; ++q) {
-                            const uint32_t cid = (uint32_t)__builtin_amdgcn_readlane((int)act.id, q);
-                            const float *og = a.origins + (size_t)cid * 3;
-                            const float ex = px - og[0], ey = py - og[1], ez = pz - og[2];
-                            const float w = (a.blend_range + best) - __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
-                            tot = tot + (w > 0.0f ? w : 0.0f);
-                        }
-                        const float uc = uniform01(philox4x32_10((uint32_t)s, (uint32_t)gray, (uint32_t)((uint64_t)gray >> 32), 3u, a.seed_lo, a.seed_hi));
-                        const float target = uc * tot;
-                        float acc = 0.0f, wp = 0.0f;
-                        bool found = false;
-                        for (int q = 0; q < act.n; ++q) {
-                            const uint32_t cid = (uint32_t)__builtin_amdgcn_readlane((int)act.id, q);
-                            const float *og = a.origins + (size_t)cid * 3;
-                            const float ex = px - og[0], ey = py - og[1], ez = pz - og[2];
-                            float w = (a.blend_range + best) - __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
-                            w = w > 0.0f ? w : 0.0f;
-                            acc = acc + w;
-                            if (!found && (target < acc || q == act.n - 1)) { found = true; inst = cid; wp = w; }
-                        }
-                        weight = tot / wp;                                                      // 1 / probability
-                    }
-                }
+    {
+        float off_q[4];
+        int f_q[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q;
+            const bool gap = j < n_gaps && cnt_q[q] > 0;
+            off_q[q] = gap ? L.gs.seg.ts[seg_q[q]] : 0.0f;
+            f_q[q] = 0;
+            if (gap) {
+                const float tj = j == m ? t_mesh : L.ev_t[j];
+                const float off = off_q[q];
+                auto before = [&](int s) {
+                    const float t_mu = ((float)s * h + t_offset) + off;
+                    return (a.use_mean ? mean_distance(t_mu, h) : t_mu) < tj;
+                };
+                const float x = ((tj - off) - t_offset) / h;
+                int s0 = x > 0.0f ? (x < (float)n_steps ? (int)x : n_steps) : 0;
+                while (s0 > 0 && !before(s0 - 1)) --s0;
+                while (s0 < n_steps && before(s0)) ++s0;
+                f_q[q] = s0;
             }
-            if (lane < c) {
-                const float *mi = a.mats + (size_t)inst * 12;
-                const float *di = a.dirs + (size_t)inst * 9;
-                float o3[3];
-                const size_t k = (size_t)ray * S + s;
-                a.t[k] = t_mu;
-                a.alpha_weight[k] = weight;
-                a.instance_id[k] = (int32_t)inst;
-                affine(mi, px, py, pz, o3);                                                     // getPt
-                a.pts[3 * k] = o3[0]; a.pts[3 * k + 1] = o3[1]; a.pts[3 * k + 2] = o3[2];
-                linear33(di, ndx, ndy, ndz, o3);                                                // getDir
-                a.rays_d_map[3 * k] = o3[0]; a.rays_d_map[3 * k + 1] = o3[1]; a.rays_d_map[3 * k + 2] = o3[2];
-                float *prow = a.params_map + k * P;
-                for (int p = 0; p < P; ++p) prow[p] = s_par[wave][p];
-                if (a.light_dir_idx >= 0) {                                                     // getShadowedLightDir(false, ...), :571-581
-                    float sx = lx, sy = ly, sz = lz;
-                    if (a.light_strength_idx >= 0) { sx = lx - px; sy = ly - py; sz = lz - pz; }
-                    normalized(sx, sy, sz);
-                    linear33(di, sx, sy, sz, o3);
-                    prow[a.light_dir_idx] = o3[0]; prow[a.light_dir_idx + 1] = o3[1]; prow[a.light_dir_idx + 2] = o3[2];
-                }
-                if (a.light_strength_idx >= 0) {                                                // getLightStrength, :583-588
-                    const float ex = lx - px, ey = ly - py, ez = lz - pz;
-                    const float d2 = (ex * ex + ey * ey) + ez * ez;
-                    prow[a.light_strength_idx] = (float)((double)lstr / (4 * M_PI * (double)d2 + (double)1e-6f));
-                }
-            }
-            step += c;
-            if (c < 64) break;
         }
-        if (is_mesh) break;                                                                     // :988
-        const bool had = act.n == 0;
-        if (act.toggle(ids[j], lane, &overflow_active)) {
-            if (act.n == 0) cleared = cleared + (tj - t_entry);                                 // :996
-        } else if (had) {
-            segment_offset = tj - cleared;                                                      // :1001
-            t_entry = tj;
+        __builtin_amdgcn_wave_barrier();                                     // the segment table is dead: g_step0 takes its place
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q;
+            int v = f_q[q];
+            for (int o = 1; o < 64; o <<= 1) {                                // running maximum over the lanes
+                const int w = __shfl_up(v, o);
+                if (lane >= o) v = w > v ? w : v;
+            }
+            v = v > step ? v : step;
+            int ex = __shfl_up(v, 1);
+            if (lane == 0) ex = step;
+            if (j <= n_gaps) { L.gs.g_step0[j] = ex; L.g_off[j] = off_q[q]; }
+            step = __shfl(v, 63);
+        }
+        if (lane == 0) L.gs.g_step0[n_gaps] = step;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    if (a.debug_skip & 64) return;
+    // ---- steps: lane per step (instancer.cpp:878-986) ----------------------------------------------------------------------
+    const float lx = a.light_dir_idx >= 0 ? L.par[a.light_dir_idx] : 0.0f;
+    const float ly = a.light_dir_idx >= 0 ? L.par[a.light_dir_idx + 1] : 0.0f;
+    const float lz = a.light_dir_idx >= 0 ? L.par[a.light_dir_idx + 2] : 0.0f;
+    const float lstr = a.light_strength_idx >= 0 ? L.par[a.light_strength_idx] : 0.0f;
+    for (int base = 0; base < ((a.debug_skip & 2) ? 0 : step); base += 64) {
+        const int s = base + lane;
+        const bool live = s < step;
+        // the gap of the step: g_step0[j] <= s < g_step0[j + 1]
+        int lo = 0, hi = n_gaps;                                               // g_step0[lo] <= s < g_step0[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (L.gs.g_step0[mid] <= s) lo = mid; else hi = mid;
+        }
+        const int j = lo;
+        const float t_mu = ((float)s * h + t_offset) + L.g_off[j];
+        const float t_pt = a.use_mean ? mean_distance(t_mu, h) : t_mu;
+        const float px = ox + t_pt * dx, py = oy + t_pt * dy, pz = oz + t_pt * dz;              // getPtOnRay
+        // the patches the point lies in, in ascending order: b < j <= e'.  Only intervals that reach into the gaps of THESE 64
+        // steps are looked at: a ballot over the intervals (lane per interval), then a loop over its set bits
+        const int n_here = step - base < 64 ? step - base : 64;
+        const int jlo = __builtin_amdgcn_readfirstlane(j), jhi = __builtin_amdgcn_readlane(j, n_here - 1);
+        uint64_t cand[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int q = lane + 64 * g;
+            bool c = false;
+            if (q < n_int) {
+                const uint32_t be = L.u.iv.be[q];
+                c = (int)(be & 0xffffu) < jhi && jlo <= (int)(be >> 16);
+            }
+            cand[g] = __ballot(c);
+        }
+        auto for_each_candidate = [&](auto body) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint64_t mk = cand[g];
+                while (mk) {
+                    const int q = 64 * g + __builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    const uint32_t be = L.u.iv.be[q];
+                    body(q, (int)(be & 0xffffu) < j && j <= (int)(be >> 16));
+                }
+            }
+        };
+        uint32_t inst = 0;
+        float weight = 1.0f;
+        int cnt = 0;
+        if (a.method == 0) {                                                                    // sampleRandom, :672-677
+            for_each_candidate([&](int, bool in) { cnt += in ? 1 : 0; });
+            const float uc = uniform01(philox4x32_10((uint32_t)s, (uint32_t)gray, (uint32_t)((uint64_t)gray >> 32), 3u, a.seed_lo, a.seed_hi));
+            int pick = cnt > 1 ? (int)(uc * (float)cnt) : 0;
+            pick = pick < cnt - 1 ? pick : cnt - 1;
+            int seen = 0;
+            for_each_candidate([&](int q, bool in) {
+                if (in && seen == pick) inst = L.u.iv.id[q];
+                seen += in ? 1 : 0;
+            });
+            weight = cnt > 1 ? (float)cnt : 1.0f;
+        } else {
+            float best = INFINITY;
+            for_each_candidate([&](int q, bool in) {                                            // sampleNearest, :681-692
+                const float ex = px - L.u.iv.ox[q], ey = py - L.u.iv.oy[q], ez = pz - L.u.iv.oz[q];
+                const float dd = __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
+                if (in) {
+                    if (cnt == 0 || dd < best) { inst = L.u.iv.id[q]; }
+                    best = dd < best ? dd : best;
+                    ++cnt;
+                }
+            });
+            if (a.method == 2 && __any(cnt > 1)) {                                              // sampleNearestBlend, :696-713
+                float tot = 0.0f;
+                for_each_candidate([&](int q, bool in) {
+                    const float ex = px - L.u.iv.ox[q], ey = py - L.u.iv.oy[q], ez = pz - L.u.iv.oz[q];
+                    const float w = (a.blend_range + best) - __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
+                    if (in) tot = tot + (w > 0.0f ? w : 0.0f);
+                });
+                const float uc = uniform01(philox4x32_10((uint32_t)s, (uint32_t)gray, (uint32_t)((uint64_t)gray >> 32), 3u, a.seed_lo, a.seed_hi));
+                const float target = uc * tot;
+                float acc = 0.0f, wp = 0.0f;
+                bool found = false;
+                int seen = 0;
+                uint32_t pick_id = inst;
+                for_each_candidate([&](int q, bool in) {
+                    const float ex = px - L.u.iv.ox[q], ey = py - L.u.iv.oy[q], ez = pz - L.u.iv.oz[q];
+                    float w = (a.blend_range + best) - __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
+                    w = w > 0.0f ? w : 0.0f;
+                    if (in) {
+                        acc = acc + w;
+                        ++seen;
+                        if (!found && (target < acc || seen == cnt)) { found = true; pick_id = L.u.iv.id[q]; wp = w; }
+                    }
+                });
+                if (cnt > 1) { inst = pick_id; weight = tot / wp; }                             // 1 / probability
+            }
+        }
+        // every lane computes its sample (lanes behind the last step work on a clamped patch index and store nothing); the rows go
+        // out DENSE: element f of the 64 samples' flat [64 x 3] / [64 x P] block is fetched from lane f / 3 (f / P) by a shuffle,
+        // so that a store instruction writes 256 consecutive bytes whatever the width of the row
+        const float *mi = a.mats + (size_t)inst * 12;
+        const float *di = a.dirs + (size_t)inst * 9;
+        float p3[3], d3[3], l3[3] = {0.0f, 0.0f, 0.0f}, lst = 0.0f;
+        affine(mi, px, py, pz, p3);                                                             // getPt
+        linear33(di, ndx, ndy, ndz, d3);                                                        // getDir
+        if (a.light_dir_idx >= 0) {                                                             // getShadowedLightDir(false, ...), :571-581
+            float sx = lx, sy = ly, sz = lz;
+            if (a.light_strength_idx >= 0) { sx = lx - px; sy = ly - py; sz = lz - pz; }
+            normalized(sx, sy, sz);
+            linear33(di, sx, sy, sz, l3);
+        }
+        if (a.light_strength_idx >= 0) {                                                        // getLightStrength, :583-588
+            const float ex = lx - px, ey = ly - py, ez = lz - pz;
+            const float d2 = (ex * ex + ey * ey) + ez * ez;
+            lst = (float)((double)lstr / (4 * M_PI * (double)d2 + (double)1e-6f));
+        }
+        const size_t k0 = (size_t)ray * S + base;
+        if (live) {
+            a.t[k0 + lane] = t_mu;
+            a.alpha_weight[k0 + lane] = weight;
+            a.instance_id[k0 + lane] = (int32_t)inst;
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int f = it * 64 + lane;
+            const int src = (int)(((uint32_t)f * 21846u) >> 16);                                 // f / 3 for f < 192
+            const int comp = f - 3 * src;
+            const float pa = __shfl(p3[0], src), pb = __shfl(p3[1], src), pc = __shfl(p3[2], src);
+            const float da = __shfl(d3[0], src), db = __shfl(d3[1], src), dc = __shfl(d3[2], src);
+            if (src < n_here) {
+                a.pts[3 * k0 + f] = comp == 0 ? pa : (comp == 1 ? pb : pc);
+                a.rays_d_map[3 * k0 + f] = comp == 0 ? da : (comp == 1 ? db : dc);
+            }
+        }
+        if (P > 0) {
+            const float inv_p = 1.0f / (float)P;
+            float *prow = a.params_map + k0 * P;
+            for (int it = 0; it < P; ++it) {
+                const int f = it * 64 + lane;
+                const int src = (int)(((float)f + 0.5f) * inv_p);                               // f / P, exact for f < 2048, P <= 32
+                const int comp = f - P * src;
+                const float la = __shfl(l3[0], src), lb = __shfl(l3[1], src), lc = __shfl(l3[2], src), ls = __shfl(lst, src);
+                float v = L.par[comp];
+                const int lc_i = comp - a.light_dir_idx;
+                if (a.light_dir_idx >= 0 && lc_i >= 0 && lc_i < 3) v = lc_i == 0 ? la : (lc_i == 1 ? lb : lc);
+                if (comp == a.light_strength_idx) v = ls;
+                if (src < n_here) prow[f] = v;
+            }
         }
     }
 
     // ---- what instancer.pyx:41-50 leaves in the rows behind the last emitted step -----------------------------------------
-    {
+    if (!(a.debug_skip & 1)) {
         const size_t base = (size_t)ray * S;
-        for (int s = step + lane; s < S; s += 64) {
-            a.t[base + s] = 0.0f;
-            a.alpha_weight[base + s] = 1.0f;
-            a.instance_id[base + s] = 0;
-        }
-        float *pr = a.pts + base * 3, *dr = a.rays_d_map + base * 3;
-        const float d3[3] = {dx, dy, dz};
-        int rem = (step * 3 + lane) % 3;
-        for (int f = step * 3 + lane; f < S * 3; f += 64) {
-            pr[f] = 0.0f;
-            dr[f] = rem == 0 ? d3[0] : (rem == 1 ? d3[1] : d3[2]);
-            rem = (rem + 1) % 3;                                                                // 64 % 3 = 1
-        }
-        if (P > 0) {
-            float *qr = a.params_map + base * P;
-            const int inc = 64 % P;
-            int pm = (step * P + lane) % P;
-            for (int f = step * P + lane; f < S * P; f += 64) {
-                qr[f] = s_par[wave][pm];
-                pm += inc; pm = pm >= P ? pm - P : pm;
-            }
-        }
+        fill_pattern(a.t + base, step, S, 1, lane, [](int) { return 0.0f; });
+        fill_pattern(a.alpha_weight + base, step, S, 1, lane, [](int) { return 1.0f; });
+        fill_pattern(reinterpret_cast<float *>(a.instance_id + base), step, S, 1, lane, [](int) { return 0.0f; });
+        fill_pattern(a.pts + base * 3, step * 3, S * 3, 1, lane, [](int) { return 0.0f; });
+        fill_pattern(a.rays_d_map + base * 3, step * 3, S * 3, 3, lane, [&](int q) { return q == 0 ? dx : (q == 1 ? dy : dz); });
+        if (P > 0) fill_pattern(a.params_map + base * P, step * P, S * P, P, lane, [&](int q) { return L.par[q]; });
     }
     if (lane == 0) {
         // the closing sample (:1013-1027): the instancer mesh is black and opaque, no mesh = nothing
         a.color_last[3 * ray] = 0.0f; a.color_last[3 * ray + 1] = 0.0f; a.color_last[3 * ray + 2] = 0.0f;
         a.alpha_last[ray] = has_mesh ? 1.0f : 0.0f;
         a.hit[ray] = any_hit ? 1 : 0;
-        if (a.status && (overflow_hits || overflow_active)) atomicOr(a.status, (overflow_hits ? 1 : 0) | (overflow_active ? 2 : 0));
+        if (a.status && overflow_hits) atomicOr(a.status, 1);
     }
 }
 
@@ -441,7 +636,8 @@ struct ntx_instancer {
     ntx_instancer_desc desc{};
     int64_t n_inst = 0, n_tri = 0, cap_rays = 0;
     std::vector<float> h_mats, h_dirs, h_org;          // world -> patch [K,12], direction maps [K,9], origins [K,3]
-    float *d_mats = nullptr, *d_dirs = nullptr, *d_org = nullptr, *d_tris = nullptr;
+    std::vector<float> h_spheres;                      // [K,4] centre and squared radius of the instanced box, world
+    float *d_mats = nullptr, *d_dirs = nullptr, *d_org = nullptr, *d_tris = nullptr, *d_spheres = nullptr;
     uint32_t *d_count = nullptr, *d_tmesh = nullptr;
     uint2 *d_hits = nullptr;
 };
@@ -477,7 +673,7 @@ bool invert4(const float *m, double *out) {
 void release(ntx_instancer *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    for (void *q : {(void *)p->d_mats, (void *)p->d_dirs, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits})
+    for (void *q : {(void *)p->d_mats, (void *)p->d_dirs, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits})
         if (q) (void)hipFree(q);
     delete p;
 }
@@ -518,12 +714,28 @@ int ntx_instancer_create(const ntx_instancer_desc *desc, const float *transforma
     if (device < 0 || device >= ndev) return ntx_set_error(NTX_E_INVALID, "device %d out of range [0,%d)", device, ndev);
     ntx_instancer *p = new ntx_instancer();
     p->device = device; p->desc = *desc; p->n_inst = n_instances;
-    p->h_mats.resize((size_t)n_instances * 12); p->h_dirs.resize((size_t)n_instances * 9); p->h_org.resize((size_t)n_instances * 3);
+    p->h_mats.resize((size_t)n_instances * 12); p->h_dirs.resize((size_t)n_instances * 9); p->h_org.resize((size_t)n_instances * 3); p->h_spheres.resize((size_t)n_instances * 4);
     for (int64_t k = 0; k < n_instances; ++k) {                        // AddInstance, instancer.cpp:124-141
         const float *m = transformations + k * 16;
         double inv[16];
         if (!invert4(m, inv)) { delete p; return ntx_set_error(NTX_E_INVALID, "transformation %lld is singular", (long long)k); }
         for (int i = 0; i < 12; ++i) p->h_mats[k * 12 + i] = (float)inv[i];
+        {   // sphere around the box's eight corners in world coordinates
+            double c[3], r2 = 0.0;
+            const double mid[3] = {0.5 * ((double)desc->b_0[0] + desc->b_1[0]), 0.5 * ((double)desc->b_0[1] + desc->b_1[1]), 0.5 * ((double)desc->b_0[2] + desc->b_1[2])};
+            for (int r = 0; r < 3; ++r) c[r] = m[4 * r] * mid[0] + m[4 * r + 1] * mid[1] + m[4 * r + 2] * mid[2] + m[4 * r + 3];
+            for (int corner = 0; corner < 8; ++corner) {
+                const double q[3] = {corner & 1 ? desc->b_1[0] : desc->b_0[0], corner & 2 ? desc->b_1[1] : desc->b_0[1], corner & 4 ? desc->b_1[2] : desc->b_0[2]};
+                double d2 = 0.0;
+                for (int r = 0; r < 3; ++r) {
+                    const double w = m[4 * r] * q[0] + m[4 * r + 1] * q[1] + m[4 * r + 2] * q[2] + m[4 * r + 3] - c[r];
+                    d2 += w * w;
+                }
+                r2 = d2 > r2 ? d2 : r2;
+            }
+            for (int r = 0; r < 3; ++r) p->h_spheres[k * 4 + r] = (float)c[r];
+            p->h_spheres[k * 4 + 3] = (float)(r2 * 1.002 + 1e-12);
+        }
         for (int r = 0; r < 3; ++r) {                                  // block<3,3>.transpose().rowwise().normalized()
             const double c0 = m[r], c1 = m[4 + r], c2 = m[8 + r];
             const double n = std::sqrt(c0 * c0 + c1 * c1 + c2 * c2);
@@ -541,6 +753,7 @@ int ntx_instancer_create(const ntx_instancer_desc *desc, const float *transforma
     if (rc == NTX_OK) rc = up(&p->d_mats, p->h_mats);
     if (rc == NTX_OK) rc = up(&p->d_dirs, p->h_dirs);
     if (rc == NTX_OK) rc = up(&p->d_org, p->h_org);
+    if (rc == NTX_OK) rc = up(&p->d_spheres, p->h_spheres);
     if (rc == NTX_OK) rc = reserve(p, NTX_INSTANCER_DEFAULT_MAX_RAYS);
     if (rc != NTX_OK) { release(p); return rc; }
     *out = p;
@@ -577,12 +790,23 @@ int ntx_instancer_set_mesh(ntx_instancer *inst, const float *vertices, int64_t n
     if (!inst) return ntx_set_error(NTX_E_INVALID, "inst is NULL");
     if (n_faces < 0 || n_faces > 0x7fffffff || n_vertices < 0 || (n_faces > 0 && (!vertices || !faces))) return ntx_set_error(NTX_E_INVALID, "bad mesh");
     INST_TRY(hipSetDevice(inst->device));
-    std::vector<float> tris((size_t)n_faces * 9);
+    std::vector<float> tris((size_t)n_faces * 13);
     for (int64_t f = 0; f < n_faces; ++f) {
         for (int c = 0; c < 3; ++c)
             if (faces[3 * f + c] < 0 || faces[3 * f + c] >= n_vertices) return ntx_set_error(NTX_E_INVALID, "face %lld names vertex %d of %lld", (long long)f, faces[3 * f + c], (long long)n_vertices);
         const float *v0 = vertices + 3 * (int64_t)faces[3 * f], *v1 = vertices + 3 * (int64_t)faces[3 * f + 1], *v2 = vertices + 3 * (int64_t)faces[3 * f + 2];
-        for (int c = 0; c < 3; ++c) { tris[f * 9 + c] = v0[c]; tris[f * 9 + 3 + c] = v1[c] - v0[c]; tris[f * 9 + 6 + c] = v2[c] - v0[c]; }
+        double r2 = 0.0, cen[3];
+        for (int c = 0; c < 3; ++c) {
+            tris[f * 13 + c] = v0[c]; tris[f * 13 + 3 + c] = v1[c] - v0[c]; tris[f * 13 + 6 + c] = v2[c] - v0[c];
+            cen[c] = ((double)v0[c] + v1[c] + v2[c]) / 3.0;
+        }
+        for (const float *vv : {v0, v1, v2}) {
+            double d2 = 0.0;
+            for (int c = 0; c < 3; ++c) d2 += (vv[c] - cen[c]) * (vv[c] - cen[c]);
+            r2 = d2 > r2 ? d2 : r2;
+        }
+        for (int c = 0; c < 3; ++c) tris[f * 13 + 9 + c] = (float)cen[c];
+        tris[f * 13 + 12] = (float)(r2 * 1.002 + 1e-12);
     }
     if (inst->d_tris) { (void)hipFree(inst->d_tris); inst->d_tris = nullptr; }
     inst->n_tri = 0;
@@ -635,7 +859,7 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
             int per_wave = 256;
             while (per_wave > 32 && (int64_t)tiles * ((K + per_wave - 1) / per_wave) < 4096) per_wave >>= 1;
             const int gy = (K + 4 * per_wave - 1) / (4 * per_wave);
-            hipLaunchKernelGGL(inst_hits_kernel, dim3(tiles, gy), dim3(256), 0, st, ro, rd, n, inst->d_mats, K, per_wave, box, inst->d_count, inst->d_hits);
+            hipLaunchKernelGGL(inst_hits_kernel, dim3(tiles, gy), dim3(256), 0, st, ro, rd, n, inst->d_mats, inst->d_spheres, K, per_wave, box, inst->d_count, inst->d_hits);
         }
         if (F > 0) {
             INST_TRY(hipMemsetD32Async((hipDeviceptr_t)inst->d_tmesh, (int)INF_BITS, (size_t)n, st));
@@ -658,6 +882,7 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         a.method = inst->desc.instance_sample_method; a.use_mean = inst->desc.use_mean_distance ? 1 : 0;
         a.step_size = step_size; a.blend_range = 0.2f * inst->desc.patch_scale;
         a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+        { const char *dbg = getenv("NERFTEX_INST_DEBUG"); a.debug_skip = dbg ? atoi(dbg) : 0; }
         // the piece's rays continue the call's index map: local k of the piece = local c0 + k of the call
         if (idx_run == 0xffffffffu) { a.idx0 = idx0 + c0; a.idx_run = 0xffffffffu; a.idx_stride = 0; }
         else if (c0 % idx_run == 0) { a.idx0 = idx0 + (c0 / idx_run) * idx_stride; a.idx_run = idx_run; a.idx_stride = idx_stride; }

@@ -162,8 +162,7 @@ class Instancer:
         return rays_d_map, pts, t, dists, color, density, weight, instance_id, idxs, params_map
 
     def status(self) -> int:
-        """Flags of the last call (synchronises): 1 = a ray crossed more than 200 faces (MAX_TOTAL_HITS), 2 = a point lay in
-        more than 64 patches."""
+        """Flags of the last call (synchronises): 1 = a ray crossed more than 200 faces (MAX_TOTAL_HITS, instancer.cpp:22)."""
         st = getattr(self, "_status", None)
         return 0 if st is None else int(st.item())
 

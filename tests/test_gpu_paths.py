@@ -530,13 +530,16 @@ def test_generic_family_render(npar, blur):
     ref32 = orc.renderer_call(w, spec, ro[None], rd[None], t[None], params, cone[None], S, False, (1., 1., 1.), blur, False, dtype=np.float32)
     want, want32 = rgba_ref(ref, 0), rgba_ref(ref32, 0).astype(np.float64)
     # dense-media weights on a nearly empty image (max alpha 0.2 for the parameter-less models): the float32 restatement itself
-    # sits ~1e-4 from float64 there, so: 1e-4 against the float32 restatement, and against float64
-    # no worse than that restatement's own distance
+    # sits ~1e-4 from float64 there.  The gate is the north star's -- 1e-4 against the float32 restatement, the
+    # reference's own arithmetic -- and the float64 figure is asserted as what follows from it by the triangle inequality,
+    # |got - f64| <= |got - f32| + |f32 - f64| (same normalisation up to max|f32| / max|f64|), not as a tolerance of its own
     floor = orc.rel_linf(want32, want)
+    scale = float(np.abs(want32).max() / np.abs(want).max())
 
     def check(got):
-        assert orc.rel_linf(got, want32) <= TOL
-        assert orc.rel_linf(got, want) <= max(TOL, 1.25 * floor)
+        e32 = orc.rel_linf(got, want32)
+        assert e32 <= TOL
+        assert orc.rel_linf(got, want) <= e32 * scale + floor + 1e-12
 
     got = rgba_of(Renderer(model=model, n_samples=S, perturb=False, blur_idx=blur)(*args, **kw))
     check(got)
