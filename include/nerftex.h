@@ -346,8 +346,8 @@ int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_hos
  * reference's only native code: Embree 3 on one CPU thread.  Built here: the constructor with explicit `transformations`
  * (instancer.pyx:19-20 -> AddInstance, instancer.cpp:124-141), an instancer mesh given as arrays, GetNumberOfInstances (:426-428),
  * the matrices ExportTransformations writes (:1040-1061) and GetModelInput (:751-1037) with the three patch choices, mean
- * distances, directional and point lights.  NOT built (NTX_E_UNSUPPORTED / no entry point): shadow rays (:591-602), image
- * textures on the instancer mesh (:640-667), auxiliary meshes with their shading (:393-417, 716-743) and
+ * distances, directional and point lights, shadow rays (:591-602, 945-961, 1018-1027).  NOT built (NTX_E_UNSUPPORTED / no entry
+ * point): image textures on the instancer mesh (:640-667), auxiliary meshes with their shading (:393-417, 716-743) and
  * DistributeInstancesOnMesh (:233-390: libigl curvature directions on LFS meshes; the reference can export what it computes
  * there with `transformation_export_path`, and that list is what ntx_instancer_create takes).
  *
@@ -355,7 +355,14 @@ int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_hos
  * coordinates; n_parameters, light_dir_parameter_idx, light_strength_parameter_idx as the `textures` list defines them
  * ("" = 1 parameter, "light" = 3 with light_dir at their start, "point" = 4: strength, then position = light_dir + 1;
  * -1 = none); instance_sample_method 0 random / 1 nearest / 2 nearest_blend (instancer.pyx:14); patch_scale only scales
- * nearest_blend's transition range (:697; 1 unless the patches were distributed on a mesh). */
+ * nearest_blend's transition range (:697; 1 unless the patches were distributed on a mesh).  cast_shadow_rays (needs a light
+ * entry): a sample whose shadow query is occluded gets the light direction (0, 0, -1) (:571-573).  A query (isShadowed, :591-602:
+ * from the point along the light parameter AS GIVEN -- for 'point' that is the light's position, :956 -- with 0 < t <= 100) is
+ * occluded by the top face of a patch box entered from outside, by its bottom face either way, and by the instancer mesh hit
+ * from its front (filter :543-554).  With N = max(min_shadow_samples, n_shadow_samples * total length) < n_pts the queries are
+ * made at max(min_shadow_samples, N * length / total) points spaced evenly along every segment and a step takes the nearer of
+ * the two around it (:946-958, 1018-1027), else every step makes its own (:959-961).  min_shadow_samples >= 2.
+ * *status_flag |= 4 when a ray needed more than 4096 shadow samples (the rest read as unshadowed). */
 typedef struct ntx_instancer ntx_instancer;
 typedef struct ntx_instancer_desc {
     uint32_t size;                       /* sizeof(ntx_instancer_desc) */
@@ -363,6 +370,7 @@ typedef struct ntx_instancer_desc {
     int32_t n_parameters, light_dir_parameter_idx, light_strength_parameter_idx;
     int32_t instance_sample_method, use_mean_distance, cast_shadow_rays;
     float patch_scale;
+    int32_t min_shadow_samples, n_shadow_samples;   /* with cast_shadow_rays (instancer.cpp:53, 861, 1019) */
 } ntx_instancer_desc;
 #define NTX_INSTANCER_DEFAULT_MAX_RAYS (1 << 16)
 /* transformations: HOST [n_instances,4,4] row-major patch -> world, what AddInstance takes.  The instancer keeps, per instance,

@@ -49,7 +49,7 @@ class InstancerDesc(C.Structure):
     _fields_ = [("size", C.c_uint32), ("b_0", C.c_float * 3), ("b_1", C.c_float * 3), ("n_parameters", C.c_int32),
                 ("light_dir_parameter_idx", C.c_int32), ("light_strength_parameter_idx", C.c_int32),
                 ("instance_sample_method", C.c_int32), ("use_mean_distance", C.c_int32), ("cast_shadow_rays", C.c_int32),
-                ("patch_scale", C.c_float)]
+                ("patch_scale", C.c_float), ("min_shadow_samples", C.c_int32), ("n_shadow_samples", C.c_int32)]
 
 
 class NtxError(RuntimeError):

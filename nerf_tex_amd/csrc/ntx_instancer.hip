@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 extern "C" int ntx_set_error(int code, const char *fmt, ...);   // nerftex.hip
@@ -185,6 +186,8 @@ struct MarchArgs {
     float step_size, blend_range;
     uint32_t seed_lo, seed_hi;
     int64_t idx0, idx_stride; uint32_t idx_run;
+    const float *spheres, *tris; int n_inst, n_tri; Box box;      // shadow rays: the scene again
+    int min_shadow, n_shadow;
     int debug_skip;   // development (NERFTEX_INST_DEBUG): leave parts of the kernel out to time the rest; results are then wrong
 };
 
@@ -219,6 +222,91 @@ __device__ __forceinline__ float mean_distance(float mu_f, float hw_f) {   // in
     return (float)(mu + 2 * mu * (hw * hw) / (3 * (mu * mu) + hw * hw));
 }
 
+// ---- shadow rays (instancer.cpp:591-602, filter :543-554) ---------------------------------------------------------------------
+constexpr int MAX_SHADOW_ENTRIES = 4096;
+struct ShadowLds {
+    uint32_t bits[MAX_SHADOW_ENTRIES / 32];   // the shadow samples of the ray's segments, one bit each
+    float ts[MAX_HITS / 2 + 2], len[MAX_HITS / 2 + 2];   // start and length of a segment, then (len -> ) the spacing of its shadow samples
+    uint16_t base[MAX_HITS / 2 + 4];          // first entry of segment i in `bits`; [n_segments] = number of entries
+    uint8_t g_seg[MAX_HITS + 8];              // the segment gap j lies in
+};
+struct NoShadowLds {};
+template <bool SHADOW> struct MarchLds { WaveLds w; typename std::conditional<SHADOW, ShadowLds, NoShadowLds>::type sh; };
+
+// isShadowed for 64 points at once: lane = a point (px,py,pz) on the wave's primary ray, all with direction (lx,ly,lz).  Every
+// shadow ray of the wave lies in the plane through the primary ray along the light direction, so a patch or triangle whose
+// sphere stays clear of that plane is nobody's occluder: lane per instance tests that (a ballot per 64 instances), and only the
+// set bits are walked with the full test.  Accepted: the top face of a patch box entered from outside, its bottom face either
+// way (primID 4 / 1 of createAABB), a triangle hit from its front.  Call in uniform control flow.
+__device__ __forceinline__ bool occluded(const MarchArgs &a, int lane, float ox, float oy, float oz, float dx, float dy, float dz,
+                                         float px, float py, float pz, float lx, float ly, float lz) {
+    const float nx = dy * lz - dz * ly, ny = dz * lx - dx * lz, nz = dx * ly - dy * lx;          // normal of the plane, not normalised
+    const float nn = (nx * nx + ny * ny) + nz * nz;
+    const float ll = (lx * lx + ly * ly) + lz * lz;
+    bool occ = false;
+    for (int k0 = 0; k0 < a.n_inst; k0 += 64) {
+        const int k = k0 + lane;
+        bool near = false;
+        if (k < a.n_inst) {
+            const float *sp = a.spheres + (size_t)k * 4;
+            const float h0 = ((sp[0] - ox) * nx + (sp[1] - oy) * ny) + (sp[2] - oz) * nz;
+            near = h0 * h0 <= sp[3] * nn * 1.001f;
+        }
+        uint64_t mk = __ballot(near);
+        while (mk) {
+            const int kk = k0 + __builtin_ctzll(mk);
+            mk &= mk - 1;
+            const float *sp = a.spheres + (size_t)kk * 4;                                     // wave-uniform from here on
+            const float cx = sp[0] - px, cy = sp[1] - py, cz = sp[2] - pz;
+            const float qx = cy * lz - cz * ly, qy = cz * lx - cx * lz, qz = cx * ly - cy * lx;
+            if (!__any((qx * qx + qy * qy) + qz * qz <= sp[3] * ll)) continue;
+            const float *m = a.mats + (size_t)kk * 12;
+            float ol[3], dl[3];
+            affine(m, px, py, pz, ol);
+            linear34(m, lx, ly, lz, dl);
+            if (dl[2] != 0.0f) {
+                const float inv = 1.0f / dl[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float z = e ? a.box.b0[2] : a.box.b1[2];
+                    const float tt = (z - ol[2]) * inv;
+                    const float x = ol[0] + tt * dl[0], y = ol[1] + tt * dl[1];
+                    const bool on_face = tt > 0.0f && tt <= T_FAR && a.box.b0[0] <= x && x <= a.box.b1[0] && a.box.b0[1] <= y && y <= a.box.b1[1];
+                    occ = occ || (on_face && (e == 1 || dl[2] < 0.0f));
+                }
+            }
+        }
+    }
+    for (int f0 = 0; f0 < a.n_tri; f0 += 64) {
+        const int f = f0 + lane;
+        bool near = false;
+        if (f < a.n_tri) {
+            const float *tr = a.tris + (size_t)f * 13;
+            const float h0 = ((tr[9] - ox) * nx + (tr[10] - oy) * ny) + (tr[11] - oz) * nz;
+            near = h0 * h0 <= tr[12] * nn * 1.001f;
+        }
+        uint64_t mk = __ballot(near);
+        while (mk) {
+            const int ff = f0 + __builtin_ctzll(mk);
+            mk &= mk - 1;
+            const float *tr = a.tris + (size_t)ff * 13;
+            const float *v0 = tr, *e1 = tr + 3, *e2 = tr + 6;
+            const float p[3] = {ly * e2[2] - lz * e2[1], lz * e2[0] - lx * e2[2], lx * e2[1] - ly * e2[0]};
+            const float det = (e1[0] * p[0] + e1[1] * p[1]) + e1[2] * p[2];
+            const float inv_det = 1.0f / det;
+            const float sv[3] = {px - v0[0], py - v0[1], pz - v0[2]};
+            const float u = ((sv[0] * p[0] + sv[1] * p[1]) + sv[2] * p[2]) * inv_det;
+            const float q[3] = {sv[1] * e1[2] - sv[2] * e1[1], sv[2] * e1[0] - sv[0] * e1[2], sv[0] * e1[1] - sv[1] * e1[0]};
+            const float v = ((lx * q[0] + ly * q[1]) + lz * q[2]) * inv_det;
+            const float tt = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv_det;
+            const float ng[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            const bool front = (lx * ng[0] + ly * ng[1]) + lz * ng[2] < 0.0f;
+            occ = occ || (det != 0.0f && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && tt > 0.0f && tt <= T_FAR && front);
+        }
+    }
+    return occ;
+}
+
 // fill row[f0 .. f1) with pattern[f % period] (period <= MAX_PARAMS, pattern in LDS or registers through `at`)
 template <typename At>
 __device__ __forceinline__ void fill_pattern(float *row, int f0, int f1, int period, int lane, At at) {
@@ -246,13 +334,16 @@ __device__ __forceinline__ void fill_pattern(float *row, int f0, int f1, int per
     for (int f = h1 + 4 * nvec + lane; f < f1; f += 64) __builtin_nontemporal_store(at(f % period), row + f);
 }
 
+template <bool SHADOW>
 __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
-    __shared__ WaveLds lds[4];
+    __shared__ MarchLds<SHADOW> lds[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ray = blockIdx.x * 4 + wave;
     if (ray >= a.n_rays) return;
-    WaveLds &L = lds[wave];
+    WaveLds &L = lds[wave].w;
+    auto &SH = lds[wave].sh;      // shadow tables (SHADOW only)
+    (void)SH;
     const int S = a.n_pts, P = a.n_params;
     const float h = a.step_size;
     const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
@@ -380,6 +471,10 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
         for (int i = 0; i < n_starts; ++i) {
             const float ts = L.gs.seg.ts[i];
             L.gs.seg.ts[i] = ts - cleared;                                   // segment_offset of the segment, :1001
+            if constexpr (SHADOW) {                                          // segment_lengths, :809, 818
+                SH.ts[i] = ts;
+                SH.len[i] = i < n_ends ? L.gs.seg.te[i] - ts : (has_mesh ? t_mesh - ts : 0.0f);
+            }
             if (i < n_ends) cleared = cleared + (L.gs.seg.te[i] - ts);      // :996 = :817
             else if (has_mesh) { total = cleared + (t_mesh - ts); }         // :808: the mesh closes the open segment
         }
@@ -450,11 +545,50 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
             int ex = __shfl_up(v, 1);
             if (lane == 0) ex = step;
             if (j <= n_gaps) { L.gs.g_step0[j] = ex; L.g_off[j] = off_q[q]; }
+            if constexpr (SHADOW) { if (j <= n_gaps) SH.g_seg[j] = (uint8_t)(seg_q[q] < 0 ? 0 : seg_q[q]); }
             step = __shfl(v, 63);
         }
         if (lane == 0) L.gs.g_step0[n_gaps] = step;
     }
     __builtin_amdgcn_wave_barrier();
+
+    // ---- the shadow samples of the ray (instancer.cpp:861, 1018-1027): a segment of length len gets n = max(min, N * len / total)
+    // samples spaced len / (n - 1) from its start; sample k of segment i is bit base[i] + k ---------------------------------------
+    bool interpolate = false;
+    bool overflow_shadow = false;
+    if constexpr (SHADOW) {
+        if (total > 0.0f) {
+            const uint32_t n_ray = (uint32_t)((float)(uint32_t)a.n_shadow * total);
+            const uint32_t n_shadow = n_ray > (uint32_t)a.min_shadow ? n_ray : (uint32_t)a.min_shadow;
+            interpolate = n_shadow < (uint32_t)S;
+            if (interpolate) {
+                int entries = 0;
+                for (int i = 0; i < n_starts; ++i) {
+                    const float len = SH.len[i];
+                    const uint32_t ns = (uint32_t)(((float)n_shadow * len) / total);
+                    const int n_seg = (int)(ns > (uint32_t)a.min_shadow ? ns : (uint32_t)a.min_shadow);
+                    SH.len[i] = len / (float)(uint32_t)(n_seg - 1);
+                    SH.base[i] = (uint16_t)entries;
+                    entries += n_seg + 1;
+                    if (entries > MAX_SHADOW_ENTRIES) { overflow_shadow = true; entries = MAX_SHADOW_ENTRIES; }
+                }
+                SH.base[n_starts] = (uint16_t)entries;
+                __builtin_amdgcn_wave_barrier();
+                const float lx0 = L.par[a.light_dir_idx], ly0 = L.par[a.light_dir_idx + 1], lz0 = L.par[a.light_dir_idx + 2];
+                for (int x0 = 0; x0 < entries; x0 += 64) {
+                    const int x = x0 + lane;
+                    int i = 0;
+                    for (int q = 1; q < n_starts; ++q) i += (int)SH.base[q] <= x ? 1 : 0;
+                    const int k = x - (int)SH.base[i];
+                    const float tk = SH.ts[i] + (float)(uint32_t)k * SH.len[i];
+                    const bool occ = occluded(a, lane, ox, oy, oz, dx, dy, dz, ox + tk * dx, oy + tk * dy, oz + tk * dz, lx0, ly0, lz0);
+                    const uint64_t mk = __ballot(occ && x < entries);
+                    if (lane == 0) { SH.bits[x0 >> 5] = (uint32_t)mk; SH.bits[(x0 >> 5) + 1] = (uint32_t)(mk >> 32); }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
 
     if (a.debug_skip & 64) return;
     // ---- steps: lane per step (instancer.cpp:878-986) ----------------------------------------------------------------------
@@ -561,11 +695,29 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
         float p3[3], d3[3], l3[3] = {0.0f, 0.0f, 0.0f}, lst = 0.0f;
         affine(mi, px, py, pz, p3);                                                             // getPt
         linear33(di, ndx, ndy, ndz, d3);                                                        // getDir
-        if (a.light_dir_idx >= 0) {                                                             // getShadowedLightDir(false, ...), :571-581
+        if (a.light_dir_idx >= 0) {                                                             // getShadowedLightDir, :571-581
             float sx = lx, sy = ly, sz = lz;
             if (a.light_strength_idx >= 0) { sx = lx - px; sy = ly - py; sz = lz - pz; }
             normalized(sx, sy, sz);
             linear33(di, sx, sy, sz, l3);
+            if constexpr (SHADOW) {
+                bool shadowed;
+                if (interpolate) {                                                              // :946-958: the nearer of the two shadow samples around t_pt
+                    const int i = SH.g_seg[j];
+                    const float ts = SH.ts[i], sl = SH.len[i];
+                    const int n_seg = (int)SH.base[i + 1] - (int)SH.base[i] - 1;
+                    const float xk = (t_pt - ts) / sl;
+                    int k = xk > 1.0f ? (xk < (float)n_seg ? (int)xk : n_seg) : 1;              // smallest k >= 1 with !(t_pt > ts + k * sl)
+                    while (k > 1 && !(t_pt > ts + (float)(uint32_t)(k - 1) * sl)) --k;
+                    while (k < n_seg && t_pt > ts + (float)(uint32_t)k * sl) ++k;
+                    const float t0 = ts + (float)(uint32_t)(k - 1) * sl;
+                    const int e = (int)SH.base[i] + ((t_pt - t0) / sl >= 0.5f ? k : k - 1);
+                    shadowed = e < MAX_SHADOW_ENTRIES && ((SH.bits[e >> 5] >> (e & 31)) & 1u);
+                } else {                                                                        // :959-961: a query per step
+                    shadowed = occluded(a, lane, ox, oy, oz, dx, dy, dz, px, py, pz, lx, ly, lz);
+                }
+                if (shadowed) { l3[0] = 0.0f; l3[1] = 0.0f; l3[2] = -1.0f; }
+            }
         }
         if (a.light_strength_idx >= 0) {                                                        // getLightStrength, :583-588
             const float ex = lx - px, ey = ly - py, ez = lz - pz;
@@ -622,7 +774,7 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
         a.color_last[3 * ray] = 0.0f; a.color_last[3 * ray + 1] = 0.0f; a.color_last[3 * ray + 2] = 0.0f;
         a.alpha_last[ray] = has_mesh ? 1.0f : 0.0f;
         a.hit[ray] = any_hit ? 1 : 0;
-        if (a.status && overflow_hits) atomicOr(a.status, 1);
+        if (a.status && (overflow_hits || overflow_shadow)) atomicOr(a.status, (overflow_hits ? 1 : 0) | (overflow_shadow ? 4 : 0));
     }
 }
 
@@ -707,8 +859,8 @@ int ntx_instancer_create(const ntx_instancer_desc *desc, const float *transforma
     const int ld = desc->light_dir_parameter_idx, ls = desc->light_strength_parameter_idx;
     if (ld < -1 || (ld >= 0 && ld + 3 > desc->n_parameters) || ls < -1 || ls >= desc->n_parameters || (ls >= 0 && ld < 0))
         return ntx_set_error(NTX_E_INVALID, "light parameter indices (%d, %d) do not fit %d parameters", ld, ls, desc->n_parameters);
-    if (desc->cast_shadow_rays)
-        return ntx_set_error(NTX_E_UNSUPPORTED, "cast_shadow_rays (instancer.cpp:591-602) is not built: occlusion queries per shadow sample need a hierarchy over the instances");
+    if (desc->cast_shadow_rays && (desc->min_shadow_samples < 2 || desc->n_shadow_samples < 0))
+        return ntx_set_error(NTX_E_INVALID, "cast_shadow_rays needs min_shadow_samples >= 2 (the spacing is length / (n - 1), instancer.cpp:1021) and n_shadow_samples >= 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ntx_set_error(NTX_E_NODEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return ntx_set_error(NTX_E_INVALID, "device %d out of range [0,%d)", device, ndev);
@@ -887,7 +1039,10 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         if (idx_run == 0xffffffffu) { a.idx0 = idx0 + c0; a.idx_run = 0xffffffffu; a.idx_stride = 0; }
         else if (c0 % idx_run == 0) { a.idx0 = idx0 + (c0 / idx_run) * idx_stride; a.idx_run = idx_run; a.idx_stride = idx_stride; }
         else return ntx_set_error(NTX_E_INVALID, "ray_run_length %u must divide the reserved %lld rays when a call is split (ntx_instancer_reserve)", idx_run, (long long)inst->cap_rays);
-        hipLaunchKernelGGL(inst_march_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
+        a.spheres = inst->d_spheres; a.tris = inst->d_tris; a.n_inst = K; a.n_tri = F; a.box = box;
+        a.min_shadow = inst->desc.min_shadow_samples; a.n_shadow = inst->desc.n_shadow_samples;
+        if (inst->desc.cast_shadow_rays && a.light_dir_idx >= 0) hipLaunchKernelGGL(inst_march_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(inst_march_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, a);
     }
     INST_TRY(hipGetLastError());
     return NTX_OK;

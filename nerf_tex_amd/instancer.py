@@ -6,10 +6,10 @@ config names `nerf_tex_amd.instancer.Instancer` where it named `instancer.instan
 `ntx_render_instanced` -- the reference walks its rays through Embree on one CPU thread and uploads ~70 bytes per (ray, step).
 
 What is built: explicit `transformations` (instancer.pyx:19-20) or the JSON file the reference's `transformation_export_path`
-writes (instancer.cpp:1040-1061), a culling mesh given as arrays, the three `instance_sampling_method`s, `use_mean_distance`,
-'' / 'light' / 'point' entries of `textures`.  What is refused (NtxError, NTX_E_UNSUPPORTED): `cast_shadow_rays`, image
-textures, `auxiliary_meshes`, and `mesh_path` without an exported transformation list (DistributeInstancesOnMesh needs libigl's
-curvature directions on meshes the reference keeps in LFS).
+writes (instancer.cpp:1040-1061), a culling mesh given as arrays or a PLY file, the three `instance_sampling_method`s,
+`use_mean_distance`, '' / 'light' / 'point' entries of `textures`, `cast_shadow_rays` with `min_shadow_samples` /
+`n_shadow_samples`.  What is refused (NtxError, NTX_E_UNSUPPORTED): image textures, `auxiliary_meshes`, and `mesh_path` without an
+exported transformation list (DistributeInstancesOnMesh needs libigl's curvature directions on meshes the reference keeps in LFS).
 """
 
 from __future__ import annotations
@@ -80,6 +80,7 @@ class Instancer:
         desc.instance_sample_method = SAMPLING_METHODS[instance_sampling_method]
         desc.use_mean_distance = int(bool(use_mean_distance)); desc.cast_shadow_rays = int(bool(cast_shadow_rays))
         desc.patch_scale = self.patch_scale
+        desc.min_shadow_samples, desc.n_shadow_samples = int(min_shadow_samples), int(n_shadow_samples)
         self._h = C.c_void_p()
         _lib.check(_lib.lib.ntx_instancer_create(C.byref(desc), self._tr.ctypes.data_as(C.POINTER(C.c_float)), self._tr.shape[0],
                                                  self.device, C.byref(self._h)))

@@ -54,6 +54,9 @@ class InstancerSpec:
     patch_scale: float = 1.0             # only DistributeInstancesOnMesh sets it (instancer.cpp:236); 1 otherwise (:53)
     mesh_v: Optional[np.ndarray] = None  # the instancer mesh (culls, closes a ray with an opaque black sample)
     mesh_f: Optional[np.ndarray] = None
+    cast_shadow_rays: bool = False       # instancer.cpp:53
+    min_shadow_samples: int = 4
+    n_shadow_samples: int = 512
 
 
 def parse_textures(textures: Sequence[str]) -> Tuple[int, int, int]:
@@ -83,7 +86,7 @@ def prepare_instances(transformations) -> Tuple[np.ndarray, np.ndarray, np.ndarr
 
 
 def make_spec(b_0, b_1, transformations, textures=(), instance_sampling_method="random", use_mean_distance=False,
-              mesh=None, matrices=None) -> InstancerSpec:
+              mesh=None, matrices=None, cast_shadow_rays=False, min_shadow_samples=4, n_shadow_samples=512) -> InstancerSpec:
     n, ld, ls = parse_textures(textures)
     inv, dir_t, org = prepare_instances(transformations) if matrices is None else matrices
     mv = mf = None
@@ -91,7 +94,7 @@ def make_spec(b_0, b_1, transformations, textures=(), instance_sampling_method="
         mv = np.asarray(mesh[0], F32).reshape(-1, 3); mf = np.asarray(mesh[1], np.int32).reshape(-1, 3)
     return InstancerSpec(np.asarray(b_0, F32), np.asarray(b_1, F32), inv, dir_t, org, n, ld, ls,
                          {"random": 0, "nearest": 1, "nearest_blend": 2}[instance_sampling_method], bool(use_mean_distance),
-                         1.0, mv, mf)
+                         1.0, mv, mf, bool(cast_shadow_rays), int(min_shadow_samples), int(n_shadow_samples))
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -195,6 +198,51 @@ def mesh_hit(spec: InstancerSpec, o, d) -> Optional[np.float32]:
     return best
 
 
+def is_shadowed(spec: InstancerSpec, pt, direction) -> bool:
+    """isShadowed (instancer.cpp:591-602): an occlusion query from `pt` along `direction` (as given, not normalised; 0 < t <= 100)
+    whose filter (:543-554) accepts a hit on the TOP face of a patch box from outside (primID 4 = the z = b_1 quad of createAABB,
+    :113; dot(dir, Ng) < 0), any hit on the BOTTOM face (primID 1 = the z = b_0 quad, :110), or a hit on a mesh from its front
+    (Ng = cross(v1 - v0, v2 - v0)); side faces are ignored.  Ray and normal are taken in patch coordinates, where Embree's
+    instance traversal calls the filter: from outside through the top = the patch-space direction points down."""
+    pt = np.asarray(pt, F32); direction = np.asarray(direction, F32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for k in range(spec.inv.shape[0]):
+            ol = _affine(spec.inv[k], pt); dl = _linear(spec.inv[k], direction)
+            if dl[2] == 0:
+                continue
+            inv_d = F32(1.0) / dl[2]
+            for z, top in ((spec.b_1[2], True), (spec.b_0[2], False)):
+                tt = (z - ol[2]) * inv_d
+                if not (T_NEAR < tt <= T_FAR):
+                    continue
+                x = ol[0] + tt * dl[0]; y = ol[1] + tt * dl[1]
+                if spec.b_0[0] <= x <= spec.b_1[0] and spec.b_0[1] <= y <= spec.b_1[1] and (not top or dl[2] < 0):
+                    return True
+        if spec.mesh_v is not None:
+            cross = lambda a, b: np.asarray([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], F32)
+            dot = lambda a, b: (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+            o, d = pt, direction
+            for f in spec.mesh_f:
+                v0, v1, v2 = spec.mesh_v[f[0]], spec.mesh_v[f[1]], spec.mesh_v[f[2]]
+                e1 = v1 - v0; e2 = v2 - v0
+                p = cross(d, e2); det = dot(e1, p)
+                if det == 0:
+                    continue
+                inv_det = F32(1.0) / det
+                sv = o - v0
+                u = dot(sv, p) * inv_det
+                if u < 0 or u > 1:
+                    continue
+                q = cross(sv, e1)
+                v = dot(d, q) * inv_det
+                if v < 0 or u + v > 1:
+                    continue
+                tt = dot(e2, q) * inv_det
+                if T_NEAR < tt <= T_FAR and dot(d, cross(e1, e2)) < 0:
+                    return True
+    return False
+
+
 def get_mean_distance(mu, hw):
     """instancer.cpp:746-748; std::pow(float, int) promotes to double, the result is returned as float."""
     mu = float(mu); hw = float(hw)
@@ -242,16 +290,19 @@ def get_model_input(spec: InstancerSpec, rays_o, rays_d, parameters, n_samples: 
         active: set = set()
         total = F32(0.0); t_entry = F32(0.0)
         has_mesh = False
+        segment_lengths = []
         for tt, k, is_mesh in hits:
             if is_mesh:
                 if active:
                     total = total + (tt - t_entry)
+                    segment_lengths.append(tt - t_entry)
                 has_mesh = True
                 break
             if k in active:
                 active.discard(k)
                 if not active:
                     total = total + (tt - t_entry)
+                    segment_lengths.append(tt - t_entry)
             else:
                 if not active:
                     t_entry = tt
@@ -272,6 +323,12 @@ def get_model_input(spec: InstancerSpec, rays_o, rays_d, parameters, n_samples: 
                 dists[i, :n_steps - 1] = h
                 dists[i, n_steps - 1] = (h + total) - F32(n_steps) * h                  # :853
                 t_offset = u_offset[i] * h
+            # shadow samples of the ray (:861-862) and the interpolation state of :866-869
+            interpolate = False
+            if spec.cast_shadow_rays and spec.light_dir_idx >= 0:
+                n_shadow = max(spec.min_shadow_samples, int(np.uint32(F32(spec.n_shadow_samples) * total)))
+                interpolate = n_shadow < S
+            seg_l = 0; k_shadow = 0; t_0_sh = t_1_sh = step_sh = F32(0.0); s_0 = s_1 = False
             segment_offset = F32(0.0); cleared = F32(0.0); t_entry = F32(0.0)
             step = 0
             for tt, k, is_mesh in hits:
@@ -313,9 +370,24 @@ def get_model_input(spec: InstancerSpec, rays_o, rays_d, parameters, n_samples: 
                         inst = ids[pick]
                         density_weight[i, step] = tot / ws[pick]                        # 1 / probability
                     instance_id[i, step] = inst
-                    if spec.light_dir_idx >= 0:                                         # :945 ff with cast_shadow_rays = false
-                        src = (default_light - pt).astype(F32) if spec.light_strength_idx >= 0 else default_light   # :573-579
-                        params_map[i, step, spec.light_dir_idx:spec.light_dir_idx + 3] = _linear(spec.dir_t[inst], _normalized(src))
+                    if spec.light_dir_idx >= 0:                                         # :945-967
+                        shadowed = False
+                        if spec.cast_shadow_rays and interpolate:                       # :946-958
+                            while t_pt > t_1_sh:
+                                t_0_sh = t_1_sh
+                                k_shadow += 1
+                                t_1_sh = t_entry + F32(k_shadow) * step_sh
+                                s_0 = s_1
+                                s_1 = is_shadowed(spec, (o + t_1_sh * d).astype(F32), default_light)
+                            w = (t_pt - t_0_sh) / step_sh >= F32(0.5)                    # nearest of the two shadow samples
+                            shadowed = (not w and s_0) or (w and s_1)
+                        elif spec.cast_shadow_rays:                                     # :959-961
+                            shadowed = is_shadowed(spec, pt, default_light)
+                        if shadowed:                                                    # getShadowedLightDir, :571-581
+                            params_map[i, step, spec.light_dir_idx:spec.light_dir_idx + 3] = F32([0, 0, -1])
+                        else:
+                            src = (default_light - pt).astype(F32) if spec.light_strength_idx >= 0 else default_light
+                            params_map[i, step, spec.light_dir_idx:spec.light_dir_idx + 3] = _linear(spec.dir_t[inst], _normalized(src))
                     if spec.light_strength_idx >= 0:                                    # :970-972, :583-588 (double)
                         dv = (default_light - pt).astype(F32)
                         d2 = (dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]
@@ -334,6 +406,15 @@ def get_model_input(spec: InstancerSpec, rays_o, rays_d, parameters, n_samples: 
                     if not active:
                         segment_offset = tt - cleared                                   # :1001
                         t_entry = tt
+                        if spec.cast_shadow_rays and spec.light_dir_idx >= 0 and interpolate:      # :1018-1027
+                            seg_len = segment_lengths[seg_l]
+                            n_seg = max(spec.min_shadow_samples, int(np.uint32(F32(n_shadow) * seg_len / total)))
+                            step_sh = seg_len / F32(n_seg - 1)
+                            k_shadow = 1
+                            t_0_sh = t_entry; t_1_sh = t_entry + step_sh
+                            s_0 = is_shadowed(spec, (o + t_0_sh * d).astype(F32), default_light)
+                            s_1 = is_shadowed(spec, (o + t_1_sh * d).astype(F32), default_light)
+                        seg_l += 1                                                      # :1029
                     active.add(k)
         if has_mesh:                                                                    # :1013-1027 (instancer mesh: black, opaque)
             density[i, 0] = 1.0

@@ -35,9 +35,10 @@ def run_gpu(inst, o, d, params, S, h, seed, ray_index=None):
     return res
 
 
-def run_oracle(inst, box, o, d, params, S, h, seed, method="random", textures=(), mean=False, mesh=None, ray_index=None, patch_scale=1.0):
+def run_oracle(inst, box, o, d, params, S, h, seed, method="random", textures=(), mean=False, mesh=None, ray_index=None, patch_scale=1.0,
+               **shadow):
     spec = io.make_spec(box["b_0"], box["b_1"], None, textures=textures, instance_sampling_method=method, use_mean_distance=mean,
-                        mesh=mesh, matrices=inst.matrices())
+                        mesh=mesh, matrices=inst.matrices(), **shadow)
     spec.patch_scale = patch_scale
     n = o.shape[0]
     return list(io.get_model_input(spec, o, d, params, S, h, io.offset_uniforms(n, seed, ray_index), io.choice_uniforms(n, S, seed, ray_index)))
@@ -106,6 +107,36 @@ def test_model_input_bit_for_bit(method, mesh, textures, mean):
     assert inst.status() == 0
 
 
+@pytest.mark.parametrize("textures", [("", "light", ""), ("point", "")])
+@pytest.mark.parametrize("mesh", [False, True])
+@pytest.mark.parametrize("n_shadow_samples,min_shadow", [(48, 4), (96, 8), (100000, 4)])
+def test_shadow_rays_bit_for_bit(textures, mesh, n_shadow_samples, min_shadow):
+    """cast_shadow_rays (instancer.cpp:591-602, 861, 945-961, 1018-1027): shadow samples spaced along every segment and the nearer of
+    the two around a step (N * total < n_pts), or a query per step (the last case); a shadowed sample gets the light direction
+    (0, 0, -1).  `point`: the reference hands isShadowed the light's POSITION as the direction (:956, 961) -- kept."""
+    spec0 = random_scene(31, k=24, method="nearest", textures=textures, mesh=mesh)
+    box = dict(b_0=spec0.b_0.tolist(), b_1=spec0.b_1.tolist())
+    tr = [np.linalg.inv(m.astype(np.float64)).astype(F) for m in spec0.inv]
+    msh = (spec0.mesh_v, spec0.mesh_f) if mesh else None
+    sh = dict(cast_shadow_rays=True, min_shadow_samples=min_shadow, n_shadow_samples=n_shadow_samples)
+    inst = gpu_instancer(box, tr, textures=list(textures), instance_sampling_method="nearest", mesh=msh, **sh)
+    n, S, h = 120, 128, 0.02
+    o, d = random_rays(31, n)
+    rng = np.random.default_rng(31)
+    P = spec0.n_parameters
+    params = rng.uniform(0.2, 1.0, size=(n, P)).astype(F)
+    ld = 1 if textures[0] == "" else 1                          # ('', 'light', ''): light at 1..3; ('point', ''): position at 1..3
+    light = rng.normal(size=(n, 3)); light[:, 2] = np.abs(light[:, 2]) * 0.7 + 0.1
+    params[:, ld:ld + 3] = light
+    got = run_gpu(inst, o, d, params, S, h, seed=5)
+    want = run_oracle(inst, box, o, d, params, S, h, 5, "nearest", textures, False, msh, **sh)
+    emitted = want[2] > 0
+    dark = emitted & np.all(want[9][..., ld:ld + 3] == F([0, 0, -1]), axis=-1)
+    assert dark.sum() > 100 and (emitted & ~dark).sum() > 100, (dark.sum(), emitted.sum())
+    assert_same(got, want)
+    assert inst.status() == 0
+
+
 def test_rays_can_be_split_and_sharded():
     """The draws are keyed by the global ray index: two calls with an index map, and a call longer than the reserved
     workspace (cut into pieces inside the library), give the bits of one call."""
@@ -143,7 +174,7 @@ def test_overflow_flags_and_refusals(tmp_path):
     assert inst.status() == 0
     assert_same(out, want)
     assert out[6].max() == 90                                                    # density_weight = patches the point lies in
-    for kw in (dict(cast_shadow_rays=True), dict(textures=["meshes/smooth_checkerboard.png"]), dict(auxiliary_meshes=[("a.ply", "")]),
+    for kw in (dict(textures=["meshes/smooth_checkerboard.png"]), dict(auxiliary_meshes=[("a.ply", "")]),
                dict(mesh_path="meshes/cloth_mesh.ply")):
         with pytest.raises(_lib.NtxError) as e:
             Instancer(UNIT["b_0"], UNIT["b_1"], transformations=[translate().tolist()], **kw)

@@ -741,7 +741,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                    'int main(void) {\n'
                    '    ntx_model_desc d = {NTX_MODEL_PARAMNERF, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, NTX_POS_FOURIER};\n'
                    '    ntx_render_opts o = {sizeof(ntx_render_opts), 0.5f, 7u, 100, 800, 6400};\n'
-                   '    ntx_instancer_desc q = {sizeof(ntx_instancer_desc), {-1, -1, -1}, {1, 1, 1}, 7, 4, -1, 1, 0, 0, 1.0f};\n'
+                   '    ntx_instancer_desc q = {sizeof(ntx_instancer_desc), {-1, -1, -1}, {1, 1, 1}, 7, 4, -1, 1, 0, 0, 1.0f, 8, 256};\n'
                    '    if (ntx_instancer_count(NULL) != -1 || q.n_parameters != 7) return 3;\n'
                    '    long long counts[8], offs[8]; int eq, direct;\n'
                    '    if (ntx_gather_plan(642400, 800, 8, (int64_t *)counts, (int64_t *)offs, &eq, &direct) != NTX_OK) return 2;\n'
@@ -791,8 +791,8 @@ def test_instancer_host_side(tmp_path):
     assert _lib.lib.ntx_instancer_create(None, None, 0, 0, C.byref(h)) == _lib.NTX_E_INVALID
     d = _lib.InstancerDesc(); d.size = C.sizeof(_lib.InstancerDesc); d.cast_shadow_rays = 1
     d.light_dir_parameter_idx = d.light_strength_parameter_idx = -1
-    assert _lib.lib.ntx_instancer_create(C.byref(d), None, 0, 0, C.byref(h)) == _lib.NTX_E_UNSUPPORTED
-    assert b"shadow" in _lib.lib.ntx_last_error()
+    assert _lib.lib.ntx_instancer_create(C.byref(d), None, 0, 0, C.byref(h)) == _lib.NTX_E_INVALID     # min_shadow_samples = 0
+    assert b"min_shadow_samples" in _lib.lib.ntx_last_error()
     d.cast_shadow_rays = 0; d.instance_sample_method = 3
     assert _lib.lib.ntx_instancer_create(C.byref(d), None, 0, 0, C.byref(h)) == _lib.NTX_E_INVALID
     assert _lib.lib.ntx_instancer_count(None) == -1

@@ -150,6 +150,25 @@ def test_mean_distance():
     assert np.allclose(pts[0, :4, 2], want - 5, atol=1e-6)
 
 
+def test_is_shadowed_known_answers():
+    """instancer.cpp:591-602 with the filter of :543-554: the top face of a patch box from outside, its bottom face either way, a
+    mesh from its front; side faces and back faces let the light through."""
+    spec = io.make_spec(transformations=[translate()], **UNIT)
+    up, down = F([0, 0, 1]), F([0, 0, -2.5])
+    assert not io.is_shadowed(spec, F([0, 0, 0]), up)            # inside: leaves through the top from INSIDE
+    assert io.is_shadowed(spec, F([0, 0, 2]), down)              # above, light from below the box: enters through the top
+    assert io.is_shadowed(spec, F([0, 0, -2]), up)               # below: crosses the bottom face
+    assert io.is_shadowed(spec, F([0, 0, 0]), down)              # inside, looking down: the bottom face counts either way
+    assert not io.is_shadowed(spec, F([3, 0, 0]), up)            # beside
+    assert not io.is_shadowed(spec, F([3, 0, 0]), F([-1, 0, 0]))  # through the side faces only
+    assert not io.is_shadowed(spec, F([0, 0, 102]), F([0, 0, -1]))          # the top face lies beyond tfar = 100
+    tri = ([[-1, -1, 2], [1, -1, 2], [0, 1, 2]], [[0, 1, 2]])    # counter-clockwise seen from +z: Ng = +z
+    spec = io.make_spec(transformations=[translate(z=-50)], mesh=tri, **UNIT)
+    assert io.is_shadowed(spec, F([0, 0, 3]), F([0, 0, -1]))     # onto the front
+    assert not io.is_shadowed(spec, F([0, 0, 0]), up)            # onto the back
+    assert not io.is_shadowed(spec, F([5, 0, 3]), F([0, 0, -1]))
+
+
 def random_scene(seed, k=12, method="nearest", textures=(), mesh=False):
     rng = np.random.default_rng(seed)
     tr = []

@@ -69,12 +69,13 @@ def main():
     ap.add_argument("--method", default="nearest")
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--no-mesh", action="store_true")
+    ap.add_argument("--shadows", type=int, default=0, metavar="N", help="cast_shadow_rays with n_shadow_samples = N, min 8 (config_grass_render.py:92-98: 128)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     tr, v, f = sheet(a.grid)
     textures = ['', '', '', '', 'light']                                         # config_carpet_render.py:86 without the image texture
     inst = Instancer(B0, B1, textures=textures, transformations=tr, instance_sampling_method=a.method,
-                     mesh=None if a.no_mesh else (v, f))
+                     mesh=None if a.no_mesh else (v, f), cast_shadow_rays=a.shadows > 0, min_shadow_samples=8, n_shadow_samples=max(a.shadows, 1))
     fam = synthetic.FAMILIES["carpet"]
     side = int(np.sqrt(a.rays))
     assert side * side == a.rays, "--rays must be a square number (a side x side window of the 800 x 800 camera)"
@@ -99,7 +100,9 @@ def main():
     in_bytes = a.rays * (24 + 4 * P)
     gbps = (out_bytes + in_bytes) / (ms * 1e-3) / 1e9
     line = {"what": "ntx_instancer_model_input (hits + mesh + march kernels, HIP events around the call incl. the output torch.empty)",
-            "scene": f"{a.grid}x{a.grid} = {a.grid ** 2} patches + {0 if a.no_mesh else f.shape[0]} triangles, method {a.method}",
+            "scene": f"{a.grid}x{a.grid} = {a.grid ** 2} patches + {0 if a.no_mesh else f.shape[0]} triangles, method {a.method}"
+                     + (f", shadow rays ({a.shadows} per unit length, min 8)" if a.shadows else ""),
+            "shadowed_samples": int((out[9][..., 4:7] == torch.tensor([0., 0., -1.], device=dev)).all(-1).logical_and(out[2] > 0).sum().item()),
             "rays": a.rays, "n_pts": S, "step_size": a.step_size, "hit_rays": int(hit.sum().item()), "in_patch_samples": in_patch,
             "emitted_samples": emitted, "status": inst.status(), "ms": round(ms, 4),
             "rays_per_s": round(a.rays / (ms * 1e-3)), "in_patch_samples_per_s": round(in_patch / (ms * 1e-3)),
