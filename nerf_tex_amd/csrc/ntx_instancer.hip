@@ -239,18 +239,35 @@ template <bool SHADOW> struct MarchLds { WaveLds w; typename std::conditional<SH
 // set bits are walked with the full test.  Accepted: the top face of a patch box entered from outside, its bottom face either
 // way (primID 4 / 1 of createAABB), a triangle hit from its front.  Call in uniform control flow.
 __device__ __forceinline__ bool occluded(const MarchArgs &a, int lane, float ox, float oy, float oz, float dx, float dy, float dz,
-                                         float px, float py, float pz, float lx, float ly, float lz) {
+                                         float tp, float px, float py, float pz, float lx, float ly, float lz) {
     const float nx = dy * lz - dz * ly, ny = dz * lx - dx * lz, nz = dx * ly - dy * lx;          // normal of the plane, not normalised
-    const float nn = (nx * nx + ny * ny) + nz * nz;
-    const float ll = (lx * lx + ly * ly) + lz * lz;
+    const float nn = (nx * nx + ny * ny) + nz * nz;                                             // = |d|^2 |l|^2 - (d.l)^2
+    const float ll = (lx * lx + ly * ly) + lz * lz, ddq = (dx * dx + dy * dy) + dz * dz, dl_ = (dx * lx + dy * ly) + dz * lz;
+    // ... and inside the plane the shadow rays sweep the strip { o + alpha d + beta l : ta <= alpha <= tb, beta >= 0 }: a sphere whose
+    // centre has oblique coordinates (alpha, beta) reaches alpha +- r |l| / sqrt(nn), beta +- r |d| / sqrt(nn)
+    float ta = tp, tb = tp;
+    for (int o = 32; o > 0; o >>= 1) { ta = fminf(ta, __shfl_xor(ta, o)); tb = fmaxf(tb, __shfl_xor(tb, o)); }
+    const bool strip = nn > 1e-10f * ddq * ll;                                                  // d and l not parallel
+    const float inv_nn = strip ? 1.0f / nn : 0.0f, inv_rt = strip ? 1.0f / __builtin_sqrtf(nn) : 0.0f;
+    const float ra = __builtin_sqrtf(ll) * inv_rt * 1.01f, rb = __builtin_sqrtf(ddq) * inv_rt * 1.01f;
+    auto reaches = [&](const float *c, float r2) {
+        const float wx = c[0] - ox, wy = c[1] - oy, wz = c[2] - oz;
+        const float h0 = (wx * nx + wy * ny) + wz * nz;
+        if (!(h0 * h0 <= r2 * nn * 1.001f)) return false;
+        if (!strip) return true;
+        const float b1 = (wx * dx + wy * dy) + wz * dz, b2 = (wx * lx + wy * ly) + wz * lz;
+        const float alpha = (b1 * ll - b2 * dl_) * inv_nn, beta = (b2 * ddq - b1 * dl_) * inv_nn;
+        const float r = __builtin_sqrtf(r2);
+        const float tol = 1e-4f * (fabsf(alpha) + fabsf(beta) + 1.0f);
+        return alpha + r * ra + tol >= ta && alpha - r * ra - tol <= tb && beta + r * rb + tol >= 0.0f;
+    };
     bool occ = false;
     for (int k0 = 0; k0 < a.n_inst; k0 += 64) {
         const int k = k0 + lane;
         bool near = false;
         if (k < a.n_inst) {
             const float *sp = a.spheres + (size_t)k * 4;
-            const float h0 = ((sp[0] - ox) * nx + (sp[1] - oy) * ny) + (sp[2] - oz) * nz;
-            near = h0 * h0 <= sp[3] * nn * 1.001f;
+            near = reaches(sp, sp[3]);
         }
         uint64_t mk = __ballot(near);
         while (mk) {
@@ -282,8 +299,7 @@ __device__ __forceinline__ bool occluded(const MarchArgs &a, int lane, float ox,
         bool near = false;
         if (f < a.n_tri) {
             const float *tr = a.tris + (size_t)f * 13;
-            const float h0 = ((tr[9] - ox) * nx + (tr[10] - oy) * ny) + (tr[11] - oz) * nz;
-            near = h0 * h0 <= tr[12] * nn * 1.001f;
+            near = reaches(tr + 9, tr[12]);
         }
         uint64_t mk = __ballot(near);
         while (mk) {
@@ -581,7 +597,7 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
                     for (int q = 1; q < n_starts; ++q) i += (int)SH.base[q] <= x ? 1 : 0;
                     const int k = x - (int)SH.base[i];
                     const float tk = SH.ts[i] + (float)(uint32_t)k * SH.len[i];
-                    const bool occ = occluded(a, lane, ox, oy, oz, dx, dy, dz, ox + tk * dx, oy + tk * dy, oz + tk * dz, lx0, ly0, lz0);
+                    const bool occ = occluded(a, lane, ox, oy, oz, dx, dy, dz, tk, ox + tk * dx, oy + tk * dy, oz + tk * dz, lx0, ly0, lz0);
                     const uint64_t mk = __ballot(occ && x < entries);
                     if (lane == 0) { SH.bits[x0 >> 5] = (uint32_t)mk; SH.bits[(x0 >> 5) + 1] = (uint32_t)(mk >> 32); }
                 }
@@ -714,7 +730,7 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
                     const int e = (int)SH.base[i] + ((t_pt - t0) / sl >= 0.5f ? k : k - 1);
                     shadowed = e < MAX_SHADOW_ENTRIES && ((SH.bits[e >> 5] >> (e & 31)) & 1u);
                 } else {                                                                        // :959-961: a query per step
-                    shadowed = occluded(a, lane, ox, oy, oz, dx, dy, dz, px, py, pz, lx, ly, lz);
+                    shadowed = occluded(a, lane, ox, oy, oz, dx, dy, dz, t_pt, px, py, pz, lx, ly, lz);
                 }
                 if (shadowed) { l3[0] = 0.0f; l3[1] = 0.0f; l3[2] = -1.0f; }
             }

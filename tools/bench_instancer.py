@@ -88,7 +88,10 @@ def main():
     loc = torch.as_tensor(np.stack([rows.ravel(), cols.ravel()], -1).astype(np.float32), device=dev)
     ro, rd, t, cone = Proxy(800, 800, focal, AABB([-1.7, -1.7, -.3], [1.7, 1.7, .4]))(loc, c2w, device=dev)
     P = inst.n_parameters
-    params = torch.as_tensor(np.asarray([fam["params"]], np.float32), device=dev).repeat(a.rays, 1)
+    par = np.asarray([fam["params"]], np.float32)
+    if a.shadows:
+        par[0, 4:7] = (0.9, 0.2, 0.08)                                            # a sun 5 degrees over the horizon: the waves of the sheet (slopes up to 9 degrees) shade each other
+    params = torch.as_tensor(par, device=dev).repeat(a.rays, 1)
     S = a.samples
     out = inst.get_model_input(ro, rd, params, S, a.step_size, seed=1)
     torch.cuda.synchronize()

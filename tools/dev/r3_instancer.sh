@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3inst; mkdir -p $O; cd $R
 B="timeout 300 python tools/bench_instancer.py"
 $B 2>/dev/null | grep "^{" > $O/instancer_bench.jsonl
 { $B --grid 64 --no-render; $B --method random --no-render; $B --method nearest_blend --no-render; $B --no-mesh --no-render;
-  $B --rays 65536 --no-render; $B --rays 4096 --no-render; $B --samples 256 --step-size 0.008 --no-render; } 2>/dev/null | grep "^{" > $O/instancer_variants.jsonl
+  $B --shadows 128 --no-render; $B --shadows 100000 --no-render; $B --rays 65536 --no-render; $B --rays 4096 --no-render; $B --samples 256 --step-size 0.008 --no-render; } 2>/dev/null | grep "^{" > $O/instancer_variants.jsonl
 P="python tools/bench_instancer.py --no-render --steps 10"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $P > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o p -- $P > /dev/null 2>&1
@@ -41,4 +41,4 @@ PY
 cp $O/kt/*kernel_stats.csv $O/instancer_kernel_stats.csv
 cut -c1-400 $O/instancer_bench.jsonl; python -c "
 import json
-for l in open('$O/instancer_variants.jsonl'): j = json.loads(l); print(j['scene'], j['rays'], j['n_pts'], j['ms'], j['roofline']['frac'], j['status'])"
+for l in open('$O/instancer_variants.jsonl'): j = json.loads(l); print(j['scene'], j['rays'], j['n_pts'], j['ms'], j['roofline']['frac'], j['status'], j.get('shadowed_samples'))"
