@@ -227,3 +227,36 @@ def test_instance_renderer_end_to_end(npar, textures, blur):
         want[sl, :3] = rc; want[sl, 3] = ra
     assert orc.rel_linf(got, want) <= TOL
     assert want[:, 3].max() > 0.5 and (want[:, 3] > 0).sum() > 40 and np.all(got[7] == 0)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_scenes_bit_for_bit(seed):
+    """Random scenes, ray sets and settings (patch count, box, scales, step size, buffer length incl. too short ones, choice rule,
+    lights, mean distances, mesh, shadow rays in both modes, rays that start inside the patch layer): every buffer bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.integers(3, 48))
+    method = ["random", "nearest", "nearest_blend"][seed % 3]
+    textures = [(), ("", "light"), ("point",), ("", "", "light", "")][int(rng.integers(0, 4))]
+    mesh = bool(rng.integers(0, 2))
+    mean = bool(rng.integers(0, 2))
+    shadows = bool(textures) and bool(rng.integers(0, 2))
+    spec0 = random_scene(200 + seed, k=k, method=method, textures=textures, mesh=mesh)
+    box = dict(b_0=spec0.b_0.tolist(), b_1=spec0.b_1.tolist())
+    tr = [np.linalg.inv(m.astype(np.float64)).astype(F) for m in spec0.inv]
+    msh = (spec0.mesh_v, spec0.mesh_f) if mesh else None
+    sh = dict(cast_shadow_rays=True, min_shadow_samples=int(rng.integers(2, 9)), n_shadow_samples=int(rng.choice([16, 64, 100000]))) if shadows else {}
+    inst = gpu_instancer(box, tr, textures=list(textures), instance_sampling_method=method, use_mean_distance=mean, mesh=msh, **sh)
+    n = 48
+    o, d = random_rays(200 + seed, n)
+    if not shadows:                      # (a segment the ray never leaves has no length in the reference: instancer.cpp:1019 reads past its list)
+        o[:6] = o[:6] * F(0.15)                                                  # six rays start inside the layer of patches
+    d[6:9] = d[6:9] * F(rng.uniform(0.5, 2.0))                                   # rays_d is used as given (un-normalised rays march in their own units)
+    S = int(rng.choice([7, 33, 64, 100, 257]))
+    h = float(rng.choice([0.004, 0.01, 0.05, 0.7]))
+    P = spec0.n_parameters
+    params = rng.uniform(0.1, 2.0, size=(n, P)).astype(F)
+    seed64 = int(rng.integers(0, 2 ** 62))
+    got = run_gpu(inst, o, d, params, S, h, seed=seed64)
+    want = run_oracle(inst, box, o, d, params, S, h, seed64, method, textures, mean, msh, **sh)
+    assert_same(got, want)
+    assert inst.status() == 0
