@@ -10,10 +10,13 @@
 //                      thousand patches of a scene, all pairs on the VALUs cost less than one BVH build -- face crossings
 //                      appended to the ray's hit list (<= 200, instancer.cpp:22)
 //   inst_mesh_kernel   the same against the triangles of the instancer mesh (closest crossing)
-//   inst_march_kernel  wave per ray, lane = marching step: rank sort of the hit list, the active set of instancer.cpp:800-826
-//                      one id per lane (insert / erase by ballot + lane shift), steps handed out 64 at a time between two
-//                      events, every output row written whole (emitted samples + the defaults of instancer.pyx:41-50).
-//                      Bound: HBM writes, (3+3+1+1+1+1+P) * 4 bytes per (ray, step).
+//   inst_march_kernel  wave per ray.  The reference's walk over the sorted crossings with a std::set of open patches
+//                      (instancer.cpp:800-826, 870-1010) is taken apart into steps that are parallel over crossings, gaps or
+//                      marching steps (see WaveLds below); emission is lane per marching step, every output row is written
+//                      whole (emitted samples + the defaults of instancer.pyx:41-50), dense, once.  <true>: with shadow rays
+//                      (occlusion queries by the wave, see `occluded`).
+//                      Bound: HBM writes, (3+3+1+1+1+1+P) * 4 bytes per (ray, step); measured at 0.25-0.35 of the peak, the
+//                      rest is per-ray event work.
 //
 // Float32 operations are spelled in the order of oracle/instancer_oracle.py (-ffp-contract=off, IEEE divide and sqrt), so that
 // the two agree bit for bit on the same instance matrices.
@@ -437,10 +440,18 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
         if (e < m && my_enter[q]) {
             const uint32_t ie = L.ev_id[e];
             int rank = 0;
-            #pragma unroll 8
-            for (int k = 0; k < m; ++k) {
-                const uint32_t ik = L.ev_id[k];
-                rank += ((L.ev_info[k] & 1u) && (ik < ie || (ik == ie && k < e))) ? 1 : 0;
+            if (a.method == 1) {
+                // 'nearest' does not depend on the order it meets the patches in once ties go to the smaller id (below): the
+                // intervals stay in event order, which is a popcount
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (g <= q) rank += __builtin_popcountll(g < q ? enter_mask[g] : (enter_mask[g] & ((1ull << lane) - 1ull)));
+            } else {
+                #pragma unroll 8
+                for (int k = 0; k < m; ++k) {
+                    const uint32_t ik = L.ev_id[k];
+                    rank += ((L.ev_info[k] & 1u) && (ik < ie || (ik == ie && k < e))) ? 1 : 0;
+                }
             }
             const float *og = a.origins + (size_t)ie * 3;
             L.u.iv.id[rank] = ie;
@@ -672,7 +683,10 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
                 const float ex = px - L.u.iv.ox[q], ey = py - L.u.iv.oy[q], ez = pz - L.u.iv.oz[q];
                 const float dd = __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
                 if (in) {
-                    if (cnt == 0 || dd < best) { inst = L.u.iv.id[q]; }
+                    // the reference keeps the FIRST patch of its ascending std::set at the smallest distance (strict <, :687): the
+                    // smallest id among equals, whatever order the intervals come in
+                    const uint32_t id = L.u.iv.id[q];
+                    if (cnt == 0 || dd < best || (dd == best && id < inst)) { inst = id; }
                     best = dd < best ? dd : best;
                     ++cnt;
                 }
