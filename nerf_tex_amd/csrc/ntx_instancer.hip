@@ -15,7 +15,7 @@
 //                      marching steps (see WaveLds below); emission is lane per marching step, every output row is written
 //                      whole (emitted samples + the defaults of instancer.pyx:41-50), dense, once.  <true>: with shadow rays
 //                      (occlusion queries by the wave, see `occluded`).
-//                      Bound: HBM writes, (3+3+1+1+1+1+P) * 4 bytes per (ray, step); measured at 0.25-0.35 of the peak, the
+//                      Bound: HBM writes, (3+3+1+1+1+1+P) * 4 bytes per (ray, step); measured at 0.30-0.43 of the peak, the
 //                      rest is per-ray event work.
 //
 // Float32 operations are spelled in the order of oracle/instancer_oracle.py (-ffp-contract=off, IEEE divide and sqrt), so that
@@ -83,6 +83,44 @@ __device__ __forceinline__ void normalized(float &x, float &y, float &z) {   // 
     if (n2 > 0.0f) { const float n = __builtin_sqrtf(n2); x = x / n; y = y / n; z = z / n; }
 }
 
+// A cone around the 64 rays of a wave: apex = mean origin (the rays of a camera share theirs), axis = mean direction, opening =
+// the widest ray; `reach` = how far an origin lies from the apex.  A sphere (c, r^2) that stays further than r + reach from the
+// cone cannot be met by any of the rays: tested lane per sphere, 64 spheres per ballot.  Conservative (widened; rays pointing
+// more than 60 degrees apart switch it off), so it never changes a result.
+struct WaveCone {
+    float ax, ay, az, ux, uy, uz, cos_t, sin_t, reach;
+    bool on;
+    __device__ __forceinline__ bool reaches(const float *c, float r2) const {
+        if (!on) return true;
+        const float vx = c[0] - ax, vy = c[1] - ay, vz = c[2] - az;
+        const float along = (vx * ux + vy * uy) + vz * uz;
+        const float v2 = (vx * vx + vy * vy) + vz * vz;
+        const float perp = __builtin_sqrtf(fmaxf(v2 - along * along, 0.0f));
+        const float r = __builtin_sqrtf(r2) * 1.001f + reach;
+        return perp * cos_t - along * sin_t <= r + 1e-4f * (__builtin_sqrtf(v2) + 1.0f);
+    }
+};
+__device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ WaveCone wave_cone(float ox, float oy, float oz, float dx, float dy, float dz) {
+    WaveCone c;
+    c.ax = wave_sum(ox) * (1.0f / 64.0f); c.ay = wave_sum(oy) * (1.0f / 64.0f); c.az = wave_sum(oz) * (1.0f / 64.0f);
+    const float dn = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float inv = dn > 0.0f ? 1.0f / dn : 0.0f;
+    const float nx = dx * inv, ny = dy * inv, nz = dz * inv;
+    float ux = wave_sum(nx), uy = wave_sum(ny), uz = wave_sum(nz);
+    const float un = __builtin_sqrtf((ux * ux + uy * uy) + uz * uz);
+    const float uinv = un > 0.0f ? 1.0f / un : 0.0f;
+    c.ux = ux * uinv; c.uy = uy * uinv; c.uz = uz * uinv;
+    const float cmin = wave_min((nx * c.ux + ny * c.uy) + nz * c.uz) - 1e-5f;
+    const float ex = ox - c.ax, ey = oy - c.ay, ez = oz - c.az;
+    c.reach = wave_max(__builtin_sqrtf((ex * ex + ey * ey) + ez * ez)) * 1.001f;
+    c.on = cmin > 0.5f && wave_min(dn) > 0.0f;
+    c.cos_t = cmin; c.sin_t = __builtin_sqrtf(fmaxf(1.0f - cmin * cmin, 0.0f));
+    return c;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // all (ray, instance) pairs: what rtcIntersect1 with the all-hits filter reports (instancer.cpp:779, 526-541)
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -99,10 +137,16 @@ __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict_
     const int k0 = (blockIdx.y * 4 + wave) * per_wave;
     const int k1 = k0 + per_wave < n_inst ? k0 + per_wave : n_inst;
     const float dd2 = (dx * dx + dy * dy) + dz * dz;
-    for (int k = k0; k < k1; ++k) {
-        // a sphere around the instanced box (centre, radius^2 widened by 1e-3): when none of the wave's 64 rays comes near it the
-        // instance is skipped -- a wave holds neighbouring rays, so this is the fate of most instances
-        const float *sp = spheres + (size_t)k * 4;       // wave-uniform: scalar loads
+    const WaveCone cone = wave_cone(ox, oy, oz, dx, dy, dz);
+    // spheres around the instanced boxes (centre, radius^2 widened): 64 instances per ballot against the wave's cone -- a wave holds
+    // neighbouring rays, so few instances survive -- and the survivors once more against each ray
+    for (int kb = k0; kb < k1; kb += 64) {
+      const int kl = kb + lane;
+      uint64_t mk = __ballot(kl < k1 && cone.reaches(spheres + (size_t)kl * 4, spheres[(size_t)kl * 4 + 3]));
+      while (mk) {
+        const int k = kb + __builtin_ctzll(mk);
+        mk &= mk - 1;
+        const float *sp = spheres + (size_t)k * 4;       // wave-uniform from here on: scalar loads
         const float cx = sp[0] - ox, cy = sp[1] - oy, cz = sp[2] - oz;
         const float qx = cy * dz - cz * dy, qy = cz * dx - cx * dz, qz = cx * dy - cy * dx;
         if (!__any((qx * qx + qy * qy) + qz * qz <= sp[3] * dd2)) continue;
@@ -134,6 +178,7 @@ __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict_
                 }
             }
         }
+      }
     }
 }
 
@@ -151,7 +196,13 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
     const int f1 = f0 + per_wave < n_tri ? f0 + per_wave : n_tri;
     float best = INFINITY;
     const float dd2 = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
-    for (int f = f0; f < f1; ++f) {
+    const WaveCone cone = wave_cone(o[0], o[1], o[2], d[0], d[1], d[2]);
+    for (int fb = f0; fb < f1; fb += 64) {
+      const int fl = fb + lane;
+      uint64_t mk = __ballot(fl < f1 && cone.reaches(tris + (size_t)fl * 13 + 9, tris[(size_t)fl * 13 + 12]));
+      while (mk) {
+        const int f = fb + __builtin_ctzll(mk);
+        mk &= mk - 1;
         const float *tr = tris + (size_t)f * 13;
         {   // the triangle's sphere, as in inst_hits_kernel
             const float cx = tr[9] - o[0], cy = tr[10] - o[1], cz = tr[11] - o[2];
@@ -171,6 +222,7 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
         if (v < 0.0f || u + v > 1.0f) continue;
         const float tt = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv_det;
         if (tt > 0.0f && tt <= T_FAR && tt < best) best = tt;
+      }
     }
     if (live && best < INFINITY) atomicMin(&t_mesh[ray], __builtin_bit_cast(uint32_t, best));   // positive floats order like their bits
 }
