@@ -6,6 +6,7 @@ The oracle is fed the instance matrices the library holds (`ntx_instancer_matric
 and both sides spell their float32 operations in one order: every output is compared BIT FOR BIT."""
 
 import json
+import os
 
 import numpy as np
 import pytest
@@ -229,7 +230,7 @@ def test_instance_renderer_end_to_end(npar, textures, blur):
     assert want[:, 3].max() > 0.5 and (want[:, 3] > 0).sum() > 40 and np.all(got[7] == 0)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NTX_INSTANCER_FUZZ_SEEDS", "16"))))     # a soak run sets more (profiles/r03/soak_instancer.txt)
 def test_fuzz_scenes_bit_for_bit(seed):
     """Random scenes, ray sets and settings (patch count, box, scales, step size, buffer length incl. too short ones, choice rule,
     lights, mean distances, mesh, shadow rays in both modes, rays that start inside the patch layer): every buffer bit for bit."""
@@ -260,3 +261,33 @@ def test_fuzz_scenes_bit_for_bit(seed):
     want = run_oracle(inst, box, o, d, params, S, h, seed64, method, textures, mean, msh, **sh)
     assert_same(got, want)
     assert inst.status() == 0
+
+
+def test_the_measured_scene_bit_for_bit():
+    """Parity where the numbers of DESIGN 4.5 are measured: the scene of tools/bench_instancer.py (48 x 48 patches of the carpet
+    config's box on a waving sheet that is also the mesh, 1024 steps of 0.002, 'nearest', a directional light) -- 40 seeded rays of a
+    4096-ray call against the restatement, every buffer bit for bit (~260 steps per ray through ~35 overlapping patches)."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("bench_instancer", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_instancer.py"))
+    bi = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(bi)
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.dataset import look_at
+    from nerf_tex_amd.instancer import Instancer
+    tr, v, f = bi.sheet(48)
+    textures = ['', '', '', '', 'light']
+    inst = Instancer(bi.B0, bi.B1, textures=textures, transformations=tr, instance_sampling_method="nearest", mesh=(v, f))
+    fam = synthetic.FAMILIES["carpet"]
+    c2w = look_at(np.asarray(fam["cam"], F))
+    focal = 800 / np.tan(fam["angle"] / 2) / 2
+    side, n, S, h = 64, 4096, 1024, 0.002
+    r0 = (800 - side) // 2
+    rows, cols = np.meshgrid(np.arange(r0, r0 + side), np.arange(r0, r0 + side), indexing="ij")
+    ro, rd, t, cone = orc.proxy_rays(np.stack([rows.ravel(), cols.ravel()], -1), 800, 800, focal, c2w, [-1.7, -1.7, -.3], [1.7, 1.7, .4], F)
+    params = np.tile(np.asarray([fam["params"]], F), (n, 1))
+    got = run_gpu(inst, ro, rd, params, S, h, seed=1)
+    pick = np.random.default_rng(0).choice(n, size=40, replace=False)
+    box = dict(b_0=bi.B0, b_1=bi.B1)
+    spec = io.make_spec(box["b_0"], box["b_1"], None, textures=textures, instance_sampling_method="nearest", mesh=(v, f), matrices=inst.matrices())
+    want = io.get_model_input(spec, ro[pick], rd[pick], params[pick], S, h, io.offset_uniforms(n, 1)[pick], io.choice_uniforms(n, S, 1)[pick])
+    assert (want[3] > 0).sum() > 40 * 150 and want[8].all() and want[5].all()          # long marches, every ray ends on the sheet
+    assert_same([g[pick] for g in got], list(want))
