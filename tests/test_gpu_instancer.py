@@ -291,3 +291,66 @@ def test_the_measured_scene_bit_for_bit():
     want = io.get_model_input(spec, ro[pick], rd[pick], params[pick], S, h, io.offset_uniforms(n, 1)[pick], io.choice_uniforms(n, S, 1)[pick])
     assert (want[3] > 0).sum() > 40 * 150 and want[8].all() and want[5].all()          # long marches, every ray ends on the sheet
     assert_same([g[pick] for g in got], list(want))
+
+
+def test_instanced_image_through_the_render_harness():
+    """What the shipped render configs run, through the reference's plugin path: a config dict in the reference's format
+    (network.render.Render -> Dataset -> ParamNerf -> network.renderer.InstanceRenderer with an instancer_config), remapped and
+    instantiated like main.py does; the instancer is this package's.  A 40 x 40 image of 36 patches on a sheet against the whole
+    pipeline restated: oracle rays -> oracle instancer -> float64 tail."""
+    import importlib.util
+    from nerf_tex_amd import synthetic, util
+    from nerf_tex_amd.dataset import look_at
+    spec_ = importlib.util.spec_from_file_location("bench_instancer", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_instancer.py"))
+    bi = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(bi)
+    tr, v, f = bi.sheet(6, extent=0.35, scale=0.09)
+    H = W = 40
+    S, step, patch_scale, dscale = 192, 0.004, 0.09, 60.0
+    textures = ['', '', '', '', 'light']
+    params = [1, 1, 1, .1, 0.3, 0.2, 1]
+    cam = 6. * np.asarray([0.9165, 0., 0.4])
+    c2w = look_at(cam)
+    emb = lambda n_: {'module': 'network.model.FourierFeatures', 'n_freq_bands': n_}
+    aabb0, aabb1 = [-0.7, -0.7, -.2], [0.7, 0.7, .3]
+    config = {
+        'module': 'network.render.Render', 'target_path': None,
+        'test_dataset_config': {
+            'module': 'network.dataset.Dataset',
+            'data_loader_config': {'module': 'nerf_tex_amd.dataset.FromViews', 'height': H, 'width': W, 'angle': 0.16,
+                                   'views': [{'pose': c2w, 'parameters': params}]},
+            'pixel_sampler_config': {'module': 'network.pixel_sampler.Full'},
+            'ray_sampler_config': {'module': 'network.ray_sampler.Proxy'},
+            'proxy_config': {'module': 'network.proxy.AABB', 'b_0': aabb0, 'b_1': aabb1},
+            'n_epochs': 1},
+        'model_config': {'module': 'network.model.ParamNerf', 'pos_embedding': emb(10), 'dir_embedding': emb(4), 'param_embedding': emb(4),
+                         'n_parameters': [1, 6]},
+        'renderer_config': {
+            'module': 'network.renderer.InstanceRenderer', 'n_samples': S, 'render_chunk': 16384, 'density_scale': dscale,
+            'instancer_config': {'module': 'nerf_tex_amd.instancer.Instancer', 'b_0': bi.B0, 'b_1': bi.B1, 'cast_shadow_rays': False,
+                                 'textures': textures, 'transformations': [m.tolist() for m in tr], 'mesh': (v, f), 'patch_scale': patch_scale,
+                                 'instance_sampling_method': 'nearest'},
+            'density_reweighting': True, 'step_size': step},
+        'logger_config': {'module': 'network.logger.Logger'},
+    }
+    model, mspec, wts = make_model((1, 6), dense_media=True)
+    blob = synthetic.synthetic_weights(model.layer_table(), seed=0, dense_media=True)
+    imgs = util.instantiate(dict(util.remap_reference_config(config), weights=blob, weights_order="keras_get_weights"))
+    rgba = imgs[0][0].cpu().numpy().reshape(H * W, 4)
+    # the same, restated
+    focal = orc.focal_from_angle(W, 0.16)
+    ro, rd, t, cone = orc.proxy_rays(orc.full_pixels(H, W), H, W, focal, c2w.astype(F), aabb0, aabb1, F)
+    keep = np.isfinite(t[:, 0])
+    k = int(keep.sum())
+    inv, dir_t, org = io.prepare_instances(tr)
+    from nerf_tex_amd.instancer import Instancer
+    lib_side = Instancer(bi.B0, bi.B1, textures=textures, transformations=tr, mesh=(v, f))
+    spec = io.make_spec(bi.B0, bi.B1, None, textures=textures, instance_sampling_method="nearest", mesh=(v, f), matrices=lib_side.matrices())
+    par = np.tile(np.asarray([params], F), (k, 1))
+    b = io.get_model_input(spec, ro[keep], rd[keep], par, S, step, io.offset_uniforms(k, 0, (0, k, k)), io.choice_uniforms(k, S, 0, (0, k, k)))
+    rc, ra = orc.instance_evaluate_model(wts, mspec, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9], cone[keep], None,
+                                         patch_scale, dscale, True, False, False, (1., 1., 1.), None, dtype=np.float64)
+    want = np.zeros((H * W, 4)); want[keep, :3] = rc; want[keep, 3] = ra
+    assert orc.rel_linf(rgba, want) <= TOL
+    # ... of an image with something in it: rays beside the sheet, rays through tens of patches, opaque and half-transparent pixels
+    assert k > 0.8 * H * W and 0.3 * k < b[8].sum() < 0.9 * k and (b[3] > 0).sum() > 20 * b[8].sum()
+    assert want[:, 3].max() > 0.9 and 0.2 < want[:, 3].mean()
