@@ -399,6 +399,7 @@ int ntx_instancer_set_mesh(ntx_instancer *inst, const float *vertices, int64_t n
  * here the offset of a ray is U[0,1) from word 0 of Philox4x32-10 at counter (0, ray lo, ray hi, 2) under `seed`, the patch
  * choice of (ray, step) from counter (step, ray lo, ray hi, 3); `opts` carries the ray index map (as for ntx_render_rays;
  * NULL = the call's own indices), so chunked or sharded calls draw what the whole image draws.
+ * An instancer belongs to one device and owns one workspace: calls on it must be stream-ordered (like a context's).
  * *status_flag (DEVICE, may be NULL) |= 1 when a ray had more than 200 face crossings (the rest were dropped, which ones is
  * unspecified -- as in the reference).  1 <= n_pts <= 4096. */
 int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const float *rays_d, const float *parameters, int64_t n_rays,

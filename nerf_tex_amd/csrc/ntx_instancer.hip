@@ -1077,6 +1077,10 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
             idx_run = opts->ray_run_length > 0xffffffffLL ? 0xffffffffu : (uint32_t)opts->ray_run_length;
         }
     }
+    // a call longer than the workspace is cut into pieces; every piece must start on a run boundary of the index map (checked
+    // here, before anything is launched: a call that fails has written nothing)
+    if (n_rays > inst->cap_rays && idx_run != 0xffffffffu && inst->cap_rays % idx_run != 0)
+        return ntx_set_error(NTX_E_INVALID, "ray_run_length %u must divide the reserved %lld rays when a call is split (ntx_instancer_reserve)", idx_run, (long long)inst->cap_rays);
     INST_TRY(hipSetDevice(inst->device));
     hipStream_t st = (hipStream_t)stream;
     Box box;
@@ -1119,8 +1123,7 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         { const char *dbg = getenv("NERFTEX_INST_DEBUG"); a.debug_skip = dbg ? atoi(dbg) : 0; }
         // the piece's rays continue the call's index map: local k of the piece = local c0 + k of the call
         if (idx_run == 0xffffffffu) { a.idx0 = idx0 + c0; a.idx_run = 0xffffffffu; a.idx_stride = 0; }
-        else if (c0 % idx_run == 0) { a.idx0 = idx0 + (c0 / idx_run) * idx_stride; a.idx_run = idx_run; a.idx_stride = idx_stride; }
-        else return ntx_set_error(NTX_E_INVALID, "ray_run_length %u must divide the reserved %lld rays when a call is split (ntx_instancer_reserve)", idx_run, (long long)inst->cap_rays);
+        else { a.idx0 = idx0 + (c0 / idx_run) * idx_stride; a.idx_run = idx_run; a.idx_stride = idx_stride; }
         a.spheres = inst->d_spheres; a.tris = inst->d_tris; a.n_inst = K; a.n_tri = F; a.box = box;
         a.min_shadow = inst->desc.min_shadow_samples; a.n_shadow = inst->desc.n_shadow_samples;
         if (inst->desc.cast_shadow_rays && a.light_dir_idx >= 0) hipLaunchKernelGGL(inst_march_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, a);

@@ -93,7 +93,7 @@ class Instancer:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and h.value:
+        if h is not None and h.value and _lib is not None and getattr(_lib, "lib", None) is not None:   # (interpreter shutdown)
             _lib.lib.ntx_instancer_destroy(h)
             self._h = None
 

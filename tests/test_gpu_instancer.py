@@ -160,6 +160,11 @@ def test_rays_can_be_split_and_sharded():
     tail = run_gpu(inst, ob[65_000:], db[65_000:], np.zeros((5_000, 0), F), 8, 0.2, seed=4, ray_index=(65_000, 5_000, 5_000))
     assert_same([x[65_000:] for x in outb], tail)
     assert outb[8][65_536:].any()
+    # a split call's pieces must start on run boundaries of the index map: refused before anything is launched
+    from nerf_tex_amd import _lib
+    with pytest.raises(_lib.NtxError) as e:
+        inst.get_model_input(ob, db, np.zeros((big, 0), F), 8, 0.2, seed=4, ray_index=(0, 1000, 1000))
+    assert e.value.code == _lib.NTX_E_INVALID and "ray_run_length" in str(e.value)
 
 
 def test_overflow_flags_and_refusals(tmp_path):
