@@ -18,7 +18,9 @@ Workloads
       `--shard bands`), gathered to rank 0 through `ntx_gather_image` (RCCL ncclGather).  value = rays that hit the proxy
       x S / time.  After the timed region rank 0 renders the whole image alone and the line reports whether the
       gathered image is bit-identical to it.
-  carpet_instanced                        the InstanceRenderer tail, N = 1.
+  carpet_instanced                        the InstanceRenderer tail on synthetic instancer buffers, N = 1.
+  carpet_instanced_scene                  what the shipped render configs run per chunk, from rays: the patch instancer on the GPU
+      (`ntx_instancer_model_input`) on a synthetic scene in the carpet config's shape, then the tail on ITS output; N = 1.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel: algorithmic FLOPs = 2 * MACs(model) per
 ray-sample / average launch duration measured with HIP events on the launch stream.
@@ -202,6 +204,127 @@ def bench_instanced(args) -> None:
                      "kernel_ms": kernel_ms}}), flush=True)
 
 
+def bench_instanced_scene(args) -> None:
+    """`--workload carpet_instanced_scene`: one render chunk of configs/config_carpet_render.py from RAYS -- 16 384 rays of the
+    config's first camera -> `ntx_instancer_model_input` (the reference's C_Instancer::GetModelInput, instancer.cpp:751-1037:
+    Embree on one CPU thread there, three HIP kernels here) -> `ntx_render_instanced` on the ten buffers it leaves in
+    HBM, both on one stream, nothing through the host.  The reference's meshes are LFS pointers, so the scene is synthetic in the
+    config's shape: its patch box, patch_scale 0.09, step 0.002, 1024 samples, 'nearest', 48 x 48 patches on a waving sheet that is
+    also the instancer mesh (`synthetic.patch_sheet`).  value = in-patch ray-samples/s over the whole step; `roofline` = the tail's
+    kernel (MFMA) on the in-patch samples the instancer produced; `instancer` = its own HBM roofline (every output element once);
+    `parity` = 48 seeded rays: the instancer's buffers bit for bit and the rendered RGBA within 1e-4 of the restated pipeline."""
+    import torch
+    from nerf_tex_amd import _lib, synthetic
+    from nerf_tex_amd.dataset import look_at
+    from nerf_tex_amd.instancer import Instancer
+    from nerf_tex_amd.model import ParamNerf
+    from nerf_tex_amd.proxy import AABB
+    from nerf_tex_amd.ray_sampler import Proxy
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("carpet_instanced_scene is a single-GPU workload")
+    if args.precision != "float32":
+        raise SystemExit("carpet_instanced_scene is timed at float32")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    fam = synthetic.FAMILIES["carpet"]
+    emb = lambda n: {"module": "network.model.FourierFeatures", "n_freq_bands": n}
+    model = ParamNerf(emb(10), emb(4), emb(4), list(fam["n_parameters"]))["model"]
+    model.set_blob(synthetic.synthetic_weights(model.layer_table(), seed=0))
+    grid, side, S, step_size, patch_scale, density_scale = 48, 128, 1024, 0.002, 0.09, 400.0      # (weights and density scale of carpet_instanced)
+    n, P = side * side, model.n_params
+    tr, mesh_v, mesh_f = synthetic.patch_sheet(grid)
+    textures = ['', '', '', '', 'light']                      # config_carpet_render.py:86 without its image texture
+    b_0, b_1 = synthetic.PATCH_BOX
+    inst = Instancer(b_0, b_1, textures=textures, transformations=tr, instance_sampling_method="nearest", mesh=(mesh_v, mesh_f))
+    c2w = look_at(np.asarray(fam["cam"], np.float32))
+    focal = 800 / np.tan(fam["angle"] / 2) / 2
+    r0 = (800 - side) // 2                                    # a centred side x side window of the config's 800 x 800 grid
+    rows, cols = np.meshgrid(np.arange(r0, r0 + side), np.arange(r0, r0 + side), indexing="ij")
+    loc = torch.as_tensor(np.stack([rows.ravel(), cols.ravel()], -1).astype(np.float32), device=dev)
+    aabb = ([-1.7, -1.7, -.3], [1.7, 1.7, .4])
+    ro, rd, t, cone = Proxy(800, 800, focal, AABB(*aabb))(loc, c2w, device=dev)
+    params = torch.as_tensor(np.asarray([fam["params"]], np.float32), device=dev).repeat(n, 1).contiguous()
+    e = lambda *shape, dt=torch.float32: torch.empty(shape, device=dev, dtype=dt)
+    rays_d_map, pts, tt, dists = e(n, S, 3), e(n, S, 3), e(n, S), e(n, S)
+    color_last, alpha_last, weight = e(n, 3), e(n), e(n, S)
+    instance_id, hit, params_map = e(n, S, dt=torch.int32), e(n, dt=torch.uint8), e(n, S, P)
+    status = torch.zeros(1, device=dev, dtype=torch.int32)
+    color, alpha = e(n, 3), e(n)
+    cone1 = cone.reshape(n).contiguous()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    model.reserve(0, n)
+    seed = 1
+
+    def instancer_step():
+        _lib.check(_lib.lib.ntx_instancer_model_input(
+            inst._h, ro.data_ptr(), rd.data_ptr(), params.data_ptr(), n, S, step_size, seed, None, rays_d_map.data_ptr(), pts.data_ptr(),
+            tt.data_ptr(), dists.data_ptr(), color_last.data_ptr(), alpha_last.data_ptr(), weight.data_ptr(), instance_id.data_ptr(),
+            hit.data_ptr(), params_map.data_ptr(), status.data_ptr(), stream))
+
+    def tail_step():
+        _lib.check(_lib.lib.ntx_render_instanced(
+            model.ctx(0), rays_d_map.data_ptr(), pts.data_ptr(), tt.data_ptr(), dists.data_ptr(), color_last.data_ptr(),
+            alpha_last.data_ptr(), weight.data_ptr(), instance_id.data_ptr(), hit.data_ptr(), params_map.data_ptr(), cone1.data_ptr(),
+            n, S, -1, patch_scale, density_scale, 0, _lib.f3([1, 1, 1.]), None, None, color.data_ptr(), alpha.data_ptr(), None, stream))
+
+    for _ in range(args.warmup):
+        instancer_step(); tail_step()
+    torch.cuda.synchronize()
+    n_in = int((dists > 0).sum().item())
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b, c in ev:
+        a.record(); instancer_step(); b.record(); tail_step(); c.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    inst_ms = float(np.mean([a.elapsed_time(b) for a, b, c in ev]))
+    kernel_ms = float(np.mean([b.elapsed_time(c) for a, b, c in ev]))
+    flops_per_sample = 2 * model.macs_per_sample()
+    achieved = n_in * flops_per_sample / (kernel_ms * 1e-3) / 1e12
+    out_bytes = n * S * 4 * (3 + 3 + 1 + 1 + 1 + 1 + P) + n * (12 + 4 + 1) + n * (24 + 4 * P)
+    gbps = out_bytes / (inst_ms * 1e-3) / 1e9
+    line = {
+        "metric": "in-patch ray-samples/sec (rays -> patch instancer -> InstanceRenderer tail, one render chunk)",
+        "value": n_in * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"carpet_instanced_scene: {n} rays of config_carpet_render.py's first camera x {S} marching steps of {step_size} through "
+                               f"{grid * grid} patches (box {b_0}..{b_1} x {patch_scale}) on a waving sheet of {mesh_f.shape[0]} triangles, 'nearest', "
+                               f"directional light; {n_in} in-patch samples ({n_in / n:.1f} per ray); ParamNerf n_parameters={list(fam['n_parameters'])}; "
+                               "ntx_instancer_model_input -> ntx_render_instanced on one stream",
+                   "rays": n, "marching_samples_per_ray": S, "in_patch_samples": n_in, "hit_rays": int(hit.sum().item()), "flops_per_sample": flops_per_sample},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "kernel": "ntx::instance_kernel", "kernel_ms": kernel_ms,
+                     "what": "ntx_render_instanced (ordering kernels + instance_kernel) on the instancer's own output"},
+        "instancer": {"ms": inst_ms, "share_of_step": inst_ms / (inst_ms + kernel_ms), "rays_per_s": n / (inst_ms * 1e-3), "status_flag": int(status.item()),
+                      "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "algorithmic_bytes": out_bytes,
+                                   "traffic": 1168796834 + 16595173 + 110656 + 16551669 + 1320704 + 2285568,
+                                   "traffic_source": "profiles/r03/instancer_pmc_summary.json (WRITE_SIZE + 2 x FETCH_SIZE of the three kernels, same scene)"},
+                      "kernels": "inst_hits_kernel + inst_mesh_kernel + inst_march_kernel (DESIGN 4.5)"}}
+    if not args.no_parity:
+        from oracle import instancer_oracle as io
+        from oracle import nerftex_oracle as orc
+        t1 = time.perf_counter()
+        pick = np.sort(np.random.default_rng(7).choice(n, size=48, replace=False))
+        ti = torch.as_tensor(pick, device=dev)
+        spec = io.make_spec(b_0, b_1, None, textures=textures, instance_sampling_method="nearest", mesh=(mesh_v, mesh_f), matrices=inst.matrices())
+        h = lambda x: x[ti].cpu().numpy()
+        want = io.get_model_input(spec, h(ro), h(rd), h(params), S, step_size, io.offset_uniforms(n, seed)[pick], io.choice_uniforms(n, S, seed)[pick])
+        got = [h(rays_d_map), h(pts), h(tt), h(dists), h(color_last)[:, None, :], h(alpha_last)[:, None], h(weight), h(instance_id), h(hit).astype(bool), h(params_map)]
+        same = all(np.array_equal(g, w) for g, w in zip(got, want))
+        mspec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(fam["n_parameters"]))
+        rc, ra = orc.instance_evaluate_model(orc.split_blob(mspec, model.get_blob()), mspec, *want[:8], want[8], want[9], h(cone1)[:, None], None,
+                                             patch_scale, density_scale, True, False, False, (1., 1., 1.), None, dtype=np.float64)
+        rgba = np.concatenate([h(color), h(alpha)[:, None]], -1)
+        err = float(orc.rel_linf(rgba, np.concatenate([rc, ra[:, None]], -1)))
+        line["parity"] = {"rays": 48, "instancer_buffers_bit_identical": bool(same), "rel_linf_f64": err, "tolerance": 1e-4, "ok": bool(same and err <= 1e-4),
+                          "what": "seeded rays of the timed chunk: the ten buffers of ntx_instancer_model_input against the restatement of "
+                                  "instancer.cpp:751-1037 (oracle/instancer_oracle.py; Embree cannot be built here: unpinned), and [color, alpha] against "
+                                  "that restatement followed by the float64 restatement of renderer.py:247-354",
+                          "oracle_seconds": round(time.perf_counter() - t1, 2)}
+    print(json.dumps(line), flush=True)
+
+
 def launch_ranks(cmds, envs, deadline_s: float, log_dir: str, poll_s: float = 0.2, label: str = "bench.py") -> int:
     """Start one process per rank (own session each, so a rank's children die with it), rank 0's stdout passed through, every
     rank's stderr in `log_dir/rank<r>.err`.  Poll them: the first non-zero exit ends the others (SIGTERM, SIGKILL after 5 s); so
@@ -312,7 +435,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS) + sorted(SHARDED) + ["carpet_instanced"])
+    ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS) + sorted(SHARDED) + ["carpet_instanced", "carpet_instanced_scene"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="float32", choices=["float32", "fp16x3"],
                     help="arithmetic of the Dense layers (include/nerftex.h: ntx_precision); float32 = the reference's")
@@ -330,6 +453,8 @@ def main() -> None:
         sys.exit(self_launch(args))
     if args.workload == "carpet_instanced":
         return bench_instanced(args)
+    if args.workload == "carpet_instanced_scene":
+        return bench_instanced_scene(args)
 
     # The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL writes its version banner with printf
     # when a communicator is created), so from here on file descriptor 1 goes to stderr and the line is written to the

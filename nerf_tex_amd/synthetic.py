@@ -63,3 +63,28 @@ def all_hit_rays(n_rays: int, b_0, b_1, cam, seed: int = 1):
     rays_o = np.broadcast_to(o, d.shape).astype(np.float32)
     cone = rng.uniform(1e-4, 1e-3, size=(n_rays, 1)).astype(np.float32)
     return rays_o.copy(), d.astype(np.float32), np.stack([t0, t1], -1).astype(np.float32), cone
+
+
+PATCH_BOX = ([-1.4, -1.2, -.1], [1.2, 1.2, 1.8])     # configs/config_carpet_render.py:83-84
+
+
+def patch_sheet(grid: int, extent: float = 1.5, scale: float = 0.09):
+    """A synthetic scene for the patch instancer in the shape of the shipped render configs (their meshes are LFS pointers):
+    grid x grid patches on the sheet z = 0.08 sin(2x) cos(2y), |x|, |y| <= extent.  Returns the patch -> world transformations
+    [grid^2,4,4] -- (tangent, bitangent, normal) * scale at the vertex, what DistributeInstancesOnMesh builds
+    (instancer.cpp:360-366) -- and the sheet itself as a triangle mesh (vertices [grid^2,3], faces [2 (grid-1)^2, 3])."""
+    xs = np.linspace(-extent, extent, grid)
+    x, y = np.meshgrid(xs, xs, indexing="ij")
+    z = 0.08 * np.sin(2 * x) * np.cos(2 * y)
+    dzdx = 0.16 * np.cos(2 * x) * np.cos(2 * y); dzdy = -0.16 * np.sin(2 * x) * np.sin(2 * y)
+    tr = np.zeros((grid, grid, 4, 4), np.float32)
+    n = np.stack([-dzdx, -dzdy, np.ones_like(z)], -1); n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    tx = np.stack([np.ones_like(z), np.zeros_like(z), dzdx], -1); tx /= np.linalg.norm(tx, axis=-1, keepdims=True)
+    bt = np.cross(n, tx)
+    tr[..., :3, 0] = tx * scale; tr[..., :3, 1] = bt * scale; tr[..., :3, 2] = n * scale
+    tr[..., :3, 3] = np.stack([x, y, z], -1); tr[..., 3, 3] = 1
+    v = np.stack([x, y, z], -1).reshape(-1, 3).astype(np.float32)
+    idx = np.arange(grid * grid).reshape(grid, grid)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    f = np.concatenate([np.stack([a, b, c], -1), np.stack([a, c, d], -1)]).astype(np.int32)
+    return tr.reshape(-1, 4, 4), v, f

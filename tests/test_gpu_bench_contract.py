@@ -53,6 +53,22 @@ def test_sharded_workload_line_at_one_gpu():
     assert "ntx_generate_rays_strided" in d["with_ray_setup"]["what"] and d["with_ray_setup"]["value"] > 0.95 * d["value"]
 
 
+def test_instanced_scene_line():
+    """`--workload carpet_instanced_scene`: rays -> patch instancer -> InstanceRenderer tail, one chunk: the tail's MFMA roofline on the
+    samples the instancer produced, the instancer's own HBM roofline, and the parity block (buffers bit for bit, RGBA <= 1e-4)."""
+    d = _run("--workload", "carpet_instanced_scene")
+    assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["unit"] == "ray-samples/s" and "model" not in d["config"]
+    c, r, i = d["config"], d["roofline"], d["instancer"]
+    assert c["rays"] == 16384 and c["marching_samples_per_ray"] == 1024 and c["hit_rays"] == 16384 and c["in_patch_samples"] > 3_000_000
+    assert r["bound"] == "mfma" and 0.8 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    ir = i["roofline"]
+    assert ir["bound"] == "hbm" and ir["peak"] == 8000.0 and abs(ir["frac"] - ir["achieved"] / ir["peak"]) < 1e-9 and 0.1 < ir["frac"] < 1.0
+    assert abs(ir["achieved"] - ir["algorithmic_bytes"] / (i["ms"] * 1e-3) / 1e9) / ir["achieved"] < 1e-6 and ir["traffic"] < 1.1 * ir["algorithmic_bytes"]
+    assert i["status_flag"] == 0 and i["share_of_step"] < 0.05 and i["ms"] < 2.0
+    p_ = d["parity"]
+    assert p_["ok"] is True and p_["instancer_buffers_bit_identical"] is True and p_["rel_linf_f64"] <= 1e-4 and p_["rays"] == 48
+
+
 MULTI_RANK_FIELDS = ("per_rank", "gather_bytes", "gather_how", "imbalance", "rank0_alone_ms")
 
 

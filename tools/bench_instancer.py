@@ -26,27 +26,10 @@ from nerf_tex_amd.ray_sampler import Proxy                    # noqa: E402
 from nerf_tex_amd.renderer import InstanceRenderer            # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md
-B0, B1 = [-1.4, -1.2, -.1], [1.2, 1.2, 1.8]                   # config_carpet_render.py:83-84
+B0, B1 = synthetic.PATCH_BOX                                  # config_carpet_render.py:83-84
 
 
-def sheet(grid: int, extent: float = 1.5, scale: float = 0.09):
-    """grid x grid patches on z = 0.08 sin(2x) cos(2y): transformations (tangent, bitangent, normal) * scale at the vertex
-    (what DistributeInstancesOnMesh builds, instancer.cpp:360-366) + the sheet as a triangle mesh."""
-    xs = np.linspace(-extent, extent, grid)
-    x, y = np.meshgrid(xs, xs, indexing="ij")
-    z = 0.08 * np.sin(2 * x) * np.cos(2 * y)
-    dzdx = 0.16 * np.cos(2 * x) * np.cos(2 * y); dzdy = -0.16 * np.sin(2 * x) * np.sin(2 * y)
-    tr = np.zeros((grid, grid, 4, 4), np.float32)
-    n = np.stack([-dzdx, -dzdy, np.ones_like(z)], -1); n /= np.linalg.norm(n, axis=-1, keepdims=True)
-    tx = np.stack([np.ones_like(z), np.zeros_like(z), dzdx], -1); tx /= np.linalg.norm(tx, axis=-1, keepdims=True)
-    bt = np.cross(n, tx)
-    tr[..., :3, 0] = tx * scale; tr[..., :3, 1] = bt * scale; tr[..., :3, 2] = n * scale
-    tr[..., :3, 3] = np.stack([x, y, z], -1); tr[..., 3, 3] = 1
-    v = np.stack([x, y, z], -1).reshape(-1, 3).astype(np.float32)
-    idx = np.arange(grid * grid).reshape(grid, grid)
-    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
-    f = np.concatenate([np.stack([a, b, c], -1), np.stack([a, c, d], -1)]).astype(np.int32)
-    return tr.reshape(-1, 4, 4), v, f
+sheet = synthetic.patch_sheet
 
 
 def timed(fn, reps):
