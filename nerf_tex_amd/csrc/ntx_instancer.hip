@@ -48,6 +48,7 @@ constexpr float T_FAR = 100.0f;          // init_ray(..., 0, 100, ...), instance
 constexpr uint32_t INF_BITS = 0x7f800000u;
 
 struct Box { float b0[3], b1[3]; };
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------------------------------------------
 struct MarchArgs {
     const float *rays_o, *rays_d, *params;
-    const float *mats, *dirs, *origins;
+    const float *mats, *dirs, *origins, *xforms;   // xforms[K][24]: mats[k] (12), dirs[k] (9), padding: what a step gathers
     const uint32_t *count; const uint2 *hits; const uint32_t *t_mesh;   // t_mesh NULL = no mesh
     float *rays_d_map, *pts, *t, *dists, *color_last, *alpha_last, *alpha_weight, *params_map;
     int32_t *instance_id; uint8_t *hit; int32_t *status;
@@ -387,7 +388,6 @@ __device__ __forceinline__ void fill_pattern(float *row, int f0, int f1, int per
     for (int f = f0 + lane; f < h1; f += 64) __builtin_nontemporal_store(at(f % period), row + f);
     const int nvec = (f1 - h1) >> 2;
     if (nvec > 0) {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4 *vp = reinterpret_cast<f32x4 *>(row + h1);
         int r = (h1 + 4 * lane) % period;
         const int inc = 256 % period;
@@ -506,8 +506,8 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
                 }
             }
             const float *og = a.origins + (size_t)ie * 3;
-            L.u.iv.id[rank] = ie;
             L.u.iv.be[rank] = (uint32_t)e | (my_next[q] << 16);
+            L.u.iv.id[rank] = ie;
             L.u.iv.ox[rank] = og[0]; L.u.iv.oy[rank] = og[1]; L.u.iv.oz[rank] = og[2];
         }
     }
@@ -695,6 +695,8 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
         uint64_t cand[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            cand[g] = 0;
+            if (64 * g >= n_int) continue;
             const int q = lane + 64 * g;
             bool c = false;
             if (q < n_int) {
@@ -772,8 +774,14 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
         // every lane computes its sample (lanes behind the last step work on a clamped patch index and store nothing); the rows go
         // out DENSE: element f of the 64 samples' flat [64 x 3] / [64 x P] block is fetched from lane f / 3 (f / P) by a shuffle,
         // so that a store instruction writes 256 consecutive bytes whatever the width of the row
-        const float *mi = a.mats + (size_t)inst * 12;
-        const float *di = a.dirs + (size_t)inst * 9;
+        float mi[12], di[9];                                   // the patch's world -> patch matrix and direction map: six 16-byte loads
+        {
+            const f32x4 *xf = reinterpret_cast<const f32x4 *>(a.xforms) + (size_t)inst * 6;
+            const f32x4 x0 = xf[0], x1 = xf[1], x2 = xf[2], x3 = xf[3], x4 = xf[4], x5 = xf[5];
+            mi[0] = x0.x; mi[1] = x0.y; mi[2] = x0.z; mi[3] = x0.w; mi[4] = x1.x; mi[5] = x1.y; mi[6] = x1.z; mi[7] = x1.w;
+            mi[8] = x2.x; mi[9] = x2.y; mi[10] = x2.z; mi[11] = x2.w;
+            di[0] = x3.x; di[1] = x3.y; di[2] = x3.z; di[3] = x3.w; di[4] = x4.x; di[5] = x4.y; di[6] = x4.z; di[7] = x4.w; di[8] = x5.x;
+        }
         float p3[3], d3[3], l3[3] = {0.0f, 0.0f, 0.0f}, lst = 0.0f;
         affine(mi, px, py, pz, p3);                                                             // getPt
         linear33(di, ndx, ndy, ndz, d3);                                                        // getDir
@@ -871,7 +879,7 @@ struct ntx_instancer {
     int64_t n_inst = 0, n_tri = 0, cap_rays = 0;
     std::vector<float> h_mats, h_dirs, h_org;          // world -> patch [K,12], direction maps [K,9], origins [K,3]
     std::vector<float> h_spheres;                      // [K,4] centre and squared radius of the instanced box, world
-    float *d_mats = nullptr, *d_dirs = nullptr, *d_org = nullptr, *d_tris = nullptr, *d_spheres = nullptr;
+    float *d_mats = nullptr, *d_dirs = nullptr, *d_org = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_xforms = nullptr;
     uint32_t *d_count = nullptr, *d_tmesh = nullptr;
     uint2 *d_hits = nullptr;
 };
@@ -907,7 +915,7 @@ bool invert4(const float *m, double *out) {
 void release(ntx_instancer *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    for (void *q : {(void *)p->d_mats, (void *)p->d_dirs, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits})
+    for (void *q : {(void *)p->d_mats, (void *)p->d_dirs, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_xforms, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits})
         if (q) (void)hipFree(q);
     delete p;
 }
@@ -935,7 +943,7 @@ int ntx_instancer_create(const ntx_instancer_desc *desc, const float *transforma
     if (!out) return ntx_set_error(NTX_E_INVALID, "out is NULL");
     *out = nullptr;
     if (!desc || desc->size < sizeof(ntx_instancer_desc)) return ntx_set_error(NTX_E_INVALID, "ntx_instancer_desc is NULL or its size field is not sizeof(ntx_instancer_desc)");
-    if (n_instances < 0 || n_instances > 0x7fffffff || (n_instances > 0 && !transformations)) return ntx_set_error(NTX_E_INVALID, "bad instance list");
+    if (n_instances < 0 || n_instances >= (1 << 29) || (n_instances > 0 && !transformations)) return ntx_set_error(NTX_E_INVALID, "bad instance list (0 <= n_instances < 2^29)");
     if (desc->n_parameters < 0 || desc->n_parameters > ntx_inst::MAX_PARAMS) return ntx_set_error(NTX_E_INVALID, "n_parameters %d outside [0, %d]", desc->n_parameters, ntx_inst::MAX_PARAMS);
     if (desc->instance_sample_method < 0 || desc->instance_sample_method > 2) return ntx_set_error(NTX_E_INVALID, "instance_sample_method %d is not 0 (random), 1 (nearest) or 2 (nearest_blend)", desc->instance_sample_method);
     const int ld = desc->light_dir_parameter_idx, ls = desc->light_strength_parameter_idx;
@@ -988,6 +996,14 @@ int ntx_instancer_create(const ntx_instancer_desc *desc, const float *transforma
     if (rc == NTX_OK) rc = up(&p->d_dirs, p->h_dirs);
     if (rc == NTX_OK) rc = up(&p->d_org, p->h_org);
     if (rc == NTX_OK) rc = up(&p->d_spheres, p->h_spheres);
+    if (rc == NTX_OK) {
+        std::vector<float> xf((size_t)n_instances * 24, 0.0f);
+        for (int64_t k = 0; k < n_instances; ++k) {
+            std::memcpy(xf.data() + k * 24, p->h_mats.data() + k * 12, 12 * sizeof(float));
+            std::memcpy(xf.data() + k * 24 + 12, p->h_dirs.data() + k * 9, 9 * sizeof(float));
+        }
+        rc = up(&p->d_xforms, xf);
+    }
     if (rc == NTX_OK) rc = reserve(p, NTX_INSTANCER_DEFAULT_MAX_RAYS);
     if (rc != NTX_OK) { release(p); return rc; }
     *out = p;
@@ -1108,7 +1124,7 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         }
         MarchArgs a{};
         a.rays_o = ro; a.rays_d = rd; a.params = P > 0 ? parameters + c0 * P : nullptr;
-        a.mats = inst->d_mats; a.dirs = inst->d_dirs; a.origins = inst->d_org;
+        a.mats = inst->d_mats; a.dirs = inst->d_dirs; a.origins = inst->d_org; a.xforms = inst->d_xforms;
         a.count = inst->d_count; a.hits = inst->d_hits; a.t_mesh = F > 0 ? inst->d_tmesh : nullptr;
         const size_t so = (size_t)c0 * n_pts;
         a.rays_d_map = rays_d_map + so * 3; a.pts = pts + so * 3; a.t = t + so; a.dists = dists + so;
