@@ -195,8 +195,9 @@ def test_overflow_flags_and_refusals(tmp_path):
     assert all(np.array_equal(x, y) for x, y in zip(a.matrices(), b.matrices())) and b.patch_scale == 0.5 and a.patch_scale == 1.0
 
 
+@pytest.mark.parametrize("precision", ["float32", "fp16x3"])
 @pytest.mark.parametrize("npar,textures,blur", [((1, 6), ["", "", "", "", "light"], None), ((2, 3), ["", "", "light"], 0)])
-def test_instance_renderer_end_to_end(npar, textures, blur):
+def test_instance_renderer_end_to_end(npar, textures, blur, precision):
     """Rays -> GPU instancer -> ntx_render_instanced without leaving HBM, against oracle instancer -> float64 oracle of the
     InstanceRenderer tail (renderer.py:247-354), through the reference-shaped classes."""
     from nerf_tex_amd.renderer import InstanceRenderer
@@ -209,7 +210,7 @@ def test_instance_renderer_end_to_end(npar, textures, blur):
     inst = gpu_instancer(box, tr, textures=textures, instance_sampling_method="nearest", mesh=msh)
     patch_scale, step, S = 0.35, 0.01, 256
     r = InstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=patch_scale, step_size=step, blur_idx=blur,
-                         render_chunk=64, density_scale=40.0)
+                         render_chunk=64, density_scale=40.0, precision=precision)
     n = 150
     o, d = random_rays(21, n)
     tt = np.tile(F([[1.0, 2.0]]), (n, 1)); tt[7] = np.inf
