@@ -7,15 +7,15 @@
 //
 //   inst_hits_kernel   ray per lane, instances wave-uniform (their 3x4 matrices arrive through the scalar cache, no vector
 //                      memory in the loop): slab test of the ray in patch coordinates against every instance -- for the few
-//                      thousand patches of a scene, all pairs on the VALUs cost less than one BVH build -- face crossings
-//                      appended to the ray's hit list (<= 200, instancer.cpp:22)
+//                      thousand patches of a scene, all pairs on the VALUs cost less than one BVH build (spheres cull per
+//                      wave) -- a crossed box goes onto the ray's list as one record {t_in, t_out, instance}
 //   inst_mesh_kernel   the same against the triangles of the instancer mesh (closest crossing)
 //   inst_march_kernel  wave per ray.  The reference's walk over the sorted crossings with a std::set of open patches
 //                      (instancer.cpp:800-826, 870-1010) is taken apart into steps that are parallel over crossings, gaps or
 //                      marching steps (see WaveLds below); emission is lane per marching step, every output row is written
 //                      whole (emitted samples + the defaults of instancer.pyx:41-50), dense, once.  <true>: with shadow rays
 //                      (occlusion queries by the wave, see `occluded`).
-//                      Bound: HBM writes, (3+3+1+1+1+1+P) * 4 bytes per (ray, step); measured at 0.30-0.43 of the peak, the
+//                      Bound: HBM writes, (3+3+1+1+1+1+P) * 4 bytes per (ray, step); measured at 0.32-0.45 of the peak, the
 //                      rest is per-ray event work.
 //
 // Float32 operations are spelled in the order of oracle/instancer_oracle.py (-ffp-contract=off, IEEE divide and sqrt), so that
@@ -42,7 +42,6 @@ extern "C" int ntx_set_error(int code, const char *fmt, ...);   // nerftex.hip
 namespace ntx_inst {
 
 constexpr int MAX_HITS = 200;            // MAX_TOTAL_HITS, instancer.cpp:22
-constexpr int SORT_SLOTS = 256;          // MAX_HITS rounded up to whole waves
 constexpr int MAX_PARAMS = 32;
 constexpr float T_FAR = 100.0f;          // init_ray(..., 0, 100, ...), instancer.cpp:776
 constexpr uint32_t INF_BITS = 0x7f800000u;
@@ -127,7 +126,7 @@ __device__ __forceinline__ WaveCone wave_cone(float ox, float oy, float oz, floa
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int n_rays,
                                                         const float *__restrict__ mats, const float *__restrict__ spheres, int n_inst,
-                                                        int per_wave, Box box, uint32_t *__restrict__ count, uint2 *__restrict__ hits) {
+                                                        int per_wave, Box box, uint32_t *__restrict__ count, uint4 *__restrict__ hits) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ray = blockIdx.x * 64 + lane;
@@ -170,13 +169,12 @@ __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict_
             }
         }
         if (live && !miss && t_in < t_out) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float tt = e ? t_out : t_in;
-                if (tt > 0.0f && tt <= T_FAR) {          // tnear < t <= tfar
-                    const uint32_t slot = atomicAdd(&count[ray], 1u);
-                    if (slot < (uint32_t)MAX_HITS) hits[(size_t)ray * MAX_HITS + slot] = make_uint2(__builtin_bit_cast(uint32_t, tt), (uint32_t)k);
-                }
+            // the two face crossings of the box, each reported when tnear < t <= tfar: one record {t_in, t_out, instance}, 0 = not reported
+            const bool in_ok = t_in > 0.0f && t_in <= T_FAR, out_ok = t_out > 0.0f && t_out <= T_FAR;
+            if (in_ok || out_ok) {
+                const uint32_t slot = atomicAdd(&count[ray], 1u);
+                if (slot < (uint32_t)MAX_HITS)
+                    hits[(size_t)ray * MAX_HITS + slot] = make_uint4(in_ok ? __builtin_bit_cast(uint32_t, t_in) : 0u, out_ok ? __builtin_bit_cast(uint32_t, t_out) : 0u, (uint32_t)k, 0u);
             }
         }
       }
@@ -234,7 +232,7 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
 struct MarchArgs {
     const float *rays_o, *rays_d, *params;
     const float *mats, *dirs, *origins, *xforms;   // xforms[K][24]: mats[k] (12), dirs[k] (9), padding: what a step gathers
-    const uint32_t *count; const uint2 *hits; const uint32_t *t_mesh;   // t_mesh NULL = no mesh
+    const uint32_t *count; const uint4 *hits; const uint32_t *t_mesh;   // t_mesh NULL = no mesh
     float *rays_d_map, *pts, *t, *dists, *color_last, *alpha_last, *alpha_weight, *params_map;
     int32_t *instance_id; uint8_t *hit; int32_t *status;
     int n_rays, n_pts, n_params;
@@ -259,7 +257,6 @@ struct MarchArgs {
 //              given to.  64 consecutive steps per pass whatever gaps they fall in.
 struct WaveLds {
     float ev_t[MAX_HITS];
-    uint32_t ev_id[MAX_HITS];
     uint32_t ev_info[MAX_HITS + 4];       // bit 0: the event enters its patch; bits 8..: patches in the set in the gap in front of it
     float g_off[MAX_HITS + 4];            // segment_offset in force in gap j (instancer.cpp:1001)
     union {
@@ -267,7 +264,7 @@ struct WaveLds {
         struct { float ts[MAX_HITS / 2 + 2], te[MAX_HITS / 2]; } seg;   // before that: start (then offset) and end of the segments
     } gs;
     union {
-        struct { float t[SORT_SLOTS]; uint32_t id[SORT_SLOTS]; } raw;                        // the hit list as the hit kernel left it
+        struct { float t_in[MAX_HITS], t_out[MAX_HITS]; uint32_t id[MAX_HITS]; } raw;        // the records of the hit kernel: a crossed box each
         struct { uint32_t id[MAX_HITS], be[MAX_HITS]; float ox[MAX_HITS], oy[MAX_HITS], oz[MAX_HITS]; } iv;   // intervals, by patch
     } u;
     float par[MAX_PARAMS];
@@ -423,92 +420,116 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
     normalized(ndx, ndy, ndz);                                             // getDir: dir.normalized(), instancer.cpp:562
     if (lane < P) L.par[lane] = a.params[(size_t)ray * P + lane];
 
-    // ---- the hit list, sorted by (t, instID) (instancer.cpp:441-452, 787) -------------------------------------------------
+    // ---- the crossings, sorted by (t, instID) (instancer.cpp:441-452, 787) ---------------------------------------------------
+    // A record of the hit kernel is a crossed box: its entry and exit parameter (0 = not reported: behind the origin or beyond
+    // tfar).  The rank of a crossing among all crossings of the ray = the number of crossings in front of it, counted over the
+    // records (lane per record); the ranks of a record's own two crossings are its interval -- no pairing to search for: with both
+    // reported the first ENTERS the patch and the second leaves it, a lone one enters and never leaves (the toggle of :812-824).
     const uint32_t raw = a.count[ray];
-    const int m_all = raw < (uint32_t)MAX_HITS ? (int)raw : MAX_HITS;
-    const bool overflow_hits = raw > (uint32_t)MAX_HITS;
-    for (int e = lane; e < m_all; e += 64) {
-        const uint2 hv = a.hits[(size_t)ray * MAX_HITS + e];
-        L.u.raw.t[e] = __builtin_bit_cast(float, hv.x);
-        L.u.raw.id[e] = hv.y;
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < m_all; e += 64) {
-        const float te = L.u.raw.t[e];
-        const uint32_t ie = L.u.raw.id[e];
-        int rank = 0;
-        #pragma unroll 8
-        for (int k = 0; k < m_all; ++k) {
-            const float tk = L.u.raw.t[k];
-            const uint32_t ik = L.u.raw.id[k];
-            rank += (tk < te || (tk == te && (ik < ie || (ik == ie && k < e)))) ? 1 : 0;
-        }
-        L.ev_t[rank] = te;
-        L.ev_id[rank] = ie;
+    const int n_rec = raw < (uint32_t)MAX_HITS ? (int)raw : MAX_HITS;
+    for (int i = lane; i < n_rec; i += 64) {
+        const uint4 r = a.hits[(size_t)ray * MAX_HITS + i];
+        L.u.raw.t_in[i] = __builtin_bit_cast(float, r.x);
+        L.u.raw.t_out[i] = __builtin_bit_cast(float, r.y);
+        L.u.raw.id[i] = r.z;
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t tm_bits = a.t_mesh ? a.t_mesh[ray] : INF_BITS;
     const bool has_mesh = tm_bits != INF_BITS;
     const float t_mesh = __builtin_bit_cast(float, tm_bits);
-    const bool any_hit = m_all > 0 || has_mesh;
-    // the mesh hit sorts behind the crossings at its own t (instID = invalid sorts last) and ends the walk (:804-811, 988)
-    int m = m_all;
-    if (has_mesh) {
-        int c = 0;
-        for (int e = lane; e < m_all; e += 64) c += L.ev_t[e] <= t_mesh ? 1 : 0;
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        m = c;
-    }
-
-    if (a.debug_skip & 4) return;
-    // ---- events: entering or leaving, and who pairs with whom ----------------------------------------------------------------
-    // (the raw list is dead: its memory holds the intervals from here on)
-    uint32_t my_next[4], my_enter[4];
+    const bool any_hit = n_rec > 0 || has_mesh;
+    float r_in[4], r_out[4];
+    uint32_t r_id[4];
+    int rk_in[4], rk_out[4];
+    int n_events = 0, n_front = 0;                // crossings of the ray; those not behind the mesh hit (it sorts behind its own t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = lane + 64 * q;
-        my_next[q] = (uint32_t)m; my_enter[q] = 0;
-        if (e < m) {
-            const uint32_t ie = L.ev_id[e];
-            int before = 0, next = m;
-            #pragma unroll 8
-            for (int k = 0; k < e; ++k) before += L.ev_id[k] == ie ? 1 : 0;
-            #pragma unroll 8
-            for (int k = m - 1; k > e; --k) next = L.ev_id[k] == ie ? k : next;
-            my_next[q] = (uint32_t)next; my_enter[q] = (before & 1) ? 0u : 1u;
-            L.ev_info[e] = my_enter[q];
+    for (int g = 0; g < 4; ++g) {
+        const int i = lane + 64 * g;
+        r_in[g] = 0.0f; r_out[g] = 0.0f; r_id[g] = 0; rk_in[g] = 0; rk_out[g] = 0;
+        if (64 * g >= n_rec) continue;
+        if (i < n_rec) { r_in[g] = L.u.raw.t_in[i]; r_out[g] = L.u.raw.t_out[i]; r_id[g] = L.u.raw.id[i]; }
+        const float xi = r_in[g], xo = r_out[g];
+        const uint32_t id = r_id[g];
+        int ci = 0, co = 0;
+        #pragma unroll 4
+        for (int k = 0; k < n_rec; ++k) {
+            const float ki = L.u.raw.t_in[k], ko = L.u.raw.t_out[k];
+            const uint32_t ik = L.u.raw.id[k];
+            const bool lt = ik < id;
+            ci += (ki != 0.0f && (ki < xi || (ki == xi && lt))) ? 1 : 0;
+            ci += (ko != 0.0f && (ko < xi || (ko == xi && lt))) ? 1 : 0;
+            co += (ki != 0.0f && (ki < xo || (ki == xo && (lt || ik == id)))) ? 1 : 0;      // a record's own entry lies in front of its exit
+            co += (ko != 0.0f && (ko < xo || (ko == xo && lt))) ? 1 : 0;
         }
+        rk_in[g] = ci; rk_out[g] = co;
+        n_events += (xi != 0.0f ? 1 : 0) + (xo != 0.0f ? 1 : 0);
+        n_front += (xi != 0.0f && xi <= t_mesh ? 1 : 0) + (xo != 0.0f && xo <= t_mesh ? 1 : 0);
+    }
+    for (int o = 32; o > 0; o >>= 1) { n_events += __shfl_xor(n_events, o); n_front += __shfl_xor(n_front, o); }
+    const bool overflow_hits = raw > (uint32_t)MAX_HITS || n_events > MAX_HITS;
+    // at most MAX_TOTAL_HITS crossings are kept (:539): the first ones of the sorted list; the mesh hit ends the walk (:804-811, 988)
+    const int m = (has_mesh ? n_front : n_events) < MAX_HITS ? (has_mesh ? n_front : n_events) : MAX_HITS;
+    bool has_iv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const bool vi = r_in[g] != 0.0f, vo = r_out[g] != 0.0f;
+        if (vi && rk_in[g] < m) { L.ev_t[rk_in[g]] = r_in[g]; L.ev_info[rk_in[g]] = 1u; }
+        if (vo && rk_out[g] < m) { L.ev_t[rk_out[g]] = r_out[g]; L.ev_info[rk_out[g]] = vi ? 0u : 1u; }
+        has_iv[g] = (vi && rk_in[g] < m) || (!vi && vo && rk_out[g] < m);
     }
     __builtin_amdgcn_wave_barrier();
-    if (a.debug_skip & 8) return;
-    // intervals in ascending patch order: rank of an entering event among the entering events by (patch, event)
+
+    if (a.debug_skip & 4) return;
+    uint32_t my_enter[4];                          // by position in the sorted list
     uint64_t enter_mask[4];
     int n_int = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { enter_mask[q] = __ballot(my_enter[q] != 0); n_int += __builtin_popcountll(enter_mask[q]); }
-#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int e = lane + 64 * q;
-        if (e < m && my_enter[q]) {
-            const uint32_t ie = L.ev_id[e];
-            int rank = 0;
-            if (a.method == 1) {
-                // 'nearest' does not depend on the order it meets the patches in once ties go to the smaller id (below): the
-                // intervals stay in event order, which is a popcount
+        my_enter[q] = e < m ? (L.ev_info[e] & 1u) : 0u;
+        enter_mask[q] = __ballot(my_enter[q] != 0);
+        n_int += __builtin_popcountll(enter_mask[q]);
+    }
+    if (a.debug_skip & 8) return;
+    // intervals: (entering crossing b, leaving crossing e' or m) per record, in ascending patch order (std::set's order) unless the
+    // rule is 'nearest', which does not depend on the order it meets the patches in once ties go to the smaller id (below)
+    int iv_at[4];
+    {
+        uint64_t iv_mask[4];
+        int before = 0;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (g <= q) rank += __builtin_popcountll(g < q ? enter_mask[g] : (enter_mask[g] & ((1ull << lane) - 1ull)));
-            } else {
+        for (int g = 0; g < 4; ++g) { iv_mask[g] = __ballot(has_iv[g]); iv_at[g] = before + __builtin_popcountll(iv_mask[g] & ((1ull << lane) - 1ull)); before += __builtin_popcountll(iv_mask[g]); }
+        if (a.method != 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (has_iv[g]) L.u.raw.id[lane + 64 * g] = r_id[g] | 0x80000000u;          // (ids are below 2^29)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (64 * g >= n_rec) continue;
+                int c = 0;
+                const uint32_t key = r_id[g] | 0x80000000u;
                 #pragma unroll 8
-                for (int k = 0; k < m; ++k) {
-                    const uint32_t ik = L.ev_id[k];
-                    rank += ((L.ev_info[k] & 1u) && (ik < ie || (ik == ie && k < e))) ? 1 : 0;
+                for (int k = 0; k < n_rec; ++k) {
+                    const uint32_t ik = L.u.raw.id[k];
+                    c += (ik >= 0x80000000u && ik < key) ? 1 : 0;
                 }
+                iv_at[g] = c;
             }
-            const float *og = a.origins + (size_t)ie * 3;
-            L.u.iv.be[rank] = (uint32_t)e | (my_next[q] << 16);
-            L.u.iv.id[rank] = ie;
-            L.u.iv.ox[rank] = og[0]; L.u.iv.oy[rank] = og[1]; L.u.iv.oz[rank] = og[2];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();               // every read of the records is done: their memory takes the intervals
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (has_iv[g]) {
+            const bool vi = r_in[g] != 0.0f;
+            const int b_ = vi ? rk_in[g] : rk_out[g];
+            const int e_ = (vi && r_out[g] != 0.0f && rk_out[g] < m) ? rk_out[g] : m;
+            const float *og = a.origins + (size_t)r_id[g] * 3;
+            const int at = iv_at[g];
+            L.u.iv.be[at] = (uint32_t)b_ | ((uint32_t)e_ << 16);
+            L.u.iv.id[at] = r_id[g];
+            L.u.iv.ox[at] = og[0]; L.u.iv.oy[at] = og[1]; L.u.iv.oz[at] = og[2];
         }
     }
 
@@ -881,7 +902,7 @@ struct ntx_instancer {
     std::vector<float> h_spheres;                      // [K,4] centre and squared radius of the instanced box, world
     float *d_mats = nullptr, *d_dirs = nullptr, *d_org = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_xforms = nullptr;
     uint32_t *d_count = nullptr, *d_tmesh = nullptr;
-    uint2 *d_hits = nullptr;
+    uint4 *d_hits = nullptr;
 };
 
 namespace {
@@ -929,7 +950,7 @@ int reserve(ntx_instancer *p, int64_t max_rays) {
     p->cap_rays = 0;
     INST_TRY(hipMalloc((void **)&p->d_count, (size_t)max_rays * sizeof(uint32_t)));
     INST_TRY(hipMalloc((void **)&p->d_tmesh, (size_t)max_rays * sizeof(uint32_t)));
-    INST_TRY(hipMalloc((void **)&p->d_hits, (size_t)max_rays * ntx_inst::MAX_HITS * sizeof(uint2)));
+    INST_TRY(hipMalloc((void **)&p->d_hits, (size_t)max_rays * ntx_inst::MAX_HITS * sizeof(uint4)));
     p->cap_rays = max_rays;
     return NTX_OK;
 }
