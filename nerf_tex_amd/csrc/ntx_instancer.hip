@@ -246,18 +246,21 @@ struct MarchArgs {
 };
 
 // The reference walks the sorted crossings with a std::set of the patches it is inside (instancer.cpp:800-826, 870-1010): a crossing
-// of a patch that is in the set takes it out, any other puts it in.  Here the walk is taken apart so that nothing but a few float
-// additions is left sequential:
-//   events     the sorted crossings; event e ENTERS its patch when an even number of earlier events name the same patch (lane per event)
-//   intervals  an entering event b and the next event e' of the same patch (or the end of the list): the patch is in the set in the
-//              GAPS b < j <= e', gap j being the stretch in front of event j; kept in ascending patch order (std::set's order)
-//   gaps       the number of patches in the set (a count of +-1 per event), the segment offset in force and the first marching step
-//              of the gap -- the one scalar loop, a handful of operations per event
-//   steps      lane per step: its gap by bisection of the gaps' first steps, then one pass over the intervals for the patch it is
-//              given to.  64 consecutive steps per pass whatever gaps they fall in.
+// of a patch that is in the set takes it out, any other puts it in.  Here the walk is taken apart so that nothing but one float
+// sum per segment is left sequential:
+//   records    what the hit kernel left: a crossed box with its entry and exit parameter (lane per record)
+//   crossings  the rank of a crossing in the sorted list = the number of crossings in front of it, counted over the records; the
+//              first crossing of a record ENTERS its patch, the second leaves it, a lone one enters and never leaves
+//   intervals  the ranks (b, e') of a record's own crossings (e' = the end of the list when there is no second): the patch is in the
+//              set in the GAPS b < j <= e', gap j being the stretch in front of crossing j; in ascending patch order (std::set's
+//              order) unless the rule is 'nearest'
+//   gaps       lane per gap: patches in the set = 2 * (entering crossings before j) - j; segments of the union compacted by ballot,
+//              their lengths summed in order (the one sequential loop); the first marching step of a gap as a running maximum
+//   steps      lane per step: its gap by bisection of the gaps' first steps, then one pass over the intervals that reach into the
+//              64 steps' gaps for the patch it is given to.  64 consecutive steps per pass whatever gaps they fall in.
 struct WaveLds {
     float ev_t[MAX_HITS];
-    uint32_t ev_info[MAX_HITS + 4];       // bit 0: the event enters its patch; bits 8..: patches in the set in the gap in front of it
+    uint32_t ev_info[MAX_HITS + 4];       // bit 0: the crossing enters its patch
     float g_off[MAX_HITS + 4];            // segment_offset in force in gap j (instancer.cpp:1001)
     union {
         int g_step0[MAX_HITS + 4];        // first step emitted in gap j; [n_gaps] = number of steps emitted
