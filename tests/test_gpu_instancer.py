@@ -360,3 +360,36 @@ def test_instanced_image_through_the_render_harness():
     # ... of an image with something in it: rays beside the sheet, rays through tens of patches, opaque and half-transparent pixels
     assert k > 0.8 * H * W and 0.3 * k < b[8].sum() < 0.9 * k and (b[3] > 0).sum() > 20 * b[8].sum()
     assert want[:, 3].max() > 0.9 and 0.2 < want[:, 3].mean()
+
+
+def test_mip_instance_renderer_end_to_end():
+    """MipInstanceRenderer (renderer.py:475-587) on the GPU instancer with use_mean_distance (instancer.cpp:746-748: the samples sit at
+    the mean distance of their cone segment, what the integrated positional encoding expects): rays -> instancer -> fused IPE tail
+    against oracle instancer -> float64 restatement of the mip tail."""
+    from nerf_tex_amd.renderer import MipInstanceRenderer
+    model, mspec, wts = make_model((1, 3), "IPE", dense_media=True)
+    textures = ["", "", "light"]                                                 # blur parameter, one geometry parameter, light: 5 per row
+    spec0 = random_scene(41, k=30, method="nearest", textures=textures, mesh=True)
+    box = dict(b_0=spec0.b_0.tolist(), b_1=spec0.b_1.tolist())
+    tr = [np.linalg.inv(m.astype(np.float64)).astype(F) for m in spec0.inv]
+    msh = (spec0.mesh_v, spec0.mesh_f)
+    inst = gpu_instancer(box, tr, textures=textures, instance_sampling_method="nearest", mesh=msh, use_mean_distance=True)
+    patch_scale, step, S = 0.35, 0.01, 256
+    r = MipInstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=patch_scale, step_size=step, blur_idx=0,
+                            render_chunk=10_000, density_scale=40.0)
+    n = 120
+    o, d = random_rays(41, n)
+    tt = np.tile(F([[1.0, 2.0]]), (n, 1))
+    rng = np.random.default_rng(3)
+    params = rng.uniform(0.2, 1, size=(1, 5)).astype(F); params[0, 0] = 6.0
+    cone = rng.uniform(1e-3, 5e-3, size=(n, 1)).astype(F)
+    dv = torch.device("cuda", 0)
+    dd = lambda a: torch.as_tensor(a, device=dv)[None]
+    out = r(dd(o), dd(d), dd(tt), parameters=torch.as_tensor(params, device=dv), cone_scale=dd(cone), instancer_seed=5)
+    r.raise_if_nonfinite()
+    got = np.concatenate([out["color_pred"][0].cpu().numpy(), out["alpha_pred"][0].cpu().numpy()[:, None]], -1)
+    b = run_oracle(inst, box, o, d, np.repeat(params, n, 0), S, step, 5, "nearest", textures, True, msh, ray_index=(0, n, n))
+    rc, ra = orc.mip_instance_evaluate_model(wts, mspec, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[8], b[9], cone, 0, patch_scale, 40.0,
+                                             True, False, False, (1., 1., 1.), dtype=np.float64)
+    assert orc.rel_linf(got, np.concatenate([rc, ra[:, None]], -1)) <= TOL
+    assert ra.max() > 0.5 and (b[3] > 0).sum() > 2000
