@@ -393,3 +393,24 @@ def test_mip_instance_renderer_end_to_end():
                                              True, False, False, (1., 1., 1.), dtype=np.float64)
     assert orc.rel_linf(got, np.concatenate([rc, ra[:, None]], -1)) <= TOL
     assert ra.max() > 0.5 and (b[3] > 0).sum() > 2000
+
+
+def test_degenerate_scenes():
+    """No patches at all, a mesh and no patches, one marching step per ray, no parameters: the defaults of instancer.pyx:41-50 and the
+    closing sample, bit for bit."""
+    quad = ([[-2, -2, .5], [2, -2, .5], [2, 2, .5], [-2, 2, .5]], [[0, 1, 2], [0, 2, 3]])
+    o = F([[0.3, 0.2, -5], [5, 5, -5], [0.1, 0.1, 3]]); d = F([[0, 0, 1], [0, 0, 1], [0, 0, 1]])
+    for mesh in (None, quad):
+        inst = gpu_instancer(UNIT, [], mesh=mesh)
+        assert inst.n_instances() == 0
+        for S in (1, 5):
+            got = run_gpu(inst, o, d, np.zeros((3, 0), F), S, 0.5, seed=2)
+            want = run_oracle(inst, UNIT, o, d, np.zeros((3, 0), F), S, 0.5, 2, mesh=mesh)
+            assert_same(got, want)
+            assert got[8].tolist() == ([True, False, False] if mesh else [False] * 3) and not got[3].any()
+    inst = gpu_instancer(UNIT, [translate()], textures=["", "light"])
+    par = F([[0.5, 0, 0, 1]] * 3)
+    got = run_gpu(inst, o, d, par, 1, 0.5, seed=2)                                # four steps needed, one fits
+    want = run_oracle(inst, UNIT, o, d, par, 1, 0.5, 2, textures=("", "light"))
+    assert_same(got, want)
+    assert got[3][0, 0] == (F(0.5) + F(2.0)) - F(1) * F(0.5) and got[8].tolist() == [True, False, False]
