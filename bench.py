@@ -127,8 +127,8 @@ def bench_instanced(args) -> None:
     (instancer/src/instancer.cpp:889-960), the direction in the patch frame, the light direction and the other appearance
     parameters are constant along a run (one patch instance: getDir(ray, instance)), while the position and the texture-mapped
     geometry parameter change from sample to sample (`--instanced-per-sample-dirs`: the round-2 workload, every sample its own
-    direction and parameters).  value = in-patch ray-samples/s; N = 1 only (the patch instancer that feeds this path is CPU
-    code outside the hot path)."""
+    direction and parameters).  value = in-patch ray-samples/s; N = 1 only.  (`carpet_instanced_scene` runs the same tail on the
+    output of this package's own patch instancer.)"""
     import torch
     from nerf_tex_amd import _lib, synthetic
     from nerf_tex_amd.model import ParamNerf

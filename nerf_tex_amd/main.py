@@ -35,7 +35,8 @@ def load_config(path: str) -> util.EasyDict:
 
 def prepare(config: dict, volumetric: bool = False) -> util.EasyDict:
     """Remap a reference config for this package.  `volumetric`: the shipped render configs name `InstanceRenderer`, which
-    needs the reference's Embree instancer (out of scope); render the bare volume inside the proxy with `Renderer` instead."""
+    needs an instancer (the reference's on Embree, or nerf_tex_amd.instancer.Instancer with an exported transformation list); render
+    the bare volume inside the proxy with `Renderer` instead."""
     cfg = util.remap_reference_config(config)
     if "train" in str(cfg.get("module", "")).lower():
         raise NotImplementedError("training (network.train.Train) is outside the render path this package implements")

@@ -207,10 +207,10 @@ class MipRenderer(Renderer):
 class InstanceRenderer(Renderer):
     """network.renderer.InstanceRenderer (renderer.py:215-354): the renderer the shipped render configs use.
 
-    The patch instancer itself (C++/Embree, instancer/) is outside this package; what is implemented here is
-    everything downstream of `instancer.get_model_input(rays_o, rays_d, parameters, n_samples, step_size)`
-    (instancer.pyx:38-54), fused into one launch of `ntx_render_instanced` per render chunk.  `instancer` is
-    any object with that method (the reference's Cython `Instancer`, or a stand-in) returning, as numpy arrays
+    Everything downstream of `instancer.get_model_input(rays_o, rays_d, parameters, n_samples, step_size)`
+    (instancer.pyx:38-54) is one launch of `ntx_render_instanced` per render chunk.  `instancer` is any object with
+    that method: this package's `nerf_tex_amd.instancer.Instancer` (the patch instancer on the GPU: the chunk then
+    never leaves HBM), the reference's Cython `Instancer` on Embree, or a stand-in, returning, as numpy arrays
     or tensors: rays_d_map [n,S,3], pts [n,S,3], t [n,S], dists [n,S], color_last [n,1,3], alpha_last [n,1],
     alpha_weight [n,S], instance_id [n,S] int32, idxs (indices of the hit rays, `tf.where(hit)`-shaped [k,1]
     or a bool mask [n]), params_map [n,S,P]."""
