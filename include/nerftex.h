@@ -375,7 +375,7 @@ typedef struct ntx_instancer_desc {
 #define NTX_INSTANCER_DEFAULT_MAX_RAYS (1 << 16)
 /* transformations: HOST [n_instances,4,4] row-major patch -> world, what AddInstance takes.  The instancer keeps, per instance,
  * the inverse (world -> patch), the direction map (columns of the 3x3 block, normalised) and the origin (instancer.cpp:127-132;
- * computed in double and rounded), plus hit-list workspace for NTX_INSTANCER_DEFAULT_MAX_RAYS rays (1.6 KB per ray). */
+ * computed in double and rounded), plus hit-list workspace for NTX_INSTANCER_DEFAULT_MAX_RAYS rays (3.2 KB per ray). */
 int ntx_instancer_create(const ntx_instancer_desc *desc, const float *transformations, int64_t n_instances, int device,
                          ntx_instancer **out);
 int ntx_instancer_destroy(ntx_instancer *inst);
