@@ -298,7 +298,7 @@ def bench_instanced_scene(args) -> None:
                      "what": "ntx_render_instanced (ordering kernels + instance_kernel) on the instancer's own output"},
         "instancer": {"ms": inst_ms, "share_of_step": inst_ms / (inst_ms + kernel_ms), "rays_per_s": n / (inst_ms * 1e-3), "status_flag": int(status.item()),
                       "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "algorithmic_bytes": out_bytes,
-                                   "traffic": 1168471141 + 13546509 + 110656 + 16112043 + 1127595 + 2285568,
+                                   "traffic": 1168982544 + 13545539 + 110656 + 16079520 + 1128757 + 2289664,
                                    "traffic_source": "profiles/r03/instancer_pmc_summary.json (WRITE_SIZE + 2 x FETCH_SIZE of the three kernels, same scene)"},
                       "kernels": "inst_hits_kernel + inst_mesh_kernel + inst_march_kernel (DESIGN 4.5)"}}
     if not args.no_parity:

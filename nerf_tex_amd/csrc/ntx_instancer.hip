@@ -13,9 +13,9 @@
 //   inst_march_kernel  wave per ray.  The reference's walk over the sorted crossings with a std::set of open patches
 //                      (instancer.cpp:800-826, 870-1010) is taken apart into steps that are parallel over crossings, gaps or
 //                      marching steps (see WaveLds below); emission is lane per marching step, every output row is written
-//                      whole (emitted samples + the defaults of instancer.pyx:41-50), dense, once.  <true>: with shadow rays
-//                      (occlusion queries by the wave, see `occluded`).
-//                      Bound: HBM writes, (3+3+1+1+1+1+P) * 4 bytes per (ray, step); measured at 0.32-0.45 of the peak, the
+//                      whole (emitted samples + the defaults of instancer.pyx:41-50), dense, once.  inst_march_shadow_kernel:
+//                      the same with shadow rays (occlusion queries by the wave, see `occluded`).
+//                      Bound: HBM writes, (3+3+1+1+1+1+P) * 4 bytes per (ray, step); measured at 0.35-0.46 of the peak, the
 //                      rest is per-ray event work.
 //
 // Float32 operations are spelled in the order of oracle/instancer_oracle.py (-ffp-contract=off, IEEE divide and sqrt), so that
@@ -406,8 +406,7 @@ __device__ __forceinline__ void fill_pattern(float *row, int f0, int f1, int per
 }
 
 template <bool SHADOW>
-__global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
-    __shared__ MarchLds<SHADOW> lds[4];
+__device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *lds) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ray = blockIdx.x * 4 + wave;
@@ -892,6 +891,17 @@ __global__ __launch_bounds__(256) void inst_march_kernel(MarchArgs a) {
     }
 }
 
+// two kernels around the one body: rays without shadow queries run at 5 waves per SIMD (what the 29.5 KB of LDS per workgroup allow;
+// the compiler is told to stay within 102 registers for it: 87, no scratch), the shadow flavour keeps its own registers and tables
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void inst_march_kernel(MarchArgs a) {
+    __shared__ MarchLds<false> lds[4];
+    march_ray<false>(a, lds);
+}
+__global__ __launch_bounds__(256) void inst_march_shadow_kernel(MarchArgs a) {
+    __shared__ MarchLds<true> lds[4];
+    march_ray<true>(a, lds);
+}
+
 }   // namespace ntx_inst
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1166,8 +1176,8 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         else { a.idx0 = idx0 + (c0 / idx_run) * idx_stride; a.idx_run = idx_run; a.idx_stride = idx_stride; }
         a.spheres = inst->d_spheres; a.tris = inst->d_tris; a.n_inst = K; a.n_tri = F; a.box = box;
         a.min_shadow = inst->desc.min_shadow_samples; a.n_shadow = inst->desc.n_shadow_samples;
-        if (inst->desc.cast_shadow_rays && a.light_dir_idx >= 0) hipLaunchKernelGGL(inst_march_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(inst_march_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, a);
+        if (inst->desc.cast_shadow_rays && a.light_dir_idx >= 0) hipLaunchKernelGGL(inst_march_shadow_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(inst_march_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
     }
     INST_TRY(hipGetLastError());
     return NTX_OK;
