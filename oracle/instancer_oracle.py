@@ -24,7 +24,7 @@ Everything is sequential Python over numpy float32 scalars: small cases only.
 
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np

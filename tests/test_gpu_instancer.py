@@ -270,16 +270,14 @@ def test_fuzz_scenes_bit_for_bit(seed):
 
 
 def test_the_measured_scene_bit_for_bit():
-    """Parity where the numbers of DESIGN 4.5 are measured: the scene of tools/bench_instancer.py (48 x 48 patches of the carpet
+    """Parity where the numbers of DESIGN 4.5 are measured: the scene of tools/bench_instancer.py and bench.py's carpet_instanced_scene (synthetic.patch_sheet: 48 x 48 patches of the carpet
     config's box on a waving sheet that is also the mesh, 1024 steps of 0.002, 'nearest', a directional light) -- 40 seeded rays of a
     4096-ray call against the restatement, every buffer bit for bit (~260 steps per ray through ~35 overlapping patches)."""
-    import importlib.util
-    spec_ = importlib.util.spec_from_file_location("bench_instancer", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_instancer.py"))
-    bi = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(bi)
     from nerf_tex_amd import synthetic
     from nerf_tex_amd.dataset import look_at
     from nerf_tex_amd.instancer import Instancer
-    tr, v, f = bi.sheet(48)
+    bi = type("scene", (), {"B0": synthetic.PATCH_BOX[0], "B1": synthetic.PATCH_BOX[1]})
+    tr, v, f = synthetic.patch_sheet(48)
     textures = ['', '', '', '', 'light']
     inst = Instancer(bi.B0, bi.B1, textures=textures, transformations=tr, instance_sampling_method="nearest", mesh=(v, f))
     fam = synthetic.FAMILIES["carpet"]
@@ -304,12 +302,10 @@ def test_instanced_image_through_the_render_harness():
     (network.render.Render -> Dataset -> ParamNerf -> network.renderer.InstanceRenderer with an instancer_config), remapped and
     instantiated like main.py does; the instancer is this package's.  A 40 x 40 image of 36 patches on a sheet against the whole
     pipeline restated: oracle rays -> oracle instancer -> float64 tail."""
-    import importlib.util
     from nerf_tex_amd import synthetic, util
     from nerf_tex_amd.dataset import look_at
-    spec_ = importlib.util.spec_from_file_location("bench_instancer", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_instancer.py"))
-    bi = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(bi)
-    tr, v, f = bi.sheet(6, extent=0.35, scale=0.09)
+    bi = type("scene", (), {"B0": synthetic.PATCH_BOX[0], "B1": synthetic.PATCH_BOX[1]})
+    tr, v, f = synthetic.patch_sheet(6, extent=0.35, scale=0.09)
     H = W = 40
     S, step, patch_scale, dscale = 192, 0.004, 0.09, 60.0
     textures = ['', '', '', '', 'light']
