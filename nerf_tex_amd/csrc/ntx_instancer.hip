@@ -15,7 +15,7 @@
 //                      marching steps (see WaveLds below); emission is lane per marching step, every output row is written
 //                      whole (emitted samples + the defaults of instancer.pyx:41-50), dense, once.  inst_march_shadow_kernel:
 //                      the same with shadow rays (occlusion queries by the wave, see `occluded`).
-//                      Bound: HBM writes, (3+3+1+1+1+1+P) * 4 bytes per (ray, step); measured at 0.35-0.46 of the peak, the
+//                      Bound: HBM writes, (3+3+1+1+1+1+P) * 4 bytes per (ray, step); measured at 0.36-0.49 of the peak, the
 //                      rest is per-ray event work.
 //
 // Float32 operations are spelled in the order of oracle/instancer_oracle.py (-ffp-contract=off, IEEE divide and sqrt), so that
