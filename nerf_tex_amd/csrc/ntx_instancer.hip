@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------------------------------------------
 struct MarchArgs {
     const float *rays_o, *rays_d, *params;
-    const float *mats, *dirs, *origins, *xforms;   // xforms[K][24]: mats[k] (12), dirs[k] (9), padding: what a step gathers
+    const float *mats, *origins, *xforms;   // xforms[K][24]: world -> patch matrix (12), direction map (9), padding: what a step gathers
     const uint32_t *count; const uint4 *hits; const uint32_t *t_mesh;   // t_mesh NULL = no mesh
     float *rays_d_map, *pts, *t, *dists, *color_last, *alpha_last, *alpha_weight, *params_map;
     int32_t *instance_id; uint8_t *hit; int32_t *status;
@@ -915,7 +915,7 @@ struct ntx_instancer {
     int64_t n_inst = 0, n_tri = 0, cap_rays = 0;
     std::vector<float> h_mats, h_dirs, h_org;          // world -> patch [K,12], direction maps [K,9], origins [K,3]
     std::vector<float> h_spheres;                      // [K,4] centre and squared radius of the instanced box, world
-    float *d_mats = nullptr, *d_dirs = nullptr, *d_org = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_xforms = nullptr;
+    float *d_mats = nullptr, *d_org = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_xforms = nullptr;
     uint32_t *d_count = nullptr, *d_tmesh = nullptr;
     uint4 *d_hits = nullptr;
 };
@@ -951,7 +951,7 @@ bool invert4(const float *m, double *out) {
 void release(ntx_instancer *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    for (void *q : {(void *)p->d_mats, (void *)p->d_dirs, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_xforms, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits})
+    for (void *q : {(void *)p->d_mats, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_xforms, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits})
         if (q) (void)hipFree(q);
     delete p;
 }
@@ -1029,7 +1029,6 @@ int ntx_instancer_create(const ntx_instancer_desc *desc, const float *transforma
     };
     int rc = hipSetDevice(device) == hipSuccess ? NTX_OK : ntx_set_error(NTX_E_HIP, "hipSetDevice(%d) failed", device);
     if (rc == NTX_OK) rc = up(&p->d_mats, p->h_mats);
-    if (rc == NTX_OK) rc = up(&p->d_dirs, p->h_dirs);
     if (rc == NTX_OK) rc = up(&p->d_org, p->h_org);
     if (rc == NTX_OK) rc = up(&p->d_spheres, p->h_spheres);
     if (rc == NTX_OK) {
@@ -1160,7 +1159,7 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         }
         MarchArgs a{};
         a.rays_o = ro; a.rays_d = rd; a.params = P > 0 ? parameters + c0 * P : nullptr;
-        a.mats = inst->d_mats; a.dirs = inst->d_dirs; a.origins = inst->d_org; a.xforms = inst->d_xforms;
+        a.mats = inst->d_mats; a.origins = inst->d_org; a.xforms = inst->d_xforms;
         a.count = inst->d_count; a.hits = inst->d_hits; a.t_mesh = F > 0 ? inst->d_tmesh : nullptr;
         const size_t so = (size_t)c0 * n_pts;
         a.rays_d_map = rays_d_map + so * 3; a.pts = pts + so * 3; a.t = t + so; a.dists = dists + so;
