@@ -49,7 +49,7 @@ class Instancer:
                  min_shadow_samples: int = 4, n_shadow_samples: int = 512, min_texture_samples: int = 4,
                  n_texture_samples: int = 512, jitter_amount: float = 0, instance_sampling_method: str = 'random',
                  use_mean_distance: bool = False, auxiliary_meshes=(), transformation_export_path: Optional[str] = None,
-                 transformations_path: Optional[str] = None, mesh=None, seed: int = 0, device: int = 0, **kwargs) -> None:
+                 transformations_path: Optional[str] = None, mesh=None, seed: int = 0, device: int = 0) -> None:
         import numpy as np
         if instance_sampling_method not in SAMPLING_METHODS:
             raise ValueError(f"instance_sampling_method must be one of {sorted(SAMPLING_METHODS)}")
