@@ -410,3 +410,35 @@ def test_degenerate_scenes():
     want = run_oracle(inst, UNIT, o, d, par, 1, 0.5, 2, textures=("", "light"))
     assert_same(got, want)
     assert got[3][0, 0] == (F(0.5) + F(2.0)) - F(1) * F(0.5) and got[8].tolist() == [True, False, False]
+
+
+def test_failed_calls_write_nothing():
+    """Every argument of ntx_instancer_model_input is checked before the first launch: a call that returns an error leaves the
+    caller's buffers as they were (the convention of the other entry points)."""
+    import ctypes as C
+    from nerf_tex_amd import _lib
+    inst = gpu_instancer(UNIT, [translate()])
+    dv = torch.device("cuda", 0)
+    n, S = 8, 16
+    ro = torch.zeros((n, 3), device=dv); ro[:, 2] = -5
+    rd = torch.zeros((n, 3), device=dv); rd[:, 2] = 1
+    bufs = {k: torch.full(shape, 7, device=dv, dtype=dt) for k, shape, dt in [
+        ("rays_d_map", (n, S, 3), torch.float32), ("pts", (n, S, 3), torch.float32), ("t", (n, S), torch.float32), ("dists", (n, S), torch.float32),
+        ("color", (n, 3), torch.float32), ("alpha", (n,), torch.float32), ("weight", (n, S), torch.float32), ("iid", (n, S), torch.int32),
+        ("hit", (n,), torch.uint8)]}
+    p = lambda k: bufs[k].data_ptr()
+
+    def call(n_pts=S, step=0.5, opts=None, pts=None, n_rays=n):
+        return _lib.lib.ntx_instancer_model_input(inst._h, ro.data_ptr(), rd.data_ptr(), None, n_rays, n_pts, step, 1, opts, p("rays_d_map"),
+                                                  pts if pts is not None else p("pts"), p("t"), p("dists"), p("color"), p("alpha"), p("weight"),
+                                                  p("iid"), p("hit"), None, None, None)
+    bad_opts = _lib.render_opts(ray_index=(0, 4, 2))                              # stride < run length
+    for rc in (call(n_pts=0), call(n_pts=5000), call(step=0.0), call(step=float("inf")), call(opts=bad_opts), call(n_rays=-1)):
+        assert rc == _lib.NTX_E_INVALID
+    assert _lib.lib.ntx_instancer_model_input(None, *([None] * 3), n, S, 0.5, 1, None, *([None] * 12)) == _lib.NTX_E_INVALID
+    assert _lib.lib.ntx_instancer_model_input(inst._h, ro.data_ptr(), rd.data_ptr(), None, n, S, 0.5, 1, None, p("rays_d_map"), None, *([None] * 10)) == _lib.NTX_E_INVALID
+    torch.cuda.synchronize()
+    assert all(bool((b == 7).all()) for b in bufs.values())
+    assert call() == _lib.NTX_OK                                                  # ... and the same call with good arguments fills them
+    torch.cuda.synchronize()
+    assert not bool((bufs["dists"] == 7).any()) and bool(bufs["hit"].all())
