@@ -346,8 +346,9 @@ int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_hos
  * reference's only native code: Embree 3 on one CPU thread.  Built here: the constructor with explicit `transformations`
  * (instancer.pyx:19-20 -> AddInstance, instancer.cpp:124-141), an instancer mesh given as arrays, GetNumberOfInstances (:426-428),
  * the matrices ExportTransformations writes (:1040-1061) and GetModelInput (:751-1037) with the three patch choices, mean
- * distances, directional and point lights, shadow rays (:591-602, 945-961, 1018-1027).  NOT built (NTX_E_UNSUPPORTED / no entry
- * point): image textures on the instancer mesh (:640-667), auxiliary meshes with their shading (:393-417, 716-743) and
+ * distances, directional and point lights, shadow rays (:591-602, 945-961, 1018-1027), auxiliary meshes with
+ * their flat shading (:393-417, 716-743).  NOT built (NTX_E_UNSUPPORTED / no entry point): image textures (on the instancer mesh, :640-667,
+ * and as the albedo of an auxiliary mesh) and
  * DistributeInstancesOnMesh (:233-390: libigl curvature directions on LFS meshes; the reference can export what it computes
  * there with `transformation_export_path`, and that list is what ntx_instancer_create takes).
  *
@@ -388,6 +389,13 @@ int ntx_instancer_matrices(const ntx_instancer *inst, float *world_to_patch, flo
 /* The instancer mesh (instancer.cpp:369-389: in the scene for culling): HOST vertices[n_vertices,3], faces[n_faces,3].  A ray
  * ends at its closest crossing of the mesh and is closed by an opaque black sample (:1013-1016).  n_faces = 0 removes it. */
 int ntx_instancer_set_mesh(ntx_instancer *inst, const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces);
+/* The same with auxiliary meshes (AddMesh, instancer.cpp:393-417) in one list: face_kind[f] = 0 for the instancer mesh (black closing
+ * sample), 1 for an auxiliary mesh, whose closing sample is shaded (shadeMesh, :716-743): albedo 0.8 * min(diffuse + 0.2, 1), diffuse =
+ * max(n . l, 0) with the interpolated vertex normal n (normals[n_vertices,3], HOST) and the light parameter l, 0 when the point just
+ * above the surface is shadowed (isShadowed).  Needs a light entry in the textures list; mesh textures are not built.  Every mesh
+ * culls and casts shadows alike.  normals / face_kind may be NULL (= ntx_instancer_set_mesh). */
+int ntx_instancer_set_meshes(ntx_instancer *inst, const float *vertices, const float *normals, int64_t n_vertices, const int32_t *faces,
+                             const uint8_t *face_kind, int64_t n_faces);
 /* GetModelInput (instancer.cpp:751-1037) with the buffers of get_model_input (instancer.pyx:38-54), all DEVICE, every element of
  * every output written: rays_o[N,3], rays_d[N,3] (per ray; the reference's [N,S,3] input is this row repeated), parameters[N,P] ->
  * rays_d_map[N,S,3], pts[N,S,3], t[N,S], dists[N,S], color_last[N,3], alpha_last[N], alpha_weight[N,S] (density_weight),

@@ -112,6 +112,7 @@ SYMBOLS = {
     "ntx_instancer_count": (C.c_int64, [_vp]),
     "ntx_instancer_matrices": (C.c_int, [_vp, _fp, _fp, _fp]),
     "ntx_instancer_set_mesh": (C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_int32), C.c_int64]),
+    "ntx_instancer_set_meshes": (C.c_int, [_vp, _fp, _fp, C.c_int64, C.POINTER(C.c_int32), _u8p, C.c_int64]),
     "ntx_instancer_model_input": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_uint64, _op] + [_vp] * 12),
 }
 

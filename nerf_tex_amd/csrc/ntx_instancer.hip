@@ -9,7 +9,8 @@
 //                      memory in the loop): slab test of the ray in patch coordinates against every instance -- for the few
 //                      thousand patches of a scene, all pairs on the VALUs cost less than one BVH build (spheres cull per
 //                      wave) -- a crossed box goes onto the ray's list as one record {t_in, t_out, instance}
-//   inst_mesh_kernel   the same against the triangles of the instancer mesh (closest crossing)
+//   inst_mesh_kernel   the same against the triangles of the meshes (closest crossing, with its triangle)
+//   inst_shade_kernel  the closing sample of rays that end on an auxiliary mesh (shadeMesh, instancer.cpp:716-743)
 //   inst_march_kernel  wave per ray.  The reference's walk over the sorted crossings with a std::set of open patches
 //                      (instancer.cpp:800-826, 870-1010) is taken apart into steps that are parallel over crossings, gaps or
 //                      marching steps (see WaveLds below); emission is lane per marching step, every output row is written
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict_
 
 // closest crossing of the instancer mesh per ray (Moeller-Trumbore, no culling); tris[f] = {v0, v1 - v0, v2 - v0, sphere centre, radius^2}
 __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int n_rays,
-                                                        const float *__restrict__ tris, int n_tri, int per_wave, uint32_t *__restrict__ t_mesh) {
+                                                        const float *__restrict__ tris, int n_tri, int per_wave, unsigned long long *__restrict__ t_mesh) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ray = blockIdx.x * 64 + lane;
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
     const int f0 = (blockIdx.y * 4 + wave) * per_wave;
     const int f1 = f0 + per_wave < n_tri ? f0 + per_wave : n_tri;
     float best = INFINITY;
+    int best_f = 0;
     const float dd2 = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
     const WaveCone cone = wave_cone(o[0], o[1], o[2], d[0], d[1], d[2]);
     for (int fb = f0; fb < f1; fb += 64) {
@@ -220,10 +222,11 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
         const float v = ((d[0] * q[0] + d[1] * q[1]) + d[2] * q[2]) * inv_det;
         if (v < 0.0f || u + v > 1.0f) continue;
         const float tt = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv_det;
-        if (tt > 0.0f && tt <= T_FAR && tt < best) best = tt;
+        if (tt > 0.0f && tt <= T_FAR && tt < best) { best = tt; best_f = f; }
       }
     }
-    if (live && best < INFINITY) atomicMin(&t_mesh[ray], __builtin_bit_cast(uint32_t, best));   // positive floats order like their bits
+    // (t, triangle) as one 64-bit key: positive floats order like their bits, ties go to the lower triangle
+    if (live && best < INFINITY) atomicMin(&t_mesh[ray], ((unsigned long long)__builtin_bit_cast(uint32_t, best) << 32) | (uint32_t)best_f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
 struct MarchArgs {
     const float *rays_o, *rays_d, *params;
     const float *mats, *origins, *xforms;   // xforms[K][24]: world -> patch matrix (12), direction map (9), padding: what a step gathers
-    const uint32_t *count; const uint4 *hits; const uint32_t *t_mesh;   // t_mesh NULL = no mesh
+    const uint32_t *count; const uint4 *hits; const unsigned long long *t_mesh;   // (t bits << 32 | triangle) of the closest mesh hit; NULL = no mesh
     float *rays_d_map, *pts, *t, *dists, *color_last, *alpha_last, *alpha_weight, *params_map;
     int32_t *instance_id; uint8_t *hit; int32_t *status;
     int n_rays, n_pts, n_params;
@@ -436,7 +439,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
         L.u.raw.id[i] = r.z;
     }
     __builtin_amdgcn_wave_barrier();
-    const uint32_t tm_bits = a.t_mesh ? a.t_mesh[ray] : INF_BITS;
+    const uint32_t tm_bits = a.t_mesh ? (uint32_t)(a.t_mesh[ray] >> 32) : INF_BITS;
     const bool has_mesh = tm_bits != INF_BITS;
     const float t_mesh = __builtin_bit_cast(float, tm_bits);
     const bool any_hit = n_rec > 0 || has_mesh;
@@ -904,6 +907,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     march_ray<true>(a, lds);
 }
 
+// The closing sample of a ray that ends on an AUXILIARY mesh (instancer.cpp:1013-1022 -> shadeMesh, :716-743): wave per ray; the hit
+// triangle's barycentrics once more, the interpolated vertex normal, one shadow query from just above the surface (`occluded`: all
+// lanes the same point), diffuse + 0.2 ambient on albedo 0.8.  Rays that end on the instancer mesh keep the black the march kernel wrote.
+struct ShadeArgs { const float *normals; const int32_t *faces; const uint8_t *kind; };
+__global__ __launch_bounds__(256) void inst_shade_kernel(MarchArgs a, ShadeArgs sh) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ray = blockIdx.x * 4 + wave;
+    if (ray >= a.n_rays) return;
+    const unsigned long long key = a.t_mesh[ray];
+    if ((uint32_t)(key >> 32) == INF_BITS) return;
+    const int f = (int)(uint32_t)key;
+    if (sh.kind[f] == 0) return;
+    const float tm = __builtin_bit_cast(float, (uint32_t)(key >> 32));
+    const float o[3] = {a.rays_o[3 * ray], a.rays_o[3 * ray + 1], a.rays_o[3 * ray + 2]};
+    const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
+    const float *tr = a.tris + (size_t)f * 13;
+    const float *v0 = tr, *e1 = tr + 3, *e2 = tr + 6;
+    const float p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+    const float det = (e1[0] * p[0] + e1[1] * p[1]) + e1[2] * p[2];
+    const float inv_det = 1.0f / det;
+    const float s[3] = {o[0] - v0[0], o[1] - v0[1], o[2] - v0[2]};
+    const float u = ((s[0] * p[0] + s[1] * p[1]) + s[2] * p[2]) * inv_det;
+    const float q[3] = {s[1] * e1[2] - s[2] * e1[1], s[2] * e1[0] - s[0] * e1[2], s[0] * e1[1] - s[1] * e1[0]};
+    const float v = ((d[0] * q[0] + d[1] * q[1]) + d[2] * q[2]) * inv_det;
+    const float w0 = (1.0f - u) - v;                                                   // Vector3f(1 - u - v, u, v), :1020
+    const int32_t *fv = sh.faces + (size_t)f * 3;
+    float n[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) n[c] = (sh.normals[3 * fv[0] + c] * w0 + sh.normals[3 * fv[1] + c] * u) + sh.normals[3 * fv[2] + c] * v;
+    normalized(n[0], n[1], n[2]);
+    const float *par = a.params + (size_t)ray * a.n_params;
+    const float lx = par[a.light_dir_idx], ly = par[a.light_dir_idx + 1], lz = par[a.light_dir_idx + 2];
+    const float px = (o[0] + tm * d[0]) + n[0] * 1e-6f, py = (o[1] + tm * d[1]) + n[1] * 1e-6f, pz = (o[2] + tm * d[2]) + n[2] * 1e-6f;
+    // `occluded` takes the wave's points as lying on one ray: here they are one point, at parameter 0 of the ray (p, l) itself
+    const bool dark = occluded(a, lane, px, py, pz, lx, ly, lz, 0.0f, px, py, pz, lx, ly, lz);
+    float nlx = lx, nly = ly, nlz = lz;
+    normalized(nlx, nly, nlz);
+    const float nd = (n[0] * nlx + n[1] * nly) + n[2] * nlz;
+    const float diffuse = dark ? 0.0f : 1.0f * (nd > 0.0f ? nd : 0.0f);
+    const float sum = diffuse + 0.2f;
+    const float shade = sum < 1.0f ? sum : 1.0f;
+    if (lane == 0) { a.color_last[3 * ray] = 0.8f * shade; a.color_last[3 * ray + 1] = 0.8f * shade; a.color_last[3 * ray + 2] = 0.8f * shade; }
+}
+
 }   // namespace ntx_inst
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -916,7 +964,9 @@ struct ntx_instancer {
     std::vector<float> h_mats, h_dirs, h_org;          // world -> patch [K,12], direction maps [K,9], origins [K,3]
     std::vector<float> h_spheres;                      // [K,4] centre and squared radius of the instanced box, world
     float *d_mats = nullptr, *d_org = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_xforms = nullptr;
-    uint32_t *d_count = nullptr, *d_tmesh = nullptr;
+    uint32_t *d_count = nullptr;
+    unsigned long long *d_tmesh = nullptr;
+    float *d_normals = nullptr; int32_t *d_faces = nullptr; uint8_t *d_kind = nullptr; bool has_aux = false;   // auxiliary meshes
     uint4 *d_hits = nullptr;
 };
 
@@ -951,7 +1001,7 @@ bool invert4(const float *m, double *out) {
 void release(ntx_instancer *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    for (void *q : {(void *)p->d_mats, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_xforms, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits})
+    for (void *q : {(void *)p->d_mats, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_xforms, (void *)p->d_normals, (void *)p->d_faces, (void *)p->d_kind, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits})
         if (q) (void)hipFree(q);
     delete p;
 }
@@ -964,7 +1014,7 @@ int reserve(ntx_instancer *p, int64_t max_rays) {
     if (p->d_hits) { (void)hipFree(p->d_hits); p->d_hits = nullptr; }
     p->cap_rays = 0;
     INST_TRY(hipMalloc((void **)&p->d_count, (size_t)max_rays * sizeof(uint32_t)));
-    INST_TRY(hipMalloc((void **)&p->d_tmesh, (size_t)max_rays * sizeof(uint32_t)));
+    INST_TRY(hipMalloc((void **)&p->d_tmesh, (size_t)max_rays * sizeof(unsigned long long)));
     INST_TRY(hipMalloc((void **)&p->d_hits, (size_t)max_rays * ntx_inst::MAX_HITS * sizeof(uint4)));
     p->cap_rays = max_rays;
     return NTX_OK;
@@ -1072,7 +1122,16 @@ int ntx_instancer_matrices(const ntx_instancer *inst, float *world_to_patch, flo
 }
 
 int ntx_instancer_set_mesh(ntx_instancer *inst, const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces) {
+    return ntx_instancer_set_meshes(inst, vertices, nullptr, n_vertices, faces, nullptr, n_faces);
+}
+
+int ntx_instancer_set_meshes(ntx_instancer *inst, const float *vertices, const float *normals, int64_t n_vertices, const int32_t *faces,
+                             const uint8_t *face_kind, int64_t n_faces) {
     if (!inst) return ntx_set_error(NTX_E_INVALID, "inst is NULL");
+    bool aux = false;
+    for (int64_t f = 0; face_kind && f < n_faces; ++f) aux = aux || face_kind[f] != 0;
+    if (aux && !normals) return ntx_set_error(NTX_E_INVALID, "auxiliary meshes are shaded with their vertex normals (instancer.cpp:722-724): normals is NULL");
+    if (aux && inst->desc.light_dir_parameter_idx < 0) return ntx_set_error(NTX_E_INVALID, "auxiliary meshes are shaded from the light parameter (instancer.cpp:1020): the textures list has none");
     if (n_faces < 0 || n_faces > 0x7fffffff || n_vertices < 0 || (n_faces > 0 && (!vertices || !faces))) return ntx_set_error(NTX_E_INVALID, "bad mesh");
     INST_TRY(hipSetDevice(inst->device));
     std::vector<float> tris((size_t)n_faces * 13);
@@ -1093,12 +1152,21 @@ int ntx_instancer_set_mesh(ntx_instancer *inst, const float *vertices, int64_t n
         for (int c = 0; c < 3; ++c) tris[f * 13 + 9 + c] = (float)cen[c];
         tris[f * 13 + 12] = (float)(r2 * 1.002 + 1e-12);
     }
-    if (inst->d_tris) { (void)hipFree(inst->d_tris); inst->d_tris = nullptr; }
-    inst->n_tri = 0;
+    for (void **q : {(void **)&inst->d_tris, (void **)&inst->d_normals, (void **)&inst->d_faces, (void **)&inst->d_kind})
+        if (*q) { (void)hipFree(*q); *q = nullptr; }
+    inst->n_tri = 0; inst->has_aux = false;
     if (n_faces > 0) {
         INST_TRY(hipMalloc((void **)&inst->d_tris, tris.size() * sizeof(float)));
         INST_TRY(hipMemcpy(inst->d_tris, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice));
-        inst->n_tri = n_faces;
+        if (aux) {
+            INST_TRY(hipMalloc((void **)&inst->d_normals, (size_t)n_vertices * 3 * sizeof(float)));
+            INST_TRY(hipMemcpy(inst->d_normals, normals, (size_t)n_vertices * 3 * sizeof(float), hipMemcpyHostToDevice));
+            INST_TRY(hipMalloc((void **)&inst->d_faces, (size_t)n_faces * 3 * sizeof(int32_t)));
+            INST_TRY(hipMemcpy(inst->d_faces, faces, (size_t)n_faces * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
+            INST_TRY(hipMalloc((void **)&inst->d_kind, (size_t)n_faces));
+            INST_TRY(hipMemcpy(inst->d_kind, face_kind, (size_t)n_faces, hipMemcpyHostToDevice));
+        }
+        inst->n_tri = n_faces; inst->has_aux = aux;
     }
     return NTX_OK;
 }
@@ -1151,7 +1219,7 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
             hipLaunchKernelGGL(inst_hits_kernel, dim3(tiles, gy), dim3(256), 0, st, ro, rd, n, inst->d_mats, inst->d_spheres, K, per_wave, box, inst->d_count, inst->d_hits);
         }
         if (F > 0) {
-            INST_TRY(hipMemsetD32Async((hipDeviceptr_t)inst->d_tmesh, (int)INF_BITS, (size_t)n, st));
+            INST_TRY(hipMemsetD32Async((hipDeviceptr_t)inst->d_tmesh, (int)INF_BITS, (size_t)n * 2, st));   // high word = +inf: no hit
             int per_wave = 256;
             while (per_wave > 32 && (int64_t)tiles * ((F + per_wave - 1) / per_wave) < 4096) per_wave >>= 1;
             const int gy = (F + 4 * per_wave - 1) / (4 * per_wave);
@@ -1179,6 +1247,7 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         a.min_shadow = inst->desc.min_shadow_samples; a.n_shadow = inst->desc.n_shadow_samples;
         if (inst->desc.cast_shadow_rays && a.light_dir_idx >= 0) hipLaunchKernelGGL(inst_march_shadow_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(inst_march_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
+        if (F > 0 && inst->has_aux) hipLaunchKernelGGL(inst_shade_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a, ShadeArgs{inst->d_normals, inst->d_faces, inst->d_kind});
     }
     INST_TRY(hipGetLastError());
     return NTX_OK;

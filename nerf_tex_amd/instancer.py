@@ -8,8 +8,8 @@ config names `nerf_tex_amd.instancer.Instancer` where it named `instancer.instan
 What is built: explicit `transformations` (instancer.pyx:19-20) or the JSON file the reference's `transformation_export_path`
 writes (instancer.cpp:1040-1061), a culling mesh given as arrays or a PLY file, the three `instance_sampling_method`s,
 `use_mean_distance`, '' / 'light' / 'point' entries of `textures`, `cast_shadow_rays` with `min_shadow_samples` /
-`n_shadow_samples`.  What is refused (NtxError, NTX_E_UNSUPPORTED): image textures, `auxiliary_meshes`, and `mesh_path` without an
-exported transformation list (DistributeInstancesOnMesh needs libigl's curvature directions on meshes the reference keeps in LFS).
+`n_shadow_samples`.  `auxiliary_meshes` (flat-shaded; a path to a PLY with vertex normals, or arrays).  What is refused (NtxError, NTX_E_UNSUPPORTED):
+image textures (parameters and auxiliary albedo), and `mesh_path` without an exported transformation list (DistributeInstancesOnMesh needs libigl's curvature directions on meshes the reference keeps in LFS).
 """
 
 from __future__ import annotations
@@ -53,8 +53,9 @@ class Instancer:
         import numpy as np
         if instance_sampling_method not in SAMPLING_METHODS:
             raise ValueError(f"instance_sampling_method must be one of {sorted(SAMPLING_METHODS)}")
-        if auxiliary_meshes:
-            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, "auxiliary meshes (instancer.cpp:393-417, 716-743) are not built")
+        for _, tex in auxiliary_meshes:
+            if tex:
+                raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, f"texture {tex!r} on an auxiliary mesh (instancer.cpp:405, 727-733) is not built")
         n_par, light_dir, light_strength = parse_textures(textures)
         tr = [np.asarray(m, np.float32).reshape(4, 4) for m in transformations]
         distributed = False
@@ -84,10 +85,12 @@ class Instancer:
         self._h = C.c_void_p()
         _lib.check(_lib.lib.ntx_instancer_create(C.byref(desc), self._tr.ctypes.data_as(C.POINTER(C.c_float)), self._tr.shape[0],
                                                  self.device, C.byref(self._h)))
-        if mesh is not None:
-            self.set_mesh(*mesh)
-        elif mesh_path is not None:
-            self.set_mesh(*read_ply(mesh_path))
+        base = mesh if mesh is not None else (read_ply(mesh_path) if mesh_path is not None else None)
+        aux = [read_ply(path, normals=True) if isinstance(path, str) else path for path, _ in auxiliary_meshes]   # (path | (V, F, N), texture)
+        if aux:                                                                              # AddMesh, instancer.cpp:393-417
+            self.set_meshes(base, aux)
+        elif base is not None:
+            self.set_mesh(*base)
         if transformation_export_path is not None:
             self.export_transformations(transformation_export_path)
 
@@ -107,6 +110,26 @@ class Instancer:
         f = np.ascontiguousarray(np.asarray(faces, np.int32).reshape(-1, 3))
         _lib.check(_lib.lib.ntx_instancer_set_mesh(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), v.shape[0],
                                                    f.ctypes.data_as(C.POINTER(C.c_int32)), f.shape[0]))
+
+    def set_meshes(self, instancer_mesh, auxiliary) -> None:
+        """The instancer mesh (vertices, faces) or None, and auxiliary meshes [(vertices, faces, vertex normals), ...] (AddMesh,
+        instancer.cpp:393-417): all of them cull and cast shadows; a ray that ends on an auxiliary mesh gets a shaded closing sample
+        (shadeMesh, :716-743)."""
+        import numpy as np
+        vs, ns, fs, ks, base = [], [], [], [], 0
+        meshes = ([(instancer_mesh[0], instancer_mesh[1], None, 0)] if instancer_mesh is not None else []) + [(m[0], m[1], m[2], 1) for m in auxiliary]
+        for v, f, n, kind in meshes:
+            v = np.asarray(v, np.float32).reshape(-1, 3); f = np.asarray(f, np.int32).reshape(-1, 3)
+            if kind and n is None:
+                raise ValueError("an auxiliary mesh needs vertex normals (the reference shades with them, instancer.cpp:722-724)")
+            vs.append(v); fs.append(f + base); ks.append(np.full(f.shape[0], kind, np.uint8))
+            ns.append(np.asarray(n, np.float32).reshape(-1, 3) if n is not None else np.zeros_like(v))
+            base += v.shape[0]
+        v, n, f, k = (np.ascontiguousarray(np.concatenate(x)) for x in (vs, ns, fs, ks))
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.lib.ntx_instancer_set_meshes(self._h, fp(v), fp(n), v.shape[0], f.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                     k.ctypes.data_as(C.POINTER(C.c_uint8)), f.shape[0]))
+        self.meshes = (v, f, n, k)                    # as the library holds them (tests hand them to the oracle)
 
     def reserve(self, max_rays: int) -> None:
         _lib.check(_lib.lib.ntx_instancer_reserve(self._h, int(max_rays)))
@@ -168,8 +191,9 @@ class Instancer:
         return 0 if st is None else int(st.item())
 
 
-def read_ply(path: str):
-    """Vertices [nv,3] float32 and triangles [nf,3] int32 of a PLY file (ascii or binary_little_endian; x/y/z of the vertex
+def read_ply(path: str, normals: bool = False):
+    """Vertices [nv,3] float32 and triangles [nf,3] int32 of a PLY file (`normals`: and the vertex normals nx / ny / nz [nv,3], for an
+    auxiliary mesh) (ascii or binary_little_endian; x/y/z of the vertex
     element, the list property of the face element; polygons are fanned) -- what igl::readPLY hands AddMesh /
     DistributeInstancesOnMesh for the culling mesh (instancer.cpp:241, 400)."""
     import numpy as np
@@ -197,7 +221,7 @@ def read_ply(path: str):
                 break
         if fmt not in ("ascii", "binary_little_endian"):
             raise ValueError(f"{path}: PLY format {fmt!r} is not supported")
-        verts, faces = None, []
+        verts, faces, vnorm = None, [], None
         for name, count, props in elements:
             is_list = any(p[0] == "list" for p in props)
             if fmt == "ascii":
@@ -206,6 +230,8 @@ def read_ply(path: str):
                     cols = [p[-1] for p in props]
                     ix = [cols.index(c) for c in ("x", "y", "z")]
                     verts = np.asarray([[float(r[i]) for i in ix] for r in rows], np.float32).reshape(-1, 3)
+                    if normals and all(c in cols for c in ("nx", "ny", "nz")):
+                        vnorm = np.asarray([[float(r[cols.index(c)]) for c in ("nx", "ny", "nz")] for r in rows], np.float32).reshape(-1, 3)
                 elif name == "face":
                     for r in rows:
                         k = int(r[0]); idx = [int(v) for v in r[1:1 + k]]
@@ -215,6 +241,8 @@ def read_ply(path: str):
                 data = np.frombuffer(f.read(dt.itemsize * count), dtype=dt, count=count)
                 if name == "vertex":
                     verts = np.stack([data["x"], data["y"], data["z"]], -1).astype(np.float32)
+                    if normals and all(c in data.dtype.names for c in ("nx", "ny", "nz")):
+                        vnorm = np.stack([data["nx"], data["ny"], data["nz"]], -1).astype(np.float32)
             else:
                 for _ in range(count):
                     idx = None
@@ -231,4 +259,9 @@ def read_ply(path: str):
                         faces += [[idx[0], idx[i], idx[i + 1]] for i in range(1, len(idx) - 1)]
     if verts is None:
         raise ValueError(f"{path}: no vertex element")
-    return verts, np.asarray(faces, np.int32).reshape(-1, 3)
+    tri = np.asarray(faces, np.int32).reshape(-1, 3)
+    if normals:
+        if vnorm is None:
+            raise ValueError(f"{path}: no vertex normals (nx, ny, nz)")
+        return verts, tri, vnorm
+    return verts, tri

@@ -54,6 +54,8 @@ class InstancerSpec:
     patch_scale: float = 1.0             # only DistributeInstancesOnMesh sets it (instancer.cpp:236); 1 otherwise (:53)
     mesh_v: Optional[np.ndarray] = None  # the instancer mesh (culls, closes a ray with an opaque black sample)
     mesh_f: Optional[np.ndarray] = None
+    mesh_n: Optional[np.ndarray] = None  # vertex normals and a kind per face (0 = instancer mesh, 1 = auxiliary mesh: shaded, :716-743)
+    mesh_kind: Optional[np.ndarray] = None
     cast_shadow_rays: bool = False       # instancer.cpp:53
     min_shadow_samples: int = 4
     n_shadow_samples: int = 512
@@ -89,12 +91,14 @@ def make_spec(b_0, b_1, transformations, textures=(), instance_sampling_method="
               mesh=None, matrices=None, cast_shadow_rays=False, min_shadow_samples=4, n_shadow_samples=512) -> InstancerSpec:
     n, ld, ls = parse_textures(textures)
     inv, dir_t, org = prepare_instances(transformations) if matrices is None else matrices
-    mv = mf = None
+    mv = mf = mn = mk = None
     if mesh is not None:
         mv = np.asarray(mesh[0], F32).reshape(-1, 3); mf = np.asarray(mesh[1], np.int32).reshape(-1, 3)
+        if len(mesh) > 2 and mesh[2] is not None:                                       # (vertices, faces, normals, kind per face)
+            mn = np.asarray(mesh[2], F32).reshape(-1, 3); mk = np.asarray(mesh[3], np.uint8).reshape(-1)
     return InstancerSpec(np.asarray(b_0, F32), np.asarray(b_1, F32), inv, dir_t, org, n, ld, ls,
                          {"random": 0, "nearest": 1, "nearest_blend": 2}[instance_sampling_method], bool(use_mean_distance),
-                         1.0, mv, mf, bool(cast_shadow_rays), int(min_shadow_samples), int(n_shadow_samples))
+                         1.0, mv, mf, mn, mk, bool(cast_shadow_rays), int(min_shadow_samples), int(n_shadow_samples))
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -169,15 +173,16 @@ def box_hits(spec: InstancerSpec, o, d) -> List[Tuple[np.float32, int]]:
     return hits
 
 
-def mesh_hit(spec: InstancerSpec, o, d) -> Optional[np.float32]:
-    """Closest crossing of the instancer mesh (Moeller-Trumbore in float32, no culling, tnear < t <= tfar) or None."""
+def mesh_hit(spec: InstancerSpec, o, d, full: bool = False):
+    """Closest crossing of the meshes (Moeller-Trumbore in float32, no culling, tnear < t <= tfar) or None; ties go to the lower
+    triangle.  `full`: (t, triangle, u, v) -- Embree's hit of :1020."""
     if spec.mesh_v is None:
         return None
     best = None
     cross = lambda a, b: np.asarray([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], F32)
     dot = lambda a, b: (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
     with np.errstate(divide="ignore", invalid="ignore"):
-        for f in spec.mesh_f:
+        for k, f in enumerate(spec.mesh_f):
             v0, v1, v2 = spec.mesh_v[f[0]], spec.mesh_v[f[1]], spec.mesh_v[f[2]]
             e1 = v1 - v0; e2 = v2 - v0
             p = cross(d, e2); det = dot(e1, p)
@@ -193,9 +198,31 @@ def mesh_hit(spec: InstancerSpec, o, d) -> Optional[np.float32]:
             if v < 0 or u + v > 1:
                 continue
             tt = dot(e2, q) * inv_det
-            if T_NEAR < tt <= T_FAR and (best is None or tt < best):
-                best = F32(tt)
-    return best
+            if T_NEAR < tt <= T_FAR and (best is None or tt < best[0]):
+                best = (F32(tt), k, u, v)
+    if best is None:
+        return None
+    return best if full else best[0]
+
+
+def shade_mesh(spec: InstancerSpec, o, d, hit, light):
+    """shadeMesh (instancer.cpp:716-743) for a hit (t, triangle, u, v) on an auxiliary mesh without a texture: albedo 0.8, the
+    interpolated vertex normal, diffuse = max(n . l, 0) unless the point just above the surface is shadowed, 0.2 ambient."""
+    tt, k, u, v = hit
+    f = spec.mesh_f[k]
+    w0 = (F32(1.0) - u) - v                                                              # Vector3f(1 - u - v, u, v), :1020
+    n = ((spec.mesh_n[f[0]] * w0 + spec.mesh_n[f[1]] * u) + spec.mesh_n[f[2]] * v).astype(F32)
+    n = _normalized(n)
+    pt = ((o + tt * d).astype(F32) + n * F32(1e-6)).astype(F32)                         # :736
+    diffuse = F32(1.0)
+    if not is_shadowed(spec, pt, light):
+        nl = _normalized(np.asarray(light, F32).copy())
+        nd = (n[0] * nl[0] + n[1] * nl[1]) + n[2] * nl[2]
+        diffuse = diffuse * (nd if nd > 0 else F32(0.0))
+    else:
+        diffuse = F32(0.0)
+    sm = diffuse + F32(0.2)
+    return np.full(3, F32(0.8) * (sm if sm < 1 else F32(1.0)), F32)
 
 
 def is_shadowed(spec: InstancerSpec, pt, direction) -> bool:
@@ -278,7 +305,8 @@ def get_model_input(spec: InstancerSpec, rays_o, rays_d, parameters, n_samples: 
         # at most MAX_TOTAL_HITS box crossings are kept (:539; here the first ones of the sorted list, in the reference the
         # first ones Embree's traversal meets -- a ray with more is flagged by the product and not comparable)
         hits = sorted([(tt, k, False) for tt, k in box_hits(spec, o, d)], key=lambda e: (e[0], e[1]))[:MAX_TOTAL_HITS]
-        tm = mesh_hit(spec, o, d)
+        mh = mesh_hit(spec, o, d, full=True)
+        tm = None if mh is None else mh[0]
         if tm is not None:
             hits.append((tm, INVALID, True))
         if not hits:                                                                    # :782
@@ -416,6 +444,8 @@ def get_model_input(spec: InstancerSpec, rays_o, rays_d, parameters, n_samples: 
                             s_1 = is_shadowed(spec, (o + t_1_sh * d).astype(F32), default_light)
                         seg_l += 1                                                      # :1029
                     active.add(k)
-        if has_mesh:                                                                    # :1013-1027 (instancer mesh: black, opaque)
+        if has_mesh:                                                                    # :1013-1027: the instancer mesh is black, an auxiliary one shaded
             density[i, 0] = 1.0
+            if spec.mesh_kind is not None and spec.mesh_kind[mh[1]] != 0:
+                color[i, 0] = shade_mesh(spec, o, d, mh, default_light)
     return rays_d_map, pts, t, dists, color, density, density_weight, instance_id, hit, params_map

@@ -180,7 +180,7 @@ def test_overflow_flags_and_refusals(tmp_path):
     assert inst.status() == 0
     assert_same(out, want)
     assert out[6].max() == 90                                                    # density_weight = patches the point lies in
-    for kw in (dict(textures=["meshes/smooth_checkerboard.png"]), dict(auxiliary_meshes=[("a.ply", "")]),
+    for kw in (dict(textures=["meshes/smooth_checkerboard.png"]), dict(auxiliary_meshes=[("a.ply", "meshes/checkerboard.png")]),
                dict(mesh_path="meshes/cloth_mesh.ply")):
         with pytest.raises(_lib.NtxError) as e:
             Instancer(UNIT["b_0"], UNIT["b_1"], transformations=[translate().tolist()], **kw)
@@ -442,3 +442,38 @@ def test_failed_calls_write_nothing():
     assert call() == _lib.NTX_OK                                                  # ... and the same call with good arguments fills them
     torch.cuda.synchronize()
     assert not bool((bufs["dists"] == 7).any()) and bool(bufs["hit"].all())
+
+
+@pytest.mark.parametrize("textures,shadows", [(("", "light", ""), False), (("point", ""), False), (("", "light"), True)])
+def test_auxiliary_meshes_bit_for_bit(textures, shadows):
+    """auxiliary_meshes (AddMesh + shadeMesh, instancer.cpp:393-417, 716-743): a ground sheet (the instancer mesh, black) and two
+    shaded auxiliary meshes -- a tilted roof over half of the scene that also shadows the ground, and a wall -- every buffer incl.
+    the closing sample's colour bit for bit."""
+    spec0 = random_scene(51, k=20, method="nearest", textures=textures, mesh=True)
+    box = dict(b_0=spec0.b_0.tolist(), b_1=spec0.b_1.tolist())
+    tr = [np.linalg.inv(m.astype(np.float64)).astype(F) for m in spec0.inv]
+    rng = np.random.default_rng(51)
+    unit = lambda v: (np.asarray(v, F) / np.linalg.norm(v)).astype(F)
+    roof_v = F([[-1.5, -1.5, 0.9], [0.2, -1.5, 1.3], [0.2, 1.5, 1.3], [-1.5, 1.5, 0.9]])
+    roof = (roof_v, [[0, 1, 2], [0, 2, 3]], np.stack([unit([-0.23, 0.05 * k, 0.97]) for k in range(4)]))          # smooth, slightly varying normals
+    wall = (F([[0.9, -1.5, -0.1], [0.9, 1.5, -0.1], [0.9, 1.5, 0.8], [0.9, -1.5, 0.8]]), [[0, 1, 2], [0, 2, 3]], np.tile(unit([-1, 0, 0.1]), (4, 1)))
+    sh = dict(cast_shadow_rays=True, min_shadow_samples=4, n_shadow_samples=64) if shadows else {}
+    from nerf_tex_amd.instancer import Instancer
+    inst = Instancer(box["b_0"], box["b_1"], textures=list(textures), transformations=[m.tolist() for m in tr], instance_sampling_method="nearest",
+                     mesh=(spec0.mesh_v, spec0.mesh_f), auxiliary_meshes=[(roof, ""), (wall, "")], **sh)
+    v, f, nrm, kind = inst.meshes
+    assert kind.tolist() == [0, 0, 1, 1, 1, 1] and f.max() == 11
+    n, S, h = 160, 96, 0.02
+    o, d = random_rays(51, n)
+    P = spec0.n_parameters
+    params = rng.uniform(0.2, 1.0, size=(n, P)).astype(F)
+    ld = 1
+    light = rng.normal(size=(n, 3)); light[:, 2] = np.abs(light[:, 2]) * 0.7 + 0.2
+    params[:, ld:ld + 3] = light
+    got = run_gpu(inst, o, d, params, S, h, seed=6)
+    want = run_oracle(inst, box, o, d, params, S, h, 6, "nearest", textures, False, (v, f, nrm, kind), **sh)
+    shaded = want[4][:, 0, 0]
+    assert (shaded > 0).sum() > 20 and len(np.unique(shaded)) > 10 and (want[5][:, 0] == 1).sum() > (shaded > 0).sum()   # shaded, black and open endings
+    assert np.isclose(shaded[shaded > 0].min(), 0.16, atol=1e-6) and shaded.max() > 0.5     # some in shadow or facing away (ambient only), some lit
+    assert_same(got, want)
+    assert inst.status() == 0

@@ -783,6 +783,14 @@ def test_instancer_host_side(tmp_path):
     b.write_bytes(hdr + body)
     vb, fb = ins.read_ply(str(b))
     assert np.array_equal(vb, v) and fb.tolist() == fa.tolist()
+    vn, fn, nn = ins.read_ply(str(a), normals=False) + (None,)
+    with pytest.raises(ValueError, match="no vertex normals"):
+        ins.read_ply(str(a), normals=True)                       # nx alone is not a normal
+    c = tmp_path / "c.ply"
+    c.write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\n"
+                 "property float nz\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0 0 0 1\n1 0 0 0 0 1\n0 1 0 0 1 0\n3 0 1 2\n")
+    vc, fc, nc = ins.read_ply(str(c), normals=True)
+    assert nc.tolist() == [[0, 0, 1], [0, 0, 1], [0, 1, 0]] and fc.tolist() == [[0, 1, 2]]
     with pytest.raises(ValueError):
         ins.read_ply(__file__)
     # the C ABI refuses bad arguments before it looks for a device

@@ -169,6 +169,31 @@ def test_is_shadowed_known_answers():
     assert not io.is_shadowed(spec, F([5, 0, 3]), F([0, 0, -1]))
 
 
+def test_auxiliary_mesh_is_shaded():
+    """shadeMesh (instancer.cpp:716-743) on the closing sample: albedo 0.8 * min(max(n . l, 0) + 0.2, 1), 0.2 ambient only when the
+    point is shadowed or faces away; the instancer mesh itself stays black."""
+    quad_v = [[-2, -2, .5], [2, -2, .5], [2, 2, .5], [-2, 2, .5]]
+    up = [[0, 0, 1]] * 4
+    mesh = (quad_v, [[0, 1, 2], [0, 2, 3]], up, [1, 1])
+    spec = io.make_spec(transformations=[translate(z=-30)], textures=["light"], mesh=mesh, **UNIT)
+    o, d = F([[0.3, 0.2, 5]]), F([[0, 0, -1]])                    # from above onto the lit side
+    light = F([[0, 3, 4]])                                       # n . l = 0.8
+    *_, color, dens, w, iid, hit, pm = io.get_model_input(spec, o, d, light, 4, 0.5, F([0.5]), np.zeros((1, 4), F))
+    assert dens[0, 0] == 1 and np.allclose(color[0, 0], 0.8 * 1.0)                      # min(0.8 + 0.2, 1)
+    *_, color, dens, w, iid, hit, pm = io.get_model_input(spec, o, d, F([[0, 0.6, 0.3]]), 4, 0.5, F([0.5]), np.zeros((1, 4), F))
+    assert np.allclose(color[0, 0], 0.8 * (0.3 / np.hypot(0.6, 0.3) + 0.2), atol=1e-6)
+    *_, color, dens, w, iid, hit, pm = io.get_model_input(spec, o, d, F([[0, 0, -1]]), 4, 0.5, F([0.5]), np.zeros((1, 4), F))
+    assert np.allclose(color[0, 0], 0.8 * 0.2)                                          # lit from behind: ambient only
+    # a patch box over the point: its bottom face shadows it
+    spec = io.make_spec(transformations=[translate(z=3)], textures=["light"], mesh=mesh, **UNIT)
+    *_, color, dens, w, iid, hit, pm = io.get_model_input(spec, F([[0.3, 0.2, 1.5]]), d, F([[0, 0.3, 4]]), 4, 0.5, F([0.5]), np.zeros((1, 4), F))
+    assert np.allclose(color[0, 0], 0.8 * 0.2) and dens[0, 0] == 1
+    # kind 0 = the instancer mesh: black
+    spec = io.make_spec(transformations=[translate(z=-30)], textures=["light"], mesh=(quad_v, mesh[1], up, [0, 0]), **UNIT)
+    *_, color, dens, w, iid, hit, pm = io.get_model_input(spec, o, d, light, 4, 0.5, F([0.5]), np.zeros((1, 4), F))
+    assert dens[0, 0] == 1 and not color.any()
+
+
 def random_scene(seed, k=12, method="nearest", textures=(), mesh=False):
     rng = np.random.default_rng(seed)
     tr = []
