@@ -348,9 +348,9 @@ int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_hos
  * the matrices ExportTransformations writes (:1040-1061) and GetModelInput (:751-1037) with the three patch choices, mean
  * distances, directional and point lights, shadow rays (:591-602, 945-961, 1018-1027), auxiliary meshes with
  * their flat shading (:393-417, 716-743).  NOT built (NTX_E_UNSUPPORTED / no entry point): image textures (on the instancer mesh, :640-667,
- * and as the albedo of an auxiliary mesh) and
- * DistributeInstancesOnMesh (:233-390: libigl curvature directions on LFS meshes; the reference can export what it computes
- * there with `transformation_export_path`, and that list is what ntx_instancer_create takes).
+ * and as the albedo of an auxiliary mesh).  DistributeInstancesOnMesh (:233-390) is setup on the host: its result is the
+ * transformation list ntx_instancer_create takes (nerf_tex_amd.instancer.distribute_instances_on_mesh restates it; the reference
+ * can also export its own with `transformation_export_path`).
  *
  * ntx_instancer_desc = the constructor arguments that survive (instancer.cpp:53-93): b_0 / b_1 the patch box in patch
  * coordinates; n_parameters, light_dir_parameter_idx, light_strength_parameter_idx as the `textures` list defines them

@@ -5,11 +5,12 @@ config names `nerf_tex_amd.instancer.Instancer` where it named `instancer.instan
 `ntx_instancer_model_input` (include/nerftex.h) and the ten buffers stay in HBM, where `InstanceRenderer` hands them to
 `ntx_render_instanced` -- the reference walks its rays through Embree on one CPU thread and uploads ~70 bytes per (ray, step).
 
-What is built: explicit `transformations` (instancer.pyx:19-20) or the JSON file the reference's `transformation_export_path`
-writes (instancer.cpp:1040-1061), a culling mesh given as arrays or a PLY file, the three `instance_sampling_method`s,
-`use_mean_distance`, '' / 'light' / 'point' entries of `textures`, `cast_shadow_rays` with `min_shadow_samples` /
-`n_shadow_samples`.  `auxiliary_meshes` (flat-shaded; a path to a PLY with vertex normals, or arrays).  What is refused (NtxError, NTX_E_UNSUPPORTED):
-image textures (parameters and auxiliary albedo), and `mesh_path` without an exported transformation list (DistributeInstancesOnMesh needs libigl's curvature directions on meshes the reference keeps in LFS).
+What is built: explicit `transformations` (instancer.pyx:19-20), the JSON file the reference's `transformation_export_path`
+writes (instancer.cpp:1040-1061), or `mesh_path` [+ `patch_origins_path`, `patch_scale`, `jitter_amount`]: DistributeInstancesOnMesh
+(instancer.cpp:233-390) on the host, from a PLY with vertex normals and texture coordinates; a culling mesh as arrays or a PLY file;
+`auxiliary_meshes` (flat-shaded; a PLY with vertex normals, or arrays); the three `instance_sampling_method`s;
+`use_mean_distance`; '' / 'light' / 'point' entries of `textures`; `cast_shadow_rays` with `min_shadow_samples` /
+`n_shadow_samples`.  What is refused (NtxError, NTX_E_UNSUPPORTED): image textures (as parameters and as auxiliary albedo).
 """
 
 from __future__ import annotations
@@ -63,10 +64,20 @@ class Instancer:
             with open(transformations_path) as f:
                 tr += [np.asarray(m, np.float32).reshape(4, 4) for m in json.load(f)]
             distributed = True
-        elif mesh_path is not None:
-            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, "mesh_path without transformations_path: DistributeInstancesOnMesh "
-                                "(instancer.cpp:233-390) is not built; export the list once with the reference's "
-                                "transformation_export_path and pass it as transformations_path")
+        elif mesh_path is not None:                    # DistributeInstancesOnMesh (instancer.cpp:233-390), on the host
+            v_, f_, n_, uv_ = read_ply(mesh_path, normals=True, uv=True)
+            origins = None
+            if patch_origins_path:
+                try:
+                    origins = read_ply(patch_origins_path)[0]
+                except (OSError, ValueError):           # the reference falls back to the vertices when it cannot read the file (:281, 341)
+                    origins = None
+            placed, scale_ = distribute_instances_on_mesh(v_, f_, n_, uv_, patch_scale, origins, jitter_amount, seed)
+            tr += list(placed)
+            patch_scale = scale_
+            distributed = True
+            if mesh is None:
+                mesh = (v_, f_)
         self._tr = np.ascontiguousarray(np.stack(tr) if tr else np.zeros((0, 4, 4), np.float32))
         # only DistributeInstancesOnMesh stores the scale (instancer.cpp:236); it widens nearest_blend's transition (:697)
         self.patch_scale = float(patch_scale) if distributed else 1.0
@@ -191,9 +202,9 @@ class Instancer:
         return 0 if st is None else int(st.item())
 
 
-def read_ply(path: str, normals: bool = False):
+def read_ply(path: str, normals: bool = False, uv: bool = False):
     """Vertices [nv,3] float32 and triangles [nf,3] int32 of a PLY file (`normals`: and the vertex normals nx / ny / nz [nv,3], for an
-    auxiliary mesh) (ascii or binary_little_endian; x/y/z of the vertex
+    auxiliary mesh; `uv`: and the texture coordinates s / t (or u / v, texture_u / texture_v) [nv,2], for DistributeInstancesOnMesh) (ascii or binary_little_endian; x/y/z of the vertex
     element, the list property of the face element; polygons are fanned) -- what igl::readPLY hands AddMesh /
     DistributeInstancesOnMesh for the culling mesh (instancer.cpp:241, 400)."""
     import numpy as np
@@ -221,7 +232,7 @@ def read_ply(path: str, normals: bool = False):
                 break
         if fmt not in ("ascii", "binary_little_endian"):
             raise ValueError(f"{path}: PLY format {fmt!r} is not supported")
-        verts, faces, vnorm = None, [], None
+        verts, faces, vnorm, vuv = None, [], None, None
         for name, count, props in elements:
             is_list = any(p[0] == "list" for p in props)
             if fmt == "ascii":
@@ -232,6 +243,10 @@ def read_ply(path: str, normals: bool = False):
                     verts = np.asarray([[float(r[i]) for i in ix] for r in rows], np.float32).reshape(-1, 3)
                     if normals and all(c in cols for c in ("nx", "ny", "nz")):
                         vnorm = np.asarray([[float(r[cols.index(c)]) for c in ("nx", "ny", "nz")] for r in rows], np.float32).reshape(-1, 3)
+                    for a_, b_ in _UV_NAMES:
+                        if a_ in cols and b_ in cols:
+                            vuv = np.asarray([[float(r[cols.index(a_)]), float(r[cols.index(b_)])] for r in rows], np.float32).reshape(-1, 2)
+                            break
                 elif name == "face":
                     for r in rows:
                         k = int(r[0]); idx = [int(v) for v in r[1:1 + k]]
@@ -243,6 +258,10 @@ def read_ply(path: str, normals: bool = False):
                     verts = np.stack([data["x"], data["y"], data["z"]], -1).astype(np.float32)
                     if normals and all(c in data.dtype.names for c in ("nx", "ny", "nz")):
                         vnorm = np.stack([data["nx"], data["ny"], data["nz"]], -1).astype(np.float32)
+                    for a_, b_ in _UV_NAMES:
+                        if a_ in data.dtype.names and b_ in data.dtype.names:
+                            vuv = np.stack([data[a_], data[b_]], -1).astype(np.float32)
+                            break
             else:
                 for _ in range(count):
                     idx = None
@@ -260,8 +279,125 @@ def read_ply(path: str, normals: bool = False):
     if verts is None:
         raise ValueError(f"{path}: no vertex element")
     tri = np.asarray(faces, np.int32).reshape(-1, 3)
-    if normals:
-        if vnorm is None:
-            raise ValueError(f"{path}: no vertex normals (nx, ny, nz)")
-        return verts, tri, vnorm
-    return verts, tri
+    if normals and vnorm is None:
+        raise ValueError(f"{path}: no vertex normals (nx, ny, nz)")
+    if uv and vuv is None:
+        raise ValueError(f"{path}: no texture coordinates (s, t)")
+    return (verts, tri) + ((vnorm,) if normals else ()) + ((vuv,) if uv else ())
+
+
+_UV_NAMES = (("s", "t"), ("u", "v"), ("texture_u", "texture_v"))
+
+
+def closest_point_triangle(p, a, b, c):
+    """closest_point_triangle (instancer.cpp:154-198; Ericson's regions): the closest point of triangle abc to p and its
+    barycentrics, float32."""
+    import numpy as np
+    F = np.float32
+    ab, ac, ap = b - a, c - a, p - a
+    d1, d2 = F(ab @ ap), F(ac @ ap)
+    if d1 <= 0 and d2 <= 0:
+        return a, np.asarray([1, 0, 0], F)
+    bp = p - b
+    d3, d4 = F(ab @ bp), F(ac @ bp)
+    if d3 >= 0 and d4 <= d3:
+        return b, np.asarray([0, 1, 0], F)
+    cp = p - c
+    d5, d6 = F(ab @ cp), F(ac @ cp)
+    if d6 >= 0 and d5 <= d6:
+        return c, np.asarray([0, 0, 1], F)
+    vc = d1 * d4 - d3 * d2
+    if vc <= 0 and d1 >= 0 and d3 <= 0:
+        v = d1 / (d1 - d3)
+        return a + v * ab, np.asarray([1 - v, v, 0], F)
+    vb = d5 * d2 - d1 * d6
+    if vb <= 0 and d2 >= 0 and d6 <= 0:
+        v = d2 / (d2 - d6)
+        return a + v * ac, np.asarray([1 - v, 0, v], F)
+    va = d3 * d6 - d5 * d4
+    if va <= 0 and (d4 - d3) >= 0 and (d5 - d6) >= 0:
+        v = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+        return b + v * (c - b), np.asarray([0, 1 - v, v], F)
+    denom = F(1.0) / (va + vb + vc)
+    v, w = vb * denom, vc * denom
+    return a + v * ab + w * ac, np.asarray([1 - v - w, v, w], F)
+
+
+def distribute_instances_on_mesh(vertices, faces, normals, uv, scale: float, patch_origins=None, jitter_amount: float = 0.0, seed: int = 0):
+    """DistributeInstancesOnMesh (instancer.cpp:233-390) on the host: the patch -> world transformations [K,4,4] it hands AddInstance,
+    and the patch scale (`scale <= 0`: the mesh's average edge length, :244-245).  Per vertex a tangent frame from the texture
+    coordinates (:249-276: the u direction, made orthogonal to the vertex normal; bitangent = n x t); per patch origin the frame of
+    the closest point of the mesh within one average edge length (:300-322), or, without origins, one patch per distinct vertex
+    (:343-366); columns (tangent, bitangent, normal) * scale, translation = the origin.  `jitter_amount` > 0 turns the frame about its
+    normal by jitter_amount * U(0, pi) (:326-329, 351-355), the draws taken like the reference's: std::mt19937(seed) through
+    std::uniform_real_distribution<float> -- numpy's legacy MT19937 seeding gives the same words, and libstdc++'s
+    generate_canonical<float, 24> is float(word) / 2^32."""
+    import numpy as np
+    F = np.float32
+    V = np.asarray(vertices, F).reshape(-1, 3); Fa = np.asarray(faces, np.int64).reshape(-1, 3)
+    N = np.asarray(normals, F).reshape(-1, 3).copy(); UV = np.asarray(uv, F).reshape(-1, 2)
+    edges = np.concatenate([np.linalg.norm(V[Fa[:, j]] - V[Fa[:, (j + 1) % 3]], axis=1).astype(F) for j in range(3)])
+    avg_edge = float(edges.astype(np.float64).sum() / (3 * Fa.shape[0]))                     # igl::avg_edge_length
+    scale = float(scale) if scale > 0 else avg_edge
+    e0, e1 = V[Fa[:, 1]] - V[Fa[:, 0]], V[Fa[:, 2]] - V[Fa[:, 0]]
+    uv0, uv1 = UV[Fa[:, 1]] - UV[Fa[:, 0]], UV[Fa[:, 2]] - UV[Fa[:, 0]]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = F(1.0) / (uv0[:, 0] * uv1[:, 1] - uv0[:, 1] * uv1[:, 0])
+        t_face = ((e0 * uv1[:, 1:2] - e1 * uv0[:, 1:2]) * r[:, None]).astype(F)
+    T = np.zeros_like(V)
+    for j in range(3):
+        np.add.at(T, Fa[:, j], t_face)                                                        # :258-264 (summation order: by face)
+    unit = lambda x: (x / np.linalg.norm(x, axis=-1, keepdims=True)).astype(F)
+    N = unit(N)
+    T = unit(T - N * np.sum(N * T, -1, keepdims=True))
+    B = np.cross(N, T).astype(F)
+    words = np.random.RandomState(int(seed))._bit_generator.random_raw
+    pi_f = F(np.pi)
+
+    def turn(b, n):                                                                           # Rodrigues about n, :328 / :353
+        c = F(words(1)[0]) / F(4294967296.0)
+        c = np.nextafter(F(1), F(0)) if c >= 1 else c
+        angle = F(jitter_amount) * (pi_f * c)
+        return (b * np.cos(angle) + np.cross(n, b) * np.sin(angle) + n * (n @ b) * (F(1) - np.cos(angle))).astype(F)
+
+    out = []
+    if patch_origins is not None:
+        origins = np.asarray(patch_origins, F).reshape(-1, 3)
+        from scipy.spatial import cKDTree
+        cen = V[Fa].mean(1); reach = np.linalg.norm(V[Fa] - cen[:, None], axis=-1).max()
+        tree = cKDTree(cen)
+        for pt in origins:
+            best = None
+            for f in sorted(tree.query_ball_point(pt, avg_edge + reach + 1e-6)):               # (the triangles that can hold a point that close)
+                q, w = closest_point_triangle(pt, V[Fa[f, 0]], V[Fa[f, 1]], V[Fa[f, 2]])
+                d = F(np.linalg.norm(pt - q))
+                if d < (best[0] if best else F(avg_edge)):                                     # radius = avg_edge_length, shrinking (:219-224)
+                    best = (d, f, w)
+            if best is None:
+                raise ValueError(f"patch origin {pt.tolist()} lies further than one average edge length ({avg_edge:.4g}) from the mesh")
+            _, f, w = best
+            mix = lambda A: (A[Fa[f, 0]] * w[0] + A[Fa[f, 1]] * w[1] + A[Fa[f, 2]] * w[2]).astype(F)
+            n, t = unit(mix(N)), unit(mix(T))
+            b = np.cross(n, t).astype(F)
+            if jitter_amount > 0:
+                b = turn(b, n)
+            t = np.cross(b, n).astype(F)
+            m = np.eye(4, dtype=F)
+            m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = t * F(scale), b * F(scale), n * F(scale), pt
+            out.append(m)
+    else:
+        seen = set()
+        for i in range(V.shape[0]):
+            key = V[i].tobytes()
+            if key in seen:
+                continue
+            seen.add(key)
+            t, b, n = T[i], B[i], N[i]
+            if jitter_amount > 0:
+                b = turn(b, n)
+                tc = np.cross(n, b).astype(F)
+                t = (F(-1.0) if (t @ tc) < 0 else F(1.0)) * tc
+            m = np.eye(4, dtype=F)
+            m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = t * F(scale), b * F(scale), n * F(scale), V[i]
+            out.append(m)
+    return np.stack(out) if out else np.zeros((0, 4, 4), F), scale

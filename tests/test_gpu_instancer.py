@@ -180,8 +180,7 @@ def test_overflow_flags_and_refusals(tmp_path):
     assert inst.status() == 0
     assert_same(out, want)
     assert out[6].max() == 90                                                    # density_weight = patches the point lies in
-    for kw in (dict(textures=["meshes/smooth_checkerboard.png"]), dict(auxiliary_meshes=[("a.ply", "meshes/checkerboard.png")]),
-               dict(mesh_path="meshes/cloth_mesh.ply")):
+    for kw in (dict(textures=["meshes/smooth_checkerboard.png"]), dict(auxiliary_meshes=[("a.ply", "meshes/checkerboard.png")])):
         with pytest.raises(_lib.NtxError) as e:
             Instancer(UNIT["b_0"], UNIT["b_1"], transformations=[translate().tolist()], **kw)
         assert e.value.code == _lib.NTX_E_UNSUPPORTED
@@ -477,3 +476,36 @@ def test_auxiliary_meshes_bit_for_bit(textures, shadows):
     assert np.isclose(shaded[shaded > 0].min(), 0.16, atol=1e-6) and shaded.max() > 0.5     # some in shadow or facing away (ambient only), some lit
     assert_same(got, want)
     assert inst.status() == 0
+
+
+def test_patches_distributed_on_a_mesh_file(tmp_path):
+    """The shipped configs' way in: mesh_path + patch_origins_path + patch_scale + jitter_amount (config_carpet_render.py:87-94) ->
+    DistributeInstancesOnMesh on the host -> the same instancer as the explicit transformation list; the mesh culls."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.instancer import Instancer, distribute_instances_on_mesh
+    tr0, v, f = synthetic.patch_sheet(8, extent=0.5)
+    nrm = tr0[:, :3, 2] / np.linalg.norm(tr0[:, :3, 2], axis=-1, keepdims=True)
+    uv = (v[:, :2] + 0.5).astype(F)
+    mesh = tmp_path / "sheet.ply"
+    mesh.write_text("ply\nformat ascii 1.0\nelement vertex 64\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\n"
+                    "property float nz\nproperty float s\nproperty float t\nelement face %d\nproperty list uchar int vertex_indices\nend_header\n" % f.shape[0]
+                    + "".join("%r %r %r %r %r %r %r %r\n" % tuple(float(x) for x in (*a, *b, *c)) for a, b, c in zip(v, nrm, uv))
+                    + "".join(f"3 {t[0]} {t[1]} {t[2]}\n" for t in f))
+    origins = v[::3] + F([0.01, -0.01, 0.0])
+    org = tmp_path / "anchors.ply"
+    org.write_text("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n" % len(origins)
+                   + "".join("%r %r %r\n" % tuple(float(x) for x in o) for o in origins))
+    b_0, b_1 = synthetic.PATCH_BOX
+    a = Instancer(b_0, b_1, textures=["", "light"], mesh_path=str(mesh), patch_origins_path=str(org), patch_scale=0.09, jitter_amount=1.0,
+                  instance_sampling_method="nearest_blend")
+    want, scale = distribute_instances_on_mesh(v, f, nrm, uv, 0.09, origins, 1.0, 0)
+    assert a.n_instances() == len(origins) == 22 and a.patch_scale == pytest.approx(0.09) and scale == pytest.approx(0.09)
+    b = Instancer(b_0, b_1, textures=["", "light"], transformations=[m.tolist() for m in want], mesh=(v, f), instance_sampling_method="nearest_blend")
+    assert all(np.array_equal(x, y) for x, y in zip(a.matrices(), b.matrices()))
+    R = np.linalg.inv(a.matrices()[0][:, :3, :3])                                 # patch -> world: orthogonal columns of length 0.09
+    assert np.allclose(np.einsum("kij,kil->kjl", R, R), 0.09 ** 2 * np.eye(3), atol=1e-6)
+    o = np.tile(F([[0.05, 0.02, 3.0]]), (4, 1)); d = np.tile(F([[0, 0, -1]]), (4, 1))
+    out = run_gpu(a, o, d, np.tile(F([[1, 0, 0, 1]]), (4, 1)), 64, 0.01, seed=1)
+    assert out[8].all() and (out[5] == 1).all() and (out[3] > 0).sum() > 8       # marches the patches, ends on the sheet
+    c = Instancer(b_0, b_1, mesh_path=str(mesh), patch_scale=-1.0)                 # no anchors: a patch per vertex; scale = the average edge length
+    assert c.n_instances() == 64 and 0.1 < c.patch_scale < 0.2

@@ -804,3 +804,57 @@ def test_instancer_host_side(tmp_path):
     d.cast_shadow_rays = 0; d.instance_sample_method = 3
     assert _lib.lib.ntx_instancer_create(C.byref(d), None, 0, 0, C.byref(h)) == _lib.NTX_E_INVALID
     assert _lib.lib.ntx_instancer_count(None) == -1
+
+
+def test_distribute_instances_on_mesh(tmp_path):
+    """DistributeInstancesOnMesh (instancer.cpp:233-390) restated on the host: tangent frames from the texture coordinates, patches at
+    the closest point of given origins or at the distinct vertices, the jitter turned by the reference's own generator
+    (std::mt19937 -> numpy's legacy MT19937: the published first word of seed 5489)."""
+    from nerf_tex_amd import instancer as ins
+    F = np.float32
+    assert np.random.RandomState(5489)._bit_generator.random_raw(1)[0] == 3499211612      # std::mt19937's known first output
+    # a flat 3 x 3 grid in z = 0.25, texture coordinates (x, y) / 2, normals +z (one of them not normalised)
+    xs = np.linspace(0, 2, 3)
+    x, y = np.meshgrid(xs, xs, indexing="ij")
+    V = np.stack([x, y, np.full_like(x, 0.25)], -1).reshape(-1, 3).astype(F)
+    idx = np.arange(9).reshape(3, 3)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    Fa = np.concatenate([np.stack([a, b, c], -1), np.stack([a, c, d], -1)])
+    N = np.tile(F([0, 0, 1]), (9, 1)); N[4] *= 3
+    UV = (V[:, :2] / 2).astype(F)
+    tr, scale = ins.distribute_instances_on_mesh(V, Fa, N, UV, 0.5, patch_origins=F([[0.5, 0.7, 0.3], [1.9, 0.1, 0.25]]))
+    assert scale == 0.5 and tr.shape == (2, 4, 4)
+    for m, org in zip(tr, ([0.5, 0.7, 0.3], [1.9, 0.1, 0.25])):                              # u runs along x: tangent x, bitangent y, normal z
+        assert np.allclose(m[:3, :3], 0.5 * np.eye(3), atol=1e-6) and np.allclose(m[:3, 3], org) and m[3].tolist() == [0, 0, 0, 1]
+    tr, scale = ins.distribute_instances_on_mesh(V, Fa, N, UV, -1.0)                          # no origins: the vertices; scale <= 0: average edge length
+    edges = [1, 1, np.sqrt(2)]
+    assert tr.shape == (9, 4, 4) and abs(scale - np.mean(edges)) < 1e-6 and np.allclose(tr[:, :3, 3], V)
+    assert np.allclose(tr[4, :3, :3], scale * np.eye(3), atol=1e-6)
+    with pytest.raises(ValueError, match="average edge length"):
+        ins.distribute_instances_on_mesh(V, Fa, N, UV, 0.5, patch_origins=F([[0.5, 0.5, 3.0]]))
+    # jitter: frames stay orthogonal with columns of length `scale`, turned about the normal by jitter * pi * float(word) / 2^32
+    tr, _ = ins.distribute_instances_on_mesh(V, Fa, N, UV, 0.5, patch_origins=F([[0.5, 0.7, 0.25], [1.5, 1.5, 0.25]]), jitter_amount=1.0, seed=0)
+    w = np.random.RandomState(0)._bit_generator.random_raw(2)
+    for m, word in zip(tr, w):
+        R = m[:3, :3] / 0.5
+        assert np.allclose(R.T @ R, np.eye(3), atol=1e-5) and np.allclose(R[:, 2], [0, 0, 1], atol=1e-6) and np.linalg.det(R) > 0.99
+        angle = np.float32(np.pi) * (np.float32(word) / np.float32(2 ** 32))
+        assert np.allclose(R[:, 1], [-np.sin(angle), np.cos(angle), 0], atol=1e-5)             # the bitangent (y) turned about z
+    # closest_point_triangle: the regions of Ericson's test
+    A, B, C_ = F([0, 0, 0]), F([1, 0, 0]), F([0, 1, 0])
+    for p, want, bary in [([-1, -1, 2], A, [1, 0, 0]), ([2, -0.5, 0], B, [0, 1, 0]), ([-0.5, 3, 1], C_, [0, 0, 1]), ([0.5, -1, 0], [0.5, 0, 0], [.5, .5, 0]),
+                          ([-1, 0.25, 0], [0, 0.25, 0], [.75, 0, .25]), ([1, 1, 5], [0.5, 0.5, 0], [0, .5, .5]), ([0.25, 0.25, 7], [0.25, 0.25, 0], [.5, .25, .25])]:
+        q, w_ = ins.closest_point_triangle(F(p), A, B, C_)
+        assert np.allclose(q, want) and np.allclose(w_, bary)
+    # through the constructor's file path: a PLY with normals and texture coordinates, origins in a second PLY
+    mesh = tmp_path / "sheet.ply"
+    mesh.write_text("ply\nformat ascii 1.0\nelement vertex 9\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\n"
+                    "property float nz\nproperty float s\nproperty float t\nelement face 8\nproperty list uchar int vertex_indices\nend_header\n"
+                    + "".join(f"{v[0]} {v[1]} {v[2]} 0 0 1 {u[0]} {u[1]}\n" for v, u in zip(V, UV)) + "".join(f"3 {f[0]} {f[1]} {f[2]}\n" for f in Fa))
+    v2, f2, n2, uv2 = ins.read_ply(str(mesh), normals=True, uv=True)
+    assert np.array_equal(v2, V) and np.array_equal(f2, Fa) and np.allclose(uv2, UV) and n2.shape == (9, 3)
+    bare = tmp_path / "bare.ply"
+    bare.write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nelement face 1\n"
+                    "property list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    with pytest.raises(ValueError, match="texture coordinates"):
+        ins.read_ply(str(bare), uv=True)
