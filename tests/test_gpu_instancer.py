@@ -251,7 +251,16 @@ def test_fuzz_scenes_bit_for_bit(seed):
     tr = [np.linalg.inv(m.astype(np.float64)).astype(F) for m in spec0.inv]
     msh = (spec0.mesh_v, spec0.mesh_f) if mesh else None
     sh = dict(cast_shadow_rays=True, min_shadow_samples=int(rng.integers(2, 9)), n_shadow_samples=int(rng.choice([16, 64, 100000]))) if shadows else {}
-    inst = gpu_instancer(box, tr, textures=list(textures), instance_sampling_method=method, use_mean_distance=mean, mesh=msh, **sh)
+    aux = bool(textures) and bool(rng.integers(0, 2))                            # an auxiliary mesh (shaded closing sample) needs a light
+    kw = {}
+    if aux:
+        z0, z1 = rng.uniform(0.3, 1.2, size=2)
+        nv = rng.normal(size=(4, 3)) * 0.2 + [0, 0, 1]
+        kw["auxiliary_meshes"] = [((F([[-1.5, -1.5, z0], [1.5, -1.5, z1], [1.5, 1.5, z1], [-1.5, 1.5, z0]]), [[0, 1, 2], [0, 2, 3]],
+                                    (nv / np.linalg.norm(nv, axis=-1, keepdims=True)).astype(F)), "")]
+    inst = gpu_instancer(box, tr, textures=list(textures), instance_sampling_method=method, use_mean_distance=mean, mesh=msh, **sh, **kw)
+    if aux:
+        msh = inst.meshes                                                        # (vertices, faces, normals, kind) as the library holds them
     n = 48
     o, d = random_rays(200 + seed, n)
     if not shadows:                      # (a segment the ray never leaves has no length in the reference: instancer.cpp:1019 reads past its list)
