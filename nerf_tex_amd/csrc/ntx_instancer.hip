@@ -313,7 +313,11 @@ __device__ __forceinline__ bool occluded(const MarchArgs &a, int lane, float ox,
         const float wx = c[0] - ox, wy = c[1] - oy, wz = c[2] - oz;
         const float h0 = (wx * nx + wy * ny) + wz * nz;
         if (!(h0 * h0 <= r2 * nn * 1.001f)) return false;
-        if (!strip) return true;
+        if (!strip) {                     // light along the ray: no strip to cull with -- unless it is EXACTLY along it (one point only,
+            if (nn != 0.0f) return true;  // inst_shade_kernel passes the shadow ray itself): then every shadow ray lies on the line (o, l)
+            const float qx = wy * lz - wz * ly, qy = wz * lx - wx * lz, qz = wx * ly - wy * lx;
+            return (qx * qx + qy * qy) + qz * qz <= r2 * ll * 1.001f + 1e-12f;
+        }
         const float b1 = (wx * dx + wy * dy) + wz * dz, b2 = (wx * lx + wy * ly) + wz * lz;
         const float alpha = (b1 * ll - b2 * dl_) * inv_nn, beta = (b2 * ddq - b1 * dl_) * inv_nn;
         const float r = __builtin_sqrtf(r2);
