@@ -19,6 +19,17 @@ Random numbers: the reference draws from one std::mt19937 in ray order (:855, :6
 parallel cannot reproduce; the product keys a Philox4x32-10 block by (seed, global ray index, sample) instead and THIS file
 restates those draws (`offset_uniforms`, `choice_uniforms`), like `nerftex_oracle.jitter_uniforms` does for the jitter.
 
+Image textures (round 4): `load_texture` (:34-50), `interpolate2d` (:605-637), `get_parameters` (:640-667: the closest point of the
+instancer mesh within patch_max_extent, `closest_point_triangle` :154-198, brute force over the triangles where the reference
+walks Embree's BVH), the per-segment texture samples with their LINEAR interpolation (:910-927, 989-998) and the albedo of an
+auxiliary mesh (:725-733).  Reference quirks kept: a texture file of c channels takes c parameters but only ONE of its channel
+matrices is ever multiplied in -- `textures[i]` for the i-th FILE, where `textures` is the list of all channel matrices (:656-662);
+an interpolated row is `s0 * (1 - w) + s1 * w` in EVERY column, also those no texture touches (:923).  Where the reference reads
+outside a texture (u or v = 1 makes idx + 1 = rows, :612-613; its assert is compiled out) the index is clamped here: the weight of
+such a texel is 0.  Which of several triangles at the same distance Embree reports first is not knowable; here the lowest primID.
+Eigen's fixed-size reductions (dot, squaredNorm of a Vector3f) pair their terms as x0 + (x1 + x2) (Redux.h's unroller): the NEW
+code below follows that; the older functions sum left to right.
+
 Everything is sequential Python over numpy float32 scalars: small cases only.
 """
 
@@ -59,22 +70,68 @@ class InstancerSpec:
     cast_shadow_rays: bool = False       # instancer.cpp:53
     min_shadow_samples: int = 4
     n_shadow_samples: int = 512
+    mesh_prim: Optional[np.ndarray] = None      # per face: its primID inside its own mesh (the shadow filter's `primID == 1`, :553)
+    mesh_uv: Optional[np.ndarray] = None        # per vertex of the mesh list: texture coordinates (auxiliary albedo, :730)
+    mesh_tex: Optional[np.ndarray] = None       # per face: index into aux_textures, -1 = none (albedo 0.8, :728)
+    aux_textures: Optional[list] = None         # per auxiliary mesh with a texture: its channel matrices (loadTexture)
+    # parameter textures on the instancer mesh (DistributeInstancesOnMesh was called: instancer_geomID is valid, :911)
+    tex_idx: Optional[list] = None              # texture_parameter_idxs: first parameter of every texture FILE (:87)
+    textures: Optional[list] = None             # all channel matrices of all files, in order (:86)
+    inst_v: Optional[np.ndarray] = None         # the instancer mesh: vertices, faces, texture coordinates (:236)
+    inst_f: Optional[np.ndarray] = None
+    inst_uv: Optional[np.ndarray] = None
+    patch_max_extent: float = 0.0               # :69, scaled by :246
+    min_texture_samples: int = 4
+    n_texture_samples: int = 512
 
 
-def parse_textures(textures: Sequence[str]) -> Tuple[int, int, int]:
-    """(n_parameters, light_dir_parameter_idx, light_strength_parameter_idx) from the constructor's `textures` list
-    (instancer.cpp:74-92).  Image textures need the instancer mesh's UVs and the LFS images: not restated."""
+def load_texture(path) -> List[np.ndarray]:
+    """loadTexture (instancer.cpp:34-50): the image's channels as matrices [width, height] of value / 255, indexed (x, y counted from
+    the BOTTOM row): stb hands rows top-down as [height * width, channels]; a channel's column is mapped column-major to
+    (width, height) -- element (x, y) = pixel (row y, column x) -- and `.rowwise().reverse()` turns the y axis over.  Decoded with PIL
+    (the product has its own decoder: nerf_tex_amd/png.py); stb's channel count: grey 1, grey + alpha 2, RGB 3, RGBA 4, a palette
+    expanded to RGB(A), 16-bit samples reduced to their high byte."""
+    from PIL import Image
+    im = Image.open(path)
+    if im.mode == "P":
+        im = im.convert("RGBA" if "transparency" in im.info else "RGB")
+    elif im.mode == "1":
+        im = im.convert("L")
+    elif im.mode.startswith("I"):
+        im = Image.fromarray((np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8))
+    a = np.asarray(im)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return texture_from_pixels(a)
+
+
+def texture_from_pixels(pixels) -> List[np.ndarray]:
+    """The matrices loadTexture builds from stb's pixels [height, width, channels] uint8 (instancer.cpp:40-46)."""
+    a = np.asarray(pixels, np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    f = a.astype(F32) / F32(255.0)                                                       # cast<float>() / 255.f
+    return [np.ascontiguousarray(f[::-1, :, c].T) for c in range(a.shape[2])]           # [x, y from the bottom]
+
+
+def parse_textures(textures: Sequence[str], images=None):
+    """(n_parameters, light_dir_parameter_idx, light_strength_parameter_idx, texture_parameter_idxs, channel matrices) from the
+    constructor's `textures` list (instancer.cpp:74-92).  `images`: {path: channel matrices} for paths that are not files."""
     n, ld, ls = 0, -1, -1
+    idx, mats = [], []
     for path in textures:
         if path == "light":
             ld = n; n += 3
         elif path == "point":
             ls = n; ld = n + 1; n += 4
         elif path != "":
-            raise ValueError("image textures are not restated")
+            tex = images[path] if images is not None and path in images else load_texture(path)
+            mats += list(tex)
+            idx.append(n)
+            n += len(tex)
         else:
             n += 1
-    return n, ld, ls
+    return n, ld, ls, idx, mats
 
 
 def prepare_instances(transformations) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -88,17 +145,39 @@ def prepare_instances(transformations) -> Tuple[np.ndarray, np.ndarray, np.ndarr
 
 
 def make_spec(b_0, b_1, transformations, textures=(), instance_sampling_method="random", use_mean_distance=False,
-              mesh=None, matrices=None, cast_shadow_rays=False, min_shadow_samples=4, n_shadow_samples=512) -> InstancerSpec:
-    n, ld, ls = parse_textures(textures)
+              mesh=None, matrices=None, cast_shadow_rays=False, min_shadow_samples=4, n_shadow_samples=512,
+              images=None, instancer_mesh=None, patch_scale=1.0, min_texture_samples=4, n_texture_samples=512,
+              mesh_uv=None, mesh_tex=None, aux_textures=None, mesh_prim=None) -> InstancerSpec:
+    """`mesh`: the list of culling meshes as (vertices, faces[, normals, kind per face]); `mesh_prim` the faces' primIDs inside their
+    own meshes (default: one mesh per run of equal kind... i.e. the face index where only one mesh is given).
+    `instancer_mesh` = (vertices, faces, uv): DistributeInstancesOnMesh was called with it (parameter textures apply, :911), and
+    `patch_scale` is its scale (patch_max_extent *= scale, :246)."""
+    n, ld, ls, tex_idx, tex = parse_textures(textures, images)
     inv, dir_t, org = prepare_instances(transformations) if matrices is None else matrices
     mv = mf = mn = mk = None
     if mesh is not None:
         mv = np.asarray(mesh[0], F32).reshape(-1, 3); mf = np.asarray(mesh[1], np.int32).reshape(-1, 3)
         if len(mesh) > 2 and mesh[2] is not None:                                       # (vertices, faces, normals, kind per face)
             mn = np.asarray(mesh[2], F32).reshape(-1, 3); mk = np.asarray(mesh[3], np.uint8).reshape(-1)
-    return InstancerSpec(np.asarray(b_0, F32), np.asarray(b_1, F32), inv, dir_t, org, n, ld, ls,
+    spec = InstancerSpec(np.asarray(b_0, F32), np.asarray(b_1, F32), inv, dir_t, org, n, ld, ls,
                          {"random": 0, "nearest": 1, "nearest_blend": 2}[instance_sampling_method], bool(use_mean_distance),
                          1.0, mv, mf, mn, mk, bool(cast_shadow_rays), int(min_shadow_samples), int(n_shadow_samples))
+    if mf is not None:
+        spec.mesh_prim = np.arange(mf.shape[0], dtype=np.int64) if mesh_prim is None else np.asarray(mesh_prim, np.int64).reshape(-1)
+    spec.mesh_uv = None if mesh_uv is None else np.asarray(mesh_uv, F32).reshape(-1, 2)
+    spec.mesh_tex = None if mesh_tex is None else np.asarray(mesh_tex, np.int64).reshape(-1)
+    spec.aux_textures = aux_textures
+    spec.tex_idx, spec.textures = tex_idx, tex
+    spec.min_texture_samples, spec.n_texture_samples = int(min_texture_samples), int(n_texture_samples)
+    # patch_max_extent (:69): the norm of the elementwise maximum of b_0 and b_1; Eigen pairs x0^2 + (x1^2 + x2^2)
+    e = np.maximum(spec.b_0, spec.b_1).astype(F32)
+    spec.patch_max_extent = np.sqrt(e[0] * e[0] + (e[1] * e[1] + e[2] * e[2]))
+    if instancer_mesh is not None:
+        spec.inst_v = np.asarray(instancer_mesh[0], F32).reshape(-1, 3); spec.inst_f = np.asarray(instancer_mesh[1], np.int64).reshape(-1, 3)
+        spec.inst_uv = np.asarray(instancer_mesh[2], F32).reshape(-1, 2)
+        spec.patch_scale = float(patch_scale)
+        spec.patch_max_extent = F32(spec.patch_max_extent * F32(patch_scale))           # :246
+    return spec
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -205,9 +284,96 @@ def mesh_hit(spec: InstancerSpec, o, d, full: bool = False):
     return best if full else best[0]
 
 
+def _dot3(a, b):
+    """Eigen's dot of two Vector3f: the unrolled reduction pairs x0 + (x1 + x2) (Redux.h, redux_novec_unroller)."""
+    return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2])
+
+
+def closest_point_triangle(p, a, b, c):
+    """closest_point_triangle (instancer.cpp:154-198): the closest point of triangle abc to p and its barycentrics, float32."""
+    one, zero = F32(1.0), F32(0.0)
+    ab = b - a; ac = c - a; ap = p - a
+    d1 = _dot3(ab, ap); d2 = _dot3(ac, ap)
+    if d1 <= 0 and d2 <= 0:
+        return a, np.asarray([1, 0, 0], F32)
+    bp = p - b
+    d3 = _dot3(ab, bp); d4 = _dot3(ac, bp)
+    if d3 >= 0 and d4 <= d3:
+        return b, np.asarray([0, 1, 0], F32)
+    cp = p - c
+    d5 = _dot3(ab, cp); d6 = _dot3(ac, cp)
+    if d6 >= 0 and d5 <= d6:
+        return c, np.asarray([0, 0, 1], F32)
+    vc = d1 * d4 - d3 * d2
+    if vc <= 0 and d1 >= 0 and d3 <= 0:
+        v = d1 / (d1 - d3)
+        return (a + v * ab).astype(F32), np.asarray([one - v, v, zero], F32)
+    vb = d5 * d2 - d1 * d6
+    if vb <= 0 and d2 >= 0 and d6 <= 0:
+        v = d2 / (d2 - d6)
+        return (a + v * ac).astype(F32), np.asarray([one - v, zero, v], F32)
+    va = d3 * d6 - d5 * d4
+    if va <= 0 and (d4 - d3) >= 0 and (d5 - d6) >= 0:
+        v = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+        return (b + v * (c - b)).astype(F32), np.asarray([zero, one - v, v], F32)
+    denom = one / ((va + vb) + vc)
+    v = vb * denom; w = vc * denom
+    return ((a + v * ab) + w * ac).astype(F32), np.asarray([(one - v) - w, v, w], F32)
+
+
+def closest_point_on_mesh(verts, faces, q, radius):
+    """rtcPointQuery with closest_point_query_function (instancer.cpp:200-230, 644-654): the triangle whose closest point lies nearest
+    to q, strictly within `radius` (the callback shrinks the radius: d < radius); (primID, barycentrics) or (None, None).  Embree
+    calls back in the order of its BVH walk; here the triangles come in ascending order, so that of several at one distance the
+    lowest primID stays."""
+    best, best_f, best_w = F32(radius), None, None
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for k in range(faces.shape[0]):
+            f = faces[k]
+            pt, uvw = closest_point_triangle(q, verts[f[0]], verts[f[1]], verts[f[2]])
+            e = q - pt
+            d = np.sqrt(e[0] * e[0] + (e[1] * e[1] + e[2] * e[2]))                     # (q - p).norm()
+            if d < best:
+                best, best_f, best_w = d, k, uvw
+    return best_f, best_w
+
+
+def interpolate2d(x, y_ref):
+    """interpolate2d (instancer.cpp:605-625) of one channel matrix at x in [0,1]^2: bilinear between the four texels around
+    x * (rows - 1, cols - 1); indices by truncation (cast<int>), weights x - floor(x).  Indices outside the matrix are clamped (the
+    reference reads past it there; for u or v = 1 the weight of that texel is 0)."""
+    rows, cols = y_ref.shape
+    x0 = F32(x[0]) * (F32(rows) - F32(1.0)); x1 = F32(x[1]) * (F32(cols) - F32(1.0))
+    i = int(np.trunc(x0)); j = int(np.trunc(x1))
+    w0 = x0 - np.floor(x0); w1 = x1 - np.floor(x1)
+    cl = lambda v, n: min(max(v, 0), n - 1)
+    y00 = y_ref[cl(i, rows), cl(j, cols)]; y01 = y_ref[cl(i, rows), cl(j + 1, cols)]
+    y10 = y_ref[cl(i + 1, rows), cl(j, cols)]; y11 = y_ref[cl(i + 1, rows), cl(j + 1, cols)]
+    one = F32(1.0)
+    return F32(((y00 * (one - w0) * (one - w1) + y01 * (one - w0) * w1) + y10 * w0 * (one - w1)) + y11 * w0 * w1)
+
+
+def _bary_mix(rows, f, uvw):
+    """A.row(f0) * uvw(0) + A.row(f1) * uvw(1) + A.row(f2) * uvw(2), elementwise, left to right (:661, 722, 730)."""
+    return ((rows[f[0]] * uvw[0] + rows[f[1]] * uvw[1]) + rows[f[2]] * uvw[2]).astype(F32)
+
+
+def get_parameters(spec: InstancerSpec, pt, parameters):
+    """getParameters (instancer.cpp:640-667): the parameter row at world point pt -- every texture FILE i multiplies parameter
+    texture_parameter_idxs[i] by the interpolated value of channel matrix textures[i] (sic) at the texture coordinates of the closest
+    point of the instancer mesh within patch_max_extent; nothing within reach: the row as given."""
+    out = np.asarray(parameters, F32).copy()
+    f, uvw = closest_point_on_mesh(spec.inst_v, spec.inst_f, np.asarray(pt, F32), spec.patch_max_extent)
+    if f is not None:
+        uv = _bary_mix(spec.inst_uv, spec.inst_f[f], uvw)
+        for i, idx in enumerate(spec.tex_idx):
+            out[idx] = out[idx] * interpolate2d(uv, spec.textures[i])
+    return out
+
+
 def shade_mesh(spec: InstancerSpec, o, d, hit, light):
-    """shadeMesh (instancer.cpp:716-743) for a hit (t, triangle, u, v) on an auxiliary mesh without a texture: albedo 0.8, the
-    interpolated vertex normal, diffuse = max(n . l, 0) unless the point just above the surface is shadowed, 0.2 ambient."""
+    """shadeMesh (instancer.cpp:716-743) for a hit (t, triangle, u, v) on an auxiliary mesh: albedo 0.8 or its texture at the hit's
+    texture coordinates (one value for all three channels unless the image has exactly three), the interpolated vertex normal, diffuse = max(n . l, 0) unless the point just above the surface is shadowed, 0.2 ambient."""
     tt, k, u, v = hit
     f = spec.mesh_f[k]
     w0 = (F32(1.0) - u) - v                                                              # Vector3f(1 - u - v, u, v), :1020
@@ -222,14 +388,22 @@ def shade_mesh(spec: InstancerSpec, o, d, hit, light):
     else:
         diffuse = F32(0.0)
     sm = diffuse + F32(0.2)
-    return np.full(3, F32(0.8) * (sm if sm < 1 else F32(1.0)), F32)
+    shade = sm if sm < 1 else F32(1.0)
+    albedo = np.full(3, F32(0.8), F32)                                                   # :728
+    if spec.mesh_tex is not None and spec.mesh_tex[k] >= 0:                              # :730-732
+        tex = spec.aux_textures[int(spec.mesh_tex[k])]
+        uv = _bary_mix(spec.mesh_uv, f, np.asarray([w0, u, v], F32))
+        val = [interpolate2d(uv, m) for m in tex]
+        albedo = np.asarray(val, F32) if len(val) == 3 else np.full(3, val[0], F32)
+    return (albedo * shade).astype(F32)
 
 
 def is_shadowed(spec: InstancerSpec, pt, direction) -> bool:
     """isShadowed (instancer.cpp:591-602): an occlusion query from `pt` along `direction` (as given, not normalised; 0 < t <= 100)
     whose filter (:543-554) accepts a hit on the TOP face of a patch box from outside (primID 4 = the z = b_1 quad of createAABB,
-    :113; dot(dir, Ng) < 0), any hit on the BOTTOM face (primID 1 = the z = b_0 quad, :110), or a hit on a mesh from its front
-    (Ng = cross(v1 - v0, v2 - v0)); side faces are ignored.  Ray and normal are taken in patch coordinates, where Embree's
+    :113; dot(dir, Ng) < 0), any hit on the BOTTOM face (primID 1 = the z = b_0 quad, :110), a hit on a mesh from its front
+    (Ng = cross(v1 - v0, v2 - v0)) or on the triangle with primID 1 of any mesh from either side (the filter's last clause does not look
+    at the geometry); side faces are ignored.  Ray and normal are taken in patch coordinates, where Embree's
     instance traversal calls the filter: from outside through the top = the patch-space direction points down."""
     pt = np.asarray(pt, F32); direction = np.asarray(direction, F32)
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -249,7 +423,7 @@ def is_shadowed(spec: InstancerSpec, pt, direction) -> bool:
             cross = lambda a, b: np.asarray([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], F32)
             dot = lambda a, b: (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
             o, d = pt, direction
-            for f in spec.mesh_f:
+            for fi, f in enumerate(spec.mesh_f):
                 v0, v1, v2 = spec.mesh_v[f[0]], spec.mesh_v[f[1]], spec.mesh_v[f[2]]
                 e1 = v1 - v0; e2 = v2 - v0
                 p = cross(d, e2); det = dot(e1, p)
@@ -265,7 +439,8 @@ def is_shadowed(spec: InstancerSpec, pt, direction) -> bool:
                 if v < 0 or u + v > 1:
                     continue
                 tt = dot(e2, q) * inv_det
-                if T_NEAR < tt <= T_FAR and dot(d, cross(e1, e2)) < 0:
+                # the filter's `primID == 1` holds for ANY geometry (:553): the second triangle of every mesh occludes from both sides
+                if T_NEAR < tt <= T_FAR and (dot(d, cross(e1, e2)) < 0 or spec.mesh_prim[fi] == 1):
                     return True
     return False
 
@@ -357,6 +532,14 @@ def get_model_input(spec: InstancerSpec, rays_o, rays_d, parameters, n_samples: 
                 n_shadow = max(spec.min_shadow_samples, int(np.uint32(F32(spec.n_shadow_samples) * total)))
                 interpolate = n_shadow < S
             seg_l = 0; k_shadow = 0; t_0_sh = t_1_sh = step_sh = F32(0.0); s_0 = s_1 = False
+            # texture samples of the ray (:863) and their interpolation state (:867-870)
+            tex_on = spec.inst_v is not None and bool(spec.tex_idx)                      # :911
+            tex_interp = False
+            if tex_on:
+                n_tex = max(spec.min_texture_samples, int(np.uint32(F32(spec.n_texture_samples) * total)))
+                tex_interp = n_tex < S
+            default_parameters = parameters[i].copy()                                    # :870
+            k_tex = 0; t_0_tx = t_1_tx = step_tx = F32(0.0); p_0 = p_1 = None
             segment_offset = F32(0.0); cleared = F32(0.0); t_entry = F32(0.0)
             step = 0
             for tt, k, is_mesh in hits:
@@ -398,6 +581,17 @@ def get_model_input(spec: InstancerSpec, rays_o, rays_d, parameters, n_samples: 
                         inst = ids[pick]
                         density_weight[i, step] = tot / ws[pick]                        # 1 / probability
                     instance_id[i, step] = inst
+                    if tex_on and tex_interp:                                           # :911-923: between the two texture samples around t_pt
+                        while t_pt > t_1_tx:
+                            t_0_tx = t_1_tx
+                            k_tex += 1
+                            t_1_tx = t_entry + F32(k_tex) * step_tx
+                            p_0 = p_1
+                            p_1 = get_parameters(spec, (o + t_1_tx * d).astype(F32), default_parameters)
+                        w = (t_pt - t_0_tx) / step_tx
+                        params_map[i, step] = p_0 * (F32(1.0) - w) + p_1 * w
+                    elif tex_on:                                                        # :924-927: a query per step
+                        params_map[i, step] = get_parameters(spec, pt, default_parameters)
                     if spec.light_dir_idx >= 0:                                         # :945-967
                         shadowed = False
                         if spec.cast_shadow_rays and interpolate:                       # :946-958
@@ -434,6 +628,14 @@ def get_model_input(spec: InstancerSpec, rays_o, rays_d, parameters, n_samples: 
                     if not active:
                         segment_offset = tt - cleared                                   # :1001
                         t_entry = tt
+                        if tex_on and tex_interp:                                       # :989-998
+                            seg_len = segment_lengths[seg_l]
+                            n_seg = max(spec.min_texture_samples, int(np.uint32(F32(n_tex) * seg_len / total)))
+                            step_tx = seg_len / F32(n_seg - 1)
+                            k_tex = 1
+                            t_0_tx = t_entry; t_1_tx = t_entry + step_tx
+                            p_0 = get_parameters(spec, (o + t_0_tx * d).astype(F32), default_parameters)
+                            p_1 = get_parameters(spec, (o + t_1_tx * d).astype(F32), default_parameters)
                         if spec.cast_shadow_rays and spec.light_dir_idx >= 0 and interpolate:      # :1018-1027
                             seg_len = segment_lengths[seg_l]
                             n_seg = max(spec.min_shadow_samples, int(np.uint32(F32(n_shadow) * seg_len / total)))

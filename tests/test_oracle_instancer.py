@@ -259,5 +259,125 @@ def test_prepare_instances_matches_add_instance():
     assert np.allclose(org[0], m[:3, 3])
     cols = m[:3, :3].T
     assert np.allclose(dir_t[0], cols / np.linalg.norm(cols, axis=1, keepdims=True), atol=1e-6)   # :131
-    with pytest.raises(ValueError):
-        io.parse_textures(["meshes/smooth_checkerboard.png"])
+    with pytest.raises(OSError):                                                         # an image that is not there (the reference's are LFS pointers)
+        io.parse_textures(["meshes/no_such_texture.png"])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# image textures (instancer.cpp:34-50, 605-667, 725-733, 910-927, 989-998): known answers worked out by hand
+# ------------------------------------------------------------------------------------------------------------------------------
+
+def test_texture_layout_known_answer():
+    # stb's pixels [height 2, width 3], one channel, rows top-down:   10 20 30 / 40 50 60
+    tex = io.texture_from_pixels(np.asarray([[10, 20, 30], [40, 50, 60]], np.uint8))
+    assert len(tex) == 1 and tex[0].shape == (3, 2)                                      # (width, height): rows = x, columns = y
+    # column-major Map(width, height): (x, y) = pixel row y, column x; rowwise().reverse() turns y over: column 0 = the BOTTOM image row
+    assert np.array_equal(tex[0], (F([[40, 10], [50, 20], [60, 30]]) / F(255)))
+    rgb = io.texture_from_pixels(np.arange(24, dtype=np.uint8).reshape(2, 4, 3))
+    assert len(rgb) == 3 and rgb[1][0, 1] == F(1) / F(255) and rgb[2][3, 0] == F(23) / F(255)
+
+
+def test_interpolate2d_known_answers():
+    y = F([[0, 1], [2, 3], [4, 5]])                                                      # rows 3 (x), cols 2 (y)
+    assert io.interpolate2d(F([0, 0]), y) == 0 and io.interpolate2d(F([1, 1]), y) == 5   # (1,1): idx + 1 would leave the matrix; its weight is 0
+    assert io.interpolate2d(F([0.5, 0]), y) == 2                                         # x * (rows - 1) = 1: exactly on row 1
+    assert io.interpolate2d(F([0.25, 0.5]), y) == F(1.5)                                 # between rows 0 / 1 (w 0.5) and columns 0 / 1 (w 0.5): (0 + 1 + 2 + 3) / 4
+    assert io.interpolate2d(F([0.75, 1.0]), y) == F(4.0)                                 # rows 1 / 2 at w 0.5, column 1 (w 0): (3 + 5) / 2
+    # the weights are x - floor(x), the indices truncate: below zero they part ways (-0.25 -> index 0, weight 0.75)
+    assert io.interpolate2d(F([-0.125, 0]), y) == F(0.75) * 2
+
+
+def test_closest_point_triangle_regions():
+    a, b, c = F([0, 0, 0]), F([2, 0, 0]), F([0, 2, 0])
+    cp = lambda p: io.closest_point_triangle(F(p), a, b, c)
+    for p, q, w in [([-1, -1, 3], a, [1, 0, 0]), ([3, -1, 0], b, [0, 1, 0]), ([-1, 4, 1], c, [0, 0, 1]),          # the three corners
+                    ([1, -2, 0], [1, 0, 0], [.5, .5, 0]), ([-3, .5, 0], [0, .5, 0], [.75, 0, .25]),              # edges ab, ac
+                    ([2, 2, 5], [1, 1, 0], [0, .5, .5]), ([.5, .5, -7], [.5, .5, 0], [.5, .25, .25])]:           # edge bc, inside
+        got_q, got_w = cp(p)
+        assert np.allclose(got_q, q, atol=1e-7) and np.allclose(got_w, w, atol=1e-7), (p, got_q, got_w)
+    v = F([[0, 0, 0], [2, 0, 0], [0, 2, 0], [2, 2, 0]]); f = np.asarray([[0, 1, 2], [1, 3, 2]])
+    assert io.closest_point_on_mesh(v, f, F([1.5, 1.5, 1]), F(2))[0] == 1
+    assert io.closest_point_on_mesh(v, f, F([1.5, 1.5, 1]), F(1))[0] is None            # d < radius is strict (:222)
+    k, w = io.closest_point_on_mesh(v, f, F([1, 1, .5]), F(2))                           # on the shared edge: both at 0.5, the lower primID stays
+    assert k == 0 and np.allclose(w, [0, .5, .5])
+
+
+def textured_sheet_spec(textures, images, **kw):
+    """Patches 0 and 1 side by side on the sheet z = 0 (|x|, |y| <= 2, texture coordinates (x + 2) / 4, (y + 2) / 4)."""
+    v = F([[-2, -2, 0], [2, -2, 0], [2, 2, 0], [-2, 2, 0]]); f = [[0, 1, 2], [0, 2, 3]]
+    uv = (v[:, :2] + 2) / 4
+    return io.make_spec([-1, -1, 0], [1, 1, 1], [translate(x=-1), translate(x=1)], textures=textures, images=images,
+                        instancer_mesh=(v, f, uv), mesh=(v, f), patch_scale=1.0, **kw)
+
+
+def test_parameter_textures_known_answers():
+    ramp = np.tile(F(np.linspace(0, 1, 5))[:, None], (1, 3))                             # 5 x 3 texels: value = u, constant in v
+    const = np.full((2, 2), F(0.5))
+    spec = textured_sheet_spec(["ramp", "", "light"], {"ramp": [ramp]})
+    assert (spec.n_parameters, spec.light_dir_idx, spec.tex_idx) == (5, 2, [0]) and np.isclose(spec.patch_max_extent, np.sqrt(3))
+    par = F([2.0, 7.0, 0, 0, 1])
+    # straight above (x, y): u = (x + 2) / 4 -> parameter 0 = 2 u, the others as given
+    for x in (-1.5, 0.0, 0.7):
+        assert np.allclose(io.get_parameters(spec, F([x, 0.3, 0.8]), par), [2 * (x + 2) / 4, 7, 0, 0, 1], rtol=1e-6, atol=0)
+    assert np.array_equal(io.get_parameters(spec, F([0, 0, 1.8]), par), par)             # further than patch_max_extent = sqrt(3): untouched (:657)
+    assert np.allclose(io.get_parameters(spec, F([3, 0, 0.5]), par), [2.0, 7, 0, 0, 1], rtol=1e-6, atol=0)   # beside the sheet: its rim, u = 1
+    # the reference's indexing (:656-662): file i multiplies its FIRST parameter by channel matrix i of the whole list
+    rgb = [np.full((2, 2), F(c)) for c in (0.5, 0.25, 0.125)]
+    spec = textured_sheet_spec(["rgb", "c"], {"rgb": rgb, "c": [const]})
+    assert (spec.n_parameters, spec.tex_idx, len(spec.textures)) == (4, [0, 3], 4)
+    assert np.array_equal(io.get_parameters(spec, F([0, 0, .5]), F([1, 1, 1, 1])), F([0.5, 1, 1, 0.25]))   # red on 0; GREEN of file 0 on 3; 1, 2 untouched
+
+
+def test_texture_samples_along_the_ray():
+    ramp = np.tile(F(np.linspace(0, 1, 5))[:, None], (1, 3))
+    # a ray from x = -3 to the right, 0.5 above the sheet: inside the two patches for t in [1, 5] (one segment)
+    o, d = F([[-3, 0, .5]]), F([[1, 0, 0]])
+    par = F([[2.0, 7.0, 0, 0, 1]])
+    per_step = textured_sheet_spec(["ramp", "", "light"], {"ramp": [ramp]}, n_texture_samples=100000)
+    rd, pts, t, dists, color, dens, w, iid, hit, pm = io.get_model_input(per_step, o, d, par, 16, 0.5, F([0.5]), np.zeros((1, 16), F))
+    assert np.array_equal(t[0, :8], F([1.25 + .5 * s for s in range(8)])) and not t[0, 8:].any()
+    x = -3 + t[0, :8]
+    assert np.allclose(pm[0, :8, 0], 2 * (x + 2) / 4, rtol=1e-6, atol=0) and (pm[0, :8, 1] == 7).all()     # a query per step (:926)
+    assert np.array_equal(pm[0, 8:], np.tile(par, (8, 1)))                               # behind the last step: the row as given
+    # 2 * 4 = 8 samples < 16: interpolated (:911-923).  The crossings at t = 3 sort (3, patch 0) before (3, patch 1): patch 0 is left before
+    # patch 1 is entered, so the ray has TWO segments [1, 3] and [3, 5], each with max(4, 8 * 2 / 4) = 4 samples 2 / 3 apart; the ramp is
+    # linear, so the blend gives 2 u again (rounded)
+    interp = textured_sheet_spec(["ramp", "", "light"], {"ramp": [ramp]}, n_texture_samples=2, min_texture_samples=4)
+    out = io.get_model_input(interp, o, d, par, 16, 0.5, F([0.5]), np.zeros((1, 16), F))
+    assert np.allclose(out[9][0, :8, 0], 2 * (x + 2) / 4, atol=2e-6) and np.array_equal(out[2], t)
+    sl = F(2) / F(3)
+    for s in range(8):                                                                   # ... and exactly s0 * (1 - w) + s1 * w in EVERY column
+        te = F(1) if s < 4 else F(3)
+        k = int((t[0, s] - te) / sl)
+        t0, t1 = te + F(k) * sl if k else te, te + F(k + 1) * sl
+        s0 = io.get_parameters(interp, (o[0] + t0 * d[0]).astype(F), par[0]); s1 = io.get_parameters(interp, (o[0] + t1 * d[0]).astype(F), par[0])
+        wgt = (t[0, s] - t0) / sl
+        want = s0 * (F(1) - wgt) + s1 * wgt
+        want[2:5] = [0, 0, 1]                                                            # the light direction is written afterwards (:943-949)
+        assert np.array_equal(out[9][0, s], want), (s, out[9][0, s], want)
+    # explicit transformations without DistributeInstancesOnMesh: the textures are loaded, counted and never applied (:911)
+    plain = io.make_spec([-1, -1, 0], [1, 1, 1], [translate(x=-1), translate(x=1)], textures=["ramp", "", "light"], images={"ramp": [ramp]})
+    assert plain.n_parameters == 5
+    out = io.get_model_input(plain, o, d, par, 16, 0.5, F([0.5]), np.zeros((1, 16), F))
+    assert (out[9][0, :, 0] == 2).all()
+
+
+def test_auxiliary_albedo_and_the_second_triangle():
+    quad_v = F([[-2, -2, .5], [2, -2, .5], [2, 2, .5], [-2, 2, .5]]); faces = [[0, 1, 2], [0, 2, 3]]
+    up = [[0, 0, 1]] * 4
+    uv = (quad_v[:, :2] + 2) / 4
+    ramp = np.tile(F(np.linspace(0, 1, 5))[:, None], (1, 3))
+    o, d, light = F([[1.0, 0.2, 5]]), F([[0, 0, -1]]), F([[0, 3, 4]])                    # n . l = 0.8 -> shade min(0.8 + 0.2, 1) = 1
+    for tex, want in [([ramp], [.75] * 3), ([ramp, ramp * F(.5), ramp * F(.25)], [.75, .375, .1875]), ([ramp, ramp * F(.5)], [.75] * 3)]:
+        spec = io.make_spec(transformations=[translate(z=-30)], textures=["light"], mesh=(quad_v, faces, up, [1, 1]), mesh_uv=uv,
+                            mesh_tex=[0, 0], aux_textures=[tex], **UNIT)
+        *_, color, dens, w, iid, hit, pm = io.get_model_input(spec, o, d, light, 4, 0.5, F([0.5]), np.zeros((1, 4), F))
+        assert dens[0, 0] == 1 and np.allclose(color[0, 0], want, atol=1e-6), (color, want)    # u = 0.75; three channels or the first for all (:732)
+    # the shadow filter's `primID == 1` (:553) does not ask which geometry: the second triangle of a mesh shadows from behind too
+    spec = io.make_spec(transformations=[translate(z=-50)], mesh=(quad_v, faces), **UNIT)
+    below_first, below_second = F([1, -1, 0]), F([-1, 1, 0])                             # under triangle 0 / under triangle 1, looking up at their backs
+    assert not io.is_shadowed(spec, below_first, F([0, 0, 1])) and io.is_shadowed(spec, below_second, F([0, 0, 1]))
+    assert io.is_shadowed(spec, F([1, -1, 3]), F([0, 0, -1])) and io.is_shadowed(spec, F([-1, 1, 3]), F([0, 0, -1]))
+    two = io.make_spec(transformations=[translate(z=-50)], mesh=(np.concatenate([quad_v, quad_v + F([0, 0, 1])]), faces + [[4, 5, 6], [4, 6, 7]]),
+                       mesh_prim=[0, 1, 0, 1], **UNIT)                                    # two meshes in one list: primIDs start over
+    assert io.is_shadowed(two, F([-1, 1, 1]), F([0, 0, 1])) and not io.is_shadowed(two, F([1, -1, 1]), F([0, 0, 1]))

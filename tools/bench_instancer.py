@@ -52,10 +52,15 @@ def main():
     ap.add_argument("--method", default="nearest")
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--no-mesh", action="store_true")
+    ap.add_argument("--scale-with-grid", action="store_true", help="patch_scale and step_size * 48 / grid: the same sheet covered by smaller "
+                    "patches, the same number of patches and steps along a ray whatever the grid (a scene of 10^5 patches at --grid 316)")
     ap.add_argument("--shadows", type=int, default=0, metavar="N", help="cast_shadow_rays with n_shadow_samples = N, min 8 (config_grass_render.py:92-98: 128)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    tr, v, f = sheet(a.grid)
+    scale = 0.09 * (48.0 / a.grid if a.scale_with_grid else 1.0)
+    if a.scale_with_grid:
+        a.step_size *= 48.0 / a.grid
+    tr, v, f = sheet(a.grid, scale=scale)
     textures = ['', '', '', '', 'light']                                         # config_carpet_render.py:86 without the image texture
     inst = Instancer(B0, B1, textures=textures, transformations=tr, instance_sampling_method=a.method,
                      mesh=None if a.no_mesh else (v, f), cast_shadow_rays=a.shadows > 0, min_shadow_samples=8, n_shadow_samples=max(a.shadows, 1))
@@ -88,7 +93,7 @@ def main():
     line = {"what": "ntx_instancer_model_input (hits + mesh + march kernels, HIP events around the call incl. the output torch.empty)",
             "scene": f"{a.grid}x{a.grid} = {a.grid ** 2} patches + {0 if a.no_mesh else f.shape[0]} triangles, method {a.method}"
                      + (f", shadow rays ({a.shadows} per unit length, min 8)" if a.shadows else ""),
-            "shadowed_samples": int((out[9][..., 4:7] == torch.tensor([0., 0., -1.], device=dev)).all(-1).logical_and(out[2] > 0).sum().item()),
+            "patch_scale": round(scale, 5), "shadowed_samples": int((out[9][..., 4:7] == torch.tensor([0., 0., -1.], device=dev)).all(-1).logical_and(out[2] > 0).sum().item()),
             "rays": a.rays, "n_pts": S, "step_size": a.step_size, "hit_rays": int(hit.sum().item()), "in_patch_samples": in_patch,
             "emitted_samples": emitted, "status": inst.status(), "ms": round(ms, 4),
             "rays_per_s": round(a.rays / (ms * 1e-3)), "in_patch_samples_per_s": round(in_patch / (ms * 1e-3)),
@@ -101,7 +106,7 @@ def main():
     emb = lambda n: {"module": "network.model.FourierFeatures", "n_freq_bands": n}
     model = ParamNerf(emb(10), emb(4), emb(4), [1, 6])["model"]
     model.set_blob(synthetic.synthetic_weights(model.layer_table(), seed=0, dense_media=True))
-    r = InstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=0.09, step_size=a.step_size, render_chunk=a.rays,
+    r = InstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=scale, step_size=a.step_size, render_chunk=a.rays,
                          density_scale=1.0, check_numerics=False)
     b = lambda x: x[None]
     call = lambda: r(b(ro), b(rd), b(t), parameters=params[:1], cone_scale=b(cone), instancer_seed=1)
