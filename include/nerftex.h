@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NTX_ABI_VERSION 4
+#define NTX_ABI_VERSION 5
 
 typedef struct ntx_ctx ntx_ctx;
 typedef void *ntx_stream; /* hipStream_t */
@@ -347,8 +347,8 @@ int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_hos
  * (instancer.pyx:19-20 -> AddInstance, instancer.cpp:124-141), an instancer mesh given as arrays, GetNumberOfInstances (:426-428),
  * the matrices ExportTransformations writes (:1040-1061) and GetModelInput (:751-1037) with the three patch choices, mean
  * distances, directional and point lights, shadow rays (:591-602, 945-961, 1018-1027), auxiliary meshes with
- * their flat shading (:393-417, 716-743).  NOT built (NTX_E_UNSUPPORTED / no entry point): image textures (on the instancer mesh, :640-667,
- * and as the albedo of an auxiliary mesh).  DistributeInstancesOnMesh (:233-390) is setup on the host: its result is the
+ * their flat shading (:393-417, 716-743); since ABI v5 image textures, as parameters on the instancer mesh (:640-667) and as the
+ * albedo of an auxiliary mesh (:725-733), see below.  DistributeInstancesOnMesh (:233-390) is setup on the host: its result is the
  * transformation list ntx_instancer_create takes (nerf_tex_amd.instancer.distribute_instances_on_mesh restates it; the reference
  * can also export its own with `transformation_export_path`).
  *
@@ -359,8 +359,8 @@ int ntx_pack_weights_fp16x3(const ntx_model_desc *desc, const float *weights_hos
  * nearest_blend's transition range (:697; 1 unless the patches were distributed on a mesh).  cast_shadow_rays (needs a light
  * entry): a sample whose shadow query is occluded gets the light direction (0, 0, -1) (:571-573).  A query (isShadowed, :591-602:
  * from the point along the light parameter AS GIVEN -- for 'point' that is the light's position, :956 -- with 0 < t <= 100) is
- * occluded by the top face of a patch box entered from outside, by its bottom face either way, and by the instancer mesh hit
- * from its front (filter :543-554).  With N = max(min_shadow_samples, n_shadow_samples * total length) < n_pts the queries are
+ * occluded by the top face of a patch box entered from outside, by its bottom face either way, by a mesh hit from its front and
+ * by the triangle with primID 1 of any mesh from either side (filter :543-554: its `primID == 1` clause does not ask which geometry).  With N = max(min_shadow_samples, n_shadow_samples * total length) < n_pts the queries are
  * made at max(min_shadow_samples, N * length / total) points spaced evenly along every segment and a step takes the nearer of
  * the two around it (:946-958, 1018-1027), else every step makes its own (:959-961).  min_shadow_samples >= 2.
  * *status_flag |= 4 when a ray needed more than 4096 shadow samples (the rest read as unshadowed). */
@@ -389,10 +389,11 @@ int ntx_instancer_matrices(const ntx_instancer *inst, float *world_to_patch, flo
 /* The instancer mesh (instancer.cpp:369-389: in the scene for culling): HOST vertices[n_vertices,3], faces[n_faces,3].  A ray
  * ends at its closest crossing of the mesh and is closed by an opaque black sample (:1013-1016).  n_faces = 0 removes it. */
 int ntx_instancer_set_mesh(ntx_instancer *inst, const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces);
-/* The same with auxiliary meshes (AddMesh, instancer.cpp:393-417) in one list: face_kind[f] = 0 for the instancer mesh (black closing
- * sample), 1 for an auxiliary mesh, whose closing sample is shaded (shadeMesh, :716-743): albedo 0.8 * min(diffuse + 0.2, 1), diffuse =
+/* The same with auxiliary meshes (AddMesh, instancer.cpp:393-417) in one list: face_kind[f] bit 0 = 0 for the instancer mesh (black closing
+ * sample), 1 for an auxiliary mesh; bit 1 (value 2) = the face is primID 1 of its own mesh (the shadow filter's clause above; without
+ * face_kind the list is one mesh and face 1 has it).  An auxiliary mesh's closing sample is shaded (shadeMesh, :716-743): albedo 0.8 * min(diffuse + 0.2, 1), diffuse =
  * max(n . l, 0) with the interpolated vertex normal n (normals[n_vertices,3], HOST) and the light parameter l, 0 when the point just
- * above the surface is shadowed (isShadowed).  Needs a light entry in the textures list; mesh textures are not built.  Every mesh
+ * above the surface is shadowed (isShadowed).  Needs a light entry in the textures list; textures: ntx_instancer_set_mesh_textures.  Every mesh
  * culls and casts shadows alike.  normals / face_kind may be NULL (= ntx_instancer_set_mesh). */
 int ntx_instancer_set_meshes(ntx_instancer *inst, const float *vertices, const float *normals, int64_t n_vertices, const int32_t *faces,
                              const uint8_t *face_kind, int64_t n_faces);
@@ -414,6 +415,37 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
                               int n_pts, float step_size, uint64_t seed, const ntx_render_opts *opts, float *rays_d_map, float *pts,
                               float *t, float *dists, float *color_last, float *alpha_last, float *alpha_weight,
                               int32_t *instance_id, uint8_t *hit, float *params_map, int32_t *status_flag, ntx_stream stream);
+
+/* ---- ABI v5: image textures of the instancer --------------------------------------------------------------------------------
+ * ntx_texture = ONE channel matrix as loadTexture builds it (instancer.cpp:34-50): value / 255, element (r, c) at texels[r * cols + c]
+ * with r = the pixel's column x (rows = image width) and c = its row counted from the BOTTOM of the image (cols = image height);
+ * HOST memory, copied.  Lookups are interpolate2d (:605-625): bilinear around x * (rows - 1, cols - 1), indices by truncation,
+ * weights x - floor(x); an index outside the matrix is clamped (the reference reads past it; at u or v = 1 that weight is 0). */
+typedef struct ntx_texture {
+    const float *texels;
+    int32_t rows, cols;
+} ntx_texture;
+/* Parameter textures (getParameters, instancer.cpp:640-667; the constructor's image entries, :84-88, after DistributeInstancesOnMesh
+ * -- without a mesh_path the reference loads and counts them and never applies them, :911: then do not call this).  The instancer
+ * mesh as the reference holds it: HOST vertices[n_vertices,3], uv[n_vertices,2], faces[n_faces,3].  Texture file i multiplies
+ * parameter parameter_idx[i] by textures[i] at the texture coordinates of the closest point of the mesh (closest_point_triangle,
+ * :154-198) strictly within patch_max_extent (:69 scaled by :246) of the sample; no triangle that close: unchanged.  The caller
+ * resolves the reference's indexing: its list holds every CHANNEL of every file and file i uses entry i of that list (:656-662),
+ * so a file of c channels takes c parameters and has one of them multiplied.  With N = max(min_texture_samples,
+ * n_texture_samples * total length) < n_pts a ray looks the textures up at max(min_texture_samples, N * length / total) points
+ * spaced evenly along every segment and a step's WHOLE parameter row is s0 * (1 - w) + s1 * w between the two around it (:910-923,
+ * 989-998; the light entries are written afterwards); else every step makes its own lookup (:926).  At most 4 files;
+ * 2 <= min_texture_samples <= 512.  n_textures = 0 removes them.  Of several triangles at one distance the lowest index wins
+ * (Embree's order is its BVH's). */
+int ntx_instancer_set_parameter_textures(ntx_instancer *inst, const float *vertices, const float *uv, int64_t n_vertices, const int32_t *faces,
+                                         int64_t n_faces, float patch_max_extent, int n_textures, const int32_t *parameter_idx,
+                                         const ntx_texture *textures, int min_texture_samples, int n_texture_samples);
+/* Albedo textures of auxiliary meshes (AddMesh's texture_path, instancer.cpp:404; shadeMesh :725-733), after
+ * ntx_instancer_set_meshes and for the same list: uv[n_vertices,2]; face_texture[n_faces] = the texture set of the face's mesh
+ * or -1 (albedo 0.8); textures[3 * n_sets]: three channel matrices per set (an image that does not have exactly three channels
+ * gives its first for all three, :732).  n_sets = 0 removes them. */
+int ntx_instancer_set_mesh_textures(ntx_instancer *inst, const float *uv, int64_t n_vertices, const int32_t *face_texture, int64_t n_faces,
+                                    int n_sets, const ntx_texture *textures);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("NERFTEX_LIB") or os.path.join(_HERE, "libnerftex_hip.
 
 NTX_OK, NTX_E_INVALID, NTX_E_UNSUPPORTED, NTX_E_HIP, NTX_E_NODEVICE = 0, -1, -2, -3, -4
 FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS, FLAG_FP16X3, FLAG_PERTURB, FLAG_RAW_NOISE = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 4
+ABI_VERSION = 5
 KIND_PARAMNERF_EX = 2           # NTX_MODEL_PARAMNERF_EX: the descriptor's param_depth / param_width count
 SKIP_MASK = 0x40000000          # NTX_SKIP_MASK: ntx_model_desc.skip carries a mask of skip-layer indices
 COMM_ID_BYTES = 128
@@ -50,6 +50,11 @@ class InstancerDesc(C.Structure):
                 ("light_dir_parameter_idx", C.c_int32), ("light_strength_parameter_idx", C.c_int32),
                 ("instance_sample_method", C.c_int32), ("use_mean_distance", C.c_int32), ("cast_shadow_rays", C.c_int32),
                 ("patch_scale", C.c_float), ("min_shadow_samples", C.c_int32), ("n_shadow_samples", C.c_int32)]
+
+
+class Texture(C.Structure):
+    """struct ntx_texture (ABI v5): one channel matrix as loadTexture builds it (instancer.cpp:34-50), texels[r * cols + c]"""
+    _fields_ = [("texels", C.POINTER(C.c_float)), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
 class NtxError(RuntimeError):
@@ -113,6 +118,9 @@ SYMBOLS = {
     "ntx_instancer_matrices": (C.c_int, [_vp, _fp, _fp, _fp]),
     "ntx_instancer_set_mesh": (C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_int32), C.c_int64]),
     "ntx_instancer_set_meshes": (C.c_int, [_vp, _fp, _fp, C.c_int64, C.POINTER(C.c_int32), _u8p, C.c_int64]),
+    "ntx_instancer_set_parameter_textures": (C.c_int, [_vp, _fp, _fp, C.c_int64, C.POINTER(C.c_int32), C.c_int64, C.c_float, C.c_int,
+                                                       C.POINTER(C.c_int32), C.POINTER(Texture), C.c_int, C.c_int]),
+    "ntx_instancer_set_mesh_textures": (C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_int32), C.c_int64, C.c_int, C.POINTER(Texture)]),
     "ntx_instancer_model_input": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_uint64, _op] + [_vp] * 12),
 }
 

@@ -40,6 +40,13 @@ extern "C" int ntx_set_error(int code, const char *fmt, ...);   // nerftex.hip
         if (e_ != hipSuccess) return ntx_set_error(NTX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// development knob (-DNTX_INST_DEBUG and NERFTEX_INST_DEBUG=bits): parts of the march kernel left out to time the rest; compiled out otherwise
+#ifdef NTX_INST_DEBUG
+#define NTX_DBG_SKIP(a, bit) ((a).debug_skip & (bit))
+#else
+#define NTX_DBG_SKIP(a, bit) false
+#endif
+
 namespace ntx_inst {
 
 constexpr int MAX_HITS = 200;            // MAX_TOTAL_HITS, instancer.cpp:22
@@ -230,6 +237,140 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// image textures (instancer.cpp:34-50, 605-667)
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int MAX_TEX_FILES = 4;         // texture FILES in the constructor's list (each multiplies one parameter, :656-662)
+struct TexTable { int32_t offset, rows, cols, pad; };      // one channel matrix: texels[offset + r * cols + c], r = x, c = y from the bottom
+struct TexArgs {
+    int n_tex;                              // 0 = no parameter textures
+    int32_t par_idx[MAX_TEX_FILES];         // texture_parameter_idxs
+    int min_samples, n_samples;             // min_texture_samples, n_texture_samples
+    float radius;                           // patch_max_extent (:69, :246)
+    const float *texels; const TexTable *table;             // the first n_tex tables are the parameter textures
+    // the instancer mesh in a uniform grid, triangles binned by centroid: cell -> [start, end) into tris[.][10] = {v0, v1, v2, primID}
+    const int32_t *cell_start; const float *tris; const float *face_uv;   // face_uv[primID][6]: texture coordinates of its corners
+    float gmin[3], cell, inv_cell, r_max;   // r_max: no corner lies further from its triangle's centroid
+    int32_t dim[3]; int32_t n_faces;
+};
+
+// interpolate2d (instancer.cpp:605-625): bilinear between the four texels around x * (rows - 1, cols - 1); indices truncate, weights are
+// x - floor(x); indices outside the matrix are clamped (the reference reads past it; at u or v = 1 that texel's weight is 0)
+__device__ __forceinline__ float interpolate2d(const float *__restrict__ texels, const TexTable tb, float u, float v) {
+    const float x0 = u * ((float)tb.rows - 1.0f), x1 = v * ((float)tb.cols - 1.0f);
+    const int i = (int)x0, j = (int)x1;
+    const float w0 = x0 - floorf(x0), w1 = x1 - floorf(x1);
+    const int i0 = min(max(i, 0), tb.rows - 1), i1 = min(max(i + 1, 0), tb.rows - 1);
+    const int j0 = min(max(j, 0), tb.cols - 1), j1 = min(max(j + 1, 0), tb.cols - 1);
+    const float *y = texels + tb.offset;
+    const float y00 = y[(size_t)i0 * tb.cols + j0], y01 = y[(size_t)i0 * tb.cols + j1], y10 = y[(size_t)i1 * tb.cols + j0], y11 = y[(size_t)i1 * tb.cols + j1];
+    return ((y00 * (1.0f - w0) * (1.0f - w1) + y01 * (1.0f - w0) * w1) + y10 * w0 * (1.0f - w1)) + y11 * w0 * w1;
+}
+
+__device__ __forceinline__ float dot3e(const float *a, const float *b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }   // Eigen pairs x0 + (x1 + x2)
+
+// closest_point_triangle (instancer.cpp:154-198): distance of p to triangle abc, barycentrics of the closest point
+__device__ __forceinline__ float closest_point_triangle(const float *p, const float *a, const float *b, const float *c, float *uvw) {
+    const float ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]};
+    float q[3];
+    const float d1 = dot3e(ab, ap), d2 = dot3e(ac, ap);
+    const float bp[3] = {p[0] - b[0], p[1] - b[1], p[2] - b[2]};
+    const float d3 = dot3e(ab, bp), d4 = dot3e(ac, bp);
+    const float cp[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+    const float d5 = dot3e(ab, cp), d6 = dot3e(ac, cp);
+    const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d1 <= 0.0f && d2 <= 0.0f) { q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; uvw[0] = 1.0f; uvw[1] = 0.0f; uvw[2] = 0.0f; }
+    else if (d3 >= 0.0f && d4 <= d3) { q[0] = b[0]; q[1] = b[1]; q[2] = b[2]; uvw[0] = 0.0f; uvw[1] = 1.0f; uvw[2] = 0.0f; }
+    else if (d6 >= 0.0f && d5 <= d6) { q[0] = c[0]; q[1] = c[1]; q[2] = c[2]; uvw[0] = 0.0f; uvw[1] = 0.0f; uvw[2] = 1.0f; }
+    else if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+        const float v = d1 / (d1 - d3);
+        q[0] = a[0] + v * ab[0]; q[1] = a[1] + v * ab[1]; q[2] = a[2] + v * ab[2]; uvw[0] = 1.0f - v; uvw[1] = v; uvw[2] = 0.0f;
+    } else if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+        const float v = d2 / (d2 - d6);
+        q[0] = a[0] + v * ac[0]; q[1] = a[1] + v * ac[1]; q[2] = a[2] + v * ac[2]; uvw[0] = 1.0f - v; uvw[1] = 0.0f; uvw[2] = v;
+    } else if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+        const float v = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        q[0] = b[0] + v * (c[0] - b[0]); q[1] = b[1] + v * (c[1] - b[1]); q[2] = b[2] + v * (c[2] - b[2]); uvw[0] = 0.0f; uvw[1] = 1.0f - v; uvw[2] = v;
+    } else {
+        const float denom = 1.0f / ((va + vb) + vc);
+        const float v = vb * denom, w = vc * denom;
+        q[0] = (a[0] + v * ab[0]) + w * ac[0]; q[1] = (a[1] + v * ab[1]) + w * ac[1]; q[2] = (a[2] + v * ab[2]) + w * ac[2];
+        uvw[0] = (1.0f - v) - w; uvw[1] = v; uvw[2] = w;
+    }
+    const float e[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+    return __builtin_sqrtf(e[0] * e[0] + (e[1] * e[1] + e[2] * e[2]));                      // (q - p).norm()
+}
+
+// getParameters' point query (instancer.cpp:644-654): the triangle of the instancer mesh whose closest point lies nearest to p, strictly
+// within the radius; of several at one distance the lowest primID (the restatement's order).  The reference walks Embree's BVH; here
+// the triangles sit in a uniform grid by centroid and the cells around p are visited ring by ring (rows of cells = one range of the
+// cell list): behind ring k every unvisited triangle is at least k * cell - r_max away, so the walk ends as soon as the best distance
+// is below that.  Exhaustive up to there: the result is that of testing every triangle.  Lane = one query; no wave collectives inside.
+__device__ __forceinline__ bool closest_uv(const TexArgs &T, float px, float py, float pz, float *u_out, float *v_out) {
+    const float p[3] = {px, py, pz};
+    float best = T.radius;
+    int best_f = -1;
+    float bw[3] = {0.0f, 0.0f, 0.0f};
+    const float fx = (px - T.gmin[0]) * T.inv_cell, fy = (py - T.gmin[1]) * T.inv_cell, fz = (pz - T.gmin[2]) * T.inv_cell;
+    // further from the grid than anything could reach: nothing (also keeps the casts below in range)
+    const float reach = (T.radius + T.r_max) * T.inv_cell + 2.0f;
+    const bool far = !(fx >= -reach && fy >= -reach && fz >= -reach && fx <= (float)T.dim[0] + reach && fy <= (float)T.dim[1] + reach && fz <= (float)T.dim[2] + reach);
+    if (!far) {
+        const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+        const int kmax = (int)reach + 1;
+        for (int k = 0; k <= kmax; ++k) {
+            for (int dz = -k; dz <= k; ++dz) {
+                const int z = cz + dz;
+                if (z < 0 || z >= T.dim[2]) continue;
+                for (int dy = -k; dy <= k; ++dy) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= T.dim[1]) continue;
+                    const bool full = dz == -k || dz == k || dy == -k || dy == k;            // a face of the ring's shell: the whole row; else its two ends
+                    const int n_part = full || k == 0 ? 1 : 2;
+                    for (int part = 0; part < n_part; ++part) {
+                        int xa = full ? cx - k : (part == 0 ? cx - k : cx + k), xb = full ? cx + k : xa;
+                        xa = xa < 0 ? 0 : xa; xb = xb >= T.dim[0] ? T.dim[0] - 1 : xb;
+                        if (xa > xb) continue;
+                        const size_t row = ((size_t)z * T.dim[1] + y) * T.dim[0];
+                        const int s0 = T.cell_start[row + xa], s1 = T.cell_start[row + xb + 1];
+                        for (int e = s0; e < s1; ++e) {
+                            const float *tr = T.tris + (size_t)e * 10;
+                            const float a[3] = {tr[0], tr[1], tr[2]}, b[3] = {tr[3], tr[4], tr[5]}, c[3] = {tr[6], tr[7], tr[8]};
+                            const int f = __builtin_bit_cast(int, tr[9]);
+                            float w[3];
+                            const float d = closest_point_triangle(p, a, b, c, w);
+                            if (d < best || (d == best && best_f >= 0 && f < best_f)) { best = d; best_f = f; bw[0] = w[0]; bw[1] = w[1]; bw[2] = w[2]; }
+                        }
+                    }
+                }
+            }
+            // every triangle not yet seen has its centroid at least k cells away along some axis
+            // (less what rounding can move p or a centroid across a cell wall)
+            const float bound = ((float)k * T.cell - T.r_max) * 0.999f - 1e-5f * ((fabsf(px) + fabsf(py)) + (fabsf(pz) + 1.0f));
+            if (best < bound || bound >= T.radius) break;
+        }
+    }
+    if (best_f < 0) return false;
+    const float *uv = T.face_uv + (size_t)best_f * 6;                                          // UV.row(f0) * w0 + UV.row(f1) * w1 + UV.row(f2) * w2 (:661)
+    *u_out = (uv[0] * bw[0] + uv[2] * bw[1]) + uv[4] * bw[2];
+    *v_out = (uv[1] * bw[0] + uv[3] * bw[1]) + uv[5] * bw[2];
+    return true;
+}
+
+// getParameters (instancer.cpp:640-667) for the texture parameters only: val[q] = parameter par_idx[q] * texture q at the closest point
+// of the mesh, or the parameter as given when nothing lies within reach
+__device__ __forceinline__ void texture_values(const TexArgs &T, const float *par, float px, float py, float pz, float *val) {
+    float u = 0.0f, v = 0.0f;
+    const bool found = closest_uv(T, px, py, pz, &u, &v);
+#pragma unroll
+    for (int q = 0; q < MAX_TEX_FILES; ++q) {
+        if (q < T.n_tex) {
+            const float p0 = par[T.par_idx[q]];
+            val[q] = found ? p0 * interpolate2d(T.texels, T.table[q], u, v) : p0;
+        } else val[q] = 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // marching (instancer.cpp:787-1030), wave per ray
 // ---------------------------------------------------------------------------------------------------------------------------
 struct MarchArgs {
@@ -245,7 +386,9 @@ struct MarchArgs {
     int64_t idx0, idx_stride; uint32_t idx_run;
     const float *spheres, *tris; int n_inst, n_tri; Box box;      // shadow rays: the scene again
     int min_shadow, n_shadow;
-    int debug_skip;   // development (NERFTEX_INST_DEBUG): leave parts of the kernel out to time the rest; results are then wrong
+    const uint8_t *kind;                       // per triangle: bit 0 = auxiliary mesh (shaded), bit 1 = primID 1 of its own mesh (shadow filter, :553)
+    TexArgs tex;                               // parameter textures on the instancer mesh (getParameters, :640-667); n_tex = 0: none
+    int debug_skip;   // development build only (-DNTX_INST_DEBUG + NERFTEX_INST_DEBUG): leave parts of the kernel out to time the rest
 };
 
 // The reference walks the sorted crossings with a std::set of the patches it is inside (instancer.cpp:800-826, 870-1010): a crossing
@@ -283,14 +426,28 @@ __device__ __forceinline__ float mean_distance(float mu_f, float hw_f) {   // in
 
 // ---- shadow rays (instancer.cpp:591-602, filter :543-554) ---------------------------------------------------------------------
 constexpr int MAX_SHADOW_ENTRIES = 4096;
-struct ShadowLds {
-    uint32_t bits[MAX_SHADOW_ENTRIES / 32];   // the shadow samples of the ray's segments, one bit each
-    float ts[MAX_HITS / 2 + 2], len[MAX_HITS / 2 + 2];   // start and length of a segment, then (len -> ) the spacing of its shadow samples
-    uint16_t base[MAX_HITS / 2 + 4];          // first entry of segment i in `bits`; [n_segments] = number of entries
+struct SegLds {                               // the segments of the ray (shadow and texture samples are spaced along them)
+    float ts[MAX_HITS / 2 + 2], len[MAX_HITS / 2 + 2];   // start and length of a segment (segment_lengths, :802-821)
     uint8_t g_seg[MAX_HITS + 8];              // the segment gap j lies in
 };
-struct NoShadowLds {};
-template <bool SHADOW> struct MarchLds { WaveLds w; typename std::conditional<SHADOW, ShadowLds, NoShadowLds>::type sh; };
+struct ShadowLds {
+    uint32_t bits[MAX_SHADOW_ENTRIES / 32];   // the shadow samples of the ray's segments, one bit each
+    float sl[MAX_HITS / 2 + 2];               // the spacing of a segment's shadow samples
+    uint16_t base[MAX_HITS / 2 + 4];          // first entry of segment i in `bits`; [n_segments] = number of entries
+};
+constexpr int TEX_RING = 128;                 // texture samples of the ray held at a time (two chunks of 64, produced in order)
+struct TexLds {
+    float ring[MAX_TEX_FILES][TEX_RING];      // value of texture parameter q at sample x: ring[q][x % TEX_RING]
+    float sl[MAX_HITS / 2 + 2];               // the spacing of a segment's texture samples
+    uint16_t base[MAX_HITS / 2 + 4];          // first sample of segment i; [n_segments] = number of samples
+};
+struct NoLds {};
+template <bool SHADOW, bool TEX> struct MarchLds {
+    WaveLds w;
+    typename std::conditional<SHADOW || TEX, SegLds, NoLds>::type sg;
+    typename std::conditional<SHADOW, ShadowLds, NoLds>::type sh;
+    typename std::conditional<TEX, TexLds, NoLds>::type tx;
+};
 
 // isShadowed for 64 points at once: lane = a point (px,py,pz) on the wave's primary ray, all with direction (lx,ly,lz).  Every
 // shadow ray of the wave lies in the plane through the primary ray along the light direction, so a patch or triangle whose
@@ -380,7 +537,8 @@ __device__ __forceinline__ bool occluded(const MarchArgs &a, int lane, float ox,
             const float tt = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv_det;
             const float ng[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
             const bool front = (lx * ng[0] + ly * ng[1]) + lz * ng[2] < 0.0f;
-            occ = occ || (det != 0.0f && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && tt > 0.0f && tt <= T_FAR && front);
+            // ... or the triangle is primID 1 of its mesh: the filter's last clause does not ask for the geometry (instancer.cpp:553)
+            occ = occ || (det != 0.0f && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && tt > 0.0f && tt <= T_FAR && (front || (a.kind[ff] & 2)));
         }
     }
     return occ;
@@ -412,15 +570,17 @@ __device__ __forceinline__ void fill_pattern(float *row, int f0, int f1, int per
     for (int f = h1 + 4 * nvec + lane; f < f1; f += 64) __builtin_nontemporal_store(at(f % period), row + f);
 }
 
-template <bool SHADOW>
-__device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *lds) {
+template <bool SHADOW, bool TEX>
+__device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, TEX> *lds) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ray = blockIdx.x * 4 + wave;
     if (ray >= a.n_rays) return;
     WaveLds &L = lds[wave].w;
+    auto &SG = lds[wave].sg;      // segment tables (SHADOW or TEX)
     auto &SH = lds[wave].sh;      // shadow tables (SHADOW only)
-    (void)SH;
+    auto &TX = lds[wave].tx;      // texture samples (TEX only)
+    (void)SG; (void)SH; (void)TX;
     const int S = a.n_pts, P = a.n_params;
     const float h = a.step_size;
     const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
@@ -488,7 +648,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
     }
     __builtin_amdgcn_wave_barrier();
 
-    if (a.debug_skip & 4) return;
+    if (NTX_DBG_SKIP(a, 4)) return;
     uint32_t my_enter[4];                          // by position in the sorted list
     uint64_t enter_mask[4];
     int n_int = 0;
@@ -499,7 +659,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
         enter_mask[q] = __ballot(my_enter[q] != 0);
         n_int += __builtin_popcountll(enter_mask[q]);
     }
-    if (a.debug_skip & 8) return;
+    if (NTX_DBG_SKIP(a, 8)) return;
     // intervals: (entering crossing b, leaving crossing e' or m) per record, in ascending patch order (std::set's order) unless the
     // rule is 'nearest', which does not depend on the order it meets the patches in once ties go to the smaller id (below)
     int iv_at[4];
@@ -542,7 +702,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
         }
     }
 
-    if (a.debug_skip & 16) return;
+    if (NTX_DBG_SKIP(a, 16)) return;
     // ---- gaps and segments, lane per gap ------------------------------------------------------------------------------------
     // gap j = the stretch in front of event j (j = m: in front of the mesh hit).  Patches in the set there = 2 * (entering events
     // before j) - j.  A SEGMENT of the union of the boxes (instancer.cpp:800-826) starts at an entering event that finds the set
@@ -580,9 +740,9 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
         for (int i = 0; i < n_starts; ++i) {
             const float ts = L.gs.seg.ts[i];
             L.gs.seg.ts[i] = ts - cleared;                                   // segment_offset of the segment, :1001
-            if constexpr (SHADOW) {                                          // segment_lengths, :809, 818
-                SH.ts[i] = ts;
-                SH.len[i] = i < n_ends ? L.gs.seg.te[i] - ts : (has_mesh ? t_mesh - ts : 0.0f);
+            if constexpr (SHADOW || TEX) {                                   // segment_lengths, :809, 818
+                SG.ts[i] = ts;
+                SG.len[i] = i < n_ends ? L.gs.seg.te[i] - ts : (has_mesh ? t_mesh - ts : 0.0f);
             }
             if (i < n_ends) cleared = cleared + (L.gs.seg.te[i] - ts);      // :996 = :817
             else if (has_mesh) { total = cleared + (t_mesh - ts); }         // :808: the mesh closes the open segment
@@ -611,7 +771,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
         for (int s = lane; s < S; s += 64) __builtin_nontemporal_store(s < n_steps - 1 ? h : (s == n_steps - 1 ? last_dist : 0.0f), row + s);
     }
 
-    if (a.debug_skip & 32) return;
+    if (NTX_DBG_SKIP(a, 32)) return;
     // ---- first step of every gap (the loop of instancer.cpp:870-1010 without its body) -------------------------------------
     // The reference emits, in gap j, the steps from its running counter on while t_pt(step) < t_j.  t_pt rises with the step, so
     // with F_j = the number of steps s >= 0 with t_pt(s) < t_j under the gap's segment offset, the counter behind gap j is
@@ -654,7 +814,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
             int ex = __shfl_up(v, 1);
             if (lane == 0) ex = step;
             if (j <= n_gaps) { L.gs.g_step0[j] = ex; L.g_off[j] = off_q[q]; }
-            if constexpr (SHADOW) { if (j <= n_gaps) SH.g_seg[j] = (uint8_t)(seg_q[q] < 0 ? 0 : seg_q[q]); }
+            if constexpr (SHADOW || TEX) { if (j <= n_gaps) SG.g_seg[j] = (uint8_t)(seg_q[q] < 0 ? 0 : seg_q[q]); }
             step = __shfl(v, 63);
         }
         if (lane == 0) L.gs.g_step0[n_gaps] = step;
@@ -673,10 +833,10 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
             if (interpolate) {
                 int entries = 0;
                 for (int i = 0; i < n_starts; ++i) {
-                    const float len = SH.len[i];
+                    const float len = SG.len[i];
                     const uint32_t ns = (uint32_t)(((float)n_shadow * len) / total);
                     const int n_seg = (int)(ns > (uint32_t)a.min_shadow ? ns : (uint32_t)a.min_shadow);
-                    SH.len[i] = len / (float)(uint32_t)(n_seg - 1);
+                    SH.sl[i] = len / (float)(uint32_t)(n_seg - 1);
                     SH.base[i] = (uint16_t)entries;
                     entries += n_seg + 1;
                     if (entries > MAX_SHADOW_ENTRIES) { overflow_shadow = true; entries = MAX_SHADOW_ENTRIES; }
@@ -689,7 +849,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
                     int i = 0;
                     for (int q = 1; q < n_starts; ++q) i += (int)SH.base[q] <= x ? 1 : 0;
                     const int k = x - (int)SH.base[i];
-                    const float tk = SH.ts[i] + (float)(uint32_t)k * SH.len[i];
+                    const float tk = SG.ts[i] + (float)(uint32_t)k * SH.sl[i];
                     const bool occ = occluded(a, lane, ox, oy, oz, dx, dy, dz, tk, ox + tk * dx, oy + tk * dy, oz + tk * dz, lx0, ly0, lz0);
                     const uint64_t mk = __ballot(occ && x < entries);
                     if (lane == 0) { SH.bits[x0 >> 5] = (uint32_t)mk; SH.bits[(x0 >> 5) + 1] = (uint32_t)(mk >> 32); }
@@ -699,13 +859,37 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
         }
     }
 
-    if (a.debug_skip & 64) return;
+    // ---- the texture samples of the ray (instancer.cpp:863, 989-998): spaced like the shadow samples, with their own counts; their
+    // values (getParameters at the sample's point) are produced 64 at a time, in order, into a ring the steps read from (below) ----
+    bool tex_interp = false;
+    int tex_entries = 0, tex_produced = 0;
+    if constexpr (TEX) {
+        if (total > 0.0f && a.tex.n_tex > 0) {
+            const uint32_t n_ray = (uint32_t)((float)(uint32_t)a.tex.n_samples * total);
+            const uint32_t n_tex = n_ray > (uint32_t)a.tex.min_samples ? n_ray : (uint32_t)a.tex.min_samples;
+            tex_interp = n_tex < (uint32_t)S;
+            if (tex_interp) {
+                for (int i = 0; i < n_starts; ++i) {
+                    const float len = SG.len[i];
+                    const uint32_t ns = (uint32_t)(((float)n_tex * len) / total);
+                    const int n_seg = (int)(ns > (uint32_t)a.tex.min_samples ? ns : (uint32_t)a.tex.min_samples);
+                    TX.sl[i] = len / (float)(uint32_t)(n_seg - 1);
+                    TX.base[i] = (uint16_t)tex_entries;
+                    tex_entries += n_seg + 1;
+                }
+                TX.base[n_starts] = (uint16_t)tex_entries;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+
+    if (NTX_DBG_SKIP(a, 64)) return;
     // ---- steps: lane per step (instancer.cpp:878-986) ----------------------------------------------------------------------
     const float lx = a.light_dir_idx >= 0 ? L.par[a.light_dir_idx] : 0.0f;
     const float ly = a.light_dir_idx >= 0 ? L.par[a.light_dir_idx + 1] : 0.0f;
     const float lz = a.light_dir_idx >= 0 ? L.par[a.light_dir_idx + 2] : 0.0f;
     const float lstr = a.light_strength_idx >= 0 ? L.par[a.light_strength_idx] : 0.0f;
-    for (int base = 0; base < ((a.debug_skip & 2) ? 0 : step); base += 64) {
+    for (int base = 0; base < (NTX_DBG_SKIP(a, 2) ? 0 : step); base += 64) {
         const int s = base + lane;
         const bool live = s < step;
         // the gap of the step: g_step0[j] <= s < g_step0[j + 1]
@@ -812,6 +996,53 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
             mi[8] = x2.x; mi[9] = x2.y; mi[10] = x2.z; mi[11] = x2.w;
             di[0] = x3.x; di[1] = x3.y; di[2] = x3.z; di[3] = x3.w; di[4] = x4.x; di[5] = x4.y; di[6] = x4.z; di[7] = x4.w; di[8] = x5.x;
         }
+        // parameter textures (:910-927): the row between the two texture samples around t_pt (linear), or a query at the point itself
+        float tv0[MAX_TEX_FILES] = {0.0f, 0.0f, 0.0f, 0.0f}, tv1[MAX_TEX_FILES] = {0.0f, 0.0f, 0.0f, 0.0f}, tw = 0.0f;
+        if constexpr (TEX) {
+            if (a.tex.n_tex > 0) {
+                if (tex_interp) {
+                    const int i = SG.g_seg[j];
+                    const float ts = SG.ts[i], sl = TX.sl[i];
+                    const int n_seg = (int)TX.base[i + 1] - (int)TX.base[i] - 1;
+                    const float xk = (t_pt - ts) / sl;
+                    int k = xk > 1.0f ? (xk < (float)n_seg ? (int)xk : n_seg) : 1;              // smallest k >= 1 with !(t_pt > ts + k * sl), :914-919
+                    while (k > 1 && !(t_pt > ts + (float)(uint32_t)(k - 1) * sl)) --k;
+                    while (k < n_seg && t_pt > ts + (float)(uint32_t)k * sl) ++k;
+                    const float t0 = ts + (float)(uint32_t)(k - 1) * sl;
+                    tw = (t_pt - t0) / sl;                                                      // :922
+                    const int e0 = (int)TX.base[i] + k - 1;
+                    // samples e0 and e0 + 1 from the ring, which holds [tex_produced - TEX_RING, tex_produced): the steps need them in
+                    // ascending order, so the ring only ever moves forward and every sample is worked out once, 64 to a pass
+                    bool pending = live;
+                    while (__any(pending)) {
+                        int lo = pending ? e0 : 0x7fffffff;
+                        for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(lo, o); lo = w < lo ? w : lo; }
+                        while (tex_produced < tex_entries && tex_produced + 64 - TEX_RING <= lo) {
+                            const int x = tex_produced + lane;
+                            if (x < tex_entries) {
+                                int si = 0;
+                                for (int q = 1; q < n_starts; ++q) si += (int)TX.base[q] <= x ? 1 : 0;
+                                const int kk = x - (int)TX.base[si];
+                                const float tk = SG.ts[si] + (float)(uint32_t)kk * TX.sl[si];
+                                float val[MAX_TEX_FILES];
+                                texture_values(a.tex, L.par, ox + tk * dx, oy + tk * dy, oz + tk * dz, val);
+#pragma unroll
+                                for (int q = 0; q < MAX_TEX_FILES; ++q) TX.ring[q][x & (TEX_RING - 1)] = val[q];
+                            }
+                            tex_produced += 64;
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        if (pending && e0 + 1 < tex_produced) {
+#pragma unroll
+                            for (int q = 0; q < MAX_TEX_FILES; ++q) { tv0[q] = TX.ring[q][e0 & (TEX_RING - 1)]; tv1[q] = TX.ring[q][(e0 + 1) & (TEX_RING - 1)]; }
+                            pending = false;
+                        }
+                    }
+                } else {
+                    texture_values(a.tex, L.par, px, py, pz, tv0);                               // :926
+                }
+            }
+        }
         float p3[3], d3[3], l3[3] = {0.0f, 0.0f, 0.0f}, lst = 0.0f;
         affine(mi, px, py, pz, p3);                                                             // getPt
         linear33(di, ndx, ndy, ndz, d3);                                                        // getDir
@@ -823,8 +1054,8 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
             if constexpr (SHADOW) {
                 bool shadowed;
                 if (interpolate) {                                                              // :946-958: the nearer of the two shadow samples around t_pt
-                    const int i = SH.g_seg[j];
-                    const float ts = SH.ts[i], sl = SH.len[i];
+                    const int i = SG.g_seg[j];
+                    const float ts = SG.ts[i], sl = SH.sl[i];
                     const int n_seg = (int)SH.base[i + 1] - (int)SH.base[i] - 1;
                     const float xk = (t_pt - ts) / sl;
                     int k = xk > 1.0f ? (xk < (float)n_seg ? (int)xk : n_seg) : 1;              // smallest k >= 1 with !(t_pt > ts + k * sl)
@@ -871,6 +1102,18 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
                 const int comp = f - P * src;
                 const float la = __shfl(l3[0], src), lb = __shfl(l3[1], src), lc = __shfl(l3[2], src), ls = __shfl(lst, src);
                 float v = L.par[comp];
+                if constexpr (TEX) {
+                    if (a.tex.n_tex > 0) {
+                        const float ws = __shfl(tw, src);
+                        float v0 = v, v1 = v;
+#pragma unroll
+                        for (int q = 0; q < MAX_TEX_FILES; ++q) {
+                            const float a0 = __shfl(tv0[q], src), a1 = __shfl(tv1[q], src);
+                            if (q < a.tex.n_tex && comp == a.tex.par_idx[q]) { v0 = a0; v1 = a1; }
+                        }
+                        v = tex_interp ? v0 * (1.0f - ws) + v1 * ws : v0;                       // :923 (every column), :926
+                    }
+                }
                 const int lc_i = comp - a.light_dir_idx;
                 if (a.light_dir_idx >= 0 && lc_i >= 0 && lc_i < 3) v = lc_i == 0 ? la : (lc_i == 1 ? lb : lc);
                 if (comp == a.light_strength_idx) v = ls;
@@ -880,7 +1123,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
     }
 
     // ---- what instancer.pyx:41-50 leaves in the rows behind the last emitted step -----------------------------------------
-    if (!(a.debug_skip & 1)) {
+    if (!NTX_DBG_SKIP(a, 1)) {
         const size_t base = (size_t)ray * S;
         fill_pattern(a.t + base, step, S, 1, lane, [](int) { return 0.0f; });
         fill_pattern(a.alpha_weight + base, step, S, 1, lane, [](int) { return 1.0f; });
@@ -898,23 +1141,34 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW> *
     }
 }
 
-// two kernels around the one body: rays without shadow queries run at 5 waves per SIMD (what the 29.5 KB of LDS per workgroup allow;
-// the compiler is told to stay within 102 registers for it: 87, no scratch); the shadow flavour, with its tables in LDS (36.5 KB), fits 4
-// workgroups per CU and is held to the 128 registers of 4 waves per SIMD -- it then spills 100 bytes per lane, and is still 19 % faster
-// than at the 157 registers / 3 waves it would take unconstrained (2.43 -> 1.97 ms on the bench scene)
+// four kernels around the one body.  Rays without shadow queries run at 5 waves per SIMD (what the 29.5 KB of LDS per workgroup allow;
+// the compiler is told to stay within 102 registers for it); the shadow flavour, with its tables in LDS, fits 4 workgroups per CU and
+// is held to the 128 registers of 4 waves per SIMD.  The texture flavours add the sample ring and the closest-point walk.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void inst_march_kernel(MarchArgs a) {
-    __shared__ MarchLds<false> lds[4];
-    march_ray<false>(a, lds);
+    __shared__ MarchLds<false, false> lds[4];
+    march_ray<false, false>(a, lds);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void inst_march_shadow_kernel(MarchArgs a) {
-    __shared__ MarchLds<true> lds[4];
-    march_ray<true>(a, lds);
+    __shared__ MarchLds<true, false> lds[4];
+    march_ray<true, false>(a, lds);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void inst_march_tex_kernel(MarchArgs a) {
+    __shared__ MarchLds<false, true> lds[4];
+    march_ray<false, true>(a, lds);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void inst_march_shadow_tex_kernel(MarchArgs a) {
+    __shared__ MarchLds<true, true> lds[4];
+    march_ray<true, true>(a, lds);
 }
 
 // The closing sample of a ray that ends on an AUXILIARY mesh (instancer.cpp:1013-1022 -> shadeMesh, :716-743): wave per ray; the hit
 // triangle's barycentrics once more, the interpolated vertex normal, one shadow query from just above the surface (`occluded`: all
-// lanes the same point), diffuse + 0.2 ambient on albedo 0.8.  Rays that end on the instancer mesh keep the black the march kernel wrote.
-struct ShadeArgs { const float *normals; const int32_t *faces; const uint8_t *kind; };
+// lanes the same point), diffuse + 0.2 ambient on albedo 0.8 or the mesh's texture.  Rays that end on the instancer mesh keep the black the march kernel wrote.
+struct ShadeArgs {
+    const float *normals; const int32_t *faces; const uint8_t *kind;
+    const float *uv; const int32_t *face_tex;        // texture coordinates per vertex; per face the first of its mesh's three channel tables, -1 = none
+    const float *texels; const TexTable *table;
+};
 __global__ __launch_bounds__(256) void inst_shade_kernel(MarchArgs a, ShadeArgs sh) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -923,7 +1177,7 @@ __global__ __launch_bounds__(256) void inst_shade_kernel(MarchArgs a, ShadeArgs 
     const unsigned long long key = a.t_mesh[ray];
     if ((uint32_t)(key >> 32) == INF_BITS) return;
     const int f = (int)(uint32_t)key;
-    if (sh.kind[f] == 0) return;
+    if ((sh.kind[f] & 1) == 0) return;
     const float tm = __builtin_bit_cast(float, (uint32_t)(key >> 32));
     const float o[3] = {a.rays_o[3 * ray], a.rays_o[3 * ray + 1], a.rays_o[3 * ray + 2]};
     const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
@@ -953,7 +1207,15 @@ __global__ __launch_bounds__(256) void inst_shade_kernel(MarchArgs a, ShadeArgs 
     const float diffuse = dark ? 0.0f : 1.0f * (nd > 0.0f ? nd : 0.0f);
     const float sum = diffuse + 0.2f;
     const float shade = sum < 1.0f ? sum : 1.0f;
-    if (lane == 0) { a.color_last[3 * ray] = 0.8f * shade; a.color_last[3 * ray + 1] = 0.8f * shade; a.color_last[3 * ray + 2] = 0.8f * shade; }
+    float albedo[3] = {0.8f, 0.8f, 0.8f};                                             // :728
+    const int tex = sh.face_tex ? sh.face_tex[f] : -1;
+    if (tex >= 0) {                                                                    // :730-732: the mesh's texture at the hit's texture coordinates
+        const float tu = (sh.uv[2 * fv[0]] * w0 + sh.uv[2 * fv[1]] * u) + sh.uv[2 * fv[2]] * v;
+        const float tv = (sh.uv[2 * fv[0] + 1] * w0 + sh.uv[2 * fv[1] + 1] * u) + sh.uv[2 * fv[2] + 1] * v;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) albedo[c] = interpolate2d(sh.texels, sh.table[tex + c], tu, tv);
+    }
+    if (lane == 0) { a.color_last[3 * ray] = albedo[0] * shade; a.color_last[3 * ray + 1] = albedo[1] * shade; a.color_last[3 * ray + 2] = albedo[2] * shade; }
 }
 
 }   // namespace ntx_inst
@@ -971,6 +1233,11 @@ struct ntx_instancer {
     uint32_t *d_count = nullptr;
     unsigned long long *d_tmesh = nullptr;
     float *d_normals = nullptr; int32_t *d_faces = nullptr; uint8_t *d_kind = nullptr; bool has_aux = false;   // auxiliary meshes
+    int64_t n_mesh_vertices = 0;
+    float *d_uv = nullptr; int32_t *d_face_tex = nullptr; float *d_atexels = nullptr; ntx_inst::TexTable *d_atable = nullptr;   // their textures
+    // parameter textures on the instancer mesh: texels + tables, the mesh in its grid
+    ntx_inst::TexArgs tex{};
+    float *d_ptexels = nullptr, *d_gtris = nullptr, *d_face_uv = nullptr; ntx_inst::TexTable *d_ptable = nullptr; int32_t *d_cell_start = nullptr;
     uint4 *d_hits = nullptr;
 };
 
@@ -1005,7 +1272,8 @@ bool invert4(const float *m, double *out) {
 void release(ntx_instancer *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    for (void *q : {(void *)p->d_mats, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_xforms, (void *)p->d_normals, (void *)p->d_faces, (void *)p->d_kind, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits})
+    for (void *q : {(void *)p->d_mats, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_xforms, (void *)p->d_normals, (void *)p->d_faces, (void *)p->d_kind, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits,
+                    (void *)p->d_uv, (void *)p->d_face_tex, (void *)p->d_atexels, (void *)p->d_atable, (void *)p->d_ptexels, (void *)p->d_gtris, (void *)p->d_face_uv, (void *)p->d_ptable, (void *)p->d_cell_start})
         if (q) (void)hipFree(q);
     delete p;
 }
@@ -1133,7 +1401,7 @@ int ntx_instancer_set_meshes(ntx_instancer *inst, const float *vertices, const f
                              const uint8_t *face_kind, int64_t n_faces) {
     if (!inst) return ntx_set_error(NTX_E_INVALID, "inst is NULL");
     bool aux = false;
-    for (int64_t f = 0; face_kind && f < n_faces; ++f) aux = aux || face_kind[f] != 0;
+    for (int64_t f = 0; face_kind && f < n_faces; ++f) aux = aux || (face_kind[f] & 1) != 0;
     if (aux && !normals) return ntx_set_error(NTX_E_INVALID, "auxiliary meshes are shaded with their vertex normals (instancer.cpp:722-724): normals is NULL");
     if (aux && inst->desc.light_dir_parameter_idx < 0) return ntx_set_error(NTX_E_INVALID, "auxiliary meshes are shaded from the light parameter (instancer.cpp:1020): the textures list has none");
     if (n_faces < 0 || n_faces > 0x7fffffff || n_vertices < 0 || (n_faces > 0 && (!vertices || !faces))) return ntx_set_error(NTX_E_INVALID, "bad mesh");
@@ -1156,22 +1424,178 @@ int ntx_instancer_set_meshes(ntx_instancer *inst, const float *vertices, const f
         for (int c = 0; c < 3; ++c) tris[f * 13 + 9 + c] = (float)cen[c];
         tris[f * 13 + 12] = (float)(r2 * 1.002 + 1e-12);
     }
-    for (void **q : {(void **)&inst->d_tris, (void **)&inst->d_normals, (void **)&inst->d_faces, (void **)&inst->d_kind})
+    for (void **q : {(void **)&inst->d_tris, (void **)&inst->d_normals, (void **)&inst->d_faces, (void **)&inst->d_kind,
+                     (void **)&inst->d_uv, (void **)&inst->d_face_tex, (void **)&inst->d_atexels, (void **)&inst->d_atable})
         if (*q) { (void)hipFree(*q); *q = nullptr; }
-    inst->n_tri = 0; inst->has_aux = false;
+    inst->n_tri = 0; inst->has_aux = false; inst->n_mesh_vertices = 0;
     if (n_faces > 0) {
         INST_TRY(hipMalloc((void **)&inst->d_tris, tris.size() * sizeof(float)));
         INST_TRY(hipMemcpy(inst->d_tris, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice));
+        {   // bit 0: auxiliary; bit 1: primID 1 of its own mesh (one mesh when no kinds are given)
+            std::vector<uint8_t> kind((size_t)n_faces, 0);
+            for (int64_t f = 0; f < n_faces; ++f) kind[f] = face_kind ? face_kind[f] : (uint8_t)(f == 1 ? 2 : 0);
+            INST_TRY(hipMalloc((void **)&inst->d_kind, (size_t)n_faces));
+            INST_TRY(hipMemcpy(inst->d_kind, kind.data(), (size_t)n_faces, hipMemcpyHostToDevice));
+        }
+        inst->n_mesh_vertices = n_vertices;
         if (aux) {
             INST_TRY(hipMalloc((void **)&inst->d_normals, (size_t)n_vertices * 3 * sizeof(float)));
             INST_TRY(hipMemcpy(inst->d_normals, normals, (size_t)n_vertices * 3 * sizeof(float), hipMemcpyHostToDevice));
             INST_TRY(hipMalloc((void **)&inst->d_faces, (size_t)n_faces * 3 * sizeof(int32_t)));
             INST_TRY(hipMemcpy(inst->d_faces, faces, (size_t)n_faces * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
-            INST_TRY(hipMalloc((void **)&inst->d_kind, (size_t)n_faces));
-            INST_TRY(hipMemcpy(inst->d_kind, face_kind, (size_t)n_faces, hipMemcpyHostToDevice));
         }
         inst->n_tri = n_faces; inst->has_aux = aux;
     }
+    return NTX_OK;
+}
+
+namespace {
+
+// concatenate channel matrices into one texel buffer + table on the device
+int upload_textures(const ntx_texture *textures, int n, float **d_texels, ntx_inst::TexTable **d_table) {
+    std::vector<ntx_inst::TexTable> table((size_t)n);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!textures[i].texels || textures[i].rows < 1 || textures[i].cols < 1 || (int64_t)textures[i].rows * textures[i].cols > (1 << 28))
+            return ntx_set_error(NTX_E_INVALID, "texture %d: NULL texels or bad size %d x %d", i, textures[i].rows, textures[i].cols);
+        table[i] = ntx_inst::TexTable{(int32_t)total, textures[i].rows, textures[i].cols, 0};
+        total += (size_t)textures[i].rows * textures[i].cols;
+        if (total > (size_t)0x7fffffff) return ntx_set_error(NTX_E_INVALID, "textures: more than 2^31 texels");
+    }
+    std::vector<float> texels(total);
+    for (int i = 0; i < n; ++i) std::memcpy(texels.data() + table[i].offset, textures[i].texels, (size_t)textures[i].rows * textures[i].cols * sizeof(float));
+    INST_TRY(hipMalloc((void **)d_texels, (total ? total : 1) * sizeof(float)));
+    INST_TRY(hipMemcpy(*d_texels, texels.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    INST_TRY(hipMalloc((void **)d_table, (size_t)(n ? n : 1) * sizeof(ntx_inst::TexTable)));
+    INST_TRY(hipMemcpy(*d_table, table.data(), (size_t)n * sizeof(ntx_inst::TexTable), hipMemcpyHostToDevice));
+    return NTX_OK;
+}
+
+}   // namespace
+
+int ntx_instancer_set_parameter_textures(ntx_instancer *inst, const float *vertices, const float *uv, int64_t n_vertices, const int32_t *faces,
+                                         int64_t n_faces, float patch_max_extent, int n_textures, const int32_t *parameter_idx,
+                                         const ntx_texture *textures, int min_texture_samples, int n_texture_samples) {
+    using namespace ntx_inst;
+    if (!inst) return ntx_set_error(NTX_E_INVALID, "inst is NULL");
+    INST_TRY(hipSetDevice(inst->device));
+    for (void **q : {(void **)&inst->d_ptexels, (void **)&inst->d_ptable, (void **)&inst->d_gtris, (void **)&inst->d_face_uv, (void **)&inst->d_cell_start})
+        if (*q) { (void)hipFree(*q); *q = nullptr; }
+    inst->tex = TexArgs{};
+    if (n_textures == 0) return NTX_OK;
+    if (n_textures < 0 || n_textures > MAX_TEX_FILES) return ntx_set_error(NTX_E_UNSUPPORTED, "%d texture files in the textures list: at most %d are built", n_textures, MAX_TEX_FILES);
+    if (!vertices || !uv || !faces || !parameter_idx || !textures || n_vertices < 1 || n_faces < 1 || n_faces > 0x7fffffff)
+        return ntx_set_error(NTX_E_INVALID, "parameter textures need the instancer mesh with texture coordinates (getParameters, instancer.cpp:640-667)");
+    if (!(patch_max_extent > 0.0f) || std::isinf(patch_max_extent)) return ntx_set_error(NTX_E_INVALID, "patch_max_extent must be finite and > 0");
+    if (min_texture_samples < 2 || min_texture_samples > 512 || n_texture_samples < 0)
+        return ntx_set_error(NTX_E_INVALID, "min_texture_samples must lie in [2, 512] (the spacing is length / (n - 1), instancer.cpp:992) and n_texture_samples be >= 0");
+    for (int i = 0; i < n_textures; ++i)
+        if (parameter_idx[i] < 0 || parameter_idx[i] >= inst->desc.n_parameters) return ntx_set_error(NTX_E_INVALID, "texture %d multiplies parameter %d of %d", i, parameter_idx[i], inst->desc.n_parameters);
+    for (int64_t f = 0; f < 3 * n_faces; ++f)
+        if (faces[f] < 0 || faces[f] >= n_vertices) return ntx_set_error(NTX_E_INVALID, "face %lld names vertex %d of %lld", (long long)(f / 3), faces[f], (long long)n_vertices);
+    // the grid: cells about one average edge wide (at most 2^21 of them), triangles binned by centroid
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, edge = 0.0;
+    for (int64_t v = 0; v < n_vertices; ++v)
+        for (int c = 0; c < 3; ++c) {
+            const double x = vertices[3 * v + c];
+            if (!std::isfinite(x)) return ntx_set_error(NTX_E_INVALID, "vertex %lld is not finite", (long long)v);
+            lo[c] = x < lo[c] ? x : lo[c]; hi[c] = x > hi[c] ? x : hi[c];
+        }
+    std::vector<double> cen((size_t)n_faces * 3);
+    double r_max = 0.0;
+    for (int64_t f = 0; f < n_faces; ++f) {
+        const float *v[3] = {vertices + 3 * (int64_t)faces[3 * f], vertices + 3 * (int64_t)faces[3 * f + 1], vertices + 3 * (int64_t)faces[3 * f + 2]};
+        for (int c = 0; c < 3; ++c) cen[3 * f + c] = ((double)v[0][c] + v[1][c] + v[2][c]) / 3.0;
+        for (int j = 0; j < 3; ++j) {
+            double e2 = 0.0, d2 = 0.0;
+            for (int c = 0; c < 3; ++c) {
+                e2 += ((double)v[j][c] - v[(j + 1) % 3][c]) * ((double)v[j][c] - v[(j + 1) % 3][c]);
+                d2 += ((double)v[j][c] - cen[3 * f + c]) * ((double)v[j][c] - cen[3 * f + c]);
+            }
+            edge += std::sqrt(e2);
+            r_max = std::sqrt(d2) > r_max ? std::sqrt(d2) : r_max;
+        }
+    }
+    edge /= 3.0 * (double)n_faces;
+    const double ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    double cell = edge > 0.0 ? edge : 1.0;
+    {
+        const double vol = (ext[0] + cell) * (ext[1] + cell) * (ext[2] + cell);
+        const double floor_cell = std::cbrt(vol / (double)(1 << 21));
+        cell = cell > floor_cell ? cell : floor_cell;
+    }
+    TexArgs T{};
+    int64_t n_cells = 1;
+    for (int c = 0; c < 3; ++c) {
+        T.gmin[c] = (float)lo[c];
+        T.dim[c] = (int32_t)std::floor((hi[c] - (double)T.gmin[c]) / cell) + 1;
+        if (T.dim[c] < 1) T.dim[c] = 1;
+        n_cells *= T.dim[c];
+    }
+    T.cell = (float)cell; T.inv_cell = (float)(1.0 / (double)T.cell); T.r_max = (float)(r_max * 1.001 + 1e-12);
+    std::vector<int32_t> cell_of((size_t)n_faces), start((size_t)n_cells + 1, 0);
+    for (int64_t f = 0; f < n_faces; ++f) {
+        int64_t id = 0, mul = 1;
+        for (int c = 0; c < 3; ++c) {
+            int64_t q = (int64_t)std::floor((cen[3 * f + c] - (double)T.gmin[c]) / (double)T.cell);
+            q = q < 0 ? 0 : (q >= T.dim[c] ? T.dim[c] - 1 : q);
+            id += q * mul; mul *= T.dim[c];
+        }
+        cell_of[f] = (int32_t)id;
+        ++start[id + 1];
+    }
+    for (int64_t c = 0; c < n_cells; ++c) start[c + 1] += start[c];
+    std::vector<float> gtris((size_t)n_faces * 10), fuv((size_t)n_faces * 6);
+    {
+        std::vector<int32_t> at(start.begin(), start.end() - 1);
+        for (int64_t f = 0; f < n_faces; ++f) {                      // ascending primID inside a cell
+            const size_t e = (size_t)at[cell_of[f]]++;
+            for (int j = 0; j < 3; ++j)
+                for (int c = 0; c < 3; ++c) gtris[e * 10 + 3 * j + c] = vertices[3 * (int64_t)faces[3 * f + j] + c];
+            const int32_t id = (int32_t)f;
+            std::memcpy(&gtris[e * 10 + 9], &id, sizeof(float));
+            for (int j = 0; j < 3; ++j) { fuv[f * 6 + 2 * j] = uv[2 * (int64_t)faces[3 * f + j]]; fuv[f * 6 + 2 * j + 1] = uv[2 * (int64_t)faces[3 * f + j] + 1]; }
+        }
+    }
+    int rc = upload_textures(textures, n_textures, &inst->d_ptexels, &inst->d_ptable);
+    if (rc != NTX_OK) return rc;
+    INST_TRY(hipMalloc((void **)&inst->d_gtris, gtris.size() * sizeof(float)));
+    INST_TRY(hipMemcpy(inst->d_gtris, gtris.data(), gtris.size() * sizeof(float), hipMemcpyHostToDevice));
+    INST_TRY(hipMalloc((void **)&inst->d_face_uv, fuv.size() * sizeof(float)));
+    INST_TRY(hipMemcpy(inst->d_face_uv, fuv.data(), fuv.size() * sizeof(float), hipMemcpyHostToDevice));
+    INST_TRY(hipMalloc((void **)&inst->d_cell_start, start.size() * sizeof(int32_t)));
+    INST_TRY(hipMemcpy(inst->d_cell_start, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    T.n_tex = n_textures;
+    for (int i = 0; i < n_textures; ++i) T.par_idx[i] = parameter_idx[i];
+    T.min_samples = min_texture_samples; T.n_samples = n_texture_samples; T.radius = patch_max_extent;
+    T.texels = inst->d_ptexels; T.table = inst->d_ptable; T.cell_start = inst->d_cell_start; T.tris = inst->d_gtris; T.face_uv = inst->d_face_uv;
+    T.n_faces = (int32_t)n_faces;
+    inst->tex = T;
+    return NTX_OK;
+}
+
+int ntx_instancer_set_mesh_textures(ntx_instancer *inst, const float *uv, int64_t n_vertices, const int32_t *face_texture, int64_t n_faces,
+                                    int n_sets, const ntx_texture *textures) {
+    if (!inst) return ntx_set_error(NTX_E_INVALID, "inst is NULL");
+    INST_TRY(hipSetDevice(inst->device));
+    for (void **q : {(void **)&inst->d_uv, (void **)&inst->d_face_tex, (void **)&inst->d_atexels, (void **)&inst->d_atable})
+        if (*q) { (void)hipFree(*q); *q = nullptr; }
+    if (n_sets == 0) return NTX_OK;
+    if (n_sets < 0 || !uv || !face_texture || !textures) return ntx_set_error(NTX_E_INVALID, "bad mesh textures");
+    if (n_vertices != inst->n_mesh_vertices || n_faces != inst->n_tri)
+        return ntx_set_error(NTX_E_INVALID, "mesh textures for %lld vertices / %lld faces, ntx_instancer_set_meshes got %lld / %lld", (long long)n_vertices, (long long)n_faces,
+                             (long long)inst->n_mesh_vertices, (long long)inst->n_tri);
+    std::vector<int32_t> ft((size_t)n_faces);
+    for (int64_t f = 0; f < n_faces; ++f) {
+        if (face_texture[f] < -1 || face_texture[f] >= n_sets) return ntx_set_error(NTX_E_INVALID, "face %lld names texture set %d of %d", (long long)f, face_texture[f], n_sets);
+        ft[f] = face_texture[f] < 0 ? -1 : 3 * face_texture[f];
+    }
+    int rc = upload_textures(textures, 3 * n_sets, &inst->d_atexels, &inst->d_atable);
+    if (rc != NTX_OK) return rc;
+    INST_TRY(hipMalloc((void **)&inst->d_uv, (size_t)n_vertices * 2 * sizeof(float)));
+    INST_TRY(hipMemcpy(inst->d_uv, uv, (size_t)n_vertices * 2 * sizeof(float), hipMemcpyHostToDevice));
+    INST_TRY(hipMalloc((void **)&inst->d_face_tex, (size_t)n_faces * sizeof(int32_t)));
+    INST_TRY(hipMemcpy(inst->d_face_tex, ft.data(), (size_t)n_faces * sizeof(int32_t), hipMemcpyHostToDevice));
     return NTX_OK;
 }
 
@@ -1243,15 +1667,23 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         a.method = inst->desc.instance_sample_method; a.use_mean = inst->desc.use_mean_distance ? 1 : 0;
         a.step_size = step_size; a.blend_range = 0.2f * inst->desc.patch_scale;
         a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-        { const char *dbg = getenv("NERFTEX_INST_DEBUG"); a.debug_skip = dbg ? atoi(dbg) : 0; }
+#ifdef NTX_INST_DEBUG
+        { const char *dbg = getenv("NERFTEX_INST_DEBUG"); a.debug_skip = dbg ? atoi(dbg) : 0; }   // development builds only: results are then wrong
+#endif
         // the piece's rays continue the call's index map: local k of the piece = local c0 + k of the call
         if (idx_run == 0xffffffffu) { a.idx0 = idx0 + c0; a.idx_run = 0xffffffffu; a.idx_stride = 0; }
         else { a.idx0 = idx0 + (c0 / idx_run) * idx_stride; a.idx_run = idx_run; a.idx_stride = idx_stride; }
         a.spheres = inst->d_spheres; a.tris = inst->d_tris; a.n_inst = K; a.n_tri = F; a.box = box;
         a.min_shadow = inst->desc.min_shadow_samples; a.n_shadow = inst->desc.n_shadow_samples;
-        if (inst->desc.cast_shadow_rays && a.light_dir_idx >= 0) hipLaunchKernelGGL(inst_march_shadow_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
+        a.kind = inst->d_kind; a.tex = inst->tex;
+        const bool shadows = inst->desc.cast_shadow_rays && a.light_dir_idx >= 0, textured = inst->tex.n_tex > 0;
+        if (shadows && textured) hipLaunchKernelGGL(inst_march_shadow_tex_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
+        else if (shadows) hipLaunchKernelGGL(inst_march_shadow_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
+        else if (textured) hipLaunchKernelGGL(inst_march_tex_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(inst_march_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a);
-        if (F > 0 && inst->has_aux) hipLaunchKernelGGL(inst_shade_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a, ShadeArgs{inst->d_normals, inst->d_faces, inst->d_kind});
+        if (F > 0 && inst->has_aux)
+            hipLaunchKernelGGL(inst_shade_kernel, dim3((n + 3) / 4), dim3(256), 0, st, a,
+                               ShadeArgs{inst->d_normals, inst->d_faces, inst->d_kind, inst->d_uv, inst->d_face_tex, inst->d_atexels, inst->d_atable});
     }
     INST_TRY(hipGetLastError());
     return NTX_OK;

@@ -9,8 +9,11 @@ What is built: explicit `transformations` (instancer.pyx:19-20), the JSON file t
 writes (instancer.cpp:1040-1061), or `mesh_path` [+ `patch_origins_path`, `patch_scale`, `jitter_amount`]: DistributeInstancesOnMesh
 (instancer.cpp:233-390) on the host, from a PLY with vertex normals and texture coordinates; a culling mesh as arrays or a PLY file;
 `auxiliary_meshes` (flat-shaded; a PLY with vertex normals, or arrays); the three `instance_sampling_method`s;
-`use_mean_distance`; '' / 'light' / 'point' entries of `textures`; `cast_shadow_rays` with `min_shadow_samples` /
-`n_shadow_samples`.  What is refused (NtxError, NTX_E_UNSUPPORTED): image textures (as parameters and as auxiliary albedo).
+`use_mean_distance`; '' / 'light' / 'point' / image entries of `textures` (PNG files: parameter textures looked up on the instancer
+mesh, instancer.cpp:640-667, with `min_texture_samples` / `n_texture_samples`; they apply when `mesh_path` is given, as in the
+reference, :911); `cast_shadow_rays` with `min_shadow_samples` / `n_shadow_samples`; textured auxiliary meshes (:725-733).  All four
+shipped render configs' `instancer_config` blocks construct as written (their mesh and texture files are LFS pointers in the
+reference's repository: bring the files).  Refused (NtxError, NTX_E_UNSUPPORTED): more than four texture files; images that are not PNG.
 """
 
 from __future__ import annotations
@@ -24,20 +27,50 @@ from . import _lib
 SAMPLING_METHODS = {"random": 0, "nearest": 1, "nearest_blend": 2}        # instancer.pyx:14
 
 
-def parse_textures(textures: Sequence[str]):
-    """(n_parameters, light_dir_parameter_idx, light_strength_parameter_idx) of a `textures` list (instancer.cpp:74-92)."""
+def load_texture(source):
+    """loadTexture (instancer.cpp:34-50): the channels of an image as float32 matrices [width, height] of value / 255, element (x, y
+    counted from the bottom row) -- stb's pixels [height * width, channels] mapped column-major to (width, height) per channel, then
+    `.rowwise().reverse()`.  `source`: a PNG file, or the pixels themselves [height, width(, channels)] uint8."""
+    import numpy as np
+    if isinstance(source, str):
+        if not source.lower().endswith(".png"):
+            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, f"texture {source!r}: only PNG files are read (nerf_tex_amd/png.py)")
+        from .png import read_png
+        px = read_png(source)
+    else:
+        px = np.asarray(source, np.uint8)
+        px = px[:, :, None] if px.ndim == 2 else px
+    f = px.astype(np.float32) / np.float32(255.0)
+    return [np.ascontiguousarray(f[::-1, :, c].T) for c in range(px.shape[2])]
+
+
+def parse_textures(textures: Sequence):
+    """(n_parameters, light_dir_parameter_idx, light_strength_parameter_idx, texture_parameter_idxs, channel matrices) of a `textures`
+    list (instancer.cpp:74-92): '' = one parameter, 'light' = three, 'point' = four, anything else an image whose channels take one
+    parameter each (an entry may also be the pixels themselves, [height, width(, channels)] uint8)."""
     n, light_dir, light_strength = 0, -1, -1
+    idx, mats = [], []
     for path in textures:
-        if path == "light":
+        if isinstance(path, str) and path == "light":
             light_dir = n; n += 3
-        elif path == "point":
+        elif isinstance(path, str) and path == "point":
             light_strength = n; light_dir = n + 1; n += 4
-        elif path != "":
-            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, f"image texture {path!r}: parameter textures on the instancer mesh "
-                                "(instancer.cpp:640-667) are not built")
+        elif not isinstance(path, str) or path != "":
+            tex = load_texture(path)
+            mats += tex
+            idx.append(n)
+            n += len(tex)
         else:
             n += 1
-    return n, light_dir, light_strength
+    return n, light_dir, light_strength, idx, mats
+
+
+def _textures_struct(mats):
+    """A ctypes array of ntx_texture over float32 matrices (kept alive by the caller)."""
+    arr = (_lib.Texture * max(len(mats), 1))()
+    for i, m in enumerate(mats):
+        arr[i].texels = m.ctypes.data_as(C.POINTER(C.c_float)); arr[i].rows, arr[i].cols = m.shape
+    return arr
 
 
 class Instancer:
@@ -50,16 +83,20 @@ class Instancer:
                  min_shadow_samples: int = 4, n_shadow_samples: int = 512, min_texture_samples: int = 4,
                  n_texture_samples: int = 512, jitter_amount: float = 0, instance_sampling_method: str = 'random',
                  use_mean_distance: bool = False, auxiliary_meshes=(), transformation_export_path: Optional[str] = None,
-                 transformations_path: Optional[str] = None, mesh=None, seed: int = 0, device: int = 0) -> None:
+                 transformations_path: Optional[str] = None, mesh=None, instancer_mesh=None, seed: int = 0, device: int = 0) -> None:
+        """Beyond the reference's keywords: `transformations_path` (a list ExportTransformations wrote), `mesh` = (vertices, faces) of a
+        culling mesh as arrays, `instancer_mesh` = (vertices, faces, uv): the state DistributeInstancesOnMesh leaves behind (the mesh
+        culls, parameter textures are looked up on it, `patch_scale` scales the lookup radius, :246) without placing patches -- they
+        come from `transformations`; `seed` (the reference's C++ default 0, not exposed by its Cython class), `device`."""
         import numpy as np
         if instance_sampling_method not in SAMPLING_METHODS:
             raise ValueError(f"instance_sampling_method must be one of {sorted(SAMPLING_METHODS)}")
-        for _, tex in auxiliary_meshes:
-            if tex:
-                raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, f"texture {tex!r} on an auxiliary mesh (instancer.cpp:405, 727-733) is not built")
-        n_par, light_dir, light_strength = parse_textures(textures)
+        n_par, light_dir, light_strength, tex_idx, tex_mats = parse_textures(textures)
+        if len(tex_idx) > 4:
+            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, f"{len(tex_idx)} texture files in `textures`: at most 4 are built")
         tr = [np.asarray(m, np.float32).reshape(4, 4) for m in transformations]
         distributed = False
+        tex_mesh = None                                # (vertices, faces, uv) parameter textures are looked up on
         if transformations_path is not None:           # what ExportTransformations wrote (patch -> world, instancer.cpp:1040-1061)
             with open(transformations_path) as f:
                 tr += [np.asarray(m, np.float32).reshape(4, 4) for m in json.load(f)]
@@ -76,8 +113,14 @@ class Instancer:
             tr += list(placed)
             patch_scale = scale_
             distributed = True
+            tex_mesh = (v_, f_, uv_)
             if mesh is None:
                 mesh = (v_, f_)
+        elif instancer_mesh is not None:
+            tex_mesh = tuple(np.asarray(a) for a in instancer_mesh)
+            distributed = True
+            if mesh is None:
+                mesh = (tex_mesh[0], tex_mesh[1])
         self._tr = np.ascontiguousarray(np.stack(tr) if tr else np.zeros((0, 4, 4), np.float32))
         # only DistributeInstancesOnMesh stores the scale (instancer.cpp:236); it widens nearest_blend's transition (:697)
         self.patch_scale = float(patch_scale) if distributed else 1.0
@@ -97,11 +140,29 @@ class Instancer:
         _lib.check(_lib.lib.ntx_instancer_create(C.byref(desc), self._tr.ctypes.data_as(C.POINTER(C.c_float)), self._tr.shape[0],
                                                  self.device, C.byref(self._h)))
         base = mesh if mesh is not None else (read_ply(mesh_path) if mesh_path is not None else None)
-        aux = [read_ply(path, normals=True) if isinstance(path, str) else path for path, _ in auxiliary_meshes]   # (path | (V, F, N), texture)
-        if aux:                                                                              # AddMesh, instancer.cpp:393-417
-            self.set_meshes(base, aux)
+        # AddMesh (instancer.cpp:393-417): (path | (V, F, N[, UV]), texture path | pixels | '')
+        has_tex = lambda t: not isinstance(t, str) or t != ""
+        aux = [(read_ply(path, normals=True, uv=has_tex(t)) if isinstance(path, str) else tuple(path)) for path, t in auxiliary_meshes]
+        self.meshes = None; self.mesh_prim = None; self.mesh_uv = None; self.mesh_tex = None; self.aux_textures = []
+        if aux:
+            self.set_meshes(base, aux, [load_texture(t) if has_tex(t) else None for _, t in auxiliary_meshes])
         elif base is not None:
             self.set_mesh(*base)
+        # parameter textures (getParameters, :640-667): only after DistributeInstancesOnMesh (:911)
+        self.tex_idx, self.textures, self.inst_mesh = tex_idx, tex_mats, tex_mesh
+        e = np.maximum(np.asarray(b_0, np.float32), np.asarray(b_1, np.float32))
+        self.patch_max_extent = np.float32(np.sqrt(e[0] * e[0] + (e[1] * e[1] + e[2] * e[2])))          # :69 (Eigen pairs x0^2 + (x1^2 + x2^2))
+        if distributed:
+            self.patch_max_extent = np.float32(self.patch_max_extent * np.float32(self.patch_scale))    # :246
+        self.min_texture_samples, self.n_texture_samples = int(min_texture_samples), int(n_texture_samples)
+        if tex_idx and tex_mesh is not None:
+            v = np.ascontiguousarray(np.asarray(tex_mesh[0], np.float32).reshape(-1, 3)); f = np.ascontiguousarray(np.asarray(tex_mesh[1], np.int32).reshape(-1, 3))
+            uv = np.ascontiguousarray(np.asarray(tex_mesh[2], np.float32).reshape(-1, 2))
+            used = [tex_mats[i] for i in range(len(tex_idx))]            # file i multiplies by entry i of the list of ALL channels (:656-662)
+            fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+            _lib.check(_lib.lib.ntx_instancer_set_parameter_textures(
+                self._h, fp(v), fp(uv), v.shape[0], f.ctypes.data_as(C.POINTER(C.c_int32)), f.shape[0], float(self.patch_max_extent), len(tex_idx),
+                (C.c_int32 * len(tex_idx))(*tex_idx), _textures_struct(used), self.min_texture_samples, self.n_texture_samples))
         if transformation_export_path is not None:
             self.export_transformations(transformation_export_path)
 
@@ -121,26 +182,43 @@ class Instancer:
         f = np.ascontiguousarray(np.asarray(faces, np.int32).reshape(-1, 3))
         _lib.check(_lib.lib.ntx_instancer_set_mesh(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), v.shape[0],
                                                    f.ctypes.data_as(C.POINTER(C.c_int32)), f.shape[0]))
+        self.meshes = (v, f, None, np.zeros(f.shape[0], np.uint8)); self.mesh_prim = np.arange(f.shape[0])
 
-    def set_meshes(self, instancer_mesh, auxiliary) -> None:
-        """The instancer mesh (vertices, faces) or None, and auxiliary meshes [(vertices, faces, vertex normals), ...] (AddMesh,
+    def set_meshes(self, instancer_mesh, auxiliary, textures=None) -> None:
+        """The instancer mesh (vertices, faces) or None, and auxiliary meshes [(vertices, faces, vertex normals[, uv]), ...] (AddMesh,
         instancer.cpp:393-417): all of them cull and cast shadows; a ray that ends on an auxiliary mesh gets a shaded closing sample
-        (shadeMesh, :716-743)."""
+        (shadeMesh, :716-743), its albedo 0.8 or `textures[i]` (the channel matrices of load_texture) at the hit's texture coordinates."""
         import numpy as np
-        vs, ns, fs, ks, base = [], [], [], [], 0
-        meshes = ([(instancer_mesh[0], instancer_mesh[1], None, 0)] if instancer_mesh is not None else []) + [(m[0], m[1], m[2], 1) for m in auxiliary]
-        for v, f, n, kind in meshes:
+        textures = list(textures) if textures is not None else [None] * len(auxiliary)
+        vs, ns, fs, ks, us, ps, ts, sets, base = [], [], [], [], [], [], [], [], 0
+        meshes = ([(instancer_mesh[0], instancer_mesh[1], None, None, 0, None)] if instancer_mesh is not None else []) + \
+                 [(m[0], m[1], m[2], m[3] if len(m) > 3 else None, 1, t) for m, t in zip(auxiliary, textures)]
+        for v, f, n, uv, kind, tex in meshes:
             v = np.asarray(v, np.float32).reshape(-1, 3); f = np.asarray(f, np.int32).reshape(-1, 3)
             if kind and n is None:
                 raise ValueError("an auxiliary mesh needs vertex normals (the reference shades with them, instancer.cpp:722-724)")
-            vs.append(v); fs.append(f + base); ks.append(np.full(f.shape[0], kind, np.uint8))
+            if tex is not None and uv is None:
+                raise ValueError("a textured auxiliary mesh needs texture coordinates (instancer.cpp:730)")
+            prim = np.arange(f.shape[0])
+            vs.append(v); fs.append(f + base); ps.append(prim)
+            ks.append((kind | np.where(prim == 1, 2, 0)).astype(np.uint8))            # bit 1: primID 1 of its own mesh (shadow filter, :553)
             ns.append(np.asarray(n, np.float32).reshape(-1, 3) if n is not None else np.zeros_like(v))
+            us.append(np.asarray(uv, np.float32).reshape(-1, 2) if uv is not None else np.zeros((v.shape[0], 2), np.float32))
+            ts.append(np.full(f.shape[0], len(sets) if tex is not None else -1, np.int32))
+            if tex is not None:
+                sets.append([np.ascontiguousarray(m, dtype=np.float32) for m in tex])
             base += v.shape[0]
-        v, n, f, k = (np.ascontiguousarray(np.concatenate(x)) for x in (vs, ns, fs, ks))
+        v, n, f, k, uv, prim, ft = (np.ascontiguousarray(np.concatenate(x)) for x in (vs, ns, fs, ks, us, ps, ts))
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
         _lib.check(_lib.lib.ntx_instancer_set_meshes(self._h, fp(v), fp(n), v.shape[0], f.ctypes.data_as(C.POINTER(C.c_int32)),
                                                      k.ctypes.data_as(C.POINTER(C.c_uint8)), f.shape[0]))
-        self.meshes = (v, f, n, k)                    # as the library holds them (tests hand them to the oracle)
+        if sets:                                      # three channel matrices per set; not exactly three channels: the first for all (:732)
+            flat = [m for s_ in sets for m in (s_ if len(s_) == 3 else [s_[0]] * 3)]
+            _lib.check(_lib.lib.ntx_instancer_set_mesh_textures(self._h, fp(uv), v.shape[0], ft.ctypes.data_as(C.POINTER(C.c_int32)), f.shape[0],
+                                                                len(sets), _textures_struct(flat)))
+        # as the library holds them (tests hand them to the oracle): kind bit 0 only, primIDs, uv, texture set per face, the sets
+        self.meshes = (v, f, n, (k & 1).astype(np.uint8))
+        self.mesh_prim, self.mesh_uv, self.mesh_tex, self.aux_textures = prim, uv, ft, sets
 
     def reserve(self, max_rays: int) -> None:
         _lib.check(_lib.lib.ntx_instancer_reserve(self._h, int(max_rays)))

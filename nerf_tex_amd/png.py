@@ -1,0 +1,146 @@
+"""A PNG reader on zlib: the pixels stb_image hands `loadTexture` (instancer/src/instancer.cpp:38, `stbi_load(path, &w, &h, &channels, 0)`).
+
+[height, width, channels] uint8, rows top-down, with stb's channel count: greyscale 1, greyscale + alpha 2, RGB 3, RGBA 4; a palette
+image expanded to RGB (RGBA when it has a tRNS chunk); a tRNS colour key on a greyscale / RGB image adds an alpha channel; samples of
+1 / 2 / 4 bits scaled to 0 .. 255, of 16 bits reduced to their high byte; Adam7 interlacing undone.  Nothing else (no gamma, no colour
+management): that is what stb does.  Other formats the reference could read through stb (JPEG, BMP ...) are not built; its texture files
+are PNGs (configs/config_carpet_render.py:86, config_plush_render.py:100).
+"""
+
+from __future__ import annotations
+
+import struct
+import zlib
+
+import numpy as np
+
+_SIGNATURE = b"\x89PNG\r\n\x1a\n"
+_CHANNELS = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}         # samples per pixel by colour type
+
+
+def _unfilter(raw: np.ndarray, rows: int, stride: int, bpp: int) -> np.ndarray:
+    """Undo the per-row filters (PNG spec 9): raw = rows x (1 + stride) bytes -> rows x stride."""
+    out = np.zeros((rows, stride), np.uint8)
+    prev = np.zeros(stride, np.int32)
+    at = 0
+    for r in range(rows):
+        ft = int(raw[at]); line = raw[at + 1:at + 1 + stride].astype(np.int32); at += 1 + stride
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:
+            cur = np.zeros(stride, np.int32)
+            if ft == 1:
+                for i in range(stride):
+                    cur[i] = (line[i] + (cur[i - bpp] if i >= bpp else 0)) & 255
+            elif ft == 3:
+                for i in range(stride):
+                    cur[i] = (line[i] + (((cur[i - bpp] if i >= bpp else 0) + prev[i]) >> 1)) & 255
+            elif ft == 4:
+                for i in range(stride):
+                    a = int(cur[i - bpp]) if i >= bpp else 0
+                    b = int(prev[i]); c = int(prev[i - bpp]) if i >= bpp else 0
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                    cur[i] = (line[i] + pred) & 255
+            else:
+                raise ValueError(f"PNG: filter type {ft}")
+        out[r] = cur
+        prev = cur
+    return out
+
+
+def _samples(lines: np.ndarray, width: int, depth: int, n: int) -> np.ndarray:
+    """Unfiltered rows -> [rows, width, n] raw sample values (not yet scaled)."""
+    rows = lines.shape[0]
+    if depth == 8:
+        return lines[:, :width * n].reshape(rows, width, n).astype(np.uint16)
+    if depth == 16:
+        b = lines[:, :width * n * 2].reshape(rows, width, n, 2).astype(np.uint16)
+        return (b[..., 0] << 8) | b[..., 1]
+    bits = np.unpackbits(lines, axis=1)[:, :width * n * depth].reshape(rows, width * n, depth)
+    vals = np.zeros((rows, width * n), np.uint16)
+    for k in range(depth):
+        vals = (vals << 1) | bits[..., k]
+    return vals.reshape(rows, width, n)
+
+
+def read_png(path: str) -> np.ndarray:
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:8] != _SIGNATURE:
+        raise ValueError(f"{path}: not a PNG file")
+    at = 8
+    ihdr = None; idat = []; palette = None; trns = None
+    while at + 8 <= len(data):
+        n, kind = struct.unpack(">I4s", data[at:at + 8])
+        body = data[at + 8:at + 8 + n]
+        at += 12 + n
+        if kind == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif kind == b"PLTE":
+            palette = np.frombuffer(body, np.uint8).reshape(-1, 3)
+        elif kind == b"tRNS":
+            trns = body
+        elif kind == b"IDAT":
+            idat.append(body)
+        elif kind == b"IEND":
+            break
+    if ihdr is None or not idat:
+        raise ValueError(f"{path}: PNG without IHDR / IDAT")
+    width, height, depth, ctype, _, _, interlace = ihdr
+    if ctype not in _CHANNELS or depth not in (1, 2, 4, 8, 16):
+        raise ValueError(f"{path}: PNG colour type {ctype} / bit depth {depth}")
+    n = _CHANNELS[ctype]
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8)
+    bpp = max(1, n * depth // 8)
+    if interlace == 0:
+        stride = (width * n * depth + 7) // 8
+        vals = _samples(_unfilter(raw, height, stride, bpp), width, depth, n)
+    else:                                                                                    # Adam7
+        vals = np.zeros((height, width, n), np.uint16)
+        at = 0
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            w = (width - x0 + dx - 1) // dx; h = (height - y0 + dy - 1) // dy
+            if w <= 0 or h <= 0:
+                continue
+            stride = (w * n * depth + 7) // 8
+            size = h * (1 + stride)
+            vals[y0::dy, x0::dx] = _samples(_unfilter(raw[at:at + size], h, stride, bpp), w, depth, n)
+            at += size
+    if ctype == 3:                                                                           # palette -> RGB(A)
+        if palette is None:
+            raise ValueError(f"{path}: palette image without PLTE")
+        idx = vals[..., 0].astype(np.int64)
+        out = palette[np.minimum(idx, len(palette) - 1)]
+        if trns is not None:
+            alpha = np.full(len(palette), 255, np.uint8); alpha[:len(trns)] = np.frombuffer(trns, np.uint8)[:len(palette)]
+            out = np.concatenate([out, alpha[np.minimum(idx, len(palette) - 1)][..., None]], -1)
+        return np.ascontiguousarray(out.astype(np.uint8))
+    key = None
+    if trns is not None and ctype in (0, 2):                                                 # a colour key: stb adds an alpha channel
+        key = np.asarray(struct.unpack(">" + "H" * n, trns[:2 * n]), np.uint16)
+    if depth == 16:
+        out = (vals >> 8).astype(np.uint8)
+    elif depth == 8:
+        out = vals.astype(np.uint8)
+    else:
+        out = (vals * (255 // ((1 << depth) - 1))).astype(np.uint8)
+    if key is not None:
+        alpha = np.where(np.all(vals == key, axis=-1), 0, 255).astype(np.uint8)
+        out = np.concatenate([out, alpha[..., None]], -1)
+    return np.ascontiguousarray(out)
+
+
+def write_png(path: str, pixels) -> None:
+    """[height, width(, channels 1..4)] uint8 -> an 8-bit non-interlaced PNG (tests and stand-in textures)."""
+    a = np.asarray(pixels, np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    raw = b"".join(b"\x00" + a[r].tobytes() for r in range(h))
+    chunk = lambda k, b: struct.pack(">I", len(b)) + k + b + struct.pack(">I", zlib.crc32(k + b) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(_SIGNATURE + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))

@@ -321,21 +321,47 @@ def closest_point_triangle(p, a, b, c):
     return ((a + v * ab) + w * ac).astype(F32), np.asarray([(one - v) - w, v, w], F32)
 
 
+def closest_points_all(verts, faces, q):
+    """closest_point_triangle for every triangle at once (numpy float32, operation for operation the scalar function above: its
+    branches become masks taken in the same order): distances [F] and barycentrics [F,3]."""
+    one, zero = F32(1.0), F32(0.0)
+    a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    dot = lambda x, y: x[:, 0] * y[:, 0] + (x[:, 1] * y[:, 1] + x[:, 2] * y[:, 2])
+    ab = b - a; ac = c - a; ap = q - a; bp = q - b; cp = q - c; bc = c - b
+    d1 = dot(ab, ap); d2 = dot(ac, ap); d3 = dot(ab, bp); d4 = dot(ac, bp); d5 = dot(ab, cp); d6 = dot(ac, cp)
+    vc = d1 * d4 - d3 * d2; vb = d5 * d2 - d1 * d6; va = d3 * d6 - d5 * d4
+    with np.errstate(divide="ignore", invalid="ignore"):
+        v_ab = d1 / (d1 - d3); v_ac = d2 / (d2 - d6); v_bc = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+        denom = one / ((va + vb) + vc)
+    v_in = vb * denom; w_in = vc * denom
+    conds = [(d1 <= 0) & (d2 <= 0), (d3 >= 0) & (d4 <= d3), (d6 >= 0) & (d5 <= d6), (vc <= 0) & (d1 >= 0) & (d3 <= 0),
+             (vb <= 0) & (d2 >= 0) & (d6 <= 0), (va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0)]
+    n = faces.shape[0]
+    z = np.zeros(n, F32); o1 = np.ones(n, F32)
+    pts = [a, b, c, a + v_ab[:, None] * ab, a + v_ac[:, None] * ac, b + v_bc[:, None] * bc, (a + v_in[:, None] * ab) + w_in[:, None] * ac]
+    uvws = [np.stack([o1, z, z], -1), np.stack([z, o1, z], -1), np.stack([z, z, o1], -1), np.stack([one - v_ab, v_ab, z], -1),
+            np.stack([one - v_ac, z, v_ac], -1), np.stack([z, one - v_bc, v_bc], -1), np.stack([(one - v_in) - w_in, v_in, w_in], -1)]
+    region = np.full(n, 6)
+    for k in range(5, -1, -1):
+        region = np.where(conds[k], k, region)
+    pt = np.choose(region[:, None], [p.astype(F32) for p in pts]); uvw = np.choose(region[:, None], [u.astype(F32) for u in uvws])
+    e = q - pt
+    with np.errstate(invalid="ignore"):
+        d = np.sqrt(e[:, 0] * e[:, 0] + (e[:, 1] * e[:, 1] + e[:, 2] * e[:, 2]))
+    return d.astype(F32), uvw
+
+
 def closest_point_on_mesh(verts, faces, q, radius):
     """rtcPointQuery with closest_point_query_function (instancer.cpp:200-230, 644-654): the triangle whose closest point lies nearest
     to q, strictly within `radius` (the callback shrinks the radius: d < radius); (primID, barycentrics) or (None, None).  Embree
     calls back in the order of its BVH walk; here the triangles come in ascending order, so that of several at one distance the
     lowest primID stays."""
-    best, best_f, best_w = F32(radius), None, None
-    with np.errstate(divide="ignore", invalid="ignore"):
-        for k in range(faces.shape[0]):
-            f = faces[k]
-            pt, uvw = closest_point_triangle(q, verts[f[0]], verts[f[1]], verts[f[2]])
-            e = q - pt
-            d = np.sqrt(e[0] * e[0] + (e[1] * e[1] + e[2] * e[2]))                     # (q - p).norm()
-            if d < best:
-                best, best_f, best_w = d, k, uvw
-    return best_f, best_w
+    d, uvw = closest_points_all(verts, faces, np.asarray(q, F32))
+    d = np.where(np.isnan(d), F32(np.inf), d)
+    k = int(np.argmin(d))                                                                # the first of the smallest
+    if not d[k] < F32(radius):
+        return None, None
+    return k, uvw[k]
 
 
 def interpolate2d(x, y_ref):

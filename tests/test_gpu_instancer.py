@@ -36,13 +36,54 @@ def run_gpu(inst, o, d, params, S, h, seed, ray_index=None):
     return res
 
 
+def oracle_textures(textures):
+    """The constructor's `textures` list for the restatement: pixel arrays become named images decoded by the ORACLE's loadTexture."""
+    names, images = [], {}
+    for i, t in enumerate(textures):
+        if isinstance(t, str):
+            names.append(t)
+        else:
+            names.append(f"#{i}"); images[f"#{i}"] = io.texture_from_pixels(t)
+    return names, images
+
+
 def run_oracle(inst, box, o, d, params, S, h, seed, method="random", textures=(), mean=False, mesh=None, ray_index=None, patch_scale=1.0,
-               **shadow):
-    spec = io.make_spec(box["b_0"], box["b_1"], None, textures=textures, instance_sampling_method=method, use_mean_distance=mean,
-                        mesh=mesh, matrices=inst.matrices(), **shadow)
+               tex_mesh=None, aux_pixels=None, **kw):
+    """`tex_mesh` = (vertices, faces, uv): DistributeInstancesOnMesh's state (parameter textures apply); `aux_pixels`: the pixel arrays
+    of the auxiliary meshes' textures, in the order of the instancer's texture sets; kw: shadow / texture sample counts."""
+    names, images = oracle_textures(textures)
+    if mesh is not None and len(mesh) > 2 and inst.mesh_prim is not None:
+        kw = dict(kw, mesh_prim=inst.mesh_prim)
+    if aux_pixels is not None:
+        kw = dict(kw, mesh_uv=inst.mesh_uv, mesh_tex=inst.mesh_tex, aux_textures=[io.texture_from_pixels(px) for px in aux_pixels])
+    spec = io.make_spec(box["b_0"], box["b_1"], None, textures=names, images=images, instance_sampling_method=method, use_mean_distance=mean,
+                        mesh=mesh, matrices=inst.matrices(), instancer_mesh=tex_mesh, patch_scale=patch_scale, **kw)
     spec.patch_scale = patch_scale
     n = o.shape[0]
     return list(io.get_model_input(spec, o, d, params, S, h, io.offset_uniforms(n, seed, ray_index), io.choice_uniforms(n, S, seed, ray_index)))
+
+
+def wavy_sheet(n=9, extent=1.7, amp=0.07, z0=-0.12):
+    """A waving sheet under the patches of `random_scene` as (vertices, faces, uv): the instancer mesh parameter textures are looked up
+    on; the texture coordinates are sheared so that neither axis of the image follows an axis of the world."""
+    xs = np.linspace(-extent, extent, n)
+    x, y = np.meshgrid(xs, xs, indexing="ij")
+    z = z0 + amp * np.sin(1.7 * x) * np.cos(1.3 * y)
+    v = np.stack([x, y, z], -1).reshape(-1, 3).astype(F)
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c, e = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    f = np.concatenate([np.stack([a, b, c], -1), np.stack([a, c, e], -1)]).astype(np.int32)
+    u = (x + extent) / (2 * extent); w = (y + extent) / (2 * extent)
+    uv = np.stack([0.8 * u + 0.2 * w, 0.1 * u + 0.9 * w], -1).reshape(-1, 2).astype(F)
+    return v, f, uv
+
+
+def random_pixels(seed, h=12, w=16, c=1):
+    """A smooth random image: neighbouring texels differ, so a wrong axis, flip or texel shows."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.linspace(0, 1, h), np.linspace(0, 1, w), indexing="ij")
+    img = np.stack([0.5 + 0.25 * np.sin(6 * xx * rng.uniform(.5, 1.5) + k) + 0.25 * np.cos(5 * yy * rng.uniform(.5, 1.5) - k) for k in range(c)], -1)
+    return np.clip(img * 255 + rng.integers(-6, 7, size=img.shape), 0, 255).astype(np.uint8)
 
 
 def assert_same(got, want):
@@ -180,7 +221,9 @@ def test_overflow_flags_and_refusals(tmp_path):
     assert inst.status() == 0
     assert_same(out, want)
     assert out[6].max() == 90                                                    # density_weight = patches the point lies in
-    for kw in (dict(textures=["meshes/smooth_checkerboard.png"]), dict(auxiliary_meshes=[("a.ply", "meshes/checkerboard.png")])):
+    with pytest.raises(OSError):                                                 # an image file that is not there
+        Instancer(UNIT["b_0"], UNIT["b_1"], transformations=[translate().tolist()], textures=["meshes/smooth_checkerboard.png"])
+    for kw in (dict(textures=["a.jpg"]), dict(textures=[random_pixels(k) for k in range(5)])):     # not a PNG; five texture files
         with pytest.raises(_lib.NtxError) as e:
             Instancer(UNIT["b_0"], UNIT["b_1"], transformations=[translate().tolist()], **kw)
         assert e.value.code == _lib.NTX_E_UNSUPPORTED
@@ -518,3 +561,111 @@ def test_patches_distributed_on_a_mesh_file(tmp_path):
     assert out[8].all() and (out[5] == 1).all() and (out[3] > 0).sum() > 8       # marches the patches, ends on the sheet
     c = Instancer(b_0, b_1, mesh_path=str(mesh), patch_scale=-1.0)                 # no anchors: a patch per vertex; scale = the average edge length
     assert c.n_instances() == 64 and 0.1 < c.patch_scale < 0.2
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# image textures (ABI v5): parameter textures on the instancer mesh, textured auxiliary meshes
+# ------------------------------------------------------------------------------------------------------------------------------
+
+def test_texture_known_answers_on_the_kernel():
+    """The hand-computed cases of tests/test_oracle_instancer.py (a ramp texture on a flat sheet, two patches side by side), from the
+    kernel: a query per step, and the two-segment interpolation."""
+    from nerf_tex_amd.instancer import Instancer
+    v = F([[-2, -2, 0], [2, -2, 0], [2, 2, 0], [-2, 2, 0]]); f = [[0, 1, 2], [0, 2, 3]]
+    uv = (v[:, :2] + 2) / 4
+    ramp_px = np.tile(np.asarray([0, 64, 128, 191, 255], np.uint8)[None, :], (3, 1))       # [height 3, width 5]: value = u
+    o, d, par = F([[-3, 0, .5]]), F([[1, 0, 0]]), F([[2.0, 7.0, 0, 0, 1]])
+    tr = [translate(x=-1).tolist(), translate(x=1).tolist()]
+    for n_tex in (100000, 2):
+        inst = Instancer([-1, -1, 0], [1, 1, 1], textures=[ramp_px, "", "light"], transformations=tr, instancer_mesh=(v, f, uv), patch_scale=1.0,
+                         n_texture_samples=n_tex, min_texture_samples=4)
+        assert inst.n_parameters == 5 and np.isclose(inst.patch_max_extent, np.sqrt(3))
+        got = run_gpu(inst, o, d, par, 16, 0.5, seed=3)
+        t = got[2][0]
+        x = -3 + t[:8]
+        assert np.allclose(got[9][0, :8, 0], 2 * (x + 2) / 4, atol=6e-3) and (got[9][0, 8:] == par[0]).all()     # the 8-bit ramp is u within 1 / 255
+        box = dict(b_0=[-1, -1, 0], b_1=[1, 1, 1])
+        want = run_oracle(inst, box, o, d, par, 16, 0.5, 3, textures=[ramp_px, "", "light"], mesh=(v, f), tex_mesh=(v, f, uv), patch_scale=1.0,
+                          n_texture_samples=n_tex, min_texture_samples=4)
+        assert_same(got, want)
+
+
+@pytest.mark.parametrize("n_texture_samples", [24, 100000])                    # interpolated between texture samples / a lookup per step
+@pytest.mark.parametrize("channels", [1, 3])
+@pytest.mark.parametrize("shadows", [False, True])
+def test_parameter_textures_bit_for_bit(n_texture_samples, channels, shadows):
+    """getParameters (instancer.cpp:640-667) through GetModelInput: two texture files (the first of `channels` channels -- the
+    reference multiplies ONE parameter per file, by entry i of its list of all channels, :656-662), a light, with and without shadow
+    rays; the lookups at the closest point of a waving, sheared-uv instancer mesh; every buffer bit for bit."""
+    spec0 = random_scene(61, k=24, method="nearest")
+    box = dict(b_0=spec0.b_0.tolist(), b_1=spec0.b_1.tolist())
+    tr = [np.linalg.inv(m.astype(np.float64)).astype(F) for m in spec0.inv]
+    tex_mesh = wavy_sheet()
+    textures = [random_pixels(1, c=channels), "", random_pixels(2, h=9, w=7), "light"]
+    tkw = dict(n_texture_samples=n_texture_samples, min_texture_samples=5)
+    sh = dict(cast_shadow_rays=True, min_shadow_samples=4, n_shadow_samples=48) if shadows else {}
+    patch_scale = 0.35
+    inst = gpu_instancer(box, tr, textures=textures, instance_sampling_method="nearest", instancer_mesh=tex_mesh, patch_scale=patch_scale, **tkw, **sh)
+    P = inst.n_parameters
+    assert P == channels + 1 + 1 + 3 and inst.tex_idx == [0, channels + 1]
+    n, S, h = 140, 128, 0.02
+    o, d = random_rays(61, n)
+    rng = np.random.default_rng(61)
+    params = rng.uniform(0.3, 2.0, size=(n, P)).astype(F)
+    light = rng.normal(size=(n, 3)); light[:, 2] = np.abs(light[:, 2]) * 0.7 + 0.1
+    params[:, P - 3:] = light
+    got = run_gpu(inst, o, d, params, S, h, seed=8)
+    want = run_oracle(inst, box, o, d, params, S, h, 8, "nearest", textures, False, (tex_mesh[0], tex_mesh[1]), tex_mesh=tex_mesh,
+                      patch_scale=patch_scale, **tkw, **sh)
+    emitted = want[2] > 0
+    ratio = want[9][..., 0][emitted] / np.repeat(params[:, None, 0], S, 1)[emitted]
+    assert emitted.sum() > 2000 and ratio.min() < 0.3 and ratio.max() > 0.7 and len(np.unique(ratio)) > 500      # the texture shows
+    if channels == 3:
+        assert np.array_equal(want[9][..., 1][emitted], np.repeat(params[:, None, 1], S, 1)[emitted]) or n_texture_samples < S   # green, blue: never multiplied
+    assert_same(got, want)
+    assert inst.status() == 0
+
+
+@pytest.mark.parametrize("channels,shadows", [(1, False), (3, False), (3, True), (4, True)])
+def test_textured_auxiliary_meshes_bit_for_bit(channels, shadows):
+    """AddMesh's texture (instancer.cpp:404, 725-733): the albedo of the closing sample at the hit's texture coordinates, three
+    channels or the first for all; a second auxiliary mesh without a texture keeps 0.8."""
+    spec0 = random_scene(71, k=16, method="nearest", textures=("", "light"), mesh=True)
+    box = dict(b_0=spec0.b_0.tolist(), b_1=spec0.b_1.tolist())
+    tr = [np.linalg.inv(m.astype(np.float64)).astype(F) for m in spec0.inv]
+    unit = lambda v: (np.asarray(v, F) / np.linalg.norm(v)).astype(F)
+    roof = (F([[-1.5, -1.5, 0.9], [0.2, -1.5, 1.3], [0.2, 1.5, 1.3], [-1.5, 1.5, 0.9]]), [[0, 1, 2], [0, 2, 3]],
+            np.stack([unit([-0.23, 0.05 * k, 0.97]) for k in range(4)]), F([[0.1, 0.05], [0.9, 0.2], [0.95, 0.85], [0.05, 0.9]]))
+    wall = (F([[0.9, -1.5, -0.1], [0.9, 1.5, -0.1], [0.9, 1.5, 0.8], [0.9, -1.5, 0.8]]), [[0, 1, 2], [0, 2, 3]], np.tile(unit([-1, 0, 0.1]), (4, 1)))
+    px = random_pixels(5, h=10, w=14, c=channels)
+    sh = dict(cast_shadow_rays=True, min_shadow_samples=4, n_shadow_samples=64) if shadows else {}
+    from nerf_tex_amd.instancer import Instancer
+    inst = Instancer(box["b_0"], box["b_1"], textures=["", "light"], transformations=[m.tolist() for m in tr], instance_sampling_method="nearest",
+                     mesh=(spec0.mesh_v, spec0.mesh_f), auxiliary_meshes=[(roof, px), (wall, "")], **sh)
+    v, f, nrm, kind = inst.meshes
+    assert kind.tolist() == [0, 0, 1, 1, 1, 1] and inst.mesh_tex.tolist() == [-1, -1, 0, 0, -1, -1] and inst.mesh_prim.tolist() == [0, 1] * 3
+    n, S, h = 160, 64, 0.03
+    o, d = random_rays(71, n)
+    rng = np.random.default_rng(71)
+    params = rng.uniform(0.2, 1.0, size=(n, 4)).astype(F)
+    light = rng.normal(size=(n, 3)); light[:, 2] = np.abs(light[:, 2]) * 0.7 + 0.2
+    params[:, 1:4] = light
+    got = run_gpu(inst, o, d, params, S, h, seed=6)
+    want = run_oracle(inst, box, o, d, params, S, h, 6, "nearest", ("", "light"), False, (v, f, nrm, kind), aux_pixels=[px], **sh)
+    col = want[4][:, 0]
+    lit = col.max(-1) > 0
+    assert lit.sum() > 20 and len(np.unique(col[lit, 0])) > 10
+    if channels == 3:
+        assert (np.abs(col[lit, 0] - col[lit, 1]) > 1e-3).any()                   # an RGB texture colours the sample
+    else:
+        assert np.array_equal(col[:, 0], col[:, 1]) and np.array_equal(col[:, 0], col[:, 2])
+    assert_same(got, want)
+
+
+def write_ply(path, v, f, normals=None, uv=None):
+    cols = ["x", "y", "z"] + (["nx", "ny", "nz"] if normals is not None else []) + (["s", "t"] if uv is not None else [])
+    rows = np.concatenate([np.asarray(v, F)] + ([np.asarray(normals, F)] if normals is not None else []) + ([np.asarray(uv, F)] if uv is not None else []), -1)
+    with open(path, "w") as fh:
+        fh.write("ply\nformat ascii 1.0\nelement vertex %d\n" % len(rows) + "".join(f"property float {c}\n" for c in cols)
+                 + "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % len(f)
+                 + "".join(" ".join(repr(float(x)) for x in r) + "\n" for r in rows) + "".join(f"3 {t[0]} {t[1]} {t[2]}\n" for t in f))

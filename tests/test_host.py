@@ -762,12 +762,29 @@ def test_instancer_host_side(tmp_path):
     binary_little_endian, extra properties, polygons fanned), the ABI v4 symbols and argument checks that need no device."""
     import struct
     from nerf_tex_amd import _lib, instancer as ins
-    assert ins.parse_textures(['', '', '', '', 'light']) == (7, 4, -1)            # config_carpet_render.py:86 without its image
-    assert ins.parse_textures(['', 'point']) == (5, 2, 1)                          # config_grass_render.py:93
-    assert ins.parse_textures([]) == (0, -1, -1)
+    assert ins.parse_textures(['', '', '', '', 'light'])[:3] == (7, 4, -1)        # config_carpet_render.py:86 without its image
+    assert ins.parse_textures(['', 'point'])[:3] == (5, 2, 1)                      # config_grass_render.py:93
+    assert ins.parse_textures([]) == (0, -1, -1, [], [])
     with pytest.raises(_lib.NtxError) as e:
-        ins.parse_textures(['meshes/smooth_checkerboard.png'])
+        ins.parse_textures(['meshes/smooth_checkerboard.jpg'])                     # PNG only
     assert e.value.code == _lib.NTX_E_UNSUPPORTED
+    # image entries (ABI v5): the carpet config's list with a one-channel image in front, the plush config's with one in the middle
+    from nerf_tex_amd.png import read_png, write_png
+    from oracle import instancer_oracle as io
+    grey = (np.arange(35, dtype=np.uint8) * 7).reshape(5, 7)
+    write_png(str(tmp_path / "grey.png"), grey)
+    rgb = np.random.default_rng(0).integers(0, 256, size=(4, 6, 3), dtype=np.uint8)
+    write_png(str(tmp_path / "rgb.png"), rgb)
+    assert np.array_equal(read_png(str(tmp_path / "grey.png"))[..., 0], grey) and np.array_equal(read_png(str(tmp_path / "rgb.png")), rgb)
+    n, ld, ls, idx, mats = ins.parse_textures([str(tmp_path / "grey.png"), '', '', '', 'light'])            # config_carpet_render.py:86
+    assert (n, ld, ls, idx) == (7, 4, -1, [0]) and len(mats) == 1 and mats[0].shape == (7, 5)                # [width, height]
+    assert mats[0][2, 0] == np.float32(grey[4, 2]) / np.float32(255)                                         # (x = 2, y = 0 from the BOTTOM row)
+    n, ld, ls, idx, mats = ins.parse_textures(['', str(tmp_path / "rgb.png"), 'light'])                      # config_plush_render.py:100 with an RGB image
+    assert (n, ld, ls, idx) == (7, 4, -1, [1]) and len(mats) == 3
+    for got, want in zip(mats, io.texture_from_pixels(rgb)):                                                 # the product's loader = the restatement's
+        assert np.array_equal(got, want)
+    for got, want in zip(ins.load_texture(str(tmp_path / "rgb.png")), io.load_texture(str(tmp_path / "rgb.png"))):   # ... whose decoder is PIL
+        assert np.array_equal(got, want)
     v = np.asarray([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0.5]], np.float32)
     a = tmp_path / "a.ply"
     a.write_text("ply\nformat ascii 1.0\ncomment made by hand\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
