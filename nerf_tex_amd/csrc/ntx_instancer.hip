@@ -1621,7 +1621,9 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
             if (opts->ray_index0 < 0 || opts->ray_run_length < 1 || opts->ray_run_stride < opts->ray_run_length)
                 return ntx_set_error(NTX_E_INVALID, "bad ray index map");
             idx0 = opts->ray_index0; idx_stride = opts->ray_run_stride;
-            idx_run = opts->ray_run_length > 0xffffffffLL ? 0xffffffffu : (uint32_t)opts->ray_run_length;
+            // a call that lies inside its first run is a plain offset (what a renderer's chunk k0 .. k0 + n passes as (k0, n, n)): it can
+            // then be cut into pieces anywhere
+            idx_run = (opts->ray_run_length > 0xffffffffLL || opts->ray_run_length >= n_rays) ? 0xffffffffu : (uint32_t)opts->ray_run_length;
         }
     }
     // a call longer than the workspace is cut into pieces; every piece must start on a run boundary of the index map (checked

@@ -125,6 +125,7 @@ class Instancer:
         # only DistributeInstancesOnMesh stores the scale (instancer.cpp:236); it widens nearest_blend's transition (:697)
         self.patch_scale = float(patch_scale) if distributed else 1.0
         self.n_parameters = n_par
+        self._light_dir_idx, self._light_strength_idx = light_dir, light_strength
         self.device = int(device)
         self.seed = int(seed)
         self._calls = 0

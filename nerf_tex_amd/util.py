@@ -72,12 +72,13 @@ _REMAP = {
     "network.render.Render": "nerf_tex_amd.render.Render",
     "network.dataset.Dataset": "nerf_tex_amd.dataset.Dataset",
     "network.dataset.GenerateData": "nerf_tex_amd.dataset.GenerateData",
+    "instancer.instancer.Instancer": "nerf_tex_amd.instancer.Instancer",
 }
 
 
 def remap_reference_config(config: dict) -> EasyDict:
     """Deep-copy a reference config dict, pointing every hot-path `'module'` at this package.
-    Modules without a drop-in (Logger, Instancer, losses ...) are left untouched."""
+    Modules without a drop-in (Logger, losses ...) are left untouched."""
 
     def walk(node):
         if isinstance(node, dict):

@@ -14,6 +14,9 @@
   (4) golden_plumbing.npz     -- BASELINE configs[0]: carpet 200x200x32 image, float64 oracle, stored
       as float32 RGBA, plus the float32 oracle's image and its rel-Linf distance from the float64 one, plus the image of
       the float64 network on the float32 sample points (`rgba_net64`; nerftex_oracle.render_rays: points_dtype).
+  (5) renderer_configs.json  -- the `renderer_config` blocks (with their `instancer_config`) of the reference's four shipped render
+      configs, as the reference's own `configs/*.py` evaluate (data: keywords, numbers, file names), so that tests can hand them to
+      this package verbatim.
 Parts (2)-(4) are outputs of THIS repo's oracle (parity unpinned, see nerftex_oracle.py): they pin the
 oracle against drift and give the GPU tests fixed vectors, they do not pin it to TensorFlow."""
 
@@ -34,6 +37,18 @@ OUT = os.path.join(ROOT, "tests", "golden")
 
 from oracle import nerftex_oracle as orc          # noqa: E402
 from nerf_tex_amd import synthetic                # noqa: E402  (seeded weights: shared by tests and bench)
+
+
+def renderer_configs():
+    """Part (5): the shipped render configs' renderer blocks, from the reference's own config modules."""
+    sys.path.insert(0, REF)
+    out = {}
+    for fam in ("carpet", "grass", "grass_filtered", "plush"):
+        cfg = importlib.import_module(f"configs.config_{fam}_render").config
+        out[fam] = {"source": f"configs/config_{fam}_render.py", "renderer_config": cfg["renderer_config"],
+                    "model_n_parameters": cfg["model_config"]["n_parameters"]}
+    with open(os.path.join(OUT, "renderer_configs.json"), "w") as f:
+        json.dump(out, f, indent=1)
 
 
 def cameras():
@@ -180,8 +195,12 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["plumbing"]:                   # regenerate part (4) alone
         plumbing()
         sys.exit(0)
+    if sys.argv[1:] == ["renderer_configs"]:           # part (5) alone
+        renderer_configs()
+        sys.exit(0)
     cameras()
     for fam in ("carpet", "grass", "fur", "grass_filtered"):
         small(fam)
     edge()
     plumbing()
+    renderer_configs()

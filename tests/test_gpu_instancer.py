@@ -201,10 +201,13 @@ def test_rays_can_be_split_and_sharded():
     tail = run_gpu(inst, ob[65_000:], db[65_000:], np.zeros((5_000, 0), F), 8, 0.2, seed=4, ray_index=(65_000, 5_000, 5_000))
     assert_same([x[65_000:] for x in outb], tail)
     assert outb[8][65_536:].any()
+    # a chunk of a larger call as its renderer passes it, (k0, n, n), is a plain offset and splits anywhere (render_chunk > 65 536)
+    chunk = run_gpu(inst, ob, db, np.zeros((big, 0), F), 8, 0.2, seed=4, ray_index=(0, big, big))
+    assert_same(chunk, outb)
     # a split call's pieces must start on run boundaries of the index map: refused before anything is launched
     from nerf_tex_amd import _lib
     with pytest.raises(_lib.NtxError) as e:
-        inst.get_model_input(ob, db, np.zeros((big, 0), F), 8, 0.2, seed=4, ray_index=(0, 1000, 1000))
+        inst.get_model_input(ob, db, np.zeros((big, 0), F), 8, 0.2, seed=4, ray_index=(0, 1000, 2000))
     assert e.value.code == _lib.NTX_E_INVALID and "ray_run_length" in str(e.value)
 
 
@@ -281,7 +284,8 @@ def test_instance_renderer_end_to_end(npar, textures, blur, precision):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("NTX_INSTANCER_FUZZ_SEEDS", "16"))))     # a soak run sets more (profiles/r03/soak_instancer.txt)
 def test_fuzz_scenes_bit_for_bit(seed):
     """Random scenes, ray sets and settings (patch count, box, scales, step size, buffer length incl. too short ones, choice rule,
-    lights, mean distances, mesh, shadow rays in both modes, rays that start inside the patch layer): every buffer bit for bit."""
+    lights, mean distances, mesh, shadow rays in both modes, rays that start inside the patch layer, image textures as parameters --
+    interpolated or per step, one or more channels -- and on auxiliary meshes): every buffer bit for bit."""
     rng = np.random.default_rng(1000 + seed)
     k = int(rng.integers(3, 48))
     method = ["random", "nearest", "nearest_blend"][seed % 3]
@@ -295,27 +299,50 @@ def test_fuzz_scenes_bit_for_bit(seed):
     msh = (spec0.mesh_v, spec0.mesh_f) if mesh else None
     sh = dict(cast_shadow_rays=True, min_shadow_samples=int(rng.integers(2, 9)), n_shadow_samples=int(rng.choice([16, 64, 100000]))) if shadows else {}
     aux = bool(textures) and bool(rng.integers(0, 2))                            # an auxiliary mesh (shaded closing sample) needs a light
-    kw = {}
+    kw, okw = {}, {}
+    # parameter textures (drawn after everything above, so that the scenes of earlier rounds' soaks stay what they were): one to three
+    # image entries in front of / between the others, looked up on a waving sheet that then is the instancer mesh
+    tex_mode = int(rng.integers(0, 3))                                           # 0: none, 1: interpolated, 2: per step
+    patch_scale = 1.0
+    textures = list(textures)
+    if tex_mode:
+        for _ in range(int(rng.integers(1, 4))):
+            textures.insert(int(rng.integers(0, len(textures) + 1)), random_pixels(int(rng.integers(0, 1000)), h=int(rng.integers(2, 12)), w=int(rng.integers(2, 12)),
+                                                                                 c=int(rng.choice([1, 1, 2, 3, 4]))))
+        tex_mesh = wavy_sheet(n=int(rng.integers(3, 10)), amp=float(rng.uniform(0, 0.15)), z0=float(rng.uniform(-0.3, 0.1)))
+        patch_scale = float(rng.choice([0.2, 0.45, 1.0]))                        # the lookup radius: some points find no triangle within reach
+        tkw = dict(min_texture_samples=int(rng.integers(2, 9)), n_texture_samples=int(rng.choice([8, 40])) if tex_mode == 1 else 100000)
+        kw.update(instancer_mesh=tex_mesh, patch_scale=patch_scale, **tkw)
+        okw.update(tex_mesh=tex_mesh, **tkw)
+        msh = (tex_mesh[0], tex_mesh[1])                                         # DistributeInstancesOnMesh's mesh is the culling mesh (:379)
+        kw["mesh"] = None
     if aux:
         z0, z1 = rng.uniform(0.3, 1.2, size=2)
         nv = rng.normal(size=(4, 3)) * 0.2 + [0, 0, 1]
-        kw["auxiliary_meshes"] = [((F([[-1.5, -1.5, z0], [1.5, -1.5, z1], [1.5, 1.5, z1], [-1.5, 1.5, z0]]), [[0, 1, 2], [0, 2, 3]],
-                                    (nv / np.linalg.norm(nv, axis=-1, keepdims=True)).astype(F)), "")]
-    inst = gpu_instancer(box, tr, textures=list(textures), instance_sampling_method=method, use_mean_distance=mean, mesh=msh, **sh, **kw)
+        quad = (F([[-1.5, -1.5, z0], [1.5, -1.5, z1], [1.5, 1.5, z1], [-1.5, 1.5, z0]]), [[0, 1, 2], [0, 2, 3]], (nv / np.linalg.norm(nv, axis=-1, keepdims=True)).astype(F))
+        if tex_mode and rng.integers(0, 2):                                      # ... with its own texture
+            px = random_pixels(int(rng.integers(0, 1000)), h=5, w=6, c=int(rng.choice([1, 3, 4])))
+            kw["auxiliary_meshes"] = [(quad + (rng.uniform(0, 1, size=(4, 2)).astype(F),), px)]
+            okw["aux_pixels"] = [px]
+        else:
+            kw["auxiliary_meshes"] = [(quad, "")]
+    if "mesh" not in kw:
+        kw["mesh"] = msh
+    inst = gpu_instancer(box, tr, textures=textures, instance_sampling_method=method, use_mean_distance=mean, **sh, **kw)
     if aux:
         msh = inst.meshes                                                        # (vertices, faces, normals, kind) as the library holds them
     n = 48
     o, d = random_rays(200 + seed, n)
-    if not shadows:                      # (a segment the ray never leaves has no length in the reference: instancer.cpp:1019 reads past its list)
+    if not shadows and not tex_mode:     # (a segment the ray never leaves has no length in the reference: instancer.cpp:990, 1001 read past its list)
         o[:6] = o[:6] * F(0.15)                                                  # six rays start inside the layer of patches
     d[6:9] = d[6:9] * F(rng.uniform(0.5, 2.0))                                   # rays_d is used as given (un-normalised rays march in their own units)
     S = int(rng.choice([7, 33, 64, 100, 257]))
     h = float(rng.choice([0.004, 0.01, 0.05, 0.7]))
-    P = spec0.n_parameters
+    P = inst.n_parameters
     params = rng.uniform(0.1, 2.0, size=(n, P)).astype(F)
     seed64 = int(rng.integers(0, 2 ** 62))
     got = run_gpu(inst, o, d, params, S, h, seed=seed64)
-    want = run_oracle(inst, box, o, d, params, S, h, seed64, method, textures, mean, msh, **sh)
+    want = run_oracle(inst, box, o, d, params, S, h, seed64, method, textures, mean, msh, patch_scale=patch_scale, **sh, **okw)
     assert_same(got, want)
     assert inst.status() == 0
 
@@ -669,3 +696,104 @@ def write_ply(path, v, f, normals=None, uv=None):
         fh.write("ply\nformat ascii 1.0\nelement vertex %d\n" % len(rows) + "".join(f"property float {c}\n" for c in cols)
                  + "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % len(f)
                  + "".join(" ".join(repr(float(x)) for x in r) + "\n" for r in rows) + "".join(f"3 {t[0]} {t[1]} {t[2]}\n" for t in f))
+
+
+def stand_in_scene(fam, root):
+    """Stand-ins for the files a shipped render config names (LFS pointers in the reference's repository), written under root/meshes:
+    a small waving sheet with normals and texture coordinates for the mesh, a few anchor points near it, a smooth one-channel image."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.png import write_png
+    os.makedirs(os.path.join(root, "meshes"), exist_ok=True)
+    grid, extent = (7, 0.30) if fam != "plush" else (6, 0.10)
+    scale = 0.09 if fam != "plush" else 0.04
+    tr0, v, f = synthetic.patch_sheet(grid, extent=extent, scale=scale)
+    if fam == "plush":                                                            # a finer relief for the smaller patches
+        v = v.copy(); v[:, 2] *= 0.25; tr0 = tr0.copy()
+    nrm = tr0[:, :3, 2] / np.linalg.norm(tr0[:, :3, 2], axis=-1, keepdims=True)
+    uv = ((v[:, :2] + extent) / (2 * extent)).astype(F)
+    files = {"carpet": ("cloth_mesh.ply", "cloth_anchor_points.ply", "smooth_checkerboard.png"), "grass": ("terrain_mesh.ply", "terrain_anchor_points.ply", None),
+             "grass_filtered": ("terrain_mesh.ply", "terrain_anchor_points.ply", None), "plush": ("stanford_bunny.ply", None, "checkerboard.png")}[fam]
+    write_ply(os.path.join(root, "meshes", files[0]), v, f, nrm, uv)
+    origins = None
+    if files[1]:
+        rng = np.random.default_rng(7)
+        origins = (v[rng.choice(len(v), size=14, replace=False)] + rng.normal(size=(14, 3)) * [0.01, 0.01, 0.002]).astype(F)
+        write_ply(os.path.join(root, "meshes", files[1]), origins, [])
+    if files[2]:
+        write_png(os.path.join(root, "meshes", files[2]), random_pixels(3, h=16, w=16)[..., 0])
+    return v, f, nrm, uv, origins, extent
+
+
+@pytest.mark.parametrize("fam", ["carpet", "grass", "grass_filtered", "plush"])
+def test_shipped_render_configs_run_as_written(fam, tmp_path, monkeypatch):
+    """The `renderer_config` block of every shipped render config (tests/golden/renderer_configs.json: the reference's own
+    configs/config_<fam>_render.py, dumped by oracle/gen_golden.py), VERBATIM -- instancer.instancer.Instancer with its mesh_path,
+    patch_origins_path, image textures, shadow rays, jitter -- through the reference's plugin path (Render -> Dataset -> ParamNerf ->
+    InstanceRenderer -> Instancer) on stand-in files, against the whole pipeline restated: oracle rays -> oracle instancer (fed the
+    library's instance matrices) -> float64 tail."""
+    from nerf_tex_amd import synthetic, util
+    from nerf_tex_amd.dataset import look_at
+    from nerf_tex_amd.instancer import Instancer
+    monkeypatch.chdir(tmp_path)                                                   # the configs name their files relative to the repository
+    v, f, nrm, uv, origins, extent = stand_in_scene(fam, str(tmp_path))
+    with open(os.path.join(os.path.dirname(__file__), "golden", "renderer_configs.json")) as fh:
+        doc = json.load(fh)[fam]
+    rc = doc["renderer_config"]
+    npar = tuple(doc["model_n_parameters"])
+    ic = rc["instancer_config"]
+    assert ic["module"] == "instancer.instancer.Instancer"
+    H = W = 14
+    P = sum(npar)
+    params = {"carpet": [1, 1, 1, .1, 0.3, 0.2, 1], "grass": [1, 6.0, 0.3, 0.4, 1.5], "grass_filtered": [4.0, 1, 0.3, 0.2, 1], "plush": [1, 1, 0.3, 0.2, 1]}[fam]
+    cam = (6. if fam != "plush" else 2.5) * np.asarray([0.9165, 0., 0.4])
+    c2w = look_at(cam)
+    angle = 0.13 if fam != "plush" else 0.11
+    emb = lambda n_: {'module': 'network.model.FourierFeatures', 'n_freq_bands': n_}
+    hi = 0.3 if fam != "plush" else 0.08
+    aabb0, aabb1 = [-extent * 1.6, -extent * 1.6, -.2 * hi / 0.3], [extent * 1.6, extent * 1.6, hi]
+    config = {
+        'module': 'network.render.Render', 'target_path': None,
+        'test_dataset_config': {
+            'module': 'network.dataset.Dataset',
+            'data_loader_config': {'module': 'nerf_tex_amd.dataset.FromViews', 'height': H, 'width': W, 'angle': angle,
+                                   'views': [{'pose': c2w, 'parameters': params}]},
+            'pixel_sampler_config': {'module': 'network.pixel_sampler.Full'},
+            'ray_sampler_config': {'module': 'network.ray_sampler.Proxy'},
+            'proxy_config': {'module': 'network.proxy.AABB', 'b_0': aabb0, 'b_1': aabb1},
+            'n_epochs': 1},
+        'model_config': {'module': 'network.model.ParamNerf', 'pos_embedding': emb(10), 'dir_embedding': emb(4), 'param_embedding': emb(4),
+                         'n_parameters': list(npar)},
+        'renderer_config': dict(rc, density_scale=60.0),                          # (the one addition: the seeded stand-in weights are thin media)
+        'logger_config': {'module': 'network.logger.Logger'},
+    }
+    model, mspec, wts = make_model(npar, dense_media=True)
+    blob = synthetic.synthetic_weights(model.layer_table(), seed=0, dense_media=True)
+    imgs = util.instantiate(dict(util.remap_reference_config(config), weights=blob, weights_order="keras_get_weights"))
+    rgba = imgs[0][0].cpu().numpy().reshape(H * W, 4)
+    # the same, restated
+    S, step, patch_scale = rc["n_samples"], rc["step_size"], ic["patch_scale"]
+    focal = orc.focal_from_angle(W, angle)
+    ro, rd, t, cone = orc.proxy_rays(orc.full_pixels(H, W), H, W, focal, c2w.astype(F), aabb0, aabb1, F)
+    keep = np.isfinite(t[:, 0])
+    k = int(keep.sum())
+    lib_side = Instancer(**{kk: vv for kk, vv in ic.items() if kk != "module"})
+    assert lib_side.n_instances() == (len(origins) if origins is not None else len(v))
+    sh = dict(cast_shadow_rays=True, min_shadow_samples=ic["min_shadow_samples"], n_shadow_samples=ic["n_shadow_samples"]) if ic["cast_shadow_rays"] else {}
+    tkw = dict(min_texture_samples=ic.get("min_texture_samples", 4), n_texture_samples=ic.get("n_texture_samples", 512))
+    par = np.tile(np.asarray([params], F), (k, 1))
+    b = run_oracle(lib_side, dict(b_0=ic["b_0"], b_1=ic["b_1"]), ro[keep], rd[keep], par, S, step, 0, ic["instance_sampling_method"], ic["textures"],
+                   False, (v, f), ray_index=(0, k, k), patch_scale=patch_scale, tex_mesh=(v, f, uv), **sh, **tkw)
+    hitmask = b[8]
+    rcol, ra = orc.instance_evaluate_model(wts, mspec, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], hitmask, b[9], cone[keep], rc.get("blur_idx"),
+                                           patch_scale, 60.0, rc.get("density_reweighting", True), False, False, (1., 1., 1.), None, dtype=np.float64)
+    want = np.zeros((H * W, 4)); want[keep, :3] = rcol; want[keep, 3] = ra
+    assert orc.rel_linf(rgba, want) <= TOL
+    emitted = b[2] > 0
+    assert k > 0.7 * H * W and hitmask.sum() > 0.3 * k and emitted.sum() > 10 * hitmask.sum()
+    assert want[:, 3].max() > 0.5
+    if any(isinstance(x, str) and x.endswith(".png") for x in ic["textures"]):   # the texture modulates its parameter along the rays
+        col = [i for i, x in enumerate(ic["textures"]) if x.endswith(".png")][0]
+        assert len(np.unique(b[9][..., col][emitted])) > 50
+    if ic["cast_shadow_rays"]:
+        ld = lib_side._light_dir_idx
+        assert (np.all(b[9][..., ld:ld + 3] == F([0, 0, -1]), axis=-1) & emitted).sum() > 0
