@@ -29,7 +29,11 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
+#include <thread>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 extern "C" int ntx_set_error(int code, const char *fmt, ...);   // nerftex.hip
@@ -247,9 +251,10 @@ struct TexArgs {
     int min_samples, n_samples;             // min_texture_samples, n_texture_samples
     float radius;                           // patch_max_extent (:69, :246)
     const float *texels; const TexTable *table;             // the first n_tex tables are the parameter textures
-    // the instancer mesh in a uniform grid, triangles binned by centroid: cell -> [start, end) into tris[.][10] = {v0, v1, v2, primID}
-    const int32_t *cell_start; const float *tris; const float *face_uv;   // face_uv[primID][6]: texture coordinates of its corners
-    float gmin[3], cell, inv_cell, r_max;   // r_max: no corner lies further from its triangle's centroid
+    // the instancer mesh behind a uniform grid of CANDIDATE lists: cell -> [start, end) into cand[] = the triangles that can be the
+    // closest one for some point of the cell (worked out when the textures are set, see ntx_instancer_set_parameter_textures)
+    const int32_t *cell_start; const int32_t *cand; const float *tris; const float *face_uv;   // tris[primID][9] corners, face_uv[primID][6]
+    float gmin[3], inv_cell;
     int32_t dim[3]; int32_t n_faces;
 };
 
@@ -302,51 +307,25 @@ __device__ __forceinline__ float closest_point_triangle(const float *p, const fl
 
 // getParameters' point query (instancer.cpp:644-654): the triangle of the instancer mesh whose closest point lies nearest to p, strictly
 // within the radius; of several at one distance the lowest primID (the restatement's order).  The reference walks Embree's BVH; here
-// the triangles sit in a uniform grid by centroid and the cells around p are visited ring by ring (rows of cells = one range of the
-// cell list): behind ring k every unvisited triangle is at least k * cell - r_max away, so the walk ends as soon as the best distance
-// is below that.  Exhaustive up to there: the result is that of testing every triangle.  Lane = one query; no wave collectives inside.
+// the cell of p names every triangle that can win for a point of that cell (its list was cut down with exact distance bounds on the
+// host), and each of them gets the reference's closest_point_triangle: the result is that of testing every triangle of the mesh.
+// Lane = one query; no wave collectives inside.
 __device__ __forceinline__ bool closest_uv(const TexArgs &T, float px, float py, float pz, float *u_out, float *v_out) {
     const float p[3] = {px, py, pz};
     float best = T.radius;
     int best_f = -1;
     float bw[3] = {0.0f, 0.0f, 0.0f};
     const float fx = (px - T.gmin[0]) * T.inv_cell, fy = (py - T.gmin[1]) * T.inv_cell, fz = (pz - T.gmin[2]) * T.inv_cell;
-    // further from the grid than anything could reach: nothing (also keeps the casts below in range)
-    const float reach = (T.radius + T.r_max) * T.inv_cell + 2.0f;
-    const bool far = !(fx >= -reach && fy >= -reach && fz >= -reach && fx <= (float)T.dim[0] + reach && fy <= (float)T.dim[1] + reach && fz <= (float)T.dim[2] + reach);
-    if (!far) {
-        const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
-        const int kmax = (int)reach + 1;
-        for (int k = 0; k <= kmax; ++k) {
-            for (int dz = -k; dz <= k; ++dz) {
-                const int z = cz + dz;
-                if (z < 0 || z >= T.dim[2]) continue;
-                for (int dy = -k; dy <= k; ++dy) {
-                    const int y = cy + dy;
-                    if (y < 0 || y >= T.dim[1]) continue;
-                    const bool full = dz == -k || dz == k || dy == -k || dy == k;            // a face of the ring's shell: the whole row; else its two ends
-                    const int n_part = full || k == 0 ? 1 : 2;
-                    for (int part = 0; part < n_part; ++part) {
-                        int xa = full ? cx - k : (part == 0 ? cx - k : cx + k), xb = full ? cx + k : xa;
-                        xa = xa < 0 ? 0 : xa; xb = xb >= T.dim[0] ? T.dim[0] - 1 : xb;
-                        if (xa > xb) continue;
-                        const size_t row = ((size_t)z * T.dim[1] + y) * T.dim[0];
-                        const int s0 = T.cell_start[row + xa], s1 = T.cell_start[row + xb + 1];
-                        for (int e = s0; e < s1; ++e) {
-                            const float *tr = T.tris + (size_t)e * 10;
-                            const float a[3] = {tr[0], tr[1], tr[2]}, b[3] = {tr[3], tr[4], tr[5]}, c[3] = {tr[6], tr[7], tr[8]};
-                            const int f = __builtin_bit_cast(int, tr[9]);
-                            float w[3];
-                            const float d = closest_point_triangle(p, a, b, c, w);
-                            if (d < best || (d == best && best_f >= 0 && f < best_f)) { best = d; best_f = f; bw[0] = w[0]; bw[1] = w[1]; bw[2] = w[2]; }
-                        }
-                    }
-                }
-            }
-            // every triangle not yet seen has its centroid at least k cells away along some axis
-            // (less what rounding can move p or a centroid across a cell wall)
-            const float bound = ((float)k * T.cell - T.r_max) * 0.999f - 1e-5f * ((fabsf(px) + fabsf(py)) + (fabsf(pz) + 1.0f));
-            if (best < bound || bound >= T.radius) break;
+    if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)T.dim[0] && fy < (float)T.dim[1] && fz < (float)T.dim[2]) {   // (the grid reaches the radius beyond the mesh)
+        const size_t cell = ((size_t)(int)fz * T.dim[1] + (int)fy) * T.dim[0] + (int)fx;
+        const int s0 = T.cell_start[cell], s1 = T.cell_start[cell + 1];
+        for (int e = s0; e < s1; ++e) {
+            const int f = T.cand[e];
+            const float *tr = T.tris + (size_t)f * 9;
+            const float a[3] = {tr[0], tr[1], tr[2]}, b[3] = {tr[3], tr[4], tr[5]}, c[3] = {tr[6], tr[7], tr[8]};
+            float w[3];
+            const float d = closest_point_triangle(p, a, b, c, w);
+            if (d < best || (d == best && best_f >= 0 && f < best_f)) { best = d; best_f = f; bw[0] = w[0]; bw[1] = w[1]; bw[2] = w[2]; }
         }
     }
     if (best_f < 0) return false;
@@ -1237,7 +1216,7 @@ struct ntx_instancer {
     float *d_uv = nullptr; int32_t *d_face_tex = nullptr; float *d_atexels = nullptr; ntx_inst::TexTable *d_atable = nullptr;   // their textures
     // parameter textures on the instancer mesh: texels + tables, the mesh in its grid
     ntx_inst::TexArgs tex{};
-    float *d_ptexels = nullptr, *d_gtris = nullptr, *d_face_uv = nullptr; ntx_inst::TexTable *d_ptable = nullptr; int32_t *d_cell_start = nullptr;
+    float *d_ptexels = nullptr, *d_gtris = nullptr, *d_face_uv = nullptr; ntx_inst::TexTable *d_ptable = nullptr; int32_t *d_cell_start = nullptr, *d_cand = nullptr;
     uint4 *d_hits = nullptr;
 };
 
@@ -1273,7 +1252,7 @@ void release(ntx_instancer *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (void *q : {(void *)p->d_mats, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_xforms, (void *)p->d_normals, (void *)p->d_faces, (void *)p->d_kind, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits,
-                    (void *)p->d_uv, (void *)p->d_face_tex, (void *)p->d_atexels, (void *)p->d_atable, (void *)p->d_ptexels, (void *)p->d_gtris, (void *)p->d_face_uv, (void *)p->d_ptable, (void *)p->d_cell_start})
+                    (void *)p->d_uv, (void *)p->d_face_tex, (void *)p->d_atexels, (void *)p->d_atable, (void *)p->d_ptexels, (void *)p->d_gtris, (void *)p->d_face_uv, (void *)p->d_ptable, (void *)p->d_cell_start, (void *)p->d_cand})
         if (q) (void)hipFree(q);
     delete p;
 }
@@ -1471,6 +1450,172 @@ int upload_textures(const ntx_texture *textures, int n, float **d_texels, ntx_in
     return NTX_OK;
 }
 
+
+// Distance of point p to triangle abc (Ericson's regions, double): what the device's closest_point_triangle computes in float32.
+double point_triangle_distance(const double *p, const double *a, const double *b, const double *c) {
+    double ab[3], ac[3], ap[3], bp[3], cp[3], q[3];
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; bp[i] = p[i] - b[i]; cp[i] = p[i] - c[i]; }
+    auto dot = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+    const double d1 = dot(ab, ap), d2 = dot(ac, ap), d3 = dot(ab, bp), d4 = dot(ac, bp), d5 = dot(ab, cp), d6 = dot(ac, cp);
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d1 <= 0 && d2 <= 0) { for (int i = 0; i < 3; ++i) q[i] = a[i]; }
+    else if (d3 >= 0 && d4 <= d3) { for (int i = 0; i < 3; ++i) q[i] = b[i]; }
+    else if (d6 >= 0 && d5 <= d6) { for (int i = 0; i < 3; ++i) q[i] = c[i]; }
+    else if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double v = d1 / (d1 - d3); for (int i = 0; i < 3; ++i) q[i] = a[i] + v * ab[i]; }
+    else if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double v = d2 / (d2 - d6); for (int i = 0; i < 3; ++i) q[i] = a[i] + v * ac[i]; }
+    else if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const double v = (d4 - d3) / ((d4 - d3) + (d5 - d6)); for (int i = 0; i < 3; ++i) q[i] = b[i] + v * (c[i] - b[i]); }
+    else { const double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den; for (int i = 0; i < 3; ++i) q[i] = a[i] + v * ab[i] + w * ac[i]; }
+    double e2 = 0.0;
+    for (int i = 0; i < 3; ++i) e2 += (p[i] - q[i]) * (p[i] - q[i]);
+    return std::isfinite(e2) ? std::sqrt(e2) : 1e300;          // (a degenerate triangle can give NaN: never the closest, on the device neither)
+}
+
+// The grid behind getParameters' point query.  A point p of cell C (centre m, half diagonal r) lies within r of m, so for every
+// triangle T:  d(m, T) - r <= d(p, T) <= d(m, T) + r.  With D = the distance of m to the mesh, the triangle closest to p is at most
+// D + r away, hence has d(m, T) <= D + 2 r; and only triangles with d(m, T) - r < radius can lie within the query radius.  The list of C
+// is exactly that set (with a rounding margin), found by a ring walk over a coarser grid of centroids: the device then tests the list
+// and nothing else, and gets what testing every triangle would give.  Cells are half an average edge wide (at most 2^21 of them) and
+// cover the mesh's bounding box grown by the radius; built on all host cores.
+int build_candidate_grid(const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces, double radius, ntx_inst::TexArgs &T,
+                         std::vector<int32_t> &start, std::vector<int32_t> &cand) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, edge = 0.0, r_max = 0.0;
+    for (int64_t v = 0; v < n_vertices; ++v)
+        for (int c = 0; c < 3; ++c) {
+            const double x = vertices[3 * v + c];
+            if (!std::isfinite(x)) return ntx_set_error(NTX_E_INVALID, "vertex %lld is not finite", (long long)v);
+            lo[c] = x < lo[c] ? x : lo[c]; hi[c] = x > hi[c] ? x : hi[c];
+        }
+    std::vector<double> tri((size_t)n_faces * 9), cen((size_t)n_faces * 3);
+    for (int64_t f = 0; f < n_faces; ++f) {
+        for (int j = 0; j < 3; ++j)
+            for (int c = 0; c < 3; ++c) tri[f * 9 + 3 * j + c] = vertices[3 * (int64_t)faces[3 * f + j] + c];
+        for (int c = 0; c < 3; ++c) cen[3 * f + c] = (tri[f * 9 + c] + tri[f * 9 + 3 + c] + tri[f * 9 + 6 + c]) / 3.0;
+        for (int j = 0; j < 3; ++j) {
+            double e2 = 0.0, d2 = 0.0;
+            for (int c = 0; c < 3; ++c) {
+                const double e = tri[f * 9 + 3 * j + c] - tri[f * 9 + 3 * ((j + 1) % 3) + c], d = tri[f * 9 + 3 * j + c] - cen[3 * f + c];
+                e2 += e * e; d2 += d * d;
+            }
+            edge += std::sqrt(e2);
+            r_max = std::sqrt(d2) > r_max ? std::sqrt(d2) : r_max;
+        }
+    }
+    edge /= 3.0 * (double)n_faces;
+    // the coarse grid of centroids (host only): cells one average edge wide, at most 2^18
+    double cc = edge > 0.0 ? edge : 1.0;
+    {
+        const double vol = (hi[0] - lo[0] + cc) * (hi[1] - lo[1] + cc) * (hi[2] - lo[2] + cc), fl = std::cbrt(vol / (double)(1 << 18));
+        cc = cc > fl ? cc : fl;
+    }
+    int cdim[3]; int64_t n_coarse = 1;
+    for (int c = 0; c < 3; ++c) { cdim[c] = (int)std::floor((hi[c] - lo[c]) / cc) + 1; n_coarse *= cdim[c]; }
+    std::vector<int32_t> cstart((size_t)n_coarse + 1, 0), clist((size_t)n_faces), cof((size_t)n_faces);
+    for (int64_t f = 0; f < n_faces; ++f) {
+        int64_t id = 0, mul = 1;
+        for (int c = 0; c < 3; ++c) {
+            int64_t q = (int64_t)std::floor((cen[3 * f + c] - lo[c]) / cc);
+            q = q < 0 ? 0 : (q >= cdim[c] ? cdim[c] - 1 : q);
+            id += q * mul; mul *= cdim[c];
+        }
+        cof[f] = (int32_t)id; ++cstart[id + 1];
+    }
+    for (int64_t c = 0; c < n_coarse; ++c) cstart[c + 1] += cstart[c];
+    {
+        std::vector<int32_t> at(cstart.begin(), cstart.end() - 1);
+        for (int64_t f = 0; f < n_faces; ++f) clist[(size_t)at[cof[f]]++] = (int32_t)f;
+    }
+    // the fine grid
+    double cell = edge > 0.0 ? 0.5 * edge : 1.0;
+    {
+        const double vol = (hi[0] - lo[0] + 2 * radius + cell) * (hi[1] - lo[1] + 2 * radius + cell) * (hi[2] - lo[2] + 2 * radius + cell), fl = std::cbrt(vol / (double)(1 << 21));
+        cell = cell > fl ? cell : fl;
+    }
+    int64_t n_cells = 1;
+    T.inv_cell = (float)(1.0 / cell);
+    const double cellf = 1.0 / (double)T.inv_cell;                  // the cell width the device's arithmetic implies
+    for (int c = 0; c < 3; ++c) {
+        T.gmin[c] = (float)(lo[c] - radius - cellf);
+        T.dim[c] = (int32_t)std::ceil((hi[c] + radius + cellf - (double)T.gmin[c]) / cellf) + 1;
+        n_cells *= T.dim[c];
+    }
+    if (n_cells > (int64_t)1 << 23) return ntx_set_error(NTX_E_INVALID, "the texture grid would have %lld cells", (long long)n_cells);
+    const double r_cell = 0.5 * std::sqrt(3.0) * cellf * 1.01 + 1e-6 * (std::fabs(lo[0]) + std::fabs(hi[0]) + std::fabs(lo[1]) + std::fabs(hi[1]) + std::fabs(lo[2]) + std::fabs(hi[2]) + 1.0);
+    std::vector<std::vector<int32_t>> lists((size_t)T.dim[2] * T.dim[1]);     // per row of cells: (count per cell, entries), flattened below
+    std::vector<std::vector<int32_t>> counts((size_t)T.dim[2] * T.dim[1]);
+    const int n_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::atomic<int64_t> next_row{0};
+    auto work = [&]() {
+        std::vector<std::pair<double, int32_t>> near;
+        for (;;) {
+            const int64_t row = next_row.fetch_add(1);
+            if (row >= (int64_t)T.dim[2] * T.dim[1]) break;
+            const int z = (int)(row / T.dim[1]), y = (int)(row % T.dim[1]);
+            auto &out = lists[(size_t)row]; auto &cnt = counts[(size_t)row];
+            cnt.assign((size_t)T.dim[0], 0);
+            for (int x = 0; x < T.dim[0]; ++x) {
+                const double m[3] = {(double)T.gmin[0] + (x + 0.5) * cellf, (double)T.gmin[1] + (y + 0.5) * cellf, (double)T.gmin[2] + (z + 0.5) * cellf};
+                // ring walk over the coarse grid around m: every triangle whose centroid cell lies in ring <= k; behind ring k no
+                // unvisited triangle is nearer than k * cc - r_max (minus how far m lies outside its clamped cell)
+                int ci[3]; double out_of = 0.0;
+                for (int c = 0; c < 3; ++c) {
+                    const double q = std::floor((m[c] - lo[c]) / cc);
+                    ci[c] = (int)(q < 0 ? 0 : (q >= cdim[c] ? cdim[c] - 1 : q));
+                    const double lo_c = lo[c] + ci[c] * cc, hi_c = lo_c + cc;
+                    const double o = m[c] < lo_c ? lo_c - m[c] : (m[c] > hi_c ? m[c] - hi_c : 0.0);
+                    out_of = o > out_of ? o : out_of;
+                }
+                near.clear();
+                double best = 1e300;
+                const double reach = radius + r_cell;                      // nothing beyond this can matter
+                const int kmax = std::max(cdim[0], std::max(cdim[1], cdim[2]));
+                for (int k = 0; k <= kmax; ++k) {
+                    for (int dz = -k; dz <= k; ++dz) {
+                        const int zz = ci[2] + dz; if (zz < 0 || zz >= cdim[2]) continue;
+                        for (int dy = -k; dy <= k; ++dy) {
+                            const int yy = ci[1] + dy; if (yy < 0 || yy >= cdim[1]) continue;
+                            const bool shell = dz == -k || dz == k || dy == -k || dy == k;
+                            for (int dx = -k; dx <= k; dx += (shell || k == 0) ? 1 : 2 * k) {
+                                const int xx = ci[0] + dx; if (xx < 0 || xx >= cdim[0]) continue;
+                                const int64_t id = ((int64_t)zz * cdim[1] + yy) * cdim[0] + xx;
+                                for (int32_t e = cstart[id]; e < cstart[id + 1]; ++e) {
+                                    const int32_t f = clist[(size_t)e];
+                                    const double d = point_triangle_distance(m, &tri[(size_t)f * 9], &tri[(size_t)f * 9 + 3], &tri[(size_t)f * 9 + 6]);
+                                    best = d < best ? d : best;
+                                    near.emplace_back(d, f);
+                                }
+                            }
+                        }
+                    }
+                    const double behind = k * cc - r_max - out_of;
+                    const double need = std::min(best + 2.0 * r_cell, reach);
+                    if (behind > need * (1.0 + 1e-9) + 1e-12) break;
+                }
+                const double cut = std::min(best + 2.0 * r_cell, reach) * (1.0 + 1e-9) + 1e-12;
+                size_t n0 = out.size();
+                for (const auto &pr : near)
+                    if (pr.first <= cut && pr.first - r_cell < radius) out.push_back(pr.second);
+                std::sort(out.begin() + (std::ptrdiff_t)n0, out.end());        // ascending primID
+                cnt[(size_t)x] = (int32_t)(out.size() - n0);
+            }
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int i = 1; i < n_threads; ++i) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+    }
+    start.assign((size_t)n_cells + 1, 0);
+    size_t total = 0;
+    for (size_t row = 0; row < lists.size(); ++row)
+        for (int x = 0; x < T.dim[0]; ++x) { start[row * T.dim[0] + x] = (int32_t)total; total += (size_t)counts[row][(size_t)x]; if (total > 0x7fffffffu) return ntx_set_error(NTX_E_INVALID, "the texture grid's lists overflow"); }
+    start[(size_t)n_cells] = (int32_t)total;
+    cand.resize(total);
+    for (size_t row = 0; row < lists.size(); ++row)
+        if (!lists[row].empty()) std::memcpy(cand.data() + start[row * T.dim[0]], lists[row].data(), lists[row].size() * sizeof(int32_t));
+    return NTX_OK;
+}
+
 }   // namespace
 
 int ntx_instancer_set_parameter_textures(ntx_instancer *inst, const float *vertices, const float *uv, int64_t n_vertices, const int32_t *faces,
@@ -1479,7 +1624,7 @@ int ntx_instancer_set_parameter_textures(ntx_instancer *inst, const float *verti
     using namespace ntx_inst;
     if (!inst) return ntx_set_error(NTX_E_INVALID, "inst is NULL");
     INST_TRY(hipSetDevice(inst->device));
-    for (void **q : {(void **)&inst->d_ptexels, (void **)&inst->d_ptable, (void **)&inst->d_gtris, (void **)&inst->d_face_uv, (void **)&inst->d_cell_start})
+    for (void **q : {(void **)&inst->d_ptexels, (void **)&inst->d_ptable, (void **)&inst->d_gtris, (void **)&inst->d_face_uv, (void **)&inst->d_cell_start, (void **)&inst->d_cand})
         if (*q) { (void)hipFree(*q); *q = nullptr; }
     inst->tex = TexArgs{};
     if (n_textures == 0) return NTX_OK;
@@ -1493,70 +1638,18 @@ int ntx_instancer_set_parameter_textures(ntx_instancer *inst, const float *verti
         if (parameter_idx[i] < 0 || parameter_idx[i] >= inst->desc.n_parameters) return ntx_set_error(NTX_E_INVALID, "texture %d multiplies parameter %d of %d", i, parameter_idx[i], inst->desc.n_parameters);
     for (int64_t f = 0; f < 3 * n_faces; ++f)
         if (faces[f] < 0 || faces[f] >= n_vertices) return ntx_set_error(NTX_E_INVALID, "face %lld names vertex %d of %lld", (long long)(f / 3), faces[f], (long long)n_vertices);
-    // the grid: cells about one average edge wide (at most 2^21 of them), triangles binned by centroid
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, edge = 0.0;
-    for (int64_t v = 0; v < n_vertices; ++v)
-        for (int c = 0; c < 3; ++c) {
-            const double x = vertices[3 * v + c];
-            if (!std::isfinite(x)) return ntx_set_error(NTX_E_INVALID, "vertex %lld is not finite", (long long)v);
-            lo[c] = x < lo[c] ? x : lo[c]; hi[c] = x > hi[c] ? x : hi[c];
-        }
-    std::vector<double> cen((size_t)n_faces * 3);
-    double r_max = 0.0;
-    for (int64_t f = 0; f < n_faces; ++f) {
-        const float *v[3] = {vertices + 3 * (int64_t)faces[3 * f], vertices + 3 * (int64_t)faces[3 * f + 1], vertices + 3 * (int64_t)faces[3 * f + 2]};
-        for (int c = 0; c < 3; ++c) cen[3 * f + c] = ((double)v[0][c] + v[1][c] + v[2][c]) / 3.0;
-        for (int j = 0; j < 3; ++j) {
-            double e2 = 0.0, d2 = 0.0;
-            for (int c = 0; c < 3; ++c) {
-                e2 += ((double)v[j][c] - v[(j + 1) % 3][c]) * ((double)v[j][c] - v[(j + 1) % 3][c]);
-                d2 += ((double)v[j][c] - cen[3 * f + c]) * ((double)v[j][c] - cen[3 * f + c]);
-            }
-            edge += std::sqrt(e2);
-            r_max = std::sqrt(d2) > r_max ? std::sqrt(d2) : r_max;
-        }
-    }
-    edge /= 3.0 * (double)n_faces;
-    const double ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
-    double cell = edge > 0.0 ? edge : 1.0;
-    {
-        const double vol = (ext[0] + cell) * (ext[1] + cell) * (ext[2] + cell);
-        const double floor_cell = std::cbrt(vol / (double)(1 << 21));
-        cell = cell > floor_cell ? cell : floor_cell;
-    }
+    std::vector<int32_t> start, cand;
     TexArgs T{};
-    int64_t n_cells = 1;
-    for (int c = 0; c < 3; ++c) {
-        T.gmin[c] = (float)lo[c];
-        T.dim[c] = (int32_t)std::floor((hi[c] - (double)T.gmin[c]) / cell) + 1;
-        if (T.dim[c] < 1) T.dim[c] = 1;
-        n_cells *= T.dim[c];
-    }
-    T.cell = (float)cell; T.inv_cell = (float)(1.0 / (double)T.cell); T.r_max = (float)(r_max * 1.001 + 1e-12);
-    std::vector<int32_t> cell_of((size_t)n_faces), start((size_t)n_cells + 1, 0);
-    for (int64_t f = 0; f < n_faces; ++f) {
-        int64_t id = 0, mul = 1;
-        for (int c = 0; c < 3; ++c) {
-            int64_t q = (int64_t)std::floor((cen[3 * f + c] - (double)T.gmin[c]) / (double)T.cell);
-            q = q < 0 ? 0 : (q >= T.dim[c] ? T.dim[c] - 1 : q);
-            id += q * mul; mul *= T.dim[c];
-        }
-        cell_of[f] = (int32_t)id;
-        ++start[id + 1];
-    }
-    for (int64_t c = 0; c < n_cells; ++c) start[c + 1] += start[c];
-    std::vector<float> gtris((size_t)n_faces * 10), fuv((size_t)n_faces * 6);
     {
-        std::vector<int32_t> at(start.begin(), start.end() - 1);
-        for (int64_t f = 0; f < n_faces; ++f) {                      // ascending primID inside a cell
-            const size_t e = (size_t)at[cell_of[f]]++;
-            for (int j = 0; j < 3; ++j)
-                for (int c = 0; c < 3; ++c) gtris[e * 10 + 3 * j + c] = vertices[3 * (int64_t)faces[3 * f + j] + c];
-            const int32_t id = (int32_t)f;
-            std::memcpy(&gtris[e * 10 + 9], &id, sizeof(float));
-            for (int j = 0; j < 3; ++j) { fuv[f * 6 + 2 * j] = uv[2 * (int64_t)faces[3 * f + j]]; fuv[f * 6 + 2 * j + 1] = uv[2 * (int64_t)faces[3 * f + j] + 1]; }
-        }
+        const int rc_grid = build_candidate_grid(vertices, n_vertices, faces, n_faces, (double)patch_max_extent, T, start, cand);
+        if (rc_grid != NTX_OK) return rc_grid;
     }
+    std::vector<float> gtris((size_t)n_faces * 9), fuv((size_t)n_faces * 6);
+    for (int64_t f = 0; f < n_faces; ++f)
+        for (int j = 0; j < 3; ++j) {
+            for (int c = 0; c < 3; ++c) gtris[f * 9 + 3 * j + c] = vertices[3 * (int64_t)faces[3 * f + j] + c];
+            fuv[f * 6 + 2 * j] = uv[2 * (int64_t)faces[3 * f + j]]; fuv[f * 6 + 2 * j + 1] = uv[2 * (int64_t)faces[3 * f + j] + 1];
+        }
     int rc = upload_textures(textures, n_textures, &inst->d_ptexels, &inst->d_ptable);
     if (rc != NTX_OK) return rc;
     INST_TRY(hipMalloc((void **)&inst->d_gtris, gtris.size() * sizeof(float)));
@@ -1565,10 +1658,12 @@ int ntx_instancer_set_parameter_textures(ntx_instancer *inst, const float *verti
     INST_TRY(hipMemcpy(inst->d_face_uv, fuv.data(), fuv.size() * sizeof(float), hipMemcpyHostToDevice));
     INST_TRY(hipMalloc((void **)&inst->d_cell_start, start.size() * sizeof(int32_t)));
     INST_TRY(hipMemcpy(inst->d_cell_start, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    INST_TRY(hipMalloc((void **)&inst->d_cand, (cand.empty() ? 1 : cand.size()) * sizeof(int32_t)));
+    INST_TRY(hipMemcpy(inst->d_cand, cand.data(), cand.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     T.n_tex = n_textures;
     for (int i = 0; i < n_textures; ++i) T.par_idx[i] = parameter_idx[i];
     T.min_samples = min_texture_samples; T.n_samples = n_texture_samples; T.radius = patch_max_extent;
-    T.texels = inst->d_ptexels; T.table = inst->d_ptable; T.cell_start = inst->d_cell_start; T.tris = inst->d_gtris; T.face_uv = inst->d_face_uv;
+    T.texels = inst->d_ptexels; T.table = inst->d_ptable; T.cell_start = inst->d_cell_start; T.cand = inst->d_cand; T.tris = inst->d_gtris; T.face_uv = inst->d_face_uv;
     T.n_faces = (int32_t)n_faces;
     inst->tex = T;
     return NTX_OK;

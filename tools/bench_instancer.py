@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-mesh", action="store_true")
     ap.add_argument("--scale-with-grid", action="store_true", help="patch_scale and step_size * 48 / grid: the same sheet covered by smaller "
                     "patches, the same number of patches and steps along a ray whatever the grid (a scene of 10^5 patches at --grid 316)")
+    ap.add_argument("--textures", type=int, default=0, metavar="N", help="a one-channel image on parameter 0, looked up on the sheet: n_texture_samples = N, "
+                    "min 8 (config_carpet_render.py:86-93: 256)")
     ap.add_argument("--shadows", type=int, default=0, metavar="N", help="cast_shadow_rays with n_shadow_samples = N, min 8 (config_grass_render.py:92-98: 128)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -62,8 +64,14 @@ def main():
         a.step_size *= 48.0 / a.grid
     tr, v, f = sheet(a.grid, scale=scale)
     textures = ['', '', '', '', 'light']                                         # config_carpet_render.py:86 without the image texture
+    tkw = {}
+    if a.textures:                                                               # ... and with it: a smooth checkerboard of 256 x 256 texels
+        yy, xx = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+        textures[0] = (127.5 + 127.5 * np.sin(xx * 0.2) * np.sin(yy * 0.2)).astype(np.uint8)
+        uv = ((v[:, :2] + 1.5) / 3.0).astype(np.float32)
+        tkw = dict(instancer_mesh=(v, f, uv), patch_scale=scale, min_texture_samples=8, n_texture_samples=a.textures)
     inst = Instancer(B0, B1, textures=textures, transformations=tr, instance_sampling_method=a.method,
-                     mesh=None if a.no_mesh else (v, f), cast_shadow_rays=a.shadows > 0, min_shadow_samples=8, n_shadow_samples=max(a.shadows, 1))
+                     mesh=None if a.no_mesh else (v, f), cast_shadow_rays=a.shadows > 0, min_shadow_samples=8, n_shadow_samples=max(a.shadows, 1), **tkw)
     fam = synthetic.FAMILIES["carpet"]
     side = int(np.sqrt(a.rays))
     assert side * side == a.rays, "--rays must be a square number (a side x side window of the 800 x 800 camera)"
@@ -92,7 +100,8 @@ def main():
     gbps = (out_bytes + in_bytes) / (ms * 1e-3) / 1e9
     line = {"what": "ntx_instancer_model_input (hits + mesh + march kernels, HIP events around the call incl. the output torch.empty)",
             "scene": f"{a.grid}x{a.grid} = {a.grid ** 2} patches + {0 if a.no_mesh else f.shape[0]} triangles, method {a.method}"
-                     + (f", shadow rays ({a.shadows} per unit length, min 8)" if a.shadows else ""),
+                     + (f", shadow rays ({a.shadows} per unit length, min 8)" if a.shadows else "")
+                     + (f", a parameter texture ({a.textures} lookups per unit length, min 8)" if a.textures else ""),
             "patch_scale": round(scale, 5), "shadowed_samples": int((out[9][..., 4:7] == torch.tensor([0., 0., -1.], device=dev)).all(-1).logical_and(out[2] > 0).sum().item()),
             "rays": a.rays, "n_pts": S, "step_size": a.step_size, "hit_rays": int(hit.sum().item()), "in_patch_samples": in_patch,
             "emitted_samples": emitted, "status": inst.status(), "ms": round(ms, 4),
