@@ -134,11 +134,46 @@ __device__ __forceinline__ WaveCone wave_cone(float ox, float oy, float oz, floa
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// all (ray, instance) pairs: what rtcIntersect1 with the all-hits filter reports (instancer.cpp:779, 526-541)
+// the two-level cull every kernel walks: the objects (instanced boxes or triangles, each behind a sphere) sit in Morton order behind a
+// permutation, a sphere around every block of 64 consecutive ones.  A wave tests 64 block spheres per ballot, then the 64 objects of
+// every block that passed, lane per object: `body(id, near)` is called in uniform control flow with the lane's object (its index in
+// the ORIGINAL order, -1 behind the end) and whether its own sphere passed.  The tests are culls only: what they let through gets the
+// exact test, so neither the order nor the grouping changes a result.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Scene {
+    const float *spheres; int stride;       // (centre, r^2) of object i at spheres + i * stride
+    const int32_t *perm; const float *bspheres;
+    int n, nb;
+};
+template <typename Reach, typename Body>
+__device__ __forceinline__ void walk_blocks(const Scene &sc, int b0, int b1, int lane, Reach reach, Body body) {
+    for (int bb = b0; bb < b1; bb += 64) {
+        const int b = bb + lane;
+        bool pass = false;
+        if (b < b1) { const float *bsp = sc.bspheres + (size_t)b * 4; pass = reach(bsp, bsp[3]); }
+        uint64_t bm = __ballot(pass);
+        while (bm) {
+            const int blk = bb + __builtin_ctzll(bm);
+            bm &= bm - 1;
+            const int idx = blk * 64 + lane;
+            int id = -1;
+            bool near = false;
+            if (idx < sc.n) {
+                id = sc.perm[idx];
+                const float *sp = sc.spheres + (size_t)id * sc.stride;
+                near = reach(sp, sp[3]);
+            }
+            body(id, near);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// (ray, instance) pairs: what rtcIntersect1 with the all-hits filter reports (instancer.cpp:779, 526-541)
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int n_rays,
-                                                        const float *__restrict__ mats, const float *__restrict__ spheres, int n_inst,
-                                                        int per_wave, Box box, uint32_t *__restrict__ count, uint4 *__restrict__ hits) {
+                                                        const float *__restrict__ mats, Scene sc, int blocks_per_wave, Box box,
+                                                        uint32_t *__restrict__ count, uint4 *__restrict__ hits) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ray = blockIdx.x * 64 + lane;
@@ -146,19 +181,18 @@ __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict_
     const int r = live ? ray : n_rays - 1;
     const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
     const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
-    const int k0 = (blockIdx.y * 4 + wave) * per_wave;
-    const int k1 = k0 + per_wave < n_inst ? k0 + per_wave : n_inst;
+    const int b0 = (blockIdx.y * 4 + wave) * blocks_per_wave;
+    const int b1 = b0 + blocks_per_wave < sc.nb ? b0 + blocks_per_wave : sc.nb;
     const float dd2 = (dx * dx + dy * dy) + dz * dz;
     const WaveCone cone = wave_cone(ox, oy, oz, dx, dy, dz);
-    // spheres around the instanced boxes (centre, radius^2 widened): 64 instances per ballot against the wave's cone -- a wave holds
-    // neighbouring rays, so few instances survive -- and the survivors once more against each ray
-    for (int kb = k0; kb < k1; kb += 64) {
-      const int kl = kb + lane;
-      uint64_t mk = __ballot(kl < k1 && cone.reaches(spheres + (size_t)kl * 4, spheres[(size_t)kl * 4 + 3]));
+    // spheres around the instanced boxes (centre, radius^2 widened) against the wave's cone -- a wave holds neighbouring rays, so few
+    // instances survive -- and the survivors once more against each ray
+    walk_blocks(sc, b0, b1, lane, [&](const float *c, float r2) { return cone.reaches(c, r2); }, [&](int id, bool near) {
+      uint64_t mk = __ballot(near);
       while (mk) {
-        const int k = kb + __builtin_ctzll(mk);
+        const int k = __builtin_amdgcn_readlane(id, __builtin_ctzll(mk));       // wave-uniform from here on: scalar loads
         mk &= mk - 1;
-        const float *sp = spheres + (size_t)k * 4;       // wave-uniform from here on: scalar loads
+        const float *sp = sc.spheres + (size_t)k * 4;
         const float cx = sp[0] - ox, cy = sp[1] - oy, cz = sp[2] - oz;
         const float qx = cy * dz - cz * dy, qy = cz * dx - cx * dz, qz = cx * dy - cy * dx;
         if (!__any((qx * qx + qy * qy) + qz * qz <= sp[3] * dd2)) continue;
@@ -190,12 +224,12 @@ __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict_
             }
         }
       }
-    }
+    });
 }
 
-// closest crossing of the instancer mesh per ray (Moeller-Trumbore, no culling); tris[f] = {v0, v1 - v0, v2 - v0, sphere centre, radius^2}
+// closest crossing of the meshes per ray (Moeller-Trumbore, no culling); tris[f] = {v0, v1 - v0, v2 - v0, sphere centre, radius^2}
 __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int n_rays,
-                                                        const float *__restrict__ tris, int n_tri, int per_wave, unsigned long long *__restrict__ t_mesh) {
+                                                        const float *__restrict__ tris, Scene sc, int blocks_per_wave, unsigned long long *__restrict__ t_mesh) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ray = blockIdx.x * 64 + lane;
@@ -203,17 +237,16 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
     const int r = live ? ray : n_rays - 1;
     const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
     const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
-    const int f0 = (blockIdx.y * 4 + wave) * per_wave;
-    const int f1 = f0 + per_wave < n_tri ? f0 + per_wave : n_tri;
+    const int b0 = (blockIdx.y * 4 + wave) * blocks_per_wave;
+    const int b1 = b0 + blocks_per_wave < sc.nb ? b0 + blocks_per_wave : sc.nb;
     float best = INFINITY;
     int best_f = 0;
     const float dd2 = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
     const WaveCone cone = wave_cone(o[0], o[1], o[2], d[0], d[1], d[2]);
-    for (int fb = f0; fb < f1; fb += 64) {
-      const int fl = fb + lane;
-      uint64_t mk = __ballot(fl < f1 && cone.reaches(tris + (size_t)fl * 13 + 9, tris[(size_t)fl * 13 + 12]));
+    walk_blocks(sc, b0, b1, lane, [&](const float *c, float r2) { return cone.reaches(c, r2); }, [&](int id, bool near) {
+      uint64_t mk = __ballot(near);
       while (mk) {
-        const int f = fb + __builtin_ctzll(mk);
+        const int f = __builtin_amdgcn_readlane(id, __builtin_ctzll(mk));
         mk &= mk - 1;
         const float *tr = tris + (size_t)f * 13;
         {   // the triangle's sphere, as in inst_hits_kernel
@@ -233,9 +266,10 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
         const float v = ((d[0] * q[0] + d[1] * q[1]) + d[2] * q[2]) * inv_det;
         if (v < 0.0f || u + v > 1.0f) continue;
         const float tt = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv_det;
-        if (tt > 0.0f && tt <= T_FAR && tt < best) { best = tt; best_f = f; }
+        // ties go to the lower triangle whatever order they are met in
+        if (tt > 0.0f && tt <= T_FAR && (tt < best || (tt == best && f < best_f))) { best = tt; best_f = f; }
       }
-    }
+    });
     // (t, triangle) as one 64-bit key: positive floats order like their bits, ties go to the lower triangle
     if (live && best < INFINITY) atomicMin(&t_mesh[ray], ((unsigned long long)__builtin_bit_cast(uint32_t, best) << 32) | (uint32_t)best_f);
 }
@@ -363,7 +397,7 @@ struct MarchArgs {
     float step_size, blend_range;
     uint32_t seed_lo, seed_hi;
     int64_t idx0, idx_stride; uint32_t idx_run;
-    const float *spheres, *tris; int n_inst, n_tri; Box box;      // shadow rays: the scene again
+    const float *tris; Box box; Scene inst_scene, tri_scene;      // shadow rays: the scene again, behind its two-level cull
     int min_shadow, n_shadow;
     const uint8_t *kind;                       // per triangle: bit 0 = auxiliary mesh (shaded), bit 1 = primID 1 of its own mesh (shadow filter, :553)
     TexArgs tex;                               // parameter textures on the instancer mesh (getParameters, :640-667); n_tex = 0: none
@@ -407,10 +441,13 @@ __device__ __forceinline__ float mean_distance(float mu_f, float hw_f) {   // in
 constexpr int MAX_SHADOW_ENTRIES = 4096;
 struct SegLds {                               // the segments of the ray (shadow and texture samples are spaced along them)
     float ts[MAX_HITS / 2 + 2], len[MAX_HITS / 2 + 2];   // start and length of a segment (segment_lengths, :802-821)
+    float off[MAX_HITS / 2 + 2];              // its segment_offset (:1001)
+    int step0[MAX_HITS / 2 + 2];              // the first marching step emitted in it; [n_segments] = number of steps
     uint8_t g_seg[MAX_HITS + 8];              // the segment gap j lies in
 };
 struct ShadowLds {
-    uint32_t bits[MAX_SHADOW_ENTRIES / 32];   // the shadow samples of the ray's segments, one bit each
+    uint32_t bits[MAX_SHADOW_ENTRIES / 32];   // the shadow queries of the ray, one bit each: its shadow samples, or its marching steps
+    int32_t cand_id[128]; float cand_a0[128], cand_a1[128];   // occluders waiting for their exact tests: id and the stretch of the ray they can shadow
     float sl[MAX_HITS / 2 + 2];               // the spacing of a segment's shadow samples
     uint16_t base[MAX_HITS / 2 + 4];          // first entry of segment i in `bits`; [n_segments] = number of entries
 };
@@ -428,24 +465,26 @@ template <bool SHADOW, bool TEX> struct MarchLds {
     typename std::conditional<TEX, TexLds, NoLds>::type tx;
 };
 
-// isShadowed for 64 points at once: lane = a point (px,py,pz) on the wave's primary ray, all with direction (lx,ly,lz).  Every
-// shadow ray of the wave lies in the plane through the primary ray along the light direction, so a patch or triangle whose
-// sphere stays clear of that plane is nobody's occluder: lane per instance tests that (a ballot per 64 instances), and only the
-// set bits are walked with the full test.  Accepted: the top face of a patch box entered from outside, its bottom face either
-// way (primID 4 / 1 of createAABB), a triangle hit from its front.  Call in uniform control flow.
-__device__ __forceinline__ bool occluded(const MarchArgs &a, int lane, float ox, float oy, float oz, float dx, float dy, float dz,
-                                         float tp, float px, float py, float pz, float lx, float ly, float lz) {
-    const float nx = dy * lz - dz * ly, ny = dz * lx - dx * lz, nz = dx * ly - dy * lx;          // normal of the plane, not normalised
-    const float nn = (nx * nx + ny * ny) + nz * nz;                                             // = |d|^2 |l|^2 - (d.l)^2
-    const float ll = (lx * lx + ly * ly) + lz * lz, ddq = (dx * dx + dy * dy) + dz * dz, dl_ = (dx * lx + dy * ly) + dz * lz;
-    // ... and inside the plane the shadow rays sweep the strip { o + alpha d + beta l : ta <= alpha <= tb, beta >= 0 }: a sphere whose
-    // centre has oblique coordinates (alpha, beta) reaches alpha +- r |l| / sqrt(nn), beta +- r |d| / sqrt(nn)
-    float ta = tp, tb = tp;
-    for (int o = 32; o > 0; o >>= 1) { ta = fminf(ta, __shfl_xor(ta, o)); tb = fmaxf(tb, __shfl_xor(tb, o)); }
-    const bool strip = nn > 1e-10f * ddq * ll;                                                  // d and l not parallel
-    const float inv_nn = strip ? 1.0f / nn : 0.0f, inv_rt = strip ? 1.0f / __builtin_sqrtf(nn) : 0.0f;
-    const float ra = __builtin_sqrtf(ll) * inv_rt * 1.01f, rb = __builtin_sqrtf(ddq) * inv_rt * 1.01f;
-    auto reaches = [&](const float *c, float r2) {
+// ---- shadow rays (instancer.cpp:591-602, filter :543-554) ---------------------------------------------------------------------
+// Every shadow ray of a primary ray (o, d) starts on it, at o + alpha d, and runs along the one light direction l: they all lie in the
+// plane through the ray along l, and sweep the strip { o + alpha d + beta l : alpha_min <= alpha <= alpha_max, beta >= 0 } of it.
+struct Strip {
+    float ox, oy, oz, dx, dy, dz, lx, ly, lz;
+    float nx, ny, nz, nn, ll, ddq, dl_, inv_nn, ra, rb, ta, tb;
+    bool strip;
+    __device__ __forceinline__ Strip(float ox_, float oy_, float oz_, float dx_, float dy_, float dz_, float lx_, float ly_, float lz_, float ta_, float tb_)
+        : ox(ox_), oy(oy_), oz(oz_), dx(dx_), dy(dy_), dz(dz_), lx(lx_), ly(ly_), lz(lz_), ta(ta_), tb(tb_) {
+        nx = dy * lz - dz * ly; ny = dz * lx - dx * lz; nz = dx * ly - dy * lx;                   // normal of the plane, not normalised
+        nn = (nx * nx + ny * ny) + nz * nz;                                                       // = |d|^2 |l|^2 - (d.l)^2
+        ll = (lx * lx + ly * ly) + lz * lz; ddq = (dx * dx + dy * dy) + dz * dz; dl_ = (dx * lx + dy * ly) + dz * lz;
+        strip = nn > 1e-10f * ddq * ll;                                                           // d and l not parallel
+        inv_nn = strip ? 1.0f / nn : 0.0f;
+        const float inv_rt = strip ? 1.0f / __builtin_sqrtf(nn) : 0.0f;
+        ra = __builtin_sqrtf(ll) * inv_rt * 1.01f; rb = __builtin_sqrtf(ddq) * inv_rt * 1.01f;
+    }
+    // can the sphere (c, r^2) meet the strip?  Inside the plane a sphere whose centre has oblique coordinates (alpha, beta) reaches
+    // alpha +- r |l| / sqrt(nn), beta +- r |d| / sqrt(nn).  Conservative.
+    __device__ __forceinline__ bool reaches(const float *c, float r2) const {
         const float wx = c[0] - ox, wy = c[1] - oy, wz = c[2] - oz;
         const float h0 = (wx * nx + wy * ny) + wz * nz;
         if (!(h0 * h0 <= r2 * nn * 1.001f)) return false;
@@ -459,68 +498,124 @@ __device__ __forceinline__ bool occluded(const MarchArgs &a, int lane, float ox,
         const float r = __builtin_sqrtf(r2);
         const float tol = 1e-4f * (fabsf(alpha) + fabsf(beta) + 1.0f);
         return alpha + r * ra + tol >= ta && alpha - r * ra - tol <= tb && beta + r * rb + tol >= 0.0f;
-    };
-    bool occ = false;
-    for (int k0 = 0; k0 < a.n_inst; k0 += 64) {
-        const int k = k0 + lane;
-        bool near = false;
-        if (k < a.n_inst) {
-            const float *sp = a.spheres + (size_t)k * 4;
-            near = reaches(sp, sp[3]);
-        }
-        uint64_t mk = __ballot(near);
-        while (mk) {
-            const int kk = k0 + __builtin_ctzll(mk);
-            mk &= mk - 1;
-            const float *sp = a.spheres + (size_t)kk * 4;                                     // wave-uniform from here on
-            const float cx = sp[0] - px, cy = sp[1] - py, cz = sp[2] - pz;
-            const float qx = cy * lz - cz * ly, qy = cz * lx - cx * lz, qz = cx * ly - cy * lx;
-            if (!__any((qx * qx + qy * qy) + qz * qz <= sp[3] * ll)) continue;
-            const float *m = a.mats + (size_t)kk * 12;
-            float ol[3], dl[3];
-            affine(m, px, py, pz, ol);
-            linear34(m, lx, ly, lz, dl);
-            if (dl[2] != 0.0f) {
-                const float inv = 1.0f / dl[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float z = e ? a.box.b0[2] : a.box.b1[2];
-                    const float tt = (z - ol[2]) * inv;
-                    const float x = ol[0] + tt * dl[0], y = ol[1] + tt * dl[1];
-                    const bool on_face = tt > 0.0f && tt <= T_FAR && a.box.b0[0] <= x && x <= a.box.b1[0] && a.box.b0[1] <= y && y <= a.box.b1[1];
-                    occ = occ || (on_face && (e == 1 || dl[2] < 0.0f));
-                }
-            }
-        }
     }
-    for (int f0 = 0; f0 < a.n_tri; f0 += 64) {
-        const int f = f0 + lane;
-        bool near = false;
-        if (f < a.n_tri) {
-            const float *tr = a.tris + (size_t)f * 13;
-            near = reaches(tr + 9, tr[12]);
-        }
-        uint64_t mk = __ballot(near);
-        while (mk) {
-            const int ff = f0 + __builtin_ctzll(mk);
-            mk &= mk - 1;
-            const float *tr = a.tris + (size_t)ff * 13;
-            const float *v0 = tr, *e1 = tr + 3, *e2 = tr + 6;
-            const float p[3] = {ly * e2[2] - lz * e2[1], lz * e2[0] - lx * e2[2], lx * e2[1] - ly * e2[0]};
-            const float det = (e1[0] * p[0] + e1[1] * p[1]) + e1[2] * p[2];
-            const float inv_det = 1.0f / det;
-            const float sv[3] = {px - v0[0], py - v0[1], pz - v0[2]};
-            const float u = ((sv[0] * p[0] + sv[1] * p[1]) + sv[2] * p[2]) * inv_det;
-            const float q[3] = {sv[1] * e1[2] - sv[2] * e1[1], sv[2] * e1[0] - sv[0] * e1[2], sv[0] * e1[1] - sv[1] * e1[0]};
-            const float v = ((lx * q[0] + ly * q[1]) + lz * q[2]) * inv_det;
-            const float tt = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv_det;
-            const float ng[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-            const bool front = (lx * ng[0] + ly * ng[1]) + lz * ng[2] < 0.0f;
-            // ... or the triangle is primID 1 of its mesh: the filter's last clause does not ask for the geometry (instancer.cpp:553)
-            occ = occ || (det != 0.0f && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && tt > 0.0f && tt <= T_FAR && (front || (a.kind[ff] & 2)));
+};
+
+// the EXACT tests, spelled like the restatement: is the shadow ray from p along l stopped by instance k / by triangle f?
+// Accepted (filter :543-554): the top face of a patch box entered from outside, its bottom face either way (primID 4 / 1 of createAABB),
+// a triangle hit from its front or primID 1 of its mesh from either side.
+__device__ __forceinline__ bool instance_occludes(const float *__restrict__ mats, const Box &box, int k, float px, float py, float pz, float lx, float ly, float lz) {
+    const float *m = mats + (size_t)k * 12;
+    float ol[3], dl[3];
+    affine(m, px, py, pz, ol);
+    linear34(m, lx, ly, lz, dl);
+    bool occ = false;
+    if (dl[2] != 0.0f) {
+        const float inv = 1.0f / dl[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float z = e ? box.b0[2] : box.b1[2];
+            const float tt = (z - ol[2]) * inv;
+            const float x = ol[0] + tt * dl[0], y = ol[1] + tt * dl[1];
+            const bool on_face = tt > 0.0f && tt <= T_FAR && box.b0[0] <= x && x <= box.b1[0] && box.b0[1] <= y && y <= box.b1[1];
+            occ = occ || (on_face && (e == 1 || dl[2] < 0.0f));
         }
     }
     return occ;
+}
+__device__ __forceinline__ bool triangle_occludes(const float *__restrict__ tris, const uint8_t *__restrict__ kind, int f, float px, float py, float pz, float lx, float ly, float lz) {
+    const float *tr = tris + (size_t)f * 13;
+    const float *v0 = tr, *e1 = tr + 3, *e2 = tr + 6;
+    const float p[3] = {ly * e2[2] - lz * e2[1], lz * e2[0] - lx * e2[2], lx * e2[1] - ly * e2[0]};
+    const float det = (e1[0] * p[0] + e1[1] * p[1]) + e1[2] * p[2];
+    const float inv_det = 1.0f / det;
+    const float sv[3] = {px - v0[0], py - v0[1], pz - v0[2]};
+    const float u = ((sv[0] * p[0] + sv[1] * p[1]) + sv[2] * p[2]) * inv_det;
+    const float q[3] = {sv[1] * e1[2] - sv[2] * e1[1], sv[2] * e1[0] - sv[0] * e1[2], sv[0] * e1[1] - sv[1] * e1[0]};
+    const float v = ((lx * q[0] + ly * q[1]) + lz * q[2]) * inv_det;
+    const float tt = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv_det;
+    const float ng[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const bool front = (lx * ng[0] + ly * ng[1]) + lz * ng[2] < 0.0f;
+    // ... or the triangle is primID 1 of its mesh: the filter's last clause does not ask for the geometry (instancer.cpp:553)
+    return det != 0.0f && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && tt > 0.0f && tt <= T_FAR && (front || (kind[f] & 2));
+}
+
+// isShadowed for ONE point (all lanes the same p and l): the closing sample of a ray that ends on an auxiliary mesh (shadeMesh, :736).
+// The wave walks the two-level cull with the shadow ray's own line, lane per occluder, and votes.
+__device__ __forceinline__ bool occluded_point(const MarchArgs &a, int lane, float px, float py, float pz, float lx, float ly, float lz) {
+    const Strip st(px, py, pz, lx, ly, lz, lx, ly, lz, 0.0f, 0.0f);                               // d = l: nn == 0, the line (p, l)
+    bool occ = false;
+    walk_blocks(a.inst_scene, 0, a.inst_scene.nb, lane, [&](const float *c, float r2) { return st.reaches(c, r2); },
+                [&](int id, bool near) { if (near) occ = occ || instance_occludes(a.mats, a.box, id, px, py, pz, lx, ly, lz); });
+    walk_blocks(a.tri_scene, 0, a.tri_scene.nb, lane, [&](const float *c, float r2) { return st.reaches(c, r2); },
+                [&](int id, bool near) { if (near) occ = occ || triangle_occludes(a.tris, a.kind, id, px, py, pz, lx, ly, lz); });
+    return __any(occ);
+}
+
+// Keep the alphas with lo <= A + B alpha <= hi in [a0, a1], WIDENED by a margin far above what float32 rounding can move either this
+// linear form or the exact test it stands in for: a cull, never a decision.
+__device__ __forceinline__ void clip_alpha(float A, float B, float lo, float hi, float amax, float &a0, float &a1) {
+    const float m = 1e-4f * (((fabsf(A) + fabsf(B) * amax) + (fabsf(lo) + fabsf(hi))) + 1.0f);
+    const float l = lo - m, h = hi + m;
+    if (fabsf(B) * amax <= m) {                                         // flat over the range: A decides (NaN: nothing passes, as in the exact test)
+        if (!(A >= l - m && A <= h + m)) { a0 = INFINITY; a1 = -INFINITY; }
+        return;
+    }
+    const float x0 = (l - A) / B, x1 = (h - A) / B;
+    const float lo_a = x0 < x1 ? x0 : x1, hi_a = x0 < x1 ? x1 : x0;
+    a0 = lo_a > a0 ? lo_a : a0;
+    a1 = hi_a < a1 ? hi_a : a1;
+}
+
+// The stretch [a0, a1] of the primary ray from which a shadow ray can be stopped by instance k (empty: a0 > a1): in patch coordinates the
+// point is ol0 + alpha dd and the shadow ray runs along dl, so where it meets the plane of a face -- tau, x, y -- is LINEAR in alpha.
+__device__ __forceinline__ void instance_interval(const float *__restrict__ mats, const Box &box, int k, const Strip &st, float amax, float &a0, float &a1) {
+    const float *m = mats + (size_t)k * 12;
+    float ol0[3], dd[3], dl[3];
+    affine(m, st.ox, st.oy, st.oz, ol0);
+    linear34(m, st.dx, st.dy, st.dz, dd);
+    linear34(m, st.lx, st.ly, st.lz, dl);
+    float lo_all = INFINITY, hi_all = -INFINITY;
+    if (dl[2] != 0.0f) {
+        const float inv = 1.0f / dl[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (e == 0 && !(dl[2] < 0.0f)) continue;                    // the top face counts only when entered from outside
+            const float z = e ? box.b0[2] : box.b1[2];
+            const float At = (z - ol0[2]) * inv, Bt = -dd[2] * inv;     // tau(alpha)
+            float f0 = st.ta, f1 = st.tb;
+            clip_alpha(At, Bt, 0.0f, T_FAR, amax, f0, f1);
+            clip_alpha(ol0[0] + At * dl[0], dd[0] + Bt * dl[0], box.b0[0], box.b1[0], amax, f0, f1);
+            clip_alpha(ol0[1] + At * dl[1], dd[1] + Bt * dl[1], box.b0[1], box.b1[1], amax, f0, f1);
+            if (f0 <= f1) { lo_all = f0 < lo_all ? f0 : lo_all; hi_all = f1 > hi_all ? f1 : hi_all; }
+        }
+    }
+    a0 = lo_all; a1 = hi_all;
+}
+// ... and by triangle f: Moeller-Trumbore's u, v, tau for the origin o + alpha d are linear in alpha too
+__device__ __forceinline__ void triangle_interval(const float *__restrict__ tris, const uint8_t *__restrict__ kind, int f, const Strip &st, float amax, float &a0, float &a1) {
+    const float *tr = tris + (size_t)f * 13;
+    const float *v0 = tr, *e1 = tr + 3, *e2 = tr + 6;
+    const float lx = st.lx, ly = st.ly, lz = st.lz;
+    const float p[3] = {ly * e2[2] - lz * e2[1], lz * e2[0] - lx * e2[2], lx * e2[1] - ly * e2[0]};
+    const float det = (e1[0] * p[0] + e1[1] * p[1]) + e1[2] * p[2];
+    const float ng[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const bool front = (lx * ng[0] + ly * ng[1]) + lz * ng[2] < 0.0f;
+    a0 = INFINITY; a1 = -INFINITY;
+    if (det == 0.0f || !(front || (kind[f] & 2))) return;              // (the same floats as the exact test: the same decision)
+    const float inv_det = 1.0f / det;
+    const float s0[3] = {st.ox - v0[0], st.oy - v0[1], st.oz - v0[2]}, d[3] = {st.dx, st.dy, st.dz};
+    const float q0[3] = {s0[1] * e1[2] - s0[2] * e1[1], s0[2] * e1[0] - s0[0] * e1[2], s0[0] * e1[1] - s0[1] * e1[0]};
+    const float q1[3] = {d[1] * e1[2] - d[2] * e1[1], d[2] * e1[0] - d[0] * e1[2], d[0] * e1[1] - d[1] * e1[0]};
+    const float Au = ((s0[0] * p[0] + s0[1] * p[1]) + s0[2] * p[2]) * inv_det, Bu = ((d[0] * p[0] + d[1] * p[1]) + d[2] * p[2]) * inv_det;
+    const float Av = ((lx * q0[0] + ly * q0[1]) + lz * q0[2]) * inv_det, Bv = ((lx * q1[0] + ly * q1[1]) + lz * q1[2]) * inv_det;
+    const float At = ((e2[0] * q0[0] + e2[1] * q0[1]) + e2[2] * q0[2]) * inv_det, Bt = ((e2[0] * q1[0] + e2[1] * q1[1]) + e2[2] * q1[2]) * inv_det;
+    float f0 = st.ta, f1 = st.tb;
+    clip_alpha(Au, Bu, 0.0f, 1.0f, amax, f0, f1);
+    clip_alpha(Av, Bv, 0.0f, 1.0f, amax, f0, f1);
+    clip_alpha(Au + Av, Bu + Bv, 0.0f, 1.0f, amax, f0, f1);
+    clip_alpha(At, Bt, 0.0f, T_FAR, amax, f0, f1);
+    a0 = f0; a1 = f1;
 }
 
 // fill row[f0 .. f1) with pattern[f % period] (period <= MAX_PARAMS, pattern in LDS or registers through `at`)
@@ -758,13 +853,14 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
     const int n_gaps = m + (has_mesh ? 1 : 0);
     int step = 0;
     {
-        float off_q[4];
+        float off_q[4], off_next[4];
         int f_q[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = lane + 64 * q;
             const bool gap = j < n_gaps && cnt_q[q] > 0;
             off_q[q] = gap ? L.gs.seg.ts[seg_q[q]] : 0.0f;
+            off_next[q] = (j < m && my_enter[q] && cnt_q[q] == 0) ? L.gs.seg.ts[seg_q[q] + 1] : 0.0f;   // event j starts a segment: that segment's offset
             f_q[q] = 0;
             if (gap) {
                 const float tj = j == m ? t_mesh : L.ev_t[j];
@@ -797,11 +893,28 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
             step = __shfl(v, 63);
         }
         if (lane == 0) L.gs.g_step0[n_gaps] = step;
+        if constexpr (SHADOW) {                                              // per segment: its first step and its offset (read off its first gap)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = lane + 64 * q;
+                if (j < m && my_enter[q] && cnt_q[q] == 0) { SG.step0[seg_q[q] + 1] = L.gs.g_step0[j + 1]; SG.off[seg_q[q] + 1] = off_next[q]; }
+            }
+            if (lane == 0) SG.step0[n_starts] = step;
+        }
     }
     __builtin_amdgcn_wave_barrier();
 
-    // ---- the shadow samples of the ray (instancer.cpp:861, 1018-1027): a segment of length len gets n = max(min, N * len / total)
-    // samples spaced len / (n - 1) from its start; sample k of segment i is bit base[i] + k ---------------------------------------
+    // ---- shadow queries (instancer.cpp:861, 945-961, 1018-1027).  With N = max(min, n * total) < n_pts the ray has shadow SAMPLES: a
+    // segment of length len gets max(min, N * len / total) of them spaced len / (n - 1) from its start (sample k of segment i = bit
+    // base[i] + k), and a step takes the nearer of the two around it; else every STEP makes its own query (bit = the step).  Either way
+    // the queries are points o + alpha d of this ray asking along one light direction, and they are all answered here, before the steps:
+    //   1. the two-level cull finds the occluders whose sphere meets the strip the shadow rays sweep (lane per occluder)
+    //   2. for each, the stretch [a0, a1] of the ray from which a shadow ray can be stopped by it -- where the shadow ray meets a face
+    //      is linear in alpha -- widened well beyond rounding; mostly empty (a low sun meets a patch's top face from few places)
+    //   3. the queries inside [a0, a1] pair up with the occluder; the pairs of 64 occluders are dealt out lane per pair, each gets the
+    //      EXACT test of the restatement, and a hit sets the query's bit.
+    // Culls 1 and 2 only ever drop pairs the exact test would turn down, so the bits are those of testing every pair.
     bool interpolate = false;
     bool overflow_shadow = false;
     if constexpr (SHADOW) {
@@ -809,32 +922,137 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
             const uint32_t n_ray = (uint32_t)((float)(uint32_t)a.n_shadow * total);
             const uint32_t n_shadow = n_ray > (uint32_t)a.min_shadow ? n_ray : (uint32_t)a.min_shadow;
             interpolate = n_shadow < (uint32_t)S;
+            int n_targets = step;
+            float a_min = INFINITY, a_max = -INFINITY;
             if (interpolate) {
                 int entries = 0;
                 for (int i = 0; i < n_starts; ++i) {
                     const float len = SG.len[i];
                     const uint32_t ns = (uint32_t)(((float)n_shadow * len) / total);
                     const int n_seg = (int)(ns > (uint32_t)a.min_shadow ? ns : (uint32_t)a.min_shadow);
-                    SH.sl[i] = len / (float)(uint32_t)(n_seg - 1);
+                    const float sl = len / (float)(uint32_t)(n_seg - 1);
+                    SH.sl[i] = sl;
                     SH.base[i] = (uint16_t)entries;
                     entries += n_seg + 1;
                     if (entries > MAX_SHADOW_ENTRIES) { overflow_shadow = true; entries = MAX_SHADOW_ENTRIES; }
+                    const float t_first = SG.ts[i], t_last = SG.ts[i] + (float)(uint32_t)n_seg * sl;
+                    a_min = fminf(a_min, fminf(t_first, t_last)); a_max = fmaxf(a_max, fmaxf(t_first, t_last));
                 }
                 SH.base[n_starts] = (uint16_t)entries;
-                __builtin_amdgcn_wave_barrier();
-                const float lx0 = L.par[a.light_dir_idx], ly0 = L.par[a.light_dir_idx + 1], lz0 = L.par[a.light_dir_idx + 2];
-                for (int x0 = 0; x0 < entries; x0 += 64) {
-                    const int x = x0 + lane;
+                n_targets = entries;
+            }
+            for (int w = lane; w < (n_targets + 31) / 32; w += 64) SH.bits[w] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            // the query's parameter on the ray, as the steps below and the restatement work it out
+            auto target_alpha = [&](int x) -> float {
+                if (interpolate) {
                     int i = 0;
                     for (int q = 1; q < n_starts; ++q) i += (int)SH.base[q] <= x ? 1 : 0;
                     const int k = x - (int)SH.base[i];
-                    const float tk = SG.ts[i] + (float)(uint32_t)k * SH.sl[i];
-                    const bool occ = occluded(a, lane, ox, oy, oz, dx, dy, dz, tk, ox + tk * dx, oy + tk * dy, oz + tk * dz, lx0, ly0, lz0);
-                    const uint64_t mk = __ballot(occ && x < entries);
-                    if (lane == 0) { SH.bits[x0 >> 5] = (uint32_t)mk; SH.bits[(x0 >> 5) + 1] = (uint32_t)(mk >> 32); }
+                    return SG.ts[i] + (float)(uint32_t)k * SH.sl[i];
                 }
-                __builtin_amdgcn_wave_barrier();
+                int lo = 0, hi = n_gaps;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (L.gs.g_step0[mid] <= x) lo = mid; else hi = mid;
+                }
+                const float t_mu = ((float)x * h + t_offset) + L.g_off[lo];
+                return a.use_mean ? mean_distance(t_mu, h) : t_mu;
+            };
+            if (!interpolate && n_targets > 0) { a_min = target_alpha(0); a_max = target_alpha(n_targets - 1); }
+            if (n_targets > 0 && a_min <= a_max) {
+                const float lx0 = L.par[a.light_dir_idx], ly0 = L.par[a.light_dir_idx + 1], lz0 = L.par[a.light_dir_idx + 2];
+                const float pad = 1e-5f * (fabsf(a_min) + fabsf(a_max)) + 1e-30f;
+                const Strip st(ox, oy, oz, dx, dy, dz, lx0, ly0, lz0, a_min - pad, a_max + pad);
+                const float amax = fmaxf(fabsf(a_min), fabsf(a_max)) + pad;
+                // the queries that can lie in [a0, a1], as a range of bits (generous by a sample or step at either end)
+                auto target_range = [&](float a0, float a1, int &x0, int &x1) {
+                    x0 = 0x7fffffff; x1 = -1;
+                    for (int i = 0; i < n_starts; ++i) {
+                        int lo_x, hi_x;                                                      // the segment's queries lo_x .. hi_x, at first + k * spacing
+                        float first, spacing, lead;
+                        if (interpolate) {
+                            lo_x = (int)SH.base[i]; hi_x = (int)SH.base[i + 1] - 1;
+                            if (hi_x >= n_targets) hi_x = n_targets - 1;
+                            first = SG.ts[i]; spacing = SH.sl[i]; lead = 1.0f;
+                        } else {
+                            lo_x = SG.step0[i]; hi_x = SG.step0[i + 1] - 1;
+                            first = ((float)lo_x * h + t_offset) + SG.off[i]; spacing = h; lead = a.use_mean ? 4.0f : 2.0f;   // (a mean distance lies up to 2 h behind t_mu)
+                        }
+                        if (hi_x < lo_x) continue;
+                        int k0 = 0, k1 = hi_x - lo_x;
+                        if (spacing > 0.0f) {
+                            const float q0 = (a0 - first) / spacing - lead, q1 = (a1 - first) / spacing + 2.0f;
+                            if (q1 < 0.0f || q0 > (float)k1) continue;
+                            k0 = q0 > 0.0f ? (int)q0 : 0;
+                            k1 = q1 < (float)k1 ? (int)q1 : k1;
+                        }
+                        x0 = lo_x + k0 < x0 ? lo_x + k0 : x0;
+                        x1 = lo_x + k1 > x1 ? lo_x + k1 : x1;
+                    }
+                };
+                int n_cand = 0;
+                const uint64_t ltm = (1ull << lane) - 1ull;
+                // the exact tests of the first `count` (<= 64) occluders waiting in the list, lane per (occluder, query) pair
+                auto flush = [&](bool is_tri, int count) {
+                    int id = 0, x0 = 0, cnt = 0;
+                    if (lane < count) {
+                        int x1;
+                        id = SH.cand_id[lane];
+                        target_range(SH.cand_a0[lane], SH.cand_a1[lane], x0, x1);
+                        cnt = x1 >= x0 ? x1 - x0 + 1 : 0;
+                    }
+                    int incl = cnt;
+                    for (int o = 1; o < 64; o <<= 1) { const int w = __shfl_up(incl, o); if (lane >= o) incl += w; }
+                    const int total_pairs = __shfl(incl, 63);
+                    for (int p0 = 0; p0 < total_pairs; p0 += 64) {
+                        const int pp = p0 + lane;
+                        int cl = 0;                                                          // the first occluder whose inclusive count exceeds pp
+#pragma unroll
+                        for (int bit = 32; bit > 0; bit >>= 1) { const int v = __shfl(incl, cl + bit - 1); if (v <= pp) cl += bit; }
+                        cl = cl < 63 ? cl : 63;
+                        const int pid = __shfl(id, cl), px0 = __shfl(x0, cl), pincl = __shfl(incl, cl), pcnt = __shfl(cnt, cl);
+                        if (pp < total_pairs) {
+                            const int x = px0 + (pp - (pincl - pcnt));
+                            const float tk = target_alpha(x);
+                            const float px = ox + tk * dx, py = oy + tk * dy, pz = oz + tk * dz;
+                            const bool occ = is_tri ? triangle_occludes(a.tris, a.kind, pid, px, py, pz, lx0, ly0, lz0)
+                                                    : instance_occludes(a.mats, a.box, pid, px, py, pz, lx0, ly0, lz0);
+                            if (occ) atomicOr(&SH.bits[x >> 5], 1u << (x & 31));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int rest = n_cand - count;                                         // (< 64) the others move to the front
+                    int rid = 0; float r0 = 0.0f, r1 = 0.0f;
+                    if (lane < rest) { rid = SH.cand_id[count + lane]; r0 = SH.cand_a0[count + lane]; r1 = SH.cand_a1[count + lane]; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rest) { SH.cand_id[lane] = rid; SH.cand_a0[lane] = r0; SH.cand_a1[lane] = r1; }
+                    __builtin_amdgcn_wave_barrier();
+                    n_cand = rest;
+                };
+                auto gather = [&](const Scene &sc, bool is_tri) {
+                    walk_blocks(sc, 0, sc.nb, lane, [&](const float *c, float r2) { return st.reaches(c, r2); }, [&](int id, bool near) {
+                        float a0 = INFINITY, a1 = -INFINITY;
+                        if (near) {
+                            if (is_tri) triangle_interval(a.tris, a.kind, id, st, amax, a0, a1);
+                            else instance_interval(a.mats, a.box, id, st, amax, a0, a1);
+                        }
+                        const bool keep = near && a0 <= a1;
+                        const uint64_t km = __ballot(keep);
+                        if (keep) {
+                            const int at = n_cand + __builtin_popcountll(km & ltm);
+                            SH.cand_id[at] = id; SH.cand_a0[at] = a0; SH.cand_a1[at] = a1;
+                        }
+                        n_cand += __builtin_popcountll(km);
+                        __builtin_amdgcn_wave_barrier();
+                        if (n_cand >= 64) flush(is_tri, 64);
+                    });
+                    if (n_cand > 0) flush(is_tri, n_cand);
+                };
+                gather(a.inst_scene, false);
+                gather(a.tri_scene, true);
             }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 
@@ -1043,8 +1261,8 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
                     const float t0 = ts + (float)(uint32_t)(k - 1) * sl;
                     const int e = (int)SH.base[i] + ((t_pt - t0) / sl >= 0.5f ? k : k - 1);
                     shadowed = e < MAX_SHADOW_ENTRIES && ((SH.bits[e >> 5] >> (e & 31)) & 1u);
-                } else {                                                                        // :959-961: a query per step
-                    shadowed = occluded(a, lane, ox, oy, oz, dx, dy, dz, t_pt, px, py, pz, lx, ly, lz);
+                } else {                                                                        // :959-961: a query per step, answered above
+                    shadowed = live && ((SH.bits[s >> 5] >> (s & 31)) & 1u);
                 }
                 if (shadowed) { l3[0] = 0.0f; l3[1] = 0.0f; l3[2] = -1.0f; }
             }
@@ -1178,8 +1396,7 @@ __global__ __launch_bounds__(256) void inst_shade_kernel(MarchArgs a, ShadeArgs 
     const float *par = a.params + (size_t)ray * a.n_params;
     const float lx = par[a.light_dir_idx], ly = par[a.light_dir_idx + 1], lz = par[a.light_dir_idx + 2];
     const float px = (o[0] + tm * d[0]) + n[0] * 1e-6f, py = (o[1] + tm * d[1]) + n[1] * 1e-6f, pz = (o[2] + tm * d[2]) + n[2] * 1e-6f;
-    // `occluded` takes the wave's points as lying on one ray: here they are one point, at parameter 0 of the ray (p, l) itself
-    const bool dark = occluded(a, lane, px, py, pz, lx, ly, lz, 0.0f, px, py, pz, lx, ly, lz);
+    const bool dark = occluded_point(a, lane, px, py, pz, lx, ly, lz);
     float nlx = lx, nly = ly, nlz = lz;
     normalized(nlx, nly, nlz);
     const float nd = (n[0] * nlx + n[1] * nly) + n[2] * nlz;
@@ -1213,6 +1430,8 @@ struct ntx_instancer {
     unsigned long long *d_tmesh = nullptr;
     float *d_normals = nullptr; int32_t *d_faces = nullptr; uint8_t *d_kind = nullptr; bool has_aux = false;   // auxiliary meshes
     int64_t n_mesh_vertices = 0;
+    // the cull's hierarchy: objects in Morton order behind a permutation, a sphere around every block of 64 of them
+    int32_t *d_iperm = nullptr, *d_tperm = nullptr; float *d_ibs = nullptr, *d_tbs = nullptr;
     float *d_uv = nullptr; int32_t *d_face_tex = nullptr; float *d_atexels = nullptr; ntx_inst::TexTable *d_atable = nullptr;   // their textures
     // parameter textures on the instancer mesh: texels + tables, the mesh in its grid
     ntx_inst::TexArgs tex{};
@@ -1252,9 +1471,61 @@ void release(ntx_instancer *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (void *q : {(void *)p->d_mats, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_xforms, (void *)p->d_normals, (void *)p->d_faces, (void *)p->d_kind, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits,
-                    (void *)p->d_uv, (void *)p->d_face_tex, (void *)p->d_atexels, (void *)p->d_atable, (void *)p->d_ptexels, (void *)p->d_gtris, (void *)p->d_face_uv, (void *)p->d_ptable, (void *)p->d_cell_start, (void *)p->d_cand})
+                    (void *)p->d_uv, (void *)p->d_face_tex, (void *)p->d_atexels, (void *)p->d_atable, (void *)p->d_ptexels, (void *)p->d_gtris, (void *)p->d_face_uv, (void *)p->d_ptable, (void *)p->d_cell_start, (void *)p->d_cand,
+                    (void *)p->d_iperm, (void *)p->d_tperm, (void *)p->d_ibs, (void *)p->d_tbs})
         if (q) (void)hipFree(q);
     delete p;
+}
+
+// Morton order of sphere centres + a sphere around every block of 64 consecutive ones: what the kernels' two-level cull walks.
+// spheres: n entries of `stride` floats, (centre, r^2) at the front.
+void build_blocks(const float *spheres, int64_t n, int stride, std::vector<int32_t> &perm, std::vector<float> &bs) {
+    perm.resize((size_t)n);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) { const double x = spheres[i * stride + c]; if (x < lo[c]) lo[c] = x; if (x > hi[c]) hi[c] = x; }
+    std::vector<std::pair<uint64_t, int32_t>> key((size_t)n);
+    auto spread = [](uint64_t v) { v &= 0x1fffff; v = (v | v << 32) & 0x1f00000000ffffULL; v = (v | v << 16) & 0x1f0000ff0000ffULL; v = (v | v << 8) & 0x100f00f00f00f00fULL;
+                                   v = (v | v << 4) & 0x10c30c30c30c30c3ULL; v = (v | v << 2) & 0x1249249249249249ULL; return v; };
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t code = 0;
+        for (int c = 0; c < 3; ++c) {
+            const double w = hi[c] > lo[c] ? (spheres[i * stride + c] - lo[c]) / (hi[c] - lo[c]) : 0.0;
+            const uint64_t q = (uint64_t)(w * 2097151.0);
+            code |= spread(std::isfinite(w) ? q : 0) << c;
+        }
+        key[(size_t)i] = {code, (int32_t)i};
+    }
+    std::sort(key.begin(), key.end());
+    for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = key[(size_t)i].second;
+    const int64_t nb = (n + 63) / 64;
+    bs.assign((size_t)(nb ? nb : 1) * 4, 0.0f);
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t i0 = b * 64, i1 = i0 + 64 < n ? i0 + 64 : n;
+        double c[3] = {0, 0, 0}, r = 0.0;
+        for (int64_t i = i0; i < i1; ++i)
+            for (int k = 0; k < 3; ++k) c[k] += spheres[(int64_t)perm[(size_t)i] * stride + k];
+        for (int k = 0; k < 3; ++k) c[k] /= (double)(i1 - i0);
+        for (int64_t i = i0; i < i1; ++i) {
+            const float *sp = spheres + (int64_t)perm[(size_t)i] * stride;
+            double d2 = 0.0;
+            for (int k = 0; k < 3; ++k) d2 += (sp[k] - c[k]) * (sp[k] - c[k]);
+            const double rr = std::sqrt(d2) + std::sqrt((double)sp[3]);
+            r = rr > r ? rr : r;
+        }
+        for (int k = 0; k < 3; ++k) bs[(size_t)b * 4 + k] = (float)c[k];
+        bs[(size_t)b * 4 + 3] = (float)(r * r * 1.002 + 1e-12);
+    }
+}
+
+int upload_blocks(const std::vector<int32_t> &perm, const std::vector<float> &bs, int32_t **d_perm, float **d_bs) {
+    for (void **q : {(void **)d_perm, (void **)d_bs})
+        if (*q) { (void)hipFree(*q); *q = nullptr; }
+    INST_TRY(hipMalloc((void **)d_perm, (perm.empty() ? 1 : perm.size()) * sizeof(int32_t)));
+    if (!perm.empty()) INST_TRY(hipMemcpy(*d_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    INST_TRY(hipMalloc((void **)d_bs, bs.size() * sizeof(float)));
+    INST_TRY(hipMemcpy(*d_bs, bs.data(), bs.size() * sizeof(float), hipMemcpyHostToDevice));
+    return NTX_OK;
 }
 
 int reserve(ntx_instancer *p, int64_t max_rays) {
@@ -1340,6 +1611,11 @@ int ntx_instancer_create(const ntx_instancer_desc *desc, const float *transforma
         }
         rc = up(&p->d_xforms, xf);
     }
+    if (rc == NTX_OK) {
+        std::vector<int32_t> perm; std::vector<float> bs;
+        build_blocks(p->h_spheres.data(), n_instances, 4, perm, bs);
+        rc = upload_blocks(perm, bs, &p->d_iperm, &p->d_ibs);
+    }
     if (rc == NTX_OK) rc = reserve(p, NTX_INSTANCER_DEFAULT_MAX_RAYS);
     if (rc != NTX_OK) { release(p); return rc; }
     *out = p;
@@ -1410,6 +1686,12 @@ int ntx_instancer_set_meshes(ntx_instancer *inst, const float *vertices, const f
     if (n_faces > 0) {
         INST_TRY(hipMalloc((void **)&inst->d_tris, tris.size() * sizeof(float)));
         INST_TRY(hipMemcpy(inst->d_tris, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice));
+        {
+            std::vector<int32_t> perm; std::vector<float> bs;
+            build_blocks(tris.data() + 9, n_faces, 13, perm, bs);
+            const int rcb = upload_blocks(perm, bs, &inst->d_tperm, &inst->d_tbs);
+            if (rcb != NTX_OK) return rcb;
+        }
         {   // bit 0: auxiliary; bit 1: primID 1 of its own mesh (one mesh when no kinds are given)
             std::vector<uint8_t> kind((size_t)n_faces, 0);
             for (int64_t f = 0; f < n_faces; ++f) kind[f] = face_kind ? face_kind[f] : (uint8_t)(f == 1 ? 2 : 0);
@@ -1736,19 +2018,24 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         const float *ro = rays_o + c0 * 3, *rd = rays_d + c0 * 3;
         INST_TRY(hipMemsetAsync(inst->d_count, 0, (size_t)n * sizeof(uint32_t), st));
         const int tiles = (n + 63) / 64;
+        const Scene isc{inst->d_spheres, 4, inst->d_iperm, inst->d_ibs, K, (K + 63) / 64};
+        const Scene tsc{F > 0 ? inst->d_tris + 9 : nullptr, 13, inst->d_tperm, inst->d_tbs, F, (F + 63) / 64};
+        // a wave takes 64 rays x a range of blocks (64 objects each); ranges short enough for >= 4096 waves, what fills 256 CUs
+        auto split = [&](int nb, int &bpw, int &gy) {
+            bpw = (int)(((int64_t)nb * tiles) / 4096);
+            bpw = bpw < 1 ? 1 : bpw;
+            gy = (nb + 4 * bpw - 1) / (4 * bpw);
+        };
         if (K > 0) {
-            // enough waves to fill 256 CUs: a wave takes 64 rays x per_wave instances
-            int per_wave = 256;
-            while (per_wave > 32 && (int64_t)tiles * ((K + per_wave - 1) / per_wave) < 4096) per_wave >>= 1;
-            const int gy = (K + 4 * per_wave - 1) / (4 * per_wave);
-            hipLaunchKernelGGL(inst_hits_kernel, dim3(tiles, gy), dim3(256), 0, st, ro, rd, n, inst->d_mats, inst->d_spheres, K, per_wave, box, inst->d_count, inst->d_hits);
+            int bpw, gy;
+            split(isc.nb, bpw, gy);
+            hipLaunchKernelGGL(inst_hits_kernel, dim3(tiles, gy), dim3(256), 0, st, ro, rd, n, inst->d_mats, isc, bpw, box, inst->d_count, inst->d_hits);
         }
         if (F > 0) {
             INST_TRY(hipMemsetD32Async((hipDeviceptr_t)inst->d_tmesh, (int)INF_BITS, (size_t)n * 2, st));   // high word = +inf: no hit
-            int per_wave = 256;
-            while (per_wave > 32 && (int64_t)tiles * ((F + per_wave - 1) / per_wave) < 4096) per_wave >>= 1;
-            const int gy = (F + 4 * per_wave - 1) / (4 * per_wave);
-            hipLaunchKernelGGL(inst_mesh_kernel, dim3(tiles, gy), dim3(256), 0, st, ro, rd, n, inst->d_tris, F, per_wave, inst->d_tmesh);
+            int bpw, gy;
+            split(tsc.nb, bpw, gy);
+            hipLaunchKernelGGL(inst_mesh_kernel, dim3(tiles, gy), dim3(256), 0, st, ro, rd, n, inst->d_tris, tsc, bpw, inst->d_tmesh);
         }
         MarchArgs a{};
         a.rays_o = ro; a.rays_d = rd; a.params = P > 0 ? parameters + c0 * P : nullptr;
@@ -1770,7 +2057,7 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         // the piece's rays continue the call's index map: local k of the piece = local c0 + k of the call
         if (idx_run == 0xffffffffu) { a.idx0 = idx0 + c0; a.idx_run = 0xffffffffu; a.idx_stride = 0; }
         else { a.idx0 = idx0 + (c0 / idx_run) * idx_stride; a.idx_run = idx_run; a.idx_stride = idx_stride; }
-        a.spheres = inst->d_spheres; a.tris = inst->d_tris; a.n_inst = K; a.n_tri = F; a.box = box;
+        a.tris = inst->d_tris; a.box = box; a.inst_scene = isc; a.tri_scene = tsc;
         a.min_shadow = inst->desc.min_shadow_samples; a.n_shadow = inst->desc.n_shadow_samples;
         a.kind = inst->d_kind; a.tex = inst->tex;
         const bool shadows = inst->desc.cast_shadow_rays && a.light_dir_idx >= 0, textured = inst->tex.n_tex > 0;
