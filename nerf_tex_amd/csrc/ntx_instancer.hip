@@ -101,17 +101,21 @@ __device__ __forceinline__ void normalized(float &x, float &y, float &z) {   // 
 // more than 60 degrees apart switch it off), so it never changes a result.
 struct WaveCone {
     float ax, ay, az, ux, uy, uz, cos_t, sin_t, reach;
-    bool on;
+    float wx, wy, wz, ws, wo;       // ... and a wedge: the 64 rays of a pixel row fan out in ONE plane (unit normal w); ws = the largest sine of a ray
+    bool on, wedge;                 // out of that plane, wo = how far an origin lies off it.  A sphere further from the plane than r + wo + |v| ws is out.
     __device__ __forceinline__ bool reaches(const float *c, float r2) const {
         if (!on) return true;
         const float vx = c[0] - ax, vy = c[1] - ay, vz = c[2] - az;
         const float along = (vx * ux + vy * uy) + vz * uz;
         const float v2 = (vx * vx + vy * vy) + vz * vz;
         const float perp = __builtin_sqrtf(fmaxf(v2 - along * along, 0.0f));
-        const float r = __builtin_sqrtf(r2) * 1.001f + reach;
-        return perp * cos_t - along * sin_t <= r + 1e-4f * (__builtin_sqrtf(v2) + 1.0f);
+        const float rs = __builtin_sqrtf(r2) * 1.001f, vn = __builtin_sqrtf(v2);
+        const float tol = 1e-4f * (vn + 1.0f);
+        if (wedge && fabsf((vx * wx + vy * wy) + vz * wz) > rs + wo + vn * ws + tol) return false;
+        return perp * cos_t - along * sin_t <= rs + reach + tol;
     }
 };
+__device__ __forceinline__ float lane_value(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 __device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
@@ -130,40 +134,71 @@ __device__ __forceinline__ WaveCone wave_cone(float ox, float oy, float oz, floa
     c.reach = wave_max(__builtin_sqrtf((ex * ex + ey * ey) + ez * ez)) * 1.001f;
     c.on = cmin > 0.5f && wave_min(dn) > 0.0f;
     c.cos_t = cmin; c.sin_t = __builtin_sqrtf(fmaxf(1.0f - cmin * cmin, 0.0f));
+    // the wedge's plane: through the apex, along the first and the last ray's directions
+    const float fx = lane_value(nx, 0), fy = lane_value(ny, 0), fz = lane_value(nz, 0), gx = lane_value(nx, 63), gy = lane_value(ny, 63), gz = lane_value(nz, 63);
+    float px = fy * gz - fz * gy, py = fz * gx - fx * gz, pz = fx * gy - fy * gx;
+    const float pn = __builtin_sqrtf((px * px + py * py) + pz * pz);
+    c.wedge = c.on && pn > 1e-6f;
+    const float pinv = c.wedge ? 1.0f / pn : 0.0f;
+    c.wx = px * pinv; c.wy = py * pinv; c.wz = pz * pinv;
+    c.ws = wave_max(fabsf((nx * c.wx + ny * c.wy) + nz * c.wz)) * 1.001f + 1e-7f;
+    c.wo = wave_max(fabsf((ex * c.wx + ey * c.wy) + ez * c.wz)) * 1.001f;
     return c;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // the two-level cull every kernel walks: the objects (instanced boxes or triangles, each behind a sphere) sit in Morton order behind a
 // permutation, a sphere around every block of 64 consecutive ones.  A wave tests 64 block spheres per ballot, then the 64 objects of
-// every block that passed, lane per object: `body(id, near)` is called in uniform control flow with the lane's object (its index in
-// the ORIGINAL order, -1 behind the end) and whether its own sphere passed.  The tests are culls only: what they let through gets the
+// every block that passed, lane per object: `body(id, near, record)` is called in uniform control flow with the lane's object (its index
+// in the ORIGINAL order, -1 behind the end), whether its own sphere passed, and its record (already in registers).  The tests are culls only: what they let through gets the
 // exact test, so neither the order nor the grouping changes a result.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct Scene {
-    const float *spheres; int stride;       // (centre, r^2) of object i at spheres + i * stride
-    const int32_t *perm; const float *bspheres;
+    const float *recs;                      // object at Morton position idx: recs[idx * 16 ..]: an instance = {sphere (centre, r^2), world -> patch 3x4};
+    int sph;                                //   a triangle = {v0, v1 - v0, v2 - v0, sphere, padding}; sph = where the sphere sits (0 or 9)
+    const int32_t *perm; const float *bspheres;   // perm[idx] = the object's index in the ORIGINAL order; a sphere per block of 64
     int n, nb;
 };
+struct Rec { f32x4 q[4]; __device__ __forceinline__ float at(int i) const { return q[i >> 2][i & 3]; } };
 template <typename Reach, typename Body>
-__device__ __forceinline__ void walk_blocks(const Scene &sc, int b0, int b1, int lane, Reach reach, Body body) {
-    for (int bb = b0; bb < b1; bb += 64) {
+__device__ __forceinline__ void walk_blocks(const Scene &sc, int lane, int part, int parts, Reach reach, Body body) {
+    // `parts` waves share one walk: all of them cull the block spheres (cheap), the blocks that pass are dealt out round robin
+    auto fetch = [&](int blk, Rec &r, int &id) {                                  // the lane's object of a block: its record and its id, one round of loads
+        const int idx = blk * 64 + lane;
+        id = -1;
+        if (idx < sc.n) {
+            const f32x4 *g = reinterpret_cast<const f32x4 *>(sc.recs) + (size_t)idx * 4;
+            r.q[0] = g[0]; r.q[1] = g[1]; r.q[2] = g[2]; r.q[3] = g[3];
+            id = sc.perm[idx];
+        }
+    };
+    int dealt = 0;                                                                // blocks that passed so far (the same count in every wave of the walk)
+    for (int bb = 0; bb < sc.nb; bb += 64) {
         const int b = bb + lane;
-        bool pass = false;
-        if (b < b1) { const float *bsp = sc.bspheres + (size_t)b * 4; pass = reach(bsp, bsp[3]); }
-        uint64_t bm = __ballot(pass);
+        bool pass = b < sc.nb;
+        if (pass && sc.nb > 4) { const float *bsp = sc.bspheres + (size_t)b * 4; pass = reach(bsp, bsp[3]); }   // (a handful of blocks: straight to their objects)
+        uint64_t all = __ballot(pass), bm = all;
+        if (parts > 1) {                                                          // this wave's share: every parts-th set bit
+            bm = 0;
+            int rank = dealt;
+            for (uint64_t w = all; w; w &= w - 1, ++rank)
+                if (rank % parts == part) bm |= w & (~w + 1);
+        }
+        dealt += __builtin_popcountll(all);
+        Rec cur{}, nxt{};
+        int cur_id = -1, nxt_id = -1;
+        if (bm) fetch(bb + __builtin_ctzll(bm), cur, cur_id);
         while (bm) {
-            const int blk = bb + __builtin_ctzll(bm);
             bm &= bm - 1;
-            const int idx = blk * 64 + lane;
-            int id = -1;
+            if (bm) fetch(bb + __builtin_ctzll(bm), nxt, nxt_id);                 // the next block's loads fly while this one is worked on
             bool near = false;
-            if (idx < sc.n) {
-                id = sc.perm[idx];
-                const float *sp = sc.spheres + (size_t)id * sc.stride;
-                near = reach(sp, sp[3]);
+            if (cur_id >= 0) {
+                const bool tri = sc.sph != 0;                                      // (selects, not indexing: the record stays in registers)
+                const float sp[3] = {tri ? cur.q[2].y : cur.q[0].x, tri ? cur.q[2].z : cur.q[0].y, tri ? cur.q[2].w : cur.q[0].z};
+                near = reach(sp, tri ? cur.q[3].x : cur.q[0].w);
             }
-            body(id, near);
+            body(cur_id, near, cur);
+            cur = nxt; cur_id = nxt_id;
         }
     }
 }
@@ -171,32 +206,40 @@ __device__ __forceinline__ void walk_blocks(const Scene &sc, int b0, int b1, int
 // ---------------------------------------------------------------------------------------------------------------------------
 // (ray, instance) pairs: what rtcIntersect1 with the all-hits filter reports (instancer.cpp:779, 526-541)
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int n_rays,
-                                                        const float *__restrict__ mats, Scene sc, int blocks_per_wave, Box box,
+constexpr int TILE_WAVES = 16;            // most waves that share the walk of one 64-ray tile (hit and mesh kernels); the launch picks 4 or 16
+__global__ __launch_bounds__(64 * TILE_WAVES) void inst_hits_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int n_rays,
+                                                        Scene sc, Box box,
                                                         uint32_t *__restrict__ count, uint4 *__restrict__ hits) {
+    // a workgroup = 64 rays; its waves share the walk over the instances and hand out a ray's list slots from a counter in LDS
+    __shared__ uint32_t slots[64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ray = blockIdx.x * 64 + lane;
     const bool live = ray < n_rays;
     const int r = live ? ray : n_rays - 1;
+    if (threadIdx.x < 64) slots[threadIdx.x] = 0u;
+    __syncthreads();
     const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
     const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
-    const int b0 = (blockIdx.y * 4 + wave) * blocks_per_wave;
-    const int b1 = b0 + blocks_per_wave < sc.nb ? b0 + blocks_per_wave : sc.nb;
     const float dd2 = (dx * dx + dy * dy) + dz * dz;
     const WaveCone cone = wave_cone(ox, oy, oz, dx, dy, dz);
     // spheres around the instanced boxes (centre, radius^2 widened) against the wave's cone -- a wave holds neighbouring rays, so few
     // instances survive -- and the survivors once more against each ray
-    walk_blocks(sc, b0, b1, lane, [&](const float *c, float r2) { return cone.reaches(c, r2); }, [&](int id, bool near) {
+    walk_blocks(sc, lane, wave, (int)(blockDim.x >> 6), [&](const float *c, float r2) { return cone.reaches(c, r2); }, [&](int id, bool near, const Rec &own) {
+      // the lane's own instance sits in registers and the survivors are handed round by readlane: no memory access, and so no latency,
+      // inside the loop over them
       uint64_t mk = __ballot(near);
       while (mk) {
-        const int k = __builtin_amdgcn_readlane(id, __builtin_ctzll(mk));       // wave-uniform from here on: scalar loads
+        const int src = __builtin_ctzll(mk);
         mk &= mk - 1;
-        const float *sp = sc.spheres + (size_t)k * 4;
+        const int k = __builtin_amdgcn_readlane(id, src);
+        const float sp[4] = {lane_value(own.q[0].x, src), lane_value(own.q[0].y, src), lane_value(own.q[0].z, src), lane_value(own.q[0].w, src)};
         const float cx = sp[0] - ox, cy = sp[1] - oy, cz = sp[2] - oz;
         const float qx = cy * dz - cz * dy, qy = cz * dx - cx * dz, qz = cx * dy - cy * dx;
         if (!__any((qx * qx + qy * qy) + qz * qz <= sp[3] * dd2)) continue;
-        const float *m = mats + (size_t)k * 12;
+        const float m[12] = {lane_value(own.q[1].x, src), lane_value(own.q[1].y, src), lane_value(own.q[1].z, src), lane_value(own.q[1].w, src),
+                             lane_value(own.q[2].x, src), lane_value(own.q[2].y, src), lane_value(own.q[2].z, src), lane_value(own.q[2].w, src),
+                             lane_value(own.q[3].x, src), lane_value(own.q[3].y, src), lane_value(own.q[3].z, src), lane_value(own.q[3].w, src)};
         float ol[3], dl[3];
         affine(m, ox, oy, oz, ol);
         linear34(m, dx, dy, dz, dl);
@@ -218,42 +261,47 @@ __global__ __launch_bounds__(256) void inst_hits_kernel(const float *__restrict_
             // the two face crossings of the box, each reported when tnear < t <= tfar: one record {t_in, t_out, instance}, 0 = not reported
             const bool in_ok = t_in > 0.0f && t_in <= T_FAR, out_ok = t_out > 0.0f && t_out <= T_FAR;
             if (in_ok || out_ok) {
-                const uint32_t slot = atomicAdd(&count[ray], 1u);
+                const uint32_t slot = atomicAdd(&slots[lane], 1u);
                 if (slot < (uint32_t)MAX_HITS)
                     hits[(size_t)ray * MAX_HITS + slot] = make_uint4(in_ok ? __builtin_bit_cast(uint32_t, t_in) : 0u, out_ok ? __builtin_bit_cast(uint32_t, t_out) : 0u, (uint32_t)k, 0u);
             }
         }
       }
     });
+    __syncthreads();
+    if (threadIdx.x < 64 && live) count[ray] = slots[lane];
 }
 
 // closest crossing of the meshes per ray (Moeller-Trumbore, no culling); tris[f] = {v0, v1 - v0, v2 - v0, sphere centre, radius^2}
-__global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int n_rays,
-                                                        const float *__restrict__ tris, Scene sc, int blocks_per_wave, unsigned long long *__restrict__ t_mesh) {
+__global__ __launch_bounds__(64 * TILE_WAVES) void inst_mesh_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d, int n_rays,
+                                                        Scene sc, unsigned long long *__restrict__ t_mesh) {
+    __shared__ unsigned long long nearest[64];                                   // per ray: (t bits << 32 | triangle) of the closest crossing, over the tile's waves
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ray = blockIdx.x * 64 + lane;
     const bool live = ray < n_rays;
     const int r = live ? ray : n_rays - 1;
+    if (threadIdx.x < 64) nearest[threadIdx.x] = (unsigned long long)INF_BITS << 32 | INF_BITS;
+    __syncthreads();
     const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
     const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
-    const int b0 = (blockIdx.y * 4 + wave) * blocks_per_wave;
-    const int b1 = b0 + blocks_per_wave < sc.nb ? b0 + blocks_per_wave : sc.nb;
     float best = INFINITY;
     int best_f = 0;
     const float dd2 = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
     const WaveCone cone = wave_cone(o[0], o[1], o[2], d[0], d[1], d[2]);
-    walk_blocks(sc, b0, b1, lane, [&](const float *c, float r2) { return cone.reaches(c, r2); }, [&](int id, bool near) {
-      uint64_t mk = __ballot(near);
+    walk_blocks(sc, lane, wave, (int)(blockDim.x >> 6), [&](const float *c, float r2) { return cone.reaches(c, r2); }, [&](int id, bool near, const Rec &own) {
+      uint64_t mk = __ballot(near);                                              // (the lane's own triangle sits in registers, handed round by readlane)
       while (mk) {
-        const int f = __builtin_amdgcn_readlane(id, __builtin_ctzll(mk));
+        const int src = __builtin_ctzll(mk);
         mk &= mk - 1;
-        const float *tr = tris + (size_t)f * 13;
+        const int f = __builtin_amdgcn_readlane(id, src);
         {   // the triangle's sphere, as in inst_hits_kernel
-            const float cx = tr[9] - o[0], cy = tr[10] - o[1], cz = tr[11] - o[2];
+            const float cx = lane_value(own.at(9), src) - o[0], cy = lane_value(own.at(10), src) - o[1], cz = lane_value(own.at(11), src) - o[2];
             const float qx = cy * d[2] - cz * d[1], qy = cz * d[0] - cx * d[2], qz = cx * d[1] - cy * d[0];
-            if (!__any((qx * qx + qy * qy) + qz * qz <= tr[12] * dd2)) continue;
+            if (!__any((qx * qx + qy * qy) + qz * qz <= lane_value(own.at(12), src) * dd2)) continue;
         }
+        const float tr[9] = {lane_value(own.at(0), src), lane_value(own.at(1), src), lane_value(own.at(2), src), lane_value(own.at(3), src), lane_value(own.at(4), src),
+                             lane_value(own.at(5), src), lane_value(own.at(6), src), lane_value(own.at(7), src), lane_value(own.at(8), src)};
         const float *v0 = tr, *e1 = tr + 3, *e2 = tr + 6;
         const float p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
         const float det = (e1[0] * p[0] + e1[1] * p[1]) + e1[2] * p[2];
@@ -271,7 +319,9 @@ __global__ __launch_bounds__(256) void inst_mesh_kernel(const float *__restrict_
       }
     });
     // (t, triangle) as one 64-bit key: positive floats order like their bits, ties go to the lower triangle
-    if (live && best < INFINITY) atomicMin(&t_mesh[ray], ((unsigned long long)__builtin_bit_cast(uint32_t, best) << 32) | (uint32_t)best_f);
+    if (best < INFINITY) atomicMin(&nearest[lane], ((unsigned long long)__builtin_bit_cast(uint32_t, best) << 32) | (uint32_t)best_f);
+    __syncthreads();
+    if (threadIdx.x < 64 && live) t_mesh[ray] = nearest[lane];                  // (no crossing: the high word stays +inf)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -545,10 +595,10 @@ __device__ __forceinline__ bool triangle_occludes(const float *__restrict__ tris
 __device__ __forceinline__ bool occluded_point(const MarchArgs &a, int lane, float px, float py, float pz, float lx, float ly, float lz) {
     const Strip st(px, py, pz, lx, ly, lz, lx, ly, lz, 0.0f, 0.0f);                               // d = l: nn == 0, the line (p, l)
     bool occ = false;
-    walk_blocks(a.inst_scene, 0, a.inst_scene.nb, lane, [&](const float *c, float r2) { return st.reaches(c, r2); },
-                [&](int id, bool near) { if (near) occ = occ || instance_occludes(a.mats, a.box, id, px, py, pz, lx, ly, lz); });
-    walk_blocks(a.tri_scene, 0, a.tri_scene.nb, lane, [&](const float *c, float r2) { return st.reaches(c, r2); },
-                [&](int id, bool near) { if (near) occ = occ || triangle_occludes(a.tris, a.kind, id, px, py, pz, lx, ly, lz); });
+    walk_blocks(a.inst_scene, lane, 0, 1, [&](const float *c, float r2) { return st.reaches(c, r2); },
+                [&](int id, bool near, const Rec &) { if (near) occ = occ || instance_occludes(a.mats, a.box, id, px, py, pz, lx, ly, lz); });
+    walk_blocks(a.tri_scene, lane, 0, 1, [&](const float *c, float r2) { return st.reaches(c, r2); },
+                [&](int id, bool near, const Rec &) { if (near) occ = occ || triangle_occludes(a.tris, a.kind, id, px, py, pz, lx, ly, lz); });
     return __any(occ);
 }
 
@@ -1031,7 +1081,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
                     n_cand = rest;
                 };
                 auto gather = [&](const Scene &sc, bool is_tri) {
-                    walk_blocks(sc, 0, sc.nb, lane, [&](const float *c, float r2) { return st.reaches(c, r2); }, [&](int id, bool near) {
+                    walk_blocks(sc, lane, 0, 1, [&](const float *c, float r2) { return st.reaches(c, r2); }, [&](int id, bool near, const Rec &) {
                         float a0 = INFINITY, a1 = -INFINITY;
                         if (near) {
                             if (is_tri) triangle_interval(a.tris, a.kind, id, st, amax, a0, a1);
@@ -1431,7 +1481,7 @@ struct ntx_instancer {
     float *d_normals = nullptr; int32_t *d_faces = nullptr; uint8_t *d_kind = nullptr; bool has_aux = false;   // auxiliary meshes
     int64_t n_mesh_vertices = 0;
     // the cull's hierarchy: objects in Morton order behind a permutation, a sphere around every block of 64 of them
-    int32_t *d_iperm = nullptr, *d_tperm = nullptr; float *d_ibs = nullptr, *d_tbs = nullptr;
+    int32_t *d_iperm = nullptr, *d_tperm = nullptr; float *d_ibs = nullptr, *d_tbs = nullptr, *d_irecs = nullptr, *d_trecs = nullptr;
     float *d_uv = nullptr; int32_t *d_face_tex = nullptr; float *d_atexels = nullptr; ntx_inst::TexTable *d_atable = nullptr;   // their textures
     // parameter textures on the instancer mesh: texels + tables, the mesh in its grid
     ntx_inst::TexArgs tex{};
@@ -1472,7 +1522,7 @@ void release(ntx_instancer *p) {
     (void)hipSetDevice(p->device);
     for (void *q : {(void *)p->d_mats, (void *)p->d_org, (void *)p->d_tris, (void *)p->d_spheres, (void *)p->d_xforms, (void *)p->d_normals, (void *)p->d_faces, (void *)p->d_kind, (void *)p->d_count, (void *)p->d_tmesh, (void *)p->d_hits,
                     (void *)p->d_uv, (void *)p->d_face_tex, (void *)p->d_atexels, (void *)p->d_atable, (void *)p->d_ptexels, (void *)p->d_gtris, (void *)p->d_face_uv, (void *)p->d_ptable, (void *)p->d_cell_start, (void *)p->d_cand,
-                    (void *)p->d_iperm, (void *)p->d_tperm, (void *)p->d_ibs, (void *)p->d_tbs})
+                    (void *)p->d_iperm, (void *)p->d_tperm, (void *)p->d_ibs, (void *)p->d_tbs, (void *)p->d_irecs, (void *)p->d_trecs})
         if (q) (void)hipFree(q);
     delete p;
 }
@@ -1518,9 +1568,11 @@ void build_blocks(const float *spheres, int64_t n, int stride, std::vector<int32
     }
 }
 
-int upload_blocks(const std::vector<int32_t> &perm, const std::vector<float> &bs, int32_t **d_perm, float **d_bs) {
-    for (void **q : {(void **)d_perm, (void **)d_bs})
+int upload_blocks(const std::vector<int32_t> &perm, const std::vector<float> &bs, const std::vector<float> &recs, int32_t **d_perm, float **d_bs, float **d_recs) {
+    for (void **q : {(void **)d_perm, (void **)d_bs, (void **)d_recs})
         if (*q) { (void)hipFree(*q); *q = nullptr; }
+    INST_TRY(hipMalloc((void **)d_recs, (recs.empty() ? 16 : recs.size()) * sizeof(float)));
+    if (!recs.empty()) INST_TRY(hipMemcpy(*d_recs, recs.data(), recs.size() * sizeof(float), hipMemcpyHostToDevice));
     INST_TRY(hipMalloc((void **)d_perm, (perm.empty() ? 1 : perm.size()) * sizeof(int32_t)));
     if (!perm.empty()) INST_TRY(hipMemcpy(*d_perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     INST_TRY(hipMalloc((void **)d_bs, bs.size() * sizeof(float)));
@@ -1614,7 +1666,12 @@ int ntx_instancer_create(const ntx_instancer_desc *desc, const float *transforma
     if (rc == NTX_OK) {
         std::vector<int32_t> perm; std::vector<float> bs;
         build_blocks(p->h_spheres.data(), n_instances, 4, perm, bs);
-        rc = upload_blocks(perm, bs, &p->d_iperm, &p->d_ibs);
+        std::vector<float> recs((size_t)n_instances * 16);                 // in Morton order: {sphere, world -> patch 3x4}
+        for (int64_t i = 0; i < n_instances; ++i) {
+            std::memcpy(&recs[(size_t)i * 16], &p->h_spheres[(size_t)perm[(size_t)i] * 4], 4 * sizeof(float));
+            std::memcpy(&recs[(size_t)i * 16 + 4], &p->h_mats[(size_t)perm[(size_t)i] * 12], 12 * sizeof(float));
+        }
+        rc = upload_blocks(perm, bs, recs, &p->d_iperm, &p->d_ibs, &p->d_irecs);
     }
     if (rc == NTX_OK) rc = reserve(p, NTX_INSTANCER_DEFAULT_MAX_RAYS);
     if (rc != NTX_OK) { release(p); return rc; }
@@ -1689,7 +1746,9 @@ int ntx_instancer_set_meshes(ntx_instancer *inst, const float *vertices, const f
         {
             std::vector<int32_t> perm; std::vector<float> bs;
             build_blocks(tris.data() + 9, n_faces, 13, perm, bs);
-            const int rcb = upload_blocks(perm, bs, &inst->d_tperm, &inst->d_tbs);
+            std::vector<float> recs((size_t)n_faces * 16, 0.0f);                // in Morton order: {v0, e1, e2, sphere, padding}
+            for (int64_t i = 0; i < n_faces; ++i) std::memcpy(&recs[(size_t)i * 16], &tris[(size_t)perm[(size_t)i] * 13], 13 * sizeof(float));
+            const int rcb = upload_blocks(perm, bs, recs, &inst->d_tperm, &inst->d_tbs, &inst->d_trecs);
             if (rcb != NTX_OK) return rcb;
         }
         {   // bit 0: auxiliary; bit 1: primID 1 of its own mesh (one mesh when no kinds are given)
@@ -2016,27 +2075,14 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
     for (int64_t c0 = 0; c0 < n_rays; c0 += inst->cap_rays) {
         const int n = (int)(n_rays - c0 < inst->cap_rays ? n_rays - c0 : inst->cap_rays);
         const float *ro = rays_o + c0 * 3, *rd = rays_d + c0 * 3;
-        INST_TRY(hipMemsetAsync(inst->d_count, 0, (size_t)n * sizeof(uint32_t), st));
         const int tiles = (n + 63) / 64;
-        const Scene isc{inst->d_spheres, 4, inst->d_iperm, inst->d_ibs, K, (K + 63) / 64};
-        const Scene tsc{F > 0 ? inst->d_tris + 9 : nullptr, 13, inst->d_tperm, inst->d_tbs, F, (F + 63) / 64};
-        // a wave takes 64 rays x a range of blocks (64 objects each); ranges short enough for >= 4096 waves, what fills 256 CUs
-        auto split = [&](int nb, int &bpw, int &gy) {
-            bpw = (int)(((int64_t)nb * tiles) / 4096);
-            bpw = bpw < 1 ? 1 : bpw;
-            gy = (nb + 4 * bpw - 1) / (4 * bpw);
-        };
-        if (K > 0) {
-            int bpw, gy;
-            split(isc.nb, bpw, gy);
-            hipLaunchKernelGGL(inst_hits_kernel, dim3(tiles, gy), dim3(256), 0, st, ro, rd, n, inst->d_mats, isc, bpw, box, inst->d_count, inst->d_hits);
-        }
-        if (F > 0) {
-            INST_TRY(hipMemsetD32Async((hipDeviceptr_t)inst->d_tmesh, (int)INF_BITS, (size_t)n * 2, st));   // high word = +inf: no hit
-            int bpw, gy;
-            split(tsc.nb, bpw, gy);
-            hipLaunchKernelGGL(inst_mesh_kernel, dim3(tiles, gy), dim3(256), 0, st, ro, rd, n, inst->d_tris, tsc, bpw, inst->d_tmesh);
-        }
+        const Scene isc{inst->d_irecs, 0, inst->d_iperm, inst->d_ibs, K, (K + 63) / 64};
+        const Scene tsc{inst->d_trecs, 9, inst->d_tperm, inst->d_tbs, F, (F + 63) / 64};
+        // a workgroup per 64 rays; its waves share the walk: 16 of them while that still leaves CUs idle, else 4
+        const int tile_waves = tiles <= 512 ? TILE_WAVES : 4;
+        if (K > 0) hipLaunchKernelGGL(inst_hits_kernel, dim3(tiles), dim3(64 * tile_waves), 0, st, ro, rd, n, isc, box, inst->d_count, inst->d_hits);
+        else INST_TRY(hipMemsetAsync(inst->d_count, 0, (size_t)n * sizeof(uint32_t), st));
+        if (F > 0) hipLaunchKernelGGL(inst_mesh_kernel, dim3(tiles), dim3(64 * tile_waves), 0, st, ro, rd, n, tsc, inst->d_tmesh);
         MarchArgs a{};
         a.rays_o = ro; a.rays_d = rd; a.params = P > 0 ? parameters + c0 * P : nullptr;
         a.mats = inst->d_mats; a.origins = inst->d_org; a.xforms = inst->d_xforms;

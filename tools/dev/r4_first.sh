@@ -3,14 +3,14 @@
 #   (1) the shadow kernel under rocprofv3 (kernel trace + SQ / memory counters in their own passes) at 128 samples per unit and per step
 #   (2) the instancer from 2.3 k to 10^5 patches (the same sheet under smaller patches), with and without shadow rays
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4first; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${OUT:-r4first}; mkdir -p $O; cd $R
 B="timeout 600 python tools/bench_instancer.py"
 for G in 48 100 200 316; do
   for RAYS in 16384 65536; do
     $B --grid $G --scale-with-grid --rays $RAYS --steps 10 2>/dev/null | grep "^{" | head -2
     $B --grid $G --scale-with-grid --rays $RAYS --steps 5 --shadows 128 --no-render 2>/dev/null | grep "^{"
   done
-done > $O/instancer_scaling_before.jsonl
+done > $O/${SCALING:-instancer_scaling_before}.jsonl
 for N in 128 100000; do
   P="python tools/bench_instancer.py --no-render --steps 10 --shadows $N"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$N -o kt -- $P > /dev/null 2>&1
@@ -22,4 +22,4 @@ for N in 128 100000; do
 done
 find $O -name "*.db" -delete 2>/dev/null; find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -path "*pmc*" -delete
 python tools/dev/r4_reduce_inst.py $O 128 100000
-cut -c1-330 $O/instancer_scaling_before.jsonl
+cut -c1-330 $O/${SCALING:-instancer_scaling_before}.jsonl
