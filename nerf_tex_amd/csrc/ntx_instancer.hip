@@ -158,6 +158,7 @@ struct Scene {
     int sph;                                //   a triangle = {v0, v1 - v0, v2 - v0, sphere, padding}; sph = where the sphere sits (0 or 9)
     const int32_t *perm; const float *bspheres;   // perm[idx] = the object's index in the ORIGINAL order; a sphere per block of 64
     int n, nb;
+    int top_min;                            // with at most this many blocks the walk goes straight to the objects (4; tests force the block level on with -1)
 };
 struct Rec { f32x4 q[4]; __device__ __forceinline__ float at(int i) const { return q[i >> 2][i & 3]; } };
 template <typename Reach, typename Body>
@@ -176,7 +177,7 @@ __device__ __forceinline__ void walk_blocks(const Scene &sc, int lane, int part,
     for (int bb = 0; bb < sc.nb; bb += 64) {
         const int b = bb + lane;
         bool pass = b < sc.nb;
-        if (pass && sc.nb > 4) { const float *bsp = sc.bspheres + (size_t)b * 4; pass = reach(bsp, bsp[3]); }   // (a handful of blocks: straight to their objects)
+        if (pass && sc.nb > sc.top_min) { const float *bsp = sc.bspheres + (size_t)b * 4; pass = reach(bsp, bsp[3]); }   // (a handful of blocks: straight to their objects)
         uint64_t all = __ballot(pass), bm = all;
         if (parts > 1) {                                                          // this wave's share: every parts-th set bit
             bm = 0;
@@ -1480,6 +1481,7 @@ struct ntx_instancer {
     unsigned long long *d_tmesh = nullptr;
     float *d_normals = nullptr; int32_t *d_faces = nullptr; uint8_t *d_kind = nullptr; bool has_aux = false;   // auxiliary meshes
     int64_t n_mesh_vertices = 0;
+    int top_min = 4;                                   // NERFTEX_INST_FORCE_BLOCKS=1 (read at create): the block level of the cull also for tiny scenes (tests)
     // the cull's hierarchy: objects in Morton order behind a permutation, a sphere around every block of 64 of them
     int32_t *d_iperm = nullptr, *d_tperm = nullptr; float *d_ibs = nullptr, *d_tbs = nullptr, *d_irecs = nullptr, *d_trecs = nullptr;
     float *d_uv = nullptr; int32_t *d_face_tex = nullptr; float *d_atexels = nullptr; ntx_inst::TexTable *d_atable = nullptr;   // their textures
@@ -1616,6 +1618,7 @@ int ntx_instancer_create(const ntx_instancer_desc *desc, const float *transforma
     if (device < 0 || device >= ndev) return ntx_set_error(NTX_E_INVALID, "device %d out of range [0,%d)", device, ndev);
     ntx_instancer *p = new ntx_instancer();
     p->device = device; p->desc = *desc; p->n_inst = n_instances;
+    { const char *force = getenv("NERFTEX_INST_FORCE_BLOCKS"); if (force && force[0] == '1') p->top_min = -1; }
     p->h_mats.resize((size_t)n_instances * 12); p->h_dirs.resize((size_t)n_instances * 9); p->h_org.resize((size_t)n_instances * 3); p->h_spheres.resize((size_t)n_instances * 4);
     for (int64_t k = 0; k < n_instances; ++k) {                        // AddInstance, instancer.cpp:124-141
         const float *m = transformations + k * 16;
@@ -2076,8 +2079,8 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         const int n = (int)(n_rays - c0 < inst->cap_rays ? n_rays - c0 : inst->cap_rays);
         const float *ro = rays_o + c0 * 3, *rd = rays_d + c0 * 3;
         const int tiles = (n + 63) / 64;
-        const Scene isc{inst->d_irecs, 0, inst->d_iperm, inst->d_ibs, K, (K + 63) / 64};
-        const Scene tsc{inst->d_trecs, 9, inst->d_tperm, inst->d_tbs, F, (F + 63) / 64};
+        const Scene isc{inst->d_irecs, 0, inst->d_iperm, inst->d_ibs, K, (K + 63) / 64, inst->top_min};
+        const Scene tsc{inst->d_trecs, 9, inst->d_tperm, inst->d_tbs, F, (F + 63) / 64, inst->top_min};
         // a workgroup per 64 rays; its waves share the walk: 16 of them while that still leaves CUs idle, else 4
         const int tile_waves = tiles <= 512 ? TILE_WAVES : 4;
         if (K > 0) hipLaunchKernelGGL(inst_hits_kernel, dim3(tiles), dim3(64 * tile_waves), 0, st, ro, rd, n, isc, box, inst->d_count, inst->d_hits);

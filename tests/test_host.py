@@ -21,7 +21,7 @@ def test_abi_exports_every_declared_symbol():
     raw = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_create_without_gpu_reports_no_device():
@@ -303,7 +303,7 @@ def test_reference_render_config_runs_through_remap():
     assert m.test_dataset_config.module == "nerf_tex_amd.dataset.Dataset"
     assert m.test_dataset_config.proxy_config.module == "nerf_tex_amd.proxy.AABB"
     assert m.renderer_config.module == "nerf_tex_amd.renderer.InstanceRenderer"
-    assert m.renderer_config.instancer_config.module == "instancer.instancer.Instancer"   # the Embree instancer stays the reference's
+    assert m.renderer_config.instancer_config.module == "nerf_tex_amd.instancer.Instancer"   # the patch instancer is this package's (ABI v4/v5)
     assert m.logger_config.module == "network.logger.Logger"                               # out of scope: left untouched
 
 
@@ -742,7 +742,9 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                    '    ntx_model_desc d = {NTX_MODEL_PARAMNERF, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, NTX_POS_FOURIER};\n'
                    '    ntx_render_opts o = {sizeof(ntx_render_opts), 0.5f, 7u, 100, 800, 6400};\n'
                    '    ntx_instancer_desc q = {sizeof(ntx_instancer_desc), {-1, -1, -1}, {1, 1, 1}, 7, 4, -1, 1, 0, 0, 1.0f, 8, 256};\n'
-                   '    if (ntx_instancer_count(NULL) != -1 || q.n_parameters != 7) return 3;\n'
+                   '    float texel = 0.5f; ntx_texture tx = {&texel, 1, 1};\n'
+                   '    if (ntx_instancer_count(NULL) != -1 || q.n_parameters != 7 || tx.rows != 1) return 3;\n'
+                   '    if (ntx_instancer_set_parameter_textures(NULL, NULL, NULL, 0, NULL, 0, 1.0f, 0, NULL, &tx, 8, 256) != NTX_E_INVALID) return 4;\n'
                    '    long long counts[8], offs[8]; int eq, direct;\n'
                    '    if (ntx_gather_plan(642400, 800, 8, (int64_t *)counts, (int64_t *)offs, &eq, &direct) != NTX_OK) return 2;\n'
                    '    printf("%d %zu %lld %lld %lld %d %d %u\\n", ntx_abi_version(), ntx_weight_count(&d), (long long)ntx_shard_count(640000, 800, 8, 3),\n'
@@ -754,7 +756,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                     "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     # 803 rows of 800 over 8 ranks: ranks 0-2 hold 101 rows, the others 100 -> exact-count Send/Recv into staging, blocks at r * 80800
-    assert out == ["4", "683524", "80000", "80800", str(7 * 80800), "0", "0", "40"]
+    assert out == ["5", "683524", "80000", "80800", str(7 * 80800), "0", "0", "40"]
 
 
 def test_instancer_host_side(tmp_path):
