@@ -90,8 +90,17 @@ __device__ __forceinline__ void linear33(const float *m, float x, float y, float
 #pragma unroll
     for (int r = 0; r < 3; ++r) out[r] = (m[3 * r] * x + m[3 * r + 1] * y) + m[3 * r + 2] * z;
 }
-__device__ __forceinline__ void normalized(float &x, float &y, float &z) {   // Eigen's normalized()
-    const float n2 = (x * x + y * y) + z * z;
+// ... and as EIGEN evaluates them (getPt, getDir: a coefficient of a 3x3 * 3 product is the unrolled reduction x0 + (x1 + x2))
+__device__ __forceinline__ void affine_e(const float *m, float x, float y, float z, float *out) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) out[r] = (m[4 * r] * x + (m[4 * r + 1] * y + m[4 * r + 2] * z)) + m[4 * r + 3];
+}
+__device__ __forceinline__ void linear33_e(const float *m, float x, float y, float z, float *out) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) out[r] = m[3 * r] * x + (m[3 * r + 1] * y + m[3 * r + 2] * z);
+}
+__device__ __forceinline__ void normalized(float &x, float &y, float &z) {   // Eigen's normalized(): squaredNorm = x0^2 + (x1^2 + x2^2)
+    const float n2 = x * x + (y * y + z * z);
     if (n2 > 0.0f) { const float n = __builtin_sqrtf(n2); x = x / n; y = y / n; z = z / n; }
 }
 
@@ -131,7 +140,7 @@ __device__ __forceinline__ WaveCone wave_cone(float ox, float oy, float oz, floa
     c.ux = ux * uinv; c.uy = uy * uinv; c.uz = uz * uinv;
     const float cmin = wave_min((nx * c.ux + ny * c.uy) + nz * c.uz) - 1e-5f;
     const float ex = ox - c.ax, ey = oy - c.ay, ez = oz - c.az;
-    c.reach = wave_max(__builtin_sqrtf((ex * ex + ey * ey) + ez * ez)) * 1.001f;
+    c.reach = wave_max(__builtin_sqrtf(ex * ex + (ey * ey + ez * ez))) * 1.001f;
     c.on = cmin > 0.5f && wave_min(dn) > 0.0f;
     c.cos_t = cmin; c.sin_t = __builtin_sqrtf(fmaxf(1.0f - cmin * cmin, 0.0f));
     // the wedge's plane: through the apex, along the first and the last ray's directions
@@ -1197,7 +1206,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
             float best = INFINITY;
             for_each_candidate([&](int q, bool in) {                                            // sampleNearest, :681-692
                 const float ex = px - L.u.iv.ox[q], ey = py - L.u.iv.oy[q], ez = pz - L.u.iv.oz[q];
-                const float dd = __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
+                const float dd = __builtin_sqrtf(ex * ex + (ey * ey + ez * ez));
                 if (in) {
                     // the reference keeps the FIRST patch of its ascending std::set at the smallest distance (strict <, :687): the
                     // smallest id among equals, whatever order the intervals come in
@@ -1211,7 +1220,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
                 float tot = 0.0f;
                 for_each_candidate([&](int q, bool in) {
                     const float ex = px - L.u.iv.ox[q], ey = py - L.u.iv.oy[q], ez = pz - L.u.iv.oz[q];
-                    const float w = (a.blend_range + best) - __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
+                    const float w = (a.blend_range + best) - __builtin_sqrtf(ex * ex + (ey * ey + ez * ez));
                     if (in) tot = tot + (w > 0.0f ? w : 0.0f);
                 });
                 const float uc = uniform01(philox4x32_10((uint32_t)s, (uint32_t)gray, (uint32_t)((uint64_t)gray >> 32), 3u, a.seed_lo, a.seed_hi));
@@ -1222,7 +1231,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
                 uint32_t pick_id = inst;
                 for_each_candidate([&](int q, bool in) {
                     const float ex = px - L.u.iv.ox[q], ey = py - L.u.iv.oy[q], ez = pz - L.u.iv.oz[q];
-                    float w = (a.blend_range + best) - __builtin_sqrtf((ex * ex + ey * ey) + ez * ez);
+                    float w = (a.blend_range + best) - __builtin_sqrtf(ex * ex + (ey * ey + ez * ez));
                     w = w > 0.0f ? w : 0.0f;
                     if (in) {
                         acc = acc + w;
@@ -1292,13 +1301,13 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
             }
         }
         float p3[3], d3[3], l3[3] = {0.0f, 0.0f, 0.0f}, lst = 0.0f;
-        affine(mi, px, py, pz, p3);                                                             // getPt
-        linear33(di, ndx, ndy, ndz, d3);                                                        // getDir
+        affine_e(mi, px, py, pz, p3);                                                           // getPt
+        linear33_e(di, ndx, ndy, ndz, d3);                                                      // getDir
         if (a.light_dir_idx >= 0) {                                                             // getShadowedLightDir, :571-581
             float sx = lx, sy = ly, sz = lz;
             if (a.light_strength_idx >= 0) { sx = lx - px; sy = ly - py; sz = lz - pz; }
             normalized(sx, sy, sz);
-            linear33(di, sx, sy, sz, l3);
+            linear33_e(di, sx, sy, sz, l3);
             if constexpr (SHADOW) {
                 bool shadowed;
                 if (interpolate) {                                                              // :946-958: the nearer of the two shadow samples around t_pt
@@ -1320,7 +1329,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
         }
         if (a.light_strength_idx >= 0) {                                                        // getLightStrength, :583-588
             const float ex = lx - px, ey = ly - py, ez = lz - pz;
-            const float d2 = (ex * ex + ey * ey) + ez * ez;
+            const float d2 = ex * ex + (ey * ey + ez * ez);                                       // squaredNorm
             lst = (float)((double)lstr / (4 * M_PI * (double)d2 + (double)1e-6f));
         }
         const size_t k0 = (size_t)ray * S + base;
@@ -1450,7 +1459,7 @@ __global__ __launch_bounds__(256) void inst_shade_kernel(MarchArgs a, ShadeArgs 
     const bool dark = occluded_point(a, lane, px, py, pz, lx, ly, lz);
     float nlx = lx, nly = ly, nlz = lz;
     normalized(nlx, nly, nlz);
-    const float nd = (n[0] * nlx + n[1] * nly) + n[2] * nlz;
+    const float nd = n[0] * nlx + (n[1] * nly + n[2] * nlz);                          // n.dot(dir.normalized())
     const float diffuse = dark ? 0.0f : 1.0f * (nd > 0.0f ? nd : 0.0f);
     const float sum = diffuse + 0.2f;
     const float shade = sum < 1.0f ? sum : 1.0f;

@@ -426,7 +426,9 @@ def distribute_instances_on_mesh(vertices, faces, normals, uv, scale: float, pat
     T = np.zeros_like(V)
     for j in range(3):
         np.add.at(T, Fa[:, j], t_face)                                                        # :258-264 (summation order: by face)
-    unit = lambda x: (x / np.linalg.norm(x, axis=-1, keepdims=True)).astype(F)
+    def unit(x):                                                                              # Eigen's normalize(): only when the squared norm is positive
+        n = np.linalg.norm(x, axis=-1, keepdims=True)
+        return (x / np.where(n > 0, n, 1)).astype(F)
     N = unit(N)
     T = unit(T - N * np.sum(N * T, -1, keepdims=True))
     B = np.cross(N, T).astype(F)

@@ -381,3 +381,163 @@ def test_auxiliary_albedo_and_the_second_triangle():
     two = io.make_spec(transformations=[translate(z=-50)], mesh=(np.concatenate([quad_v, quad_v + F([0, 0, 1])]), faces + [[4, 5, 6], [4, 6, 7]]),
                        mesh_prim=[0, 1, 0, 1], **UNIT)                                    # two meshes in one list: primIDs start over
     assert io.is_shadowed(two, F([-1, 1, 1]), F([0, 0, 1])) and not io.is_shadowed(two, F([1, -1, 1]), F([0, 0, 1]))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the second restatement (plain C, oracle/c/ntx_instancer_oracle.c, written from instancer.cpp): element for element
+# ------------------------------------------------------------------------------------------------------------------------------
+
+NAMES = ["rays_d_map", "pts", "t", "dists", "color", "density", "density_weight", "instance_id", "hit", "params_map"]
+
+
+def assert_twins_agree(spec, o, d, params, S, h, seed):
+    from oracle import c_instancer as ci
+    n = o.shape[0]
+    uo, uc = io.offset_uniforms(n, seed), io.choice_uniforms(n, S, seed)
+    a = io.get_model_input(spec, o, d, params, S, h, uo, uc)
+    b = ci.get_model_input(spec, o, d, params, S, h, uo, uc)
+    for name, x, y in zip(NAMES, a, b):
+        assert x.shape == y.shape and x.dtype == y.dtype, (name, x.shape, y.shape, x.dtype, y.dtype)
+        if not np.array_equal(x, y):
+            bad = np.argwhere(x != y)
+            raise AssertionError(f"{name}: {len(bad)} of {x.size} differ, first at {bad[0].tolist()}: python {x[tuple(bad[0])]!r}, C {y[tuple(bad[0])]!r}")
+    return a
+
+
+def sheet_mesh(n=7, extent=1.7, amp=0.07, z0=-0.12):
+    xs = np.linspace(-extent, extent, n)
+    x, y = np.meshgrid(xs, xs, indexing="ij")
+    z = z0 + amp * np.sin(1.7 * x) * np.cos(1.3 * y)
+    v = np.stack([x, y, z], -1).reshape(-1, 3).astype(F)
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c, e = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    f = np.concatenate([np.stack([a, b, c], -1), np.stack([a, c, e], -1)]).astype(np.int32)
+    u = (x + extent) / (2 * extent); w = (y + extent) / (2 * extent)
+    return v, f, np.stack([0.8 * u + 0.2 * w, 0.1 * u + 0.9 * w], -1).reshape(-1, 2).astype(F)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_the_two_restatements_agree(seed):
+    """Random scenes over every branch of GetModelInput -- the three patch choices, lights, mean distances, a culling mesh, shadow rays
+    interpolated and per step, parameter textures interpolated and per step with one to four channels, shaded and textured auxiliary
+    meshes, buffers too short -- through both restatements with the same draws: all ten buffers identical."""
+    rng = np.random.default_rng(7000 + seed)
+    method = ["random", "nearest", "nearest_blend"][seed % 3]
+    textures = [(), ("", "light"), ("point",), ("", "", "light", "")][int(rng.integers(0, 4))]
+    mean = bool(rng.integers(0, 2))
+    shadows = bool(textures) and bool(rng.integers(0, 2))
+    tex_mode = int(rng.integers(0, 3))
+    names, images = list(textures), {}
+    kw = {}
+    if shadows:
+        kw.update(cast_shadow_rays=True, min_shadow_samples=int(rng.integers(2, 7)), n_shadow_samples=int(rng.choice([16, 48, 100000])))
+    mesh = bool(rng.integers(0, 2))
+    spec0 = random_scene(300 + seed, k=int(rng.integers(3, 20)), method=method, textures=textures, mesh=mesh)
+    msh = (spec0.mesh_v, spec0.mesh_f) if mesh else None
+    patch_scale = 1.0
+    if tex_mode:
+        for q in range(int(rng.integers(1, 3))):
+            key = f"#{q}"
+            images[key] = io.texture_from_pixels(rng.integers(0, 256, size=(int(rng.integers(2, 9)), int(rng.integers(2, 9)), int(rng.choice([1, 3, 4]))), dtype=np.uint8))
+            names.insert(int(rng.integers(0, len(names) + 1)), key)
+        tm = sheet_mesh(n=int(rng.integers(3, 8)), amp=float(rng.uniform(0, 0.15)))
+        patch_scale = float(rng.choice([0.3, 1.0]))
+        kw.update(instancer_mesh=tm, patch_scale=patch_scale, min_texture_samples=int(rng.integers(2, 7)),
+                  n_texture_samples=int(rng.choice([8, 32])) if tex_mode == 1 else 100000)
+        msh = (tm[0], tm[1])
+    aux = bool(textures) and bool(rng.integers(0, 2))
+    if aux:                                                                      # an auxiliary quad over part of the scene, sometimes textured
+        base_v = msh[0] if msh is not None else np.zeros((0, 3), F); base_f = msh[1] if msh is not None else np.zeros((0, 3), np.int32)
+        z0, z1 = rng.uniform(0.3, 1.2, size=2)
+        qv = F([[-1.5, -1.5, z0], [1.5, -1.5, z1], [1.5, 1.5, z1], [-1.5, 1.5, z0]]); qf = np.asarray([[0, 1, 2], [0, 2, 3]], np.int32) + len(base_v)
+        nv = rng.normal(size=(4, 3)) * 0.2 + [0, 0, 1]
+        nrm = np.concatenate([np.zeros((len(base_v), 3), F), (nv / np.linalg.norm(nv, axis=-1, keepdims=True)).astype(F)])
+        msh = (np.concatenate([np.asarray(base_v, F).reshape(-1, 3), qv]), np.concatenate([np.asarray(base_f, np.int32).reshape(-1, 3), qf]), nrm,
+               np.r_[np.zeros(len(base_f), np.uint8), np.ones(2, np.uint8)])
+        kw["mesh_prim"] = np.r_[np.arange(len(base_f)), [0, 1]]
+        if rng.integers(0, 2):
+            kw.update(mesh_uv=np.concatenate([np.zeros((len(base_v), 2), F), rng.uniform(0, 1, size=(4, 2)).astype(F)]),
+                      mesh_tex=np.r_[np.full(len(base_f), -1), [0, 0]],
+                      aux_textures=[io.texture_from_pixels(rng.integers(0, 256, size=(4, 5, int(rng.choice([1, 3, 4]))), dtype=np.uint8))])
+    spec = io.make_spec(spec0.b_0, spec0.b_1, None, textures=names, images=images, instance_sampling_method=method, use_mean_distance=mean, mesh=msh,
+                        matrices=(spec0.inv, spec0.dir_t, spec0.origins), **kw)
+    spec.patch_scale = patch_scale
+    n = 24
+    o, d = random_rays(300 + seed, n)
+    d[3:6] = d[3:6] * F(rng.uniform(0.5, 2.0))
+    S = int(rng.choice([7, 33, 64, 100]))
+    h = float(rng.choice([0.01, 0.05, 0.7]))
+    params = rng.uniform(0.1, 2.0, size=(n, spec.n_parameters)).astype(F)
+    out = assert_twins_agree(spec, o, d, params, S, h, seed)
+    assert out[8].any()
+
+
+def test_float_inverse_of_add_instance():
+    """AddInstance keeps `transform_mat.inverse()` (instancer.cpp:130), Eigen's float32 4x4 inverse; the product (and prepare_instances)
+    invert in double and round.  Against the cofactor expansion in float32 (oracle/c: io_inverse4_float) the two differ by a few units
+    in the last place on the patch matrices DistributeInstancesOnMesh builds (orthogonal frames times a scale, a translation)."""
+    from oracle import c_instancer as ci
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for _ in range(200):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        m = np.eye(4); m[:3, :3] = q * rng.uniform(0.02, 0.5); m[:3, 3] = rng.uniform(-3, 3, size=3)
+        m32 = m.astype(F)
+        a = ci.inverse4_float(m32)
+        b = np.linalg.inv(m32.astype(np.float64)).astype(F)
+        scale = np.abs(b).max(axis=1, keepdims=True)                             # a row's entries share their magnitude (1 / scale; the translation row a few times that)
+        worst = max(worst, float((np.abs(a - b) / (scale * np.finfo(F).eps)).max()))
+    assert worst < 64, worst                                                    # within a few dozen ulps of the row's largest entry: rounding, not a different matrix
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# DistributeInstancesOnMesh (instancer.cpp:233-390): the restatement's known answers, and the product's vectorised version against it
+# ------------------------------------------------------------------------------------------------------------------------------
+
+def test_distribute_known_answer_on_a_tilted_plane_with_sheared_uv():
+    # the plane z = x: normal (-1, 0, 1) / sqrt 2.  Texture coordinates u = x + y / 2, v = y: at constant v, u grows along (1, 0, 1), so that is
+    # the tangent whatever the shear; bitangent = n x t = (0, 1, 0)
+    v = F([[0, 0, 0], [1, 0, 1], [0, 1, 0], [1, 1, 1]]); f = [[0, 1, 2], [1, 3, 2]]
+    n = np.tile(F([-1, 0, 1]) * F(3.0), (4, 1))                                   # (not normalised: the reference normalises, :266)
+    uv = np.stack([v[:, 0] + 0.5 * v[:, 1], v[:, 1]], -1)
+    tr, scale = io.distribute_instances_on_mesh(v, f, n, uv, 0.25)
+    r2 = np.sqrt(0.5)
+    assert scale == 0.25 and tr.shape == (4, 4, 4)
+    for k in range(4):
+        assert np.allclose(tr[k, :3, 0], 0.25 * np.asarray([r2, 0, r2]), atol=1e-7) and np.allclose(tr[k, :3, 1], [0, 0.25, 0], atol=1e-7)
+        assert np.allclose(tr[k, :3, 2], 0.25 * np.asarray([-r2, 0, r2]), atol=1e-7) and np.array_equal(tr[k, :3, 3], v[k]) and np.array_equal(tr[k, 3], [0, 0, 0, 1])
+    # anchors: the frame at the closest point; one further than an average edge length away has no triangle (the reference indexes with -1)
+    tr, _ = io.distribute_instances_on_mesh(v, f, n, uv, 0.25, patch_origins=F([[0.5, 0.25, 0.6]]))
+    assert np.allclose(tr[0, :3, 2], 0.25 * np.asarray([-r2, 0, r2]), atol=1e-7) and np.array_equal(tr[0, :3, 3], F([0.5, 0.25, 0.6]))
+    with pytest.raises(ValueError):
+        io.distribute_instances_on_mesh(v, f, n, uv, 0.25, patch_origins=F([[0.5, 0.5, 9.0]]))
+    # scale <= 0: the average edge length; 2 sides sqrt 2, 2 sides 1, the diagonal sqrt 3 (twice): (2 sqrt 2 + 2 + 2 sqrt 3) / 6
+    _, scale = io.distribute_instances_on_mesh(v, f, n, uv, -1.0)
+    assert np.isclose(scale, (2 * np.sqrt(2) + 2 + 2 * np.sqrt(3)) / 6, rtol=1e-6)
+    # a vertex listed twice gets ONE patch (:348-349); jitter turns the frame about its normal by jitter_amount * U(0, pi) of mt19937(seed)
+    v2 = np.concatenate([v, v[:1]]); n2 = np.concatenate([n, n[:1]]); uv2 = np.concatenate([uv, uv[:1]])
+    tr, _ = io.distribute_instances_on_mesh(v2, f, n2, uv2, 0.25, jitter_amount=0.5, seed=3)
+    assert tr.shape[0] == 4
+    u0 = next(io.mt19937_canonical_floats(3))
+    ang = 0.5 * float(u0) * np.pi
+    assert np.allclose(tr[0, :3, 1] / 0.25, np.cos(ang) * np.asarray([0, 1, 0]) + np.sin(ang) * np.cross([-r2, 0, r2], [0, 1, 0]), atol=1e-6)
+    assert np.allclose(np.einsum("kij,kil->kjl", tr[:, :3, :3], tr[:, :3, :3]), 0.0625 * np.eye(3), atol=1e-6)      # still orthogonal frames
+
+
+@pytest.mark.parametrize("anchors,jitter", [(False, 0.0), (False, 0.7), (True, 0.0), (True, 1.0)])
+def test_the_products_distribute_matches_the_restatement(anchors, jitter):
+    """nerf_tex_amd.instancer.distribute_instances_on_mesh (vectorised numpy, a k-d tree for the anchors) against the sequential
+    restatement on a CURVED mesh with sheared texture coordinates and a duplicated vertex: the same patches, to float32 rounding."""
+    from nerf_tex_amd.instancer import distribute_instances_on_mesh as product
+    v, f, uv = sheet_mesh(n=6, extent=1.0, amp=0.25, z0=0.0)
+    xs = v[:, 0]; ys = v[:, 1]
+    nrm = np.stack([-0.25 * 1.7 * np.cos(1.7 * xs) * np.cos(1.3 * ys), 0.25 * 1.3 * np.sin(1.7 * xs) * np.sin(1.3 * ys), np.ones_like(xs)], -1).astype(F)
+    v = np.concatenate([v, v[7:8]]); nrm = np.concatenate([nrm, nrm[7:8]]); uv = np.concatenate([uv, uv[7:8]])     # vertex 7 once more (unused by faces)
+    origins = None
+    if anchors:
+        rng = np.random.default_rng(5)
+        origins = (v[rng.choice(36, size=11, replace=False)] + rng.normal(size=(11, 3)) * [0.05, 0.05, 0.01]).astype(F)
+    want, s0 = io.distribute_instances_on_mesh(v, f, nrm, uv, 0.09, origins, jitter, seed=4)
+    got, s1 = product(v, f, nrm, uv, 0.09, origins, jitter, 4)
+    assert got.shape == want.shape == ((11 if anchors else 36), 4, 4) and np.isclose(s0, s1)
+    assert np.allclose(got, want, rtol=0, atol=2e-7 * 0.09 + 1e-7), np.abs(got - want).max()
