@@ -797,3 +797,43 @@ def test_shipped_render_configs_run_as_written(fam, tmp_path, monkeypatch):
     if ic["cast_shadow_rays"]:
         ld = lib_side._light_dir_idx
         assert (np.all(b[9][..., ld:ld + 3] == F([0, 0, -1]), axis=-1) & emitted).sum() > 0
+
+
+@pytest.mark.parametrize("mode", ["interpolated", "per_step"])
+def test_the_bench_scene_with_shadows_and_textures_against_the_c_restatement(mode):
+    """The scene the instancer's numbers are measured on (48 x 48 patches on a waving sheet, 1024 steps of 0.002), now with shadow rays under a
+    low sun AND a parameter texture, 1024 rays -- every ray, every buffer, bit for bit against the SECOND restatement (plain C,
+    oracle/c/ntx_instancer_oracle.c; fast enough for a thousand rays through 2304 patches and 4418 triangles).  This is where the two-level
+    cull, the shadow intervals and the candidate lists of the texture lookups all have work to do."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.dataset import look_at
+    from nerf_tex_amd.instancer import Instancer
+    from oracle import c_instancer as ci
+    B0, B1 = synthetic.PATCH_BOX
+    tr, v, f = synthetic.patch_sheet(48)
+    yy, xx = np.meshgrid(np.arange(64), np.arange(64), indexing="ij")
+    px = (127.5 + 127.5 * np.sin(xx * 0.4) * np.sin(yy * 0.4)).astype(np.uint8)
+    uv = ((v[:, :2] + 1.5) / 3.0).astype(F)
+    n_sh, n_tx = (128, 256) if mode == "interpolated" else (100000, 100000)
+    kw = dict(cast_shadow_rays=True, min_shadow_samples=8, n_shadow_samples=n_sh, min_texture_samples=8, n_texture_samples=n_tx)
+    textures = [px, '', '', '', 'light']
+    inst = Instancer(B0, B1, textures=textures, transformations=tr, instance_sampling_method="nearest", instancer_mesh=(v, f, uv), patch_scale=0.09, **kw)
+    fam = synthetic.FAMILIES["carpet"]
+    c2w = look_at(np.asarray(fam["cam"], F))
+    focal = 800 / np.tan(fam["angle"] / 2) / 2
+    side, S, h = 32, 1024, 0.002
+    r0 = (800 - side) // 2
+    rows, cols = np.meshgrid(np.arange(r0, r0 + side), np.arange(r0, r0 + side), indexing="ij")
+    ro, rd, t, cone = orc.proxy_rays(np.stack([rows.ravel(), cols.ravel()], -1), 800, 800, focal, c2w, [-1.7, -1.7, -.3], [1.7, 1.7, .4], F)
+    n = side * side
+    par = np.tile(np.asarray([fam["params"]], F), (n, 1)); par[:, 4:7] = (0.9, 0.2, 0.08)
+    got = run_gpu(inst, ro, rd, par, S, h, seed=1)
+    names, images = oracle_textures(textures)
+    spec = io.make_spec(B0, B1, None, textures=names, images=images, instance_sampling_method="nearest", mesh=(v, f), matrices=inst.matrices(),
+                        instancer_mesh=(v, f, uv), patch_scale=0.09, **kw)
+    want = ci.get_model_input(spec, ro, rd, par, S, h, io.offset_uniforms(n, 1), io.choice_uniforms(n, S, 1))
+    emitted = want[2] > 0
+    dark = emitted & np.all(want[9][..., 4:7] == F([0, 0, -1]), axis=-1)
+    assert emitted.sum() > n * 150 and 0.02 < dark.sum() / emitted.sum() < 0.6 and len(np.unique(want[9][..., 0][emitted])) > 10000
+    assert_same(got, list(want))
+    assert inst.status() == 0
