@@ -106,17 +106,31 @@ def cpu_baseline(family: str, n_samples: int, target_seconds: float = 15.0):
 def measured_traffic(workload: str, precision: str = "float32"):
     """HBM-side bytes per ntx_render_rays call (ALL its kernels: hit compaction + render) from the committed rocprofv3 PMC
     summary of this very command (separate --pmc passes, FETCH_SIZE x2 for gfx950's wide reads; tools/summarize_profile.py).
-    PMC collection cannot run inside the timed bench, so the latest committed profile is quoted; None if absent."""
+    PMC collection cannot run inside the timed bench, so the latest committed profile is quoted; None if absent.
+    Returns (bytes, file, profile) with profile = {"git_head", "kernel_sources_sha16", "current"}: the tree the profile was taken on and
+    whether the kernel sources of THIS tree hash the same (None: the profile predates the record)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", ("bench_" if precision == "float32" else "benchx3_") + f"{workload}_v[0-9]*pmc_summary.json")))
     if not files:
-        return None, None
+        return None, None, None
     d = json.load(open(files[-1]))["derived"]
     rd = d.get("call_hbm_side_read_bytes_corrected", d.get("hbm_side_read_bytes_corrected"))
     wr = d.get("call_hbm_side_write_bytes_uncalibrated", d.get("hbm_side_write_bytes_uncalibrated"))
     if rd is None:
-        return None, None
-    return float(rd) + float(wr or 0.0), os.path.relpath(files[-1], ROOT)
+        return None, None, None
+    prof = {"git_head": d.get("git_head"), "kernel_sources_sha16": d.get("kernel_sources_sha16"), "current": None}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_hash import kernel_sources_sha16
+        if prof["kernel_sources_sha16"]:
+            prof["current"] = prof["kernel_sources_sha16"] == kernel_sources_sha16(ROOT)
+    except Exception:
+        pass
+    if prof["current"] is not True:
+        print(f"bench.py: roofline.traffic is quoted from {os.path.relpath(files[-1], ROOT)} (taken at {prof['git_head'] or 'an unrecorded commit'}); "
+              + ("the kernel sources have changed since" if prof["current"] is False else "whether the kernels changed since is not recorded")
+              + " -- re-run tools/profile_bench.sh + tools/summarize_profile.py", file=sys.stderr)
+    return float(rd) + float(wr or 0.0), os.path.relpath(files[-1], ROOT), prof
 
 
 def bench_instanced(args) -> None:
@@ -184,6 +198,7 @@ def bench_instanced(args) -> None:
     achieved = n_in * flops_per_sample / (kernel_ms * 1e-3) / 1e12
     peak = F32_MFMA_PEAK_TFLOPS if args.precision == "float32" else F16_MFMA_PEAK_TFLOPS
     in_bytes = n * S * 4 * (3 + 3 + 1 + 1 + 1 + 1 + P)
+    traffic_ = measured_traffic("instanced", args.precision)
     print(json.dumps({
         "metric": "in-patch ray-samples/sec (InstanceRenderer tail: compaction + MLP + composite)",
         "value": n_in * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -197,8 +212,8 @@ def bench_instanced(args) -> None:
                                f"ParamNerf n_parameters={list(fam['n_parameters'])}, buffers resident in HBM",
                    "rays": n, "marching_samples_per_ray": S, "in_patch_samples": n_in, "flops_per_sample": flops_per_sample},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": measured_traffic("instanced", args.precision)[0],
-                     "traffic_source": measured_traffic("instanced", args.precision)[1],
+                     "frac": achieved / peak, "traffic": traffic_[0], "traffic_source": traffic_[1], "traffic_profile_head": (traffic_[2] or {}).get("git_head"),
+                     "traffic_profile_current": (traffic_[2] or {}).get("current"),
                      "algorithmic_bytes": in_bytes, "algorithmic_GBps": in_bytes / (kernel_ms * 1e-3) / 1e9,
                      "kernel": "ntx::instance_kernel" if args.precision == "float32" else "ntx::instance_kernel_x3",
                      "kernel_ms": kernel_ms}}), flush=True)
@@ -696,7 +711,7 @@ def main() -> None:
         # multiplicity does not count) against the dense peak of the issued MFMA dtype
         achieved = n_hit * S * flops_per_sample / (kernel_ms * 1e-3) / 1e12
         peak = F32_MFMA_PEAK_TFLOPS if args.precision == "float32" else F16_MFMA_PEAK_TFLOPS
-        traffic, traffic_src = measured_traffic(args.workload, args.precision)
+        traffic, traffic_src, traffic_prof = measured_traffic(args.workload, args.precision)
         if sharded:
             what = (f"{args.workload}: ONE {H}x{W}x{S} image of the {family} config's camera (BASELINE configs[{cfg_idx}]), rays generated on "
                     f"the device, {'pixel rows dealt round-robin' if args.shard == 'rows' else 'contiguous bands'} over {world} GPU(s), "
@@ -720,6 +735,7 @@ def main() -> None:
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes per ntx_render_rays call, all kernels (HBM side, rocprofv3 PMC)", "traffic_source": traffic_src,
+                         "traffic_profile_head": (traffic_prof or {}).get("git_head"), "traffic_profile_current": (traffic_prof or {}).get("current"),
                          "algorithmic_bytes": n_rays * 4 * (3 + 3 + 2 + 1 + 4) + 4 * model.n_params,
                          "kernel": "ntx::render_kernel" if args.precision == "float32" else "ntx::render_kernel_x3",
                          "kernel_ms": kernel_ms},

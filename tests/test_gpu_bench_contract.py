@@ -53,6 +53,22 @@ def test_sharded_workload_line_at_one_gpu():
     assert "ntx_generate_rays_strided" in d["with_ray_setup"]["what"] and d["with_ray_setup"]["value"] > 0.95 * d["value"]
 
 
+def test_the_largest_single_image_at_one_gpu():
+    """BASELINE configs[4] as ONE 1600 x 1600 x 128 image on one GPU (2.56 M rays, 327.68 M samples, ~3 s a step): the workload that needs
+    `ntx_reserve` beyond the default ray capacity on a fresh context.  One timed step, no warm-up."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras",
+                          "--workload", "grass_filtered_sharded"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["steps"] == 1 and d["warmup"] == 0
+    assert d["config"]["hit_rays_total"] == 2_560_000 and d["config"]["samples_per_ray"] == 128 and "1600x1600x128" in d["config"]["workload"]
+    assert d["parity"]["ok"] is True and d["parity"]["rel_linf_f32"] <= 1e-4
+    assert d["roofline"]["frac"] >= 0.95, d["roofline"]                        # cold: the one step includes the first launch
+    assert "traffic_profile_head" in d["roofline"] and "traffic_profile_current" in d["roofline"]
+
+
 def test_instanced_scene_line():
     """`--workload carpet_instanced_scene`: rays -> patch instancer -> InstanceRenderer tail, one chunk: the tail's MFMA roofline on the
     samples the instancer produced, the instancer's own HBM roofline, and the parity block (buffers bit for bit, RGBA <= 1e-4)."""

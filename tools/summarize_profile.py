@@ -49,5 +49,10 @@ derived = {
     "call_kernels": sorted(per_kernel),
     "l2_hit_rate": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")) if "TCC_HIT_sum" in summ else None,
 }
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_hash import kernel_sources_sha16, git_head
+# the tree the numbers belong to: bench.py quotes `traffic` from here and says whether the kernels have changed since
+derived["kernel_sources_sha16"] = os.environ.get("NTX_PROFILE_SOURCES") or kernel_sources_sha16()
+derived["git_head"] = os.environ.get("NTX_PROFILE_HEAD") or git_head()
 json.dump({"dispatch": info, "counters": summ, "derived": derived}, open(f"{P}/{name}_pmc_summary.json", "w"), indent=1)
 print(json.dumps(derived, indent=1))
