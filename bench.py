@@ -133,6 +133,27 @@ def measured_traffic(workload: str, precision: str = "float32"):
     return float(rd) + float(wr or 0.0), os.path.relpath(files[-1], ROOT), prof
 
 
+def instancer_traffic():
+    """HBM-side bytes of one ntx_instancer_model_input call on the bench scene (WRITE_SIZE + 2 x FETCH_SIZE of its three kernels) from the
+    newest committed rocprofv3 summary of `tools/bench_instancer.py` (profiles/r*/instancer_base_pmc_summary.json), quoted like
+    `measured_traffic` quotes the render kernel's."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "instancer_base_pmc_summary.json")))
+    if not files:
+        return {"traffic": None, "traffic_source": None}
+    d = json.load(open(files[-1]))
+    total = sum(float(k.get("hbm_side_write_bytes", 0.0)) + float(k.get("hbm_side_read_bytes_corrected", 0.0)) for k in d["kernels"].values())
+    cur = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_hash import kernel_sources_sha16
+        cur = d.get("kernel_sources_sha16") == kernel_sources_sha16(ROOT) if d.get("kernel_sources_sha16") else None
+    except Exception:
+        pass
+    return {"traffic": total, "traffic_source": os.path.relpath(files[-1], ROOT) + " (WRITE_SIZE + 2 x FETCH_SIZE of the three kernels, same scene)",
+            "traffic_profile_head": d.get("git_head"), "traffic_profile_current": cur}
+
+
 def bench_instanced(args) -> None:
     """`--workload carpet_instanced`: the InstanceRenderer tail (what config_carpet_render.py runs) on one
     render chunk of synthetic instancer output resident in HBM: 16 384 rays x 1024 marching samples
@@ -313,8 +334,7 @@ def bench_instanced_scene(args) -> None:
                      "what": "ntx_render_instanced (ordering kernels + instance_kernel) on the instancer's own output"},
         "instancer": {"ms": inst_ms, "share_of_step": inst_ms / (inst_ms + kernel_ms), "rays_per_s": n / (inst_ms * 1e-3), "status_flag": int(status.item()),
                       "roofline": {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "algorithmic_bytes": out_bytes,
-                                   "traffic": 1168982544 + 13545539 + 110656 + 16079520 + 1128757 + 2289664,
-                                   "traffic_source": "profiles/r03/instancer_pmc_summary.json (WRITE_SIZE + 2 x FETCH_SIZE of the three kernels, same scene)"},
+                                   **instancer_traffic()},
                       "kernels": "inst_hits_kernel + inst_mesh_kernel + inst_march_kernel (DESIGN 4.5)"}}
     if not args.no_parity:
         from oracle import instancer_oracle as io
