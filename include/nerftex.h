@@ -447,6 +447,62 @@ int ntx_instancer_set_parameter_textures(ntx_instancer *inst, const float *verti
 int ntx_instancer_set_mesh_textures(ntx_instancer *inst, const float *uv, int64_t n_vertices, const int32_t *face_texture, int64_t n_faces,
                                     int n_sets, const ntx_texture *textures);
 
+/* ---- ABI v5: one training step (f6) ------------------------------------------------------------------------------------------
+ * Replaces the body of the reference's training loop, network/train.py:61-67: `pred = renderer(**data)` under a GradientTape, a loss
+ * of network/loss.py:6-59, `tape.gradient`, `optimizer.apply_gradients` with tf.keras.optimizers.Adam under ExponentialDecay
+ * (train.py:49-52).  Built for the architecture of the shipped training configs: ParamNerf, depth 8, width 256, skips [4],
+ * color_depth 1, Fourier features (any n_parameters, any band counts); NTX_E_UNSUPPORTED otherwise.  The trainer owns the weights
+ * (Keras get_weights() order, like ntx_create), Adam's moments, the gradient and every layer's activations for up to
+ * max_rays x max_samples_per_ray samples (<= 1024 samples per ray; 13.4 KB per sample: 3.5 GB for the configs' 4 x 256 x 256).
+ * Everything float32.  A step is bit-reproducible: weight gradients are summed over the samples in a fixed order. */
+typedef struct ntx_trainer ntx_trainer;
+#define NTX_LOSS_NERF 0                  /* network.loss.NerfLoss  (loss.py:6-19):  loss_fn(color_true, color_pred) */
+#define NTX_LOSS_ALPHA 1                 /* network.loss.AlphaLoss (loss.py:21-49): + gamma * alpha_loss_fn(alpha_true, alpha_pred), colours masked by alpha_true */
+#define NTX_LOSS_MSE 0                   /* network.loss.mse   (loss.py:51-54) */
+#define NTX_LOSS_SMAPE 1                 /* network.loss.smape (loss.py:56-59), eps = 1e-2 */
+typedef struct ntx_loss_desc {
+    uint32_t size;                       /* sizeof(ntx_loss_desc) */
+    int32_t kind, loss_fn, alpha_loss_fn;
+    float gamma;                         /* AlphaLoss: 1 */
+    int32_t filter_color_loss, use_hard_mask;   /* AlphaLoss: True, True */
+} ntx_loss_desc;
+int ntx_trainer_create(const ntx_model_desc *desc, const float *weights_host, size_t n_floats, int device, int64_t max_rays, int max_samples_per_ray,
+                       ntx_trainer **out);
+int ntx_trainer_destroy(ntx_trainer *t);
+size_t ntx_trainer_weight_count(const ntx_trainer *t);
+#define NTX_TRAINER_WEIGHTS 0
+#define NTX_TRAINER_GRADIENTS 1
+#define NTX_TRAINER_ADAM_M 2
+#define NTX_TRAINER_ADAM_V 3
+/* Copies one of the trainer's weight-shaped vectors to HOST memory (Keras get_weights() order; synchronises the device). */
+int ntx_trainer_get(ntx_trainer *t, int what, float *out_host, size_t n_floats);
+int ntx_trainer_set_weights(ntx_trainer *t, const float *weights_host, size_t n_floats);
+/* The activations the last step kept, to HOST memory as [n_samples_total][width]: layer 0-7 = the trunk layers' outputs (after their ReLU),
+ * 8 / 9 = the two colour layers' (width 256 / 128), 10 = the raw density (width 1).  Tests hand their signs to the float64 restatement, so
+ * that its autograd follows the ReLU branches the float32 forward took (a pre-activation within rounding of zero can fall either way). */
+int ntx_trainer_activation(ntx_trainer *t, int layer, int64_t n_samples_total, float *out_host);
+/* Forward (Renderer.__call__ for rays that all hit, renderer.py:92-213: sample depths by ntx_sample_depths -- NTX_FLAG_PERTURB /
+ * perturb_seed / opts as there -- or given as z_vals[N,S]; encodings; the network; map_model_output with NTX_FLAG_MAP_EXR /
+ * NTX_FLAG_COMPOSITE_BKGD), the loss, and its gradient with respect to every weight, left in the trainer (ntx_trainer_get /
+ * ntx_trainer_adam_step).  DEVICE: rays_o[N,3], rays_d[N,3], tnear_far[N,2] (or NULL with z_vals), params[rows,P] (ray r uses row
+ * r / rays_per_param_row), cone_scale[N] (blur_idx >= 0), color_true[N,3], alpha_true[N] (AlphaLoss); outputs, each may be NULL:
+ * color_pred[N,3], alpha_pred[N], loss_out[1].  bkgd: HOST [3] or NULL (white). */
+int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *rays_d, const float *tnear_far, const float *params, int64_t rays_per_param_row,
+                             const float *cone_scale, int64_t n_rays, int n_samples, int blur_idx, uint32_t flags, const float *bkgd, uint64_t perturb_seed,
+                             const ntx_render_opts *opts, const float *z_vals, const float *color_true, const float *alpha_true, const ntx_loss_desc *loss,
+                             float *color_pred, float *alpha_pred, float *loss_out, ntx_stream stream);
+/* optimizer.apply_gradients (train.py:67): Adam (m += (g - m)(1 - beta_1); v += (g^2 - v)(1 - beta_2); w -= lr_t m / (sqrt(v) + epsilon),
+ * lr_t = lr sqrt(1 - beta_2^t) / (1 - beta_1^t), t = iterations + 1: TF 2.4's ApplyAdam) with lr = lrate * lrate_decay_rate ^
+ * (iterations / lrate_decay_steps) when lrate_decay_steps > 0 (ExponentialDecay, train.py:49-50: decay_steps = lrate_decay * 1e3,
+ * decay_rate 0.1), else lrate.  Keras defaults: beta_1 0.9, beta_2 0.999, epsilon 1e-7.  Counts the iteration. */
+int ntx_trainer_adam_step(ntx_trainer *t, float lrate, float lrate_decay_steps, float lrate_decay_rate, float beta_1, float beta_2, float epsilon,
+                          ntx_stream stream);
+int64_t ntx_trainer_iterations(const ntx_trainer *t);
+/* The dense contraction the trainer is made of (f32 MFMA, 128 x 128 x 16 tiles through LDS), on DEVICE buffers, for tests and benches:
+ * C[M][N] = op(A) . op(B) (+ bias[N]) (ReLU); a_kcontig: A is [M][K] (row stride lda), else [K][M]; b_kcontig: B is [N][K], else [K][N]. */
+int ntx_gemm_f32(const float *A, int lda, int a_kcontig, const float *B, int ldb, int b_kcontig, float *C, int ldc, int M, int N, int K, const float *bias,
+                 int relu, ntx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

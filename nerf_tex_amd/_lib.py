@@ -57,6 +57,16 @@ class Texture(C.Structure):
     _fields_ = [("texels", C.POINTER(C.c_float)), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
+class LossDesc(C.Structure):
+    """struct ntx_loss_desc (ABI v5): network.loss.NerfLoss / AlphaLoss over mse / smape (loss.py:6-59)"""
+    _fields_ = [("size", C.c_uint32), ("kind", C.c_int32), ("loss_fn", C.c_int32), ("alpha_loss_fn", C.c_int32), ("gamma", C.c_float),
+                ("filter_color_loss", C.c_int32), ("use_hard_mask", C.c_int32)]
+
+
+LOSS_NERF, LOSS_ALPHA, LOSS_MSE, LOSS_SMAPE = 0, 1, 0, 1
+TRAINER_WEIGHTS, TRAINER_GRADIENTS, TRAINER_ADAM_M, TRAINER_ADAM_V = 0, 1, 2, 3
+
+
 class NtxError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"nerftex error {code}: {message}")
@@ -121,6 +131,17 @@ SYMBOLS = {
     "ntx_instancer_set_parameter_textures": (C.c_int, [_vp, _fp, _fp, C.c_int64, C.POINTER(C.c_int32), C.c_int64, C.c_float, C.c_int,
                                                        C.POINTER(C.c_int32), C.POINTER(Texture), C.c_int, C.c_int]),
     "ntx_instancer_set_mesh_textures": (C.c_int, [_vp, _fp, C.c_int64, C.POINTER(C.c_int32), C.c_int64, C.c_int, C.POINTER(Texture)]),
+    "ntx_trainer_create": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, C.c_int, C.c_int64, C.c_int, C.POINTER(_vp)]),
+    "ntx_trainer_destroy": (C.c_int, [_vp]),
+    "ntx_trainer_weight_count": (C.c_size_t, [_vp]),
+    "ntx_trainer_get": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
+    "ntx_trainer_activation": (C.c_int, [_vp, C.c_int, C.c_int64, _fp]),
+    "ntx_trainer_set_weights": (C.c_int, [_vp, _fp, C.c_size_t]),
+    "ntx_train_step_gradients": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, C.c_int, C.c_uint32, _fp, C.c_uint64, _op, _vp,
+                                           _vp, _vp, C.POINTER(LossDesc), _vp, _vp, _vp, _vp]),
+    "ntx_trainer_adam_step": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
+    "ntx_trainer_iterations": (C.c_int64, [_vp]),
+    "ntx_gemm_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "ntx_instancer_model_input": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_uint64, _op] + [_vp] * 12),
 }
 

@@ -1,0 +1,725 @@
+// ntx_train.hip -- one training step of the reference on the GPU: network/train.py:49-70 (GradientTape over Renderer.__call__, a loss of
+// network/loss.py:6-59, Adam under ExponentialDecay) for the ParamNerf architecture of the shipped training configs (8 x 256, skip 4,
+// color_depth 1; configs/config_carpet_train.py: 4 images x 256 rays x 256 samples = 262 144 samples a step).  gfx950 only.
+//
+// Inference fuses the whole network into one kernel because nothing of it has to survive (ntx_device.h).  A training step has to keep
+// every layer's activations for the backward pass; with 288 GB of HBM they are simply stored -- 13 layers x 262 144 x 256 floats = 3.5 GB
+// -- and the step is a sequence of plain dense contractions on the f32 matrix cores:
+//
+//   encode_kernel          sample points, positional encodings of position / direction / parameters (layer.py:8-23), written straight into
+//                          the two concat buffers the network reads them from ([pos_map | h4] for the skip, [dir_map | feature])
+//   gemm_kernel<A, B>      C = op(A) . op(B) on v_mfma_f32_32x32x2_f32, 128 x 128 x 16 tiles through LDS (double buffered), with the
+//                          epilogues a Dense layer and its gradient need (bias, ReLU, the ReLU mask of a stored activation, accumulate);
+//                          three operand layouts: forward  Y = X . W,   dX = dY . W^T,   dW = X^T . dY  (the last one split along the
+//                          262 144 samples into partial sums that one pass adds up in a fixed order: a step is bit-reproducible)
+//   head kernels           the 1-wide density head and the 3-wide colour head, forward and backward, on the vector ALUs
+//   composite_forward / _backward   renderer.py:170-213 per ray (wave per ray) and its adjoint: suffix sums of the weights' gradients
+//   loss_kernel            NerfLoss / AlphaLoss with mse / smape (loss.py), value and gradient
+//   adam_kernel            tf.keras.optimizers.Adam under ExponentialDecay (train.py:49-52), one fused pass over the 2.7 MB of weights
+//
+// Everything is float32 with float32 accumulation, like the reference's TensorFlow graph.
+#include "nerftex.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+extern "C" int ntx_set_error(int code, const char *fmt, ...);   // nerftex.hip
+
+#define TRAIN_TRY(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return ntx_set_error(NTX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace ntx_train {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// the contraction.  C[i][j] = sum_p A'(i, p) B'(p, j) for i < M, j < N, p < K, with
+//   A'(i, p) = A_KCONTIG ? A[i * lda + p] : A[p * lda + i]          B'(p, j) = B_KCONTIG ? B[j * ldb + p] : B[p * ldb + j]
+// A workgroup (4 waves) owns a 128 x 128 tile of C, a wave a 64 x 64 quarter of it = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator
+// registers).  K advances 16 at a time: the next 128 x 16 / 16 x 128 panels are fetched into registers while the current ones, already
+// in LDS as As[p][i] / Bs[p][j], feed 32 MFMAs per wave; one barrier per panel (double buffered).  LDS rows are 130 floats apart so that
+// both the transposing stores (8 rows apart -> 16 banks apart) and the operand reads (32 consecutive floats) are conflict free.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int TM = 128, TN = 128, TK = 16, LROW = 130;
+
+struct GemmArgs {
+    const float *A; int lda; const float *B; int ldb; float *C; int ldc;
+    int M, N, K;
+    const float *bias;               // NULL or [N]: added to every row
+    const float *mask; int ldmask;   // NULL, or C[i][j] is kept only where mask[i * ldmask + j] > 0 (the ReLU of a stored activation)
+    int relu, accumulate;            // C = max(C, 0);  C += what was there
+    int k_chunk; long long split_stride;   // blockIdx.z = z covers p in [z * k_chunk, (z + 1) * k_chunk) and writes to C + z * split_stride
+};
+
+// a 128 x 16 panel whose 16 run along memory (k-contiguous rows): thread t takes row t >> 1, elements (t & 1) * 8 .. + 7
+__device__ __forceinline__ void fetch_kcontig(const float *src, int ld, int row0, int nrows, int k0, int k1, float *r) {
+    const int row = row0 + (int)(threadIdx.x >> 1), p0 = k0 + (int)(threadIdx.x & 1) * 8;
+    const float *g = src + (size_t)row * ld + p0;
+    const bool rv = row < nrows;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[q] = (rv && p0 + q < k1) ? g[q] : 0.0f;
+}
+__device__ __forceinline__ void stash_kcontig(float (*S)[LROW], const float *r) {
+    const int row = (int)(threadIdx.x >> 1), p0 = (int)(threadIdx.x & 1) * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) S[p0 + q][row] = r[q];
+}
+// a 16 x 128 panel whose 128 run along memory: thread t takes row (of 16) t >> 4, elements (t & 15) * 8 .. + 7
+__device__ __forceinline__ void fetch_mncontig(const float *src, int ld, int col0, int ncols, int k0, int k1, float *r) {
+    const int p = k0 + (int)(threadIdx.x >> 4), c0 = col0 + (int)(threadIdx.x & 15) * 8;
+    const float *g = src + (size_t)p * ld + c0;
+    const bool pv = p < k1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[q] = (pv && c0 + q < ncols) ? g[q] : 0.0f;
+}
+__device__ __forceinline__ void stash_mncontig(float (*S)[LROW], const float *r) {
+    const int p = (int)(threadIdx.x >> 4), c0 = (int)(threadIdx.x & 15) * 8;
+    f32x2 *d = reinterpret_cast<f32x2 *>(&S[p][c0]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = f32x2{r[2 * q], r[2 * q + 1]};
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][TK][LROW], Bs[2][TK][LROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * TM, j0 = blockIdx.y * TN;
+    const int k_begin = blockIdx.z * g.k_chunk;
+    const int k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
+    float *C = g.C + (size_t)blockIdx.z * (size_t)g.split_stride;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
+        if (A_KCONTIG) fetch_kcontig(g.A, g.lda, i0, g.M, k0, k_end, ra); else fetch_mncontig(g.A, g.lda, i0, g.M, k0, k_end, ra);
+        if (B_KCONTIG) fetch_kcontig(g.B, g.ldb, j0, g.N, k0, k_end, rb); else fetch_mncontig(g.B, g.ldb, j0, g.N, k0, k_end, rb);
+    };
+    auto stash = [&](int buf) {
+        if (A_KCONTIG) stash_kcontig(As[buf], ra); else stash_mncontig(As[buf], ra);
+        if (B_KCONTIG) stash_kcontig(Bs[buf], rb); else stash_mncontig(Bs[buf], rb);
+    };
+    const int n_panels = (k_end - k_begin + TK - 1) / TK;
+    if (n_panels > 0) { fetch(k_begin); stash(0); }
+    __syncthreads();
+    const int wi = (wave >> 1) * 64 + (lane & 31), wj = (wave & 1) * 64 + (lane & 31), kh = lane >> 5;
+    for (int kt = 0; kt < n_panels; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < n_panels) fetch(k_begin + (kt + 1) * TK);
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 2) {
+            const float a0 = As[buf][kk + kh][wi], a1 = As[buf][kk + kh][wi + 32];
+            const float b0 = Bs[buf][kk + kh][wj], b1 = Bs[buf][kk + kh][wj + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < n_panels) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // D of a 32 x 32 tile: lane l, register r  <->  row 8 (r >> 2) + (r & 3) + 4 (l >> 5), column l & 31
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = j0 + (wave & 1) * 64 + b * 32 + (lane & 31);
+            const float bj = (g.bias && j < g.N) ? g.bias[j] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + (wave >> 1) * 64 + a * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh;
+                if (i < g.M && j < g.N) {
+                    float v = acc[a][b][r];
+                    float *c = C + (size_t)i * g.ldc + j;
+                    if (g.accumulate) v = v + *c;
+                    v = v + bj;
+                    if (g.relu) v = v > 0.0f ? v : 0.0f;
+                    if (g.mask && !(g.mask[(size_t)i * g.ldmask + j] > 0.0f)) v = 0.0f;
+                    *c = v;
+                }
+            }
+        }
+}
+
+// out[e] = sum_z partial[z][e], z ascending: the fixed order that makes a step reproducible
+__global__ void reduce_partials_kernel(const float *__restrict__ partial, int n_split, long long stride, long long count, float *__restrict__ out) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    float s = 0.0f;
+    for (int z = 0; z < n_split; ++z) s += partial[(size_t)z * stride + e];
+    out[e] = s;
+}
+// column sums of G[M][ld] (the bias gradient): block b sums rows [b * rows, ...) of column threadIdx.x into partial[b][col]
+__global__ void colsum_partial_kernel(const float *__restrict__ G, int ld, long long M, int N, int rows, float *__restrict__ partial) {
+    const int j = threadIdx.x;
+    if (j >= N) return;
+    const long long m0 = (long long)blockIdx.x * rows, m1 = m0 + rows < M ? m0 + rows : M;
+    float s = 0.0f;
+    for (long long m = m0; m < m1; ++m) s += G[(size_t)m * ld + j];
+    partial[(size_t)blockIdx.x * N + j] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// encoder: layer.FourierFeatures (layer.py:8-23) of position [+ geometry parameters] and of direction [+ appearance parameters]
+// (model.py:77-101), the sample points of renderer.py:98-114 and the blur product of :155-158; thread per sample
+// ---------------------------------------------------------------------------------------------------------------------------
+struct EncodeArgs {
+    const float *rays_o, *rays_d, *z, *params, *cone;
+    long long rays_per_param_row;
+    int n_rays, S, n_geo, n_app, pos_freq, dir_freq, param_freq, blur_idx;
+    float *pos_out; int ld_pos;      // [M][ld_pos]: pos_map in columns 0 .. Kp
+    float *dir_out; int ld_dir;      // [M][ld_dir]: dir_map in columns 0 .. Kd
+    float *dists;                    // [N][S]: z[i+1] - z[i], the last one repeated, times |rays_d| (renderer.py:174-180)
+};
+__device__ __forceinline__ int fourier(float *out, const float *x, int d, int nf) {
+    int p = 0;
+    for (int c = 0; c < d; ++c) out[p++] = x[c];
+    float f = 1.0f;
+    for (int k = 0; k < nf; ++k) {
+        for (int c = 0; c < d; ++c) out[p++] = sinf(f * x[c]);
+        for (int c = 0; c < d; ++c) out[p++] = cosf(f * x[c]);
+        f *= 2.0f;
+    }
+    return p;
+}
+__global__ void encode_kernel(EncodeArgs a) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= (long long)a.n_rays * a.S) return;
+    const int ray = (int)(m / a.S), s = (int)(m - (long long)ray * a.S);
+    const float o[3] = {a.rays_o[3 * ray], a.rays_o[3 * ray + 1], a.rays_o[3 * ray + 2]};
+    const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
+    const float dn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const float z = a.z[(size_t)ray * a.S + s];
+    const float pos[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z};                  // renderer.py:114 (un-normalised rays_d)
+    const float dir[3] = {d[0] / dn, d[1] / dn, d[2] / dn};                                    // :98
+    const int P = a.n_geo + a.n_app;
+    float par[16];
+    const float *pr = a.params + (size_t)(ray / a.rays_per_param_row) * P;
+    for (int c = 0; c < P; ++c) par[c] = pr[c];
+    if (a.blur_idx >= 0) par[a.blur_idx] = par[a.blur_idx] * (a.cone[ray] * z);                // :155-158
+    float *po = a.pos_out + (size_t)m * a.ld_pos;
+    int p = fourier(po, pos, 3, a.pos_freq);
+    if (a.n_geo > 0) fourier(po + p, par, a.n_geo, a.param_freq);                              // model.py:88-93
+    float *dp = a.dir_out + (size_t)m * a.ld_dir;
+    p = fourier(dp, dir, 3, a.dir_freq);
+    if (a.n_app > 0) fourier(dp + p, par + a.n_geo, a.n_app, a.param_freq);                    // :96-101
+    const float zn = s + 1 < a.S ? a.z[(size_t)ray * a.S + s + 1] : 0.0f;
+    float dist = s + 1 < a.S ? zn - z : (a.S > 1 ? z - a.z[(size_t)ray * a.S + s - 1] : 0.0f);
+    a.dists[(size_t)ray * a.S + s] = dist * dn;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// the narrow heads on the vector ALUs: y[m][c] = x[m] . W[:, c] + b[c] for n_out = 1 (alpha) or 3 (color)
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ void head_forward_kernel(const float *__restrict__ X, int ldx, int K, const float *__restrict__ W, const float *__restrict__ b, int n_out,
+                                    long long M, float *__restrict__ Y) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float *x = X + (size_t)m * ldx;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < K; ++k) {
+        const float v = x[k];
+        for (int c = 0; c < n_out; ++c) acc[c] += v * W[k * n_out + c];
+    }
+    for (int c = 0; c < n_out; ++c) Y[(size_t)m * n_out + c] = acc[c] + b[c];
+}
+// dX[m][k] (+)= sum_c dY[m][c] W[k][c], kept where mask > 0 (mask NULL: everywhere); thread per (m, k)
+__global__ void head_backward_dx_kernel(const float *__restrict__ dY, int n_out, const float *__restrict__ W, int K, long long M, const float *__restrict__ mask,
+                                        int ldmask, int accumulate, float *__restrict__ dX, int lddx) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * K) return;
+    const long long m = e / K; const int k = (int)(e - m * K);
+    float v = 0.0f;
+    for (int c = 0; c < n_out; ++c) v += dY[(size_t)m * n_out + c] * W[k * n_out + c];
+    float *d = dX + (size_t)m * lddx + k;
+    if (accumulate) v += *d;
+    if (mask && !(mask[(size_t)m * ldmask + k] > 0.0f)) v = 0.0f;
+    *d = v;
+}
+// dW[k][c] partial over a block of rows: block b, thread k: sum_m X[m][k] dY[m][c]
+__global__ void head_backward_dw_partial_kernel(const float *__restrict__ X, int ldx, int K, const float *__restrict__ dY, int n_out, long long M, int rows,
+                                                float *__restrict__ partial) {
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    const long long m0 = (long long)blockIdx.x * rows, m1 = m0 + rows < M ? m0 + rows : M;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    for (long long m = m0; m < m1; ++m) {
+        const float x = X[(size_t)m * ldx + k];
+        for (int c = 0; c < n_out; ++c) acc[c] += x * dY[(size_t)m * n_out + c];
+    }
+    for (int c = 0; c < n_out; ++c) partial[((size_t)blockIdx.x * K + k) * n_out + c] = acc[c];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// map_model_output (renderer.py:170-213) per ray and its adjoint; wave per ray, lane l holds samples l, l + 64, ...
+// ---------------------------------------------------------------------------------------------------------------------------
+struct CompositeArgs {
+    const float *raw_rgb, *sigma, *dists;      // [N][S][3], [N][S], [N][S]
+    int n_rays, S, map_exr, composite_bkgd; float bkgd[3];
+    float *color, *alpha;                      // forward outputs [N][3], [N]
+    const float *d_color, *d_alpha;            // backward inputs
+    float *d_raw_rgb, *d_sigma;                // backward outputs
+};
+constexpr int MAX_TRAIN_SAMPLES = 1024;
+__device__ __forceinline__ float wave_sumf(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ float rgb_of(float raw, int map_exr) {
+    if (map_exr) return raw > 0.0f ? raw + 1.0f : expf(raw);                                   // elu + 1 (:184-185)
+    return 1.0f / (1.0f + expf(-raw));                                                         // sigmoid (:187)
+}
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
+    __shared__ float sh_a[4][MAX_TRAIN_SAMPLES], sh_T[4][MAX_TRAIN_SAMPLES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wave;
+    if (ray >= a.n_rays) return;
+    const int S = a.S;
+    const float *sg = a.sigma + (size_t)ray * S, *ds = a.dists + (size_t)ray * S, *rr = a.raw_rgb + (size_t)ray * S * 3;
+    float *al = sh_a[wave], *T = sh_T[wave];
+    for (int s = lane; s < S; s += 64) { const float r = sg[s] > 0.0f ? sg[s] : 0.0f; al[s] = 1.0f - expf(-r * ds[s]); }    // :195
+    __builtin_amdgcn_wave_barrier();
+    // exclusive running product of (1 - a) + 1e-10, sequential like tf.math.cumprod (:198): chunks of 64 with a carry
+    float carry = 1.0f;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        float f = s < S ? (1.0f - al[s]) + 1e-10f : 1.0f, incl = f;
+        for (int o = 1; o < 64; o <<= 1) { const float w = __shfl_up(incl, o); if (lane >= o) incl *= w; }
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0f;
+        if (s < S) T[s] = carry * excl;
+        carry *= __shfl(incl, 63);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, A = 0.0f;
+    for (int s = lane; s < S; s += 64) {
+        const float w = al[s] * T[s];
+        c0 += w * rgb_of(rr[3 * s], a.map_exr); c1 += w * rgb_of(rr[3 * s + 1], a.map_exr); c2 += w * rgb_of(rr[3 * s + 2], a.map_exr);
+        A += w;
+    }
+    c0 = wave_sumf(c0); c1 = wave_sumf(c1); c2 = wave_sumf(c2); A = wave_sumf(A);
+    if (!BACKWARD) {
+        if (a.composite_bkgd) { c0 += (1.0f - A) * a.bkgd[0]; c1 += (1.0f - A) * a.bkgd[1]; c2 += (1.0f - A) * a.bkgd[2]; }   // :210-211
+        if (lane == 0) { a.color[3 * ray] = c0; a.color[3 * ray + 1] = c1; a.color[3 * ray + 2] = c2; a.alpha[ray] = A; }
+        return;
+    }
+    // adjoint.  C = sum w rgb (+ (1 - A) bkgd), A = sum w, w_i = a_i T_i, T_i = prod_{j<i} ((1 - a_j) + 1e-10):
+    //   g_i = dL/dw_i = dC . rgb_i + dA';   dL/da_i = T_i g_i - (sum_{k>i} g_k w_k) / ((1 - a_i) + 1e-10)
+    const float dC[3] = {a.d_color[3 * ray], a.d_color[3 * ray + 1], a.d_color[3 * ray + 2]};
+    float dA = a.d_alpha[ray];
+    if (a.composite_bkgd) dA -= (dC[0] * a.bkgd[0] + dC[1] * a.bkgd[1]) + dC[2] * a.bkgd[2];
+    float suffix = 0.0f;                                   // sum of g_k w_k over the samples behind the current chunk
+    for (int s0 = ((S - 1) / 64) * 64; s0 >= 0; s0 -= 64) {
+        const int s = s0 + lane;
+        float gw = 0.0f, g = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f};
+        if (s < S) {
+            for (int c = 0; c < 3; ++c) rgb[c] = rgb_of(rr[3 * s + c], a.map_exr);
+            g = ((dC[0] * rgb[0] + dC[1] * rgb[1]) + dC[2] * rgb[2]) + dA;
+            gw = g * (al[s] * T[s]);
+        }
+        float incl = gw;                                   // inclusive suffix sum inside the chunk
+        for (int o = 1; o < 64; o <<= 1) { const float w = __shfl_down(incl, o); if (lane + o < 64) incl += w; }
+        const float behind = (incl - gw) + suffix;         // strictly behind s
+        if (s < S) {
+            const float w = al[s] * T[s];
+            const float d_a = T[s] * g - behind / ((1.0f - al[s]) + 1e-10f);
+            const float sig = sg[s];
+            a.d_sigma[(size_t)ray * S + s] = sig > 0.0f ? d_a * ds[s] * expf(-sig * ds[s]) : 0.0f;
+            for (int c = 0; c < 3; ++c) {
+                const float raw = rr[3 * s + c];
+                const float drgb = a.map_exr ? (raw > 0.0f ? 1.0f : expf(raw)) : rgb[c] * (1.0f - rgb[c]);
+                a.d_raw_rgb[((size_t)ray * S + s) * 3 + c] = w * dC[c] * drgb;
+            }
+        }
+        suffix += __shfl(incl, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// loss.py: NerfLoss / AlphaLoss over mse / smape; one workgroup (a training batch is a thousand rays).  Value and gradient.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct LossArgs {
+    const float *color_true, *alpha_true, *color_pred, *alpha_pred;
+    int n_rays, kind, loss_fn, alpha_loss_fn, filter_color_loss, use_hard_mask; float gamma;
+    float *loss, *d_color, *d_alpha;
+};
+__device__ __forceinline__ void loss_term(int fn, float t, float p, float inv_n, float &value, float &grad) {
+    if (fn == NTX_LOSS_MSE) { const float e = t - p; value = e * e * inv_n; grad = -2.0f * e * inv_n; }          // loss.py:51-54
+    else {                                                                                                        // smape, eps 1e-2 (:56-59)
+        const float e = t - p, den = (t + p) + 1e-2f, ae = fabsf(e);
+        const float sgn = e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f);
+        value = ae / den * inv_n; grad = (-sgn / den - ae / (den * den)) * inv_n;
+    }
+}
+__global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
+    __shared__ float red[1024];
+    float total = 0.0f;
+    const float inv_c = 1.0f / (float)(a.n_rays * 3), inv_a = 1.0f / (float)a.n_rays;
+    for (int r = threadIdx.x; r < a.n_rays; r += blockDim.x) {
+        float mask = 1.0f;
+        if (a.kind == NTX_LOSS_ALPHA && a.filter_color_loss) mask = a.use_hard_mask ? (a.alpha_true[r] > 0.0f ? 1.0f : 0.0f) : a.alpha_true[r];   // :29-35
+        for (int c = 0; c < 3; ++c) {
+            float v, gr;
+            loss_term(a.loss_fn, a.color_true[3 * r + c] * mask, a.color_pred[3 * r + c] * mask, inv_c, v, gr);
+            total += v; a.d_color[3 * r + c] = gr * mask;
+        }
+        float ga = 0.0f;
+        if (a.kind == NTX_LOSS_ALPHA) { float v; loss_term(a.alpha_loss_fn, a.alpha_true[r], a.alpha_pred[r], inv_a, v, ga); total += a.gamma * v; ga *= a.gamma; }   // :38
+        a.d_alpha[r] = ga;
+    }
+    red[threadIdx.x] = total;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) *a.loss = red[0];
+}
+
+// tf.keras.optimizers.Adam (TF 2.4, non-amsgrad): m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2;
+// w -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps), t = iterations + 1; lr from ExponentialDecay (train.py:49-52) on the host
+__global__ void adam_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long long n, float lr_t, float b1,
+                            float b2, float eps) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float ge = g[e];
+    const float me = m[e] + (ge - m[e]) * (1.0f - b1);
+    const float ve = v[e] + (ge * ge - v[e]) * (1.0f - b2);
+    m[e] = me; v[e] = ve;
+    w[e] = w[e] - (me * lr_t) / (sqrtf(ve) + eps);
+}
+
+}   // namespace ntx_train
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------------
+struct TLayer { int in, out; size_t w, b; };      // offsets into the Keras-order blob (kernel [in][out], then bias)
+
+struct ntx_trainer {
+    int device = 0;
+    ntx_model_desc desc{};
+    int Kp = 0, Kd = 0, P = 0;
+    TLayer trunk[8], feature, c1, c2, rgb, alpha;
+    size_t n_weights = 0;
+    long long cap = 0;                         // samples the buffers hold
+    float *w = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    // activations (per sample): h[i] = output of trunk layer i (h[4] lives inside h4c), c1o, c2o; concat buffers; heads' raw outputs
+    float *h[8] = {}, *h4c = nullptr, *fc = nullptr, *c1o = nullptr, *c2o = nullptr, *raw_rgb = nullptr, *sigma = nullptr;
+    float *z = nullptr, *dists = nullptr, *g0 = nullptr, *g1 = nullptr, *d_raw = nullptr, *d_sigma = nullptr, *partial = nullptr;
+    float *color = nullptr, *alpha_out = nullptr, *d_color = nullptr, *d_alpha = nullptr, *loss = nullptr;
+    long long cap_rays = 0;
+    size_t partial_floats = 0;
+    long long adam_iterations = 0;
+};
+
+namespace {
+
+using namespace ntx_train;
+
+constexpr int SPLIT = 128;        // partial sums of a weight gradient along the samples
+constexpr int HEAD_ROWS = 2048;   // rows per block of the narrow reductions
+
+void free_all(ntx_trainer *t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    void *ptrs[] = {t->w, t->grad, t->adam_m, t->adam_v, t->h4c, t->fc, t->c1o, t->c2o, t->raw_rgb, t->sigma, t->z, t->dists, t->g0, t->g1, t->d_raw, t->d_sigma,
+                    t->partial, t->color, t->alpha_out, t->d_color, t->d_alpha, t->loss};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 8; ++i) if (i != 4 && t->h[i]) (void)hipFree(t->h[i]);
+    delete t;
+}
+
+template <bool AK, bool BK>
+void launch_gemm(hipStream_t st, GemmArgs g, int n_split) {
+    if (n_split < 1) n_split = 1;
+    g.k_chunk = n_split == 1 ? g.K : ((g.K + n_split - 1) / n_split + TK - 1) / TK * TK;
+    const int nz = (g.K + g.k_chunk - 1) / g.k_chunk;
+    hipLaunchKernelGGL((gemm_kernel<AK, BK>), dim3((g.M + TM - 1) / TM, (g.N + TN - 1) / TN, nz), dim3(256), 0, st, g);
+}
+
+// Y = act(X . W + b): X [M][K] (row stride ldx), W [K][N] row-major, Y [M][N] (row stride ldy)
+void dense_forward(hipStream_t st, const float *X, int ldx, int K, const float *W, const float *b, int N, long long M, float *Y, int ldy, int relu) {
+    GemmArgs g{}; g.A = X; g.lda = ldx; g.B = W; g.ldb = N; g.C = Y; g.ldc = ldy; g.M = (int)M; g.N = N; g.K = K; g.bias = b; g.relu = relu;
+    launch_gemm<true, false>(st, g, 1);
+}
+// dX = dY . W[row0 .. row0 + K)^T, kept where mask > 0:  dY [M][N], W [.][N], dX [M][K]
+void dense_backward_dx(hipStream_t st, const float *dY, int N, const float *W, int row0, int K, long long M, const float *mask, int ldmask, int accumulate, float *dX,
+                       int lddx) {
+    GemmArgs g{}; g.A = dY; g.lda = N; g.B = W + (size_t)row0 * N; g.ldb = N; g.C = dX; g.ldc = lddx; g.M = (int)M; g.N = K; g.K = N; g.mask = mask; g.ldmask = ldmask;
+    g.accumulate = accumulate;
+    launch_gemm<true, true>(st, g, 1);
+}
+// dW = X^T . dY and db = column sums of dY, both through partial sums added up in a fixed order
+int dense_backward_dw(ntx_trainer *t, hipStream_t st, const float *X, int ldx, int K, const float *dY, int N, long long M, float *dW, float *db) {
+    const size_t need = (size_t)SPLIT * K * N;
+    if (need > t->partial_floats) return ntx_set_error(NTX_E_INVALID, "trainer: partial buffer too small");
+    GemmArgs g{}; g.A = X; g.lda = ldx; g.B = dY; g.ldb = N; g.C = t->partial; g.ldc = N; g.M = K; g.N = N; g.K = (int)M; g.split_stride = (long long)K * N;
+    launch_gemm<false, false>(st, g, SPLIT);
+    {
+        const int chunk = (((int)M + SPLIT - 1) / SPLIT + TK - 1) / TK * TK, parts = ((int)M + chunk - 1) / chunk;
+        const long long count = (long long)K * N;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, t->partial, parts, count, count, dW);
+    }
+    {
+        const int blocks = (int)((M + HEAD_ROWS - 1) / HEAD_ROWS);
+        if ((size_t)blocks * N > t->partial_floats) return ntx_set_error(NTX_E_INVALID, "trainer: partial buffer too small");
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), 0, st, dY, N, M, N, HEAD_ROWS, t->partial);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, t->partial, blocks, (long long)N, (long long)N, db);
+    }
+    return NTX_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+int ntx_sample_depths(const float *t, int64_t n_rays, int n_points, uint32_t flags, uint64_t perturb_seed, const ntx_render_opts *opts, float *z_out,
+                      ntx_stream stream);
+
+int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t n_floats, int device, int64_t max_rays, int max_samples_per_ray, ntx_trainer **out) {
+    if (!out) return ntx_set_error(NTX_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!desc || !weights) return ntx_set_error(NTX_E_INVALID, "desc / weights is NULL");
+    if (desc->kind != NTX_MODEL_PARAMNERF || desc->depth != 8 || desc->width != 256 || desc->skip != 4 || desc->color_depth != 1 || desc->n_pos != 3 ||
+        desc->pos_encoding != NTX_POS_FOURIER)
+        return ntx_set_error(NTX_E_UNSUPPORTED, "training is built for the ParamNerf architecture of the shipped training configs (depth 8, width 256, skips [4], color_depth 1, "
+                                                "Fourier features); others render but do not train");
+    if (desc->n_geo < 0 || desc->n_app < 0 || desc->n_geo + desc->n_app > 16) return ntx_set_error(NTX_E_INVALID, "n_parameters out of range");
+    if (max_rays < 1 || max_samples_per_ray < 2 || max_samples_per_ray > MAX_TRAIN_SAMPLES || max_rays * (int64_t)max_samples_per_ray > (int64_t)1 << 30)
+        return ntx_set_error(NTX_E_INVALID, "max_rays / max_samples_per_ray out of range (samples per ray <= %d)", MAX_TRAIN_SAMPLES);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ntx_set_error(NTX_E_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return ntx_set_error(NTX_E_INVALID, "device %d out of range [0,%d)", device, ndev);
+    ntx_trainer *t = new ntx_trainer();
+    t->device = device; t->desc = *desc;
+    t->P = desc->n_geo + desc->n_app;
+    t->Kp = 3 * (1 + 2 * desc->pos_freq) + desc->n_geo * (1 + 2 * desc->param_freq);
+    t->Kd = 3 * (1 + 2 * desc->dir_freq) + desc->n_app * (1 + 2 * desc->param_freq);
+    size_t p = 0;
+    auto take = [&](int in, int o) { TLayer l{in, o, p, p + (size_t)in * o}; p += (size_t)in * o + o; return l; };
+    int k = t->Kp;
+    for (int i = 0; i < 8; ++i) { t->trunk[i] = take(k, 256); k = 256 + (i == 4 ? t->Kp : 0); }       // model.py:104-108
+    t->feature = take(256, 256); t->c1 = take(256 + t->Kd, 256); t->c2 = take(256, 128); t->rgb = take(128, 3); t->alpha = take(256, 1);   // Keras order: alpha last
+    t->n_weights = p;
+    if (n_floats != p) { delete t; return ntx_set_error(NTX_E_INVALID, "weights: %zu floats, the model has %zu", n_floats, p); }
+    const long long M = (long long)max_rays * max_samples_per_ray;
+    t->cap = M; t->cap_rays = max_rays;
+    auto alloc = [&](float **d, size_t n) -> int { TRAIN_TRY(hipMalloc((void **)d, (n ? n : 1) * sizeof(float))); return NTX_OK; };
+    int rc = hipSetDevice(device) == hipSuccess ? NTX_OK : ntx_set_error(NTX_E_HIP, "hipSetDevice(%d) failed", device);
+    if (rc == NTX_OK) rc = alloc(&t->w, p);
+    if (rc == NTX_OK) rc = alloc(&t->grad, p);
+    if (rc == NTX_OK) rc = alloc(&t->adam_m, p);
+    if (rc == NTX_OK) rc = alloc(&t->adam_v, p);
+    if (rc == NTX_OK) rc = alloc(&t->h4c, (size_t)M * (t->Kp + 256));
+    if (rc == NTX_OK) rc = alloc(&t->fc, (size_t)M * (t->Kd + 256));
+    for (int i = 0; i < 8 && rc == NTX_OK; ++i)
+        if (i != 4) rc = alloc(&t->h[i], (size_t)M * 256);
+    if (rc == NTX_OK) rc = alloc(&t->c1o, (size_t)M * 256);
+    if (rc == NTX_OK) rc = alloc(&t->c2o, (size_t)M * 128);
+    if (rc == NTX_OK) rc = alloc(&t->raw_rgb, (size_t)M * 3);
+    if (rc == NTX_OK) rc = alloc(&t->sigma, (size_t)M);
+    if (rc == NTX_OK) rc = alloc(&t->z, (size_t)M);
+    if (rc == NTX_OK) rc = alloc(&t->dists, (size_t)M);
+    if (rc == NTX_OK) rc = alloc(&t->g0, (size_t)M * 256);
+    if (rc == NTX_OK) rc = alloc(&t->g1, (size_t)M * 256);
+    if (rc == NTX_OK) rc = alloc(&t->d_raw, (size_t)M * 3);
+    if (rc == NTX_OK) rc = alloc(&t->d_sigma, (size_t)M);
+    t->partial_floats = (size_t)SPLIT * (256 + (t->Kd > t->Kp ? t->Kd : t->Kp)) * 256;
+    {
+        const size_t head = (size_t)((M + HEAD_ROWS - 1) / HEAD_ROWS) * 256 * 3;
+        if (head > t->partial_floats) t->partial_floats = head;
+    }
+    if (rc == NTX_OK) rc = alloc(&t->partial, t->partial_floats);
+    if (rc == NTX_OK) rc = alloc(&t->color, (size_t)max_rays * 3);
+    if (rc == NTX_OK) rc = alloc(&t->alpha_out, (size_t)max_rays);
+    if (rc == NTX_OK) rc = alloc(&t->d_color, (size_t)max_rays * 3);
+    if (rc == NTX_OK) rc = alloc(&t->d_alpha, (size_t)max_rays);
+    if (rc == NTX_OK) rc = alloc(&t->loss, 1);
+    if (rc == NTX_OK && hipMemcpy(t->w, weights, p * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = ntx_set_error(NTX_E_HIP, "weight upload failed");
+    if (rc == NTX_OK && (hipMemset(t->adam_m, 0, p * sizeof(float)) != hipSuccess || hipMemset(t->adam_v, 0, p * sizeof(float)) != hipSuccess || hipMemset(t->grad, 0, p * sizeof(float)) != hipSuccess))
+        rc = ntx_set_error(NTX_E_HIP, "hipMemset failed");
+    if (rc != NTX_OK) { free_all(t); return rc; }
+    t->h[4] = t->h4c + t->Kp;                     // trunk layer 4 writes behind the position features: [pos_map | h4] is the skip's concat (model.py:108)
+    *out = t;
+    return NTX_OK;
+}
+
+int ntx_trainer_destroy(ntx_trainer *t) { free_all(t); return NTX_OK; }
+
+size_t ntx_trainer_weight_count(const ntx_trainer *t) { return t ? t->n_weights : 0; }
+
+int ntx_trainer_get(ntx_trainer *t, int what, float *out_host, size_t n_floats) {
+    if (!t || !out_host) return ntx_set_error(NTX_E_INVALID, "NULL argument");
+    if (n_floats != t->n_weights) return ntx_set_error(NTX_E_INVALID, "%zu floats asked, the model has %zu", n_floats, t->n_weights);
+    const float *src = what == NTX_TRAINER_WEIGHTS ? t->w : what == NTX_TRAINER_GRADIENTS ? t->grad : what == NTX_TRAINER_ADAM_M ? t->adam_m : what == NTX_TRAINER_ADAM_V ? t->adam_v : nullptr;
+    if (!src) return ntx_set_error(NTX_E_INVALID, "what = %d", what);
+    TRAIN_TRY(hipSetDevice(t->device));
+    TRAIN_TRY(hipDeviceSynchronize());
+    TRAIN_TRY(hipMemcpy(out_host, src, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return NTX_OK;
+}
+
+int ntx_trainer_activation(ntx_trainer *t, int layer, int64_t n_samples_total, float *out_host) {
+    if (!t || !out_host) return ntx_set_error(NTX_E_INVALID, "NULL argument");
+    if (n_samples_total < 1 || n_samples_total > t->cap) return ntx_set_error(NTX_E_INVALID, "n_samples_total out of range");
+    const float *src = nullptr; int ld = 256, width = 256;
+    if (layer >= 0 && layer < 8) { src = t->h[layer]; ld = layer == 4 ? t->Kp + 256 : 256; }
+    else if (layer == 8) src = t->c1o;
+    else if (layer == 9) { src = t->c2o; ld = 128; width = 128; }
+    else if (layer == 10) { src = t->sigma; ld = 1; width = 1; }
+    else return ntx_set_error(NTX_E_INVALID, "layer %d (0-7 trunk, 8 / 9 the colour layers, 10 the density)", layer);
+    TRAIN_TRY(hipSetDevice(t->device));
+    TRAIN_TRY(hipDeviceSynchronize());
+    TRAIN_TRY(hipMemcpy2D(out_host, (size_t)width * sizeof(float), src, (size_t)ld * sizeof(float), (size_t)width * sizeof(float), (size_t)n_samples_total, hipMemcpyDeviceToHost));
+    return NTX_OK;
+}
+
+int ntx_trainer_set_weights(ntx_trainer *t, const float *weights_host, size_t n_floats) {
+    if (!t || !weights_host) return ntx_set_error(NTX_E_INVALID, "NULL argument");
+    if (n_floats != t->n_weights) return ntx_set_error(NTX_E_INVALID, "%zu floats given, the model has %zu", n_floats, t->n_weights);
+    TRAIN_TRY(hipSetDevice(t->device));
+    TRAIN_TRY(hipMemcpy(t->w, weights_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    return NTX_OK;
+}
+
+int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *rays_d, const float *tnear_far, const float *params, int64_t rays_per_param_row,
+                             const float *cone_scale, int64_t n_rays, int n_samples, int blur_idx, uint32_t flags, const float *bkgd, uint64_t perturb_seed,
+                             const ntx_render_opts *opts, const float *z_vals, const float *color_true, const float *alpha_true, const ntx_loss_desc *loss,
+                             float *color_pred, float *alpha_pred, float *loss_out, ntx_stream stream) {
+    if (!t) return ntx_set_error(NTX_E_INVALID, "trainer is NULL");
+    if (!rays_o || !rays_d || (!tnear_far && !z_vals) || !color_true || !loss || (t->P > 0 && !params)) return ntx_set_error(NTX_E_INVALID, "NULL buffer");
+    if (n_rays < 1 || n_rays > t->cap_rays || n_samples < 2 || (long long)n_rays * n_samples > t->cap) return ntx_set_error(NTX_E_INVALID, "n_rays x n_samples beyond what the trainer was created for");
+    if (n_samples > MAX_TRAIN_SAMPLES) return ntx_set_error(NTX_E_INVALID, "n_samples > %d", MAX_TRAIN_SAMPLES);
+    if (blur_idx >= t->P || (blur_idx >= 0 && !cone_scale)) return ntx_set_error(NTX_E_INVALID, "bad blur_idx / cone_scale");
+    if (loss->size < sizeof(ntx_loss_desc) || (loss->kind != NTX_LOSS_NERF && loss->kind != NTX_LOSS_ALPHA) || (loss->loss_fn != NTX_LOSS_MSE && loss->loss_fn != NTX_LOSS_SMAPE) ||
+        (loss->alpha_loss_fn != NTX_LOSS_MSE && loss->alpha_loss_fn != NTX_LOSS_SMAPE))
+        return ntx_set_error(NTX_E_INVALID, "bad ntx_loss_desc");
+    if (loss->kind == NTX_LOSS_ALPHA && !alpha_true) return ntx_set_error(NTX_E_INVALID, "AlphaLoss needs alpha_true");
+    if (rays_per_param_row < 1) rays_per_param_row = 1;
+    TRAIN_TRY(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long long M = (long long)n_rays * n_samples;
+    const int S = n_samples, Kp = t->Kp, Kd = t->Kd, ldp = Kp + 256, ldd = Kd + 256;
+    const float *W = t->w;
+    // ---- forward, every activation kept ----------------------------------------------------------------------------------------
+    const float *z = z_vals;
+    if (!z) {
+        int rc = ntx_sample_depths(tnear_far, n_rays, S, flags & NTX_FLAG_PERTURB, perturb_seed, opts, t->z, stream);     // renderer.py:101-111
+        if (rc != NTX_OK) return rc;
+        z = t->z;
+    }
+    {
+        EncodeArgs e{}; e.rays_o = rays_o; e.rays_d = rays_d; e.z = z; e.params = params; e.cone = cone_scale; e.rays_per_param_row = rays_per_param_row;
+        e.n_rays = (int)n_rays; e.S = S; e.n_geo = t->desc.n_geo; e.n_app = t->desc.n_app; e.pos_freq = t->desc.pos_freq; e.dir_freq = t->desc.dir_freq;
+        e.param_freq = t->desc.param_freq; e.blur_idx = blur_idx; e.pos_out = t->h4c; e.ld_pos = ldp; e.dir_out = t->fc; e.ld_dir = ldd; e.dists = t->dists;
+        hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, e);
+    }
+    for (int i = 0; i < 8; ++i) {                                                               // model.py:104-108
+        const TLayer &l = t->trunk[i];
+        const float *X = (i == 0 || i == 5) ? t->h4c : t->h[i - 1];
+        const int ldx = (i == 0 || i == 5) ? ldp : (i - 1 == 4 ? ldp : 256);
+        dense_forward(st, X, ldx, l.in, W + l.w, W + l.b, 256, M, t->h[i], i == 4 ? ldp : 256, 1);
+    }
+    hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, t->h[7], 256, 256, W + t->alpha.w, W + t->alpha.b, 1, M, t->sigma);   // :111
+    dense_forward(st, t->h[7], 256, 256, W + t->feature.w, W + t->feature.b, 256, M, t->fc + Kd, ldd, 0);                                  // :114-115
+    dense_forward(st, t->fc, ldd, Kd + 256, W + t->c1.w, W + t->c1.b, 256, M, t->c1o, 256, 1);                                             // :118-119
+    dense_forward(st, t->c1o, 256, 256, W + t->c2.w, W + t->c2.b, 128, M, t->c2o, 128, 1);                                                 // :122
+    hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, t->c2o, 128, 128, W + t->rgb.w, W + t->rgb.b, 3, M, t->raw_rgb);   // :123
+    CompositeArgs c{};
+    c.raw_rgb = t->raw_rgb; c.sigma = t->sigma; c.dists = t->dists; c.n_rays = (int)n_rays; c.S = S; c.map_exr = (flags & NTX_FLAG_MAP_EXR) ? 1 : 0;
+    c.composite_bkgd = (flags & NTX_FLAG_COMPOSITE_BKGD) ? 1 : 0;
+    for (int k = 0; k < 3; ++k) c.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
+    c.color = t->color; c.alpha = t->alpha_out; c.d_color = t->d_color; c.d_alpha = t->d_alpha; c.d_raw_rgb = t->d_raw; c.d_sigma = t->d_sigma;
+    hipLaunchKernelGGL(composite_kernel<false>, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st, c);
+    // ---- loss (loss.py) -----------------------------------------------------------------------------------------------------------
+    {
+        LossArgs a{}; a.color_true = color_true; a.alpha_true = alpha_true; a.color_pred = t->color; a.alpha_pred = t->alpha_out; a.n_rays = (int)n_rays;
+        a.kind = loss->kind; a.loss_fn = loss->loss_fn; a.alpha_loss_fn = loss->alpha_loss_fn; a.filter_color_loss = loss->filter_color_loss; a.use_hard_mask = loss->use_hard_mask;
+        a.gamma = loss->gamma; a.loss = t->loss; a.d_color = t->d_color; a.d_alpha = t->d_alpha;
+        hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, st, a);
+    }
+    // ---- backward -----------------------------------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st, c);
+    float *G = t->grad;
+    const int hb = (int)((M + HEAD_ROWS - 1) / HEAD_ROWS);
+    auto head_dw = [&](const float *X, int ldx, int K, const float *dY, int n_out, const TLayer &l) {
+        hipLaunchKernelGGL(head_backward_dw_partial_kernel, dim3(hb), dim3(256), 0, st, X, ldx, K, dY, n_out, M, HEAD_ROWS, t->partial);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((K * n_out + 255) / 256), dim3(256), 0, st, t->partial, hb, (long long)K * n_out, (long long)K * n_out, G + l.w);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(hb), dim3(256), 0, st, dY, n_out, M, n_out, HEAD_ROWS, t->partial);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, t->partial, hb, (long long)n_out, (long long)n_out, G + l.b);
+    };
+    // color head (128 -> 3): dW, db; d c2o = (d_raw . W^T) where c2o > 0
+    head_dw(t->c2o, 128, 128, t->d_raw, 3, t->rgb);
+    hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, st, t->d_raw, 3, W + t->rgb.w, 128, M, t->c2o, 128, 0, t->g0, 128);
+    int rc = dense_backward_dw(t, st, t->c1o, 256, 256, t->g0, 128, M, G + t->c2.w, G + t->c2.b);
+    if (rc != NTX_OK) return rc;
+    dense_backward_dx(st, t->g0, 128, W + t->c2.w, 0, 256, M, t->c1o, 256, 0, t->g1, 256);              // d c1o, masked by its ReLU
+    rc = dense_backward_dw(t, st, t->fc, ldd, Kd + 256, t->g1, 256, M, G + t->c1.w, G + t->c1.b);
+    if (rc != NTX_OK) return rc;
+    dense_backward_dx(st, t->g1, 256, W + t->c1.w, Kd, 256, M, nullptr, 0, 0, t->g0, 256);              // d feature (linear layer: no mask)
+    rc = dense_backward_dw(t, st, t->h[7], 256, 256, t->g0, 256, M, G + t->feature.w, G + t->feature.b);
+    if (rc != NTX_OK) return rc;
+    head_dw(t->h[7], 256, 256, t->d_sigma, 1, t->alpha);
+    // d h7 = d_sigma (x) W_alpha + d feature . W_feature^T, masked by h7's ReLU
+    hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 256 + 255) / 256)), dim3(256), 0, st, t->d_sigma, 1, W + t->alpha.w, 256, M, nullptr, 0, 0, t->g1, 256);
+    dense_backward_dx(st, t->g0, 256, W + t->feature.w, 0, 256, M, t->h[7], 256, 1, t->g1, 256);
+    float *cur = t->g1, *nxt = t->g0;
+    for (int i = 7; i >= 0; --i) {
+        const TLayer &l = t->trunk[i];
+        const float *X = (i == 0 || i == 5) ? t->h4c : t->h[i - 1];
+        const int ldx = (i == 0 || i == 5) ? ldp : (i - 1 == 4 ? ldp : 256);
+        rc = dense_backward_dw(t, st, X, ldx, l.in, cur, 256, M, G + l.w, G + l.b);
+        if (rc != NTX_OK) return rc;
+        if (i == 0) break;
+        const int row0 = i == 5 ? Kp : 0;                                                           // the skip's position rows take no gradient further
+        dense_backward_dx(st, cur, 256, W + l.w, row0, 256, M, t->h[i - 1], (i - 1 == 4) ? ldp : 256, 0, nxt, 256);
+        float *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (color_pred) TRAIN_TRY(hipMemcpyAsync(color_pred, t->color, (size_t)n_rays * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (alpha_pred) TRAIN_TRY(hipMemcpyAsync(alpha_pred, t->alpha_out, (size_t)n_rays * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (loss_out) TRAIN_TRY(hipMemcpyAsync(loss_out, t->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
+    TRAIN_TRY(hipGetLastError());
+    return NTX_OK;
+}
+
+int ntx_trainer_adam_step(ntx_trainer *t, float lrate, float lrate_decay_steps, float lrate_decay_rate, float beta_1, float beta_2, float epsilon, ntx_stream stream) {
+    if (!t) return ntx_set_error(NTX_E_INVALID, "trainer is NULL");
+    TRAIN_TRY(hipSetDevice(t->device));
+    const double step = (double)t->adam_iterations;
+    double lr = lrate;
+    if (lrate_decay_steps > 0) lr = (double)lrate * std::pow((double)lrate_decay_rate, step / (double)lrate_decay_steps);      // ExponentialDecay, staircase off
+    const double tt = step + 1.0;
+    const float lr_t = (float)((double)(float)lr * std::sqrt(1.0 - std::pow((double)beta_2, tt)) / (1.0 - std::pow((double)beta_1, tt)));
+    hipLaunchKernelGGL(ntx_train::adam_kernel, dim3((unsigned)((t->n_weights + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t->w, t->grad, t->adam_m, t->adam_v,
+                       (long long)t->n_weights, lr_t, beta_1, beta_2, epsilon);
+    t->adam_iterations += 1;
+    TRAIN_TRY(hipGetLastError());
+    return NTX_OK;
+}
+
+int64_t ntx_trainer_iterations(const ntx_trainer *t) { return t ? t->adam_iterations : -1; }
+
+/* The contraction the trainer is made of, on caller buffers (DEVICE): C[M][N] = op(A) . op(B) (+ bias) (ReLU), op = identity or transpose as
+ * a_kcontig / b_kcontig say (see gemm_kernel).  For tests and benches of the kernel itself. */
+int ntx_gemm_f32(const float *A, int lda, int a_kcontig, const float *B, int ldb, int b_kcontig, float *C, int ldc, int M, int N, int K, const float *bias, int relu,
+                 ntx_stream stream) {
+    if (!A || !B || !C || M < 1 || N < 1 || K < 1) return ntx_set_error(NTX_E_INVALID, "bad GEMM arguments");
+    ntx_train::GemmArgs g{}; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu;
+    hipStream_t st = (hipStream_t)stream;
+    if (a_kcontig && !b_kcontig) launch_gemm<true, false>(st, g, 1);
+    else if (a_kcontig && b_kcontig) launch_gemm<true, true>(st, g, 1);
+    else if (!a_kcontig && !b_kcontig) launch_gemm<false, false>(st, g, 1);
+    else return ntx_set_error(NTX_E_UNSUPPORTED, "A transposed with B transposed is not built");
+    TRAIN_TRY(hipGetLastError());
+    return NTX_OK;
+}
+
+}   // extern "C"

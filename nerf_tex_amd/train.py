@@ -1,0 +1,114 @@
+"""The training step of the reference on the GPU (network/train.py:49-70): `Trainer` owns the weights, Adam's state and every layer's
+activations behind the C ABI (`ntx_trainer_*`, include/nerftex.h); `step(...)` is the body of the reference's loop -- forward under a
+tape, loss, gradients, `optimizer.apply_gradients`.
+
+    trainer = Trainer(model, max_rays=1024, n_samples=256, lrate=5e-4, lrate_decay=500)       # config_carpet_train.py:100-109
+    loss = trainer.step(rays_o, rays_d, t, parameters, cone_scale, color, alpha, loss_fn)      # one iteration of train.py:61-67
+
+Built for the ParamNerf architecture of the shipped training configs (8 x 256, skips [4], color_depth 1).  The data side of training
+(TFRecord datasets, logging, checkpoints: train.py:20-58, dataset.py) stays out of scope: SURVEY section 2."""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+from . import _lib
+
+
+class Trainer:
+    def __init__(self, model, max_rays: int, n_samples: int, lrate: float = 5e-4, lrate_decay: float = 0, perturb: bool = True, blur_idx: Optional[int] = None,
+                 map_exr: bool = False, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7, device: int = 0) -> None:
+        """`model`: a nerf_tex_amd.model.ParamNerf container (its blob gives the initial weights); `lrate`, `lrate_decay` as train.py:49-50
+        (ExponentialDecay(lrate, decay_steps=lrate_decay * 1e3, decay_rate=0.1) when lrate_decay > 0); `perturb`, `blur_idx`, `map_exr`: the
+        renderer's (renderer.py:34)."""
+        import numpy as np
+        self.model = model
+        self.device = int(device)
+        self.n_samples, self.max_rays = int(n_samples), int(max_rays)
+        self.lrate, self.lrate_decay = float(lrate), float(lrate_decay)
+        self.perturb, self.blur_idx, self.map_exr = bool(perturb), blur_idx, bool(map_exr)
+        self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
+        blob = np.ascontiguousarray(model.get_blob(), dtype=np.float32)
+        self._h = C.c_void_p()
+        desc = model.desc()
+        _lib.check(_lib.lib.ntx_trainer_create(C.byref(desc), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, self.device, self.max_rays,
+                                               self.n_samples, C.byref(self._h)))
+        self.n_weights = int(_lib.lib.ntx_trainer_weight_count(self._h))
+        self._calls = 0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and _lib is not None and getattr(_lib, "lib", None) is not None:
+            _lib.lib.ntx_trainer_destroy(h)
+            self._h = None
+
+    def _vector(self, what: int):
+        import numpy as np
+        out = np.empty(self.n_weights, np.float32)
+        _lib.check(_lib.lib.ntx_trainer_get(self._h, what, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
+    def weights(self):
+        """The weights as one float32 vector in `get_weights()` order (hand it to `model.set_blob` to render with them)."""
+        return self._vector(_lib.TRAINER_WEIGHTS)
+
+    def gradients(self):
+        return self._vector(_lib.TRAINER_GRADIENTS)
+
+    def adam_state(self):
+        return self._vector(_lib.TRAINER_ADAM_M), self._vector(_lib.TRAINER_ADAM_V)
+
+    def activation(self, layer: int, n_samples_total: int):
+        """What the last step kept of layer 0-7 (trunk), 8 / 9 (colour layers), 10 (raw density): [n_samples_total, width] float32 (tests)."""
+        import numpy as np
+        width = 256 if layer < 9 else (128 if layer == 9 else 1)
+        out = np.empty((int(n_samples_total), width), np.float32)
+        _lib.check(_lib.lib.ntx_trainer_activation(self._h, int(layer), int(n_samples_total), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def set_weights(self, blob) -> None:
+        import numpy as np
+        b = np.ascontiguousarray(blob, dtype=np.float32).reshape(-1)
+        _lib.check(_lib.lib.ntx_trainer_set_weights(self._h, b.ctypes.data_as(C.POINTER(C.c_float)), b.size))
+
+    @property
+    def iterations(self) -> int:
+        return int(_lib.lib.ntx_trainer_iterations(self._h))
+
+    def gradients_step(self, rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, loss, composite_bkgd: bool = False, bkgd_color=(1., 1., 1.),
+                       seed: Optional[int] = None, z_vals=None, rays_per_param_row: int = 1):
+        """Forward + loss + gradients (train.py:61-66) for rays that all hit the proxy: rays_o / rays_d [N,3], t [N,2], parameters [rows,P],
+        cone_scale [N] or [N,1], color_true [N,3], alpha_true [N]; `loss`: a nerf_tex_amd.loss object.  Returns (loss [1], color_pred [N,3],
+        alpha_pred [N]) as GPU tensors; the gradients stay in the trainer."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        to = lambda a: None if a is None else (a if isinstance(a, torch.Tensor) else torch.as_tensor(a)).to(device=dev, dtype=torch.float32).contiguous()
+        rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, z_vals = (to(a) for a in (rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, z_vals))
+        n = rays_o.reshape(-1, 3).shape[0]
+        flags = (_lib.FLAG_PERTURB if self.perturb else 0) | (_lib.FLAG_MAP_EXR if self.map_exr else 0) | (_lib.FLAG_COMPOSITE_BKGD if composite_bkgd else 0)
+        if seed is None:
+            seed = self._calls
+        self._calls += 1
+        color = torch.empty((n, 3), device=dev); alpha = torch.empty((n,), device=dev); val = torch.empty((1,), device=dev)
+        desc = loss.desc()
+        ptr = lambda x: x.data_ptr() if x is not None and x.numel() else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.ntx_train_step_gradients(
+                self._h, ptr(rays_o), ptr(rays_d), ptr(t), ptr(parameters), int(rays_per_param_row), ptr(cone_scale), n, self.n_samples,
+                -1 if self.blur_idx is None else int(self.blur_idx), flags, _lib.f3(bkgd_color), int(seed) & (2 ** 64 - 1), None, ptr(z_vals), ptr(color_true), ptr(alpha_true),
+                C.byref(desc), ptr(color), ptr(alpha), ptr(val), torch.cuda.current_stream(dev).cuda_stream))
+        return val, color, alpha
+
+    def apply_gradients(self) -> None:
+        """optimizer.apply_gradients (train.py:67): Adam under the learning-rate schedule of train.py:49-52."""
+        import torch
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib.ntx_trainer_adam_step(self._h, self.lrate, self.lrate_decay * 1e3 if self.lrate_decay > 0 else 0.0, 0.1, self.beta_1, self.beta_2,
+                                                      self.epsilon, torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream))
+
+    def step(self, *args, **kwargs):
+        """One iteration of the reference's loop (train.py:61-67); returns the loss (a GPU tensor)."""
+        val, _, _ = self.gradients_step(*args, **kwargs)
+        self.apply_gradients()
+        return val

@@ -73,6 +73,8 @@ _REMAP = {
     "network.dataset.Dataset": "nerf_tex_amd.dataset.Dataset",
     "network.dataset.GenerateData": "nerf_tex_amd.dataset.GenerateData",
     "instancer.instancer.Instancer": "nerf_tex_amd.instancer.Instancer",
+    "network.loss.NerfLoss": "nerf_tex_amd.loss.NerfLoss",
+    "network.loss.AlphaLoss": "nerf_tex_amd.loss.AlphaLoss",
 }
 
 

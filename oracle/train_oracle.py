@@ -1,0 +1,129 @@
+"""One training step of the reference restated on the CPU: network/train.py:61-67 over network/renderer.py:92-213 and network/loss.py:6-59,
+with torch autograd in FLOAT64 standing in for tf.GradientTape, and TF 2.4's Adam + ExponentialDecay (train.py:49-52) written out.
+
+TEST INFRASTRUCTURE ONLY (the rules of nerftex_oracle.py: nothing under nerf_tex_amd/ imports it).  PARITY UNPINNED: TensorFlow cannot
+run here and the reference ships no gradients; the forward pass is torch_cpu.py's (checked against nerftex_oracle.py in
+tests/test_oracle.py), the gradients are whatever autograd derives from it -- no hand-written adjoint on this side, which is the point:
+the kernels' hand-written backward pass is compared with it."""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import torch_cpu
+
+
+def mse(y_true, y_pred):                                                                  # loss.py:51-54
+    return torch.mean((y_true - y_pred) ** 2)
+
+
+def smape(y_true, y_pred, eps=1e-2):                                                      # loss.py:56-59
+    return torch.mean(torch.abs(y_true - y_pred) / (y_true + y_pred + eps))
+
+
+LOSS_FNS = {"mse": mse, "smape": smape}
+
+
+def nerf_loss(color_true, color_pred, loss_fn="mse"):                                    # loss.py:6-19 (no coarse pass)
+    return LOSS_FNS[loss_fn](color_true, color_pred)
+
+
+def alpha_loss(color_true, alpha_true, color_pred, alpha_pred, loss_fn="mse", alpha_loss_fn=None, gamma=1.0, filter_color_loss=True, use_hard_mask=True):
+    """loss.py:21-49 (no coarse pass)."""
+    fn, afn = LOSS_FNS[loss_fn], LOSS_FNS[alpha_loss_fn or loss_fn]
+    if filter_color_loss:
+        mask = (alpha_true[..., None] > 0).to(color_true.dtype) if use_hard_mask else alpha_true[..., None]
+        color_true = color_true * mask
+        color_pred = color_pred * mask
+    return fn(color_true, color_pred) + gamma * afn(alpha_true, alpha_pred)
+
+
+def model_forward_masked(w, spec, pos, dirs, params, masks):
+    """torch_cpu.model_forward with every ReLU replaced by a GIVEN 0/1 pattern (`masks`: trunk 0..depth-1, then the colour layers): the
+    network as a float32 forward pass branched it.  A pre-activation within float32 rounding of zero falls on either side of its ReLU
+    depending on summation order; autograd through this function follows the pattern it is handed instead of float64's own."""
+    ff = torch_cpu.fourier_features
+    g, a = spec.n_geo, spec.n_app
+    pos_map = ff(pos, spec.pos_freq); dir_map = ff(dirs, spec.dir_freq)
+    if g > 0:
+        pos_map = torch.cat([pos_map, ff(params[:, :g], spec.param_freq)], -1)
+    if a > 0:
+        dir_map = torch.cat([dir_map, ff(params[:, g:g + a], spec.param_freq)], -1)
+    it = iter(range(0, len(w) - 2, 2)); mk = iter(masks)
+    h = pos_map
+    for i in range(spec.depth):
+        j = next(it)
+        h = torch.addmm(w[j + 1], h, w[j]) * next(mk)
+        if i in spec.skips:
+            h = torch.cat([pos_map, h], -1)
+    alpha = torch.addmm(w[-1], h, w[-2])
+    j = next(it)
+    h = torch.cat([dir_map, torch.addmm(w[j + 1], h, w[j])], -1)
+    for _ in range(spec.color_depth):
+        j = next(it)
+        h = torch.addmm(w[j + 1], h, w[j]) * next(mk)
+    j = next(it)
+    h = torch.addmm(w[j + 1], h, w[j]) * next(mk)
+    j = next(it)
+    return torch.addmm(w[j + 1], h, w[j]), alpha
+
+
+def render(w, spec, rays_o, rays_d, z, parameters, cone_scale, blur_idx=None, map_exr=False, composite_bkgd=False, bkgd=(1., 1., 1.), masks=None,
+           sigma_mask=None):
+    """Renderer.render_rays on given sample depths z [n, S] (renderer.py:114-213; the depths themselves, :101-111, are the caller's:
+    with perturb they come from the product's restated generator, nerftex_oracle.sample_depths)."""
+    n, S = z.shape
+    rays_d_n = rays_d / torch.linalg.norm(rays_d, dim=-1, keepdim=True)
+    pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]
+    pos = pts.reshape(-1, 3)
+    dirs = rays_d_n.repeat_interleave(S, 0)
+    params = parameters.repeat_interleave(S, 0)
+    if blur_idx is not None:
+        scale = (cone_scale.reshape(n, 1, 1) * z[:, :, None]).reshape(-1, 1)
+        params = torch.cat([params[:, :blur_idx], params[:, blur_idx, None] * scale, params[:, blur_idx + 1:]], -1)
+    if masks is None:
+        color, alpha = torch_cpu.model_forward(w, spec, pos, dirs, params)
+    else:
+        color, alpha = model_forward_masked(w, spec, pos, dirs, params, masks)
+    color = color.reshape(n, S, 3); alpha = alpha.reshape(n, S)
+    dists = z[:, 1:] - z[:, :-1]
+    dists = torch.cat([dists, dists[:, -1:]], -1) * torch.linalg.norm(rays_d, dim=-1, keepdim=True)
+    rgb = torch.nn.functional.elu(color) + 1 if map_exr else torch.sigmoid(color)
+    am = 1. - torch.exp(-(torch.relu(alpha) if sigma_mask is None else alpha * sigma_mask) * dists)
+    trans = torch.cumprod(1. - am + 1e-10, -1)
+    wts = am * torch.cat([torch.ones_like(trans[:, :1]), trans[:, :-1]], -1)
+    c = torch.sum(wts[..., None] * rgb, -2); a = torch.sum(wts, -1)
+    if composite_bkgd:
+        c = c + (1. - a[..., None]) * torch.as_tensor(bkgd, dtype=c.dtype)
+    return c, a
+
+
+def step_gradients(w_np, spec, rays_o, rays_d, z, parameters, cone_scale, color_true, alpha_true, loss, blur_idx=None, map_exr=False,
+                   composite_bkgd=False, bkgd=(1., 1., 1.), dtype=torch.float64, masks=None, sigma_mask=None):
+    """(loss, color_pred, alpha_pred, gradients in get_weights() order as a list of arrays) of one step; `loss` = dict(kind='nerf'|'alpha', **kwargs).
+    `masks` / `sigma_mask`: the ReLU patterns of a float32 forward pass (model_forward_masked), as 0/1 arrays."""
+    w = [torch.tensor(np.asarray(a), dtype=dtype, requires_grad=True) for a in w_np]
+    t_ = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=dtype)
+    mk = None if masks is None else [t_(m) for m in masks]
+    c, a = render(w, spec, t_(rays_o), t_(rays_d), t_(z), t_(parameters), t_(cone_scale), blur_idx, map_exr, composite_bkgd, bkgd, mk,
+                  None if sigma_mask is None else t_(sigma_mask))
+    kw = {k: v for k, v in loss.items() if k != "kind"}
+    val = nerf_loss(t_(color_true), c, **kw) if loss["kind"] == "nerf" else alpha_loss(t_(color_true), t_(alpha_true), c, a, **kw)
+    val.backward()
+    return float(val.detach()), c.detach().numpy(), a.detach().numpy(), [x.grad.numpy() for x in w]
+
+
+def adam_step(w, g, m, v, iterations, lrate, decay_steps=0.0, decay_rate=0.1, beta_1=0.9, beta_2=0.999, epsilon=1e-7, dtype=np.float64):
+    """tf.keras.optimizers.Adam (TF 2.4 ApplyAdam, non-amsgrad) under ExponentialDecay (train.py:49-52): flat arrays in, (w, m, v) out."""
+    w, g, m, v = (np.asarray(x, dtype) for x in (w, g, m, v))
+    lr = lrate * decay_rate ** (iterations / decay_steps) if decay_steps > 0 else lrate
+    t = iterations + 1.0
+    # Keras holds beta_1 / beta_2 as float32 hyper-parameters and forms 1 - beta in float32 (optimizer_v2/adam.py: _prepare_local):
+    # 1 - 0.999f = 9.99987e-4, not 1e-3
+    b1, b2 = np.float32(beta_1), np.float32(beta_2)
+    omb1, omb2 = float(np.float32(1) - b1), float(np.float32(1) - b2)
+    lr_t = lr * np.sqrt(1.0 - float(b2) ** t) / (1.0 - float(b1) ** t)
+    m = m + (g - m) * omb1
+    v = v + (g * g - v) * omb2
+    return w - lr_t * m / (np.sqrt(v) + epsilon), m, v

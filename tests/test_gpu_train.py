@@ -1,0 +1,180 @@
+"""One training step on the GPU (`ntx_trainer_*`, ABI v5) against the reference's step restated with float64 autograd
+(oracle/train_oracle.py <- network/train.py:61-67, renderer.py:92-213, loss.py:6-59).  `-m gpu`.
+
+The bar of VERDICT r3 #6: the gradient of every layer within 1e-4 rel-Linf of float64 autograd on three model families, an optimiser
+step that is bit-reproducible, Adam against its restatement."""
+
+import numpy as np
+import pytest
+
+from oracle import nerftex_oracle as orc
+from oracle import train_oracle as tro
+from tests.common import make_model
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+F = np.float32
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def rel_linf(got, want):
+    return float(np.max(np.abs(np.asarray(got, np.float64) - want)) / max(np.max(np.abs(want)), 1e-300))
+
+
+@pytest.mark.parametrize("ak,bk,M,N,K", [(1, 0, 300, 200, 77), (1, 1, 257, 129, 256), (0, 0, 337, 256, 1000), (1, 0, 128, 128, 16), (0, 0, 72, 3, 5000), (1, 1, 4096, 256, 128)])
+def test_gemm_kernel_against_float64(ak, bk, M, N, K):
+    """The contraction the trainer is made of, in its three operand layouts, at sizes off the 128 x 128 x 16 tiles."""
+    import ctypes as C
+    from nerf_tex_amd import _lib
+    rng = np.random.default_rng(M + N + K)
+    A = rng.normal(size=(M, K) if ak else (K, M)).astype(F); B = rng.normal(size=(N, K) if bk else (K, N)).astype(F)
+    bias = rng.normal(size=N).astype(F)
+    want = (A.astype(np.float64) if ak else A.astype(np.float64).T) @ (B.astype(np.float64).T if bk else B.astype(np.float64)) + bias
+    want = np.maximum(want, 0)
+    dA, dB, db = (torch.as_tensor(x, device=dev()) for x in (A, B, bias))
+    out = torch.full((M, N + 3), 7.0, device=dev())                                # a wider row: ldc > N, the columns beyond stay untouched
+    with torch.cuda.device(dev()):
+        _lib.check(_lib.lib.ntx_gemm_f32(dA.data_ptr(), A.shape[1], ak, dB.data_ptr(), B.shape[1], bk, out.data_ptr(), N + 3, M, N, K, db.data_ptr(), 1,
+                                         torch.cuda.current_stream(dev()).cuda_stream))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert (got[:, N:] == 7).all()
+    assert rel_linf(got[:, :N], want) <= 2e-6 * np.sqrt(K)
+
+
+def batch(seed, n, S, P, fam):
+    """A training batch in the shape of config_carpet_train.py: rays from a few cameras through the family's box (all hit), per-image
+    parameters, targets."""
+    from nerf_tex_amd import synthetic
+    rng = np.random.default_rng(seed)
+    f = synthetic.FAMILIES[fam]
+    ro, rd, t, cone = synthetic.all_hit_rays(n, f["b_0"], f["b_1"], f["cam"])
+    params = np.tile(np.asarray([f["params"]], F), (n, 1))
+    params[:, :] *= rng.uniform(0.8, 1.2, size=(n, P)).astype(F)
+    color = rng.uniform(0, 1, size=(n, 3)).astype(F)
+    alpha = (rng.uniform(0, 1, size=n) > 0.3).astype(F) * rng.uniform(0.5, 1, size=n).astype(F)
+    return ro, rd, t, cone, params, color, alpha
+
+
+LOSSES = {"alpha_smape": (dict(kind="alpha", loss_fn="smape", alpha_loss_fn="mse"), dict(loss_fn="network.loss.smape", alpha_loss_fn="network.loss.mse")),
+          "alpha_mse_soft": (dict(kind="alpha", loss_fn="mse", gamma=0.5, use_hard_mask=False), dict(loss_fn="network.loss.mse", gamma=0.5, use_hard_mask=False)),
+          "nerf_mse": (dict(kind="nerf", loss_fn="mse"), dict(loss_fn="network.loss.mse"))}
+
+
+def make_loss(name):
+    from nerf_tex_amd import loss as L
+    okw, pkw = LOSSES[name]
+    return okw, (L.AlphaLoss(**pkw) if okw["kind"] == "alpha" else L.NerfLoss(**pkw))
+
+
+def layer_slices(spec):
+    out, p = [], 0
+    for name, i, o in orc.layer_table(spec):
+        out.append((name + ".kernel", slice(p, p + i * o))); p += i * o
+        out.append((name + ".bias", slice(p, p + o))); p += o
+    return out
+
+
+@pytest.mark.parametrize("fam,npar,blur,loss_name,bkgd", [("carpet", (1, 6), None, "alpha_smape", False), ("grass", (1, 4), None, "nerf_mse", True),
+                                                         ("grass_filtered", (2, 3), 0, "alpha_mse_soft", False)])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_gradients_match_float64_autograd(fam, npar, blur, loss_name, bkgd, perturb):
+    """dL/dW of all 13 layers (kernels and biases) after one forward + backward of the fused step, per layer within 1e-4 rel-Linf of float64
+    autograd through the restated renderer and loss; also the loss value and the predictions."""
+    from nerf_tex_amd.train import Trainer
+    model, spec, wts = make_model(npar, dense_media=True)
+    n, S, P = 96, 48, sum(npar)
+    ro, rd, t, cone, params, color, alpha = batch(3, n, S, P, fam)
+    okw, loss = make_loss(loss_name)
+    tr = Trainer(model, max_rays=n, n_samples=S, perturb=perturb, blur_idx=blur)
+    # the sample depths the kernel places itself (renderer.py:101-111; with perturb: the product's Philox jitter), restated for the oracle
+    z = orc.z_values_perturbed(t, S, 11, np.float32) if perturb else orc.z_values(t, S, np.float32)
+    val, cp, ap = tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss, composite_bkgd=bkgd, bkgd_color=(1., .5, .25), seed=11)
+    torch.cuda.synchronize()
+    got = tr.gradients()
+    # float64 autograd, branched like the float32 forward pass was: the signs of the activations the step kept (a pre-activation within
+    # rounding of zero falls on either side of its ReLU depending on summation order -- in TensorFlow's float32 as much as here)
+    M = n * S
+    masks = [(tr.activation(k, M) > 0).astype(np.float64) for k in list(range(8)) + [8, 9]]
+    sigma_mask = (tr.activation(10, M) > 0).astype(np.float64).reshape(n, S)
+    kw = dict(blur_idx=blur, composite_bkgd=bkgd, bkgd=(1., .5, .25))
+    want_val, wc, wa, wg = tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, okw, masks=masks, sigma_mask=sigma_mask, **kw)
+    assert abs(float(val.item()) - want_val) <= 1e-5 * abs(want_val) + 1e-7
+    assert orc.rel_linf(np.concatenate([cp.cpu().numpy(), ap.cpu().numpy()[:, None]], -1), np.concatenate([wc, wa[:, None]], -1)) <= 1e-4
+    flat = np.concatenate([g.ravel() for g in wg])
+    assert flat.size == got.size == tr.n_weights
+    worst = {name: rel_linf(got[sl], flat[sl]) for name, sl in layer_slices(spec)}
+    assert max(worst.values()) <= 1e-4, {k: v for k, v in worst.items() if v > 1e-5}
+    assert np.abs(flat).max() > 1e-6                                             # a gradient worth the name
+    # ... and against float64 autograd left to its own branches: as close as float32 autograd of the same restatement gets (the float32 floor
+    # of this comparison, measured beside it), and the two patterns differ in a handful of units
+    free = np.concatenate([g.ravel() for g in tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, okw, **kw)[3]])
+    f32 = np.concatenate([g.ravel() for g in tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, okw, dtype=torch.float32, **kw)[3]])
+    for name, sl in layer_slices(spec):
+        floor = rel_linf(f32[sl], free[sl])
+        assert rel_linf(got[sl], free[sl]) <= max(1e-4, 4 * floor), (name, rel_linf(got[sl], free[sl]), floor)
+
+
+def test_training_step_is_bit_reproducible_and_adam_matches_its_restatement():
+    """Two trainers from the same weights take the same step bit for bit (weight gradients are summed over the samples in a fixed order);
+    Adam under ExponentialDecay (train.py:49-52) within float32 rounding of the float64 restatement, over three iterations."""
+    from nerf_tex_amd.train import Trainer
+    model, spec, wts = make_model((1, 6), dense_media=True)
+    n, S = 128, 64
+    ro, rd, t, cone, params, color, alpha = batch(5, n, S, 7, "carpet")
+    okw, loss = make_loss("alpha_smape")
+    runs = []
+    for _ in range(2):
+        tr = Trainer(model, max_rays=n, n_samples=S, lrate=5e-4, lrate_decay=0.002, perturb=True)      # decay_steps = 2: the schedule shows within three steps
+        w0 = tr.weights(); hist = []
+        for it in range(3):
+            tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss, seed=it)
+            g = tr.gradients(); m_before, v_before = tr.adam_state(); w_before = tr.weights()
+            tr.apply_gradients()
+            hist.append((g, w_before, m_before, v_before, tr.weights(), *tr.adam_state()))
+        assert tr.iterations == 3
+        runs.append((w0, hist))
+    for (g, wb, mb, vb, wa, ma, va), (g2, wb2, mb2, vb2, wa2, ma2, va2) in zip(runs[0][1], runs[1][1]):
+        assert np.array_equal(g, g2) and np.array_equal(wa, wa2) and np.array_equal(ma, ma2) and np.array_equal(va, va2)
+    for it, (g, wb, mb, vb, wa, ma, va) in enumerate(runs[0][1]):
+        ww, mm, vv = tro.adam_step(wb, g, mb, vb, it, 5e-4, decay_steps=2.0, decay_rate=0.1)
+        g64, mb64, vb64 = g.astype(np.float64), mb.astype(np.float64), vb.astype(np.float64)
+        assert (np.abs(ma - mm) <= 4e-7 * (np.abs(g64) + np.abs(mb64)) + 1e-30).all()                  # float32 rounding of m + (g - m)(1 - beta_1)
+        assert (np.abs(va - vv) <= 4e-7 * (g64 * g64 + vb64) + 1e-38).all()
+        step = ww - wb.astype(np.float64)
+        assert (np.abs(wa.astype(np.float64) - ww) <= 1.01 * np.spacing(np.abs(wa)) + 1e-6 * np.abs(step)).all()   # the updated weight, to its last place
+        assert np.abs(step).max() > 1e-5
+
+
+def test_a_few_steps_fit_a_target():
+    """The loop of train.py:61-67 does what a training loop is for: fitting one batch, the loss falls."""
+    from nerf_tex_amd.train import Trainer
+    model, spec, wts = make_model((1, 6), dense_media=True)
+    n, S = 256, 64
+    ro, rd, t, cone, params, color, alpha = batch(9, n, S, 7, "carpet")
+    okw, loss = make_loss("alpha_smape")
+    tr = Trainer(model, max_rays=n, n_samples=S, lrate=5e-4, lrate_decay=500, perturb=True)
+    losses = [float(tr.step(ro, rd, t, params, cone, color, alpha, loss).item()) for _ in range(40)]
+    assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0] and np.mean(losses[-5:]) < np.mean(losses[5:10]) < np.mean(losses[:5]), losses[::5]   # random targets: smape cannot fall far, it falls steadily
+    model.set_blob(tr.weights())                                                 # the trained weights render through the inference path
+
+
+def test_the_configs_batch_size_runs_and_refusals():
+    """config_carpet_train.py's step -- 4 images x 256 rays x 256 samples = 262 144 samples -- runs; other architectures are refused."""
+    from nerf_tex_amd import _lib
+    from nerf_tex_amd.train import Trainer
+    model, spec, wts = make_model((1, 6), dense_media=True)
+    n, S = 1024, 256
+    ro, rd, t, cone, params, color, alpha = batch(1, n, S, 7, "carpet")
+    okw, loss = make_loss("alpha_smape")
+    tr = Trainer(model, max_rays=n, n_samples=S, lrate=5e-4, lrate_decay=500)
+    l0 = float(tr.step(ro, rd, t, params, cone, color, alpha, loss).item())
+    g = tr.gradients()
+    assert np.isfinite(l0) and np.isfinite(g).all() and np.abs(g).max() > 0
+    flex, _, _ = make_model((1, 6), arch=dict(depth=6))
+    with pytest.raises(_lib.NtxError) as e:
+        Trainer(flex, max_rays=8, n_samples=8)
+    assert e.value.code == _lib.NTX_E_UNSUPPORTED
