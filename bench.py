@@ -240,6 +240,78 @@ def bench_instanced(args) -> None:
                      "kernel_ms": kernel_ms}}), flush=True)
 
 
+def bench_train_step(args) -> None:
+    """`--workload carpet_train_step`: one iteration of the reference's training loop (network/train.py:61-67) at the batch of
+    configs/config_carpet_train.py -- 4 images x 256 rays x 256 samples = 262 144 ray-samples (:23, 33, 101), perturb=True, AlphaLoss with smape /
+    mse (:95-99), Adam under ExponentialDecay (lrate 5e-4, lrate_decay 500) -- forward with every activation kept, loss, backward, optimiser
+    step, on `ntx_trainer_*`.  value = ray-samples/s through a whole step; roofline: 3 x the forward's canonical FLOPs
+    (2 MACs per weight per sample; the backward pass is two contractions of the forward's size per layer) against the f32 MFMA
+    peak.  cpu_baseline: the same step as float32 torch autograd on the host (oracle/train_oracle.py), a bounded sample.  N = 1 only."""
+    import torch
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.loss import AlphaLoss
+    from nerf_tex_amd.model import ParamNerf
+    from nerf_tex_amd.train import Trainer
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        sys.exit("carpet_train_step is a single-GPU workload (data parallel training would all-reduce 2.7 MB of gradients per step: not built)")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    fam = synthetic.FAMILIES["carpet"]
+    emb = lambda n_: {"module": "network.model.FourierFeatures", "n_freq_bands": n_}
+    model = ParamNerf(emb(10), emb(4), emb(4), list(fam["n_parameters"]))["model"]
+    model.set_blob(synthetic.synthetic_weights(model.layer_table(), seed=0, dense_media=True))
+    n, S = 4 * 256, 256
+    ro, rd, t, cone = synthetic.all_hit_rays(n, [-1.5, -1.3, -.2], [1.3, 1.3, 1.9], fam["cam"])           # config_carpet_train.py:28-31
+    rng = np.random.default_rng(3)
+    params = np.tile(np.asarray([fam["params"]], np.float32), (n, 1))
+    color = rng.uniform(0, 1, size=(n, 3)).astype(np.float32)
+    alpha = ((rng.uniform(0, 1, size=n) > 0.3) * rng.uniform(0.5, 1, size=n)).astype(np.float32)
+    d = lambda a: torch.as_tensor(a, device=dev)
+    batch = [d(x) for x in (ro, rd, t, params, cone, color, alpha)]
+    loss = AlphaLoss(loss_fn="network.loss.smape", alpha_loss_fn="network.loss.mse")
+    tr = Trainer(model, max_rays=n, n_samples=S, lrate=5e-4, lrate_decay=500, perturb=True)
+    for _ in range(args.warmup):
+        tr.step(*batch, loss)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(); val = tr.step(*batch, loss); b.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    step_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    flops_fwd = 2 * model.macs_per_sample()
+    achieved = 3 * flops_fwd * n * S / (step_ms * 1e-3) / 1e12
+    line = {"metric": "ray-samples/sec through one training step (forward + loss + backward + Adam) at 4 x 256 rays x 256 samples",
+            "value": n * S * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"carpet_train_step: config_carpet_train.py's batch ({n} all-hit rays x {S} samples = {n * S} ray-samples), ParamNerf "
+                                   f"n_parameters={list(fam['n_parameters'])}, perturb=True, AlphaLoss(smape, mse), Adam + ExponentialDecay(5e-4, 5e5 steps, 0.1); "
+                                   "seeded weights and targets, batch resident in HBM", "rays": n, "samples_per_ray": S, "flops_per_sample_forward": flops_fwd,
+                       "loss_after": float(val.item())},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "ntx_train::gemm_kernel (three operand layouts; 29 launches a step)", "kernel_ms": step_ms,
+                         "what": "3 x forward FLOPs (2 MACs per weight per sample) over the WHOLE step's HIP-event time: encoders, heads, composite, loss and Adam included"}}
+    if not args.no_cpu_baseline:
+        from oracle import nerftex_oracle as orc
+        from oracle import torch_cpu, train_oracle as tro
+        cores = torch_cpu.effective_cpus()
+        torch.set_num_threads(cores)
+        spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(fam["n_parameters"]))
+        w = orc.split_blob(spec, model.get_blob())
+        nb = 64                                                                  # 64 rays x 256 samples of the same batch: a bounded sample
+        z = orc.z_values(t[:nb], S, np.float32)
+        okw = dict(kind="alpha", loss_fn="smape", alpha_loss_fn="mse")
+        tro.step_gradients(w, spec, ro[:8], rd[:8], z[:8], params[:8], cone[:8], color[:8], alpha[:8], okw, dtype=torch.float32)       # warm the BLAS threads
+        t1 = time.perf_counter()
+        tro.step_gradients(w, spec, ro[:nb], rd[:nb], z, params[:nb], cone[:nb], color[:nb], alpha[:nb], okw, dtype=torch.float32)
+        dt = time.perf_counter() - t1
+        line["cpu_baseline"] = {"value": nb * S / dt, "unit": "ray-samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
+                                "sample": f"{nb} rays x {S} samples of the same batch: forward + loss + torch autograd backward in float32 (oracle/train_oracle.py, no optimiser "
+                                          f"step), {dt:.2f} s on {torch.get_num_threads()} threads"}
+    print(json.dumps(line), flush=True)
+
+
 def bench_instanced_scene(args) -> None:
     """`--workload carpet_instanced_scene`: one render chunk of configs/config_carpet_render.py from RAYS -- 16 384 rays of the
     config's first camera -> `ntx_instancer_model_input` (the reference's C_Instancer::GetModelInput, instancer.cpp:751-1037:
@@ -470,7 +542,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS) + sorted(SHARDED) + ["carpet_instanced", "carpet_instanced_scene"])
+    ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS) + sorted(SHARDED) + ["carpet_instanced", "carpet_instanced_scene", "carpet_train_step"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="float32", choices=["float32", "fp16x3"],
                     help="arithmetic of the Dense layers (include/nerftex.h: ntx_precision); float32 = the reference's")
@@ -490,6 +562,8 @@ def main() -> None:
         return bench_instanced(args)
     if args.workload == "carpet_instanced_scene":
         return bench_instanced_scene(args)
+    if args.workload == "carpet_train_step":
+        return bench_train_step(args)
 
     # The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL writes its version banner with printf
     # when a communicator is created), so from here on file descriptor 1 goes to stderr and the line is written to the

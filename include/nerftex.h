@@ -499,7 +499,7 @@ int ntx_trainer_adam_step(ntx_trainer *t, float lrate, float lrate_decay_steps, 
                           ntx_stream stream);
 int64_t ntx_trainer_iterations(const ntx_trainer *t);
 /* The dense contraction the trainer is made of (f32 MFMA, 128 x 128 x 16 tiles through LDS), on DEVICE buffers, for tests and benches:
- * C[M][N] = op(A) . op(B) (+ bias[N]) (ReLU); a_kcontig: A is [M][K] (row stride lda), else [K][M]; b_kcontig: B is [N][K], else [K][N]. */
+ * C[M][N] = op(A) . op(B) (+ bias[N]) (ReLU); a_kcontig: A is [M][K] (row stride lda), else [K][M]; B is [K][N] (b_kcontig must be 0: the trainer transposes its weights once a step instead). */
 int ntx_gemm_f32(const float *A, int lda, int a_kcontig, const float *B, int ldb, int b_kcontig, float *C, int ldc, int M, int N, int K, const float *bias,
                  int relu, ntx_stream stream);
 

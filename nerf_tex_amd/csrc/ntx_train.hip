@@ -24,6 +24,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -41,14 +42,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// the contraction.  C[i][j] = sum_p A'(i, p) B'(p, j) for i < M, j < N, p < K, with
-//   A'(i, p) = A_KCONTIG ? A[i * lda + p] : A[p * lda + i]          B'(p, j) = B_KCONTIG ? B[j * ldb + p] : B[p * ldb + j]
-// A workgroup (4 waves) owns a 128 x 128 tile of C, a wave a 64 x 64 quarter of it = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator
-// registers).  K advances 16 at a time: the next 128 x 16 / 16 x 128 panels are fetched into registers while the current ones, already
-// in LDS as As[p][i] / Bs[p][j], feed 32 MFMAs per wave; one barrier per panel (double buffered).  LDS rows are 130 floats apart so that
-// both the transposing stores (8 rows apart -> 16 banks apart) and the operand reads (32 consecutive floats) are conflict free.
+// the contraction.  C[i][j] = sum_p A'(i, p) B(p, j) for i < M, j < N, p < K, with B[p * ldb + j] and
+//   A'(i, p) = A_KCONTIG ? A[i * lda + p] : A[p * lda + i]
+// (forward and dX: activations [samples][features] times a [features][out] matrix -- dX takes the TRANSPOSED weights, made once a step;
+// dW: A' = X^T, the reduction runs over the samples).  A workgroup (4 waves) owns a 128 x 128 tile of C, a wave a 64 x 64 quarter of it
+// = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator registers).  K advances 32 at a time: the next 128 x 32 / 32 x 128 panels are fetched
+// into registers (16-byte loads when the panel lies inside the matrices and the rows are 16-byte aligned, element by element with
+// bounds otherwise) while the current ones, already in LDS as As[p][i] / Bs[p][j], feed 64 MFMAs per wave; one barrier per panel
+// (double buffered).  The f32 MFMA shares the vector ALUs' lanes, so every VALU instruction of the loop costs MFMA time:
+// hence the long panels, the vector loads and the bounds-free interior path.
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int TM = 128, TN = 128, TK = 16, LROW = 130;
+constexpr int TM = 128;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
     const float *A; int lda; const float *B; int ldb; float *C; int ldc;
@@ -57,41 +62,36 @@ struct GemmArgs {
     const float *mask; int ldmask;   // NULL, or C[i][j] is kept only where mask[i * ldmask + j] > 0 (the ReLU of a stored activation)
     int relu, accumulate;            // C = max(C, 0);  C += what was there
     int k_chunk; long long split_stride;   // blockIdx.z = z covers p in [z * k_chunk, (z + 1) * k_chunk) and writes to C + z * split_stride
+    float *colsum;                   // NULL, or [n_split][N]: the column sums of B over each split's rows (the bias gradient rides along with dW)
+    int aligned;                     // every row of A and B starts on a 16-byte boundary
+    int debug;                       // development (NERFTEX_GEMM_DEBUG): 1 = no MFMAs, 2 = no panel fetches behind the first: WRONG results, timing only
 };
 
-// a 128 x 16 panel whose 16 run along memory (k-contiguous rows): thread t takes row t >> 1, elements (t & 1) * 8 .. + 7
-__device__ __forceinline__ void fetch_kcontig(const float *src, int ld, int row0, int nrows, int k0, int k1, float *r) {
-    const int row = row0 + (int)(threadIdx.x >> 1), p0 = k0 + (int)(threadIdx.x & 1) * 8;
-    const float *g = src + (size_t)row * ld + p0;
-    const bool rv = row < nrows;
+// n consecutive floats of a row into registers: 16-byte loads, or one by one under a bound
+template <int n, bool FAST>
+__device__ __forceinline__ void fetch_run(const float *g, bool row_ok, int first, int bound, float *r) {
+    if (FAST) {
+        const f32x4 *v = reinterpret_cast<const f32x4 *>(g);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) r[q] = (rv && p0 + q < k1) ? g[q] : 0.0f;
-}
-__device__ __forceinline__ void stash_kcontig(float (*S)[LROW], const float *r) {
-    const int row = (int)(threadIdx.x >> 1), p0 = (int)(threadIdx.x & 1) * 8;
+        for (int q = 0; q < n / 4; ++q) { const f32x4 x = v[q]; r[4 * q] = x.x; r[4 * q + 1] = x.y; r[4 * q + 2] = x.z; r[4 * q + 3] = x.w; }
+    } else {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) S[p0 + q][row] = r[q];
-}
-// a 16 x 128 panel whose 128 run along memory: thread t takes row (of 16) t >> 4, elements (t & 15) * 8 .. + 7
-__device__ __forceinline__ void fetch_mncontig(const float *src, int ld, int col0, int ncols, int k0, int k1, float *r) {
-    const int p = k0 + (int)(threadIdx.x >> 4), c0 = col0 + (int)(threadIdx.x & 15) * 8;
-    const float *g = src + (size_t)p * ld + c0;
-    const bool pv = p < k1;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) r[q] = (pv && c0 + q < ncols) ? g[q] : 0.0f;
-}
-__device__ __forceinline__ void stash_mncontig(float (*S)[LROW], const float *r) {
-    const int p = (int)(threadIdx.x >> 4), c0 = (int)(threadIdx.x & 15) * 8;
-    f32x2 *d = reinterpret_cast<f32x2 *>(&S[p][c0]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) d[q] = f32x2{r[2 * q], r[2 * q + 1]};
+        for (int q = 0; q < n; ++q) r[q] = (row_ok && first + q < bound) ? g[q] : 0.0f;
+    }
 }
 
-template <bool A_KCONTIG, bool B_KCONTIG>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[2][TK][LROW], Bs[2][TK][LROW];
+// TN_: columns of the workgroup's tile (128 or 256: two or four 64-wide waves across), TK_: depth of a panel; a wave always owns 64 x 64
+template <bool A_KCONTIG, int TN_, int TK_>
+__global__ __launch_bounds__(TN_ * 2) void gemm_kernel(GemmArgs g) {
+    constexpr int THREADS = TN_ * 2, WCOLS = TN_ / 64, LROWA = TM + 4, LROWB_ = TN_ + 4;
+    constexpr int FA = TM * TK_ / THREADS;          // floats of the A panel a thread carries
+    constexpr int FB = TN_ * TK_ / THREADS;         // ... of the B panel
+    constexpr int TPR = THREADS / TK_;              // threads along a panel row (B, and A when its rows run along i)
+    static_assert(FA % 4 == 0 && FB % 4 == 0 && FA * (THREADS / TM) == TK_ && TPR * FB == TN_ && TPR * FA == TM, "panel split");
+    __shared__ __attribute__((aligned(16))) float As[2][TK_][LROWA], Bs[2][TK_][LROWB_];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i0 = blockIdx.x * TM, j0 = blockIdx.y * TN;
+    // the column tiles of one row tile are neighbours in the launch order: the second and later ones find their rows of A in the L2
+    const int j0 = blockIdx.x * TN_, i0 = blockIdx.y * TM;
     const int k_begin = blockIdx.z * g.k_chunk;
     const int k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
     float *C = g.C + (size_t)blockIdx.z * (size_t)g.split_stride;
@@ -102,75 +102,153 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    float ra[8], rb[8];
-    auto fetch = [&](int k0) {
-        if (A_KCONTIG) fetch_kcontig(g.A, g.lda, i0, g.M, k0, k_end, ra); else fetch_mncontig(g.A, g.lda, i0, g.M, k0, k_end, ra);
-        if (B_KCONTIG) fetch_kcontig(g.B, g.ldb, j0, g.N, k0, k_end, rb); else fetch_mncontig(g.B, g.ldb, j0, g.N, k0, k_end, rb);
-    };
-    auto stash = [&](int buf) {
-        if (A_KCONTIG) stash_kcontig(As[buf], ra); else stash_mncontig(As[buf], ra);
-        if (B_KCONTIG) stash_kcontig(Bs[buf], rb); else stash_mncontig(Bs[buf], rb);
-    };
-    const int n_panels = (k_end - k_begin + TK - 1) / TK;
-    if (n_panels > 0) { fetch(k_begin); stash(0); }
-    __syncthreads();
-    const int wi = (wave >> 1) * 64 + (lane & 31), wj = (wave & 1) * 64 + (lane & 31), kh = lane >> 5;
-    for (int kt = 0; kt < n_panels; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < n_panels) fetch(k_begin + (kt + 1) * TK);
+    // two panels are in flight from memory at any time: the registers of panel kt + 2 are being filled while panel kt + 1 goes from its
+    // registers into LDS and panel kt feeds the MFMAs
+    float ra[2][FA], rb[2][FB], cs[FB];
 #pragma unroll
-        for (int kk = 0; kk < TK; kk += 2) {
-            const float a0 = As[buf][kk + kh][wi], a1 = As[buf][kk + kh][wi + 32];
-            const float b0 = Bs[buf][kk + kh][wj], b1 = Bs[buf][kk + kh][wj + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int q = 0; q < FB; ++q) cs[q] = 0.0f;
+    const bool want_colsum = !A_KCONTIG && g.colsum != nullptr && blockIdx.y == 0;
+    const bool inner = g.aligned && i0 + TM <= g.M && j0 + TN_ <= g.N;          // the tile lies inside A' and B: only the K end of a panel can stick out
+    // thread -> its run of the A panel (k-contiguous rows A[i][p]: row t % 128, FA elements from (t / 128) * FA; rows along i, A[p][i]: panel row
+    // t / TPR, FA elements from (t % TPR) * FA) and of the B panel (B[p][j]: panel row t / TPR, FB elements from (t % TPR) * FB)
+    const int a_row = A_KCONTIG ? (int)(threadIdx.x % TM) : (int)(threadIdx.x / TPR), a_off = A_KCONTIG ? (int)(threadIdx.x / TM) * FA : (int)(threadIdx.x % TPR) * FA;
+    const int b_row = (int)(threadIdx.x / TPR), b_off = (int)(threadIdx.x % TPR) * FB;
+    auto fetch = [&](int k0, float *fa, float *fb) {
+        const bool fast = inner && k0 + TK_ <= k_end;
+        if (A_KCONTIG) {
+            const float *ga = g.A + (size_t)(i0 + a_row) * g.lda + k0 + a_off;
+            if (fast) fetch_run<FA, true>(ga, true, 0, 0, fa); else fetch_run<FA, false>(ga, i0 + a_row < g.M, k0 + a_off, k_end, fa);
+        } else {
+            const float *ga = g.A + (size_t)(k0 + a_row) * g.lda + i0 + a_off;
+            if (fast) fetch_run<FA, true>(ga, true, 0, 0, fa); else fetch_run<FA, false>(ga, k0 + a_row < k_end, i0 + a_off, g.M, fa);
         }
-        if (kt + 1 < n_panels) stash(buf ^ 1);
+        const float *gb = g.B + (size_t)(k0 + b_row) * g.ldb + j0 + b_off;
+        if (fast) fetch_run<FB, true>(gb, true, 0, 0, fb); else fetch_run<FB, false>(gb, k0 + b_row < k_end, j0 + b_off, g.N, fb);
+    };
+    auto stash = [&](int buf, const float *fa, const float *fb) {
+        if (want_colsum) {
+#pragma unroll
+            for (int q = 0; q < FB; ++q) cs[q] += fb[q];
+        }
+        if (A_KCONTIG) {
+#pragma unroll
+            for (int q = 0; q < FA; ++q) As[buf][a_off + q][a_row] = fa[q];
+        } else {
+            f32x4 *d = reinterpret_cast<f32x4 *>(&As[buf][a_row][a_off]);
+#pragma unroll
+            for (int q = 0; q < FA / 4; ++q) d[q] = f32x4{fa[4 * q], fa[4 * q + 1], fa[4 * q + 2], fa[4 * q + 3]};
+        }
+        f32x4 *d = reinterpret_cast<f32x4 *>(&Bs[buf][b_row][b_off]);
+#pragma unroll
+        for (int q = 0; q < FB / 4; ++q) d[q] = f32x4{fb[4 * q], fb[4 * q + 1], fb[4 * q + 2], fb[4 * q + 3]};
+    };
+    const int n_panels = (k_end - k_begin + TK_ - 1) / TK_;
+    if (n_panels > 0) { fetch(k_begin, ra[0], rb[0]); stash(0, ra[0], rb[0]); }
+    if (n_panels > 1) fetch(k_begin + TK_, ra[1], rb[1]);
+    __syncthreads();
+    // a wave's 64 x 64 quarter as 2 x 2 MFMA tiles that INTERLEAVE: tile (a, b) = its rows 2 m + a, its columns 2 n + b -- a lane's two A
+    // (two B) operands of a k-step then sit side by side in LDS (one 8-byte read each) and its results pair up into 8-byte stores
+    const int wi = (wave / WCOLS) * 64 + 2 * (lane & 31), wj = (wave % WCOLS) * 64 + 2 * (lane & 31), kh = lane >> 5;
+    const bool wave_live = j0 + (wave % WCOLS) * 64 < g.N;       // a narrow matrix leaves some of the tile's waves without columns
+    // one panel: fetch kt + 2 into `fill`, MFMAs from LDS[kt & 1], then `ready` (panel kt + 1) into LDS[(kt + 1) & 1]
+    auto panel = [&](int kt, float *fill_a, float *fill_b, const float *ready_a, const float *ready_b) {
+        const int buf = kt & 1;
+        if (kt + 2 < n_panels && !(g.debug & 2)) fetch(k_begin + (kt + 2) * TK_, fill_a, fill_b);
+        if (!(g.debug & 1) && wave_live) {
+            // operands of k-step s + 1 are on their way from LDS while the four MFMAs of step s run
+            f32x2 av[2], bv[2];
+            av[0] = *reinterpret_cast<const f32x2 *>(&As[buf][kh][wi]); bv[0] = *reinterpret_cast<const f32x2 *>(&Bs[buf][kh][wj]);
+#pragma unroll
+            for (int st = 0; st < TK_ / 2; ++st) {
+                const int c = st & 1, n = c ^ 1;
+                if (st + 1 < TK_ / 2) {
+                    const int kk = 2 * (st + 1) + kh;
+                    av[n] = *reinterpret_cast<const f32x2 *>(&As[buf][kk][wi]); bv[n] = *reinterpret_cast<const f32x2 *>(&Bs[buf][kk][wj]);
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].y, acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < n_panels && !(g.debug & 2)) stash(buf ^ 1, ready_a, ready_b);
         __syncthreads();
+    };
+    for (int kt = 0; kt < n_panels; kt += 2) {
+        panel(kt, ra[0], rb[0], ra[1], rb[1]);                       // panel kt + 1 sits in set 1; set 0 (panel kt, already in LDS) takes panel kt + 2
+        if (kt + 1 < n_panels) panel(kt + 1, ra[1], rb[1], ra[0], rb[0]);
     }
-    // D of a 32 x 32 tile: lane l, register r  <->  row 8 (r >> 2) + (r & 3) + 4 (l >> 5), column l & 31
+    // D of a 32 x 32 tile: lane l, register r  <->  tile row m = 8 (r >> 2) + (r & 3) + 4 (l >> 5), tile column n = l & 31; with the
+    // interleaved tiles that is row 2 m + a, columns 2 n and 2 n + 1 (b = 0, 1): one 8-byte access per (a, r)
+    const bool whole = i0 + TM <= g.M && j0 + TN_ <= g.N && (g.ldc % 2 == 0) && (!g.mask || g.ldmask % 2 == 0) && ((uintptr_t)C % 8 == 0) && ((uintptr_t)g.mask % 8 == 0);
+    const int j = j0 + (wave % WCOLS) * 64 + 2 * (lane & 31);
+    const float bj0 = (g.bias && j < g.N) ? g.bias[j] : 0.0f, bj1 = (g.bias && j + 1 < g.N) ? g.bias[j + 1] : 0.0f;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int j = j0 + (wave & 1) * 64 + b * 32 + (lane & 31);
-            const float bj = (g.bias && j < g.N) ? g.bias[j] : 0.0f;
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + (wave / WCOLS) * 64 + 2 * (8 * (r >> 2) + (r & 3) + 4 * kh) + a;
+            float v0 = acc[a][0][r], v1 = acc[a][1][r];
+            float *c = C + (size_t)i * g.ldc + j;
+            if (whole) {
+                f32x2 *c2 = reinterpret_cast<f32x2 *>(c);
+                if (g.accumulate) { const f32x2 o = *c2; v0 += o.x; v1 += o.y; }
+                v0 += bj0; v1 += bj1;
+                if (g.relu) { v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; }
+                if (g.mask) { const f32x2 mk = *reinterpret_cast<const f32x2 *>(g.mask + (size_t)i * g.ldmask + j); if (!(mk.x > 0.0f)) v0 = 0.0f; if (!(mk.y > 0.0f)) v1 = 0.0f; }
+                *c2 = f32x2{v0, v1};
+            } else if (i < g.M) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = i0 + (wave >> 1) * 64 + a * 32 + 8 * (r >> 2) + (r & 3) + 4 * kh;
-                if (i < g.M && j < g.N) {
-                    float v = acc[a][b][r];
-                    float *c = C + (size_t)i * g.ldc + j;
-                    if (g.accumulate) v = v + *c;
-                    v = v + bj;
+                for (int b = 0; b < 2; ++b) {
+                    if (j + b >= g.N) continue;
+                    float v = b ? v1 : v0;
+                    if (g.accumulate) v = v + c[b];
+                    v = v + (b ? bj1 : bj0);
                     if (g.relu) v = v > 0.0f ? v : 0.0f;
-                    if (g.mask && !(g.mask[(size_t)i * g.ldmask + j] > 0.0f)) v = 0.0f;
-                    *c = v;
+                    if (g.mask && !(g.mask[(size_t)i * g.ldmask + j + b] > 0.0f)) v = 0.0f;
+                    c[b] = v;
                 }
             }
         }
+    if (want_colsum) {                                        // the panel rows a column was spread over, added up in a fixed order
+        float (*red)[LROWB_] = Bs[0];
+#pragma unroll
+        for (int q = 0; q < FB; ++q) red[b_row][b_off + q] = cs[q];
+        __syncthreads();
+        if ((int)threadIdx.x < TN_ && j0 + (int)threadIdx.x < g.N) {
+            float sum = 0.0f;
+            for (int q = 0; q < TK_; ++q) sum += red[q][threadIdx.x];
+            g.colsum[(size_t)blockIdx.z * g.N + j0 + threadIdx.x] = sum;
+        }
+    }
+}
+
+// Wt[j][i] = W[i][j] for a [rows][cols] matrix (the transposed weights dX contracts with, made once a step)
+__global__ void transpose_kernel(const float *__restrict__ W, int rows, int cols, float *__restrict__ Wt) {
+    __shared__ float tile[32][33];
+    const int x = blockIdx.x * 32 + threadIdx.x, y0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8)
+        if (y0 + r < rows && x < cols) tile[r][threadIdx.x] = W[(size_t)(y0 + r) * cols + x];
+    __syncthreads();
+    const int xo = blockIdx.y * 32 + threadIdx.x, yo0 = blockIdx.x * 32;
+    for (int r = threadIdx.y; r < 32; r += 8)
+        if (yo0 + r < cols && xo < rows) Wt[(size_t)(yo0 + r) * rows + xo] = tile[threadIdx.x][r];
 }
 
 // out[e] = sum_z partial[z][e], z ascending: the fixed order that makes a step reproducible
 __global__ void reduce_partials_kernel(const float *__restrict__ partial, int n_split, long long stride, long long count, float *__restrict__ out) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= count) return;
-    float s = 0.0f;
-    for (int z = 0; z < n_split; ++z) s += partial[(size_t)z * stride + e];
-    out[e] = s;
+    // four running sums over z = 0, 4, 8 ... / 1, 5, ... / ..., combined at the end: a fixed order, four loads in flight
+    float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int z = 0;
+    for (; z + 4 <= n_split; z += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s4[q] += partial[(size_t)(z + q) * stride + e];
+    }
+    for (int q = 0; z < n_split; ++z, ++q) s4[q] += partial[(size_t)z * stride + e];
+    out[e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
-// column sums of G[M][ld] (the bias gradient): block b sums rows [b * rows, ...) of column threadIdx.x into partial[b][col]
-__global__ void colsum_partial_kernel(const float *__restrict__ G, int ld, long long M, int N, int rows, float *__restrict__ partial) {
-    const int j = threadIdx.x;
-    if (j >= N) return;
-    const long long m0 = (long long)blockIdx.x * rows, m1 = m0 + rows < M ? m0 + rows : M;
-    float s = 0.0f;
-    for (long long m = m0; m < m1; ++m) s += G[(size_t)m * ld + j];
-    partial[(size_t)blockIdx.x * N + j] = s;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
 // encoder: layer.FourierFeatures (layer.py:8-23) of position [+ geometry parameters] and of direction [+ appearance parameters]
 // (model.py:77-101), the sample points of renderer.py:98-114 and the blur product of :155-158; thread per sample
@@ -227,11 +305,14 @@ __global__ void head_forward_kernel(const float *__restrict__ X, int ldx, int K,
                                     long long M, float *__restrict__ Y) {
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    const float *x = X + (size_t)m * ldx;
+    const f32x4 *x = reinterpret_cast<const f32x4 *>(X + (size_t)m * ldx);      // (ldx and K are multiples of 4: 256 / 128)
     float acc[3] = {0.0f, 0.0f, 0.0f};
-    for (int k = 0; k < K; ++k) {
-        const float v = x[k];
-        for (int c = 0; c < n_out; ++c) acc[c] += v * W[k * n_out + c];
+    for (int k4 = 0; k4 < K / 4; ++k4) {
+        const f32x4 v = x[k4];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            for (int c = 0; c < n_out; ++c) acc[c] += e[q] * W[(4 * k4 + q) * n_out + c];
     }
     for (int c = 0; c < n_out; ++c) Y[(size_t)m * n_out + c] = acc[c] + b[c];
 }
@@ -248,18 +329,19 @@ __global__ void head_backward_dx_kernel(const float *__restrict__ dY, int n_out,
     if (mask && !(mask[(size_t)m * ldmask + k] > 0.0f)) v = 0.0f;
     *d = v;
 }
-// dW[k][c] partial over a block of rows: block b, thread k: sum_m X[m][k] dY[m][c]
+// (dW | db) partial over a block of rows: block b, thread k < K: sum_m X[m][k] dY[m][c]; thread K: sum_m dY[m][c] (the bias row: kernel and
+// bias are neighbours in the blob).  partial[b][K + 1][n_out]
 __global__ void head_backward_dw_partial_kernel(const float *__restrict__ X, int ldx, int K, const float *__restrict__ dY, int n_out, long long M, int rows,
                                                 float *__restrict__ partial) {
     const int k = threadIdx.x;
-    if (k >= K) return;
+    if (k > K) return;
     const long long m0 = (long long)blockIdx.x * rows, m1 = m0 + rows < M ? m0 + rows : M;
     float acc[3] = {0.0f, 0.0f, 0.0f};
     for (long long m = m0; m < m1; ++m) {
-        const float x = X[(size_t)m * ldx + k];
+        const float x = k < K ? X[(size_t)m * ldx + k] : 1.0f;
         for (int c = 0; c < n_out; ++c) acc[c] += x * dY[(size_t)m * n_out + c];
     }
-    for (int c = 0; c < n_out; ++c) partial[((size_t)blockIdx.x * K + k) * n_out + c] = acc[c];
+    for (int c = 0; c < n_out; ++c) partial[((size_t)blockIdx.x * (K + 1) + k) * n_out + c] = acc[c];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -406,11 +488,11 @@ struct TLayer { int in, out; size_t w, b; };      // offsets into the Keras-orde
 struct ntx_trainer {
     int device = 0;
     ntx_model_desc desc{};
-    int Kp = 0, Kd = 0, P = 0;
+    int Kp = 0, Kd = 0, P = 0, ldp = 0, ldd = 0;   // ldp / ldd: row strides of the two concat buffers (Kp + 256, Kd + 256 rounded up to 16 bytes)
     TLayer trunk[8], feature, c1, c2, rgb, alpha;
     size_t n_weights = 0;
     long long cap = 0;                         // samples the buffers hold
-    float *w = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    float *w = nullptr, *wt = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;   // wt: the weight blocks dX contracts with, transposed
     // activations (per sample): h[i] = output of trunk layer i (h[4] lives inside h4c), c1o, c2o; concat buffers; heads' raw outputs
     float *h[8] = {}, *h4c = nullptr, *fc = nullptr, *c1o = nullptr, *c2o = nullptr, *raw_rgb = nullptr, *sigma = nullptr;
     float *z = nullptr, *dists = nullptr, *g0 = nullptr, *g1 = nullptr, *d_raw = nullptr, *d_sigma = nullptr, *partial = nullptr;
@@ -425,55 +507,69 @@ namespace {
 using namespace ntx_train;
 
 constexpr int SPLIT = 128;        // partial sums of a weight gradient along the samples
-constexpr int HEAD_ROWS = 2048;   // rows per block of the narrow reductions
+constexpr int HEAD_ROWS = 256;    // rows per block of the narrow reductions
 
 void free_all(ntx_trainer *t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
-    void *ptrs[] = {t->w, t->grad, t->adam_m, t->adam_v, t->h4c, t->fc, t->c1o, t->c2o, t->raw_rgb, t->sigma, t->z, t->dists, t->g0, t->g1, t->d_raw, t->d_sigma,
+    void *ptrs[] = {t->w, t->wt, t->grad, t->adam_m, t->adam_v, t->h4c, t->fc, t->c1o, t->c2o, t->raw_rgb, t->sigma, t->z, t->dists, t->g0, t->g1, t->d_raw, t->d_sigma,
                     t->partial, t->color, t->alpha_out, t->d_color, t->d_alpha, t->loss};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 8; ++i) if (i != 4 && t->h[i]) (void)hipFree(t->h[i]);
     delete t;
 }
 
-template <bool AK, bool BK>
+int gemm_config() {                              // development: NERFTEX_GEMM_CONFIG = 0 (128 x 128 x 32), 1 (128 x 256 x 32), 2 (128 x 128 x 16), 3 (128 x 256 x 16: the default), 4 (128 x 128 x 8)
+    static const char *e = getenv("NERFTEX_GEMM_CONFIG");
+    return e ? atoi(e) : 3;
+}
+int gemm_tk() { const int c = gemm_config(); return c == 4 ? 8 : ((c == 2 || c == 3) ? 16 : 32); }
+template <bool AK>
 void launch_gemm(hipStream_t st, GemmArgs g, int n_split) {
     if (n_split < 1) n_split = 1;
-    g.k_chunk = n_split == 1 ? g.K : ((g.K + n_split - 1) / n_split + TK - 1) / TK * TK;
+    const int tk = gemm_tk();
+    g.k_chunk = n_split == 1 ? g.K : ((g.K + n_split - 1) / n_split + tk - 1) / tk * tk;
     const int nz = (g.K + g.k_chunk - 1) / g.k_chunk;
-    hipLaunchKernelGGL((gemm_kernel<AK, BK>), dim3((g.M + TM - 1) / TM, (g.N + TN - 1) / TN, nz), dim3(256), 0, st, g);
+    g.aligned = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (((uintptr_t)g.A | (uintptr_t)g.B) % 16 == 0);
+    { static const char *dbg = getenv("NERFTEX_GEMM_DEBUG"); g.debug = dbg ? atoi(dbg) : 0; }
+    const int rows = (g.M + TM - 1) / TM;
+    switch (gemm_config()) {
+    case 1: hipLaunchKernelGGL((gemm_kernel<AK, 256, 32>), dim3((g.N + 255) / 256, rows, nz), dim3(512), 0, st, g); break;
+    case 2: hipLaunchKernelGGL((gemm_kernel<AK, 128, 16>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
+    case 3: hipLaunchKernelGGL((gemm_kernel<AK, 256, 16>), dim3((g.N + 255) / 256, rows, nz), dim3(512), 0, st, g); break;
+    case 4: hipLaunchKernelGGL((gemm_kernel<AK, 128, 8>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
+    default: hipLaunchKernelGGL((gemm_kernel<AK, 128, 32>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
+    }
+}
+int split_parts(long long K, int n_split) {
+    const int tk = gemm_tk();
+    const int chunk = (((int)K + n_split - 1) / n_split + tk - 1) / tk * tk;
+    return ((int)K + chunk - 1) / chunk;
 }
 
 // Y = act(X . W + b): X [M][K] (row stride ldx), W [K][N] row-major, Y [M][N] (row stride ldy)
 void dense_forward(hipStream_t st, const float *X, int ldx, int K, const float *W, const float *b, int N, long long M, float *Y, int ldy, int relu) {
     GemmArgs g{}; g.A = X; g.lda = ldx; g.B = W; g.ldb = N; g.C = Y; g.ldc = ldy; g.M = (int)M; g.N = N; g.K = K; g.bias = b; g.relu = relu;
-    launch_gemm<true, false>(st, g, 1);
+    launch_gemm<true>(st, g, 1);
 }
-// dX = dY . W[row0 .. row0 + K)^T, kept where mask > 0:  dY [M][N], W [.][N], dX [M][K]
-void dense_backward_dx(hipStream_t st, const float *dY, int N, const float *W, int row0, int K, long long M, const float *mask, int ldmask, int accumulate, float *dX,
-                       int lddx) {
-    GemmArgs g{}; g.A = dY; g.lda = N; g.B = W + (size_t)row0 * N; g.ldb = N; g.C = dX; g.ldc = lddx; g.M = (int)M; g.N = K; g.K = N; g.mask = mask; g.ldmask = ldmask;
+// dX = dY . Wt, kept where mask > 0:  dY [M][N], Wt [N][K] (the layer's weight block, transposed), dX [M][K]
+void dense_backward_dx(hipStream_t st, const float *dY, int N, const float *Wt, int K, long long M, const float *mask, int ldmask, int accumulate, float *dX, int lddx) {
+    GemmArgs g{}; g.A = dY; g.lda = N; g.B = Wt; g.ldb = K; g.C = dX; g.ldc = lddx; g.M = (int)M; g.N = K; g.K = N; g.mask = mask; g.ldmask = ldmask;
     g.accumulate = accumulate;
-    launch_gemm<true, true>(st, g, 1);
+    launch_gemm<true>(st, g, 1);
 }
-// dW = X^T . dY and db = column sums of dY, both through partial sums added up in a fixed order
+// dW = X^T . dY and db = the column sums of dY (riding along in the same kernel), both through partial sums added up in a fixed order;
+// kernel [K][N] and bias [N] are neighbours in the blob
 int dense_backward_dw(ntx_trainer *t, hipStream_t st, const float *X, int ldx, int K, const float *dY, int N, long long M, float *dW, float *db) {
-    const size_t need = (size_t)SPLIT * K * N;
+    const size_t need = (size_t)SPLIT * K * N + (size_t)SPLIT * N;
     if (need > t->partial_floats) return ntx_set_error(NTX_E_INVALID, "trainer: partial buffer too small");
-    GemmArgs g{}; g.A = X; g.lda = ldx; g.B = dY; g.ldb = N; g.C = t->partial; g.ldc = N; g.M = K; g.N = N; g.K = (int)M; g.split_stride = (long long)K * N;
-    launch_gemm<false, false>(st, g, SPLIT);
-    {
-        const int chunk = (((int)M + SPLIT - 1) / SPLIT + TK - 1) / TK * TK, parts = ((int)M + chunk - 1) / chunk;
-        const long long count = (long long)K * N;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, t->partial, parts, count, count, dW);
-    }
-    {
-        const int blocks = (int)((M + HEAD_ROWS - 1) / HEAD_ROWS);
-        if ((size_t)blocks * N > t->partial_floats) return ntx_set_error(NTX_E_INVALID, "trainer: partial buffer too small");
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), 0, st, dY, N, M, N, HEAD_ROWS, t->partial);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, t->partial, blocks, (long long)N, (long long)N, db);
-    }
+    float *cs = t->partial + (size_t)SPLIT * K * N;
+    GemmArgs g{}; g.A = X; g.lda = ldx; g.B = dY; g.ldb = N; g.C = t->partial; g.ldc = N; g.M = K; g.N = N; g.K = (int)M; g.split_stride = (long long)K * N; g.colsum = cs;
+    launch_gemm<false>(st, g, SPLIT);
+    const int parts = split_parts(M, SPLIT);
+    const long long count = (long long)K * N;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, t->partial, parts, count, count, dW);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, cs, parts, (long long)N, (long long)N, db);
     return NTX_OK;
 }
 
@@ -509,17 +605,19 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     for (int i = 0; i < 8; ++i) { t->trunk[i] = take(k, 256); k = 256 + (i == 4 ? t->Kp : 0); }       // model.py:104-108
     t->feature = take(256, 256); t->c1 = take(256 + t->Kd, 256); t->c2 = take(256, 128); t->rgb = take(128, 3); t->alpha = take(256, 1);   // Keras order: alpha last
     t->n_weights = p;
+    t->ldp = (t->Kp + 256 + 3) / 4 * 4; t->ldd = (t->Kd + 256 + 3) / 4 * 4;
     if (n_floats != p) { delete t; return ntx_set_error(NTX_E_INVALID, "weights: %zu floats, the model has %zu", n_floats, p); }
     const long long M = (long long)max_rays * max_samples_per_ray;
     t->cap = M; t->cap_rays = max_rays;
     auto alloc = [&](float **d, size_t n) -> int { TRAIN_TRY(hipMalloc((void **)d, (n ? n : 1) * sizeof(float))); return NTX_OK; };
     int rc = hipSetDevice(device) == hipSuccess ? NTX_OK : ntx_set_error(NTX_E_HIP, "hipSetDevice(%d) failed", device);
     if (rc == NTX_OK) rc = alloc(&t->w, p);
+    if (rc == NTX_OK) rc = alloc(&t->wt, p);
     if (rc == NTX_OK) rc = alloc(&t->grad, p);
     if (rc == NTX_OK) rc = alloc(&t->adam_m, p);
     if (rc == NTX_OK) rc = alloc(&t->adam_v, p);
-    if (rc == NTX_OK) rc = alloc(&t->h4c, (size_t)M * (t->Kp + 256));
-    if (rc == NTX_OK) rc = alloc(&t->fc, (size_t)M * (t->Kd + 256));
+    if (rc == NTX_OK) rc = alloc(&t->h4c, (size_t)M * t->ldp);
+    if (rc == NTX_OK) rc = alloc(&t->fc, (size_t)M * t->ldd);
     for (int i = 0; i < 8 && rc == NTX_OK; ++i)
         if (i != 4) rc = alloc(&t->h[i], (size_t)M * 256);
     if (rc == NTX_OK) rc = alloc(&t->c1o, (size_t)M * 256);
@@ -532,9 +630,9 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     if (rc == NTX_OK) rc = alloc(&t->g1, (size_t)M * 256);
     if (rc == NTX_OK) rc = alloc(&t->d_raw, (size_t)M * 3);
     if (rc == NTX_OK) rc = alloc(&t->d_sigma, (size_t)M);
-    t->partial_floats = (size_t)SPLIT * (256 + (t->Kd > t->Kp ? t->Kd : t->Kp)) * 256;
+    t->partial_floats = (size_t)SPLIT * (256 + (t->Kd > t->Kp ? t->Kd : t->Kp)) * 256 + (size_t)SPLIT * 256;
     {
-        const size_t head = (size_t)((M + HEAD_ROWS - 1) / HEAD_ROWS) * 256 * 3;
+        const size_t head = (size_t)((M + HEAD_ROWS - 1) / HEAD_ROWS) * 257 * 3;
         if (head > t->partial_floats) t->partial_floats = head;
     }
     if (rc == NTX_OK) rc = alloc(&t->partial, t->partial_floats);
@@ -571,7 +669,7 @@ int ntx_trainer_activation(ntx_trainer *t, int layer, int64_t n_samples_total, f
     if (!t || !out_host) return ntx_set_error(NTX_E_INVALID, "NULL argument");
     if (n_samples_total < 1 || n_samples_total > t->cap) return ntx_set_error(NTX_E_INVALID, "n_samples_total out of range");
     const float *src = nullptr; int ld = 256, width = 256;
-    if (layer >= 0 && layer < 8) { src = t->h[layer]; ld = layer == 4 ? t->Kp + 256 : 256; }
+    if (layer >= 0 && layer < 8) { src = t->h[layer]; ld = layer == 4 ? t->ldp : 256; }
     else if (layer == 8) src = t->c1o;
     else if (layer == 9) { src = t->c2o; ld = 128; width = 128; }
     else if (layer == 10) { src = t->sigma; ld = 1; width = 1; }
@@ -607,7 +705,7 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     TRAIN_TRY(hipSetDevice(t->device));
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)n_rays * n_samples;
-    const int S = n_samples, Kp = t->Kp, Kd = t->Kd, ldp = Kp + 256, ldd = Kd + 256;
+    const int S = n_samples, Kp = t->Kp, Kd = t->Kd, ldp = t->ldp, ldd = t->ldd;
     const float *W = t->w;
     // ---- forward, every activation kept ----------------------------------------------------------------------------------------
     const float *z = z_vals;
@@ -649,38 +747,42 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     // ---- backward -----------------------------------------------------------------------------------------------------------------
     hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st, c);
     float *G = t->grad;
+    // the weight blocks dX contracts with, transposed once: Wt[out][in'] at the layer's own offset (in' = the rows that take a gradient on)
+    auto transposed = [&](const TLayer &l, int row0, int rows) {
+        hipLaunchKernelGGL(transpose_kernel, dim3((l.out + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, W + l.w + (size_t)row0 * l.out, rows, l.out, t->wt + l.w);
+        return (const float *)(t->wt + l.w);
+    };
     const int hb = (int)((M + HEAD_ROWS - 1) / HEAD_ROWS);
-    auto head_dw = [&](const float *X, int ldx, int K, const float *dY, int n_out, const TLayer &l) {
-        hipLaunchKernelGGL(head_backward_dw_partial_kernel, dim3(hb), dim3(256), 0, st, X, ldx, K, dY, n_out, M, HEAD_ROWS, t->partial);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((K * n_out + 255) / 256), dim3(256), 0, st, t->partial, hb, (long long)K * n_out, (long long)K * n_out, G + l.w);
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(hb), dim3(256), 0, st, dY, n_out, M, n_out, HEAD_ROWS, t->partial);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, t->partial, hb, (long long)n_out, (long long)n_out, G + l.b);
+    auto head_dw = [&](const float *X, int ldx, int K, const float *dY, int n_out, const TLayer &l) {       // (kernel | bias) of a narrow head
+        hipLaunchKernelGGL(head_backward_dw_partial_kernel, dim3(hb), dim3(320), 0, st, X, ldx, K, dY, n_out, M, HEAD_ROWS, t->partial);
+        const long long count = (long long)(K + 1) * n_out;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, t->partial, hb, count, count, G + l.w);
     };
     // color head (128 -> 3): dW, db; d c2o = (d_raw . W^T) where c2o > 0
     head_dw(t->c2o, 128, 128, t->d_raw, 3, t->rgb);
     hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, st, t->d_raw, 3, W + t->rgb.w, 128, M, t->c2o, 128, 0, t->g0, 128);
     int rc = dense_backward_dw(t, st, t->c1o, 256, 256, t->g0, 128, M, G + t->c2.w, G + t->c2.b);
     if (rc != NTX_OK) return rc;
-    dense_backward_dx(st, t->g0, 128, W + t->c2.w, 0, 256, M, t->c1o, 256, 0, t->g1, 256);              // d c1o, masked by its ReLU
+    dense_backward_dx(st, t->g0, 128, transposed(t->c2, 0, 256), 256, M, t->c1o, 256, 0, t->g1, 256);            // d c1o, masked by its ReLU
     rc = dense_backward_dw(t, st, t->fc, ldd, Kd + 256, t->g1, 256, M, G + t->c1.w, G + t->c1.b);
     if (rc != NTX_OK) return rc;
-    dense_backward_dx(st, t->g1, 256, W + t->c1.w, Kd, 256, M, nullptr, 0, 0, t->g0, 256);              // d feature (linear layer: no mask)
+    dense_backward_dx(st, t->g1, 256, transposed(t->c1, Kd, 256), 256, M, nullptr, 0, 0, t->g0, 256);            // d feature (linear layer: no mask)
     rc = dense_backward_dw(t, st, t->h[7], 256, 256, t->g0, 256, M, G + t->feature.w, G + t->feature.b);
     if (rc != NTX_OK) return rc;
     head_dw(t->h[7], 256, 256, t->d_sigma, 1, t->alpha);
     // d h7 = d_sigma (x) W_alpha + d feature . W_feature^T, masked by h7's ReLU
     hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 256 + 255) / 256)), dim3(256), 0, st, t->d_sigma, 1, W + t->alpha.w, 256, M, nullptr, 0, 0, t->g1, 256);
-    dense_backward_dx(st, t->g0, 256, W + t->feature.w, 0, 256, M, t->h[7], 256, 1, t->g1, 256);
+    dense_backward_dx(st, t->g0, 256, transposed(t->feature, 0, 256), 256, M, t->h[7], 256, 1, t->g1, 256);
     float *cur = t->g1, *nxt = t->g0;
     for (int i = 7; i >= 0; --i) {
         const TLayer &l = t->trunk[i];
         const float *X = (i == 0 || i == 5) ? t->h4c : t->h[i - 1];
-        const int ldx = (i == 0 || i == 5) ? ldp : (i - 1 == 4 ? ldp : 256);
+        const int ldx = (i == 0 || i == 5) ? ldp : 256;
         rc = dense_backward_dw(t, st, X, ldx, l.in, cur, 256, M, G + l.w, G + l.b);
         if (rc != NTX_OK) return rc;
         if (i == 0) break;
         const int row0 = i == 5 ? Kp : 0;                                                           // the skip's position rows take no gradient further
-        dense_backward_dx(st, cur, 256, W + l.w, row0, 256, M, t->h[i - 1], (i - 1 == 4) ? ldp : 256, 0, nxt, 256);
+        dense_backward_dx(st, cur, 256, transposed(l, row0, 256), 256, M, t->h[i - 1], (i - 1 == 4) ? ldp : 256, 0, nxt, 256);
         float *tmp = cur; cur = nxt; nxt = tmp;
     }
     if (color_pred) TRAIN_TRY(hipMemcpyAsync(color_pred, t->color, (size_t)n_rays * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -714,10 +816,8 @@ int ntx_gemm_f32(const float *A, int lda, int a_kcontig, const float *B, int ldb
     if (!A || !B || !C || M < 1 || N < 1 || K < 1) return ntx_set_error(NTX_E_INVALID, "bad GEMM arguments");
     ntx_train::GemmArgs g{}; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu;
     hipStream_t st = (hipStream_t)stream;
-    if (a_kcontig && !b_kcontig) launch_gemm<true, false>(st, g, 1);
-    else if (a_kcontig && b_kcontig) launch_gemm<true, true>(st, g, 1);
-    else if (!a_kcontig && !b_kcontig) launch_gemm<false, false>(st, g, 1);
-    else return ntx_set_error(NTX_E_UNSUPPORTED, "A transposed with B transposed is not built");
+    if (b_kcontig) return ntx_set_error(NTX_E_UNSUPPORTED, "B must be [K][N] (the trainer transposes its weights once a step instead)");
+    if (a_kcontig) launch_gemm<true>(st, g, 1); else launch_gemm<false>(st, g, 1);
     TRAIN_TRY(hipGetLastError());
     return NTX_OK;
 }

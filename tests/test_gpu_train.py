@@ -24,7 +24,8 @@ def rel_linf(got, want):
     return float(np.max(np.abs(np.asarray(got, np.float64) - want)) / max(np.max(np.abs(want)), 1e-300))
 
 
-@pytest.mark.parametrize("ak,bk,M,N,K", [(1, 0, 300, 200, 77), (1, 1, 257, 129, 256), (0, 0, 337, 256, 1000), (1, 0, 128, 128, 16), (0, 0, 72, 3, 5000), (1, 1, 4096, 256, 128)])
+@pytest.mark.parametrize("ak,bk,M,N,K", [(1, 0, 300, 200, 77), (1, 0, 257, 129, 256), (0, 0, 337, 256, 1000), (1, 0, 128, 128, 32), (0, 0, 72, 3, 5000), (1, 0, 4096, 256, 128),
+                                         (1, 0, 512, 256, 340), (0, 0, 340, 256, 2048)])
 def test_gemm_kernel_against_float64(ak, bk, M, N, K):
     """The contraction the trainer is made of, in its three operand layouts, at sizes off the 128 x 128 x 16 tiles."""
     import ctypes as C
