@@ -1,0 +1,66 @@
+"""The training-step restatement (oracle/train_oracle.py <- network/train.py:49-70, network/loss.py) against hand-computed cases and against
+finite differences: it is what the GPU trainer's gradients are compared with (tests/test_gpu_train.py), so it gets its own checks.  CPU only."""
+
+import numpy as np
+import pytest
+
+from oracle import nerftex_oracle as orc
+from oracle import train_oracle as tro
+
+torch = pytest.importorskip("torch")
+F = np.float32
+
+
+def test_losses_known_answers():
+    t = torch.tensor([[0.5, 0.0, 1.0]], dtype=torch.float64); p = torch.tensor([[0.25, 0.5, 1.0]], dtype=torch.float64)
+    assert float(tro.mse(t, p)) == pytest.approx((0.0625 + 0.25 + 0) / 3)                                   # loss.py:51-54
+    assert float(tro.smape(t, p)) == pytest.approx((0.25 / 0.76 + 0.5 / 0.51 + 0) / 3)                       # loss.py:56-59, eps 1e-2
+    at = torch.tensor([0.0], dtype=torch.float64); ap = torch.tensor([0.3], dtype=torch.float64)
+    # AlphaLoss (loss.py:21-49): a pixel with alpha_true = 0 is masked out of the colour term (hard mask), the alpha term stays
+    assert float(tro.alpha_loss(t, at, p, ap)) == pytest.approx(0.0 + 0.09)
+    assert float(tro.alpha_loss(t, at + 0.5, p, ap, gamma=2.0, use_hard_mask=False)) == pytest.approx(float(tro.mse(0.5 * t, 0.5 * p)) + 2.0 * 0.04)
+    assert float(tro.nerf_loss(t, p, "smape")) == pytest.approx(float(tro.smape(t, p)))
+
+
+def test_adam_first_step_known_answer():
+    # t = 1: m = (1 - b1) g, v = (1 - b2) g^2, lr_t = lr sqrt(1 - b2) / (1 - b1)  ->  w -= lr g / (|g| + eps / sqrt(1 - b2)): a step of lr against the sign
+    w = np.asarray([1.0, -2.0, 0.5]); g = np.asarray([0.3, -4.0, 1e-3])
+    w1, m1, v1 = tro.adam_step(w, g, np.zeros(3), np.zeros(3), 0, 5e-4)
+    omb1, omb2 = float(F(1) - F(0.9)), float(F(1) - F(0.999))                  # Keras forms 1 - beta in float32
+    assert np.allclose(m1, omb1 * g) and np.allclose(v1, omb2 * g * g)
+    assert np.allclose(w1, w - 5e-4 * np.sign(g), rtol=0, atol=5e-4 * 5e-3)      # (eps / sqrt(1 - b2) = 3.2e-6 against |g| >= 1e-3)
+    # ExponentialDecay(lrate, decay_steps, 0.1) without staircase: the rate at iteration 5e5 of config_carpet_train.py (lrate_decay 500) is a tenth
+    wa, _, _ = tro.adam_step(w, g, m1, v1, 500000, 5e-4, decay_steps=5e5)
+    wb, _, _ = tro.adam_step(w, g, m1, v1, 500000, 5e-5)
+    assert np.allclose(wa, wb, rtol=0, atol=1e-12)
+
+
+def tiny_batch(seed=0, n=6, S=5):
+    rng = np.random.default_rng(seed)
+    ro = rng.normal(size=(n, 3)); rd = rng.normal(size=(n, 3)); rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    t = np.stack([np.full(n, 0.5), np.full(n, 1.5)], -1)
+    z = orc.z_values(t.astype(F), S, F).astype(np.float64)
+    return ro, rd, z, rng.uniform(0.2, 1, size=(n, 3)), rng.uniform(1e-3, 5e-3, size=(n, 1)), rng.uniform(0, 1, size=(n, 3)), (rng.uniform(0, 1, size=n) > 0.3) * 0.8
+
+
+@pytest.mark.parametrize("loss", [dict(kind="alpha", loss_fn="smape", alpha_loss_fn="mse"), dict(kind="nerf", loss_fn="mse")])
+def test_autograd_matches_finite_differences(loss):
+    """The float64 gradients the GPU trainer is held to, against central differences of the same restated step on a small network."""
+    spec = orc.ModelSpec(kind="ParamNerf", n_parameters=(1, 2), depth=3, width=8, skips=(1,), pos_freq=2, dir_freq=1, param_freq=1)
+    rng = np.random.default_rng(1)
+    w = [rng.normal(size=(i, o)) * 0.5 if b == 0 else rng.normal(size=o) * 0.1 for _, i, o in orc.layer_table(spec) for b in (0, 1)]
+    ro, rd, z, par, cone, ct, at = tiny_batch()
+    val, c, a, g = tro.step_gradients(w, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0, composite_bkgd=True, bkgd=(1., .5, .2))
+    f = lambda ws: tro.step_gradients(ws, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0, composite_bkgd=True, bkgd=(1., .5, .2))[0]
+    for k in range(len(w)):
+        idx = tuple(rng.integers(0, s_) for s_ in w[k].shape)
+        h = 1e-6
+        wp = [x.copy() for x in w]; wp[k][idx] += h
+        wm = [x.copy() for x in w]; wm[k][idx] -= h
+        fd = (f(wp) - f(wm)) / (2 * h)
+        assert fd == pytest.approx(g[k][idx], rel=2e-5, abs=1e-9), (k, idx)
+    # handing the restatement its own ReLU pattern changes nothing
+    n, S = z.shape
+    wt = [torch.tensor(x) for x in w]
+    pos = torch.tensor(ro)[:, None, :] + torch.tensor(rd)[:, None, :] * torch.tensor(z)[:, :, None]
+    assert val == pytest.approx(float(tro.step_gradients(w, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0, composite_bkgd=True, bkgd=(1., .5, .2))[0]))
