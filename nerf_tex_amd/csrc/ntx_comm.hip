@@ -40,6 +40,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     char path[512] = "";
+    char why[512] = "";           // dlerror() of the dlopen / dlsym that failed, taken where it failed (a later call would overwrite or clear it)
 };
 
 // librccl is bound once per process (function-local static: initialisation is thread-safe).  The copy PyTorch has already
@@ -52,10 +53,15 @@ Rccl load_rccl() {
     if (!r.handle)
         for (const char *n : names)
             if ((r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!r.handle) return r;
+    if (!r.handle) {
+        const char *e = dlerror();
+        snprintf(r.why, sizeof(r.why), "%s", e ? e : "dlopen failed without a message");
+        return r;
+    }
     bool ok = true;
     auto sym = [&](auto &fn, const char *name) {
         fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(r.handle, name));
+        if (fn == nullptr && ok) { const char *e = dlerror(); snprintf(r.why, sizeof(r.why), "%s: %s", name, e ? e : "symbol not found"); }
         ok = ok && fn != nullptr;
     };
     sym(r.GetUniqueId, "ncclGetUniqueId"); sym(r.CommInitRank, "ncclCommInitRank"); sym(r.CommDestroy, "ncclCommDestroy");
@@ -67,11 +73,13 @@ Rccl load_rccl() {
     return r;
 }
 
-// NULL when librccl cannot be had
-const Rccl *rccl() {
+// NULL when librccl cannot be had (rccl_why() then says why)
+const Rccl &rccl_state() {
     static const Rccl r = load_rccl();
-    return r.handle ? &r : nullptr;
+    return r;
 }
+const Rccl *rccl() { return rccl_state().handle ? &rccl_state() : nullptr; }
+const char *rccl_why() { return rccl_state().why[0] ? rccl_state().why : "no message"; }
 
 using ntx_shard::shard_count;
 
@@ -118,7 +126,7 @@ const char *ntx_comm_library(void) {
 }
 
 int ntx_comm_preflight(int device) {
-    if (!rccl()) return ntx_set_error(NTX_E_UNSUPPORTED, "librccl.so.1 could not be loaded (or lacks a symbol of rccl.h): %s", dlerror() ? dlerror() : "no dlerror");
+    if (!rccl()) return ntx_set_error(NTX_E_UNSUPPORTED, "librccl.so.1 could not be loaded (or lacks a symbol of rccl.h): %s", rccl_why());
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return ntx_set_error(NTX_E_INVALID, "device %d out of range [0,%d)", device, ndev);

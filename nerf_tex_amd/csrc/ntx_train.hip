@@ -81,8 +81,8 @@ __device__ __forceinline__ void fetch_run(const float *g, bool row_ok, int first
 }
 
 // TN_: columns of the workgroup's tile (128 or 256: two or four 64-wide waves across), TK_: depth of a panel; a wave always owns 64 x 64
-template <bool A_KCONTIG, int TN_, int TK_>
-__global__ __launch_bounds__(TN_ * 2) void gemm_kernel(GemmArgs g) {
+template <bool A_KCONTIG, int TN_, int TK_, int WAVES_PER_EU = 2>
+__global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_PER_EU, 8))) void gemm_kernel(GemmArgs g) {
     constexpr int THREADS = TN_ * 2, WCOLS = TN_ / 64, LROWA = TM + 4, LROWB_ = TN_ + 4;
     constexpr int FA = TM * TK_ / THREADS;          // floats of the A panel a thread carries
     constexpr int FB = TN_ * TK_ / THREADS;         // ... of the B panel
@@ -523,7 +523,7 @@ int gemm_config() {                              // development: NERFTEX_GEMM_CO
     static const char *e = getenv("NERFTEX_GEMM_CONFIG");
     return e ? atoi(e) : 3;
 }
-int gemm_tk() { const int c = gemm_config(); return c == 4 ? 8 : ((c == 2 || c == 3) ? 16 : 32); }
+int gemm_tk() { const int c = gemm_config(); return c == 4 ? 8 : ((c == 2 || c == 3 || c == 5 || c == 6) ? 16 : 32); }
 template <bool AK>
 void launch_gemm(hipStream_t st, GemmArgs g, int n_split) {
     if (n_split < 1) n_split = 1;
@@ -538,6 +538,8 @@ void launch_gemm(hipStream_t st, GemmArgs g, int n_split) {
     case 2: hipLaunchKernelGGL((gemm_kernel<AK, 128, 16>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
     case 3: hipLaunchKernelGGL((gemm_kernel<AK, 256, 16>), dim3((g.N + 255) / 256, rows, nz), dim3(512), 0, st, g); break;
     case 4: hipLaunchKernelGGL((gemm_kernel<AK, 128, 8>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
+    case 5: hipLaunchKernelGGL((gemm_kernel<AK, 128, 16, 4>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
+    case 6: hipLaunchKernelGGL((gemm_kernel<AK, 128, 16, 3>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
     default: hipLaunchKernelGGL((gemm_kernel<AK, 128, 32>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
     }
 }
