@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 extern "C" int ntx_set_error(int code, const char *fmt, ...);   // nerftex.hip
@@ -69,8 +70,12 @@ struct GemmArgs {
 
 // n consecutive floats of a row into registers: 16-byte loads, or one by one under a bound
 template <int n, bool FAST>
-__device__ __forceinline__ void fetch_run(const float *g, bool row_ok, int first, int bound, float *r) {
+__device__ __forceinline__ void fetch_run(const float *g, bool row_ok, int first, int bound, float *r, bool aligned_ok = false) {
     if (FAST) {
+        const f32x4 *v = reinterpret_cast<const f32x4 *>(g);
+#pragma unroll
+        for (int q = 0; q < n / 4; ++q) { const f32x4 x = v[q]; r[4 * q] = x.x; r[4 * q + 1] = x.y; r[4 * q + 2] = x.z; r[4 * q + 3] = x.w; }
+    } else if (row_ok && first + n <= bound && aligned_ok) {         // the run lies inside: vector loads here too
         const f32x4 *v = reinterpret_cast<const f32x4 *>(g);
 #pragma unroll
         for (int q = 0; q < n / 4; ++q) { const f32x4 x = v[q]; r[4 * q] = x.x; r[4 * q + 1] = x.y; r[4 * q + 2] = x.z; r[4 * q + 3] = x.w; }
@@ -113,17 +118,11 @@ __global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_P
     // t / TPR, FA elements from (t % TPR) * FA) and of the B panel (B[p][j]: panel row t / TPR, FB elements from (t % TPR) * FB)
     const int a_row = A_KCONTIG ? (int)(threadIdx.x % TM) : (int)(threadIdx.x / TPR), a_off = A_KCONTIG ? (int)(threadIdx.x / TM) * FA : (int)(threadIdx.x % TPR) * FA;
     const int b_row = (int)(threadIdx.x / TPR), b_off = (int)(threadIdx.x % TPR) * FB;
-    auto fetch = [&](int k0, float *fa, float *fb) {
-        const bool fast = inner && k0 + TK_ <= k_end;
-        if (A_KCONTIG) {
-            const float *ga = g.A + (size_t)(i0 + a_row) * g.lda + k0 + a_off;
-            if (fast) fetch_run<FA, true>(ga, true, 0, 0, fa); else fetch_run<FA, false>(ga, i0 + a_row < g.M, k0 + a_off, k_end, fa);
-        } else {
-            const float *ga = g.A + (size_t)(k0 + a_row) * g.lda + i0 + a_off;
-            if (fast) fetch_run<FA, true>(ga, true, 0, 0, fa); else fetch_run<FA, false>(ga, k0 + a_row < k_end, i0 + a_off, g.M, fa);
-        }
-        const float *gb = g.B + (size_t)(k0 + b_row) * g.ldb + j0 + b_off;
-        if (fast) fetch_run<FB, true>(gb, true, 0, 0, fb); else fetch_run<FB, false>(gb, k0 + b_row < k_end, j0 + b_off, g.N, fb);
+    auto fetch = [&](int k0, float *fa, float *fb) {                  // with bounds: a run that lies inside still comes by 16-byte loads
+        const bool al = g.aligned != 0;
+        if (A_KCONTIG) fetch_run<FA, false>(g.A + (size_t)(i0 + a_row) * g.lda + k0 + a_off, i0 + a_row < g.M, k0 + a_off, k_end, fa, al);
+        else fetch_run<FA, false>(g.A + (size_t)(k0 + a_row) * g.lda + i0 + a_off, k0 + a_row < k_end, i0 + a_off, g.M, fa, al);
+        fetch_run<FB, false>(g.B + (size_t)(k0 + b_row) * g.ldb + j0 + b_off, k0 + b_row < k_end, j0 + b_off, g.N, fb, al);
     };
     auto stash = [&](int buf, const float *fa, const float *fb) {
         if (want_colsum) {
@@ -143,41 +142,66 @@ __global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_P
         for (int q = 0; q < FB / 4; ++q) d[q] = f32x4{fb[4 * q], fb[4 * q + 1], fb[4 * q + 2], fb[4 * q + 3]};
     };
     const int n_panels = (k_end - k_begin + TK_ - 1) / TK_;
-    if (n_panels > 0) { fetch(k_begin, ra[0], rb[0]); stash(0, ra[0], rb[0]); }
-    if (n_panels > 1) fetch(k_begin + TK_, ra[1], rb[1]);
-    __syncthreads();
+    const int n_full = inner ? (k_end - k_begin) / TK_ : 0;            // panels the bounds-free pipeline takes; the rest (a K tail, edge tiles) go one by one
     // a wave's 64 x 64 quarter as 2 x 2 MFMA tiles that INTERLEAVE: tile (a, b) = its rows 2 m + a, its columns 2 n + b -- a lane's two A
     // (two B) operands of a k-step then sit side by side in LDS (one 8-byte read each) and its results pair up into 8-byte stores
     const int wi = (wave / WCOLS) * 64 + 2 * (lane & 31), wj = (wave % WCOLS) * 64 + 2 * (lane & 31), kh = lane >> 5;
     const bool wave_live = j0 + (wave % WCOLS) * 64 < g.N;       // a narrow matrix leaves some of the tile's waves without columns
-    // one panel: fetch kt + 2 into `fill`, MFMAs from LDS[kt & 1], then `ready` (panel kt + 1) into LDS[(kt + 1) & 1]
-    auto panel = [&](int kt, float *fill_a, float *fill_b, const float *ready_a, const float *ready_b) {
-        const int buf = kt & 1;
-        if (kt + 2 < n_panels && !(g.debug & 2)) fetch(k_begin + (kt + 2) * TK_, fill_a, fill_b);
-        if (!(g.debug & 1) && wave_live) {
-            // operands of k-step s + 1 are on their way from LDS while the four MFMAs of step s run
-            f32x2 av[2], bv[2];
-            av[0] = *reinterpret_cast<const f32x2 *>(&As[buf][kh][wi]); bv[0] = *reinterpret_cast<const f32x2 *>(&Bs[buf][kh][wj]);
+    // the MFMAs of one panel in LDS[buf].  The operands of k-step s + 1 are asked for BEFORE the four MFMAs of step s are issued (the
+    // scheduling barriers keep the compiler from sinking the reads back down to their use, which leaves the matrix pipe idle for an LDS
+    // round trip every step)
+    auto compute = [&](int buf) {
+        if ((g.debug & 1) || !wave_live) return;
+        f32x2 av[2], bv[2];
+        av[0] = *reinterpret_cast<const f32x2 *>(&As[buf][kh][wi]); bv[0] = *reinterpret_cast<const f32x2 *>(&Bs[buf][kh][wj]);
 #pragma unroll
-            for (int st = 0; st < TK_ / 2; ++st) {
-                const int c = st & 1, n = c ^ 1;
-                if (st + 1 < TK_ / 2) {
-                    const int kk = 2 * (st + 1) + kh;
-                    av[n] = *reinterpret_cast<const f32x2 *>(&As[buf][kk][wi]); bv[n] = *reinterpret_cast<const f32x2 *>(&Bs[buf][kk][wj]);
-                }
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].x, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].y, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].x, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].y, acc[1][1], 0, 0, 0);
+        for (int st = 0; st < TK_ / 2; ++st) {
+            const int c = st & 1, n = c ^ 1;
+            if (st + 1 < TK_ / 2) {
+                const int kk = 2 * (st + 1) + kh;
+                av[n] = *reinterpret_cast<const f32x2 *>(&As[buf][kk][wi]); bv[n] = *reinterpret_cast<const f32x2 *>(&Bs[buf][kk][wj]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].y, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto fetch_fast = [&](int k0, float *fa, float *fb) {
+        const float *ga = A_KCONTIG ? g.A + (size_t)(i0 + a_row) * g.lda + k0 + a_off : g.A + (size_t)(k0 + a_row) * g.lda + i0 + a_off;
+        fetch_run<FA, true>(ga, true, 0, 0, fa);
+        fetch_run<FB, true>(g.B + (size_t)(k0 + b_row) * g.ldb + j0 + b_off, true, 0, 0, fb);
+    };
+    // Two panels are in flight from memory at any time: panel kt feeds the MFMAs from LDS, panel kt + 1 waits in one register set for its
+    // turn to go into LDS, panel kt + 2 is on its way into the other.  With the bounds-free loads the steady-state loop has no branch around
+    // a load, so the wait in front of the LDS stores covers panel kt + 1 only (s_waitcnt vmcnt(loads of one panel)), not the panel just
+    // asked for.  Panels [first, last) of this workgroup's K range.
+    auto pipeline = [&](auto fast_tag, int first, int last) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        auto get = [&](int kt, float *fa, float *fb) { if (FAST) fetch_fast(k_begin + kt * TK_, fa, fb); else fetch(k_begin + kt * TK_, fa, fb); };
+        if (first >= last) return;
+        get(first, ra[0], rb[0]); stash(0, ra[0], rb[0]);
+        if (first + 1 < last) get(first + 1, ra[1], rb[1]);
+        __syncthreads();
+        int kt = first;                                               // LDS buffer of panel kt = (kt - first) & 1
+        if (!(g.debug & 2)) {
+            for (; kt + 3 < last; kt += 2) {
+                get(kt + 2, ra[0], rb[0]); compute(0); stash(1, ra[1], rb[1]); __syncthreads();
+                get(kt + 3, ra[1], rb[1]); compute(1); stash(0, ra[0], rb[0]); __syncthreads();
             }
         }
-        if (kt + 1 < n_panels && !(g.debug & 2)) stash(buf ^ 1, ready_a, ready_b);
-        __syncthreads();
+        for (; kt < last; ++kt) {                                     // the last two or three panels: nothing left to ask for behind them
+            const int buf = (kt - first) & 1;
+            if (kt + 2 < last && !(g.debug & 2)) { if (buf) get(kt + 2, ra[1], rb[1]); else get(kt + 2, ra[0], rb[0]); }
+            compute(buf);
+            if (kt + 1 < last && !(g.debug & 2)) { if (buf) stash(0, ra[0], rb[0]); else stash(1, ra[1], rb[1]); }
+            __syncthreads();
+        }
     };
-    for (int kt = 0; kt < n_panels; kt += 2) {
-        panel(kt, ra[0], rb[0], ra[1], rb[1]);                       // panel kt + 1 sits in set 1; set 0 (panel kt, already in LDS) takes panel kt + 2
-        if (kt + 1 < n_panels) panel(kt + 1, ra[1], rb[1], ra[0], rb[0]);
-    }
+    pipeline(std::true_type{}, 0, n_full);
+    pipeline(std::false_type{}, n_full, n_panels);                    // a K tail; every panel of a tile on the matrix's edge
     // D of a 32 x 32 tile: lane l, register r  <->  tile row m = 8 (r >> 2) + (r & 3) + 4 (l >> 5), tile column n = l & 31; with the
     // interleaved tiles that is row 2 m + a, columns 2 n and 2 n + 1 (b = 0, 1): one 8-byte access per (a, r)
     const bool whole = i0 + TM <= g.M && j0 + TN_ <= g.N && (g.ldc % 2 == 0) && (!g.mask || g.ldmask % 2 == 0) && ((uintptr_t)C % 8 == 0) && ((uintptr_t)g.mask % 8 == 0);
@@ -519,11 +543,11 @@ void free_all(ntx_trainer *t) {
     delete t;
 }
 
-int gemm_config() {                              // development: NERFTEX_GEMM_CONFIG = 0 (128 x 128 x 32), 1 (128 x 256 x 32), 2 (128 x 128 x 16), 3 (128 x 256 x 16: the default), 4 (128 x 128 x 8)
+int gemm_config() {                              // development: NERFTEX_GEMM_CONFIG = 0 (128 x 128 x 32), 1 (128 x 256 x 32), 2 (128 x 128 x 16: the default), 3 (128 x 256 x 16), 4 (128 x 128 x 8)
     static const char *e = getenv("NERFTEX_GEMM_CONFIG");
-    return e ? atoi(e) : 3;
+    return e ? atoi(e) : 2;
 }
-int gemm_tk() { const int c = gemm_config(); return c == 4 ? 8 : ((c == 2 || c == 3 || c == 5 || c == 6) ? 16 : 32); }
+int gemm_tk() { const int c = gemm_config(); return c == 4 ? 8 : ((c == 2 || c == 3) ? 16 : 32); }
 template <bool AK>
 void launch_gemm(hipStream_t st, GemmArgs g, int n_split) {
     if (n_split < 1) n_split = 1;
@@ -538,8 +562,6 @@ void launch_gemm(hipStream_t st, GemmArgs g, int n_split) {
     case 2: hipLaunchKernelGGL((gemm_kernel<AK, 128, 16>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
     case 3: hipLaunchKernelGGL((gemm_kernel<AK, 256, 16>), dim3((g.N + 255) / 256, rows, nz), dim3(512), 0, st, g); break;
     case 4: hipLaunchKernelGGL((gemm_kernel<AK, 128, 8>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
-    case 5: hipLaunchKernelGGL((gemm_kernel<AK, 128, 16, 4>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
-    case 6: hipLaunchKernelGGL((gemm_kernel<AK, 128, 16, 3>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
     default: hipLaunchKernelGGL((gemm_kernel<AK, 128, 32>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
     }
 }
