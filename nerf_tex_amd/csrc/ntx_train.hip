@@ -24,6 +24,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -247,17 +248,6 @@ __global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_P
     }
 }
 
-// Wt[j][i] = W[i][j] for a [rows][cols] matrix (the transposed weights dX contracts with, made once a step)
-__global__ void transpose_kernel(const float *__restrict__ W, int rows, int cols, float *__restrict__ Wt) {
-    __shared__ float tile[32][33];
-    const int x = blockIdx.x * 32 + threadIdx.x, y0 = blockIdx.y * 32;
-    for (int r = threadIdx.y; r < 32; r += 8)
-        if (y0 + r < rows && x < cols) tile[r][threadIdx.x] = W[(size_t)(y0 + r) * cols + x];
-    __syncthreads();
-    const int xo = blockIdx.y * 32 + threadIdx.x, yo0 = blockIdx.x * 32;
-    for (int r = threadIdx.y; r < 32; r += 8)
-        if (yo0 + r < cols && xo < rows) Wt[(size_t)(yo0 + r) * rows + xo] = tile[threadIdx.x][r];
-}
 
 // out[e] = sum_z partial[z][e], z ascending: the fixed order that makes a step reproducible
 __global__ void reduce_partials_kernel(const float *__restrict__ partial, int n_split, long long stride, long long count, float *__restrict__ out) {
@@ -273,6 +263,235 @@ __global__ void reduce_partials_kernel(const float *__restrict__ partial, int n_
     for (int q = 0; z < n_split; ++z, ++q) s4[q] += partial[(size_t)z * stride + e];
     out[e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// The two contractions of a step whose reduction is SHORT (the layer's width) and whose other side is the samples -- forward Y = X . W and
+// dX = dY . W^T -- the way the render kernel does a layer (ntx_device.h): one wave owns 32 samples and ALL of a layer's
+// outputs (8 tiles of 32 x 32 = 128 accumulator registers), computed transposed, out^T[feature][sample] = W^T . X^T on
+// v_mfma_f32_32x32x2_f32.  The B operand is the wave's own 32 rows of X, read straight from HBM 16 bytes a lane, a body (32 k) ahead.  The A
+// operand is the weights, from a PACKED image that the workgroup's four waves pull through a double-buffered LDS ring with direct
+// global -> LDS loads (one 1 KiB record per instruction; a body's 32 records in four quarters) and read back with ds_read_b128: the
+// weights cost no registers, wait on the LDS counter and not behind the HBM loads on the in-order vector-memory counter (a register ring
+// did: every X load held up the ring eight records later), and reach a CU once per workgroup instead of once per wave.  One barrier per
+// body of 128 MFMAs; every vector-memory load is asked for at the top of a body and waited for at its end.  No VALU work in the loop (the
+// f32 MFMA shares the vector ALUs' lanes: every VALU instruction costs MFMA time).  Where the 128 x 128 LDS tiles of gemm_kernel reach
+// 0.58-0.64 of the MFMA peak, this is bound by the matrix pipe.  dW = X^T . dY reduces over the samples: it stays with gemm_kernel.
+//
+// k order.  A lane (sample m = l & 31, half h = l >> 5) loads X[m][8 q + 4 h .. + 3] in one piece; k-step s = 4 q + c then pairs
+// k = 8 q + c (lower half-wave) with k = 8 q + 4 + c (upper) -- the order of the summation over k is free.  The packed image follows:
+// record (s, g) = 64 lanes x 4 floats, component c' of lane (f, h) = Wsrc[k(s, h)][32 (4 g + c') + f]: one 16-byte read feeds 4 MFMAs.
+// Rows of the image with no counterpart (K rounded up to 32; the pad columns between the two halves of a concat buffer) are zero, the X
+// values they meet are finite (pad columns are zeroed once, what lies behind a row is the next row; beyond the matrix the buffer
+// descriptor returns 0).
+//
+// D of a tile (the MFMA's A operand is X, its B operand the weights): lane (f = l & 31, h), register r <-> sample 8 (r >> 2) + 4 h + (r & 3),
+// feature 32 t + f: a register is 32 consecutive features of one sample per half-wave, so a row-major Y[sample][feature] is written (and
+// an accumulate operand read) in full 128-byte lines.  The ReLU mask dX needs is not
+// read back as 268 MB of activations: the forward pass leaves ONE BIT per output, in the accumulators' own layout (lane, tile, register:
+// 128 bits = 16 bytes a lane and block), and dX -- whose outputs lie in the same layout -- reads those 8 MB.
+//
+// Launch: persistent, two workgroups of four waves per CU (one wave of each per SIMD): one workgroup's epilogues and block changes fall
+// into the other's k loops.  A block's epilogue is issued at the top of the NEXT block's first body, behind that body's loads: its stores
+// have a whole body to drain before anything waits on the vector-memory counter again.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct RowsArgs {
+    const float *X; int ldx; long long M;
+    const float *recs; int kblocks;                    // packed weights; blocks of 8 k (a multiple of 4)
+    float *Y; int ldy;
+    const float *bias; int relu;                       // forward
+    unsigned int *bits_out;                            // forward: one bit per output, set where it is > 0 (or NULL)
+    const unsigned int *bits_in; int accumulate;       // dX: keep where the bit is set; add to what Y holds first
+    int debug, phase;
+    unsigned long long *stamps;                        // development: [start, end] of every workgroup on the 100 MHz clock
+};
+enum { ROWS_FORWARD = 0, ROWS_DX = 1, ROWS_DX_MASK = 2, ROWS_DX_ACC_MASK = 3 };   // what the epilogue does: a template parameter, no load of it behind a branch
+template <int N, class F> __device__ __forceinline__ void static_for_(F &&f) {
+    if constexpr (N > 0) { static_for_<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void *base, long long bytes) {
+    const long long b = bytes < 0 ? 0 : (bytes > 0x7ffffff0ll ? 0x7ffffff0ll : bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)b, 0x00020000);
+}
+template <int NT, int MODE, int VARIANT = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rows_kernel(RowsArgs a) {
+    constexpr int G = NT / 4;                          // records per k-step
+    constexpr int CHUNK = 16 * G;                      // records per body (4 blocks of 8 k = 16 k-steps): 16 or 32 KiB
+    __shared__ f32x4 lds[2 * CHUNK * 64 + NT * 8];     // two chunks, then the bias
+    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long n_blocks = (a.M + 31) / 32, n_groups = (n_blocks + 3) / 4;
+    const int nb = a.kblocks / 4;
+    if ((long long)blockIdx.x >= n_groups) return;
+    if (a.stamps && threadIdx.x == 0) { a.stamps[2 * blockIdx.x] = wall_clock64(); a.stamps[8192 + 2 * blockIdx.x] = clock64(); }
+    const __amdgpu_buffer_rsrc_t rw = rows_rsrc(a.recs, (long long)a.kblocks * NT * 1024);
+    const uint32_t woff = (uint32_t)lane * 16u, xoff = (uint32_t)(m * a.ldx + 4 * h) * 4u;
+    constexpr bool MASK = MODE == ROWS_DX_MASK || MODE == ROWS_DX_ACC_MASK;
+    const __amdgpu_buffer_rsrc_t rbits = rows_rsrc(MASK ? (const void *)a.bits_in : (const void *)a.recs, MASK ? n_blocks * 1024 : 0);
+    if constexpr (MODE == ROWS_FORWARD) {
+        float *bl = reinterpret_cast<float *>(&lds[2 * CHUNK * 64]);
+        if ((int)threadIdx.x < NT * 32) bl[threadIdx.x] = a.bias[threadIdx.x];
+    }
+    // this wave's quarter of a chunk, straight into LDS: one record (64 lanes x 16 bytes, lane-linear) per instruction
+    auto fill = [&](int chunk, int buf) {
+        static_for_<CHUNK / 4>([&](auto I) {
+            const int r = wave * (CHUNK / 4) + I;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)&lds[(buf * CHUNK + r) * 64], 16, woff,
+                                                     (uint32_t)(chunk * CHUNK + r) * 1024u, 0, 0);
+        });
+    };
+    auto block_rows = [&](long long grp) { return (grp * 4 + wave) * 32; };
+    auto x_rsrc = [&](long long row0) { return rows_rsrc(a.X + row0 * a.ldx, (a.M - row0) * a.ldx * 4); };
+    auto xload4 = [&](const __amdgpu_buffer_rsrc_t &rx, int q0, f32x4 (&x)[4]) {
+        static_for_<4>([&](auto I) { x[I] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff, (uint32_t)(q0 + I) * 32u, 0)); });
+    };
+    f32x16 acc[NT];
+    auto acc_init = [&]() {
+        if constexpr (MODE == ROWS_FORWARD) {          // the accumulators start from the bias: a lane's feature is the same in all of a tile's registers
+            const float *bl = reinterpret_cast<const float *>(&lds[2 * CHUNK * 64]);
+            static_for_<NT>([&](auto T) {
+                constexpr int t = T;
+                const float b = bl[32 * t + m];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = b;
+            });
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        }
+    };
+    // the epilogue of the block at row0: register r of tile t is 32 consecutive features of one sample per half-wave -- a store writes two
+    // full 128-byte lines (16-byte pieces of four features scattered over 32 rows cost the L2 four times the requests: measured, 9 us a
+    // block); rows behind the matrix fall outside the descriptor (loads 0, stores dropped)
+    unsigned long long epi_cycles = 0;
+    auto epilogue = [&](long long row0, u32x4 bits) {
+        if (a.debug & 8) return;
+        const unsigned long long e0 = a.stamps ? clock64() : 0;
+        const long long yrow = (a.debug & 128) ? (row0 & 8191) : row0;       // development: every block stores into the same 8 MB
+        const __amdgpu_buffer_rsrc_t ry = rows_rsrc(a.Y + yrow * a.ldy, (a.debug & 64) ? 0 : (a.M - yrow) * a.ldy * 4);   // development: stores dropped at the descriptor
+        const uint32_t yoff = (uint32_t)(4 * h * a.ldy + m) * 4u;
+        const float lo = a.relu ? 0.0f : -__builtin_inff();
+        u32x4 out_bits = {0u, 0u, 0u, 0u};
+        static_for_<16>([&](auto R) {
+            constexpr int r = R;
+            const uint32_t rowb = (uint32_t)((8 * (r >> 2) + (r & 3)) * a.ldy) * 4u;
+            float old[NT];
+            if constexpr (MODE == ROWS_DX_ACC_MASK)
+                static_for_<NT>([&](auto T) { old[T] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yoff, rowb + (uint32_t)T * 128u, 0)); });
+            static_for_<NT>([&](auto T) {
+                constexpr int t = T;
+                float v = acc[t][r];
+                if constexpr (MODE == ROWS_FORWARD) {
+                    v = fmaxf(v, lo);
+                    out_bits[t >> 1] |= v > 0.0f ? 1u << (16 * (t & 1) + r) : 0u;
+                }
+                if constexpr (MODE == ROWS_DX_ACC_MASK) v += old[t];
+                if constexpr (MASK) {                                      // covers what was there too (d h7 = (alpha's part + feature's part) where h7 > 0)
+                    const int keep = __builtin_amdgcn_sbfe((int)bits[t >> 1], 16 * (t & 1) + r, 1);   // 0 or -1
+                    v = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keep);
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff, rowb + (uint32_t)t * 128u, 0);
+            });
+        });
+        if constexpr (MODE == ROWS_FORWARD)
+            if (a.bits_out) {
+                const __amdgpu_buffer_rsrc_t rbo = rows_rsrc(a.bits_out, n_blocks * 1024);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out_bits), rbo, woff, (uint32_t)(row0 / 32) * 1024u, 0);
+            }
+        if (a.stamps) epi_cycles += clock64() - e0;
+    };
+    f32x4 xn[4];
+    u32x4 bits_n = {0u, 0u, 0u, 0u};
+    long long grp = blockIdx.x;
+    if (a.phase > 0) {                                 // the second workgroup of a CU starts a.phase quarter-bodies (of 2048 cycles) late
+        const unsigned slot = (a.debug & 32) ? (blockIdx.x >= gridDim.x / 2 ? 1u : 0u) : (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1u);   // HW_ID[3:0]: the wave's slot on its SIMD
+        if (__builtin_amdgcn_readfirstlane(slot)) {
+            const int naps = a.phase * 2048 / 64;
+            for (int i = 0; i < naps / 127; ++i) __builtin_amdgcn_s_sleep(127);
+            for (int i = 0; i < (naps % 127) / 8; ++i) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    {
+        fill(0, 0);
+        xload4(x_rsrc(block_rows(grp)), 0, xn);
+        if constexpr (MASK) bits_n = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbits, woff, (uint32_t)(block_rows(grp) / 32) * 1024u, 0));
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): an instruction the compiler's own counting sees, unlike inline assembly
+        __syncthreads();
+    }
+    int buf = 0;
+    bool have_prev = false;
+    const __amdgpu_buffer_rsrc_t rx0 = x_rsrc(block_rows(blockIdx.x));
+    long long prev_row0 = 0;
+    u32x4 prev_bits = {0u, 0u, 0u, 0u}, bits = {0u, 0u, 0u, 0u};
+    for (; grp < n_groups; grp += gridDim.x) {
+        const long long row0 = block_rows(grp);
+        const long long next_grp = grp + gridDim.x;
+        const long long row0n = next_grp < n_groups ? block_rows(next_grp) : a.M;      // nothing behind the last group: an empty descriptor
+        const __amdgpu_buffer_rsrc_t rx = x_rsrc(row0), rxn = x_rsrc(row0n);
+        bits = bits_n;
+        for (int b = 0; b < nb; ++b) {
+            f32x4 x[4] = {xn[0], xn[1], xn[2], xn[3]};
+            const bool last = b == nb - 1;
+            // what the next body needs, asked for now
+            fill((last || (a.debug & 4)) ? 0 : b + 1, buf ^ 1);
+            xload4((a.debug & 2) ? rx0 : (last ? rxn : rx), (last || (a.debug & 2)) ? 0 : 4 * (b + 1), xn);
+            if constexpr (MASK) bits_n = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbits, woff, (uint32_t)((last ? row0n : row0) / 32) * 1024u, 0));
+            if (b == 0) {
+                if (have_prev) epilogue(prev_row0, prev_bits);
+                acc_init();
+            }
+            const f32x4 *L = &lds[buf * CHUNK * 64 + lane];
+            f32x4 w0 = L[0], w1 = L[64];
+            static_for_<CHUNK>([&](auto IDX) {
+                constexpr int idx = IDX, ks = idx / G, gi = idx % G, qi = ks / 4, c = ks % 4;
+                f32x4 w;
+                if constexpr (idx % 2 == 0) { w = w0; if constexpr (idx + 2 < CHUNK && !(VARIANT & 1)) w0 = L[(idx + 2) * 64]; }
+                else { w = w1; if constexpr (idx + 2 < CHUNK && !(VARIANT & 1)) w1 = L[(idx + 2) * 64]; }
+                static_for_<4>([&](auto T) {
+                    constexpr int tt = T, tile = 4 * gi + T;
+                    acc[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[qi][c], w[tt], acc[tile], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            if constexpr (!(VARIANT & 2)) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): an instruction the compiler's own counting sees, unlike inline assembly
+            __syncthreads();
+            }
+            buf ^= 1;
+        }
+        have_prev = true; prev_row0 = row0; prev_bits = bits;
+    }
+    if (have_prev) epilogue(prev_row0, prev_bits);
+    if (a.stamps && threadIdx.x == 0) { a.stamps[2 * blockIdx.x + 1] = wall_clock64(); a.stamps[8192 + 2 * blockIdx.x + 1] = clock64(); a.stamps[12288 + blockIdx.x] = epi_cycles; }
+}
+
+// the packed images of every layer, both directions, in one launch (the weights move every step)
+struct PackJob {
+    const float *src; long long sk, sc;               // Wsrc[k][col] = src[krow(k) * sk + col * sc]
+    int K1, K1p, K2;                                  // k < K1: row k; K1 <= k < K1p: the pad, zero; then K2 more rows; zero behind
+    int nt, kblocks;
+    float *dst; long long first;                      // where the image lies; the job's first float in the launch's index space
+};
+constexpr int MAX_PACK_JOBS = 24;
+struct PackArgs { PackJob job[MAX_PACK_JOBS]; int n_jobs; long long total; };
+__global__ void pack_records_kernel(PackArgs a) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.total) return;
+    int j = 0;
+    while (j + 1 < a.n_jobs && e >= a.job[j + 1].first) ++j;
+    const PackJob &p = a.job[j];
+    const long long o = e - p.first;
+    const int c = (int)(o & 3), lane = (int)((o >> 2) & 63);
+    const long long rec = o >> 8;
+    const int G = p.nt / 4, g = (int)(rec % G), s = (int)(rec / G);
+    const int f = lane & 31, h = lane >> 5;
+    const int k = 8 * (s >> 2) + 4 * h + (s & 3), col = 32 * (4 * g + c) + f;
+    const int row = k < p.K1 ? k : (k < p.K1p ? -1 : (k < p.K1p + p.K2 ? p.K1 + (k - p.K1p) : -1));
+    p.dst[o] = row < 0 ? 0.0f : p.src[row * p.sk + col * p.sc];
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // encoder: layer.FourierFeatures (layer.py:8-23) of position [+ geometry parameters] and of direction [+ appearance parameters]
 // (model.py:77-101), the sample points of renderer.py:98-114 and the blur product of :155-158; thread per sample
@@ -512,13 +731,17 @@ struct TLayer { int in, out; size_t w, b; };      // offsets into the Keras-orde
 struct ntx_trainer {
     int device = 0;
     ntx_model_desc desc{};
-    int Kp = 0, Kd = 0, P = 0, ldp = 0, ldd = 0;   // ldp / ldd: row strides of the two concat buffers (Kp + 256, Kd + 256 rounded up to 16 bytes)
+    int Kp = 0, Kd = 0, P = 0, Kp4 = 0, Kd4 = 0, ldp = 0, ldd = 0;   // the two concat buffers: [pos_map | pad to 16 bytes | h4], row stride ldp = Kp4 + 256; [dir_map | pad | feature], ldd
     TLayer trunk[8], feature, c1, c2, rgb, alpha;
     size_t n_weights = 0;
     long long cap = 0;                         // samples the buffers hold
-    float *w = nullptr, *wt = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;   // wt: the weight blocks dX contracts with, transposed
+    float *w = nullptr, *wp = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;   // wp: the packed images rows_kernel streams (made once a step)
+    ntx_train::PackArgs pack{};
+    const float *fwd_recs[11] = {}; int fwd_kblocks[11] = {};   // trunk 0-7, feature, c1, c2
+    const float *bwd_recs[10] = {}; int bwd_kblocks[10] = {};   // trunk 1-7 (index i - 1), feature, c1, c2
     // activations (per sample): h[i] = output of trunk layer i (h[4] lives inside h4c), c1o, c2o; concat buffers; heads' raw outputs
     float *h[8] = {}, *h4c = nullptr, *fc = nullptr, *c1o = nullptr, *c2o = nullptr, *raw_rgb = nullptr, *sigma = nullptr;
+    unsigned int *bits[9] = {};                // where h[0..7] and c1o are > 0, one bit per output in rows_kernel's layout (1 KiB per 32 samples)
     float *z = nullptr, *dists = nullptr, *g0 = nullptr, *g1 = nullptr, *d_raw = nullptr, *d_sigma = nullptr, *partial = nullptr;
     float *color = nullptr, *alpha_out = nullptr, *d_color = nullptr, *d_alpha = nullptr, *loss = nullptr;
     long long cap_rays = 0;
@@ -536,10 +759,11 @@ constexpr int HEAD_ROWS = 256;    // rows per block of the narrow reductions
 void free_all(ntx_trainer *t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
-    void *ptrs[] = {t->w, t->wt, t->grad, t->adam_m, t->adam_v, t->h4c, t->fc, t->c1o, t->c2o, t->raw_rgb, t->sigma, t->z, t->dists, t->g0, t->g1, t->d_raw, t->d_sigma,
+    void *ptrs[] = {t->w, t->wp, t->grad, t->adam_m, t->adam_v, t->h4c, t->fc, t->c1o, t->c2o, t->raw_rgb, t->sigma, t->z, t->dists, t->g0, t->g1, t->d_raw, t->d_sigma,
                     t->partial, t->color, t->alpha_out, t->d_color, t->d_alpha, t->loss};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 8; ++i) if (i != 4 && t->h[i]) (void)hipFree(t->h[i]);
+    for (int i = 0; i < 9; ++i) if (t->bits[i]) (void)hipFree(t->bits[i]);
     delete t;
 }
 
@@ -571,16 +795,64 @@ int split_parts(long long K, int n_split) {
     return ((int)K + chunk - 1) / chunk;
 }
 
-// Y = act(X . W + b): X [M][K] (row stride ldx), W [K][N] row-major, Y [M][N] (row stride ldy)
-void dense_forward(hipStream_t st, const float *X, int ldx, int K, const float *W, const float *b, int N, long long M, float *Y, int ldy, int relu) {
-    GemmArgs g{}; g.A = X; g.lda = ldx; g.B = W; g.ldb = N; g.C = Y; g.ldc = ldy; g.M = (int)M; g.N = N; g.K = K; g.bias = b; g.relu = relu;
-    launch_gemm<true>(st, g, 1);
+// Y = act(X . W + b) through the layer's packed image: X [M][..] (row stride ldx), Y [M][N] (row stride ldy)
+void launch_rows(hipStream_t st, const RowsArgs &r, int N) {
+    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const long long n_groups = ((r.M + 31) / 32 + 3) / 4;
+    static const int per_cu = [] { const char *e = getenv("NERFTEX_ROWS_WGS"); return e ? atoi(e) : 2; }();   // development
+    const dim3 grid((unsigned)(n_groups < per_cu * cus ? n_groups : per_cu * cus)), wg(256);
+    RowsArgs a = r;
+    { static const char *dbg = getenv("NERFTEX_ROWS_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
+    { static const char *ph = getenv("NERFTEX_ROWS_PHASE"); a.phase = ph ? atoi(ph) : 0; }
+    {
+        static unsigned long long *stamps = [] { unsigned long long *p = nullptr; if (getenv("NERFTEX_ROWS_STAMPS")) (void)hipMalloc((void **)&p, 16384 * 8); return p; }();
+        a.stamps = stamps;
+    }
+    if (N != 256) hipLaunchKernelGGL((rows_kernel<4, ROWS_FORWARD>), grid, wg, 0, st, a);
+    else if (a.bias) hipLaunchKernelGGL((rows_kernel<8, ROWS_FORWARD>), grid, wg, 0, st, a);
+    else if (!a.bits_in) {
+        static const int variant = [] { const char *e = getenv("NERFTEX_ROWS_VARIANT"); return e ? atoi(e) : 0; }();   // development
+        if (variant == 1) hipLaunchKernelGGL((rows_kernel<8, ROWS_DX, 1>), grid, wg, 0, st, a);
+        else if (variant == 2) hipLaunchKernelGGL((rows_kernel<8, ROWS_DX, 2>), grid, wg, 0, st, a);
+        else if (variant == 3) hipLaunchKernelGGL((rows_kernel<8, ROWS_DX, 3>), grid, wg, 0, st, a);
+        else hipLaunchKernelGGL((rows_kernel<8, ROWS_DX>), grid, wg, 0, st, a);
+    }
+    else if (!a.accumulate) hipLaunchKernelGGL((rows_kernel<8, ROWS_DX_MASK>), grid, wg, 0, st, a);
+    else hipLaunchKernelGGL((rows_kernel<8, ROWS_DX_ACC_MASK>), grid, wg, 0, st, a);
+    if (a.stamps) {                                    // development: when did the workgroups run
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(12288 + grid.x);
+        (void)hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (unsigned i = 0; i < grid.x; ++i) { if (h[2 * i] < t0) t0 = h[2 * i]; if (h[2 * i + 1] > t1) t1 = h[2 * i + 1]; }
+        double s_sum = 0, e_sum = 0, s_max = 0, e_min = 1e30, life = 0;
+        for (unsigned i = 0; i < grid.x; ++i) {
+            const double sa = (h[2 * i] - t0) * 0.01, en = (h[2 * i + 1] - t0) * 0.01;
+            s_sum += sa; e_sum += en; if (sa > s_max) s_max = sa; if (en < e_min) e_min = en; life += en - sa;
+        }
+        if (getenv("NERFTEX_ROWS_STAMPS")[0] == '2') {
+            for (int x = 0; x < 8; ++x) {
+                double mn = 1e30, mx = 0, sm = 0; int n = 0;
+                for (unsigned i = x; i < grid.x; i += 8) { const double en = (h[2 * i + 1] - t0) * 0.01; mn = en < mn ? en : mn; mx = en > mx ? en : mx; sm += en; ++n; }
+                fprintf(stderr, "   blockIdx %% 8 = %d: end min %.1f mean %.1f max %.1f\n", x, mn, sm / n, mx);
+            }
+            for (unsigned i = 0; i < grid.x; i += 8) fprintf(stderr, "%s%.0f", i % 256 == 0 ? "\n   xcd0 ends: " : " ", (h[2 * i + 1] - t0) * 0.01);
+            fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "epilogue cycles wg0 %.0f wg%u %.0f; ", (double)h[12288], grid.x - 1, (double)h[12288 + grid.x - 1]);
+        fprintf(stderr, "workgroup 0: %.0f shader cycles in %.2f us = %.3f GHz;  ", (double)(h[8193] - h[8192]), (h[1] - h[0]) * 0.01, (double)(h[8193] - h[8192]) / ((h[1] - h[0]) * 10.0));
+        fprintf(stderr, "rows N=%d kblocks=%d mode bias=%d bits=%d acc=%d: span %.1f us; start mean %.1f max %.1f; end mean %.1f min %.1f; life mean %.1f\n", N, a.kblocks, a.bias != nullptr,
+                a.bits_in != nullptr, a.accumulate, (t1 - t0) * 0.01, s_sum / grid.x, s_max, e_sum / grid.x, e_min, life / grid.x);
+    }
 }
-// dX = dY . Wt, kept where mask > 0:  dY [M][N], Wt [N][K] (the layer's weight block, transposed), dX [M][K]
-void dense_backward_dx(hipStream_t st, const float *dY, int N, const float *Wt, int K, long long M, const float *mask, int ldmask, int accumulate, float *dX, int lddx) {
-    GemmArgs g{}; g.A = dY; g.lda = N; g.B = Wt; g.ldb = K; g.C = dX; g.ldc = lddx; g.M = (int)M; g.N = K; g.K = N; g.mask = mask; g.ldmask = ldmask;
-    g.accumulate = accumulate;
-    launch_gemm<true>(st, g, 1);
+void dense_forward(hipStream_t st, const float *X, int ldx, const float *recs, int kblocks, const float *b, int N, long long M, float *Y, int ldy, int relu, unsigned int *bits_out) {
+    RowsArgs r{}; r.X = X; r.ldx = ldx; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = Y; r.ldy = ldy; r.bias = b; r.relu = relu; r.bits_out = bits_out;
+    launch_rows(st, r, N);
+}
+// dX = dY . W^T (the image packed from the layer's own block, transposed on the way), kept where the forward pass left a bit:  dY [M][N], dX [M][256]
+void dense_backward_dx(hipStream_t st, const float *dY, int N, const float *recs, int kblocks, long long M, const unsigned int *bits, int accumulate, float *dX, int lddx) {
+    RowsArgs r{}; r.X = dY; r.ldx = N; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = dX; r.ldy = lddx; r.bits_in = bits; r.accumulate = accumulate;
+    launch_rows(st, r, 256);
 }
 // dW = X^T . dY and db = the column sums of dY (riding along in the same kernel), both through partial sums added up in a fixed order;
 // kernel [K][N] and bias [N] are neighbours in the blob
@@ -588,12 +860,12 @@ int dense_backward_dw(ntx_trainer *t, hipStream_t st, const float *X, int ldx, i
     const size_t need = (size_t)SPLIT * K * N + (size_t)SPLIT * N;
     if (need > t->partial_floats) return ntx_set_error(NTX_E_INVALID, "trainer: partial buffer too small");
     float *cs = t->partial + (size_t)SPLIT * K * N;
-    GemmArgs g{}; g.A = X; g.lda = ldx; g.B = dY; g.ldb = N; g.C = t->partial; g.ldc = N; g.M = K; g.N = N; g.K = (int)M; g.split_stride = (long long)K * N; g.colsum = cs;
+    GemmArgs g{}; g.A = X; g.lda = ldx; g.B = dY; g.ldb = N; g.C = t->partial; g.ldc = N; g.M = K; g.N = N; g.K = (int)M; g.split_stride = (long long)K * N; g.colsum = db ? cs : nullptr;
     launch_gemm<false>(st, g, SPLIT);
     const int parts = split_parts(M, SPLIT);
     const long long count = (long long)K * N;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, t->partial, parts, count, count, dW);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, cs, parts, (long long)N, (long long)N, db);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, cs, parts, (long long)N, (long long)N, db);
     return NTX_OK;
 }
 
@@ -629,14 +901,14 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     for (int i = 0; i < 8; ++i) { t->trunk[i] = take(k, 256); k = 256 + (i == 4 ? t->Kp : 0); }       // model.py:104-108
     t->feature = take(256, 256); t->c1 = take(256 + t->Kd, 256); t->c2 = take(256, 128); t->rgb = take(128, 3); t->alpha = take(256, 1);   // Keras order: alpha last
     t->n_weights = p;
-    t->ldp = (t->Kp + 256 + 3) / 4 * 4; t->ldd = (t->Kd + 256 + 3) / 4 * 4;
+    t->Kp4 = (t->Kp + 3) / 4 * 4; t->Kd4 = (t->Kd + 3) / 4 * 4;
+    t->ldp = t->Kp4 + 256; t->ldd = t->Kd4 + 256;
     if (n_floats != p) { delete t; return ntx_set_error(NTX_E_INVALID, "weights: %zu floats, the model has %zu", n_floats, p); }
     const long long M = (long long)max_rays * max_samples_per_ray;
     t->cap = M; t->cap_rays = max_rays;
     auto alloc = [&](float **d, size_t n) -> int { TRAIN_TRY(hipMalloc((void **)d, (n ? n : 1) * sizeof(float))); return NTX_OK; };
     int rc = hipSetDevice(device) == hipSuccess ? NTX_OK : ntx_set_error(NTX_E_HIP, "hipSetDevice(%d) failed", device);
     if (rc == NTX_OK) rc = alloc(&t->w, p);
-    if (rc == NTX_OK) rc = alloc(&t->wt, p);
     if (rc == NTX_OK) rc = alloc(&t->grad, p);
     if (rc == NTX_OK) rc = alloc(&t->adam_m, p);
     if (rc == NTX_OK) rc = alloc(&t->adam_v, p);
@@ -644,6 +916,7 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     if (rc == NTX_OK) rc = alloc(&t->fc, (size_t)M * t->ldd);
     for (int i = 0; i < 8 && rc == NTX_OK; ++i)
         if (i != 4) rc = alloc(&t->h[i], (size_t)M * 256);
+    for (int i = 0; i < 9 && rc == NTX_OK; ++i) rc = alloc((float **)&t->bits[i], (size_t)((M + 31) / 32) * 256);
     if (rc == NTX_OK) rc = alloc(&t->c1o, (size_t)M * 256);
     if (rc == NTX_OK) rc = alloc(&t->c2o, (size_t)M * 128);
     if (rc == NTX_OK) rc = alloc(&t->raw_rgb, (size_t)M * 3);
@@ -669,7 +942,37 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     if (rc == NTX_OK && (hipMemset(t->adam_m, 0, p * sizeof(float)) != hipSuccess || hipMemset(t->adam_v, 0, p * sizeof(float)) != hipSuccess || hipMemset(t->grad, 0, p * sizeof(float)) != hipSuccess))
         rc = ntx_set_error(NTX_E_HIP, "hipMemset failed");
     if (rc != NTX_OK) { free_all(t); return rc; }
-    t->h[4] = t->h4c + t->Kp;                     // trunk layer 4 writes behind the position features: [pos_map | h4] is the skip's concat (model.py:108)
+    // the pad columns of the concat buffers meet zero weights: they only have to be finite
+    if (hipMemset(t->h4c, 0, (size_t)M * t->ldp * sizeof(float)) != hipSuccess || hipMemset(t->fc, 0, (size_t)M * t->ldd * sizeof(float)) != hipSuccess) {
+        free_all(t); return ntx_set_error(NTX_E_HIP, "hipMemset failed");
+    }
+    t->h[4] = t->h4c + t->Kp4;                    // trunk layer 4 writes behind the position features: [pos_map | h4] is the skip's concat (model.py:108)
+    {   // the packed images: where each lies and what it is gathered from
+        PackArgs &pa = t->pack;
+        long long first = 0;
+        auto job = [&](const float *src, long long sk, long long sc, int K1, int K1p, int K2, int n_out, const float **recs, int *kblocks) {
+            PackJob &j = pa.job[pa.n_jobs++];
+            j.src = src; j.sk = sk; j.sc = sc; j.K1 = K1; j.K1p = K1p; j.K2 = K2; j.nt = n_out / 32;
+            j.kblocks = ((K1p + K2 + 7) / 8 + 3) / 4 * 4;
+            j.first = first; j.dst = nullptr;
+            *kblocks = j.kblocks;
+            *recs = (const float *)(uintptr_t)first;          // an offset until the buffer exists
+            first += (long long)j.kblocks * 8 * n_out;
+        };
+        auto fwd = [&](const TLayer &l, int K1, int K1p, int K2, int slot) { job(t->w + l.w, l.out, 1, K1, K1p, K2, l.out, &t->fwd_recs[slot], &t->fwd_kblocks[slot]); };
+        auto bwd = [&](const TLayer &l, int row0, int slot) { job(t->w + l.w + (size_t)row0 * l.out, 1, l.out, l.out, l.out, 0, 256, &t->bwd_recs[slot], &t->bwd_kblocks[slot]); };
+        for (int i = 0; i < 8; ++i) {
+            if (i == 5) fwd(t->trunk[i], t->Kp, t->Kp4, 256, i); else fwd(t->trunk[i], t->trunk[i].in, t->trunk[i].in, 0, i);
+        }
+        fwd(t->feature, 256, 256, 0, 8); fwd(t->c1, t->Kd, t->Kd4, 256, 9); fwd(t->c2, 256, 256, 0, 10);
+        for (int i = 1; i < 8; ++i) bwd(t->trunk[i], i == 5 ? t->Kp : 0, i - 1);      // the skip's position rows take no gradient further
+        bwd(t->feature, 0, 7); bwd(t->c1, t->Kd, 8); bwd(t->c2, 0, 9);
+        pa.total = first;
+        if (alloc(&t->wp, (size_t)first) != NTX_OK) { free_all(t); return NTX_E_HIP; }
+        for (int j = 0; j < pa.n_jobs; ++j) pa.job[j].dst = t->wp + pa.job[j].first;
+        for (int i = 0; i < 11; ++i) t->fwd_recs[i] = t->wp + (uintptr_t)t->fwd_recs[i];
+        for (int i = 0; i < 10; ++i) t->bwd_recs[i] = t->wp + (uintptr_t)t->bwd_recs[i];
+    }
     *out = t;
     return NTX_OK;
 }
@@ -731,6 +1034,7 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     const long long M = (long long)n_rays * n_samples;
     const int S = n_samples, Kp = t->Kp, Kd = t->Kd, ldp = t->ldp, ldd = t->ldd;
     const float *W = t->w;
+    hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((t->pack.total + 255) / 256)), dim3(256), 0, st, t->pack);
     // ---- forward, every activation kept ----------------------------------------------------------------------------------------
     const float *z = z_vals;
     if (!z) {
@@ -748,12 +1052,12 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
         const TLayer &l = t->trunk[i];
         const float *X = (i == 0 || i == 5) ? t->h4c : t->h[i - 1];
         const int ldx = (i == 0 || i == 5) ? ldp : (i - 1 == 4 ? ldp : 256);
-        dense_forward(st, X, ldx, l.in, W + l.w, W + l.b, 256, M, t->h[i], i == 4 ? ldp : 256, 1);
+        dense_forward(st, X, ldx, t->fwd_recs[i], t->fwd_kblocks[i], W + l.b, 256, M, t->h[i], i == 4 ? ldp : 256, 1, t->bits[i]);
     }
     hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, t->h[7], 256, 256, W + t->alpha.w, W + t->alpha.b, 1, M, t->sigma);   // :111
-    dense_forward(st, t->h[7], 256, 256, W + t->feature.w, W + t->feature.b, 256, M, t->fc + Kd, ldd, 0);                                  // :114-115
-    dense_forward(st, t->fc, ldd, Kd + 256, W + t->c1.w, W + t->c1.b, 256, M, t->c1o, 256, 1);                                             // :118-119
-    dense_forward(st, t->c1o, 256, 256, W + t->c2.w, W + t->c2.b, 128, M, t->c2o, 128, 1);                                                 // :122
+    dense_forward(st, t->h[7], 256, t->fwd_recs[8], t->fwd_kblocks[8], W + t->feature.b, 256, M, t->fc + t->Kd4, ldd, 0, nullptr);                                  // :114-115
+    dense_forward(st, t->fc, ldd, t->fwd_recs[9], t->fwd_kblocks[9], W + t->c1.b, 256, M, t->c1o, 256, 1, t->bits[8]);                                             // :118-119
+    dense_forward(st, t->c1o, 256, t->fwd_recs[10], t->fwd_kblocks[10], W + t->c2.b, 128, M, t->c2o, 128, 1, nullptr);                                                 // :122
     hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, t->c2o, 128, 128, W + t->rgb.w, W + t->rgb.b, 3, M, t->raw_rgb);   // :123
     CompositeArgs c{};
     c.raw_rgb = t->raw_rgb; c.sigma = t->sigma; c.dists = t->dists; c.n_rays = (int)n_rays; c.S = S; c.map_exr = (flags & NTX_FLAG_MAP_EXR) ? 1 : 0;
@@ -771,10 +1075,12 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     // ---- backward -----------------------------------------------------------------------------------------------------------------
     hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st, c);
     float *G = t->grad;
-    // the weight blocks dX contracts with, transposed once: Wt[out][in'] at the layer's own offset (in' = the rows that take a gradient on)
-    auto transposed = [&](const TLayer &l, int row0, int rows) {
-        hipLaunchKernelGGL(transpose_kernel, dim3((l.out + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, W + l.w + (size_t)row0 * l.out, rows, l.out, t->wt + l.w);
-        return (const float *)(t->wt + l.w);
+    // dW of a layer that reads a concat buffer [first | pad | 256 more]: two contractions when there is a pad, the bias gradient rides with the first
+    auto concat_dw = [&](const float *X, int ldx, int K1, int K1p, const float *dY, const TLayer &l) -> int {
+        if (K1 == K1p) return dense_backward_dw(t, st, X, ldx, K1 + 256, dY, 256, M, G + l.w, G + l.b);
+        const int rc1 = dense_backward_dw(t, st, X, ldx, K1, dY, 256, M, G + l.w, G + l.b);
+        if (rc1 != NTX_OK) return rc1;
+        return dense_backward_dw(t, st, X + K1p, ldx, 256, dY, 256, M, G + l.w + (size_t)K1 * 256, nullptr);
     };
     const int hb = (int)((M + HEAD_ROWS - 1) / HEAD_ROWS);
     auto head_dw = [&](const float *X, int ldx, int K, const float *dY, int n_out, const TLayer &l) {       // (kernel | bias) of a narrow head
@@ -787,26 +1093,25 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, st, t->d_raw, 3, W + t->rgb.w, 128, M, t->c2o, 128, 0, t->g0, 128);
     int rc = dense_backward_dw(t, st, t->c1o, 256, 256, t->g0, 128, M, G + t->c2.w, G + t->c2.b);
     if (rc != NTX_OK) return rc;
-    dense_backward_dx(st, t->g0, 128, transposed(t->c2, 0, 256), 256, M, t->c1o, 256, 0, t->g1, 256);            // d c1o, masked by its ReLU
-    rc = dense_backward_dw(t, st, t->fc, ldd, Kd + 256, t->g1, 256, M, G + t->c1.w, G + t->c1.b);
+    dense_backward_dx(st, t->g0, 128, t->bwd_recs[9], t->bwd_kblocks[9], M, t->bits[8], 0, t->g1, 256);         // d c1o, masked by its ReLU
+    rc = concat_dw(t->fc, ldd, Kd, t->Kd4, t->g1, t->c1);
     if (rc != NTX_OK) return rc;
-    dense_backward_dx(st, t->g1, 256, transposed(t->c1, Kd, 256), 256, M, nullptr, 0, 0, t->g0, 256);            // d feature (linear layer: no mask)
+    dense_backward_dx(st, t->g1, 256, t->bwd_recs[8], t->bwd_kblocks[8], M, nullptr, 0, t->g0, 256);          // d feature (linear layer: no mask)
     rc = dense_backward_dw(t, st, t->h[7], 256, 256, t->g0, 256, M, G + t->feature.w, G + t->feature.b);
     if (rc != NTX_OK) return rc;
     head_dw(t->h[7], 256, 256, t->d_sigma, 1, t->alpha);
     // d h7 = d_sigma (x) W_alpha + d feature . W_feature^T, masked by h7's ReLU
     hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 256 + 255) / 256)), dim3(256), 0, st, t->d_sigma, 1, W + t->alpha.w, 256, M, nullptr, 0, 0, t->g1, 256);
-    dense_backward_dx(st, t->g0, 256, transposed(t->feature, 0, 256), 256, M, t->h[7], 256, 1, t->g1, 256);
+    dense_backward_dx(st, t->g0, 256, t->bwd_recs[7], t->bwd_kblocks[7], M, t->bits[7], 1, t->g1, 256);
     float *cur = t->g1, *nxt = t->g0;
     for (int i = 7; i >= 0; --i) {
         const TLayer &l = t->trunk[i];
         const float *X = (i == 0 || i == 5) ? t->h4c : t->h[i - 1];
         const int ldx = (i == 0 || i == 5) ? ldp : 256;
-        rc = dense_backward_dw(t, st, X, ldx, l.in, cur, 256, M, G + l.w, G + l.b);
+        rc = i == 5 ? concat_dw(X, ldx, Kp, t->Kp4, cur, l) : dense_backward_dw(t, st, X, ldx, l.in, cur, 256, M, G + l.w, G + l.b);
         if (rc != NTX_OK) return rc;
         if (i == 0) break;
-        const int row0 = i == 5 ? Kp : 0;                                                           // the skip's position rows take no gradient further
-        dense_backward_dx(st, cur, 256, transposed(l, row0, 256), 256, M, t->h[i - 1], (i - 1 == 4) ? ldp : 256, 0, nxt, 256);
+        dense_backward_dx(st, cur, 256, t->bwd_recs[i - 1], t->bwd_kblocks[i - 1], M, t->bits[i - 1], 0, nxt, 256);
         float *tmp = cur; cur = nxt; nxt = tmp;
     }
     if (color_pred) TRAIN_TRY(hipMemcpyAsync(color_pred, t->color, (size_t)n_rays * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
