@@ -266,15 +266,28 @@ __global__ void reduce_partials_kernel(const float *__restrict__ partial, int n_
 // ---------------------------------------------------------------------------------------------------------------------------
 // The two contractions of a step whose reduction is SHORT (the layer's width) and whose other side is the samples -- forward Y = X . W and
 // dX = dY . W^T -- the way the render kernel does a layer (ntx_device.h): one wave owns 32 samples and ALL of a layer's
-// outputs (8 tiles of 32 x 32 = 128 accumulator registers), computed transposed, out^T[feature][sample] = W^T . X^T on
-// v_mfma_f32_32x32x2_f32.  The B operand is the wave's own 32 rows of X, read straight from HBM 16 bytes a lane, a body (32 k) ahead.  The A
-// operand is the weights, from a PACKED image that the workgroup's four waves pull through a double-buffered LDS ring with direct
-// global -> LDS loads (one 1 KiB record per instruction; a body's 32 records in four quarters) and read back with ds_read_b128: the
-// weights cost no registers, wait on the LDS counter and not behind the HBM loads on the in-order vector-memory counter (a register ring
-// did: every X load held up the ring eight records later), and reach a CU once per workgroup instead of once per wave.  One barrier per
-// body of 128 MFMAs; every vector-memory load is asked for at the top of a body and waited for at its end.  No VALU work in the loop (the
-// f32 MFMA shares the vector ALUs' lanes: every VALU instruction costs MFMA time).  Where the 128 x 128 LDS tiles of gemm_kernel reach
-// 0.58-0.64 of the MFMA peak, this is bound by the matrix pipe.  dW = X^T . dY reduces over the samples: it stays with gemm_kernel.
+// outputs (8 tiles of 32 x 32 = 128 accumulator registers) on v_mfma_f32_32x32x2_f32.  The A operand is the wave's own 32 rows of X,
+// read straight from HBM 16 bytes a lane, a body (32 k) ahead.  The B operand is the weights, from a PACKED image that the workgroup's
+// four waves pull through a triple-buffered LDS ring with direct global -> LDS loads (one 1 KiB record per instruction; a body's 32 records
+// in four quarters) and read back with ds_read_b128 two records ahead: the weights cost no registers, wait on the LDS counter and not
+// behind the HBM loads on the in-order vector-memory counter (a register ring did: every X load held up the ring eight records later), and
+// reach a CU once per workgroup instead of once per wave.  No VALU work in the k loop (the f32 MFMA shares the vector ALUs' lanes: every
+// VALU instruction costs MFMA time).  Where the 128 x 128 LDS tiles of gemm_kernel reach 0.58-0.64 of the MFMA peak, this is bound by
+// the matrix pipe and the clock the power limit leaves it (2.25-2.38 GHz while it runs).  dW = X^T . dY reduces over the samples: it
+// stays with gemm_kernel.
+//
+// One wave per SIMD, one stream of instructions with nothing to wait for:
+//  * a body = 128 MFMAs on one 32 KiB chunk of the image.  The chunk after the next one is asked for and the workgroup's one barrier per
+//    body falls 8 MFMAs BEFORE a body's end: behind it the next chunk is known to be complete (every wave waited for its own quarter) and
+//    the buffer two chunks back to be free, so the ds_reads run on into the next chunk without a gap -- no wave ever stands at a barrier
+//    with an empty pipe behind it;
+//  * two accumulator sets: while block n + 1 accumulates into one, block n's results leave the other: made final in ONE dense block of VALU
+//    work (bias is already in; ReLU and its bits), then stored PIECE BY PIECE in the shadow of the MFMAs of block n + 1's first two bodies
+//    (one output register every second MFMA).  The stores never come in bursts (all waves of the chip storing 32 KB each at the same
+//    moment cost 3.5 us a block with the matrix pipe idle), and the wait in front of the barrier counts them out (vmcnt(stores of this
+//    body): only what is older has to be there).  VALU instructions scattered between f32 MFMAs cost 18 cycles each here, in a dense block
+//    8: hence the split.  (The mask of dX alone is applied on the way out, four outputs at a time: all 128 at once need more registers
+//    than a wave has.)
 //
 // k order.  A lane (sample m = l & 31, half h = l >> 5) loads X[m][8 q + 4 h .. + 3] in one piece; k-step s = 4 q + c then pairs
 // k = 8 q + c (lower half-wave) with k = 8 q + 4 + c (upper) -- the order of the summation over k is free.  The packed image follows:
@@ -284,28 +297,23 @@ __global__ void reduce_partials_kernel(const float *__restrict__ partial, int n_
 // descriptor returns 0).
 //
 // D of a tile (the MFMA's A operand is X, its B operand the weights): lane (f = l & 31, h), register r <-> sample 8 (r >> 2) + 4 h + (r & 3),
-// feature 32 t + f: a register is 32 consecutive features of one sample per half-wave, so a row-major Y[sample][feature] is written (and
-// an accumulate operand read) in full 128-byte lines.  The ReLU mask dX needs is not
-// read back as 268 MB of activations: the forward pass leaves ONE BIT per output, in the accumulators' own layout (lane, tile, register:
-// 128 bits = 16 bytes a lane and block), and dX -- whose outputs lie in the same layout -- reads those 8 MB.
-//
-// Launch: persistent, two workgroups of four waves per CU (one wave of each per SIMD): one workgroup's epilogues and block changes fall
-// into the other's k loops.  A block's epilogue is issued at the top of the NEXT block's first body, behind that body's loads: its stores
-// have a whole body to drain before anything waits on the vector-memory counter again.
+// feature 32 t + f: a register is 32 consecutive features of one sample per half-wave, so a row-major Y[sample][feature] is written in
+// full 128-byte lines.  The ReLU mask dX needs is not read back as 268 MB of activations: the forward pass leaves ONE BIT per output,
+// in the accumulators' own layout (lane, tile, register: 128 bits = 16 bytes a lane and block), and dX -- whose outputs lie in the same
+// layout -- reads those 8 MB.
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct RowsArgs {
     const float *X; int ldx; long long M;
-    const float *recs; int kblocks;                    // packed weights; blocks of 8 k (a multiple of 4)
+    const float *recs; int kblocks;                    // packed weights; blocks of 8 k (a multiple of 4, at least 12)
     float *Y; int ldy;
-    const float *bias; int relu;                       // forward
+    const float *bias;                                 // forward
     unsigned int *bits_out;                            // forward: one bit per output, set where it is > 0 (or NULL)
-    const unsigned int *bits_in; int accumulate;       // dX: keep where the bit is set; add to what Y holds first
-    int debug, phase;
-    unsigned long long *stamps;                        // development: [start, end] of every workgroup on the 100 MHz clock
+    const unsigned int *bits_in;                       // dX: keep where the bit is set
 };
-enum { ROWS_FORWARD = 0, ROWS_DX = 1, ROWS_DX_MASK = 2, ROWS_DX_ACC_MASK = 3 };   // what the epilogue does: a template parameter, no load of it behind a branch
+enum { ROWS_FORWARD = 0, ROWS_DX = 1, ROWS_DX_MASK = 2, ROWS_FORWARD_LINEAR = 3 };   // what the epilogue does (bias + ReLU + its bits; nothing; the mask; bias only): a template
+                                                                                  // parameter, nothing of it behind a branch
 template <int N, class F> __device__ __forceinline__ void static_for_(F &&f) {
     if constexpr (N > 0) { static_for_<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
@@ -313,158 +321,183 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void *base, lo
     const long long b = bytes < 0 ? 0 : (bytes > 0x7ffffff0ll ? 0x7ffffff0ll : bytes);
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)b, 0x00020000);
 }
-template <int NT, int MODE, int VARIANT = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rows_kernel(RowsArgs a) {
+// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima) -- as an
+// instruction the compiler's own counting sees, unlike inline assembly
+template <int N> __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt(((N >> 4) << 14) | 0x0F70 | (N & 15)); }
+
+template <int NT, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rows_kernel(RowsArgs a) {
     constexpr int G = NT / 4;                          // records per k-step
     constexpr int CHUNK = 16 * G;                      // records per body (4 blocks of 8 k = 16 k-steps): 16 or 32 KiB
-    __shared__ f32x4 lds[2 * CHUNK * 64 + NT * 8];     // two chunks, then the bias
+    constexpr int RING = 2;                            // records read ahead of the MFMAs (CHUNK is a multiple: the ring's phase is the same in every body)
+    constexpr int TAIL = CHUNK - RING - 1;             // the barrier stands behind this record's MFMAs: the next one reads ahead into the next chunk
+    __shared__ f32x4 lds[3 * CHUNK * 64 + NT * 8];     // three chunks, then the bias
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long n_blocks = (a.M + 31) / 32, n_groups = (n_blocks + 3) / 4;
-    const int nb = a.kblocks / 4;
+    const int nb = a.kblocks / 4;                      // bodies per block: at least 3
     if ((long long)blockIdx.x >= n_groups) return;
-    if (a.stamps && threadIdx.x == 0) { a.stamps[2 * blockIdx.x] = wall_clock64(); a.stamps[8192 + 2 * blockIdx.x] = clock64(); }
     const __amdgpu_buffer_rsrc_t rw = rows_rsrc(a.recs, (long long)a.kblocks * NT * 1024);
-    const uint32_t woff = (uint32_t)lane * 16u, xoff = (uint32_t)(m * a.ldx + 4 * h) * 4u;
-    constexpr bool MASK = MODE == ROWS_DX_MASK || MODE == ROWS_DX_ACC_MASK;
+    const uint32_t woff = (uint32_t)lane * 16u, xoff = (uint32_t)(m * a.ldx + 4 * h) * 4u, yoff = (uint32_t)(4 * h * a.ldy + m) * 4u;
+    const uint32_t ld4 = (uint32_t)a.ldy * 4u;
+    constexpr bool MASK = MODE == ROWS_DX_MASK;
     const __amdgpu_buffer_rsrc_t rbits = rows_rsrc(MASK ? (const void *)a.bits_in : (const void *)a.recs, MASK ? n_blocks * 1024 : 0);
-    if constexpr (MODE == ROWS_FORWARD) {
-        float *bl = reinterpret_cast<float *>(&lds[2 * CHUNK * 64]);
+    const __amdgpu_buffer_rsrc_t rbo = rows_rsrc(MODE == ROWS_FORWARD && a.bits_out ? (const void *)a.bits_out : (const void *)a.recs,
+                                                 MODE == ROWS_FORWARD && a.bits_out ? n_blocks * 1024 : 0);
+    constexpr bool BIAS = MODE == ROWS_FORWARD || MODE == ROWS_FORWARD_LINEAR;
+    if constexpr (BIAS) {
+        float *bl = reinterpret_cast<float *>(&lds[3 * CHUNK * 64]);
         if ((int)threadIdx.x < NT * 32) bl[threadIdx.x] = a.bias[threadIdx.x];
     }
     // this wave's quarter of a chunk, straight into LDS: one record (64 lanes x 16 bytes, lane-linear) per instruction
-    auto fill = [&](int chunk, int buf) {
+    auto fill = [&](int chunk, int buf_byte) {
         static_for_<CHUNK / 4>([&](auto I) {
             const int r = wave * (CHUNK / 4) + I;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)&lds[(buf * CHUNK + r) * 64], 16, woff,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(lds) + buf_byte + r * 1024), 16, woff,
                                                      (uint32_t)(chunk * CHUNK + r) * 1024u, 0, 0);
         });
     };
-    auto block_rows = [&](long long grp) { return (grp * 4 + wave) * 32; };
+    auto block_rows = [&](long long grp) { return grp < n_groups ? (grp * 4 + wave) * 32 : a.M; };   // behind the last group: an empty descriptor
     auto x_rsrc = [&](long long row0) { return rows_rsrc(a.X + row0 * a.ldx, (a.M - row0) * a.ldx * 4); };
     auto xload4 = [&](const __amdgpu_buffer_rsrc_t &rx, int q0, f32x4 (&x)[4]) {
         static_for_<4>([&](auto I) { x[I] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff, (uint32_t)(q0 + I) * 32u, 0)); });
     };
-    f32x16 acc[NT];
-    auto acc_init = [&]() {
-        if constexpr (MODE == ROWS_FORWARD) {          // the accumulators start from the bias: a lane's feature is the same in all of a tile's registers
-            const float *bl = reinterpret_cast<const float *>(&lds[2 * CHUNK * 64]);
-            static_for_<NT>([&](auto T) {
-                constexpr int t = T;
-                const float b = bl[32 * t + m];
+    f32x16 accs[2][NT];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = b;
+    for (int t = 0; t < NT; ++t)                       // set 1 "leaves" once before it has been filled (into an empty descriptor): keep even that read defined
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[1][t][r] = 0.0f;
+    f32x4 x[4], xn[4], ring[RING];
+    u32x4 bits_set[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // dX: the masks of the blocks in the two accumulator sets, asked for in a block's last body (every body without an epilogue asks: no branch)
+    auto bits_out_of = [&](int set) -> u32x4 & { return bits_set[set]; };
+    // A block's outputs are made final in place in ONE dense block of VALU work (ReLU and its bits, or the mask): VALU instructions
+    // scattered between f32 MFMAs cost several times their own issue time (the f32 MFMA runs on the vector ALUs' lanes;
+    // measured here, 20 cycles an instruction) -- only the stores, which need no ALU, are spread over the next block's MFMAs.
+    // The bit of (tile t, register r) lies in word t >> 1 at position 16 (t & 1) + r.
+    auto finalize = [&](auto SETc, long long blk) {
+        constexpr int SET = SETc;
+        if constexpr (MODE == ROWS_FORWARD) {
+            u32x4 out_bits = {0u, 0u, 0u, 0u};
+            static_for_<NT>([&](auto T) {
+                static_for_<16>([&](auto R) {
+                    constexpr int t = T, r = R;
+                    const float v = fmaxf(accs[SET][t][r], 0.0f);
+                    accs[SET][t][r] = v;
+                    const int one = __builtin_bit_cast(int, v) < 1 ? __builtin_bit_cast(int, v) : 1;       // v >= 0: its bits as an integer are 0 or positive
+                    out_bits[t >> 1] |= (unsigned)one << (16 * (t & 1) + r);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out_bits), rbo, woff, (uint32_t)blk * 1024u, 0);
+        }
+    };
+    // output register (tile t, register r) leaves: two full 128-byte lines
+    // (dX under a mask: the mask goes on here, four outputs at a time -- 8 VALU instructions in one piece every 8 MFMAs; all 128 at once
+    // need more registers than there are, one at a time between the MFMAs costs 18 us a launch)
+    auto element = [&](auto SETc, auto Tc, auto Rc, const __amdgpu_buffer_rsrc_t &ry) {
+        constexpr int SET = SETc, t = Tc, r = Rc;
+        float v = accs[SET][t][r];                     // (a vector element is not an lvalue __builtin_bit_cast can take: it would read element 0)
+        if constexpr (MASK) {
+            const int keep = __builtin_amdgcn_sbfe((int)bits_out_of(SET)[t >> 1], 16 * (t & 1) + r, 1);   // 0 or -1
+            v = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keep);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff + (uint32_t)t * 128u, (uint32_t)(8 * (r >> 2) + (r & 3)) * ld4, 0);
+    };
+    auto acc_init = [&](auto SETc) {
+        constexpr int SET = SETc;
+        if constexpr (BIAS) {                          // the accumulators start from the bias: a lane's feature is the same in all of a tile's registers
+            const float *bl = reinterpret_cast<const float *>(&lds[3 * CHUNK * 64]);
+            static_for_<NT>([&](auto T) {
+                const float b = bl[32 * T + m];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[SET][T][r] = b;
             });
         } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) accs[SET][t][r] = 0.0f;
         }
     };
-    // the epilogue of the block at row0: register r of tile t is 32 consecutive features of one sample per half-wave -- a store writes two
-    // full 128-byte lines (16-byte pieces of four features scattered over 32 rows cost the L2 four times the requests: measured, 9 us a
-    // block); rows behind the matrix fall outside the descriptor (loads 0, stores dropped)
-    unsigned long long epi_cycles = 0;
-    auto epilogue = [&](long long row0, u32x4 bits) {
-        if (a.debug & 8) return;
-        const unsigned long long e0 = a.stamps ? clock64() : 0;
-        const long long yrow = (a.debug & 128) ? (row0 & 8191) : row0;       // development: every block stores into the same 8 MB
-        const __amdgpu_buffer_rsrc_t ry = rows_rsrc(a.Y + yrow * a.ldy, (a.debug & 64) ? 0 : (a.M - yrow) * a.ldy * 4);   // development: stores dropped at the descriptor
-        const uint32_t yoff = (uint32_t)(4 * h * a.ldy + m) * 4u;
-        const float lo = a.relu ? 0.0f : -__builtin_inff();
-        u32x4 out_bits = {0u, 0u, 0u, 0u};
-        static_for_<16>([&](auto R) {
-            constexpr int r = R;
-            const uint32_t rowb = (uint32_t)((8 * (r >> 2) + (r & 3)) * a.ldy) * 4u;
-            float old[NT];
-            if constexpr (MODE == ROWS_DX_ACC_MASK)
-                static_for_<NT>([&](auto T) { old[T] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yoff, rowb + (uint32_t)T * 128u, 0)); });
-            static_for_<NT>([&](auto T) {
-                constexpr int t = T;
-                float v = acc[t][r];
-                if constexpr (MODE == ROWS_FORWARD) {
-                    v = fmaxf(v, lo);
-                    out_bits[t >> 1] |= v > 0.0f ? 1u << (16 * (t & 1) + r) : 0u;
-                }
-                if constexpr (MODE == ROWS_DX_ACC_MASK) v += old[t];
-                if constexpr (MASK) {                                      // covers what was there too (d h7 = (alpha's part + feature's part) where h7 > 0)
-                    const int keep = __builtin_amdgcn_sbfe((int)bits[t >> 1], 16 * (t & 1) + r, 1);   // 0 or -1
-                    v = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keep);
-                }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff, rowb + (uint32_t)t * 128u, 0);
-            });
-        });
-        if constexpr (MODE == ROWS_FORWARD)
-            if (a.bits_out) {
-                const __amdgpu_buffer_rsrc_t rbo = rows_rsrc(a.bits_out, n_blocks * 1024);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out_bits), rbo, woff, (uint32_t)(row0 / 32) * 1024u, 0);
-            }
-        if (a.stamps) epi_cycles += clock64() - e0;
-    };
-    f32x4 xn[4];
-    u32x4 bits_n = {0u, 0u, 0u, 0u};
+    // LDS byte offsets of the chunk being read, the next one, the one after (being filled): they rotate
+    int buf0 = 0, buf1 = CHUNK * 1024, buf2 = 2 * CHUNK * 1024;
     long long grp = blockIdx.x;
-    if (a.phase > 0) {                                 // the second workgroup of a CU starts a.phase quarter-bodies (of 2048 cycles) late
-        const unsigned slot = (a.debug & 32) ? (blockIdx.x >= gridDim.x / 2 ? 1u : 0u) : (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1u);   // HW_ID[3:0]: the wave's slot on its SIMD
-        if (__builtin_amdgcn_readfirstlane(slot)) {
-            const int naps = a.phase * 2048 / 64;
-            for (int i = 0; i < naps / 127; ++i) __builtin_amdgcn_s_sleep(127);
-            for (int i = 0; i < (naps % 127) / 8; ++i) __builtin_amdgcn_s_sleep(8);
-        }
-    }
+    __amdgpu_buffer_rsrc_t rx = x_rsrc(block_rows(grp)), rxn = x_rsrc(block_rows(grp + gridDim.x));
     {
-        fill(0, 0);
-        xload4(x_rsrc(block_rows(grp)), 0, xn);
-        if constexpr (MASK) bits_n = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbits, woff, (uint32_t)(block_rows(grp) / 32) * 1024u, 0));
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): an instruction the compiler's own counting sees, unlike inline assembly
+        fill(0, buf0); fill(1, buf1);
+        xload4(rx, 0, x);
+        wait_vmcnt<0>();
         __syncthreads();
+        const f32x4 *L = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(lds) + buf0) + lane;
+        static_for_<RING>([&](auto I) { ring[I] = L[I * 64]; });
     }
-    int buf = 0;
-    bool have_prev = false;
-    const __amdgpu_buffer_rsrc_t rx0 = x_rsrc(block_rows(blockIdx.x));
-    long long prev_row0 = 0;
-    u32x4 prev_bits = {0u, 0u, 0u, 0u}, bits = {0u, 0u, 0u, 0u};
-    for (; grp < n_groups; grp += gridDim.x) {
-        const long long row0 = block_rows(grp);
-        const long long next_grp = grp + gridDim.x;
-        const long long row0n = next_grp < n_groups ? block_rows(next_grp) : a.M;      // nothing behind the last group: an empty descriptor
-        const __amdgpu_buffer_rsrc_t rx = x_rsrc(row0), rxn = x_rsrc(row0n);
-        bits = bits_n;
-        for (int b = 0; b < nb; ++b) {
-            f32x4 x[4] = {xn[0], xn[1], xn[2], xn[3]};
-            const bool last = b == nb - 1;
-            // what the next body needs, asked for now
-            fill((last || (a.debug & 4)) ? 0 : b + 1, buf ^ 1);
-            xload4((a.debug & 2) ? rx0 : (last ? rxn : rx), (last || (a.debug & 2)) ? 0 : 4 * (b + 1), xn);
-            if constexpr (MASK) bits_n = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbits, woff, (uint32_t)((last ? row0n : row0) / 32) * 1024u, 0));
-            if (b == 0) {
-                if (have_prev) epilogue(prev_row0, prev_bits);
-                acc_init();
-            }
-            const f32x4 *L = &lds[buf * CHUNK * 64 + lane];
-            f32x4 w0 = L[0], w1 = L[64];
-            static_for_<CHUNK>([&](auto IDX) {
-                constexpr int idx = IDX, ks = idx / G, gi = idx % G, qi = ks / 4, c = ks % 4;
-                f32x4 w;
-                if constexpr (idx % 2 == 0) { w = w0; if constexpr (idx + 2 < CHUNK && !(VARIANT & 1)) w0 = L[(idx + 2) * 64]; }
-                else { w = w1; if constexpr (idx + 2 < CHUNK && !(VARIANT & 1)) w1 = L[(idx + 2) * 64]; }
-                static_for_<4>([&](auto T) {
-                    constexpr int tt = T, tile = 4 * gi + T;
-                    acc[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[qi][c], w[tt], acc[tile], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
+    // one body: EP = 0 nothing else, 1 / 2 the first / second half of the previous block's outputs leave from the other accumulator set
+    auto body = [&](auto SETc, auto EPc, int b, const __amdgpu_buffer_rsrc_t &ry) {
+        constexpr int SET = SETc, EP = EPc;
+        const bool last = b == nb - 1;
+        xload4(last ? rxn : rx, last ? 0 : 4 * (b + 1), xn);
+        if constexpr (MASK && EP == 0) bits_set[SET] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbits, woff, (uint32_t)(block_rows(grp) / 32) * 1024u, 0));
+        const f32x4 *L = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(lds) + buf0) + lane;
+        const f32x4 *Ln = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(lds) + buf1) + lane;
+        static_for_<CHUNK>([&](auto IDX) {
+            constexpr int idx = IDX, ks = idx / G, gi = idx % G, qi = ks / 4, c = ks % 4;
+            const f32x4 w = ring[idx % RING];
+            if constexpr (idx + RING < CHUNK) ring[idx % RING] = L[(idx + RING) * 64];
+            else ring[idx % RING] = Ln[(idx + RING - CHUNK) * 64];      // behind the barrier: the next chunk's first records
+            static_for_<4>([&](auto T) {
+                constexpr int tt = T, tile = 4 * gi + T;
+                accs[SET][tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[qi][c], w[tt], accs[SET][tile], 0, 0, 0);
+                // output e = 0 .. 8 NT - 1 of this half of the block: register-major, so that a sample's stores follow each other
+                auto leave = [&](auto Ec) {
+                    constexpr int e = Ec, r = e / (NT / 2), t = (EP - 1) * (NT / 2) + e % (NT / 2);
+                    element(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, t>{}, std::integral_constant<int, r>{}, ry);
+                };
+                if constexpr (EP != 0 && !MASK && (tt == 0 || tt == 2)) leave(std::integral_constant<int, 2 * idx + tt / 2>{});
+                if constexpr (EP != 0 && MASK && idx % 2 == 0 && tt == 0) static_for_<4>([&](auto I) { leave(std::integral_constant<int, 2 * idx + I>{}); });
+                __builtin_amdgcn_sched_barrier(0);
             });
-            if constexpr (!(VARIANT & 2)) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): an instruction the compiler's own counting sees, unlike inline assembly
-            __syncthreads();
+            if constexpr (idx == TAIL) {
+                // what is older than this body's stores -- the next chunk's quarter, the next body's X -- has to be there; then everyone's is, and
+                // nobody reads the chunk before this one any more: its buffer takes the chunk after the next
+                wait_vmcnt<(EP == 0 ? 0 : MASK ? 4 * (TAIL / 2 + 1) : 2 * (TAIL + 1))>();
+                __builtin_amdgcn_s_barrier();
+                const int chunk2 = b + 2 < nb ? b + 2 : b + 2 - nb;
+                fill(chunk2, buf2);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            buf ^= 1;
-        }
-        have_prev = true; prev_row0 = row0; prev_bits = bits;
+        });
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = xn[i];
+        const int tmp = buf0; buf0 = buf1; buf1 = buf2; buf2 = tmp;
+    };
+    // a block into accumulator set SET; the block before it (at prev_row0, in the other set) leaves meanwhile
+    auto block = [&](auto SETc, long long prev_row0) {
+        const __amdgpu_buffer_rsrc_t ry = rows_rsrc(a.Y + prev_row0 * a.ldy, (a.M - prev_row0) * a.ldy * 4);
+        acc_init(SETc);
+        body(SETc, std::integral_constant<int, 1>{}, 0, ry);
+        body(SETc, std::integral_constant<int, 2>{}, 1, ry);
+        for (int b = 2; b < nb; ++b) body(SETc, std::integral_constant<int, 0>{}, b, ry);
+    };
+    long long prev_row0 = a.M;                         // no block before the first: its stores fall outside an empty descriptor
+    int set = 0;
+    for (;;) {
+        block(std::integral_constant<int, 0>{}, prev_row0);
+        prev_row0 = block_rows(grp); set = 0;
+        finalize(std::integral_constant<int, 0>{}, prev_row0 / 32);
+        grp += gridDim.x; rx = rxn; rxn = x_rsrc(block_rows(grp + gridDim.x));
+        if (grp >= n_groups) break;
+        block(std::integral_constant<int, 1>{}, prev_row0);
+        prev_row0 = block_rows(grp); set = 1;
+        finalize(std::integral_constant<int, 1>{}, prev_row0 / 32);
+        grp += gridDim.x; rx = rxn; rxn = x_rsrc(block_rows(grp + gridDim.x));
+        if (grp >= n_groups) break;
     }
-    if (have_prev) epilogue(prev_row0, prev_bits);
-    if (a.stamps && threadIdx.x == 0) { a.stamps[2 * blockIdx.x + 1] = wall_clock64(); a.stamps[8192 + 2 * blockIdx.x + 1] = clock64(); a.stamps[12288 + blockIdx.x] = epi_cycles; }
+    // the last block's outputs
+    {
+        const __amdgpu_buffer_rsrc_t ry = rows_rsrc(a.Y + prev_row0 * a.ldy, (a.M - prev_row0) * a.ldy * 4);
+        if (set == 0) static_for_<16>([&](auto R) { static_for_<NT>([&](auto T) { element(std::integral_constant<int, 0>{}, T, R, ry); }); });
+        else static_for_<16>([&](auto R) { static_for_<NT>([&](auto T) { element(std::integral_constant<int, 1>{}, T, R, ry); }); });
+    }
 }
 
 // the packed images of every layer, both directions, in one launch (the weights move every step)
@@ -796,63 +829,24 @@ int split_parts(long long K, int n_split) {
 }
 
 // Y = act(X . W + b) through the layer's packed image: X [M][..] (row stride ldx), Y [M][N] (row stride ldy)
-void launch_rows(hipStream_t st, const RowsArgs &r, int N) {
+void launch_rows(hipStream_t st, const RowsArgs &a, int N, int relu) {
     static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    const long long n_groups = ((r.M + 31) / 32 + 3) / 4;
-    static const int per_cu = [] { const char *e = getenv("NERFTEX_ROWS_WGS"); return e ? atoi(e) : 2; }();   // development
-    const dim3 grid((unsigned)(n_groups < per_cu * cus ? n_groups : per_cu * cus)), wg(256);
-    RowsArgs a = r;
-    { static const char *dbg = getenv("NERFTEX_ROWS_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
-    { static const char *ph = getenv("NERFTEX_ROWS_PHASE"); a.phase = ph ? atoi(ph) : 0; }
-    {
-        static unsigned long long *stamps = [] { unsigned long long *p = nullptr; if (getenv("NERFTEX_ROWS_STAMPS")) (void)hipMalloc((void **)&p, 16384 * 8); return p; }();
-        a.stamps = stamps;
-    }
+    const long long n_groups = ((a.M + 31) / 32 + 3) / 4;
+    const dim3 grid((unsigned)(n_groups < cus ? n_groups : cus)), wg(256);     // persistent: a workgroup of four waves per CU
     if (N != 256) hipLaunchKernelGGL((rows_kernel<4, ROWS_FORWARD>), grid, wg, 0, st, a);
-    else if (a.bias) hipLaunchKernelGGL((rows_kernel<8, ROWS_FORWARD>), grid, wg, 0, st, a);
-    else if (!a.bits_in) {
-        static const int variant = [] { const char *e = getenv("NERFTEX_ROWS_VARIANT"); return e ? atoi(e) : 0; }();   // development
-        if (variant == 1) hipLaunchKernelGGL((rows_kernel<8, ROWS_DX, 1>), grid, wg, 0, st, a);
-        else if (variant == 2) hipLaunchKernelGGL((rows_kernel<8, ROWS_DX, 2>), grid, wg, 0, st, a);
-        else if (variant == 3) hipLaunchKernelGGL((rows_kernel<8, ROWS_DX, 3>), grid, wg, 0, st, a);
-        else hipLaunchKernelGGL((rows_kernel<8, ROWS_DX>), grid, wg, 0, st, a);
-    }
-    else if (!a.accumulate) hipLaunchKernelGGL((rows_kernel<8, ROWS_DX_MASK>), grid, wg, 0, st, a);
-    else hipLaunchKernelGGL((rows_kernel<8, ROWS_DX_ACC_MASK>), grid, wg, 0, st, a);
-    if (a.stamps) {                                    // development: when did the workgroups run
-        (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h(12288 + grid.x);
-        (void)hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost);
-        unsigned long long t0 = ~0ull, t1 = 0;
-        for (unsigned i = 0; i < grid.x; ++i) { if (h[2 * i] < t0) t0 = h[2 * i]; if (h[2 * i + 1] > t1) t1 = h[2 * i + 1]; }
-        double s_sum = 0, e_sum = 0, s_max = 0, e_min = 1e30, life = 0;
-        for (unsigned i = 0; i < grid.x; ++i) {
-            const double sa = (h[2 * i] - t0) * 0.01, en = (h[2 * i + 1] - t0) * 0.01;
-            s_sum += sa; e_sum += en; if (sa > s_max) s_max = sa; if (en < e_min) e_min = en; life += en - sa;
-        }
-        if (getenv("NERFTEX_ROWS_STAMPS")[0] == '2') {
-            for (int x = 0; x < 8; ++x) {
-                double mn = 1e30, mx = 0, sm = 0; int n = 0;
-                for (unsigned i = x; i < grid.x; i += 8) { const double en = (h[2 * i + 1] - t0) * 0.01; mn = en < mn ? en : mn; mx = en > mx ? en : mx; sm += en; ++n; }
-                fprintf(stderr, "   blockIdx %% 8 = %d: end min %.1f mean %.1f max %.1f\n", x, mn, sm / n, mx);
-            }
-            for (unsigned i = 0; i < grid.x; i += 8) fprintf(stderr, "%s%.0f", i % 256 == 0 ? "\n   xcd0 ends: " : " ", (h[2 * i + 1] - t0) * 0.01);
-            fprintf(stderr, "\n");
-        }
-        fprintf(stderr, "epilogue cycles wg0 %.0f wg%u %.0f; ", (double)h[12288], grid.x - 1, (double)h[12288 + grid.x - 1]);
-        fprintf(stderr, "workgroup 0: %.0f shader cycles in %.2f us = %.3f GHz;  ", (double)(h[8193] - h[8192]), (h[1] - h[0]) * 0.01, (double)(h[8193] - h[8192]) / ((h[1] - h[0]) * 10.0));
-        fprintf(stderr, "rows N=%d kblocks=%d mode bias=%d bits=%d acc=%d: span %.1f us; start mean %.1f max %.1f; end mean %.1f min %.1f; life mean %.1f\n", N, a.kblocks, a.bias != nullptr,
-                a.bits_in != nullptr, a.accumulate, (t1 - t0) * 0.01, s_sum / grid.x, s_max, e_sum / grid.x, e_min, life / grid.x);
-    }
+    else if (a.bias && relu) hipLaunchKernelGGL((rows_kernel<8, ROWS_FORWARD>), grid, wg, 0, st, a);
+    else if (a.bias) hipLaunchKernelGGL((rows_kernel<8, ROWS_FORWARD_LINEAR>), grid, wg, 0, st, a);
+    else if (!a.bits_in) hipLaunchKernelGGL((rows_kernel<8, ROWS_DX>), grid, wg, 0, st, a);
+    else hipLaunchKernelGGL((rows_kernel<8, ROWS_DX_MASK>), grid, wg, 0, st, a);
 }
 void dense_forward(hipStream_t st, const float *X, int ldx, const float *recs, int kblocks, const float *b, int N, long long M, float *Y, int ldy, int relu, unsigned int *bits_out) {
-    RowsArgs r{}; r.X = X; r.ldx = ldx; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = Y; r.ldy = ldy; r.bias = b; r.relu = relu; r.bits_out = bits_out;
-    launch_rows(st, r, N);
+    RowsArgs r{}; r.X = X; r.ldx = ldx; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = Y; r.ldy = ldy; r.bias = b; r.bits_out = bits_out;
+    launch_rows(st, r, N, relu);
 }
 // dX = dY . W^T (the image packed from the layer's own block, transposed on the way), kept where the forward pass left a bit:  dY [M][N], dX [M][256]
-void dense_backward_dx(hipStream_t st, const float *dY, int N, const float *recs, int kblocks, long long M, const unsigned int *bits, int accumulate, float *dX, int lddx) {
-    RowsArgs r{}; r.X = dY; r.ldx = N; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = dX; r.ldy = lddx; r.bits_in = bits; r.accumulate = accumulate;
-    launch_rows(st, r, 256);
+void dense_backward_dx(hipStream_t st, const float *dY, int N, const float *recs, int kblocks, long long M, const unsigned int *bits, float *dX, int lddx) {
+    RowsArgs r{}; r.X = dY; r.ldx = N; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = dX; r.ldy = lddx; r.bits_in = bits;
+    launch_rows(st, r, 256, 0);
 }
 // dW = X^T . dY and db = the column sums of dY (riding along in the same kernel), both through partial sums added up in a fixed order;
 // kernel [K][N] and bias [N] are neighbours in the blob
@@ -1093,16 +1087,16 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, st, t->d_raw, 3, W + t->rgb.w, 128, M, t->c2o, 128, 0, t->g0, 128);
     int rc = dense_backward_dw(t, st, t->c1o, 256, 256, t->g0, 128, M, G + t->c2.w, G + t->c2.b);
     if (rc != NTX_OK) return rc;
-    dense_backward_dx(st, t->g0, 128, t->bwd_recs[9], t->bwd_kblocks[9], M, t->bits[8], 0, t->g1, 256);         // d c1o, masked by its ReLU
+    dense_backward_dx(st, t->g0, 128, t->bwd_recs[9], t->bwd_kblocks[9], M, t->bits[8], t->g1, 256);         // d c1o, masked by its ReLU
     rc = concat_dw(t->fc, ldd, Kd, t->Kd4, t->g1, t->c1);
     if (rc != NTX_OK) return rc;
-    dense_backward_dx(st, t->g1, 256, t->bwd_recs[8], t->bwd_kblocks[8], M, nullptr, 0, t->g0, 256);          // d feature (linear layer: no mask)
+    dense_backward_dx(st, t->g1, 256, t->bwd_recs[8], t->bwd_kblocks[8], M, nullptr, t->g0, 256);          // d feature (linear layer: no mask)
     rc = dense_backward_dw(t, st, t->h[7], 256, 256, t->g0, 256, M, G + t->feature.w, G + t->feature.b);
     if (rc != NTX_OK) return rc;
     head_dw(t->h[7], 256, 256, t->d_sigma, 1, t->alpha);
-    // d h7 = d_sigma (x) W_alpha + d feature . W_feature^T, masked by h7's ReLU
-    hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 256 + 255) / 256)), dim3(256), 0, st, t->d_sigma, 1, W + t->alpha.w, 256, M, nullptr, 0, 0, t->g1, 256);
-    dense_backward_dx(st, t->g0, 256, t->bwd_recs[7], t->bwd_kblocks[7], M, t->bits[7], 1, t->g1, 256);
+    // d h7 = (d feature . W_feature^T + d_sigma (x) W_alpha) where h7 > 0: the wide part first, the 1-wide head adds its own and masks
+    dense_backward_dx(st, t->g0, 256, t->bwd_recs[7], t->bwd_kblocks[7], M, nullptr, t->g1, 256);
+    hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 256 + 255) / 256)), dim3(256), 0, st, t->d_sigma, 1, W + t->alpha.w, 256, M, t->h[7], 256, 1, t->g1, 256);
     float *cur = t->g1, *nxt = t->g0;
     for (int i = 7; i >= 0; --i) {
         const TLayer &l = t->trunk[i];
@@ -1111,7 +1105,7 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
         rc = i == 5 ? concat_dw(X, ldx, Kp, t->Kp4, cur, l) : dense_backward_dw(t, st, X, ldx, l.in, cur, 256, M, G + l.w, G + l.b);
         if (rc != NTX_OK) return rc;
         if (i == 0) break;
-        dense_backward_dx(st, cur, 256, t->bwd_recs[i - 1], t->bwd_kblocks[i - 1], M, t->bits[i - 1], 0, nxt, 256);
+        dense_backward_dx(st, cur, 256, t->bwd_recs[i - 1], t->bwd_kblocks[i - 1], M, t->bits[i - 1], nxt, 256);
         float *tmp = cur; cur = nxt; nxt = tmp;
     }
     if (color_pred) TRAIN_TRY(hipMemcpyAsync(color_pred, t->color, (size_t)n_rays * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -2,7 +2,7 @@
 # GPU box: the rows kernel with parts switched off (NERFTEX_ROWS_DEBUG bits: 1 no stagger, 2 no X stream, 4 no weight stream, 8 no epilogue)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4rows; mkdir -p $O; cd $R
-for D in ${DBG_LIST:-0 1 8}; do
+for D in ${DBG_LIST:-0}; do
   NERFTEX_ROWS_PHASE=${D#*p} NERFTEX_ROWS_DEBUG=${D%p*} timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt$D -o kt -- python bench.py --workload carpet_train_step --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   python - $D <<'PY'
 import csv, sys, os
