@@ -263,6 +263,23 @@ __global__ void reduce_partials_kernel(const float *__restrict__ partial, int n_
     for (int q = 0; z < n_split; ++z, ++q) s4[q] += partial[(size_t)z * stride + e];
     out[e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
+// the same for FEW elements and MANY partial sums (the narrow heads: a thousand row blocks of 257 or 771 numbers): 32 elements a block,
+// 8 threads each taking every 8th partial sum, their results added in order -- as fixed an order as the above, an eighth of the chain
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float *__restrict__ partial, int n_split, long long stride, long long count, float *__restrict__ out) {
+    __shared__ float part[8][32];
+    const int slice = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    const long long e = (long long)blockIdx.x * 32 + lane;
+    float sum = 0.0f;
+    if (e < count)
+        for (int z = slice; z < n_split; z += 8) sum += partial[(size_t)z * stride + e];
+    part[slice][lane] = sum;
+    __syncthreads();
+    if (slice == 0 && e < count) {
+        float total = part[0][lane];
+        for (int q = 1; q < 8; ++q) total += part[q][lane];
+        out[e] = total;
+    }
+}
 // ---------------------------------------------------------------------------------------------------------------------------
 // The two contractions of a step whose reduction is SHORT (the layer's width) and whose other side is the samples -- forward Y = X . W and
 // dX = dY . W^T -- the way the render kernel does a layer (ntx_device.h): one wave owns 32 samples and ALL of a layer's
@@ -502,8 +519,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // the packed images of every layer, both directions, in one launch (the weights move every step)
 struct PackJob {
-    const float *src; long long sk, sc;               // Wsrc[k][col] = src[krow(k) * sk + col * sc]
-    int K1, K1p, K2;                                  // k < K1: row k; K1 <= k < K1p: the pad, zero; then K2 more rows; zero behind
+    const float *src; long long sk, sc;               // k < K1: Wsrc[k][col] = src[k * sk + col * sc]
+    const float *src2; long long sk2, sc2;            // K1p <= k < K1p + K2: src2[(k - K1p) * sk2 + col * sc2]
+    int K1, K1p, K2;                                  // K1 <= k < K1p: the pad of a concat buffer, zero; zero behind K1p + K2
     int nt, kblocks;
     float *dst; long long first;                      // where the image lies; the job's first float in the launch's index space
 };
@@ -521,8 +539,10 @@ __global__ void pack_records_kernel(PackArgs a) {
     const int G = p.nt / 4, g = (int)(rec % G), s = (int)(rec / G);
     const int f = lane & 31, h = lane >> 5;
     const int k = 8 * (s >> 2) + 4 * h + (s & 3), col = 32 * (4 * g + c) + f;
-    const int row = k < p.K1 ? k : (k < p.K1p ? -1 : (k < p.K1p + p.K2 ? p.K1 + (k - p.K1p) : -1));
-    p.dst[o] = row < 0 ? 0.0f : p.src[row * p.sk + col * p.sc];
+    float v = 0.0f;
+    if (k < p.K1) v = p.src[k * p.sk + col * p.sc];
+    else if (k >= p.K1p && k < p.K1p + p.K2) v = p.src2[(k - p.K1p) * p.sk2 + col * p.sc2];
+    p.dst[o] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -604,6 +624,11 @@ __global__ void head_backward_dx_kernel(const float *__restrict__ dY, int n_out,
     if (accumulate) v += *d;
     if (mask && !(mask[(size_t)m * ldmask + k] > 0.0f)) v = 0.0f;
     *d = v;
+}
+// dst[m * ld] = src[m]: a column of a row-major matrix
+__global__ void column_kernel(const float *__restrict__ src, long long M, float *__restrict__ dst, int ld) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < M) dst[m * ld] = src[m];
 }
 // (dW | db) partial over a block of rows: block b, thread k < K: sum_m X[m][k] dY[m][c]; thread K: sum_m dY[m][c] (the bias row: kernel and
 // bias are neighbours in the blob).  partial[b][K + 1][n_out]
@@ -775,6 +800,7 @@ struct ntx_trainer {
     // activations (per sample): h[i] = output of trunk layer i (h[4] lives inside h4c), c1o, c2o; concat buffers; heads' raw outputs
     float *h[8] = {}, *h4c = nullptr, *fc = nullptr, *c1o = nullptr, *c2o = nullptr, *raw_rgb = nullptr, *sigma = nullptr;
     unsigned int *bits[9] = {};                // where h[0..7] and c1o are > 0, one bit per output in rows_kernel's layout (1 KiB per 32 samples)
+    float *gf = nullptr;                       // [d feature (256) | d_sigma | 3 zeros] per sample, row stride LDGF
     float *z = nullptr, *dists = nullptr, *g0 = nullptr, *g1 = nullptr, *d_raw = nullptr, *d_sigma = nullptr, *partial = nullptr;
     float *color = nullptr, *alpha_out = nullptr, *d_color = nullptr, *d_alpha = nullptr, *loss = nullptr;
     long long cap_rays = 0;
@@ -788,11 +814,12 @@ using namespace ntx_train;
 
 constexpr int SPLIT = 128;        // partial sums of a weight gradient along the samples
 constexpr int HEAD_ROWS = 256;    // rows per block of the narrow reductions
+constexpr int LDGF = 260;
 
 void free_all(ntx_trainer *t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
-    void *ptrs[] = {t->w, t->wp, t->grad, t->adam_m, t->adam_v, t->h4c, t->fc, t->c1o, t->c2o, t->raw_rgb, t->sigma, t->z, t->dists, t->g0, t->g1, t->d_raw, t->d_sigma,
+    void *ptrs[] = {t->w, t->wp, t->grad, t->adam_m, t->adam_v, t->h4c, t->fc, t->c1o, t->c2o, t->raw_rgb, t->sigma, t->z, t->dists, t->g0, t->g1, t->gf, t->d_raw, t->d_sigma,
                     t->partial, t->color, t->alpha_out, t->d_color, t->d_alpha, t->loss};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 8; ++i) if (i != 4 && t->h[i]) (void)hipFree(t->h[i]);
@@ -843,18 +870,19 @@ void dense_forward(hipStream_t st, const float *X, int ldx, const float *recs, i
     RowsArgs r{}; r.X = X; r.ldx = ldx; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = Y; r.ldy = ldy; r.bias = b; r.bits_out = bits_out;
     launch_rows(st, r, N, relu);
 }
-// dX = dY . W^T (the image packed from the layer's own block, transposed on the way), kept where the forward pass left a bit:  dY [M][N], dX [M][256]
-void dense_backward_dx(hipStream_t st, const float *dY, int N, const float *recs, int kblocks, long long M, const unsigned int *bits, float *dX, int lddx) {
-    RowsArgs r{}; r.X = dY; r.ldx = N; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = dX; r.ldy = lddx; r.bits_in = bits;
+// dX = dY . W^T (the image packed from the layer's own block, transposed on the way), kept where the forward pass left a bit:  dY [M][..] (row stride lddy),
+// dX [M][256]
+void dense_backward_dx(hipStream_t st, const float *dY, int lddy, const float *recs, int kblocks, long long M, const unsigned int *bits, float *dX, int lddx) {
+    RowsArgs r{}; r.X = dY; r.ldx = lddy; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = dX; r.ldy = lddx; r.bits_in = bits;
     launch_rows(st, r, 256, 0);
 }
 // dW = X^T . dY and db = the column sums of dY (riding along in the same kernel), both through partial sums added up in a fixed order;
 // kernel [K][N] and bias [N] are neighbours in the blob
-int dense_backward_dw(ntx_trainer *t, hipStream_t st, const float *X, int ldx, int K, const float *dY, int N, long long M, float *dW, float *db) {
+int dense_backward_dw(ntx_trainer *t, hipStream_t st, const float *X, int ldx, int K, const float *dY, int N, long long M, float *dW, float *db, int lddy = 0) {
     const size_t need = (size_t)SPLIT * K * N + (size_t)SPLIT * N;
     if (need > t->partial_floats) return ntx_set_error(NTX_E_INVALID, "trainer: partial buffer too small");
     float *cs = t->partial + (size_t)SPLIT * K * N;
-    GemmArgs g{}; g.A = X; g.lda = ldx; g.B = dY; g.ldb = N; g.C = t->partial; g.ldc = N; g.M = K; g.N = N; g.K = (int)M; g.split_stride = (long long)K * N; g.colsum = db ? cs : nullptr;
+    GemmArgs g{}; g.A = X; g.lda = ldx; g.B = dY; g.ldb = lddy ? lddy : N; g.C = t->partial; g.ldc = N; g.M = K; g.N = N; g.K = (int)M; g.split_stride = (long long)K * N; g.colsum = db ? cs : nullptr;
     launch_gemm<false>(st, g, SPLIT);
     const int parts = split_parts(M, SPLIT);
     const long long count = (long long)K * N;
@@ -919,6 +947,7 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     if (rc == NTX_OK) rc = alloc(&t->dists, (size_t)M);
     if (rc == NTX_OK) rc = alloc(&t->g0, (size_t)M * 256);
     if (rc == NTX_OK) rc = alloc(&t->g1, (size_t)M * 256);
+    if (rc == NTX_OK) rc = alloc(&t->gf, (size_t)M * LDGF);
     if (rc == NTX_OK) rc = alloc(&t->d_raw, (size_t)M * 3);
     if (rc == NTX_OK) rc = alloc(&t->d_sigma, (size_t)M);
     t->partial_floats = (size_t)SPLIT * (256 + (t->Kd > t->Kp ? t->Kd : t->Kp)) * 256 + (size_t)SPLIT * 256;
@@ -937,30 +966,39 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
         rc = ntx_set_error(NTX_E_HIP, "hipMemset failed");
     if (rc != NTX_OK) { free_all(t); return rc; }
     // the pad columns of the concat buffers meet zero weights: they only have to be finite
-    if (hipMemset(t->h4c, 0, (size_t)M * t->ldp * sizeof(float)) != hipSuccess || hipMemset(t->fc, 0, (size_t)M * t->ldd * sizeof(float)) != hipSuccess) {
+    if (hipMemset(t->h4c, 0, (size_t)M * t->ldp * sizeof(float)) != hipSuccess || hipMemset(t->fc, 0, (size_t)M * t->ldd * sizeof(float)) != hipSuccess ||
+        hipMemset(t->gf, 0, (size_t)M * LDGF * sizeof(float)) != hipSuccess) {
         free_all(t); return ntx_set_error(NTX_E_HIP, "hipMemset failed");
     }
     t->h[4] = t->h4c + t->Kp4;                    // trunk layer 4 writes behind the position features: [pos_map | h4] is the skip's concat (model.py:108)
     {   // the packed images: where each lies and what it is gathered from
         PackArgs &pa = t->pack;
         long long first = 0;
-        auto job = [&](const float *src, long long sk, long long sc, int K1, int K1p, int K2, int n_out, const float **recs, int *kblocks) {
+        auto job = [&](const float *src, long long sk, long long sc, int K1, int K1p, int K2, const float *src2, long long sk2, long long sc2, int n_out, const float **recs,
+                       int *kblocks) {
             PackJob &j = pa.job[pa.n_jobs++];
-            j.src = src; j.sk = sk; j.sc = sc; j.K1 = K1; j.K1p = K1p; j.K2 = K2; j.nt = n_out / 32;
+            j.src = src; j.sk = sk; j.sc = sc; j.src2 = src2; j.sk2 = sk2; j.sc2 = sc2; j.K1 = K1; j.K1p = K1p; j.K2 = K2; j.nt = n_out / 32;
             j.kblocks = ((K1p + K2 + 7) / 8 + 3) / 4 * 4;
             j.first = first; j.dst = nullptr;
             *kblocks = j.kblocks;
             *recs = (const float *)(uintptr_t)first;          // an offset until the buffer exists
             first += (long long)j.kblocks * 8 * n_out;
         };
-        auto fwd = [&](const TLayer &l, int K1, int K1p, int K2, int slot) { job(t->w + l.w, l.out, 1, K1, K1p, K2, l.out, &t->fwd_recs[slot], &t->fwd_kblocks[slot]); };
-        auto bwd = [&](const TLayer &l, int row0, int slot) { job(t->w + l.w + (size_t)row0 * l.out, 1, l.out, l.out, l.out, 0, 256, &t->bwd_recs[slot], &t->bwd_kblocks[slot]); };
+        auto fwd = [&](const TLayer &l, int K1, int K1p, int K2, int slot) {
+            job(t->w + l.w, l.out, 1, K1, K1p, K2, t->w + l.w + (size_t)K1 * l.out, l.out, 1, l.out, &t->fwd_recs[slot], &t->fwd_kblocks[slot]);
+        };
+        auto bwd = [&](const TLayer &l, int row0, int slot) {
+            job(t->w + l.w + (size_t)row0 * l.out, 1, l.out, l.out, l.out, 0, nullptr, 0, 0, 256, &t->bwd_recs[slot], &t->bwd_kblocks[slot]);
+        };
         for (int i = 0; i < 8; ++i) {
             if (i == 5) fwd(t->trunk[i], t->Kp, t->Kp4, 256, i); else fwd(t->trunk[i], t->trunk[i].in, t->trunk[i].in, 0, i);
         }
         fwd(t->feature, 256, 256, 0, 8); fwd(t->c1, t->Kd, t->Kd4, 256, 9); fwd(t->c2, 256, 256, 0, 10);
         for (int i = 1; i < 8; ++i) bwd(t->trunk[i], i == 5 ? t->Kp : 0, i - 1);      // the skip's position rows take no gradient further
-        bwd(t->feature, 0, 7); bwd(t->c1, t->Kd, 8); bwd(t->c2, 0, 9);
+        bwd(t->c1, t->Kd, 8); bwd(t->c2, 0, 9);
+        // d h7 takes two gradients on: d feature . W_feature^T and d_sigma (x) W_alpha (model.py:111-115).  One contraction: the 1-wide head's
+        // weights are row 256 of the image, d_sigma column 256 of the buffer d feature is written to (row stride LDGF)
+        job(t->w + t->feature.w, 1, 256, 256, 256, 1, t->w + t->alpha.w, 0, 1, 256, &t->bwd_recs[7], &t->bwd_kblocks[7]);
         pa.total = first;
         if (alloc(&t->wp, (size_t)first) != NTX_OK) { free_all(t); return NTX_E_HIP; }
         for (int j = 0; j < pa.n_jobs; ++j) pa.job[j].dst = t->wp + pa.job[j].first;
@@ -1080,7 +1118,7 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     auto head_dw = [&](const float *X, int ldx, int K, const float *dY, int n_out, const TLayer &l) {       // (kernel | bias) of a narrow head
         hipLaunchKernelGGL(head_backward_dw_partial_kernel, dim3(hb), dim3(320), 0, st, X, ldx, K, dY, n_out, M, HEAD_ROWS, t->partial);
         const long long count = (long long)(K + 1) * n_out;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, t->partial, hb, count, count, G + l.w);
+        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, st, t->partial, hb, count, count, G + l.w);
     };
     // color head (128 -> 3): dW, db; d c2o = (d_raw . W^T) where c2o > 0
     head_dw(t->c2o, 128, 128, t->d_raw, 3, t->rgb);
@@ -1090,13 +1128,13 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     dense_backward_dx(st, t->g0, 128, t->bwd_recs[9], t->bwd_kblocks[9], M, t->bits[8], t->g1, 256);         // d c1o, masked by its ReLU
     rc = concat_dw(t->fc, ldd, Kd, t->Kd4, t->g1, t->c1);
     if (rc != NTX_OK) return rc;
-    dense_backward_dx(st, t->g1, 256, t->bwd_recs[8], t->bwd_kblocks[8], M, nullptr, t->g0, 256);          // d feature (linear layer: no mask)
-    rc = dense_backward_dw(t, st, t->h[7], 256, 256, t->g0, 256, M, G + t->feature.w, G + t->feature.b);
+    dense_backward_dx(st, t->g1, 256, t->bwd_recs[8], t->bwd_kblocks[8], M, nullptr, t->gf, LDGF);         // d feature (linear layer: no mask)
+    rc = dense_backward_dw(t, st, t->h[7], 256, 256, t->gf, 256, M, G + t->feature.w, G + t->feature.b, LDGF);
     if (rc != NTX_OK) return rc;
     head_dw(t->h[7], 256, 256, t->d_sigma, 1, t->alpha);
-    // d h7 = (d feature . W_feature^T + d_sigma (x) W_alpha) where h7 > 0: the wide part first, the 1-wide head adds its own and masks
-    dense_backward_dx(st, t->g0, 256, t->bwd_recs[7], t->bwd_kblocks[7], M, nullptr, t->g1, 256);
-    hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 256 + 255) / 256)), dim3(256), 0, st, t->d_sigma, 1, W + t->alpha.w, 256, M, t->h[7], 256, 1, t->g1, 256);
+    // d h7 = (d feature . W_feature^T + d_sigma (x) W_alpha) where h7 > 0, as ONE contraction over 257: d_sigma goes beside d feature
+    hipLaunchKernelGGL(column_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, t->d_sigma, M, t->gf + 256, LDGF);
+    dense_backward_dx(st, t->gf, LDGF, t->bwd_recs[7], t->bwd_kblocks[7], M, t->bits[7], t->g1, 256);
     float *cur = t->g1, *nxt = t->g0;
     for (int i = 7; i >= 0; --i) {
         const TLayer &l = t->trunk[i];
