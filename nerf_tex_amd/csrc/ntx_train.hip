@@ -557,73 +557,122 @@ struct EncodeArgs {
     float *dir_out; int ld_dir;      // [M][ld_dir]: dir_map in columns 0 .. Kd
     float *dists;                    // [N][S]: z[i+1] - z[i], the last one repeated, times |rays_d| (renderer.py:174-180)
 };
-__device__ __forceinline__ int fourier(float *out, const float *x, int d, int nf) {
-    int p = 0;
-    for (int c = 0; c < d; ++c) out[p++] = x[c];
-    float f = 1.0f;
-    for (int k = 0; k < nf; ++k) {
-        for (int c = 0; c < d; ++c) out[p++] = sinf(f * x[c]);
-        for (int c = 0; c < d; ++c) out[p++] = cosf(f * x[c]);
-        f *= 2.0f;
-    }
-    return p;
+// feature j of layer.FourierFeatures over x[0 .. d): [x | sin(x), cos(x) | sin(2 x), cos(2 x) | ...] (layer.py:14-23)
+__device__ __forceinline__ float fourier_feature(const float *x, int d, int j) {
+    if (j < d) return x[j];
+    const int jj = j - d, k = jj / (2 * d), r = jj - k * 2 * d;
+    const float arg = ldexpf(1.0f, k) * (r < d ? x[r] : x[r - d]);
+    return r < d ? sinf(arg) : cosf(arg);
 }
-__global__ void encode_kernel(EncodeArgs a) {
-    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= (long long)a.n_rays * a.S) return;
-    const int ray = (int)(m / a.S), s = (int)(m - (long long)ray * a.S);
-    const float o[3] = {a.rays_o[3 * ray], a.rays_o[3 * ray + 1], a.rays_o[3 * ray + 2]};
-    const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
-    const float dn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
-    const float z = a.z[(size_t)ray * a.S + s];
-    const float pos[3] = {o[0] + d[0] * z, o[1] + d[1] * z, o[2] + d[2] * z};                  // renderer.py:114 (un-normalised rays_d)
-    const float dir[3] = {d[0] / dn, d[1] / dn, d[2] / dn};                                    // :98
+// 64 samples a block: every thread works out a quarter of its sample's features into LDS, then the block writes the rows out in runs of
+// whole feature vectors (a thread writing its own sample's 153 numbers one by one, 1.3 KB from its neighbour's, ran at 0.8 TB/s)
+constexpr int ENC_SAMPLES = 64, ENC_BASE = 24;           // per sample in LDS: its features, and in front of them pos (3), dir (3), parameters (16)
+__global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
+    extern __shared__ float enc_lds[];                     // [ENC_SAMPLES][ENC_BASE], then [ENC_SAMPLES][Kp + Kd]
+    float *enc_tile = enc_lds + ENC_SAMPLES * ENC_BASE;
+    const long long M = (long long)a.n_rays * a.S;
+    const int ls = threadIdx.x & (ENC_SAMPLES - 1), part = threadIdx.x / ENC_SAMPLES;
+    const long long m = (long long)blockIdx.x * ENC_SAMPLES + ls;
     const int P = a.n_geo + a.n_app;
-    float par[16];
-    const float *pr = a.params + (size_t)(ray / a.rays_per_param_row) * P;
-    for (int c = 0; c < P; ++c) par[c] = pr[c];
-    if (a.blur_idx >= 0) par[a.blur_idx] = par[a.blur_idx] * (a.cone[ray] * z);                // :155-158
-    float *po = a.pos_out + (size_t)m * a.ld_pos;
-    int p = fourier(po, pos, 3, a.pos_freq);
-    if (a.n_geo > 0) fourier(po + p, par, a.n_geo, a.param_freq);                              // model.py:88-93
-    float *dp = a.dir_out + (size_t)m * a.ld_dir;
-    p = fourier(dp, dir, 3, a.dir_freq);
-    if (a.n_app > 0) fourier(dp + p, par + a.n_geo, a.n_app, a.param_freq);                    // :96-101
-    const float zn = s + 1 < a.S ? a.z[(size_t)ray * a.S + s + 1] : 0.0f;
-    float dist = s + 1 < a.S ? zn - z : (a.S > 1 ? z - a.z[(size_t)ray * a.S + s - 1] : 0.0f);
-    a.dists[(size_t)ray * a.S + s] = dist * dn;
+    const int Kp3 = 3 * (1 + 2 * a.pos_freq), Kpg = a.n_geo * (1 + 2 * a.param_freq), Kp = Kp3 + Kpg;
+    const int Kd3 = 3 * (1 + 2 * a.dir_freq), Kda = a.n_app * (1 + 2 * a.param_freq), Kd = Kd3 + Kda, KF = Kp + Kd;
+    float *base = enc_lds + ls * ENC_BASE;                  // (registers cannot be indexed by a feature's number: the sample's inputs go through LDS)
+    if (m < M && part == 0) {
+        const int ray = (int)(m / a.S), s = (int)(m - (long long)ray * a.S);
+        const float o[3] = {a.rays_o[3 * ray], a.rays_o[3 * ray + 1], a.rays_o[3 * ray + 2]};
+        const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
+        const float dn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+        const float z = a.z[(size_t)ray * a.S + s];
+        for (int c = 0; c < 3; ++c) { base[c] = o[c] + d[c] * z; base[3 + c] = d[c] / dn; }   // renderer.py:114 (un-normalised rays_d), :98
+        const float *pr = a.params + (size_t)(ray / a.rays_per_param_row) * P;
+        for (int c = 0; c < P; ++c) base[6 + c] = c == a.blur_idx ? pr[c] * (a.cone[ray] * z) : pr[c];   // :155-158
+        const float zn = s + 1 < a.S ? a.z[(size_t)ray * a.S + s + 1] : 0.0f;
+        const float dist = s + 1 < a.S ? zn - z : (a.S > 1 ? z - a.z[(size_t)ray * a.S + s - 1] : 0.0f);
+        a.dists[(size_t)ray * a.S + s] = dist * dn;
+    }
+    __syncthreads();
+    if (m < M) {
+        float *row = enc_tile + ls * KF;
+        for (int j = part; j < KF; j += 4) {                                                  // model.py:88-101
+            float v;
+            if (j < Kp3) v = fourier_feature(base, 3, j);
+            else if (j < Kp) v = fourier_feature(base + 6, a.n_geo, j - Kp3);
+            else if (j < Kp + Kd3) v = fourier_feature(base + 3, 3, j - Kp);
+            else v = fourier_feature(base + 6 + a.n_geo, a.n_app, j - Kp - Kd3);
+            row[j] = v;
+        }
+    }
+    __syncthreads();
+    const long long m0 = (long long)blockIdx.x * ENC_SAMPLES;
+    for (int e = threadIdx.x; e < ENC_SAMPLES * Kp; e += 256) {
+        const int r = e / Kp, j = e - r * Kp;
+        if (m0 + r < M) a.pos_out[(size_t)(m0 + r) * a.ld_pos + j] = enc_tile[r * KF + j];
+    }
+    for (int e = threadIdx.x; e < ENC_SAMPLES * Kd; e += 256) {
+        const int r = e / Kd, j = e - r * Kd;
+        if (m0 + r < M) a.dir_out[(size_t)(m0 + r) * a.ld_dir + j] = enc_tile[r * KF + Kp + j];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // the narrow heads on the vector ALUs: y[m][c] = x[m] . W[:, c] + b[c] for n_out = 1 (alpha) or 3 (color)
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ void head_forward_kernel(const float *__restrict__ X, int ldx, int K, const float *__restrict__ W, const float *__restrict__ b, int n_out,
-                                    long long M, float *__restrict__ Y) {
-    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    const f32x4 *x = reinterpret_cast<const f32x4 *>(X + (size_t)m * ldx);      // (ldx and K are multiples of 4: 256 / 128)
-    float acc[3] = {0.0f, 0.0f, 0.0f};
-    for (int k4 = 0; k4 < K / 4; ++k4) {
-        const f32x4 v = x[k4];
-        const float e[4] = {v.x, v.y, v.z, v.w};
+// A row is read by K / 4 neighbouring lanes, 16 bytes each (a wave's load is one or two whole rows); their partial sums meet by butterfly.
+// A thread takes four rows, a block's worth of rows apart: four loads in flight.  K / 4 = 64 or 32.
+__global__ __launch_bounds__(256) void head_forward_kernel(const float *__restrict__ X, int ldx, int K, const float *__restrict__ W, const float *__restrict__ b, int n_out,
+                                                           long long M, float *__restrict__ Y) {
+    const int q = K / 4, kq = threadIdx.x % q, rows = 256 / q;
+    const long long row0 = (long long)blockIdx.x * (4 * rows) + threadIdx.x / q;
+    f32x4 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            for (int c = 0; c < n_out; ++c) acc[c] += e[q] * W[(4 * k4 + q) * n_out + c];
+    for (int i = 0; i < 4; ++i) {
+        const long long m = row0 + i * rows;
+        v[i] = m < M ? *reinterpret_cast<const f32x4 *>(X + (size_t)m * ldx + 4 * kq) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
-    for (int c = 0; c < n_out; ++c) Y[(size_t)m * n_out + c] = acc[c] + b[c];
+    float w[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        for (int c = 0; c < 3; ++c) w[j][c] = c < n_out ? W[(4 * kq + j) * n_out + c] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] += e[j] * w[j][c];
+        for (int o = q / 2; o > 0; o >>= 1)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] += __shfl_xor(acc[c], o);
+        const long long m = row0 + i * rows;
+        if (kq == 0 && m < M)
+            for (int c = 0; c < n_out; ++c) Y[(size_t)m * n_out + c] = acc[c] + b[c];
+    }
 }
-// dX[m][k] (+)= sum_c dY[m][c] W[k][c], kept where mask > 0 (mask NULL: everywhere); thread per (m, k)
+// dX[m][k] (+)= sum_c dY[m][c] W[k][c], kept where mask > 0 (mask NULL: everywhere); thread per four neighbouring k of a row (K, lddx and
+// ldmask are multiples of 4)
 __global__ void head_backward_dx_kernel(const float *__restrict__ dY, int n_out, const float *__restrict__ W, int K, long long M, const float *__restrict__ mask,
                                         int ldmask, int accumulate, float *__restrict__ dX, int lddx) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= M * K) return;
-    const long long m = e / K; const int k = (int)(e - m * K);
-    float v = 0.0f;
-    for (int c = 0; c < n_out; ++c) v += dY[(size_t)m * n_out + c] * W[k * n_out + c];
-    float *d = dX + (size_t)m * lddx + k;
-    if (accumulate) v += *d;
-    if (mask && !(mask[(size_t)m * ldmask + k] > 0.0f)) v = 0.0f;
-    *d = v;
+    const int q = K / 4;
+    if (e >= M * q) return;
+    const long long m = e / q; const int k = 4 * (int)(e - m * q);
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c = 0; c < n_out; ++c) {
+        const float d = dY[(size_t)m * n_out + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += d * W[(k + j) * n_out + c];
+    }
+    f32x4 *out = reinterpret_cast<f32x4 *>(dX + (size_t)m * lddx + k);
+    if (accumulate) { const f32x4 o = *out; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+    if (mask) {
+        const f32x4 k4 = *reinterpret_cast<const f32x4 *>(mask + (size_t)m * ldmask + k);
+        if (!(k4.x > 0.0f)) v[0] = 0.0f;
+        if (!(k4.y > 0.0f)) v[1] = 0.0f;
+        if (!(k4.z > 0.0f)) v[2] = 0.0f;
+        if (!(k4.w > 0.0f)) v[3] = 0.0f;
+    }
+    *out = f32x4{v[0], v[1], v[2], v[3]};
 }
 // dst[m * ld] = src[m]: a column of a row-major matrix
 __global__ void column_kernel(const float *__restrict__ src, long long M, float *__restrict__ dst, int ld) {
@@ -638,9 +687,14 @@ __global__ void head_backward_dw_partial_kernel(const float *__restrict__ X, int
     if (k > K) return;
     const long long m0 = (long long)blockIdx.x * rows, m1 = m0 + rows < M ? m0 + rows : M;
     float acc[3] = {0.0f, 0.0f, 0.0f};
-    for (long long m = m0; m < m1; ++m) {
-        const float x = k < K ? X[(size_t)m * ldx + k] : 1.0f;
-        for (int c = 0; c < n_out; ++c) acc[c] += x * dY[(size_t)m * n_out + c];
+    for (long long m = m0; m < m1; m += 8) {               // eight rows' loads in flight; added up in row order
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = m + i < m1 ? (k < K ? X[(size_t)(m + i) * ldx + k] : 1.0f) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (m + i < m1)
+                for (int c = 0; c < n_out; ++c) acc[c] += x[i] * dY[(size_t)(m + i) * n_out + c];
     }
     for (int c = 0; c < n_out; ++c) partial[((size_t)blockIdx.x * (K + 1) + k) * n_out + c] = acc[c];
 }
@@ -1078,7 +1132,7 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
         EncodeArgs e{}; e.rays_o = rays_o; e.rays_d = rays_d; e.z = z; e.params = params; e.cone = cone_scale; e.rays_per_param_row = rays_per_param_row;
         e.n_rays = (int)n_rays; e.S = S; e.n_geo = t->desc.n_geo; e.n_app = t->desc.n_app; e.pos_freq = t->desc.pos_freq; e.dir_freq = t->desc.dir_freq;
         e.param_freq = t->desc.param_freq; e.blur_idx = blur_idx; e.pos_out = t->h4c; e.ld_pos = ldp; e.dir_out = t->fc; e.ld_dir = ldd; e.dists = t->dists;
-        hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, e);
+        hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((M + ENC_SAMPLES - 1) / ENC_SAMPLES)), dim3(256), (size_t)ENC_SAMPLES * (ENC_BASE + Kp + Kd) * sizeof(float), st, e);
     }
     for (int i = 0; i < 8; ++i) {                                                               // model.py:104-108
         const TLayer &l = t->trunk[i];
@@ -1086,11 +1140,11 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
         const int ldx = (i == 0 || i == 5) ? ldp : (i - 1 == 4 ? ldp : 256);
         dense_forward(st, X, ldx, t->fwd_recs[i], t->fwd_kblocks[i], W + l.b, 256, M, t->h[i], i == 4 ? ldp : 256, 1, t->bits[i]);
     }
-    hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, t->h[7], 256, 256, W + t->alpha.w, W + t->alpha.b, 1, M, t->sigma);   // :111
+    hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, t->h[7], 256, 256, W + t->alpha.w, W + t->alpha.b, 1, M, t->sigma);   // :111
     dense_forward(st, t->h[7], 256, t->fwd_recs[8], t->fwd_kblocks[8], W + t->feature.b, 256, M, t->fc + t->Kd4, ldd, 0, nullptr);                                  // :114-115
     dense_forward(st, t->fc, ldd, t->fwd_recs[9], t->fwd_kblocks[9], W + t->c1.b, 256, M, t->c1o, 256, 1, t->bits[8]);                                             // :118-119
     dense_forward(st, t->c1o, 256, t->fwd_recs[10], t->fwd_kblocks[10], W + t->c2.b, 128, M, t->c2o, 128, 1, nullptr);                                                 // :122
-    hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, t->c2o, 128, 128, W + t->rgb.w, W + t->rgb.b, 3, M, t->raw_rgb);   // :123
+    hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 31) / 32)), dim3(256), 0, st, t->c2o, 128, 128, W + t->rgb.w, W + t->rgb.b, 3, M, t->raw_rgb);   // :123
     CompositeArgs c{};
     c.raw_rgb = t->raw_rgb; c.sigma = t->sigma; c.dists = t->dists; c.n_rays = (int)n_rays; c.S = S; c.map_exr = (flags & NTX_FLAG_MAP_EXR) ? 1 : 0;
     c.composite_bkgd = (flags & NTX_FLAG_COMPOSITE_BKGD) ? 1 : 0;
@@ -1122,7 +1176,7 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     };
     // color head (128 -> 3): dW, db; d c2o = (d_raw . W^T) where c2o > 0
     head_dw(t->c2o, 128, 128, t->d_raw, 3, t->rgb);
-    hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 128 + 255) / 256)), dim3(256), 0, st, t->d_raw, 3, W + t->rgb.w, 128, M, t->c2o, 128, 0, t->g0, 128);
+    hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 32 + 255) / 256)), dim3(256), 0, st, t->d_raw, 3, W + t->rgb.w, 128, M, t->c2o, 128, 0, t->g0, 128);
     int rc = dense_backward_dw(t, st, t->c1o, 256, 256, t->g0, 128, M, G + t->c2.w, G + t->c2.b);
     if (rc != NTX_OK) return rc;
     dense_backward_dx(st, t->g0, 128, t->bwd_recs[9], t->bwd_kblocks[9], M, t->bits[8], t->g1, 256);         // d c1o, masked by its ReLU
