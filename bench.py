@@ -133,6 +133,29 @@ def measured_traffic(workload: str, precision: str = "float32"):
     return float(rd) + float(wr or 0.0), os.path.relpath(files[-1], ROOT), prof
 
 
+def train_step_traffic():
+    """HBM-side bytes of ONE training step (every kernel of the trainer: WRITE_SIZE + 2 x FETCH_SIZE per launch x launches a step) from the newest
+    committed rocprofv3 summary of `bench.py --workload carpet_train_step` (profiles/r*/train_step_pmc_summary.json, tools/dev/r4_train_profiles.sh),
+    quoted like `measured_traffic` quotes the render kernel's."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "train_step_pmc_summary.json")))
+    if not files:
+        return {"traffic": None, "traffic_source": None}
+    d = json.load(open(files[-1]))
+    total = sum((float(k.get("hbm_read_MB", 0.0)) + float(k.get("hbm_written_MB", 0.0))) * 1e6 * float(k.get("launches_per_5_steps") or 0) / 5.0 for k in d["kernels"].values())
+    tree = str(d.get("tree", "")).split()
+    cur = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_hash import kernel_sources_sha16
+        if tree:
+            cur = tree[0] == kernel_sources_sha16(ROOT)
+    except Exception:
+        pass
+    return {"traffic": total, "traffic_unit": "bytes per training step, all kernels (HBM side, rocprofv3 PMC)", "traffic_source": os.path.relpath(files[-1], ROOT),
+            "traffic_profile_head": tree[1] if len(tree) > 1 and tree[1] != "None" else None, "traffic_profile_current": cur}
+
+
 def instancer_traffic():
     """HBM-side bytes of one ntx_instancer_model_input call on the bench scene (WRITE_SIZE + 2 x FETCH_SIZE of its three kernels) from the
     newest committed rocprofv3 summary of `tools/bench_instancer.py` (profiles/r*/instancer_base_pmc_summary.json), quoted like
@@ -289,8 +312,9 @@ def bench_train_step(args) -> None:
                                    f"n_parameters={list(fam['n_parameters'])}, perturb=True, AlphaLoss(smape, mse), Adam + ExponentialDecay(5e-4, 5e5 steps, 0.1); "
                                    "seeded weights and targets, batch resident in HBM", "rays": n, "samples_per_ray": S, "flops_per_sample_forward": flops_fwd,
                        "loss_after": float(val.item())},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "ntx_train::gemm_kernel (three operand layouts; 29 launches a step)", "kernel_ms": step_ms,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                         **train_step_traffic(),
+                         "kernel": "ntx_train::rows_kernel (forward and dX: 20 launches a step) + ntx_train::gemm_kernel (dW: 12 launches a step)", "kernel_ms": step_ms,
                          "what": "3 x forward FLOPs (2 MACs per weight per sample) over the WHOLE step's HIP-event time: encoders, heads, composite, loss and Adam included"}}
     if not args.no_cpu_baseline:
         from oracle import nerftex_oracle as orc

@@ -4,14 +4,16 @@
 //
 // Inference fuses the whole network into one kernel because nothing of it has to survive (ntx_device.h).  A training step has to keep
 // every layer's activations for the backward pass; with 288 GB of HBM they are simply stored -- 13 layers x 262 144 x 256 floats = 3.5 GB
-// -- and the step is a sequence of plain dense contractions on the f32 matrix cores:
+// -- and the step is a sequence of dense contractions on the f32 matrix cores:
 //
-//   encode_kernel          sample points, positional encodings of position / direction / parameters (layer.py:8-23), written straight into
-//                          the two concat buffers the network reads them from ([pos_map | h4] for the skip, [dir_map | feature])
-//   gemm_kernel<A, B>      C = op(A) . op(B) on v_mfma_f32_32x32x2_f32, 128 x 128 x 16 tiles through LDS (double buffered), with the
-//                          epilogues a Dense layer and its gradient need (bias, ReLU, the ReLU mask of a stored activation, accumulate);
-//                          three operand layouts: forward  Y = X . W,   dX = dY . W^T,   dW = X^T . dY  (the last one split along the
-//                          262 144 samples into partial sums that one pass adds up in a fixed order: a step is bit-reproducible)
+//   encode_kernel          sample points, positional encodings of position / direction / parameters (layer.py:8-23), written into the two
+//                          concat buffers the network reads them from ([pos_map | pad | h4] for the skip, [dir_map | pad | feature])
+//   rows_kernel<NT, MODE>  forward Y = act(X . W + b) and dX = (dY . W^T) masked: a wave owns 32 samples and all of a layer's outputs on
+//                          v_mfma_f32_32x32x2_f32, X straight from HBM, the weights from a packed image through an LDS ring
+//                          (pack_records_kernel makes the images once a step)
+//   gemm_kernel<A, TN, TK> dW = X^T . dY: 128 x 128 x 16 tiles through LDS (double buffered), split along the 262 144 samples into
+//                          partial sums that one pass adds up in a fixed order (a step is bit-reproducible), the bias gradient riding along;
+//                          also C = A . B on caller buffers (ntx_gemm_f32)
 //   head kernels           the 1-wide density head and the 3-wide colour head, forward and backward, on the vector ALUs
 //   composite_forward / _backward   renderer.py:170-213 per ray (wave per ray) and its adjoint: suffix sums of the weights' gradients
 //   loss_kernel            NerfLoss / AlphaLoss with mse / smape (loss.py), value and gradient
@@ -97,10 +99,19 @@ __global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_P
     __shared__ __attribute__((aligned(16))) float As[2][TK_][LROWA], Bs[2][TK_][LROWB_];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the column tiles of one row tile are neighbours in the launch order: the second and later ones find their rows of A in the L2
-    const int j0 = blockIdx.x * TN_, i0 = blockIdx.y * TM;
-    const int k_begin = blockIdx.z * g.k_chunk;
+    // Which tile of which K range.  The tiles of ONE range read the same panels of A and B: workgroups are dealt to the 8 XCDs round-robin by
+    // their linear number, each XCD has its own L2 -- so a range's tiles are given numbers that land on one XCD, next to each other in time,
+    // and the panels come from HBM once instead of once per tile (dW of a 256 x 256 layer: 999 MB a launch at 3.8 TB/s before, for 537 MB of operands).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (gridDim.z % 8 == 0) {
+        const int tiles = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = lin & 7, slot = lin >> 3, tile = slot % tiles;
+        bz = (slot / tiles) * 8 + xcd; bx = tile % gridDim.x; by = tile / gridDim.x;
+    }
+    const int j0 = bx * TN_, i0 = by * TM;
+    const int k_begin = bz * g.k_chunk;
     const int k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
-    float *C = g.C + (size_t)blockIdx.z * (size_t)g.split_stride;
+    float *C = g.C + (size_t)bz * (size_t)g.split_stride;
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_P
     float ra[2][FA], rb[2][FB], cs[FB];
 #pragma unroll
     for (int q = 0; q < FB; ++q) cs[q] = 0.0f;
-    const bool want_colsum = !A_KCONTIG && g.colsum != nullptr && blockIdx.y == 0;
+    const bool want_colsum = !A_KCONTIG && g.colsum != nullptr && by == 0;
     const bool inner = g.aligned && i0 + TM <= g.M && j0 + TN_ <= g.N;          // the tile lies inside A' and B: only the K end of a panel can stick out
     // thread -> its run of the A panel (k-contiguous rows A[i][p]: row t % 128, FA elements from (t / 128) * FA; rows along i, A[p][i]: panel row
     // t / TPR, FA elements from (t % TPR) * FA) and of the B panel (B[p][j]: panel row t / TPR, FB elements from (t % TPR) * FB)
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_P
         if ((int)threadIdx.x < TN_ && j0 + (int)threadIdx.x < g.N) {
             float sum = 0.0f;
             for (int q = 0; q < TK_; ++q) sum += red[q][threadIdx.x];
-            g.colsum[(size_t)blockIdx.z * g.N + j0 + threadIdx.x] = sum;
+            g.colsum[(size_t)bz * g.N + j0 + threadIdx.x] = sum;
         }
     }
 }
