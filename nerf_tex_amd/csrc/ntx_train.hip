@@ -89,8 +89,8 @@ __device__ __forceinline__ void fetch_run(const float *g, bool row_ok, int first
 }
 
 // TN_: columns of the workgroup's tile (128 or 256: two or four 64-wide waves across), TK_: depth of a panel; a wave always owns 64 x 64
-template <bool A_KCONTIG, int TN_, int TK_, int WAVES_PER_EU = 2>
-__global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_PER_EU, 8))) void gemm_kernel(GemmArgs g) {
+template <bool A_KCONTIG, int TN_, int TK_>
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, int bx, int by, int bz) {
     constexpr int THREADS = TN_ * 2, WCOLS = TN_ / 64, LROWA = TM + 4, LROWB_ = TN_ + 4;
     constexpr int FA = TM * TK_ / THREADS;          // floats of the A panel a thread carries
     constexpr int FB = TN_ * TK_ / THREADS;         // ... of the B panel
@@ -98,16 +98,6 @@ __global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_P
     static_assert(FA % 4 == 0 && FB % 4 == 0 && FA * (THREADS / TM) == TK_ && TPR * FB == TN_ && TPR * FA == TM, "panel split");
     __shared__ __attribute__((aligned(16))) float As[2][TK_][LROWA], Bs[2][TK_][LROWB_];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // the column tiles of one row tile are neighbours in the launch order: the second and later ones find their rows of A in the L2
-    // Which tile of which K range.  The tiles of ONE range read the same panels of A and B: workgroups are dealt to the 8 XCDs round-robin by
-    // their linear number, each XCD has its own L2 -- so a range's tiles are given numbers that land on one XCD, next to each other in time,
-    // and the panels come from HBM once instead of once per tile (dW of a 256 x 256 layer: 999 MB a launch at 3.8 TB/s before, for 537 MB of operands).
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (gridDim.z % 8 == 0) {
-        const int tiles = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int xcd = lin & 7, slot = lin >> 3, tile = slot % tiles;
-        bz = (slot / tiles) * 8 + xcd; bx = tile % gridDim.x; by = tile / gridDim.x;
-    }
     const int j0 = bx * TN_, i0 = by * TM;
     const int k_begin = bz * g.k_chunk;
     const int k_end = k_begin + g.k_chunk < g.K ? k_begin + g.k_chunk : g.K;
@@ -260,6 +250,38 @@ __global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_P
 }
 
 
+// Which tile of which K range.  The tiles of ONE range read the same panels of A and B: workgroups are dealt to the 8 XCDs round-robin by
+// their linear number, each XCD has its own L2 -- so a range's tiles are given numbers that land on one XCD, next to each other in time,
+// and the panels come from HBM once instead of once per tile (dW of a 256 x 256 layer: 999 MB a launch at 3.8 TB/s before, for 537 MB of
+// operands).  lin: the workgroup's number within its problem; nx x ny tiles, nz ranges (a multiple of 8, or the plain order is kept).
+__device__ __forceinline__ void gemm_place(int lin, int nx, int ny, int nz, int &bx, int &by, int &bz) {
+    const int tiles = nx * ny;
+    if (nz % 8 == 0) {
+        const int xcd = lin & 7, slot = lin >> 3, tile = slot % tiles;
+        bz = (slot / tiles) * 8 + xcd; bx = tile % nx; by = tile / nx;
+    } else { bx = lin % nx; by = (lin / nx) % ny; bz = lin / tiles; }
+}
+template <bool A_KCONTIG, int TN_, int TK_, int WAVES_PER_EU = 2>
+__global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_PER_EU, 8))) void gemm_kernel(GemmArgs g) {
+    int bx, by, bz;
+    gemm_place(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z, bx, by, bz);
+    gemm_body<A_KCONTIG, TN_, TK_>(g, bx, by, bz);
+}
+// several contractions in one launch (the weight gradients of every layer of a step: 12 launches' ramps, tails and write-backs become one);
+// a problem's workgroups are numbered consecutively from first[p] (multiples of 8, so that a workgroup's XCD is its local number's too)
+constexpr int MAX_GEMM_BATCH = 14;
+struct GemmBatch { GemmArgs g[MAX_GEMM_BATCH]; int first[MAX_GEMM_BATCH + 1]; int nx[MAX_GEMM_BATCH], ny[MAX_GEMM_BATCH], nz[MAX_GEMM_BATCH]; int n; };
+template <bool A_KCONTIG, int TN_, int TK_, int WAVES_PER_EU = 2>
+__global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_PER_EU, 8))) void gemm_batch_kernel(GemmBatch b) {
+    int p = 0;
+    while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
+    const int lin = (int)blockIdx.x - b.first[p];
+    if (lin >= b.nx[p] * b.ny[p] * b.nz[p]) return;           // (the numbers between two problems, rounded up to 8)
+    int bx, by, bz;
+    gemm_place(lin, b.nx[p], b.ny[p], b.nz[p], bx, by, bz);
+    gemm_body<A_KCONTIG, TN_, TK_>(b.g[p], bx, by, bz);
+}
+
 // out[e] = sum_z partial[z][e], z ascending: the fixed order that makes a step reproducible
 __global__ void reduce_partials_kernel(const float *__restrict__ partial, int n_split, long long stride, long long count, float *__restrict__ out) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -273,6 +295,26 @@ __global__ void reduce_partials_kernel(const float *__restrict__ partial, int n_
     }
     for (int q = 0; z < n_split; ++z, ++q) s4[q] += partial[(size_t)z * stride + e];
     out[e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+// ... of several results in one launch; a job's elements are numbered from first (multiples of 256: a block belongs to one job)
+constexpr int MAX_REDUCE_BATCH = 2 * MAX_GEMM_BATCH;
+struct ReduceJob { const float *partial; int n_split; long long stride, count; float *out; long long first; };
+struct ReduceBatch { ReduceJob job[MAX_REDUCE_BATCH]; int n; };
+__global__ void reduce_batch_kernel(ReduceBatch b) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int j = 0;
+    while (j + 1 < b.n && g >= b.job[j + 1].first) ++j;
+    const ReduceJob &r = b.job[j];
+    const long long e = g - r.first;
+    if (e >= r.count) return;
+    float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int z = 0;
+    for (; z + 4 <= r.n_split; z += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s4[q] += r.partial[(size_t)(z + q) * r.stride + e];
+    }
+    for (int q = 0; z < r.n_split; ++z, ++q) s4[q] += r.partial[(size_t)z * r.stride + e];
+    r.out[e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 // the same for FEW elements and MANY partial sums (the narrow heads: a thousand row blocks of 257 or 771 numbers): 32 elements a block,
 // 8 threads each taking every 8th partial sum, their results added in order -- as fixed an order as the above, an eighth of the chain
@@ -866,6 +908,8 @@ struct ntx_trainer {
     float *h[8] = {}, *h4c = nullptr, *fc = nullptr, *c1o = nullptr, *c2o = nullptr, *raw_rgb = nullptr, *sigma = nullptr;
     unsigned int *bits[9] = {};                // where h[0..7] and c1o are > 0, one bit per output in rows_kernel's layout (1 KiB per 32 samples)
     float *gf = nullptr;                       // [d feature (256) | d_sigma | 3 zeros] per sample, row stride LDGF
+    float *dyt[8] = {};                        // the gradient at every trunk layer's output (what its dW contracts with): kept, so that all dW run in one launch
+    float *dw_partial = nullptr; size_t dw_partial_floats = 0;
     float *z = nullptr, *dists = nullptr, *g0 = nullptr, *g1 = nullptr, *d_raw = nullptr, *d_sigma = nullptr, *partial = nullptr;
     float *color = nullptr, *alpha_out = nullptr, *d_color = nullptr, *d_alpha = nullptr, *loss = nullptr;
     long long cap_rays = 0;
@@ -889,6 +933,8 @@ void free_all(ntx_trainer *t) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 8; ++i) if (i != 4 && t->h[i]) (void)hipFree(t->h[i]);
     for (int i = 0; i < 9; ++i) if (t->bits[i]) (void)hipFree(t->bits[i]);
+    for (int i = 0; i < 8; ++i) if (t->dyt[i]) (void)hipFree(t->dyt[i]);
+    if (t->dw_partial) (void)hipFree(t->dw_partial);
     delete t;
 }
 
@@ -941,21 +987,6 @@ void dense_backward_dx(hipStream_t st, const float *dY, int lddy, const float *r
     RowsArgs r{}; r.X = dY; r.ldx = lddy; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = dX; r.ldy = lddx; r.bits_in = bits;
     launch_rows(st, r, 256, 0);
 }
-// dW = X^T . dY and db = the column sums of dY (riding along in the same kernel), both through partial sums added up in a fixed order;
-// kernel [K][N] and bias [N] are neighbours in the blob
-int dense_backward_dw(ntx_trainer *t, hipStream_t st, const float *X, int ldx, int K, const float *dY, int N, long long M, float *dW, float *db, int lddy = 0) {
-    const size_t need = (size_t)SPLIT * K * N + (size_t)SPLIT * N;
-    if (need > t->partial_floats) return ntx_set_error(NTX_E_INVALID, "trainer: partial buffer too small");
-    float *cs = t->partial + (size_t)SPLIT * K * N;
-    GemmArgs g{}; g.A = X; g.lda = ldx; g.B = dY; g.ldb = lddy ? lddy : N; g.C = t->partial; g.ldc = N; g.M = K; g.N = N; g.K = (int)M; g.split_stride = (long long)K * N; g.colsum = db ? cs : nullptr;
-    launch_gemm<false>(st, g, SPLIT);
-    const int parts = split_parts(M, SPLIT);
-    const long long count = (long long)K * N;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, t->partial, parts, count, count, dW);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, cs, parts, (long long)N, (long long)N, db);
-    return NTX_OK;
-}
-
 }   // namespace
 
 extern "C" {
@@ -1013,6 +1044,14 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     if (rc == NTX_OK) rc = alloc(&t->g0, (size_t)M * 256);
     if (rc == NTX_OK) rc = alloc(&t->g1, (size_t)M * 256);
     if (rc == NTX_OK) rc = alloc(&t->gf, (size_t)M * LDGF);
+    for (int i = 0; i < 8 && rc == NTX_OK; ++i) rc = alloc(&t->dyt[i], (size_t)M * 256);
+    {
+        size_t per_split = 0;
+        for (int i = 0; i < 8; ++i) per_split += (size_t)(t->trunk[i].in + 1) * 256;
+        per_split += (size_t)(t->feature.in + 1) * 256 + (size_t)(t->c1.in + 2) * 256 + (size_t)(t->c2.in + 1) * 128 + 256;
+        t->dw_partial_floats = (size_t)SPLIT * per_split;
+        if (rc == NTX_OK) rc = alloc(&t->dw_partial, t->dw_partial_floats);
+    }
     if (rc == NTX_OK) rc = alloc(&t->d_raw, (size_t)M * 3);
     if (rc == NTX_OK) rc = alloc(&t->d_sigma, (size_t)M);
     t->partial_floats = (size_t)SPLIT * (256 + (t->Kd > t->Kp ? t->Kd : t->Kp)) * 256 + (size_t)SPLIT * 256;
@@ -1172,12 +1211,41 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     // ---- backward -----------------------------------------------------------------------------------------------------------------
     hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st, c);
     float *G = t->grad;
-    // dW of a layer that reads a concat buffer [first | pad | 256 more]: two contractions when there is a pad, the bias gradient rides with the first
+    // The gradient runs down the network first (every layer's dY kept), then ALL weight gradients are taken in one launch: dW = X^T . dY and
+    // db = the column sums of dY (riding along in the same kernel), both through partial sums added up in a fixed order by one more launch;
+    // kernel [K][N] and bias [N] are neighbours in the blob
+    GemmBatch gb{}; ReduceBatch rb{};
+    size_t partial_used = 0; long long reduce_first = 0; int wg_first = 0;
+    const int tk = 16;
+    const int k_chunk = (((int)M + SPLIT - 1) / SPLIT + tk - 1) / tk * tk, parts = ((int)M + k_chunk - 1) / k_chunk;
+    auto dw = [&](const float *X, int ldx, int K, const float *dY, int lddy, int N, float *dW, float *db) -> int {
+        if (gb.n >= MAX_GEMM_BATCH || rb.n + 2 > MAX_REDUCE_BATCH) return ntx_set_error(NTX_E_INVALID, "trainer: too many weight gradients for one launch");
+        const size_t need = (size_t)parts * K * N + (db ? (size_t)parts * N : 0);
+        if (partial_used + need > t->dw_partial_floats) return ntx_set_error(NTX_E_INVALID, "trainer: partial buffer too small");
+        float *pw = t->dw_partial + partial_used, *pb = pw + (size_t)parts * K * N;
+        partial_used += need;
+        GemmArgs &g = gb.g[gb.n];
+        g = GemmArgs{}; g.A = X; g.lda = ldx; g.B = dY; g.ldb = lddy; g.C = pw; g.ldc = N; g.M = K; g.N = N; g.K = (int)M; g.split_stride = (long long)K * N;
+        g.colsum = db ? pb : nullptr; g.k_chunk = k_chunk;
+        g.aligned = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (((uintptr_t)g.A | (uintptr_t)g.B) % 16 == 0);
+        gb.nx[gb.n] = (N + 127) / 128; gb.ny[gb.n] = (K + TM - 1) / TM; gb.nz[gb.n] = parts; gb.first[gb.n] = wg_first;
+        wg_first += (gb.nx[gb.n] * gb.ny[gb.n] * parts + 7) / 8 * 8;
+        gb.n += 1; gb.first[gb.n] = wg_first;
+        auto red = [&](const float *partial, long long count, float *out) {
+            ReduceJob &r = rb.job[rb.n++];
+            r.partial = partial; r.n_split = parts; r.stride = count; r.count = count; r.out = out; r.first = reduce_first;
+            reduce_first += (count + 255) / 256 * 256;
+        };
+        red(pw, (long long)K * N, dW);
+        if (db) red(pb, N, db);
+        return NTX_OK;
+    };
+    // a layer that reads a concat buffer [first | pad | 256 more]: two contractions when there is a pad, the bias gradient rides with the first
     auto concat_dw = [&](const float *X, int ldx, int K1, int K1p, const float *dY, const TLayer &l) -> int {
-        if (K1 == K1p) return dense_backward_dw(t, st, X, ldx, K1 + 256, dY, 256, M, G + l.w, G + l.b);
-        const int rc1 = dense_backward_dw(t, st, X, ldx, K1, dY, 256, M, G + l.w, G + l.b);
+        if (K1 == K1p) return dw(X, ldx, K1 + 256, dY, 256, 256, G + l.w, G + l.b);
+        const int rc1 = dw(X, ldx, K1, dY, 256, 256, G + l.w, G + l.b);
         if (rc1 != NTX_OK) return rc1;
-        return dense_backward_dw(t, st, X + K1p, ldx, 256, dY, 256, M, G + l.w + (size_t)K1 * 256, nullptr);
+        return dw(X + K1p, ldx, 256, dY, 256, 256, G + l.w + (size_t)K1 * 256, nullptr);
     };
     const int hb = (int)((M + HEAD_ROWS - 1) / HEAD_ROWS);
     auto head_dw = [&](const float *X, int ldx, int K, const float *dY, int n_out, const TLayer &l) {       // (kernel | bias) of a narrow head
@@ -1188,29 +1256,25 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     // color head (128 -> 3): dW, db; d c2o = (d_raw . W^T) where c2o > 0
     head_dw(t->c2o, 128, 128, t->d_raw, 3, t->rgb);
     hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 32 + 255) / 256)), dim3(256), 0, st, t->d_raw, 3, W + t->rgb.w, 128, M, t->c2o, 128, 0, t->g0, 128);
-    int rc = dense_backward_dw(t, st, t->c1o, 256, 256, t->g0, 128, M, G + t->c2.w, G + t->c2.b);
-    if (rc != NTX_OK) return rc;
-    dense_backward_dx(st, t->g0, 128, t->bwd_recs[9], t->bwd_kblocks[9], M, t->bits[8], t->g1, 256);         // d c1o, masked by its ReLU
-    rc = concat_dw(t->fc, ldd, Kd, t->Kd4, t->g1, t->c1);
-    if (rc != NTX_OK) return rc;
-    dense_backward_dx(st, t->g1, 256, t->bwd_recs[8], t->bwd_kblocks[8], M, nullptr, t->gf, LDGF);         // d feature (linear layer: no mask)
-    rc = dense_backward_dw(t, st, t->h[7], 256, 256, t->gf, 256, M, G + t->feature.w, G + t->feature.b, LDGF);
-    if (rc != NTX_OK) return rc;
     head_dw(t->h[7], 256, 256, t->d_sigma, 1, t->alpha);
+    dense_backward_dx(st, t->g0, 128, t->bwd_recs[9], t->bwd_kblocks[9], M, t->bits[8], t->g1, 256);         // d c1o, masked by its ReLU
+    dense_backward_dx(st, t->g1, 256, t->bwd_recs[8], t->bwd_kblocks[8], M, nullptr, t->gf, LDGF);         // d feature (linear layer: no mask)
     // d h7 = (d feature . W_feature^T + d_sigma (x) W_alpha) where h7 > 0, as ONE contraction over 257: d_sigma goes beside d feature
     hipLaunchKernelGGL(column_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, t->d_sigma, M, t->gf + 256, LDGF);
-    dense_backward_dx(st, t->gf, LDGF, t->bwd_recs[7], t->bwd_kblocks[7], M, t->bits[7], t->g1, 256);
-    float *cur = t->g1, *nxt = t->g0;
-    for (int i = 7; i >= 0; --i) {
+    dense_backward_dx(st, t->gf, LDGF, t->bwd_recs[7], t->bwd_kblocks[7], M, t->bits[7], t->dyt[7], 256);
+    for (int i = 7; i >= 1; --i) dense_backward_dx(st, t->dyt[i], 256, t->bwd_recs[i - 1], t->bwd_kblocks[i - 1], M, t->bits[i - 1], t->dyt[i - 1], 256);
+    int rc = dw(t->c1o, 256, 256, t->g0, 128, 128, G + t->c2.w, G + t->c2.b);
+    if (rc == NTX_OK) rc = concat_dw(t->fc, ldd, Kd, t->Kd4, t->g1, t->c1);
+    if (rc == NTX_OK) rc = dw(t->h[7], 256, 256, t->gf, LDGF, 256, G + t->feature.w, G + t->feature.b);
+    for (int i = 7; i >= 0 && rc == NTX_OK; --i) {
         const TLayer &l = t->trunk[i];
         const float *X = (i == 0 || i == 5) ? t->h4c : t->h[i - 1];
         const int ldx = (i == 0 || i == 5) ? ldp : 256;
-        rc = i == 5 ? concat_dw(X, ldx, Kp, t->Kp4, cur, l) : dense_backward_dw(t, st, X, ldx, l.in, cur, 256, M, G + l.w, G + l.b);
-        if (rc != NTX_OK) return rc;
-        if (i == 0) break;
-        dense_backward_dx(st, cur, 256, t->bwd_recs[i - 1], t->bwd_kblocks[i - 1], M, t->bits[i - 1], nxt, 256);
-        float *tmp = cur; cur = nxt; nxt = tmp;
+        rc = i == 5 ? concat_dw(X, ldx, Kp, t->Kp4, t->dyt[i], l) : dw(X, ldx, l.in, t->dyt[i], 256, 256, G + l.w, G + l.b);
     }
+    if (rc != NTX_OK) return rc;
+    hipLaunchKernelGGL((gemm_batch_kernel<false, 128, 16>), dim3((unsigned)wg_first), dim3(256), 0, st, gb);
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(reduce_first / 256)), dim3(256), 0, st, rb);
     if (color_pred) TRAIN_TRY(hipMemcpyAsync(color_pred, t->color, (size_t)n_rays * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (alpha_pred) TRAIN_TRY(hipMemcpyAsync(alpha_pred, t->alpha_out, (size_t)n_rays * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (loss_out) TRAIN_TRY(hipMemcpyAsync(loss_out, t->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
