@@ -374,16 +374,21 @@ __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float *
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-struct RowsArgs {
-    const float *X; int ldx; long long M;
+// A launch walks every pair of row blocks through a CHAIN of layers (the whole trunk forward; the whole way back for dX): block A layer l,
+// block B layer l, block A layer l + 1 ...  A block's layer-l outputs leave under the other block's MFMAs and are complete a body later,
+// long before the same wave reads them back as layer l + 1's X (its own rows, through its own CU's L2: nothing is shared between waves
+// but the weights) -- ten launches' ramps, first loads, last stores and L2 write-backs become one.
+struct RowsLayer {
+    const float *X; int ldx;
     const float *recs; int kblocks;                    // packed weights; blocks of 8 k (a multiple of 4, at least 12)
     float *Y; int ldy;
-    const float *bias;                                 // forward
+    const float *bias; int linear;                     // forward: bias [32 NT]; linear: no ReLU (and no bits)
     unsigned int *bits_out;                            // forward: one bit per output, set where it is > 0 (or NULL)
-    const unsigned int *bits_in;                       // dX: keep where the bit is set
+    const unsigned int *bits_in;                       // dX: keep where the bit is set (a layer without a ReLU behind it: a buffer of ones)
 };
-enum { ROWS_FORWARD = 0, ROWS_DX = 1, ROWS_DX_MASK = 2, ROWS_FORWARD_LINEAR = 3 };   // what the epilogue does (bias + ReLU + its bits; nothing; the mask; bias only): a template
-                                                                                  // parameter, nothing of it behind a branch
+constexpr int MAX_ROWS_LAYERS = 10;
+struct RowsArgs { RowsLayer layer[MAX_ROWS_LAYERS]; int n_layers; long long M; };
+enum { ROWS_FORWARD = 0, ROWS_DX_MASK = 2 };           // what the epilogue does: a template parameter
 template <int N, class F> __device__ __forceinline__ void static_for_(F &&f) {
     if constexpr (N > 0) { static_for_<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
@@ -401,37 +406,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int CHUNK = 16 * G;                      // records per body (4 blocks of 8 k = 16 k-steps): 16 or 32 KiB
     constexpr int RING = 2;                            // records read ahead of the MFMAs (CHUNK is a multiple: the ring's phase is the same in every body)
     constexpr int TAIL = CHUNK - RING - 1;             // the barrier stands behind this record's MFMAs: the next one reads ahead into the next chunk
-    __shared__ f32x4 lds[3 * CHUNK * 64 + NT * 8];     // three chunks, then the bias
+    __shared__ f32x4 lds[3 * CHUNK * 64 + MAX_ROWS_LAYERS * NT * 8];     // three chunks, then every layer's bias
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long n_blocks = (a.M + 31) / 32, n_groups = (n_blocks + 3) / 4;
-    const int nb = a.kblocks / 4;                      // bodies per block: at least 3
     if ((long long)blockIdx.x >= n_groups) return;
-    const __amdgpu_buffer_rsrc_t rw = rows_rsrc(a.recs, (long long)a.kblocks * NT * 1024);
-    const uint32_t woff = (uint32_t)lane * 16u, xoff = (uint32_t)(m * a.ldx + 4 * h) * 4u, yoff = (uint32_t)(4 * h * a.ldy + m) * 4u;
-    const uint32_t ld4 = (uint32_t)a.ldy * 4u;
-    constexpr bool MASK = MODE == ROWS_DX_MASK;
-    const __amdgpu_buffer_rsrc_t rbits = rows_rsrc(MASK ? (const void *)a.bits_in : (const void *)a.recs, MASK ? n_blocks * 1024 : 0);
-    const __amdgpu_buffer_rsrc_t rbo = rows_rsrc(MODE == ROWS_FORWARD && a.bits_out ? (const void *)a.bits_out : (const void *)a.recs,
-                                                 MODE == ROWS_FORWARD && a.bits_out ? n_blocks * 1024 : 0);
-    constexpr bool BIAS = MODE == ROWS_FORWARD || MODE == ROWS_FORWARD_LINEAR;
+    const int L = a.n_layers;
+    const int n_mine = (int)((n_groups - blockIdx.x + gridDim.x - 1) / gridDim.x), n_items = (n_mine + 1) / 2 * 2 * L;   // pairs of groups x layers x 2
+    constexpr bool MASK = MODE == ROWS_DX_MASK, BIAS = MODE == ROWS_FORWARD;
+    const uint32_t woff = (uint32_t)lane * 16u;
     if constexpr (BIAS) {
         float *bl = reinterpret_cast<float *>(&lds[3 * CHUNK * 64]);
-        if ((int)threadIdx.x < NT * 32) bl[threadIdx.x] = a.bias[threadIdx.x];
+        for (int e = threadIdx.x; e < L * NT * 32; e += 256) bl[e] = a.layer[e / (NT * 32)].bias[e % (NT * 32)];
     }
+    // item w of this wave: which rows, which layer.  Behind the last one (and for the second half of an odd pair): no rows -- empty descriptors
+    auto item_row0 = [&](int w) -> long long {
+        if (w < 0 || w >= n_items) return a.M;
+        const int p = w / (2 * L), rem = w - p * 2 * L;
+        const long long grp = (long long)blockIdx.x + (long long)(2 * p + (rem & 1)) * gridDim.x;
+        return grp < n_groups ? (grp * 4 + wave) * 32 : a.M;
+    };
+    auto item_layer = [&](int w) -> int { return (w < 0 || w >= n_items) ? 0 : (w % (2 * L)) >> 1; };
     // this wave's quarter of a chunk, straight into LDS: one record (64 lanes x 16 bytes, lane-linear) per instruction
-    auto fill = [&](int chunk, int buf_byte) {
+    auto fill = [&](const __amdgpu_buffer_rsrc_t &rw, int chunk, int buf_byte) {
         static_for_<CHUNK / 4>([&](auto I) {
             const int r = wave * (CHUNK / 4) + I;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(lds) + buf_byte + r * 1024), 16, woff,
                                                      (uint32_t)(chunk * CHUNK + r) * 1024u, 0, 0);
         });
     };
-    auto block_rows = [&](long long grp) { return grp < n_groups ? (grp * 4 + wave) * 32 : a.M; };   // behind the last group: an empty descriptor
-    auto x_rsrc = [&](long long row0) { return rows_rsrc(a.X + row0 * a.ldx, (a.M - row0) * a.ldx * 4); };
-    auto xload4 = [&](const __amdgpu_buffer_rsrc_t &rx, int q0, f32x4 (&x)[4]) {
+    auto w_rsrc = [&](int l) { return rows_rsrc(a.layer[l].recs, (long long)a.layer[l].kblocks * NT * 1024); };
+    auto x_rsrc = [&](int l, long long row0) { return rows_rsrc(a.layer[l].X + row0 * a.layer[l].ldx, (a.M - row0) * a.layer[l].ldx * 4); };
+    auto xload4 = [&](const __amdgpu_buffer_rsrc_t &rx, uint32_t xoff, int q0, f32x4 (&x)[4]) {
         static_for_<4>([&](auto I) { x[I] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff, (uint32_t)(q0 + I) * 32u, 0)); });
     };
+    auto x_off = [&](int l) { return (uint32_t)(m * a.layer[l].ldx + 4 * h) * 4u; };
     f32x16 accs[2][NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)                       // set 1 "leaves" once before it has been filled (into an empty descriptor): keep even that read defined
@@ -439,14 +448,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int r = 0; r < 16; ++r) accs[1][t][r] = 0.0f;
     f32x4 x[4], xn[4], ring[RING];
     u32x4 bits_set[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // dX: the masks of the blocks in the two accumulator sets, asked for in a block's last body (every body without an epilogue asks: no branch)
-    auto bits_out_of = [&](int set) -> u32x4 & { return bits_set[set]; };
-    // A block's outputs are made final in place in ONE dense block of VALU work (ReLU and its bits, or the mask): VALU instructions
+    // A block's outputs are made final in place in ONE dense block of VALU work (ReLU and its bits): VALU instructions
     // scattered between f32 MFMAs cost several times their own issue time (the f32 MFMA runs on the vector ALUs' lanes;
-    // measured here, 20 cycles an instruction) -- only the stores, which need no ALU, are spread over the next block's MFMAs.
+    // measured here, 18 cycles an instruction against 8) -- only the stores, which need no ALU, are spread over the next block's MFMAs.
     // The bit of (tile t, register r) lies in word t >> 1 at position 16 (t & 1) + r.
-    auto finalize = [&](auto SETc, long long blk) {
+    auto finalize = [&](auto SETc, int l, long long blk) {
         constexpr int SET = SETc;
         if constexpr (MODE == ROWS_FORWARD) {
+            if (a.layer[l].linear) return;
             u32x4 out_bits = {0u, 0u, 0u, 0u};
             static_for_<NT>([&](auto T) {
                 static_for_<16>([&](auto R) {
@@ -458,25 +467,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
+            const __amdgpu_buffer_rsrc_t rbo = rows_rsrc(a.layer[l].bits_out ? (const void *)a.layer[l].bits_out : (const void *)a.layer[l].recs, a.layer[l].bits_out ? n_blocks * 1024 : 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out_bits), rbo, woff, (uint32_t)blk * 1024u, 0);
         }
     };
+    // where the block in the OTHER accumulator set goes: its layer's Y at its rows (set by block())
+    __amdgpu_buffer_rsrc_t ry = rows_rsrc(a.layer[0].Y, 0);
+    uint32_t yoff = 0, ld4 = 0;
     // output register (tile t, register r) leaves: two full 128-byte lines
     // (dX under a mask: the mask goes on here, four outputs at a time -- 8 VALU instructions in one piece every 8 MFMAs; all 128 at once
     // need more registers than there are, one at a time between the MFMAs costs 18 us a launch)
-    auto element = [&](auto SETc, auto Tc, auto Rc, const __amdgpu_buffer_rsrc_t &ry) {
+    auto element = [&](auto SETc, auto Tc, auto Rc) {
         constexpr int SET = SETc, t = Tc, r = Rc;
         float v = accs[SET][t][r];                     // (a vector element is not an lvalue __builtin_bit_cast can take: it would read element 0)
         if constexpr (MASK) {
-            const int keep = __builtin_amdgcn_sbfe((int)bits_out_of(SET)[t >> 1], 16 * (t & 1) + r, 1);   // 0 or -1
+            const int keep = __builtin_amdgcn_sbfe((int)bits_set[SET][t >> 1], 16 * (t & 1) + r, 1);   // 0 or -1
             v = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keep);
         }
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff + (uint32_t)t * 128u, (uint32_t)(8 * (r >> 2) + (r & 3)) * ld4, 0);
     };
-    auto acc_init = [&](auto SETc) {
+    auto leaves_to = [&](int l, long long row0) {
+        ry = rows_rsrc(a.layer[l].Y + row0 * a.layer[l].ldy, (a.M - row0) * a.layer[l].ldy * 4);
+        yoff = (uint32_t)(4 * h * a.layer[l].ldy + m) * 4u; ld4 = (uint32_t)a.layer[l].ldy * 4u;
+    };
+    auto acc_init = [&](auto SETc, int l) {
         constexpr int SET = SETc;
         if constexpr (BIAS) {                          // the accumulators start from the bias: a lane's feature is the same in all of a tile's registers
-            const float *bl = reinterpret_cast<const float *>(&lds[3 * CHUNK * 64]);
+            const float *bl = reinterpret_cast<const float *>(&lds[3 * CHUNK * 64]) + l * NT * 32;
             static_for_<NT>([&](auto T) {
                 const float b = bl[32 * T + m];
 #pragma unroll
@@ -491,28 +508,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // LDS byte offsets of the chunk being read, the next one, the one after (being filled): they rotate
     int buf0 = 0, buf1 = CHUNK * 1024, buf2 = 2 * CHUNK * 1024;
-    long long grp = blockIdx.x;
-    __amdgpu_buffer_rsrc_t rx = x_rsrc(block_rows(grp)), rxn = x_rsrc(block_rows(grp + gridDim.x));
     {
-        fill(0, buf0); fill(1, buf1);
-        xload4(rx, 0, x);
+        const int l0 = item_layer(0);
+        const __amdgpu_buffer_rsrc_t rw = w_rsrc(l0);
+        fill(rw, 0, buf0); fill(rw, 1, buf1);
+        xload4(x_rsrc(l0, item_row0(0)), x_off(l0), 0, x);
         wait_vmcnt<0>();
         __syncthreads();
-        const f32x4 *L = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(lds) + buf0) + lane;
-        static_for_<RING>([&](auto I) { ring[I] = L[I * 64]; });
+        const f32x4 *Lp = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(lds) + buf0) + lane;
+        static_for_<RING>([&](auto I) { ring[I] = Lp[I * 64]; });
     }
+    // the block under way and the one after it
+    __amdgpu_buffer_rsrc_t rx = x_rsrc(0, a.M), rxn = rx, rw = w_rsrc(0), rwn = rw, rbits = rw;
+    uint32_t xoff = 0, xoffn = 0, bits_at = 0;
+    int nb = 3;
     // one body: EP = 0 nothing else, 1 / 2 the first / second half of the previous block's outputs leave from the other accumulator set
-    auto body = [&](auto SETc, auto EPc, int b, const __amdgpu_buffer_rsrc_t &ry) {
+    auto body = [&](auto SETc, auto EPc, int b) {
         constexpr int SET = SETc, EP = EPc;
         const bool last = b == nb - 1;
-        xload4(last ? rxn : rx, last ? 0 : 4 * (b + 1), xn);
-        if constexpr (MASK && EP == 0) bits_set[SET] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbits, woff, (uint32_t)(block_rows(grp) / 32) * 1024u, 0));
-        const f32x4 *L = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(lds) + buf0) + lane;
+        if (nb == 3 && last) wait_vmcnt<0>();          // (a three-body block: the outputs that left in its first two bodies are what the next block's X may be)
+        xload4(last ? rxn : rx, last ? xoffn : xoff, last ? 0 : 4 * (b + 1), xn);
+        if constexpr (MASK && EP == 0) bits_set[SET] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbits, woff, bits_at, 0));
+        const f32x4 *Lp = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(lds) + buf0) + lane;
         const f32x4 *Ln = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(lds) + buf1) + lane;
         static_for_<CHUNK>([&](auto IDX) {
             constexpr int idx = IDX, ks = idx / G, gi = idx % G, qi = ks / 4, c = ks % 4;
             const f32x4 w = ring[idx % RING];
-            if constexpr (idx + RING < CHUNK) ring[idx % RING] = L[(idx + RING) * 64];
+            if constexpr (idx + RING < CHUNK) ring[idx % RING] = Lp[(idx + RING) * 64];
             else ring[idx % RING] = Ln[(idx + RING - CHUNK) * 64];      // behind the barrier: the next chunk's first records
             static_for_<4>([&](auto T) {
                 constexpr int tt = T, tile = 4 * gi + T;
@@ -520,7 +542,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 // output e = 0 .. 8 NT - 1 of this half of the block: register-major, so that a sample's stores follow each other
                 auto leave = [&](auto Ec) {
                     constexpr int e = Ec, r = e / (NT / 2), t = (EP - 1) * (NT / 2) + e % (NT / 2);
-                    element(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, t>{}, std::integral_constant<int, r>{}, ry);
+                    element(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, t>{}, std::integral_constant<int, r>{});
                 };
                 if constexpr (EP != 0 && !MASK && (tt == 0 || tt == 2)) leave(std::integral_constant<int, 2 * idx + tt / 2>{});
                 if constexpr (EP != 0 && MASK && idx % 2 == 0 && tt == 0) static_for_<4>([&](auto I) { leave(std::integral_constant<int, 2 * idx + I>{}); });
@@ -528,11 +550,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             });
             if constexpr (idx == TAIL) {
                 // what is older than this body's stores -- the next chunk's quarter, the next body's X -- has to be there; then everyone's is, and
-                // nobody reads the chunk before this one any more: its buffer takes the chunk after the next
+                // nobody reads the chunk before this one any more: its buffer takes the chunk after the next (of this block's image or the next's)
                 wait_vmcnt<(EP == 0 ? 0 : MASK ? 4 * (TAIL / 2 + 1) : 2 * (TAIL + 1))>();
                 __builtin_amdgcn_s_barrier();
-                const int chunk2 = b + 2 < nb ? b + 2 : b + 2 - nb;
-                fill(chunk2, buf2);
+                const bool over = b + 2 >= nb;
+                fill(over ? rwn : rw, over ? b + 2 - nb : b + 2, buf2);
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
@@ -540,34 +562,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int i = 0; i < 4; ++i) x[i] = xn[i];
         const int tmp = buf0; buf0 = buf1; buf1 = buf2; buf2 = tmp;
     };
-    // a block into accumulator set SET; the block before it (at prev_row0, in the other set) leaves meanwhile
-    auto block = [&](auto SETc, long long prev_row0) {
-        const __amdgpu_buffer_rsrc_t ry = rows_rsrc(a.Y + prev_row0 * a.ldy, (a.M - prev_row0) * a.ldy * 4);
-        acc_init(SETc);
-        body(SETc, std::integral_constant<int, 1>{}, 0, ry);
-        body(SETc, std::integral_constant<int, 2>{}, 1, ry);
-        for (int b = 2; b < nb; ++b) body(SETc, std::integral_constant<int, 0>{}, b, ry);
+    // item w into accumulator set SET; the item before it (in the other set) leaves meanwhile
+    auto block = [&](auto SETc, int w) {
+        const int l = item_layer(w), ln = item_layer(w + 1);
+        const long long row0 = item_row0(w), row0n = item_row0(w + 1);
+        rx = x_rsrc(l, row0); xoff = x_off(l); rxn = x_rsrc(ln, row0n); xoffn = x_off(ln);
+        rw = w_rsrc(l); rwn = w_rsrc(ln); nb = a.layer[l].kblocks / 4;
+        if constexpr (MASK) { rbits = rows_rsrc(a.layer[l].bits_in, n_blocks * 1024); bits_at = (uint32_t)(row0 / 32) * 1024u; }
+        leaves_to(item_layer(w - 1), item_row0(w - 1));
+        acc_init(SETc, l);
+        body(SETc, std::integral_constant<int, 1>{}, 0);
+        body(SETc, std::integral_constant<int, 2>{}, 1);
+        for (int b = 2; b < nb; ++b) body(SETc, std::integral_constant<int, 0>{}, b);
+        finalize(SETc, l, row0 / 32);
     };
-    long long prev_row0 = a.M;                         // no block before the first: its stores fall outside an empty descriptor
-    int set = 0;
-    for (;;) {
-        block(std::integral_constant<int, 0>{}, prev_row0);
-        prev_row0 = block_rows(grp); set = 0;
-        finalize(std::integral_constant<int, 0>{}, prev_row0 / 32);
-        grp += gridDim.x; rx = rxn; rxn = x_rsrc(block_rows(grp + gridDim.x));
-        if (grp >= n_groups) break;
-        block(std::integral_constant<int, 1>{}, prev_row0);
-        prev_row0 = block_rows(grp); set = 1;
-        finalize(std::integral_constant<int, 1>{}, prev_row0 / 32);
-        grp += gridDim.x; rx = rxn; rxn = x_rsrc(block_rows(grp + gridDim.x));
-        if (grp >= n_groups) break;
+    for (int w = 0; w < n_items; w += 2) {
+        block(std::integral_constant<int, 0>{}, w);
+        block(std::integral_constant<int, 1>{}, w + 1);
     }
-    // the last block's outputs
-    {
-        const __amdgpu_buffer_rsrc_t ry = rows_rsrc(a.Y + prev_row0 * a.ldy, (a.M - prev_row0) * a.ldy * 4);
-        if (set == 0) static_for_<16>([&](auto R) { static_for_<NT>([&](auto T) { element(std::integral_constant<int, 0>{}, T, R, ry); }); });
-        else static_for_<16>([&](auto R) { static_for_<NT>([&](auto T) { element(std::integral_constant<int, 1>{}, T, R, ry); }); });
-    }
+    // the last block's outputs (always in set 1)
+    leaves_to(item_layer(n_items - 1), item_row0(n_items - 1));
+    static_for_<16>([&](auto R) { static_for_<NT>([&](auto T) { element(std::integral_constant<int, 1>{}, T, R); }); });
 }
 
 // the packed images of every layer, both directions, in one launch (the weights move every step)
@@ -906,6 +921,7 @@ struct ntx_trainer {
     const float *bwd_recs[10] = {}; int bwd_kblocks[10] = {};   // trunk 1-7 (index i - 1), feature, c1, c2
     // activations (per sample): h[i] = output of trunk layer i (h[4] lives inside h4c), c1o, c2o; concat buffers; heads' raw outputs
     float *h[8] = {}, *h4c = nullptr, *fc = nullptr, *c1o = nullptr, *c2o = nullptr, *raw_rgb = nullptr, *sigma = nullptr;
+    unsigned int *bits_ones = nullptr;         // all set: the "mask" of a layer without a ReLU behind it
     unsigned int *bits[9] = {};                // where h[0..7] and c1o are > 0, one bit per output in rows_kernel's layout (1 KiB per 32 samples)
     float *gf = nullptr;                       // [d feature (256) | d_sigma | 3 zeros] per sample, row stride LDGF
     float *dyt[8] = {};                        // the gradient at every trunk layer's output (what its dW contracts with): kept, so that all dW run in one launch
@@ -933,6 +949,7 @@ void free_all(ntx_trainer *t) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 8; ++i) if (i != 4 && t->h[i]) (void)hipFree(t->h[i]);
     for (int i = 0; i < 9; ++i) if (t->bits[i]) (void)hipFree(t->bits[i]);
+    if (t->bits_ones) (void)hipFree(t->bits_ones);
     for (int i = 0; i < 8; ++i) if (t->dyt[i]) (void)hipFree(t->dyt[i]);
     if (t->dw_partial) (void)hipFree(t->dw_partial);
     delete t;
@@ -966,27 +983,26 @@ int split_parts(long long K, int n_split) {
     return ((int)K + chunk - 1) / chunk;
 }
 
-// Y = act(X . W + b) through the layer's packed image: X [M][..] (row stride ldx), Y [M][N] (row stride ldy)
-void launch_rows(hipStream_t st, const RowsArgs &a, int N, int relu) {
+// a chain of layers in one launch: forward Y = act(X . W + b) through each layer's packed image, or dX = dY . W^T kept where the forward
+// pass left a bit
+void launch_rows(hipStream_t st, const RowsArgs &a, int N, bool forward) {
     static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const long long n_groups = ((a.M + 31) / 32 + 3) / 4;
     const dim3 grid((unsigned)(n_groups < cus ? n_groups : cus)), wg(256);     // persistent: a workgroup of four waves per CU
     if (N != 256) hipLaunchKernelGGL((rows_kernel<4, ROWS_FORWARD>), grid, wg, 0, st, a);
-    else if (a.bias && relu) hipLaunchKernelGGL((rows_kernel<8, ROWS_FORWARD>), grid, wg, 0, st, a);
-    else if (a.bias) hipLaunchKernelGGL((rows_kernel<8, ROWS_FORWARD_LINEAR>), grid, wg, 0, st, a);
-    else if (!a.bits_in) hipLaunchKernelGGL((rows_kernel<8, ROWS_DX>), grid, wg, 0, st, a);
+    else if (forward) hipLaunchKernelGGL((rows_kernel<8, ROWS_FORWARD>), grid, wg, 0, st, a);
     else hipLaunchKernelGGL((rows_kernel<8, ROWS_DX_MASK>), grid, wg, 0, st, a);
 }
-void dense_forward(hipStream_t st, const float *X, int ldx, const float *recs, int kblocks, const float *b, int N, long long M, float *Y, int ldy, int relu, unsigned int *bits_out) {
-    RowsArgs r{}; r.X = X; r.ldx = ldx; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = Y; r.ldy = ldy; r.bias = b; r.bits_out = bits_out;
-    launch_rows(st, r, N, relu);
+RowsLayer forward_layer(const float *X, int ldx, const float *recs, int kblocks, const float *b, float *Y, int ldy, int relu, unsigned int *bits_out) {
+    RowsLayer r{}; r.X = X; r.ldx = ldx; r.recs = recs; r.kblocks = kblocks; r.Y = Y; r.ldy = ldy; r.bias = b; r.linear = !relu; r.bits_out = bits_out;
+    return r;
 }
-// dX = dY . W^T (the image packed from the layer's own block, transposed on the way), kept where the forward pass left a bit:  dY [M][..] (row stride lddy),
-// dX [M][256]
-void dense_backward_dx(hipStream_t st, const float *dY, int lddy, const float *recs, int kblocks, long long M, const unsigned int *bits, float *dX, int lddx) {
-    RowsArgs r{}; r.X = dY; r.ldx = lddy; r.M = M; r.recs = recs; r.kblocks = kblocks; r.Y = dX; r.ldy = lddx; r.bits_in = bits;
-    launch_rows(st, r, 256, 0);
+// dY [M][..] (row stride lddy) -> dX [M][256]
+RowsLayer dx_layer(const float *dY, int lddy, const float *recs, int kblocks, const unsigned int *bits, float *dX, int lddx) {
+    RowsLayer r{}; r.X = dY; r.ldx = lddy; r.recs = recs; r.kblocks = kblocks; r.Y = dX; r.ldy = lddx; r.bits_in = bits;
+    return r;
 }
+
 }   // namespace
 
 extern "C" {
@@ -1035,6 +1051,8 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     for (int i = 0; i < 8 && rc == NTX_OK; ++i)
         if (i != 4) rc = alloc(&t->h[i], (size_t)M * 256);
     for (int i = 0; i < 9 && rc == NTX_OK; ++i) rc = alloc((float **)&t->bits[i], (size_t)((M + 31) / 32) * 256);
+    if (rc == NTX_OK) rc = alloc((float **)&t->bits_ones, (size_t)((M + 31) / 32) * 256);
+    if (rc == NTX_OK && hipMemset(t->bits_ones, 0xFF, (size_t)((M + 31) / 32) * 1024) != hipSuccess) rc = ntx_set_error(NTX_E_HIP, "hipMemset failed");
     if (rc == NTX_OK) rc = alloc(&t->c1o, (size_t)M * 256);
     if (rc == NTX_OK) rc = alloc(&t->c2o, (size_t)M * 128);
     if (rc == NTX_OK) rc = alloc(&t->raw_rgb, (size_t)M * 3);
@@ -1184,16 +1202,24 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
         e.param_freq = t->desc.param_freq; e.blur_idx = blur_idx; e.pos_out = t->h4c; e.ld_pos = ldp; e.dir_out = t->fc; e.ld_dir = ldd; e.dists = t->dists;
         hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((M + ENC_SAMPLES - 1) / ENC_SAMPLES)), dim3(256), (size_t)ENC_SAMPLES * (ENC_BASE + Kp + Kd) * sizeof(float), st, e);
     }
-    for (int i = 0; i < 8; ++i) {                                                               // model.py:104-108
-        const TLayer &l = t->trunk[i];
-        const float *X = (i == 0 || i == 5) ? t->h4c : t->h[i - 1];
-        const int ldx = (i == 0 || i == 5) ? ldp : (i - 1 == 4 ? ldp : 256);
-        dense_forward(st, X, ldx, t->fwd_recs[i], t->fwd_kblocks[i], W + l.b, 256, M, t->h[i], i == 4 ? ldp : 256, 1, t->bits[i]);
+    {   // the trunk, the feature layer and the first colour layer as ONE chain (model.py:104-119)
+        RowsArgs fa{}; fa.M = M;
+        for (int i = 0; i < 8; ++i) {
+            const TLayer &l = t->trunk[i];
+            const float *X = (i == 0 || i == 5) ? t->h4c : t->h[i - 1];
+            const int ldx = (i == 0 || i == 5) ? ldp : (i - 1 == 4 ? ldp : 256);
+            fa.layer[fa.n_layers++] = forward_layer(X, ldx, t->fwd_recs[i], t->fwd_kblocks[i], W + l.b, t->h[i], i == 4 ? ldp : 256, 1, t->bits[i]);
+        }
+        fa.layer[fa.n_layers++] = forward_layer(t->h[7], 256, t->fwd_recs[8], t->fwd_kblocks[8], W + t->feature.b, t->fc + t->Kd4, ldd, 0, nullptr);    // :114-115
+        fa.layer[fa.n_layers++] = forward_layer(t->fc, ldd, t->fwd_recs[9], t->fwd_kblocks[9], W + t->c1.b, t->c1o, 256, 1, t->bits[8]);               // :118-119
+        launch_rows(st, fa, 256, true);
     }
     hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, t->h[7], 256, 256, W + t->alpha.w, W + t->alpha.b, 1, M, t->sigma);   // :111
-    dense_forward(st, t->h[7], 256, t->fwd_recs[8], t->fwd_kblocks[8], W + t->feature.b, 256, M, t->fc + t->Kd4, ldd, 0, nullptr);                                  // :114-115
-    dense_forward(st, t->fc, ldd, t->fwd_recs[9], t->fwd_kblocks[9], W + t->c1.b, 256, M, t->c1o, 256, 1, t->bits[8]);                                             // :118-119
-    dense_forward(st, t->c1o, 256, t->fwd_recs[10], t->fwd_kblocks[10], W + t->c2.b, 128, M, t->c2o, 128, 1, nullptr);                                                 // :122
+    {
+        RowsArgs ca{}; ca.M = M; ca.n_layers = 1;
+        ca.layer[0] = forward_layer(t->c1o, 256, t->fwd_recs[10], t->fwd_kblocks[10], W + t->c2.b, t->c2o, 128, 1, nullptr);                         // :122
+        launch_rows(st, ca, 128, true);
+    }
     hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 31) / 32)), dim3(256), 0, st, t->c2o, 128, 128, W + t->rgb.w, W + t->rgb.b, 3, M, t->raw_rgb);   // :123
     CompositeArgs c{};
     c.raw_rgb = t->raw_rgb; c.sigma = t->sigma; c.dists = t->dists; c.n_rays = (int)n_rays; c.S = S; c.map_exr = (flags & NTX_FLAG_MAP_EXR) ? 1 : 0;
@@ -1257,12 +1283,16 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     head_dw(t->c2o, 128, 128, t->d_raw, 3, t->rgb);
     hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 32 + 255) / 256)), dim3(256), 0, st, t->d_raw, 3, W + t->rgb.w, 128, M, t->c2o, 128, 0, t->g0, 128);
     head_dw(t->h[7], 256, 256, t->d_sigma, 1, t->alpha);
-    dense_backward_dx(st, t->g0, 128, t->bwd_recs[9], t->bwd_kblocks[9], M, t->bits[8], t->g1, 256);         // d c1o, masked by its ReLU
-    dense_backward_dx(st, t->g1, 256, t->bwd_recs[8], t->bwd_kblocks[8], M, nullptr, t->gf, LDGF);         // d feature (linear layer: no mask)
     // d h7 = (d feature . W_feature^T + d_sigma (x) W_alpha) where h7 > 0, as ONE contraction over 257: d_sigma goes beside d feature
     hipLaunchKernelGGL(column_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, t->d_sigma, M, t->gf + 256, LDGF);
-    dense_backward_dx(st, t->gf, LDGF, t->bwd_recs[7], t->bwd_kblocks[7], M, t->bits[7], t->dyt[7], 256);
-    for (int i = 7; i >= 1; --i) dense_backward_dx(st, t->dyt[i], 256, t->bwd_recs[i - 1], t->bwd_kblocks[i - 1], M, t->bits[i - 1], t->dyt[i - 1], 256);
+    {   // the way back, one chain: d c1o (masked by its ReLU), d feature (a linear layer: all kept), d h7, ... d h0
+        RowsArgs ba{}; ba.M = M;
+        ba.layer[ba.n_layers++] = dx_layer(t->g0, 128, t->bwd_recs[9], t->bwd_kblocks[9], t->bits[8], t->g1, 256);
+        ba.layer[ba.n_layers++] = dx_layer(t->g1, 256, t->bwd_recs[8], t->bwd_kblocks[8], t->bits_ones, t->gf, LDGF);
+        ba.layer[ba.n_layers++] = dx_layer(t->gf, LDGF, t->bwd_recs[7], t->bwd_kblocks[7], t->bits[7], t->dyt[7], 256);
+        for (int i = 7; i >= 1; --i) ba.layer[ba.n_layers++] = dx_layer(t->dyt[i], 256, t->bwd_recs[i - 1], t->bwd_kblocks[i - 1], t->bits[i - 1], t->dyt[i - 1], 256);
+        launch_rows(st, ba, 256, false);
+    }
     int rc = dw(t->c1o, 256, 256, t->g0, 128, 128, G + t->c2.w, G + t->c2.b);
     if (rc == NTX_OK) rc = concat_dw(t->fc, ldd, Kd, t->Kd4, t->g1, t->c1);
     if (rc == NTX_OK) rc = dw(t->h[7], 256, 256, t->gf, LDGF, 256, G + t->feature.w, G + t->feature.b);
