@@ -314,7 +314,7 @@ def bench_train_step(args) -> None:
                        "loss_after": float(val.item())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                          **train_step_traffic(),
-                         "kernel": "ntx_train::rows_kernel (forward and dX: 20 launches a step) + ntx_train::gemm_kernel (dW: 12 launches a step)", "kernel_ms": step_ms,
+                         "kernel": "ntx_train::rows_kernel (forward and dX: two chains of ten layers + the 128-wide colour layer) + ntx_train::gemm_batch_kernel (dW of all twelve layers)", "kernel_ms": step_ms,
                          "what": "3 x forward FLOPs (2 MACs per weight per sample) over the WHOLE step's HIP-event time: encoders, heads, composite, loss and Adam included"}}
     if not args.no_cpu_baseline:
         from oracle import nerftex_oracle as orc
