@@ -479,7 +479,9 @@ int ntx_trainer_get(ntx_trainer *t, int what, float *out_host, size_t n_floats);
 int ntx_trainer_set_weights(ntx_trainer *t, const float *weights_host, size_t n_floats);
 /* The activations the last step kept, to HOST memory as [n_samples_total][width]: layer 0-7 = the trunk layers' outputs (after their ReLU),
  * 8 / 9 = the two colour layers' (width 256 / 128), 10 = the raw density (width 1).  Tests hand their signs to the float64 restatement, so
- * that its autograd follows the ReLU branches the float32 forward took (a pre-activation within rounding of zero can fall either way). */
+ * that its autograd follows the ReLU branches the float32 forward took (a pre-activation within rounding of zero can fall either way).
+ * 20-27 = the GRADIENTS the last step kept at the trunk layers' outputs (behind their ReLU: what the layer's weight gradient contracts
+ * with), 28 = at the first colour layer's output, 29 = at the feature layer's (all width 256): tests compare them row by row. */
 int ntx_trainer_activation(ntx_trainer *t, int layer, int64_t n_samples_total, float *out_host);
 /* Forward (Renderer.__call__ for rays that all hit, renderer.py:92-213: sample depths by ntx_sample_depths -- NTX_FLAG_PERTURB /
  * perturb_seed / opts as there -- or given as z_vals[N,S]; encodings; the network; map_model_output with NTX_FLAG_MAP_EXR /

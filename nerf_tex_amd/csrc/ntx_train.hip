@@ -420,11 +420,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int e = threadIdx.x; e < L * NT * 32; e += 256) bl[e] = a.layer[e / (NT * 32)].bias[e % (NT * 32)];
     }
     // item w of this wave: which rows, which layer.  Behind the last one (and for the second half of an odd pair): no rows -- empty descriptors
+    const long long no_rows = n_blocks * 32;           // "no block": behind every row AND on a block boundary (its bits, too, must fall outside: M / 32 is the last block when M is ragged)
     auto item_row0 = [&](int w) -> long long {
-        if (w < 0 || w >= n_items) return a.M;
+        if (w < 0 || w >= n_items) return no_rows;
         const int p = w / (2 * L), rem = w - p * 2 * L;
         const long long grp = (long long)blockIdx.x + (long long)(2 * p + (rem & 1)) * gridDim.x;
-        return grp < n_groups ? (grp * 4 + wave) * 32 : a.M;
+        return grp < n_groups ? (grp * 4 + wave) * 32 : no_rows;
     };
     auto item_layer = [&](int w) -> int { return (w < 0 || w >= n_items) ? 0 : (w % (2 * L)) >> 1; };
     // this wave's quarter of a chunk, straight into LDS: one record (64 lanes x 16 bytes, lane-linear) per instruction
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         static_for_<RING>([&](auto I) { ring[I] = Lp[I * 64]; });
     }
     // the block under way and the one after it
-    __amdgpu_buffer_rsrc_t rx = x_rsrc(0, a.M), rxn = rx, rw = w_rsrc(0), rwn = rw, rbits = rw;
+    __amdgpu_buffer_rsrc_t rx = x_rsrc(0, no_rows), rxn = rx, rw = w_rsrc(0), rwn = rw, rbits = rw;
     uint32_t xoff = 0, xoffn = 0, bits_at = 0;
     int nb = 3;
     // one body: EP = 0 nothing else, 1 / 2 the first / second half of the previous block's outputs leave from the other accumulator set
@@ -1154,7 +1155,10 @@ int ntx_trainer_activation(ntx_trainer *t, int layer, int64_t n_samples_total, f
     else if (layer == 8) src = t->c1o;
     else if (layer == 9) { src = t->c2o; ld = 128; width = 128; }
     else if (layer == 10) { src = t->sigma; ld = 1; width = 1; }
-    else return ntx_set_error(NTX_E_INVALID, "layer %d (0-7 trunk, 8 / 9 the colour layers, 10 the density)", layer);
+    else if (layer >= 20 && layer < 28) src = t->dyt[layer - 20];
+    else if (layer == 28) src = t->g1;
+    else if (layer == 29) { src = t->gf; ld = LDGF; }
+    else return ntx_set_error(NTX_E_INVALID, "layer %d (0-7 trunk, 8 / 9 the colour layers, 10 the density; 20-29 the kept gradients)", layer);
     TRAIN_TRY(hipSetDevice(t->device));
     TRAIN_TRY(hipDeviceSynchronize());
     TRAIN_TRY(hipMemcpy2D(out_host, (size_t)width * sizeof(float), src, (size_t)ld * sizeof(float), (size_t)width * sizeof(float), (size_t)n_samples_total, hipMemcpyDeviceToHost));

@@ -85,9 +85,21 @@ def layer_slices(spec):
 def test_gradients_match_float64_autograd(fam, npar, blur, loss_name, bkgd, perturb):
     """dL/dW of all 13 layers (kernels and biases) after one forward + backward of the fused step, per layer within 1e-4 rel-Linf of float64
     autograd through the restated renderer and loss; also the loss value and the predictions."""
+    check_gradients(fam, npar, blur, loss_name, bkgd, perturb, 96, 48)
+
+
+@pytest.mark.parametrize("n,S", [(50, 37), (301, 33), (700, 64)])
+def test_gradients_at_ragged_sizes(n, S):
+    """The same at sample counts off every granule of the kernels: 1850 samples (the last block of 32 rows ragged, fewer groups of four blocks
+    than workgroups, a workgroup's second block of a pair empty), 9933 (ragged, an odd number of groups), 44 800 (more groups than the 256
+    persistent workgroups: some walk two pairs of blocks through the layer chain, some one and a half)."""
+    check_gradients("carpet", (1, 6), None, "alpha_smape", False, False, n, S, floor_check=False)
+
+
+def check_gradients(fam, npar, blur, loss_name, bkgd, perturb, n, S, floor_check=True):
     from nerf_tex_amd.train import Trainer
     model, spec, wts = make_model(npar, dense_media=True)
-    n, S, P = 96, 48, sum(npar)
+    P = sum(npar)
     ro, rd, t, cone, params, color, alpha = batch(3, n, S, P, fam)
     okw, loss = make_loss(loss_name)
     tr = Trainer(model, max_rays=n, n_samples=S, perturb=perturb, blur_idx=blur)
@@ -110,6 +122,8 @@ def test_gradients_match_float64_autograd(fam, npar, blur, loss_name, bkgd, pert
     worst = {name: rel_linf(got[sl], flat[sl]) for name, sl in layer_slices(spec)}
     assert max(worst.values()) <= 1e-4, {k: v for k, v in worst.items() if v > 1e-5}
     assert np.abs(flat).max() > 1e-6                                             # a gradient worth the name
+    if not floor_check:
+        return
     # ... and against float64 autograd left to its own branches: as close as float32 autograd of the same restatement gets (the float32 floor
     # of this comparison, measured beside it), and the two patterns differ in a handful of units
     free = np.concatenate([g.ravel() for g in tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, okw, **kw)[3]])

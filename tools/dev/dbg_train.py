@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo')
 from tests.test_gpu_train import *
 from nerf_tex_amd.train import Trainer
 model, spec, wts = make_model((1, 6), dense_media=True)
-n, S, P = 96, 48, 7
+n, S, P = (int(sys.argv[1]) if len(sys.argv) > 1 else 96), (int(sys.argv[2]) if len(sys.argv) > 2 else 48), 7
 ro, rd, t, cone, params, color, alpha = batch(3, n, S, P, "carpet")
 okw, loss = make_loss("alpha_smape")
 tr = Trainer(model, max_rays=n, n_samples=S, perturb=False)
