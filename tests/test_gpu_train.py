@@ -88,9 +88,9 @@ def test_gradients_match_float64_autograd(fam, npar, blur, loss_name, bkgd, pert
     check_gradients(fam, npar, blur, loss_name, bkgd, perturb, 96, 48)
 
 
-@pytest.mark.parametrize("n,S", [(50, 37), (301, 33), (700, 64)])
+@pytest.mark.parametrize("n,S", [(2, 3), (3, 5), (50, 37), (301, 33), (700, 64)])
 def test_gradients_at_ragged_sizes(n, S):
-    """The same at sample counts off every granule of the kernels: 1850 samples (the last block of 32 rows ragged, fewer groups of four blocks
+    """The same at sample counts off every granule of the kernels: 6 and 15 samples (less than one block of 32 rows), 1850 samples (the last block of 32 rows ragged, fewer groups of four blocks
     than workgroups, a workgroup's second block of a pair empty), 9933 (ragged, an odd number of groups), 44 800 (more groups than the 256
     persistent workgroups: some walk two pairs of blocks through the layer chain, some one and a half)."""
     check_gradients("carpet", (1, 6), None, "alpha_smape", False, False, n, S, floor_check=False)
@@ -115,13 +115,16 @@ def check_gradients(fam, npar, blur, loss_name, bkgd, perturb, n, S, floor_check
     sigma_mask = (tr.activation(10, M) > 0).astype(np.float64).reshape(n, S)
     kw = dict(blur_idx=blur, composite_bkgd=bkgd, bkgd=(1., .5, .25))
     want_val, wc, wa, wg = tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, okw, masks=masks, sigma_mask=sigma_mask, **kw)
-    assert abs(float(val.item()) - want_val) <= 1e-5 * abs(want_val) + 1e-7
-    assert orc.rel_linf(np.concatenate([cp.cpu().numpy(), ap.cpu().numpy()[:, None]], -1), np.concatenate([wc, wa[:, None]], -1)) <= 1e-4
+    # (a handful of rays with a handful of coarse steps each: 1 - exp(-sigma dist) at dist ~ 0.5 carries a float32 sigma's rounding five times as
+    # far, and nothing averages out -- those cases are here for the kernels' granules, at five times the tolerance)
+    tiny = 5.0 if n * S < 100 else 1.0
+    assert abs(float(val.item()) - want_val) <= (1e-5 if n * S >= 1000 else 1e-4) * tiny * abs(want_val) + 1e-7
+    assert orc.rel_linf(np.concatenate([cp.cpu().numpy(), ap.cpu().numpy()[:, None]], -1), np.concatenate([wc, wa[:, None]], -1)) <= 1e-4 * tiny
     flat = np.concatenate([g.ravel() for g in wg])
     assert flat.size == got.size == tr.n_weights
     worst = {name: rel_linf(got[sl], flat[sl]) for name, sl in layer_slices(spec)}
-    assert max(worst.values()) <= 1e-4, {k: v for k, v in worst.items() if v > 1e-5}
-    assert np.abs(flat).max() > 1e-6                                             # a gradient worth the name
+    assert max(worst.values()) <= 1e-4 * tiny, {k: v for k, v in worst.items() if v > 1e-5}
+    assert np.abs(flat).max() > 1e-6 or n * S < 100                              # a gradient worth the name (a handful of samples may see none)
     if not floor_check:
         return
     # ... and against float64 autograd left to its own branches: as close as float32 autograd of the same restatement gets (the float32 floor
