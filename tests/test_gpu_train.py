@@ -167,6 +167,26 @@ def test_training_step_is_bit_reproducible_and_adam_matches_its_restatement():
         assert np.abs(step).max() > 1e-5
 
 
+def test_gradients_do_not_depend_on_capacity_or_history():
+    """A trainer created for more rays than a step brings, and one whose buffers still hold a larger batch's activations, gradients and mask
+    bits, take the step of a fresh right-sized one bit for bit (nothing behind the last sample is read)."""
+    from nerf_tex_amd.train import Trainer
+    model, spec, wts = make_model((1, 6), dense_media=True)
+    n, S = 75, 41                                                                # 3075 samples: ragged
+    ro, rd, t, cone, params, color, alpha = batch(7, n, S, 7, "carpet")
+    big = batch(8, 200, S, 7, "carpet")
+    okw, loss = make_loss("alpha_smape")
+    grads = []
+    for cap, history in ((n, False), (200, False), (200, True)):
+        tr = Trainer(model, max_rays=cap, n_samples=S, perturb=True)
+        if history:
+            tr.gradients_step(*big[:3], big[4], big[3], big[5], big[6], loss, seed=1)
+        tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss, seed=3)
+        grads.append(tr.gradients())
+    assert np.abs(grads[0]).max() > 1e-6
+    assert np.array_equal(grads[0], grads[1]) and np.array_equal(grads[0], grads[2])
+
+
 def test_a_few_steps_fit_a_target():
     """The loop of train.py:61-67 does what a training loop is for: fitting one batch, the loss falls."""
     from nerf_tex_amd.train import Trainer
