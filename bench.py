@@ -269,23 +269,59 @@ def bench_train_step(args) -> None:
     mse (:95-99), Adam under ExponentialDecay (lrate 5e-4, lrate_decay 500) -- forward with every activation kept, loss, backward, optimiser
     step, on `ntx_trainer_*`.  value = ray-samples/s through a whole step; roofline: 3 x the forward's canonical FLOPs
     (2 MACs per weight per sample; the backward pass is two contractions of the forward's size per layer) against the f32 MFMA
-    peak.  cpu_baseline: the same step as float32 torch autograd on the host (oracle/train_oracle.py), a bounded sample.  N = 1 only."""
+    peak.  cpu_baseline: the same step as float32 torch autograd on the host (oracle/train_oracle.py), a bounded sample.
+    N > 1: data parallel, weak scaling -- every rank its own 1024 rays, ONE collective a step: the mean of the 2.7 MB of gradients over the
+    ranks (`Trainer.sync_gradients`: ncclAllReduce behind the C ABI), then the same Adam step everywhere; value = all ranks' ray-samples over
+    the slowest rank's time."""
     import torch
     from nerf_tex_amd import synthetic
     from nerf_tex_amd.loss import AlphaLoss
     from nerf_tex_amd.model import ParamNerf
     from nerf_tex_amd.train import Trainer
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
-        sys.exit("carpet_train_step is a single-GPU workload (data parallel training would all-reduce 2.7 MB of gradients per step: not built)")
-    dev = torch.device("cuda", 0)
+    import torch.distributed as dist
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")                     # RCCL prints its banner on stdout: the line goes to the original one
+    os.dup2(2, 1)
+    share_gpu = world > 1 and os.environ.get("NTX_BENCH_SHARE_GPU") == "1"          # development: all ranks on GPU 0, gloo (see main)
+    if share_gpu:
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    comm, how = None, None
+    if world > 1:
+        import faulthandler
+        from nerf_tex_amd.dist import Comm
+        faulthandler.dump_traceback_later(args.deadline, exit=True)
+        if share_gpu:
+            dist.init_process_group("gloo")
+            how = "torch.distributed (gloo) through host memory: NTX_BENCH_SHARE_GPU=1, all ranks on one GPU -- timings are not a measurement"
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+            err = None
+            try:
+                comm = Comm(local_rank)
+            except Exception as e:                           # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+            flag = torch.tensor([0 if err is None else 1], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                if comm is not None:
+                    comm.close()
+                comm = None
+                how = "torch.distributed all_reduce through host memory (fallback: no ntx_comm on some rank" + (f"; here: {err})" if err else ")")
+                print("bench.py: " + how, file=sys.stderr)
+            else:
+                how = f"ntx_trainer_allreduce_gradients (one ncclAllReduce through the C ABI, {comm.library})"
     fam = synthetic.FAMILIES["carpet"]
     emb = lambda n_: {"module": "network.model.FourierFeatures", "n_freq_bands": n_}
     model = ParamNerf(emb(10), emb(4), emb(4), list(fam["n_parameters"]))["model"]
     model.set_blob(synthetic.synthetic_weights(model.layer_table(), seed=0, dense_media=True))
     n, S = 4 * 256, 256
-    ro, rd, t, cone = synthetic.all_hit_rays(n, [-1.5, -1.3, -.2], [1.3, 1.3, 1.9], fam["cam"])           # config_carpet_train.py:28-31
-    rng = np.random.default_rng(3)
+    ro, rd, t, cone = synthetic.all_hit_rays(n, [-1.5, -1.3, -.2], [1.3, 1.3, 1.9], fam["cam"], seed=1 + rank)           # config_carpet_train.py:28-31
+    rng = np.random.default_rng(3 + rank)
     params = np.tile(np.asarray([fam["params"]], np.float32), (n, 1))
     color = rng.uniform(0, 1, size=(n, 3)).astype(np.float32)
     alpha = ((rng.uniform(0, 1, size=n) > 0.3) * rng.uniform(0.5, 1, size=n)).astype(np.float32)
@@ -294,19 +330,35 @@ def bench_train_step(args) -> None:
     loss = AlphaLoss(loss_fn="network.loss.smape", alpha_loss_fn="network.loss.mse")
     tr = Trainer(model, max_rays=n, n_samples=S, lrate=5e-4, lrate_decay=500, perturb=True)
     for _ in range(args.warmup):
-        tr.step(*batch, loss)
+        tr.step(*batch, loss, comm=comm)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for a, b in ev:
-        a.record(); val = tr.step(*batch, loss); b.record()
+        a.record(); val = tr.step(*batch, loss, comm=comm); b.record()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
     step_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    in_step = True
+    if world > 1:                                            # the slowest rank's clock; do the ranks hold the same weights after the same steps?
+        sdev = torch.device("cpu") if share_gpu else dev
+        tmax = torch.tensor([elapsed, step_ms], dtype=torch.float64, device=sdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed, step_ms = float(tmax[0]), float(tmax[1])
+        w = torch.from_numpy(tr.weights()).to(sdev)
+        ws = [torch.empty_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        in_step = all(bool(torch.equal(ws[0], x)) for x in ws)
+        if rank != 0:
+            return
     flops_fwd = 2 * model.macs_per_sample()
     achieved = 3 * flops_fwd * n * S / (step_ms * 1e-3) / 1e12
     line = {"metric": "ray-samples/sec through one training step (forward + loss + backward + Adam) at 4 x 256 rays x 256 samples",
-            "value": n * S * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "value": world * n * S * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"carpet_train_step: config_carpet_train.py's batch ({n} all-hit rays x {S} samples = {n * S} ray-samples), ParamNerf "
                                    f"n_parameters={list(fam['n_parameters'])}, perturb=True, AlphaLoss(smape, mse), Adam + ExponentialDecay(5e-4, 5e5 steps, 0.1); "
@@ -316,7 +368,7 @@ def bench_train_step(args) -> None:
                          **train_step_traffic(),
                          "kernel": "ntx_train::rows_kernel (forward and dX: two chains of ten layers + the 128-wide colour layer) + ntx_train::gemm_batch_kernel (dW of all twelve layers)", "kernel_ms": step_ms,
                          "what": "3 x forward FLOPs (2 MACs per weight per sample) over the WHOLE step's HIP-event time: encoders, heads, composite, loss and Adam included"}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         from oracle import nerftex_oracle as orc
         from oracle import torch_cpu, train_oracle as tro
         cores = torch_cpu.effective_cpus()
@@ -333,7 +385,14 @@ def bench_train_step(args) -> None:
         line["cpu_baseline"] = {"value": nb * S / dt, "unit": "ray-samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
                                 "sample": f"{nb} rays x {S} samples of the same batch: forward + loss + torch autograd backward in float32 (oracle/train_oracle.py, no optimiser "
                                           f"step), {dt:.2f} s on {torch.get_num_threads()} threads"}
-    print(json.dumps(line), flush=True)
+    if world > 1:
+        line["allreduce_how"] = how
+        line["allreduce_bytes"] = int(tr.n_weights) * 4
+        line["ranks_hold_identical_weights"] = in_step
+        line["config"]["workload"] += f"; data parallel over {world} GPUs: every rank its own {n} rays, gradients averaged once a step" + (
+            " [NTX_BENCH_SHARE_GPU=1: all ranks on one GPU]" if share_gpu else "")
+    json_out.write(json.dumps(line) + "\n")
+    json_out.flush()
 
 
 def bench_instanced_scene(args) -> None:

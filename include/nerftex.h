@@ -318,6 +318,12 @@ int ntx_comm_destroy(ntx_comm *comm);
 int ntx_gather_image(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, int64_t run_length, float *image_out,
                      float *staging, int root, ntx_stream stream);
 
+/* ABI v5.  values[n] (DEVICE) <- the mean over all ranks of their values[n], in place, on `stream`: one ncclAllReduce (rccl.h) and a scale.
+ * The one collective of data-parallel TRAINING (the reference trains on one device: train.py:61-67): ranks take the same step on different
+ * rays, the loss is a mean over rays, so the full batch's gradient is the mean of the shards' (equal shard sizes).  ntx_comm_size: n_ranks. */
+int ntx_comm_size(const ntx_comm *comm);
+int ntx_allreduce_mean_f32(ntx_comm *comm, float *values, size_t n, ntx_stream stream);
+
 /* ABI v3, host only (no device, no communicator): the exchange ntx_gather_image performs for a shard map, as numbers -- rank r
  * holds counts_out[r] pixels and its block starts at pixel slot offsets_out[r] of the destination; *equal_out = one ncclGather
  * (else grouped Send/Recv with the exact counts); *direct_out = the destination is image_out itself (else `staging`, followed by
@@ -477,6 +483,11 @@ size_t ntx_trainer_weight_count(const ntx_trainer *t);
 /* Copies one of the trainer's weight-shaped vectors to HOST memory (Keras get_weights() order; synchronises the device). */
 int ntx_trainer_get(ntx_trainer *t, int what, float *out_host, size_t n_floats);
 int ntx_trainer_set_weights(ntx_trainer *t, const float *weights_host, size_t n_floats);
+/* ... any of the four, from HOST memory (NTX_TRAINER_GRADIENTS: a gradient averaged over ranks by another transport than RCCL). */
+int ntx_trainer_set(ntx_trainer *t, int what, const float *values_host, size_t n_floats);
+/* Data-parallel training: every rank's gradient <- the mean over the ranks (ntx_allreduce_mean_f32 on the trainer's own buffer), between
+ * ntx_train_step_gradients and ntx_trainer_adam_step; all ranks then take the same Adam step. */
+int ntx_trainer_allreduce_gradients(ntx_trainer *t, ntx_comm *comm, ntx_stream stream);
 /* The activations the last step kept, to HOST memory as [n_samples_total][width]: layer 0-7 = the trunk layers' outputs (after their ReLU),
  * 8 / 9 = the two colour layers' (width 256 / 128), 10 = the raw density (width 1).  Tests hand their signs to the float64 restatement, so
  * that its autograd follows the ReLU branches the float32 forward took (a pre-activation within rounding of zero can fall either way).

@@ -24,6 +24,11 @@ __global__ __launch_bounds__(256) void ntx_unshard_kernel(const f32x4 *staging, 
     image[p] = staging[ntx_shard::staging_index(p, run_length, n_ranks, rank_stride)];
 }
 
+__global__ void ntx_scale_kernel(float *v, size_t n, float f) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) v[e] *= f;
+}
+
 extern "C" int ntx_set_error(int code, const char *fmt, ...);   // nerftex.hip: per-thread message behind ntx_last_error()
 
 namespace {
@@ -34,6 +39,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Gather)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -65,7 +71,7 @@ Rccl load_rccl() {
         ok = ok && fn != nullptr;
     };
     sym(r.GetUniqueId, "ncclGetUniqueId"); sym(r.CommInitRank, "ncclCommInitRank"); sym(r.CommDestroy, "ncclCommDestroy");
-    sym(r.Gather, "ncclGather"); sym(r.Send, "ncclSend"); sym(r.Recv, "ncclRecv");
+    sym(r.Gather, "ncclGather"); sym(r.AllReduce, "ncclAllReduce"); sym(r.Send, "ncclSend"); sym(r.Recv, "ncclRecv");
     sym(r.GroupStart, "ncclGroupStart"); sym(r.GroupEnd, "ncclGroupEnd"); sym(r.GetErrorString, "ncclGetErrorString");
     if (!ok) { r.handle = nullptr; return r; }
     Dl_info info;   // which file the symbols really come from (diagnostics: ntx_comm_library)
@@ -227,6 +233,21 @@ int ntx_gather_image(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, 
             reinterpret_cast<const f32x4 *>(staging), n_pixels, run_length, R_, cap, reinterpret_cast<f32x4 *>(image_out));
         HIP_TRY(hipGetLastError());
     }
+    return NTX_OK;
+}
+
+int ntx_comm_size(const ntx_comm *comm) { return comm ? comm->n_ranks : 0; }
+
+int ntx_allreduce_mean_f32(ntx_comm *comm, float *values, size_t n, ntx_stream stream) {
+    if (!comm || (!values && n > 0)) return ntx_set_error(NTX_E_INVALID, "NULL argument");
+    if (n == 0 || comm->n_ranks == 1) return NTX_OK;
+    const Rccl *R = rccl();
+    if (!R) return ntx_set_error(NTX_E_UNSUPPORTED, "librccl is not loaded: %s", rccl_why());
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(comm->device));
+    RCCL_TRY(R->AllReduce(values, values, n, ncclFloat, ncclSum, comm->comm, st));
+    hipLaunchKernelGGL(ntx_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, values, n, 1.0f / (float)comm->n_ranks);
+    HIP_TRY(hipGetLastError());
     return NTX_OK;
 }
 

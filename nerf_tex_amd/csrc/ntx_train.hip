@@ -1173,6 +1173,22 @@ int ntx_trainer_set_weights(ntx_trainer *t, const float *weights_host, size_t n_
     return NTX_OK;
 }
 
+int ntx_trainer_set(ntx_trainer *t, int what, const float *values_host, size_t n_floats) {
+    if (!t || !values_host) return ntx_set_error(NTX_E_INVALID, "NULL argument");
+    if (n_floats != t->n_weights) return ntx_set_error(NTX_E_INVALID, "%zu floats given, the model has %zu", n_floats, t->n_weights);
+    float *dst = what == NTX_TRAINER_WEIGHTS ? t->w : what == NTX_TRAINER_GRADIENTS ? t->grad : what == NTX_TRAINER_ADAM_M ? t->adam_m : what == NTX_TRAINER_ADAM_V ? t->adam_v : nullptr;
+    if (!dst) return ntx_set_error(NTX_E_INVALID, "what = %d", what);
+    TRAIN_TRY(hipSetDevice(t->device));
+    TRAIN_TRY(hipDeviceSynchronize());
+    TRAIN_TRY(hipMemcpy(dst, values_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    return NTX_OK;
+}
+
+int ntx_trainer_allreduce_gradients(ntx_trainer *t, ntx_comm *comm, ntx_stream stream) {
+    if (!t || !comm) return ntx_set_error(NTX_E_INVALID, "NULL argument");
+    return ntx_allreduce_mean_f32(comm, t->grad, t->n_weights, stream);
+}
+
 int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *rays_d, const float *tnear_far, const float *params, int64_t rays_per_param_row,
                              const float *cone_scale, int64_t n_rays, int n_samples, int blur_idx, uint32_t flags, const float *bkgd, uint64_t perturb_seed,
                              const ntx_render_opts *opts, const float *z_vals, const float *color_true, const float *alpha_true, const ntx_loss_desc *loss,

@@ -138,3 +138,25 @@ def test_cpu_baseline_block():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "ray-samples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert c["cpu_count"] >= c["cores"] and "BLAS_INFO" in c["blas"]       # threads and BLAS backend stated
+
+
+def test_train_step_line_at_one_and_at_two_ranks():
+    """`--workload carpet_train_step`: the N = 1 line (roofline on 3 x forward FLOPs, the step's measured traffic quoted, a torch-CPU
+    baseline beside it) and the data-parallel N = 2 line with everything but RCCL itself (NTX_BENCH_SHARE_GPU: both ranks on GPU 0, the
+    gradient mean through gloo): launcher, per-rank batches, max-over-ranks clock, and the ranks holding identical weights after the steps."""
+    d = _run("--workload", "carpet_train_step")
+    assert d["n_gpus"] == 1 and d["unit"] == "ray-samples/s" and d["dtype"] == "f32" and d["scaling"] == "weak" and "carpet_train_step" in d["config"]["workload"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.4 < r["frac"] < 1.0
+    assert abs(3 * d["config"]["flops_per_sample_forward"] * 262144 / (r["kernel_ms"] * 1e-3) / 1e12 - r["achieved"]) / r["achieved"] < 1e-6
+    assert r["traffic"] is None or r["traffic"] > 1e10
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["value"] > 50 * d["cpu_baseline"]["value"]
+    env = dict(os.environ, NTX_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--deadline", "500", "--workload", "carpet_train_step"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and "NTX_BENCH_SHARE_GPU" in d2["allreduce_how"] and "NTX_BENCH_SHARE_GPU" in d2["config"]["workload"]
+    assert d2["allreduce_bytes"] == 683524 * 4 and d2["ranks_hold_identical_weights"] is True and d2["value"] > 0 and "cpu_baseline" not in d2

@@ -187,6 +187,19 @@ def test_gradients_do_not_depend_on_capacity_or_history():
     assert np.array_equal(grads[0], grads[1]) and np.array_equal(grads[0], grads[2])
 
 
+def test_two_ranks_train_data_parallel():
+    """Data-parallel training with everything but RCCL itself on a 1-GPU box: two processes (torch.distributed.run, gloo) share GPU 0, each
+    takes the gradient of its half of a batch, `Trainer.sync_gradients` averages -- the whole batch's gradient to float32 rounding -- and both
+    take the same Adam step bit for bit (tests/_dp_train_worker.py).  With a communicator the same mean is one ncclAllReduce behind
+    `ntx_trainer_allreduce_gradients`."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29653",
+                          os.path.join(root, "tests", "_dp_train_worker.py")], capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "DP_TRAIN_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
 def test_a_few_steps_fit_a_target():
     """The loop of train.py:61-67 does what a training loop is for: fitting one batch, the loss falls."""
     from nerf_tex_amd.train import Trainer

@@ -64,3 +64,42 @@ def test_autograd_matches_finite_differences(loss):
     wt = [torch.tensor(x) for x in w]
     pos = torch.tensor(ro)[:, None, :] + torch.tensor(rd)[:, None, :] * torch.tensor(z)[:, :, None]
     assert val == pytest.approx(float(tro.step_gradients(w, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0, composite_bkgd=True, bkgd=(1., .5, .2))[0]))
+
+
+def _dp_worker(rank, world, port, q):
+    """Rank `rank` of a data-parallel step on CPU: the restated step on ITS half of the rays, the product's host-side mean over ranks."""
+    import os
+    import torch.distributed as dist
+    from nerf_tex_amd.train import allreduce_mean_host
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = orc.ModelSpec(kind="ParamNerf", n_parameters=(1, 2), depth=3, width=8, skips=(1,), pos_freq=2, dir_freq=1, param_freq=1)
+    rng = np.random.default_rng(1)
+    w = [rng.normal(size=(i, o)) * 0.5 if b == 0 else rng.normal(size=o) * 0.1 for _, i, o in orc.layer_table(spec) for b in (0, 1)]
+    ro, rd, z, par, cone, ct, at = tiny_batch(seed=3, n=8, S=5)
+    ok = True
+    for loss in (dict(kind="alpha", loss_fn="smape", alpha_loss_fn="mse"), dict(kind="nerf", loss_fn="mse")):
+        whole = np.concatenate([g.ravel() for g in tro.step_gradients(w, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0)[3]])
+        lo, hi = rank * 8 // world, (rank + 1) * 8 // world
+        mine = np.concatenate([g.ravel() for g in tro.step_gradients(w, spec, ro[lo:hi], rd[lo:hi], z[lo:hi], par[lo:hi], cone[lo:hi], ct[lo:hi], at[lo:hi], loss, blur_idx=0)[3]])
+        mean = allreduce_mean_host(mine)
+        ok = ok and mean.dtype == np.float32 and bool(np.allclose(mean, whole, rtol=2e-6, atol=1e-7 * np.abs(whole).max())) and not np.allclose(mine, whole, rtol=1e-3)
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_world2_gloo():
+    """N > 1 training on CPU: the losses of loss.py are means over rays, so the mean over ranks of the gradients of equal shards is the whole
+    batch's gradient -- the one collective of data-parallel training (`Trainer.sync_gradients`: ncclAllReduce behind the C ABI on GPUs, this
+    host-side mean otherwise), executed by two gloo ranks on the restated step."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=180) for _ in procs)
+    [p.join(60) for p in procs]
+    assert res == [(0, True), (1, True)]
