@@ -240,13 +240,13 @@ int ntx_comm_size(const ntx_comm *comm) { return comm ? comm->n_ranks : 0; }
 
 int ntx_allreduce_mean_f32(ntx_comm *comm, float *values, size_t n, ntx_stream stream) {
     if (!comm || (!values && n > 0)) return ntx_set_error(NTX_E_INVALID, "NULL argument");
-    if (n == 0 || comm->n_ranks == 1) return NTX_OK;
-    const Rccl *R = rccl();
+    if (n == 0) return NTX_OK;
+    const Rccl *R = rccl();                                   // (a communicator of one rank runs the collective too: the call is exercised wherever there is a GPU)
     if (!R) return ntx_set_error(NTX_E_UNSUPPORTED, "librccl is not loaded: %s", rccl_why());
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(comm->device));
     RCCL_TRY(R->AllReduce(values, values, n, ncclFloat, ncclSum, comm->comm, st));
-    hipLaunchKernelGGL(ntx_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, values, n, 1.0f / (float)comm->n_ranks);
+    if (comm->n_ranks > 1) hipLaunchKernelGGL(ntx_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, values, n, 1.0f / (float)comm->n_ranks);
     HIP_TRY(hipGetLastError());
     return NTX_OK;
 }

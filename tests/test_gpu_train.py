@@ -187,6 +187,28 @@ def test_gradients_do_not_depend_on_capacity_or_history():
     assert np.array_equal(grads[0], grads[1]) and np.array_equal(grads[0], grads[2])
 
 
+def test_gradient_allreduce_on_a_one_rank_communicator():
+    """ntx_trainer_allreduce_gradients on real RCCL with one rank (ncclAllReduce in place on the trainer's own buffer, on the step's stream):
+    the mean over one rank is the gradient itself, bit for bit, and the step after it is the step without it."""
+    from nerf_tex_amd.dist import Comm
+    from nerf_tex_amd.train import Trainer
+    model, spec, wts = make_model((1, 6), dense_media=True)
+    n, S = 64, 32
+    ro, rd, t, cone, params, color, alpha = batch(4, n, S, 7, "carpet")
+    okw, loss = make_loss("alpha_smape")
+    comm = Comm(0)
+    assert comm.world == 1
+    a = Trainer(model, max_rays=n, n_samples=S, perturb=False); b = Trainer(model, max_rays=n, n_samples=S, perturb=False)
+    a.gradients_step(ro, rd, t, params, cone, color, alpha, loss); g = a.gradients()
+    a.sync_gradients(comm)
+    torch.cuda.synchronize()
+    assert np.array_equal(a.gradients(), g) and np.abs(g).max() > 1e-6
+    a.apply_gradients()
+    b.step(ro, rd, t, params, cone, color, alpha, loss, comm=comm)
+    assert np.array_equal(a.weights(), b.weights())
+    comm.close()
+
+
 def test_two_ranks_train_data_parallel():
     """Data-parallel training with everything but RCCL itself on a 1-GPU box: two processes (torch.distributed.run, gloo) share GPU 0, each
     takes the gradient of its half of a batch, `Trainer.sync_gradients` averages -- the whole batch's gradient to float32 rounding -- and both
