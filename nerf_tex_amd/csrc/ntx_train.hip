@@ -46,15 +46,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// the contraction.  C[i][j] = sum_p A'(i, p) B(p, j) for i < M, j < N, p < K, with B[p * ldb + j] and
+// the general contraction.  C[i][j] = sum_p A'(i, p) B(p, j) for i < M, j < N, p < K, with B[p * ldb + j] and
 //   A'(i, p) = A_KCONTIG ? A[i * lda + p] : A[p * lda + i]
-// (forward and dX: activations [samples][features] times a [features][out] matrix -- dX takes the TRANSPOSED weights, made once a step;
-// dW: A' = X^T, the reduction runs over the samples).  A workgroup (4 waves) owns a 128 x 128 tile of C, a wave a 64 x 64 quarter of it
-// = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator registers).  K advances 32 at a time: the next 128 x 32 / 32 x 128 panels are fetched
-// into registers (16-byte loads when the panel lies inside the matrices and the rows are 16-byte aligned, element by element with
-// bounds otherwise) while the current ones, already in LDS as As[p][i] / Bs[p][j], feed 64 MFMAs per wave; one barrier per panel
-// (double buffered).  The f32 MFMA shares the vector ALUs' lanes, so every VALU instruction of the loop costs MFMA time:
-// hence the long panels, the vector loads and the bounds-free interior path.
+// In a training step it takes the weight gradients, dW = X^T . dY (A' = X^T: the reduction runs over the samples, split into ranges whose
+// partial sums are added in a fixed order); the row-major form (A_KCONTIG) is what ntx_gemm_f32 offers on caller buffers -- the step's
+// forward and dX contractions were here until rows_kernel (below) took them.  A workgroup (4 waves) owns a 128 x 128 tile of C, a wave a
+// 64 x 64 quarter of it = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator registers).  K advances a panel (16) at a time: the next
+// 128 x 16 / 16 x 128 panels are fetched into registers (16-byte loads when the panel lies inside the matrices and the rows are 16-byte
+// aligned, element by element with bounds otherwise) while the current ones, already in LDS as As[p][i] / Bs[p][j], feed the MFMAs; one
+// barrier per panel (double buffered).  The f32 MFMA shares the vector ALUs' lanes, so every VALU instruction of the loop
+// costs MFMA time: hence the vector loads and the branch-free interior path.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int TM = 128;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
