@@ -69,7 +69,6 @@ struct GemmArgs {
     int k_chunk; long long split_stride;   // blockIdx.z = z covers p in [z * k_chunk, (z + 1) * k_chunk) and writes to C + z * split_stride
     float *colsum;                   // NULL, or [n_split][N]: the column sums of B over each split's rows (the bias gradient rides along with dW)
     int aligned;                     // every row of A and B starts on a 16-byte boundary
-    int debug;                       // development (NERFTEX_GEMM_DEBUG): 1 = no MFMAs, 2 = no panel fetches behind the first: WRONG results, timing only
 };
 
 // n consecutive floats of a row into registers: 16-byte loads, or one by one under a bound
@@ -154,7 +153,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, int bx, int by, int
     // scheduling barriers keep the compiler from sinking the reads back down to their use, which leaves the matrix pipe idle for an LDS
     // round trip every step)
     auto compute = [&](int buf) {
-        if ((g.debug & 1) || !wave_live) return;
+        if (!wave_live) return;
         f32x2 av[2], bv[2];
         av[0] = *reinterpret_cast<const f32x2 *>(&As[buf][kh][wi]); bv[0] = *reinterpret_cast<const f32x2 *>(&Bs[buf][kh][wj]);
 #pragma unroll
@@ -189,17 +188,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, int bx, int by, int
         if (first + 1 < last) get(first + 1, ra[1], rb[1]);
         __syncthreads();
         int kt = first;                                               // LDS buffer of panel kt = (kt - first) & 1
-        if (!(g.debug & 2)) {
-            for (; kt + 3 < last; kt += 2) {
-                get(kt + 2, ra[0], rb[0]); compute(0); stash(1, ra[1], rb[1]); __syncthreads();
-                get(kt + 3, ra[1], rb[1]); compute(1); stash(0, ra[0], rb[0]); __syncthreads();
-            }
+        for (; kt + 3 < last; kt += 2) {
+            get(kt + 2, ra[0], rb[0]); compute(0); stash(1, ra[1], rb[1]); __syncthreads();
+            get(kt + 3, ra[1], rb[1]); compute(1); stash(0, ra[0], rb[0]); __syncthreads();
         }
         for (; kt < last; ++kt) {                                     // the last two or three panels: nothing left to ask for behind them
             const int buf = (kt - first) & 1;
-            if (kt + 2 < last && !(g.debug & 2)) { if (buf) get(kt + 2, ra[1], rb[1]); else get(kt + 2, ra[0], rb[0]); }
+            if (kt + 2 < last) { if (buf) get(kt + 2, ra[1], rb[1]); else get(kt + 2, ra[0], rb[0]); }
             compute(buf);
-            if (kt + 1 < last && !(g.debug & 2)) { if (buf) stash(0, ra[0], rb[0]); else stash(1, ra[1], rb[1]); }
+            if (kt + 1 < last) { if (buf) stash(0, ra[0], rb[0]); else stash(1, ra[1], rb[1]); }
             __syncthreads();
         }
     };
@@ -957,32 +954,13 @@ void free_all(ntx_trainer *t) {
     delete t;
 }
 
-int gemm_config() {                              // development: NERFTEX_GEMM_CONFIG = 0 (128 x 128 x 32), 1 (128 x 256 x 32), 2 (128 x 128 x 16: the default), 3 (128 x 256 x 16), 4 (128 x 128 x 8)
-    static const char *e = getenv("NERFTEX_GEMM_CONFIG");
-    return e ? atoi(e) : 2;
-}
-int gemm_tk() { const int c = gemm_config(); return c == 4 ? 8 : ((c == 2 || c == 3) ? 16 : 32); }
+// one contraction on caller buffers (ntx_gemm_f32): 128 x 128 tiles, panels of 16 -- the shape every measurement of the round ended on
+// (deeper panels or 256-wide tiles cost occupancy: 0.552 / 0.467 of the peak in the step against 0.58)
 template <bool AK>
-void launch_gemm(hipStream_t st, GemmArgs g, int n_split) {
-    if (n_split < 1) n_split = 1;
-    const int tk = gemm_tk();
-    g.k_chunk = n_split == 1 ? g.K : ((g.K + n_split - 1) / n_split + tk - 1) / tk * tk;
-    const int nz = (g.K + g.k_chunk - 1) / g.k_chunk;
+void launch_gemm(hipStream_t st, GemmArgs g) {
+    g.k_chunk = g.K;
     g.aligned = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (((uintptr_t)g.A | (uintptr_t)g.B) % 16 == 0);
-    { static const char *dbg = getenv("NERFTEX_GEMM_DEBUG"); g.debug = dbg ? atoi(dbg) : 0; }
-    const int rows = (g.M + TM - 1) / TM;
-    switch (gemm_config()) {
-    case 1: hipLaunchKernelGGL((gemm_kernel<AK, 256, 32>), dim3((g.N + 255) / 256, rows, nz), dim3(512), 0, st, g); break;
-    case 2: hipLaunchKernelGGL((gemm_kernel<AK, 128, 16>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
-    case 3: hipLaunchKernelGGL((gemm_kernel<AK, 256, 16>), dim3((g.N + 255) / 256, rows, nz), dim3(512), 0, st, g); break;
-    case 4: hipLaunchKernelGGL((gemm_kernel<AK, 128, 8>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
-    default: hipLaunchKernelGGL((gemm_kernel<AK, 128, 32>), dim3((g.N + 127) / 128, rows, nz), dim3(256), 0, st, g); break;
-    }
-}
-int split_parts(long long K, int n_split) {
-    const int tk = gemm_tk();
-    const int chunk = (((int)K + n_split - 1) / n_split + tk - 1) / tk * tk;
-    return ((int)K + chunk - 1) / chunk;
+    hipLaunchKernelGGL((gemm_kernel<AK, 128, 16>), dim3((g.N + 127) / 128, (g.M + TM - 1) / TM, 1), dim3(256), 0, st, g);
 }
 
 // a chain of layers in one launch: forward Y = act(X . W + b) through each layer's packed image, or dX = dY . W^T kept where the forward
@@ -1358,7 +1336,7 @@ int ntx_gemm_f32(const float *A, int lda, int a_kcontig, const float *B, int ldb
     ntx_train::GemmArgs g{}; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu;
     hipStream_t st = (hipStream_t)stream;
     if (b_kcontig) return ntx_set_error(NTX_E_UNSUPPORTED, "B must be [K][N] (the trainer transposes its weights once a step instead)");
-    if (a_kcontig) launch_gemm<true>(st, g, 1); else launch_gemm<false>(st, g, 1);
+    if (a_kcontig) launch_gemm<true>(st, g); else launch_gemm<false>(st, g);
     TRAIN_TRY(hipGetLastError());
     return NTX_OK;
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The trainer's contraction alone (ntx_gemm_f32): the three shapes a training step is made of, HIP-event timed.  GPU box only.
+"""The general contraction alone (ntx_gemm_f32; in a training step it takes the weight gradients, rows_kernel the rest), HIP-event timed.  GPU box only.
     python tools/bench_gemm.py [--m 262144]"""
 import argparse, json, os, sys
 import torch
@@ -24,4 +24,4 @@ def run(ak, Mg, N, K, lda, ldb):
 for name, args in [("forward / dX  [M,256] x [256,256]", (1, M, 256, 256, 256, 256)), ("forward  [M,340] x [337,256]", (1, M, 256, 337, 340, 256)),
                    ("dW  [M,256]^T x [M,256] (no split: one pass over M)", (0, 256, 256, M, 256, 256))]:
     ms, tf = run(*args)
-    print(json.dumps({"what": name, "ms": round(ms, 4), "TFLOP/s": round(tf, 1), "frac_of_157.3": round(tf / 157.3, 3), "debug": os.environ.get("NERFTEX_GEMM_DEBUG", "0")}))
+    print(json.dumps({"what": name, "ms": round(ms, 4), "TFLOP/s": round(tf, 1), "frac_of_157.3": round(tf / 157.3, 3)}))
