@@ -220,6 +220,12 @@ int ntx_composite(const float *color, const float *sigma, const float *z_vals, c
 int ntx_sample_depths(const float *t, int64_t n_rays, int n_points, uint32_t flags, uint64_t perturb_seed,
                       const ntx_render_opts *opts /* ray index map; may be NULL */, float *z_out, ntx_stream stream);
 
+/* ABI v5.  noise_out[n_rays, n_points] (DEVICE) = raw_noise_std * N(0,1): exactly the draws NTX_FLAG_RAW_NOISE adds to the density inside
+ * ntx_render_rays / ntx_render_instanced (ntx_render_opts above: Philox counter (sample, ray index, 1) under `seed`, Box-Muller), as a
+ * tensor -- what the reference's `tf.random.normal(alpha.shape) * raw_noise_std` is (renderer.py:190-192).  opts: raw_noise_std and the
+ * ray index map.  The training step uses it (config_grass_filtered_train.py:99 trains with raw_noise_std 0.1). */
+int ntx_sample_noise(int64_t n_rays, int n_points, uint64_t seed, const ntx_render_opts *opts, float *noise_out, ntx_stream stream);
+
 /* Replaces Renderer.__call__ + render_rays + evaluate_model + map_model_output
  * (renderer.py:47-213) with n_importance=0, fused in one launch:
  * culling of t==inf rays, sample placement, positional encoding, the MLP and the composite.

@@ -137,6 +137,7 @@ SYMBOLS = {
     "ntx_trainer_get": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
     "ntx_trainer_activation": (C.c_int, [_vp, C.c_int, C.c_int64, _fp]),
     "ntx_trainer_set_weights": (C.c_int, [_vp, _fp, C.c_size_t]),
+    "ntx_sample_noise": (C.c_int, [C.c_int64, C.c_int, C.c_uint64, _op, _vp, _vp]),
     "ntx_trainer_set": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
     "ntx_trainer_allreduce_gradients": (C.c_int, [_vp, _vp, _vp]),
     "ntx_comm_size": (C.c_int, [_vp]),

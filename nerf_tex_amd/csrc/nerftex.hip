@@ -1162,6 +1162,31 @@ int ntx_sample_depths(const float *t, int64_t n_rays, int n_points, uint32_t fla
     return NTX_OK;
 }
 
+// noise_out[ray][i] = raw_noise_std * N(0,1): the very draws the render kernels add to the density (ntx_device.h normal01)
+__global__ __launch_bounds__(256) void sample_noise_kernel(int64_t n_rays, int npts, float noise_std, uint32_t seed_lo, uint32_t seed_hi, int64_t idx0,
+                                                           uint32_t idx_run, int64_t idx_stride, float *noise_out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_rays * npts) return;
+    const int64_t ray = k / npts;
+    noise_out[k] = noise_std * normal01(global_index(idx0, idx_run, idx_stride, ray), (int)(k % npts), seed_lo, seed_hi);
+}
+
+int ntx_sample_noise(int64_t n_rays, int n_points, uint64_t seed, const ntx_render_opts *opts, float *noise_out, ntx_stream stream) {
+    if (n_rays < 0 || n_points < 1) return fail(NTX_E_INVALID, "n_rays < 0 or n_points < 1");
+    IndexMap im;
+    if (int rc = index_map_of(opts, &im)) return rc;
+    float noise_std = 0.0f;
+    if (int rc = noise_of(opts, NTX_FLAG_RAW_NOISE, &noise_std)) return rc;
+    if (n_rays > 0x7fffffff) return fail(NTX_E_INVALID, "n_rays %lld exceeds int32", (long long)n_rays);
+    if (n_rays == 0) return NTX_OK;
+    if (!noise_out) return fail(NTX_E_INVALID, "NULL buffer");
+    const int64_t n = n_rays * n_points;
+    sample_noise_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(n_rays, n_points, noise_std, (uint32_t)seed, (uint32_t)(seed >> 32), im.idx0,
+                                                                                                   im.run, im.stride, noise_out);
+    HIP_TRY(hipGetLastError());
+    return NTX_OK;
+}
+
 int ntx_sample_pdf(const float *t, const float *z_vals, const float *weights, const float *u, int64_t n_rays,
                    int n_samples, int n_importance, uint32_t flags, uint64_t perturb_seed, const ntx_render_opts *opts, float *z_out,
                    ntx_stream stream) {

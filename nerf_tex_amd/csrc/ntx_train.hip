@@ -771,6 +771,7 @@ __global__ void head_backward_dw_partial_kernel(const float *__restrict__ X, int
 // ---------------------------------------------------------------------------------------------------------------------------
 struct CompositeArgs {
     const float *raw_rgb, *sigma, *dists;      // [N][S][3], [N][S], [N][S]
+    const float *noise;                        // NULL, or [N][S]: raw_noise_std * N(0,1), added to the density before its ReLU (renderer.py:190-195)
     int n_rays, S, map_exr, composite_bkgd; float bkgd[3];
     float *color, *alpha;                      // forward outputs [N][3], [N]
     const float *d_color, *d_alpha;            // backward inputs
@@ -790,8 +791,9 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
     if (ray >= a.n_rays) return;
     const int S = a.S;
     const float *sg = a.sigma + (size_t)ray * S, *ds = a.dists + (size_t)ray * S, *rr = a.raw_rgb + (size_t)ray * S * 3;
+    const float *nz = a.noise ? a.noise + (size_t)ray * S : nullptr;
     float *al = sh_a[wave], *T = sh_T[wave];
-    for (int s = lane; s < S; s += 64) { const float r = sg[s] > 0.0f ? sg[s] : 0.0f; al[s] = 1.0f - expf(-r * ds[s]); }    // :195
+    for (int s = lane; s < S; s += 64) { const float v = nz ? sg[s] + nz[s] : sg[s]; const float r = v > 0.0f ? v : 0.0f; al[s] = 1.0f - expf(-r * ds[s]); }    // :190-195
     __builtin_amdgcn_wave_barrier();
     // exclusive running product of (1 - a) + 1e-10, sequential like tf.math.cumprod (:198): chunks of 64 with a carry
     float carry = 1.0f;
@@ -837,7 +839,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
         if (s < S) {
             const float w = al[s] * T[s];
             const float d_a = T[s] * g - behind / ((1.0f - al[s]) + 1e-10f);
-            const float sig = sg[s];
+            const float sig = nz ? sg[s] + nz[s] : sg[s];
             a.d_sigma[(size_t)ray * S + s] = sig > 0.0f ? d_a * ds[s] * expf(-sig * ds[s]) : 0.0f;
             for (int c = 0; c < 3; ++c) {
                 const float raw = rr[3 * s + c];
@@ -925,6 +927,7 @@ struct ntx_trainer {
     float *gf = nullptr;                       // [d feature (256) | d_sigma | 3 zeros] per sample, row stride LDGF
     float *dyt[8] = {};                        // the gradient at every trunk layer's output (what its dW contracts with): kept, so that all dW run in one launch
     float *dw_partial = nullptr; size_t dw_partial_floats = 0;
+    float *noise = nullptr;                    // [M]: the density regulariser's draws of a step (raw_noise_std)
     float *z = nullptr, *dists = nullptr, *g0 = nullptr, *g1 = nullptr, *d_raw = nullptr, *d_sigma = nullptr, *partial = nullptr;
     float *color = nullptr, *alpha_out = nullptr, *d_color = nullptr, *d_alpha = nullptr, *loss = nullptr;
     long long cap_rays = 0;
@@ -943,7 +946,7 @@ constexpr int LDGF = 260;
 void free_all(ntx_trainer *t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
-    void *ptrs[] = {t->w, t->wp, t->grad, t->adam_m, t->adam_v, t->h4c, t->fc, t->c1o, t->c2o, t->raw_rgb, t->sigma, t->z, t->dists, t->g0, t->g1, t->gf, t->d_raw, t->d_sigma,
+    void *ptrs[] = {t->w, t->wp, t->grad, t->adam_m, t->adam_v, t->h4c, t->fc, t->c1o, t->c2o, t->raw_rgb, t->sigma, t->z, t->dists, t->noise, t->g0, t->g1, t->gf, t->d_raw, t->d_sigma,
                     t->partial, t->color, t->alpha_out, t->d_color, t->d_alpha, t->loss};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 8; ++i) if (i != 4 && t->h[i]) (void)hipFree(t->h[i]);
@@ -989,6 +992,7 @@ extern "C" {
 
 int ntx_sample_depths(const float *t, int64_t n_rays, int n_points, uint32_t flags, uint64_t perturb_seed, const ntx_render_opts *opts, float *z_out,
                       ntx_stream stream);
+int ntx_sample_noise(int64_t n_rays, int n_points, uint64_t seed, const ntx_render_opts *opts, float *noise_out, ntx_stream stream);
 
 int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t n_floats, int device, int64_t max_rays, int max_samples_per_ray, ntx_trainer **out) {
     if (!out) return ntx_set_error(NTX_E_INVALID, "out is NULL");
@@ -1039,6 +1043,7 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     if (rc == NTX_OK) rc = alloc(&t->sigma, (size_t)M);
     if (rc == NTX_OK) rc = alloc(&t->z, (size_t)M);
     if (rc == NTX_OK) rc = alloc(&t->dists, (size_t)M);
+    if (rc == NTX_OK) rc = alloc(&t->noise, (size_t)M);
     if (rc == NTX_OK) rc = alloc(&t->g0, (size_t)M * 256);
     if (rc == NTX_OK) rc = alloc(&t->g1, (size_t)M * 256);
     if (rc == NTX_OK) rc = alloc(&t->gf, (size_t)M * LDGF);
@@ -1195,6 +1200,12 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
         if (rc != NTX_OK) return rc;
         z = t->z;
     }
+    const float *noise = nullptr;
+    if (flags & NTX_FLAG_RAW_NOISE) {                                                           // renderer.py:190-192
+        int rc = ntx_sample_noise(n_rays, S, perturb_seed, opts, t->noise, stream);
+        if (rc != NTX_OK) return rc;
+        noise = t->noise;
+    }
     {
         EncodeArgs e{}; e.rays_o = rays_o; e.rays_d = rays_d; e.z = z; e.params = params; e.cone = cone_scale; e.rays_per_param_row = rays_per_param_row;
         e.n_rays = (int)n_rays; e.S = S; e.n_geo = t->desc.n_geo; e.n_app = t->desc.n_app; e.pos_freq = t->desc.pos_freq; e.dir_freq = t->desc.dir_freq;
@@ -1221,7 +1232,7 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     }
     hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 31) / 32)), dim3(256), 0, st, t->c2o, 128, 128, W + t->rgb.w, W + t->rgb.b, 3, M, t->raw_rgb);   // :123
     CompositeArgs c{};
-    c.raw_rgb = t->raw_rgb; c.sigma = t->sigma; c.dists = t->dists; c.n_rays = (int)n_rays; c.S = S; c.map_exr = (flags & NTX_FLAG_MAP_EXR) ? 1 : 0;
+    c.raw_rgb = t->raw_rgb; c.sigma = t->sigma; c.dists = t->dists; c.noise = noise; c.n_rays = (int)n_rays; c.S = S; c.map_exr = (flags & NTX_FLAG_MAP_EXR) ? 1 : 0;
     c.composite_bkgd = (flags & NTX_FLAG_COMPOSITE_BKGD) ? 1 : 0;
     for (int k = 0; k < 3; ++k) c.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
     c.color = t->color; c.alpha = t->alpha_out; c.d_color = t->d_color; c.d_alpha = t->d_alpha; c.d_raw_rgb = t->d_raw; c.d_sigma = t->d_sigma;

@@ -18,16 +18,20 @@ from . import _lib
 
 class Trainer:
     def __init__(self, model, max_rays: int, n_samples: int, lrate: float = 5e-4, lrate_decay: float = 0, perturb: bool = True, blur_idx: Optional[int] = None,
-                 map_exr: bool = False, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7, device: int = 0) -> None:
+                 map_exr: bool = False, raw_noise_std: float = 0.0, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7, device: int = 0) -> None:
         """`model`: a nerf_tex_amd.model.ParamNerf container (its blob gives the initial weights); `lrate`, `lrate_decay` as train.py:49-50
         (ExponentialDecay(lrate, decay_steps=lrate_decay * 1e3, decay_rate=0.1) when lrate_decay > 0); `perturb`, `blur_idx`, `map_exr`: the
-        renderer's (renderer.py:34)."""
+        renderer's (renderer.py:34); `raw_noise_std`: the density regulariser of map_model_output (renderer.py:190-192; config_grass_filtered_train.py:99
+        trains with 0.1), drawn per (seed, ray, sample) like the jitter."""
         import numpy as np
         self.model = model
         self.device = int(device)
         self.n_samples, self.max_rays = int(n_samples), int(max_rays)
         self.lrate, self.lrate_decay = float(lrate), float(lrate_decay)
         self.perturb, self.blur_idx, self.map_exr = bool(perturb), blur_idx, bool(map_exr)
+        self.raw_noise_std = float(raw_noise_std)
+        if self.raw_noise_std < 0:
+            raise ValueError("raw_noise_std must be >= 0")
         self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
         blob = np.ascontiguousarray(model.get_blob(), dtype=np.float32)
         self._h = C.c_void_p()
@@ -36,6 +40,33 @@ class Trainer:
                                                self.n_samples, C.byref(self._h)))
         self.n_weights = int(_lib.lib.ntx_trainer_weight_count(self._h))
         self._calls = 0
+
+    @classmethod
+    def from_config(cls, config: dict, max_rays: Optional[int] = None, device: int = 0, weights=None):
+        """The trainer and the loss a reference TRAINING config asks for, from its own blocks as written (train.py:20-52): `model_config`
+        (network.model.ParamNerf ...), `loss_config`, `lrate`, `lrate_decay`, `renderer_config` (n_samples, perturb, raw_noise_std, blur_idx,
+        map_exr; render_chunk / net_chunk have no meaning here: a step is one batch).  `max_rays` defaults to the config's batch --
+        `train_dataset_config.batchsize` images x `pixel_sampler_config.n_samples` rays -- when the config says it.  Returns (trainer, loss).
+        The data side (TFRecord datasets, logger, checkpoints) is not built from it: SURVEY section 2."""
+        from . import util
+        cfg = util.remap_reference_config(config)
+        model = util.instantiate(dict(cfg["model_config"]))["model"]
+        if weights is not None:
+            model.set_weights(weights) if isinstance(weights, (list, tuple)) else model.set_blob(weights)
+        loss = util.instantiate(dict(cfg["loss_config"]))
+        r = dict(cfg["renderer_config"])
+        for k in ("module", "render_chunk", "net_chunk"):
+            r.pop(k, None)
+        n_samples = int(r.pop("n_samples", 64))                                   # renderer.py:34 default
+        known = {k: r.pop(k) for k in ("perturb", "raw_noise_std", "blur_idx", "map_exr") if k in r}
+        if r.pop("n_importance", 0):
+            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, "training with n_importance > 0 (a coarse and a fine network) is not built")
+        if r:
+            raise TypeError(f"renderer_config keys without a meaning in a training step: {sorted(r)}")
+        if max_rays is None:
+            ds = cfg.get("train_dataset_config") or {}
+            max_rays = int(cfg.get("batchsize", ds.get("batchsize", 1))) * int(cfg.get("rays_per_image", (ds.get("pixel_sampler_config") or {}).get("n_samples", 1024)))
+        return cls(model, max_rays=max_rays, n_samples=n_samples, lrate=cfg.get("lrate", 5e-4), lrate_decay=cfg.get("lrate_decay", 0), device=device, **known), loss
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -88,6 +119,10 @@ class Trainer:
         rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, z_vals = (to(a) for a in (rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, z_vals))
         n = rays_o.reshape(-1, 3).shape[0]
         flags = (_lib.FLAG_PERTURB if self.perturb else 0) | (_lib.FLAG_MAP_EXR if self.map_exr else 0) | (_lib.FLAG_COMPOSITE_BKGD if composite_bkgd else 0)
+        opts = None
+        if self.raw_noise_std > 0:
+            flags |= _lib.FLAG_RAW_NOISE
+            opts = C.byref(_lib.render_opts(raw_noise_std=self.raw_noise_std))
         if seed is None:
             seed = self._calls
         self._calls += 1
@@ -97,7 +132,7 @@ class Trainer:
         with torch.cuda.device(dev):
             _lib.check(_lib.lib.ntx_train_step_gradients(
                 self._h, ptr(rays_o), ptr(rays_d), ptr(t), ptr(parameters), int(rays_per_param_row), ptr(cone_scale), n, self.n_samples,
-                -1 if self.blur_idx is None else int(self.blur_idx), flags, _lib.f3(bkgd_color), int(seed) & (2 ** 64 - 1), None, ptr(z_vals), ptr(color_true), ptr(alpha_true),
+                -1 if self.blur_idx is None else int(self.blur_idx), flags, _lib.f3(bkgd_color), int(seed) & (2 ** 64 - 1), opts, ptr(z_vals), ptr(color_true), ptr(alpha_true),
                 C.byref(desc), ptr(color), ptr(alpha), ptr(val), torch.cuda.current_stream(dev).cuda_stream))
         return val, color, alpha
 

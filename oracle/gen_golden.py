@@ -51,6 +51,20 @@ def renderer_configs():
         json.dump(out, f, indent=1)
 
 
+def train_configs():
+    """Part (6): what the shipped TRAINING configs hand the step of train.py:49-67 -- model, loss, learning-rate schedule, renderer block and
+    the batch shape (images per batch x rays per image) -- from the reference's own config modules."""
+    sys.path.insert(0, REF)
+    out = {}
+    for fam in ("carpet", "fur", "grass", "grass_filtered", "plush"):
+        cfg = importlib.import_module(f"configs.config_{fam}_train").config
+        out[fam] = {"source": f"configs/config_{fam}_train.py", "model_config": cfg["model_config"], "loss_config": cfg["loss_config"],
+                    "lrate": cfg["lrate"], "lrate_decay": cfg["lrate_decay"], "renderer_config": cfg["renderer_config"],
+                    "batchsize": cfg["train_dataset_config"]["batchsize"], "rays_per_image": cfg["train_dataset_config"]["pixel_sampler_config"]["n_samples"]}
+    with open(os.path.join(OUT, "train_configs.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def cameras():
     """Part (1): run the reference's TF-free pose / parameter generators."""
     sys.path.insert(0, REF)
@@ -198,9 +212,13 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["renderer_configs"]:           # part (5) alone
         renderer_configs()
         sys.exit(0)
+    if sys.argv[1:] == ["train_configs"]:              # part (6) alone
+        train_configs()
+        sys.exit(0)
     cameras()
     for fam in ("carpet", "grass", "fur", "grass_filtered"):
         small(fam)
     edge()
     plumbing()
     renderer_configs()
+    train_configs()

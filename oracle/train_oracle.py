@@ -70,7 +70,7 @@ def model_forward_masked(w, spec, pos, dirs, params, masks):
 
 
 def render(w, spec, rays_o, rays_d, z, parameters, cone_scale, blur_idx=None, map_exr=False, composite_bkgd=False, bkgd=(1., 1., 1.), masks=None,
-           sigma_mask=None):
+           sigma_mask=None, noise=None):
     """Renderer.render_rays on given sample depths z [n, S] (renderer.py:114-213; the depths themselves, :101-111, are the caller's:
     with perturb they come from the product's restated generator, nerftex_oracle.sample_depths)."""
     n, S = z.shape
@@ -87,6 +87,8 @@ def render(w, spec, rays_o, rays_d, z, parameters, cone_scale, blur_idx=None, ma
     else:
         color, alpha = model_forward_masked(w, spec, pos, dirs, params, masks)
     color = color.reshape(n, S, 3); alpha = alpha.reshape(n, S)
+    if noise is not None:                                                                   # renderer.py:190-192: [n, S], raw_noise_std * N(0,1)
+        alpha = alpha + noise
     dists = z[:, 1:] - z[:, :-1]
     dists = torch.cat([dists, dists[:, -1:]], -1) * torch.linalg.norm(rays_d, dim=-1, keepdim=True)
     rgb = torch.nn.functional.elu(color) + 1 if map_exr else torch.sigmoid(color)
@@ -100,14 +102,15 @@ def render(w, spec, rays_o, rays_d, z, parameters, cone_scale, blur_idx=None, ma
 
 
 def step_gradients(w_np, spec, rays_o, rays_d, z, parameters, cone_scale, color_true, alpha_true, loss, blur_idx=None, map_exr=False,
-                   composite_bkgd=False, bkgd=(1., 1., 1.), dtype=torch.float64, masks=None, sigma_mask=None):
+                   composite_bkgd=False, bkgd=(1., 1., 1.), dtype=torch.float64, masks=None, sigma_mask=None, noise=None):
     """(loss, color_pred, alpha_pred, gradients in get_weights() order as a list of arrays) of one step; `loss` = dict(kind='nerf'|'alpha', **kwargs).
-    `masks` / `sigma_mask`: the ReLU patterns of a float32 forward pass (model_forward_masked), as 0/1 arrays."""
+    `masks` / `sigma_mask`: the ReLU patterns of a float32 forward pass (model_forward_masked), as 0/1 arrays; `noise` [n, S]: the density
+    regulariser's draws (raw_noise_std * N(0,1), renderer.py:190-192)."""
     w = [torch.tensor(np.asarray(a), dtype=dtype, requires_grad=True) for a in w_np]
     t_ = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=dtype)
     mk = None if masks is None else [t_(m) for m in masks]
     c, a = render(w, spec, t_(rays_o), t_(rays_d), t_(z), t_(parameters), t_(cone_scale), blur_idx, map_exr, composite_bkgd, bkgd, mk,
-                  None if sigma_mask is None else t_(sigma_mask))
+                  None if sigma_mask is None else t_(sigma_mask), t_(noise))
     kw = {k: v for k, v in loss.items() if k != "kind"}
     val = nerf_loss(t_(color_true), c, **kw) if loss["kind"] == "nerf" else alpha_loss(t_(color_true), t_(alpha_true), c, a, **kw)
     val.backward()

@@ -88,6 +88,59 @@ def test_gradients_match_float64_autograd(fam, npar, blur, loss_name, bkgd, pert
     check_gradients(fam, npar, blur, loss_name, bkgd, perturb, 96, 48)
 
 
+@pytest.mark.parametrize("fam", ["carpet", "fur", "grass", "grass_filtered", "plush"])
+def test_shipped_training_configs_run_as_written(fam):
+    """Every shipped training config's model / loss / schedule / renderer blocks, verbatim (tests/golden/train_configs.json, made by
+    oracle/gen_golden.py from the reference's config modules), through `Trainer.from_config`: the trainer is what the config says -- 256
+    samples, perturb, AlphaLoss(smape, mse), Adam from 5e-4 decaying over 5e5 steps, grass_filtered with blur_idx 0 and raw_noise_std 0.1 --
+    sized for its batch of 4 x 256 rays, and a step on a slice of such a batch gives the restated step's loss and predictions."""
+    import json, os
+    from nerf_tex_amd.train import Trainer
+    cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "train_configs.json")))[fam]
+    npar = tuple(cfg["model_config"]["n_parameters"])
+    tr, loss = Trainer.from_config(cfg)
+    r = cfg["renderer_config"]
+    assert tr.max_rays == 1024 and tr.n_samples == 256 and tr.perturb is True and tr.lrate == 5e-4 and tr.lrate_decay == 500
+    assert tr.raw_noise_std == r.get("raw_noise_std", 0.0) and tr.blur_idx == r.get("blur_idx") and type(loss).__name__ == "AlphaLoss"
+    spec = orc.ModelSpec(kind="ParamNerf", n_parameters=npar)
+    n, S, P = 48, 256, sum(npar)
+    ro, rd, t, cone, params, color, alpha = batch(2, n, S, P, fam if fam != "plush" else "grass")
+    wts = orc.split_blob(spec, tr.weights())
+    val, cp, ap = tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss, seed=5)
+    z = orc.z_values_perturbed(t, S, 5, np.float32)
+    noise = tr.raw_noise_std * orc.noise_normals(n, S, 5, dtype=np.float32).astype(np.float64) if tr.raw_noise_std > 0 else None
+    want_val, wc, wa, _ = tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, dict(kind="alpha", loss_fn="smape", alpha_loss_fn="mse"),
+                                              blur_idx=tr.blur_idx, noise=noise)
+    assert orc.rel_linf(np.concatenate([cp.cpu().numpy(), ap.cpu().numpy()[:, None]], -1), np.concatenate([wc, wa[:, None]], -1)) <= 1e-4
+    assert abs(float(val.item()) - want_val) <= 1e-4 * abs(want_val)
+    g = tr.gradients()
+    assert np.isfinite(g).all() and np.abs(g).max() > 1e-6
+    tr.apply_gradients()
+    assert tr.iterations == 1
+
+
+def test_sample_noise_matches_the_restated_draws():
+    """ntx_sample_noise: raw_noise_std * N(0,1) per (seed, ray, sample) -- Philox4x32-10 counter (sample, ray, 1), Box-Muller as tf.random.normal
+    does it -- against the restated generator, identity and strided ray index maps."""
+    import ctypes as C
+    from nerf_tex_amd import _lib
+    n, S, seed = 37, 19, 0x1234567890ab
+    for ray_index in (None, (1000, 8, 64)):
+        out = torch.empty((n, S), device="cuda")
+        opts = _lib.render_opts(raw_noise_std=0.25, ray_index=ray_index)
+        _lib.check(_lib.lib.ntx_sample_noise(n, S, seed, C.byref(opts), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        want = 0.25 * orc.noise_normals(n, S, seed, ray_index=ray_index, dtype=np.float64)
+        assert np.abs(out.cpu().numpy() - want).max() <= 2e-6 and 0.2 < out.std().item() < 0.3
+    assert _lib.lib.ntx_sample_noise(n, S, seed, None, out.data_ptr(), None) == _lib.NTX_E_INVALID       # the flag's opts are not optional
+
+
+def test_gradients_with_the_density_regulariser():
+    """config_grass_filtered_train.py as written: perturb, blur_idx 0 AND raw_noise_std 0.1 (:96-102) -- N(0, 0.1) added to every sample's
+    density before its ReLU (renderer.py:190-195), drawn inside the step like the jitter; the oracle gets the restated draws."""
+    check_gradients("grass_filtered", (2, 3), 0, "alpha_smape", False, True, 96, 48, raw_noise_std=0.1)
+
+
 @pytest.mark.parametrize("n,S", [(2, 3), (3, 5), (50, 37), (301, 33), (700, 64)])
 def test_gradients_at_ragged_sizes(n, S):
     """The same at sample counts off every granule of the kernels: 6 and 15 samples (less than one block of 32 rows), 1850 samples (the last block of 32 rows ragged, fewer groups of four blocks
@@ -96,13 +149,13 @@ def test_gradients_at_ragged_sizes(n, S):
     check_gradients("carpet", (1, 6), None, "alpha_smape", False, False, n, S, floor_check=False)
 
 
-def check_gradients(fam, npar, blur, loss_name, bkgd, perturb, n, S, floor_check=True):
+def check_gradients(fam, npar, blur, loss_name, bkgd, perturb, n, S, floor_check=True, raw_noise_std=0.0):
     from nerf_tex_amd.train import Trainer
     model, spec, wts = make_model(npar, dense_media=True)
     P = sum(npar)
     ro, rd, t, cone, params, color, alpha = batch(3, n, S, P, fam)
     okw, loss = make_loss(loss_name)
-    tr = Trainer(model, max_rays=n, n_samples=S, perturb=perturb, blur_idx=blur)
+    tr = Trainer(model, max_rays=n, n_samples=S, perturb=perturb, blur_idx=blur, raw_noise_std=raw_noise_std)
     # the sample depths the kernel places itself (renderer.py:101-111; with perturb: the product's Philox jitter), restated for the oracle
     z = orc.z_values_perturbed(t, S, 11, np.float32) if perturb else orc.z_values(t, S, np.float32)
     val, cp, ap = tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss, composite_bkgd=bkgd, bkgd_color=(1., .5, .25), seed=11)
@@ -112,8 +165,10 @@ def check_gradients(fam, npar, blur, loss_name, bkgd, perturb, n, S, floor_check
     # rounding of zero falls on either side of its ReLU depending on summation order -- in TensorFlow's float32 as much as here)
     M = n * S
     masks = [(tr.activation(k, M) > 0).astype(np.float64) for k in list(range(8)) + [8, 9]]
-    sigma_mask = (tr.activation(10, M) > 0).astype(np.float64).reshape(n, S)
-    kw = dict(blur_idx=blur, composite_bkgd=bkgd, bkgd=(1., .5, .25))
+    # the density regulariser (renderer.py:190-192): the product's restated draws, keyed like the jitter by (seed, ray, sample)
+    noise = raw_noise_std * orc.noise_normals(n, S, 11, dtype=np.float32).astype(np.float64) if raw_noise_std > 0 else None
+    sigma_mask = ((tr.activation(10, M).reshape(n, S) + (0 if noise is None else noise.astype(np.float32))) > 0).astype(np.float64)
+    kw = dict(blur_idx=blur, composite_bkgd=bkgd, bkgd=(1., .5, .25), noise=noise)
     want_val, wc, wa, wg = tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, okw, masks=masks, sigma_mask=sigma_mask, **kw)
     # (a handful of rays with a handful of coarse steps each: 1 - exp(-sigma dist) at dist ~ 0.5 carries a float32 sigma's rounding five times as
     # far, and nothing averages out -- those cases are here for the kernels' granules, at five times the tolerance)

@@ -50,8 +50,10 @@ def test_autograd_matches_finite_differences(loss):
     rng = np.random.default_rng(1)
     w = [rng.normal(size=(i, o)) * 0.5 if b == 0 else rng.normal(size=o) * 0.1 for _, i, o in orc.layer_table(spec) for b in (0, 1)]
     ro, rd, z, par, cone, ct, at = tiny_batch()
-    val, c, a, g = tro.step_gradients(w, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0, composite_bkgd=True, bkgd=(1., .5, .2))
-    f = lambda ws: tro.step_gradients(ws, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0, composite_bkgd=True, bkgd=(1., .5, .2))[0]
+    noise = 0.1 * rng.normal(size=z.shape)                                       # the density regulariser (renderer.py:190-192) rides along
+    val, c, a, g = tro.step_gradients(w, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0, composite_bkgd=True, bkgd=(1., .5, .2), noise=noise)
+    assert abs(val - tro.step_gradients(w, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0, composite_bkgd=True, bkgd=(1., .5, .2))[0]) > 1e-6
+    f = lambda ws: tro.step_gradients(ws, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0, composite_bkgd=True, bkgd=(1., .5, .2), noise=noise)[0]
     for k in range(len(w)):
         idx = tuple(rng.integers(0, s_) for s_ in w[k].shape)
         h = 1e-6
@@ -63,7 +65,7 @@ def test_autograd_matches_finite_differences(loss):
     n, S = z.shape
     wt = [torch.tensor(x) for x in w]
     pos = torch.tensor(ro)[:, None, :] + torch.tensor(rd)[:, None, :] * torch.tensor(z)[:, :, None]
-    assert val == pytest.approx(float(tro.step_gradients(w, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0, composite_bkgd=True, bkgd=(1., .5, .2))[0]))
+    assert val == pytest.approx(float(tro.step_gradients(w, spec, ro, rd, z, par, cone, ct, at, loss, blur_idx=0, composite_bkgd=True, bkgd=(1., .5, .2), noise=noise)[0]))
 
 
 def _dp_worker(rank, world, port, q):
@@ -103,3 +105,22 @@ def test_data_parallel_step_world2_gloo():
     res = sorted(q.get(timeout=180) for _ in procs)
     [p.join(60) for p in procs]
     assert res == [(0, True), (1, True)]
+
+
+def test_train_config_fixture_is_what_the_trainer_is_built_from():
+    """tests/golden/train_configs.json (oracle/gen_golden.py train_configs, from the reference's config modules): the five shipped training
+    configs' blocks -- what `Trainer.from_config` reads on the GPU box (tests/test_gpu_train.py) -- and the reference paths they name remap
+    to this package's classes."""
+    import json, os
+    from nerf_tex_amd import util
+    cfgs = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "train_configs.json")))
+    assert sorted(cfgs) == ["carpet", "fur", "grass", "grass_filtered", "plush"]
+    for fam, c in cfgs.items():
+        assert c["source"] == f"configs/config_{fam}_train.py" and c["batchsize"] * c["rays_per_image"] == 1024 and c["renderer_config"]["n_samples"] == 256
+        r = util.remap_reference_config(c)
+        assert r["model_config"]["module"] == "nerf_tex_amd.model.ParamNerf" and r["loss_config"]["module"] == "nerf_tex_amd.loss.AlphaLoss"
+        loss = util.instantiate(dict(r["loss_config"]))
+        d = loss.desc()
+        assert d.size > 0                                                        # (the descriptor is built without a device)
+    assert cfgs["grass_filtered"]["renderer_config"]["raw_noise_std"] == 0.1 and cfgs["grass_filtered"]["renderer_config"]["blur_idx"] == 0
+    assert all("raw_noise_std" not in cfgs[f]["renderer_config"] for f in ("carpet", "fur", "grass", "plush"))
