@@ -500,7 +500,8 @@ int ntx_trainer_allreduce_gradients(ntx_trainer *t, ntx_comm *comm, ntx_stream s
  * 20-27 = the GRADIENTS the last step kept at the trunk layers' outputs (behind their ReLU: what the layer's weight gradient contracts
  * with), 28 = at the first colour layer's output, 29 = at the feature layer's (all width 256): tests compare them row by row. */
 int ntx_trainer_activation(ntx_trainer *t, int layer, int64_t n_samples_total, float *out_host);
-/* Forward (Renderer.__call__ for rays that all hit, renderer.py:92-213: sample depths by ntx_sample_depths -- NTX_FLAG_PERTURB /
+/* Forward (Renderer.__call__, renderer.py:47-213 -- a ray whose tnear_far is inf, i.e. that misses the proxy, stays in the batch and predicts
+ * 0 / the background with alpha 0 as the reference's filter-and-scatter makes it, :58-86 -- : sample depths by ntx_sample_depths -- NTX_FLAG_PERTURB /
  * perturb_seed / opts as there -- or given as z_vals[N,S]; encodings; the network; map_model_output with NTX_FLAG_MAP_EXR /
  * NTX_FLAG_COMPOSITE_BKGD), the loss, and its gradient with respect to every weight, left in the trainer (ntx_trainer_get /
  * ntx_trainer_adam_step).  DEVICE: rays_o[N,3], rays_d[N,3], tnear_far[N,2] (or NULL with z_vals), params[rows,P] (ray r uses row

@@ -649,13 +649,18 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
         const float o[3] = {a.rays_o[3 * ray], a.rays_o[3 * ray + 1], a.rays_o[3 * ray + 2]};
         const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
         const float dn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
-        const float z = a.z[(size_t)ray * a.S + s];
+        // A ray that misses the proxy (t = inf: the reference's Renderer.__call__ filters it out and scatters 0 / the background back,
+        // renderer.py:58-86) stays in the batch with depth 0 and distances 0: every alpha of it is 1 - exp(-sigma 0) = 0, so it composites to
+        // exactly 0 / the background, no gradient flows into or out of its rows, and the loss still counts it among its rays
+        const float zr = a.z[(size_t)ray * a.S + s];
+        const bool hit = isfinite(zr);
+        const float z = hit ? zr : 0.0f;
         for (int c = 0; c < 3; ++c) { base[c] = o[c] + d[c] * z; base[3 + c] = d[c] / dn; }   // renderer.py:114 (un-normalised rays_d), :98
         const float *pr = a.params + (size_t)(ray / a.rays_per_param_row) * P;
-        for (int c = 0; c < P; ++c) base[6 + c] = c == a.blur_idx ? pr[c] * (a.cone[ray] * z) : pr[c];   // :155-158
+        for (int c = 0; c < P; ++c) base[6 + c] = c == a.blur_idx ? (hit ? pr[c] * (a.cone[ray] * z) : 0.0f) : pr[c];   // :155-158 (a missing ray's cone scale may be anything)
         const float zn = s + 1 < a.S ? a.z[(size_t)ray * a.S + s + 1] : 0.0f;
         const float dist = s + 1 < a.S ? zn - z : (a.S > 1 ? z - a.z[(size_t)ray * a.S + s - 1] : 0.0f);
-        a.dists[(size_t)ray * a.S + s] = dist * dn;
+        a.dists[(size_t)ray * a.S + s] = hit ? dist * dn : 0.0f;
     }
     __syncthreads();
     if (m < M) {

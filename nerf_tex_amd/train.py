@@ -110,7 +110,8 @@ class Trainer:
 
     def gradients_step(self, rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, loss, composite_bkgd: bool = False, bkgd_color=(1., 1., 1.),
                        seed: Optional[int] = None, z_vals=None, rays_per_param_row: int = 1):
-        """Forward + loss + gradients (train.py:61-66) for rays that all hit the proxy: rays_o / rays_d [N,3], t [N,2], parameters [rows,P],
+        """Forward + loss + gradients (train.py:61-66): rays_o / rays_d [N,3], t [N,2] (inf for a ray that misses the proxy: it predicts 0 / the
+        background and counts in the loss, renderer.py:58-86), parameters [rows,P],
         cone_scale [N] or [N,1], color_true [N,3], alpha_true [N]; `loss`: a nerf_tex_amd.loss object.  Returns (loss [1], color_pred [N,3],
         alpha_pred [N]) as GPU tensors; the gradients stay in the trainer."""
         import torch

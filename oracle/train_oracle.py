@@ -109,8 +109,23 @@ def step_gradients(w_np, spec, rays_o, rays_d, z, parameters, cone_scale, color_
     w = [torch.tensor(np.asarray(a), dtype=dtype, requires_grad=True) for a in w_np]
     t_ = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=dtype)
     mk = None if masks is None else [t_(m) for m in masks]
-    c, a = render(w, spec, t_(rays_o), t_(rays_d), t_(z), t_(parameters), t_(cone_scale), blur_idx, map_exr, composite_bkgd, bkgd, mk,
-                  None if sigma_mask is None else t_(sigma_mask), t_(noise))
+    hit = np.isfinite(np.asarray(z)[:, 0])
+    if hit.all():
+        c, a = render(w, spec, t_(rays_o), t_(rays_d), t_(z), t_(parameters), t_(cone_scale), blur_idx, map_exr, composite_bkgd, bkgd, mk,
+                      None if sigma_mask is None else t_(sigma_mask), t_(noise))
+    else:
+        # Renderer.__call__ (renderer.py:58-86): rays whose t is inf are filtered out, the rest rendered, the results scattered back into zeros --
+        # plus the background colour for the filtered ones when compositing -- and the loss runs over ALL rays
+        S = np.asarray(z).shape[1]
+        rows = np.repeat(hit, S)
+        sub = lambda x: None if x is None else t_(np.asarray(x)[hit])
+        ch, ah = render(w, spec, sub(rays_o), sub(rays_d), sub(z), sub(parameters), sub(cone_scale), blur_idx, map_exr, composite_bkgd, bkgd,
+                        None if mk is None else [m[torch.as_tensor(rows)] for m in mk], sub(sigma_mask), sub(noise))
+        idx = torch.as_tensor(np.nonzero(hit)[0])
+        c = torch.zeros((hit.size, 3), dtype=dtype).index_put((idx,), ch)
+        a = torch.zeros((hit.size,), dtype=dtype).index_put((idx,), ah)
+        if composite_bkgd:
+            c = c + torch.as_tensor((~hit)[:, None] * np.asarray(bkgd, np.float64)[None, :], dtype=dtype)
     kw = {k: v for k, v in loss.items() if k != "kind"}
     val = nerf_loss(t_(color_true), c, **kw) if loss["kind"] == "nerf" else alpha_loss(t_(color_true), t_(alpha_true), c, a, **kw)
     val.backward()

@@ -119,6 +119,40 @@ def test_shipped_training_configs_run_as_written(fam):
     assert tr.iterations == 1
 
 
+@pytest.mark.parametrize("bkgd", [False, True])
+def test_rays_that_miss_the_proxy_stay_in_the_batch(bkgd):
+    """pixel_sampler.Proxy tests the proxy on an 8x coarser grid (pixel_sampler.py:46-62), so a training batch can hold rays with t = inf;
+    Renderer.__call__ filters them out, scatters 0 -- or the background -- back and the loss runs over all rays (renderer.py:58-86).  Here they
+    stay in the batch as rays whose every alpha is 0: predictions, loss and every layer's gradient equal the restated filter-and-scatter."""
+    from nerf_tex_amd.train import Trainer
+    model, spec, wts = make_model((2, 3), dense_media=True)
+    n, S = 96, 48
+    ro, rd, t, cone, params, color, alpha = batch(6, n, S, 5, "grass_filtered")
+    miss = np.zeros(n, bool); miss[[0, 5, 17, 31, 32, 33, 64, 95]] = True
+    t = t.copy(); t[miss] = np.inf
+    cone = cone.copy(); cone[miss] = np.nan                                       # whatever a ray sampler leaves there
+    okw, loss = make_loss("alpha_smape")
+    tr = Trainer(model, max_rays=n, n_samples=S, perturb=True, blur_idx=0, raw_noise_std=0.1)
+    val, cp, ap = tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss, composite_bkgd=bkgd, bkgd_color=(1., .5, .25), seed=11)
+    torch.cuda.synchronize()
+    cp, ap = cp.cpu().numpy(), ap.cpu().numpy()
+    assert (ap[miss] == 0).all() and (cp[miss] == (np.asarray([1., .5, .25], np.float32) if bkgd else 0)).all()
+    M = n * S
+    z = orc.z_values_perturbed(np.where(np.isfinite(t), t, 0).astype(np.float32), S, 11, np.float32)
+    z[miss] = np.inf
+    noise = 0.1 * orc.noise_normals(n, S, 11, dtype=np.float32).astype(np.float64)
+    masks = [(tr.activation(k, M) > 0).astype(np.float64) for k in list(range(8)) + [8, 9]]
+    sigma_mask = ((tr.activation(10, M).reshape(n, S) + noise.astype(np.float32)) > 0).astype(np.float64)
+    want_val, wc, wa, wg = tro.step_gradients(wts, spec, ro, rd, z, params, np.nan_to_num(cone), color, alpha, okw, masks=masks, sigma_mask=sigma_mask, blur_idx=0,
+                                              composite_bkgd=bkgd, bkgd=(1., .5, .25), noise=noise)
+    assert abs(float(val.item()) - want_val) <= 1e-5 * abs(want_val) + 1e-7
+    assert orc.rel_linf(np.concatenate([cp, ap[:, None]], -1), np.concatenate([wc, wa[:, None]], -1)) <= 1e-4
+    got, flat = tr.gradients(), np.concatenate([g.ravel() for g in wg])
+    assert np.isfinite(got).all() and np.abs(flat).max() > 1e-6
+    worst = {name: rel_linf(got[sl], flat[sl]) for name, sl in layer_slices(spec)}
+    assert max(worst.values()) <= 1e-4, {k: v for k, v in worst.items() if v > 1e-5}
+
+
 def test_sample_noise_matches_the_restated_draws():
     """ntx_sample_noise: raw_noise_std * N(0,1) per (seed, ray, sample) -- Philox4x32-10 counter (sample, ray, 1), Box-Muller as tf.random.normal
     does it -- against the restated generator, identity and strided ray index maps."""
