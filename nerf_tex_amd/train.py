@@ -144,6 +144,23 @@ class Trainer:
             _lib.check(_lib.lib.ntx_trainer_adam_step(self._h, self.lrate, self.lrate_decay * 1e3 if self.lrate_decay > 0 else 0.0, 0.1, self.beta_1, self.beta_2,
                                                       self.epsilon, torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream))
 
+    def train_step(self, data: dict, loss, composite_bkgd: bool = False, bkgd_color=(1., 1., 1.), comm=None, group=None, seed: Optional[int] = None) -> dict:
+        """The body of the reference's loop on ITS batch dict (train.py:61-67: `pred = renderer(**data, composite_bkgd=..., bkgd_color=...)`,
+        `loss_fn(color_true=data['color'], alpha_true=data['alpha'], **pred)`, gradients, `apply_gradients`): `data` as network/dataset.py maps it
+        -- rays_o / rays_d [B,R,3], t [B,R,2], cone_scale [B,R,1], parameters [B,P] (one row per image: renderer.py:54), color [B,R,3],
+        alpha [B,R].  Returns {'loss', 'color_pred' [B,R,3], 'alpha_pred' [B,R]} (GPU tensors)."""
+        import torch
+        as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+        ro = as_t(data["rays_o"]); B, R = int(ro.shape[0]), int(ro.shape[1])
+        flat = lambda k, w: as_t(data[k]).reshape(B * R, w) if w else as_t(data[k]).reshape(B * R)
+        alpha = flat("alpha", 0) if data.get("alpha") is not None else None
+        val, c, a = self.gradients_step(flat("rays_o", 3), flat("rays_d", 3), flat("t", 2), as_t(data["parameters"]).reshape(B, -1), flat("cone_scale", 0),
+                                        flat("color", 3), alpha, loss, composite_bkgd=composite_bkgd, bkgd_color=bkgd_color, seed=seed, rays_per_param_row=R)
+        if comm is not None or (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1):
+            self.sync_gradients(comm, group)
+        self.apply_gradients()
+        return {"loss": val, "color_pred": c.reshape(B, R, 3), "alpha_pred": a.reshape(B, R)}
+
     def sync_gradients(self, comm=None, group=None) -> None:
         """Data-parallel training (one process per GPU, every rank on its own rays -- equally many): the gradient becomes the mean over the
         ranks, which is the gradient of the loss over all their rays (the losses of loss.py are means over rays).  `comm`: a

@@ -153,6 +153,24 @@ def test_rays_that_miss_the_proxy_stay_in_the_batch(bkgd):
     assert max(worst.values()) <= 1e-4, {k: v for k, v in worst.items() if v > 1e-5}
 
 
+def test_train_step_takes_the_reference_batch_dict():
+    """`Trainer.train_step(data, ...)` on the dict network/dataset.py hands train.py:61 -- [B, R, ...] tensors, one parameter row per image --
+    is `step` on the flattened rays with every ray of image b using parameter row b (renderer.py:54): same weights afterwards, bit for bit."""
+    from nerf_tex_amd.train import Trainer
+    model, spec, wts = make_model((1, 6), dense_media=True)
+    B, R, S = 3, 32, 40
+    ro, rd, t, cone, params, color, alpha = batch(13, B * R, S, 7, "carpet")
+    per_image = params[::R].copy()                                               # [B, P]
+    okw, loss = make_loss("alpha_smape")
+    data = dict(rays_o=ro.reshape(B, R, 3), rays_d=rd.reshape(B, R, 3), t=t.reshape(B, R, 2), cone_scale=cone.reshape(B, R, 1), parameters=per_image,
+                color=color.reshape(B, R, 3), alpha=alpha.reshape(B, R))
+    a = Trainer(model, max_rays=B * R, n_samples=S); b = Trainer(model, max_rays=B * R, n_samples=S)
+    out = a.train_step(data, loss, composite_bkgd=True, bkgd_color=(.2, .4, .6), seed=9)
+    assert out["color_pred"].shape == (B, R, 3) and out["alpha_pred"].shape == (B, R) and out["loss"].shape == (1,)
+    val = b.step(ro, rd, t, np.repeat(per_image, R, 0), cone, color, alpha, loss, composite_bkgd=True, bkgd_color=(.2, .4, .6), seed=9)
+    assert float(val.item()) == float(out["loss"].item()) and np.array_equal(a.weights(), b.weights()) and a.iterations == 1
+
+
 def test_sample_noise_matches_the_restated_draws():
     """ntx_sample_noise: raw_noise_std * N(0,1) per (seed, ray, sample) -- Philox4x32-10 counter (sample, ray, 1), Box-Muller as tf.random.normal
     does it -- against the restated generator, identity and strided ray index maps."""
