@@ -45,7 +45,7 @@ class Trainer:
     def from_config(cls, config: dict, max_rays: Optional[int] = None, device: int = 0, weights=None):
         """The trainer and the loss a reference TRAINING config asks for, from its own blocks as written (train.py:20-52): `model_config`
         (network.model.ParamNerf ...), `loss_config`, `lrate`, `lrate_decay`, `renderer_config` (n_samples, perturb, raw_noise_std, blur_idx,
-        map_exr; render_chunk / net_chunk have no meaning here: a step is one batch).  `max_rays` defaults to the config's batch --
+        map_exr; render_chunk / net_chunk / downsampling_factor have no meaning here: a step is one batch).  `max_rays` defaults to the config's batch --
         `train_dataset_config.batchsize` images x `pixel_sampler_config.n_samples` rays -- when the config says it.  Returns (trainer, loss).
         The data side (TFRecord datasets, logger, checkpoints) is not built from it: SURVEY section 2."""
         from . import util
@@ -55,7 +55,7 @@ class Trainer:
             model.set_weights(weights) if isinstance(weights, (list, tuple)) else model.set_blob(weights)
         loss = util.instantiate(dict(cfg["loss_config"]))
         r = dict(cfg["renderer_config"])
-        for k in ("module", "render_chunk", "net_chunk"):
+        for k in ("module", "render_chunk", "net_chunk", "downsampling_factor"):
             r.pop(k, None)
         n_samples = int(r.pop("n_samples", 64))                                   # renderer.py:34 default
         known = {k: r.pop(k) for k in ("perturb", "raw_noise_std", "blur_idx", "map_exr") if k in r}
