@@ -2,7 +2,10 @@
 (oracle/train_oracle.py <- network/train.py:61-67, renderer.py:92-213, loss.py:6-59).  `-m gpu`.
 
 The bar of VERDICT r3 #6: the gradient of every layer within 1e-4 rel-Linf of float64 autograd on three model families, an optimiser
-step that is bit-reproducible, Adam against its restatement."""
+step that is bit-reproducible, Adam against its restatement.  Beyond it: sample counts off every granule of the kernels, the density
+regulariser and rays that miss the proxy (what the shipped training configs and their pixel sampler bring), the five shipped training configs'
+blocks as written, the reference's batch dict, independence of capacity and history, data parallel steps (two ranks sharing the GPU; the
+all-reduce on a one-rank RCCL communicator).  tools/dev/soak_train.py runs random mixtures of all of it."""
 
 import numpy as np
 import pytest
