@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from tests.test_gpu_train import make_model, batch, make_loss, layer_slices, rel_linf, orc, tro   # noqa: E402
 from nerf_tex_amd.train import Trainer                                                            # noqa: E402
 
-ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=150); ap.add_argument("--seed", type=int, default=0)
+ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=150); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--only", type=int, nargs="*", default=None)
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 FAMS = [("carpet", (1, 6)), ("grass", (1, 4)), ("fur", (1, 4)), ("grass_filtered", (2, 3))]
@@ -33,7 +33,9 @@ for case in range(a.cases):
     miss = rng.uniform(size=n) < float(rng.choice([0.0, 0.0, 0.05, 0.3]))
     t = t.copy(); t[miss] = np.inf
     okw, loss = make_loss(loss_name)
-    tr = Trainer(model, max_rays=n + int(rng.integers(0, 50)), n_samples=S, perturb=perturb, blur_idx=blur, raw_noise_std=noise_std)
+    cap = n + int(rng.integers(0, 50))
+    if a.only is not None and case not in a.only: continue
+    tr = Trainer(model, max_rays=cap, n_samples=S, perturb=perturb, blur_idx=blur, raw_noise_std=noise_std)
     val, cp, ap_ = tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss, composite_bkgd=bkgd, bkgd_color=(1., .5, .25), seed=seed)
     torch.cuda.synchronize()
     M = n * S
@@ -50,7 +52,11 @@ for case in range(a.cases):
     e_loss = abs(float(val.item()) - want_val) / (abs(want_val) + 1e-7)
     e_pred = orc.rel_linf(np.concatenate([cp.cpu().numpy(), ap_.cpu().numpy()[:, None]], -1), np.concatenate([wc, wa[:, None]], -1))
     got, flat = tr.gradients(), np.concatenate([g.ravel() for g in wg])
-    e_grad = max(rel_linf(got[sl], flat[sl]) for _, sl in layer_slices(spec)) if np.abs(flat).max() > 0 else float(np.abs(got).max())
+    # per layer, relative to the layer's largest entry -- but a layer whose whole gradient vanishes beside the others' (the density head of a
+    # batch without density: 1e-13 against 1e-3) is held to the batch's scale: float32 sums cannot resolve it
+    gmax = float(np.abs(flat).max())
+    lerr = lambda sl: float(np.abs(got[sl] - flat[sl]).max() / max(float(np.abs(flat[sl]).max()), 1e-6 * gmax, 1e-30))
+    e_grad = max(lerr(sl) for _, sl in layer_slices(spec)) if gmax > 0 else float(np.abs(got).max())
     ok = e_loss <= (1e-5 if M >= 1000 else 1e-4) * tiny and e_pred <= 1e-4 * tiny and e_grad <= 1e-4 * tiny and bool(np.isfinite(got).all())
     floor_pred = floor_grad = None
     if not ok and np.isfinite(got).all():
@@ -62,11 +68,14 @@ for case in range(a.cases):
         floor_pred = orc.rel_linf(np.concatenate([fc, fa[:, None]], -1), np.concatenate([wc, wa[:, None]], -1))
         floors = {nm: rel_linf(f32[sl], flat[sl]) for nm, sl in layer_slices(spec)}
         floor_grad = max(floors.values())
-        ok = e_pred <= max(1e-4 * tiny, 4 * floor_pred) and all(rel_linf(got[sl], flat[sl]) <= max(1e-4 * tiny, 4 * floors[nm]) for nm, sl in layer_slices(spec)) \
+        ok = e_pred <= max(1e-4 * tiny, 4 * floor_pred) and all(lerr(sl) <= max(1e-4 * tiny, 4 * floors[nm]) for nm, sl in layer_slices(spec)) \
             and e_loss <= max(1e-4, 4 * floor_pred)
         if ok: print("beyond the gate, within 4 float32 floors:", json.dumps(dict(case=case, n=n, S=S, e_pred=e_pred, floor_pred=floor_pred, e_grad=e_grad, floor_grad=floor_grad)), flush=True)
     desc = dict(case=case, fam=fam, n=n, S=S, loss=loss_name, perturb=perturb, bkgd=bkgd, noise=noise_std, blur=blur, missing=int(miss.sum()), e_loss=e_loss, e_pred=e_pred, e_grad=e_grad)
-    if not ok: fails.append(desc); print("FAIL", json.dumps(desc), flush=True)
+    if not ok:
+        fails.append(desc); print("FAIL", json.dumps(desc), flush=True)
+        for nm, sl in layer_slices(spec):
+            if lerr(sl) > 1e-4: print("    ", nm, "max |want| %.3e max |got - want| %.3e" % (np.abs(flat[sl]).max(), np.abs(got[sl] - flat[sl]).max()), flush=True)
     if M >= 100:
         worst = {"loss": max(worst["loss"], e_loss), "pred": max(worst["pred"], e_pred), "grad": max(worst["grad"], e_grad)}
     del tr
