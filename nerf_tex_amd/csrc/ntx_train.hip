@@ -751,24 +751,51 @@ __global__ void column_kernel(const float *__restrict__ src, long long M, float 
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m < M) dst[m * ld] = src[m];
 }
-// (dW | db) partial over a block of rows: block b, thread k < K: sum_m X[m][k] dY[m][c]; thread K: sum_m dY[m][c] (the bias row: kernel and
-// bias are neighbours in the blob).  partial[b][K + 1][n_out]
-__global__ void head_backward_dw_partial_kernel(const float *__restrict__ X, int ldx, int K, const float *__restrict__ dY, int n_out, long long M, int rows,
-                                                float *__restrict__ partial) {
-    const int k = threadIdx.x;
-    if (k > K) return;
+// (dW | db) partial over a block of `rows` rows: partial[b][K + 1][n_out], row k < K = sum_m X[m][k] dY[m][c], row K = sum_m dY[m][c] (the bias
+// row: kernel and bias are neighbours in the blob).  K / 4 neighbouring threads read a row 16 bytes each; 256 / (K / 4) such groups take every
+// group-count-th row of the block, eight rows' loads in flight each, and their sums meet in LDS in group order (a fixed order of additions).
+__global__ __launch_bounds__(256) void head_backward_dw_partial_kernel(const float *__restrict__ X, int ldx, int K, const float *__restrict__ dY, int n_out, long long M, int rows,
+                                                                       float *__restrict__ partial) {
+    __shared__ float part[8][(256 + 1) * 3];
+    const int q = K / 4, groups = 256 / q, grp = threadIdx.x / q, c4 = threadIdx.x % q;
     const long long m0 = (long long)blockIdx.x * rows, m1 = m0 + rows < M ? m0 + rows : M;
-    float acc[3] = {0.0f, 0.0f, 0.0f};
-    for (long long m = m0; m < m1; m += 8) {               // eight rows' loads in flight; added up in row order
-        float x[8];
+    float acc[4][3], bias[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = m + i < m1 ? (k < K ? X[(size_t)(m + i) * ldx + k] : 1.0f) : 0.0f;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (m + i < m1)
-                for (int c = 0; c < n_out; ++c) acc[c] += x[i] * dY[(size_t)(m + i) * n_out + c];
+        for (int c = 0; c < 3; ++c) acc[j][c] = 0.0f;
+    for (long long m = m0 + grp; m < m1; m += 8 * groups) {
+        f32x4 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long r = m + (long long)i * groups;
+            x[i] = r < m1 ? *reinterpret_cast<const f32x4 *>(X + (size_t)r * ldx + 4 * c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long r = m + (long long)i * groups;
+            if (r < m1) {
+                const float e[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+                for (int c = 0; c < n_out; ++c) {
+                    const float d = dY[(size_t)r * n_out + c];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j][c] += e[j] * d;
+                    if (c4 == 0) bias[c] += d;
+                }
+            }
+        }
     }
-    for (int c = 0; c < n_out; ++c) partial[((size_t)blockIdx.x * (K + 1) + k) * n_out + c] = acc[c];
+    for (int c = 0; c < n_out; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[grp][(4 * c4 + j) * n_out + c] = acc[j][c];
+        if (c4 == 0) part[grp][K * n_out + c] = bias[c];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < (K + 1) * n_out; e += 256) {
+        float total = part[0][e];
+        for (int g = 1; g < groups; ++g) total += part[g][e];
+        partial[(size_t)blockIdx.x * (K + 1) * n_out + e] = total;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -945,7 +972,7 @@ namespace {
 using namespace ntx_train;
 
 constexpr int SPLIT = 128;        // partial sums of a weight gradient along the samples
-constexpr int HEAD_ROWS = 256;    // rows per block of the narrow reductions
+constexpr int HEAD_ROWS = 512;    // rows per block of the narrow reductions
 constexpr int LDGF = 260;
 
 void free_all(ntx_trainer *t) {
@@ -1290,7 +1317,7 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     };
     const int hb = (int)((M + HEAD_ROWS - 1) / HEAD_ROWS);
     auto head_dw = [&](const float *X, int ldx, int K, const float *dY, int n_out, const TLayer &l) {       // (kernel | bias) of a narrow head
-        hipLaunchKernelGGL(head_backward_dw_partial_kernel, dim3(hb), dim3(320), 0, st, X, ldx, K, dY, n_out, M, HEAD_ROWS, t->partial);
+        hipLaunchKernelGGL(head_backward_dw_partial_kernel, dim3(hb), dim3(256), 0, st, X, ldx, K, dY, n_out, M, HEAD_ROWS, t->partial);
         const long long count = (long long)(K + 1) * n_out;
         hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, st, t->partial, hb, count, count, G + l.w);
     };
