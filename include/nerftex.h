@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NTX_ABI_VERSION 5
+#define NTX_ABI_VERSION 6
 
 typedef struct ntx_ctx ntx_ctx;
 typedef void *ntx_stream; /* hipStream_t */
@@ -465,8 +465,9 @@ int ntx_instancer_set_mesh_textures(ntx_instancer *inst, const float *uv, int64_
  * (train.py:49-52).  Built for the architecture of the shipped training configs: ParamNerf, depth 8, width 256, skips [4],
  * color_depth 1, Fourier features (any n_parameters, any band counts); NTX_E_UNSUPPORTED otherwise.  The trainer owns the weights
  * (Keras get_weights() order, like ntx_create), Adam's moments, the gradient and every layer's activations for up to
- * max_rays x max_samples_per_ray samples (<= 1024 samples per ray; 13.4 KB per sample: 3.5 GB for the configs' 4 x 256 x 256).
- * Everything float32.  A step is bit-reproducible: weight gradients are summed over the samples in a fixed order. */
+ * max_rays x max_samples_per_ray samples (<= 1024 samples per ray; 23 KB per sample: 6 GB for the configs' 4 x 256 x 256; pos_map and
+ * dir_map at most 96 features wide each).  Everything float32.  A step is bit-reproducible: weight gradients are summed over the samples
+ * in a fixed order. */
 typedef struct ntx_trainer ntx_trainer;
 #define NTX_LOSS_NERF 0                  /* network.loss.NerfLoss  (loss.py:6-19):  loss_fn(color_true, color_pred) */
 #define NTX_LOSS_ALPHA 1                 /* network.loss.AlphaLoss (loss.py:21-49): + gamma * alpha_loss_fn(alpha_true, alpha_pred), colours masked by alpha_true */
@@ -518,6 +519,13 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
 int ntx_trainer_adam_step(ntx_trainer *t, float lrate, float lrate_decay_steps, float lrate_decay_rate, float beta_1, float beta_2, float epsilon,
                           ntx_stream stream);
 int64_t ntx_trainer_iterations(const ntx_trainer *t);
+/* ABI v6.  Resuming a run (train.py:55-60, logger.py:30-39: the reference checkpoints model + step + optimizer and continues with
+ * `train_dataset.take(n_iters - logger.step)`): Adam's iteration count -- what its bias correction and the ExponentialDecay schedule run
+ * on -- is set beside the weights and moments (ntx_trainer_set). */
+int ntx_trainer_set_iterations(ntx_trainer *t, int64_t iterations);
+/* The trainer's weights where they live: DEVICE memory of the trainer's device, Keras get_weights() order, ntx_trainer_weight_count floats,
+ * valid until ntx_trainer_destroy; steps on a stream change them in that stream's order.  What ntx_set_weights_device takes. */
+int ntx_trainer_device_weights(ntx_trainer *t, const float **weights_dev);
 /* The dense contraction the trainer is made of (f32 MFMA, 128 x 128 x 16 tiles through LDS), on DEVICE buffers, for tests and benches:
  * C[M][N] = op(A) . op(B) (+ bias[N]) (ReLU); a_kcontig: A is [M][K] (row stride lda), else [K][M]; B is [K][N] (b_kcontig must be 0: the trainer transposes its weights once a step instead). */
 int ntx_gemm_f32(const float *A, int lda, int a_kcontig, const float *B, int ldb, int b_kcontig, float *C, int ldc, int M, int N, int K, const float *bias,

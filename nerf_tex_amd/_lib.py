@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("NERFTEX_LIB") or os.path.join(_HERE, "libnerftex_hip.
 
 NTX_OK, NTX_E_INVALID, NTX_E_UNSUPPORTED, NTX_E_HIP, NTX_E_NODEVICE = 0, -1, -2, -3, -4
 FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS, FLAG_FP16X3, FLAG_PERTURB, FLAG_RAW_NOISE = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 5
+ABI_VERSION = 6
 KIND_PARAMNERF_EX = 2           # NTX_MODEL_PARAMNERF_EX: the descriptor's param_depth / param_width count
 SKIP_MASK = 0x40000000          # NTX_SKIP_MASK: ntx_model_desc.skip carries a mask of skip-layer indices
 COMM_ID_BYTES = 128
@@ -146,6 +146,8 @@ SYMBOLS = {
                                            _vp, _vp, C.POINTER(LossDesc), _vp, _vp, _vp, _vp]),
     "ntx_trainer_adam_step": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     "ntx_trainer_iterations": (C.c_int64, [_vp]),
+    "ntx_trainer_set_iterations": (C.c_int, [_vp, C.c_int64]),
+    "ntx_trainer_device_weights": (C.c_int, [_vp, C.POINTER(_vp)]),
     "ntx_gemm_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "ntx_instancer_model_input": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_uint64, _op] + [_vp] * 12),
 }

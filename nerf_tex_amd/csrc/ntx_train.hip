@@ -3,20 +3,17 @@
 // color_depth 1; configs/config_carpet_train.py: 4 images x 256 rays x 256 samples = 262 144 samples a step).  gfx950 only.
 //
 // Inference fuses the whole network into one kernel because nothing of it has to survive (ntx_device.h).  A training step has to keep
-// every layer's activations for the backward pass; with 288 GB of HBM they are simply stored -- 13 layers x 262 144 x 256 floats = 3.5 GB
-// -- and the step is a sequence of dense contractions on the f32 matrix cores:
+// every layer's activations for the weight gradients; with 288 GB of HBM they are simply stored, once each, and the step is three passes on
+// the f32 matrix cores (ntx_train_device.h) between a handful of small kernels:
 //
-//   encode_kernel          sample points, positional encodings of position / direction / parameters (layer.py:8-23), written into the two
-//                          concat buffers the network reads them from ([pos_map | pad | h4] for the skip, [dir_map | pad | feature])
-//   rows_kernel<NT, MODE>  forward Y = act(X . W + b) and dX = (dY . W^T) masked: a wave owns 32 samples and all of a layer's outputs on
-//                          v_mfma_f32_32x32x2_f32, X straight from HBM, the weights from a packed image through an LDS ring
-//                          (pack_records_kernel makes the images once a step)
-//   gemm_kernel<A, TN, TK> dW = X^T . dY: 128 x 128 x 16 tiles through LDS (double buffered), split along the 262 144 samples into
-//                          partial sums that one pass adds up in a fixed order (a step is bit-reproducible), the bias gradient riding along;
-//                          also C = A . B on caller buffers (ntx_gemm_f32)
-//   head kernels           the 1-wide density head and the 3-wide colour head, forward and backward, on the vector ALUs
-//   composite_forward / _backward   renderer.py:170-213 per ray (wave per ray) and its adjoint: suffix sums of the weights' gradients
-//   loss_kernel            NerfLoss / AlphaLoss with mse / smape (loss.py), value and gradient
+//   pack_kernel            the weights move every step: the forward and the transposed weight streams and the aux block (biases, narrow heads)
+//   encode_kernel          sample points, positional encodings of position / direction / parameters (layer.py:8-23): the first layer's and the
+//                          two concatenations' inputs, in the row order the chain reads and in the operand order the weight gradients read
+//   fwd_chain_kernel       the network forward with the activations of a block of 32 samples in registers from layer to layer, stored once
+//   composite_loss_kernel  renderer.py:170-213 per ray, the ray's term of the loss (loss.py) and the adjoint of both (wave per ray)
+//   dx_chain_kernel        the gradient back through the layers, masked by the forward pass's ReLU bits, every layer's stored once
+//   dw_kernel              dW = X^T . dY of every layer in one launch, partial sums over ranges of samples; reduce_batch_kernel adds them in a
+//                          fixed order (a step is bit-reproducible)
 //   adam_kernel            tf.keras.optimizers.Adam under ExponentialDecay (train.py:49-52), one fused pass over the 2.7 MB of weights
 //
 // Everything is float32 with float32 accumulation, like the reference's TensorFlow graph.
@@ -24,6 +21,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -31,6 +29,8 @@
 #include <cstring>
 #include <type_traits>
 #include <vector>
+
+#include "ntx_train_device.h"
 
 extern "C" int ntx_set_error(int code, const char *fmt, ...);   // nerftex.hip
 
@@ -42,15 +42,11 @@ extern "C" int ntx_set_error(int code, const char *fmt, ...);   // nerftex.hip
 
 namespace ntx_train {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 // ---------------------------------------------------------------------------------------------------------------------------
-// the general contraction.  C[i][j] = sum_p A'(i, p) B(p, j) for i < M, j < N, p < K, with B[p * ldb + j] and
+// the general contraction on caller buffers (ntx_gemm_f32; the step itself runs on the kernels of ntx_train_device.h).
+//   C[i][j] = sum_p A'(i, p) B(p, j) for i < M, j < N, p < K, with B[p * ldb + j] and
 //   A'(i, p) = A_KCONTIG ? A[i * lda + p] : A[p * lda + i]
-// In a training step it takes the weight gradients, dW = X^T . dY (A' = X^T: the reduction runs over the samples, split into ranges whose
-// partial sums are added in a fixed order); the row-major form (A_KCONTIG) is what ntx_gemm_f32 offers on caller buffers -- the step's
-// forward and dX contractions were here until rows_kernel (below) took them.  A workgroup (4 waves) owns a 128 x 128 tile of C, a wave a
+// A workgroup (4 waves) owns a 128 x 128 tile of C, a wave a
 // 64 x 64 quarter of it = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator registers).  K advances a panel (16) at a time: the next
 // 128 x 16 / 16 x 128 panels are fetched into registers (16-byte loads when the panel lies inside the matrices and the rows are 16-byte
 // aligned, element by element with bounds otherwise) while the current ones, already in LDS as As[p][i] / Bs[p][j], feed the MFMAs; one
@@ -58,7 +54,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // costs MFMA time: hence the vector loads and the branch-free interior path.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int TM = 128;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
     const float *A; int lda; const float *B; int ldb; float *C; int ldc;
@@ -265,38 +260,11 @@ __global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_P
     gemm_place(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z, bx, by, bz);
     gemm_body<A_KCONTIG, TN_, TK_>(g, bx, by, bz);
 }
-// several contractions in one launch (the weight gradients of every layer of a step: 12 launches' ramps, tails and write-backs become one);
-// a problem's workgroups are numbered consecutively from first[p] (multiples of 8, so that a workgroup's XCD is its local number's too)
-constexpr int MAX_GEMM_BATCH = 14;
-struct GemmBatch { GemmArgs g[MAX_GEMM_BATCH]; int first[MAX_GEMM_BATCH + 1]; int nx[MAX_GEMM_BATCH], ny[MAX_GEMM_BATCH], nz[MAX_GEMM_BATCH]; int n; };
-template <bool A_KCONTIG, int TN_, int TK_, int WAVES_PER_EU = 2>
-__global__ __launch_bounds__(TN_ * 2) __attribute__((amdgpu_waves_per_eu(WAVES_PER_EU, 8))) void gemm_batch_kernel(GemmBatch b) {
-    int p = 0;
-    while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
-    const int lin = (int)blockIdx.x - b.first[p];
-    if (lin >= b.nx[p] * b.ny[p] * b.nz[p]) return;           // (the numbers between two problems, rounded up to 8)
-    int bx, by, bz;
-    gemm_place(lin, b.nx[p], b.ny[p], b.nz[p], bx, by, bz);
-    gemm_body<A_KCONTIG, TN_, TK_>(b.g[p], bx, by, bz);
-}
 
-// out[e] = sum_z partial[z][e], z ascending: the fixed order that makes a step reproducible
-__global__ void reduce_partials_kernel(const float *__restrict__ partial, int n_split, long long stride, long long count, float *__restrict__ out) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= count) return;
-    // four running sums over z = 0, 4, 8 ... / 1, 5, ... / ..., combined at the end: a fixed order, four loads in flight
-    float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    int z = 0;
-    for (; z + 4 <= n_split; z += 4) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s4[q] += partial[(size_t)(z + q) * stride + e];
-    }
-    for (int q = 0; z < n_split; ++z, ++q) s4[q] += partial[(size_t)z * stride + e];
-    out[e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-}
-// ... of several results in one launch; a job's elements are numbered from first (multiples of 256: a block belongs to one job)
-constexpr int MAX_REDUCE_BATCH = 2 * MAX_GEMM_BATCH;
-struct ReduceJob { const float *partial; int n_split; long long stride, count; float *out; long long first; };
+// out[e] = sum_z partial[z][e] (+ the second half of a bias's pair), z ascending: the fixed order that makes a step reproducible.  Several
+// results in one launch; a job's elements are numbered from first (multiples of 256: a block belongs to one job)
+constexpr int MAX_REDUCE_BATCH = 32;
+struct ReduceJob { const float *partial; int n_split; long long stride, count, pair; float *out; long long first; };   // pair > 0: element e of a split is partial[e] + partial[pair + e]
 struct ReduceBatch { ReduceJob job[MAX_REDUCE_BATCH]; int n; };
 __global__ void reduce_batch_kernel(ReduceBatch b) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -305,509 +273,129 @@ __global__ void reduce_batch_kernel(ReduceBatch b) {
     const ReduceJob &r = b.job[j];
     const long long e = g - r.first;
     if (e >= r.count) return;
+    // four running sums over z = 0, 4, 8 ... / 1, 5, ... / ..., combined at the end: a fixed order, four loads in flight
     float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto at = [&](int z) { const float *p = r.partial + (size_t)z * r.stride + e; return r.pair > 0 ? p[0] + p[r.pair] : p[0]; };
     int z = 0;
     for (; z + 4 <= r.n_split; z += 4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s4[q] += r.partial[(size_t)(z + q) * r.stride + e];
+        for (int q = 0; q < 4; ++q) s4[q] += at(z + q);
     }
-    for (int q = 0; z < r.n_split; ++z, ++q) s4[q] += r.partial[(size_t)z * r.stride + e];
+    for (int q = 0; z < r.n_split; ++z, ++q) s4[q] += at(z);
     r.out[e] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
-// the same for FEW elements and MANY partial sums (the narrow heads: a thousand row blocks of 257 or 771 numbers): 32 elements a block,
-// 8 threads each taking every 8th partial sum, their results added in order -- as fixed an order as the above, an eighth of the chain
-__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float *__restrict__ partial, int n_split, long long stride, long long count, float *__restrict__ out) {
-    __shared__ float part[8][32];
-    const int slice = threadIdx.x >> 5, lane = threadIdx.x & 31;
-    const long long e = (long long)blockIdx.x * 32 + lane;
-    float sum = 0.0f;
-    if (e < count)
-        for (int z = slice; z < n_split; z += 8) sum += partial[(size_t)z * stride + e];
-    part[slice][lane] = sum;
-    __syncthreads();
-    if (slice == 0 && e < count) {
-        float total = part[0][lane];
-        for (int q = 1; q < 8; ++q) total += part[q][lane];
-        out[e] = total;
-    }
-}
-// ---------------------------------------------------------------------------------------------------------------------------
-// The two contractions of a step whose reduction is SHORT (the layer's width) and whose other side is the samples -- forward Y = X . W and
-// dX = dY . W^T -- the way the render kernel does a layer (ntx_device.h): one wave owns 32 samples and ALL of a layer's
-// outputs (8 tiles of 32 x 32 = 128 accumulator registers) on v_mfma_f32_32x32x2_f32.  The A operand is the wave's own 32 rows of X,
-// read straight from HBM 16 bytes a lane, a body (32 k) ahead.  The B operand is the weights, from a PACKED image that the workgroup's
-// four waves pull through a triple-buffered LDS ring with direct global -> LDS loads (one 1 KiB record per instruction; a body's 32 records
-// in four quarters) and read back with ds_read_b128 two records ahead: the weights cost no registers, wait on the LDS counter and not
-// behind the HBM loads on the in-order vector-memory counter (a register ring did: every X load held up the ring eight records later), and
-// reach a CU once per workgroup instead of once per wave.  No VALU work in the k loop (the f32 MFMA shares the vector ALUs' lanes: every
-// VALU instruction costs MFMA time).  Where the 128 x 128 LDS tiles of gemm_kernel reach 0.58-0.64 of the MFMA peak, this is bound by
-// the matrix pipe and the clock the power limit leaves it (2.25-2.38 GHz while it runs).  dW = X^T . dY reduces over the samples: it
-// stays with gemm_kernel.
-//
-// One wave per SIMD, one stream of instructions with nothing to wait for:
-//  * a body = 128 MFMAs on one 32 KiB chunk of the image.  The chunk after the next one is asked for and the workgroup's one barrier per
-//    body falls 8 MFMAs BEFORE a body's end: behind it the next chunk is known to be complete (every wave waited for its own quarter) and
-//    the buffer two chunks back to be free, so the ds_reads run on into the next chunk without a gap -- no wave ever stands at a barrier
-//    with an empty pipe behind it;
-//  * two accumulator sets: while block n + 1 accumulates into one, block n's results leave the other: made final in ONE dense block of VALU
-//    work (bias is already in; ReLU and its bits), then stored PIECE BY PIECE in the shadow of the MFMAs of block n + 1's first two bodies
-//    (one output register every second MFMA).  The stores never come in bursts (all waves of the chip storing 32 KB each at the same
-//    moment cost 3.5 us a block with the matrix pipe idle), and the wait in front of the barrier counts them out (vmcnt(stores of this
-//    body): only what is older has to be there).  VALU instructions scattered between f32 MFMAs cost 18 cycles each here, in a dense block
-//    8: hence the split.  (The mask of dX alone is applied on the way out, four outputs at a time: all 128 at once need more registers
-//    than a wave has.)
-//
-// k order.  A lane (sample m = l & 31, half h = l >> 5) loads X[m][8 q + 4 h .. + 3] in one piece; k-step s = 4 q + c then pairs
-// k = 8 q + c (lower half-wave) with k = 8 q + 4 + c (upper) -- the order of the summation over k is free.  The packed image follows:
-// record (s, g) = 64 lanes x 4 floats, component c' of lane (f, h) = Wsrc[k(s, h)][32 (4 g + c') + f]: one 16-byte read feeds 4 MFMAs.
-// Rows of the image with no counterpart (K rounded up to 32; the pad columns between the two halves of a concat buffer) are zero, the X
-// values they meet are finite (pad columns are zeroed once, what lies behind a row is the next row; beyond the matrix the buffer
-// descriptor returns 0).
-//
-// D of a tile (the MFMA's A operand is X, its B operand the weights): lane (f = l & 31, h), register r <-> sample 8 (r >> 2) + 4 h + (r & 3),
-// feature 32 t + f: a register is 32 consecutive features of one sample per half-wave, so a row-major Y[sample][feature] is written in
-// full 128-byte lines.  The ReLU mask dX needs is not read back as 268 MB of activations: the forward pass leaves ONE BIT per output,
-// in the accumulators' own layout (lane, tile, register: 128 bits = 16 bytes a lane and block), and dX -- whose outputs lie in the same
-// layout -- reads those 8 MB.
-// ---------------------------------------------------------------------------------------------------------------------------
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// A launch walks every pair of row blocks through a CHAIN of layers (the whole trunk forward; the whole way back for dX): block A layer l,
-// block B layer l, block A layer l + 1 ...  A block's layer-l outputs leave under the other block's MFMAs and are complete a body later,
-// long before the same wave reads them back as layer l + 1's X (its own rows, through its own CU's L2: nothing is shared between waves
-// but the weights) -- ten launches' ramps, first loads, last stores and L2 write-backs become one.
-struct RowsLayer {
-    const float *X; int ldx;
-    const float *recs; int kblocks;                    // packed weights; blocks of 8 k (a multiple of 4, at least 12)
-    float *Y; int ldy;
-    const float *bias; int linear;                     // forward: bias [32 NT]; linear: no ReLU (and no bits)
-    unsigned int *bits_out;                            // forward: one bit per output, set where it is > 0 (or NULL)
-    const unsigned int *bits_in;                       // dX: keep where the bit is set (a layer without a ReLU behind it: a buffer of ones)
-};
-constexpr int MAX_ROWS_LAYERS = 10;
-struct RowsArgs { RowsLayer layer[MAX_ROWS_LAYERS]; int n_layers; long long M; };
-enum { ROWS_FORWARD = 0, ROWS_DX_MASK = 2 };           // what the epilogue does: a template parameter
-template <int N, class F> __device__ __forceinline__ void static_for_(F &&f) {
-    if constexpr (N > 0) { static_for_<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void *base, long long bytes) {
-    const long long b = bytes < 0 ? 0 : (bytes > 0x7ffffff0ll ? 0x7ffffff0ll : bytes);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)b, 0x00020000);
-}
-// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima) -- as an
-// instruction the compiler's own counting sees, unlike inline assembly
-template <int N> __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt(((N >> 4) << 14) | 0x0F70 | (N & 15)); }
 
-template <int NT, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rows_kernel(RowsArgs a) {
-    constexpr int G = NT / 4;                          // records per k-step
-    constexpr int CHUNK = 16 * G;                      // records per body (4 blocks of 8 k = 16 k-steps): 16 or 32 KiB
-    constexpr int RING = 2;                            // records read ahead of the MFMAs (CHUNK is a multiple: the ring's phase is the same in every body)
-    constexpr int TAIL = CHUNK - RING - 1;             // the barrier stands behind this record's MFMAs: the next one reads ahead into the next chunk
-    __shared__ f32x4 lds[3 * CHUNK * 64 + MAX_ROWS_LAYERS * NT * 8];     // three chunks, then every layer's bias
-    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long n_blocks = (a.M + 31) / 32, n_groups = (n_blocks + 3) / 4;
-    if ((long long)blockIdx.x >= n_groups) return;
-    const int L = a.n_layers;
-    const int n_mine = (int)((n_groups - blockIdx.x + gridDim.x - 1) / gridDim.x), n_items = (n_mine + 1) / 2 * 2 * L;   // pairs of groups x layers x 2
-    constexpr bool MASK = MODE == ROWS_DX_MASK, BIAS = MODE == ROWS_FORWARD;
-    const uint32_t woff = (uint32_t)lane * 16u;
-    if constexpr (BIAS) {
-        float *bl = reinterpret_cast<float *>(&lds[3 * CHUNK * 64]);
-        for (int e = threadIdx.x; e < L * NT * 32; e += 256) bl[e] = a.layer[e / (NT * 32)].bias[e % (NT * 32)];
-    }
-    // item w of this wave: which rows, which layer.  Behind the last one (and for the second half of an odd pair): no rows -- empty descriptors
-    const long long no_rows = n_blocks * 32;           // "no block": behind every row AND on a block boundary (its bits, too, must fall outside: M / 32 is the last block when M is ragged)
-    auto item_row0 = [&](int w) -> long long {
-        if (w < 0 || w >= n_items) return no_rows;
-        const int p = w / (2 * L), rem = w - p * 2 * L;
-        const long long grp = (long long)blockIdx.x + (long long)(2 * p + (rem & 1)) * gridDim.x;
-        return grp < n_groups ? (grp * 4 + wave) * 32 : no_rows;
-    };
-    auto item_layer = [&](int w) -> int { return (w < 0 || w >= n_items) ? 0 : (w % (2 * L)) >> 1; };
-    // this wave's quarter of a chunk, straight into LDS: one record (64 lanes x 16 bytes, lane-linear) per instruction
-    auto fill = [&](const __amdgpu_buffer_rsrc_t &rw, int chunk, int buf_byte) {
-        static_for_<CHUNK / 4>([&](auto I) {
-            const int r = wave * (CHUNK / 4) + I;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(lds) + buf_byte + r * 1024), 16, woff,
-                                                     (uint32_t)(chunk * CHUNK + r) * 1024u, 0, 0);
-        });
-    };
-    auto w_rsrc = [&](int l) { return rows_rsrc(a.layer[l].recs, (long long)a.layer[l].kblocks * NT * 1024); };
-    auto x_rsrc = [&](int l, long long row0) { return rows_rsrc(a.layer[l].X + row0 * a.layer[l].ldx, (a.M - row0) * a.layer[l].ldx * 4); };
-    auto xload4 = [&](const __amdgpu_buffer_rsrc_t &rx, uint32_t xoff, int q0, f32x4 (&x)[4]) {
-        static_for_<4>([&](auto I) { x[I] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff, (uint32_t)(q0 + I) * 32u, 0)); });
-    };
-    auto x_off = [&](int l) { return (uint32_t)(m * a.layer[l].ldx + 4 * h) * 4u; };
-    f32x16 accs[2][NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)                       // set 1 "leaves" once before it has been filled (into an empty descriptor): keep even that read defined
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accs[1][t][r] = 0.0f;
-    f32x4 x[4], xn[4], ring[RING];
-    u32x4 bits_set[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // dX: the masks of the blocks in the two accumulator sets, asked for in a block's last body (every body without an epilogue asks: no branch)
-    // A block's outputs are made final in place in ONE dense block of VALU work (ReLU and its bits): VALU instructions
-    // scattered between f32 MFMAs cost several times their own issue time (the f32 MFMA runs on the vector ALUs' lanes;
-    // measured here, 18 cycles an instruction against 8) -- only the stores, which need no ALU, are spread over the next block's MFMAs.
-    // The bit of (tile t, register r) lies in word t >> 1 at position 16 (t & 1) + r.
-    auto finalize = [&](auto SETc, int l, long long blk) {
-        constexpr int SET = SETc;
-        if constexpr (MODE == ROWS_FORWARD) {
-            if (a.layer[l].linear) return;
-            u32x4 out_bits = {0u, 0u, 0u, 0u};
-            static_for_<NT>([&](auto T) {
-                static_for_<16>([&](auto R) {
-                    constexpr int t = T, r = R;
-                    const float v = fmaxf(accs[SET][t][r], 0.0f);
-                    accs[SET][t][r] = v;
-                    const int one = __builtin_bit_cast(int, v) < 1 ? __builtin_bit_cast(int, v) : 1;       // v >= 0: its bits as an integer are 0 or positive
-                    out_bits[t >> 1] |= (unsigned)one << (16 * (t & 1) + r);
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            const __amdgpu_buffer_rsrc_t rbo = rows_rsrc(a.layer[l].bits_out ? (const void *)a.layer[l].bits_out : (const void *)a.layer[l].recs, a.layer[l].bits_out ? n_blocks * 1024 : 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out_bits), rbo, woff, (uint32_t)blk * 1024u, 0);
-        }
-    };
-    // where the block in the OTHER accumulator set goes: its layer's Y at its rows (set by block())
-    __amdgpu_buffer_rsrc_t ry = rows_rsrc(a.layer[0].Y, 0);
-    uint32_t yoff = 0, ld4 = 0;
-    // output register (tile t, register r) leaves: two full 128-byte lines
-    // (dX under a mask: the mask goes on here, four outputs at a time -- 8 VALU instructions in one piece every 8 MFMAs; all 128 at once
-    // need more registers than there are, one at a time between the MFMAs costs 18 us a launch)
-    auto element = [&](auto SETc, auto Tc, auto Rc) {
-        constexpr int SET = SETc, t = Tc, r = Rc;
-        float v = accs[SET][t][r];                     // (a vector element is not an lvalue __builtin_bit_cast can take: it would read element 0)
-        if constexpr (MASK) {
-            const int keep = __builtin_amdgcn_sbfe((int)bits_set[SET][t >> 1], 16 * (t & 1) + r, 1);   // 0 or -1
-            v = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & keep);
-        }
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff + (uint32_t)t * 128u, (uint32_t)(8 * (r >> 2) + (r & 3)) * ld4, 0);
-    };
-    auto leaves_to = [&](int l, long long row0) {
-        ry = rows_rsrc(a.layer[l].Y + row0 * a.layer[l].ldy, (a.M - row0) * a.layer[l].ldy * 4);
-        yoff = (uint32_t)(4 * h * a.layer[l].ldy + m) * 4u; ld4 = (uint32_t)a.layer[l].ldy * 4u;
-    };
-    auto acc_init = [&](auto SETc, int l) {
-        constexpr int SET = SETc;
-        if constexpr (BIAS) {                          // the accumulators start from the bias: a lane's feature is the same in all of a tile's registers
-            const float *bl = reinterpret_cast<const float *>(&lds[3 * CHUNK * 64]) + l * NT * 32;
-            static_for_<NT>([&](auto T) {
-                const float b = bl[32 * T + m];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accs[SET][T][r] = b;
-            });
-        } else {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accs[SET][t][r] = 0.0f;
-        }
-    };
-    // LDS byte offsets of the chunk being read, the next one, the one after (being filled): they rotate
-    int buf0 = 0, buf1 = CHUNK * 1024, buf2 = 2 * CHUNK * 1024;
-    {
-        const int l0 = item_layer(0);
-        const __amdgpu_buffer_rsrc_t rw = w_rsrc(l0);
-        fill(rw, 0, buf0); fill(rw, 1, buf1);
-        xload4(x_rsrc(l0, item_row0(0)), x_off(l0), 0, x);
-        wait_vmcnt<0>();
-        __syncthreads();
-        const f32x4 *Lp = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(lds) + buf0) + lane;
-        static_for_<RING>([&](auto I) { ring[I] = Lp[I * 64]; });
-    }
-    // the block under way and the one after it
-    __amdgpu_buffer_rsrc_t rx = x_rsrc(0, no_rows), rxn = rx, rw = w_rsrc(0), rwn = rw, rbits = rw;
-    uint32_t xoff = 0, xoffn = 0, bits_at = 0;
-    int nb = 3;
-    // one body: EP = 0 nothing else, 1 / 2 the first / second half of the previous block's outputs leave from the other accumulator set
-    auto body = [&](auto SETc, auto EPc, int b) {
-        constexpr int SET = SETc, EP = EPc;
-        const bool last = b == nb - 1;
-        if (nb == 3 && last) wait_vmcnt<0>();          // (a three-body block: the outputs that left in its first two bodies are what the next block's X may be)
-        xload4(last ? rxn : rx, last ? xoffn : xoff, last ? 0 : 4 * (b + 1), xn);
-        if constexpr (MASK && EP == 0) bits_set[SET] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbits, woff, bits_at, 0));
-        const f32x4 *Lp = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(lds) + buf0) + lane;
-        const f32x4 *Ln = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(lds) + buf1) + lane;
-        static_for_<CHUNK>([&](auto IDX) {
-            constexpr int idx = IDX, ks = idx / G, gi = idx % G, qi = ks / 4, c = ks % 4;
-            const f32x4 w = ring[idx % RING];
-            if constexpr (idx + RING < CHUNK) ring[idx % RING] = Lp[(idx + RING) * 64];
-            else ring[idx % RING] = Ln[(idx + RING - CHUNK) * 64];      // behind the barrier: the next chunk's first records
-            static_for_<4>([&](auto T) {
-                constexpr int tt = T, tile = 4 * gi + T;
-                accs[SET][tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[qi][c], w[tt], accs[SET][tile], 0, 0, 0);
-                // output e = 0 .. 8 NT - 1 of this half of the block: register-major, so that a sample's stores follow each other
-                auto leave = [&](auto Ec) {
-                    constexpr int e = Ec, r = e / (NT / 2), t = (EP - 1) * (NT / 2) + e % (NT / 2);
-                    element(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, t>{}, std::integral_constant<int, r>{});
-                };
-                if constexpr (EP != 0 && !MASK && (tt == 0 || tt == 2)) leave(std::integral_constant<int, 2 * idx + tt / 2>{});
-                if constexpr (EP != 0 && MASK && idx % 2 == 0 && tt == 0) static_for_<4>([&](auto I) { leave(std::integral_constant<int, 2 * idx + I>{}); });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            if constexpr (idx == TAIL) {
-                // what is older than this body's stores -- the next chunk's quarter, the next body's X -- has to be there; then everyone's is, and
-                // nobody reads the chunk before this one any more: its buffer takes the chunk after the next (of this block's image or the next's)
-                wait_vmcnt<(EP == 0 ? 0 : MASK ? 4 * (TAIL / 2 + 1) : 2 * (TAIL + 1))>();
-                __builtin_amdgcn_s_barrier();
-                const bool over = b + 2 >= nb;
-                fill(over ? rwn : rw, over ? b + 2 - nb : b + 2, buf2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        });
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = xn[i];
-        const int tmp = buf0; buf0 = buf1; buf1 = buf2; buf2 = tmp;
-    };
-    // item w into accumulator set SET; the item before it (in the other set) leaves meanwhile
-    auto block = [&](auto SETc, int w) {
-        const int l = item_layer(w), ln = item_layer(w + 1);
-        const long long row0 = item_row0(w), row0n = item_row0(w + 1);
-        rx = x_rsrc(l, row0); xoff = x_off(l); rxn = x_rsrc(ln, row0n); xoffn = x_off(ln);
-        rw = w_rsrc(l); rwn = w_rsrc(ln); nb = a.layer[l].kblocks / 4;
-        if constexpr (MASK) { rbits = rows_rsrc(a.layer[l].bits_in, n_blocks * 1024); bits_at = (uint32_t)(row0 / 32) * 1024u; }
-        leaves_to(item_layer(w - 1), item_row0(w - 1));
-        acc_init(SETc, l);
-        body(SETc, std::integral_constant<int, 1>{}, 0);
-        body(SETc, std::integral_constant<int, 2>{}, 1);
-        for (int b = 2; b < nb; ++b) body(SETc, std::integral_constant<int, 0>{}, b);
-        finalize(SETc, l, row0 / 32);
-    };
-    for (int w = 0; w < n_items; w += 2) {
-        block(std::integral_constant<int, 0>{}, w);
-        block(std::integral_constant<int, 1>{}, w + 1);
-    }
-    // the last block's outputs (always in set 1)
-    leaves_to(item_layer(n_items - 1), item_row0(n_items - 1));
-    static_for_<16>([&](auto R) { static_for_<NT>([&](auto T) { element(std::integral_constant<int, 1>{}, T, R); }); });
-}
-
-// the packed images of every layer, both directions, in one launch (the weights move every step)
-struct PackJob {
-    const float *src; long long sk, sc;               // k < K1: Wsrc[k][col] = src[k * sk + col * sc]
-    const float *src2; long long sk2, sc2;            // K1p <= k < K1p + K2: src2[(k - K1p) * sk2 + col * sc2]
-    int K1, K1p, K2;                                  // K1 <= k < K1p: the pad of a concat buffer, zero; zero behind K1p + K2
-    int nt, kblocks;
-    float *dst; long long first;                      // where the image lies; the job's first float in the launch's index space
+// ---------------------------------------------------------------------------------------------------------------------------
+// the weights as the chains stream them (ntx_train_device.h), made once a step.  A segment of a stream: records (k-step s, tile group g) of
+// 64 lanes x 4 floats, component c of lane (f, kh) = Wsrc[row(s, kh)][32 (4 g + c) + f] with Wsrc[k][col] = src[k * sk + col * sc]; rows
+// beyond K (padding k-steps, the odd half of a last k-step) and columns beyond ncols are zero.  The aux block's pieces ride along.
+// ---------------------------------------------------------------------------------------------------------------------------
+enum { PACK_HIDDEN = 0, PACK_LINEAR = 1, PACK_AUX_ROW = 2, PACK_AUX_RGB = 3, PACK_COPY = 4 };
+struct PackSeg {
+    const float *src; long long sk, sc;
+    int mode;                 // PACK_HIDDEN: row(s, kh) = hidden_row(s, kh) (the k-steps of a layer whose input is a lane's registers); PACK_LINEAR: 2 s + kh
+    int K, ncols, nt;         // rows / columns that exist; tiles of the layer (4 or 8)
+    float *dst; long long first, count;   // where it goes; the segment's first float in the launch's index space and how many
 };
-constexpr int MAX_PACK_JOBS = 24;
-struct PackArgs { PackJob job[MAX_PACK_JOBS]; int n_jobs; long long total; };
-__global__ void pack_records_kernel(PackArgs a) {
+struct PackArgs { const PackSeg *seg; int n_seg; long long total; };
+__global__ void pack_kernel(PackArgs a) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.total) return;
-    int j = 0;
-    while (j + 1 < a.n_jobs && e >= a.job[j + 1].first) ++j;
-    const PackJob &p = a.job[j];
+    int lo = 0, hi = a.n_seg - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.seg[mid].first <= e) lo = mid; else hi = mid - 1; }
+    const PackSeg &p = a.seg[lo];
     const long long o = e - p.first;
-    const int c = (int)(o & 3), lane = (int)((o >> 2) & 63);
-    const long long rec = o >> 8;
-    const int G = p.nt / 4, g = (int)(rec % G), s = (int)(rec / G);
-    const int f = lane & 31, h = lane >> 5;
-    const int k = 8 * (s >> 2) + 4 * h + (s & 3), col = 32 * (4 * g + c) + f;
     float v = 0.0f;
-    if (k < p.K1) v = p.src[k * p.sk + col * p.sc];
-    else if (k >= p.K1p && k < p.K1p + p.K2) v = p.src2[(k - p.K1p) * p.sk2 + col * p.sc2];
+    if (p.mode == PACK_COPY) v = p.src[o];
+    else if (p.mode == PACK_AUX_ROW) {                   // [half][128]: value V of half h <-> feature hidden_row(V, h)
+        const int h = (int)(o >> 7) & 1, V = (int)(o & 127), k = hidden_row(V, h);
+        v = k < p.K ? p.src[k * p.sk] : 0.0f;
+    } else if (p.mode == PACK_AUX_RGB) {                 // [3][half][64]
+        const int c = (int)(o >> 7), h = (int)(o >> 6) & 1, V = (int)(o & 63);
+        v = p.src[hidden_row(V, h) * 3 + c];
+    } else {
+        const int c = (int)(o & 3), lane = (int)((o >> 2) & 63);
+        const long long rec = o >> 8;
+        const int G = p.nt / 4, g = (int)(rec % G), s = (int)(rec / G);
+        const int f = lane & 31, kh = lane >> 5;
+        const int k = p.mode == PACK_HIDDEN ? hidden_row(s, kh) : 2 * s + kh, col = 32 * (4 * g + c) + f;
+        if (k < p.K && col < p.ncols) v = p.src[k * p.sk + col * p.sc];
+    }
     p.dst[o] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // encoder: layer.FourierFeatures (layer.py:8-23) of position [+ geometry parameters] and of direction [+ appearance parameters]
-// (model.py:77-101), the sample points of renderer.py:98-114 and the blur product of :155-158; thread per sample
+// (model.py:77-101), the sample points of renderer.py:98-114 and the blur product of :155-158.  One wave per block of 32 samples and map:
+// lane (n, h) evaluates sin (h = 0) or cos (h = 1) of its sample with ONE function (ntx_device.h sin_q, the render kernels' own) and writes
+// rows of 32 samples -- twice: in row order [block][row][32] (the chain's B operands) and in O layout (the weight gradients' A operands).
 // ---------------------------------------------------------------------------------------------------------------------------
 struct EncodeArgs {
     const float *rays_o, *rays_d, *z, *params, *cone;
-    long long rays_per_param_row;
+    long long rays_per_param_row, M;
     int n_rays, S, n_geo, n_app, pos_freq, dir_freq, param_freq, blur_idx;
-    float *pos_out; int ld_pos;      // [M][ld_pos]: pos_map in columns 0 .. Kp
-    float *dir_out; int ld_dir;      // [M][ld_dir]: dir_map in columns 0 .. Kd
-    float *dists;                    // [N][S]: z[i+1] - z[i], the last one repeated, times |rays_d| (renderer.py:174-180)
+    float *posR, *posO; int ptiles;      // rows 0 .. Kp: pos_map; the rest of the ptiles * 32 rows stays zero
+    float *dirR, *dirO; int dtiles;
+    float *dists;                        // [N][S]: z[i+1] - z[i], the last one repeated, times |rays_d| (renderer.py:174-180)
 };
-// feature j of layer.FourierFeatures over x[0 .. d): [x | sin(x), cos(x) | sin(2 x), cos(2 x) | ...] (layer.py:14-23)
-__device__ __forceinline__ float fourier_feature(const float *x, int d, int j) {
-    if (j < d) return x[j];
-    const int jj = j - d, k = jj / (2 * d), r = jj - k * 2 * d;
-    const float arg = ldexpf(1.0f, k) * (r < d ? x[r] : x[r - d]);
-    return r < d ? sinf(arg) : cosf(arg);
-}
-// 64 samples a block: every thread works out a quarter of its sample's features into LDS, then the block writes the rows out in runs of
-// whole feature vectors (a thread writing its own sample's 153 numbers one by one, 1.3 KB from its neighbour's, ran at 0.8 TB/s)
-constexpr int ENC_SAMPLES = 64, ENC_BASE = 24;           // per sample in LDS: its features, and in front of them pos (3), dir (3), parameters (16)
-__global__ __launch_bounds__(256) void encode_kernel(EncodeArgs a) {
-    extern __shared__ float enc_lds[];                     // [ENC_SAMPLES][ENC_BASE], then [ENC_SAMPLES][Kp + Kd]
-    float *enc_tile = enc_lds + ENC_SAMPLES * ENC_BASE;
-    const long long M = (long long)a.n_rays * a.S;
-    const int ls = threadIdx.x & (ENC_SAMPLES - 1), part = threadIdx.x / ENC_SAMPLES;
-    const long long m = (long long)blockIdx.x * ENC_SAMPLES + ls;
+__global__ __launch_bounds__(64) void encode_kernel(EncodeArgs a) {
+    const int lane = threadIdx.x, n = lane & 31, h = lane >> 5, blk = blockIdx.x, part = blockIdx.y;
+    const long long m = (long long)blk * 32 + n;
+    const bool valid = m < a.M;
+    const int ray = valid ? (int)(m / a.S) : 0, s = valid ? (int)(m - (long long)ray * a.S) : 0;
+    const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
+    const float dn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    // A ray that misses the proxy (t = inf: the reference's Renderer.__call__ filters it out and scatters 0 / the background back,
+    // renderer.py:58-86) stays in the batch with depth 0 and distances 0: every alpha of it is 1 - exp(-sigma 0) = 0, so it composites to
+    // exactly 0 / the background, no gradient flows into or out of its rows, and the loss still counts it among its rays
+    const float zr = a.z[(size_t)ray * a.S + s];
+    const bool hit = isfinite(zr);
+    const float z = hit ? zr : 0.0f;
     const int P = a.n_geo + a.n_app;
-    const int Kp3 = 3 * (1 + 2 * a.pos_freq), Kpg = a.n_geo * (1 + 2 * a.param_freq), Kp = Kp3 + Kpg;
-    const int Kd3 = 3 * (1 + 2 * a.dir_freq), Kda = a.n_app * (1 + 2 * a.param_freq), Kd = Kd3 + Kda, KF = Kp + Kd;
-    float *base = enc_lds + ls * ENC_BASE;                  // (registers cannot be indexed by a feature's number: the sample's inputs go through LDS)
-    if (m < M && part == 0) {
-        const int ray = (int)(m / a.S), s = (int)(m - (long long)ray * a.S);
+    const float *pr = a.params + (size_t)(ray / a.rays_per_param_row) * (P > 0 ? P : 1);
+    auto param = [&](int c) { return c == a.blur_idx ? (hit ? pr[c] * (a.cone[ray] * z) : 0.0f) : pr[c]; };   // :155-158 (a missing ray's cone scale may be anything)
+    float *R = part == 0 ? a.posR : a.dirR, *O = part == 0 ? a.posO : a.dirO;
+    const int tiles = part == 0 ? a.ptiles : a.dtiles;
+    auto put = [&](int row, float v) {
+        if (!valid) v = 0.0f;                                                            // the tail of the last block: finite, and no gradient comes back
+        R[((size_t)blk * tiles * 32 + row) * 32 + n] = v;
+        O[(((size_t)blk * tiles + (row >> 5)) * 4 + (n >> 3)) * 256 + ((row & 31) + 32 * ((n >> 2) & 1)) * 4 + (n & 3)] = v;
+    };
+    // FourierFeatures of x[0 .. D) with L bands from row r0 on: [x | sin(2^0 x) | cos(2^0 x) | sin(2^1 x) | ...], every block D wide (layer.py:14-23)
+    auto fourier = [&](int r0, int D, int L, auto x) {
+        if (h == 0) for (int c = 0; c < D; ++c) put(r0 + c, x(c));
+        for (int f = 0; f < L; ++f)
+            for (int c = 0; c < D; ++c) put(r0 + D + 2 * D * f + h * D + c, ntx::sin_q(ldexpf(1.0f, f) * x(c), h));
+    };
+    if (part == 0) {
         const float o[3] = {a.rays_o[3 * ray], a.rays_o[3 * ray + 1], a.rays_o[3 * ray + 2]};
-        const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
-        const float dn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
-        // A ray that misses the proxy (t = inf: the reference's Renderer.__call__ filters it out and scatters 0 / the background back,
-        // renderer.py:58-86) stays in the batch with depth 0 and distances 0: every alpha of it is 1 - exp(-sigma 0) = 0, so it composites to
-        // exactly 0 / the background, no gradient flows into or out of its rows, and the loss still counts it among its rays
-        const float zr = a.z[(size_t)ray * a.S + s];
-        const bool hit = isfinite(zr);
-        const float z = hit ? zr : 0.0f;
-        for (int c = 0; c < 3; ++c) { base[c] = o[c] + d[c] * z; base[3 + c] = d[c] / dn; }   // renderer.py:114 (un-normalised rays_d), :98
-        const float *pr = a.params + (size_t)(ray / a.rays_per_param_row) * P;
-        for (int c = 0; c < P; ++c) base[6 + c] = c == a.blur_idx ? (hit ? pr[c] * (a.cone[ray] * z) : 0.0f) : pr[c];   // :155-158 (a missing ray's cone scale may be anything)
-        const float zn = s + 1 < a.S ? a.z[(size_t)ray * a.S + s + 1] : 0.0f;
-        const float dist = s + 1 < a.S ? zn - z : (a.S > 1 ? z - a.z[(size_t)ray * a.S + s - 1] : 0.0f);
-        a.dists[(size_t)ray * a.S + s] = hit ? dist * dn : 0.0f;
-    }
-    __syncthreads();
-    if (m < M) {
-        float *row = enc_tile + ls * KF;
-        for (int j = part; j < KF; j += 4) {                                                  // model.py:88-101
-            float v;
-            if (j < Kp3) v = fourier_feature(base, 3, j);
-            else if (j < Kp) v = fourier_feature(base + 6, a.n_geo, j - Kp3);
-            else if (j < Kp + Kd3) v = fourier_feature(base + 3, 3, j - Kp);
-            else v = fourier_feature(base + 6 + a.n_geo, a.n_app, j - Kp - Kd3);
-            row[j] = v;
+        fourier(0, 3, a.pos_freq, [&](int c) { return o[c] + d[c] * z; });                  // renderer.py:114 (un-normalised rays_d)
+        if (a.n_geo > 0) fourier(3 * (1 + 2 * a.pos_freq), a.n_geo, a.param_freq, [&](int c) { return param(c); });      // model.py:88-93
+    } else {
+        fourier(0, 3, a.dir_freq, [&](int c) { return d[c] / dn; });                        // renderer.py:98
+        if (a.n_app > 0) fourier(3 * (1 + 2 * a.dir_freq), a.n_app, a.param_freq, [&](int c) { return param(a.n_geo + c); });   // model.py:96-101
+        if (valid && h == 0) {
+            const float zn = s + 1 < a.S ? a.z[(size_t)ray * a.S + s + 1] : 0.0f;
+            const float dist = s + 1 < a.S ? zn - z : (a.S > 1 ? z - a.z[(size_t)ray * a.S + s - 1] : 0.0f);
+            a.dists[(size_t)ray * a.S + s] = hit ? dist * dn : 0.0f;
         }
-    }
-    __syncthreads();
-    const long long m0 = (long long)blockIdx.x * ENC_SAMPLES;
-    for (int e = threadIdx.x; e < ENC_SAMPLES * Kp; e += 256) {
-        const int r = e / Kp, j = e - r * Kp;
-        if (m0 + r < M) a.pos_out[(size_t)(m0 + r) * a.ld_pos + j] = enc_tile[r * KF + j];
-    }
-    for (int e = threadIdx.x; e < ENC_SAMPLES * Kd; e += 256) {
-        const int r = e / Kd, j = e - r * Kd;
-        if (m0 + r < M) a.dir_out[(size_t)(m0 + r) * a.ld_dir + j] = enc_tile[r * KF + Kp + j];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// the narrow heads on the vector ALUs: y[m][c] = x[m] . W[:, c] + b[c] for n_out = 1 (alpha) or 3 (color)
-// ---------------------------------------------------------------------------------------------------------------------------
-// A row is read by K / 4 neighbouring lanes, 16 bytes each (a wave's load is one or two whole rows); their partial sums meet by butterfly.
-// A thread takes four rows, a block's worth of rows apart: four loads in flight.  K / 4 = 64 or 32.
-__global__ __launch_bounds__(256) void head_forward_kernel(const float *__restrict__ X, int ldx, int K, const float *__restrict__ W, const float *__restrict__ b, int n_out,
-                                                           long long M, float *__restrict__ Y) {
-    const int q = K / 4, kq = threadIdx.x % q, rows = 256 / q;
-    const long long row0 = (long long)blockIdx.x * (4 * rows) + threadIdx.x / q;
-    f32x4 v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long long m = row0 + i * rows;
-        v[i] = m < M ? *reinterpret_cast<const f32x4 *>(X + (size_t)m * ldx + 4 * kq) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-    float w[4][3];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        for (int c = 0; c < 3; ++c) w[j][c] = c < n_out ? W[(4 * kq + j) * n_out + c] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-        float acc[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] += e[j] * w[j][c];
-        for (int o = q / 2; o > 0; o >>= 1)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] += __shfl_xor(acc[c], o);
-        const long long m = row0 + i * rows;
-        if (kq == 0 && m < M)
-            for (int c = 0; c < n_out; ++c) Y[(size_t)m * n_out + c] = acc[c] + b[c];
-    }
-}
-// dX[m][k] (+)= sum_c dY[m][c] W[k][c], kept where mask > 0 (mask NULL: everywhere); thread per four neighbouring k of a row (K, lddx and
-// ldmask are multiples of 4)
-__global__ void head_backward_dx_kernel(const float *__restrict__ dY, int n_out, const float *__restrict__ W, int K, long long M, const float *__restrict__ mask,
-                                        int ldmask, int accumulate, float *__restrict__ dX, int lddx) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = K / 4;
-    if (e >= M * q) return;
-    const long long m = e / q; const int k = 4 * (int)(e - m * q);
-    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int c = 0; c < n_out; ++c) {
-        const float d = dY[(size_t)m * n_out + c];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += d * W[(k + j) * n_out + c];
-    }
-    f32x4 *out = reinterpret_cast<f32x4 *>(dX + (size_t)m * lddx + k);
-    if (accumulate) { const f32x4 o = *out; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-    if (mask) {
-        const f32x4 k4 = *reinterpret_cast<const f32x4 *>(mask + (size_t)m * ldmask + k);
-        if (!(k4.x > 0.0f)) v[0] = 0.0f;
-        if (!(k4.y > 0.0f)) v[1] = 0.0f;
-        if (!(k4.z > 0.0f)) v[2] = 0.0f;
-        if (!(k4.w > 0.0f)) v[3] = 0.0f;
-    }
-    *out = f32x4{v[0], v[1], v[2], v[3]};
-}
-// dst[m * ld] = src[m]: a column of a row-major matrix
-__global__ void column_kernel(const float *__restrict__ src, long long M, float *__restrict__ dst, int ld) {
-    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < M) dst[m * ld] = src[m];
-}
-// (dW | db) partial over a block of `rows` rows: partial[b][K + 1][n_out], row k < K = sum_m X[m][k] dY[m][c], row K = sum_m dY[m][c] (the bias
-// row: kernel and bias are neighbours in the blob).  K / 4 neighbouring threads read a row 16 bytes each; 256 / (K / 4) such groups take every
-// group-count-th row of the block, eight rows' loads in flight each, and their sums meet in LDS in group order (a fixed order of additions).
-__global__ __launch_bounds__(256) void head_backward_dw_partial_kernel(const float *__restrict__ X, int ldx, int K, const float *__restrict__ dY, int n_out, long long M, int rows,
-                                                                       float *__restrict__ partial) {
-    __shared__ float part[8][(256 + 1) * 3];
-    const int q = K / 4, groups = 256 / q, grp = threadIdx.x / q, c4 = threadIdx.x % q;
-    const long long m0 = (long long)blockIdx.x * rows, m1 = m0 + rows < M ? m0 + rows : M;
-    float acc[4][3], bias[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[j][c] = 0.0f;
-    for (long long m = m0 + grp; m < m1; m += 8 * groups) {
-        f32x4 x[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const long long r = m + (long long)i * groups;
-            x[i] = r < m1 ? *reinterpret_cast<const f32x4 *>(X + (size_t)r * ldx + 4 * c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const long long r = m + (long long)i * groups;
-            if (r < m1) {
-                const float e[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
-                for (int c = 0; c < n_out; ++c) {
-                    const float d = dY[(size_t)r * n_out + c];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j][c] += e[j] * d;
-                    if (c4 == 0) bias[c] += d;
-                }
-            }
-        }
-    }
-    for (int c = 0; c < n_out; ++c) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) part[grp][(4 * c4 + j) * n_out + c] = acc[j][c];
-        if (c4 == 0) part[grp][K * n_out + c] = bias[c];
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < (K + 1) * n_out; e += 256) {
-        float total = part[0][e];
-        for (int g = 1; g < groups; ++g) total += part[g][e];
-        partial[(size_t)blockIdx.x * (K + 1) * n_out + e] = total;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// map_model_output (renderer.py:170-213) per ray and its adjoint; wave per ray, lane l holds samples l, l + 64, ...
+// map_model_output (renderer.py:170-213) per ray, the ray's terms of the loss (loss.py: both losses are means over the rays, so a ray's
+// gradient needs nothing of the others) and the adjoint of both; wave per ray, lane l holds samples l, l + 64, ...
 // ---------------------------------------------------------------------------------------------------------------------------
 struct CompositeArgs {
     const float *raw_rgb, *sigma, *dists;      // [N][S][3], [N][S], [N][S]
     const float *noise;                        // NULL, or [N][S]: raw_noise_std * N(0,1), added to the density before its ReLU (renderer.py:190-195)
     int n_rays, S, map_exr, composite_bkgd; float bkgd[3];
-    float *color, *alpha;                      // forward outputs [N][3], [N]
-    const float *d_color, *d_alpha;            // backward inputs
-    float *d_raw_rgb, *d_sigma;                // backward outputs
+    const float *color_true, *alpha_true;
+    int kind, loss_fn, alpha_loss_fn, filter_color_loss, use_hard_mask; float gamma;
+    float *color, *alpha, *ray_loss;           // [N][3], [N], [N]: the predictions and each ray's share of the loss
+    float *dgrad;                              // [M][4]: dL/d raw rgb, dL/d sigma per sample (the way back starts from these)
+    float *dhead;                              // the same as one O-layout tile per block of 32 samples (rows 0-2, 3): the narrow heads' dY
+    long long M;
 };
 constexpr int MAX_TRAIN_SAMPLES = 1024;
 __device__ __forceinline__ float wave_sumf(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
@@ -815,10 +403,26 @@ __device__ __forceinline__ float rgb_of(float raw, int map_exr) {
     if (map_exr) return raw > 0.0f ? raw + 1.0f : expf(raw);                                   // elu + 1 (:184-185)
     return 1.0f / (1.0f + expf(-raw));                                                         // sigmoid (:187)
 }
-template <bool BACKWARD>
-__global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
+__device__ __forceinline__ void loss_term(int fn, float t, float p, float inv_n, float &value, float &grad) {
+    if (fn == NTX_LOSS_MSE) { const float e = t - p; value = e * e * inv_n; grad = -2.0f * e * inv_n; }          // loss.py:51-54
+    else {                                                                                                        // smape, eps 1e-2 (:56-59)
+        const float e = t - p, den = (t + p) + 1e-2f, ae = fabsf(e);
+        const float sgn = e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f);
+        value = ae / den * inv_n; grad = (-sgn / den - ae / (den * den)) * inv_n;
+    }
+}
+__device__ __forceinline__ size_t dhead_at(long long m, int row) {
+    const long long blk = m >> 5; const int p = (int)(m & 31);
+    return (size_t)((blk * 4 + (p >> 3)) * 256 + (row + 32 * ((p >> 2) & 1)) * 4 + (p & 3));
+}
+__global__ __launch_bounds__(256) void composite_loss_kernel(CompositeArgs a) {
     __shared__ float sh_a[4][MAX_TRAIN_SAMPLES], sh_T[4][MAX_TRAIN_SAMPLES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0) {                                 // the tail of the last block of 32 samples: no gradient
+        const long long end = (a.M + 31) / 32 * 32;
+        for (long long m = a.M + threadIdx.x; m < end; m += 256)
+            for (int r = 0; r < 4; ++r) a.dhead[dhead_at(m, r)] = 0.0f;
+    }
     const int ray = blockIdx.x * 4 + wave;
     if (ray >= a.n_rays) return;
     const int S = a.S;
@@ -846,15 +450,24 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
         A += w;
     }
     c0 = wave_sumf(c0); c1 = wave_sumf(c1); c2 = wave_sumf(c2); A = wave_sumf(A);
-    if (!BACKWARD) {
-        if (a.composite_bkgd) { c0 += (1.0f - A) * a.bkgd[0]; c1 += (1.0f - A) * a.bkgd[1]; c2 += (1.0f - A) * a.bkgd[2]; }   // :210-211
-        if (lane == 0) { a.color[3 * ray] = c0; a.color[3 * ray + 1] = c1; a.color[3 * ray + 2] = c2; a.alpha[ray] = A; }
-        return;
+    if (a.composite_bkgd) { c0 += (1.0f - A) * a.bkgd[0]; c1 += (1.0f - A) * a.bkgd[1]; c2 += (1.0f - A) * a.bkgd[2]; }   // :210-211
+    // the ray's terms of the loss and their derivatives (loss.py:6-49)
+    const float cp[3] = {c0, c1, c2};
+    float dC[3], dA = 0.0f, total = 0.0f;
+    {
+        const float inv_c = 1.0f / (float)(a.n_rays * 3), inv_a = 1.0f / (float)a.n_rays;
+        float mask = 1.0f;
+        if (a.kind == NTX_LOSS_ALPHA && a.filter_color_loss) mask = a.use_hard_mask ? (a.alpha_true[ray] > 0.0f ? 1.0f : 0.0f) : a.alpha_true[ray];   // :29-35
+        for (int c = 0; c < 3; ++c) {
+            float v, gr;
+            loss_term(a.loss_fn, a.color_true[3 * ray + c] * mask, cp[c] * mask, inv_c, v, gr);
+            total += v; dC[c] = gr * mask;
+        }
+        if (a.kind == NTX_LOSS_ALPHA) { float v; loss_term(a.alpha_loss_fn, a.alpha_true[ray], A, inv_a, v, dA); total += a.gamma * v; dA *= a.gamma; }   // :38
     }
+    if (lane == 0) { a.color[3 * ray] = c0; a.color[3 * ray + 1] = c1; a.color[3 * ray + 2] = c2; a.alpha[ray] = A; a.ray_loss[ray] = total; }
     // adjoint.  C = sum w rgb (+ (1 - A) bkgd), A = sum w, w_i = a_i T_i, T_i = prod_{j<i} ((1 - a_j) + 1e-10):
     //   g_i = dL/dw_i = dC . rgb_i + dA';   dL/da_i = T_i g_i - (sum_{k>i} g_k w_k) / ((1 - a_i) + 1e-10)
-    const float dC[3] = {a.d_color[3 * ray], a.d_color[3 * ray + 1], a.d_color[3 * ray + 2]};
-    float dA = a.d_alpha[ray];
     if (a.composite_bkgd) dA -= (dC[0] * a.bkgd[0] + dC[1] * a.bkgd[1]) + dC[2] * a.bkgd[2];
     float suffix = 0.0f;                                   // sum of g_k w_k over the samples behind the current chunk
     for (int s0 = ((S - 1) / 64) * 64; s0 >= 0; s0 -= 64) {
@@ -872,53 +485,29 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
             const float w = al[s] * T[s];
             const float d_a = T[s] * g - behind / ((1.0f - al[s]) + 1e-10f);
             const float sig = nz ? sg[s] + nz[s] : sg[s];
-            a.d_sigma[(size_t)ray * S + s] = sig > 0.0f ? d_a * ds[s] * expf(-sig * ds[s]) : 0.0f;
+            float gr[4];
             for (int c = 0; c < 3; ++c) {
                 const float raw = rr[3 * s + c];
                 const float drgb = a.map_exr ? (raw > 0.0f ? 1.0f : expf(raw)) : rgb[c] * (1.0f - rgb[c]);
-                a.d_raw_rgb[((size_t)ray * S + s) * 3 + c] = w * dC[c] * drgb;
+                gr[c] = w * dC[c] * drgb;
             }
+            gr[3] = sig > 0.0f ? d_a * ds[s] * expf(-sig * ds[s]) : 0.0f;
+            const long long m = (long long)ray * S + s;
+            *reinterpret_cast<f32x4 *>(a.dgrad + 4 * m) = f32x4{gr[0], gr[1], gr[2], gr[3]};
+            for (int r = 0; r < 4; ++r) a.dhead[dhead_at(m, r)] = gr[r];
         }
         suffix += __shfl(incl, 0);
     }
 }
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// loss.py: NerfLoss / AlphaLoss over mse / smape; one workgroup (a training batch is a thousand rays).  Value and gradient.
-// ---------------------------------------------------------------------------------------------------------------------------
-struct LossArgs {
-    const float *color_true, *alpha_true, *color_pred, *alpha_pred;
-    int n_rays, kind, loss_fn, alpha_loss_fn, filter_color_loss, use_hard_mask; float gamma;
-    float *loss, *d_color, *d_alpha;
-};
-__device__ __forceinline__ void loss_term(int fn, float t, float p, float inv_n, float &value, float &grad) {
-    if (fn == NTX_LOSS_MSE) { const float e = t - p; value = e * e * inv_n; grad = -2.0f * e * inv_n; }          // loss.py:51-54
-    else {                                                                                                        // smape, eps 1e-2 (:56-59)
-        const float e = t - p, den = (t + p) + 1e-2f, ae = fabsf(e);
-        const float sgn = e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f);
-        value = ae / den * inv_n; grad = (-sgn / den - ae / (den * den)) * inv_n;
-    }
-}
-__global__ __launch_bounds__(1024) void loss_kernel(LossArgs a) {
+// the loss: the rays' terms added up by one workgroup in a fixed order
+__global__ __launch_bounds__(1024) void loss_sum_kernel(const float *__restrict__ ray_loss, int n_rays, float *__restrict__ loss) {
     __shared__ float red[1024];
     float total = 0.0f;
-    const float inv_c = 1.0f / (float)(a.n_rays * 3), inv_a = 1.0f / (float)a.n_rays;
-    for (int r = threadIdx.x; r < a.n_rays; r += blockDim.x) {
-        float mask = 1.0f;
-        if (a.kind == NTX_LOSS_ALPHA && a.filter_color_loss) mask = a.use_hard_mask ? (a.alpha_true[r] > 0.0f ? 1.0f : 0.0f) : a.alpha_true[r];   // :29-35
-        for (int c = 0; c < 3; ++c) {
-            float v, gr;
-            loss_term(a.loss_fn, a.color_true[3 * r + c] * mask, a.color_pred[3 * r + c] * mask, inv_c, v, gr);
-            total += v; a.d_color[3 * r + c] = gr * mask;
-        }
-        float ga = 0.0f;
-        if (a.kind == NTX_LOSS_ALPHA) { float v; loss_term(a.alpha_loss_fn, a.alpha_true[r], a.alpha_pred[r], inv_a, v, ga); total += a.gamma * v; ga *= a.gamma; }   // :38
-        a.d_alpha[r] = ga;
-    }
+    for (int r = threadIdx.x; r < n_rays; r += blockDim.x) total += ray_loss[r];
     red[threadIdx.x] = total;
     __syncthreads();
     for (int o = blockDim.x / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) *a.loss = red[0];
+    if (threadIdx.x == 0) *loss = red[0];
 }
 
 // tf.keras.optimizers.Adam (TF 2.4, non-amsgrad): m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2;
@@ -942,28 +531,28 @@ __global__ void adam_kernel(float *__restrict__ w, const float *__restrict__ g, 
 struct TLayer { int in, out; size_t w, b; };      // offsets into the Keras-order blob (kernel [in][out], then bias)
 
 struct ntx_trainer {
-    int device = 0;
+    int device = 0, cus = 256;
     ntx_model_desc desc{};
-    int Kp = 0, Kd = 0, P = 0, Kp4 = 0, Kd4 = 0, ldp = 0, ldd = 0;   // the two concat buffers: [pos_map | pad to 16 bytes | h4], row stride ldp = Kp4 + 256; [dir_map | pad | feature], ldd
+    int Kp = 0, Kd = 0, P = 0, ptiles = 0, dtiles = 0, PS = 0, DS = 0;   // pos_map / dir_map: features, tiles of 32 rows of their buffers, k-steps of their segments
     TLayer trunk[8], feature, c1, c2, rgb, alpha;
     size_t n_weights = 0;
-    long long cap = 0;                         // samples the buffers hold
-    float *w = nullptr, *wp = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;   // wp: the packed images rows_kernel streams (made once a step)
-    ntx_train::PackArgs pack{};
-    const float *fwd_recs[11] = {}; int fwd_kblocks[11] = {};   // trunk 0-7, feature, c1, c2
-    const float *bwd_recs[10] = {}; int bwd_kblocks[10] = {};   // trunk 1-7 (index i - 1), feature, c1, c2
-    // activations (per sample): h[i] = output of trunk layer i (h[4] lives inside h4c), c1o, c2o; concat buffers; heads' raw outputs
-    float *h[8] = {}, *h4c = nullptr, *fc = nullptr, *c1o = nullptr, *c2o = nullptr, *raw_rgb = nullptr, *sigma = nullptr;
-    unsigned int *bits_ones = nullptr;         // all set: the "mask" of a layer without a ReLU behind it
-    unsigned int *bits[9] = {};                // where h[0..7] and c1o are > 0, one bit per output in rows_kernel's layout (1 KiB per 32 samples)
-    float *gf = nullptr;                       // [d feature (256) | d_sigma | 3 zeros] per sample, row stride LDGF
-    float *dyt[8] = {};                        // the gradient at every trunk layer's output (what its dW contracts with): kept, so that all dW run in one launch
-    float *dw_partial = nullptr; size_t dw_partial_floats = 0;
-    float *noise = nullptr;                    // [M]: the density regulariser's draws of a step (raw_noise_std)
-    float *z = nullptr, *dists = nullptr, *g0 = nullptr, *g1 = nullptr, *d_raw = nullptr, *d_sigma = nullptr, *partial = nullptr;
-    float *color = nullptr, *alpha_out = nullptr, *d_color = nullptr, *d_alpha = nullptr, *loss = nullptr;
-    long long cap_rays = 0;
-    size_t partial_floats = 0;
+    long long cap = 0, cap_blocks = 0, cap_rays = 0;   // samples (blocks of 32 samples, rays) the buffers hold
+    float *w = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    // what pack_kernel makes of the weights once a step: the two streams and the aux block
+    float *wfwd = nullptr, *wdx = nullptr, *aux = nullptr; size_t fwd_floats = 0, dx_floats = 0;
+    ntx_train::PackSeg *pack_seg = nullptr; int n_pack = 0; long long pack_total = 0;
+    // forward: the encoded inputs (row order and O layout), every layer's output (O layout), the ReLU bits, the heads' raw outputs
+    float *posR = nullptr, *posO = nullptr, *dirR = nullptr, *dirO = nullptr;
+    float *act = nullptr; long long act_stride = 0;       // eleven matrices act + i * act_stride: h0 .. h7, feature, c1o, c2o
+    unsigned int *bits = nullptr; long long bits_stride = 0;   // ten: h0 .. h7, c1o, c2o
+    int fwd_variant = 0;
+    float *sigma = nullptr, *raw_rgb = nullptr, *z = nullptr, *dists = nullptr, *noise = nullptr;
+    // backward: the composite's adjoint, the gradient at every layer's output (O layout: d c2o, d c1o, d feature, dy7 .. dy0)
+    float *dgrad = nullptr, *dhead = nullptr, *gout = nullptr; long long gout_stride = 0;
+    ntx_train::DwTask *tasks = nullptr; int n_tasks = 0, wg_tasks = 0;
+    size_t per_split = 0; float *dw_partial = nullptr;
+    ntx_train::ReduceBatch reduce{};           // (n_split per step)
+    float *color = nullptr, *alpha_out = nullptr, *ray_loss = nullptr, *loss = nullptr;
     long long adam_iterations = 0;
 };
 
@@ -971,26 +560,18 @@ namespace {
 
 using namespace ntx_train;
 
-constexpr int SPLIT = 128;        // partial sums of a weight gradient along the samples
-constexpr int HEAD_ROWS = 512;    // rows per block of the narrow reductions
-constexpr int LDGF = 260;
+constexpr int SPLIT = 128;        // ranges of sample blocks whose weight-gradient sums are kept apart (at most)
 
 void free_all(ntx_trainer *t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
-    void *ptrs[] = {t->w, t->wp, t->grad, t->adam_m, t->adam_v, t->h4c, t->fc, t->c1o, t->c2o, t->raw_rgb, t->sigma, t->z, t->dists, t->noise, t->g0, t->g1, t->gf, t->d_raw, t->d_sigma,
-                    t->partial, t->color, t->alpha_out, t->d_color, t->d_alpha, t->loss};
+    void *ptrs[] = {t->w, t->grad, t->adam_m, t->adam_v, t->wfwd, t->wdx, t->aux, t->pack_seg, t->posR, t->posO, t->dirR, t->dirO, t->sigma, t->raw_rgb, t->z, t->dists, t->noise,
+                    t->dgrad, t->dhead, t->tasks, t->dw_partial, t->color, t->alpha_out, t->ray_loss, t->loss, t->act, t->bits, t->gout};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (int i = 0; i < 8; ++i) if (i != 4 && t->h[i]) (void)hipFree(t->h[i]);
-    for (int i = 0; i < 9; ++i) if (t->bits[i]) (void)hipFree(t->bits[i]);
-    if (t->bits_ones) (void)hipFree(t->bits_ones);
-    for (int i = 0; i < 8; ++i) if (t->dyt[i]) (void)hipFree(t->dyt[i]);
-    if (t->dw_partial) (void)hipFree(t->dw_partial);
     delete t;
 }
 
-// one contraction on caller buffers (ntx_gemm_f32): 128 x 128 tiles, panels of 16 -- the shape every measurement of the round ended on
-// (deeper panels or 256-wide tiles cost occupancy: 0.552 / 0.467 of the peak in the step against 0.58)
+// one contraction on caller buffers (ntx_gemm_f32): 128 x 128 tiles, panels of 16
 template <bool AK>
 void launch_gemm(hipStream_t st, GemmArgs g) {
     g.k_chunk = g.K;
@@ -998,27 +579,19 @@ void launch_gemm(hipStream_t st, GemmArgs g) {
     hipLaunchKernelGGL((gemm_kernel<AK, 128, 16>), dim3((g.N + 127) / 128, (g.M + TM - 1) / TM, 1), dim3(256), 0, st, g);
 }
 
-// a chain of layers in one launch: forward Y = act(X . W + b) through each layer's packed image, or dX = dY . W^T kept where the forward
-// pass left a bit
-void launch_rows(hipStream_t st, const RowsArgs &a, int N, bool forward) {
-    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    const long long n_groups = ((a.M + 31) / 32 + 3) / 4;
-    const dim3 grid((unsigned)(n_groups < cus ? n_groups : cus)), wg(256);     // persistent: a workgroup of four waves per CU
-    if (N != 256) hipLaunchKernelGGL((rows_kernel<4, ROWS_FORWARD>), grid, wg, 0, st, a);
-    else if (forward) hipLaunchKernelGGL((rows_kernel<8, ROWS_FORWARD>), grid, wg, 0, st, a);
-    else hipLaunchKernelGGL((rows_kernel<8, ROWS_DX_MASK>), grid, wg, 0, st, a);
-}
-RowsLayer forward_layer(const float *X, int ldx, const float *recs, int kblocks, const float *b, float *Y, int ldy, int relu, unsigned int *bits_out) {
-    RowsLayer r{}; r.X = X; r.ldx = ldx; r.recs = recs; r.kblocks = kblocks; r.Y = Y; r.ldy = ldy; r.bias = b; r.linear = !relu; r.bits_out = bits_out;
-    return r;
-}
-// dY [M][..] (row stride lddy) -> dX [M][256]
-RowsLayer dx_layer(const float *dY, int lddy, const float *recs, int kblocks, const unsigned int *bits, float *dX, int lddx) {
-    RowsLayer r{}; r.X = dY; r.ldx = lddy; r.recs = recs; r.kblocks = kblocks; r.Y = dX; r.ldy = lddx; r.bits_in = bits;
-    return r;
-}
-
 }   // namespace
+
+namespace ntx_train {
+template <int K> void launch_fwd_variant(hipStream_t st, unsigned grid, const FwdArgs &a);      // ntx_train_chain.hip, one object each
+void launch_fwd_chain(int variant, hipStream_t st, unsigned grid, const FwdArgs &a) {
+    switch (variant) {
+        case 0: launch_fwd_variant<0>(st, grid, a); break;
+        case 1: launch_fwd_variant<1>(st, grid, a); break;
+        case 2: launch_fwd_variant<2>(st, grid, a); break;
+        default: launch_fwd_variant<3>(st, grid, a); break;
+    }
+}
+}   // namespace ntx_train
 
 extern "C" {
 
@@ -1035,6 +608,11 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
         return ntx_set_error(NTX_E_UNSUPPORTED, "training is built for the ParamNerf architecture of the shipped training configs (depth 8, width 256, skips [4], color_depth 1, "
                                                 "Fourier features); others render but do not train");
     if (desc->n_geo < 0 || desc->n_app < 0 || desc->n_geo + desc->n_app > 16) return ntx_set_error(NTX_E_INVALID, "n_parameters out of range");
+    if (desc->pos_freq < 0 || desc->dir_freq < 0 || desc->param_freq < 0) return ntx_set_error(NTX_E_INVALID, "negative band count");
+    const int Kp = 3 * (1 + 2 * desc->pos_freq) + desc->n_geo * (1 + 2 * desc->param_freq), Kd = 3 * (1 + 2 * desc->dir_freq) + desc->n_app * (1 + 2 * desc->param_freq);
+    if (Kp > 8 * MAX_PB_GROUPS || Kd > 8 * MAX_PB_GROUPS)
+        return ntx_set_error(NTX_E_UNSUPPORTED, "training: pos_map (%d) / dir_map (%d) wider than %d features (the chain holds a block's encoded inputs in registers)", Kp, Kd,
+                             8 * MAX_PB_GROUPS);
     if (max_rays < 1 || max_samples_per_ray < 2 || max_samples_per_ray > MAX_TRAIN_SAMPLES || max_rays * (int64_t)max_samples_per_ray > (int64_t)1 << 30)
         return ntx_set_error(NTX_E_INVALID, "max_rays / max_samples_per_ray out of range (samples per ray <= %d)", MAX_TRAIN_SAMPLES);
     int ndev = 0;
@@ -1042,108 +620,159 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     if (device < 0 || device >= ndev) return ntx_set_error(NTX_E_INVALID, "device %d out of range [0,%d)", device, ndev);
     ntx_trainer *t = new ntx_trainer();
     t->device = device; t->desc = *desc;
-    t->P = desc->n_geo + desc->n_app;
-    t->Kp = 3 * (1 + 2 * desc->pos_freq) + desc->n_geo * (1 + 2 * desc->param_freq);
-    t->Kd = 3 * (1 + 2 * desc->dir_freq) + desc->n_app * (1 + 2 * desc->param_freq);
+    t->P = desc->n_geo + desc->n_app; t->Kp = Kp; t->Kd = Kd;
+    t->ptiles = (Kp + 31) / 32; t->dtiles = (Kd + 31) / 32;
+    {   // the forward chain's build for these segment lengths, or the longest one (the streams are then padded with zero rows)
+        const int psg = ((Kp + 1) / 2 + 3) / 4, dsg = ((Kd + 1) / 2 + 3) / 4;
+        t->fwd_variant = 3;
+        for (int v = 0; v < 3; ++v) if (FWD_VARIANTS[v][0] == psg && FWD_VARIANTS[v][1] == dsg) t->fwd_variant = v;
+        t->PS = 4 * FWD_VARIANTS[t->fwd_variant][0]; t->DS = 4 * FWD_VARIANTS[t->fwd_variant][1];
+    }
     size_t p = 0;
     auto take = [&](int in, int o) { TLayer l{in, o, p, p + (size_t)in * o}; p += (size_t)in * o + o; return l; };
-    int k = t->Kp;
-    for (int i = 0; i < 8; ++i) { t->trunk[i] = take(k, 256); k = 256 + (i == 4 ? t->Kp : 0); }       // model.py:104-108
-    t->feature = take(256, 256); t->c1 = take(256 + t->Kd, 256); t->c2 = take(256, 128); t->rgb = take(128, 3); t->alpha = take(256, 1);   // Keras order: alpha last
+    int k = Kp;
+    for (int i = 0; i < 8; ++i) { t->trunk[i] = take(k, 256); k = 256 + (i == 4 ? Kp : 0); }       // model.py:104-108
+    t->feature = take(256, 256); t->c1 = take(256 + Kd, 256); t->c2 = take(256, 128); t->rgb = take(128, 3); t->alpha = take(256, 1);   // Keras order: alpha last
     t->n_weights = p;
-    t->Kp4 = (t->Kp + 3) / 4 * 4; t->Kd4 = (t->Kd + 3) / 4 * 4;
-    t->ldp = t->Kp4 + 256; t->ldd = t->Kd4 + 256;
     if (n_floats != p) { delete t; return ntx_set_error(NTX_E_INVALID, "weights: %zu floats, the model has %zu", n_floats, p); }
-    const long long M = (long long)max_rays * max_samples_per_ray;
-    t->cap = M; t->cap_rays = max_rays;
-    auto alloc = [&](float **d, size_t n) -> int { TRAIN_TRY(hipMalloc((void **)d, (n ? n : 1) * sizeof(float))); return NTX_OK; };
+    const long long M = (long long)max_rays * max_samples_per_ray, NB = (M + 31) / 32;
+    t->cap = M; t->cap_rays = max_rays; t->cap_blocks = NB;
     int rc = hipSetDevice(device) == hipSuccess ? NTX_OK : ntx_set_error(NTX_E_HIP, "hipSetDevice(%d) failed", device);
-    if (rc == NTX_OK) rc = alloc(&t->w, p);
-    if (rc == NTX_OK) rc = alloc(&t->grad, p);
-    if (rc == NTX_OK) rc = alloc(&t->adam_m, p);
-    if (rc == NTX_OK) rc = alloc(&t->adam_v, p);
-    if (rc == NTX_OK) rc = alloc(&t->h4c, (size_t)M * t->ldp);
-    if (rc == NTX_OK) rc = alloc(&t->fc, (size_t)M * t->ldd);
-    for (int i = 0; i < 8 && rc == NTX_OK; ++i)
-        if (i != 4) rc = alloc(&t->h[i], (size_t)M * 256);
-    for (int i = 0; i < 9 && rc == NTX_OK; ++i) rc = alloc((float **)&t->bits[i], (size_t)((M + 31) / 32) * 256);
-    if (rc == NTX_OK) rc = alloc((float **)&t->bits_ones, (size_t)((M + 31) / 32) * 256);
-    if (rc == NTX_OK && hipMemset(t->bits_ones, 0xFF, (size_t)((M + 31) / 32) * 1024) != hipSuccess) rc = ntx_set_error(NTX_E_HIP, "hipMemset failed");
-    if (rc == NTX_OK) rc = alloc(&t->c1o, (size_t)M * 256);
-    if (rc == NTX_OK) rc = alloc(&t->c2o, (size_t)M * 128);
-    if (rc == NTX_OK) rc = alloc(&t->raw_rgb, (size_t)M * 3);
-    if (rc == NTX_OK) rc = alloc(&t->sigma, (size_t)M);
-    if (rc == NTX_OK) rc = alloc(&t->z, (size_t)M);
-    if (rc == NTX_OK) rc = alloc(&t->dists, (size_t)M);
-    if (rc == NTX_OK) rc = alloc(&t->noise, (size_t)M);
-    if (rc == NTX_OK) rc = alloc(&t->g0, (size_t)M * 256);
-    if (rc == NTX_OK) rc = alloc(&t->g1, (size_t)M * 256);
-    if (rc == NTX_OK) rc = alloc(&t->gf, (size_t)M * LDGF);
-    for (int i = 0; i < 8 && rc == NTX_OK; ++i) rc = alloc(&t->dyt[i], (size_t)M * 256);
-    {
-        size_t per_split = 0;
-        for (int i = 0; i < 8; ++i) per_split += (size_t)(t->trunk[i].in + 1) * 256;
-        per_split += (size_t)(t->feature.in + 1) * 256 + (size_t)(t->c1.in + 2) * 256 + (size_t)(t->c2.in + 1) * 128 + 256;
-        t->dw_partial_floats = (size_t)SPLIT * per_split;
-        if (rc == NTX_OK) rc = alloc(&t->dw_partial, t->dw_partial_floats);
-    }
-    if (rc == NTX_OK) rc = alloc(&t->d_raw, (size_t)M * 3);
-    if (rc == NTX_OK) rc = alloc(&t->d_sigma, (size_t)M);
-    t->partial_floats = (size_t)SPLIT * (256 + (t->Kd > t->Kp ? t->Kd : t->Kp)) * 256 + (size_t)SPLIT * 256;
-    {
-        const size_t head = (size_t)((M + HEAD_ROWS - 1) / HEAD_ROWS) * 257 * 3;
-        if (head > t->partial_floats) t->partial_floats = head;
-    }
-    if (rc == NTX_OK) rc = alloc(&t->partial, t->partial_floats);
-    if (rc == NTX_OK) rc = alloc(&t->color, (size_t)max_rays * 3);
-    if (rc == NTX_OK) rc = alloc(&t->alpha_out, (size_t)max_rays);
-    if (rc == NTX_OK) rc = alloc(&t->d_color, (size_t)max_rays * 3);
-    if (rc == NTX_OK) rc = alloc(&t->d_alpha, (size_t)max_rays);
-    if (rc == NTX_OK) rc = alloc(&t->loss, 1);
+    if (rc == NTX_OK) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) t->cus = n; }
+    auto alloc = [&](float **d, size_t n, bool zero = false) -> int {
+        if (rc != NTX_OK) return rc;
+        if (hipMalloc((void **)d, (n ? n : 1) * sizeof(float)) != hipSuccess) return rc = ntx_set_error(NTX_E_HIP, "hipMalloc of %zu floats failed", n);
+        if (zero && hipMemset(*d, 0, (n ? n : 1) * sizeof(float)) != hipSuccess) return rc = ntx_set_error(NTX_E_HIP, "hipMemset failed");
+        return rc;
+    };
+    alloc(&t->w, p); alloc(&t->grad, p, true); alloc(&t->adam_m, p, true); alloc(&t->adam_v, p, true);
+    // rows of the encoded inputs beyond Kp / Kd meet zero weights and are never written: they have to be finite
+    alloc(&t->posR, (size_t)NB * t->ptiles * 1024, true); alloc(&t->posO, (size_t)NB * t->ptiles * 1024, true);
+    alloc(&t->dirR, (size_t)NB * t->dtiles * 1024, true); alloc(&t->dirO, (size_t)NB * t->dtiles * 1024, true);
+    t->act_stride = t->gout_stride = NB * 8 * 1024; t->bits_stride = NB * 256;
+    alloc(&t->act, (size_t)t->act_stride * 11); alloc((float **)&t->bits, (size_t)t->bits_stride * 10); alloc(&t->gout, (size_t)t->gout_stride * 11);
+    auto act = [&](int i) { return t->act + (size_t)i * t->act_stride; };
+    auto gout = [&](int i) { return t->gout + (size_t)i * t->gout_stride; };
+    alloc(&t->sigma, (size_t)M); alloc(&t->raw_rgb, (size_t)M * 3); alloc(&t->z, (size_t)M); alloc(&t->dists, (size_t)M); alloc(&t->noise, (size_t)M);
+    alloc(&t->dgrad, (size_t)NB * 32 * 4); alloc(&t->dhead, (size_t)NB * 1024, true);       // rows 4 .. 31 of the heads' dY tile stay zero
+    alloc(&t->color, (size_t)max_rays * 3); alloc(&t->alpha_out, (size_t)max_rays); alloc(&t->ray_loss, (size_t)max_rays); alloc(&t->loss, 1);
     if (rc == NTX_OK && hipMemcpy(t->w, weights, p * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = ntx_set_error(NTX_E_HIP, "weight upload failed");
-    if (rc == NTX_OK && (hipMemset(t->adam_m, 0, p * sizeof(float)) != hipSuccess || hipMemset(t->adam_v, 0, p * sizeof(float)) != hipSuccess || hipMemset(t->grad, 0, p * sizeof(float)) != hipSuccess))
-        rc = ntx_set_error(NTX_E_HIP, "hipMemset failed");
-    if (rc != NTX_OK) { free_all(t); return rc; }
-    // the pad columns of the concat buffers meet zero weights: they only have to be finite
-    if (hipMemset(t->h4c, 0, (size_t)M * t->ldp * sizeof(float)) != hipSuccess || hipMemset(t->fc, 0, (size_t)M * t->ldd * sizeof(float)) != hipSuccess ||
-        hipMemset(t->gf, 0, (size_t)M * LDGF * sizeof(float)) != hipSuccess) {
-        free_all(t); return ntx_set_error(NTX_E_HIP, "hipMemset failed");
+    // ---- the two weight streams and the aux block: what lies where, and what pack_kernel gathers it from
+    std::vector<PackSeg> segs;
+    long long first = 0;
+    auto seg = [&](const float *src, long long sk, long long sc, int mode, int K, int ncols, int nt, size_t *stream_floats, int nsteps) {
+        PackSeg s{}; s.src = src; s.sk = sk; s.sc = sc; s.mode = mode; s.K = K; s.ncols = ncols; s.nt = nt;
+        const long long recs = ((long long)nsteps * (nt / 4) + RING - 1) / RING * RING;
+        s.count = recs * 256; s.first = first; s.dst = (float *)(uintptr_t)(*stream_floats * sizeof(float));      // an offset until the buffer exists
+        first += s.count; *stream_floats += (size_t)s.count;
+        segs.push_back(s);
+    };
+    const float *W = t->w;
+    // forward (model.py:104-123): W_l[k][col] row-major, k in the order of the layer's input
+    auto fwd_hidden = [&](const TLayer &l, int row0, int nt) { seg(W + l.w + (size_t)row0 * l.out, l.out, 1, PACK_HIDDEN, 256, l.out, nt, &t->fwd_floats, 128); };
+    auto fwd_linear = [&](const TLayer &l, int K, int nsteps) { seg(W + l.w, l.out, 1, PACK_LINEAR, K, l.out, 8, &t->fwd_floats, nsteps); };
+    fwd_linear(t->trunk[0], Kp, t->PS);
+    for (int i = 1; i < 8; ++i) {
+        if (i == 5) { fwd_linear(t->trunk[5], Kp, t->PS); fwd_hidden(t->trunk[5], Kp, 8); }
+        else fwd_hidden(t->trunk[i], 0, 8);
     }
-    t->h[4] = t->h4c + t->Kp4;                    // trunk layer 4 writes behind the position features: [pos_map | h4] is the skip's concat (model.py:108)
-    {   // the packed images: where each lies and what it is gathered from
-        PackArgs &pa = t->pack;
-        long long first = 0;
-        auto job = [&](const float *src, long long sk, long long sc, int K1, int K1p, int K2, const float *src2, long long sk2, long long sc2, int n_out, const float **recs,
-                       int *kblocks) {
-            PackJob &j = pa.job[pa.n_jobs++];
-            j.src = src; j.sk = sk; j.sc = sc; j.src2 = src2; j.sk2 = sk2; j.sc2 = sc2; j.K1 = K1; j.K1p = K1p; j.K2 = K2; j.nt = n_out / 32;
-            j.kblocks = ((K1p + K2 + 7) / 8 + 3) / 4 * 4;
-            j.first = first; j.dst = nullptr;
-            *kblocks = j.kblocks;
-            *recs = (const float *)(uintptr_t)first;          // an offset until the buffer exists
-            first += (long long)j.kblocks * 8 * n_out;
-        };
-        auto fwd = [&](const TLayer &l, int K1, int K1p, int K2, int slot) {
-            job(t->w + l.w, l.out, 1, K1, K1p, K2, t->w + l.w + (size_t)K1 * l.out, l.out, 1, l.out, &t->fwd_recs[slot], &t->fwd_kblocks[slot]);
-        };
-        auto bwd = [&](const TLayer &l, int row0, int slot) {
-            job(t->w + l.w + (size_t)row0 * l.out, 1, l.out, l.out, l.out, 0, nullptr, 0, 0, 256, &t->bwd_recs[slot], &t->bwd_kblocks[slot]);
-        };
-        for (int i = 0; i < 8; ++i) {
-            if (i == 5) fwd(t->trunk[i], t->Kp, t->Kp4, 256, i); else fwd(t->trunk[i], t->trunk[i].in, t->trunk[i].in, 0, i);
+    fwd_hidden(t->feature, 0, 8);
+    fwd_linear(t->c1, Kd, t->DS); fwd_hidden(t->c1, Kd, 8);
+    fwd_hidden(t->c2, 0, 4);
+    const size_t n_fwd_segs = segs.size();
+    // backward: row(s, kh) runs over the layer's OUTPUTS (what the lane holds of dY), the columns over its inputs: Wsrc[k][col] = W_l[col][k]
+    auto dx_hidden = [&](const TLayer &l, int row0, int K, int nsteps) { seg(W + l.w + (size_t)row0 * l.out, 1, l.out, PACK_HIDDEN, K, 256, 8, &t->dx_floats, nsteps); };
+    seg(W + t->rgb.w, 1, 3, PACK_LINEAR, 3, 128, 4, &t->dx_floats, 2);             // d c2o = d raw . W_rgb^T
+    dx_hidden(t->c2, 0, 128, 64);                                                   // d c1o = d c2o . W_c2^T
+    dx_hidden(t->c1, Kd, 256, 128);                                                 // d feature = d c1o . W_c1[the feature rows]^T
+    dx_hidden(t->feature, 0, 256, 128);                                             // d h7 = d feature . W_feature^T
+    seg(W + t->alpha.w, 1, 1, PACK_LINEAR, 1, 256, 8, &t->dx_floats, 1);            //        + d_sigma (x) W_alpha (model.py:111)
+    for (int i = 7; i >= 1; --i) dx_hidden(t->trunk[i], i == 5 ? Kp : 0, 256, 128);  // d h(i-1) = dy_i . W_i^T (the skip's position rows take no gradient further)
+    const size_t n_stream_segs = segs.size();
+    // a stream ends with its first RING records again
+    auto tail = [&](size_t of, size_t *stream_floats) { PackSeg s = segs[of]; s.count = (long long)RING * 256; s.first = first; s.dst = (float *)(uintptr_t)(*stream_floats * sizeof(float));
+                                                        first += s.count; *stream_floats += (size_t)s.count; segs.push_back(s); };
+    tail(0, &t->fwd_floats); tail(n_fwd_segs, &t->dx_floats);
+    // aux: biases of the eleven layers in accumulator order, the density head's weights and bias, the colour head's
+    auto aux_seg = [&](const float *src, int mode, int K, long long count, size_t at) {
+        PackSeg s{}; s.src = src; s.sk = 1; s.mode = mode; s.K = K; s.count = count; s.first = first; s.dst = (float *)(uintptr_t)(at * sizeof(float));
+        first += count; segs.push_back(s);
+    };
+    for (int i = 0; i < 8; ++i) aux_seg(W + t->trunk[i].b, PACK_AUX_ROW, 256, 256, AUX_BIAS + (size_t)i * 256);
+    aux_seg(W + t->feature.b, PACK_AUX_ROW, 256, 256, AUX_BIAS + 8 * 256); aux_seg(W + t->c1.b, PACK_AUX_ROW, 256, 256, AUX_BIAS + 9 * 256);
+    aux_seg(W + t->c2.b, PACK_AUX_ROW, 128, 256, AUX_BIAS + 10 * 256);
+    aux_seg(W + t->alpha.w, PACK_AUX_ROW, 256, 256, AUX_ALPHA_W); aux_seg(W + t->alpha.b, PACK_COPY, 1, 1, AUX_ALPHA_B);
+    aux_seg(W + t->rgb.w, PACK_AUX_RGB, 128, 384, AUX_RGB_W); aux_seg(W + t->rgb.b, PACK_COPY, 3, 3, AUX_RGB_B);
+    t->pack_total = first; t->n_pack = (int)segs.size();
+    alloc(&t->wfwd, t->fwd_floats); alloc(&t->wdx, t->dx_floats); alloc(&t->aux, AUX_FLOATS, true);
+    if (rc == NTX_OK) {
+        for (size_t i = 0; i < segs.size(); ++i) {
+            const bool is_aux = i >= n_stream_segs + 2, is_fwd = i < n_fwd_segs || i == n_stream_segs;
+            float *base = is_aux ? t->aux : is_fwd ? t->wfwd : t->wdx;
+            segs[i].dst = (float *)((char *)base + (uintptr_t)segs[i].dst);
         }
-        fwd(t->feature, 256, 256, 0, 8); fwd(t->c1, t->Kd, t->Kd4, 256, 9); fwd(t->c2, 256, 256, 0, 10);
-        for (int i = 1; i < 8; ++i) bwd(t->trunk[i], i == 5 ? t->Kp : 0, i - 1);      // the skip's position rows take no gradient further
-        bwd(t->c1, t->Kd, 8); bwd(t->c2, 0, 9);
-        // d h7 takes two gradients on: d feature . W_feature^T and d_sigma (x) W_alpha (model.py:111-115).  One contraction: the 1-wide head's
-        // weights are row 256 of the image, d_sigma column 256 of the buffer d feature is written to (row stride LDGF)
-        job(t->w + t->feature.w, 1, 256, 256, 256, 1, t->w + t->alpha.w, 0, 1, 256, &t->bwd_recs[7], &t->bwd_kblocks[7]);
-        pa.total = first;
-        if (alloc(&t->wp, (size_t)first) != NTX_OK) { free_all(t); return NTX_E_HIP; }
-        for (int j = 0; j < pa.n_jobs; ++j) pa.job[j].dst = t->wp + pa.job[j].first;
-        for (int i = 0; i < 11; ++i) t->fwd_recs[i] = t->wp + (uintptr_t)t->fwd_recs[i];
-        for (int i = 0; i < 10; ++i) t->bwd_recs[i] = t->wp + (uintptr_t)t->bwd_recs[i];
+        if (hipMalloc((void **)&t->pack_seg, segs.size() * sizeof(PackSeg)) != hipSuccess ||
+            hipMemcpy(t->pack_seg, segs.data(), segs.size() * sizeof(PackSeg), hipMemcpyHostToDevice) != hipSuccess)
+            rc = ntx_set_error(NTX_E_HIP, "segment table upload failed");
     }
+    // ---- the weight gradients' tasks: dW_l = X_l^T . dY_l, X_l = the O-layout input of layer l, dY_l = the gradient at its output
+    std::vector<DwTask> tasks;
+    size_t part_off = 0;
+    struct RJ { size_t part; long long count, pair; size_t out; };
+    std::vector<RJ> rjobs;
+    auto job = [&](const float *A, int rtA, int K, const float *B, int rtB, int c_lo, int N, size_t g_kernel, long long g_bias) {
+        const size_t pw = part_off; part_off += (size_t)K * N;
+        size_t pb = 0;
+        if (g_bias >= 0) { pb = part_off; part_off += (size_t)2 * N; }
+        rjobs.push_back(RJ{pw, (long long)K * N, 0, g_kernel});
+        if (g_bias >= 0) rjobs.push_back(RJ{pb, N, N, (size_t)g_bias});
+        const int tb0 = c_lo / 32, ntb = (c_lo + N + 31) / 32 - tb0, nta = (K + 31) / 32;     // the dY tiles that carry the columns; the X tiles with rows
+        for (int a0 = 0; a0 < nta; a0 += 2)
+            for (int b0 = 0; b0 < ntb; b0 += 4) {
+                const int na = a0 + 1 < nta ? 2 : 1, nb = ntb - b0 >= 4 ? 4 : 1;      // (dY is 8, 4 or 1 tiles wide)
+                DwTask d{}; d.A = A; d.rtA = rtA; d.a0 = a0; d.B = B; d.rtB = rtB; d.b0 = tb0 + b0;
+                d.kind = nb == 4 ? (na == 2 ? 0 : 1) : (na == 2 ? 2 : 3);
+                d.out = (float *)(uintptr_t)(pw * sizeof(float)); d.ldc = N; d.row0 = a0 * 32; d.rows_valid = K; d.col0 = (tb0 + b0) * 32; d.c_lo = c_lo; d.c_hi = c_lo + N;
+                d.bias_out = (g_bias >= 0 && a0 == 0) ? (float *)(uintptr_t)(pb * sizeof(float)) : nullptr;
+                tasks.push_back(d);
+            }
+    };
+    {
+        const TLayer &r = t->rgb, &al = t->alpha, &c2 = t->c2, &c1 = t->c1, &f = t->feature;
+        job(act(10), 4, 128, t->dhead, 1, 0, 3, r.w, (long long)r.b);                                   // colour head: X = c2o, dY = d raw
+        job(act(7), 8, 256, t->dhead, 1, 3, 1, al.w, (long long)al.b);                                   // density head: X = h7, dY = d sigma
+        job(act(9), 8, 256, gout(0), 4, 0, 128, c2.w, (long long)c2.b);                               // C2: X = c1o
+        job(t->dirO, t->dtiles, Kd, gout(1), 8, 0, 256, c1.w, -1);                                       // C1: X = [dir_map | feature]
+        job(act(8), 8, 256, gout(1), 8, 0, 256, c1.w + (size_t)Kd * 256, (long long)c1.b);
+        job(act(7), 8, 256, gout(2), 8, 0, 256, f.w, (long long)f.b);                                 // feature layer: X = h7
+        for (int i = 7; i >= 1; --i) {
+            const TLayer &l = t->trunk[i];
+            if (i == 5) job(t->posO, t->ptiles, Kp, gout(10 - i), 8, 0, 256, l.w, -1);                   // the skip: X = [pos_map | h4]
+            job(act(i - 1), 8, 256, gout(10 - i), 8, 0, 256, l.w + (size_t)(i == 5 ? Kp : 0) * 256, (long long)l.b);
+        }
+        job(t->posO, t->ptiles, Kp, gout(10), 8, 0, 256, t->trunk[0].w, (long long)t->trunk[0].b);
+    }
+    std::stable_sort(tasks.begin(), tasks.end(), [](const DwTask &x, const DwTask &y) { return x.kind < y.kind; });     // a workgroup's four tasks: of one size
+    t->per_split = part_off; t->n_tasks = (int)tasks.size(); t->wg_tasks = (t->n_tasks + 3) / 4;
+    alloc(&t->dw_partial, (size_t)SPLIT * t->per_split);
+    if (rc == NTX_OK) {
+        for (DwTask &d : tasks) {
+            d.out = (float *)((char *)t->dw_partial + (uintptr_t)d.out); d.split_stride = (long long)t->per_split;
+            if (d.bias_out) { d.bias_out = (float *)((char *)t->dw_partial + (uintptr_t)d.bias_out); d.bias_split_stride = (long long)t->per_split; }
+        }
+        if (hipMalloc((void **)&t->tasks, tasks.size() * sizeof(DwTask)) != hipSuccess ||
+            hipMemcpy(t->tasks, tasks.data(), tasks.size() * sizeof(DwTask), hipMemcpyHostToDevice) != hipSuccess)
+            rc = ntx_set_error(NTX_E_HIP, "task table upload failed");
+        if ((int)rjobs.size() > MAX_REDUCE_BATCH) rc = ntx_set_error(NTX_E_INVALID, "trainer: too many weight gradients for one launch");
+        long long rfirst = 0;
+        for (size_t i = 0; i < rjobs.size() && rc == NTX_OK; ++i) {
+            ReduceJob &r = t->reduce.job[t->reduce.n++];
+            r.partial = t->dw_partial + rjobs[i].part; r.n_split = 0; r.stride = (long long)t->per_split; r.count = rjobs[i].count; r.pair = rjobs[i].pair;
+            r.out = t->grad + rjobs[i].out; r.first = rfirst;
+            rfirst += (rjobs[i].count + 255) / 256 * 256;
+        }
+    }
+    if (rc != NTX_OK) { free_all(t); return rc; }
     *out = t;
     return NTX_OK;
 }
@@ -1152,10 +781,14 @@ int ntx_trainer_destroy(ntx_trainer *t) { free_all(t); return NTX_OK; }
 
 size_t ntx_trainer_weight_count(const ntx_trainer *t) { return t ? t->n_weights : 0; }
 
+static float *trainer_vector(ntx_trainer *t, int what) {
+    return what == NTX_TRAINER_WEIGHTS ? t->w : what == NTX_TRAINER_GRADIENTS ? t->grad : what == NTX_TRAINER_ADAM_M ? t->adam_m : what == NTX_TRAINER_ADAM_V ? t->adam_v : nullptr;
+}
+
 int ntx_trainer_get(ntx_trainer *t, int what, float *out_host, size_t n_floats) {
     if (!t || !out_host) return ntx_set_error(NTX_E_INVALID, "NULL argument");
     if (n_floats != t->n_weights) return ntx_set_error(NTX_E_INVALID, "%zu floats asked, the model has %zu", n_floats, t->n_weights);
-    const float *src = what == NTX_TRAINER_WEIGHTS ? t->w : what == NTX_TRAINER_GRADIENTS ? t->grad : what == NTX_TRAINER_ADAM_M ? t->adam_m : what == NTX_TRAINER_ADAM_V ? t->adam_v : nullptr;
+    const float *src = trainer_vector(t, what);
     if (!src) return ntx_set_error(NTX_E_INVALID, "what = %d", what);
     TRAIN_TRY(hipSetDevice(t->device));
     TRAIN_TRY(hipDeviceSynchronize());
@@ -1166,37 +799,57 @@ int ntx_trainer_get(ntx_trainer *t, int what, float *out_host, size_t n_floats) 
 int ntx_trainer_activation(ntx_trainer *t, int layer, int64_t n_samples_total, float *out_host) {
     if (!t || !out_host) return ntx_set_error(NTX_E_INVALID, "NULL argument");
     if (n_samples_total < 1 || n_samples_total > t->cap) return ntx_set_error(NTX_E_INVALID, "n_samples_total out of range");
-    const float *src = nullptr; int ld = 256, width = 256;
-    if (layer >= 0 && layer < 8) { src = t->h[layer]; ld = layer == 4 ? t->ldp : 256; }
-    else if (layer == 8) src = t->c1o;
-    else if (layer == 9) { src = t->c2o; ld = 128; width = 128; }
-    else if (layer == 10) { src = t->sigma; ld = 1; width = 1; }
-    else if (layer >= 20 && layer < 28) src = t->dyt[layer - 20];
-    else if (layer == 28) src = t->g1;
-    else if (layer == 29) { src = t->gf; ld = LDGF; }
+    const float *src = nullptr; int tiles = 8;
+    auto act = [&](int i) { return t->act + (size_t)i * t->act_stride; };
+    auto gout = [&](int i) { return t->gout + (size_t)i * t->gout_stride; };
+    if (layer >= 0 && layer < 8) src = act(layer);
+    else if (layer == 8) src = act(9);
+    else if (layer == 9) { src = act(10); tiles = 4; }
+    else if (layer == 10) src = t->sigma;
+    else if (layer >= 20 && layer < 28) src = gout(10 - (layer - 20));
+    else if (layer == 28) src = gout(1);
+    else if (layer == 29) src = gout(2);
     else return ntx_set_error(NTX_E_INVALID, "layer %d (0-7 trunk, 8 / 9 the colour layers, 10 the density; 20-29 the kept gradients)", layer);
     TRAIN_TRY(hipSetDevice(t->device));
     TRAIN_TRY(hipDeviceSynchronize());
-    TRAIN_TRY(hipMemcpy2D(out_host, (size_t)width * sizeof(float), src, (size_t)ld * sizeof(float), (size_t)width * sizeof(float), (size_t)n_samples_total, hipMemcpyDeviceToHost));
+    if (layer == 10) { TRAIN_TRY(hipMemcpy(out_host, src, (size_t)n_samples_total * sizeof(float), hipMemcpyDeviceToHost)); return NTX_OK; }
+    // O layout -> [sample][feature]
+    const long long nb = (n_samples_total + 31) / 32;
+    std::vector<float> tmp((size_t)nb * tiles * 1024);
+    TRAIN_TRY(hipMemcpy(tmp.data(), src, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const int width = tiles * 32;
+    for (long long m = 0; m < n_samples_total; ++m) {
+        const long long blk = m >> 5; const int p = (int)(m & 31);
+        const float *rec = tmp.data() + ((size_t)blk * tiles * 4 + (p >> 3)) * 256 + 32 * ((p >> 2) & 1) * 4 + (p & 3);
+        float *o = out_host + (size_t)m * width;
+        for (int T = 0; T < tiles; ++T)
+            for (int i = 0; i < 32; ++i) o[32 * T + i] = rec[(size_t)T * 1024 + i * 4];
+    }
     return NTX_OK;
 }
 
-int ntx_trainer_set_weights(ntx_trainer *t, const float *weights_host, size_t n_floats) {
-    if (!t || !weights_host) return ntx_set_error(NTX_E_INVALID, "NULL argument");
-    if (n_floats != t->n_weights) return ntx_set_error(NTX_E_INVALID, "%zu floats given, the model has %zu", n_floats, t->n_weights);
-    TRAIN_TRY(hipSetDevice(t->device));
-    TRAIN_TRY(hipMemcpy(t->w, weights_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
-    return NTX_OK;
-}
+int ntx_trainer_set_weights(ntx_trainer *t, const float *weights_host, size_t n_floats) { return ntx_trainer_set(t, NTX_TRAINER_WEIGHTS, weights_host, n_floats); }
 
 int ntx_trainer_set(ntx_trainer *t, int what, const float *values_host, size_t n_floats) {
     if (!t || !values_host) return ntx_set_error(NTX_E_INVALID, "NULL argument");
     if (n_floats != t->n_weights) return ntx_set_error(NTX_E_INVALID, "%zu floats given, the model has %zu", n_floats, t->n_weights);
-    float *dst = what == NTX_TRAINER_WEIGHTS ? t->w : what == NTX_TRAINER_GRADIENTS ? t->grad : what == NTX_TRAINER_ADAM_M ? t->adam_m : what == NTX_TRAINER_ADAM_V ? t->adam_v : nullptr;
+    float *dst = trainer_vector(t, what);
     if (!dst) return ntx_set_error(NTX_E_INVALID, "what = %d", what);
     TRAIN_TRY(hipSetDevice(t->device));
     TRAIN_TRY(hipDeviceSynchronize());
     TRAIN_TRY(hipMemcpy(dst, values_host, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    return NTX_OK;
+}
+
+int ntx_trainer_set_iterations(ntx_trainer *t, int64_t iterations) {
+    if (!t || iterations < 0) return ntx_set_error(NTX_E_INVALID, "trainer is NULL or iterations < 0");
+    t->adam_iterations = iterations;
+    return NTX_OK;
+}
+
+int ntx_trainer_device_weights(ntx_trainer *t, const float **weights_dev) {
+    if (!t || !weights_dev) return ntx_set_error(NTX_E_INVALID, "NULL argument");
+    *weights_dev = t->w;
     return NTX_OK;
 }
 
@@ -1222,9 +875,11 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     TRAIN_TRY(hipSetDevice(t->device));
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)n_rays * n_samples;
-    const int S = n_samples, Kp = t->Kp, Kd = t->Kd, ldp = t->ldp, ldd = t->ldd;
-    const float *W = t->w;
-    hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((t->pack.total + 255) / 256)), dim3(256), 0, st, t->pack);
+    const int S = n_samples, n_blocks = (int)((M + 31) / 32);
+    {
+        PackArgs pa{t->pack_seg, t->n_pack, t->pack_total};
+        hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((t->pack_total + 255) / 256)), dim3(256), 0, st, pa);
+    }
     // ---- forward, every activation kept ----------------------------------------------------------------------------------------
     const float *z = z_vals;
     if (!z) {
@@ -1239,117 +894,48 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
         noise = t->noise;
     }
     {
-        EncodeArgs e{}; e.rays_o = rays_o; e.rays_d = rays_d; e.z = z; e.params = params; e.cone = cone_scale; e.rays_per_param_row = rays_per_param_row;
+        EncodeArgs e{}; e.rays_o = rays_o; e.rays_d = rays_d; e.z = z; e.params = params; e.cone = cone_scale; e.rays_per_param_row = rays_per_param_row; e.M = M;
         e.n_rays = (int)n_rays; e.S = S; e.n_geo = t->desc.n_geo; e.n_app = t->desc.n_app; e.pos_freq = t->desc.pos_freq; e.dir_freq = t->desc.dir_freq;
-        e.param_freq = t->desc.param_freq; e.blur_idx = blur_idx; e.pos_out = t->h4c; e.ld_pos = ldp; e.dir_out = t->fc; e.ld_dir = ldd; e.dists = t->dists;
-        hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((M + ENC_SAMPLES - 1) / ENC_SAMPLES)), dim3(256), (size_t)ENC_SAMPLES * (ENC_BASE + Kp + Kd) * sizeof(float), st, e);
+        e.param_freq = t->desc.param_freq; e.blur_idx = blur_idx; e.posR = t->posR; e.posO = t->posO; e.ptiles = t->ptiles; e.dirR = t->dirR; e.dirO = t->dirO;
+        e.dtiles = t->dtiles; e.dists = t->dists;
+        hipLaunchKernelGGL(encode_kernel, dim3((unsigned)n_blocks, 2), dim3(64), 0, st, e);
     }
-    {   // the trunk, the feature layer and the first colour layer as ONE chain (model.py:104-119)
-        RowsArgs fa{}; fa.M = M;
-        for (int i = 0; i < 8; ++i) {
-            const TLayer &l = t->trunk[i];
-            const float *X = (i == 0 || i == 5) ? t->h4c : t->h[i - 1];
-            const int ldx = (i == 0 || i == 5) ? ldp : (i - 1 == 4 ? ldp : 256);
-            fa.layer[fa.n_layers++] = forward_layer(X, ldx, t->fwd_recs[i], t->fwd_kblocks[i], W + l.b, t->h[i], i == 4 ? ldp : 256, 1, t->bits[i]);
-        }
-        fa.layer[fa.n_layers++] = forward_layer(t->h[7], 256, t->fwd_recs[8], t->fwd_kblocks[8], W + t->feature.b, t->fc + t->Kd4, ldd, 0, nullptr);    // :114-115
-        fa.layer[fa.n_layers++] = forward_layer(t->fc, ldd, t->fwd_recs[9], t->fwd_kblocks[9], W + t->c1.b, t->c1o, 256, 1, t->bits[8]);               // :118-119
-        launch_rows(st, fa, 256, true);
-    }
-    hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, t->h[7], 256, 256, W + t->alpha.w, W + t->alpha.b, 1, M, t->sigma);   // :111
+    const unsigned chain_grid = (unsigned)std::min<long long>(t->cus, (n_blocks + 3) / 4);      // persistent: a workgroup of four waves per CU
     {
-        RowsArgs ca{}; ca.M = M; ca.n_layers = 1;
-        ca.layer[0] = forward_layer(t->c1o, 256, t->fwd_recs[10], t->fwd_kblocks[10], W + t->c2.b, t->c2o, 128, 1, nullptr);                         // :122
-        launch_rows(st, ca, 128, true);
+        FwdArgs f{}; f.stream = t->wfwd; f.stream_bytes = (uint32_t)(t->fwd_floats * sizeof(float)); f.aux = t->aux; f.M = M;
+        f.ptiles = t->ptiles; f.dtiles = t->dtiles; f.posR = t->posR; f.dirR = t->dirR;
+        f.act = t->act; f.act_stride = t->act_stride; f.bits = t->bits; f.bits_stride = t->bits_stride;
+        f.sigma = t->sigma; f.raw_rgb = t->raw_rgb;
+        launch_fwd_chain(t->fwd_variant, st, chain_grid, f);
     }
-    hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)((M + 31) / 32)), dim3(256), 0, st, t->c2o, 128, 128, W + t->rgb.w, W + t->rgb.b, 3, M, t->raw_rgb);   // :123
-    CompositeArgs c{};
-    c.raw_rgb = t->raw_rgb; c.sigma = t->sigma; c.dists = t->dists; c.noise = noise; c.n_rays = (int)n_rays; c.S = S; c.map_exr = (flags & NTX_FLAG_MAP_EXR) ? 1 : 0;
-    c.composite_bkgd = (flags & NTX_FLAG_COMPOSITE_BKGD) ? 1 : 0;
-    for (int k = 0; k < 3; ++k) c.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
-    c.color = t->color; c.alpha = t->alpha_out; c.d_color = t->d_color; c.d_alpha = t->d_alpha; c.d_raw_rgb = t->d_raw; c.d_sigma = t->d_sigma;
-    hipLaunchKernelGGL(composite_kernel<false>, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st, c);
-    // ---- loss (loss.py) -----------------------------------------------------------------------------------------------------------
+    // ---- the composite, the loss (loss.py) and their adjoint ------------------------------------------------------------------------
     {
-        LossArgs a{}; a.color_true = color_true; a.alpha_true = alpha_true; a.color_pred = t->color; a.alpha_pred = t->alpha_out; a.n_rays = (int)n_rays;
-        a.kind = loss->kind; a.loss_fn = loss->loss_fn; a.alpha_loss_fn = loss->alpha_loss_fn; a.filter_color_loss = loss->filter_color_loss; a.use_hard_mask = loss->use_hard_mask;
-        a.gamma = loss->gamma; a.loss = t->loss; a.d_color = t->d_color; a.d_alpha = t->d_alpha;
-        hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, st, a);
+        CompositeArgs c{};
+        c.raw_rgb = t->raw_rgb; c.sigma = t->sigma; c.dists = t->dists; c.noise = noise; c.n_rays = (int)n_rays; c.S = S; c.map_exr = (flags & NTX_FLAG_MAP_EXR) ? 1 : 0;
+        c.composite_bkgd = (flags & NTX_FLAG_COMPOSITE_BKGD) ? 1 : 0;
+        for (int k = 0; k < 3; ++k) c.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
+        c.color_true = color_true; c.alpha_true = alpha_true; c.kind = loss->kind; c.loss_fn = loss->loss_fn; c.alpha_loss_fn = loss->alpha_loss_fn;
+        c.filter_color_loss = loss->filter_color_loss; c.use_hard_mask = loss->use_hard_mask; c.gamma = loss->gamma;
+        c.color = color_pred ? color_pred : t->color; c.alpha = alpha_pred ? alpha_pred : t->alpha_out; c.ray_loss = t->ray_loss; c.dgrad = t->dgrad; c.dhead = t->dhead; c.M = M;
+        hipLaunchKernelGGL(composite_loss_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st, c);
+        hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, st, t->ray_loss, (int)n_rays, loss_out ? loss_out : t->loss);
     }
     // ---- backward -----------------------------------------------------------------------------------------------------------------
-    hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st, c);
-    float *G = t->grad;
-    // The gradient runs down the network first (every layer's dY kept), then ALL weight gradients are taken in one launch: dW = X^T . dY and
-    // db = the column sums of dY (riding along in the same kernel), both through partial sums added up in a fixed order by one more launch;
-    // kernel [K][N] and bias [N] are neighbours in the blob
-    GemmBatch gb{}; ReduceBatch rb{};
-    size_t partial_used = 0; long long reduce_first = 0; int wg_first = 0;
-    const int tk = 16;
-    const int k_chunk = (((int)M + SPLIT - 1) / SPLIT + tk - 1) / tk * tk, parts = ((int)M + k_chunk - 1) / k_chunk;
-    auto dw = [&](const float *X, int ldx, int K, const float *dY, int lddy, int N, float *dW, float *db) -> int {
-        if (gb.n >= MAX_GEMM_BATCH || rb.n + 2 > MAX_REDUCE_BATCH) return ntx_set_error(NTX_E_INVALID, "trainer: too many weight gradients for one launch");
-        const size_t need = (size_t)parts * K * N + (db ? (size_t)parts * N : 0);
-        if (partial_used + need > t->dw_partial_floats) return ntx_set_error(NTX_E_INVALID, "trainer: partial buffer too small");
-        float *pw = t->dw_partial + partial_used, *pb = pw + (size_t)parts * K * N;
-        partial_used += need;
-        GemmArgs &g = gb.g[gb.n];
-        g = GemmArgs{}; g.A = X; g.lda = ldx; g.B = dY; g.ldb = lddy; g.C = pw; g.ldc = N; g.M = K; g.N = N; g.K = (int)M; g.split_stride = (long long)K * N;
-        g.colsum = db ? pb : nullptr; g.k_chunk = k_chunk;
-        g.aligned = (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (((uintptr_t)g.A | (uintptr_t)g.B) % 16 == 0);
-        gb.nx[gb.n] = (N + 127) / 128; gb.ny[gb.n] = (K + TM - 1) / TM; gb.nz[gb.n] = parts; gb.first[gb.n] = wg_first;
-        wg_first += (gb.nx[gb.n] * gb.ny[gb.n] * parts + 7) / 8 * 8;
-        gb.n += 1; gb.first[gb.n] = wg_first;
-        auto red = [&](const float *partial, long long count, float *out) {
-            ReduceJob &r = rb.job[rb.n++];
-            r.partial = partial; r.n_split = parts; r.stride = count; r.count = count; r.out = out; r.first = reduce_first;
-            reduce_first += (count + 255) / 256 * 256;
-        };
-        red(pw, (long long)K * N, dW);
-        if (db) red(pb, N, db);
-        return NTX_OK;
-    };
-    // a layer that reads a concat buffer [first | pad | 256 more]: two contractions when there is a pad, the bias gradient rides with the first
-    auto concat_dw = [&](const float *X, int ldx, int K1, int K1p, const float *dY, const TLayer &l) -> int {
-        if (K1 == K1p) return dw(X, ldx, K1 + 256, dY, 256, 256, G + l.w, G + l.b);
-        const int rc1 = dw(X, ldx, K1, dY, 256, 256, G + l.w, G + l.b);
-        if (rc1 != NTX_OK) return rc1;
-        return dw(X + K1p, ldx, 256, dY, 256, 256, G + l.w + (size_t)K1 * 256, nullptr);
-    };
-    const int hb = (int)((M + HEAD_ROWS - 1) / HEAD_ROWS);
-    auto head_dw = [&](const float *X, int ldx, int K, const float *dY, int n_out, const TLayer &l) {       // (kernel | bias) of a narrow head
-        hipLaunchKernelGGL(head_backward_dw_partial_kernel, dim3(hb), dim3(256), 0, st, X, ldx, K, dY, n_out, M, HEAD_ROWS, t->partial);
-        const long long count = (long long)(K + 1) * n_out;
-        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, st, t->partial, hb, count, count, G + l.w);
-    };
-    // color head (128 -> 3): dW, db; d c2o = (d_raw . W^T) where c2o > 0
-    head_dw(t->c2o, 128, 128, t->d_raw, 3, t->rgb);
-    hipLaunchKernelGGL(head_backward_dx_kernel, dim3((unsigned)((M * 32 + 255) / 256)), dim3(256), 0, st, t->d_raw, 3, W + t->rgb.w, 128, M, t->c2o, 128, 0, t->g0, 128);
-    head_dw(t->h[7], 256, 256, t->d_sigma, 1, t->alpha);
-    // d h7 = (d feature . W_feature^T + d_sigma (x) W_alpha) where h7 > 0, as ONE contraction over 257: d_sigma goes beside d feature
-    hipLaunchKernelGGL(column_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, t->d_sigma, M, t->gf + 256, LDGF);
-    {   // the way back, one chain: d c1o (masked by its ReLU), d feature (a linear layer: all kept), d h7, ... d h0
-        RowsArgs ba{}; ba.M = M;
-        ba.layer[ba.n_layers++] = dx_layer(t->g0, 128, t->bwd_recs[9], t->bwd_kblocks[9], t->bits[8], t->g1, 256);
-        ba.layer[ba.n_layers++] = dx_layer(t->g1, 256, t->bwd_recs[8], t->bwd_kblocks[8], t->bits_ones, t->gf, LDGF);
-        ba.layer[ba.n_layers++] = dx_layer(t->gf, LDGF, t->bwd_recs[7], t->bwd_kblocks[7], t->bits[7], t->dyt[7], 256);
-        for (int i = 7; i >= 1; --i) ba.layer[ba.n_layers++] = dx_layer(t->dyt[i], 256, t->bwd_recs[i - 1], t->bwd_kblocks[i - 1], t->bits[i - 1], t->dyt[i - 1], 256);
-        launch_rows(st, ba, 256, false);
+    {
+        DxArgs d{}; d.stream = t->wdx; d.stream_bytes = (uint32_t)(t->dx_floats * sizeof(float)); d.M = M; d.dgrad = t->dgrad;
+        d.out = t->gout; d.out_stride = t->gout_stride; d.bits = t->bits; d.bits_stride = t->bits_stride;
+        launch_dx_chain(st, chain_grid, d);
     }
-    int rc = dw(t->c1o, 256, 256, t->g0, 128, 128, G + t->c2.w, G + t->c2.b);
-    if (rc == NTX_OK) rc = concat_dw(t->fc, ldd, Kd, t->Kd4, t->g1, t->c1);
-    if (rc == NTX_OK) rc = dw(t->h[7], 256, 256, t->gf, LDGF, 256, G + t->feature.w, G + t->feature.b);
-    for (int i = 7; i >= 0 && rc == NTX_OK; --i) {
-        const TLayer &l = t->trunk[i];
-        const float *X = (i == 0 || i == 5) ? t->h4c : t->h[i - 1];
-        const int ldx = (i == 0 || i == 5) ? ldp : 256;
-        rc = i == 5 ? concat_dw(X, ldx, Kp, t->Kp4, t->dyt[i], l) : dw(X, ldx, l.in, t->dyt[i], 256, 256, G + l.w, G + l.b);
+    {   // every layer's dW = X^T . dY and db = the column sums of dY in one launch, as partial sums over ranges of sample blocks ...
+        DwArgs d{}; d.tasks = t->tasks; d.n_tasks = t->n_tasks; d.wg_tasks = t->wg_tasks; d.n_blocks = n_blocks;
+        d.bpr = (n_blocks + SPLIT - 1) / SPLIT; d.parts = (n_blocks + d.bpr - 1) / d.bpr;
+        launch_dw(st, (unsigned)(d.wg_tasks * ((d.parts + 7) / 8 * 8)), d);
+        // ... added up in a fixed order
+        ReduceBatch rb = t->reduce;
+        for (int i = 0; i < rb.n; ++i) rb.job[i].n_split = d.parts;
+        const long long total = rb.job[rb.n - 1].first + (rb.job[rb.n - 1].count + 255) / 256 * 256;
+        hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(total / 256)), dim3(256), 0, st, rb);
     }
-    if (rc != NTX_OK) return rc;
-    hipLaunchKernelGGL((gemm_batch_kernel<false, 128, 16>), dim3((unsigned)wg_first), dim3(256), 0, st, gb);
-    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(reduce_first / 256)), dim3(256), 0, st, rb);
-    if (color_pred) TRAIN_TRY(hipMemcpyAsync(color_pred, t->color, (size_t)n_rays * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (alpha_pred) TRAIN_TRY(hipMemcpyAsync(alpha_pred, t->alpha_out, (size_t)n_rays * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (loss_out) TRAIN_TRY(hipMemcpyAsync(loss_out, t->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
     TRAIN_TRY(hipGetLastError());
     return NTX_OK;
 }
@@ -1371,14 +957,14 @@ int ntx_trainer_adam_step(ntx_trainer *t, float lrate, float lrate_decay_steps, 
 
 int64_t ntx_trainer_iterations(const ntx_trainer *t) { return t ? t->adam_iterations : -1; }
 
-/* The contraction the trainer is made of, on caller buffers (DEVICE): C[M][N] = op(A) . op(B) (+ bias) (ReLU), op = identity or transpose as
+/* The contraction on caller buffers (DEVICE): C[M][N] = op(A) . op(B) (+ bias) (ReLU), op = identity or transpose as
  * a_kcontig / b_kcontig say (see gemm_kernel).  For tests and benches of the kernel itself. */
 int ntx_gemm_f32(const float *A, int lda, int a_kcontig, const float *B, int ldb, int b_kcontig, float *C, int ldc, int M, int N, int K, const float *bias, int relu,
                  ntx_stream stream) {
     if (!A || !B || !C || M < 1 || N < 1 || K < 1) return ntx_set_error(NTX_E_INVALID, "bad GEMM arguments");
     ntx_train::GemmArgs g{}; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu;
     hipStream_t st = (hipStream_t)stream;
-    if (b_kcontig) return ntx_set_error(NTX_E_UNSUPPORTED, "B must be [K][N] (the trainer transposes its weights once a step instead)");
+    if (b_kcontig) return ntx_set_error(NTX_E_UNSUPPORTED, "B must be [K][N]");
     if (a_kcontig) launch_gemm<true>(st, g); else launch_gemm<false>(st, g);
     TRAIN_TRY(hipGetLastError());
     return NTX_OK;

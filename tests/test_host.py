@@ -21,7 +21,7 @@ def test_abi_exports_every_declared_symbol():
     raw = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_create_without_gpu_reports_no_device():
@@ -756,7 +756,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                     "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     # 803 rows of 800 over 8 ranks: ranks 0-2 hold 101 rows, the others 100 -> exact-count Send/Recv into staging, blocks at r * 80800
-    assert out == ["5", "683524", "80000", "80800", str(7 * 80800), "0", "0", "40"]
+    assert out == ["6", "683524", "80000", "80800", str(7 * 80800), "0", "0", "40"]
 
 
 def test_instancer_host_side(tmp_path):
