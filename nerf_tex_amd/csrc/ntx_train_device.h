@@ -46,6 +46,8 @@ TRN_DEV uint32_t o_lane_bytes(int lane) {
     const int n = lane & 31, h = lane >> 5;
     return (uint32_t)((n >> 3) * 1024 + ((n >> 2) & 1) * 512 + h * 64 + (n & 3) * 4);
 }
+// cache policy of the activations' stores
+constexpr int STORE_NT = 0;   // (measured: with the nt bit L2 stops combining the 16-byte pieces of a line -- twice the HBM writes, chains 20 % slower)
 constexpr uint32_t o_value_bytes(int V) { return (uint32_t)((V >> 4) * 4096 + ((V & 15) >> 2) * 128 + (V & 3) * 16); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         auto leaves_to = [&](int idx, int tiles) { rs_out = make_rsrc(a.act + (size_t)idx * a.act_stride + (size_t)blk * tiles * 1024, (long long)tiles * 4096); };
         auto leave = [&](auto V) {
             constexpr int v = V;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hin[v]), rs_out, lane_o, o_value_bytes(v), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hin[v]), rs_out, lane_o, o_value_bytes(v), STORE_NT);
         };
         auto bits_leave = [&](int idx, const u32x4 &bw) {
             const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bits + (size_t)idx * a.bits_stride + (size_t)blk * 256, 1024);
@@ -286,7 +288,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     sig_part = __builtin_fmaf(hin[4 * i + 2], w.z, sig_part); sig_part = __builtin_fmaf(hin[4 * i + 3], w.w, sig_part);
                 });
             }
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (LI < 10) static_for<(LI == 9 ? 4 : 8)>([&](auto T) { bias_tile<decltype(T)::value>(prev, aux, LI + 1, h); });
+            __builtin_amdgcn_sched_barrier(0);
             leaves_to(in_idx, 8);
             if constexpr (LI == 5) seg_mem<PSG>(cur, ws, sbase, pb, fetch);        // concat[pos_map, h4] (model.py:107-108)
             if constexpr (LI == 9) seg_mem<DSG>(cur, ws, sbase, pb, fetch);        // concat[dir_map, feature] (model.py:115)
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         auto leaves_to = [&](int idx, int tiles) { rs_out = make_rsrc(a.out + (size_t)idx * a.out_stride + (size_t)blk * tiles * 1024, (long long)tiles * 4096); };
         auto leave = [&](auto V) {
             constexpr int v = V;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hin[v]), rs_out, lane_o, o_value_bytes(v), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hin[v]), rs_out, lane_o, o_value_bytes(v), STORE_NT);
         };
         auto fetch_bits = [&](int idx) {
             const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bits + (size_t)idx * a.bits_stride + (size_t)blk * 256, 1024);
@@ -441,7 +445,17 @@ struct DwArgs { const DwTask *tasks; int n_tasks, wg_tasks; int n_blocks, bpr, p
 
 #ifdef NTX_TRAIN_DW
 template <int NA, int NB>
-TRN_DEV void dw_body(const DwTask &t, int z, int blk0, int blk1, int lane) {
+TRN_DEV void dw_body(const DwTask &tg, int z, int blk0, int blk1, int lane) {
+    // the task's description in scalar registers once (left in memory, the loop re-reads fields and waits for them)
+    DwTask t;
+    auto uniform_ptr = [](const float *p) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)p >> 32));
+        return (const float *)(uintptr_t)(((uint64_t)hi << 32) | (uint64_t)lo);
+    };
+    t.A = uniform_ptr(tg.A); t.B = uniform_ptr(tg.B);
+    t.rtA = __builtin_amdgcn_readfirstlane(tg.rtA); t.a0 = __builtin_amdgcn_readfirstlane(tg.a0); t.rtB = __builtin_amdgcn_readfirstlane(tg.rtB); t.b0 = __builtin_amdgcn_readfirstlane(tg.b0);
+    t.out = tg.out; t.split_stride = tg.split_stride; t.ldc = tg.ldc; t.row0 = tg.row0; t.rows_valid = tg.rows_valid; t.col0 = tg.col0; t.c_lo = tg.c_lo; t.c_hi = tg.c_hi;
+    t.bias_out = tg.bias_out; t.bias_split_stride = tg.bias_split_stride; t.kind = 0;
     f32x16 acc[NA][NB];
     static_for<NA>([&](auto A) { static_for<NB>([&](auto B) {
         acc[A][B] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }); });
@@ -449,13 +463,13 @@ TRN_DEV void dw_body(const DwTask &t, int z, int blk0, int blk1, int lane) {
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(t.A + (size_t)blk0 * t.rtA * 1024, (long long)nblk * t.rtA * 4096);
     const __amdgpu_buffer_rsrc_t rb = make_rsrc(t.B + (size_t)blk0 * t.rtB * 1024, (long long)nblk * t.rtB * 4096);
     const uint32_t voff = (uint32_t)lane * 16u;
-    const uint32_t stepA = (uint32_t)t.rtA * 4096u, stepB = (uint32_t)t.rtB * 4096u;
+    const uint32_t stepA = (uint32_t)t.rtA * 4096u, stepB = (uint32_t)t.rtB * 4096u, offA = (uint32_t)t.a0 * 4096u, offB = (uint32_t)t.b0 * 4096u;
     f32x4 xa[2][NA][4], xb[2][NB][4];
     f32x4 bsum[NB];
     static_for<NB>([&](auto B) { bsum[B] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; });
     auto fetch = [&](auto BUF, int i) {                  // block blk0 + i of the range
         constexpr int buf = BUF;
-        const uint32_t oa = (uint32_t)i * stepA + (uint32_t)t.a0 * 4096u, ob = (uint32_t)i * stepB + (uint32_t)t.b0 * 4096u;
+        const uint32_t oa = (uint32_t)i * stepA + offA, ob = (uint32_t)i * stepB + offB;
         static_for<NA>([&](auto A) { static_for<4>([&](auto Q) {
             xa[buf][A][Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voff, oa + (uint32_t)(decltype(A)::value * 4 + decltype(Q)::value) * 1024u, 0)); }); });
         static_for<NB>([&](auto B) { static_for<4>([&](auto Q) {
@@ -472,18 +486,18 @@ TRN_DEV void dw_body(const DwTask &t, int z, int blk0, int blk1, int lane) {
         }); });
         if (want_bias) static_for<NB>([&](auto B) { bsum[B] += (xb[buf][B][0] + xb[buf][B][1]) + (xb[buf][B][2] + xb[buf][B][3]); });
     };
+    // The fetches are UNCONDITIONAL (behind the range's end the last block is asked for again and not used): with a branch around a fetch the
+    // compiler cannot count how many loads are younger than the ones it waits for, and waits for all of them -- the block just asked for too.
     fetch(std::integral_constant<int, 0>{}, 0);
     for (int i = 0; i < nblk; i += 2) {
-        if (i + 1 < nblk) fetch(std::integral_constant<int, 1>{}, i + 1);
+        fetch(std::integral_constant<int, 1>{}, i + 1 < nblk ? i + 1 : nblk - 1);
         __builtin_amdgcn_sched_barrier(0);
         compute(std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < nblk) {
-            if (i + 2 < nblk) fetch(std::integral_constant<int, 0>{}, i + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(std::integral_constant<int, 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        fetch(std::integral_constant<int, 0>{}, i + 2 < nblk ? i + 2 : nblk - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < nblk) compute(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
     }
     // D of a tile: lane l, register r <-> row 8 (r >> 2) + (r & 3) + 4 (l >> 5), column l & 31
     const int j = lane & 31, hh = lane >> 5;
