@@ -549,8 +549,9 @@ struct ntx_trainer {
     float *sigma = nullptr, *raw_rgb = nullptr, *z = nullptr, *dists = nullptr, *noise = nullptr;
     // backward: the composite's adjoint, the gradient at every layer's output (O layout: d c2o, d c1o, d feature, dy7 .. dy0)
     float *dgrad = nullptr, *dhead = nullptr, *gout = nullptr; long long gout_stride = 0;
-    ntx_train::DwTask *tasks = nullptr; int n_tasks = 0, wg_tasks = 0;
-    size_t per_split = 0; float *dw_partial = nullptr;
+    ntx_train::DwJob *jobs = nullptr; int n_jobs = 0; long long total_cost = 0;      // the weight gradients' jobs (ntx_train_device.h), their costs per block added up
+    std::vector<ntx_train::DwJob> jobs_host; std::vector<int> reduce_job;      // reduce_job[i]: the job whose slots reduction i adds up
+    float *dw_partial = nullptr;
     ntx_train::ReduceBatch reduce{};           // (n_split per step)
     float *color = nullptr, *alpha_out = nullptr, *ray_loss = nullptr, *loss = nullptr;
     long long adam_iterations = 0;
@@ -560,13 +561,12 @@ namespace {
 
 using namespace ntx_train;
 
-constexpr int SPLIT = 128;        // ranges of sample blocks whose weight-gradient sums are kept apart (at most)
 
 void free_all(ntx_trainer *t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
     void *ptrs[] = {t->w, t->grad, t->adam_m, t->adam_v, t->wfwd, t->wdx, t->aux, t->pack_seg, t->posR, t->posO, t->dirR, t->dirO, t->sigma, t->raw_rgb, t->z, t->dists, t->noise,
-                    t->dgrad, t->dhead, t->tasks, t->dw_partial, t->color, t->alpha_out, t->ray_loss, t->loss, t->act, t->bits, t->gout};
+                    t->dgrad, t->dhead, t->jobs, t->dw_partial, t->color, t->alpha_out, t->ray_loss, t->loss, t->act, t->bits, t->gout};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete t;
 }
@@ -715,61 +715,78 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
             hipMemcpy(t->pack_seg, segs.data(), segs.size() * sizeof(PackSeg), hipMemcpyHostToDevice) != hipSuccess)
             rc = ntx_set_error(NTX_E_HIP, "segment table upload failed");
     }
-    // ---- the weight gradients' tasks: dW_l = X_l^T . dY_l, X_l = the O-layout input of layer l, dY_l = the gradient at its output
-    std::vector<DwTask> tasks;
-    size_t part_off = 0;
-    struct RJ { size_t part; long long count, pair; size_t out; };
+    // ---- the weight gradients' jobs: dW_l = X_l^T . dY_l, X_l = the O-layout input of layer l, dY_l = the gradient at its output.  A job =
+    // four waves side by side on the same blocks of samples (ntx_train_device.h); a slot of its partial sums holds the matrices its waves write
+    std::vector<DwJob> &jobs = t->jobs_host;
+    struct RJ { int job; long long at, count, pair; size_t out; };
     std::vector<RJ> rjobs;
-    auto job = [&](const float *A, int rtA, int K, const float *B, int rtB, int c_lo, int N, size_t g_kernel, long long g_bias) {
-        const size_t pw = part_off; part_off += (size_t)K * N;
-        size_t pb = 0;
-        if (g_bias >= 0) { pb = part_off; part_off += (size_t)2 * N; }
-        rjobs.push_back(RJ{pw, (long long)K * N, 0, g_kernel});
-        if (g_bias >= 0) rjobs.push_back(RJ{pb, N, N, (size_t)g_bias});
-        const int tb0 = c_lo / 32, ntb = (c_lo + N + 31) / 32 - tb0, nta = (K + 31) / 32;     // the dY tiles that carry the columns; the X tiles with rows
-        for (int a0 = 0; a0 < nta; a0 += 2)
-            for (int b0 = 0; b0 < ntb; b0 += 4) {
-                const int na = a0 + 1 < nta ? 2 : 1, nb = ntb - b0 >= 4 ? 4 : 1;      // (dY is 8, 4 or 1 tiles wide)
-                DwTask d{}; d.A = A; d.rtA = rtA; d.a0 = a0; d.B = B; d.rtB = rtB; d.b0 = tb0 + b0;
-                d.kind = nb == 4 ? (na == 2 ? 0 : 1) : (na == 2 ? 2 : 3);
-                d.out = (float *)(uintptr_t)(pw * sizeof(float)); d.ldc = N; d.row0 = a0 * 32; d.rows_valid = K; d.col0 = (tb0 + b0) * 32; d.c_lo = c_lo; d.c_hi = c_lo + N;
-                d.bias_out = (g_bias >= 0 && a0 == 0) ? (float *)(uintptr_t)(pb * sizeof(float)) : nullptr;
-                tasks.push_back(d);
-            }
+    auto new_job = [&]() { DwJob j{}; for (DwWave &w : j.w) w.shape = -1; jobs.push_back(j); return (int)jobs.size() - 1; };
+    // a matrix of the job's slot: the [K][N] kernel gradient, behind it (g_bias >= 0) the [2][N] halves of the bias gradient
+    auto matrix = [&](int j, int K, int N, size_t g_kernel, long long g_bias, long long *at_bias) {
+        const long long at = jobs[j].slot_floats;
+        jobs[j].slot_floats += (long long)K * N;
+        rjobs.push_back(RJ{j, at, (long long)K * N, 0, g_kernel});
+        *at_bias = -1;
+        if (g_bias >= 0) { *at_bias = jobs[j].slot_floats; jobs[j].slot_floats += 2 * N; rjobs.push_back(RJ{j, *at_bias, N, N, (size_t)g_bias}); }
+        return at;
+    };
+    auto wave = [&](int j, int w, int shape, const float *A, int rtA, int a0, const float *B, int rtB, int b0, long long at, int K, int N, int c_lo, long long at_bias) {
+        DwWave &d = jobs[j].w[w];
+        d.A = A; d.rtA = rtA; d.a0 = a0; d.B = B; d.rtB = rtB; d.b0 = b0; d.shape = shape; d.out = at; d.ldc = N; d.row0 = a0 * 32; d.rows_valid = K;
+        d.col0 = b0 * 32; d.c_lo = c_lo; d.c_hi = c_lo + N; d.bias_out = a0 == 0 ? at_bias : -1;
+        const int cost = shape == 0 ? 256 : shape == 1 ? 192 : 64;             // MFMAs per block of 32 samples: 16 k-steps x tiles
+        if (cost > jobs[j].cost) jobs[j].cost = cost;
+    };
+    // a 256 x 256 layer: wave w takes X tiles 4 (w >> 1) .., dY tiles 4 (w & 1) ..
+    auto layer_job = [&](const float *X, const float *dY, size_t g_kernel, size_t g_bias) {
+        const int j = new_job(); long long ab; const long long at = matrix(j, 256, 256, g_kernel, (long long)g_bias, &ab);
+        for (int w = 0; w < 4; ++w) wave(j, w, 0, X, 8, 4 * (w >> 1), dY, 8, 4 * (w & 1), at, 256, 256, 0, ab);
     };
     {
         const TLayer &r = t->rgb, &al = t->alpha, &c2 = t->c2, &c1 = t->c1, &f = t->feature;
-        job(act(10), 4, 128, t->dhead, 1, 0, 3, r.w, (long long)r.b);                                   // colour head: X = c2o, dY = d raw
-        job(act(7), 8, 256, t->dhead, 1, 3, 1, al.w, (long long)al.b);                                   // density head: X = h7, dY = d sigma
-        job(act(9), 8, 256, gout(0), 4, 0, 128, c2.w, (long long)c2.b);                               // C2: X = c1o
-        job(t->dirO, t->dtiles, Kd, gout(1), 8, 0, 256, c1.w, -1);                                       // C1: X = [dir_map | feature]
-        job(act(8), 8, 256, gout(1), 8, 0, 256, c1.w + (size_t)Kd * 256, (long long)c1.b);
-        job(act(7), 8, 256, gout(2), 8, 0, 256, f.w, (long long)f.b);                                 // feature layer: X = h7
-        for (int i = 7; i >= 1; --i) {
-            const TLayer &l = t->trunk[i];
-            if (i == 5) job(t->posO, t->ptiles, Kp, gout(10 - i), 8, 0, 256, l.w, -1);                   // the skip: X = [pos_map | h4]
-            job(act(i - 1), 8, 256, gout(10 - i), 8, 0, 256, l.w + (size_t)(i == 5 ? Kp : 0) * 256, (long long)l.b);
+        for (int i = 7; i >= 1; --i) layer_job(act(i - 1), gout(10 - i), t->trunk[i].w + (size_t)(i == 5 ? Kp : 0) * 256, t->trunk[i].b);    // trunk 7 .. 1 (the skip: its h4 rows)
+        layer_job(act(7), gout(2), f.w, f.b);                                       // feature layer: X = h7
+        layer_job(act(8), gout(1), c1.w + (size_t)Kd * 256, c1.b);                  // C1: the feature rows of X = [dir_map | feature]
+        {   // the position rows: trunk 0 (X = pos_map) and the skip (X = [pos_map | h4]); up to three tiles of rows x two halves of the columns
+            const int j = new_job(); long long ab0, ab5;
+            const long long at0 = matrix(j, Kp, 256, t->trunk[0].w, (long long)t->trunk[0].b, &ab0), at5 = matrix(j, Kp, 256, t->trunk[5].w, -1, &ab5);
+            for (int w = 0; w < 2; ++w) { wave(j, w, 1, t->posO, t->ptiles, 0, gout(10), 8, 4 * w, at0, Kp, 256, 0, ab0); wave(j, 2 + w, 1, t->posO, t->ptiles, 0, gout(5), 8, 4 * w, at5, Kp, 256, 0, ab5); }
         }
-        job(t->posO, t->ptiles, Kp, gout(10), 8, 0, 256, t->trunk[0].w, (long long)t->trunk[0].b);
+        {   // C1's direction rows (X = dir_map) beside C2 (X = c1o, dY 128 wide)
+            const int j = new_job(); long long abd, ab2;
+            const long long atd = matrix(j, Kd, 256, c1.w, -1, &abd), at2 = matrix(j, 256, 128, c2.w, (long long)c2.b, &ab2);
+            for (int w = 0; w < 2; ++w) { wave(j, w, 1, t->dirO, t->dtiles, 0, gout(1), 8, 4 * w, atd, Kd, 256, 0, abd); wave(j, 2 + w, 0, act(9), 8, 4 * w, gout(0), 4, 0, at2, 256, 128, 0, ab2); }
+        }
+        {   // the narrow heads: X = c2o against d raw (columns 0-2 of the heads' tile), X = h7 against d sigma (column 3)
+            const int j = new_job(); long long abr, aba;
+            const long long atr = matrix(j, 128, 3, r.w, (long long)r.b, &abr), ata = matrix(j, 256, 1, al.w, (long long)al.b, &aba);
+            wave(j, 0, 2, act(10), 4, 0, t->dhead, 1, 0, atr, 128, 3, 0, abr);
+            for (int w = 0; w < 2; ++w) wave(j, 1 + w, 2, act(7), 8, 4 * w, t->dhead, 1, 0, ata, 256, 1, 3, aba);
+        }
     }
-    std::stable_sort(tasks.begin(), tasks.end(), [](const DwTask &x, const DwTask &y) { return x.kind < y.kind; });     // a workgroup's four tasks: of one size
-    t->per_split = part_off; t->n_tasks = (int)tasks.size(); t->wg_tasks = (t->n_tasks + 3) / 4;
-    alloc(&t->dw_partial, (size_t)SPLIT * t->per_split);
+    t->n_jobs = (int)jobs.size();
+    size_t partial_floats = 0;
+    for (DwJob &j : jobs) {
+        t->total_cost += j.cost;
+    }
+    for (DwJob &j : jobs) {                                  // a job fills at most its share of the workgroups' slots (+ the two it may share with its neighbours)
+        const long long slots = ((long long)j.cost * t->cus + t->total_cost - 1) / t->total_cost + 2;
+        j.first_float = (long long)partial_floats; partial_floats += (size_t)(slots * j.slot_floats);
+    }
+    alloc(&t->dw_partial, partial_floats);
     if (rc == NTX_OK) {
-        for (DwTask &d : tasks) {
-            d.out = (float *)((char *)t->dw_partial + (uintptr_t)d.out); d.split_stride = (long long)t->per_split;
-            if (d.bias_out) { d.bias_out = (float *)((char *)t->dw_partial + (uintptr_t)d.bias_out); d.bias_split_stride = (long long)t->per_split; }
-        }
-        if (hipMalloc((void **)&t->tasks, tasks.size() * sizeof(DwTask)) != hipSuccess ||
-            hipMemcpy(t->tasks, tasks.data(), tasks.size() * sizeof(DwTask), hipMemcpyHostToDevice) != hipSuccess)
-            rc = ntx_set_error(NTX_E_HIP, "task table upload failed");
+        if (hipMalloc((void **)&t->jobs, jobs.size() * sizeof(DwJob)) != hipSuccess ||
+            hipMemcpy(t->jobs, jobs.data(), jobs.size() * sizeof(DwJob), hipMemcpyHostToDevice) != hipSuccess)
+            rc = ntx_set_error(NTX_E_HIP, "job table upload failed");
         if ((int)rjobs.size() > MAX_REDUCE_BATCH) rc = ntx_set_error(NTX_E_INVALID, "trainer: too many weight gradients for one launch");
         long long rfirst = 0;
         for (size_t i = 0; i < rjobs.size() && rc == NTX_OK; ++i) {
             ReduceJob &r = t->reduce.job[t->reduce.n++];
-            r.partial = t->dw_partial + rjobs[i].part; r.n_split = 0; r.stride = (long long)t->per_split; r.count = rjobs[i].count; r.pair = rjobs[i].pair;
+            const DwJob &j = jobs[rjobs[i].job];
+            r.partial = t->dw_partial + j.first_float + rjobs[i].at; r.n_split = 0; r.stride = j.slot_floats; r.count = rjobs[i].count; r.pair = rjobs[i].pair;
             r.out = t->grad + rjobs[i].out; r.first = rfirst;
             rfirst += (rjobs[i].count + 255) / 256 * 256;
+            t->reduce_job.push_back(rjobs[i].job);
         }
     }
     if (rc != NTX_OK) { free_all(t); return rc; }
@@ -926,13 +943,20 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
         d.out = t->gout; d.out_stride = t->gout_stride; d.bits = t->bits; d.bits_stride = t->bits_stride;
         launch_dx_chain(st, chain_grid, d);
     }
-    {   // every layer's dW = X^T . dY and db = the column sums of dY in one launch, as partial sums over ranges of sample blocks ...
-        DwArgs d{}; d.tasks = t->tasks; d.n_tasks = t->n_tasks; d.wg_tasks = t->wg_tasks; d.n_blocks = n_blocks;
-        d.bpr = (n_blocks + SPLIT - 1) / SPLIT; d.parts = (n_blocks + d.bpr - 1) / d.bpr;
-        launch_dw(st, (unsigned)(d.wg_tasks * ((d.parts + 7) / 8 * 8)), d);
-        // ... added up in a fixed order
+    {   // every layer's dW = X^T . dY and db = the column sums of dY in one launch of one workgroup per CU, each with an equal share of the work ...
+        DwArgs d{}; d.jobs = t->jobs; d.n_jobs = t->n_jobs; d.n_blocks = n_blocks; d.total_cost = t->total_cost; d.partial = t->dw_partial;
+        const long long G = t->cus, W = t->total_cost * n_blocks;
+        launch_dw(st, (unsigned)G, d);
+        // ... and the slots every job filled added up in a fixed order
         ReduceBatch rb = t->reduce;
-        for (int i = 0; i < rb.n; ++i) rb.job[i].n_split = d.parts;
+        std::vector<int> slots(t->n_jobs);
+        long long start = 0;
+        for (int j = 0; j < t->n_jobs; ++j) {
+            const long long span = (long long)t->jobs_host[j].cost * n_blocks;
+            slots[j] = (int)(dw_last_g(G, W, start, span) - dw_first_g(G, W, start) + 1);
+            start += span;
+        }
+        for (int i = 0; i < rb.n; ++i) rb.job[i].n_split = slots[t->reduce_job[i]];
         const long long total = rb.job[rb.n - 1].first + (rb.job[rb.n - 1].count + 255) / 256 * 256;
         hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(total / 256)), dim3(256), 0, st, rb);
     }

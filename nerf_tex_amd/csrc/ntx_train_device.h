@@ -431,117 +431,136 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // ---------------------------------------------------------------------------------------------------------------------------
 // weight gradients
 // ---------------------------------------------------------------------------------------------------------------------------
-// One wave's share of dW = X^T . dY of one layer over one range of sample blocks: NA x NB tiles of 32 x 32 (rows: X's features, columns:
-// dY's), both operands straight from their O-layout records, a block of 32 samples (16 k-steps) ahead.
-struct DwTask {
-    const float *A; int rtA, a0;                       // X: tiles of 32 rows per block, the task's first tile
+// dW = X^T . dY of every layer (reduction over the samples) in one launch of PERSISTENT workgroups, one per CU, each with an equal share of
+// the launch's matrix work fixed before it starts: nothing is scheduled at run time, nobody waits for a last workgroup, and a layer's sum
+// over the samples falls into about as many partial sums as the layer has CUs' worth of work (a fixed order: a step is bit-reproducible).
+//
+// A JOB is what one workgroup's four waves do side by side on the same blocks of 32 samples: the waves of a job share their operands (a
+// 256 x 256 layer: wave w takes X tiles 4 (w >> 1) .. + 3 and dY tiles 4 (w & 1) .. + 3, so each of the layer's 16 tiles is read by two
+// waves of ONE CU at the same moment and comes from HBM once).  A wave's share of a block: NA x NB tiles of 32 x 32 (rows: X's features,
+// columns: dY's), 16 k-steps; both operands are read straight from their O-layout records, half a block (8 k-steps, 128 MFMAs) ahead.
+//
+// The split: the jobs' blocks are laid end to end, job j's block costing cost_j (the MFMAs of its slowest wave); workgroup g of G takes the
+// cost interval [g W / G, (g + 1) W / G) of the total W, i.e. of job j the blocks [cut(g, j), cut(g + 1, j)) with
+// cut(g, j) = clamp(round((g W / G - start_j) / cost_j), 0, n_blocks).  Its sums go to slot g - first_g(j) of the job's partial sums; every
+// workgroup between the job's first and last writes its slot, were its range empty (zeros).
+struct DwWave {
+    const float *A; int rtA, a0;                       // X: tiles of 32 rows per block, the wave's first tile
     const float *B; int rtB, b0;                       // dY
-    int kind;                                          // 0: 2 x 4 tiles, 1: 1 x 4, 2: 2 x 1, 3: 1 x 1
-    float *out; long long split_stride; int ldc;       // partial sums: out[z * split_stride + row * ldc + (col - c_lo)]
-    int row0, rows_valid, col0, c_lo, c_hi;            // the task's first row / column, and what of the tiles exists
-    float *bias_out; long long bias_split_stride;      // NULL, or [z][2][c_hi - c_lo]: the column sums of dY over the range (two halves of the samples)
+    int shape;                                         // 0: 4 x 4 tiles, 1: 3 x 4, 2: 4 x 1; -1: the wave has nothing to do in this job
+    long long out; int ldc;                            // the matrix within a slot of the job's partial sums (floats): out + row * ldc + (col - c_lo)
+    int row0, rows_valid, col0, c_lo, c_hi;            // the wave's first row / column, and what of the tiles exists
+    long long bias_out;                                // -1, or within the slot: [2][c_hi - c_lo], the column sums of dY (two halves of the samples)
 };
-struct DwArgs { const DwTask *tasks; int n_tasks, wg_tasks; int n_blocks, bpr, parts; };
+struct DwJob { DwWave w[4]; int cost; long long slot_floats, first_float; };      // first_float: the job's slot 0 in the partial buffer
+struct DwArgs { const DwJob *jobs; int n_jobs, n_blocks; long long total_cost; float *partial; };     // total_cost: sum of the jobs' costs (per block)
+
+// the split, on both sides (the reduction has to know how many slots a job filled)
+__host__ __device__ inline long long dw_cut(long long g, long long G, long long W, long long start, long long cost, long long n_blocks) {
+    const long long x = g * W / G - start;             // cost units into the job
+    long long b = x <= 0 ? 0 : (x + cost / 2) / cost;
+    return b > n_blocks ? n_blocks : b;
+}
+__host__ __device__ inline long long dw_first_g(long long G, long long W, long long start) { return start * G / W; }                 // the workgroup whose interval holds the job's first unit
+__host__ __device__ inline long long dw_last_g(long long G, long long W, long long start, long long span) { return (start + span - 1) * G / W; }
 
 #ifdef NTX_TRAIN_DW
 template <int NA, int NB>
-TRN_DEV void dw_body(const DwTask &tg, int z, int blk0, int blk1, int lane) {
-    // the task's description in scalar registers once (left in memory, the loop re-reads fields and waits for them)
-    DwTask t;
+TRN_DEV void dw_piece(const DwWave &tg, float *slot, int blk0, int blk1, int lane) {
     auto uniform_ptr = [](const float *p) {
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)p >> 32));
         return (const float *)(uintptr_t)(((uint64_t)hi << 32) | (uint64_t)lo);
     };
-    t.A = uniform_ptr(tg.A); t.B = uniform_ptr(tg.B);
-    t.rtA = __builtin_amdgcn_readfirstlane(tg.rtA); t.a0 = __builtin_amdgcn_readfirstlane(tg.a0); t.rtB = __builtin_amdgcn_readfirstlane(tg.rtB); t.b0 = __builtin_amdgcn_readfirstlane(tg.b0);
-    t.out = tg.out; t.split_stride = tg.split_stride; t.ldc = tg.ldc; t.row0 = tg.row0; t.rows_valid = tg.rows_valid; t.col0 = tg.col0; t.c_lo = tg.c_lo; t.c_hi = tg.c_hi;
-    t.bias_out = tg.bias_out; t.bias_split_stride = tg.bias_split_stride; t.kind = 0;
+    const float *A = uniform_ptr(tg.A), *B = uniform_ptr(tg.B);
+    const int rtA = __builtin_amdgcn_readfirstlane(tg.rtA), a0 = __builtin_amdgcn_readfirstlane(tg.a0), rtB = __builtin_amdgcn_readfirstlane(tg.rtB), b0 = __builtin_amdgcn_readfirstlane(tg.b0);
     f32x16 acc[NA][NB];
-    static_for<NA>([&](auto A) { static_for<NB>([&](auto B) {
-        acc[A][B] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }); });
-    const int nblk = blk1 - blk0;
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(t.A + (size_t)blk0 * t.rtA * 1024, (long long)nblk * t.rtA * 4096);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(t.B + (size_t)blk0 * t.rtB * 1024, (long long)nblk * t.rtB * 4096);
-    const uint32_t voff = (uint32_t)lane * 16u;
-    const uint32_t stepA = (uint32_t)t.rtA * 4096u, stepB = (uint32_t)t.rtB * 4096u, offA = (uint32_t)t.a0 * 4096u, offB = (uint32_t)t.b0 * 4096u;
-    f32x4 xa[2][NA][4], xb[2][NB][4];
+    static_for<NA>([&](auto Ai) { static_for<NB>([&](auto Bi) {
+        acc[Ai][Bi] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }); });
     f32x4 bsum[NB];
-    static_for<NB>([&](auto B) { bsum[B] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; });
-    auto fetch = [&](auto BUF, int i) {                  // block blk0 + i of the range
-        constexpr int buf = BUF;
-        const uint32_t oa = (uint32_t)i * stepA + offA, ob = (uint32_t)i * stepB + offB;
-        static_for<NA>([&](auto A) { static_for<4>([&](auto Q) {
-            xa[buf][A][Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voff, oa + (uint32_t)(decltype(A)::value * 4 + decltype(Q)::value) * 1024u, 0)); }); });
-        static_for<NB>([&](auto B) { static_for<4>([&](auto Q) {
-            xb[buf][B][Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, voff, ob + (uint32_t)(decltype(B)::value * 4 + decltype(Q)::value) * 1024u, 0)); }); });
-    };
-    const bool want_bias = t.bias_out != nullptr;
-    auto compute = [&](auto BUF) {
-        constexpr int buf = BUF;
-        static_for<4>([&](auto Q) { static_for<4>([&](auto C) {
-            constexpr int q = Q, c = C;
-            static_for<NA>([&](auto A) { static_for<NB>([&](auto B) {
-                acc[A][B] = mfma32(xa[buf][A][q][c], xb[buf][B][q][c], acc[A][B]);
+    static_for<NB>([&](auto Bi) { bsum[Bi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; });
+    const bool want_bias = tg.bias_out >= 0;
+    const int nblk = blk1 - blk0;
+    if (nblk > 0) {
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(A + (size_t)blk0 * rtA * 1024, (long long)nblk * rtA * 4096);
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(B + (size_t)blk0 * rtB * 1024, (long long)nblk * rtB * 4096);
+        const uint32_t voff = (uint32_t)lane * 16u;
+        const uint32_t stepA = (uint32_t)rtA * 4096u, stepB = (uint32_t)rtB * 4096u, offA = (uint32_t)a0 * 4096u, offB = (uint32_t)b0 * 4096u;
+        f32x4 xa[2][NA][2], xb[2][NB][2];                  // two halves of a block in flight: [half][tile][record of the half]
+        auto fetch = [&](auto BUF, int i) {                // half BUF of block blk0 + i
+            constexpr int buf = BUF;
+            const uint32_t oa = (uint32_t)i * stepA + offA + (uint32_t)buf * 2048u, ob = (uint32_t)i * stepB + offB + (uint32_t)buf * 2048u;
+            static_for<NA>([&](auto Ai) { static_for<2>([&](auto Q) {
+                xa[buf][Ai][Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voff, oa + (uint32_t)(decltype(Ai)::value * 4 + decltype(Q)::value) * 1024u, 0)); }); });
+            static_for<NB>([&](auto Bi) { static_for<2>([&](auto Q) {
+                xb[buf][Bi][Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, voff, ob + (uint32_t)(decltype(Bi)::value * 4 + decltype(Q)::value) * 1024u, 0)); }); });
+        };
+        auto compute = [&](auto BUF) {
+            constexpr int buf = BUF;
+            static_for<2>([&](auto Q) { static_for<4>([&](auto C) {
+                constexpr int q = Q, c = C;
+                static_for<NA>([&](auto Ai) { static_for<NB>([&](auto Bi) {
+                    acc[Ai][Bi] = mfma32(xa[buf][Ai][q][c], xb[buf][Bi][q][c], acc[Ai][Bi]);
+                }); });
             }); });
-        }); });
-        if (want_bias) static_for<NB>([&](auto B) { bsum[B] += (xb[buf][B][0] + xb[buf][B][1]) + (xb[buf][B][2] + xb[buf][B][3]); });
-    };
-    // The fetches are UNCONDITIONAL (behind the range's end the last block is asked for again and not used): with a branch around a fetch the
-    // compiler cannot count how many loads are younger than the ones it waits for, and waits for all of them -- the block just asked for too.
-    fetch(std::integral_constant<int, 0>{}, 0);
-    for (int i = 0; i < nblk; i += 2) {
-        fetch(std::integral_constant<int, 1>{}, i + 1 < nblk ? i + 1 : nblk - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(std::integral_constant<int, 0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(std::integral_constant<int, 0>{}, i + 2 < nblk ? i + 2 : nblk - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < nblk) compute(std::integral_constant<int, 1>{});
-        __builtin_amdgcn_sched_barrier(0);
+            if (want_bias) static_for<NB>([&](auto Bi) { bsum[Bi] += xb[buf][Bi][0] + xb[buf][Bi][1]; });
+        };
+        // The fetches are UNCONDITIONAL (behind the range's end the last block is asked for again and not used): with a branch around a fetch
+        // the compiler cannot count how many loads are younger than the ones it waits for, and waits for all of them
+        fetch(std::integral_constant<int, 0>{}, 0);
+        for (int i = 0; i < nblk; ++i) {
+            fetch(std::integral_constant<int, 1>{}, i);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(std::integral_constant<int, 0>{}, i + 1 < nblk ? i + 1 : i);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // D of a tile: lane l, register r <-> row 8 (r >> 2) + (r & 3) + 4 (l >> 5), column l & 31
     const int j = lane & 31, hh = lane >> 5;
-    float *out = t.out + (size_t)z * (size_t)t.split_stride;
-    static_for<NA>([&](auto A) { static_for<NB>([&](auto B) {
-        const int col = t.col0 + 32 * decltype(B)::value + j;
+    float *out = slot + tg.out;
+    static_for<NA>([&](auto Ai) { static_for<NB>([&](auto Bi) {
+        const int col = tg.col0 + 32 * decltype(Bi)::value + j;
         static_for<16>([&](auto R) {
             constexpr int r = R;
-            const int row = t.row0 + 32 * decltype(A)::value + 8 * (r >> 2) + (r & 3) + 4 * hh;
-            if (row < t.rows_valid && col >= t.c_lo && col < t.c_hi) out[(size_t)row * t.ldc + (col - t.c_lo)] = acc[A][B][r];
+            const int row = tg.row0 + 32 * decltype(Ai)::value + 8 * (r >> 2) + (r & 3) + 4 * hh;
+            if (row < tg.rows_valid && col >= tg.c_lo && col < tg.c_hi) out[(size_t)row * tg.ldc + (col - tg.c_lo)] = acc[Ai][Bi][r];
         });
     }); });
     if (want_bias) {
-        float *bo = t.bias_out + (size_t)z * (size_t)t.bias_split_stride + (size_t)hh * (t.c_hi - t.c_lo);
-        static_for<NB>([&](auto B) {
-            const int col = t.col0 + 32 * decltype(B)::value + j;
-            const f32x4 s = bsum[B];
-            if (col >= t.c_lo && col < t.c_hi) bo[col - t.c_lo] = (s.x + s.y) + (s.z + s.w);
+        float *bo = slot + tg.bias_out + (size_t)hh * (tg.c_hi - tg.c_lo);
+        static_for<NB>([&](auto Bi) {
+            const int col = tg.col0 + 32 * decltype(Bi)::value + j;
+            const f32x4 sm = bsum[Bi];
+            if (col >= tg.c_lo && col < tg.c_hi) bo[col - tg.c_lo] = (sm.x + sm.y) + (sm.z + sm.w);
         });
     }
 }
 
-// A workgroup = four neighbouring tasks of one range of sample blocks.  Workgroups are dealt to the 8 XCDs round-robin by their number and
-// every XCD has its own L2: the workgroups of ONE range are given numbers that land on one XCD, next to each other in time, so that what
-// two tasks share (a layer's dY is read by all the tasks of its rows) comes from HBM once.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dw_kernel(DwArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int z, wt;
-    if (a.parts % 8 == 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        z = (slot / a.wg_tasks) * 8 + xcd; wt = slot % a.wg_tasks;
-    } else { z = blockIdx.x / a.wg_tasks; wt = blockIdx.x % a.wg_tasks; }
-    const int ti = wt * 4 + wave;
-    if (z >= a.parts || ti >= a.n_tasks) return;
-    const DwTask &t = a.tasks[ti];
-    const int blk0 = z * a.bpr, blk1 = blk0 + a.bpr < a.n_blocks ? blk0 + a.bpr : a.n_blocks;
-    if (blk0 >= blk1) return;
-    const int kind = __builtin_amdgcn_readfirstlane(t.kind);
-    if (kind == 0) dw_body<2, 4>(t, z, blk0, blk1, lane);
-    else if (kind == 1) dw_body<1, 4>(t, z, blk0, blk1, lane);
-    else if (kind == 2) dw_body<2, 1>(t, z, blk0, blk1, lane);
-    else dw_body<1, 1>(t, z, blk0, blk1, lane);
+    const long long g = blockIdx.x, G = gridDim.x, W = a.total_cost * a.n_blocks;
+    long long start = 0;
+    for (int jn = 0; jn < a.n_jobs; ++jn) {
+        const DwJob &job = a.jobs[jn];
+        const long long cost = job.cost, span = cost * a.n_blocks;
+        const long long g0 = dw_first_g(G, W, start), g1 = dw_last_g(G, W, start, span);
+        if (__builtin_amdgcn_readfirstlane((int)(g >= g0 && g <= g1))) {
+            // (64-bit divisions: the compiler no longer sees that their results are the same in every lane)
+            const int blk0 = __builtin_amdgcn_readfirstlane((int)dw_cut(g, G, W, start, cost, a.n_blocks)), blk1 = __builtin_amdgcn_readfirstlane((int)dw_cut(g + 1, G, W, start, cost, a.n_blocks));
+            const DwWave &wv = job.w[wave];
+            const int shape = __builtin_amdgcn_readfirstlane(wv.shape);
+            const int my_slot = __builtin_amdgcn_readfirstlane((int)(g - g0));
+            float *slot = a.partial + job.first_float + (long long)my_slot * job.slot_floats;
+            if (shape == 0) dw_piece<4, 4>(wv, slot, blk0, blk1, lane);
+            else if (shape == 1) dw_piece<3, 4>(wv, slot, blk0, blk1, lane);
+            else if (shape == 2) dw_piece<4, 1>(wv, slot, blk0, blk1, lane);
+        }
+        start += span;
+    }
 }
-
 #endif   // NTX_TRAIN_DW
 
 // the launchers of ntx_train_chain.hip (one object per kernel: each takes minutes to compile).  The forward chain exists for the segment
