@@ -523,6 +523,11 @@ int64_t ntx_trainer_iterations(const ntx_trainer *t);
  * `train_dataset.take(n_iters - logger.step)`): Adam's iteration count -- what its bias correction and the ExponentialDecay schedule run
  * on -- is set beside the weights and moments (ntx_trainer_set). */
 int ntx_trainer_set_iterations(ntx_trainer *t, int64_t iterations);
+/* ABI v6.  ntx_set_weights from DEVICE memory (the context's device; Keras get_weights() order), in the stream's order and without a
+ * host copy: the float32 weight image is remade by one gather kernel.  The validation render inside the reference's training loop
+ * (logger.py:76-81 from train.py:61-70) is this with the trainer's weights (ntx_trainer_device_weights).  The fp16x3 images are NOT
+ * remade: NTX_FLAG_FP16X3 is refused (NTX_E_UNSUPPORTED) until the next ntx_set_weights. */
+int ntx_set_weights_device(ntx_ctx *ctx, const float *weights_dev, size_t n_floats, ntx_stream stream);
 /* The trainer's weights where they live: DEVICE memory of the trainer's device, Keras get_weights() order, ntx_trainer_weight_count floats,
  * valid until ntx_trainer_destroy; steps on a stream change them in that stream's order.  What ntx_set_weights_device takes. */
 int ntx_trainer_device_weights(ntx_trainer *t, const float **weights_dev);

@@ -10,6 +10,12 @@ published formats (LevelDB table format for `.index`; `BundleHeaderProto` / `Bun
 tensorflow/core/protobuf/tensor_bundle.proto; the object-graph key naming of TF2 checkpoints) and is tested by
 round trip against an independently written writer in `tests/`.
 
+Training state (train.py:55-57: `tf.train.Checkpoint(model=..., step=..., optimizer=...)`): beside the Dense variables the bundle holds
+`step`, `optimizer/iter`, the optimizer's hyper-parameters and Adam's two slots per variable
+(`<variable>/.OPTIMIZER_SLOT/optimizer/{m,v}/...`); `training_state_from_bundle` reads them, `write_checkpoint` writes a bundle with
+the same keys and the `_CHECKPOINTABLE_OBJECT_GRAPH` that object-based restore walks -- so that a run of either side can continue
+from the other's `checkpoints/ckpt-<step>` (logger.py:30-39, 84-86).  Unpinned like the reader: no TensorFlow has read these files.
+
 Formats, as implemented:
   .index  = LevelDB table: data blocks of prefix-compressed (key, value) entries
             [varint shared][varint non_shared][varint value_len][key suffix][value], a restart array, a 5-byte
@@ -239,4 +245,211 @@ def load_checkpoint(model, path: str, root: str = None, verify: bool = True) -> 
     prefix = latest_checkpoint(path) if os.path.isdir(path) else path
     tensors = read_bundle(prefix, verify)
     model.set_weights(model_weights_from_bundle(tensors, model.layer_table(), root or model.name))
+    return prefix
+
+
+# ---- training state ----------------------------------------------------------------------------------------------
+_ATTR = "/.ATTRIBUTES/VARIABLE_VALUE"
+_SLOT = re.compile(r"^(?P<root>.+?)/layer_with_weights-(?P<i>\d+)/(?P<kind>kernel|bias)/\.OPTIMIZER_SLOT/(?P<opt>[^/]+)/(?P<slot>m|v)/\.ATTRIBUTES/VARIABLE_VALUE$")
+
+
+def training_state_from_bundle(tensors: Dict[str, np.ndarray], layer_table, root: str = "model", optimizer: str = "optimizer") -> dict:
+    """What `tf.train.Checkpoint(**{root: keras_model}, step=step, optimizer=adam)` saved (train.py:55-57), in `layer_table` order:
+    {'weights': [kernel, bias, ...], 'm': [...] | None, 'v': [...] | None, 'iterations': int | None, 'step': int | None,
+    'hyper': {name: float}}.  Slots are matched to their variables by `layer_with_weights-<i>`, and the layers to `layer_table` by
+    shape, like `model_weights_from_bundle` (same rule, so weights and moments stay together)."""
+    weights = model_weights_from_bundle(tensors, layer_table, root)
+    layers: Dict[int, dict] = {}
+    for name, arr in tensors.items():
+        m = _VAR.match(name)
+        if m and m.group("root") == root:
+            layers.setdefault(int(m.group("i")), {})[m.group("kind")] = arr
+        m = _SLOT.match(name)
+        if m and m.group("root") == root and m.group("opt") == optimizer:
+            layers.setdefault(int(m.group("i")), {})[m.group("kind") + "/" + m.group("slot")] = arr
+    pool = [layers[i] for i in sorted(layers)]
+    used = [False] * len(pool)
+    slots = {"m": [], "v": []}
+    have = all(all(f"{k}/{sl}" in d for k in ("kernel", "bias") for sl in ("m", "v")) for d in pool)
+    for lname, i, o in layer_table:
+        for k, d in enumerate(pool):
+            if not used[k] and d["kernel"].shape == (i, o) and d["bias"].shape == (o,):
+                used[k] = True
+                if have:
+                    for sl in ("m", "v"):
+                        if d[f"kernel/{sl}"].shape != (i, o) or d[f"bias/{sl}"].shape != (o,):
+                            raise KeyError(f"slot '{sl}' of layer '{lname}' has the wrong shape")
+                        slots[sl] += [np.asarray(d[f"kernel/{sl}"], np.float32), np.asarray(d[f"bias/{sl}"], np.float32)]
+                break
+    scalar = lambda key: tensors.get(key + _ATTR)
+    it, step = scalar(f"{optimizer}/iter"), scalar("step")
+    hyper = {n: float(np.asarray(scalar(f"{optimizer}/{n}")).reshape(())) for n in ("learning_rate", "beta_1", "beta_2", "decay", "epsilon")
+             if scalar(f"{optimizer}/{n}") is not None}
+    return {"weights": weights, "m": slots["m"] if have else None, "v": slots["v"] if have else None,
+            "iterations": None if it is None else int(np.asarray(it).reshape(())), "step": None if step is None else int(np.asarray(step).reshape(())),
+            "hyper": hyper}
+
+
+def _vi(n: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = n & 0x7F; n >>= 7
+        if n:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _pb(num: int, wt: int, payload: bytes) -> bytes:
+    return _vi((num << 3) | wt) + payload
+
+
+def _pb_bytes(num: int, payload: bytes) -> bytes:
+    return _pb(num, 2, _vi(len(payload)) + payload)
+
+
+def _table_block(items, restart_interval: int = 16) -> bytes:
+    buf, restarts, prev = bytearray(), [], b""
+    for n, (k, v) in enumerate(items):
+        shared = 0
+        if n % restart_interval == 0:
+            restarts.append(len(buf))
+        else:
+            while shared < min(len(prev), len(k)) and prev[shared] == k[shared]:
+                shared += 1
+        buf += _vi(shared) + _vi(len(k) - shared) + _vi(len(v)) + k[shared:] + v
+        prev = k
+    for r in restarts or [0]:
+        buf += struct.pack("<I", r)
+    buf += struct.pack("<I", len(restarts) or 1)
+    return bytes(buf)
+
+
+def _object_graph(root: str, n_layers: int, opt_scalars, with_slots: bool) -> bytes:
+    """TrackableObjectGraph (tensorflow/core/protobuf/trackable_object_graph.proto) of Checkpoint(**{root: model}, step, optimizer,
+    save_counter): nodes {1: children {1: node_id, 2: local_name}, 2: attributes {1: name, 2: full_name, 3: checkpoint_key},
+    3: slot_variables {1: original_variable_node_id, 2: slot_name, 3: slot_variable_node_id}}."""
+    nodes = []                                                       # (children [(id, name)], attributes [(name, full_name, key)], slot refs)
+
+    def add(children=None, attrs=None, slots=None):
+        nodes.append((children or [], attrs or [], slots or []))
+        return len(nodes) - 1
+
+    var = lambda key, full: add(attrs=[("VARIABLE_VALUE", full, key + _ATTR)])
+    root_children = []
+    root_id = add()
+    model_children, var_ids = [], []
+    model_id = add()
+    for i in range(n_layers):
+        base = f"{root}/layer_with_weights-{i}"
+        dense = "dense" if i == 0 else f"dense_{i}"
+        kid, bid = var(f"{base}/kernel", f"{dense}/kernel"), var(f"{base}/bias", f"{dense}/bias")
+        var_ids += [(kid, f"{base}/kernel", f"{dense}/kernel"), (bid, f"{base}/bias", f"{dense}/bias")]
+        model_children.append((add(children=[(kid, "kernel"), (bid, "bias")]), f"layer_with_weights-{i}"))
+    nodes[model_id] = (model_children, [], [])
+    step_id = var("step", "Variable")
+    opt_children = [(var(f"optimizer/{n}", f"Adam/{n}"), n) for n in opt_scalars]
+    slot_refs = []
+    if with_slots:
+        for vid, key, full in var_ids:
+            for sl in ("m", "v"):
+                sid = add(attrs=[("VARIABLE_VALUE", f"Adam/{full}/{sl}", f"{key}/.OPTIMIZER_SLOT/optimizer/{sl}{_ATTR}")])
+                slot_refs.append((vid, sl, sid))
+    opt_id = add(children=opt_children, slots=slot_refs)
+    counter_id = var("save_counter", "save_counter")
+    nodes[root_id] = ([(model_id, root), (step_id, "step"), (opt_id, "optimizer"), (counter_id, "save_counter")], [], [])
+    out = b""
+    for children, attrs, slots in nodes:
+        msg = b""
+        for cid, name in children:
+            msg += _pb_bytes(1, _pb(1, 0, _vi(cid)) + _pb_bytes(2, name.encode()))
+        for name, full, key in attrs:
+            msg += _pb_bytes(2, _pb_bytes(1, name.encode()) + _pb_bytes(2, full.encode()) + _pb_bytes(3, key.encode()))
+        for vid, sl, sid in slots:
+            msg += _pb_bytes(3, _pb(1, 0, _vi(vid)) + _pb_bytes(2, sl.encode()) + _pb(3, 0, _vi(sid)))
+        out += _pb_bytes(1, msg)
+    return out
+
+
+def write_bundle(prefix: str, tensors: Dict[str, object], block_bytes: int = 4096) -> None:
+    """`<prefix>.index` + `<prefix>.data-00000-of-00001` in TensorBundle format.  tensors: {key: ndarray (float32 / int32 / int64) or bytes
+    (a scalar DT_STRING)}.  A string tensor's data is [varint length][4-byte masked crc32c of the length as uint64][bytes], the entry's
+    checksum running over all three (tensor_bundle.cc WriteStringTensor, as published)."""
+    data, entries = bytearray(), {}
+    dt_of = {np.dtype("float32"): DT_FLOAT, np.dtype("int32"): DT_INT32, np.dtype("int64"): DT_INT64}
+    for name in sorted(tensors, key=lambda k: k.encode()):
+        val = tensors[name]
+        if isinstance(val, (bytes, bytearray)):
+            lens = _vi(len(val))
+            len_crc = struct.pack("<I", mask_crc(crc32c(struct.pack("<Q", len(val)))))
+            raw, dt, shape = lens + len_crc + bytes(val), DT_STRING, ()
+            crc = crc32c(bytes(val), crc32c(len_crc, crc32c(struct.pack("<Q", len(val)))))
+        else:
+            a = np.ascontiguousarray(val)
+            raw, dt, shape = a.tobytes(), dt_of[a.dtype], a.shape
+            crc = crc32c(raw)
+        dims = b"".join(_pb_bytes(2, _pb(1, 0, _vi(d))) for d in shape)
+        msg = _pb(1, 0, _vi(dt)) + _pb_bytes(2, dims) + _pb(4, 0, _vi(len(data))) + _pb(5, 0, _vi(len(raw))) + _pb(6, 5, struct.pack("<I", mask_crc(crc)))
+        entries[name] = msg
+        data += raw
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(bytes(data))
+    header = _pb(1, 0, _vi(1)) + _pb(2, 0, _vi(0)) + _pb_bytes(3, _pb(1, 0, _vi(1)))
+    items = [(b"", header)] + [(k.encode(), entries[k]) for k in sorted(entries, key=lambda k: k.encode())]
+    out, index_items, cur, cur_size = bytearray(), [], [], 0
+
+    def flush():
+        nonlocal cur, cur_size
+        if not cur:
+            return
+        blk = _table_block(cur)
+        index_items.append((cur[-1][0] + b"\x00", _vi(len(out)) + _vi(len(blk))))     # a separator >= the block's last key
+        out.extend(blk + b"\x00" + struct.pack("<I", mask_crc(crc32c(blk + b"\x00"))))
+        cur, cur_size = [], 0
+
+    for kv in items:
+        cur.append(kv); cur_size += len(kv[0]) + len(kv[1])
+        if cur_size >= block_bytes:
+            flush()
+    flush()
+    meta = _table_block([])
+    moff = len(out); out += meta + b"\x00" + struct.pack("<I", mask_crc(crc32c(meta + b"\x00")))
+    idx = _table_block(index_items, restart_interval=1)
+    ioff = len(out); out += idx + b"\x00" + struct.pack("<I", mask_crc(crc32c(idx + b"\x00")))
+    footer = _vi(moff) + _vi(len(meta)) + _vi(ioff) + _vi(len(idx))
+    out += footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", TABLE_MAGIC)
+    with open(prefix + ".index", "wb") as f:
+        f.write(bytes(out))
+
+
+def write_checkpoint(prefix: str, layer_table, weights, m=None, v=None, iterations: int = 0, step: int = 0, hyper: dict = None, root: str = "model",
+                     save_counter: int = 1) -> str:
+    """A checkpoint with the keys of `tf.train.Checkpoint(**{root: model}, step=step, optimizer=Adam(...))` (train.py:55-57, logger.py:30-34):
+    `weights` / `m` / `v` in `layer_table` order ([kernel, bias, ...]; m, v: Adam's slots or None), `iterations` = `optimizer.iterations`,
+    `hyper`: beta_1 / beta_2 / decay [/ learning_rate: only a constant rate is a variable, a schedule is not].  Also maintains the
+    directory's `checkpoint` state file the way CheckpointManager does (latest_checkpoint reads the newest index either way)."""
+    hyper = {"beta_1": 0.9, "beta_2": 0.999, "decay": 0.0, **(hyper or {})}
+    t: Dict[str, object] = {}
+    f32 = lambda a, shape: np.ascontiguousarray(np.asarray(a, np.float32).reshape(shape))
+    for i, (_, fan_in, fan_out) in enumerate(layer_table):
+        base = f"{root}/layer_with_weights-{i}"
+        for kind, shape, j in (("kernel", (fan_in, fan_out), 2 * i), ("bias", (fan_out,), 2 * i + 1)):
+            t[f"{base}/{kind}{_ATTR}"] = f32(weights[j], shape)
+            if m is not None and v is not None:
+                t[f"{base}/{kind}/.OPTIMIZER_SLOT/optimizer/m{_ATTR}"] = f32(m[j], shape)
+                t[f"{base}/{kind}/.OPTIMIZER_SLOT/optimizer/v{_ATTR}"] = f32(v[j], shape)
+    t["step" + _ATTR] = np.asarray(int(step), np.int64)
+    t["optimizer/iter" + _ATTR] = np.asarray(int(iterations), np.int64)
+    scalars = ["iter"]
+    for n in ("beta_1", "beta_2", "decay", "learning_rate"):
+        if n in hyper:
+            t[f"optimizer/{n}{_ATTR}"] = np.asarray(hyper[n], np.float32); scalars.append(n)
+    t["save_counter" + _ATTR] = np.asarray(int(save_counter), np.int64)
+    t["_CHECKPOINTABLE_OBJECT_GRAPH"] = _object_graph(root, len(layer_table), scalars, m is not None and v is not None)
+    os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
+    write_bundle(prefix, t)
+    with open(os.path.join(os.path.dirname(os.path.abspath(prefix)), "checkpoint"), "w") as f:
+        name = os.path.basename(prefix)
+        f.write(f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n')
     return prefix

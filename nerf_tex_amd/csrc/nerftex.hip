@@ -569,6 +569,9 @@ struct ntx_ctx {
     int32_t *hit_count;   // device int32[8]: [0] number of hit rays, [1] work counter of the instance kernel, [2..5] its chunk table (inst_order_kernel)
     bool hoist_dir;       // false when NERFTEX_NO_DIR_HOIST is set at ntx_create (A/B knob for tests: same bits either way)
     uint16_t *inst_sidx;  // device scratch of ntx_render_instanced: per wave, the execution list of its bundle of rays in flight (8.5 KiB each)
+    // ntx_set_weights_device: where every float of the packed image comes from -- an index into the weight blob, or -1 and a constant
+    int32_t *gather_idx = nullptr; float *gather_const = nullptr;
+    bool x3_stale = false;   // the fp16x3 images were not remade by the last ntx_set_weights_device
 };
 
 // The big kernels of each model family live in their own translation units (ntx_variant.hip / ntx_variant_x3.hip
@@ -816,6 +819,47 @@ int ntx_reserve(ntx_ctx *ctx, int64_t max_rays) {
     return NTX_OK;
 }
 
+// packed[i] = idx[i] >= 0 ? w[idx[i]] : konst[i]: the weight image remade where the weights are
+__global__ void gather_weights_kernel(const float *__restrict__ w, const int32_t *__restrict__ idx, const float *__restrict__ konst, size_t n, float *__restrict__ packed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t g = idx[i];
+    packed[i] = g >= 0 ? w[g] : konst[i];
+}
+
+int ntx_set_weights_device(ntx_ctx *ctx, const float *weights_dev, size_t n_floats, ntx_stream stream) {
+    if (!ctx || !weights_dev) return fail(NTX_E_INVALID, "NULL argument");
+    const size_t want = weight_count_of(ctx->variant, &ctx->descx.base);
+    if (n_floats != want) return fail(NTX_E_INVALID, "weight blob has %zu floats, model needs %zu", n_floats, want);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->gather_idx) {
+        // The packer only PLACES weights (and a few constants: the flex family's descriptor, zero padding).  Packing two blobs of the weights'
+        // own numbers -- i + 1 and 2 (i + 1), exact in float32 below 2^23 -- tells every packed float's source: doubled = weight i, equal = constant.
+        if (n_floats >= (size_t)1 << 22) return fail(NTX_E_UNSUPPORTED, "ntx_set_weights_device: the model has more than 2^22 weights");
+        std::vector<float> b1(n_floats), b2(n_floats), p1(ctx->n_packed), p2(ctx->n_packed);
+        for (size_t i = 0; i < n_floats; ++i) { b1[i] = (float)(i + 1); b2[i] = (float)(2 * (i + 1)); }
+        int rc = ntx_pack_weights(&ctx->descx.base, b1.data(), n_floats, p1.data(), p1.size());
+        if (rc == NTX_OK) rc = ntx_pack_weights(&ctx->descx.base, b2.data(), n_floats, p2.data(), p2.size());
+        if (rc != NTX_OK) return rc;
+        std::vector<int32_t> idx(ctx->n_packed);
+        for (size_t i = 0; i < ctx->n_packed; ++i) {
+            const float a = p1[i], b = p2[i];
+            if (a >= 1.0f && a <= (float)n_floats && b == 2.0f * a && a == std::floor(a)) idx[i] = (int32_t)a - 1;
+            else if (memcmp(&a, &b, sizeof(float)) == 0) idx[i] = -1;
+            else return fail(NTX_E_UNSUPPORTED, "ntx_set_weights_device: packed float %zu is neither a weight nor a constant", i);
+        }
+        HIP_TRY(hipMalloc((void **)&ctx->gather_idx, ctx->n_packed * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&ctx->gather_const, ctx->n_packed * sizeof(float)));
+        HIP_TRY(hipMemcpy(ctx->gather_idx, idx.data(), ctx->n_packed * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->gather_const, p1.data(), ctx->n_packed * sizeof(float), hipMemcpyHostToDevice));
+    }
+    gather_weights_kernel<<<dim3((unsigned)((ctx->n_packed + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(weights_dev, ctx->gather_idx, ctx->gather_const, ctx->n_packed,
+                                                                                                                 ctx->packed);
+    HIP_TRY(hipGetLastError());
+    ctx->x3_stale = ctx->packed16 != nullptr;
+    return NTX_OK;
+}
+
 int ntx_set_weights(ntx_ctx *ctx, const float *weights_host, size_t n_floats) {
     if (!ctx || !weights_host) return fail(NTX_E_INVALID, "NULL argument");
     std::vector<float> packed(ctx->n_packed);
@@ -833,6 +877,7 @@ int ntx_set_weights(ntx_ctx *ctx, const float *weights_host, size_t n_floats) {
         pack16(kVariants[ctx->variant], dims_of(&ctx->descx.base), weights_host, p16.data(), 1);
         HIP_TRY(hipMemcpy(ctx->packed16i, p16.data(), ctx->packed16i_bytes, hipMemcpyHostToDevice));
     }
+    ctx->x3_stale = false;
     return NTX_OK;
 }
 
@@ -844,6 +889,8 @@ int ntx_destroy(ntx_ctx *ctx) {
     if (ctx->hit_list) (void)hipFree(ctx->hit_list);
     if (ctx->hit_count) (void)hipFree(ctx->hit_count);
     if (ctx->inst_sidx) (void)hipFree(ctx->inst_sidx);
+    if (ctx->gather_idx) (void)hipFree(ctx->gather_idx);
+    if (ctx->gather_const) (void)hipFree(ctx->gather_const);
     delete ctx;
     return NTX_OK;
 }
@@ -951,6 +998,9 @@ int ntx_mlp_forward(ntx_ctx *ctx, const float *pos, const float *dirs, const flo
     if (m == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
     if (flags & NTX_FLAG_FP16X3) if (int rc = no_fp16x3(v)) return rc;
+    if ((flags & NTX_FLAG_FP16X3) && ctx->x3_stale)
+        return fail(NTX_E_UNSUPPORTED, "the fp16x3 images are stale: the weights last came from device memory (ntx_set_weights_device remakes the float32 image only); "
+                                       "ntx_set_weights remakes all of them");
     const Dims dm_ = dims_of(&ctx->descx.base);
     if (!pos || !dirs || !color_out || !sigma_out || (!params && dm_.g + dm_.a > 0))
         return fail(NTX_E_INVALID, "NULL buffer");
@@ -1005,6 +1055,9 @@ int ntx_render_rays(ntx_ctx *ctx, const float *rays_o, const float *rays_d, cons
     if (n_rays == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
     if (flags & NTX_FLAG_FP16X3) if (int rc = no_fp16x3(v)) return rc;
+    if ((flags & NTX_FLAG_FP16X3) && ctx->x3_stale)
+        return fail(NTX_E_UNSUPPORTED, "the fp16x3 images are stale: the weights last came from device memory (ntx_set_weights_device remakes the float32 image only); "
+                                       "ntx_set_weights remakes all of them");
     const Dims dm_ = dims_of(&ctx->descx.base);
     const int np = dm_.g + dm_.a + v.ipe;   // parameters per row at the ABI (mip: incl. the spliced-out blur parameter)
     if (!rays_o || !rays_d || !t || !color_out || !alpha_out || (!params && np > 0))
@@ -1080,6 +1133,9 @@ int ntx_render_instanced(ntx_ctx *ctx, const float *rays_d_map, const float *pts
     if (n_rays == 0) return NTX_OK;
     const Variant &v = kVariants[ctx->variant];
     if (flags & NTX_FLAG_FP16X3) if (int rc = no_fp16x3(v)) return rc;
+    if ((flags & NTX_FLAG_FP16X3) && ctx->x3_stale)
+        return fail(NTX_E_UNSUPPORTED, "the fp16x3 images are stale: the weights last came from device memory (ntx_set_weights_device remakes the float32 image only); "
+                                       "ntx_set_weights remakes all of them");
     const Dims dm_ = dims_of(&ctx->descx.base);
     const int np = dm_.g + dm_.a + v.ipe;
     if (v.ipe && (blur_idx < 0 || !t)) return fail(NTX_E_INVALID, "an IPE (mip) model needs blur_idx and t (renderer.py:511, 575)");

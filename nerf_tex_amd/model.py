@@ -154,6 +154,24 @@ class NerfModel:
             for ctx in self._ctx.values():
                 _lib.check(_lib.lib.ntx_set_weights(ctx, self._blob.ctypes.data_as(C.POINTER(C.c_float)), self._blob.size))
 
+    def set_weights_from_trainer(self, trainer, sync_host: bool = False) -> None:
+        """The weights a `nerf_tex_amd.train.Trainer` holds become this model's, WITHOUT leaving the GPU: the render context of the
+        trainer's device remakes its weight image from the trainer's device memory in the current stream's order (`ntx_set_weights_device`) --
+        the validation render inside the reference's training loop (logger.py:76-81).  The model's host copy (`get_weights`, contexts
+        of other devices, the fp16x3 images) is NOT updated unless `sync_host`, which is `set_blob(trainer.weights())`."""
+        import torch
+        from . import _lib
+        if sync_host:
+            self.set_blob(trainer.weights())
+            return
+        if trainer.n_weights != self.n_weight_floats():
+            raise ValueError(f"trainer has {trainer.n_weights} weights, model needs {self.n_weight_floats()}")
+        dev = torch.device("cuda", trainer.device)
+        ptr = C.c_void_p()
+        _lib.check(_lib.lib.ntx_trainer_device_weights(trainer._h, C.byref(ptr)))
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.ntx_set_weights_device(self.ctx(trainer.device), ptr, trainer.n_weights, torch.cuda.current_stream(dev).cuda_stream))
+
     # ---- device ------------------------------------------------------------------------
     def ctx(self, device_index: int) -> int:
         """Context of the HIP library for `device_index`, created on first use."""

@@ -5,8 +5,13 @@ tape, loss, gradients, `optimizer.apply_gradients`.
     trainer = Trainer(model, max_rays=1024, n_samples=256, lrate=5e-4, lrate_decay=500)       # config_carpet_train.py:100-109
     loss = trainer.step(rays_o, rays_d, t, parameters, cone_scale, color, alpha, loss_fn)      # one iteration of train.py:61-67
 
-Built for the ParamNerf architecture of the shipped training configs (8 x 256, skips [4], color_depth 1).  The data side of training
-(TFRecord datasets, logging, checkpoints: train.py:20-58, dataset.py) stays out of scope: SURVEY section 2."""
+`Train(...)` is the reference's function of that name (train.py:7-70) over an in-memory iterable of batch dicts: model, loss, schedule and
+renderer from the config blocks, the loop, and what its Logger does every i_img / i_checkpoint steps (logger.py:57-86) -- the validation
+views rendered through the inference path with the trainer's weights handed over on the device, checkpoints in TensorFlow's bundle format
+with model + step + optimizer (train.py:55-57) that `Trainer.restore` resumes from.
+
+Built for the ParamNerf architecture of the shipped training configs (8 x 256, skips [4], color_depth 1).  TFRecord datasets and
+TensorBoard summaries (train.py:20-28, logger.py:41-64, dataset.py) stay out of scope: SURVEY section 2."""
 
 from __future__ import annotations
 
@@ -40,6 +45,7 @@ class Trainer:
                                                self.n_samples, C.byref(self._h)))
         self.n_weights = int(_lib.lib.ntx_trainer_weight_count(self._h))
         self._calls = 0
+        self._last_rays = 0
 
     @classmethod
     def from_config(cls, config: dict, max_rays: Optional[int] = None, device: int = 0, weights=None):
@@ -100,13 +106,62 @@ class Trainer:
         return out
 
     def set_weights(self, blob) -> None:
+        """New weights (waits for what is in flight on the device); Adam's moments and iteration count stay as they are."""
+        self._set(_lib.TRAINER_WEIGHTS, blob)
+
+    def _set(self, what: int, values) -> None:
         import numpy as np
-        b = np.ascontiguousarray(blob, dtype=np.float32).reshape(-1)
-        _lib.check(_lib.lib.ntx_trainer_set_weights(self._h, b.ctypes.data_as(C.POINTER(C.c_float)), b.size))
+        b = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)
+        _lib.check(_lib.lib.ntx_trainer_set(self._h, what, b.ctypes.data_as(C.POINTER(C.c_float)), b.size))
 
     @property
     def iterations(self) -> int:
         return int(_lib.lib.ntx_trainer_iterations(self._h))
+
+    # ---- resuming (train.py:55-60, logger.py:30-39, 84-86) -------------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        """Everything a resumed run needs to continue bit for bit: weights, Adam's moments and iteration count (its bias correction and
+        the ExponentialDecay schedule run on it), and the counter the default jitter / noise seeds come from."""
+        m, v = self.adam_state()
+        return {"weights": self.weights(), "adam_m": m, "adam_v": v, "iterations": self.iterations, "calls": self._calls}
+
+    def load_state_dict(self, state: dict) -> None:
+        self._set(_lib.TRAINER_WEIGHTS, state["weights"])
+        self._set(_lib.TRAINER_ADAM_M, state["adam_m"]); self._set(_lib.TRAINER_ADAM_V, state["adam_v"])
+        _lib.check(_lib.lib.ntx_trainer_set_iterations(self._h, int(state["iterations"])))
+        self._calls = int(state.get("calls", state["iterations"]))
+
+    def save(self, prefix: str, step: int = None, root: str = None) -> str:
+        """`checkpoint_manager.save(checkpoint_number=step)` (logger.py:84-86): a TensorBundle `<prefix>.index` / `.data-00000-of-00001` with
+        the keys of `tf.train.Checkpoint(**{model.name: model}, step=step, optimizer=optimizer)` (train.py:55-57; nerf_tex_amd/checkpoint.py)."""
+        import numpy as np
+        from . import checkpoint
+        table = self.model.layer_table()
+        split = lambda blob: _split_blob(table, blob)
+        st = self.state_dict()
+        hyper = {"beta_1": self.beta_1, "beta_2": self.beta_2, "decay": 0.0}
+        if not self.lrate_decay > 0:
+            hyper["learning_rate"] = self.lrate                  # (under a schedule Keras has no such variable)
+        return checkpoint.write_checkpoint(prefix, table, split(st["weights"]), split(st["adam_m"]), split(st["adam_v"]), iterations=st["iterations"],
+                                           step=st["iterations"] if step is None else int(step), hyper=hyper, root=root or self.model.name)
+
+    def restore(self, path: str, root: str = None, verify: bool = True) -> dict:
+        """`checkpoint.restore(manager.latest_checkpoint)` (logger.py:39): `path` is a checkpoint prefix or a directory of `ckpt-<n>`.  Weights,
+        Adam's slots and iteration count when the bundle holds them (a bundle with weights alone restarts the optimiser, as TensorFlow's
+        `expect_partial()` restore would).  Returns {'prefix', 'step', 'iterations'}."""
+        import os
+        import numpy as np
+        from . import checkpoint
+        prefix = checkpoint.latest_checkpoint(path) if os.path.isdir(path) else path
+        st = checkpoint.training_state_from_bundle(checkpoint.read_bundle(prefix, verify), self.model.layer_table(), root or self.model.name)
+        flat = lambda arrs: np.concatenate([np.asarray(a, np.float32).ravel() for a in arrs])
+        self._set(_lib.TRAINER_WEIGHTS, flat(st["weights"]))
+        zeros = np.zeros(self.n_weights, np.float32)
+        self._set(_lib.TRAINER_ADAM_M, zeros if st["m"] is None else flat(st["m"])); self._set(_lib.TRAINER_ADAM_V, zeros if st["v"] is None else flat(st["v"]))
+        it = st["iterations"] if st["iterations"] is not None and st["m"] is not None else 0
+        _lib.check(_lib.lib.ntx_trainer_set_iterations(self._h, int(it)))
+        self._calls = int(it)
+        return {"prefix": prefix, "step": st["step"], "iterations": it}
 
     def gradients_step(self, rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, loss, composite_bkgd: bool = False, bkgd_color=(1., 1., 1.),
                        seed: Optional[int] = None, z_vals=None, rays_per_param_row: int = 1):
@@ -119,6 +174,7 @@ class Trainer:
         to = lambda a: None if a is None else (a if isinstance(a, torch.Tensor) else torch.as_tensor(a)).to(device=dev, dtype=torch.float32).contiguous()
         rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, z_vals = (to(a) for a in (rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, z_vals))
         n = rays_o.reshape(-1, 3).shape[0]
+        self._last_rays = n
         flags = (_lib.FLAG_PERTURB if self.perturb else 0) | (_lib.FLAG_MAP_EXR if self.map_exr else 0) | (_lib.FLAG_COMPOSITE_BKGD if composite_bkgd else 0)
         opts = None
         if self.raw_noise_std > 0:
@@ -167,6 +223,14 @@ class Trainer:
         nerf_tex_amd.dist.Comm -- ONE ncclAllReduce of the 2.7 MB over xGMI behind the C ABI (`ntx_trainer_allreduce_gradients`), on the current
         stream.  Without one, the same mean through torch.distributed on host memory (gloo: the CPU-side tests, ranks sharing a GPU)."""
         import torch
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            # the mean of the ranks' means is the batch's gradient only when every rank brought as many rays (the losses are means over rays)
+            mine = torch.tensor([self._last_rays], dtype=torch.int64, device=torch.device("cuda", self.device) if dist.get_backend(group) == "nccl" else "cpu")
+            counts = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+            dist.all_gather(counts, mine, group=group)
+            if len({int(c.item()) for c in counts}) != 1:
+                raise ValueError(f"data-parallel step with unequal shards ({[int(c.item()) for c in counts]} rays): the mean of per-rank gradients would be wrong")
         if comm is not None:
             with torch.cuda.device(self.device):
                 _lib.check(_lib.lib.ntx_trainer_allreduce_gradients(self._h, comm.handle, torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream))
@@ -195,3 +259,83 @@ def allreduce_mean_host(values, group=None):
         dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
         v /= dist.get_world_size(group)
     return v.numpy()
+
+
+def _split_blob(table, blob):
+    import numpy as np
+    out, p = [], 0
+    b = np.asarray(blob, np.float32).ravel()
+    for _, i, o in table:
+        out.append(b[p:p + i * o].reshape(i, o)); p += i * o
+        out.append(b[p:p + o]); p += o
+    return out
+
+
+def Train(target_path: str, train_dataset, val_dataset=None, model_config: dict = None, loss_config: dict = None, n_iters: int = 1000, lrate: float = 5e-4,
+          lrate_decay: float = 0, renderer_config: dict = None, logger_config: dict = None, max_rays: int = None, device: int = 0, weights=None,
+          composite_bkgd: bool = None, bkgd_color=None, **kwargs) -> dict:
+    """network.train.Train (train.py:7-70) with the data side handed in: `train_dataset` is an iterable of batch dicts as network/dataset.py
+    maps them (rays_o / rays_d [B,R,3], t [B,R,2], cone_scale [B,R,1], parameters [B,P], color [B,R,3], alpha [B,R]) -- TFRecord reading
+    stays out of scope --, `val_dataset` a `nerf_tex_amd.dataset.Dataset` (or any iterable of ray batch dicts with height / width / composite_bkgd /
+    bkgd_color) whose views are rendered every `i_img` steps.  The other arguments are the reference's: `model_config` / `loss_config` /
+    `renderer_config` blocks, `n_iters`, `lrate`, `lrate_decay`, and of `logger_config` (logger.py:14) `i_print`, `i_img`, `i_checkpoint`,
+    `max_to_keep`.  What the reference's Logger does at its cadences happens here: a checkpoint `checkpoints/ckpt-<step>` under `target_path`
+    (model + step + optimizer, train.py:55-57) every `i_checkpoint` steps, the validation views through `Renderer` -- the inference path, the
+    trainer's weights handed over on the device -- every `i_img` steps; a run whose `target_path` holds checkpoints resumes from the newest and
+    takes `n_iters - step` batches (train.py:60).  Returns {'trainer', 'renderer', 'loss' [(step, value)], 'images' {step: [RGBA [H,W,4]]},
+    'checkpoints' [prefix], 'step'}."""
+    import os
+    import torch
+    from . import checkpoint, util
+    from .renderer import Renderer
+    cfg = util.remap_reference_config(dict(model_config=model_config, loss_config=loss_config, renderer_config=renderer_config or {}, lrate=lrate,
+                                           lrate_decay=lrate_decay))
+    if max_rays is None:
+        first = next(iter(train_dataset))
+        max_rays = int(first["rays_o"].shape[0]) * int(first["rays_o"].shape[1])
+    trainer, loss_fn = Trainer.from_config(cfg, max_rays=max_rays, device=device, weights=weights)
+    model = trainer.model
+    rcfg = {k: v for k, v in dict(cfg["renderer_config"]).items() if k != "module"}
+    renderer = Renderer(model=model, **rcfg)
+    lg = dict(i_print=100, i_img=5e3, i_checkpoint=1e3, max_to_keep=3)
+    lg.update({k: v for k, v in (logger_config or {}).items() if k in lg})
+    i_print, i_img, i_ckpt, keep = int(lg["i_print"]), int(lg["i_img"]), int(lg["i_checkpoint"]), int(lg["max_to_keep"])
+    ckpt_dir = os.path.join(target_path, "checkpoints")
+    os.makedirs(ckpt_dir, exist_ok=True)
+    step = 0
+    try:                                                          # logger.py:39: restore the newest checkpoint if there is one
+        info = trainer.restore(ckpt_dir)
+        step = int(info["step"] if info["step"] is not None else info["iterations"])
+        print(f"Restored model & optimizer from {info['prefix']}.")
+    except FileNotFoundError:
+        pass
+    cb = getattr(train_dataset, "composite_bkgd", False) if composite_bkgd is None else composite_bkgd
+    bc = getattr(train_dataset, "bkgd_color", (1., 1., 1.)) if bkgd_color is None else bkgd_color
+    out = {"trainer": trainer, "renderer": renderer, "loss": [], "images": {}, "checkpoints": [], "step": step}
+    if step >= n_iters:
+        return out
+    todo = int(n_iters) - step
+    for data in train_dataset:                                    # train.py:60: train_dataset.take(n_iters - logger.step)
+        if todo <= 0:
+            break
+        todo -= 1
+        pred = trainer.train_step(data, loss_fn, composite_bkgd=cb, bkgd_color=bc)
+        step += 1
+        if i_print > 0 and step % i_print == 0:
+            val = float(pred["loss"].item())
+            out["loss"].append((step, val))
+            print(f"Step {step} | Loss {val:.3g}")
+        if val_dataset is not None and i_img > 0 and step % i_img == 0:      # logger.py:76-81
+            from .render import render_image
+            model.set_weights_from_trainer(trainer)
+            out["images"][step] = [render_image(renderer, val_dataset, view)[0] for view in val_dataset]
+        if i_ckpt > 0 and step % i_ckpt == 0:                               # logger.py:84-86
+            out["checkpoints"].append(trainer.save(os.path.join(ckpt_dir, f"ckpt-{step}"), step=step))
+            for old in out["checkpoints"][:-keep] if keep > 0 else []:
+                for suffix in (".index", ".data-00000-of-00001"):
+                    if os.path.exists(old + suffix):
+                        os.remove(old + suffix)
+            out["checkpoints"] = out["checkpoints"][-keep:] if keep > 0 else out["checkpoints"]
+    out["step"] = step
+    torch.cuda.synchronize(torch.device("cuda", device))
+    return out

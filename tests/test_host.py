@@ -598,6 +598,68 @@ def test_checkpoint_reader_round_trip(tmp_path):
         ck.model_weights_from_bundle(got, other.layer_table())
 
 
+def test_checkpoint_training_state_both_writers(tmp_path):
+    """train.py:55-57 saves model + step + optimizer.  The reader's training state -- weights, Adam's m / v slots per variable, optimizer/iter,
+    step, the hyper-parameters -- from a bundle made by the INDEPENDENT writer in tests/ with the key names TF2 gives them, and from the
+    product's own `write_checkpoint`; the product's file also read back key by key through the independent route (the table, the entries,
+    the string tensor of the object graph and its structure)."""
+    from nerf_tex_amd import checkpoint as ck
+    from nerf_tex_amd.model import ParamNerf
+    from tests.bundle_writer import write_bundle
+    from tests.common import EMB
+    np.random.seed(4)
+    src = ParamNerf(EMB(10), EMB(4), EMB(4), [2, 3])["model"]
+    table, ws = src.layer_table(), src.get_weights()
+    rng = np.random.default_rng(8)
+    ms = [rng.normal(size=w.shape).astype(np.float32) for w in ws]; vs = [np.square(m) for m in ms]
+    A = "/.ATTRIBUTES/VARIABLE_VALUE"
+    tensors = {"step" + A: np.asarray(4000, np.int64), "optimizer/iter" + A: np.asarray(4000, np.int64), "optimizer/beta_1" + A: np.asarray(0.9, np.float32),
+               "optimizer/beta_2" + A: np.asarray(0.999, np.float32), "optimizer/decay" + A: np.asarray(0.0, np.float32), "save_counter" + A: np.asarray(4, np.int64)}
+    for i in range(len(table)):
+        for kind, j in (("kernel", 2 * i), ("bias", 2 * i + 1)):
+            base = f"model/layer_with_weights-{i}/{kind}"
+            tensors[base + A] = ws[j]
+            tensors[base + "/.OPTIMIZER_SLOT/optimizer/m" + A] = ms[j]
+            tensors[base + "/.OPTIMIZER_SLOT/optimizer/v" + A] = vs[j]
+    write_bundle(str(tmp_path / "ckpt-4000"), tensors, block_bytes=2048)
+    st = ck.training_state_from_bundle(ck.read_bundle(str(tmp_path / "ckpt-4000")), table)
+    assert st["iterations"] == 4000 and st["step"] == 4000 and abs(st["hyper"]["beta_2"] - 0.999) < 1e-7 and "learning_rate" not in st["hyper"]
+    for got, want in ((st["weights"], ws), (st["m"], ms), (st["v"], vs)):
+        assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    only_weights = {k: v for k, v in tensors.items() if "OPTIMIZER_SLOT" not in k}
+    st2 = ck.training_state_from_bundle(only_weights, table)
+    assert st2["m"] is None and st2["v"] is None and all(np.array_equal(a, b) for a, b in zip(st2["weights"], ws))
+    # the product's writer: the same keys (a constant rate IS a variable), read back by the reader; the newest checkpoint of the directory wins
+    d = tmp_path / "run" / "checkpoints"
+    ck.write_checkpoint(str(d / "ckpt-10"), table, ws, ms, vs, iterations=10, step=10, hyper={"learning_rate": 5e-4})
+    ck.write_checkpoint(str(d / "ckpt-20"), table, ws, [2 * m for m in ms], vs, iterations=20, step=21)
+    got = ck.read_bundle(ck.latest_checkpoint(str(d)))
+    assert set(k for k in tensors) - {"optimizer/learning_rate" + A} <= set(got)
+    st3 = ck.training_state_from_bundle(got, table)
+    assert st3["iterations"] == 20 and st3["step"] == 21 and all(np.array_equal(a, 2 * b) for a, b in zip(st3["m"], ms))
+    assert "optimizer/learning_rate" + A in ck.read_bundle(str(d / "ckpt-10"))
+    assert open(d / "checkpoint").read().startswith('model_checkpoint_path: "ckpt-20"')
+    # the object graph: one string tensor; its nodes reach every variable's key, and every slot refers to its variable
+    idx = ck.read_bundle_index(str(d / "ckpt-20") + ".index")
+    e = idx["_CHECKPOINTABLE_OBJECT_GRAPH"]
+    assert e["dtype"] == ck.DT_STRING and e["shape"] == []
+    raw = open(str(d / "ckpt-20") + ".data-00000-of-00001", "rb").read()[e["offset"]:e["offset"] + e["size"]]
+    n, p0 = ck._varint(raw, 0)
+    graph = raw[p0 + 4:]
+    assert len(graph) == n and ck.mask_crc(ck.crc32c(raw[p0 + 4:], ck.crc32c(raw[p0:p0 + 4], ck.crc32c(n.to_bytes(8, "little"))))) == e["crc32c"]
+    nodes = [v for f, _, v in ck._proto_fields(graph) if f == 1]
+    keys, slots, children = set(), [], {}
+    for i, node in enumerate(nodes):
+        for f, _, v in ck._proto_fields(node):
+            sub = {ff: vv for ff, _, vv in ck._proto_fields(v)}
+            if f == 1: children.setdefault(i, []).append((sub.get(1, 0), sub[2].decode()))
+            elif f == 2: keys.add(sub[3].decode())
+            elif f == 3: slots.append((sub.get(1, 0), sub[2].decode(), sub[3]))
+    assert keys == {k for k in got if k != "_CHECKPOINTABLE_OBJECT_GRAPH"} - {"_CHECKPOINTABLE_OBJECT_GRAPH"}
+    assert sorted(name for _, name in children[0]) == ["model", "optimizer", "save_counter", "step"]
+    assert len(slots) == 4 * len(table) and {s for _, s, _ in slots} == {"m", "v"}
+
+
 def test_main_entry_point_prepares_reference_configs():
     """nerf_tex_amd.main (reference: main.py): config file -> remapped config; `--volumetric` swaps the Embree-backed
     InstanceRenderer for the volumetric Renderer; training configs are refused."""
