@@ -114,11 +114,19 @@ typedef struct ntx_model_desc_ex {
  *                  image in chunks passes the chunk's first ray as ray_index0; rank r of a shard map passes its pixel set
  *                  (r * run_length, run_length, n_ranks * run_length): the image then does not depend on how it was split. */
 typedef struct ntx_render_opts {
-    uint32_t size;
+    uint32_t size;                       /* sizeof(ntx_render_opts) of the caller's header: >= NTX_RENDER_OPTS_V3_SIZE; fields beyond `size` read as 0 */
     float raw_noise_std;
     uint64_t noise_seed;
     int64_t ray_index0, ray_run_length, ray_run_stride;
+    uint32_t flags;                      /* ABI v6: NTX_OPT_* */
+    uint32_t reserved;
 } ntx_render_opts;
+#define NTX_RENDER_OPTS_V3_SIZE 40u
+/* ntx_instancer_model_input: the rows of its [N,S,...] outputs behind a ray's last marching step -- dists == 0 there, and it is written in
+ * full -- are left UNWRITTEN in the other six (rays_d_map, pts, t, alpha_weight, instance_id, params_map) instead of holding the defaults
+ * of instancer.pyx:41-50.  For callers that hand the buffers to ntx_render_instanced, which reads a row of those only where dists > 0
+ * (renderer.py:284-288): three quarters of the bytes of a carpet frame are such defaults. */
+#define NTX_OPT_INSTANCER_SPARSE 1u
 
 /* Arithmetic of the Dense layers inside ntx_render_rays, ntx_render_instanced and ntx_mlp_forward (everything else -- encoders, heads,
  * compositing -- is float32 either way).  The reference computes in float32 (TensorFlow's default dtype, model.py:104-123):

@@ -34,14 +34,17 @@ class ModelDesc(C.Structure):
 class RenderOpts(C.Structure):
     """struct ntx_render_opts (ABI v3): raw_noise_std / noise_seed and the global ray index map of the generators"""
     _fields_ = [("size", C.c_uint32), ("raw_noise_std", C.c_float), ("noise_seed", C.c_uint64),
-                ("ray_index0", C.c_int64), ("ray_run_length", C.c_int64), ("ray_run_stride", C.c_int64)]
+                ("ray_index0", C.c_int64), ("ray_run_length", C.c_int64), ("ray_run_stride", C.c_int64), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-def render_opts(raw_noise_std: float = 0.0, noise_seed: int = 0, ray_index=None) -> "RenderOpts":
+OPT_INSTANCER_SPARSE = 1
+
+
+def render_opts(raw_noise_std: float = 0.0, noise_seed: int = 0, ray_index=None, flags: int = 0) -> "RenderOpts":
     """`ray_index` = (index0, run_length, run_stride) of the call's rays (ShardMap.pixel_set(rank)[0, 2, 3]; a chunk that starts at
     ray k0 of a larger call: (k0, n, n)), or None = the index within the call."""
     i0, run, stride = (0, 0, 0) if ray_index is None else (int(v) for v in ray_index)
-    return RenderOpts(C.sizeof(RenderOpts), float(raw_noise_std), int(noise_seed) & (2 ** 64 - 1), i0, run, stride)
+    return RenderOpts(C.sizeof(RenderOpts), float(raw_noise_std), int(noise_seed) & (2 ** 64 - 1), i0, run, stride, int(flags), 0)
 
 
 class InstancerDesc(C.Structure):

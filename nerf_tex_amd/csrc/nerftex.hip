@@ -648,7 +648,7 @@ struct IndexMap {
 static int index_map_of(const ntx_render_opts *o, IndexMap *m) {
     *m = IndexMap{0, 0, 0xffffffffu};
     if (!o) return NTX_OK;
-    if (o->size < sizeof(ntx_render_opts)) return fail(NTX_E_INVALID, "ntx_render_opts.size %u < %zu: set it to sizeof(ntx_render_opts)", o->size, sizeof(ntx_render_opts));
+    if (o->size < NTX_RENDER_OPTS_V3_SIZE) return fail(NTX_E_INVALID, "ntx_render_opts.size %u < %u: set it to sizeof(ntx_render_opts)", o->size, NTX_RENDER_OPTS_V3_SIZE);
     if (o->ray_index0 == 0 && o->ray_run_length == 0 && o->ray_run_stride == 0) return NTX_OK;
     if (o->ray_index0 < 0 || o->ray_run_length < 1 || o->ray_run_stride < o->ray_run_length)
         return fail(NTX_E_INVALID, "bad ray index map: index0 %lld run_length %lld run_stride %lld", (long long)o->ray_index0,

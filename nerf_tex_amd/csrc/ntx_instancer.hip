@@ -461,6 +461,7 @@ struct MarchArgs {
     int min_shadow, n_shadow;
     const uint8_t *kind;                       // per triangle: bit 0 = auxiliary mesh (shaded), bit 1 = primID 1 of its own mesh (shadow filter, :553)
     TexArgs tex;                               // parameter textures on the instancer mesh (getParameters, :640-667); n_tex = 0: none
+    int sparse;       // NTX_OPT_INSTANCER_SPARSE: no defaults behind a ray's last step (the rows whose dists are 0)
     int debug_skip;   // development build only (-DNTX_INST_DEBUG + NERFTEX_INST_DEBUG): leave parts of the kernel out to time the rest
 };
 
@@ -1382,12 +1383,14 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
     // ---- what instancer.pyx:41-50 leaves in the rows behind the last emitted step -----------------------------------------
     if (!NTX_DBG_SKIP(a, 1)) {
         const size_t base = (size_t)ray * S;
-        fill_pattern(a.t + base, step, S, 1, lane, [](int) { return 0.0f; });
-        fill_pattern(a.alpha_weight + base, step, S, 1, lane, [](int) { return 1.0f; });
-        fill_pattern(reinterpret_cast<float *>(a.instance_id + base), step, S, 1, lane, [](int) { return 0.0f; });
-        fill_pattern(a.pts + base * 3, step * 3, S * 3, 1, lane, [](int) { return 0.0f; });
-        fill_pattern(a.rays_d_map + base * 3, step * 3, S * 3, 3, lane, [&](int q) { return q == 0 ? dx : (q == 1 ? dy : dz); });
-        if (P > 0) fill_pattern(a.params_map + base * P, step * P, S * P, P, lane, [&](int q) { return L.par[q]; });
+        // (sparse: only the rows a consumer that goes by dists > 0 reads -- the steps the loop above did not reach, if any)
+        const int E = a.sparse ? (n_steps > step ? n_steps : step) : S;
+        fill_pattern(a.t + base, step, E, 1, lane, [](int) { return 0.0f; });
+        fill_pattern(a.alpha_weight + base, step, E, 1, lane, [](int) { return 1.0f; });
+        fill_pattern(reinterpret_cast<float *>(a.instance_id + base), step, E, 1, lane, [](int) { return 0.0f; });
+        fill_pattern(a.pts + base * 3, step * 3, E * 3, 1, lane, [](int) { return 0.0f; });
+        fill_pattern(a.rays_d_map + base * 3, step * 3, E * 3, 3, lane, [&](int q) { return q == 0 ? dx : (q == 1 ? dy : dz); });
+        if (P > 0) fill_pattern(a.params_map + base * P, step * P, E * P, P, lane, [&](int q) { return L.par[q]; });
     }
     if (lane == 0) {
         // the closing sample (:1013-1027): the instancer mesh is black and opaque, no mesh = nothing
@@ -2063,8 +2066,10 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         return ntx_set_error(NTX_E_INVALID, "NULL buffer");
     int64_t idx0 = 0, idx_stride = 0;
     uint32_t idx_run = 0xffffffffu;
+    bool sparse = false;
     if (opts) {
-        if (opts->size < sizeof(ntx_render_opts)) return ntx_set_error(NTX_E_INVALID, "ntx_render_opts.size %u < %zu", opts->size, sizeof(ntx_render_opts));
+        if (opts->size < NTX_RENDER_OPTS_V3_SIZE) return ntx_set_error(NTX_E_INVALID, "ntx_render_opts.size %u < %u", opts->size, NTX_RENDER_OPTS_V3_SIZE);
+        sparse = opts->size >= sizeof(ntx_render_opts) && (opts->flags & NTX_OPT_INSTANCER_SPARSE) != 0;
         if (!(opts->ray_index0 == 0 && opts->ray_run_length == 0 && opts->ray_run_stride == 0)) {
             if (opts->ray_index0 < 0 || opts->ray_run_length < 1 || opts->ray_run_stride < opts->ray_run_length)
                 return ntx_set_error(NTX_E_INVALID, "bad ray index map");
@@ -2104,7 +2109,7 @@ int ntx_instancer_model_input(ntx_instancer *inst, const float *rays_o, const fl
         a.color_last = color_last + c0 * 3; a.alpha_last = alpha_last + c0; a.alpha_weight = alpha_weight + so;
         a.params_map = P > 0 ? params_map + so * P : nullptr;
         a.instance_id = instance_id + so; a.hit = hit + c0; a.status = status_flag;
-        a.n_rays = n; a.n_pts = n_pts; a.n_params = P;
+        a.n_rays = n; a.n_pts = n_pts; a.n_params = P; a.sparse = sparse ? 1 : 0;
         a.light_dir_idx = inst->desc.light_dir_parameter_idx; a.light_strength_idx = inst->desc.light_strength_parameter_idx;
         a.method = inst->desc.instance_sample_method; a.use_mean = inst->desc.use_mean_distance ? 1 : 0;
         a.step_size = step_size; a.blend_range = 0.2f * inst->desc.patch_scale;

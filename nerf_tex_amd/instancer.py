@@ -239,12 +239,14 @@ class Instancer:
             json.dump([[[float(v) for v in row] for row in m] for m in self._tr], f, indent=4)
 
     def get_model_input(self, rays_o, rays_d, parameters, n_samples: int, step_size: float, seed: Optional[int] = None,
-                        ray_index=None):
+                        ray_index=None, sparse: bool = False, fill: Optional[float] = None):
         """instancer.pyx:38-54: rays_o [n,3], rays_d [n,3], parameters [n,P] -> (rays_d_map [n,S,3], pts [n,S,3], t [n,S],
         dists [n,S], color [n,1,3], density [n,1], density_weight [n,S], instance_id [n,S] int32, idxs [k,1] = where(hit),
         params_map [n,S,P]) as torch tensors on the instancer's GPU (numpy or CPU inputs are uploaded).  `seed` fixes the call's
         draws (default: the constructor's seed and a call counter), `ray_index` = (index0, run_length, run_stride) of the rays
-        in a larger image (include/nerftex.h: ntx_render_opts)."""
+        in a larger image (include/nerftex.h: ntx_render_opts).  `sparse` (NTX_OPT_INSTANCER_SPARSE): the rows behind a ray's last step
+        (dists == 0) stay unwritten in the six [n,S,...] buffers beside dists -- for `InstanceRenderer`, which reads rows with dists > 0
+        only; `fill`: what the buffers hold before the call (tests)."""
         import numpy as np
         import torch
         dev = torch.device("cuda", self.device)
@@ -254,7 +256,8 @@ class Instancer:
         par = to(parameters).reshape(n, -1) if P > 0 else None
         if P > 0 and par.shape[1] != P:
             raise ValueError(f"parameters must be [n,{P}] (the textures list has {P} entries' worth), got {tuple(parameters.shape)}")
-        e = lambda *shape, dt=torch.float32: torch.empty(shape, device=dev, dtype=dt)
+        e = lambda *shape, dt=torch.float32: (torch.empty(shape, device=dev, dtype=dt) if fill is None else
+                                              torch.full(shape, fill if dt == torch.float32 else (int(fill) if fill == fill else (255 if dt == torch.uint8 else -2 ** 31)), device=dev, dtype=dt))
         rays_d_map, pts, t, dists = e(n, S, 3), e(n, S, 3), e(n, S), e(n, S)
         color, density, weight = e(n, 1, 3), e(n, 1), e(n, S)
         instance_id, hit = e(n, S, dt=torch.int32), e(n, dt=torch.uint8)
@@ -264,7 +267,7 @@ class Instancer:
             seed = (self.seed << 32) + self._calls
             self._calls += 1
         self.last_seed = int(seed)
-        opts = _lib.render_opts(ray_index=ray_index) if ray_index is not None else None
+        opts = _lib.render_opts(ray_index=ray_index, flags=_lib.OPT_INSTANCER_SPARSE if sparse else 0) if (ray_index is not None or sparse) else None
         ptr = lambda x: x.data_ptr() if x is not None and x.numel() else None
         with torch.cuda.device(dev):
             _lib.check(_lib.lib.ntx_instancer_model_input(

@@ -281,6 +281,46 @@ def test_instance_renderer_end_to_end(npar, textures, blur, precision):
     assert want[:, 3].max() > 0.5 and (want[:, 3] > 0).sum() > 40 and np.all(got[7] == 0)
 
 
+@pytest.mark.parametrize("precision", ["float32", "fp16x3"])
+@pytest.mark.parametrize("shadows", [False, True])
+def test_sparse_hand_off_is_the_dense_one(precision, shadows):
+    """NTX_OPT_INSTANCER_SPARSE (what InstanceRenderer asks of this package's instancer): the rows behind a ray's last marching step stay
+    unwritten in six of the ten buffers -- here they hold NaN from before the call -- and the image is the image of the dense buffers bit
+    for bit, with finite numerics: the tail reads a row only where dists > 0 (renderer.py:284-288).  The buffers themselves: equal wherever
+    dists > 0, dists equal everywhere, untouched NaN behind."""
+    from nerf_tex_amd.renderer import InstanceRenderer
+    model, mspec, wts = make_model((1, 6), dense_media=True)
+    spec0 = random_scene(33, k=40, method="nearest", mesh=True)
+    box = dict(b_0=spec0.b_0.tolist(), b_1=spec0.b_1.tolist())
+    tr = [np.linalg.inv(m.astype(np.float64)).astype(F) for m in spec0.inv]
+    textures = ["", "", "", "", "light"]
+    inst = gpu_instancer(box, tr, textures=textures, instance_sampling_method="nearest", mesh=(spec0.mesh_v, spec0.mesh_f), cast_shadow_rays=shadows)
+    n, S, step = 300, 256, 0.01
+    o, d = random_rays(5, n)
+    params = np.tile(F([[1, 1, 1, .1, 0.3, 0.2, 1]]), (n, 1))
+    dense = inst.get_model_input(o, d, params, S, step, seed=9)
+    sparse = inst.get_model_input(o, d, params, S, step, seed=9, sparse=True, fill=float("nan"))
+    live = (dense[3] > 0)
+    assert torch.equal(dense[3], sparse[3]) and 0 < int(live.sum()) < live.numel() // 2
+    for k in (0, 1, 2, 6, 7, 9):                                                  # rays_d_map, pts, t, density_weight, instance_id, params_map
+        a, b = dense[k], sparse[k]
+        m = live if a.dim() == 2 else live[..., None].expand_as(a)
+        assert torch.equal(a[m], b[m])
+        if a.dtype == torch.float32:
+            assert torch.isnan(b[~m]).all()
+    for k in (4, 5, 8):
+        assert torch.equal(dense[k], sparse[k])
+    r = InstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=0.35, step_size=step, render_chunk=128, density_scale=40.0, precision=precision)
+    dv = torch.device("cuda", 0)
+    dd = lambda a: torch.as_tensor(a, device=dv)[None]
+    tt = np.tile(F([[1.0, 2.0]]), (n, 1))
+    call = lambda **kw: r(dd(o), dd(d), dd(tt), parameters=torch.as_tensor(params[:1], device=dv), cone_scale=dd(np.full((n, 1), 2e-3, F)), instancer_seed=5, **kw)
+    a = call(instancer_sparse=False)
+    b = call(instancer_fill=float("nan"))                                         # sparse is the renderer's default with this instancer
+    r.raise_if_nonfinite()
+    assert torch.equal(a["color_pred"], b["color_pred"]) and torch.equal(a["alpha_pred"], b["alpha_pred"]) and float(a["alpha_pred"].max()) > 0.5
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("NTX_INSTANCER_FUZZ_SEEDS", "16"))))     # a soak run sets more (profiles/r03/soak_instancer.txt)
 def test_fuzz_scenes_bit_for_bit(seed):
     """Random scenes, ray sets and settings (patch count, box, scales, step size, buffer length incl. too short ones, choice rule,

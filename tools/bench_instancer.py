@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--method", default="nearest")
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--no-mesh", action="store_true")
+    ap.add_argument("--sparse", action="store_true", help="NTX_OPT_INSTANCER_SPARSE: no defaults behind a ray's last step (what InstanceRenderer asks for)")
+    ap.add_argument("--dense-render", action="store_true", help="the chunk end to end with the dense ten buffers (A/B of the sparse hand-off)")
     ap.add_argument("--scale-with-grid", action="store_true", help="patch_scale and step_size * 48 / grid: the same sheet covered by smaller "
                     "patches, the same number of patches and steps along a ray whatever the grid (a scene of 10^5 patches at --grid 316)")
     ap.add_argument("--textures", type=int, default=0, metavar="N", help="a one-channel image on parameter 0, looked up on the sheet: n_texture_samples = N, "
@@ -89,16 +91,18 @@ def main():
         par[0, 4:7] = (0.9, 0.2, 0.08)                                            # a sun 5 degrees over the horizon: the waves of the sheet (slopes up to 9 degrees) shade each other
     params = torch.as_tensor(par, device=dev).repeat(a.rays, 1)
     S = a.samples
-    out = inst.get_model_input(ro, rd, params, S, a.step_size, seed=1)
+    out = inst.get_model_input(ro, rd, params, S, a.step_size, seed=1, sparse=a.sparse, fill=0.0 if a.sparse else None)   # (sparse: the rows it leaves alone read as 0 for the counts below)
     torch.cuda.synchronize()
     dists, hit = out[3], inst.last_hit
     in_patch = int((dists > 0).sum().item())
     emitted = int((out[2] > 0).sum().item())
-    ms = timed(lambda: inst.get_model_input(ro, rd, params, S, a.step_size, seed=1), a.steps)
+    ms = timed(lambda: inst.get_model_input(ro, rd, params, S, a.step_size, seed=1, sparse=a.sparse), a.steps)
     out_bytes = a.rays * S * (12 + 12 + 4 + 4 + 4 + 4 + 4 * P) + a.rays * (12 + 4 + 1)
+    if a.sparse:                                                                  # dists in full, the other six buffers where dists > 0
+        out_bytes = a.rays * S * 4 + in_patch * (12 + 12 + 4 + 4 + 4 + 4 * P) + a.rays * (12 + 4 + 1)
     in_bytes = a.rays * (24 + 4 * P)
     gbps = (out_bytes + in_bytes) / (ms * 1e-3) / 1e9
-    line = {"what": "ntx_instancer_model_input (hits + mesh + march kernels, HIP events around the call incl. the output torch.empty)",
+    line = {"what": "ntx_instancer_model_input (hits + mesh + march kernels, HIP events around the call incl. the output torch.empty)" + (", NTX_OPT_INSTANCER_SPARSE" if a.sparse else ""),
             "scene": f"{a.grid}x{a.grid} = {a.grid ** 2} patches + {0 if a.no_mesh else f.shape[0]} triangles, method {a.method}"
                      + (f", shadow rays ({a.shadows} per unit length, min 8)" if a.shadows else "")
                      + (f", a parameter texture ({a.textures} lookups per unit length, min 8)" if a.textures else ""),
@@ -108,7 +112,8 @@ def main():
             "rays_per_s": round(a.rays / (ms * 1e-3)), "in_patch_samples_per_s": round(in_patch / (ms * 1e-3)),
             "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
                          "algorithmic_bytes": out_bytes + in_bytes,
-                         "what": "every element of the ten output buffers written once ((3+3+1+1+1+1+P)*4 B per (ray, step)) + the rays read"}}
+                         "what": ("dists in full and the other six [N,S,...] buffers where dists > 0" if a.sparse else
+                                  "every element of the ten output buffers written once ((3+3+1+1+1+1+P)*4 B per (ray, step))") + " + the rays read"}}
     print(json.dumps(line), flush=True)
     if a.no_render:
         return
@@ -118,11 +123,11 @@ def main():
     r = InstanceRenderer(model=model, n_samples=S, instancer=inst, patch_scale=scale, step_size=a.step_size, render_chunk=a.rays,
                          density_scale=1.0, check_numerics=False)
     b = lambda x: x[None]
-    call = lambda: r(b(ro), b(rd), b(t), parameters=params[:1], cone_scale=b(cone), instancer_seed=1)
+    call = lambda: r(b(ro), b(rd), b(t), parameters=params[:1], cone_scale=b(cone), instancer_seed=1, instancer_sparse=not a.dense_render)
     res = call(); torch.cuda.synchronize()
     ms_all = timed(call, max(3, a.steps // 2))
     alpha = res["alpha_pred"]
-    print(json.dumps({"what": "InstanceRenderer.__call__ on one render chunk: instancer + ntx_render_instanced, nothing through the host",
+    print(json.dumps({"what": "InstanceRenderer.__call__ on one render chunk: instancer + ntx_render_instanced, nothing through the host" + (", dense hand-off" if a.dense_render else ", sparse hand-off"),
                       "rays": a.rays, "in_patch_samples": in_patch, "ms": round(ms_all, 3), "ms_instancer": round(ms, 4),
                       "instancer_share": round(ms / ms_all, 4), "in_patch_samples_per_s": round(in_patch / (ms_all * 1e-3)),
                       "mfma_frac_of_f32_peak": round(in_patch * 1361664 / (ms_all * 1e-3) / 157.3e12, 4),
