@@ -531,6 +531,12 @@ int64_t ntx_trainer_iterations(const ntx_trainer *t);
  * `train_dataset.take(n_iters - logger.step)`): Adam's iteration count -- what its bias correction and the ExponentialDecay schedule run
  * on -- is set beside the weights and moments (ntx_trainer_set). */
 int ntx_trainer_set_iterations(ntx_trainer *t, int64_t iterations);
+/* ABI v6.  A coarse and a fine pass (renderer.py:125-138, loss.py:15-16, 41-47, model.py:47-56): the coarse step also leaves the composite's
+ * weights a_i T_i -- what sample_pdf takes, with no gradient through it (:129) -- in weights_dev[N,S] (DEVICE; NULL: no more); ntx_sample_pdf
+ * places the fine depths, a step with z_vals takes them.  When both passes run on ONE network (model_fine is None, :132) its gradient is the
+ * sum of the two steps': op 0 keeps the gradient of the step just taken, op 1 adds it to the next one's. */
+int ntx_trainer_composite_weights(ntx_trainer *t, float *weights_dev);
+int ntx_trainer_stash_gradients(ntx_trainer *t, int op, ntx_stream stream);
 /* ABI v6.  ntx_set_weights from DEVICE memory (the context's device; Keras get_weights() order), in the stream's order and without a
  * host copy: the float32 weight image is remade by one gather kernel.  The validation render inside the reference's training loop
  * (logger.py:76-81 from train.py:61-70) is this with the trainer's weights (ntx_trainer_device_weights).  The fp16x3 images are NOT

@@ -152,6 +152,8 @@ SYMBOLS = {
     "ntx_trainer_set_iterations": (C.c_int, [_vp, C.c_int64]),
     "ntx_trainer_device_weights": (C.c_int, [_vp, C.POINTER(_vp)]),
     "ntx_set_weights_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "ntx_trainer_composite_weights": (C.c_int, [_vp, _vp]),
+    "ntx_trainer_stash_gradients": (C.c_int, [_vp, C.c_int, _vp]),
     "ntx_gemm_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "ntx_instancer_model_input": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_uint64, _op] + [_vp] * 12),
 }

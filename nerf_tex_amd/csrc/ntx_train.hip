@@ -393,6 +393,7 @@ struct CompositeArgs {
     const float *color_true, *alpha_true;
     int kind, loss_fn, alpha_loss_fn, filter_color_loss, use_hard_mask; float gamma;
     float *color, *alpha, *ray_loss;           // [N][3], [N], [N]: the predictions and each ray's share of the loss
+    float *weights;                            // NULL, or [N][S]: the composite's weights a_i T_i (what the importance sampler takes, renderer.py:127-128)
     float *dgrad;                              // [M][4]: dL/d raw rgb, dL/d sigma per sample (the way back starts from these)
     float *dhead;                              // the same as one O-layout tile per block of 32 samples (rows 0-2, 3): the narrow heads' dY
     long long M;
@@ -448,6 +449,7 @@ __global__ __launch_bounds__(256) void composite_loss_kernel(CompositeArgs a) {
         const float w = al[s] * T[s];
         c0 += w * rgb_of(rr[3 * s], a.map_exr); c1 += w * rgb_of(rr[3 * s + 1], a.map_exr); c2 += w * rgb_of(rr[3 * s + 2], a.map_exr);
         A += w;
+        if (a.weights) a.weights[(size_t)ray * S + s] = w;
     }
     c0 = wave_sumf(c0); c1 = wave_sumf(c1); c2 = wave_sumf(c2); A = wave_sumf(A);
     if (a.composite_bkgd) { c0 += (1.0f - A) * a.bkgd[0]; c1 += (1.0f - A) * a.bkgd[1]; c2 += (1.0f - A) * a.bkgd[2]; }   // :210-211
@@ -554,6 +556,8 @@ struct ntx_trainer {
     float *dw_partial = nullptr;
     ntx_train::ReduceBatch reduce{};           // (n_split per step)
     float *color = nullptr, *alpha_out = nullptr, *ray_loss = nullptr, *loss = nullptr;
+    float *weights_out = nullptr;              // caller's [N][S] buffer for the composite's weights of the next steps, or NULL
+    float *stash = nullptr;                    // a second gradient (ntx_trainer_stash_gradients)
     long long adam_iterations = 0;
 };
 
@@ -566,7 +570,7 @@ void free_all(ntx_trainer *t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
     void *ptrs[] = {t->w, t->grad, t->adam_m, t->adam_v, t->wfwd, t->wdx, t->aux, t->pack_seg, t->posR, t->posO, t->dirR, t->dirO, t->sigma, t->raw_rgb, t->z, t->dists, t->noise,
-                    t->dgrad, t->dhead, t->jobs, t->dw_partial, t->color, t->alpha_out, t->ray_loss, t->loss, t->act, t->bits, t->gout};
+                    t->dgrad, t->dhead, t->jobs, t->dw_partial, t->stash, t->color, t->alpha_out, t->ray_loss, t->loss, t->act, t->bits, t->gout};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete t;
 }
@@ -864,6 +868,32 @@ int ntx_trainer_set_iterations(ntx_trainer *t, int64_t iterations) {
     return NTX_OK;
 }
 
+int ntx_trainer_composite_weights(ntx_trainer *t, float *weights_dev) {
+    if (!t) return ntx_set_error(NTX_E_INVALID, "trainer is NULL");
+    t->weights_out = weights_dev;
+    return NTX_OK;
+}
+
+namespace ntx_train {
+__global__ void add_kernel(float *__restrict__ dst, const float *__restrict__ src, long long n) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) dst[e] += src[e];
+}
+}   // namespace ntx_train
+
+int ntx_trainer_stash_gradients(ntx_trainer *t, int op, ntx_stream stream) {
+    if (!t || (op != 0 && op != 1)) return ntx_set_error(NTX_E_INVALID, "trainer is NULL or op is not 0 (keep) / 1 (add back)");
+    TRAIN_TRY(hipSetDevice(t->device));
+    if (!t->stash) {
+        if (op == 1) return ntx_set_error(NTX_E_INVALID, "no gradient was kept");
+        TRAIN_TRY(hipMalloc((void **)&t->stash, t->n_weights * sizeof(float)));
+    }
+    if (op == 0) TRAIN_TRY(hipMemcpyAsync(t->stash, t->grad, t->n_weights * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    else hipLaunchKernelGGL(ntx_train::add_kernel, dim3((unsigned)((t->n_weights + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t->grad, t->stash, (long long)t->n_weights);
+    TRAIN_TRY(hipGetLastError());
+    return NTX_OK;
+}
+
 int ntx_trainer_device_weights(ntx_trainer *t, const float **weights_dev) {
     if (!t || !weights_dev) return ntx_set_error(NTX_E_INVALID, "NULL argument");
     *weights_dev = t->w;
@@ -933,6 +963,7 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
         for (int k = 0; k < 3; ++k) c.bkgd[k] = bkgd ? bkgd[k] : 1.0f;
         c.color_true = color_true; c.alpha_true = alpha_true; c.kind = loss->kind; c.loss_fn = loss->loss_fn; c.alpha_loss_fn = loss->alpha_loss_fn;
         c.filter_color_loss = loss->filter_color_loss; c.use_hard_mask = loss->use_hard_mask; c.gamma = loss->gamma;
+        c.weights = t->weights_out;
         c.color = color_pred ? color_pred : t->color; c.alpha = alpha_pred ? alpha_pred : t->alpha_out; c.ray_loss = t->ray_loss; c.dgrad = t->dgrad; c.dhead = t->dhead; c.M = M;
         hipLaunchKernelGGL(composite_loss_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, st, c);
         hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, st, t->ray_loss, (int)n_rays, loss_out ? loss_out : t->loss);

@@ -56,7 +56,8 @@ class Trainer:
         The data side (TFRecord datasets, logger, checkpoints) is not built from it: SURVEY section 2."""
         from . import util
         cfg = util.remap_reference_config(config)
-        model = util.instantiate(dict(cfg["model_config"]))["model"]
+        models = util.instantiate(dict(cfg["model_config"]))                     # {'model': ...} or CoarseFine's {'model': ..., 'model_fine': ...}
+        model = models["model"] if "model" in models else next(iter(models.values()))
         if weights is not None:
             model.set_weights(weights) if isinstance(weights, (list, tuple)) else model.set_blob(weights)
         loss = util.instantiate(dict(cfg["loss_config"]))
@@ -65,14 +66,16 @@ class Trainer:
             r.pop(k, None)
         n_samples = int(r.pop("n_samples", 64))                                   # renderer.py:34 default
         known = {k: r.pop(k) for k in ("perturb", "raw_noise_std", "blur_idx", "map_exr") if k in r}
-        if r.pop("n_importance", 0):
-            raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, "training with n_importance > 0 (a coarse and a fine network) is not built")
+        n_importance = int(r.pop("n_importance", 0))
         if r:
             raise TypeError(f"renderer_config keys without a meaning in a training step: {sorted(r)}")
         if max_rays is None:
             ds = cfg.get("train_dataset_config") or {}
             max_rays = int(cfg.get("batchsize", ds.get("batchsize", 1))) * int(cfg.get("rays_per_image", (ds.get("pixel_sampler_config") or {}).get("n_samples", 1024)))
-        return cls(model, max_rays=max_rays, n_samples=n_samples, lrate=cfg.get("lrate", 5e-4), lrate_decay=cfg.get("lrate_decay", 0), device=device, **known), loss
+        kw = dict(max_rays=max_rays, n_samples=n_samples, lrate=cfg.get("lrate", 5e-4), lrate_decay=cfg.get("lrate_decay", 0), device=device, **known)
+        if n_importance > 0:                                                    # renderer.py:125-138: a coarse and a fine pass
+            return CoarseFineTrainer(model, models.get(model.name + "_fine"), n_importance=n_importance, **kw), loss
+        return cls(model, **kw), loss
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -164,11 +167,12 @@ class Trainer:
         return {"prefix": prefix, "step": st["step"], "iterations": it}
 
     def gradients_step(self, rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, loss, composite_bkgd: bool = False, bkgd_color=(1., 1., 1.),
-                       seed: Optional[int] = None, z_vals=None, rays_per_param_row: int = 1):
+                       seed: Optional[int] = None, z_vals=None, rays_per_param_row: int = 1, n_samples: Optional[int] = None):
         """Forward + loss + gradients (train.py:61-66): rays_o / rays_d [N,3], t [N,2] (inf for a ray that misses the proxy: it predicts 0 / the
         background and counts in the loss, renderer.py:58-86), parameters [rows,P],
         cone_scale [N] or [N,1], color_true [N,3], alpha_true [N]; `loss`: a nerf_tex_amd.loss object.  Returns (loss [1], color_pred [N,3],
-        alpha_pred [N]) as GPU tensors; the gradients stay in the trainer."""
+        alpha_pred [N]) as GPU tensors; the gradients stay in the trainer.  `z_vals` [N, n_samples]: given sample depths (`n_samples` of them,
+        default the trainer's) instead of the ones placed between t."""
         import torch
         dev = torch.device("cuda", self.device)
         to = lambda a: None if a is None else (a if isinstance(a, torch.Tensor) else torch.as_tensor(a)).to(device=dev, dtype=torch.float32).contiguous()
@@ -188,7 +192,7 @@ class Trainer:
         ptr = lambda x: x.data_ptr() if x is not None and x.numel() else None
         with torch.cuda.device(dev):
             _lib.check(_lib.lib.ntx_train_step_gradients(
-                self._h, ptr(rays_o), ptr(rays_d), ptr(t), ptr(parameters), int(rays_per_param_row), ptr(cone_scale), n, self.n_samples,
+                self._h, ptr(rays_o), ptr(rays_d), ptr(t), ptr(parameters), int(rays_per_param_row), ptr(cone_scale), n, int(n_samples or self.n_samples),
                 -1 if self.blur_idx is None else int(self.blur_idx), flags, _lib.f3(bkgd_color), int(seed) & (2 ** 64 - 1), opts, ptr(z_vals), ptr(color_true), ptr(alpha_true),
                 C.byref(desc), ptr(color), ptr(alpha), ptr(val), torch.cuda.current_stream(dev).cuda_stream))
         return val, color, alpha
@@ -249,6 +253,94 @@ class Trainer:
         return val
 
 
+class CoarseFineTrainer:
+    """Training with `n_importance > 0` (renderer.py:125-138, loss.py:15-16, 41-47, model.py:47-56): a coarse pass on `n_samples` depths, the
+    importance sampler on its composite weights (sample_pdf, no gradient through it: `tf.stop_gradient`, :129), a fine pass on the
+    n_samples + n_importance merged depths by `model_fine` -- or by the same network when there is none (:132) -- and the loss of both
+    passes added up.  Two networks take one step each, on their own gradients; one network takes one step on the sum of the two passes'.
+    Every piece is the C ABI's: two `ntx_train_step_gradients` (the coarse one also leaves the weights: `ntx_trainer_composite_weights`),
+    `ntx_sample_pdf` between them, `ntx_trainer_stash_gradients` for the shared network."""
+
+    def __init__(self, model, model_fine=None, max_rays: int = 1024, n_samples: int = 64, n_importance: int = 64, **kw) -> None:
+        self.n_samples, self.n_importance, self.shared = int(n_samples), int(n_importance), model_fine is None
+        if self.n_importance < 1:
+            raise ValueError("n_importance must be >= 1 (a plain Trainer otherwise)")
+        total = self.n_samples + self.n_importance
+        self.fine = Trainer(model if self.shared else model_fine, max_rays=max_rays, n_samples=total, **kw)
+        self.coarse = self.fine if self.shared else Trainer(model, max_rays=max_rays, n_samples=self.n_samples, **kw)
+        self.model, self.model_fine, self.device, self.perturb = model, model_fine, self.fine.device, self.fine.perturb
+        self._calls = 0
+
+    @property
+    def trainers(self):
+        return (self.fine,) if self.shared else (self.coarse, self.fine)
+
+    @property
+    def iterations(self) -> int:
+        return self.fine.iterations
+
+    def gradients_step(self, rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, loss, composite_bkgd: bool = False, bkgd_color=(1., 1., 1.),
+                       seed: Optional[int] = None, rays_per_param_row: int = 1, u=None, on_coarse=None):
+        """Both passes and their gradients.  Returns (loss [1] = fine + coarse, color_pred, alpha_pred, color_pred_coarse, alpha_pred_coarse).
+        `u` [N, n_importance]: the sampler's uniform draws when perturb is off (renderer.py:128 `det=self.perturb`: with perturb they are
+        tf.linspace); default: torch's generator under `seed`.  `on_coarse()`: called between the passes (tests read the coarse activations)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        to = lambda a: None if a is None else (a if isinstance(a, torch.Tensor) else torch.as_tensor(a)).to(device=dev, dtype=torch.float32).contiguous()
+        rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true = (to(a) for a in (rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true))
+        n, S, NI = rays_o.reshape(-1, 3).shape[0], self.n_samples, self.n_importance
+        if seed is None:
+            seed = self._calls
+        self._calls += 1
+        wts = torch.empty((n, S), device=dev)
+        _lib.check(_lib.lib.ntx_trainer_composite_weights(self.coarse._h, wts.data_ptr()))
+        try:
+            val_c, cc, ac = self.coarse.gradients_step(rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, loss, composite_bkgd=composite_bkgd,
+                                                       bkgd_color=bkgd_color, seed=seed, rays_per_param_row=rays_per_param_row, n_samples=S)
+        finally:
+            _lib.check(_lib.lib.ntx_trainer_composite_weights(self.coarse._h, None))
+        if on_coarse is not None:
+            on_coarse()
+        if not self.perturb and u is None:
+            u = torch.rand((n, NI), device=dev, generator=torch.Generator(device=dev).manual_seed(int(seed) & (2 ** 63 - 1)))
+        u = None if self.perturb else to(u).reshape(n, NI).contiguous()
+        z_all = torch.empty((n, S + NI), device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.ntx_sample_pdf(t.data_ptr(), None, wts.data_ptr(), u.data_ptr() if u is not None else None, n, S, NI,
+                                               _lib.FLAG_PERTURB if self.perturb else 0, int(seed) & (2 ** 64 - 1), None, z_all.data_ptr(), stream))
+            if self.shared:
+                _lib.check(_lib.lib.ntx_trainer_stash_gradients(self.fine._h, 0, stream))
+        val_f, cf, af = self.fine.gradients_step(rays_o, rays_d, t, parameters, cone_scale, color_true, alpha_true, loss, composite_bkgd=composite_bkgd,
+                                                 bkgd_color=bkgd_color, seed=seed, z_vals=z_all, rays_per_param_row=rays_per_param_row, n_samples=S + NI)
+        if self.shared:
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib.ntx_trainer_stash_gradients(self.fine._h, 1, stream))
+        self.last_z = z_all
+        return val_f + val_c, cf, af, cc, ac
+
+    def apply_gradients(self) -> None:
+        for tr in self.trainers:
+            tr.apply_gradients()
+
+    def step(self, *args, **kwargs):
+        val = self.gradients_step(*args, **kwargs)[0]
+        self.apply_gradients()
+        return val
+
+    def train_step(self, data: dict, loss, composite_bkgd: bool = False, bkgd_color=(1., 1., 1.), seed: Optional[int] = None) -> dict:
+        """`Trainer.train_step` on the reference's batch dict; the predictions carry the coarse pass's too, as Renderer.render_rays returns them (:138)."""
+        import torch
+        as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+        ro = as_t(data["rays_o"]); B, R = int(ro.shape[0]), int(ro.shape[1])
+        flat = lambda k, w: as_t(data[k]).reshape(B * R, w) if w else as_t(data[k]).reshape(B * R)
+        alpha = flat("alpha", 0) if data.get("alpha") is not None else None
+        val, c, a, cc, ac = self.gradients_step(flat("rays_o", 3), flat("rays_d", 3), flat("t", 2), as_t(data["parameters"]).reshape(B, -1), flat("cone_scale", 0),
+                                                flat("color", 3), alpha, loss, composite_bkgd=composite_bkgd, bkgd_color=bkgd_color, seed=seed, rays_per_param_row=R)
+        self.apply_gradients()
+        return {"loss": val, "color_pred": c.reshape(B, R, 3), "alpha_pred": a.reshape(B, R), "color_pred_coarse": cc.reshape(B, R, 3), "alpha_pred_coarse": ac.reshape(B, R)}
+
+
 def allreduce_mean_host(values, group=None):
     """The mean over the ranks of a float32 vector, through torch.distributed on host memory (sum in the backend's order, then / world)."""
     import numpy as np
@@ -294,6 +386,8 @@ def Train(target_path: str, train_dataset, val_dataset=None, model_config: dict 
         first = next(iter(train_dataset))
         max_rays = int(first["rays_o"].shape[0]) * int(first["rays_o"].shape[1])
     trainer, loss_fn = Trainer.from_config(cfg, max_rays=max_rays, device=device, weights=weights)
+    if isinstance(trainer, CoarseFineTrainer):
+        raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, "Train: the loop (checkpoints, validation renders) is built for one network; step a CoarseFineTrainer directly")
     model = trainer.model
     rcfg = {k: v for k, v in dict(cfg["renderer_config"]).items() if k != "module"}
     renderer = Renderer(model=model, **rcfg)

@@ -171,3 +171,24 @@ def step_gradients_chunked(w_np, spec, rays_o, rays_d, z, parameters, cone_scale
         grads = [x * wgt for x in g] if grads is None else [acc + x * wgt for acc, x in zip(grads, g)]
         cs.append(c); al.append(a)
     return total, np.concatenate(cs), np.concatenate(al), grads
+
+
+def step_gradients_coarse_fine(w_coarse_np, w_fine_np, spec, rays_o, rays_d, z_coarse, z_fine, parameters, cone_scale, color_true, alpha_true, loss,
+                               masks_coarse=None, sigma_mask_coarse=None, masks_fine=None, sigma_mask_fine=None, noise_coarse=None, noise_fine=None, dtype=torch.float64, **kw):
+    """A step with n_importance > 0 (renderer.py:125-138, loss.py:15-16, 41-47): the coarse pass on z_coarse, the fine pass on z_fine -- GIVEN:
+    the sampler carries no gradient (`tf.stop_gradient`, :129) and is restated and tested on its own (nerftex_oracle.sample_pdf) --, the
+    loss of both added.  w_fine_np None: one network runs both passes (model_fine is None, :132) and its gradient is the sum.
+    Returns (loss, (color, alpha) fine, (color, alpha) coarse, gradients of the coarse network, of the fine one (None when shared))."""
+    t_ = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=dtype)
+    wc = [torch.tensor(np.asarray(a), dtype=dtype, requires_grad=True) for a in w_coarse_np]
+    wf = wc if w_fine_np is None else [torch.tensor(np.asarray(a), dtype=dtype, requires_grad=True) for a in w_fine_np]
+    mk = lambda m: None if m is None else [t_(x) for x in m]
+    args = (t_(rays_o), t_(rays_d))
+    c1, a1 = render(wc, spec, *args, t_(z_coarse), t_(parameters), t_(cone_scale), masks=mk(masks_coarse), sigma_mask=t_(sigma_mask_coarse), noise=t_(noise_coarse), **kw)
+    c2, a2 = render(wf, spec, *args, t_(z_fine), t_(parameters), t_(cone_scale), masks=mk(masks_fine), sigma_mask=t_(sigma_mask_fine), noise=t_(noise_fine), **kw)
+    lk = {k: v for k, v in loss.items() if k != "kind"}
+    one = (lambda c, a: nerf_loss(t_(color_true), c, **lk)) if loss["kind"] == "nerf" else (lambda c, a: alpha_loss(t_(color_true), t_(alpha_true), c, a, **lk))
+    val = one(c2, a2) + one(c1, a1)
+    val.backward()
+    g = lambda w: [x.grad.numpy() for x in w]
+    return float(val.detach()), (c2.detach().numpy(), a2.detach().numpy()), (c1.detach().numpy(), a1.detach().numpy()), g(wc), None if w_fine_np is None else g(wf)

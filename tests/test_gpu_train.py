@@ -530,3 +530,75 @@ def test_train_loop_renders_validation_views_and_checkpoints(tmp_path):
     assert torch.equal(again, out["images"][200][0])
     more = Train(str(tmp_path), Batches(), None, n_iters=230, logger_config=dict(i_print=10, i_img=0, i_checkpoint=0), **common)
     assert more["step"] == 230 and more["trainer"].iterations == 230 and [s for s, _ in more["loss"]] == [210, 220, 230]
+
+
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("perturb", [True, False])
+def test_coarse_and_fine_training(shared, perturb):
+    """n_importance > 0 (renderer.py:125-138, loss.py:41-47, model.py:47-56): the coarse pass, the importance sampler on its weights (no
+    gradient through it), the fine pass on the merged depths by a second network -- or by the same one, whose gradient is then the sum of
+    both passes' --, the loss of both added.  Losses, all four predictions and every layer's gradient of both networks against float64
+    autograd of the two passes on the depths the step itself placed; the fine depths are the coarse ones merged with the restated sampler's
+    (within its own conditioning, tests/test_gpu_parity.py)."""
+    from nerf_tex_amd.train import CoarseFineTrainer
+    model, spec, wts = make_model((1, 6), dense_media=True)
+    fine, _, wts_f = make_model((1, 6), seed=3, dense_media=True)
+    n, S, NI = 72, 24, 16
+    ro, rd, t, cone, params, color, alpha = batch(14, n, S, 7, "carpet")
+    okw, loss = make_loss("alpha_smape")
+    tr = CoarseFineTrainer(model, None if shared else fine, max_rays=n, n_samples=S, n_importance=NI, perturb=perturb)
+    kept = {}
+    M, MF = n * S, n * (S + NI)
+    def on_coarse():
+        torch.cuda.synchronize()
+        kept["masks"] = [(tr.coarse.activation(k, M) > 0).astype(np.float64) for k in list(range(8)) + [8, 9]]
+        kept["sigma"] = (tr.coarse.activation(10, M).reshape(n, S) > 0).astype(np.float64)
+        kept["grad"] = tr.coarse.gradients()
+    val, cf, af, cc, ac = tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss, seed=6, on_coarse=on_coarse)
+    torch.cuda.synchronize()
+    z_c = orc.z_values_perturbed(t, S, 6, np.float32) if perturb else orc.z_values(t, S, np.float32)
+    z_f = tr.last_z.cpu().numpy()
+    assert z_f.shape == (n, S + NI) and (np.diff(z_f, axis=-1) >= 0).all()
+    merged = np.sort(np.concatenate([z_c, z_f], -1), -1)                          # every coarse depth is among the fine ones
+    assert all(np.isin(z_c[r], z_f[r]).all() for r in range(n)) and merged.shape[1] == 2 * S + NI
+    masks_f = [(tr.fine.activation(k, MF) > 0).astype(np.float64) for k in list(range(8)) + [8, 9]]
+    sigma_f = (tr.fine.activation(10, MF).reshape(n, S + NI) > 0).astype(np.float64)
+    want, (wc2, wa2), (wc1, wa1), g_c, g_f = tro.step_gradients_coarse_fine(wts, None if shared else wts_f, spec, ro, rd, z_c, z_f, params, cone, color, alpha, okw,
+                                                                              masks_coarse=kept["masks"], sigma_mask_coarse=kept["sigma"], masks_fine=masks_f, sigma_mask_fine=sigma_f)
+    assert abs(float(val.item()) - want) <= 1e-5 * abs(want)
+    pred = lambda c, a: np.concatenate([c.cpu().numpy(), a.cpu().numpy()[:, None]], -1)
+    assert orc.rel_linf(pred(cf, af), np.concatenate([wc2, wa2[:, None]], -1)) <= 1e-4 and orc.rel_linf(pred(cc, ac), np.concatenate([wc1, wa1[:, None]], -1)) <= 1e-4
+    flat = lambda g: np.concatenate([x.ravel() for x in g])
+    # The merged depths hold pairs a hair apart (a sampled depth beside a coarse one): 1 - exp(-sigma dist) at dist ~ 1e-6 of the ray carries a
+    # float32 sigma's rounding a long way, and the density head's gradient is a sum of such terms.  The bar is 1e-4 or four times what float32
+    # AUTOGRAD of the same restatement with the same branches is off by (the float32 floor of the comparison, measured beside it).
+    _, _, _, f_c, f_f = tro.step_gradients_coarse_fine(wts, None if shared else wts_f, spec, ro, rd, z_c, z_f, params, cone, color, alpha, okw, masks_coarse=kept["masks"],
+                                                       sigma_mask_coarse=kept["sigma"], masks_fine=masks_f, sigma_mask_fine=sigma_f, dtype=torch.float32)
+    checks = [(tr.fine.gradients(), flat(g_c), flat(f_c))] if shared else [(tr.coarse.gradients(), flat(g_c), flat(f_c)), (tr.fine.gradients(), flat(g_f), flat(f_f))]
+    for got, wantg, f32 in checks:
+        assert np.abs(wantg).max() > 1e-6
+        for name, sl in layer_slices(spec):
+            floor = rel_linf(f32[sl], wantg[sl])
+            assert rel_linf(got[sl], wantg[sl]) <= max(1e-4, 4 * floor), (name, rel_linf(got[sl], wantg[sl]), floor)
+    if shared:
+        assert not np.array_equal(kept["grad"], tr.fine.gradients())             # the coarse pass's gradient alone is not the step's
+    w0 = [x.weights() for x in tr.trainers]
+    tr.apply_gradients()
+    assert all(x.iterations == 1 for x in tr.trainers) and all(not np.array_equal(a, x.weights()) for a, x in zip(w0, tr.trainers))
+
+
+def test_coarse_fine_trainer_from_a_config():
+    """`Trainer.from_config` on a reference-format config with n_importance and network.model.CoarseFine: two networks, two trainers."""
+    import json, os
+    from nerf_tex_amd.train import CoarseFineTrainer, Trainer
+    cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "train_configs.json")))["carpet"]
+    cfg = dict(cfg, model_config={"module": "network.model.CoarseFine", "model_config": dict(cfg["model_config"])},
+               renderer_config=dict(cfg["renderer_config"], n_samples=32, n_importance=16))
+    tr, loss = Trainer.from_config(cfg, max_rays=64)
+    assert isinstance(tr, CoarseFineTrainer) and not tr.shared and tr.n_samples == 32 and tr.n_importance == 16 and tr.model_fine.name == "model_fine"
+    B, R = 2, 32
+    ro, rd, t, cone, params, color, alpha = batch(3, B * R, 32, 7, "carpet")
+    data = dict(rays_o=ro.reshape(B, R, 3), rays_d=rd.reshape(B, R, 3), t=t.reshape(B, R, 2), cone_scale=cone.reshape(B, R, 1), parameters=params[::R].copy(),
+                color=color.reshape(B, R, 3), alpha=alpha.reshape(B, R))
+    out = tr.train_step(data, loss)
+    assert sorted(out) == ["alpha_pred", "alpha_pred_coarse", "color_pred", "color_pred_coarse", "loss"] and np.isfinite(float(out["loss"].item())) and tr.iterations == 1

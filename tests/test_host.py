@@ -802,7 +802,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     src.write_text('#include "nerftex.h"\n#include <stdio.h>\n'
                    'int main(void) {\n'
                    '    ntx_model_desc d = {NTX_MODEL_PARAMNERF, 1, 6, 3, 10, 4, 4, 8, 256, 4, 1, NTX_POS_FOURIER};\n'
-                   '    ntx_render_opts o = {sizeof(ntx_render_opts), 0.5f, 7u, 100, 800, 6400};\n'
+                   '    ntx_render_opts o = {sizeof(ntx_render_opts), 0.5f, 7u, 100, 800, 6400, 0u, 0u};\n'
                    '    ntx_instancer_desc q = {sizeof(ntx_instancer_desc), {-1, -1, -1}, {1, 1, 1}, 7, 4, -1, 1, 0, 0, 1.0f, 8, 256};\n'
                    '    float texel = 0.5f; ntx_texture tx = {&texel, 1, 1};\n'
                    '    if (ntx_instancer_count(NULL) != -1 || q.n_parameters != 7 || tx.rows != 1) return 3;\n'
@@ -818,7 +818,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                     "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     # 803 rows of 800 over 8 ranks: ranks 0-2 hold 101 rows, the others 100 -> exact-count Send/Recv into staging, blocks at r * 80800
-    assert out == ["6", "683524", "80000", "80800", str(7 * 80800), "0", "0", "40"]
+    assert out == ["6", "683524", "80000", "80800", str(7 * 80800), "0", "0", "48"]
 
 
 def test_instancer_host_side(tmp_path):
