@@ -135,7 +135,7 @@ def measured_traffic(workload: str, precision: str = "float32"):
 
 def train_step_traffic():
     """HBM-side bytes of ONE training step (every kernel of the trainer: WRITE_SIZE + 2 x FETCH_SIZE per launch x launches a step) from the newest
-    committed rocprofv3 summary of `bench.py --workload carpet_train_step` (profiles/r*/train_step_pmc_summary.json, tools/dev/r4_train_profiles.sh),
+    committed rocprofv3 summary of `bench.py --workload carpet_train_step` (profiles/r*/train_step_pmc_summary.json, tools/dev/r5_train_profiles.sh),
     quoted like `measured_traffic` quotes the render kernel's."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "train_step_pmc_summary.json")))
@@ -154,6 +154,22 @@ def train_step_traffic():
         pass
     return {"traffic": total, "traffic_unit": "bytes per training step, all kernels (HBM side, rocprofv3 PMC)", "traffic_source": os.path.relpath(files[-1], ROOT),
             "traffic_profile_head": tree[1] if len(tree) > 1 and tree[1] != "None" else None, "traffic_profile_current": cur}
+
+
+def train_step_algorithmic_bytes(model, n_samples_total: int) -> int:
+    """HBM bytes a stored-activation training step cannot do without, per the layout of ntx_train_device.h: per sample, the eleven stored layer
+    outputs (10 x 256 + 128 floats) and the eleven stored gradients written once and read once by the weight gradients; pos_map / dir_map
+    (padded to tiles of 32 rows) written in row order and in O layout, the row copy read three times by the chain (layer 0, the skip, the colour
+    layer's concatenation) and the O copy by the weight gradients (pos_map twice: layer 0 and the skip); the heads' 4 + 16 floats; weights and
+    moments are 2.7 MB and do not count."""
+    kp = -(-model.pos_map_dim // 32) * 32
+    kd = -(-model.dir_map_dim // 32) * 32
+    acts = 10 * 256 + 128
+    per_sample = 4 * (2 * acts                       # forward outputs: written, read by dW
+                      + 2 * acts                     # gradients at them: written, read by dW
+                      + 2 * (kp + kd) + (2 * kp + kd) + (2 * kp + kd)      # encodings: two copies written, row copy read by the chain, O copy by dW
+                      + 4 + 4 + 4 + 32 + 32)         # raw rgb / sigma written and read, the composite's adjoint written (plain and as a tile) and read
+    return int(per_sample * n_samples_total)
 
 
 def instancer_traffic():
@@ -366,7 +382,11 @@ def bench_train_step(args) -> None:
                        "loss_after": float(val.item())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                          **train_step_traffic(),
-                         "kernel": "ntx_train::rows_kernel (forward and dX: two chains of ten layers + the 128-wide colour layer) + ntx_train::gemm_batch_kernel (dW of all twelve layers)", "kernel_ms": step_ms,
+                         "algorithmic_bytes": train_step_algorithmic_bytes(model, n * S),
+                         "algorithmic_bytes_what": "a stored-activation step: every layer's output and the gradient at it written once (O layout) and read once by the weight "
+                                                   "gradients, the encoded inputs written in both orders and read by the chain and by the weight gradients (DESIGN section 10)",
+                         "kernel": "ntx_train::fwd_chain_kernel + dx_chain_kernel (the network forward and back with a block's activations in registers from layer to layer) "
+                                   "+ dw_kernel (dW of every layer from the operand-order stores, persistent workgroups with an equal share each)", "kernel_ms": step_ms,
                          "what": "3 x forward FLOPs (2 MACs per weight per sample) over the WHOLE step's HIP-event time: encoders, heads, composite, loss and Adam included"}}
     if not args.no_cpu_baseline and world == 1:
         from oracle import nerftex_oracle as orc

@@ -977,7 +977,35 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     {   // every layer's dW = X^T . dY and db = the column sums of dY in one launch of one workgroup per CU, each with an equal share of the work ...
         DwArgs d{}; d.jobs = t->jobs; d.n_jobs = t->n_jobs; d.n_blocks = n_blocks; d.total_cost = t->total_cost; d.partial = t->dw_partial;
         const long long G = t->cus, W = t->total_cost * n_blocks;
+#ifdef NTX_TRAIN_CLOCKS
+        static unsigned long long *clocks = nullptr;
+        const size_t nck = (size_t)G * (2 + 3 * t->n_jobs);
+        if (getenv("NERFTEX_DW_CLOCKS")) {
+            if (!clocks) (void)hipMalloc((void **)&clocks, nck * sizeof(unsigned long long));
+            (void)hipMemsetAsync(clocks, 0, nck * sizeof(unsigned long long), st);
+            d.clocks = clocks;
+        }
+#endif
         launch_dw(st, (unsigned)G, d);
+#ifdef NTX_TRAIN_CLOCKS
+        if (d.clocks) {     // development: every workgroup's pieces, in 100 MHz ticks from the earliest start
+            std::vector<unsigned long long> h(nck);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h.data(), clocks, nck * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull;
+            for (long long g = 0; g < G; ++g) t0 = std::min(t0, h[g * (2 + 3 * t->n_jobs)]);
+            FILE *f = fopen(getenv("NERFTEX_DW_CLOCKS"), "w");
+            if (f) {
+                for (long long g = 0; g < G; ++g) {
+                    const unsigned long long *c = &h[g * (2 + 3 * t->n_jobs)];
+                    fprintf(f, "%lld %llu %llu", g, c[0] - t0, c[1] - t0);
+                    for (int j = 0; j < t->n_jobs; ++j) if (c[4 + 3 * j]) fprintf(f, "  j%d cost %d blocks %llu %llu-%llu", j, t->jobs_host[j].cost, c[2 + 3 * j], c[3 + 3 * j] - t0, c[4 + 3 * j] - t0);
+                    fprintf(f, "\n");
+                }
+                fclose(f);
+            }
+        }
+#endif
         // ... and the slots every job filled added up in a fixed order
         ReduceBatch rb = t->reduce;
         std::vector<int> slots(t->n_jobs);

@@ -453,7 +453,8 @@ struct DwWave {
     long long bias_out;                                // -1, or within the slot: [2][c_hi - c_lo], the column sums of dY (two halves of the samples)
 };
 struct DwJob { DwWave w[4]; int cost; long long slot_floats, first_float; };      // first_float: the job's slot 0 in the partial buffer
-struct DwArgs { const DwJob *jobs; int n_jobs, n_blocks; long long total_cost; float *partial; };     // total_cost: sum of the jobs' costs (per block)
+struct DwArgs { const DwJob *jobs; int n_jobs, n_blocks; long long total_cost; float *partial;      // total_cost: sum of the jobs' costs (per block)
+                unsigned long long *clocks; };   // development builds (-DNTX_TRAIN_CLOCKS): [workgroup][2 + 3 n_jobs] wall clock at start / end and per piece (blocks, start, end)
 
 // the split, on both sides (the reduction has to know how many slots a job filled)
 __host__ __device__ inline long long dw_cut(long long g, long long G, long long W, long long start, long long cost, long long n_blocks) {
@@ -543,6 +544,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long g = blockIdx.x, G = gridDim.x, W = a.total_cost * a.n_blocks;
     long long start = 0;
+#ifdef NTX_TRAIN_CLOCKS
+    unsigned long long *ck = a.clocks ? a.clocks + (size_t)blockIdx.x * (2 + 3 * a.n_jobs) : nullptr;
+    if (ck && threadIdx.x == 0) ck[0] = wall_clock64();
+#endif
     for (int jn = 0; jn < a.n_jobs; ++jn) {
         const DwJob &job = a.jobs[jn];
         const long long cost = job.cost, span = cost * a.n_blocks;
@@ -554,12 +559,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int shape = __builtin_amdgcn_readfirstlane(wv.shape);
             const int my_slot = __builtin_amdgcn_readfirstlane((int)(g - g0));
             float *slot = a.partial + job.first_float + (long long)my_slot * job.slot_floats;
+#ifdef NTX_TRAIN_CLOCKS
+            const unsigned long long c0 = wall_clock64();
+#endif
             if (shape == 0) dw_piece<4, 4>(wv, slot, blk0, blk1, lane);
             else if (shape == 1) dw_piece<3, 4>(wv, slot, blk0, blk1, lane);
             else if (shape == 2) dw_piece<4, 1>(wv, slot, blk0, blk1, lane);
+#ifdef NTX_TRAIN_CLOCKS
+            __syncthreads();
+            if (ck && threadIdx.x == 0) { ck[2 + 3 * jn] = (unsigned long long)(blk1 - blk0); ck[3 + 3 * jn] = c0; ck[4 + 3 * jn] = wall_clock64(); }
+#endif
         }
         start += span;
     }
+#ifdef NTX_TRAIN_CLOCKS
+    if (ck && threadIdx.x == 0) ck[1] = wall_clock64();
+#endif
 }
 #endif   // NTX_TRAIN_DW
 

@@ -127,16 +127,11 @@ def test_train_config_fixture_is_what_the_trainer_is_built_from():
 
 
 def test_from_config_refuses_what_a_step_does_not_do():
-    """`Trainer.from_config` on a config's blocks: a coarse + fine step (n_importance > 0) is refused, a renderer key without a meaning in a
-    training step is an error -- both before any device is touched."""
+    """`Trainer.from_config` on a config's blocks: a renderer key without a meaning in a training step is an error, and so is the `Train` loop
+    on a coarse + fine configuration (n_importance > 0 is a `CoarseFineTrainer`'s: tests/test_gpu_train.py) -- before any device is touched."""
     import copy, json, os
-    from nerf_tex_amd import _lib
     from nerf_tex_amd.train import Trainer
     cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "train_configs.json")))["carpet"]
-    c = copy.deepcopy(cfg); c["renderer_config"]["n_importance"] = 64
-    with pytest.raises(_lib.NtxError) as e:
-        Trainer.from_config(c)
-    assert e.value.code == _lib.NTX_E_UNSUPPORTED
     c = copy.deepcopy(cfg); c["renderer_config"]["no_such_key"] = 1
     with pytest.raises(TypeError):
         Trainer.from_config(c)
