@@ -738,7 +738,7 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
         DwWave &d = jobs[j].w[w];
         d.A = A; d.rtA = rtA; d.a0 = a0; d.B = B; d.rtB = rtB; d.b0 = b0; d.shape = shape; d.out = at; d.ldc = N; d.row0 = a0 * 32; d.rows_valid = K;
         d.col0 = b0 * 32; d.c_lo = c_lo; d.c_hi = c_lo + N; d.bias_out = a0 == 0 ? at_bias : -1;
-        const int cost = shape == 0 ? 256 : shape == 1 ? 192 : 64;             // MFMAs per block of 32 samples: 16 k-steps x tiles
+        const int cost = shape == 0 ? 256 : shape == 1 ? 192 : 66;             // MFMAs per block of 32 samples: 16 k-steps x tiles (the narrow shape: 64, and 3 % for its loads -- five tiles for four tiles of work -- as measured)
         if (cost > jobs[j].cost) jobs[j].cost = cost;
     };
     // a 256 x 256 layer: wave w takes X tiles 4 (w >> 1) .., dY tiles 4 (w & 1) ..

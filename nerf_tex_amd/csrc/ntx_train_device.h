@@ -519,23 +519,34 @@ TRN_DEV void dw_piece(const DwWave &tg, float *slot, int blk0, int blk1, int lan
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // D of a tile: lane l, register r <-> row 8 (r >> 2) + (r & 3) + 4 (l >> 5), column l & 31
+    // D of a tile: lane l, register r <-> row 8 (r >> 2) + (r & 3) + 4 (l >> 5), column l & 31.  What of a tile exists is a matter of
+    // offsets, not of branches: a row or column beyond the matrix gets an offset beyond the buffer, and the hardware drops the store.
     const int j = lane & 31, hh = lane >> 5;
-    float *out = slot + tg.out;
-    static_for<NA>([&](auto Ai) { static_for<NB>([&](auto Bi) {
-        const int col = tg.col0 + 32 * decltype(Bi)::value + j;
-        static_for<16>([&](auto R) {
-            constexpr int r = R;
-            const int row = tg.row0 + 32 * decltype(Ai)::value + 8 * (r >> 2) + (r & 3) + 4 * hh;
-            if (row < tg.rows_valid && col >= tg.c_lo && col < tg.c_hi) out[(size_t)row * tg.ldc + (col - tg.c_lo)] = acc[Ai][Bi][r];
+    const int ldc = __builtin_amdgcn_readfirstlane(tg.ldc), row0 = __builtin_amdgcn_readfirstlane(tg.row0), rows_valid = __builtin_amdgcn_readfirstlane(tg.rows_valid);
+    const int col0 = __builtin_amdgcn_readfirstlane(tg.col0), c_lo = __builtin_amdgcn_readfirstlane(tg.c_lo), c_hi = __builtin_amdgcn_readfirstlane(tg.c_hi);
+    const long long at_out = (long long)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)tg.out >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)tg.out));
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(slot + at_out, (long long)rows_valid * ldc * 4);
+    constexpr uint32_t NOWHERE = 0x7ffffff0u;
+    static_for<NB>([&](auto Bi) {
+        const int col = col0 + 32 * decltype(Bi)::value + j;
+        const bool col_ok = col >= c_lo && col < c_hi;
+        const uint32_t coff = (uint32_t)(col - c_lo) * 4u;
+        static_for<NA>([&](auto Ai) {
+            static_for<16>([&](auto R) {
+                constexpr int r = R;
+                const int row = row0 + 32 * decltype(Ai)::value + 8 * (r >> 2) + (r & 3) + 4 * hh;
+                const uint32_t off = (col_ok && row < rows_valid) ? (uint32_t)(row * ldc) * 4u + coff : NOWHERE;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)acc[Ai][Bi][r]), ro, off, 0, 0);
+            });
         });
-    }); });
+    });
     if (want_bias) {
-        float *bo = slot + tg.bias_out + (size_t)hh * (tg.c_hi - tg.c_lo);
+        const long long at_bias = (long long)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)tg.bias_out >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)tg.bias_out));
+        float *bo = slot + at_bias + (size_t)hh * (c_hi - c_lo);
         static_for<NB>([&](auto Bi) {
-            const int col = tg.col0 + 32 * decltype(Bi)::value + j;
+            const int col = col0 + 32 * decltype(Bi)::value + j;
             const f32x4 sm = bsum[Bi];
-            if (col >= tg.c_lo && col < tg.c_hi) bo[col - tg.c_lo] = (sm.x + sm.y) + (sm.z + sm.w);
+            if (col >= c_lo && col < c_hi) bo[col - c_lo] = (sm.x + sm.y) + (sm.z + sm.w);
         });
     }
 }
