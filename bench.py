@@ -159,15 +159,14 @@ def train_step_traffic():
 def train_step_algorithmic_bytes(model, n_samples_total: int) -> int:
     """HBM bytes a stored-activation training step cannot do without, per the layout of ntx_train_device.h: per sample, the eleven stored layer
     outputs (10 x 256 + 128 floats) and the eleven stored gradients written once and read once by the weight gradients; pos_map / dir_map
-    (padded to tiles of 32 rows) written in row order and in O layout, the row copy read three times by the chain (layer 0, the skip, the colour
-    layer's concatenation) and the O copy by the weight gradients (pos_map twice: layer 0 and the skip); the heads' 4 + 16 floats; weights and
-    moments are 2.7 MB and do not count."""
+    (padded to tiles of 32 rows) written once, read by the chain (layer 0, the skip, the colour layer's concatenation) and by the weight
+    gradients (pos_map twice each: layer 0 and the skip); the heads' few floats; weights and moments are 2.7 MB and do not count."""
     kp = -(-model.pos_map_dim // 32) * 32
     kd = -(-model.dir_map_dim // 32) * 32
     acts = 10 * 256 + 128
     per_sample = 4 * (2 * acts                       # forward outputs: written, read by dW
                       + 2 * acts                     # gradients at them: written, read by dW
-                      + 2 * (kp + kd) + (2 * kp + kd) + (2 * kp + kd)      # encodings: two copies written, row copy read by the chain, O copy by dW
+                      + (kp + kd) + (2 * kp + kd) + (2 * kp + kd)          # encodings: written, read by the chain (pos_map twice), read by dW (pos_map twice)
                       + 4 + 4 + 4 + 32 + 32)         # raw rgb / sigma written and read, the composite's adjoint written (plain and as a tile) and read
     return int(per_sample * n_samples_total)
 

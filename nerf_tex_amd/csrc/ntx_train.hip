@@ -328,14 +328,14 @@ __global__ void pack_kernel(PackArgs a) {
 // encoder: layer.FourierFeatures (layer.py:8-23) of position [+ geometry parameters] and of direction [+ appearance parameters]
 // (model.py:77-101), the sample points of renderer.py:98-114 and the blur product of :155-158.  One wave per block of 32 samples and map:
 // lane (n, h) evaluates sin (h = 0) or cos (h = 1) of its sample with ONE function (ntx_device.h sin_q, the render kernels' own) and writes
-// rows of 32 samples -- twice: in row order [block][row][32] (the chain's B operands) and in O layout (the weight gradients' A operands).
+// rows of 32 samples in O layout: the weight gradients' A operands, and what the chain gathers its B operands from.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct EncodeArgs {
     const float *rays_o, *rays_d, *z, *params, *cone;
     long long rays_per_param_row, M;
     int n_rays, S, n_geo, n_app, pos_freq, dir_freq, param_freq, blur_idx;
-    float *posR, *posO; int ptiles;      // rows 0 .. Kp: pos_map; the rest of the ptiles * 32 rows stays zero
-    float *dirR, *dirO; int dtiles;
+    float *posO; int ptiles;             // rows 0 .. Kp: pos_map; the rest of the ptiles * 32 rows stays zero
+    float *dirO; int dtiles;
     float *dists;                        // [N][S]: z[i+1] - z[i], the last one repeated, times |rays_d| (renderer.py:174-180)
 };
 __global__ __launch_bounds__(64) void encode_kernel(EncodeArgs a) {
@@ -354,11 +354,10 @@ __global__ __launch_bounds__(64) void encode_kernel(EncodeArgs a) {
     const int P = a.n_geo + a.n_app;
     const float *pr = a.params + (size_t)(ray / a.rays_per_param_row) * (P > 0 ? P : 1);
     auto param = [&](int c) { return c == a.blur_idx ? (hit ? pr[c] * (a.cone[ray] * z) : 0.0f) : pr[c]; };   // :155-158 (a missing ray's cone scale may be anything)
-    float *R = part == 0 ? a.posR : a.dirR, *O = part == 0 ? a.posO : a.dirO;
+    float *O = part == 0 ? a.posO : a.dirO;
     const int tiles = part == 0 ? a.ptiles : a.dtiles;
     auto put = [&](int row, float v) {
         if (!valid) v = 0.0f;                                                            // the tail of the last block: finite, and no gradient comes back
-        R[((size_t)blk * tiles * 32 + row) * 32 + n] = v;
         O[(((size_t)blk * tiles + (row >> 5)) * 4 + (n >> 3)) * 256 + ((row & 31) + 32 * ((n >> 2) & 1)) * 4 + (n & 3)] = v;
     };
     // FourierFeatures of x[0 .. D) with L bands from row r0 on: [x | sin(2^0 x) | cos(2^0 x) | sin(2^1 x) | ...], every block D wide (layer.py:14-23)
@@ -543,8 +542,8 @@ struct ntx_trainer {
     // what pack_kernel makes of the weights once a step: the two streams and the aux block
     float *wfwd = nullptr, *wdx = nullptr, *aux = nullptr; size_t fwd_floats = 0, dx_floats = 0;
     ntx_train::PackSeg *pack_seg = nullptr; int n_pack = 0; long long pack_total = 0;
-    // forward: the encoded inputs (row order and O layout), every layer's output (O layout), the ReLU bits, the heads' raw outputs
-    float *posR = nullptr, *posO = nullptr, *dirR = nullptr, *dirO = nullptr;
+    // forward: the encoded inputs and every layer's output (O layout), the ReLU bits, the heads' raw outputs
+    float *posO = nullptr, *dirO = nullptr;
     float *act = nullptr; long long act_stride = 0;       // eleven matrices act + i * act_stride: h0 .. h7, feature, c1o, c2o
     unsigned int *bits = nullptr; long long bits_stride = 0;   // ten: h0 .. h7, c1o, c2o
     int fwd_variant = 0;
@@ -569,7 +568,7 @@ using namespace ntx_train;
 void free_all(ntx_trainer *t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
-    void *ptrs[] = {t->w, t->grad, t->adam_m, t->adam_v, t->wfwd, t->wdx, t->aux, t->pack_seg, t->posR, t->posO, t->dirR, t->dirO, t->sigma, t->raw_rgb, t->z, t->dists, t->noise,
+    void *ptrs[] = {t->w, t->grad, t->adam_m, t->adam_v, t->wfwd, t->wdx, t->aux, t->pack_seg, t->posO, t->dirO, t->sigma, t->raw_rgb, t->z, t->dists, t->noise,
                     t->dgrad, t->dhead, t->jobs, t->dw_partial, t->stash, t->color, t->alpha_out, t->ray_loss, t->loss, t->act, t->bits, t->gout};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete t;
@@ -651,8 +650,7 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     };
     alloc(&t->w, p); alloc(&t->grad, p, true); alloc(&t->adam_m, p, true); alloc(&t->adam_v, p, true);
     // rows of the encoded inputs beyond Kp / Kd meet zero weights and are never written: they have to be finite
-    alloc(&t->posR, (size_t)NB * t->ptiles * 1024, true); alloc(&t->posO, (size_t)NB * t->ptiles * 1024, true);
-    alloc(&t->dirR, (size_t)NB * t->dtiles * 1024, true); alloc(&t->dirO, (size_t)NB * t->dtiles * 1024, true);
+    alloc(&t->posO, (size_t)NB * t->ptiles * 1024, true); alloc(&t->dirO, (size_t)NB * t->dtiles * 1024, true);
     t->act_stride = t->gout_stride = NB * 8 * 1024; t->bits_stride = NB * 256;
     alloc(&t->act, (size_t)t->act_stride * 11); alloc((float **)&t->bits, (size_t)t->bits_stride * 10); alloc(&t->gout, (size_t)t->gout_stride * 11);
     auto act = [&](int i) { return t->act + (size_t)i * t->act_stride; };
@@ -738,7 +736,9 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
         DwWave &d = jobs[j].w[w];
         d.A = A; d.rtA = rtA; d.a0 = a0; d.B = B; d.rtB = rtB; d.b0 = b0; d.shape = shape; d.out = at; d.ldc = N; d.row0 = a0 * 32; d.rows_valid = K;
         d.col0 = b0 * 32; d.c_lo = c_lo; d.c_hi = c_lo + N; d.bias_out = a0 == 0 ? at_bias : -1;
-        const int cost = shape == 0 ? 256 : shape == 1 ? 192 : 66;             // MFMAs per block of 32 samples: 16 k-steps x tiles (the narrow shape: 64, and 3 % for its loads -- five tiles for four tiles of work -- as measured)
+        // a block's cost in MFMAs of the full shape: 16 k-steps x 16 tiles = 256; the narrower shapes load more per MFMA (7 tiles for 12, 5 for 4) and
+        // run 3 % / 6 % behind their MFMA counts (192, 64): measured per block with the kernel's clock probe (-DNTX_TRAIN_CLOCKS)
+        const int cost = shape == 0 ? 256 : shape == 1 ? 198 : 68;
         if (cost > jobs[j].cost) jobs[j].cost = cost;
     };
     // a 256 x 256 layer: wave w takes X tiles 4 (w >> 1) .., dY tiles 4 (w & 1) ..
@@ -943,14 +943,14 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
     {
         EncodeArgs e{}; e.rays_o = rays_o; e.rays_d = rays_d; e.z = z; e.params = params; e.cone = cone_scale; e.rays_per_param_row = rays_per_param_row; e.M = M;
         e.n_rays = (int)n_rays; e.S = S; e.n_geo = t->desc.n_geo; e.n_app = t->desc.n_app; e.pos_freq = t->desc.pos_freq; e.dir_freq = t->desc.dir_freq;
-        e.param_freq = t->desc.param_freq; e.blur_idx = blur_idx; e.posR = t->posR; e.posO = t->posO; e.ptiles = t->ptiles; e.dirR = t->dirR; e.dirO = t->dirO;
+        e.param_freq = t->desc.param_freq; e.blur_idx = blur_idx; e.posO = t->posO; e.ptiles = t->ptiles; e.dirO = t->dirO;
         e.dtiles = t->dtiles; e.dists = t->dists;
         hipLaunchKernelGGL(encode_kernel, dim3((unsigned)n_blocks, 2), dim3(64), 0, st, e);
     }
     const unsigned chain_grid = (unsigned)std::min<long long>(t->cus, (n_blocks + 3) / 4);      // persistent: a workgroup of four waves per CU
     {
         FwdArgs f{}; f.stream = t->wfwd; f.stream_bytes = (uint32_t)(t->fwd_floats * sizeof(float)); f.aux = t->aux; f.M = M;
-        f.ptiles = t->ptiles; f.dtiles = t->dtiles; f.posR = t->posR; f.dirR = t->dirR;
+        f.ptiles = t->ptiles; f.dtiles = t->dtiles; f.pos = t->posO; f.dir = t->dirO;
         f.act = t->act; f.act_stride = t->act_stride; f.bits = t->bits; f.bits_stride = t->bits_stride;
         f.sigma = t->sigma; f.raw_rgb = t->raw_rgb;
         launch_fwd_chain(t->fwd_variant, st, chain_grid, f);

@@ -213,8 +213,8 @@ struct FwdArgs {
     const float *stream; uint32_t stream_bytes;        // the forward weight stream (pack_kernel), tail included
     const float *aux;                                  // biases and the two narrow heads, AUX_FLOATS
     long long M;
-    int ptiles, dtiles;                                // rows / 32 of posR / dirR
-    const float *posR, *dirR;                          // encoded inputs in ROW layout [block][row][32 samples]: row 2 S + h is k-step S's B operand
+    int ptiles, dtiles;                                // rows / 32 of pos / dir
+    const float *pos, *dir;                            // encoded inputs (O layout, what the weight gradients read): row 2 S + h is k-step S's B operand
     float *act; long long act_stride;                  // O layout, act + i * act_stride: h0 .. h7 (256 rows), feature (256), c1o (256), c2o (128)
     unsigned int *bits; long long bits_stride;         // h0 .. h7, c1o, c2o: [block][64 lanes][4 words]
     float *sigma, *raw_rgb;                            // [M], [M][3]
@@ -234,14 +234,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     ws.rsrc = make_rsrc(a.stream, a.stream_bytes);
     ws.voff = (uint32_t)lane * 16u;
     static_for<RING>([&](auto I) { ws.r[I] = wr_load(ws, (uint32_t)decltype(I)::value * 1024u); });
-    const uint32_t lane_o = o_lane_bytes(lane), lane_r = (uint32_t)(h * 32 + n) * 4u, lane16 = (uint32_t)lane * 16u;
+    // (row 2 S + h, sample n) of an O-layout block: this lane's part of the offset, and S's: (S >> 4) * 4096 + (S & 15) * 32
+    const uint32_t lane_o = o_lane_bytes(lane), lane_r = (uint32_t)((n >> 3) * 1024 + ((n >> 2) & 1) * 512 + (n & 3) * 4 + h * 16), lane16 = (uint32_t)lane * 16u;
     float pb[12];
-    __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.posR + (size_t)wave * a.ptiles * 1024, (long long)a.ptiles * 4096);
+    __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.pos + (size_t)wave * a.ptiles * 1024, (long long)a.ptiles * 4096);
     auto fetch = [&](auto G) {                          // group G of the segment rs_in points at
         constexpr int g = G;
         static_for<4>([&](auto K) {
             constexpr int k = K;
-            pb[4 * (g % 3) + k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, lane_r, (uint32_t)(4 * g + k) * 256u, 0));
+            constexpr int s = 4 * g + k;
+            pb[4 * (g % 3) + k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, lane_r, (uint32_t)((s >> 4) * 4096 + (s & 15) * 32), 0));
         });
     };
     fetch(std::integral_constant<int, 0>{}); fetch(std::integral_constant<int, 1>{});
@@ -296,11 +298,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (LI == 9) seg_mem<DSG>(cur, ws, sbase, pb, fetch);        // concat[dir_map, feature] (model.py:115)
             // the next memory-fed segment's first two groups are asked for a layer ahead (this block's position again for the skip, its
             // direction for the colour layer, the next block's position)
-            if constexpr (LI == 4) rs_in = make_rsrc(a.posR + (size_t)blk * a.ptiles * 1024, (long long)a.ptiles * 4096);
-            if constexpr (LI == 8) rs_in = make_rsrc(a.dirR + (size_t)blk * a.dtiles * 1024, (long long)a.dtiles * 4096);
+            if constexpr (LI == 4) rs_in = make_rsrc(a.pos + (size_t)blk * a.ptiles * 1024, (long long)a.ptiles * 4096);
+            if constexpr (LI == 8) rs_in = make_rsrc(a.dir + (size_t)blk * a.dtiles * 1024, (long long)a.dtiles * 4096);
             if constexpr (LI == 10) {
                 const int nb = blk + nwaves < n_blocks ? blk + nwaves : blk;
-                rs_in = make_rsrc(a.posR + (size_t)nb * a.ptiles * 1024, (long long)a.ptiles * 4096);
+                rs_in = make_rsrc(a.pos + (size_t)nb * a.ptiles * 1024, (long long)a.ptiles * 4096);
             }
             auto extra = [&](auto S, auto MT) {
                 constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
