@@ -660,6 +660,35 @@ def test_checkpoint_training_state_both_writers(tmp_path):
     assert len(slots) == 4 * len(table) and {s for _, s, _ in slots} == {"m", "v"}
 
 
+def test_png_reader_undoes_every_row_filter(tmp_path):
+    """nerf_tex_amd/png.py (what loadTexture's cv::imread does for the instancer's textures, instancer.cpp:34-50): an image whose rows use the
+    five PNG filters in turn (None, Sub, Up, Average, Paeth: spec 9), filtered here by the spec's own formulas, reads back byte for byte; a
+    truncated stream is an error with a name, not a broadcast failure."""
+    import struct, zlib
+    from nerf_tex_amd import png
+    chunk = lambda k, b: struct.pack(">I", len(b)) + k + b + struct.pack(">I", zlib.crc32(k + b) & 0xFFFFFFFF)
+
+    def paeth(a, b, c):
+        p = a + b - c; pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+    rng = np.random.default_rng(0)
+    for n, ctype in ((3, 2), (4, 6), (1, 0)):
+        H, W = 13, 17
+        img = rng.integers(0, 256, (H, W, n), dtype=np.uint8)
+        stride, rows, raw = W * n, img.reshape(H, W * n).astype(int), bytearray()
+        for r in range(H):
+            ft = r % 5; raw.append(ft)
+            for i in range(stride):
+                a = rows[r][i - n] if i >= n else 0; b = rows[r - 1][i] if r else 0; c = rows[r - 1][i - n] if (r and i >= n) else 0
+                raw.append((rows[r][i] - [0, a, b, (a + b) // 2, paeth(a, b, c)][ft]) & 255)
+        f = str(tmp_path / f"t{n}.png")
+        open(f, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+        assert np.array_equal(np.asarray(png.read_png(f)).reshape(H, W, n), img)
+    with pytest.raises(ValueError, match="truncated"):
+        png._unfilter(np.zeros(10, np.uint8), 2, 8, 4)
+
+
 def test_main_entry_point_prepares_reference_configs():
     """nerf_tex_amd.main (reference: main.py): config file -> remapped config; `--volumetric` swaps the Embree-backed
     InstanceRenderer for the volumetric Renderer; training configs are refused."""

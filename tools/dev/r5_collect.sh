@@ -1,0 +1,13 @@
+#!/bin/bash
+# build container, after `gpurun -- bash tools/dev/r5_final.sh`: gpurun_out/ -> profiles/r05/ (the files the docs and bench.py quote)
+set -e
+cd "$(dirname "$0")/../.."
+P=profiles/r05; O=gpurun_out; mkdir -p $P
+for w in carpet grass fur grass_filtered fur_sharded grass_filtered_sharded; do python tools/summarize_profile.py pg_$w r05 bench_${w}_v16 > /dev/null; done
+python tools/summarize_profile.py pg_instanced r05 bench_instanced_v16 "instance_kernel<" > /dev/null
+python tools/summarize_profile.py pg_instanced_scene r05 bench_instanced_scene "instance_kernel<" > /dev/null
+cp $O/r5trainprof/train_step_kernel_stats.csv $O/r5trainprof/train_step_pmc_summary.json $O/r5trainprof/train_step_timeline.txt $P/
+cp $O/r5inst/instancer_handoff_ab.json $P/
+cp $O/r5inst/instancer_base_kernel_stats.csv $O/r5inst/instancer_base_pmc_summary.json $P/ 2>/dev/null || true
+cp $O/r5_tree.txt $P/tree.txt
+ls $P

@@ -17,6 +17,8 @@ def kernel_sources_sha16(root: str = ROOT) -> str:
 
 
 def git_head(root: str = ROOT):
+    if os.environ.get("NTX_PROFILE_HEAD"):       # a GPU box has no .git: the build container passes its head along (tools/dev/r5_refresh.sh)
+        return os.environ["NTX_PROFILE_HEAD"]
     try:
         import subprocess
         return subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
