@@ -664,7 +664,8 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     long long first = 0;
     auto seg = [&](const float *src, long long sk, long long sc, int mode, int K, int ncols, int nt, size_t *stream_floats, int nsteps) {
         PackSeg s{}; s.src = src; s.sk = sk; s.sc = sc; s.mode = mode; s.K = K; s.ncols = ncols; s.nt = nt;
-        const long long recs = ((long long)nsteps * (nt / 4) + RING - 1) / RING * RING;
+        const int ring = stream_floats == &t->dx_floats ? DX_RING : RING;                 // a segment is whole turns of its chain's ring
+        const long long recs = ((long long)nsteps * (nt / 4) + ring - 1) / ring * ring;
         s.count = recs * 256; s.first = first; s.dst = (float *)(uintptr_t)(*stream_floats * sizeof(float));      // an offset until the buffer exists
         first += s.count; *stream_floats += (size_t)s.count;
         segs.push_back(s);
@@ -692,7 +693,7 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     for (int i = 7; i >= 1; --i) dx_hidden(t->trunk[i], i == 5 ? Kp : 0, 256, 128);  // d h(i-1) = dy_i . W_i^T (the skip's position rows take no gradient further)
     const size_t n_stream_segs = segs.size();
     // a stream ends with its first RING records again
-    auto tail = [&](size_t of, size_t *stream_floats) { PackSeg s = segs[of]; s.count = (long long)RING * 256; s.first = first; s.dst = (float *)(uintptr_t)(*stream_floats * sizeof(float));
+    auto tail = [&](size_t of, size_t *stream_floats) { PackSeg s = segs[of]; s.count = (long long)(stream_floats == &t->dx_floats ? DX_RING : RING) * 256; s.first = first; s.dst = (float *)(uintptr_t)(*stream_floats * sizeof(float));
                                                         first += s.count; *stream_floats += (size_t)s.count; segs.push_back(s); };
     tail(0, &t->fwd_floats); tail(n_fwd_segs, &t->dx_floats);
     // aux: biases of the eleven layers in accumulator order, the density head's weights and bias, the colour head's

@@ -56,20 +56,25 @@ constexpr uint32_t o_value_bytes(int V) { return (uint32_t)((V >> 4) * 4096 + ((
 // the ring's phase is a compile-time fact everywhere; the stream ends with a copy of its first RING records: the prefetch runs on into the
 // next block of samples.
 // ---------------------------------------------------------------------------------------------------------------------------
-struct WRing {
+template <int R>
+struct WRingT {
+    static constexpr int DEPTH = R;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff;
-    f32x4 r[RING];
+    f32x4 r[R];
 };
-TRN_DEV f32x4 wr_load(const WRing &w, uint32_t byte_off) {
+typedef WRingT<RING> WRing;            // the forward chain: as the render kernels (its registers are spoken for)
+constexpr int DX_RING = 16;            // the chain back has registers to spare: twice the depth rides out an L2 miss of the weight stream
+template <class WR>
+TRN_DEV f32x4 wr_load(const WR &w, uint32_t byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rsrc, w.voff, byte_off, 0));
 }
 
 // NSTEPS k-steps of an NMT-tile layer whose B operands are this lane's `hin` (the previous layer's outputs); ZERO: the accumulators start
 // from nothing (the first k-step takes the constant 0 as C).  extra(S, MT): what else goes into the slot behind MFMA (S, MT).
-template <int NSTEPS, int NMT, bool ZERO, class Extra>
-TRN_DEV void seg_hidden(f32x16 (&acc)[8], WRing &ws, uint32_t &sbase, const float (&hin)[128], Extra &&extra) {
-    constexpr int RPS = NMT / 4;
+template <int NSTEPS, int NMT, bool ZERO, class WR, class Extra>
+TRN_DEV void seg_hidden(f32x16 (&acc)[8], WR &ws, uint32_t &sbase, const float (&hin)[128], Extra &&extra) {
+    constexpr int RPS = NMT / 4, RING = WR::DEPTH;
     static_assert((NSTEPS * RPS) % RING == 0, "whole ring turns");
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     static_for<NSTEPS>([&](auto S) {
@@ -120,9 +125,9 @@ TRN_DEV void seg_mem(f32x16 (&acc)[8], WRing &ws, uint32_t &sbase, float (&pb)[1
 
 // one ring turn of which the first NREC records are k-steps with the given B values (NMT tiles; NREC = k-steps * NMT / 4), the rest padding
 // that is fetched to keep the ring turning and never multiplied
-template <int NKS, int NMT, bool ZERO>
-TRN_DEV void seg_few(f32x16 (&acc)[8], WRing &ws, uint32_t &sbase, const float (&b)[NKS]) {
-    constexpr int RPS = NMT / 4;
+template <int NKS, int NMT, bool ZERO, class WR>
+TRN_DEV void seg_few(f32x16 (&acc)[8], WR &ws, uint32_t &sbase, const float (&b)[NKS]) {
+    constexpr int RPS = NMT / 4, RING = WR::DEPTH;
     static_assert(NKS * RPS <= RING, "one ring turn");
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     static_for<RING>([&](auto I) {
@@ -365,10 +370,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
     const int n_blocks = (int)((a.M + 31) >> 5);
     if (wave >= n_blocks) return;
-    WRing ws;
+    WRingT<DX_RING> ws;
     ws.rsrc = make_rsrc(a.stream, a.stream_bytes);
     ws.voff = (uint32_t)lane * 16u;
-    static_for<RING>([&](auto I) { ws.r[I] = wr_load(ws, (uint32_t)decltype(I)::value * 1024u); });
+    static_for<DX_RING>([&](auto I) { ws.r[I] = wr_load(ws, (uint32_t)decltype(I)::value * 1024u); });
     const uint32_t lane_o = o_lane_bytes(lane), lane16 = (uint32_t)lane * 16u;
     auto fetch_grad = [&](int blk) {
         const long long m = (long long)blk * 32 + n;
