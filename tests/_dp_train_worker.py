@@ -38,6 +38,16 @@ def main():
     dist.all_gather(both, w)
     assert all(torch.equal(both[0], b) for b in both)                                    # the ranks stay in step bit for bit
     assert not np.array_equal(mine.weights(), np.asarray(model.get_blob(), np.float32).reshape(-1))
+    # unequal shards: the mean of per-rank means would weigh rank 0's rays more -- refused on every rank before anything is averaged
+    k = 40 if rank == 0 else 24
+    odd = Trainer(model, max_rays=k, n_samples=S, perturb=False)
+    odd.gradients_step(ro[:k], rd[:k], t[:k], params[:k], cone[:k], color[:k], alpha[:k], loss)
+    before = odd.gradients()
+    try:
+        odd.sync_gradients(group=None)
+        raise AssertionError("unequal shards were averaged")
+    except ValueError as e:
+        assert "unequal shards" in str(e) and np.array_equal(odd.gradients(), before)
     dist.barrier()
     if rank == 0:
         print("DP_TRAIN_OK", worst)
