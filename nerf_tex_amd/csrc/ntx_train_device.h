@@ -473,6 +473,10 @@ __host__ __device__ inline long long dw_first_g(long long G, long long W, long l
 __host__ __device__ inline long long dw_last_g(long long G, long long W, long long start, long long span) { return (start + span - 1) * G / W; }
 
 #ifdef NTX_TRAIN_DW
+#ifndef NTX_DW_SYNC
+#define NTX_DW_SYNC 8
+#endif
+constexpr int DW_SYNC = NTX_DW_SYNC;               // blocks of 32 samples between two meetings of a job's waves (a power of two)
 template <int NA, int NB>
 TRN_DEV void dw_piece(const DwWave &tg, float *slot, int blk0, int blk1, int lane) {
     auto uniform_ptr = [](const float *p) {
@@ -516,6 +520,10 @@ TRN_DEV void dw_piece(const DwWave &tg, float *slot, int blk0, int blk1, int lan
         // the compiler cannot count how many loads are younger than the ones it waits for, and waits for all of them
         fetch(std::integral_constant<int, 0>{}, 0);
         for (int i = 0; i < nblk; ++i) {
+            // Every DW_SYNC blocks the job's four waves wait for each other (a wave without work in this job keeps the count: dw_kernel): they
+            // drift apart otherwise, and what two of them share is then read from HBM twice.  (Every block: the read falls from 8.4 to
+            // 6.7 GB a step and the kernel takes 6 % longer, the waves waiting for each other's loads.)
+            if ((i & (DW_SYNC - 1)) == 0) __builtin_amdgcn_s_barrier();
             fetch(std::integral_constant<int, 1>{}, i);
             __builtin_amdgcn_sched_barrier(0);
             compute(std::integral_constant<int, 0>{});
@@ -583,6 +591,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (shape == 0) dw_piece<4, 4>(wv, slot, blk0, blk1, lane);
             else if (shape == 1) dw_piece<3, 4>(wv, slot, blk0, blk1, lane);
             else if (shape == 2) dw_piece<4, 1>(wv, slot, blk0, blk1, lane);
+            else for (int i = 0; i < blk1 - blk0; i += DW_SYNC) __builtin_amdgcn_s_barrier();
 #ifdef NTX_TRAIN_CLOCKS
             __syncthreads();
             if (ck && threadIdx.x == 0) { ck[2 + 3 * jn] = (unsigned long long)(blk1 - blk0); ck[3 + 3 * jn] = c0; ck[4 + 3 * jn] = wall_clock64(); }
