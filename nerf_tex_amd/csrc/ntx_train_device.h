@@ -474,7 +474,7 @@ __host__ __device__ inline long long dw_last_g(long long G, long long W, long lo
 
 #ifdef NTX_TRAIN_DW
 #ifndef NTX_DW_SYNC
-#define NTX_DW_SYNC 8
+#define NTX_DW_SYNC 16
 #endif
 constexpr int DW_SYNC = NTX_DW_SYNC;               // blocks of 32 samples between two meetings of a job's waves (a power of two)
 template <int NA, int NB>
@@ -521,8 +521,9 @@ TRN_DEV void dw_piece(const DwWave &tg, float *slot, int blk0, int blk1, int lan
         fetch(std::integral_constant<int, 0>{}, 0);
         for (int i = 0; i < nblk; ++i) {
             // Every DW_SYNC blocks the job's four waves wait for each other (a wave without work in this job keeps the count: dw_kernel): they
-            // drift apart otherwise, and what two of them share is then read from HBM twice.  (Every block: the read falls from 8.4 to
-            // 6.7 GB a step and the kernel takes 6 % longer, the waves waiting for each other's loads.)
+            // drift apart otherwise, and what two of them share is then read from HBM twice.  Measured on one box, kernel time / HBM-side read a
+            // step: never 2.69 ms / 8.4 GB; every block 2.85 ms / 6.7 GB (the waves wait for each other's loads); every 8 blocks 2.69 / 6.7;
+            // every 16 or 64 blocks 2.67 / 6.7.
             if ((i & (DW_SYNC - 1)) == 0) __builtin_amdgcn_s_barrier();
             fetch(std::integral_constant<int, 1>{}, i);
             __builtin_amdgcn_sched_barrier(0);
