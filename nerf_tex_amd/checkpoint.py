@@ -326,9 +326,10 @@ def _table_block(items, restart_interval: int = 16) -> bytes:
     return bytes(buf)
 
 
-def _object_graph(root: str, n_layers: int, opt_scalars, with_slots: bool) -> bytes:
-    """TrackableObjectGraph (tensorflow/core/protobuf/trackable_object_graph.proto) of Checkpoint(**{root: model}, step, optimizer,
-    save_counter): nodes {1: children {1: node_id, 2: local_name}, 2: attributes {1: name, 2: full_name, 3: checkpoint_key},
+def _object_graph(models, opt_scalars, with_slots: bool) -> bytes:
+    """TrackableObjectGraph (tensorflow/core/protobuf/trackable_object_graph.proto) of Checkpoint(**{root: model, ...}, step, optimizer,
+    save_counter) for `models` = [(root, number of Dense layers)] (train.py:55: `dict(model, step=..., optimizer=...)` -- with
+    network.model.CoarseFine the dict holds 'model' and 'model_fine'): nodes {1: children {1: node_id, 2: local_name}, 2: attributes {1: name, 2: full_name, 3: checkpoint_key},
     3: slot_variables {1: original_variable_node_id, 2: slot_name, 3: slot_variable_node_id}}."""
     nodes = []                                                       # (children [(id, name)], attributes [(name, full_name, key)], slot refs)
 
@@ -337,17 +338,20 @@ def _object_graph(root: str, n_layers: int, opt_scalars, with_slots: bool) -> by
         return len(nodes) - 1
 
     var = lambda key, full: add(attrs=[("VARIABLE_VALUE", full, key + _ATTR)])
-    root_children = []
     root_id = add()
-    model_children, var_ids = [], []
-    model_id = add()
-    for i in range(n_layers):
-        base = f"{root}/layer_with_weights-{i}"
-        dense = "dense" if i == 0 else f"dense_{i}"
-        kid, bid = var(f"{base}/kernel", f"{dense}/kernel"), var(f"{base}/bias", f"{dense}/bias")
-        var_ids += [(kid, f"{base}/kernel", f"{dense}/kernel"), (bid, f"{base}/bias", f"{dense}/bias")]
-        model_children.append((add(children=[(kid, "kernel"), (bid, "bias")]), f"layer_with_weights-{i}"))
-    nodes[model_id] = (model_children, [], [])
+    var_ids, model_ids, n_dense = [], [], 0
+    for root, n_layers in models:
+        model_children = []
+        model_id = add()
+        for i in range(n_layers):
+            base = f"{root}/layer_with_weights-{i}"
+            dense = "dense" if n_dense == 0 else f"dense_{n_dense}"          # Keras numbers its layers across the process
+            n_dense += 1
+            kid, bid = var(f"{base}/kernel", f"{dense}/kernel"), var(f"{base}/bias", f"{dense}/bias")
+            var_ids += [(kid, f"{base}/kernel", f"{dense}/kernel"), (bid, f"{base}/bias", f"{dense}/bias")]
+            model_children.append((add(children=[(kid, "kernel"), (bid, "bias")]), f"layer_with_weights-{i}"))
+        nodes[model_id] = (model_children, [], [])
+        model_ids.append((model_id, root))
     step_id = var("step", "Variable")
     opt_children = [(var(f"optimizer/{n}", f"Adam/{n}"), n) for n in opt_scalars]
     slot_refs = []
@@ -358,7 +362,7 @@ def _object_graph(root: str, n_layers: int, opt_scalars, with_slots: bool) -> by
                 slot_refs.append((vid, sl, sid))
     opt_id = add(children=opt_children, slots=slot_refs)
     counter_id = var("save_counter", "save_counter")
-    nodes[root_id] = ([(model_id, root), (step_id, "step"), (opt_id, "optimizer"), (counter_id, "save_counter")], [], [])
+    nodes[root_id] = (model_ids + [(step_id, "step"), (opt_id, "optimizer"), (counter_id, "save_counter")], [], [])
     out = b""
     for children, attrs, slots in nodes:
         msg = b""
@@ -424,21 +428,26 @@ def write_bundle(prefix: str, tensors: Dict[str, object], block_bytes: int = 409
 
 
 def write_checkpoint(prefix: str, layer_table, weights, m=None, v=None, iterations: int = 0, step: int = 0, hyper: dict = None, root: str = "model",
-                     save_counter: int = 1) -> str:
+                     save_counter: int = 1, more=()) -> str:
     """A checkpoint with the keys of `tf.train.Checkpoint(**{root: model}, step=step, optimizer=Adam(...))` (train.py:55-57, logger.py:30-34):
     `weights` / `m` / `v` in `layer_table` order ([kernel, bias, ...]; m, v: Adam's slots or None), `iterations` = `optimizer.iterations`,
     `hyper`: beta_1 / beta_2 / decay [/ learning_rate: only a constant rate is a variable, a schedule is not].  Also maintains the
-    directory's `checkpoint` state file the way CheckpointManager does (latest_checkpoint reads the newest index either way)."""
+    directory's `checkpoint` state file the way CheckpointManager does (latest_checkpoint reads the newest index either way).
+    `more`: further models of the same Checkpoint under the same optimizer, [(root, layer_table, weights, m, v)] -- the fine network of
+    network.model.CoarseFine is saved as 'model_fine' beside 'model' (model.py:47-56, train.py:55)."""
     hyper = {"beta_1": 0.9, "beta_2": 0.999, "decay": 0.0, **(hyper or {})}
     t: Dict[str, object] = {}
     f32 = lambda a, shape: np.ascontiguousarray(np.asarray(a, np.float32).reshape(shape))
-    for i, (_, fan_in, fan_out) in enumerate(layer_table):
-        base = f"{root}/layer_with_weights-{i}"
-        for kind, shape, j in (("kernel", (fan_in, fan_out), 2 * i), ("bias", (fan_out,), 2 * i + 1)):
-            t[f"{base}/{kind}{_ATTR}"] = f32(weights[j], shape)
-            if m is not None and v is not None:
-                t[f"{base}/{kind}/.OPTIMIZER_SLOT/optimizer/m{_ATTR}"] = f32(m[j], shape)
-                t[f"{base}/{kind}/.OPTIMIZER_SLOT/optimizer/v{_ATTR}"] = f32(v[j], shape)
+    everything = [(root, layer_table, weights, m, v)] + [tuple(x) for x in more]
+    slots = all(mm is not None and vv is not None for _, _, _, mm, vv in everything)
+    for root_, table_, w_, m_, v_ in everything:
+        for i, (_, fan_in, fan_out) in enumerate(table_):
+            base = f"{root_}/layer_with_weights-{i}"
+            for kind, shape, j in (("kernel", (fan_in, fan_out), 2 * i), ("bias", (fan_out,), 2 * i + 1)):
+                t[f"{base}/{kind}{_ATTR}"] = f32(w_[j], shape)
+                if slots:
+                    t[f"{base}/{kind}/.OPTIMIZER_SLOT/optimizer/m{_ATTR}"] = f32(m_[j], shape)
+                    t[f"{base}/{kind}/.OPTIMIZER_SLOT/optimizer/v{_ATTR}"] = f32(v_[j], shape)
     t["step" + _ATTR] = np.asarray(int(step), np.int64)
     t["optimizer/iter" + _ATTR] = np.asarray(int(iterations), np.int64)
     scalars = ["iter"]
@@ -446,7 +455,7 @@ def write_checkpoint(prefix: str, layer_table, weights, m=None, v=None, iteratio
         if n in hyper:
             t[f"optimizer/{n}{_ATTR}"] = np.asarray(hyper[n], np.float32); scalars.append(n)
     t["save_counter" + _ATTR] = np.asarray(int(save_counter), np.int64)
-    t["_CHECKPOINTABLE_OBJECT_GRAPH"] = _object_graph(root, len(layer_table), scalars, m is not None and v is not None)
+    t["_CHECKPOINTABLE_OBJECT_GRAPH"] = _object_graph([(r_, len(tb_)) for r_, tb_, _, _, _ in everything], scalars, slots)
     os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
     write_bundle(prefix, t)
     with open(os.path.join(os.path.dirname(os.path.abspath(prefix)), "checkpoint"), "w") as f:

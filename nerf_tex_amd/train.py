@@ -323,6 +323,37 @@ class CoarseFineTrainer:
         for tr in self.trainers:
             tr.apply_gradients()
 
+    # ---- resuming: ONE checkpoint holds both networks under one optimizer (train.py:55: dict(model, step=..., optimizer=...)) --------------
+    def save(self, prefix: str, step: int = None) -> str:
+        from . import checkpoint
+        parts = []
+        for tr in self.trainers:
+            st, table = tr.state_dict(), tr.model.layer_table()
+            parts.append((tr.model.name, table, _split_blob(table, st["weights"]), _split_blob(table, st["adam_m"]), _split_blob(table, st["adam_v"])))
+        f = self.fine
+        hyper = {"beta_1": f.beta_1, "beta_2": f.beta_2, "decay": 0.0}
+        if not f.lrate_decay > 0:
+            hyper["learning_rate"] = f.lrate
+        root, table, w, m, v = parts[0]
+        return checkpoint.write_checkpoint(prefix, table, w, m, v, iterations=self.iterations, step=self.iterations if step is None else int(step), hyper=hyper,
+                                           root=root, more=parts[1:])
+
+    def restore(self, path: str, verify: bool = True) -> dict:
+        """As `Trainer.restore`, every network from its own root of the one bundle."""
+        import os
+        from . import checkpoint
+        prefix = checkpoint.latest_checkpoint(path) if os.path.isdir(path) else path
+        info = {}
+        for tr in self.trainers:
+            info = tr.restore(prefix, root=tr.model.name, verify=verify)
+        self._calls = int(info.get("iterations") or 0)
+        return info
+
+    def hand_weights_to_models(self) -> None:
+        """Both networks' render contexts take the trainers' weights on the device (`NerfModel.set_weights_from_trainer`)."""
+        for tr in self.trainers:
+            tr.model.set_weights_from_trainer(tr)
+
     def step(self, *args, **kwargs):
         val = self.gradients_step(*args, **kwargs)[0]
         self.apply_gradients()
@@ -386,11 +417,10 @@ def Train(target_path: str, train_dataset, val_dataset=None, model_config: dict 
         first = next(iter(train_dataset))
         max_rays = int(first["rays_o"].shape[0]) * int(first["rays_o"].shape[1])
     trainer, loss_fn = Trainer.from_config(cfg, max_rays=max_rays, device=device, weights=weights)
-    if isinstance(trainer, CoarseFineTrainer):
-        raise _lib.NtxError(_lib.NTX_E_UNSUPPORTED, "Train: the loop (checkpoints, validation renders) is built for one network; step a CoarseFineTrainer directly")
     model = trainer.model
     rcfg = {k: v for k, v in dict(cfg["renderer_config"]).items() if k != "module"}
-    renderer = Renderer(model=model, **rcfg)
+    two = isinstance(trainer, CoarseFineTrainer)                  # n_importance > 0: render.py:24 hands the renderer every model of the dict
+    renderer = Renderer(model=model, model_fine=trainer.model_fine if two else None, **rcfg)
     lg = dict(i_print=100, i_img=5e3, i_checkpoint=1e3, max_to_keep=3)
     lg.update({k: v for k, v in (logger_config or {}).items() if k in lg})
     i_print, i_img, i_ckpt, keep = int(lg["i_print"]), int(lg["i_img"]), int(lg["i_checkpoint"]), int(lg["max_to_keep"])
@@ -421,7 +451,7 @@ def Train(target_path: str, train_dataset, val_dataset=None, model_config: dict 
             print(f"Step {step} | Loss {val:.3g}")
         if val_dataset is not None and i_img > 0 and step % i_img == 0:      # logger.py:76-81
             from .render import render_image
-            model.set_weights_from_trainer(trainer)
+            trainer.hand_weights_to_models() if two else model.set_weights_from_trainer(trainer)
             out["images"][step] = [render_image(renderer, val_dataset, view)[0] for view in val_dataset]
         if i_ckpt > 0 and step % i_ckpt == 0:                               # logger.py:84-86
             out["checkpoints"].append(trainer.save(os.path.join(ckpt_dir, f"ckpt-{step}"), step=step))

@@ -602,3 +602,48 @@ def test_coarse_fine_trainer_from_a_config():
                 color=color.reshape(B, R, 3), alpha=alpha.reshape(B, R))
     out = tr.train_step(data, loss)
     assert sorted(out) == ["alpha_pred", "alpha_pred_coarse", "color_pred", "color_pred_coarse", "loss"] and np.isfinite(float(out["loss"].item())) and tr.iterations == 1
+
+
+def test_train_loop_with_a_coarse_and_a_fine_network(tmp_path):
+    """`Train` on a configuration with n_importance > 0 and network.model.CoarseFine: both networks step, the validation view goes through
+    `Renderer(model, model_fine, n_importance)` with both weight sets handed over on the device, ONE checkpoint holds 'model' and 'model_fine'
+    with their optimizer slots (train.py:55), and a run continued from it ends bit for bit where the uninterrupted one does."""
+    import json, os
+    from nerf_tex_amd.train import Train
+    cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "train_configs.json")))["carpet"]
+    B, R, S, NI = 2, 64, 24, 16
+    ro, rd, t, cone, params, color, alpha = batch(41, B * R, S, 7, "carpet")
+    data = dict(rays_o=ro.reshape(B, R, 3), rays_d=rd.reshape(B, R, 3), t=t.reshape(B, R, 2), cone_scale=cone.reshape(B, R, 1), parameters=params[::R].copy(),
+                color=color.reshape(B, R, 3), alpha=alpha.reshape(B, R))
+
+    class Batches:
+        composite_bkgd, bkgd_color = False, (1., 1., 1.)
+        def __iter__(self):
+            while True:
+                yield data
+
+    class Views:
+        height, width, composite_bkgd, bkgd_color = 16, 16, False, (1., 1., 1.)
+        def __iter__(self):
+            from nerf_tex_amd import synthetic
+            f = synthetic.FAMILIES["carpet"]
+            vo, vd, vt, vc = synthetic.all_hit_rays(256, f["b_0"], f["b_1"], f["cam"], seed=3)
+            d = lambda x: torch.as_tensor(x, device=dev())
+            yield dict(rays_o=d(vo)[None], rays_d=d(vd)[None], t=d(vt)[None], cone_scale=d(vc).reshape(1, -1, 1), parameters=d(params[:1]), seed=5)
+
+    common = dict(model_config={"module": "network.model.CoarseFine", "model_config": dict(cfg["model_config"])}, loss_config=cfg["loss_config"], lrate=cfg["lrate"],
+                  lrate_decay=cfg["lrate_decay"], renderer_config=dict(cfg["renderer_config"], n_samples=S, n_importance=NI))
+    np.random.seed(11)
+    whole = Train(str(tmp_path / "a"), Batches(), Views(), n_iters=30, logger_config=dict(i_print=10, i_img=30, i_checkpoint=0), **common)
+    np.random.seed(11)
+    first = Train(str(tmp_path / "b"), Batches(), None, n_iters=20, logger_config=dict(i_print=10, i_img=0, i_checkpoint=20), **common)
+    keys = __import__("nerf_tex_amd.checkpoint", fromlist=["x"]).read_bundle_index(str(tmp_path / "b" / "checkpoints" / "ckpt-20") + ".index")
+    assert "model/layer_with_weights-3/kernel/.ATTRIBUTES/VARIABLE_VALUE" in keys and "model_fine/layer_with_weights-12/bias/.OPTIMIZER_SLOT/optimizer/m/.ATTRIBUTES/VARIABLE_VALUE" in keys
+    np.random.seed(99)                                             # other initial weights: everything comes from the checkpoint
+    rest = Train(str(tmp_path / "b"), Batches(), Views(), n_iters=30, logger_config=dict(i_print=10, i_img=30, i_checkpoint=0), **common)
+    assert whole["step"] == rest["step"] == 30 and first["step"] == 20
+    for x, y in zip(whole["trainer"].trainers, rest["trainer"].trainers):
+        assert np.array_equal(x.weights(), y.weights()) and x.iterations == y.iterations == 30
+    assert torch.equal(whole["images"][30][0], rest["images"][30][0]) and whole["images"][30][0].shape == (16, 16, 4)
+    losses = [v for _, v in whole["loss"]]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]

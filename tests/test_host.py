@@ -658,6 +658,13 @@ def test_checkpoint_training_state_both_writers(tmp_path):
     assert keys == {k for k in got if k != "_CHECKPOINTABLE_OBJECT_GRAPH"} - {"_CHECKPOINTABLE_OBJECT_GRAPH"}
     assert sorted(name for _, name in children[0]) == ["model", "optimizer", "save_counter", "step"]
     assert len(slots) == 4 * len(table) and {s for _, s, _ in slots} == {"m", "v"}
+    # two networks under one optimizer (network.model.CoarseFine: 'model' and 'model_fine' in the one Checkpoint, train.py:55)
+    ws2 = [w + np.float32(1) for w in ws]
+    ck.write_checkpoint(str(d / "ckpt-30"), table, ws, ms, vs, iterations=30, step=30, more=[("model_fine", table, ws2, vs, ms)])
+    both = ck.read_bundle(str(d / "ckpt-30"))
+    a_, b_ = ck.training_state_from_bundle(both, table, "model"), ck.training_state_from_bundle(both, table, "model_fine")
+    assert all(np.array_equal(x, y) for x, y in zip(a_["weights"], ws)) and all(np.array_equal(x, y) for x, y in zip(b_["weights"], ws2))
+    assert all(np.array_equal(x, y) for x, y in zip(b_["m"], vs)) and all(np.array_equal(x, y) for x, y in zip(b_["v"], ms)) and a_["iterations"] == b_["iterations"] == 30
 
 
 def test_png_reader_undoes_every_row_filter(tmp_path):
