@@ -647,3 +647,33 @@ def test_train_loop_with_a_coarse_and_a_fine_network(tmp_path):
     assert torch.equal(whole["images"][30][0], rest["images"][30][0]) and whole["images"][30][0].shape == (16, 16, 4)
     losses = [v for _, v in whole["loss"]]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def test_full_batch_properties_without_an_oracle():
+    """At the configs' 1024 x 256 batch, properties that need no restatement: the step is bit-reproducible across trainers (262 144 samples
+    summed in a fixed order by 256 persistent workgroups); the batch's gradient is the mean of its four images' gradients taken alone (the
+    losses are means over rays: loss.py:51-59) to float32 summation order; and the jitter is keyed by the ray's index in the batch, so image
+    b alone with the same seed samples other depths than image b inside the batch -- the comparison runs on given depths."""
+    from nerf_tex_amd.renderer import Renderer
+    from nerf_tex_amd.train import Trainer
+    model, spec, wts = make_model((1, 6), dense_media=True)
+    B, R, S = 4, 256, 256
+    ro, rd, t, cone, params, color, alpha = batch(5, B * R, S, 7, "carpet")
+    okw, loss = make_loss("alpha_smape")
+    z = Renderer.sample_depths(torch.as_tensor(t, device=dev()), S, perturb=True, seed=3)
+    whole = Trainer(model, max_rays=B * R, n_samples=S)
+    v0, c0, a0 = whole.gradients_step(ro, rd, t, params, cone, color, alpha, loss, z_vals=z)
+    g = whole.gradients()
+    again = Trainer(model, max_rays=B * R, n_samples=S)
+    v1, c1, a1 = again.gradients_step(ro, rd, t, params, cone, color, alpha, loss, z_vals=z)
+    assert np.array_equal(g, again.gradients()) and torch.equal(c0, c1) and torch.equal(a0, a1) and float(v0.item()) == float(v1.item())
+    part = Trainer(model, max_rays=R, n_samples=S)
+    acc, vals = np.zeros_like(g, dtype=np.float64), []
+    for b in range(B):
+        sl = slice(b * R, (b + 1) * R)
+        v, c, a = part.gradients_step(ro[sl], rd[sl], t[sl], params[sl], cone[sl], color[sl], alpha[sl], loss, z_vals=z[sl])
+        assert torch.equal(c, c0[sl]) and torch.equal(a, a0[sl])                  # a ray's prediction does not depend on its batch
+        acc += part.gradients(); vals.append(float(v.item()))
+    assert abs(np.mean(vals) - float(v0.item())) <= 1e-6 * abs(float(v0.item()))
+    worst = max(rel_linf(g[sl_], (acc / B)[sl_]) for _, sl_ in layer_slices(spec))
+    assert worst <= 2e-5 and np.abs(g).max() > 1e-6, worst
