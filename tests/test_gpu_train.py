@@ -363,25 +363,30 @@ def test_the_configs_batch_size_runs_and_refusals():
     assert e.value.code == _lib.NTX_E_UNSUPPORTED
 
 
-@pytest.mark.parametrize("n,S", [(1024, 256), (1021, 255)])
-def test_gradients_at_the_configs_batch(n, S):
-    """The step the row is about: config_carpet_train.py's 4 images x 256 rays x 256 samples = 262 144 samples (:23, 33, 101) -- 8192 blocks of 32
-    samples over 1024 persistent waves, every workgroup of the weight gradients with its share of every layer -- and a ragged neighbour.
-    Every layer's gradient, the loss and the predictions against float64 autograd, which takes the batch 16 rays at a time (the loss is a
-    mean over rays: oracle/train_oracle.py step_gradients_chunked), branched by the signs of the activations the step kept."""
+@pytest.mark.parametrize("fam,npar,blur,noise_std,n,S", [("carpet", (1, 6), None, 0.0, 1024, 256), ("carpet", (1, 6), None, 0.0, 1021, 255),
+                                                         ("grass_filtered", (2, 3), 0, 0.1, 1024, 256), ("fur", (1, 4), None, 0.0, 1024, 256)])
+def test_gradients_at_the_configs_batch(fam, npar, blur, noise_std, n, S):
+    """The step the row is about: the shipped training configs' 4 images x 256 rays x 256 samples = 262 144 samples
+    (config_carpet_train.py:23, 33, 101; config_grass_filtered_train.py with blur_idx 0 and raw_noise_std 0.1, :96-102; config_fur_train.py) --
+    8192 blocks of 32 samples over 1024 persistent waves, every workgroup of the weight gradients with its share of every layer, each
+    family on its own build of the forward chain -- and a ragged neighbour.  Every layer's gradient, the loss and the predictions against
+    float64 autograd, which takes the batch 16 rays at a time (the loss is a mean over rays: oracle/train_oracle.py step_gradients_chunked),
+    branched by the signs of the activations the step kept."""
     from nerf_tex_amd.train import Trainer
-    model, spec, wts = make_model((1, 6), dense_media=True)
-    ro, rd, t, cone, params, color, alpha = batch(21, n, S, 7, "carpet")
+    model, spec, wts = make_model(npar, dense_media=True)
+    ro, rd, t, cone, params, color, alpha = batch(21, n, S, sum(npar), fam)
     okw, loss = make_loss("alpha_smape")
-    tr = Trainer(model, max_rays=n, n_samples=S, perturb=True)
+    tr = Trainer(model, max_rays=n, n_samples=S, perturb=True, blur_idx=blur, raw_noise_std=noise_std)
     val, cp, ap = tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss, seed=4)
     torch.cuda.synchronize()
     got = tr.gradients()
     M = n * S
     masks = [tr.activation(k, M) > 0 for k in list(range(8)) + [8, 9]]                   # bool: 67 MB each
-    sigma_mask = tr.activation(10, M).reshape(n, S) > 0
+    noise = noise_std * orc.noise_normals(n, S, 4, dtype=np.float32).astype(np.float64) if noise_std > 0 else None
+    sigma_mask = (tr.activation(10, M).reshape(n, S) + (0 if noise is None else noise.astype(np.float32))) > 0
     z = orc.z_values_perturbed(t, S, 4, np.float32)
-    want_val, wc, wa, wg = tro.step_gradients_chunked(wts, spec, ro, rd, z, params, cone, color, alpha, okw, chunk_rays=16, masks=masks, sigma_mask=sigma_mask)
+    want_val, wc, wa, wg = tro.step_gradients_chunked(wts, spec, ro, rd, z, params, cone, color, alpha, okw, chunk_rays=16, masks=masks, sigma_mask=sigma_mask,
+                                                      noise=noise, blur_idx=blur)
     assert abs(float(val.item()) - want_val) <= 1e-5 * abs(want_val)
     assert orc.rel_linf(np.concatenate([cp.cpu().numpy(), ap.cpu().numpy()[:, None]], -1), np.concatenate([wc, wa[:, None]], -1)) <= 1e-4
     flat = np.concatenate([g.ravel() for g in wg])
