@@ -475,7 +475,9 @@ int ntx_instancer_set_mesh_textures(ntx_instancer *inst, const float *uv, int64_
  * (Keras get_weights() order, like ntx_create), Adam's moments, the gradient and every layer's activations for up to
  * max_rays x max_samples_per_ray samples (<= 1024 samples per ray; 23 KB per sample: 6 GB for the configs' 4 x 256 x 256; pos_map and
  * dir_map at most 96 features wide each).  Everything float32.  A step is bit-reproducible: weight gradients are summed over the samples
- * in a fixed order. */
+ * in a fixed order.  Against float64 autograd of the restated step (oracle/train_oracle.py, following the float32 pass's ReLU branches) every
+ * layer's gradient, the loss and the predictions are within 1e-4 rel-Linf at the configs' batch; where a batch is ill-conditioned (a handful
+ * of coarse steps per ray, depths a hair apart) within 4 times what float32 autograd of the same restatement is off by. */
 typedef struct ntx_trainer ntx_trainer;
 #define NTX_LOSS_NERF 0                  /* network.loss.NerfLoss  (loss.py:6-19):  loss_fn(color_true, color_pred) */
 #define NTX_LOSS_ALPHA 1                 /* network.loss.AlphaLoss (loss.py:21-49): + gamma * alpha_loss_fn(alpha_true, alpha_pred), colours masked by alpha_true */
@@ -545,8 +547,9 @@ int ntx_set_weights_device(ntx_ctx *ctx, const float *weights_dev, size_t n_floa
 /* The trainer's weights where they live: DEVICE memory of the trainer's device, Keras get_weights() order, ntx_trainer_weight_count floats,
  * valid until ntx_trainer_destroy; steps on a stream change them in that stream's order.  What ntx_set_weights_device takes. */
 int ntx_trainer_device_weights(ntx_trainer *t, const float **weights_dev);
-/* The dense contraction the trainer is made of (f32 MFMA, 128 x 128 x 16 tiles through LDS), on DEVICE buffers, for tests and benches:
- * C[M][N] = op(A) . op(B) (+ bias[N]) (ReLU); a_kcontig: A is [M][K] (row stride lda), else [K][M]; B is [K][N] (b_kcontig must be 0: the trainer transposes its weights once a step instead). */
+/* A dense contraction (f32 MFMA, 128 x 128 x 16 tiles through LDS) on DEVICE buffers, for tests and benches (round 4's trainer was made of it;
+ * the step now runs on the chain and weight-gradient kernels of csrc/ntx_train_device.h):
+ * C[M][N] = op(A) . op(B) (+ bias[N]) (ReLU); a_kcontig: A is [M][K] (row stride lda), else [K][M]; B is [K][N] (b_kcontig must be 0). */
 int ntx_gemm_f32(const float *A, int lda, int a_kcontig, const float *B, int ldb, int b_kcontig, float *C, int ldc, int M, int N, int K, const float *bias,
                  int relu, ntx_stream stream);
 
