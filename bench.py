@@ -330,12 +330,14 @@ def bench_train_step(args) -> None:
                 print("bench.py: " + how, file=sys.stderr)
             else:
                 how = f"ntx_trainer_allreduce_gradients (one ncclAllReduce through the C ABI, {comm.library})"
-    fam = synthetic.FAMILIES["carpet"]
+    fam_name = args.workload[:-len("_train_step")]              # carpet (the default and the quoted line), grass_filtered, fur: the shipped training configs' families
+    fam = synthetic.FAMILIES[fam_name]
     emb = lambda n_: {"module": "network.model.FourierFeatures", "n_freq_bands": n_}
     model = ParamNerf(emb(10), emb(4), emb(4), list(fam["n_parameters"]))["model"]
     model.set_blob(synthetic.synthetic_weights(model.layer_table(), seed=0, dense_media=True))
     n, S = 4 * 256, 256
-    ro, rd, t, cone = synthetic.all_hit_rays(n, [-1.5, -1.3, -.2], [1.3, 1.3, 1.9], fam["cam"], seed=1 + rank)           # config_carpet_train.py:28-31
+    box = ([-1.5, -1.3, -.2], [1.3, 1.3, 1.9]) if fam_name == "carpet" else (fam["b_0"], fam["b_1"])                    # config_carpet_train.py:28-31; config_<family>_train.py:29-30
+    ro, rd, t, cone = synthetic.all_hit_rays(n, box[0], box[1], fam["cam"], seed=1 + rank)
     rng = np.random.default_rng(3 + rank)
     params = np.tile(np.asarray([fam["params"]], np.float32), (n, 1))
     color = rng.uniform(0, 1, size=(n, 3)).astype(np.float32)
@@ -343,7 +345,8 @@ def bench_train_step(args) -> None:
     d = lambda a: torch.as_tensor(a, device=dev)
     batch = [d(x) for x in (ro, rd, t, params, cone, color, alpha)]
     loss = AlphaLoss(loss_fn="network.loss.smape", alpha_loss_fn="network.loss.mse")
-    tr = Trainer(model, max_rays=n, n_samples=S, lrate=5e-4, lrate_decay=500, perturb=True)
+    noise_std = 0.1 if fam_name == "grass_filtered" else 0.0     # config_grass_filtered_train.py:96-102: blur_idx 0, raw_noise_std 0.1
+    tr = Trainer(model, max_rays=n, n_samples=S, lrate=5e-4, lrate_decay=500, perturb=True, blur_idx=fam["blur_idx"], raw_noise_std=noise_std)
     for _ in range(args.warmup):
         tr.step(*batch, loss, comm=comm)
     torch.cuda.synchronize()
@@ -375,12 +378,13 @@ def bench_train_step(args) -> None:
     line = {"metric": "ray-samples/sec through one training step (forward + loss + backward + Adam) at 4 x 256 rays x 256 samples",
             "value": world * n * S * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"carpet_train_step: config_carpet_train.py's batch ({n} all-hit rays x {S} samples = {n * S} ray-samples), ParamNerf "
-                                   f"n_parameters={list(fam['n_parameters'])}, perturb=True, AlphaLoss(smape, mse), Adam + ExponentialDecay(5e-4, 5e5 steps, 0.1); "
+            "config": {"workload": f"{fam_name}_train_step: config_{fam_name}_train.py's batch ({n} all-hit rays x {S} samples = {n * S} ray-samples), ParamNerf "
+                                   f"n_parameters={list(fam['n_parameters'])}, perturb=True" + (f", blur_idx={fam['blur_idx']}" if fam["blur_idx"] is not None else "")
+                                   + (f", raw_noise_std={noise_std}" if noise_std else "") + ", AlphaLoss(smape, mse), Adam + ExponentialDecay(5e-4, 5e5 steps, 0.1); "
                                    "seeded weights and targets, batch resident in HBM", "rays": n, "samples_per_ray": S, "flops_per_sample_forward": flops_fwd,
                        "loss_after": float(val.item())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                         **train_step_traffic(),
+                         **(train_step_traffic() if fam_name == "carpet" else {"traffic": None, "traffic_source": None}),     # (the counter summary is the carpet step's)
                          "algorithmic_bytes": train_step_algorithmic_bytes(model, n * S),
                          "algorithmic_bytes_what": "a stored-activation step: every layer's output and the gradient at it written once (O layout) and read once by the weight "
                                                    "gradients, the encoded inputs written in both orders and read by the chain and by the weight gradients (DESIGN section 10)",
@@ -644,7 +648,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS) + sorted(SHARDED) + ["carpet_instanced", "carpet_instanced_scene", "carpet_train_step"])
+    ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS) + sorted(SHARDED) + ["carpet_instanced", "carpet_instanced_scene", "carpet_train_step", "grass_filtered_train_step", "fur_train_step"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="float32", choices=["float32", "fp16x3"],
                     help="arithmetic of the Dense layers (include/nerftex.h: ntx_precision); float32 = the reference's")
@@ -664,7 +668,7 @@ def main() -> None:
         return bench_instanced(args)
     if args.workload == "carpet_instanced_scene":
         return bench_instanced_scene(args)
-    if args.workload == "carpet_train_step":
+    if args.workload.endswith("_train_step"):
         return bench_train_step(args)
 
     # The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL writes its version banner with printf
