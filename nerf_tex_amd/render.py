@@ -2,8 +2,9 @@
 
 `Render` builds dataset -> model -> renderer exactly as render.py:16-25 does and then plays the
 part of `Logger.render_images` (logger.py:88-137): loop over views, call the renderer, pack RGBA.
-Checkpoint restore and PNG/EXR writing are the reference's I/O layer and are out of scope; images
-are returned (and optionally saved as .npy).
+With a `target_path` every view is written under `media/test/` as the reference's Logger does (logger.py:88-144): the PNG of the
+filtered, un-premultiplied uint8 image (`write_image`; EXR writing needs pyexr and is not built), and beside it the raw premultiplied
+float32 RGBA as .npy.
 """
 
 from __future__ import annotations
@@ -76,9 +77,24 @@ def Render(target_path: Optional[str], test_dataset_config, model_config, render
             import numpy as np
             os.makedirs(os.path.join(target_path, "media", "test"), exist_ok=True)
             np.save(os.path.join(target_path, "media", "test", util_format(i, len(test_dataset))), img.cpu().numpy())
+            write_images(os.path.join(target_path, "media", "test"), img, i, len(test_dataset), int((logger_config or {}).get("downsampling_factor", 1)))
         if return_imgs:
             imgs.append(img)
     return imgs
+
+
+def write_images(directory: str, rgba, first_idx: int, max_idx: int, downsampling_factor: int = 1) -> List[str]:
+    """Logger.render_image's post-processing and write_image (logger.py:128-144) for a batch of premultiplied RGBA images [B, H, W, 4]:
+    filtered downsample, un-premultiply, uint8 (`ntx_image_epilogue`), one PNG each named like `util.format_name('', idx, max_idx, '.png')`."""
+    from . import png
+    os.makedirs(directory, exist_ok=True)
+    out = []
+    for k in range(rgba.shape[0]):
+        _, u8 = image_epilogue(rgba[k], downsampling_factor, write_exr=False, uint8=True)
+        path = os.path.join(directory, util_format(first_idx + k, max_idx)[:-4] + ".png")
+        png.write_png(path, u8.cpu().numpy())
+        out.append(path)
+    return out
 
 
 def util_format(idx: int, max_idx: int) -> str:

@@ -453,6 +453,10 @@ def Train(target_path: str, train_dataset, val_dataset=None, model_config: dict 
             from .render import render_image
             trainer.hand_weights_to_models() if two else model.set_weights_from_trainer(trainer)
             out["images"][step] = [render_image(renderer, val_dataset, view)[0] for view in val_dataset]
+            from .render import write_images, util_format                 # logger.py:76-78: media/validation/<step padded to n_iters>/<view>.png
+            vdir = os.path.join(target_path, "media", "validation", util_format(step, int(n_iters))[:-4])
+            for k, im in enumerate(out["images"][step]):
+                write_images(vdir, im[None], k, len(out["images"][step]), int((logger_config or {}).get("downsampling_factor", 1)))
         if i_ckpt > 0 and step % i_ckpt == 0:                               # logger.py:84-86
             out["checkpoints"].append(trainer.save(os.path.join(ckpt_dir, f"ckpt-{step}"), step=step))
             for old in out["checkpoints"][:-keep] if keep > 0 else []:

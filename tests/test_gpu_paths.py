@@ -606,7 +606,7 @@ def test_main_entry_point_renders_the_example_config(tmp_path, monkeypatch):
     a = imgs[0][0, ..., 3]
     assert bool(torch.isfinite(imgs[0]).all()) and float(a.max()) > 0.0 and float(a.min()) == 0.0      # object and empty background
     saved = sorted(os.listdir(tmp_path / "logs" / "example_carpet" / "media" / "test"))
-    assert saved == ["0.npy", "1.npy"] and os.path.exists(tmp_path / "logs" / "example_carpet" / "config_render.py")
+    assert saved == ["0.npy", "0.png", "1.npy", "1.png"] and os.path.exists(tmp_path / "logs" / "example_carpet" / "config_render.py")
 
 
 def test_rays_at_any_image_plane_locations():

@@ -527,6 +527,9 @@ def test_train_loop_renders_validation_views_and_checkpoints(tmp_path):
     assert out["step"] == 200 and len(losses) == 10 and np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0]
     assert sorted(out["images"]) == [100, 200] and out["images"][200][0].shape == (24, 24, 4)
     assert not torch.equal(out["images"][100][0], out["images"][200][0])
+    from nerf_tex_amd import png                                   # the Logger's files (logger.py:76-78, 139-144): media/validation/<step>/<view>.png
+    shot = np.asarray(png.read_png(str(tmp_path / "media" / "validation" / "200" / "0.png")))
+    assert shot.shape[:2] == (24, 24) and sorted(os.listdir(tmp_path / "media" / "validation")) == ["100", "200"]
     kept = sorted(f for f in os.listdir(tmp_path / "checkpoints") if f.endswith(".index"))
     assert kept == ["ckpt-150.index", "ckpt-200.index"]
     tr, model, renderer = out["trainer"], out["trainer"].model, out["renderer"]

@@ -694,6 +694,12 @@ def test_png_reader_undoes_every_row_filter(tmp_path):
         assert np.array_equal(np.asarray(png.read_png(f)).reshape(H, W, n), img)
     with pytest.raises(ValueError, match="truncated"):
         png._unfilter(np.zeros(10, np.uint8), 2, 8, 4)
+    for c in (1, 2, 3, 4):                                          # and the writer (Logger.write_image, logger.py:139-144): its files decode to what went in
+        img = rng.integers(0, 256, (9, 11, c), dtype=np.uint8)
+        png.write_png(str(tmp_path / "w.png"), img)
+        assert np.array_equal(np.asarray(png.read_png(str(tmp_path / "w.png"))).reshape(9, 11, c), img)
+    with pytest.raises(ValueError):
+        png.write_png(str(tmp_path / "w.png"), np.zeros((4, 4, 3), np.float32))
 
 
 def test_main_entry_point_prepares_reference_configs():
