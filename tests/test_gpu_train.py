@@ -685,3 +685,32 @@ def test_full_batch_properties_without_an_oracle():
     assert abs(np.mean(vals) - float(v0.item())) <= 1e-6 * abs(float(v0.item()))
     worst = max(rel_linf(g[sl_], (acc / B)[sl_]) for _, sl_ in layer_slices(spec))
     assert worst <= 2e-5 and np.abs(g).max() > 1e-6, worst
+
+
+def test_a_student_network_learns_a_teacher_s_render():
+    """The loop end to end on a target that CAN be learnt: the colours and alphas a teacher network renders along 512 rays (the inference
+    path, no jitter) are the training targets of a student started from other weights; 1500 steps of AlphaLoss(mse) under Adam with jitter
+    bring the loss down by more than an order of magnitude and the student's own render (weights handed over on the device) close to the
+    teacher's -- what gradient parity on random targets cannot show: that the steps add up."""
+    from nerf_tex_amd.loss import AlphaLoss
+    from nerf_tex_amd.renderer import Renderer
+    from nerf_tex_amd.train import Trainer
+    teacher, _, _ = make_model((1, 6), seed=2, dense_media=True)
+    student, _, _ = make_model((1, 6), seed=1)
+    n, S = 512, 64
+    ro, rd, t, cone, params, _, _ = batch(8, n, S, 7, "carpet")
+    d = lambda x: torch.as_tensor(x, device=dev())
+    view = dict(rays_o=d(ro)[None], rays_d=d(rd)[None], t=d(t)[None], parameters=d(params[:1]), cone_scale=d(cone).reshape(1, -1, 1))
+    params = np.repeat(params[:1], n, 0)
+    want = Renderer(model=teacher, n_samples=S, perturb=False)(**view, training=False)
+    color, alpha = want["color_pred"][0].contiguous(), want["alpha_pred"][0].contiguous()
+    assert float(alpha.std()) > 0.05 and float(color.std()) > 0.03                              # something to learn: alphas 0.2 .. 1 over the rays
+    loss = AlphaLoss(loss_fn="network.loss.mse", filter_color_loss=False)
+    tr = Trainer(student, max_rays=n, n_samples=S, lrate=5e-4, lrate_decay=0, perturb=True)
+    hist = [float(tr.step(ro, rd, t, params, cone, color, alpha, loss).item()) for _ in range(1500)]
+    first, last = np.mean(hist[:5]), np.mean(hist[-20:])
+    assert np.isfinite(hist).all() and last < first / 10, (first, last, hist[::150])
+    student.set_weights_from_trainer(tr)
+    got = Renderer(model=student, n_samples=S, perturb=False)(**view, training=False)
+    err = float((got["color_pred"] - want["color_pred"]).abs().mean()), float((got["alpha_pred"] - want["alpha_pred"]).abs().mean())
+    assert max(err) < 0.05, err
