@@ -144,23 +144,13 @@ def read_png(path: str) -> np.ndarray:
     return np.ascontiguousarray(out)
 
 
-def write_png(path: str, pixels) -> None:
-    """[height, width(, channels 1..4)] uint8 -> an 8-bit non-interlaced PNG (tests and stand-in textures)."""
-    a = np.asarray(pixels, np.uint8)
+def write_png(path: str, img: np.ndarray, level: int = 6) -> None:
+    """An 8-bit non-interlaced PNG of img [H, W, C] (or [H, W]: grey), C in 1 (grey), 2 (grey + alpha), 3 (RGB), 4 (RGBA) -- what
+    `tf.io.encode_png` makes of the uint8 image in `Logger.write_image` (logger.py:139-144); also the tests' stand-in textures.  Rows
+    unfiltered (type 0), one IDAT; the pixels decode to `img`, the bytes are not TensorFlow's."""
+    a = np.ascontiguousarray(img)
     if a.ndim == 2:
         a = a[:, :, None]
-    h, w, c = a.shape
-    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
-    raw = b"".join(b"\x00" + a[r].tobytes() for r in range(h))
-    chunk = lambda k, b: struct.pack(">I", len(b)) + k + b + struct.pack(">I", zlib.crc32(k + b) & 0xffffffff)
-    with open(path, "wb") as f:
-        f.write(_SIGNATURE + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
-
-
-def write_png(path: str, img: np.ndarray, level: int = 6) -> None:
-    """An 8-bit PNG of img [H, W, C], C in 1 (grey), 2 (grey + alpha), 3 (RGB), 4 (RGBA) -- what `tf.io.encode_png` makes of the uint8 image in
-    `Logger.write_image` (logger.py:139-144).  Rows unfiltered (type 0), one IDAT; the pixels decode to `img`, the bytes are not TensorFlow's."""
-    a = np.ascontiguousarray(img)
     if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] not in (1, 2, 3, 4):
         raise ValueError(f"write_png takes uint8 [H, W, 1..4], got {a.dtype} {a.shape}")
     h, w, c = a.shape
