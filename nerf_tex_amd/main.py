@@ -3,9 +3,10 @@ points its hot-path modules at this package (`util.remap_reference_config`) and 
 
 What main.py does for a render config is kept: the config is a python file with a `config` dict (main.py:17-23), the random
 seed is set from it (main.py:30-32; numpy only -- it drives the pose / parameter distributions, the initial weights and the
-stratified jitter's seeds), the target folder is created and the config copied into it (main.py:35-42).  Training configs
-(`network.train.Train`) are out of scope and refused.  The reference's TF-free `data.distribution` / `data.sampler` modules are
-used as they are when the config names them: pass `--reference-root` (the directory holding `data/` and `util/`) or run from it.
+stratified jitter's seeds), the target folder is created and the config copied into it as `config_render.py` / `config_train.py`
+(main.py:35-42).  Training configs (`network.train.Train`) run through `nerf_tex_amd.train.Train` with their own dataset, model, loss,
+renderer and logger blocks.  The pose / parameter generators a config names (`data.distribution.*`, `data.sampler.*`) are this package's
+(`nerf_tex_amd/distributions.py`); `--reference-root` puts a reference tree on the path for anything else a config may name.
 
     python -m nerf_tex_amd.main configs/example_carpet_render.py
     python -m nerf_tex_amd.main /path/to/nerf-tex/configs/config_carpet_render.py --reference-root /path/to/nerf-tex --volumetric
@@ -38,8 +39,6 @@ def prepare(config: dict, volumetric: bool = False) -> util.EasyDict:
     needs an instancer (the reference's on Embree, or nerf_tex_amd.instancer.Instancer with an exported transformation list); render
     the bare volume inside the proxy with `Renderer` instead."""
     cfg = util.remap_reference_config(config)
-    if "train" in str(cfg.get("module", "")).lower():
-        raise NotImplementedError("training (network.train.Train) is outside the render path this package implements")
     if volumetric:
         rc = cfg.renderer_config
         if rc.module.endswith("InstanceRenderer"):
@@ -65,7 +64,7 @@ def main(argv=None) -> list:
     target = raw.get("target_path")
     if target:                                                             # main.py:35-42
         os.makedirs(target, exist_ok=bool(raw.get("override", True)))
-        dst = os.path.join(target, "config_render.py")
+        dst = os.path.join(target, "config_train.py" if "train" in str(raw.get("module", "")) else "config_render.py")   # main.py:36-37
         src = args.config if args.config.endswith(".py") else args.config + ".py"
         if os.path.abspath(src) != os.path.abspath(dst):
             shutil.copy(src, dst)
@@ -73,5 +72,5 @@ def main(argv=None) -> list:
 
 
 if __name__ == "__main__":
-    imgs = main()
-    print(f"rendered {len(imgs)} image(s)")
+    out = main()
+    print(f"trained to step {out['step']}" if isinstance(out, dict) else f"rendered {len(out)} image(s)")

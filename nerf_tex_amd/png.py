@@ -79,7 +79,28 @@ def _samples(lines: np.ndarray, width: int, depth: int, n: int) -> np.ndarray:
 
 def read_png(path: str) -> np.ndarray:
     with open(path, "rb") as f:
-        data = f.read()
+        return decode_png(f.read(), path)
+
+
+def with_channels(img: np.ndarray, channels: int = 4) -> np.ndarray:
+    """`tf.image.decode_image(..., channels=4)` / `stbi_load(..., 4)` of a decoded [H, W, 1..4] image: grey becomes R = G = B, a missing
+    alpha 255; `channels=3` drops the alpha."""
+    a = np.asarray(img)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    n = a.shape[2]
+    top = np.iinfo(a.dtype).max if a.dtype.kind in "iu" else 1
+    rgb = a[..., :3] if n >= 3 else np.repeat(a[..., :1], 3, axis=2)
+    if channels == 3:
+        return np.ascontiguousarray(rgb)
+    if channels != 4:
+        raise ValueError("channels 3 or 4")
+    alpha = a[..., n - 1:n] if n in (2, 4) else np.full(a.shape[:2] + (1,), top, a.dtype)
+    return np.ascontiguousarray(np.concatenate([rgb, alpha], axis=2))
+
+
+def decode_png(data: bytes, path: str = "<bytes>") -> np.ndarray:
+    """The uint8 [H, W, C] image of an encoded PNG (every colour type and bit depth, Adam7; 16-bit samples keep their high byte)."""
     if data[:8] != _SIGNATURE:
         raise ValueError(f"{path}: not a PNG file")
     at = 8
@@ -145,6 +166,11 @@ def read_png(path: str) -> np.ndarray:
 
 
 def write_png(path: str, img: np.ndarray, level: int = 6) -> None:
+    with open(path, "wb") as f:
+        f.write(encode_png(img, level))
+
+
+def encode_png(img: np.ndarray, level: int = 6) -> bytes:
     """An 8-bit non-interlaced PNG of img [H, W, C] (or [H, W]: grey), C in 1 (grey), 2 (grey + alpha), 3 (RGB), 4 (RGBA) -- what
     `tf.io.encode_png` makes of the uint8 image in `Logger.write_image` (logger.py:139-144); also the tests' stand-in textures.  Rows
     unfiltered (type 0), one IDAT; the pixels decode to `img`, the bytes are not TensorFlow's."""
@@ -157,5 +183,4 @@ def write_png(path: str, img: np.ndarray, level: int = 6) -> None:
     ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
     raw = np.concatenate([np.zeros((h, 1), np.uint8), a.reshape(h, w * c)], axis=1).tobytes()
     chunk = lambda kind, body: struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
-    with open(path, "wb") as f:
-        f.write(_SIGNATURE + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, level)) + chunk(b"IEND", b""))
+    return _SIGNATURE + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, level)) + chunk(b"IEND", b"")

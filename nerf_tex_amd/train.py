@@ -53,7 +53,7 @@ class Trainer:
         (network.model.ParamNerf ...), `loss_config`, `lrate`, `lrate_decay`, `renderer_config` (n_samples, perturb, raw_noise_std, blur_idx,
         map_exr; render_chunk / net_chunk / downsampling_factor have no meaning here: a step is one batch).  `max_rays` defaults to the config's batch --
         `train_dataset_config.batchsize` images x `pixel_sampler_config.n_samples` rays -- when the config says it.  Returns (trainer, loss).
-        The data side (TFRecord datasets, logger, checkpoints) is not built from it: SURVEY section 2."""
+        The data side (`nerf_tex_amd.dataset`) and the loop around the step are `Train`'s."""
         from . import util
         cfg = util.remap_reference_config(config)
         models = util.instantiate(dict(cfg["model_config"]))                     # {'model': ...} or CoarseFine's {'model': ..., 'model_fine': ...}
@@ -394,13 +394,15 @@ def _split_blob(table, blob):
     return out
 
 
-def Train(target_path: str, train_dataset, val_dataset=None, model_config: dict = None, loss_config: dict = None, n_iters: int = 1000, lrate: float = 5e-4,
+def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: dict = None, loss_config: dict = None, n_iters: int = 1000, lrate: float = 5e-4,
           lrate_decay: float = 0, renderer_config: dict = None, logger_config: dict = None, max_rays: int = None, device: int = 0, weights=None,
-          composite_bkgd: bool = None, bkgd_color=None, **kwargs) -> dict:
-    """network.train.Train (train.py:7-70) with the data side handed in: `train_dataset` is an iterable of batch dicts as network/dataset.py
-    maps them (rays_o / rays_d [B,R,3], t [B,R,2], cone_scale [B,R,1], parameters [B,P], color [B,R,3], alpha [B,R]) -- TFRecord reading
-    stays out of scope --, `val_dataset` a `nerf_tex_amd.dataset.Dataset` (or any iterable of ray batch dicts with height / width / composite_bkgd /
-    bkgd_color) whose views are rendered every `i_img` steps.  The other arguments are the reference's: `model_config` / `loss_config` /
+          composite_bkgd: bool = None, bkgd_color=None, train_dataset_config: dict = None, val_dataset_config: dict = None, **kwargs) -> dict:
+    """network.train.Train (train.py:7-70).  The data side either as the reference's blocks -- `train_dataset_config` / `val_dataset_config`
+    (`network.dataset.Dataset` over `TFRecord` / `FileFolder` / `GenerateData`, instantiated here as train.py:23-26 does, `n_parameters` of the
+    model defaulting to the dataset's, :29) -- or handed in: `train_dataset` any iterable of batch dicts as network/dataset.py maps them
+    (rays_o / rays_d [B,R,3], t [B,R,2], cone_scale [B,R,1], parameters [B,P], color [B,R,3], alpha [B,R]), `val_dataset` a
+    `nerf_tex_amd.dataset.Dataset` (or any iterable of ray batch dicts with height / width / composite_bkgd / bkgd_color) whose views are
+    rendered every `i_img` steps.  The other arguments are the reference's: `model_config` / `loss_config` /
     `renderer_config` blocks, `n_iters`, `lrate`, `lrate_decay`, and of `logger_config` (logger.py:14) `i_print`, `i_img`, `i_checkpoint`,
     `max_to_keep`.  What the reference's Logger does at its cadences happens here: a checkpoint `checkpoints/ckpt-<step>` under `target_path`
     (model + step + optimizer, train.py:55-57) every `i_checkpoint` steps, the validation views through `Renderer` -- the inference path, the
@@ -411,11 +413,23 @@ def Train(target_path: str, train_dataset, val_dataset=None, model_config: dict 
     import torch
     from . import checkpoint, util
     from .renderer import Renderer
+    if train_dataset is None:
+        if train_dataset_config is None:
+            raise TypeError("Train needs train_dataset_config (the reference's block) or train_dataset (an iterable of batches)")
+        train_dataset = util.instantiate(dict(util.remap_reference_config(train_dataset_config), device=torch.device("cuda", device)))
+    if val_dataset is None and val_dataset_config is not None:
+        val_dataset = util.instantiate(dict(util.remap_reference_config(val_dataset_config), device=torch.device("cuda", device)))
+    if model_config is not None and hasattr(train_dataset, "n_parameters"):
+        model_config = dict(model_config)
+        model_config.setdefault("n_parameters", train_dataset.n_parameters)     # train.py:29
     cfg = util.remap_reference_config(dict(model_config=model_config, loss_config=loss_config, renderer_config=renderer_config or {}, lrate=lrate,
                                            lrate_decay=lrate_decay))
     if max_rays is None:
-        first = next(iter(train_dataset))
-        max_rays = int(first["rays_o"].shape[0]) * int(first["rays_o"].shape[1])
+        if hasattr(train_dataset, "batchsize") and hasattr(train_dataset, "n_samples"):
+            max_rays = int(train_dataset.batchsize) * int(train_dataset.n_samples)
+        else:
+            first = next(iter(train_dataset))
+            max_rays = int(first["rays_o"].shape[0]) * int(first["rays_o"].shape[1])
     trainer, loss_fn = Trainer.from_config(cfg, max_rays=max_rays, device=device, weights=weights)
     model = trainer.model
     rcfg = {k: v for k, v in dict(cfg["renderer_config"]).items() if k != "module"}

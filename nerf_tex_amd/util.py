@@ -43,11 +43,12 @@ def get_attr_from_path(path: str) -> Any:
 
 
 def instantiate(config: dict) -> Any:
-    """`{'module': 'pkg.mod.Attr', **kwargs}` -> `Attr(**kwargs)`; None -> None (util.py:44-54)."""
+    """`{'module': 'pkg.mod.Attr', **kwargs}` -> `Attr(**kwargs)`; None -> None (util.py:44-54).  A reference module name that has a
+    drop-in here (`_REMAP` below) resolves to it, so nested blocks need no remapping of their own."""
     if config is None:
         return None
     args = EasyDict(config)
-    module = args.module
+    module = _REMAP.get(args.module, args.module)
     del args["module"]
     return get_attr_from_path(module)(**args)
 
@@ -69,10 +70,27 @@ _REMAP = {
     "network.ray_sampler.Frustum": "nerf_tex_amd.ray_sampler.Frustum",
     "network.proxy.AABB": "nerf_tex_amd.proxy.AABB",
     "network.pixel_sampler.Full": "nerf_tex_amd.pixel_sampler.Full",
+    "network.pixel_sampler.Independent": "nerf_tex_amd.pixel_sampler.Independent",
+    "network.pixel_sampler.Proxy": "nerf_tex_amd.pixel_sampler.Proxy",
+    "network.train.Train": "nerf_tex_amd.train.Train",
+    "network.dataset.TFRecord": "nerf_tex_amd.dataset.TFRecord",
+    "network.dataset.FileFolder": "nerf_tex_amd.dataset.FileFolder",
     "network.render.Render": "nerf_tex_amd.render.Render",
     "network.dataset.Dataset": "nerf_tex_amd.dataset.Dataset",
     "network.dataset.GenerateData": "nerf_tex_amd.dataset.GenerateData",
     "instancer.instancer.Instancer": "nerf_tex_amd.instancer.Instancer",
+    "data.sampler.Sampler": "nerf_tex_amd.distributions.Counter",
+    "data.sampler.Independent": "nerf_tex_amd.distributions.UniformPoints",
+    "data.sampler.Constant": "nerf_tex_amd.distributions.FixedPoint",
+    "data.sampler.Grid": "nerf_tex_amd.distributions.GridPoints",
+    "data.sampler.Stratified": "nerf_tex_amd.distributions.JitteredGridPoints",
+    "data.sampler.Concat": "nerf_tex_amd.distributions.JoinedPoints",
+    "data.distribution.Sphere": "nerf_tex_amd.distributions.Sphere",
+    "data.distribution.Hemisphere": "nerf_tex_amd.distributions.Hemisphere",
+    "data.distribution.AABB": "nerf_tex_amd.distributions.Box",
+    "data.distribution.Constant": "nerf_tex_amd.distributions.Constants",
+    "data.distribution.Range": "nerf_tex_amd.distributions.Range",
+    "data.distribution.Concat": "nerf_tex_amd.distributions.Joined",
     "network.loss.NerfLoss": "nerf_tex_amd.loss.NerfLoss",
     "network.loss.AlphaLoss": "nerf_tex_amd.loss.AlphaLoss",
 }

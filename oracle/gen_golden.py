@@ -53,16 +53,69 @@ def renderer_configs():
 
 def train_configs():
     """Part (6): what the shipped TRAINING configs hand the step of train.py:49-67 -- model, loss, learning-rate schedule, renderer block and
-    the batch shape (images per batch x rays per image) -- from the reference's own config modules."""
+    the batch shape (images per batch x rays per image), and the data and logger blocks `Train` is called with (train.py:7-17) -- from the
+    reference's own config modules."""
     sys.path.insert(0, REF)
     out = {}
     for fam in ("carpet", "fur", "grass", "grass_filtered", "plush"):
         cfg = importlib.import_module(f"configs.config_{fam}_train").config
         out[fam] = {"source": f"configs/config_{fam}_train.py", "model_config": cfg["model_config"], "loss_config": cfg["loss_config"],
                     "lrate": cfg["lrate"], "lrate_decay": cfg["lrate_decay"], "renderer_config": cfg["renderer_config"],
-                    "batchsize": cfg["train_dataset_config"]["batchsize"], "rays_per_image": cfg["train_dataset_config"]["pixel_sampler_config"]["n_samples"]}
+                    "batchsize": cfg["train_dataset_config"]["batchsize"], "rays_per_image": cfg["train_dataset_config"]["pixel_sampler_config"]["n_samples"],
+                    "train_dataset_config": cfg["train_dataset_config"], "val_dataset_config": cfg["val_dataset_config"], "n_iters": cfg["n_iters"],
+                    "logger_config": cfg["logger_config"]}
+        # what the reference's own data/distribution.py + data/sampler.py make of the validation block (dataset.py:201-219), run here
+        from util import util as ref_util
+        np.random.seed(cfg["seed"])
+        dl = ref_util.EasyDict(cfg["val_dataset_config"]["data_loader_config"])
+        pose_dist, param_dist = ref_util.instantiate(dl.pose_dist_config), ref_util.instantiate(dl.parameter_dist_config)
+        radius = dl.get("radius", 5.)                                                      # dataset.py:198 default
+        rad = ref_util.instantiate(radius) if isinstance(radius, dict) else (lambda r=radius: r)
+        n = max([dl.get("dataset_size", -1), pose_dist.sampler.n, param_dist.sampler.n])
+        out[fam]["seed"] = cfg["seed"]
+        out[fam]["val_views_reference"] = {"n": n, "views": [{"pose_dist_sample": np.asarray(pose_dist(), np.float64).tolist(), "radius": float(np.asarray(rad()).reshape(-1)[0]),
+                                                                "parameters": np.asarray(param_dist(), np.float64).tolist()} for _ in range(min(n, 8))]}
     with open(os.path.join(OUT, "train_configs.json"), "w") as f:
         json.dump(out, f, indent=1)
+
+
+def distributions():
+    """Part (7): the reference's data/distribution.py + data/sampler.py (TensorFlow-free, run here) on blocks that reach what the shipped
+    configs do not: random points, boxes, ranges, hemispheres, grids in several dimensions.  tests/test_data.py asks
+    nerf_tex_amd/distributions.py for the same sequences."""
+    sys.path.insert(0, REF)
+    from util import util as ref_util
+    S, D = "data.sampler.", "data.distribution."
+    cases = [
+        {"module": D + "Sphere"},
+        {"module": D + "Sphere", "u_range": [0.1, 0.4], "v_range": [0.25, 0.5]},
+        {"module": D + "Hemisphere", "axis": 0, "sampler_config": {"module": S + "Grid", "d": 2, "n": 9, "sample_center": True}},
+        {"module": D + "Hemisphere", "axis": 1, "sampler_config": {"module": S + "Grid", "d": 2, "n": 7}},
+        {"module": D + "Hemisphere", "axis": 2},
+        {"module": D + "AABB"},
+        {"module": D + "AABB", "b_0": [-1.5, 0.25, 2.0], "b_1": [1.5, 0.75, 3.0]},
+        {"module": D + "AABB", "sampler_config": {"module": S + "Grid", "d": 3, "n": 20}, "b_0": [-2.0, -2.0, 0.5], "b_1": [1.0, 2.0, 4.0]},
+        {"module": D + "Range", "n": 5, "b_0": [0.0, 1.0], "b_1": [1.0, 3.0]},
+        {"module": D + "Range", "n": 3},
+        {"module": D + "Constant", "constants": [[1, 2], [3, 4], [5, 6]]},
+        {"module": D + "Concat", "distribution_config_0": {"module": D + "Constant", "constants": [[0.5], [0.75]]},
+         "distribution_config_1": {"module": D + "Range", "n": 4, "b_0": [0.0, 10.0], "b_1": [1.0, 20.0]}},
+        {"module": D + "Concat", "distribution_config_0": {"module": D + "Constant", "constants": [[7]]}, "distribution_config_1": {"module": D + "AABB"}},
+        {"module": D + "Sphere", "sampler_config": {"module": S + "Concat", "sampler_config_0": {"module": S + "Constant", "c": [0.3]},
+                                                   "sampler_config_1": {"module": S + "Grid", "sample_center": True}, "n": 6}},
+        {"module": D + "AABB", "sampler_config": {"module": S + "Concat", "sampler_config_0": {"module": S + "Constant", "d": 2, "c": 0.25},
+                                                 "sampler_config_1": {"module": S + "Independent", "d": 1}, "n": 4, "idx": 2}},
+    ]
+    out = []
+    for k, block in enumerate(cases):
+        np.random.seed(100 + k)
+        dist = ref_util.instantiate(ref_util.EasyDict(json.loads(json.dumps(block))))
+        samples = [np.asarray(dist(), np.float64).tolist() for _ in range(7)]
+        out.append({"config": block, "seed": 100 + k, "n": int(dist.sampler.n), "idx_after": int(dist.sampler.idx), "done_after": bool(dist.sampler.done()),
+                    "samples": samples})
+    with open(os.path.join(OUT, "distributions.json"), "w") as f:
+        json.dump({"source": "/root/reference/data/distribution.py + data/sampler.py (reference code, run here by oracle/gen_golden.py)", "cases": out}, f, indent=1)
+    print("distributions", len(out), "cases")
 
 
 def cameras():
@@ -93,6 +146,7 @@ def cameras():
                "seed": cfg["seed"], "height": dl.height, "width": dl.width, "angle": dl.angle,
                "focal": orc.focal_from_angle(dl.width, dl.angle), "b_0": proxy["b_0"], "b_1": proxy["b_1"],
                "n_parameters": cfg["model_config"]["n_parameters"], "views": views,
+               "data_loader_config": cfg["test_dataset_config"]["data_loader_config"],      # the block itself: tests/test_data.py runs the package's own generators on it
                "note": "c2w_oracle_look_at_f32 comes from the oracle's restatement of dataset.look_at, not from the reference"}
         with open(os.path.join(OUT, f"cameras_{fam}.json"), "w") as f:
             json.dump(doc, f, indent=1)
@@ -212,6 +266,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["renderer_configs"]:           # part (5) alone
         renderer_configs()
         sys.exit(0)
+    if sys.argv[1:] == ["distributions"]:              # part (7) alone
+        distributions()
+        sys.exit(0)
     if sys.argv[1:] == ["train_configs"]:              # part (6) alone
         train_configs()
         sys.exit(0)
@@ -222,3 +279,4 @@ if __name__ == "__main__":
     plumbing()
     renderer_configs()
     train_configs()
+    distributions()

@@ -704,13 +704,16 @@ def test_png_reader_undoes_every_row_filter(tmp_path):
 
 def test_main_entry_point_prepares_reference_configs():
     """nerf_tex_amd.main (reference: main.py): config file -> remapped config; `--volumetric` swaps the Embree-backed
-    InstanceRenderer for the volumetric Renderer; training configs are refused."""
+    InstanceRenderer for the volumetric Renderer; a training config's top-level module and data blocks resolve to this package's."""
     from nerf_tex_amd import main as m
     cfg = m.prepare(m.load_config(os.path.join(ROOT, "configs", "example_carpet_render.py")))
     assert cfg.module == "nerf_tex_amd.render.Render" and cfg.renderer_config.module == "nerf_tex_amd.renderer.Renderer"
     assert "seed" not in cfg and len(cfg.test_dataset_config.data_loader_config.views) == 2
-    with pytest.raises(NotImplementedError):
-        m.prepare({"module": "network.train.Train"})
+    import json
+    tcfg = json.load(open(os.path.join(ROOT, "tests", "golden", "train_configs.json")))["carpet"]
+    t = m.prepare({"module": "network.train.Train", "seed": 0, "override": True, **{k: tcfg[k] for k in ("train_dataset_config", "val_dataset_config", "model_config")}})
+    assert t.module == "nerf_tex_amd.train.Train" and t.train_dataset_config.data_loader_config.module == "nerf_tex_amd.dataset.TFRecord"
+    assert t.val_dataset_config.data_loader_config.pose_dist_config.module == "nerf_tex_amd.distributions.Constants" and "seed" not in t
     ref = "/root/reference/configs/config_carpet_render.py"
     if os.path.exists(ref):
         sys.path.insert(0, "/root/reference")
