@@ -1,0 +1,128 @@
+"""The training loop fed the way the reference feeds it (train.py:20-26, 60): `network.dataset.Dataset` over a TFRecord file, `pixel_sampler.Proxy`,
+`ray_sampler.Proxy`, the proxy box -- the shipped carpet training config's own blocks (tests/golden/train_configs.json, made from the reference's
+config module), pointed at a small file made here from a teacher network's renders."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+H = W = 64
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def teacher_set(root, n_views=6, S=48):
+    """A NeRF-layout folder of a teacher network's renders (uint8 RGBA PNGs, un-premultiplied as logger.py:133-144 writes them) from cameras
+    on a ring, the seven carpet parameters as `driver_parameters`; converted to TFRecord shards.  Returns (tfr dir, the uint8 images, poses)."""
+    from nerf_tex_amd import dataset as D, png, synthetic, tfrecord
+    from nerf_tex_amd.model import ParamNerf
+    from nerf_tex_amd.layer import FourierFeatures
+    from nerf_tex_amd.render import image_epilogue, render_image
+    from nerf_tex_amd.renderer import Renderer
+    cfg = json.load(open(os.path.join(GOLDEN, "train_configs.json")))["carpet"]
+    box = cfg["train_dataset_config"]["proxy_config"]
+    teacher = ParamNerf(FourierFeatures(10), FourierFeatures(4), FourierFeatures(4), [1, 6])["model"]
+    teacher.set_blob(synthetic.synthetic_weights(teacher.layer_table(), seed=2, dense_media=True))
+    params = [1.0, 1.0, 1.0, 0.1, 0.0, -0.707, 0.707]
+    views = [{"pose": D.look_at(np.asarray([np.cos(a), np.sin(a), 0.6]) * 5), "parameters": params} for a in np.linspace(0, 2 * np.pi, n_views, endpoint=False)]
+    ds = D.Dataset({"module": "nerf_tex_amd.dataset.FromViews", "views": views, "height": H, "width": W, "angle": 0.63},
+                   {"module": "network.pixel_sampler.Full"}, {"module": "network.ray_sampler.Proxy"}, dict(box), n_epochs=1, device=dev())
+    renderer = Renderer(model=teacher, n_samples=S, perturb=False)
+    os.makedirs(os.path.join(root, "nerf", "train"))
+    imgs, frames = [], []
+    for k, data in enumerate(ds):
+        rgba = render_image(renderer, ds, data)[0]
+        u8 = image_epilogue(rgba, uint8=True)[1].cpu().numpy()
+        png.write_png(os.path.join(root, "nerf", "train", f"r_{k:03d}.png"), u8)
+        imgs.append(u8)
+        frames.append({"transform_matrix": views[k]["pose"].tolist(), "driver_parameters": {f"p{i}": v for i, v in enumerate(params)}})
+    with open(os.path.join(root, "nerf", "transforms_train.json"), "w") as f:
+        json.dump({"camera_angle_x": 0.63, "frames": frames}, f)
+    tfrecord.convert_folder(os.path.join(root, "nerf"), os.path.join(root, "tfr"), imgs_per_shard=4)
+    return os.path.join(root, "tfr"), imgs, [v["pose"] for v in views], teacher
+
+
+def carpet_blocks(tfr_path, **over):
+    cfg = json.load(open(os.path.join(GOLDEN, "train_configs.json")))["carpet"]
+    train = json.loads(json.dumps(cfg["train_dataset_config"]))
+    assert train["data_loader_config"] == {"module": "network.dataset.TFRecord", "tfr_path": "datasets/materials/carpet/tfr/train.tfr"}
+    train["data_loader_config"]["tfr_path"] = tfr_path
+    train.update(over)
+    val = json.loads(json.dumps(cfg["val_dataset_config"]))
+    val["data_loader_config"].update(height=H, width=W)                               # 256 x 256 in the config: smaller here
+    return cfg, train, val
+
+
+def test_batches_of_a_tfrecord_dataset(tmp_path):
+    """What `Dataset` hands the step: per view `n_samples` pixels among those whose rays hit the proxy (pixel_sampler.Proxy), their rays, and
+    the image's premultiplied colour / alpha AT those pixels -- recovered here from the rays themselves (a ray's direction names its pixel)."""
+    from nerf_tex_amd import util
+    tfr, imgs, poses, _ = teacher_set(str(tmp_path))
+    _, train, _ = carpet_blocks(tfr, seed=3)
+    ds = util.instantiate(dict(train, device=dev()))
+    assert type(ds).__module__ == "nerf_tex_amd.dataset" and ds.has_images and len(ds.views) == 6
+    assert (ds.height, ds.width, ds.n_samples, ds.n_parameters, ds.batchsize) == (H, W, 256, 7, 4)
+    assert abs(ds.focal - W / np.tan(float(np.float32(0.63)) / 2) / 2) < 1e-9
+    seen = []
+    for b in ds.take(5):                                                               # endless (n_epochs None): the loop takes what it needs
+        assert {k: tuple(v.shape) for k, v in b.items()} == {"parameters": (4, 7), "rays_o": (4, 256, 3), "rays_d": (4, 256, 3), "t": (4, 256, 2),
+                                                             "cone_scale": (4, 256, 1), "color": (4, 256, 3), "alpha": (4, 256)}
+        assert all(v.is_cuda and v.dtype == torch.float32 for v in b.values())
+        assert torch.isfinite(b["t"]).float().mean() > 0.9                             # chosen among the pixels that hit ON THE 8x COARSER GRID (pixel_sampler.py:40-59): a few at the rim miss
+        for e in range(4):
+            o = b["rays_o"][e, 0].cpu().numpy()
+            k = int(np.argmin([np.abs(p[:3, 3] - o).max() for p in poses]))            # which view: its camera position
+            seen.append(k)
+            c2w = torch.as_tensor(poses[k], device=dev())
+            d_cam = b["rays_d"][e] @ c2w[:3, :3]                                       # back to camera space: (j + .5 - W/2) / f, -(i + .5 - H/2) / f, -1, normalised
+            d_cam = d_cam / -d_cam[:, 2:3]
+            j = torch.round(d_cam[:, 0] * ds.focal + W / 2 - 0.5).long()
+            i = torch.round(-d_cam[:, 1] * ds.focal + H / 2 - 0.5).long()
+            assert len({(int(a), int(c)) for a, c in zip(i.tolist(), j.tolist())}) == 256   # a permutation's head: no pixel twice
+            px = torch.as_tensor(imgs[k], device=dev())[i, j].float() * torch.tensor(1.0 / 255)
+            assert torch.equal(b["color"][e], px[:, :3] * px[:, 3:]) and torch.equal(b["alpha"][e], px[:, 3])
+    assert len(set(seen[:6])) == 6 and sorted(seen[:6]) == list(range(6))             # an epoch holds every view once (buffer 100 > 6), batches cut across
+    again = [float(b["color"].sum()) for b in util.instantiate(dict(train, device=dev())).take(3)]
+    assert again == [float(b["color"].sum()) for b in util.instantiate(dict(train, device=dev())).take(3)]   # the seed decides pixels and order
+
+
+def test_train_from_the_config_s_own_dataset_blocks(tmp_path):
+    """`Train(**config)` with the shipped carpet config's blocks as written -- TFRecord dataset (pointed at the file made here), Proxy pixel
+    and ray samplers in its box, batches of 4 x 256 rays, GenerateData validation views from `data.distribution.Constant`, ParamNerf,
+    AlphaLoss(smape, mse), the renderer block (fewer samples), Adam + decay: the loss falls, the validation view moves towards the teacher's
+    render of that camera, checkpoints and validation PNGs are where the Logger puts them, and the run resumes."""
+    from nerf_tex_amd import dataset as D, png
+    from nerf_tex_amd.render import render_image
+    from nerf_tex_amd.renderer import Renderer
+    from nerf_tex_amd.train import Train
+    tfr, imgs, poses, teacher = teacher_set(str(tmp_path))
+    cfg, train, val = carpet_blocks(tfr, seed=1)
+    rcfg = dict(cfg["renderer_config"], n_samples=48)
+    model_config = {k: v for k, v in cfg["model_config"].items()}
+    torch.manual_seed(0)
+    kw = dict(train_dataset_config=train, val_dataset_config=val, model_config=model_config, loss_config=cfg["loss_config"], lrate=cfg["lrate"],
+              lrate_decay=cfg["lrate_decay"], renderer_config=rcfg)
+    out = Train(str(tmp_path / "run"), n_iters=400, logger_config={"module": "network.logger.Logger", "i_print": 20, "i_img": 200, "i_checkpoint": 200}, **kw)
+    losses = [v for _, v in out["loss"]]
+    assert out["step"] == 400 and np.isfinite(losses).all() and np.mean(losses[-3:]) < 0.7 * np.mean(losses[:3]), losses
+    assert sorted(out["images"]) == [200, 400] and len(out["images"][400]) == 2        # the config's two validation parameter sets
+    assert sorted(os.listdir(tmp_path / "run" / "media" / "validation")) == ["200", "400"]
+    assert np.asarray(png.read_png(str(tmp_path / "run" / "media" / "validation" / "400" / "1.png"))).shape[:2] == (H, W)
+    assert sorted(f for f in os.listdir(tmp_path / "run" / "checkpoints") if f.endswith(".index")) == ["ckpt-200.index", "ckpt-400.index"]
+    # the validation camera is the config's own ([0.47, -0.65, 0.6] x 5); its second parameter set is the one the teacher's images were made with
+    vds = D.Dataset(dict(val["data_loader_config"]), {"module": "network.pixel_sampler.Full"}, {"module": "network.ray_sampler.Proxy"}, dict(val["proxy_config"]),
+                    n_epochs=1, device=dev())
+    view = list(vds)[1]
+    want = render_image(Renderer(model=teacher, n_samples=48, perturb=False), vds, view)[0]
+    err = lambda img: float((img - want).abs().mean())
+    assert err(out["images"][400][1]) < 0.8 * err(out["images"][200][1]) or err(out["images"][400][1]) < 0.05, (err(out["images"][200][1]), err(out["images"][400][1]))
+    more = Train(str(tmp_path / "run"), n_iters=420, logger_config={"i_print": 10, "i_img": 0, "i_checkpoint": 0}, **kw)
+    assert more["step"] == 420 and more["trainer"].iterations == 420 and [s for s, _ in more["loss"]] == [410, 420]
