@@ -59,10 +59,16 @@ def GenerateData(height: int = 256, width: int = 256, angle: float = .7,
 
 def FromViews(views: list, height: int = 256, width: int = 256, angle: float = .7, composite_bkgd: bool = False,
               bkgd_color=[1, 1, 1.]):
-    """Data loader with explicit views (`[{'pose': c2w 4x4, 'parameters': [...]}, ...]`): same return tuple
-    as GenerateData (dataset.py:229) without the pose/parameter distributions, which stay the reference's."""
-    data = [{"pose": np.asarray(v["pose"], dtype=np.float32), "parameters": np.asarray(v["parameters"], dtype=np.float32)}
-            for v in views]
+    """Data loader with explicit views (`[{'pose': c2w 4x4, 'parameters': [...][, 'rgba': uint8 or float32 [H, W, 4]]}, ...]`): same return
+    tuple as the other loaders without the pose / parameter distributions or files; views with an `rgba` image make an image dataset
+    (un-premultiplied, as a PNG holds it), whose height and width are the images'."""
+    data = []
+    for v in views:
+        d = {"pose": np.asarray(v["pose"], dtype=np.float32), "parameters": np.asarray(v["parameters"], dtype=np.float32)}
+        if v.get("rgba") is not None:
+            d.update(rgba=v["rgba"], premultiplied=bool(v.get("premultiplied", False)))
+            height, width = int(d["rgba"].shape[0]), int(d["rgba"].shape[1])
+        data.append(d)
     return data, height, width, width / tan(angle / 2) / 2, composite_bkgd, bkgd_color
 
 
@@ -189,7 +195,7 @@ class Dataset:
         self.seed = seed
         self._generator = None
         self._host_rng = np.random.default_rng(seed)
-        self._resident = {}
+        self._resident, self._hits, self._params, self._bkgd = {}, {}, {}, None
         from .pixel_sampler import Full
         self._sampled = not isinstance(self.pixel_sampler, Full)
         self.n_samples = int(self.pixel_sampler.n_samples) if self._sampled else self.height * self.width
@@ -260,21 +266,30 @@ class Dataset:
             return px[:, :3].contiguous(), alpha.contiguous()
         color = px[:, :3] * px[:, 3:]
         if self.composite_bkgd:
-            color = color + (1 - px[:, 3:]) * torch.as_tensor(self.bkgd_color, dtype=torch.float32, device=px.device)
+            if self._bkgd is None or self._bkgd.device != px.device:
+                self._bkgd = torch.as_tensor(self.bkgd_color, dtype=torch.float32, device=px.device)
+            color = color + (1 - px[:, 3:]) * self._bkgd
         return color, alpha.contiguous()
 
     def _element(self, k: int, dev):
         import torch
         v = self.views[k]
         if self._sampled:
-            loc = self.pixel_sampler(c2w=v["pose"], device=dev, generator=self._gen(dev))
+            kw = {}
+            if hasattr(self.pixel_sampler, "hit_pixels"):             # the proxy's hit pixels of this camera: found once
+                if k not in self._hits:
+                    self._hits[k] = self.pixel_sampler.hit_pixels(v["pose"], dev)
+                kw.update(hits=self._hits[k], rng=self._host_rng)
+            loc = self.pixel_sampler(c2w=v["pose"], device=dev, generator=self._gen(dev), **kw)
             if loc.shape[0] != self.n_samples:
                 raise ValueError(f"view {k}: the pixel sampler found {loc.shape[0]} of {self.n_samples} pixels")     # tf.gather_nd out of range (pixel_sampler.py:69)
         else:
             loc = self.pixel_sampler(c2w=v["pose"])
         out = {}
         if "parameters" in v:
-            out["parameters"] = torch.as_tensor(v["parameters"], dtype=torch.float32, device=dev)
+            if k not in self._params:
+                self._params[k] = torch.as_tensor(v["parameters"], dtype=torch.float32, device=dev)
+            out["parameters"] = self._params[k]
         if self.ray_sampler is not None:
             out["rays_o"], out["rays_d"], out["t"], out["cone_scale"] = self.ray_sampler(image_plane_loc=loc, c2w=v["pose"], device=dev)
         if "rgba" in v:
