@@ -680,8 +680,7 @@ def test_png_reader_undoes_every_row_filter(tmp_path):
         return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
 
     rng = np.random.default_rng(0)
-    for n, ctype in ((3, 2), (4, 6), (1, 0)):
-        H, W = 13, 17
+    for n, ctype, H, W in ((3, 2, 13, 17), (4, 6, 13, 17), (1, 0, 13, 17), (4, 6, 150, 190), (3, 2, 141, 163)):   # the large ones: the anti-diagonal pass
         img = rng.integers(0, 256, (H, W, n), dtype=np.uint8)
         stride, rows, raw = W * n, img.reshape(H, W * n).astype(int), bytearray()
         for r in range(H):
@@ -689,7 +688,8 @@ def test_png_reader_undoes_every_row_filter(tmp_path):
             for i in range(stride):
                 a = rows[r][i - n] if i >= n else 0; b = rows[r - 1][i] if r else 0; c = rows[r - 1][i - n] if (r and i >= n) else 0
                 raw.append((rows[r][i] - [0, a, b, (a + b) // 2, paeth(a, b, c)][ft]) & 255)
-        f = str(tmp_path / f"t{n}.png")
+        assert (H < 100) == (sum(1 for r in range(H) if r % 5 >= 3) * stride <= 1 << 16)
+        f = str(tmp_path / f"t{n}_{H}.png")
         open(f, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
         assert np.array_equal(np.asarray(png.read_png(f)).reshape(H, W, n), img)
     with pytest.raises(ValueError, match="truncated"):
