@@ -680,7 +680,7 @@ def test_png_reader_undoes_every_row_filter(tmp_path):
         return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
 
     rng = np.random.default_rng(0)
-    for n, ctype, H, W in ((3, 2, 13, 17), (4, 6, 13, 17), (1, 0, 13, 17), (4, 6, 150, 190), (3, 2, 141, 163)):   # the large ones: the anti-diagonal pass
+    for n, ctype, H, W in ((3, 2, 13, 17), (4, 6, 13, 17), (1, 0, 13, 17), (4, 6, 220, 240), (3, 2, 241, 263)):   # the large ones: the anti-diagonal pass
         img = rng.integers(0, 256, (H, W, n), dtype=np.uint8)
         stride, rows, raw = W * n, img.reshape(H, W * n).astype(int), bytearray()
         for r in range(H):
