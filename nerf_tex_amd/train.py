@@ -413,10 +413,15 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
     import torch
     from . import checkpoint, util
     from .renderer import Renderer
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
     if train_dataset is None:
         if train_dataset_config is None:
             raise TypeError("Train needs train_dataset_config (the reference's block) or train_dataset (an iterable of batches)")
-        train_dataset = util.instantiate(dict(util.remap_reference_config(train_dataset_config), device=torch.device("cuda", device)))
+        block = dict(util.remap_reference_config(train_dataset_config), device=torch.device("cuda", device))
+        if world > 1 and block.get("seed") is not None:
+            block["seed"] = int(block["seed"]) + rank                         # every rank its own views and pixels
+        train_dataset = util.instantiate(block)
     if val_dataset is None and val_dataset_config is not None:
         val_dataset = util.instantiate(dict(util.remap_reference_config(val_dataset_config), device=torch.device("cuda", device)))
     if model_config is not None and hasattr(train_dataset, "n_parameters"):
@@ -447,6 +452,19 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
         print(f"Restored model & optimizer from {info['prefix']}.")
     except FileNotFoundError:
         pass
+    if world > 1:
+        # Data parallel (one process per GPU; the reference has one): every rank on its own batches, the gradient their mean
+        # (`Trainer.train_step` -> `sync_gradients`), so the ranks must start from ONE state -- rank 0's, restored or freshly drawn --
+        # and only rank 0 keeps the Logger's files.
+        if two:
+            raise NotImplementedError("data-parallel coarse + fine training")
+        state = [dict(trainer.state_dict(), step=step) if rank == 0 else None]
+        with torch.cuda.device(device):
+            dist.broadcast_object_list(state, src=0)
+        trainer.load_state_dict({k: v for k, v in state[0].items() if k != "step"})
+        step = int(state[0]["step"])
+        if rank != 0:
+            i_print = i_img = i_ckpt = 0
     cb = getattr(train_dataset, "composite_bkgd", False) if composite_bkgd is None else composite_bkgd
     bc = getattr(train_dataset, "bkgd_color", (1., 1., 1.)) if bkgd_color is None else bkgd_color
     out = {"trainer": trainer, "renderer": renderer, "loss": [], "images": {}, "checkpoints": [], "step": step}
@@ -457,7 +475,7 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
         if todo <= 0:
             break
         todo -= 1
-        pred = trainer.train_step(data, loss_fn, composite_bkgd=cb, bkgd_color=bc)
+        pred = trainer.train_step(data, loss_fn, composite_bkgd=cb, bkgd_color=bc, **({"seed": step * world + rank} if world > 1 else {}))
         step += 1
         if i_print > 0 and step % i_print == 0:
             val = float(pred["loss"].item())

@@ -126,3 +126,15 @@ def test_train_from_the_config_s_own_dataset_blocks(tmp_path):
     assert err(out["images"][400][1]) < 0.8 * err(out["images"][200][1]) or err(out["images"][400][1]) < 0.05, (err(out["images"][200][1]), err(out["images"][400][1]))
     more = Train(str(tmp_path / "run"), n_iters=420, logger_config={"i_print": 10, "i_img": 0, "i_checkpoint": 0}, **kw)
     assert more["step"] == 420 and more["trainer"].iterations == 420 and [s for s, _ in more["loss"]] == [410, 420]
+
+
+def test_two_ranks_run_the_loop_data_parallel(tmp_path):
+    """`Train` under torch.distributed (one process per GPU; here two ranks sharing GPU 0 on gloo): rank 0's state is everybody's start,
+    every rank draws its own batches (seed + rank), the gradients are averaged each step, only rank 0 logs and checkpoints
+    (tests/_dp_loop_worker.py)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29657",
+                          os.path.join(root, "tests", "_dp_loop_worker.py"), str(tmp_path / "run")], capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "DP_LOOP_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
