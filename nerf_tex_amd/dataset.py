@@ -174,7 +174,8 @@ class Dataset:
     Attributes `height / width / focal / composite_bkgd / bkgd_color / n_samples / n_parameters` as the reference sets them (:64-73)."""
 
     def __init__(self, data_loader_config, pixel_sampler_config, ray_sampler_config=None, proxy_config=None,
-                 n_epochs: int = None, batchsize: int = 1, shuffle_buffer_size: int = 1, step=None, device=None, seed: int = None):
+                 n_epochs: int = None, batchsize: int = 1, shuffle_buffer_size: int = 1, step=None, device=None, seed: int = None,
+                 fused_batches: bool = True):
         self.views, self.height, self.width, self.focal, self.composite_bkgd, self.bkgd_color = \
             util.instantiate(data_loader_config)
         proxy = util.instantiate(proxy_config) if proxy_config is not None else None
@@ -194,8 +195,11 @@ class Dataset:
         self.device = device
         self.seed = seed
         self._generator = None
-        self._host_rng = np.random.default_rng(seed)
+        self._host_rng = np.random.default_rng(seed if seed is None else [int(seed), 0])       # the order of the views
+        self._pixel_rng = np.random.default_rng(seed if seed is None else [int(seed), 1])      # the pixels of a view
         self._resident, self._hits, self._params, self._bkgd = {}, {}, {}, None
+        self._hits_host, self._stacked = {}, None
+        self.fused_batches = bool(fused_batches)
         from .pixel_sampler import Full
         self._sampled = not isinstance(self.pixel_sampler, Full)
         self.n_samples = int(self.pixel_sampler.n_samples) if self._sampled else self.height * self.width
@@ -279,7 +283,7 @@ class Dataset:
             if hasattr(self.pixel_sampler, "hit_pixels"):             # the proxy's hit pixels of this camera: found once
                 if k not in self._hits:
                     self._hits[k] = self.pixel_sampler.hit_pixels(v["pose"], dev)
-                kw.update(hits=self._hits[k], rng=self._host_rng)
+                kw.update(hits=self._hits[k], rng=self._pixel_rng)
             loc = self.pixel_sampler(c2w=v["pose"], device=dev, generator=self._gen(dev), **kw)
             if loc.shape[0] != self.n_samples:
                 raise ValueError(f"view {k}: the pixel sampler found {loc.shape[0]} of {self.n_samples} pixels")     # tf.gather_nd out of range (pixel_sampler.py:69)
@@ -296,17 +300,64 @@ class Dataset:
             out["color"], out["alpha"] = self.colors_at(k, loc, dev)
         return out
 
+    # ---- a training batch in one piece --------------------------------------------------------------------------------------------
+    def _can_fuse(self, dev) -> bool:
+        """Proxy-sampled rays of uint8 images of one size: the pixel positions of ALL the batch's views are drawn on the host, go to the
+        device in one pinned copy, and the colours come out of one gather over the stacked images -- a dozen kernels a batch instead of
+        fifty (they run on the training step's stream, serial with it).  The batches are the per-view path's, bit for bit."""
+        import torch
+        if not (self.fused_batches and self._sampled and hasattr(self.pixel_sampler, "hit_pixels") and self.has_images and self.ray_sampler is not None):
+            return False
+        v0 = self.views[0]
+        return dev.type == "cuda" and all("parameters" in v and "rgba" in v and not v["premultiplied"] and tuple(v["rgba"].shape) == tuple(v0["rgba"].shape)
+                                          and str(v["rgba"].dtype).endswith("uint8") for v in self.views)
+
+    def _fused_batch(self, ks, dev) -> dict:
+        import torch
+        H, W, R = self.height, self.width, self.n_samples
+        if self._stacked is None:
+            self._stacked = torch.stack([self._image(k, dev) for k in range(len(self.views))]).reshape(-1, 4)
+            self._resident = {k: self._stacked.reshape(len(self.views), H, W, 4)[k] for k in range(len(self.views))}
+        loc = np.empty((len(ks), R, 2), np.int64)
+        for e, k in enumerate(ks):
+            if k not in self._hits_host:
+                if k not in self._hits:
+                    self._hits[k] = self.pixel_sampler.hit_pixels(self.views[k]["pose"], dev)
+                self._hits_host[k] = self._hits[k].cpu().numpy()
+            hits = self._hits_host[k]
+            if hits.shape[0] < R:
+                raise ValueError(f"view {k}: the pixel sampler found {hits.shape[0]} of {R} pixels")
+            loc[e] = hits[self._pixel_rng.choice(hits.shape[0], size=R, replace=False)]
+        flat = ((np.asarray(ks, np.int64)[:, None] * H + loc[..., 0]) * W + loc[..., 1]).reshape(-1)
+        locf = torch.from_numpy(loc.astype(np.float32)).pin_memory().to(dev, non_blocking=True)
+        flat = torch.from_numpy(flat).pin_memory().to(dev, non_blocking=True)
+        rays = [self.ray_sampler(image_plane_loc=locf[e], c2w=self.views[k]["pose"], device=dev) for e, k in enumerate(ks)]
+        for k in ks:
+            if k not in self._params:
+                self._params[k] = torch.as_tensor(self.views[k]["parameters"], dtype=torch.float32, device=dev)
+        px = self._stacked[flat].to(torch.float32) * torch.tensor(1.0 / 255, dtype=torch.float32)
+        color = px[:, :3] * px[:, 3:]
+        if self.composite_bkgd:
+            if self._bkgd is None or self._bkgd.device != px.device:
+                self._bkgd = torch.as_tensor(self.bkgd_color, dtype=torch.float32, device=px.device)
+            color = color + (1 - px[:, 3:]) * self._bkgd
+        n = len(ks)
+        return {"parameters": torch.stack([self._params[k] for k in ks]), "rays_o": torch.stack([r[0] for r in rays]), "rays_d": torch.stack([r[1] for r in rays]),
+                "t": torch.stack([r[2] for r in rays]), "cone_scale": torch.stack([r[3] for r in rays]), "color": color.reshape(n, R, 3),
+                "alpha": px[:, 3].reshape(n, R).contiguous()}
+
     def __iter__(self):
         import torch
         dev = self._device()
+        fuse = self._can_fuse(dev)
         batch = []
         for k in self._order():
-            batch.append(self._element(k, dev))
+            batch.append(k if fuse else self._element(k, dev))
             if len(batch) == self.batchsize:
-                yield {key: torch.stack([e[key] for e in batch]) for key in batch[0]}
+                yield self._fused_batch(batch, dev) if fuse else {key: torch.stack([e[key] for e in batch]) for key in batch[0]}
                 batch = []
         if batch:
-            yield {key: torch.stack([e[key] for e in batch]) for key in batch[0]}
+            yield self._fused_batch(batch, dev) if fuse else {key: torch.stack([e[key] for e in batch]) for key in batch[0]}
 
     def take(self, n: int):
         """`tf.data.Dataset.take`: at most n batches (a fresh iteration)."""

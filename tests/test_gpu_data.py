@@ -90,6 +90,9 @@ def test_batches_of_a_tfrecord_dataset(tmp_path):
             px = torch.as_tensor(imgs[k], device=dev())[i, j].float() * torch.tensor(1.0 / 255)
             assert torch.equal(b["color"][e], px[:, :3] * px[:, 3:]) and torch.equal(b["alpha"][e], px[:, 3])
     assert len(set(seen[:6])) == 6 and sorted(seen[:6]) == list(range(6))             # an epoch holds every view once (buffer 100 > 6), batches cut across
+    one = list(util.instantiate(dict(train, device=dev())).take(4))                     # a batch made in one piece is the batch made view by view
+    per_view = list(util.instantiate(dict(train, device=dev(), fused_batches=False)).take(4))
+    assert all(torch.equal(a[k], b[k]) for a, b in zip(one, per_view) for k in a) and set(one[0]) == set(per_view[0])
     again = [float(b["color"].sum()) for b in util.instantiate(dict(train, device=dev())).take(3)]
     assert again == [float(b["color"].sum()) for b in util.instantiate(dict(train, device=dev())).take(3)]   # the seed decides pixels and order
 
