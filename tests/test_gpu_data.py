@@ -141,3 +141,22 @@ def test_two_ranks_run_the_loop_data_parallel(tmp_path):
                           os.path.join(root, "tests", "_dp_loop_worker.py"), str(tmp_path / "run")], capture_output=True, text=True, timeout=600, cwd=root,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0 and "DP_LOOP_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_main_runs_a_training_config_file(tmp_path):
+    """`python -m nerf_tex_amd.main <config>` on a TRAINING config written like the shipped ones (main.py:17-50): the seed set, the target
+    folder made with a copy of the config as `config_train.py`, `network.train.Train` instantiated with the file's blocks."""
+    from nerf_tex_amd import main as m
+    tfr, _, _, _ = teacher_set(str(tmp_path), n_views=4)
+    cfg, train, val = carpet_blocks(tfr)
+    config = {"module": "network.train.Train", "target_path": str(tmp_path / "out"), "seed": 0, "override": True,
+              "train_dataset_config": train, "val_dataset_config": val, "model_config": cfg["model_config"], "loss_config": cfg["loss_config"],
+              "n_iters": 30, "lrate": cfg["lrate"], "lrate_decay": cfg["lrate_decay"], "renderer_config": dict(cfg["renderer_config"], n_samples=32),
+              "logger_config": {"module": "network.logger.Logger", "i_print": 10, "i_img": 30, "i_checkpoint": 30}}
+    path = str(tmp_path / "config_tiny_train.py")
+    with open(path, "w") as f:
+        f.write("config = " + repr(config) + "\n")
+    out = m.main([path])
+    assert out["step"] == 30 and [s for s, _ in out["loss"]] == [10, 20, 30] and sorted(out["images"]) == [30]
+    assert os.path.exists(tmp_path / "out" / "config_train.py") and os.path.exists(tmp_path / "out" / "checkpoints" / "ckpt-30.index")
+    assert os.path.exists(tmp_path / "out" / "media" / "validation" / "30" / "0.png")
