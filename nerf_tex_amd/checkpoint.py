@@ -199,6 +199,14 @@ def latest_checkpoint(checkpoint_dir: str) -> str:
     return best
 
 
+def write_manager_state(checkpoint_dir: str, prefixes) -> None:
+    """The `checkpoint` file tf.train.CheckpointManager keeps beside its checkpoints (a text `CheckpointState`): the newest as
+    `model_checkpoint_path`, every kept one, oldest first, as `all_model_checkpoint_paths` -- names relative to the directory."""
+    names = [os.path.basename(p) for p in prefixes]
+    with open(os.path.join(checkpoint_dir, "checkpoint"), "w") as f:
+        f.write(f'model_checkpoint_path: "{names[-1]}"\n' + "".join(f'all_model_checkpoint_paths: "{n}"\n' for n in names))
+
+
 _VAR = re.compile(r"^(?P<root>.+?)/layer_with_weights-(?P<i>\d+)/(?P<kind>kernel|bias)/\.ATTRIBUTES/VARIABLE_VALUE$")
 
 

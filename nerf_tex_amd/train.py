@@ -467,7 +467,10 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
             i_print = i_img = i_ckpt = 0
     cb = getattr(train_dataset, "composite_bkgd", False) if composite_bkgd is None else composite_bkgd
     bc = getattr(train_dataset, "bkgd_color", (1., 1., 1.)) if bkgd_color is None else bkgd_color
-    out = {"trainer": trainer, "renderer": renderer, "loss": [], "images": {}, "checkpoints": [], "step": step}
+    # (CheckpointManager keeps its list of kept checkpoints in the directory's `checkpoint` file: a resumed run goes on rotating the old ones)
+    import re
+    found = sorted((int(m.group(1)), os.path.join(ckpt_dir, f[:-6])) for f in os.listdir(ckpt_dir) for m in [re.fullmatch(r"ckpt-(\d+)\.index", f)] if m)
+    out = {"trainer": trainer, "renderer": renderer, "loss": [], "images": {}, "checkpoints": [p for _, p in found] if rank == 0 else [], "step": step}
     if step >= n_iters:
         return out
     todo = int(n_iters) - step
@@ -496,6 +499,7 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
                     if os.path.exists(old + suffix):
                         os.remove(old + suffix)
             out["checkpoints"] = out["checkpoints"][-keep:] if keep > 0 else out["checkpoints"]
+            checkpoint.write_manager_state(ckpt_dir, out["checkpoints"])
     out["step"] = step
     torch.cuda.synchronize(torch.device("cuda", device))
     return out

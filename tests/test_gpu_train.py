@@ -532,12 +532,15 @@ def test_train_loop_renders_validation_views_and_checkpoints(tmp_path):
     assert shot.shape[:2] == (24, 24) and sorted(os.listdir(tmp_path / "media" / "validation")) == ["100", "200"]
     kept = sorted(f for f in os.listdir(tmp_path / "checkpoints") if f.endswith(".index"))
     assert kept == ["ckpt-150.index", "ckpt-200.index"]
+    assert open(tmp_path / "checkpoints" / "checkpoint").read() == 'model_checkpoint_path: "ckpt-200"\nall_model_checkpoint_paths: "ckpt-150"\nall_model_checkpoint_paths: "ckpt-200"\n'
     tr, model, renderer = out["trainer"], out["trainer"].model, out["renderer"]
     model.set_blob(tr.weights())                                   # the same weights through the host: the same image
     again = render_image(renderer, Views(), next(iter(Views())))[0]
     assert torch.equal(again, out["images"][200][0])
-    more = Train(str(tmp_path), Batches(), None, n_iters=230, logger_config=dict(i_print=10, i_img=0, i_checkpoint=0), **common)
+    more = Train(str(tmp_path), Batches(), None, n_iters=230, logger_config=dict(i_print=10, i_img=0, i_checkpoint=15, max_to_keep=2), **common)
     assert more["step"] == 230 and more["trainer"].iterations == 230 and [s for s, _ in more["loss"]] == [210, 220, 230]
+    kept = sorted(f for f in os.listdir(tmp_path / "checkpoints") if f.endswith(".index"))      # a resumed run goes on rotating what the first one left
+    assert kept == ["ckpt-210.index", "ckpt-225.index"], kept
 
 
 @pytest.mark.parametrize("shared", [False, True])
