@@ -77,23 +77,29 @@ def Render(target_path: Optional[str], test_dataset_config, model_config, render
             import numpy as np
             os.makedirs(os.path.join(target_path, "media", "test"), exist_ok=True)
             np.save(os.path.join(target_path, "media", "test", util_format(i, len(test_dataset))), img.cpu().numpy())
-            write_images(os.path.join(target_path, "media", "test"), img, i, len(test_dataset), int((logger_config or {}).get("downsampling_factor", 1)))
+            write_images(os.path.join(target_path, "media", "test"), img, i, len(test_dataset), int((logger_config or {}).get("downsampling_factor", 1)),
+                         bool((logger_config or {}).get("write_exr", False)))
         if return_imgs:
             imgs.append(img)
     return imgs
 
 
-def write_images(directory: str, rgba, first_idx: int, max_idx: int, downsampling_factor: int = 1) -> List[str]:
+def write_images(directory: str, rgba, first_idx: int, max_idx: int, downsampling_factor: int = 1, write_exr: bool = False) -> List[str]:
     """Logger.render_image's post-processing and write_image (logger.py:128-144) for a batch of premultiplied RGBA images [B, H, W, 4]:
-    filtered downsample, un-premultiply, uint8 (`ntx_image_epilogue`), one PNG each named like `util.format_name('', idx, max_idx, '.png')`."""
-    from . import png
+    filtered downsample, then either un-premultiply, uint8 (`ntx_image_epilogue`) and one PNG each, or with `write_exr` the float32 image
+    as it is (premultiplied) in one OpenEXR file each (`nerf_tex_amd/exr.py`); named like `util.format_name('', idx, max_idx, '.png' / '.exr')`."""
+    from . import exr, png
     os.makedirs(directory, exist_ok=True)
     out = []
     for k in range(rgba.shape[0]):
-        _, u8 = image_epilogue(rgba[k], downsampling_factor, write_exr=False, uint8=True)
-        path = os.path.join(directory, util_format(first_idx + k, max_idx)[:-4] + ".png")
-        png.write_png(path, u8.cpu().numpy())
-        out.append(path)
+        stem = os.path.join(directory, util_format(first_idx + k, max_idx)[:-4])
+        if write_exr:
+            exr.write_exr(stem + ".exr", image_epilogue(rgba[k], downsampling_factor, write_exr=True).cpu().numpy())
+            out.append(stem + ".exr")
+        else:
+            _, u8 = image_epilogue(rgba[k], downsampling_factor, write_exr=False, uint8=True)
+            png.write_png(stem + ".png", u8.cpu().numpy())
+            out.append(stem + ".png")
     return out
 
 

@@ -205,7 +205,8 @@ def convert_folder(path_in: str, path_out: str, subsets=("train",), skip_params:
     """`data/nerf2tfr.py:65-112`: for every subset the sorted files of `<path_in>/<subset>/` with the frames of `transforms_<subset>.json`
     in order -- `image` the `.png` file's bytes as they are, `pose` the frame's `transform_matrix`, `parameters` the values of its
     `driver_parameters` in the file's order (none with `skip_params`), `angle` = `camera_angle_x` -- into `<path_out>/<subset>[_<shard>].tfr`.
-    (`.exr` images, which the reference stores as serialized tensors through pyexr, are refused: no EXR reader here.)  Returns the files."""
+    An `.exr` image goes in as the serialized float32 tensor of its pixels (:47-49; `nerf_tex_amd/exr.py` reads it), to be loaded with
+    `TFRecord(read_exr=True)`.  Returns the files."""
     import json
     import math
     import os
@@ -224,10 +225,15 @@ def convert_folder(path_in: str, path_out: str, subsets=("train",), skip_params:
         for shard in range(n_shards):
             def records():
                 for i in range(shard * per, min((shard + 1) * per, len(names))):
-                    if os.path.splitext(names[i])[1] != ".png":
-                        raise ValueError(f"{names[i]}: only .png images are converted here")
-                    with open(os.path.join(folder, names[i]), "rb") as g:
-                        img = g.read()
+                    ext = os.path.splitext(names[i])[1]
+                    if ext == ".png":
+                        with open(os.path.join(folder, names[i]), "rb") as g:
+                            img = g.read()
+                    elif ext == ".exr":
+                        from . import exr
+                        img = serialize_tensor(exr.read_exr(os.path.join(folder, names[i])))
+                    else:
+                        raise ValueError(f"{names[i]}: unknown filetype")              # nerf2tfr.py:51
                     fr = frames[i]
                     par = [] if skip_params or "driver_parameters" not in fr else list(fr["driver_parameters"].values())
                     yield make_example({"image": img, "pose": serialize_tensor(np.asarray(fr["transform_matrix"], np.float32)), "angle": angle,

@@ -491,7 +491,8 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
             from .render import write_images, util_format                 # logger.py:76-78: media/validation/<step padded to n_iters>/<view>.png
             vdir = os.path.join(target_path, "media", "validation", util_format(step, int(n_iters))[:-4])
             for k, im in enumerate(out["images"][step]):
-                write_images(vdir, im[None], k, len(out["images"][step]), int((logger_config or {}).get("downsampling_factor", 1)))
+                write_images(vdir, im[None], k, len(out["images"][step]), int((logger_config or {}).get("downsampling_factor", 1)),
+                             bool((logger_config or {}).get("write_exr", False)))
         if i_ckpt > 0 and step % i_ckpt == 0:                               # logger.py:84-86
             out["checkpoints"].append(trainer.save(os.path.join(ckpt_dir, f"ckpt-{step}"), step=step))
             for old in out["checkpoints"][:-keep] if keep > 0 else []:

@@ -334,3 +334,59 @@ def test_generate_data_quirks():
     assert len(r) == 1 and np.allclose(np.linalg.norm(r[0]["pose"][:3, 3]), 2.0 * np.linalg.norm([0.0, -1.0, 0.5]))
     with pytest.raises(ValueError):
         D.GenerateData()
+
+
+# ---- OpenEXR (the Logger's write_exr, the EXR branch of nerf2tfr / TFRecord) ---------------------------------------------------------
+def test_exr_files_round_trip_and_a_hand_assembled_one(tmp_path):
+    from nerf_tex_amd import exr
+    rng = np.random.default_rng(0)
+    for shape in ((37, 29, 4), (16, 16, 3), (5, 7, 1), (33, 10, 2), (20, 21)):
+        for comp in ("NO", "ZIPS", "ZIP"):
+            for dt in (np.float32, np.float16):
+                a = (rng.standard_normal(shape) * 3).astype(dt)
+                exr.write_exr(str(tmp_path / "a.exr"), a, compression=comp)
+                b, names = exr.read_exr(str(tmp_path / "a.exr"), with_names=True)
+                assert np.array_equal(b[..., 0] if a.ndim == 2 else b, a.astype(np.float32)) and b.dtype == np.float32
+                assert names == {1: ["Z"], 2: ["X", "Y"], 3: list("RGB"), 4: list("RGBA")}[1 if a.ndim == 2 else a.shape[2]]
+    smooth = np.linspace(0, 1, 64 * 64 * 4, dtype=np.float32).reshape(64, 64, 4)
+    exr.write_exr(str(tmp_path / "s.exr"), smooth)
+    assert os.path.getsize(tmp_path / "s.exr") < smooth.nbytes / 4 and np.array_equal(exr.read_exr(str(tmp_path / "s.exr")), smooth)
+    # a 2 x 3 file assembled here from the published layout: channels B (HALF) and R (FLOAT), uncompressed, data window starting at (5, 7)
+    attr = lambda n, t, v: n.encode() + b"\0" + t.encode() + b"\0" + struct.pack("<i", len(v)) + v
+    ch = b"B\0" + struct.pack("<iB3xii", 1, 0, 1, 1) + b"R\0" + struct.pack("<iB3xii", 2, 0, 1, 1) + b"\0"
+    box = struct.pack("<4i", 5, 7, 7, 8)
+    header = attr("channels", "chlist", ch) + attr("compression", "compression", b"\0") + attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + \
+        attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + \
+        attr("screenWindowWidth", "float", struct.pack("<f", 1)) + b"\0"
+    B = np.asarray([[0.5, 1.0, -2.0], [4.0, 0.25, 8.0]], "<f2"); R = np.asarray([[1.5, 2.5, 3.5], [-1.0, 0.0, 1e-3]], "<f4")
+    rows = [struct.pack("<ii", 7 + r, 3 * 2 + 3 * 4) + B[r].tobytes() + R[r].tobytes() for r in range(2)]
+    start = 8 + len(header) + 16
+    blob = struct.pack("<ii", 20000630, 2) + header + struct.pack("<2Q", start, start + len(rows[0])) + rows[0] + rows[1]
+    open(tmp_path / "h.exr", "wb").write(blob)
+    img, names = exr.read_exr(str(tmp_path / "h.exr"), with_names=True)
+    assert names == ["R", "B"] and np.array_equal(img[..., 0], R) and np.array_equal(img[..., 1], B.astype(np.float32))
+    piz = bytearray(blob); piz[blob.index(b"compression\0compression\0") + 28] = 4
+    open(tmp_path / "p.exr", "wb").write(bytes(piz))
+    with pytest.raises(NotImplementedError, match="PIZ"):
+        exr.read_exr(str(tmp_path / "p.exr"))
+    with pytest.raises(ValueError):
+        exr.write_exr(str(tmp_path / "x.exr"), np.zeros((2, 2, 3), np.uint8))
+
+
+def test_exr_images_through_the_folder_converter(tmp_path):
+    """nerf2tfr.py:47-49 + dataset.py:99-101: `.exr` images become serialized float32 tensors in the TFRecord; `read_exr=True` gives their
+    first three channels as the colours, the fourth as alpha."""
+    from nerf_tex_amd import exr
+    rng = np.random.default_rng(1)
+    os.makedirs(tmp_path / "nerf" / "train")
+    imgs = [rng.random((6, 8, 4), dtype=np.float32) * 2 for _ in range(3)]
+    for k, im in enumerate(imgs):
+        exr.write_exr(str(tmp_path / "nerf" / "train" / f"r_{k}.exr"), im)
+    json.dump({"camera_angle_x": 0.5, "frames": [{"transform_matrix": np.eye(4).tolist(), "driver_parameters": {"a": float(k)}} for k in range(3)]},
+              open(tmp_path / "nerf" / "transforms_train.json", "w"))
+    files = T.convert_folder(str(tmp_path / "nerf"), str(tmp_path / "tfr"))
+    views, h, w, _, cb, _ = D.TFRecord(files[0], read_exr=True, composite_bkgd=True)
+    assert (h, w) == (6, 8) and not cb and all(np.array_equal(v["rgba"], im) and v["premultiplied"] for v, im in zip(views, imgs))
+    os.rename(tmp_path / "nerf" / "train" / "r_2.exr", tmp_path / "nerf" / "train" / "r_2.txt")
+    with pytest.raises(ValueError, match="unknown filetype"):
+        T.convert_folder(str(tmp_path / "nerf"), str(tmp_path / "tfr2"))

@@ -607,6 +607,14 @@ def test_main_entry_point_renders_the_example_config(tmp_path, monkeypatch):
     assert bool(torch.isfinite(imgs[0]).all()) and float(a.max()) > 0.0 and float(a.min()) == 0.0      # object and empty background
     saved = sorted(os.listdir(tmp_path / "logs" / "example_carpet" / "media" / "test"))
     assert saved == ["0.npy", "0.png", "1.npy", "1.png"] and os.path.exists(tmp_path / "logs" / "example_carpet" / "config_render.py")
+    # logger_config.write_exr (logger.py:132-142): the premultiplied float32 image as it is, one OpenEXR file a view
+    from nerf_tex_amd import exr, util
+    cfg = m.prepare(m.load_config(os.path.join(ROOT, "configs", "example_carpet_render.py")))
+    cfg.target_path = str(tmp_path / "exr"); cfg.logger_config = dict(cfg.get("logger_config") or {}, write_exr=True)
+    cfg.renderer_config = dict(cfg.renderer_config, perturb=False)
+    again = util.instantiate(cfg)
+    assert sorted(os.listdir(tmp_path / "exr" / "media" / "test")) == ["0.exr", "0.npy", "1.exr", "1.npy"]
+    assert np.array_equal(exr.read_exr(str(tmp_path / "exr" / "media" / "test" / "1.exr")), again[1][0].cpu().numpy())
 
 
 def test_rays_at_any_image_plane_locations():
