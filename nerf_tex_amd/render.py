@@ -3,8 +3,8 @@
 `Render` builds dataset -> model -> renderer exactly as render.py:16-25 does and then plays the
 part of `Logger.render_images` (logger.py:88-137): loop over views, call the renderer, pack RGBA.
 With a `target_path` every view is written under `media/test/` as the reference's Logger does (logger.py:88-144): the PNG of the
-filtered, un-premultiplied uint8 image (`write_image`; EXR writing needs pyexr and is not built), and beside it the raw premultiplied
-float32 RGBA as .npy.
+filtered, un-premultiplied uint8 image -- or, with `logger_config.write_exr`, the premultiplied float32 image as an OpenEXR file
+(`write_image`; nerf_tex_amd/exr.py) --, and beside it the raw premultiplied float32 RGBA as .npy.
 """
 
 from __future__ import annotations

@@ -5,13 +5,13 @@ tape, loss, gradients, `optimizer.apply_gradients`.
     trainer = Trainer(model, max_rays=1024, n_samples=256, lrate=5e-4, lrate_decay=500)       # config_carpet_train.py:100-109
     loss = trainer.step(rays_o, rays_d, t, parameters, cone_scale, color, alpha, loss_fn)      # one iteration of train.py:61-67
 
-`Train(...)` is the reference's function of that name (train.py:7-70) over an in-memory iterable of batch dicts: model, loss, schedule and
-renderer from the config blocks, the loop, and what its Logger does every i_img / i_checkpoint steps (logger.py:57-86) -- the validation
+`Train(...)` is the reference's function of that name (train.py:7-70): the datasets (`nerf_tex_amd.dataset`; or any iterable of batch
+dicts), model, loss, schedule and renderer from the config blocks, the loop, and what its Logger does every i_img / i_checkpoint steps (logger.py:57-86) -- the validation
 views rendered through the inference path with the trainer's weights handed over on the device, checkpoints in TensorFlow's bundle format
 with model + step + optimizer (train.py:55-57) that `Trainer.restore` resumes from.
 
-Built for the ParamNerf architecture of the shipped training configs (8 x 256, skips [4], color_depth 1).  TFRecord datasets and
-TensorBoard summaries (train.py:20-28, logger.py:41-64, dataset.py) stay out of scope: SURVEY section 2."""
+Built for the ParamNerf architecture of the shipped training configs (8 x 256, skips [4], color_depth 1).  TensorBoard summaries
+(logger.py:41-64) stay out of scope: SURVEY section 2."""
 
 from __future__ import annotations
 
