@@ -110,7 +110,7 @@ def test_train_from_the_config_s_own_dataset_blocks(tmp_path):
     cfg, train, val = carpet_blocks(tfr, seed=1)
     rcfg = dict(cfg["renderer_config"], n_samples=48)
     model_config = {k: v for k, v in cfg["model_config"].items()}
-    torch.manual_seed(0)
+    torch.manual_seed(0); np.random.seed(0)                                          # the initial weights are numpy draws (main.py:30 seeds them from the config)
     kw = dict(train_dataset_config=train, val_dataset_config=val, model_config=model_config, loss_config=cfg["loss_config"], lrate=cfg["lrate"],
               lrate_decay=cfg["lrate_decay"], renderer_config=rcfg)
     out = Train(str(tmp_path / "run"), n_iters=400, logger_config={"module": "network.logger.Logger", "i_print": 20, "i_img": 200, "i_checkpoint": 200}, **kw)
