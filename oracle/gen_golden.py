@@ -113,8 +113,10 @@ def distributions():
         samples = [np.asarray(dist(), np.float64).tolist() for _ in range(7)]
         out.append({"config": block, "seed": 100 + k, "n": int(dist.sampler.n), "idx_after": int(dist.sampler.idx), "done_after": bool(dist.sampler.done()),
                     "samples": samples})
+    names = [[idx, mx, ref_util.format_name("", idx, mx, ".png")] for idx, mx in ((0, 0), (0, 1), (3, 9), (3, 10), (7, 99), (7, 100), (12, 256), (250000, 500000), (5, 1000000))]
     with open(os.path.join(OUT, "distributions.json"), "w") as f:
-        json.dump({"source": "/root/reference/data/distribution.py + data/sampler.py (reference code, run here by oracle/gen_golden.py)", "cases": out}, f, indent=1)
+        json.dump({"source": "/root/reference/data/distribution.py + data/sampler.py + util/util.py format_name (reference code, run here by oracle/gen_golden.py)", "cases": out,
+                   "format_name": names}, f, indent=1)
     print("distributions", len(out), "cases")
 
 

@@ -281,6 +281,13 @@ def test_distributions_are_the_reference_s_bit_for_bit():
         assert (dist.sampler.n, dist.sampler.idx, dist.sampler.done()) == (c["n"], c["idx_after"], c["done_after"]), c["config"]
 
 
+def test_file_names_are_the_reference_s():
+    """util.format_name (util.py:56-62; the Logger's image and step-folder names), run by oracle/gen_golden.py: `render.util_format`."""
+    from nerf_tex_amd.render import util_format
+    names = json.load(open(os.path.join(GOLDEN, "distributions.json")))["format_name"]
+    assert len(names) == 9 and all(util_format(idx, mx)[:-4] + ".png" == name for idx, mx, name in names), names
+
+
 def test_jittered_grid_points_stay_in_their_cells():
     """data.sampler.Stratified cannot run in the reference (it calls a method its parent lacks): no vector to pin; what it describes is checked."""
     from nerf_tex_amd.distributions import GridPoints, JitteredGridPoints
