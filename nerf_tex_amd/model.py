@@ -161,7 +161,7 @@ class NerfModel:
         of other devices, the fp16x3 images) is NOT updated unless `sync_host`, which is `set_blob(trainer.weights())`."""
         import torch
         from . import _lib
-        if sync_host:
+        if sync_host or getattr(trainer, "_pad", None) is not None:               # (a narrow network trained inside the 256-wide one: its own weights through the host)
             self.set_blob(trainer.weights())
             return
         if trainer.n_weights != self.n_weight_floats():

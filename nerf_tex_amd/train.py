@@ -40,10 +40,18 @@ class Trainer:
         self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
         blob = np.ascontiguousarray(model.get_blob(), dtype=np.float32)
         self._h = C.c_void_p()
-        desc = model.desc()
+        self._pad = None
+        wide = _widened(model)
+        if wide is not None:                                                    # a narrower network trains inside the 256-wide one (see _widened)
+            self._pad = _narrow_in_wide(model, wide)
+            full = np.zeros(wide.n_weight_floats(), np.float32)
+            full[self._pad] = blob
+            blob = full
+        desc = (wide or model).desc()
         _lib.check(_lib.lib.ntx_trainer_create(C.byref(desc), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, self.device, self.max_rays,
                                                self.n_samples, C.byref(self._h)))
-        self.n_weights = int(_lib.lib.ntx_trainer_weight_count(self._h))
+        self._n_native = int(_lib.lib.ntx_trainer_weight_count(self._h))
+        self.n_weights = self._n_native if self._pad is None else int(self._pad.size)
         self._calls = 0
         self._last_rays = 0
 
@@ -85,9 +93,9 @@ class Trainer:
 
     def _vector(self, what: int):
         import numpy as np
-        out = np.empty(self.n_weights, np.float32)
+        out = np.empty(self._n_native, np.float32)
         _lib.check(_lib.lib.ntx_trainer_get(self._h, what, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
-        return out
+        return out if self._pad is None else np.ascontiguousarray(out[self._pad])
 
     def weights(self):
         """The weights as one float32 vector in `get_weights()` order (hand it to `model.set_blob` to render with them)."""
@@ -106,6 +114,8 @@ class Trainer:
         width = 256 if (layer < 9 or layer >= 20) else (128 if layer == 9 else 1)
         out = np.empty((int(n_samples_total), width), np.float32)
         _lib.check(_lib.lib.ntx_trainer_activation(self._h, int(layer), int(n_samples_total), out.ctypes.data_as(C.POINTER(C.c_float))))
+        if self._pad is not None and width > 1:                                 # the narrow network's own columns
+            out = np.ascontiguousarray(out[:, :self.model.width // (2 if layer == 9 else 1)])
         return out
 
     def set_weights(self, blob) -> None:
@@ -115,6 +125,12 @@ class Trainer:
     def _set(self, what: int, values) -> None:
         import numpy as np
         b = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)
+        if self._pad is not None:
+            if b.size != self._pad.size:
+                raise ValueError(f"{b.size} floats given, the model has {self._pad.size}")
+            full = np.zeros(self._n_native, np.float32)
+            full[self._pad] = b
+            b = full
         _lib.check(_lib.lib.ntx_trainer_set(self._h, what, b.ctypes.data_as(C.POINTER(C.c_float)), b.size))
 
     @property
@@ -370,6 +386,37 @@ class CoarseFineTrainer:
                                                 flat("color", 3), alpha, loss, composite_bkgd=composite_bkgd, bkgd_color=bkgd_color, seed=seed, rays_per_param_row=R)
         self.apply_gradients()
         return {"loss": val, "color_pred": c.reshape(B, R, 3), "alpha_pred": a.reshape(B, R), "color_pred_coarse": cc.reshape(B, R, 3), "alpha_pred_coarse": ac.reshape(B, R)}
+
+
+def _widened(model):
+    """Training is built for 8 x 256.  A ParamNerf of the same shape but NARROWER (`width` < 256, even) trains inside it:
+    its kernels sit in the top-left corners of the 256-wide ones (behind the encoding rows of the skip and colour layers), everything else is
+    zero and STAYS zero -- a padded unit's pre-activation is exactly 0, its ReLU gate is shut, so no gradient reaches its incoming weights, and
+    its outgoing weights see an activation of exactly 0; Adam leaves a weight whose gradient was always 0 where it is.  The step is then the
+    narrow network's, value for value (adding exact zeros changes no float32 sum), at the 256-wide network's cost -- as the flex render
+    family does.  Returns the 256-wide twin, or None if `model` is not such a network (256 itself included)."""
+    from .model import KIND_PARAMNERF, NerfModel
+    if not (model.kind == KIND_PARAMNERF and model.width < 256 and model.width >= 2 and model.width % 2 == 0 and model.depth == 8 and tuple(model.skips) == (4,)
+            and model.color_depth == 1 and model.param_depth == 0 and model.pos_encoding == "fourier"):
+        return None
+    return NerfModel(model.kind, [model.n_geo, model.n_app], model.n_pos, model.pos_freq, model.dir_freq, model.param_freq, 8, 256, (4,), 1, model.name)
+
+
+def _narrow_in_wide(narrow, wide):
+    """Index of every float of `narrow`'s weight blob inside `wide`'s (both in `get_weights()` order): a layer's input rows are
+    [encoding rows (the same in both) | hidden rows 0 .. w-1 of the wide layer's 256 (128 for the last colour layer)], its columns 0 .. out-1."""
+    import numpy as np
+    idx, at = [], 0
+    for (name, i_n, o_n), (name_w, i_w, o_w) in zip(narrow.layer_table(), wide.layer_table()):
+        assert name == name_w
+        hidden_n = 0 if name == "trunk0" else narrow.width // 2 if name == "color" else narrow.width     # the rows that come from a hidden layer
+        hidden_w = 0 if name == "trunk0" else 128 if name == "color" else 256
+        assert i_n - hidden_n == i_w - hidden_w and i_n >= hidden_n, (name, i_n, i_w)                # the pos_map / dir_map rows in front of them (model.py:107, 115)
+        rows = np.arange(i_n)                                                 # narrow row r -> wide row r: the hidden rows follow the encoding rows in both
+        kernel = at + rows[:, None] * o_w + np.arange(o_n)[None, :]
+        idx += [kernel.reshape(-1), at + i_w * o_w + np.arange(o_n)]
+        at += i_w * o_w + o_w
+    return np.concatenate(idx).astype(np.int64)
 
 
 def allreduce_mean_host(values, group=None):

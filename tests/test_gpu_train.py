@@ -357,10 +357,11 @@ def test_the_configs_batch_size_runs_and_refusals():
     l0 = float(tr.step(ro, rd, t, params, cone, color, alpha, loss).item())
     g = tr.gradients()
     assert np.isfinite(l0) and np.isfinite(g).all() and np.abs(g).max() > 0
-    flex, _, _ = make_model((1, 6), arch=dict(depth=6))
-    with pytest.raises(_lib.NtxError) as e:
-        Trainer(flex, max_rays=8, n_samples=8)
-    assert e.value.code == _lib.NTX_E_UNSUPPORTED
+    for arch in (dict(depth=6), dict(skips=[2]), dict(color_depth=2), dict(width=128, depth=4)):     # (a narrower 8-layer network does train: below)
+        flex, _, _ = make_model((1, 6), arch=arch)
+        with pytest.raises(_lib.NtxError) as e:
+            Trainer(flex, max_rays=8, n_samples=8)
+        assert e.value.code == _lib.NTX_E_UNSUPPORTED
 
 
 @pytest.mark.parametrize("fam,npar,blur,noise_std,n,S", [("carpet", (1, 6), None, 0.0, 1024, 256), ("carpet", (1, 6), None, 0.0, 1021, 255),
@@ -417,6 +418,58 @@ def test_gradients_with_narrow_encodings(npar, freqs):
     got, flat = tr.gradients(), np.concatenate([g.ravel() for g in wg])
     worst = {name: rel_linf(got[sl], flat[sl]) for name, sl in layer_slices(spec)}
     assert max(worst.values()) <= 1e-4, {k: v for k, v in worst.items() if v > 1e-5}
+
+
+@pytest.mark.parametrize("width", [128, 64, 30])
+def test_a_narrower_network_trains_inside_the_256_wide_one(width):
+    """`ParamNerf(width=w)` with w < 256 (model.py:58: the trunk w wide, the last colour layer w // 2): its weights sit in the corners of
+    the 256-wide kernels, the rest is zero and stays zero (nerf_tex_amd/train.py `_widened`).  Loss, predictions and every layer's gradient
+    against float64 autograd of the NARROW network; after three Adam steps the native trainer's padding is still exactly zero, the narrow
+    weights moved, and they render through the inference path (the flex family) to what the trainer predicted."""
+    from nerf_tex_amd import _lib
+    from nerf_tex_amd.renderer import Renderer
+    from nerf_tex_amd.train import Trainer
+    model, spec, wts = make_model((1, 6), dense_media=True, arch=dict(width=width))
+    n, S = 96, 40
+    ro, rd, t, cone, params, color, alpha = batch(23, n, S, 7, "carpet")
+    okw, loss = make_loss("alpha_smape")
+    tr = Trainer(model, max_rays=n, n_samples=S, perturb=False)
+    assert tr.n_weights == model.n_weight_floats() < tr._n_native and np.array_equal(tr.weights(), np.asarray(model.get_blob(), np.float32).reshape(-1))
+    val, cp, ap = tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss)
+    torch.cuda.synchronize()
+    M = n * S
+    masks = [(tr.activation(k, M) > 0).astype(np.float64) for k in list(range(8)) + [8, 9]]
+    assert [m.shape[1] for m in masks] == [width] * 9 + [width // 2]
+    sigma_mask = (tr.activation(10, M).reshape(n, S) > 0).astype(np.float64)
+    z = orc.z_values(t, S, np.float32)
+    want_val, wc, wa, wg = tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, okw, masks=masks, sigma_mask=sigma_mask)
+    assert abs(float(val.item()) - want_val) <= 1e-5 * abs(want_val)
+    assert orc.rel_linf(np.concatenate([cp.cpu().numpy(), ap.cpu().numpy()[:, None]], -1), np.concatenate([wc, wa[:, None]], -1)) <= 1e-4
+    got, flat = tr.gradients(), np.concatenate([g.ravel() for g in wg])
+    worst = {name: rel_linf(got[sl], flat[sl]) for name, sl in layer_slices(spec)}
+    assert max(worst.values()) <= 1e-4 and np.abs(flat).max() > 1e-6, {k: v for k, v in worst.items() if v > 1e-5}
+    tr.apply_gradients()
+    for _ in range(2):
+        pred = tr.step(ro, rd, t, params, cone, color, alpha, loss)
+    native = np.empty(tr._n_native, np.float32)
+    for what in (_lib.TRAINER_WEIGHTS, _lib.TRAINER_GRADIENTS, _lib.TRAINER_ADAM_M, _lib.TRAINER_ADAM_V):
+        _lib.check(_lib.lib.ntx_trainer_get(tr._h, what, native.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_float)), native.size))
+        outside = np.ones(native.size, bool); outside[tr._pad] = False
+        assert not native[outside].any() and native[tr._pad].any()                       # the padding: exactly zero, weights and moments
+    assert tr.iterations == 3 and not np.array_equal(tr.weights(), np.asarray(model.get_blob(), np.float32).reshape(-1))
+    st = tr.state_dict()                                                              # resuming speaks the narrow network's sizes
+    other = Trainer(make_model((1, 6), seed=5, arch=dict(width=width))[0], max_rays=n, n_samples=S, perturb=False)
+    other.load_state_dict(st)
+    a = tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss)
+    b = other.gradients_step(ro, rd, t, params, cone, color, alpha, loss)
+    assert torch.equal(a[1], b[1]) and np.array_equal(tr.gradients(), other.gradients())
+    model.set_weights_from_trainer(tr)                                                # through the host: the flex render family
+    d = lambda x: torch.as_tensor(x, device=dev())
+    view = dict(rays_o=d(ro)[None], rays_d=d(rd)[None], t=d(t)[None], parameters=d(params[:1]), cone_scale=d(cone).reshape(1, -1, 1))
+    params_row = np.repeat(params[:1], n, 0)
+    c_train = tr.gradients_step(ro, rd, t, params_row, cone, color, alpha, loss)[1]
+    img = Renderer(model=model, n_samples=S, perturb=False)(**view, training=False)
+    assert float((img["color_pred"][0] - c_train).abs().max()) <= 1e-4 * max(1.0, float(c_train.abs().max()))
 
 
 def test_training_resumes_bit_for_bit(tmp_path):
