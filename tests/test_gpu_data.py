@@ -160,3 +160,25 @@ def test_main_runs_a_training_config_file(tmp_path):
     assert out["step"] == 30 and [s for s, _ in out["loss"]] == [10, 20, 30] and sorted(out["images"]) == [30]
     assert os.path.exists(tmp_path / "out" / "config_train.py") and os.path.exists(tmp_path / "out" / "checkpoints" / "ckpt-30.index")
     assert os.path.exists(tmp_path / "out" / "media" / "validation" / "30" / "0.png")
+
+
+def test_the_example_training_config_runs(tmp_path, monkeypatch):
+    """README's quick start for training: `python tools/make_example_dataset.py` then `python -m nerf_tex_amd.main configs/example_carpet_train.py`
+    (fewer views, a smaller image and 40 steps here): the config file as it is, but for `n_iters` and the Logger's cadences."""
+    import importlib.util
+    from nerf_tex_amd import main as m
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_example_dataset", os.path.join(root, "tools", "make_example_dataset.py"))
+    maker = importlib.util.module_from_spec(spec); spec.loader.exec_module(maker)
+    monkeypatch.chdir(tmp_path)
+    files, _ = maker.make("datasets/example_carpet", n_views=5, size=64, n_samples=48)
+    assert [os.path.basename(f) for f in files] == ["train.tfr"]
+    raw = m.load_config(os.path.join(root, "configs", "example_carpet_train.py"))
+    assert raw.train_dataset_config.data_loader_config.tfr_path == "datasets/example_carpet/tfr" and raw.module == "network.train.Train"
+    raw.n_iters = 40; raw.logger_config.update(i_print=20, i_img=40, i_checkpoint=40)
+    raw.val_dataset_config.data_loader_config.update(height=32, width=32)
+    np.random.seed(raw.seed)
+    from nerf_tex_amd import util
+    out = util.instantiate(m.prepare(raw))
+    assert out["step"] == 40 and len(out["loss"]) == 2 and np.isfinite([v for _, v in out["loss"]]).all()
+    assert os.path.exists("logs/example_carpet_train/checkpoints/ckpt-40.index") and os.path.exists("logs/example_carpet_train/media/validation/40/0.png")

@@ -28,24 +28,10 @@ def main():
     dev = torch.device("cuda", 0)
     H = W = args.size
     root = tempfile.mkdtemp()
-    box = cfg["train_dataset_config"]["proxy_config"]
-    teacher = ParamNerf(FourierFeatures(10), FourierFeatures(4), FourierFeatures(4), [1, 6])["model"]
-    teacher.set_blob(synthetic.synthetic_weights(teacher.layer_table(), seed=2, dense_media=True))
-    params = [1.0, 1.0, 1.0, 0.1, 0.0, -0.707, 0.707]
-    rng = np.random.default_rng(0)
-    cams = [np.asarray([np.cos(a) * np.sqrt(1 - z * z), np.sin(a) * np.sqrt(1 - z * z), z]) * 5 for a, z in zip(rng.uniform(0, 2 * np.pi, 24), rng.uniform(0.3, 0.9, 24))]
-    views = [{"pose": D.look_at(c), "parameters": params} for c in cams]
-    ds = D.Dataset({"module": "nerf_tex_amd.dataset.FromViews", "views": views, "height": H, "width": W, "angle": 0.63}, {"module": "network.pixel_sampler.Full"},
-                   {"module": "network.ray_sampler.Proxy"}, dict(box), n_epochs=1, device=dev)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_example_dataset
+    _, teacher = make_example_dataset.make(root, 24, H)                                   # PNGs -> NeRF folder -> TFRecord shards
     renderer = Renderer(model=teacher, n_samples=256, perturb=False)
-    os.makedirs(os.path.join(root, "nerf", "train"))
-    frames = []
-    for k, data in enumerate(ds):
-        u8 = image_epilogue(render_image(renderer, ds, data)[0], uint8=True)[1].cpu().numpy()
-        png.write_png(os.path.join(root, "nerf", "train", f"r_{k:03d}.png"), u8)
-        frames.append({"transform_matrix": views[k]["pose"].tolist(), "driver_parameters": {f"p{i}": v for i, v in enumerate(params)}})
-    json.dump({"camera_angle_x": 0.63, "frames": frames}, open(os.path.join(root, "nerf", "transforms_train.json"), "w"))
-    tfrecord.convert_folder(os.path.join(root, "nerf"), os.path.join(root, "tfr"), imgs_per_shard=8)
     train = json.loads(json.dumps(cfg["train_dataset_config"])); train["data_loader_config"]["tfr_path"] = os.path.join(root, "tfr")
     val = json.loads(json.dumps(cfg["val_dataset_config"])); val["data_loader_config"].update(height=H, width=W)
     vds = D.Dataset(dict(val["data_loader_config"]), {"module": "network.pixel_sampler.Full"}, {"module": "network.ray_sampler.Proxy"}, dict(val["proxy_config"]), n_epochs=1, device=dev)
