@@ -182,3 +182,40 @@ def test_the_example_training_config_runs(tmp_path, monkeypatch):
     out = util.instantiate(m.prepare(raw))
     assert out["step"] == 40 and len(out["loss"]) == 2 and np.isfinite([v for _, v in out["loss"]]).all()
     assert os.path.exists("logs/example_carpet_train/checkpoints/ckpt-40.index") and os.path.exists("logs/example_carpet_train/media/validation/40/0.png")
+
+
+def test_independent_pixels_and_frustum_rays_over_a_folder(tmp_path):
+    """The other samplers on the same path (pixel_sampler.Independent: iid pixels, misses included; ray_sampler.Frustum: near / far instead of
+    a proxy) over `network.dataset.FileFolder`, view by view (no proxy hits to keep: the per-view path), with the background composited in."""
+    from nerf_tex_amd import png, util
+    rng = np.random.default_rng(2)
+    os.makedirs(tmp_path / "nerf" / "train")
+    imgs, frames = [], []
+    from nerf_tex_amd.dataset import look_at
+    for k in range(3):
+        imgs.append(rng.integers(0, 256, (40, 56, 4), dtype=np.uint8))
+        png.write_png(str(tmp_path / "nerf" / "train" / f"r_{k}.png"), imgs[-1])
+        frames.append({"transform_matrix": look_at(np.asarray([np.cos(k), np.sin(k), 0.5]) * 4).tolist(), "driver_parameters": {"a": 0.5, "b": float(k)}})
+    json.dump({"camera_angle_x": 0.7, "frames": frames}, open(tmp_path / "nerf" / "transforms_train.json", "w"))
+    ds = util.instantiate({"module": "network.dataset.Dataset",
+                           "data_loader_config": {"module": "network.dataset.FileFolder", "imgs_path": str(tmp_path / "nerf" / "train"),
+                                                  "poses_path": str(tmp_path / "nerf" / "transforms_train.json"), "idxs": [0, 1, 2], "composite_bkgd": True, "bkgd_color": [0.2, 0.4, 1.0]},
+                           "pixel_sampler_config": {"module": "network.pixel_sampler.Independent", "n_samples": 300},
+                           "ray_sampler_config": {"module": "network.ray_sampler.Frustum", "near": 2.0, "far": 6.0},
+                           "n_epochs": 1, "batchsize": 2, "device": dev(), "seed": 4})
+    assert (ds.height, ds.width, ds.n_samples, ds.n_parameters, ds.composite_bkgd) == (40, 56, 300, 2, True) and not ds._can_fuse(dev())
+    batches = list(ds)
+    assert [b["color"].shape[0] for b in batches] == [2, 1] and batches[0]["t"].shape == (2, 300, 2)
+    assert torch.equal(batches[0]["t"][..., 0], torch.full((2, 300), 2.0, device=dev())) and torch.equal(batches[0]["t"][..., 1], torch.full((2, 300), 6.0, device=dev()))
+    k = 0
+    for b in batches:
+        for e in range(b["color"].shape[0]):
+            c2w = torch.as_tensor(np.asarray(frames[k]["transform_matrix"], np.float32), device=dev())
+            d_cam = b["rays_d"][e] @ c2w[:3, :3]
+            d_cam = d_cam / -d_cam[:, 2:3]
+            j = torch.round(d_cam[:, 0] * ds.focal + 56 / 2 - 0.5).long(); i = torch.round(-d_cam[:, 1] * ds.focal + 40 / 2 - 0.5).long()
+            assert int(i.min()) >= 0 and int(i.max()) < 40 and int(j.min()) >= 0 and int(j.max()) < 56
+            px = torch.as_tensor(imgs[k], device=dev())[i, j].float() * torch.tensor(1.0 / 255)
+            want = px[:, :3] * px[:, 3:] + (1 - px[:, 3:]) * torch.tensor([0.2, 0.4, 1.0], device=dev())
+            assert torch.equal(b["color"][e], want) and torch.equal(b["alpha"][e], px[:, 3]) and float(b["parameters"][e, 1]) == float(k)
+            k += 1
