@@ -50,6 +50,8 @@ def test_crc32c_and_the_record_framing(tmp_path):
     assert crc32c(b"123456789") == 0xE3069283 == crc32c_bitwise(b"123456789")            # the check value of CRC-32C (Castagnoli)
     assert crc32c(b"\x00" * 32) == 0x8A9136AA                                              # RFC 3720 B.4: 32 bytes of zeros
     assert mask_crc(0xE3069283) == masked(0xE3069283)
+    big = np.random.default_rng(0).integers(0, 256, 70001, dtype=np.uint8).tobytes()       # long buffers go through the stretch-parallel pass
+    assert crc32c(big) == crc32c_bitwise(big) and crc32c(big[30000:], crc32c(big[:30000])) == crc32c(big) and crc32c(big[:65536]) == crc32c_bitwise(big[:65536])
     recs = [b"", b"a", bytes(range(256)) * 5]
     path = str(tmp_path / "x.tfr")
     with open(path, "wb") as f:
