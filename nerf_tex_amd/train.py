@@ -521,6 +521,8 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
     if step >= n_iters:
         return out
     todo = int(n_iters) - step
+    import time
+    t_print = time.perf_counter()
     for data in train_dataset:                                    # train.py:60: train_dataset.take(n_iters - logger.step)
         if todo <= 0:
             break
@@ -530,7 +532,10 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
         if i_print > 0 and step % i_print == 0:
             val = float(pred["loss"].item())
             out["loss"].append((step, val))
-            print(f"Step {step} | Loss {val:.3g}")
+            import time
+            now = time.perf_counter()
+            print(f"Step {step} | Loss {val:.3g} | Duration {now - t_print:.3g}")      # logger.py:68-73
+            t_print = now
         if val_dataset is not None and i_img > 0 and step % i_img == 0:      # logger.py:76-81
             from .render import render_image
             trainer.hand_weights_to_models() if two else model.set_weights_from_trainer(trainer)
