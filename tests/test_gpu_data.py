@@ -219,3 +219,34 @@ def test_independent_pixels_and_frustum_rays_over_a_folder(tmp_path):
             want = px[:, :3] * px[:, 3:] + (1 - px[:, 3:]) * torch.tensor([0.2, 0.4, 1.0], device=dev())
             assert torch.equal(b["color"][e], want) and torch.equal(b["alpha"][e], px[:, 3]) and float(b["parameters"][e, 1]) == float(k)
             k += 1
+
+
+@pytest.mark.parametrize("fam", ["carpet", "fur", "grass", "grass_filtered", "plush"])
+def test_every_shipped_training_config_runs_from_its_blocks(tmp_path, fam):
+    """All five shipped training configs (tests/golden/train_configs.json: the reference's config modules, evaluated): `Train(**config)`
+    with every block as written -- the TFRecord dataset (its `tfr_path` pointed at a small file of random images carrying the family's number
+    of parameters), the Proxy samplers in the family's box, batch 4 x 256 rays, the generated validation views (rendered at 48 x 48), the
+    model, loss, schedule and renderer blocks incl. grass_filtered's blur_idx 0 and raw_noise_std 0.1 -- for six steps at 256 samples a ray."""
+    from nerf_tex_amd import dataset as D, tfrecord
+    from nerf_tex_amd.train import Train
+    cfg = json.load(open(os.path.join(GOLDEN, "train_configs.json")))[fam]
+    P = sum(cfg["model_config"]["n_parameters"])
+    rng = np.random.default_rng(3)
+    from nerf_tex_amd import png
+    recs = []
+    for k in range(5):
+        pose = D.look_at(np.asarray([np.cos(k), np.sin(k), 0.7]) * 6)
+        recs.append(tfrecord.make_example({"image": png.encode_png(rng.integers(0, 256, (64, 64, 4), dtype=np.uint8)), "pose": tfrecord.serialize_tensor(pose), "angle": 0.6,
+                                           "parameters": tfrecord.serialize_tensor(rng.uniform(0, 1, P).astype(np.float32))}))
+    tfrecord.write_records(str(tmp_path / "train.tfr"), recs)
+    train = json.loads(json.dumps(cfg["train_dataset_config"])); train["data_loader_config"]["tfr_path"] = str(tmp_path / "train.tfr"); train["seed"] = 0
+    val = json.loads(json.dumps(cfg["val_dataset_config"])); val["data_loader_config"].update(height=48, width=48)
+    np.random.seed(0)
+    out = Train(str(tmp_path / "run"), train_dataset_config=train, val_dataset_config=val, model_config=cfg["model_config"], loss_config=cfg["loss_config"],
+                n_iters=6, lrate=cfg["lrate"], lrate_decay=cfg["lrate_decay"], renderer_config=cfg["renderer_config"],
+                logger_config=dict(cfg["logger_config"], i_print=2, i_img=6, i_checkpoint=6))
+    tr = out["trainer"]
+    assert out["step"] == 6 and tr.iterations == 6 and tr.n_samples == 256 and tr.max_rays == 1024 and np.isfinite([v for _, v in out["loss"]]).all() and len(out["loss"]) == 3
+    assert (tr.blur_idx, tr.raw_noise_std) == ((0, 0.1) if fam == "grass_filtered" else (None, 0.0))
+    assert len(out["images"][6]) == cfg["val_views_reference"]["n"] and all(tuple(im.shape) == (48, 48, 4) and bool(torch.isfinite(im).all()) for im in out["images"][6])
+    assert os.path.exists(tmp_path / "run" / "checkpoints" / "ckpt-6.index")
