@@ -244,9 +244,12 @@ class Trainer:
         stream.  Without one, the same mean through torch.distributed on host memory (gloo: the CPU-side tests, ranks sharing a GPU)."""
         import torch
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            # the mean of the ranks' means is the batch's gradient only when every rank brought as many rays (the losses are means over rays)
-            mine = torch.tensor([self._last_rays], dtype=torch.int64, device=torch.device("cuda", self.device) if dist.get_backend(group) == "nccl" else "cpu")
+        on_device = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and not (on_device and getattr(self, "_shards_agreed", False)):
+            # the mean of the ranks' means is the batch's gradient only when every rank brought as many rays (the losses are means over rays).
+            # Over gloo (host tensors) this is asked every step; over nccl it costs a device sync, so it is asked at the first step only.
+            self._shards_agreed = True
+            mine = torch.tensor([self._last_rays], dtype=torch.int64, device=torch.device("cuda", self.device) if on_device else "cpu")
             counts = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
             dist.all_gather(counts, mine, group=group)
             if len({int(c.item()) for c in counts}) != 1:
@@ -499,6 +502,7 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
         print(f"Restored model & optimizer from {info['prefix']}.")
     except FileNotFoundError:
         pass
+    dp_comm = None
     if world > 1:
         # Data parallel (one process per GPU; the reference has one): every rank on its own batches, the gradient their mean
         # (`Trainer.train_step` -> `sync_gradients`), so the ranks must start from ONE state -- rank 0's, restored or freshly drawn --
@@ -512,6 +516,9 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
         step = int(state[0]["step"])
         if rank != 0:
             i_print = i_img = i_ckpt = 0
+        if dist.get_backend() == "nccl":                           # one ncclAllReduce of the gradients a step on the device
+            from .dist import Comm
+            dp_comm = Comm(device)
     cb = getattr(train_dataset, "composite_bkgd", False) if composite_bkgd is None else composite_bkgd
     bc = getattr(train_dataset, "bkgd_color", (1., 1., 1.)) if bkgd_color is None else bkgd_color
     # (CheckpointManager keeps its list of kept checkpoints in the directory's `checkpoint` file: a resumed run goes on rotating the old ones)
@@ -519,6 +526,8 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
     found = sorted((int(m.group(1)), os.path.join(ckpt_dir, f[:-6])) for f in os.listdir(ckpt_dir) for m in [re.fullmatch(r"ckpt-(\d+)\.index", f)] if m)
     out = {"trainer": trainer, "renderer": renderer, "loss": [], "images": {}, "checkpoints": [p for _, p in found] if rank == 0 else [], "step": step}
     if step >= n_iters:
+        if dp_comm is not None:
+            dp_comm.close()
         return out
     todo = int(n_iters) - step
     import time
@@ -527,7 +536,7 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
         if todo <= 0:
             break
         todo -= 1
-        pred = trainer.train_step(data, loss_fn, composite_bkgd=cb, bkgd_color=bc, **({"seed": step * world + rank} if world > 1 else {}))
+        pred = trainer.train_step(data, loss_fn, composite_bkgd=cb, bkgd_color=bc, **({"seed": step * world + rank, "comm": dp_comm} if world > 1 else {}))
         step += 1
         if i_print > 0 and step % i_print == 0:
             val = float(pred["loss"].item())
@@ -555,4 +564,6 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
             checkpoint.write_manager_state(ckpt_dir, out["checkpoints"])
     out["step"] = step
     torch.cuda.synchronize(torch.device("cuda", device))
+    if dp_comm is not None:
+        dp_comm.close()
     return out
