@@ -18,10 +18,8 @@ def main():
     ap.add_argument("--every", type=int, default=500)
     ap.add_argument("--size", type=int, default=128)
     args = ap.parse_args()
-    from nerf_tex_amd import dataset as D, png, synthetic, tfrecord
-    from nerf_tex_amd.layer import FourierFeatures
-    from nerf_tex_amd.model import ParamNerf
-    from nerf_tex_amd.render import image_epilogue, render_image
+    from nerf_tex_amd import dataset as D
+    from nerf_tex_amd.render import render_image
     from nerf_tex_amd.renderer import Renderer
     from nerf_tex_amd.train import Train
     cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "train_configs.json")))["carpet"]
