@@ -10,8 +10,7 @@ dicts), model, loss, schedule and renderer from the config blocks, the loop, and
 views rendered through the inference path with the trainer's weights handed over on the device, checkpoints in TensorFlow's bundle format
 with model + step + optimizer (train.py:55-57) that `Trainer.restore` resumes from.
 
-Built for the ParamNerf architecture of the shipped training configs (8 x 256, skips [4], color_depth 1).  TensorBoard summaries
-(logger.py:41-64) stay out of scope: SURVEY section 2."""
+Built for the ParamNerf architecture of the shipped training configs (8 x 256, skips [4], color_depth 1; narrower widths inside it)."""
 
 from __future__ import annotations
 
@@ -490,9 +489,9 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
     rcfg = {k: v for k, v in dict(cfg["renderer_config"]).items() if k != "module"}
     two = isinstance(trainer, CoarseFineTrainer)                  # n_importance > 0: render.py:24 hands the renderer every model of the dict
     renderer = Renderer(model=model, model_fine=trainer.model_fine if two else None, **rcfg)
-    lg = dict(i_print=100, i_img=5e3, i_checkpoint=1e3, max_to_keep=3)
+    lg = dict(i_summary=10, i_print=100, i_img=5e3, i_checkpoint=1e3, max_to_keep=3)
     lg.update({k: v for k, v in (logger_config or {}).items() if k in lg})
-    i_print, i_img, i_ckpt, keep = int(lg["i_print"]), int(lg["i_img"]), int(lg["i_checkpoint"]), int(lg["max_to_keep"])
+    i_print, i_img, i_ckpt, keep, i_summary = int(lg["i_print"]), int(lg["i_img"]), int(lg["i_checkpoint"]), int(lg["max_to_keep"]), int(lg["i_summary"])
     ckpt_dir = os.path.join(target_path, "checkpoints")
     os.makedirs(ckpt_dir, exist_ok=True)
     step = 0
@@ -515,7 +514,7 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
         trainer.load_state_dict({k: v for k, v in state[0].items() if k != "step"})
         step = int(state[0]["step"])
         if rank != 0:
-            i_print = i_img = i_ckpt = 0
+            i_print = i_img = i_ckpt = i_summary = 0
         if dist.get_backend() == "nccl":                           # one ncclAllReduce of the gradients a step on the device
             from .dist import Comm
             dp_comm = Comm(device)
@@ -532,16 +531,32 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
     todo = int(n_iters) - step
     import time
     t_print = time.perf_counter()
+    # logger.py:41-44, 60-64, 79-81: the loss every i_summary steps and the validation images as TensorBoard summaries in target_path.  The
+    # loss stays on the device until the loop next waits for it anyway (a print, a checkpoint, the end): asking every 10 steps would stall it.
+    writer, pending = None, []
+    if i_summary > 0:
+        from .summary import FileWriter
+        writer = FileWriter(target_path)
+
+    def flush_summaries():
+        for st, value, wall in pending:
+            writer.scalar("Loss", float(value.item()), st, wall)
+        pending.clear()
+        writer.flush()
+
     for data in train_dataset:                                    # train.py:60: train_dataset.take(n_iters - logger.step)
         if todo <= 0:
             break
         todo -= 1
         pred = trainer.train_step(data, loss_fn, composite_bkgd=cb, bkgd_color=bc, **({"seed": step * world + rank, "comm": dp_comm} if world > 1 else {}))
         step += 1
+        if writer is not None and step % i_summary == 0:
+            pending.append((step, pred["loss"], time.time()))
+            if len(pending) >= 256:
+                flush_summaries()
         if i_print > 0 and step % i_print == 0:
             val = float(pred["loss"].item())
             out["loss"].append((step, val))
-            import time
             now = time.perf_counter()
             print(f"Step {step} | Loss {val:.3g} | Duration {now - t_print:.3g}")      # logger.py:68-73
             t_print = now
@@ -554,6 +569,11 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
             for k, im in enumerate(out["images"][step]):
                 write_images(vdir, im[None], k, len(out["images"][step]), int((logger_config or {}).get("downsampling_factor", 1)),
                              bool((logger_config or {}).get("write_exr", False)))
+            if writer is not None:
+                from .render import image_epilogue
+                flush_summaries()
+                u8 = [image_epilogue(im, int((logger_config or {}).get("downsampling_factor", 1)), uint8=True)[1] for im in out["images"][step][:3]]
+                writer.image("Validation Rendering", torch.stack(u8).cpu().numpy(), step)
         if i_ckpt > 0 and step % i_ckpt == 0:                               # logger.py:84-86
             out["checkpoints"].append(trainer.save(os.path.join(ckpt_dir, f"ckpt-{step}"), step=step))
             for old in out["checkpoints"][:-keep] if keep > 0 else []:
@@ -562,6 +582,12 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
                         os.remove(old + suffix)
             out["checkpoints"] = out["checkpoints"][-keep:] if keep > 0 else out["checkpoints"]
             checkpoint.write_manager_state(ckpt_dir, out["checkpoints"])
+            if writer is not None:
+                flush_summaries()
+    if writer is not None:
+        flush_summaries()
+        writer.close()
+        out["events"] = writer.path
     out["step"] = step
     torch.cuda.synchronize(torch.device("cuda", device))
     if dp_comm is not None:

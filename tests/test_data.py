@@ -399,3 +399,30 @@ def test_exr_images_through_the_folder_converter(tmp_path):
     os.rename(tmp_path / "nerf" / "train" / "r_2.exr", tmp_path / "nerf" / "train" / "r_2.txt")
     with pytest.raises(ValueError, match="unknown filetype"):
         T.convert_folder(str(tmp_path / "nerf"), str(tmp_path / "tfr2"))
+
+
+def test_tensorboard_event_files(tmp_path):
+    """nerf_tex_amd/summary.py (logger.py:41-44, 60-64, 79-81): the writer's file read back, and one scalar event assembled here from the
+    published messages (event.proto, summary.proto, tensor.proto) record for record."""
+    from nerf_tex_amd import summary
+    w = summary.FileWriter(str(tmp_path))
+    w.scalar("Loss", 0.125, 10, wall_time=1234.5)
+    imgs = np.random.default_rng(0).integers(0, 256, (4, 6, 5, 4), dtype=np.uint8)
+    w.image("Validation Rendering", imgs, 20)
+    w.close()
+    assert os.path.basename(w.path).startswith("events.out.tfevents.") and w.path.endswith(".v2")
+    ev = summary.read_events(w.path)
+    assert ev[0]["file_version"] == "brain.Event:2" and (ev[1]["tag"], ev[1]["step"], ev[1]["value"], ev[1]["wall_time"], ev[1]["data_class"]) == ("Loss", 10, 0.125, 1234.5, 1)
+    assert ev[2]["plugin"] == "images" and ev[2]["size"] == (5, 6) and len(ev[2]["images"]) == 3 and np.array_equal(ev[2]["images"][1], imgs[1])
+    # Event { wall_time = 1 (double), step = 2, summary = 5 { value = 1 { tag = 1, tensor = 8 { dtype = 1: DT_FLOAT, tensor_shape = 2 {}, float_val = 5 }, metadata = 9 {
+    #   plugin_data = 1 { plugin_name = 1 }, data_class = 4: DATA_CLASS_SCALAR } } } }
+    tensor = varint(1 << 3) + varint(1) + ld(2, b"") + ld(5, struct.pack("<f", 0.125))
+    meta = ld(1, ld(1, b"scalars")) + varint(4 << 3) + varint(1)
+    event = varint(1 << 3 | 1) + struct.pack("<d", 1234.5) + varint(2 << 3) + varint(10) + ld(5, ld(1, ld(1, b"Loss") + ld(9, meta) + ld(8, tensor)))
+    recs = list(T.read_records(w.path))
+    assert recs[1] == event
+    open(tmp_path / "hand.tfevents", "wb").write(frame(varint(1 << 3 | 1) + struct.pack("<d", 1.0) + ld(3, b"brain.Event:2")) + frame(event))
+    back = summary.read_events(str(tmp_path / "hand.tfevents"))
+    assert back[1]["value"] == 0.125 and back[1]["step"] == 10 and back[0]["file_version"] == "brain.Event:2"
+    with pytest.raises(ValueError):
+        summary.FileWriter(str(tmp_path)).image("x", np.zeros((2, 2, 3), np.float32), 1)

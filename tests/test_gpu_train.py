@@ -585,6 +585,14 @@ def test_train_loop_renders_validation_views_and_checkpoints(tmp_path):
     assert shot.shape[:2] == (24, 24) and sorted(os.listdir(tmp_path / "media" / "validation")) == ["100", "200"]
     kept = sorted(f for f in os.listdir(tmp_path / "checkpoints") if f.endswith(".index"))
     assert kept == ["ckpt-150.index", "ckpt-200.index"]
+    from nerf_tex_amd import summary                              # the Logger's TensorBoard file (logger.py:41-44, 60-64, 79-81): the loss every 10 steps, the validation images
+    ev = summary.read_events(out["events"])
+    assert os.path.dirname(out["events"]) == str(tmp_path) and os.path.basename(out["events"]).startswith("events.out.tfevents.") and ev[0]["file_version"] == "brain.Event:2"
+    scal = [e for e in ev if e.get("plugin") == "scalars"]
+    assert [e["step"] for e in scal] == list(range(10, 201, 10)) and all(e["tag"] == "Loss" for e in scal)
+    assert [round(e["value"], 6) for e in scal if e["step"] % 20 == 0] == [round(float(np.float32(v)), 6) for v in losses]
+    pics = [e for e in ev if e.get("plugin") == "images"]
+    assert [e["step"] for e in pics] == [100, 200] and pics[1]["tag"] == "Validation Rendering" and pics[1]["size"] == (24, 24) and np.array_equal(pics[1]["images"][0], shot)
     assert open(tmp_path / "checkpoints" / "checkpoint").read() == 'model_checkpoint_path: "ckpt-200"\nall_model_checkpoint_paths: "ckpt-150"\nall_model_checkpoint_paths: "ckpt-200"\n'
     tr, model, renderer = out["trainer"], out["trainer"].model, out["renderer"]
     model.set_blob(tr.weights())                                   # the same weights through the host: the same image
