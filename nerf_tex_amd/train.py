@@ -489,7 +489,7 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
     rcfg = {k: v for k, v in dict(cfg["renderer_config"]).items() if k != "module"}
     two = isinstance(trainer, CoarseFineTrainer)                  # n_importance > 0: render.py:24 hands the renderer every model of the dict
     renderer = Renderer(model=model, model_fine=trainer.model_fine if two else None, **rcfg)
-    lg = dict(i_summary=10, i_print=100, i_img=5e3, i_checkpoint=1e3, max_to_keep=3)
+    lg = dict(i_summary=10, i_print=100, i_img=5e3, i_checkpoint=1e3, max_to_keep=3, keep_every_n_hours=12)
     lg.update({k: v for k, v in (logger_config or {}).items() if k in lg})
     i_print, i_img, i_ckpt, keep, i_summary = int(lg["i_print"]), int(lg["i_img"]), int(lg["i_checkpoint"]), int(lg["max_to_keep"]), int(lg["i_summary"])
     ckpt_dir = os.path.join(target_path, "checkpoints")
@@ -534,6 +534,7 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
     # logger.py:41-44, 60-64, 79-81: the loss every i_summary steps and the validation images as TensorBoard summaries in target_path.  The
     # loss stays on the device until the loop next waits for it anyway (a print, a checkpoint, the end): asking every 10 steps would stall it.
     writer, pending = None, []
+    saved_at, kept_for_good = {}, [time.time()]
     if i_summary > 0:
         from .summary import FileWriter
         writer = FileWriter(target_path)
@@ -576,7 +577,13 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
                 writer.image("Validation Rendering", torch.stack(u8).cpu().numpy(), step)
         if i_ckpt > 0 and step % i_ckpt == 0:                               # logger.py:84-86
             out["checkpoints"].append(trainer.save(os.path.join(ckpt_dir, f"ckpt-{step}"), step=step))
+            saved_at[out["checkpoints"][-1]] = time.time()
             for old in out["checkpoints"][:-keep] if keep > 0 else []:
+                # CheckpointManager(keep_checkpoint_every_n_hours=...): one that falls out of the newest `max_to_keep` stays for good if it was
+                # saved that long after the last one kept this way (counted from the start of the run)
+                if saved_at.get(old, 0.0) - kept_for_good[0] >= 3600.0 * float(lg["keep_every_n_hours"]):
+                    kept_for_good[0] = saved_at[old]
+                    continue
                 for suffix in (".index", ".data-00000-of-00001"):
                     if os.path.exists(old + suffix):
                         os.remove(old + suffix)

@@ -129,6 +129,11 @@ def test_train_from_the_config_s_own_dataset_blocks(tmp_path):
     assert err(out["images"][400][1]) < 0.8 * err(out["images"][200][1]) or err(out["images"][400][1]) < 0.05, (err(out["images"][200][1]), err(out["images"][400][1]))
     more = Train(str(tmp_path / "run"), n_iters=420, logger_config={"i_print": 10, "i_img": 0, "i_checkpoint": 0}, **kw)
     assert more["step"] == 420 and more["trainer"].iterations == 420 and [s for s, _ in more["loss"]] == [410, 420]
+    # CheckpointManager's two rules (logger.py:34): the newest `max_to_keep`, and beyond them one every `keep_every_n_hours` (0: every one)
+    Train(str(tmp_path / "run"), n_iters=450, logger_config={"i_print": 0, "i_img": 0, "i_checkpoint": 10, "max_to_keep": 1, "keep_every_n_hours": 0}, **kw)
+    assert sorted(f for f in os.listdir(tmp_path / "run" / "checkpoints") if f.endswith(".index")) == [f"ckpt-{k}.index" for k in (410, 420, 430, 440, 450)]   # (resumed from 400: the run to 420 wrote none)
+    Train(str(tmp_path / "run"), n_iters=470, logger_config={"i_print": 0, "i_img": 0, "i_checkpoint": 10, "max_to_keep": 1}, **kw)
+    assert sorted(f for f in os.listdir(tmp_path / "run" / "checkpoints") if f.endswith(".index")) == ["ckpt-470.index"]
 
 
 def test_two_ranks_run_the_loop_data_parallel(tmp_path):
