@@ -492,7 +492,7 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
     lg = dict(i_summary=10, i_print=100, i_img=5e3, i_checkpoint=1e3, max_to_keep=3, keep_every_n_hours=12)
     lg.update({k: v for k, v in (logger_config or {}).items() if k in lg})
     i_print, i_img, i_ckpt, keep, i_summary = int(lg["i_print"]), int(lg["i_img"]), int(lg["i_checkpoint"]), int(lg["max_to_keep"]), int(lg["i_summary"])
-    ckpt_dir = os.path.join(target_path, "checkpoints")
+    ckpt_dir = os.path.join((logger_config or {}).get("source_path") or target_path, "checkpoints")     # logger.py:15, 30
     os.makedirs(ckpt_dir, exist_ok=True)
     step = 0
     try:                                                          # logger.py:39: restore the newest checkpoint if there is one
