@@ -68,6 +68,13 @@ def main(argv=None) -> list:
         src = args.config if args.config.endswith(".py") else args.config + ".py"
         if os.path.abspath(src) != os.path.abspath(dst):
             shutil.copy(src, dst)
+        try:                                                               # main.py:44-47: the commit the run was made with, behind the copy
+            import subprocess
+            label = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).strip().decode("utf-8")
+            with open(dst, "a") as f:
+                f.write("\n# GIT COMMIT HASH: " + label)
+        except (OSError, subprocess.CalledProcessError):
+            pass                                                           # (not a git checkout: the reference stops here, this goes on)
     return util.instantiate(prepare(raw, args.volumetric))                 # main.py:50
 
 
