@@ -426,3 +426,43 @@ def test_tensorboard_event_files(tmp_path):
     assert back[1]["value"] == 0.125 and back[1]["step"] == 10 and back[0]["file_version"] == "brain.Event:2"
     with pytest.raises(ValueError):
         summary.FileWriter(str(tmp_path)).image("x", np.zeros((2, 2, 3), np.float32), 1)
+
+
+def test_blur_augmentation_of_a_folder(tmp_path):
+    """nerf_tex_amd/augment.py (data/blur.py): names, the pose file with `Blur` as the FIRST driver parameter, the sigmas of the seeded
+    draw, and what the blur does -- nothing at sigma 0 but the gamma round trip, a premultiplied gaussian otherwise (energy of alpha kept away
+    from the border, the kernel's taps on an impulse)."""
+    from scipy import ndimage
+    from nerf_tex_amd import augment, exr
+    imgs, frames = nerf_folder(str(tmp_path / "nerf"), n=3, h=24, w=20)
+    for fr in json.load(open(tmp_path / "nerf" / "transforms_train.json"))["frames"]:
+        assert "file_path" in fr
+    out = augment.blur_folder(str(tmp_path / "nerf"), str(tmp_path / "blur"), max_sigma=2.0, dataset_size_increase=2)
+    names = sorted(os.listdir(tmp_path / "blur" / "train"))
+    assert names == [f"r_{k}.png" for k in range(6)] and out == [str(tmp_path / "blur" / "transforms_train.json")]
+    d = json.load(open(out[0]))
+    np.random.seed(0); u = np.random.rand(6)
+    want = (-np.log(1 - u * (1 - np.exp(-3.0))) / 3.0 * 2.0).tolist()
+    assert [fr["driver_parameters"]["Blur"] for fr in d["frames"]] == want and all(0 <= s <= 2.0 for s in want)
+    assert list(d["frames"][4]["driver_parameters"]) == ["Blur", "zeta", "alpha", "len"] and d["frames"][4]["driver_parameters"]["zeta"] == 1.0
+    assert d["frames"][4]["file_path"] == "./train/r_4" and d["camera_angle_x"] == 0.6
+    with pytest.raises(FileExistsError):
+        augment.blur_folder(str(tmp_path / "nerf"), str(tmp_path / "blur"))
+    same = augment.blur_png(imgs[0], 0.0)                                                  # sigma 0: premultiply, un-premultiply
+    opaque = imgs[0][..., 3] > 32
+    assert np.abs(same[opaque].astype(int) - imgs[0][opaque].astype(int)).max() <= 1 and np.array_equal(same[..., 3], imgs[0][..., 3])
+    dot = np.zeros((21, 21, 4), np.uint8); dot[10, 10] = 255
+    b = augment.blur_png(dot, 1.5)
+    g = ndimage.gaussian_filter(np.eye(1, 21, 10)[0], 1.5, mode="constant", truncate=4.0)  # the 1-d taps of the same filter
+    assert np.array_equal(b[..., 3], np.rint(np.outer(g, g) * 255).astype(np.uint8)) and b[10, 10, 3] > b[10, 12, 3] > b[10, 14, 3] > 0
+    assert (b[..., :3][b[..., 3] > 8] >= 250).all()                                        # white stays white where there is alpha to divide by
+    e = np.random.default_rng(0).random((12, 10, 4), dtype=np.float32)
+    assert np.array_equal(augment.blur_exr(e, 0.1), e)                                      # int(0.6) = 0 taps
+    be = augment.blur_exr(np.ones((12, 10, 4), np.float32), 1.0)                           # 6 taps, SAME padding: 1 inside, less at the border
+    assert np.allclose(be[4:8, 4:6], 1.0, atol=1e-6) and be[0, 0, 0] < 0.5 and be.dtype == np.float32
+    os.makedirs(tmp_path / "nerf2" / "train")
+    exr.write_exr(str(tmp_path / "nerf2" / "train" / "r_0.exr"), e)
+    json.dump({"camera_angle_x": 0.5, "frames": [{"file_path": "./train/r_0", "transform_matrix": np.eye(4).tolist(), "driver_parameters": {"a": 1.0}}]},
+              open(tmp_path / "nerf2" / "transforms_train.json", "w"))
+    augment.blur_folder(str(tmp_path / "nerf2"), str(tmp_path / "blur2"), max_sigma=1.0)
+    assert exr.read_exr(str(tmp_path / "blur2" / "train" / "r_0.exr")).shape == (12, 10, 4)
