@@ -391,6 +391,28 @@ def bench_train_step(args) -> None:
                          "kernel": "ntx_train::fwd_chain_kernel + dx_chain_kernel (the network forward and back with a block's activations in registers from layer to layer) "
                                    "+ dw_kernel (dW of every layer from the operand-order stores, persistent workgroups with an equal share each)", "kernel_ms": step_ms,
                          "what": "3 x forward FLOPs (2 MACs per weight per sample) over the WHOLE step's HIP-event time: encoders, heads, composite, loss and Adam included"}}
+    if world == 1 and fam_name == "carpet":
+        # the LOOP around the step (train.py:60-67): batches made by nerf_tex_amd.dataset.Dataset as the config asks -- Proxy pixel sampler among the
+        # proxy's hits, rays, colours gathered from resident 800 x 800 uint8 views -- and handed to the same step (tools/bench_train_loop.py)
+        from nerf_tex_amd import dataset as D, util
+        vrng = np.random.default_rng(0)
+        views = [{"pose": D.look_at(np.asarray([np.cos(a) * 0.8, np.sin(a) * 0.8, 0.6]) * 5), "parameters": list(fam["params"]),
+                  "rgba": vrng.integers(0, 256, (800, 800, 4), dtype=np.uint8)} for a in np.linspace(0, 2 * np.pi, 32, endpoint=False)]
+        ds = util.instantiate({"module": "network.dataset.Dataset", "data_loader_config": {"module": "nerf_tex_amd.dataset.FromViews", "views": views, "angle": 0.63},
+                               "pixel_sampler_config": {"module": "network.pixel_sampler.Proxy", "n_samples": 256}, "ray_sampler_config": {"module": "network.ray_sampler.Proxy"},
+                               "proxy_config": {"module": "network.proxy.AABB", "b_0": box[0], "b_1": box[1]}, "batchsize": 4, "shuffle_buffer_size": 100, "device": dev, "seed": 0})
+        it = iter(ds)
+        for _ in range(max(args.warmup, 9)):                                   # every view comes up once: its image and hit list go to the device
+            tr.train_step(next(it), loss)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.train_step(next(it), loss)
+        torch.cuda.synchronize()
+        loop_s = (time.perf_counter() - t1) / args.steps
+        line["with_data_side"] = {"ms_per_step": loop_s * 1e3, "value": n * S / loop_s, "unit": "ray-samples/s", "over_the_step_alone": loop_s / (elapsed / args.steps),
+                                  "what": "the same step fed by nerf_tex_amd.dataset.Dataset (config_carpet_train.py's train_dataset_config over 32 resident 800 x 800 uint8 views: "
+                                          "256 pixels a view among the proxy's hits, their rays, premultiplied colours gathered at them), batches made on the step's stream"}
     if not args.no_cpu_baseline and world == 1:
         from oracle import nerftex_oracle as orc
         from oracle import torch_cpu, train_oracle as tro
