@@ -93,6 +93,16 @@ class NerfModel:
         order = sorted(range(len(seq)), key=lambda j: (-seq[j][3], j))
         return [seq[j][:3] for j in order]
 
+    def summary(self, print_fn=print) -> None:
+        """`tf.keras.Model.summary()` as far as it can be said without Keras (train.py:36): the Dense layers in `get_weights()` order with
+        their kernel shapes and parameter counts, and the total."""
+        rows = [(name, f"({i}, {o})", i * o + o) for name, i, o in self.layer_table()]
+        print_fn(f'Model: "{self.name}"')
+        print_fn(f"{'Layer (Dense)':<20}{'kernel':<16}{'Param #':>10}")
+        for name, shape, n in rows:
+            print_fn(f"{name:<20}{shape:<16}{n:>10,}")
+        print_fn(f"Total params: {sum(r[2] for r in rows):,}")
+
     def n_weight_floats(self) -> int:
         return sum(i * o + o for _, i, o in self.layer_table())
 

@@ -488,6 +488,9 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
     model = trainer.model
     rcfg = {k: v for k, v in dict(cfg["renderer_config"]).items() if k != "module"}
     two = isinstance(trainer, CoarseFineTrainer)                  # n_importance > 0: render.py:24 hands the renderer every model of the dict
+    if rank == 0 and (logger_config or {}).get("print_model_summary", True):
+        for m in ([trainer.coarse.model, trainer.fine.model] if two and not trainer.shared else [model]):      # train.py:35-36 (plot_model needs graphviz: not drawn)
+            m.summary()
     renderer = Renderer(model=model, model_fine=trainer.model_fine if two else None, **rcfg)
     lg = dict(i_summary=10, i_print=100, i_img=5e3, i_checkpoint=1e3, max_to_keep=3, keep_every_n_hours=12)
     lg.update({k: v for k, v in (logger_config or {}).items() if k in lg})
