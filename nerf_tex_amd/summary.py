@@ -14,7 +14,7 @@ import os
 import socket
 import struct
 import time
-from typing import Dict, List, Tuple
+from typing import Dict, List
 
 import numpy as np
 
