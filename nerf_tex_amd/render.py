@@ -70,9 +70,32 @@ def Render(target_path: Optional[str], test_dataset_config, model_config, render
     renderer_config.update(model)                                                      # render.py:24
     renderer = util.instantiate(renderer_config)
     imgs = []
+    # One process per GPU (torch.distributed initialised, world > 1): rays shard freely (renderer.py:72-73 treats chunks of rays independently), so
+    # every rank renders ITS pixels of each view -- a contiguous band of the row-major order, generated on its own device -- and ONE gather brings
+    # the RGBA to rank 0 (`ncclGather` through the C ABI over the `nccl` backend, torch.distributed through host memory over `gloo`), which
+    # writes the files and returns the images; the other ranks return [].  Jitter and noise are keyed by the pixel, so the image is the one-GPU image.
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    comm = shard = None
+    if world > 1:
+        from .dist import Comm, ShardMap
+        from .pixel_sampler import Full
+        if not isinstance(test_dataset.pixel_sampler, Full):
+            raise NotImplementedError("a sharded Render needs pixel_sampler.Full")
+        shard = ShardMap(test_dataset.height * test_dataset.width, world)
+        test_dataset.pixel_sampler.shard = (shard, rank)
+        if dist.get_backend() == "nccl":
+            import torch
+            comm = Comm(torch.cuda.current_device())
     for i, data in enumerate(test_dataset):
-        img = render_image(renderer, test_dataset, data)
-        renderer.raise_if_nonfinite()
+        if world > 1:
+            img = _render_image_sharded(renderer, test_dataset, dict(data, seed=data.get("seed", 7919 * (i + 1))), shard, rank, comm)   # one jitter / noise stream a view, whatever the rank
+            renderer.raise_if_nonfinite()
+            if img is None:
+                continue
+        else:
+            img = render_image(renderer, test_dataset, data)
+            renderer.raise_if_nonfinite()
         if target_path is not None:
             import numpy as np
             os.makedirs(os.path.join(target_path, "media", "test"), exist_ok=True)
@@ -81,7 +104,26 @@ def Render(target_path: Optional[str], test_dataset_config, model_config, render
                          bool((logger_config or {}).get("write_exr", False)))
         if return_imgs:
             imgs.append(img)
+    if comm is not None:
+        comm.close()
     return imgs
+
+
+def _render_image_sharded(renderer, dataset, data: dict, shard, rank: int, comm):
+    """This rank's pixels of every view of the batch, gathered to rank 0: [B, H, W, 4] there, None elsewhere."""
+    import torch
+    from .dist import gather_image
+    pred = renderer(**data, composite_bkgd=dataset.composite_bkgd, bkgd_color=dataset.bkgd_color, training=False, ray_index=shard.ray_index(rank))
+    out = []
+    for b in range(pred["color_pred"].shape[0]):
+        local = torch.cat([pred["color_pred"][b].reshape(-1, 3), pred["alpha_pred"][b].reshape(-1, 1)], -1)
+        if comm is not None:
+            full = gather_image(local, shard, comm=comm)
+        else:                                                        # gloo: the same plan through host memory
+            full = gather_image(local.cpu(), shard)
+            full = full.to(local.device) if full is not None else None
+        out.append(full)
+    return None if out[0] is None else torch.stack(out).reshape(-1, dataset.height, dataset.width, 4)
 
 
 def write_images(directory: str, rgba, first_idx: int, max_idx: int, downsampling_factor: int = 1, write_exr: bool = False) -> List[str]:

@@ -255,3 +255,14 @@ def test_every_shipped_training_config_runs_from_its_blocks(tmp_path, fam):
     assert (tr.blur_idx, tr.raw_noise_std) == ((0, 0.1) if fam == "grass_filtered" else (None, 0.0))
     assert len(out["images"][6]) == cfg["val_views_reference"]["n"] and all(tuple(im.shape) == (48, 48, 4) and bool(torch.isfinite(im).all()) for im in out["images"][6])
     assert os.path.exists(tmp_path / "run" / "checkpoints" / "ckpt-6.index")
+
+
+def test_two_ranks_render_one_image(tmp_path):
+    """`Render` under torch.distributed (one process per GPU; here two ranks sharing GPU 0 on gloo): the ranks render bands of each view, rank 0
+    gathers and writes; the image is the one-GPU image bit for bit, with the reference's default jitter on (tests/_dp_render_worker.py)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29659",
+                          os.path.join(root, "tests", "_dp_render_worker.py"), str(tmp_path / "run")], capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "DP_RENDER_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
