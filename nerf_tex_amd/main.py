@@ -61,8 +61,24 @@ def main(argv=None) -> list:
     raw = load_config(args.config)
     if raw.get("seed") is not None:                                        # main.py:30-32
         np.random.seed(raw["seed"])
+    # One process per GPU: started as `python -m torch.distributed.run --nproc-per-node N -m nerf_tex_amd.main <config>` this joins the
+    # process group (RCCL: backend nccl), takes the GPU of its LOCAL_RANK, and `Render` / `Train` shard the work; rank 0
+    # owns the target folder.  (NTX_MAIN_SHARE_GPU=1, development: every rank on GPU 0 over gloo.)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        share = os.environ.get("NTX_MAIN_SHARE_GPU") == "1"
+        local = 0 if share else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            dist.init_process_group("gloo") if share else dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if "train" in str(raw.get("module", "")):
+            raw["device"] = local
     target = raw.get("target_path")
-    if target:                                                             # main.py:35-42
+    if target and rank != 0:
+        os.makedirs(target, exist_ok=True)
+    elif target:                                                           # main.py:35-42
         os.makedirs(target, exist_ok=bool(raw.get("override", True)))
         dst = os.path.join(target, "config_train.py" if "train" in str(raw.get("module", "")) else "config_render.py")   # main.py:36-37
         src = args.config if args.config.endswith(".py") else args.config + ".py"

@@ -266,3 +266,16 @@ def test_two_ranks_render_one_image(tmp_path):
                           os.path.join(root, "tests", "_dp_render_worker.py"), str(tmp_path / "run")], capture_output=True, text=True, timeout=600, cwd=root,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0 and "DP_RENDER_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_main_under_torch_distributed_run(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m nerf_tex_amd.main configs/example_carpet_render.py` (both ranks on GPU 0 over gloo,
+    the development knob): the entry point joins the process group, `Render` shards each view, rank 0 writes the two images."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29661",
+                          "-m", "nerf_tex_amd.main", os.path.join(root, "configs", "example_carpet_render.py")], capture_output=True, text=True, timeout=600, cwd=str(tmp_path),
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NTX_MAIN_SHARE_GPU="1", PYTHONPATH=root))
+    assert out.returncode == 0 and "rendered 2 image(s)" in out.stdout and "rendered 0 image(s)" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+    assert sorted(os.listdir(tmp_path / "logs" / "example_carpet" / "media" / "test")) == ["0.npy", "0.png", "1.npy", "1.png"]
+    assert np.load(tmp_path / "logs" / "example_carpet" / "media" / "test" / "1.npy").shape == (1, 128, 128, 4)
