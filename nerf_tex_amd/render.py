@@ -113,7 +113,18 @@ def _render_image_sharded(renderer, dataset, data: dict, shard, rank: int, comm)
     """This rank's pixels of every view of the batch, gathered to rank 0: [B, H, W, 4] there, None elsewhere."""
     import torch
     from .dist import gather_image
-    pred = renderer(**data, composite_bkgd=dataset.composite_bkgd, bkgd_color=dataset.bkgd_color, training=False, ray_index=shard.ray_index(rank))
+    extra = {}
+    if hasattr(renderer, "instancer") and data["t"].shape[0] == 1 and shard.contiguous:
+        # InstanceRenderer keys its instancer's draws (the marching offset of a ray) by the ray's place among the image's proxy hits
+        # (renderer.py:58-73): this rank's first hit comes after the hits of the bands before it -- one small all_gather a view
+        import torch.distributed as dist
+        on_device = dist.get_backend() == "nccl"
+        mine = (data["t"][0, :, 0] != float("inf")).sum().reshape(1).to(torch.int64)
+        mine = mine if on_device else mine.cpu()
+        counts = [torch.empty_like(mine) for _ in range(shard.world)]
+        dist.all_gather(counts, mine)
+        extra["hit_base"] = int(sum(int(c.item()) for c in counts[:rank]))
+    pred = renderer(**data, composite_bkgd=dataset.composite_bkgd, bkgd_color=dataset.bkgd_color, training=False, ray_index=shard.ray_index(rank), **extra)
     out = []
     for b in range(pred["color_pred"].shape[0]):
         local = torch.cat([pred["color_pred"][b].reshape(-1, 3), pred["alpha_pred"][b].reshape(-1, 1)], -1)

@@ -281,7 +281,8 @@ class InstanceRenderer(Renderer):
             if native:
                 (rays_d_map, pts, tt, dists, color_last, alpha_last, alpha_weight, instance_id, idxs, params_map) = \
                     self.instancer.get_model_input(ro_c, rd_c, p_c, S, self.step_size, seed=kwargs.get("instancer_seed"),
-                                                   ray_index=(i, k, k), sparse=kwargs.get("instancer_sparse", True), fill=kwargs.get("instancer_fill"))
+                                                   ray_index=(int(kwargs.get("hit_base", 0)) + i, k, k), sparse=kwargs.get("instancer_sparse", True),
+                                                   fill=kwargs.get("instancer_fill"))
                 # (sparse: the tail reads a row of the buffers only where dists > 0, renderer.py:284-288 -- the defaults behind a ray's last
                 # step, three quarters of a carpet frame's bytes, are not written)
                 hit = self.instancer.last_hit

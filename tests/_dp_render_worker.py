@@ -12,7 +12,49 @@ from nerf_tex_amd import main as m, util          # noqa: E402
 from nerf_tex_amd.render import render_image      # noqa: E402
 
 
+def instanced():
+    """The InstanceRenderer path: a sheet of patches, `instance_sampling_method: random` (per-step choices and per-ray marching offsets are
+    draws keyed by the ray's place among the image's proxy hits) -- the sharded image is still the one-GPU image."""
+    from nerf_tex_amd import synthetic
+    from nerf_tex_amd.dataset import look_at
+    from nerf_tex_amd.render import Render
+    target = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    tr, v, f = synthetic.patch_sheet(6, extent=0.35, scale=0.09)
+    emb = lambda n_: {'module': 'network.model.FourierFeatures', 'n_freq_bands': n_}
+
+    def config():
+        return util.remap_reference_config({
+            'module': 'network.render.Render', 'target_path': None,
+            'test_dataset_config': {'module': 'network.dataset.Dataset',
+                                    'data_loader_config': {'module': 'nerf_tex_amd.dataset.FromViews', 'height': 36, 'width': 44, 'angle': 0.16,
+                                                           'views': [{'pose': look_at(6. * np.asarray([0.9165, 0., 0.4])), 'parameters': [1, 1, 1, .1, 0.3, 0.2, 1]}]},
+                                    'pixel_sampler_config': {'module': 'network.pixel_sampler.Full'}, 'ray_sampler_config': {'module': 'network.ray_sampler.Proxy'},
+                                    'proxy_config': {'module': 'network.proxy.AABB', 'b_0': [-0.7, -0.7, -.2], 'b_1': [0.7, 0.7, .3]}, 'n_epochs': 1},
+            'model_config': {'module': 'network.model.ParamNerf', 'pos_embedding': emb(10), 'dir_embedding': emb(4), 'param_embedding': emb(4), 'n_parameters': [1, 6]},
+            'renderer_config': {'module': 'network.renderer.InstanceRenderer', 'n_samples': 192, 'render_chunk': 16384, 'density_scale': 60.0, 'perturb': False,
+                                'instancer_config': {'module': 'nerf_tex_amd.instancer.Instancer', 'b_0': synthetic.PATCH_BOX[0], 'b_1': synthetic.PATCH_BOX[1],
+                                                     'cast_shadow_rays': False, 'textures': ['', '', '', '', 'light'], 'transformations': [m.tolist() for m in tr],
+                                                     'mesh': (v, f), 'patch_scale': 0.09, 'instance_sampling_method': 'random'},
+                                'density_reweighting': True, 'step_size': 0.004},
+            'logger_config': {'module': 'network.logger.Logger'}})
+    model = util.instantiate(dict(config().model_config))["model"]
+    blob = synthetic.synthetic_weights(model.layer_table(), seed=0, dense_media=True)
+    imgs = util.instantiate(dict(config(), weights=blob, weights_order="keras_get_weights"))
+    assert (len(imgs) == 1) == (rank == 0)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        whole = util.instantiate(dict(config(), weights=blob, weights_order="keras_get_weights"))
+        a, b = imgs[0].cpu().numpy(), whole[0].cpu().numpy()
+        assert a.shape == b.shape == (1, 36, 44, 4) and float(b[..., 3].max()) > 0.3 and np.array_equal(a, b), float(np.abs(a - b).max())
+        print("DP_RENDER_OK")
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == "instanced":
+        return instanced()
     target = sys.argv[1]
     dist.init_process_group("gloo")
     rank = dist.get_rank()

@@ -257,13 +257,15 @@ def test_every_shipped_training_config_runs_from_its_blocks(tmp_path, fam):
     assert os.path.exists(tmp_path / "run" / "checkpoints" / "ckpt-6.index")
 
 
-def test_two_ranks_render_one_image(tmp_path):
+@pytest.mark.parametrize("path", ["volume", "instanced"])
+def test_two_ranks_render_one_image(tmp_path, path):
     """`Render` under torch.distributed (one process per GPU; here two ranks sharing GPU 0 on gloo): the ranks render bands of each view, rank 0
-    gathers and writes; the image is the one-GPU image bit for bit, with the reference's default jitter on (tests/_dp_render_worker.py)."""
+    gathers and writes; the image is the one-GPU image bit for bit, with the reference's default jitter on -- and through `InstanceRenderer` with
+    random patch choices, whose draws are keyed by a ray's place among the image's proxy hits (tests/_dp_render_worker.py)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29659",
-                          os.path.join(root, "tests", "_dp_render_worker.py"), str(tmp_path / "run")], capture_output=True, text=True, timeout=600, cwd=root,
+                          os.path.join(root, "tests", "_dp_render_worker.py"), str(tmp_path / "run"), path], capture_output=True, text=True, timeout=600, cwd=root,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0 and "DP_RENDER_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 
