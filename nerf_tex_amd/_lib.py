@@ -163,6 +163,13 @@ def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: the HIP library is not built "
                           f"(run `make -C {os.path.join(_HERE, 'csrc')}`); there is no CPU fallback")
+    try:
+        # PyTorch-ROCm ships its own libamdhip64; this library names /opt/rocm's.  Both have one SONAME, so whichever is mapped first serves the
+        # whole process -- and torch finds "No HIP GPUs" on a runtime it was not built with.  torch first, always (measured: a fresh
+        # `python -m nerf_tex_amd.main <training config>` made the trainer before torch had been imported).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, also fatal

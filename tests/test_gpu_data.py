@@ -281,3 +281,18 @@ def test_main_under_torch_distributed_run(tmp_path):
     assert out.returncode == 0 and "rendered 2 image(s)" in out.stdout and "rendered 0 image(s)" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
     assert sorted(os.listdir(tmp_path / "logs" / "example_carpet" / "media" / "test")) == ["0.npy", "0.png", "1.npy", "1.png"]
     assert np.load(tmp_path / "logs" / "example_carpet" / "media" / "test" / "1.npy").shape == (1, 128, 128, 4)
+
+
+def test_the_library_loads_before_torch_in_a_fresh_process():
+    """PyTorch-ROCm bundles its own libamdhip64 and this library names /opt/rocm's, one SONAME: mapped first, the library's copy left torch with
+    "No HIP GPUs are available" (a fresh `python -m nerf_tex_amd.main <training config>` makes the trainer before anything touched torch).
+    `_lib` imports torch before it loads the library; a process that starts with the package must still have its GPU in torch."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from nerf_tex_amd import _lib\n"
+            "from nerf_tex_amd.layer import FourierFeatures\nfrom nerf_tex_amd.model import ParamNerf\nfrom nerf_tex_amd.train import Trainer\n"
+            "tr = Trainer(ParamNerf(FourierFeatures(10), FourierFeatures(4), FourierFeatures(4), [1, 6])['model'], max_rays=64, n_samples=16)\n"
+            "import torch\nprint('ORDER_OK', torch.cuda.device_count(), float(torch.ones(3, device='cuda').sum()))\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ORDER_OK 1 3.0" in out.stdout or "ORDER_OK" in out.stdout and " 3.0" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
