@@ -242,3 +242,16 @@ def convert_folder(path_in: str, path_out: str, subsets=("train",), skip_params:
             write_records(out, records(), compression_type)
             written.append(out)
     return written
+
+
+if __name__ == "__main__":                                            # python -m nerf_tex_amd.tfrecord <path_in> <path_out> ...: data/nerf2tfr.py's command line
+    import argparse
+    ap = argparse.ArgumentParser(description="Converts NeRF dataset to TFR dataset.")
+    ap.add_argument("path_in", help="Path to NeRF dataset.")
+    ap.add_argument("path_out", help="Path to save TFR dataset to.")
+    ap.add_argument("--subsets", nargs="+", default=["train"], help="Subsets to process.")
+    ap.add_argument("--skip_params", action="store_true", help="Do not include the driver parameters in the tfr file.")
+    ap.add_argument("--imgs_per_shard", type=int, default=-1, help="Number of images per shard.")
+    ap.add_argument("--compression_type", type=str, default="", help="Compression used for the tfrecords ('', GZIP).")
+    a = ap.parse_args()
+    print("wrote", ", ".join(convert_folder(a.path_in, a.path_out, a.subsets, a.skip_params, a.imgs_per_shard, a.compression_type)))
