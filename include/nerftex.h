@@ -506,10 +506,11 @@ int ntx_trainer_set(ntx_trainer *t, int what, const float *values_host, size_t n
  * ntx_train_step_gradients and ntx_trainer_adam_step; all ranks then take the same Adam step. */
 int ntx_trainer_allreduce_gradients(ntx_trainer *t, ntx_comm *comm, ntx_stream stream);
 /* The activations the last step kept, to HOST memory as [n_samples_total][width]: layer 0-7 = the trunk layers' outputs (after their ReLU),
- * 8 / 9 = the two colour layers' (width 256 / 128), 10 = the raw density (width 1).  Tests hand their signs to the float64 restatement, so
+ * 8 / 9 = the two colour layers' (width 256 / 128), 10 = the raw density (width 1), 11 = the raw colour (width 3).  Tests hand their signs to the float64 restatement, so
  * that its autograd follows the ReLU branches the float32 forward took (a pre-activation within rounding of zero can fall either way).
  * 20-27 = the GRADIENTS the last step kept at the trunk layers' outputs (behind their ReLU: what the layer's weight gradient contracts
- * with), 28 = at the first colour layer's output, 29 = at the feature layer's (all width 256): tests compare them row by row. */
+ * with), 28 = at the first colour layer's output, 29 = at the feature layer's (all width 256): tests compare them row by row.
+ * 30 = the composite's adjoint (width 4): dL/d raw colour, dL/d raw density per sample, where the way back starts. */
 int ntx_trainer_activation(ntx_trainer *t, int layer, int64_t n_samples_total, float *out_host);
 /* Forward (Renderer.__call__, renderer.py:47-213 -- a ray whose tnear_far is inf, i.e. that misses the proxy, stays in the batch and predicts
  * 0 / the background with alpha 0 as the reference's filter-and-scatter makes it, :58-86 -- : sample depths by ntx_sample_depths -- NTX_FLAG_PERTURB /

@@ -428,14 +428,17 @@ __global__ __launch_bounds__(256) void composite_loss_kernel(CompositeArgs a) {
     const int S = a.S;
     const float *sg = a.sigma + (size_t)ray * S, *ds = a.dists + (size_t)ray * S, *rr = a.raw_rgb + (size_t)ray * S * 3;
     const float *nz = a.noise ? a.noise + (size_t)ray * S : nullptr;
-    float *al = sh_a[wave], *T = sh_T[wave];
-    for (int s = lane; s < S; s += 64) { const float v = nz ? sg[s] + nz[s] : sg[s]; const float r = v > 0.0f ? v : 0.0f; al[s] = 1.0f - expf(-r * ds[s]); }    // :190-195
+    // el[s] = exp(-relu(sigma) dist): a_s = 1 - el[s] (:195), and the factor of the running product, (1 - a_s) + 1e-10 (:198), is taken as
+    // el[s] + 1e-10 -- the value of the reference's expression without the float32 round trip through 1 - (1 - e), which on a saturated sample
+    // (e ~ 1e-6) leaves 1 - a with two digits: the ray's transmittance, and with it every gradient behind the sample, would carry that error
+    float *el = sh_a[wave], *T = sh_T[wave];
+    for (int s = lane; s < S; s += 64) { const float v = nz ? sg[s] + nz[s] : sg[s]; const float r = v > 0.0f ? v : 0.0f; el[s] = expf(-r * ds[s]); }    // :190-195
     __builtin_amdgcn_wave_barrier();
     // exclusive running product of (1 - a) + 1e-10, sequential like tf.math.cumprod (:198): chunks of 64 with a carry
     float carry = 1.0f;
     for (int s0 = 0; s0 < S; s0 += 64) {
         const int s = s0 + lane;
-        float f = s < S ? (1.0f - al[s]) + 1e-10f : 1.0f, incl = f;
+        float f = s < S ? el[s] + 1e-10f : 1.0f, incl = f;
         for (int o = 1; o < 64; o <<= 1) { const float w = __shfl_up(incl, o); if (lane >= o) incl *= w; }
         float excl = __shfl_up(incl, 1);
         if (lane == 0) excl = 1.0f;
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256) void composite_loss_kernel(CompositeArgs a) {
     __builtin_amdgcn_wave_barrier();
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, A = 0.0f;
     for (int s = lane; s < S; s += 64) {
-        const float w = al[s] * T[s];
+        const float w = (1.0f - el[s]) * T[s];
         c0 += w * rgb_of(rr[3 * s], a.map_exr); c1 += w * rgb_of(rr[3 * s + 1], a.map_exr); c2 += w * rgb_of(rr[3 * s + 2], a.map_exr);
         A += w;
         if (a.weights) a.weights[(size_t)ray * S + s] = w;
@@ -467,24 +470,39 @@ __global__ __launch_bounds__(256) void composite_loss_kernel(CompositeArgs a) {
         if (a.kind == NTX_LOSS_ALPHA) { float v; loss_term(a.alpha_loss_fn, a.alpha_true[ray], A, inv_a, v, dA); total += a.gamma * v; dA *= a.gamma; }   // :38
     }
     if (lane == 0) { a.color[3 * ray] = c0; a.color[3 * ray + 1] = c1; a.color[3 * ray + 2] = c2; a.alpha[ray] = A; a.ray_loss[ray] = total; }
-    // adjoint.  C = sum w rgb (+ (1 - A) bkgd), A = sum w, w_i = a_i T_i, T_i = prod_{j<i} ((1 - a_j) + 1e-10):
-    //   g_i = dL/dw_i = dC . rgb_i + dA';   dL/da_i = T_i g_i - (sum_{k>i} g_k w_k) / ((1 - a_i) + 1e-10)
+    // adjoint.  C = sum w rgb (+ (1 - A) bkgd), A = sum w, w_i = a_i T_i, T_i = prod_{j<i} f_j, f_j = (1 - a_j) + 1e-10.  With
+    // dL/dw_k = c_k + dA' (c_k = dC . rgb_k, dA' = dA - dC . bkgd):
+    //     dL/da_i = T_i (dA' Z_i + (c_i - V_i)),
+    //     V_i = sum_{k>i} c_k a_k prod_{i<j<k} f_j   (the colour composited behind sample i, along dC):   V_{i-1} = c_i a_i + f_i V_i,  V_{S-1} = 0
+    //     Z_i = 1 - sum_{k>i} a_k prod_{i<j<k} f_j   (what is left of the ray behind sample i):            Z_{i-1} = f_i Z_i - 1e-10,   Z_{S-1} = 1
+    // Nothing is divided and the opacity term is never formed as a difference of two sums.  tf.math.cumprod's own gradient
+    // (TF 2.4 math_grad.py _CumprodGrad: cumsum(out * grad, reverse) / x) is the same derivative as a quotient by f_i, which on a saturated
+    // sample (f_i -> 1e-10) loses the digits the forward product kept, and "dA' (1 - sum)" loses them again when the ray saturates BEHIND
+    // sample i (round 5's kernel did both: profiles/r05/soak_train_seed3.txt, case 297).
+    // A chunk of 64 samples is a suffix scan of the affine maps X -> b_i + f_i X (composed pairwise), carried from chunk to chunk back to front.
     if (a.composite_bkgd) dA -= (dC[0] * a.bkgd[0] + dC[1] * a.bkgd[1]) + dC[2] * a.bkgd[2];
-    float suffix = 0.0f;                                   // sum of g_k w_k over the samples behind the current chunk
+    float Z_carry = 1.0f, V_carry = 0.0f;                  // Z, V of the last sample of the current chunk (nothing lies behind the ray's end)
     for (int s0 = ((S - 1) / 64) * 64; s0 >= 0; s0 -= 64) {
         const int s = s0 + lane;
-        float gw = 0.0f, g = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f};
+        float cs = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f}, e = 1.0f;
+        float F = 1.0f, Bz = 0.0f, Bv = 0.0f;              // the identity for the lanes past the ray's end
         if (s < S) {
+            e = el[s];
             for (int c = 0; c < 3; ++c) rgb[c] = rgb_of(rr[3 * s + c], a.map_exr);
-            g = ((dC[0] * rgb[0] + dC[1] * rgb[1]) + dC[2] * rgb[2]) + dA;
-            gw = g * (al[s] * T[s]);
+            cs = (dC[0] * rgb[0] + dC[1] * rgb[1]) + dC[2] * rgb[2];
+            F = e + 1e-10f; Bz = -1e-10f; Bv = cs * (1.0f - e);
         }
-        float incl = gw;                                   // inclusive suffix sum inside the chunk
-        for (int o = 1; o < 64; o <<= 1) { const float w = __shfl_down(incl, o); if (lane + o < 64) incl += w; }
-        const float behind = (incl - gw) + suffix;         // strictly behind s
+        // inclusive suffix composition: lane l ends with the maps of samples l .. 63 of the chunk composed, X_{l-1} = B + F X_63
+        for (int o = 1; o < 64; o <<= 1) {
+            const float Fo = __shfl_down(F, o), Bzo = __shfl_down(Bz, o), Bvo = __shfl_down(Bv, o);
+            if (lane + o < 64) { Bz = fmaf(F, Bzo, Bz); Bv = fmaf(F, Bvo, Bv); F *= Fo; }
+        }
+        float Fn = __shfl_down(F, 1), Bzn = __shfl_down(Bz, 1), Bvn = __shfl_down(Bv, 1);   // the lanes strictly behind this one
+        if (lane == 63) { Fn = 1.0f; Bzn = 0.0f; Bvn = 0.0f; }
+        const float Z = fmaf(Fn, Z_carry, Bzn), V = fmaf(Fn, V_carry, Bvn);
         if (s < S) {
-            const float w = al[s] * T[s];
-            const float d_a = T[s] * g - behind / ((1.0f - al[s]) + 1e-10f);
+            const float w = (1.0f - e) * T[s];
+            const float d_a = T[s] * fmaf(dA, Z, cs - V);
             const float sig = nz ? sg[s] + nz[s] : sg[s];
             float gr[4];
             for (int c = 0; c < 3; ++c) {
@@ -492,12 +510,13 @@ __global__ __launch_bounds__(256) void composite_loss_kernel(CompositeArgs a) {
                 const float drgb = a.map_exr ? (raw > 0.0f ? 1.0f : expf(raw)) : rgb[c] * (1.0f - rgb[c]);
                 gr[c] = w * dC[c] * drgb;
             }
-            gr[3] = sig > 0.0f ? d_a * ds[s] * expf(-sig * ds[s]) : 0.0f;
+            gr[3] = sig > 0.0f ? d_a * ds[s] * e : 0.0f;                                       // da/dsigma = dist exp(-sigma dist)
             const long long m = (long long)ray * S + s;
             *reinterpret_cast<f32x4 *>(a.dgrad + 4 * m) = f32x4{gr[0], gr[1], gr[2], gr[3]};
             for (int r = 0; r < 4; ++r) a.dhead[dhead_at(m, r)] = gr[r];
         }
-        suffix += __shfl(incl, 0);
+        const float F0 = __shfl(F, 0);
+        Z_carry = fmaf(F0, Z_carry, __shfl(Bz, 0)); V_carry = fmaf(F0, V_carry, __shfl(Bv, 0));
     }
 }
 // the loss: the rays' terms added up by one workgroup in a fixed order
@@ -831,10 +850,15 @@ int ntx_trainer_activation(ntx_trainer *t, int layer, int64_t n_samples_total, f
     else if (layer >= 20 && layer < 28) src = gout(10 - (layer - 20));
     else if (layer == 28) src = gout(1);
     else if (layer == 29) src = gout(2);
-    else return ntx_set_error(NTX_E_INVALID, "layer %d (0-7 trunk, 8 / 9 the colour layers, 10 the density; 20-29 the kept gradients)", layer);
+    else if (layer == 11) src = t->raw_rgb;
+    else if (layer == 30) src = t->dgrad;
+    else return ntx_set_error(NTX_E_INVALID, "layer %d (0-7 trunk, 8 / 9 the colour layers, 10 the density, 11 the raw colour; 20-29 the kept gradients, 30 the composite's adjoint)", layer);
     TRAIN_TRY(hipSetDevice(t->device));
     TRAIN_TRY(hipDeviceSynchronize());
-    if (layer == 10) { TRAIN_TRY(hipMemcpy(out_host, src, (size_t)n_samples_total * sizeof(float), hipMemcpyDeviceToHost)); return NTX_OK; }
+    if (layer == 10 || layer == 11 || layer == 30) {
+        const size_t width = layer == 10 ? 1 : (layer == 11 ? 3 : 4);
+        TRAIN_TRY(hipMemcpy(out_host, src, (size_t)n_samples_total * width * sizeof(float), hipMemcpyDeviceToHost)); return NTX_OK;
+    }
     // O layout -> [sample][feature]
     const long long nb = (n_samples_total + 31) / 32;
     std::vector<float> tmp((size_t)nb * tiles * 1024);

@@ -107,13 +107,14 @@ class Trainer:
         return self._vector(_lib.TRAINER_ADAM_M), self._vector(_lib.TRAINER_ADAM_V)
 
     def activation(self, layer: int, n_samples_total: int):
-        """What the last step kept of layer 0-7 (trunk), 8 / 9 (colour layers), 10 (raw density), or -- 20-27, 28, 29 -- the gradient at the
-        outputs of the trunk layers, the first colour layer, the feature layer: [n_samples_total, width] float32 (tests)."""
+        """What the last step kept of layer 0-7 (trunk), 8 / 9 (colour layers), 10 (raw density), 11 (raw colour), or -- 20-27, 28, 29 -- the
+        gradient at the outputs of the trunk layers, the first colour layer, the feature layer, 30 the composite's adjoint (dL/d raw colour,
+        dL/d raw density): [n_samples_total, width] float32 (tests)."""
         import numpy as np
-        width = 256 if (layer < 9 or layer >= 20) else (128 if layer == 9 else 1)
+        width = {9: 128, 10: 1, 11: 3, 30: 4}.get(int(layer), 256)
         out = np.empty((int(n_samples_total), width), np.float32)
         _lib.check(_lib.lib.ntx_trainer_activation(self._h, int(layer), int(n_samples_total), out.ctypes.data_as(C.POINTER(C.c_float))))
-        if self._pad is not None and width > 1:                                 # the narrow network's own columns
+        if self._pad is not None and width > 4:                                 # the narrow network's own columns
             out = np.ascontiguousarray(out[:, :self.model.width // (2 if layer == 9 else 1)])
         return out
 

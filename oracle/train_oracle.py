@@ -87,6 +87,11 @@ def render(w, spec, rays_o, rays_d, z, parameters, cone_scale, blur_idx=None, ma
     else:
         color, alpha = model_forward_masked(w, spec, pos, dirs, params, masks)
     color = color.reshape(n, S, 3); alpha = alpha.reshape(n, S)
+    return composite(color, alpha, z, rays_d, map_exr, composite_bkgd, bkgd, sigma_mask, noise)
+
+
+def composite(color, alpha, z, rays_d, map_exr=False, composite_bkgd=False, bkgd=(1., 1., 1.), sigma_mask=None, noise=None):
+    """map_model_output (renderer.py:170-213) on raw network outputs color [n, S, 3], alpha [n, S]."""
     if noise is not None:                                                                   # renderer.py:190-192: [n, S], raw_noise_std * N(0,1)
         alpha = alpha + noise
     dists = z[:, 1:] - z[:, :-1]
@@ -99,6 +104,19 @@ def render(w, spec, rays_o, rays_d, z, parameters, cone_scale, blur_idx=None, ma
     if composite_bkgd:
         c = c + (1. - a[..., None]) * torch.as_tensor(bkgd, dtype=c.dtype)
     return c, a
+
+
+def composite_gradients(raw_rgb, sigma, z, rays_d, color_true, alpha_true, loss, map_exr=False, composite_bkgd=False, bkgd=(1., 1., 1.), noise=None,
+                        dtype=torch.float64):
+    """The composite and the loss alone under autograd: (loss, color_pred, alpha_pred, dL/d raw_rgb [n, S, 3], dL/d sigma [n, S]) for GIVEN raw
+    network outputs -- what a hand-written adjoint of renderer.py:170-213 + loss.py is compared with, apart from the network's own rounding."""
+    t_ = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=dtype)
+    rgb = torch.tensor(np.asarray(raw_rgb), dtype=dtype, requires_grad=True); sg = torch.tensor(np.asarray(sigma), dtype=dtype, requires_grad=True)
+    c, a = composite(rgb, sg, t_(z), t_(rays_d), map_exr, composite_bkgd, bkgd, None, t_(noise))
+    kw = {k: v for k, v in loss.items() if k != "kind"}
+    val = nerf_loss(t_(color_true), c, **kw) if loss["kind"] == "nerf" else alpha_loss(t_(color_true), t_(alpha_true), c, a, **kw)
+    val.backward()
+    return float(val.detach()), c.detach().numpy(), a.detach().numpy(), rgb.grad.numpy(), sg.grad.numpy()
 
 
 def step_gradients(w_np, spec, rays_o, rays_d, z, parameters, cone_scale, color_true, alpha_true, loss, blur_idx=None, map_exr=False,

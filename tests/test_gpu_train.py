@@ -246,6 +246,103 @@ def check_gradients(fam, npar, blur, loss_name, bkgd, perturb, n, S, floor_check
         assert rel_linf(got[sl], free[sl]) <= max(1e-4, 4 * floor), (name, rel_linf(got[sl], free[sl]), floor)
 
 
+def step_errors(model, spec, wts, fam, n, S, loss_name, perturb=False, bkgd=False, noise_std=0.0, blur=None, seed=11, batch_seed=3, miss=None, cap=None, floors=False):
+    """One `gradients_step` of a batch described by its knobs against float64 autograd branched like the float32 forward pass: relative
+    error of the loss, rel-Linf of the predictions and of every layer's gradient (relative to the layer's largest entry; a layer that
+    vanishes beside the others -- 1e-13 against 1e-3 -- to 1e-6 of the batch's largest).  `floors`: the same restatement under float32 torch
+    autograd against the float64 one, per layer (what float32 itself can do on this batch).  tools/dev/soak_train.py draws the knobs at random."""
+    from nerf_tex_amd.train import Trainer
+    ro, rd, t, cone, params, color, alpha = batch(batch_seed, n, S, sum(spec.n_parameters), fam)
+    miss = np.zeros(n, bool) if miss is None else np.asarray(miss, bool)
+    t = t.copy(); t[miss] = np.inf
+    okw, loss = make_loss(loss_name)
+    tr = Trainer(model, max_rays=cap or n, n_samples=S, perturb=perturb, blur_idx=blur, raw_noise_std=noise_std)
+    val, cp, ap_ = tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss, composite_bkgd=bkgd, bkgd_color=(1., .5, .25), seed=seed)
+    torch.cuda.synchronize()
+    M = n * S
+    tf = np.where(np.isfinite(t), t, 0).astype(np.float32)
+    z = orc.z_values_perturbed(tf, S, seed, np.float32) if perturb else orc.z_values(tf, S, np.float32)
+    z = z.copy(); z[miss] = np.inf
+    noise = noise_std * orc.noise_normals(n, S, seed, dtype=np.float32).astype(np.float64) if noise_std > 0 else None
+    masks = [(tr.activation(k, M) > 0).astype(np.float64) for k in list(range(8)) + [8, 9]]
+    sg = tr.activation(10, M).reshape(n, S)
+    sigma_mask = ((sg + (0 if noise is None else noise.astype(np.float32))) > 0).astype(np.float64)
+    kw = dict(masks=masks, sigma_mask=sigma_mask, blur_idx=blur, composite_bkgd=bkgd, bkgd=(1., .5, .25), noise=noise)
+    want_val, wc, wa, wg = tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, okw, **kw)
+    got, flat = tr.gradients(), np.concatenate([g.ravel() for g in wg])
+    gmax = float(np.abs(flat).max())
+    lerr = lambda sl: float(np.abs(got[sl] - flat[sl]).max() / max(float(np.abs(flat[sl]).max()), 1e-6 * gmax, 1e-30))
+    want_pred = np.concatenate([wc, wa[:, None]], -1)
+    out = dict(e_loss=abs(float(val.item()) - want_val) / (abs(want_val) + 1e-7),
+               e_pred=orc.rel_linf(np.concatenate([cp.cpu().numpy(), ap_.cpu().numpy()[:, None]], -1), want_pred),
+               layers={nm: lerr(sl) for nm, sl in layer_slices(spec)} if gmax > 0 else {"all": float(np.abs(got).max())},
+               finite=bool(np.isfinite(got).all()), got=got, want=flat, gmax=gmax, alpha_pred=wa, sigma=sg, z=z)
+    out["e_grad"] = max(out["layers"].values())
+    # the composite's adjoint on its own: dL/d raw colour, dL/d raw density as the step left them against float64 autograd of the composite and
+    # the loss on the step's OWN float32 network outputs (the network's rounding, which exp(-sigma dist) amplifies by sigma dist, stays out)
+    hit = ~miss
+    raw, dg = tr.activation(11, M).reshape(n, S, 3), tr.activation(30, M).reshape(n, S, 4)
+    if hit.any():
+        # the loss is a mean over ALL rays of the batch: the hit rays' share of it, scaled back
+        sub = lambda x: None if x is None else np.asarray(x)[hit]
+        _, _, _, d_rgb, d_sg = tro.composite_gradients(raw[hit], sg[hit], z[hit], rd[hit], color[hit], alpha[hit], okw, composite_bkgd=bkgd, bkgd=(1., .5, .25), noise=sub(noise))
+        scale = hit.sum() / n
+        # (the ReLU of the density: autograd's own branch on the same float32 value, so the patterns agree)
+        out["e_dsigma"] = rel_linf(dg[hit][..., 3], d_sg * scale) if np.abs(d_sg).max() > 0 else float(np.abs(dg[hit][..., 3]).max())
+        out["e_drgb"] = rel_linf(dg[hit][..., :3], d_rgb * scale) if np.abs(d_rgb).max() > 0 else float(np.abs(dg[hit][..., :3]).max())
+        out["dsigma_max"] = float(np.abs(d_sg).max() * scale)
+    if floors:
+        _, fc, fa, fg = tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, okw, dtype=torch.float32, **kw)
+        f32 = np.concatenate([g.ravel() for g in fg])
+        out["floor_pred"] = orc.rel_linf(np.concatenate([fc, fa[:, None]], -1), want_pred)
+        out["floors"] = {nm: rel_linf(f32[sl], flat[sl]) for nm, sl in layer_slices(spec)}
+    return out
+
+
+def test_saturated_rays_of_soak_seed_3_case_297():
+    """The batch tools/dev/soak_train.py --seed 3 drew as case 297 (profiles/r05/soak_train_seed3.txt): grass_filtered, 2 rays x 5 samples, both
+    saturated (alpha_pred 1.0 and 0.9999975) against alpha targets of 0, alpha_mse_soft over a background, jittered depths.  The whole gradient
+    hangs on a transmittance of 2.5e-6.  Round 5's composite adjoint divided a suffix sum by (1 - a_i) + 1e-10 and was 4.6e-3 .. 7.2e-3 per
+    layer from float64 here; the division-free reverse scan (csrc/ntx_train.hip composite_loss_kernel) is held to the plain 1e-4."""
+    model, spec, wts = make_model((2, 3), dense_media=True)
+    e = step_errors(model, spec, wts, "grass_filtered", 2, 5, "alpha_mse_soft", perturb=True, bkgd=True, seed=840038945, batch_seed=996772, cap=45)
+    assert e["alpha_pred"].min() > 0.99999, e["alpha_pred"]                      # the case is the saturated one
+    assert e["finite"] and e["e_loss"] <= 1e-4 and e["e_pred"] <= 1e-4
+    # the adjoint itself, on the step's own sigma and raw colour: float32 rounding of a five-term scan
+    assert e["e_dsigma"] <= 2e-6 and e["e_drgb"] <= 2e-6, (e["e_dsigma"], e["e_drgb"])
+    # end to end the float32 NETWORK's rounding of sigma (1e-5 relative, the MLP's own tolerance) reaches the transmittance multiplied by
+    # sigma * dist = 13 on these rays: 1.25e-4 on every layer alike, whatever the adjoint does.  The gate: twice the plain one, and a quarter
+    # of what float32 autograd of the restatement itself makes of this batch (0.7e-3 .. 1.2e-3)
+    f = step_errors(model, spec, wts, "grass_filtered", 2, 5, "alpha_mse_soft", perturb=True, bkgd=True, seed=840038945, batch_seed=996772, cap=45, floors=True)
+    assert e["e_grad"] <= 2e-4, {k: v for k, v in e["layers"].items() if v > 1e-5}
+    assert all(v <= 0.25 * f["floors"][k] for k, v in e["layers"].items() if f["floors"][k] > 4e-4), (e["layers"], f["floors"])
+
+
+@pytest.mark.parametrize("n,S,loss_name,bkgd,shift", [(2, 5, "alpha_mse_soft", True, 12.0), (7, 6, "alpha_smape", False, 20.0), (64, 9, "nerf_mse", True, 15.0),
+                                                      (33, 70, "alpha_mse_soft", True, 10.0), (128, 130, "alpha_smape", False, 10.0)])
+def test_saturated_rays_keep_their_gradient(n, S, loss_name, bkgd, shift):
+    """A family of saturated batches: the density head's bias raised until most rays end opaque (alpha_pred = 1 to five digits or more) -- by
+    one to three samples with sigma * dist of 10 .. 23 where a ray has a handful of coarse steps (a_i = 1 to float32: behind them the ray's
+    transmittance is down at the 1e-10 of renderer.py:198), by accumulation where it has 70 or 130 (the scan's 64-lane chunks and their carry) --,
+    with and without the background term.  The composite's adjoint on the step's own outputs within float32 rounding of float64 autograd,
+    every layer's gradient end to end at 1e-4 (+ the network's own rounding of sigma through the exponential).  (Raised, not scaled: a head scaled x8 has sigma = -1000 .. 140 and the float32
+    network's 1e-5 of that is 1e-3 of every alpha -- the batch would test the network's rounding, not the composite.)"""
+    model, spec, wts = make_model((1, 6), dense_media=True)
+    blob = model.get_blob().copy()
+    blob[dict(layer_slices(spec))["alpha.bias"]] += np.float32(shift)
+    model.set_blob(blob); wts = orc.split_blob(spec, blob)
+    e = step_errors(model, spec, wts, "carpet", n, S, loss_name, perturb=True, bkgd=bkgd, seed=77, batch_seed=n + S)
+    assert (e["alpha_pred"] > 0.99999).sum() >= max(1, n // 4), e["alpha_pred"]         # the batch is what its name says
+    assert e["finite"] and e["gmax"] > 1e-8
+    assert e["e_loss"] <= 1e-5 and e["e_pred"] <= 1e-5
+    assert e["e_dsigma"] <= 5e-5 and e["e_drgb"] <= 5e-6, (e["e_dsigma"], e["e_drgb"])
+    # end to end: the plain 1e-4, plus what the float32 NETWORK's rounding of sigma (1e-5 relative: its own tolerance, tests/test_gpu_parity.py)
+    # becomes in exp(-sigma dist) -- 1e-5 * sigma * dist, on every layer alike and whatever the adjoint does; it shows where a batch's whole
+    # gradient hangs on one saturated sample's transmittance (the two-ray case: 1.4e-4 at sigma * dist = 12)
+    dist = np.diff(e["z"], axis=-1); dist = np.concatenate([dist, dist[:, -1:]], -1)
+    assert e["e_grad"] <= 1e-4 + 1e-5 * float((np.maximum(e["sigma"], 0) * dist).max()), {k: v for k, v in e["layers"].items() if v > 1e-5}
+
+
 def test_training_step_is_bit_reproducible_and_adam_matches_its_restatement():
     """Two trainers from the same weights take the same step bit for bit (weight gradients are summed over the samples in a fixed order);
     Adam under ExponentialDecay (train.py:49-52) within float32 rounding of the float64 restatement, over three iterations."""

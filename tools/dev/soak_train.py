@@ -8,14 +8,13 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from tests.test_gpu_train import make_model, batch, make_loss, layer_slices, rel_linf, orc, tro   # noqa: E402
-from nerf_tex_amd.train import Trainer                                                            # noqa: E402
+from tests.test_gpu_train import make_model, step_errors                                           # noqa: E402
 
 ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=150); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--only", type=int, nargs="*", default=None)
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 FAMS = [("carpet", (1, 6)), ("grass", (1, 4)), ("fur", (1, 4)), ("grass_filtered", (2, 3))]
-worst, t0, fails = {"loss": 0.0, "pred": 0.0, "grad": 0.0}, time.time(), []
+worst, t0, fails, waived = {"loss": 0.0, "pred": 0.0, "grad": 0.0}, time.time(), [], 0
 models = {}
 for case in range(a.cases):
     fam, npar = FAMS[rng.integers(len(FAMS))]
@@ -29,56 +28,33 @@ for case in range(a.cases):
     noise_std = float(rng.choice([0.0, 0.0, 0.1, 0.5]))
     blur = None if rng.integers(2) else int(rng.integers(sum(npar)))
     seed = int(rng.integers(1 << 30))
-    ro, rd, t, cone, params, color, alpha = batch(int(rng.integers(1 << 20)), n, S, sum(npar), fam)
+    batch_seed = int(rng.integers(1 << 20))
     miss = rng.uniform(size=n) < float(rng.choice([0.0, 0.0, 0.05, 0.3]))
-    t = t.copy(); t[miss] = np.inf
-    okw, loss = make_loss(loss_name)
     cap = n + int(rng.integers(0, 50))
     if a.only is not None and case not in a.only: continue
-    tr = Trainer(model, max_rays=cap, n_samples=S, perturb=perturb, blur_idx=blur, raw_noise_std=noise_std)
-    val, cp, ap_ = tr.gradients_step(ro, rd, t, params, cone, color, alpha, loss, composite_bkgd=bkgd, bkgd_color=(1., .5, .25), seed=seed)
-    torch.cuda.synchronize()
+    knobs = dict(perturb=perturb, bkgd=bkgd, noise_std=noise_std, blur=blur, seed=seed, batch_seed=batch_seed, miss=miss, cap=cap)
+    e = step_errors(model, spec, wts, fam, n, S, loss_name, **knobs)
     M = n * S
-    tf = np.where(np.isfinite(t), t, 0).astype(np.float32)
-    z = orc.z_values_perturbed(tf, S, seed, np.float32) if perturb else orc.z_values(tf, S, np.float32)
-    z = z.copy(); z[miss] = np.inf
-    noise = noise_std * orc.noise_normals(n, S, seed, dtype=np.float32).astype(np.float64) if noise_std > 0 else None
-    masks = [(tr.activation(k, M) > 0).astype(np.float64) for k in list(range(8)) + [8, 9]]
-    sg = tr.activation(10, M).reshape(n, S)
-    sigma_mask = ((sg + (0 if noise is None else noise.astype(np.float32))) > 0).astype(np.float64)
-    want_val, wc, wa, wg = tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, okw, masks=masks, sigma_mask=sigma_mask, blur_idx=blur,
-                                              composite_bkgd=bkgd, bkgd=(1., .5, .25), noise=noise)
     tiny = 5.0 if M < 100 else 1.0
-    e_loss = abs(float(val.item()) - want_val) / (abs(want_val) + 1e-7)
-    e_pred = orc.rel_linf(np.concatenate([cp.cpu().numpy(), ap_.cpu().numpy()[:, None]], -1), np.concatenate([wc, wa[:, None]], -1))
-    got, flat = tr.gradients(), np.concatenate([g.ravel() for g in wg])
-    # per layer, relative to the layer's largest entry -- but a layer whose whole gradient vanishes beside the others' (the density head of a
-    # batch without density: 1e-13 against 1e-3) is held to the batch's scale: float32 sums cannot resolve it
-    gmax = float(np.abs(flat).max())
-    lerr = lambda sl: float(np.abs(got[sl] - flat[sl]).max() / max(float(np.abs(flat[sl]).max()), 1e-6 * gmax, 1e-30))
-    e_grad = max(lerr(sl) for _, sl in layer_slices(spec)) if gmax > 0 else float(np.abs(got).max())
-    ok = e_loss <= (1e-5 if M >= 1000 else 1e-4) * tiny and e_pred <= 1e-4 * tiny and e_grad <= 1e-4 * tiny and bool(np.isfinite(got).all())
-    floor_pred = floor_grad = None
-    if not ok and np.isfinite(got).all():
+    e_loss, e_pred, e_grad = e["e_loss"], e["e_pred"], e["e_grad"]
+    ok = e_loss <= (1e-5 if M >= 1000 else 1e-4) * tiny and e_pred <= 1e-4 * tiny and e_grad <= 1e-4 * tiny and e["finite"]
+    if not ok and e["finite"]:
         # a case beyond the gate: is it float32 itself?  The same restatement, same branches, under float32 torch autograd is the floor of this
         # comparison (few coarse steps: 1 - exp(-sigma dist) at dist ~ 1 carries sigma's rounding far); the step has to stay within 4 floors
-        _, fc, fa, fg = tro.step_gradients(wts, spec, ro, rd, z, params, cone, color, alpha, okw, masks=masks, sigma_mask=sigma_mask, blur_idx=blur,
-                                           composite_bkgd=bkgd, bkgd=(1., .5, .25), noise=noise, dtype=torch.float32)
-        f32 = np.concatenate([g.ravel() for g in fg])
-        floor_pred = orc.rel_linf(np.concatenate([fc, fa[:, None]], -1), np.concatenate([wc, wa[:, None]], -1))
-        floors = {nm: rel_linf(f32[sl], flat[sl]) for nm, sl in layer_slices(spec)}
-        floor_grad = max(floors.values())
-        ok = e_pred <= max(1e-4 * tiny, 4 * floor_pred) and all(lerr(sl) <= max(1e-4 * tiny, 4 * floors[nm]) for nm, sl in layer_slices(spec)) \
+        f = step_errors(model, spec, wts, fam, n, S, loss_name, floors=True, **knobs)
+        floor_pred, floors = f["floor_pred"], f["floors"]
+        ok = e_pred <= max(1e-4 * tiny, 4 * floor_pred) and all(v <= max(1e-4 * tiny, 4 * floors[nm]) for nm, v in e["layers"].items()) \
             and e_loss <= max(1e-4, 4 * floor_pred)
-        if ok: print("beyond the gate, within 4 float32 floors:", json.dumps(dict(case=case, n=n, S=S, e_pred=e_pred, floor_pred=floor_pred, e_grad=e_grad, floor_grad=floor_grad)), flush=True)
+        if ok:
+            waived += 1
+            print("beyond the gate, within 4 float32 floors:", json.dumps(dict(case=case, n=n, S=S, e_pred=e_pred, floor_pred=floor_pred, e_grad=e_grad, floor_grad=max(floors.values()))), flush=True)
     desc = dict(case=case, fam=fam, n=n, S=S, loss=loss_name, perturb=perturb, bkgd=bkgd, noise=noise_std, blur=blur, missing=int(miss.sum()), e_loss=e_loss, e_pred=e_pred, e_grad=e_grad)
     if not ok:
         fails.append(desc); print("FAIL", json.dumps(desc), flush=True)
-        for nm, sl in layer_slices(spec):
-            if lerr(sl) > 1e-4: print("    ", nm, "max |want| %.3e max |got - want| %.3e" % (np.abs(flat[sl]).max(), np.abs(got[sl] - flat[sl]).max()), flush=True)
+        for nm, v in e["layers"].items():
+            if v > 1e-4: print("    ", nm, "rel-Linf %.3e" % v, flush=True)
     if M >= 100:
         worst = {"loss": max(worst["loss"], e_loss), "pred": max(worst["pred"], e_pred), "grad": max(worst["grad"], e_grad)}
-    del tr
-print(json.dumps({"cases": a.cases, "seed": a.seed, "failed": len(fails), "worst_rel_loss": worst["loss"], "worst_rel_linf_predictions": worst["pred"],
-                  "worst_rel_linf_layer_gradient": worst["grad"], "seconds": round(time.time() - t0, 1)}))
+print(json.dumps({"cases": a.cases, "seed": a.seed, "failed": len(fails), "waived_within_4_float32_floors": waived, "worst_rel_loss": worst["loss"],
+                  "worst_rel_linf_predictions": worst["pred"], "worst_rel_linf_layer_gradient": worst["grad"], "seconds": round(time.time() - t0, 1)}))
 sys.exit(1 if fails else 0)
