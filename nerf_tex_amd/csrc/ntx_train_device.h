@@ -65,8 +65,17 @@ struct WRingT {
 };
 typedef WRingT<RING> WRing;            // the forward chain: as the render kernels (its registers are spoken for)
 constexpr int DX_RING = 16;            // the chain back has registers to spare: twice the depth rides out an L2 miss of the weight stream
+// (development probes, tools/dev/r6_variant.sh + r6_steady_pmc.sh: NTX_X_WSMALL keeps the weight stream inside its first 64 KB -- always in
+// L2 --, NTX_X_NOWLOAD never reloads the ring, NTX_X_NOSTORE drops the activations' stores, NTX_X_NOBITS the masks', NTX_X_DWSMALL / _DWNOLOAD
+// the same for the weight gradients' operands: wrong results, the time of what is left)
 template <class WR>
 TRN_DEV f32x4 wr_load(const WR &w, uint32_t byte_off) {
+#ifdef NTX_X_WSMALL
+    byte_off &= 0xffffu;
+#endif
+#ifdef NTX_X_NOWLOAD
+    if (byte_off >= (uint32_t)WR::DEPTH * 1024u) return w.r[(byte_off >> 10) % WR::DEPTH];
+#endif
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rsrc, w.voff, byte_off, 0));
 }
 
@@ -267,11 +276,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         auto leaves_to = [&](int idx, int tiles) { rs_out = make_rsrc(a.act + (size_t)idx * a.act_stride + (size_t)blk * tiles * 1024, (long long)tiles * 4096); };
         auto leave = [&](auto V) {
             constexpr int v = V;
+#ifndef NTX_X_NOSTORE
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hin[v]), rs_out, lane_o, o_value_bytes(v), STORE_NT);
+#endif
         };
         auto bits_leave = [&](int idx, const u32x4 &bw) {
+#ifndef NTX_X_NOBITS
             const __amdgpu_buffer_rsrc_t rb = make_rsrc(a.bits + (size_t)idx * a.bits_stride + (size_t)blk * 256, 1024);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, bw), rb, lane16, 0, 0);
+#endif
         };
         // ---- trunk layer 0: pos_map -> 256 (model.py:104-106)
         // (an accumulator set starts from its layer's bias: LDS reads, as soon as the set is free -- behind the conversion that drained it)
@@ -500,6 +513,12 @@ TRN_DEV void dw_piece(const DwWave &tg, float *slot, int blk0, int blk1, int lan
         f32x4 xa[2][NA][2], xb[2][NB][2];                  // two halves of a block in flight: [half][tile][record of the half]
         auto fetch = [&](auto BUF, int i) {                // half BUF of block blk0 + i
             constexpr int buf = BUF;
+#ifdef NTX_X_DWSMALL
+            i &= 3;
+#endif
+#ifdef NTX_X_DWNOLOAD
+            if (i > 0) return;
+#endif
             const uint32_t oa = (uint32_t)i * stepA + offA + (uint32_t)buf * 2048u, ob = (uint32_t)i * stepB + offB + (uint32_t)buf * 2048u;
             static_for<NA>([&](auto Ai) { static_for<2>([&](auto Q) {
                 xa[buf][Ai][Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voff, oa + (uint32_t)(decltype(Ai)::value * 4 + decltype(Q)::value) * 1024u, 0)); }); });
