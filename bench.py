@@ -278,7 +278,15 @@ def bench_instanced(args) -> None:
                      "kernel_ms": kernel_ms}}), flush=True)
 
 
-def bench_train_step(args) -> None:
+def train_needed_macs(model) -> int:
+    """MACs per ray-sample a training step NEEDS: the forward pass, the weight gradients (one contraction of the forward's size per layer) and
+    the gradients at the layers' INPUTS -- of which the encoded inputs' are not wanted: layer 0's (pos_map rows), the skip's pos_map columns and
+    the colour layer's dir_map columns (model.py:104-115; 256 outputs each).  carpet: 2 x 680 832 + 623 232."""
+    m = model.macs_per_sample()
+    return 2 * m + (m - (2 * model.pos_map_dim + model.dir_map_dim) * 256)
+
+
+def bench_train_step(args, emit: bool = True, data_side: bool = True, parity_rays: int = 64):
     """`--workload carpet_train_step`: one iteration of the reference's training loop (network/train.py:61-67) at the batch of
     configs/config_carpet_train.py -- 4 images x 256 rays x 256 samples = 262 144 ray-samples (:23, 33, 101), perturb=True, AlphaLoss with smape /
     mse (:95-99), Adam under ExponentialDecay (lrate 5e-4, lrate_decay 500) -- forward with every activation kept, loss, backward, optimiser
@@ -297,9 +305,11 @@ def bench_train_step(args) -> None:
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    sys.stdout.flush()
-    json_out = os.fdopen(os.dup(1), "w")                     # RCCL prints its banner on stdout: the line goes to the original one
-    os.dup2(2, 1)
+    json_out = None
+    if emit:
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")                 # RCCL prints its banner on stdout: the line goes to the original one
+        os.dup2(2, 1)
     share_gpu = world > 1 and os.environ.get("NTX_BENCH_SHARE_GPU") == "1"          # development: all ranks on GPU 0, gloo (see main)
     if share_gpu:
         local_rank = 0
@@ -374,7 +384,9 @@ def bench_train_step(args) -> None:
         if rank != 0:
             return
     flops_fwd = 2 * model.macs_per_sample()
-    achieved = 3 * flops_fwd * n * S / (step_ms * 1e-3) / 1e12
+    flops_needed = 2 * train_needed_macs(model)
+    achieved = flops_needed * n * S / (step_ms * 1e-3) / 1e12
+    achieved_3x = 3 * flops_fwd * n * S / (step_ms * 1e-3) / 1e12
     line = {"metric": "ray-samples/sec through one training step (forward + loss + backward + Adam) at 4 x 256 rays x 256 samples",
             "value": world * n * S * args.steps / elapsed, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -382,7 +394,7 @@ def bench_train_step(args) -> None:
                                    f"n_parameters={list(fam['n_parameters'])}, perturb=True" + (f", blur_idx={fam['blur_idx']}" if fam["blur_idx"] is not None else "")
                                    + (f", raw_noise_std={noise_std}" if noise_std else "") + ", AlphaLoss(smape, mse), Adam + ExponentialDecay(5e-4, 5e5 steps, 0.1); "
                                    "seeded weights and targets, batch resident in HBM", "rays": n, "samples_per_ray": S, "flops_per_sample_forward": flops_fwd,
-                       "loss_after": float(val.item())},
+                       "flops_per_sample_step": flops_needed, "loss_after": float(val.item())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                          **(train_step_traffic() if fam_name == "carpet" else {"traffic": None, "traffic_source": None}),     # (the counter summary is the carpet step's)
                          "algorithmic_bytes": train_step_algorithmic_bytes(model, n * S),
@@ -390,8 +402,47 @@ def bench_train_step(args) -> None:
                                                    "gradients, the encoded inputs written in both orders and read by the chain and by the weight gradients (DESIGN section 10)",
                          "kernel": "ntx_train::fwd_chain_kernel + dx_chain_kernel (the network forward and back with a block's activations in registers from layer to layer) "
                                    "+ dw_kernel (dW of every layer from the operand-order stores, persistent workgroups with an equal share each)", "kernel_ms": step_ms,
-                         "what": "3 x forward FLOPs (2 MACs per weight per sample) over the WHOLE step's HIP-event time: encoders, heads, composite, loss and Adam included"}}
-    if world == 1 and fam_name == "carpet":
+                         "what": "the FLOPs a step needs (2 MACs per weight per sample forward, the same for the weight gradients, and the gradients at the layers' "
+                                 "inputs except the encoded ones': 2 x forward + forward less the pos_map / dir_map rows) over the WHOLE step's HIP-event time: "
+                                 "encoders, heads, composite, loss and Adam included",
+                         "frac_3x_forward": achieved_3x / F32_MFMA_PEAK_TFLOPS,
+                         "frac_3x_forward_what": "the same time against 3 x the forward's FLOPs (rounds 4 and 5 quoted this convention: it counts input gradients nobody needs)"}}
+    if world == 1 and parity_rays:
+        # the step against the float64 restatement, outside the timed region: the first `parity_rays` rays of the batch as a batch of their own,
+        # from the weights the timed steps left -- loss, predictions, every layer's gradient (the oracle follows the float32 ReLU branches)
+        from oracle import nerftex_oracle as orc
+        from oracle import train_oracle as tro
+        t1 = time.perf_counter()
+        nb = parity_rays
+        spec = orc.ModelSpec(kind="ParamNerf", n_parameters=tuple(fam["n_parameters"]))
+        tr.perturb = False
+        pv, pc, pa = tr.gradients_step(*[x[:nb].contiguous() for x in batch], loss, seed=1)
+        torch.cuda.synchronize()
+        got = tr.gradients()
+        wts = orc.split_blob(spec, tr.weights())
+        z = orc.z_values(t[:nb], S, np.float32)
+        M = nb * S
+        masks = [(tr.activation(k, M) > 0) for k in list(range(8)) + [8, 9]]
+        noise = noise_std * orc.noise_normals(nb, S, 1, dtype=np.float32).astype(np.float64) if noise_std > 0 else None
+        sigma_mask = ((tr.activation(10, M).reshape(nb, S) + (0 if noise is None else noise.astype(np.float32))) > 0)
+        wv, wc, wa, wg = tro.step_gradients_chunked(wts, spec, ro[:nb], rd[:nb], z, params[:nb], cone[:nb], color[:nb], alpha[:nb],
+                                                    dict(kind="alpha", loss_fn="smape", alpha_loss_fn="mse"), chunk_rays=16, masks=masks, sigma_mask=sigma_mask,
+                                                    noise=noise, blur_idx=fam["blur_idx"])
+        flat = np.concatenate([g.ravel() for g in wg])
+        worst, worst_name, p = 0.0, None, 0
+        for name_, i_, o_ in orc.layer_table(spec):              # per Dense layer: kernel and bias together, relative to the layer's largest entry
+            sl = slice(p, p + i_ * o_ + o_); p += i_ * o_ + o_
+            e_ = float(np.abs(got[sl] - flat[sl]).max() / max(np.abs(flat[sl]).max(), 1e-30))
+            if e_ > worst: worst, worst_name = e_, name_
+        e_pred = float(orc.rel_linf(np.concatenate([pc.cpu().numpy(), pa.cpu().numpy()[:, None]], -1), np.concatenate([wc, wa[:, None]], -1)))
+        e_loss = abs(float(pv.item()) - wv) / abs(wv)
+        tr.perturb = True
+        line["parity"] = {"rays": nb, "rel_loss": e_loss, "rel_linf_predictions": e_pred, "rel_linf_worst_layer_gradient": worst, "worst_layer": worst_name, "tolerance": 1e-4,
+                          "ok": bool(e_loss <= 1e-4 and e_pred <= 1e-4 and worst <= 1e-4),
+                          "what": f"{nb} rays x {S} samples of the batch as a step of their own (perturb off) from the weights the timed steps left: loss, [color, alpha] "
+                                  "and every Dense layer's gradient (kernel and bias, relative to the layer's largest entry) against float64 torch autograd of the restated renderer and loss (oracle/train_oracle.py; "
+                                  "unpinned: no TensorFlow here)", "oracle_seconds": round(time.perf_counter() - t1, 2)}
+    if world == 1 and fam_name == "carpet" and data_side:
         # the LOOP around the step (train.py:60-67): batches made by nerf_tex_amd.dataset.Dataset as the config asks -- Proxy pixel sampler among the
         # proxy's hits, rays, colours gathered from resident 800 x 800 uint8 views -- and handed to the same step (tools/bench_train_loop.py)
         from nerf_tex_amd import dataset as D, util
@@ -436,11 +487,14 @@ def bench_train_step(args) -> None:
         line["ranks_hold_identical_weights"] = in_step
         line["config"]["workload"] += f"; data parallel over {world} GPUs: every rank its own {n} rays, gradients averaged once a step" + (
             " [NTX_BENCH_SHARE_GPU=1: all ranks on one GPU]" if share_gpu else "")
-    json_out.write(json.dumps(line) + "\n")
-    json_out.flush()
+    del tr
+    if emit:
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
+    return line
 
 
-def bench_instanced_scene(args) -> None:
+def bench_instanced_scene(args, emit: bool = True, parity_rays: int = 48):
     """`--workload carpet_instanced_scene`: one render chunk of configs/config_carpet_render.py from RAYS -- 16 384 rays of the
     config's first camera -> `ntx_instancer_model_input` (the reference's C_Instancer::GetModelInput, instancer.cpp:751-1037:
     Embree on one CPU thread there, three HIP kernels here) -> `ntx_render_instanced` on the ten buffers it leaves in
@@ -540,7 +594,7 @@ def bench_instanced_scene(args) -> None:
         from oracle import instancer_oracle as io
         from oracle import nerftex_oracle as orc
         t1 = time.perf_counter()
-        pick = np.sort(np.random.default_rng(7).choice(n, size=48, replace=False))
+        pick = np.sort(np.random.default_rng(7).choice(n, size=parity_rays, replace=False))
         ti = torch.as_tensor(pick, device=dev)
         spec = io.make_spec(b_0, b_1, None, textures=textures, instance_sampling_method="nearest", mesh=(mesh_v, mesh_f), matrices=inst.matrices())
         h = lambda x: x[ti].cpu().numpy()
@@ -552,12 +606,14 @@ def bench_instanced_scene(args) -> None:
                                              patch_scale, density_scale, True, False, False, (1., 1., 1.), None, dtype=np.float64)
         rgba = np.concatenate([h(color), h(alpha)[:, None]], -1)
         err = float(orc.rel_linf(rgba, np.concatenate([rc, ra[:, None]], -1)))
-        line["parity"] = {"rays": 48, "instancer_buffers_bit_identical": bool(same), "rel_linf_f64": err, "tolerance": 1e-4, "ok": bool(same and err <= 1e-4),
+        line["parity"] = {"rays": parity_rays, "instancer_buffers_bit_identical": bool(same), "rel_linf_f64": err, "tolerance": 1e-4, "ok": bool(same and err <= 1e-4),
                           "what": "seeded rays of the timed chunk: the ten buffers of ntx_instancer_model_input against the restatement of "
                                   "instancer.cpp:751-1037 (oracle/instancer_oracle.py; Embree cannot be built here: unpinned), and [color, alpha] against "
                                   "that restatement followed by the float64 restatement of renderer.py:247-354",
                           "oracle_seconds": round(time.perf_counter() - t1, 2)}
-    print(json.dumps(line), flush=True)
+    if emit:
+        print(json.dumps(line), flush=True)
+    return line
 
 
 def launch_ranks(cmds, envs, deadline_s: float, log_dir: str, poll_s: float = 0.2, label: str = "bench.py") -> int:
@@ -675,7 +731,7 @@ def main() -> None:
     ap.add_argument("--precision", default="float32", choices=["float32", "fp16x3"],
                     help="arithmetic of the Dense layers (include/nerftex.h: ntx_precision); float32 = the reference's")
     ap.add_argument("--perturb", action="store_true", help="stratified jitter of the depths inside the kernel (the reference's default perturb=True)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the fp16x3 / perturb second figures (profiling runs: one kernel flavour per process)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the second figures -- fp16x3, perturb, ray setup, and `extras` (the training step and the instanced scene) -- (profiling runs: one kernel flavour per process)")
     ap.add_argument("--shard", default="rows", choices=["rows", "bands"], help="sharded workloads: pixel rows round-robin, or contiguous bands")
     ap.add_argument("--deadline", type=float, default=float(os.environ.get("NTX_BENCH_DEADLINE", "600")),
                     help="multi-rank runs: seconds after which the launcher ends all ranks / every rank's watchdog exits")
@@ -988,6 +1044,25 @@ def main() -> None:
             line["perturb"] = jit
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(family, S)
+        if world == 1 and not args.no_extras and args.precision == "float32" and args.workload == "carpet":
+            # the two other headline figures on the driver's record, after the timed region and outside `value`: the training step
+            # (network/train.py:61-67) and the path the shipped render configs run (renderer.py:247-354 behind the patch instancer) -- 5 steps
+            # each of `--workload carpet_train_step` / `carpet_instanced_scene` with a small oracle check; `--no-extras` skips them
+            t1 = time.perf_counter()
+            ns = argparse.Namespace(**vars(args)); ns.steps, ns.warmup, ns.no_cpu_baseline, ns.no_parity = 5, 2, True, False
+            ns.workload = "carpet_train_step"
+            lt = bench_train_step(ns, emit=False, data_side=False, parity_rays=64)
+            ns.workload = "carpet_instanced_scene"
+            li = bench_instanced_scene(ns, emit=False, parity_rays=16)
+            line["extras"] = {
+                "train_step": {"ms": lt["roofline"]["kernel_ms"], "value": lt["value"], "unit": lt["unit"], "frac": lt["roofline"]["frac"], "frac_what": lt["roofline"]["what"],
+                               "frac_3x_forward": lt["roofline"]["frac_3x_forward"], "parity": {k: v for k, v in lt["parity"].items() if k != "what"},
+                               "workload": lt["config"]["workload"]},
+                "instanced_scene": {"ms": li["ms_per_step"], "value": li["value"], "unit": li["unit"], "kernel_ms": li["roofline"]["kernel_ms"], "frac": li["roofline"]["frac"],
+                                    "frac_what": li["roofline"]["what"], "instancer_ms": li["instancer"]["ms"], "in_patch_samples": li["config"]["in_patch_samples"],
+                                    "parity": {k: v for k, v in li["parity"].items() if k != "what"}, "workload": li["config"]["workload"]},
+                "seconds": None, "what": "`--workload carpet_train_step` and `--workload carpet_instanced_scene`, 5 steps each after the timed region; never part of `value`"}
+            line["extras"]["seconds"] = round(time.perf_counter() - t1, 1)
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
     if world > 1:
