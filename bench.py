@@ -888,10 +888,11 @@ def main() -> None:
         mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, hits_total = float(mx[0].item()), int(sm[1].item())
-        mine = torch.tensor([kernel_ms, gather_ms, float(n_rays), float(n_hit)], device=sdev, dtype=torch.float64)
+        mine = torch.tensor([kernel_ms, gather_ms, float(n_rays), float(n_hit), comm.init_seconds if comm is not None else -1.0], device=sdev, dtype=torch.float64)
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        per_rank = [{"rank": r, "kernel_ms": float(v[0]), "gather_ms": float(v[1]), "rays": int(v[2]), "hits": int(v[3])} for r, v in enumerate(every)]
+        per_rank = [{"rank": r, "kernel_ms": float(v[0]), "gather_ms": float(v[1]), "rays": int(v[2]), "hits": int(v[3]),
+                     "comm_init_s": (float(v[4]) if float(v[4]) >= 0 else None)} for r, v in enumerate(every)]      # ncclCommInitRank of ntx_comm_create, per rank
 
     # rank 0 re-times its own shard ALONE (no gather, the other ranks wait at the barrier below): what one GPU takes for the same
     # rays when its 7 neighbours are idle -- the reference point of the efficiency figure in the line
@@ -916,6 +917,20 @@ def main() -> None:
         whole_ms = w0.elapsed_time(w1)                       # the whole image on ONE GPU: the strong-scaling reference
         ref = torch.cat([o1["color_pred"][0], o1["alpha_pred"][0][:, None]], -1)
         identical = bool(torch.equal(ref, img))              # also under --perturb: the generators are keyed by the pixel
+    elif world > 1 and rank == 0:
+        # weak scaling: the gathered image is the N ranks' bands one after the other; rank 0 renders every band ALONE (the peers' rays are
+        # seeded by their rank) and compares -- what arrived over RCCL against what one GPU computes for the same rays, bit for bit
+        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0.record()
+        bands = []
+        for r in range(world):
+            ro_, rd_, t_, cone_ = synthetic.all_hit_rays(n_rays, fam["b_0"], fam["b_1"], fam["cam"], seed=1 + r)
+            d_ = lambda a: torch.as_tensor(a, device=dev)[None]
+            o1 = renderer(rays_o=d_(ro_), rays_d=d_(rd_), t=d_(t_), cone_scale=d_(cone_), parameters=params, ray_index=shard.ray_index(r), seed=1234)
+            bands.append(torch.cat([o1["color_pred"][0], o1["alpha_pred"][0][:, None]], -1))
+        w1.record(); torch.cuda.synchronize()
+        whole_ms = w0.elapsed_time(w1)                       # (includes making the peers' rays on the host: not a timing reference)
+        identical = bool(img is not None and torch.equal(torch.cat(bands, 0), img))
 
     # second figures on the same inputs, outside the timed region (rank 0, N = 1), clearly labelled, never `value`:
     # the opt-in fp16x3 precision, and the reference's default perturb=True (stratified jitter inside the kernel)
@@ -1023,6 +1038,7 @@ def main() -> None:
             line["per_rank"] = per_rank
             line["gather_bytes"] = int(sum(p_["rays"] for p_ in per_rank[1:]) * 16)      # RGBA float32 of every peer -> rank 0
             line["gather_how"] = gather_how
+            line["rccl_version"] = comm.version if comm is not None else None        # ncclGetVersion of the librccl behind ntx_comm (22606 = 2.26.6)
             line["imbalance"] = max(kms) / (sum(kms) / len(kms))                          # max / mean kernel_ms over the ranks
             line["rank0_alone_ms"] = alone_ms
             if sharded:
@@ -1032,6 +1048,8 @@ def main() -> None:
             else:
                 # weak scaling: every rank has rank 0's work; ideal = the job takes what rank 0 takes alone
                 line["efficiency_vs_rank0_alone"] = alone_ms / (elapsed / args.steps * 1e3)
+        if world > 1:
+            assert identical is not None, "an N > 1 run must compare its gathered image with one GPU's"
         if identical is not None:
             line["sharded_image_bit_identical_to_1gpu"] = identical
         if parity is not None:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NTX_ABI_VERSION 6
+#define NTX_ABI_VERSION 7
 
 typedef struct ntx_ctx ntx_ctx;
 typedef void *ntx_stream; /* hipStream_t */
@@ -331,6 +331,14 @@ int ntx_comm_destroy(ntx_comm *comm);
  * image_out / staging are ignored on the other ranks. */
 int ntx_gather_image(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, int64_t run_length, float *image_out,
                      float *staging, int root, ntx_stream stream);
+/* ABI v7.  The same with flags.  NTX_GATHER_FORCE_EXCHANGE: take the exact-count branch whatever the counts are -- grouped
+ * ncclSend / ncclRecv into `staging` (required on the root), then the un-shard pass -- and send the root's own block to itself too
+ * instead of copying it: a communicator of ONE rank then executes every RCCL call of the branch that uneven shards take on eight
+ * (tests; a box with one GPU).  ntx_comm_version: ncclGetVersion of the bound librccl (0 = none). */
+#define NTX_GATHER_FORCE_EXCHANGE 1u
+int ntx_gather_image_ex(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, int64_t run_length, float *image_out,
+                        float *staging, int root, uint32_t flags, ntx_stream stream);
+int ntx_comm_version(void);
 
 /* ABI v5.  values[n] (DEVICE) <- the mean over all ranks of their values[n], in place, on `stream`: one ncclAllReduce (rccl.h) and a scale.
  * The one collective of data-parallel TRAINING (the reference trains on one device: train.py:61-67): ranks take the same step on different

@@ -16,10 +16,11 @@ LIB_PATH = os.environ.get("NERFTEX_LIB") or os.path.join(_HERE, "libnerftex_hip.
 
 NTX_OK, NTX_E_INVALID, NTX_E_UNSUPPORTED, NTX_E_HIP, NTX_E_NODEVICE = 0, -1, -2, -3, -4
 FLAG_MAP_EXR, FLAG_COMPOSITE_BKGD, FLAG_CHECK_NUMERICS, FLAG_FP16X3, FLAG_PERTURB, FLAG_RAW_NOISE = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 6
+ABI_VERSION = 7
 KIND_PARAMNERF_EX = 2           # NTX_MODEL_PARAMNERF_EX: the descriptor's param_depth / param_width count
 SKIP_MASK = 0x40000000          # NTX_SKIP_MASK: ntx_model_desc.skip carries a mask of skip-layer indices
 COMM_ID_BYTES = 128
+GATHER_FORCE_EXCHANGE = 1      # NTX_GATHER_FORCE_EXCHANGE
 DEFAULT_MAX_RAYS = 1 << 20
 
 
@@ -119,6 +120,8 @@ SYMBOLS = {
     "ntx_comm_create": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "ntx_comm_destroy": (C.c_int, [_vp]),
     "ntx_gather_image": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int, _vp]),
+    "ntx_gather_image_ex": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp, C.c_int, C.c_uint32, _vp]),
+    "ntx_comm_version": (C.c_int, []),
     "ntx_kernel_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ntx_packed_count": (C.c_size_t, [C.POINTER(ModelDesc)]),
     "ntx_pack_weights": (C.c_int, [C.POINTER(ModelDesc), _fp, C.c_size_t, _fp, C.c_size_t]),

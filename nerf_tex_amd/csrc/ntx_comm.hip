@@ -45,6 +45,7 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     char path[512] = "";
     char why[512] = "";           // dlerror() of the dlopen / dlsym that failed, taken where it failed (a later call would overwrite or clear it)
 };
@@ -72,7 +73,7 @@ Rccl load_rccl() {
     };
     sym(r.GetUniqueId, "ncclGetUniqueId"); sym(r.CommInitRank, "ncclCommInitRank"); sym(r.CommDestroy, "ncclCommDestroy");
     sym(r.Gather, "ncclGather"); sym(r.AllReduce, "ncclAllReduce"); sym(r.Send, "ncclSend"); sym(r.Recv, "ncclRecv");
-    sym(r.GroupStart, "ncclGroupStart"); sym(r.GroupEnd, "ncclGroupEnd"); sym(r.GetErrorString, "ncclGetErrorString");
+    sym(r.GroupStart, "ncclGroupStart"); sym(r.GroupEnd, "ncclGroupEnd"); sym(r.GetErrorString, "ncclGetErrorString"); sym(r.GetVersion, "ncclGetVersion");
     if (!ok) { r.handle = nullptr; return r; }
     Dl_info info;   // which file the symbols really come from (diagnostics: ntx_comm_library)
     if (dladdr(reinterpret_cast<void *>(r.Gather), &info) && info.dli_fname) snprintf(r.path, sizeof(r.path), "%s", info.dli_fname);
@@ -129,6 +130,12 @@ int ntx_unshard_map(int64_t n_pixels, int64_t run_length, int n_ranks, int64_t *
 const char *ntx_comm_library(void) {
     const Rccl *R = rccl();
     return R ? R->path : "";
+}
+
+int ntx_comm_version(void) {
+    const Rccl *R = rccl();
+    int v = 0;
+    return (R && R->GetVersion(&v) == ncclSuccess) ? v : 0;
 }
 
 int ntx_comm_preflight(int device) {
@@ -189,7 +196,13 @@ int ntx_gather_plan(int64_t n_pixels, int64_t run_length, int n_ranks, int64_t *
 
 int ntx_gather_image(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, int64_t run_length, float *image_out,
                      float *staging, int root, ntx_stream stream) {
+    return ntx_gather_image_ex(comm, local_rgba, n_pixels, run_length, image_out, staging, root, 0, stream);
+}
+
+int ntx_gather_image_ex(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, int64_t run_length, float *image_out,
+                        float *staging, int root, uint32_t flags, ntx_stream stream) {
     if (!comm) return ntx_set_error(NTX_E_INVALID, "comm is NULL");
+    if (flags & ~(uint32_t)NTX_GATHER_FORCE_EXCHANGE) return ntx_set_error(NTX_E_INVALID, "unknown gather flags 0x%x", flags);
     const int R_ = comm->n_ranks, me = comm->rank;
     if (n_pixels < 0 || run_length < 1 || root < 0 || root >= R_) return ntx_set_error(NTX_E_INVALID, "bad gather arguments");
     if (n_pixels == 0) return NTX_OK;
@@ -197,7 +210,11 @@ int ntx_gather_image(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, 
     if (!R) return ntx_set_error(NTX_E_UNSUPPORTED, "librccl.so.1 could not be loaded");
     // the plan (ntx_shard.h; ntx_gather_plan hands the same numbers to host code): rank r's count, its block at pixel slot
     // rank_block(r, cap) of the destination, and whether the blocks already are the image
-    const ntx_shard::Plan pl = ntx_shard::plan(n_pixels, run_length, R_);
+    ntx_shard::Plan pl = ntx_shard::plan(n_pixels, run_length, R_);
+    // NTX_GATHER_FORCE_EXCHANGE: the exact-count branch whatever the counts -- grouped ncclSend / ncclRecv into `staging` and the un-shard
+    // pass -- with the root's own block going through a send to itself as well, so that ONE rank alone runs every call of that branch
+    const bool forced = (flags & NTX_GATHER_FORCE_EXCHANGE) != 0;
+    if (forced) { pl.equal = false; pl.direct = false; }
     const int64_t mine = shard_count(n_pixels, run_length, R_, me), cap = pl.cap;
     if (!local_rgba && mine > 0) return ntx_set_error(NTX_E_INVALID, "local_rgba is NULL");
     const bool direct = pl.direct;                                                // the gather lands in pixel order
@@ -211,16 +228,17 @@ int ntx_gather_image(ntx_comm *comm, const float *local_rgba, int64_t n_pixels, 
         RCCL_TRY(R->Gather(local_rgba, dst, (size_t)cap * 4, ncclFloat, root, comm->comm, st));
     } else {
         // same exchange with the exact per-rank counts; the group is always closed, also on an error inside it
-        if (me == root && mine > 0)
+        if (me == root && mine > 0 && !forced)
             HIP_TRY(hipMemcpyAsync(dst + (size_t)ntx_shard::rank_block(me, cap) * 4, local_rgba, (size_t)mine * 16, hipMemcpyDeviceToDevice, st));
         RCCL_TRY(R->GroupStart());
         ncclResult_t rc = ncclSuccess;
         if (me == root) {
             for (int r = 0; r < R_ && rc == ncclSuccess; ++r) {
                 const int64_t cnt = shard_count(n_pixels, run_length, R_, r);
-                if (cnt > 0 && r != me)
+                if (cnt > 0 && (r != me || forced))
                     rc = R->Recv(dst + (size_t)ntx_shard::rank_block(r, cap) * 4, (size_t)cnt * 4, ncclFloat, r, comm->comm, st);
             }
+            if (forced && mine > 0 && rc == ncclSuccess) rc = R->Send(local_rgba, (size_t)mine * 4, ncclFloat, root, comm->comm, st);
         } else if (mine > 0) {
             rc = R->Send(local_rgba, (size_t)mine * 4, ncclFloat, root, comm->comm, st);
         }

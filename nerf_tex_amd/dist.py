@@ -122,14 +122,19 @@ class Comm:
         elif err is not None:
             raise CommUnavailable(f"rank 0: {err}")
         handle = C.c_void_p()
+        import time
+        t0 = time.perf_counter()
         _lib.check(_lib.lib.ntx_comm_create(ident, self.world, self.rank, device_index, C.byref(handle)))
+        self.init_seconds = time.perf_counter() - t0          # ncclCommInitRank (blocks until every peer has joined)
+        self.version = int(_lib.lib.ntx_comm_version())       # ncclGetVersion: 22606 = 2.26.6
         self.handle = handle.value
         self.device = torch.device("cuda", device_index)
         self.library = _lib.lib.ntx_comm_library().decode("utf-8", "replace")
         self._staging = None
 
-    def gather_image(self, local_rgba, shard: ShardMap, dst: int = 0):
-        """[count(rank), 4] float32 on this GPU -> [n, 4] on `dst` (None elsewhere), on the current stream."""
+    def gather_image(self, local_rgba, shard: ShardMap, dst: int = 0, force_exchange: bool = False):
+        """[count(rank), 4] float32 on this GPU -> [n, 4] on `dst` (None elsewhere), on the current stream.  `force_exchange`
+        (NTX_GATHER_FORCE_EXCHANGE): the grouped send / recv + un-shard branch whatever the counts (tests on one rank)."""
         import torch
         from . import _lib
         local_rgba = local_rgba.contiguous()
@@ -139,16 +144,17 @@ class Comm:
         if self.rank == dst:
             image = torch.empty((shard.n, 4), device=self.device, dtype=torch.float32)
             equal = all(shard.count(r) == shard.capacity for r in range(shard.world))
-            if not (equal and shard.contiguous):
+            if force_exchange or not (equal and shard.contiguous):
                 need = shard.world * shard.capacity * 4
                 if self._staging is None or self._staging.numel() < need:
                     self._staging = torch.empty(need, device=self.device, dtype=torch.float32)
                 staging = self._staging
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib.ntx_gather_image(self.handle, local_rgba.data_ptr(), shard.n, shard.run,
-                                                 image.data_ptr() if image is not None else None,
-                                                 staging.data_ptr() if staging is not None else None, dst,
-                                                 torch.cuda.current_stream(self.device).cuda_stream))
+            _lib.check(_lib.lib.ntx_gather_image_ex(self.handle, local_rgba.data_ptr(), shard.n, shard.run,
+                                                    image.data_ptr() if image is not None else None,
+                                                    staging.data_ptr() if staging is not None else None, dst,
+                                                    _lib.GATHER_FORCE_EXCHANGE if force_exchange else 0,
+                                                    torch.cuda.current_stream(self.device).cuda_stream))
         return image
 
     def close(self) -> None:

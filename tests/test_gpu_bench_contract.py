@@ -42,6 +42,14 @@ def test_default_line_has_the_contract_fields():
     s_ = d["with_ray_setup"]                            # with and without ray setup
     # (one timed step each: launch-to-launch spread is a few tenths of a percent, ray generation costs ~0.1 ms of 364)
     assert s_["unit"] == "ray-samples/s" and 0.97 * d["value"] < s_["value"] <= 1.02 * d["value"] and s_["ms"] >= s_["ms_without"] * 0.99
+    # the two other headline figures ride on the driver's line, outside `value`: the training step and the instanced scene
+    x = d["extras"]
+    t_, i_ = x["train_step"], x["instanced_scene"]
+    assert 5.0 < t_["ms"] < 12.0 and 0.5 < t_["frac"] < 1.0 and t_["frac_3x_forward"] > t_["frac"] and t_["parity"]["ok"] is True and t_["parity"]["rays"] == 64
+    assert 20.0 < i_["ms"] < 80.0 and 0.7 < i_["frac"] < 1.0 and i_["parity"]["instancer_buffers_bit_identical"] is True and i_["parity"]["ok"] is True
+    assert x["seconds"] < 30
+    d2 = _run("--no-cpu-baseline", "--no-extras", "--no-parity")
+    assert "extras" not in d2 and "fp16x3" not in d2
 
 
 def test_sharded_workload_line_at_one_gpu():
@@ -131,6 +139,8 @@ def test_two_ranks_sharing_the_gpu_run_the_whole_multi_rank_bench(workload, shar
             assert abs(pr[0]["hits"] - pr[1]["hits"]) < 0.02 * d["config"]["hit_rays_total"]
     else:
         assert d["scaling"] == "weak" and all(p["rays"] == 640000 for p in pr) and d["efficiency_vs_rank0_alone"] > 0
+        assert d["sharded_image_bit_identical_to_1gpu"] is True      # the two bands as gathered against rank 0 rendering both alone
+    assert "rccl_version" in d and all("comm_init_s" in p for p in pr)
 
 
 def test_cpu_baseline_block():
@@ -148,7 +158,11 @@ def test_train_step_line_at_one_and_at_two_ranks():
     assert d["n_gpus"] == 1 and d["unit"] == "ray-samples/s" and d["dtype"] == "f32" and d["scaling"] == "weak" and "carpet_train_step" in d["config"]["workload"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.4 < r["frac"] < 1.0
-    assert abs(3 * d["config"]["flops_per_sample_forward"] * 262144 / (r["kernel_ms"] * 1e-3) / 1e12 - r["achieved"]) / r["achieved"] < 1e-6
+    # the fraction is on the FLOPs a step needs: 2 x forward + forward less the encoded inputs' rows; the 3 x forward figure beside it
+    assert d["config"]["flops_per_sample_step"] == 2 * (2 * 680832 + 623232) and d["config"]["flops_per_sample_forward"] == 2 * 680832
+    assert abs(d["config"]["flops_per_sample_step"] * 262144 / (r["kernel_ms"] * 1e-3) / 1e12 - r["achieved"]) / r["achieved"] < 1e-6
+    assert abs(r["frac_3x_forward"] / r["frac"] - 3 * 680832 / (2 * 680832 + 623232)) < 1e-6
+    assert d["parity"]["ok"] is True and d["parity"]["rays"] == 64
     assert r["traffic"] is None or r["traffic"] > 1e10
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["value"] > 50 * d["cpu_baseline"]["value"]
     env = dict(os.environ, NTX_BENCH_SHARE_GPU="1")

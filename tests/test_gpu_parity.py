@@ -25,7 +25,7 @@ def to_dev(*arrs):
 
 def test_native_library_is_loaded():
     from nerf_tex_amd import _lib
-    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 7
     with open("/proc/self/maps") as f:
         assert "libnerftex_hip.so" in f.read()
 

@@ -464,6 +464,28 @@ def test_gather_image_on_a_one_rank_communicator(n, run):
     comm.close()
 
 
+@pytest.mark.parametrize("n,run", [(800 * 10, None), (801, None), (800 * 10, 800), (4001, 16), (640000, 800)])
+def test_the_uneven_shards_branch_on_a_one_rank_communicator(n, run):
+    """the branch of ntx_gather_image that uneven shards take -- grouped ncclSend / ncclRecv with exact counts into the staging
+    buffer, then the un-shard kernel (csrc/ntx_comm.hip) -- had only ever run with one rank, where it did nothing.  NTX_GATHER_FORCE_EXCHANGE
+    makes a communicator of ONE rank take it in full: the root receives its own block from itself through RCCL (send + recv in one group)
+    instead of copying it, and the un-shard kernel deals the runs into pixel order.  Also: the librccl the calls went to and its version."""
+    from nerf_tex_amd import _lib
+    from nerf_tex_amd.dist import Comm, ShardMap
+    comm = Comm(0)
+    assert comm.version >= 20000 and comm.init_seconds >= 0 and "rccl" in comm.library
+    shard = ShardMap(n, 1, run)
+    local = torch.rand((n, 4), device=dev())
+    img = comm.gather_image(local, shard, force_exchange=True)
+    torch.cuda.synchronize()
+    assert img.shape == (n, 4) and torch.equal(img, local)
+    # the flag without a staging buffer is refused before any RCCL call, an unknown flag too
+    image = torch.empty((n, 4), device=dev()); st = torch.cuda.current_stream(dev()).cuda_stream
+    assert _lib.lib.ntx_gather_image_ex(comm.handle, local.data_ptr(), n, n, image.data_ptr(), None, 0, _lib.GATHER_FORCE_EXCHANGE, st) == _lib.NTX_E_INVALID
+    assert _lib.lib.ntx_gather_image_ex(comm.handle, local.data_ptr(), n, n, image.data_ptr(), None, 0, 2, st) == _lib.NTX_E_INVALID
+    comm.close()
+
+
 def test_two_rank_sharded_render_is_bit_identical():
     """BASELINE configs[3] over 2 ranks (rows dealt round-robin, ntx_gather_image over RCCL): the gathered image equals the
     one-GPU image bit for bit.  Needs two GPUs; the one-GPU box skips it."""

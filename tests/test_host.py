@@ -21,7 +21,7 @@ def test_abi_exports_every_declared_symbol():
     raw = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib.ntx_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_create_without_gpu_reports_no_device():
@@ -422,6 +422,26 @@ def test_gather_image_world8_gloo_at_the_real_partition_sizes(n_total, run):
     res = sorted(q.get(timeout=300) for _ in procs)
     [p.join(60) for p in procs]
     assert res == [(r, True) for r in range(8)]
+
+
+@pytest.mark.parametrize("world,run", [(3, 800), (3, None), (7, 800), (7, None)])
+def test_gather_image_800x800_over_3_and_7_ranks_gloo(world, run):
+    """BASELINE configs[3]'s 800 x 800 image over rank counts that do NOT divide it -- 3 ranks: 267 / 267 / 266 rows or bands of
+    213 334 / 213 334 / 213 332 pixels; 7 ranks: 115 or 114 rows each, a short last band -- so that `ntx_gather_plan` says `equal == 0` and the
+    exchange is the exact-count send / recv at block offsets r * cap followed by the un-shard map, executed by that many gloo processes."""
+    import socket
+    import torch.multiprocessing as mp
+    from nerf_tex_amd.dist import ShardMap
+    counts, offs, equal, direct = ShardMap(800 * 800, world, run).plan()
+    assert not equal and not direct and len(set(counts)) > 1 and sum(counts) == 640000
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, 800 * 800, run, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=300) for _ in procs)
+    [p.join(60) for p in procs]
+    assert res == [(r, True) for r in range(world)]
 
 
 def test_gather_plan_matches_the_shard_map():
@@ -863,7 +883,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                     "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     # 803 rows of 800 over 8 ranks: ranks 0-2 hold 101 rows, the others 100 -> exact-count Send/Recv into staging, blocks at r * 80800
-    assert out == ["6", "683524", "80000", "80800", str(7 * 80800), "0", "0", "48"]
+    assert out == ["7", "683524", "80000", "80800", str(7 * 80800), "0", "0", "48"]
 
 
 def test_instancer_host_side(tmp_path):
