@@ -728,6 +728,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="carpet", choices=sorted(WORKLOADS) + sorted(SHARDED) + ["carpet_instanced", "carpet_instanced_scene", "carpet_train_step", "grass_filtered_train_step", "fur_train_step"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="about how long the cpu_baseline sample may take (default 15 s: one full reference render_chunk where the host manages)")
     ap.add_argument("--precision", default="float32", choices=["float32", "fp16x3"],
                     help="arithmetic of the Dense layers (include/nerftex.h: ntx_precision); float32 = the reference's")
     ap.add_argument("--perturb", action="store_true", help="stratified jitter of the depths inside the kernel (the reference's default perturb=True)")
@@ -1061,7 +1062,7 @@ def main() -> None:
         if jit is not None:
             line["perturb"] = jit
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(family, S)
+            line["cpu_baseline"] = cpu_baseline(family, S, args.cpu_baseline_seconds)
         if world == 1 and not args.no_extras and args.precision == "float32" and args.workload == "carpet":
             # the two other headline figures on the driver's record, after the timed region and outside `value`: the training step
             # (network/train.py:61-67) and the path the shipped render configs run (renderer.py:247-354 behind the patch instancer) -- 5 steps

@@ -48,8 +48,6 @@ def test_default_line_has_the_contract_fields():
     assert 5.0 < t_["ms"] < 12.0 and 0.5 < t_["frac"] < 1.0 and t_["frac_3x_forward"] > t_["frac"] and t_["parity"]["ok"] is True and t_["parity"]["rays"] == 64
     assert 20.0 < i_["ms"] < 80.0 and 0.7 < i_["frac"] < 1.0 and i_["parity"]["instancer_buffers_bit_identical"] is True and i_["parity"]["ok"] is True
     assert x["seconds"] < 30
-    d2 = _run("--no-cpu-baseline", "--no-extras", "--no-parity")
-    assert "extras" not in d2 and "fp16x3" not in d2
 
 
 def test_sharded_workload_line_at_one_gpu():
@@ -74,6 +72,7 @@ def test_the_largest_single_image_at_one_gpu():
     assert d["config"]["hit_rays_total"] == 2_560_000 and d["config"]["samples_per_ray"] == 128 and "1600x1600x128" in d["config"]["workload"]
     assert d["parity"]["ok"] is True and d["parity"]["rel_linf_f32"] <= 1e-4
     assert d["roofline"]["frac"] >= 0.95, d["roofline"]                        # cold: the one step includes the first launch
+    assert "extras" not in d and "fp16x3" not in d and "with_ray_setup" not in d      # --no-extras: one kernel flavour in the process
     assert "traffic_profile_head" in d["roofline"] and "traffic_profile_current" in d["roofline"]
 
 
@@ -144,7 +143,7 @@ def test_two_ranks_sharing_the_gpu_run_the_whole_multi_rank_bench(workload, shar
 
 
 def test_cpu_baseline_block():
-    d = _run("--workload", "fur")
+    d = _run("--workload", "fur", "--cpu-baseline-seconds", "3", "--no-extras")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "ray-samples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert c["cpu_count"] >= c["cores"] and "BLAS_INFO" in c["blas"]       # threads and BLAS backend stated

@@ -11,6 +11,17 @@ from tests.common import TOL, make_model
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
+ORACLE_RAYS = 1500      # the GPU renders every ray of a case; the three restatement passes (float64, float32, float64 on float32 points) run on
+                        # at most this many of the hit rays -- a seeded draw that always holds the first and the last hit ray (block edges)
+
+
+def oracle_subset(hit, rng):
+    idx = np.nonzero(hit)[0]
+    if idx.size > ORACLE_RAYS:
+        idx = np.unique(np.concatenate([idx[:8], idx[-8:], rng.choice(idx, size=ORACLE_RAYS - 16, replace=False)]))
+    sel = np.zeros_like(hit); sel[idx] = True
+    return sel
+
 CASES = [(seed, prec) for seed in range(12) for prec in ("float32", "fp16x3")]
 
 
@@ -39,16 +50,18 @@ def test_fuzz_render_rays(seed, precision):
             bkgd_color=[0.2, 0.5, 0.9])
     r.raise_if_nonfinite()
     got = np.concatenate([out["color_pred"].cpu().numpy().reshape(n, 3), out["alpha_pred"].cpu().numpy().reshape(n, 1)], -1)
-    hit = np.isfinite(t[:, 0])
+    all_hit = np.isfinite(t[:, 0])
     want = np.zeros((n, 4))
     if bk:
-        want[~hit, :3] = (0.2, 0.5, 0.9)
+        want[~all_hit, :3] = (0.2, 0.5, 0.9)
+    assert np.array_equal(got[~all_hit], want[~all_hit].astype(np.float32))        # culled rays exact
+    assert np.isfinite(got).all()
+    hit = oracle_subset(all_hit, rng)
     if hit.any():
         pr = params if per_ray else np.repeat(params, n, 0)
         ref = orc.render_rays(w, spec, ro[hit], rd[hit], t[hit], pr[hit], cone[hit], S, bk, (0.2, 0.5, 0.9), fam["blur_idx"],
                               bool(seed & 4), dtype=np.float64)
         want[hit, :3] = ref["color_pred"]; want[hit, 3] = ref["alpha_pred"]
-    assert np.array_equal(got[~hit], want[~hit].astype(np.float32))        # culled rays exact
     if hit.any():
         # Two strict gates (tests/common.py: TOL = 1e-4): against the float32 restatement (the north star's comparison) and
         # against the float64 network on the float32 sample points (the arithmetic the kernel answers for; oracle render_rays:
@@ -60,12 +73,12 @@ def test_fuzz_render_rays(seed, precision):
                                points_dtype=np.float32, **kw2)
         w32 = np.concatenate([ref32["color_pred"], ref32["alpha_pred"][:, None]], -1).astype(np.float64)
         wn = np.concatenate([refn["color_pred"], refn["alpha_pred"][:, None]], -1)
-        scale = max(float(np.max(np.abs(want))), 1e-3)
+        scale = max(float(np.max(np.abs(want[hit]))), 1e-3)
         input_floor = float(np.max(np.abs(wn - want[hit]))) / scale
         err_net = float(np.max(np.abs(got[hit] - wn))) / scale
         assert float(np.max(np.abs(got[hit] - w32))) / scale <= TOL
         assert err_net <= TOL
-        assert float(np.max(np.abs(got - want))) / scale <= err_net + input_floor * (1 + 1e-6) + 1e-9
+        assert float(np.max(np.abs(got[hit] - want[hit]))) / scale <= err_net + input_floor * (1 + 1e-6) + 1e-9
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -85,7 +98,8 @@ def test_fuzz_around_the_direction_blocks(seed):
     t = t.copy(); t[rng.uniform(size=n) < [0.0, 0.4, 0.97][seed % 3]] = np.inf
     params = (rng.uniform(0, 1, size=(1, sum(fam["n_parameters"]))) * np.asarray(fam["params"], np.float32)).astype(np.float32)
     perturb = bool(seed % 2)
-    hit = np.isfinite(t[:, 0])
+    all_hit = np.isfinite(t[:, 0])
+    hit = oracle_subset(all_hit, rng)
     tz = np.where(np.isfinite(t), t, 0).astype(np.float32)
     z = orc.z_values_perturbed(tz, S, 77 + seed, np.float32) if perturb else None
     kw = dict(z_override=None if z is None else z[hit])
@@ -106,7 +120,7 @@ def test_fuzz_around_the_direction_blocks(seed):
         out = r(d(ro[None]), d(rd[None]), d(t[None]), parameters=d(params), cone_scale=d(cone[None]), seed=77 + seed)
         r.raise_if_nonfinite()
         got = np.concatenate([out["color_pred"][0].cpu().numpy(), out["alpha_pred"][0].cpu().numpy()[:, None]], -1)
-        assert np.all(got[~hit] == 0)
+        assert np.all(got[~all_hit] == 0) and np.isfinite(got).all()
         err_net = float(np.abs(got[hit] - wn).max()) / scale
         assert float(np.abs(got[hit] - w32).max()) / scale <= TOL                       # vs the float32 restatement
         assert err_net <= TOL                                                            # vs the float64 network on the float32 points

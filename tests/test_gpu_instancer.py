@@ -861,7 +861,7 @@ def test_the_bench_scene_with_shadows_and_textures_against_the_c_restatement(mod
     fam = synthetic.FAMILIES["carpet"]
     c2w = look_at(np.asarray(fam["cam"], F))
     focal = 800 / np.tan(fam["angle"] / 2) / 2
-    side, S, h = 32, 1024, 0.002
+    side, S, h = (32 if mode == "interpolated" else 20), 1024, 0.002      # (every-step shadow and texture lookups: 16 ms of the C restatement a ray)
     r0 = (800 - side) // 2
     rows, cols = np.meshgrid(np.arange(r0, r0 + side), np.arange(r0, r0 + side), indexing="ij")
     ro, rd, t, cone = orc.proxy_rays(np.stack([rows.ravel(), cols.ravel()], -1), 800, 800, focal, c2w, [-1.7, -1.7, -.3], [1.7, 1.7, .4], F)
@@ -874,6 +874,6 @@ def test_the_bench_scene_with_shadows_and_textures_against_the_c_restatement(mod
     want = ci.get_model_input(spec, ro, rd, par, S, h, io.offset_uniforms(n, 1), io.choice_uniforms(n, S, 1))
     emitted = want[2] > 0
     dark = emitted & np.all(want[9][..., 4:7] == F([0, 0, -1]), axis=-1)
-    assert emitted.sum() > n * 150 and 0.02 < dark.sum() / emitted.sum() < 0.6 and len(np.unique(want[9][..., 0][emitted])) > 10000
+    assert emitted.sum() > n * 150 and 0.02 < dark.sum() / emitted.sum() < 0.6 and len(np.unique(want[9][..., 0][emitted])) > (10000 if side == 32 else 4000)
     assert_same(got, list(want))
     assert inst.status() == 0
