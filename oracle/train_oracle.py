@@ -166,16 +166,21 @@ def adam_step(w, g, m, v, iterations, lrate, decay_steps=0.0, decay_rate=0.1, be
 
 
 def step_gradients_chunked(w_np, spec, rays_o, rays_d, z, parameters, cone_scale, color_true, alpha_true, loss, chunk_rays=16, masks=None, sigma_mask=None,
-                           noise=None, **kw):
+                           noise=None, workers=None, **kw):
     """`step_gradients` on a batch too large for one autograd pass in float64 (the configs' 1024 rays x 256 samples): the losses of loss.py
     are MEANS over the rays, so the batch's loss and gradient are the ray-count-weighted sums of its chunks' -- evaluated `chunk_rays` rays at
-    a time (bounded memory, minutes of CPU).  Every ray must hit (the filter-and-scatter branch of step_gradients is per call).
+    a time (bounded memory, minutes of CPU; `workers` chunks at once on Python threads: the matrices of a chunk are too small to keep every
+    BLAS thread busy), added up in chunk order.  Every ray must hit (the filter-and-scatter branch of step_gradients is per call).
     `masks`: [M, width] arrays (bool is fine), `sigma_mask` / `noise`: [n, S]."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    if workers is None:
+        workers = int(os.environ.get("NTX_ORACLE_WORKERS", "4"))
     z = np.asarray(z)
     n, S = z.shape
     assert np.isfinite(z).all(), "chunked evaluation is for all-hit batches"
-    total, grads, cs, al = 0.0, None, [], []
-    for r0 in range(0, n, chunk_rays):
+
+    def one(r0):
         r1 = min(n, r0 + chunk_rays)
         sl, rows = slice(r0, r1), slice(r0 * S, r1 * S)
         val, c, a, g = step_gradients(w_np, spec, np.asarray(rays_o)[sl], np.asarray(rays_d)[sl], z[sl], np.asarray(parameters)[sl],
@@ -184,7 +189,16 @@ def step_gradients_chunked(w_np, spec, rays_o, rays_d, z, parameters, cone_scale
                                       masks=None if masks is None else [np.asarray(m[rows], np.float64) for m in masks],
                                       sigma_mask=None if sigma_mask is None else np.asarray(sigma_mask[sl], np.float64),
                                       noise=None if noise is None else np.asarray(noise)[sl], **kw)
-        wgt = (r1 - r0) / n
+        return (r1 - r0) / n, val, c, a, g
+
+    starts = list(range(0, n, chunk_rays))
+    if workers > 1 and len(starts) > 1:
+        with ThreadPoolExecutor(workers) as ex:
+            parts = list(ex.map(one, starts))
+    else:
+        parts = [one(r0) for r0 in starts]
+    total, grads, cs, al = 0.0, None, [], []
+    for wgt, val, c, a, g in parts:                                                      # in chunk order, whatever order they finished in
         total += val * wgt
         grads = [x * wgt for x in g] if grads is None else [acc + x * wgt for acc, x in zip(grads, g)]
         cs.append(c); al.append(a)

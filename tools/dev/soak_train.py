@@ -11,13 +11,7 @@ sys.path.insert(0, ROOT)
 from tests.test_gpu_train import make_model, step_errors                                           # noqa: E402
 
 ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=150); ap.add_argument("--seed", type=int, default=0); ap.add_argument("--only", type=int, nargs="*", default=None)
-ap.add_argument("--configs-batch", action="store_true", help="instead: every shipped family and the ragged neighbour at the configs' full 1024 x 256 batch (the driver-run suite keeps carpet there and the others smaller)")
 a = ap.parse_args()
-if a.configs_batch:
-    from tests.test_gpu_train import test_gradients_at_the_configs_batch as full
-    for case in [("carpet", (1, 6), None, 0.0, 1024, 256), ("carpet", (1, 6), None, 0.0, 1021, 255), ("grass_filtered", (2, 3), 0, 0.1, 1024, 256), ("fur", (1, 4), None, 0.0, 1024, 256)]:
-        t0 = time.time(); full(*case); print("ok", case, round(time.time() - t0, 1), "s", flush=True)
-    sys.exit(0)
 rng = np.random.default_rng(a.seed)
 FAMS = [("carpet", (1, 6)), ("grass", (1, 4)), ("fur", (1, 4)), ("grass_filtered", (2, 3))]
 worst, t0, fails, waived = {"loss": 0.0, "pred": 0.0, "grad": 0.0}, time.time(), [], 0
