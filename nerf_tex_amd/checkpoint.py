@@ -255,6 +255,16 @@ def write_manager_state(checkpoint_dir: str, prefixes) -> None:
         f.write(f'model_checkpoint_path: "{names[-1]}"\n' + "".join(f'all_model_checkpoint_paths: "{n}"\n' for n in names))
 
 
+def read_manager_state(checkpoint_dir: str):
+    """Prefixes listed as `all_model_checkpoint_paths` in the directory's `checkpoint` file, oldest first: the checkpoints a
+    CheckpointManager still rotates ([] without the file).  Checkpoints kept for good (`keep_every_n_hours`) are NOT in that list."""
+    path = os.path.join(checkpoint_dir, "checkpoint")
+    if not os.path.exists(path):
+        return []
+    names = re.findall(r'^all_model_checkpoint_paths:\s*"([^"]+)"', open(path).read(), flags=re.M)
+    return [n if os.path.isabs(n) else os.path.join(checkpoint_dir, n) for n in names]
+
+
 _VAR = re.compile(r"^(?P<root>.+?)/layer_with_weights-(?P<i>\d+)/(?P<kind>kernel|bias)/\.ATTRIBUTES/VARIABLE_VALUE$")
 
 

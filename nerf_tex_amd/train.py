@@ -524,9 +524,16 @@ def Train(target_path: str, train_dataset=None, val_dataset=None, model_config: 
             dp_comm = Comm(device)
     cb = getattr(train_dataset, "composite_bkgd", False) if composite_bkgd is None else composite_bkgd
     bc = getattr(train_dataset, "bkgd_color", (1., 1., 1.)) if bkgd_color is None else bkgd_color
-    # (CheckpointManager keeps its list of kept checkpoints in the directory's `checkpoint` file: a resumed run goes on rotating the old ones)
+    # CheckpointManager keeps the list of checkpoints it still rotates in the directory's `checkpoint` file (all_model_checkpoint_paths): a
+    # resumed run goes on rotating THOSE.  A checkpoint kept for good (keep_every_n_hours) is not in the list and is never deleted; without
+    # the file, the newest max_to_keep found are taken as the list (never more: nothing this run cannot account for is removed).
     import re
-    found = sorted((int(m.group(1)), os.path.join(ckpt_dir, f[:-6])) for f in os.listdir(ckpt_dir) for m in [re.fullmatch(r"ckpt-(\d+)\.index", f)] if m)
+    listed = [p for p in checkpoint.read_manager_state(ckpt_dir) if os.path.exists(p + ".index")]
+    if listed:
+        found = [(0, p) for p in listed]
+    else:
+        found = sorted((int(m.group(1)), os.path.join(ckpt_dir, f[:-6])) for f in os.listdir(ckpt_dir) for m in [re.fullmatch(r"ckpt-(\d+)\.index", f)] if m)
+        found = found[-keep:] if keep > 0 else found
     out = {"trainer": trainer, "renderer": renderer, "loss": [], "images": {}, "checkpoints": [p for _, p in found] if rank == 0 else [], "step": step}
     if step >= n_iters:
         if dp_comm is not None:
