@@ -407,7 +407,7 @@ def bench_train_step(args, emit: bool = True, data_side: bool = True, parity_ray
                                  "encoders, heads, composite, loss and Adam included",
                          "frac_3x_forward": achieved_3x / F32_MFMA_PEAK_TFLOPS,
                          "frac_3x_forward_what": "the same time against 3 x the forward's FLOPs (rounds 4 and 5 quoted this convention: it counts input gradients nobody needs)"}}
-    if world == 1 and parity_rays:
+    if world == 1 and parity_rays and not args.no_parity:
         # the step against the float64 restatement, outside the timed region: the first `parity_rays` rays of the batch as a batch of their own,
         # from the weights the timed steps left -- loss, predictions, every layer's gradient (the oracle follows the float32 ReLU branches)
         from oracle import nerftex_oracle as orc
@@ -442,7 +442,7 @@ def bench_train_step(args, emit: bool = True, data_side: bool = True, parity_ray
                           "what": f"{nb} rays x {S} samples of the batch as a step of their own (perturb off) from the weights the timed steps left: loss, [color, alpha] "
                                   "and every Dense layer's gradient (kernel and bias, relative to the layer's largest entry) against float64 torch autograd of the restated renderer and loss (oracle/train_oracle.py; "
                                   "unpinned: no TensorFlow here)", "oracle_seconds": round(time.perf_counter() - t1, 2)}
-    if world == 1 and fam_name == "carpet" and data_side:
+    if world == 1 and fam_name == "carpet" and data_side and not args.no_extras:
         # the LOOP around the step (train.py:60-67): batches made by nerf_tex_amd.dataset.Dataset as the config asks -- Proxy pixel sampler among the
         # proxy's hits, rays, colours gathered from resident 800 x 800 uint8 views -- and handed to the same step (tools/bench_train_loop.py)
         from nerf_tex_amd import dataset as D, util

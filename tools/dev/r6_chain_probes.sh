@@ -2,7 +2,7 @@
 # GPU box: per-kernel times of the training step for development builds (tools/dev/r6_variant.sh): r6_chain_probes.sh NAME [NAME ...] ("shipped" = the in-tree library)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/probes; mkdir -p $O; cd $R
-P="python bench.py --workload carpet_train_step --steps 10 --warmup 2 --no-cpu-baseline"
+P="python bench.py --workload carpet_train_step --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-parity"
 for V in "$@"; do
   L=""; [ $V != shipped ] && L="$R/build_dev/libntx_$V.so"
   NERFTEX_LIB=$L timeout 120 python bench.py --workload carpet_train_step --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$V', 'ms_per_step', round(d['ms_per_step'],4))"
