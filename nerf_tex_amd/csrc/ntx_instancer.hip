@@ -429,75 +429,6 @@ __device__ __forceinline__ bool closest_uv(const TexArgs &T, float px, float py,
     return true;
 }
 
-// The same query for the 64 lanes of a wave at once, LANES OVER CANDIDATES.  closest_uv gives a lane its query and lets it
-// walk its cell's 10-40 candidates alone: the wave takes as long as its longest list, and 0.57 of the lanes were active
-// (profiles/r04/instancer_texture_256_pmc_summary.json).  Here the (query, candidate) pairs of all 64 queries are laid end to end (a running
-// count of the lists' lengths in LDS) and dealt 64 at a time, one pair a lane: the pair's owner by binary search in the counts, the
-// reference's closest_point_triangle on it, and the owner's best as an LDS atomic minimum of (distance bits << 32 | primID) -- distances are
-// non-negative floats, so the integer order IS (distance, primID) lexicographic: the nearest within the radius, the lowest primID of several
-// at one distance, whatever order the pairs are met in.  That is what closest_uv's loop keeps.  The winner's barycentrics are worked out
-// once more by its owner (the same pure function on the same inputs: the same bits).  Every lane of the wave must call this.
-template <class TX_T>
-__device__ __forceinline__ bool closest_uv_wave(const TexArgs &T, TX_T &TX, bool valid, float px, float py, float pz, float *u_out, float *v_out) {
-    const int lane = (int)(threadIdx.x & 63);
-    int s0 = 0, cnt = 0;
-    if (valid) {
-        const float fx = (px - T.gmin[0]) * T.inv_cell, fy = (py - T.gmin[1]) * T.inv_cell, fz = (pz - T.gmin[2]) * T.inv_cell;
-        if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)T.dim[0] && fy < (float)T.dim[1] && fz < (float)T.dim[2]) {
-            const size_t cell = ((size_t)(int)fz * T.dim[1] + (int)fy) * T.dim[0] + (int)fx;
-            s0 = T.cell_start[cell]; cnt = T.cell_start[cell + 1] - s0;
-        }
-    }
-    int incl = cnt;
-    for (int o = 1; o < 64; o <<= 1) { const int w = __shfl_up(incl, o); if (lane >= o) incl += w; }
-    const int total = __shfl(incl, 63);
-    const unsigned long long none = ((unsigned long long)__float_as_uint(T.radius) << 32) | 0xffffffffull;     // nothing strictly within the radius yet
-    __builtin_amdgcn_wave_barrier();                       // (whoever still reads the previous pass's tables is done)
-    TX.qx[lane] = px; TX.qy[lane] = py; TX.qz[lane] = pz; TX.qs0[lane] = s0; TX.qoff[lane] = incl - cnt; TX.qkey[lane] = none;
-    if (lane == 63) TX.qoff[64] = total;
-    __builtin_amdgcn_wave_barrier();
-    for (int p0 = 0; p0 < total; p0 += 64) {
-        const int pr = p0 + lane;
-        if (pr < total) {
-            int o = 0;                                     // the largest o with qoff[o] <= pr: its list is not empty, and pr falls into it
-#pragma unroll
-            for (int st = 32; st > 0; st >>= 1) if (TX.qoff[o + st] <= pr) o += st;
-            const int f = T.cand[TX.qs0[o] + (pr - TX.qoff[o])];
-            const float *tr = T.tris + (size_t)f * 9;
-            const float p[3] = {TX.qx[o], TX.qy[o], TX.qz[o]}, a[3] = {tr[0], tr[1], tr[2]}, b[3] = {tr[3], tr[4], tr[5]}, c[3] = {tr[6], tr[7], tr[8]};
-            float w[3];
-            const float d = closest_point_triangle(p, a, b, c, w);
-            if (d < T.radius) atomicMin(&TX.qkey[o], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)f);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const unsigned long long k = TX.qkey[lane];
-    const uint32_t best_f = (uint32_t)(k & 0xffffffffull);
-    if (!valid || best_f == 0xffffffffu) return false;
-    const float *tr = T.tris + (size_t)best_f * 9;
-    const float p[3] = {px, py, pz}, a[3] = {tr[0], tr[1], tr[2]}, b[3] = {tr[3], tr[4], tr[5]}, c[3] = {tr[6], tr[7], tr[8]};
-    float bw[3];
-    (void)closest_point_triangle(p, a, b, c, bw);
-    const float *uv = T.face_uv + (size_t)best_f * 6;                                          // UV.row(f0) * w0 + UV.row(f1) * w1 + UV.row(f2) * w2 (:661)
-    *u_out = (uv[0] * bw[0] + uv[2] * bw[1]) + uv[4] * bw[2];
-    *v_out = (uv[1] * bw[0] + uv[3] * bw[1]) + uv[5] * bw[2];
-    return true;
-}
-
-// ... and getParameters' texture values on top of it (texture_values below, for the 64 lanes of a wave)
-template <class TX_T>
-__device__ __forceinline__ void texture_values_wave(const TexArgs &T, TX_T &TX, bool valid, const float *par, float px, float py, float pz, float *val) {
-    float u = 0.0f, v = 0.0f;
-    const bool found = closest_uv_wave(T, TX, valid, px, py, pz, &u, &v);
-#pragma unroll
-    for (int q = 0; q < MAX_TEX_FILES; ++q) {
-        if (q < T.n_tex) {
-            const float p0 = par[T.par_idx[q]];
-            val[q] = found ? p0 * interpolate2d(T.texels, T.table[q], u, v) : p0;
-        } else val[q] = 0.0f;
-    }
-}
-
 // getParameters (instancer.cpp:640-667) for the texture parameters only: val[q] = parameter par_idx[q] * texture q at the closest point
 // of the mesh, or the parameter as given when nothing lies within reach
 __device__ __forceinline__ void texture_values(const TexArgs &T, const float *par, float px, float py, float pz, float *val) {
@@ -586,8 +517,6 @@ struct TexLds {
     float ring[MAX_TEX_FILES][TEX_RING];      // value of texture parameter q at sample x: ring[q][x % TEX_RING]
     float sl[MAX_HITS / 2 + 2];               // the spacing of a segment's texture samples
     uint16_t base[MAX_HITS / 2 + 4];          // first sample of segment i; [n_segments] = number of samples
-    // closest_uv_wave: the 64 queries of a pass -- their points, their cells' candidate ranges as one running count, their winners
-    float qx[64], qy[64], qz[64]; int32_t qs0[64], qoff[65]; unsigned long long qkey[64];
 };
 struct NoLds {};
 template <bool SHADOW, bool TEX> struct MarchLds {
@@ -1348,16 +1277,13 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
                         for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(lo, o); lo = w < lo ? w : lo; }
                         while (tex_produced < tex_entries && tex_produced + 64 - TEX_RING <= lo) {
                             const int x = tex_produced + lane;
-                            float tk = 0.0f;
                             if (x < tex_entries) {
                                 int si = 0;
                                 for (int q = 1; q < n_starts; ++q) si += (int)TX.base[q] <= x ? 1 : 0;
                                 const int kk = x - (int)TX.base[si];
-                                tk = SG.ts[si] + (float)(uint32_t)kk * TX.sl[si];
-                            }
-                            float val[MAX_TEX_FILES];
-                            texture_values_wave(a.tex, TX, x < tex_entries, L.par, ox + tk * dx, oy + tk * dy, oz + tk * dz, val);   // (every lane: the pairs are dealt over the wave)
-                            if (x < tex_entries) {
+                                const float tk = SG.ts[si] + (float)(uint32_t)kk * TX.sl[si];
+                                float val[MAX_TEX_FILES];
+                                texture_values(a.tex, L.par, ox + tk * dx, oy + tk * dy, oz + tk * dz, val);
 #pragma unroll
                                 for (int q = 0; q < MAX_TEX_FILES; ++q) TX.ring[q][x & (TEX_RING - 1)] = val[q];
                             }
@@ -1371,7 +1297,7 @@ __device__ __forceinline__ void march_ray(const MarchArgs &a, MarchLds<SHADOW, T
                         }
                     }
                 } else {
-                    texture_values_wave(a.tex, TX, live, L.par, px, py, pz, tv0);                // :926
+                    texture_values(a.tex, L.par, px, py, pz, tv0);                               // :926
                 }
             }
         }
