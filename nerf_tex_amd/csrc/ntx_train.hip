@@ -646,8 +646,10 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     t->ptiles = (Kp + 31) / 32; t->dtiles = (Kd + 31) / 32;
     {   // the forward chain's build for these segment lengths, or the longest one (the streams are then padded with zero rows)
         const int psg = ((Kp + 1) / 2 + 3) / 4, dsg = ((Kd + 1) / 2 + 3) / 4;
-        t->fwd_variant = 3;
-        for (int v = 0; v < 3; ++v) if (FWD_VARIANTS[v][0] == psg && FWD_VARIANTS[v][1] == dsg) t->fwd_variant = v;
+        t->fwd_variant = 3;                                  // the smallest build that holds both segments
+        for (int v = 2; v >= 0; --v)
+            if (FWD_VARIANTS[v][0] >= psg && FWD_VARIANTS[v][1] >= dsg &&
+                FWD_VARIANTS[v][0] + FWD_VARIANTS[v][1] <= FWD_VARIANTS[t->fwd_variant][0] + FWD_VARIANTS[t->fwd_variant][1]) t->fwd_variant = v;
         t->PS = 4 * FWD_VARIANTS[t->fwd_variant][0]; t->DS = 4 * FWD_VARIANTS[t->fwd_variant][1];
     }
     size_t p = 0;

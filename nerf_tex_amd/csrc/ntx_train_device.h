@@ -626,9 +626,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif   // NTX_TRAIN_DW
 
 // the launchers of ntx_train_chain.hip (one object per kernel: each takes minutes to compile).  The forward chain exists for the segment
-// lengths of the shipped families -- (9, 11) carpet, (9, 8) grass / fur / plush, (11, 7) grass_filtered -- and for the longest (12, 12),
-// which any other model runs on with its streams padded with zero rows.
-constexpr int FWD_VARIANTS[4][2] = {{9, 11}, {9, 8}, {11, 7}, {MAX_PB_GROUPS, MAX_PB_GROUPS}};
+// lengths of the shipped families -- (9, 11) carpet, (9, 8) grass / fur / plush, (11, 8) grass_filtered -- and for the longest (12, 12); a model
+// runs on the smallest build that holds its segments, its streams padded with zero rows.  (grass_filtered needs (11, 7): that build, like every
+// one tried with a direction segment shorter than 8 groups, makes hipcc spill four bias tiles -- 64 scratch instructions a block, each reload
+// behind a full s_waitcnt vmcnt(0); one group of zero rows more costs 32 MFMAs of 10 656 and none of that.  profiles/r06/train_probes.md)
+constexpr int FWD_VARIANTS[4][2] = {{9, 11}, {9, 8}, {11, 8}, {MAX_PB_GROUPS, MAX_PB_GROUPS}};
 void launch_fwd_chain(int variant, hipStream_t st, unsigned grid, const FwdArgs &a);
 void launch_dx_chain(hipStream_t st, unsigned grid, const DxArgs &a);
 void launch_dw(hipStream_t st, unsigned grid, const DwArgs &a);
