@@ -21,7 +21,10 @@ def _run(*extra):
 
 
 def test_default_line_has_the_contract_fields():
-    d = _run("--no-cpu-baseline")
+    d = _run("--cpu-baseline-seconds", "2")
+    c = d["cpu_baseline"]                               # the reference's CPU path beside it: a bounded sample, threads and BLAS backend stated
+    assert c["kind"] == "port" and c["unit"] == "ray-samples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["cpu_count"] >= c["cores"] and "BLAS_INFO" in c["blas"] and d["value"] > 50 * c["value"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
         assert k in d, k
@@ -140,13 +143,6 @@ def test_two_ranks_sharing_the_gpu_run_the_whole_multi_rank_bench(workload, shar
         assert d["scaling"] == "weak" and all(p["rays"] == 640000 for p in pr) and d["efficiency_vs_rank0_alone"] > 0
         assert d["sharded_image_bit_identical_to_1gpu"] is True      # the two bands as gathered against rank 0 rendering both alone
     assert "rccl_version" in d and all("comm_init_s" in p for p in pr)
-
-
-def test_cpu_baseline_block():
-    d = _run("--workload", "fur", "--cpu-baseline-seconds", "3", "--no-extras")
-    c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["unit"] == "ray-samples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
-    assert c["cpu_count"] >= c["cores"] and "BLAS_INFO" in c["blas"]       # threads and BLAS backend stated
 
 
 def test_train_step_line_at_one_and_at_two_ranks():

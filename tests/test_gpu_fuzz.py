@@ -11,7 +11,7 @@ from tests.common import TOL, make_model
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-ORACLE_RAYS = 1500      # the GPU renders every ray of a case; the three restatement passes (float64, float32, float64 on float32 points) run on
+ORACLE_RAYS = 800       # the GPU renders every ray of a case; the three restatement passes (float64, float32, float64 on float32 points) run on
                         # at most this many of the hit rays -- a seeded draw that always holds the first and the last hit ray (block edges)
 
 
