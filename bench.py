@@ -737,6 +737,7 @@ def main() -> None:
     ap.add_argument("--deadline", type=float, default=float(os.environ.get("NTX_BENCH_DEADLINE", "600")),
                     help="multi-rank runs: seconds after which the launcher ends all ranks / every rank's watchdog exits")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of 256 rays after the timed region")
+    ap.add_argument("--scene-parity-rays", type=int, default=48, help="carpet_instanced_scene: rays of the timed chunk checked against the restated instancer + renderer (0.14 s of host time a ray)")
     ap.add_argument("--raw-noise-std", type=float, default=0.0, help="raw_noise_std of the renderer (renderer.py:190-192), drawn inside the kernel")
     ap.add_argument("--instanced-per-sample-dirs", action="store_true",
                     help="carpet_instanced: every marching sample its own direction and appearance parameters (the round-2 workload) instead of one per run")
@@ -746,7 +747,7 @@ def main() -> None:
     if args.workload == "carpet_instanced":
         return bench_instanced(args)
     if args.workload == "carpet_instanced_scene":
-        return bench_instanced_scene(args)
+        return bench_instanced_scene(args, parity_rays=args.scene_parity_rays)
     if args.workload.endswith("_train_step"):
         return bench_train_step(args)
 
