@@ -381,6 +381,38 @@ __global__ __launch_bounds__(64) void encode_kernel(EncodeArgs a) {
     }
 }
 
+// The colour layer's direction segment once per ray (fwd_chain_kernel's HOIST builds): row[f] = bias_C1[f] + sum_k dir_map[k] W_C1[k][f] over
+// the Kd rows of dir_map = FourierFeatures(direction) | FourierFeatures(appearance parameters) (model.py:96-101, 115), written in the
+// accumulators' order [ray][half h][16 T + 4 g + c] for feature 32 T + 8 g + 4 h + c.  Workgroup per ray, thread per output feature.
+struct DirRowArgs {
+    const float *rays_d, *params; long long rays_per_param_row;
+    int n_rays, n_geo, n_app, dir_freq, param_freq, Kd;
+    const float *w, *bias;                     // W_C1 [Kd + 256][256] (its first Kd rows), bias_C1 [256]
+    float *rows;
+};
+__global__ __launch_bounds__(256) void dirrow_kernel(DirRowArgs a) {
+    __shared__ float feat[8 * MAX_PB_GROUPS];
+    const int ray = blockIdx.x, f = threadIdx.x;
+    const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
+    const float dn = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    const int P = a.n_geo + a.n_app;
+    const float *pr = a.params + (size_t)(ray / a.rays_per_param_row) * (P > 0 ? P : 1);
+    if (f < a.Kd) {                                                                             // row f of dir_map, as encode_kernel lays it out
+        const int K3 = 3 * (1 + 2 * a.dir_freq);
+        const int r = f < K3 ? f : f - K3, D = f < K3 ? 3 : a.n_app;
+        auto x = [&](int c) { return f < K3 ? d[c] / dn : pr[a.n_geo + c]; };                  // renderer.py:98; model.py:96-101
+        float v;
+        if (r < D) v = x(r);
+        else { const int q = r - D, band = q / (2 * D), hc = q - band * 2 * D, hh = hc / D, c = hc - hh * D; v = ntx::sin_q(ldexpf(1.0f, band) * x(c), hh); }
+        feat[f] = v;
+    }
+    __syncthreads();
+    float acc = a.bias[f];
+    for (int k = 0; k < a.Kd; ++k) acc = fmaf(feat[k], a.w[(size_t)k * 256 + f], acc);
+    const int T = f >> 5, g = (f >> 3) & 3, h = (f >> 2) & 1, c = f & 3;
+    a.rows[(size_t)ray * 256 + h * 128 + 16 * T + 4 * g + c] = acc;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // map_model_output (renderer.py:170-213) per ray, the ray's terms of the loss (loss.py: both losses are means over the rays, so a ray's
 // gradient needs nothing of the others) and the adjoint of both; wave per ray, lane l holds samples l, l + 64, ...
@@ -567,6 +599,7 @@ struct ntx_trainer {
     unsigned int *bits = nullptr; long long bits_stride = 0;   // ten: h0 .. h7, c1o, c2o
     int fwd_variant = 0;
     float *sigma = nullptr, *raw_rgb = nullptr, *z = nullptr, *dists = nullptr, *noise = nullptr;
+    float *dirrow = nullptr;                   // [max_rays][256]: the colour layer's direction segment per ray (dirrow_kernel)
     // backward: the composite's adjoint, the gradient at every layer's output (O layout: d c2o, d c1o, d feature, dy7 .. dy0)
     float *dgrad = nullptr, *dhead = nullptr, *gout = nullptr; long long gout_stride = 0;
     ntx_train::DwJob *jobs = nullptr; int n_jobs = 0; long long total_cost = 0;      // the weight gradients' jobs (ntx_train_device.h), their costs per block added up
@@ -588,7 +621,7 @@ void free_all(ntx_trainer *t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
     void *ptrs[] = {t->w, t->grad, t->adam_m, t->adam_v, t->wfwd, t->wdx, t->aux, t->pack_seg, t->posO, t->dirO, t->sigma, t->raw_rgb, t->z, t->dists, t->noise,
-                    t->dgrad, t->dhead, t->jobs, t->dw_partial, t->stash, t->color, t->alpha_out, t->ray_loss, t->loss, t->act, t->bits, t->gout};
+                    t->dgrad, t->dhead, t->jobs, t->dw_partial, t->stash, t->dirrow, t->color, t->alpha_out, t->ray_loss, t->loss, t->act, t->bits, t->gout};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete t;
 }
@@ -604,13 +637,17 @@ void launch_gemm(hipStream_t st, GemmArgs g) {
 }   // namespace
 
 namespace ntx_train {
-template <int K> void launch_fwd_variant(hipStream_t st, unsigned grid, const FwdArgs &a);      // ntx_train_chain.hip, one object each
-void launch_fwd_chain(int variant, hipStream_t st, unsigned grid, const FwdArgs &a) {
-    switch (variant) {
-        case 0: launch_fwd_variant<0>(st, grid, a); break;
-        case 1: launch_fwd_variant<1>(st, grid, a); break;
-        case 2: launch_fwd_variant<2>(st, grid, a); break;
-        default: launch_fwd_variant<3>(st, grid, a); break;
+template <int K, bool HOIST> void launch_fwd_variant(hipStream_t st, unsigned grid, const FwdArgs &a);      // ntx_train_chain.hip, one object each
+void launch_fwd_chain(int variant, bool hoist, hipStream_t st, unsigned grid, const FwdArgs &a) {
+    switch (variant * 2 + (hoist ? 1 : 0)) {
+        case 0: launch_fwd_variant<0, false>(st, grid, a); break;
+        case 1: launch_fwd_variant<0, true>(st, grid, a); break;
+        case 2: launch_fwd_variant<1, false>(st, grid, a); break;
+        case 3: launch_fwd_variant<1, true>(st, grid, a); break;
+        case 4: launch_fwd_variant<2, false>(st, grid, a); break;
+        case 5: launch_fwd_variant<2, true>(st, grid, a); break;
+        case 6: launch_fwd_variant<3, false>(st, grid, a); break;
+        default: launch_fwd_variant<3, true>(st, grid, a); break;
     }
 }
 }   // namespace ntx_train
@@ -677,6 +714,7 @@ int ntx_trainer_create(const ntx_model_desc *desc, const float *weights, size_t 
     auto act = [&](int i) { return t->act + (size_t)i * t->act_stride; };
     auto gout = [&](int i) { return t->gout + (size_t)i * t->gout_stride; };
     alloc(&t->sigma, (size_t)M); alloc(&t->raw_rgb, (size_t)M * 3); alloc(&t->z, (size_t)M); alloc(&t->dists, (size_t)M); alloc(&t->noise, (size_t)M);
+    alloc(&t->dirrow, (size_t)max_rays * 256);
     alloc(&t->dgrad, (size_t)NB * 32 * 4); alloc(&t->dhead, (size_t)NB * 1024, true);       // rows 4 .. 31 of the heads' dY tile stay zero
     alloc(&t->color, (size_t)max_rays * 3); alloc(&t->alpha_out, (size_t)max_rays); alloc(&t->ray_loss, (size_t)max_rays); alloc(&t->loss, 1);
     if (rc == NTX_OK && hipMemcpy(t->w, weights, p * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = ntx_set_error(NTX_E_HIP, "weight upload failed");
@@ -980,7 +1018,17 @@ int ntx_train_step_gradients(ntx_trainer *t, const float *rays_o, const float *r
         f.ptiles = t->ptiles; f.dtiles = t->dtiles; f.pos = t->posO; f.dir = t->dirO;
         f.act = t->act; f.act_stride = t->act_stride; f.bits = t->bits; f.bits_stride = t->bits_stride;
         f.sigma = t->sigma; f.raw_rgb = t->raw_rgb;
-        launch_fwd_chain(t->fwd_variant, st, chain_grid, f);
+        // the direction segment of the colour layer per ray instead of per sample -- unless blur_idx scales an APPEARANCE parameter per sample
+        // (renderer.py:155-158) or a block of 32 samples can lie in two rays (S no multiple of 32)
+        const bool hoist = (blur_idx < 0 || blur_idx < t->desc.n_geo) && S % 32 == 0 && getenv("NERFTEX_TRAIN_NO_DIR_HOIST") == nullptr;
+        if (hoist) {
+            DirRowArgs dr{}; dr.rays_d = rays_d; dr.params = params; dr.rays_per_param_row = rays_per_param_row; dr.n_rays = (int)n_rays; dr.n_geo = t->desc.n_geo;
+            dr.n_app = t->desc.n_app; dr.dir_freq = t->desc.dir_freq; dr.param_freq = t->desc.param_freq; dr.Kd = t->Kd; dr.w = t->w + t->c1.w; dr.bias = t->w + t->c1.b;
+            dr.rows = t->dirrow;
+            hipLaunchKernelGGL(dirrow_kernel, dim3((unsigned)n_rays), dim3(256), 0, st, dr);
+        }
+        f.dirrow = t->dirrow; f.n_rays = (int)n_rays; f.S = S;
+        launch_fwd_chain(t->fwd_variant, hoist, st, chain_grid, f);
     }
     // ---- the composite, the loss (loss.py) and their adjoint ------------------------------------------------------------------------
     {

@@ -232,13 +232,23 @@ struct FwdArgs {
     float *act; long long act_stride;                  // O layout, act + i * act_stride: h0 .. h7 (256 rows), feature (256), c1o (256), c2o (128)
     unsigned int *bits; long long bits_stride;         // h0 .. h7, c1o, c2o: [block][64 lanes][4 words]
     float *sigma, *raw_rgb;                            // [M], [M][3]
+    // HOIST builds: the colour layer's direction segment once per RAY (dirrow_kernel): bias_C1 + W_C1[:dir_map]^T . dir_map in accumulator
+    // order, [n_rays][half][128]; S samples a ray (a multiple of 32)
+    const float *dirrow; int n_rays, S;
 };
 
 #ifdef NTX_TRAIN_FWD
-// PSG / DSG: groups of 4 k-steps of the position / direction segment (the stream pads them with zero rows)
-template <int PSG, int DSG>
+// PSG / DSG: groups of 4 k-steps of the position / direction segment (the stream pads them with zero rows).
+// HOIST: Renderer.evaluate_model repeats the view direction and the appearance parameters for every sample of a ray (renderer.py:152-154), so
+// the direction segment of the colour layer is ONE vector per ray -- 8 DSG of the block's 10 656 MFMAs recompute a constant (the render
+// kernels hoist it too).  The HOIST build starts the colour layer's accumulators from the ray's row (bias included; staged in
+// the wave's LDS and read exactly like a bias) and steps over the segment's records in the stream (whole ring turns: the ring is primed again
+// behind them).  The weight gradients still contract the per-sample dir_map rows (encode_kernel); nothing else changes.  Not for a blur_idx
+// on an appearance parameter (:155-158) nor for S that is no multiple of 32 (a block then lies in two rays): the host picks the build.
+template <int PSG, int DSG, bool HOIST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fwd_chain_kernel(FwdArgs a) {
     __shared__ __attribute__((aligned(16))) float aux_lds[AUX_FLOATS];
+    __shared__ __attribute__((aligned(16))) float rows_lds[HOIST ? 4 * 256 : 4];      // HOIST: per wave the row of the ray its block lies in
     ntx::load_aux(aux_lds, a.aux, AUX_FLOATS);
     const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = gridDim.x * 4;
@@ -251,6 +261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (row 2 S + h, sample n) of an O-layout block: this lane's part of the offset, and S's: (S >> 4) * 4096 + (S & 15) * 32
     const uint32_t lane_o = o_lane_bytes(lane), lane_r = (uint32_t)((n >> 3) * 1024 + ((n >> 2) & 1) * 512 + (n & 3) * 4 + h * 16), lane16 = (uint32_t)lane * 16u;
     float pb[12];
+    const __amdgpu_buffer_rsrc_t rs_row = make_rsrc(a.dirrow, HOIST ? (long long)a.n_rays * 1024 : 0);
     __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.pos + (size_t)wave * a.ptiles * 1024, (long long)a.ptiles * 4096);
     auto fetch = [&](auto G) {                          // group G of the segment rs_in points at
         constexpr int g = G;
@@ -266,11 +277,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         uint32_t opaque_zero = 0;
         asm volatile("" : "+v"(opaque_zero));
         const float *aux = aux_lds + opaque_zero;
+        const float *rows_aux = rows_lds + opaque_zero + (HOIST ? (threadIdx.x >> 6) * 256 : 0) - AUX_BIAS - 9 * 256;     // bias_tile(.., rows_aux, 9, h) reads the ray's row
         uint32_t sbase = 0;
-        f32x16 accA[8], accB[8];
+        f32x16 acc[8];                                     // ONE accumulator set (see the note at `layer` below)
         float hin[128];
         const long long m = (long long)blk * 32 + n;
         const bool valid = m < a.M;
+        if constexpr (HOIST) {
+            // the block's ray's row -- 1 KiB, 16 bytes a lane -- into the wave's LDS now, while no layer's operands are live
+            const uint32_t ray = __builtin_amdgcn_readfirstlane((int)(((uint32_t)blk * 32u) / (uint32_t)a.S));
+            const f32x4 x0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_row, lane16, (ray < (uint32_t)a.n_rays ? ray : (uint32_t)a.n_rays - 1u) * 1024u, 0));
+            *reinterpret_cast<f32x4 *>(rows_lds + (threadIdx.x >> 6) * 256 + lane * 4) = x0;
+            __builtin_amdgcn_wave_barrier();
+        }
         // input `idx` of the chain (h0 .. h7, feature, c1o) leaves for memory one value per k-step while the layer that reads it runs
         __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.act, 0);
         auto leaves_to = [&](int idx, int tiles) { rs_out = make_rsrc(a.act + (size_t)idx * a.act_stride + (size_t)blk * tiles * 1024, (long long)tiles * 4096); };
@@ -287,18 +306,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
         };
         // ---- trunk layer 0: pos_map -> 256 (model.py:104-106)
-        // (an accumulator set starts from its layer's bias: LDS reads, as soon as the set is free -- behind the conversion that drained it)
-        static_for<8>([&](auto T) { bias_tile<decltype(T)::value>(accA, aux, 0, h); });
-        static_for<8>([&](auto T) { bias_tile<decltype(T)::value>(accB, aux, 1, h); });
-        seg_mem<PSG>(accA, ws, sbase, pb, fetch);
+        // (the accumulators start from their layer's bias: LDS reads straight into them)
+        static_for<8>([&](auto T) { bias_tile<decltype(T)::value>(acc, aux, 0, h); });
+        seg_mem<PSG>(acc, ws, sbase, pb, fetch);
         float sig_part = 0.0f;
-        // ---- layers LI = 1 .. 10: trunk 1 .. 7, the feature layer (8, linear), the colour layers (9: 256, 10: 128)
-        auto layer = [&](auto LIc, f32x16 (&cur)[8], f32x16 (&prev)[8]) {
+        // ---- layers LI = 1 .. 10: trunk 1 .. 7, the feature layer (8, linear), the colour layers (9: 256, 10: 128).
+        // Round 5 alternated TWO accumulator sets so that a layer's bias could be read while the layer before ran: 16 tiles = all 256 AGPRs live
+        // through every layer, an exact fit that hipcc's allocator met for some segment lengths and not for others (four bias tiles spilled in the
+        // middle of the chain, each reload behind a full vmcnt(0): profiles/r06/train_probes.md).  One set: the layer's results are converted
+        // out of it, its bias is read into it (32 LDS reads between two layers: ~300 of a layer's 65 000 cycles), and half the AGPRs are free.
+        auto layer = [&](auto LIc) {
+            f32x16 (&cur)[8] = acc; f32x16 (&prev)[8] = acc;
             constexpr int LI = decltype(LIc)::value, in_idx = LI - 1;
             constexpr bool relu_in = in_idx != 8;                    // the feature layer is linear (model.py:114)
             u32x4 bw = {0u, 0u, 0u, 0u};
-            if constexpr (relu_in) { convert_relu_bits<8>(hin, prev, bw); bits_leave(in_idx < 8 ? in_idx : 8, bw); }
-            else convert_linear<8>(hin, prev);
+            if constexpr (HOIST && LI == 9) {
+                // step over the direction segment's records (DSG ring turns: the ring's phase stays) and prime the ring behind them, now --
+                // the conversion below runs while they arrive
+                sbase += (uint32_t)DSG * 8192u;
+                static_for<RING>([&](auto I) { ws.r[I] = wr_load(ws, sbase + (uint32_t)decltype(I)::value * 1024u); });
+            }
+            // two tiles at a time: their 32 values out of the accumulators (ReLU, mask bits), then this layer's bias into the two tiles just
+            // drained -- the LDS reads of a pair run under the conversion of the next
+            static_for<4>([&](auto W) {
+                constexpr int wd = W;
+                if constexpr (relu_in) {
+                    uint32_t w = 0;
+                    static_for<4>([&](auto Q) { convert8_relu_bits<32 * wd + 8 * decltype(Q)::value>(hin, prev, w); });
+                    bw[wd] = w;
+                } else static_for<32>([&](auto V) { constexpr int v = 32 * wd + decltype(V)::value; hin[v] = prev[v >> 4][v & 15]; });
+                const float *bsrc = (HOIST && LI == 9) ? rows_aux : aux;      // (HOIST: the colour layer starts from the ray's row)
+                if constexpr (LI < 10 || wd < 2) { bias_tile<2 * wd>(cur, bsrc, LI, h); bias_tile<2 * wd + 1>(cur, bsrc, LI, h); }
+            });
+            if constexpr (relu_in) bits_leave(in_idx < 8 ? in_idx : 8, bw);
             if constexpr (LI == 8) {                                 // the density head rides on h7 (model.py:111): one dense block of FMAs
                 const f32x4 *wa = reinterpret_cast<const f32x4 *>(aux + AUX_ALPHA_W + h * 128);
                 static_for<32>([&](auto I) {
@@ -309,36 +349,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (LI < 10) static_for<(LI == 9 ? 4 : 8)>([&](auto T) { bias_tile<decltype(T)::value>(prev, aux, LI + 1, h); });
-            __builtin_amdgcn_sched_barrier(0);
             leaves_to(in_idx, 8);
             if constexpr (LI == 5) seg_mem<PSG>(cur, ws, sbase, pb, fetch);        // concat[pos_map, h4] (model.py:107-108)
-            if constexpr (LI == 9) seg_mem<DSG>(cur, ws, sbase, pb, fetch);        // concat[dir_map, feature] (model.py:115)
+            if constexpr (LI == 9 && !HOIST) seg_mem<DSG>(cur, ws, sbase, pb, fetch);        // concat[dir_map, feature] (model.py:115)
             // the next memory-fed segment's first two groups are asked for a layer ahead (this block's position again for the skip, its
             // direction for the colour layer, the next block's position)
             if constexpr (LI == 4) rs_in = make_rsrc(a.pos + (size_t)blk * a.ptiles * 1024, (long long)a.ptiles * 4096);
-            if constexpr (LI == 8) rs_in = make_rsrc(a.dir + (size_t)blk * a.dtiles * 1024, (long long)a.dtiles * 4096);
+            if constexpr (LI == 8 && !HOIST) rs_in = make_rsrc(a.dir + (size_t)blk * a.dtiles * 1024, (long long)a.dtiles * 4096);
             if constexpr (LI == 10) {
                 const int nb = blk + nwaves < n_blocks ? blk + nwaves : blk;
                 rs_in = make_rsrc(a.pos + (size_t)nb * a.ptiles * 1024, (long long)a.ptiles * 4096);
             }
             auto extra = [&](auto S, auto MT) {
                 constexpr int s = decltype(S)::value, mt = decltype(MT)::value;
-                if constexpr ((LI == 4 || LI == 8 || LI == 10) && mt == 2 && (s == 8 || s == 24)) fetch(std::integral_constant<int, (s == 8 ? 0 : 1)>{});
+                if constexpr ((LI == 4 || (LI == 8 && !HOIST) || LI == 10) && mt == 2 && (s == 8 || s == 24)) fetch(std::integral_constant<int, (s == 8 ? 0 : 1)>{});
                 if constexpr (mt == 5 || (LI == 10 && mt == 3)) leave(S);
             };
             if constexpr (LI == 10) seg_hidden<128, 4, false>(cur, ws, sbase, hin, extra);
             else seg_hidden<128, 8, false>(cur, ws, sbase, hin, extra);
         };
-        static_for<10>([&](auto I) {
-            constexpr int li = decltype(I)::value + 1;
-            if constexpr (li & 1) layer(std::integral_constant<int, li>{}, accB, accA);
-            else layer(std::integral_constant<int, li>{}, accA, accB);
-        });
-        // ---- c2o (the 128-wide colour layer, in set A: layer 10 is even): ReLU, bits, out; the 3-wide colour head on the VALU (model.py:123)
+        static_for<10>([&](auto I) { layer(std::integral_constant<int, decltype(I)::value + 1>{}); });
+        // ---- c2o (the 128-wide colour layer): ReLU, bits, out; the 3-wide colour head on the VALU (model.py:123)
         {
             u32x4 bw = {0u, 0u, 0u, 0u};
-            convert_relu_bits<4>(hin, accA, bw);
+            convert_relu_bits<4>(hin, acc, bw);
             bits_leave(9, bw);
             leaves_to(10, 4);
             static_for<64>([&](auto V) { leave(V); });
@@ -631,7 +665,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // one tried with a direction segment shorter than 8 groups, makes hipcc spill four bias tiles -- 64 scratch instructions a block, each reload
 // behind a full s_waitcnt vmcnt(0); one group of zero rows more costs 32 MFMAs of 10 656 and none of that.  profiles/r06/train_probes.md)
 constexpr int FWD_VARIANTS[4][2] = {{9, 11}, {9, 8}, {11, 8}, {MAX_PB_GROUPS, MAX_PB_GROUPS}};
-void launch_fwd_chain(int variant, hipStream_t st, unsigned grid, const FwdArgs &a);
+void launch_fwd_chain(int variant, bool hoist, hipStream_t st, unsigned grid, const FwdArgs &a);
 void launch_dx_chain(hipStream_t st, unsigned grid, const DxArgs &a);
 void launch_dw(hipStream_t st, unsigned grid, const DwArgs &a);
 
