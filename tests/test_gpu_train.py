@@ -343,6 +343,27 @@ def test_saturated_rays_keep_their_gradient(n, S, loss_name, bkgd, shift):
     assert e["e_grad"] <= 1e-4 + 1e-5 * float((np.maximum(e["sigma"], 0) * dist).max()), {k: v for k, v in e["layers"].items() if v > 1e-5}
 
 
+def test_direction_segment_per_ray_and_per_sample_agree(monkeypatch):
+    """The forward chain evaluates the colour layer's direction segment once per RAY (dirrow_kernel + the HOIST builds) whenever nothing varies
+    along a ray -- no blur_idx on an appearance parameter, a sample count that is a multiple of 32 -- and per sample otherwise
+    (renderer.py:152-158).  Both against float64 autograd: the per-ray path (S = 64), the per-sample path forced by the environment on the same
+    batch (same predictions and gradients to summation order), by a blur_idx on an APPEARANCE parameter, and by S = 60."""
+    from nerf_tex_amd.train import Trainer
+    model, spec, wts = make_model((1, 4), dense_media=True)
+    e_ray = step_errors(model, spec, wts, "grass", 48, 64, "alpha_smape", perturb=True, seed=5, batch_seed=9)
+    monkeypatch.setenv("NERFTEX_TRAIN_NO_DIR_HOIST", "1")
+    e_smp = step_errors(model, spec, wts, "grass", 48, 64, "alpha_smape", perturb=True, seed=5, batch_seed=9)
+    monkeypatch.delenv("NERFTEX_TRAIN_NO_DIR_HOIST")
+    for e in (e_ray, e_smp):
+        assert e["finite"] and e["e_loss"] <= 1e-5 and e["e_pred"] <= 1e-4 and e["e_grad"] <= 1e-4, {k: v for k, v in e["layers"].items() if v > 1e-5}
+    assert not np.array_equal(e_ray["got"], e_smp["got"])                                    # two different kernels ran
+    assert np.abs(e_ray["got"] - e_smp["got"]).max() <= 2e-5 * np.abs(e_smp["got"]).max()
+    e_blur = step_errors(model, spec, wts, "grass", 48, 64, "alpha_smape", perturb=True, blur=2, seed=5, batch_seed=9)      # parameter 2 = an appearance parameter of [1, 4]
+    e_s60 = step_errors(model, spec, wts, "grass", 48, 60, "alpha_smape", perturb=True, seed=5, batch_seed=9)
+    for e in (e_blur, e_s60):
+        assert e["finite"] and e["e_loss"] <= 1e-5 and e["e_pred"] <= 1e-4 and e["e_grad"] <= 1e-4, {k: v for k, v in e["layers"].items() if v > 1e-5}
+
+
 def test_training_step_is_bit_reproducible_and_adam_matches_its_restatement():
     """Two trainers from the same weights take the same step bit for bit (weight gradients are summed over the samples in a fixed order);
     Adam under ExponentialDecay (train.py:49-52) within float32 rounding of the float64 restatement, over three iterations."""
